@@ -1,0 +1,114 @@
+// Internal declarations shared by the HIP translation units of libasv_amd.so.
+// gfx950 (MI355X / CDNA4) only: wave64, MFMA, 160 KiB LDS.  No other target is supported.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/asv_amd.h"
+
+namespace asv {
+
+// ---------------------------------------------------------------------------------------
+// error plumbing: nothing throws across the C ABI
+void set_error(const char *fmt, ...);
+
+#define ASV_HIP_CHECK(expr)                                                                   \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      ::asv::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return ASV_EHIP;                                                                        \
+    }                                                                                         \
+  } while (0)
+
+#define ASV_REQUIRE(cond, ...)                                                                \
+  do {                                                                                        \
+    if (!(cond)) {                                                                            \
+      ::asv::set_error(__VA_ARGS__);                                                          \
+      return ASV_EINVAL;                                                                      \
+    }                                                                                         \
+  } while (0)
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ---------------------------------------------------------------------------------------
+// Row layout of the frames domain (see DESIGN.md "Data layout in HBM").
+//
+// A batch of S utterance segments is laid out as
+//     [HALO zero rows][seg 0][HALO zero rows][seg 1] ... [seg S-1][HALO zero rows][zero fill to R_pad]
+// so a tap that reaches up to HALO frames across a segment edge reads zeros: exactly the
+// per-layer zero padding of TdnnAffine (components.py:116-117), with no masks in the GEMM
+// main loop.  Every producer writes zeros into gap rows (row_valid bit clear).
+constexpr int kHalo = 4;           // max |tap offset| supported (ECAPA dilation 4)
+constexpr int kRowTile = 128;      // rows are padded to a multiple of the GEMM M tile
+constexpr int kChanAlign = 16;     // channel pitch granularity (elements)
+
+// ---------------------------------------------------------------------------------------
+// GEMM kernel parameters (one TDNN layer), passed by value.
+struct TdnnKernelParams {
+  const void *x;        // input rows, element type = activation type; already offset to in_ch_off
+  const void *x2;       // optional second input (added), or nullptr
+  const void *w;        // packed weights [cout_pad][n_taps][cin_pad], element type = activation type
+  const float *bias;    // [cout_pad] (zeros when absent)
+  const float *scale;   // [cout_pad] or nullptr
+  const float *shift;   // [cout_pad] or nullptr
+  const float *seg_bias;   // [segments][ld_seg] or nullptr
+  const float *seg_scale;  // [segments][ld_segscale] or nullptr
+  const void *res;      // residual rows (activation type) or nullptr
+  void *y;              // output rows
+  const int32_t *row_seg;     // [rows] segment id or -1 (gap)
+  const uint32_t *row_valid;  // [rows/32] bit r%32 set <=> row r holds a real frame
+  // fused statistics pooling (optional): per (row tile, channel) partial sums of the valid rows,
+  // segmented by utterance; see kernels_tdnn.hip
+  float *pool_partial;
+  int ldx, ldx2, ldy, ldres, ld_segbias, ld_segscale;   // pitches in elements
+  int rows;             // padded row count (multiple of kRowTile)
+  int cin_pad;          // multiple of kChanAlign
+  int cout_store;       // columns [0, cout_store) of y are written (zeros beyond out_ch)
+  int n_taps;
+  int taps[ASV_MAX_TAPS];
+  int act1, act2, affine_first;
+};
+
+struct PoolKernelParams {
+  const void *x;  int ldx;  int channels;
+  const int32_t *seg_row0;   // [segments] first row of the segment
+  const int32_t *seg_len;    // [segments]
+  float *out; int ld_out;    // utts-domain row pitch
+  int stddev, unbiased, var_mode; float eps;
+};
+
+// launchers (kernels_*.hip).  ElemBF16: activations are bf16 (else f32).
+int launch_tdnn_mfma(const TdnnKernelParams &p, bool bf16, bool out_f32, hipStream_t s);
+int launch_tdnn_ref(const TdnnKernelParams &p, bool bf16, bool out_f32, hipStream_t s);
+int launch_stats_pool(const PoolKernelParams &p, int segments, bool bf16, hipStream_t s);
+int launch_attentive_pool(const void *x, int ldx, const void *logits, int ldl, int channels,
+                          const int32_t *seg_row0, const int32_t *seg_len, int segments, float eps,
+                          float *out, int ld_out, bool bf16, hipStream_t s);
+int launch_rowmap(const int32_t *seg_row0, const int32_t *seg_len, int segments, int rows,
+                  int32_t *row_seg, uint32_t *row_valid, hipStream_t s);
+int launch_pack_input(const float *feats, int feat_dim, const int32_t *seg_src0, const int32_t *seg_row0,
+                      const int32_t *row_seg, int rows, void *x, int ldx, bool bf16, hipStream_t s);
+int launch_unpack_rows(const void *y, int ldy, int channels, const int32_t *seg_src0, const int32_t *seg_row0,
+                       const int32_t *row_seg, int rows, float *out, bool bf16, hipStream_t s);
+int launch_combine(const float *seg_emb, int ld_seg, const int32_t *utt_seg0, const int32_t *utt_nseg,
+                   const int32_t *seg_len, int n_utts, int embed_dim, float *out, hipStream_t s);
+struct EltwiseKernelParams {
+  const void *a, *b, *c; void *out;
+  int lda, ldb, ldc, ldo, channels, rows;
+  const float *scale, *shift;          // per-channel affine on a (or nullptr)
+  const float *seg_scale; int ld_segscale;
+  const int32_t *row_seg; const uint32_t *row_valid;   // nullptr in the utts domain
+};
+int launch_eltwise(const EltwiseKernelParams &p, bool bf16, hipStream_t s);
+
+// weight packing (host): dense checkpoint kernel -> [cout_pad][n_taps][cin_pad] in element type
+void pack_tdnn_weight(const float *w, int out_ch, int in_ch, int tot_ctx, int left_ctx, const int *taps,
+                      int n_taps, int cout_pad, int cin_pad, bool bf16, void *dst);
+uint16_t f32_to_bf16_host(float f);
+
+}  // namespace asv

@@ -1,0 +1,106 @@
+// Small device-side helpers shared by the kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "asv_internal.h"
+
+namespace asv {
+
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16_t;
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4_t;
+
+__host__ __device__ __forceinline__ int round_up_dev(int x, int m) { return (x + m - 1) / m * m; }
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
+
+// round-to-nearest-even, NaN preserved (quiet)
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+}
+
+// elementwise add of two 16-byte pieces holding 8 bf16 (f32 add, RNE back to bf16)
+__device__ __forceinline__ uint4 add_bf16x8(uint4 a, uint4 b) {
+  uint4 r;
+  const uint32_t *pa = reinterpret_cast<const uint32_t *>(&a);
+  const uint32_t *pb = reinterpret_cast<const uint32_t *>(&b);
+  uint32_t *pr = reinterpret_cast<uint32_t *>(&r);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float lo = bf16_bits_to_f32(pa[i] & 0xffffu) + bf16_bits_to_f32(pb[i] & 0xffffu);
+    float hi = bf16_bits_to_f32(pa[i] >> 16) + bf16_bits_to_f32(pb[i] >> 16);
+    pr[i] = pack_bf16x2(lo, hi);
+  }
+  return r;
+}
+
+__device__ __forceinline__ uint4 add_f32x4(uint4 a, uint4 b) {
+  uint4 r;
+  r.x = __float_as_uint(__uint_as_float(a.x) + __uint_as_float(b.x));
+  r.y = __float_as_uint(__uint_as_float(a.y) + __uint_as_float(b.y));
+  r.z = __float_as_uint(__uint_as_float(a.z) + __uint_as_float(b.z));
+  r.w = __float_as_uint(__uint_as_float(a.w) + __uint_as_float(b.w));
+  return r;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case ASV_ACT_RELU: return fmaxf(v, 0.0f);
+    case ASV_ACT_TANH: return tanhf(v);
+    case ASV_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    default: return v;
+  }
+}
+
+template <bool BF16>
+__device__ __forceinline__ float load_elem(const void *base, size_t idx) {
+  if constexpr (BF16) return bf16_bits_to_f32(reinterpret_cast<const uint16_t *>(base)[idx]);
+  else return reinterpret_cast<const float *>(base)[idx];
+}
+
+template <bool BF16>
+__device__ __forceinline__ void store_elem(void *base, size_t idx, float v) {
+  if constexpr (BF16) reinterpret_cast<uint16_t *>(base)[idx] = (uint16_t)f32_to_bf16_bits(v);
+  else reinterpret_cast<float *>(base)[idx] = v;
+}
+
+// The shared epilogue of one output element of a TDNN layer (asv_amd.h asv_tdnn_desc_t):
+//   z = acc + bias (+ seg_bias);  z = affine_first ? act1(z*s+t) : act1(z)*s+t;
+//   y = act2(z) (* seg_scale) (+ residual);  gap rows produce 0.
+template <bool RES_BF16>
+__device__ __forceinline__ float tdnn_epilogue(const TdnnKernelParams &p, float acc, int row, int ch,
+                                               float bias, float scale, float shift, bool valid) {
+  if (!valid) return 0.0f;
+  float z = acc + bias;
+  int seg = 0;
+  if (p.seg_bias != nullptr || p.seg_scale != nullptr) seg = p.row_seg[row];
+  if (p.seg_bias != nullptr) z += p.seg_bias[(size_t)seg * p.ld_segbias + ch];
+  if (p.affine_first) {
+    z = apply_act(z * scale + shift, p.act1);
+  } else {
+    z = apply_act(z, p.act1) * scale + shift;
+  }
+  z = apply_act(z, p.act2);
+  if (p.seg_scale != nullptr) z *= p.seg_scale[(size_t)seg * p.ld_segscale + ch];
+  if (p.res != nullptr) z += load_elem<RES_BF16>(p.res, (size_t)row * p.ldres + ch);
+  return z;
+}
+
+// XCD-aware, bijective remap of a 1-D grid (cdna_hip_programming.md T1): hardware places
+// block b on XCD b % 8; give each XCD a contiguous run of logical tiles so the N tiles that
+// share an A panel hit the same L2.
+__device__ __forceinline__ int xcd_swizzle(int bid, int nblocks) {
+  const int xcd = bid & 7, q = nblocks >> 3, r = nblocks & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+}  // namespace asv

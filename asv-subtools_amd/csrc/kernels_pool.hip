@@ -1,0 +1,391 @@
+// Row-map, feature packing, statistics / attentive pooling, elementwise and chunk-combine
+// kernels.  All of these are HBM-bound streaming kernels: 16-byte loads per lane, lanes
+// along the channel axis (the contiguous one), wavefront (DPP shuffle) reduction across the
+// lanes that share a channel group, LDS reduction across the 4 waves of a workgroup.
+#include "device_utils.h"
+
+namespace asv {
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// row map: for every padded row, which segment it belongs to (-1: gap) + a validity bitmask
+__global__ __launch_bounds__(256) void rowmap_kernel(const int32_t *seg_row0, const int32_t *seg_len, int segments,
+                                                     int rows, int32_t *row_seg, uint32_t *row_valid) {
+  const int row = blockIdx.x * 256 + threadIdx.x;      // rows is a multiple of 128; grid covers it in 64-row waves
+  int seg = -1;
+  if (row < rows) {
+    int lo = 0, hi = segments;                         // largest s with seg_row0[s] <= row
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (seg_row0[mid] <= row) lo = mid; else hi = mid;
+    }
+    if (segments > 0 && seg_row0[lo] <= row && row < seg_row0[lo] + seg_len[lo]) seg = lo;
+    row_seg[row] = seg;
+  }
+  const unsigned long long b = __ballot(seg >= 0);
+  if ((threadIdx.x & 63) == 0 && row < rows) {
+    row_valid[row >> 5] = (uint32_t)b;
+    if (row + 32 < rows) row_valid[(row >> 5) + 1] = (uint32_t)(b >> 32);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Kaldi float matrix [T_total][D] f32 (packed utterances) -> padded row layout, activation type
+template <bool BF16>
+__global__ __launch_bounds__(256) void pack_input_kernel(const float *feats, int feat_dim, const int32_t *seg_src0,
+                                                         const int32_t *seg_row0, const int32_t *row_seg, int rows,
+                                                         void *x, int ldx) {
+  constexpr int VEC = BF16 ? 8 : 4;
+  const int pieces = ldx / VEC;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long long)rows * pieces) return;
+  const int row = (int)(gid / pieces), ch0 = (int)(gid % pieces) * VEC;
+  const int seg = row_seg[row];
+  float v[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) v[i] = 0.0f;
+  if (seg >= 0) {
+    const float *src = feats + (size_t)(seg_src0[seg] + (row - seg_row0[seg])) * feat_dim;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i)
+      if (ch0 + i < feat_dim) v[i] = src[ch0 + i];
+  }
+  if constexpr (BF16) {
+    uint4 o;
+    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+    o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+    *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(x) + (size_t)row * ldx + ch0) = o;
+  } else {
+    *reinterpret_cast<float4 *>(reinterpret_cast<float *>(x) + (size_t)row * ldx + ch0) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// padded row layout -> packed [T_total][channels] f32 (single-layer entry point / tests)
+template <bool BF16>
+__global__ __launch_bounds__(256) void unpack_rows_kernel(const void *y, int ldy, int channels, const int32_t *seg_src0,
+                                                          const int32_t *seg_row0, const int32_t *row_seg, int rows,
+                                                          float *out) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long long)rows * channels) return;
+  const int row = (int)(gid / channels), ch = (int)(gid % channels);
+  const int seg = row_seg[row];
+  if (seg < 0) return;
+  out[(size_t)(seg_src0[seg] + (row - seg_row0[seg])) * channels + ch] = load_elem<BF16>(y, (size_t)row * ldy + ch);
+}
+
+// ---------------------------------------------------------------------------------------
+// shared reduction helper: VEC partial sums per lane -> full sum over the 4 waves' row slots,
+// returned to every thread of the block (indexed by its channel group).
+template <int VEC, int CG>
+__device__ __forceinline__ void block_reduce_rows(float (&v)[VEC], float (*sm)[64], int wave, int cg, int rs) {
+#pragma unroll
+  for (int off = CG; off < 64; off <<= 1)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) v[i] += __shfl_xor(v[i], off);
+  __syncthreads();                                    // previous use of sm finished
+  if (rs == 0) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) sm[wave][cg * VEC + i] = v[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < VEC; ++i)
+    v[i] = (sm[0][cg * VEC + i] + sm[1][cg * VEC + i]) + (sm[2][cg * VEC + i] + sm[3][cg * VEC + i]);
+}
+
+template <int VEC, int CG>
+__device__ __forceinline__ void block_max_rows(float (&v)[VEC], float (*sm)[64], int wave, int cg, int rs) {
+#pragma unroll
+  for (int off = CG; off < 64; off <<= 1)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) v[i] = fmaxf(v[i], __shfl_xor(v[i], off));
+  __syncthreads();
+  if (rs == 0) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) sm[wave][cg * VEC + i] = v[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < VEC; ++i)
+    v[i] = fmaxf(fmaxf(sm[0][cg * VEC + i], sm[1][cg * VEC + i]), fmaxf(sm[2][cg * VEC + i], sm[3][cg * VEC + i]));
+}
+
+template <bool BF16, int VEC>
+__device__ __forceinline__ void load_vec(const void *base, size_t idx, float (&v)[VEC]) {
+  if constexpr (BF16) {
+    const uint4 u = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(base) + idx);
+    v[0] = bf16_bits_to_f32(u.x & 0xffffu); v[1] = bf16_bits_to_f32(u.x >> 16);
+    v[2] = bf16_bits_to_f32(u.y & 0xffffu); v[3] = bf16_bits_to_f32(u.y >> 16);
+    v[4] = bf16_bits_to_f32(u.z & 0xffffu); v[5] = bf16_bits_to_f32(u.z >> 16);
+    v[6] = bf16_bits_to_f32(u.w & 0xffffu); v[7] = bf16_bits_to_f32(u.w >> 16);
+  } else {
+    const float4 f = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(base) + idx);
+    v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+  }
+}
+
+// StatisticsPooling (reference libs/nnet/pooling.py:58-67): mean over the segment's frames,
+// TWO-pass variance about that mean (same arithmetic as the reference; the second pass hits
+// L2), std = sqrt(max(var, eps)) or sqrt(var + eps).  grid = (ceil(C/64), segments).
+template <bool BF16>
+__global__ __launch_bounds__(256) void stats_pool_kernel(const PoolKernelParams p) {
+  constexpr int VEC = BF16 ? 8 : 4;
+  constexpr int CG = 64 / VEC;          // lanes along channels
+  constexpr int RS = 64 / CG;           // row slots per wave
+  __shared__ float sm[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cg = lane % CG, rs = lane / CG;
+  const int seg = blockIdx.y, ch = blockIdx.x * 64 + cg * VEC;
+  const int row0 = p.seg_row0[seg], len = p.seg_len[seg];
+  const bool active = ch < round_up_dev(p.channels, kChanAlign);
+
+  float s[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s[i] = 0.0f;
+  if (active)
+    for (int r = wave * RS + rs; r < len; r += 4 * RS) {
+      float v[VEC];
+      load_vec<BF16, VEC>(p.x, (size_t)(row0 + r) * p.ldx + ch, v);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) s[i] += v[i];
+    }
+  block_reduce_rows<VEC, CG>(s, sm, wave, cg, rs);
+  float mean[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) mean[i] = s[i] / (float)len;
+
+  float q[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) q[i] = 0.0f;
+  if (p.stddev) {
+    if (active)
+      for (int r = wave * RS + rs; r < len; r += 4 * RS) {
+        float v[VEC];
+        load_vec<BF16, VEC>(p.x, (size_t)(row0 + r) * p.ldx + ch, v);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { const float dlt = v[i] - mean[i]; q[i] += dlt * dlt; }
+      }
+    block_reduce_rows<VEC, CG>(q, sm, wave, cg, rs);
+  }
+  if (wave == 0 && rs == 0 && active) {
+    float counts = (float)len;
+    if (p.unbiased == 1 && len > 1) counts = (float)(len - 1);      // pooling.py:63-64
+    if (p.unbiased == 2) counts = (float)(len - 1);                 // torch.var default (ECAPA), NaN at len 1 like torch
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      if (ch + i >= p.channels) continue;
+      p.out[(size_t)seg * p.ld_out + ch + i] = mean[i];
+      if (p.stddev) {
+        const float var = q[i] / counts;
+        const float sd = (p.var_mode == ASV_POOL_VAR_ADD) ? sqrtf(var + p.eps) : sqrtf(fmaxf(var, p.eps));
+        p.out[(size_t)seg * p.ld_out + p.channels + ch + i] = sd;
+      }
+    }
+  }
+}
+
+// ECAPA attentive statistics (ecapa_tdnn_xvector.py:182-188).
+template <bool BF16>
+__global__ __launch_bounds__(256) void attentive_pool_kernel(const void *x, int ldx, const void *logits, int ldl,
+                                                             int channels, const int32_t *seg_row0,
+                                                             const int32_t *seg_len, float eps, float *out, int ld_out) {
+  constexpr int VEC = BF16 ? 8 : 4;
+  constexpr int CG = 64 / VEC;
+  constexpr int RS = 64 / CG;
+  __shared__ float sm[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cg = lane % CG, rs = lane / CG;
+  const int seg = blockIdx.y, ch = blockIdx.x * 64 + cg * VEC;
+  const int row0 = seg_row0[seg], len = seg_len[seg];
+  const bool active = ch < round_up_dev(channels, kChanAlign);
+
+  float mx[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) mx[i] = -INFINITY;
+  if (active)
+    for (int r = wave * RS + rs; r < len; r += 4 * RS) {
+      float e[VEC];
+      load_vec<BF16, VEC>(logits, (size_t)(row0 + r) * ldl + ch, e);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) mx[i] = fmaxf(mx[i], e[i]);
+    }
+  block_max_rows<VEC, CG>(mx, sm, wave, cg, rs);
+
+  float se[VEC], sx[VEC], sxx[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { se[i] = 0.0f; sx[i] = 0.0f; sxx[i] = 0.0f; }
+  if (active)
+    for (int r = wave * RS + rs; r < len; r += 4 * RS) {
+      float e[VEC], v[VEC];
+      load_vec<BF16, VEC>(logits, (size_t)(row0 + r) * ldl + ch, e);
+      load_vec<BF16, VEC>(x, (size_t)(row0 + r) * ldx + ch, v);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const float w = expf(e[i] - mx[i]);
+        se[i] += w; sx[i] += w * v[i]; sxx[i] += w * v[i] * v[i];
+      }
+    }
+  block_reduce_rows<VEC, CG>(se, sm, wave, cg, rs);
+  block_reduce_rows<VEC, CG>(sx, sm, wave, cg, rs);
+  block_reduce_rows<VEC, CG>(sxx, sm, wave, cg, rs);
+  if (wave == 0 && rs == 0 && active) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      if (ch + i >= channels) continue;
+      const float mean = sx[i] / se[i];
+      const float resid = sxx[i] / se[i] - mean * mean;
+      out[(size_t)seg * ld_out + ch + i] = mean;
+      out[(size_t)seg * ld_out + channels + ch + i] = sqrtf(fmaxf(resid, eps));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// elementwise: out = (a [*scale+shift]) (* seg_scale[seg]) (+ b) (+ c); gap rows -> 0
+template <bool BF16>
+__global__ __launch_bounds__(256) void eltwise_kernel(const EltwiseKernelParams p) {
+  constexpr int VEC = BF16 ? 8 : 4;
+  const int pieces = round_up_dev(p.channels, VEC) / VEC;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long long)p.rows * pieces) return;
+  const int row = (int)(gid / pieces), ch = (int)(gid % pieces) * VEC;
+  float o[VEC];
+  bool valid = true;
+  int seg = row;
+  if (p.row_valid != nullptr) {
+    valid = (p.row_valid[row >> 5] >> (row & 31)) & 1u;
+    seg = valid ? p.row_seg[row] : 0;
+  }
+  if (valid) {
+    load_vec<BF16, VEC>(p.a, (size_t)row * p.lda + ch, o);
+    if (p.scale != nullptr) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i)
+        if (ch + i < p.channels) o[i] = o[i] * p.scale[ch + i] + p.shift[ch + i];
+    }
+    if (p.seg_scale != nullptr) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i)
+        if (ch + i < p.channels) o[i] *= p.seg_scale[(size_t)seg * p.ld_segscale + ch + i];
+    }
+    if (p.b != nullptr) {
+      float t[VEC];
+      load_vec<BF16, VEC>(p.b, (size_t)row * p.ldb + ch, t);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) o[i] += t[i];
+    }
+    if (p.c != nullptr) {
+      float t[VEC];
+      load_vec<BF16, VEC>(p.c, (size_t)row * p.ldc + ch, t);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) o[i] += t[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i)
+      if (ch + i >= p.channels) o[i] = 0.0f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) o[i] = 0.0f;
+  }
+  if constexpr (BF16) {
+    uint4 u;
+    u.x = pack_bf16x2(o[0], o[1]); u.y = pack_bf16x2(o[2], o[3]);
+    u.z = pack_bf16x2(o[4], o[5]); u.w = pack_bf16x2(o[6], o[7]);
+    *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(p.out) + (size_t)row * p.ldo + ch) = u;
+  } else {
+    *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.out) + (size_t)row * p.ldo + ch) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// chunk combine (framework.py:38-47): emb = (sum_{i<n-1} len_i*e_i + len_last*e_last) / T,
+// separately rounded f32 mul/add like the reference's tensor ops.
+__global__ __launch_bounds__(256) void combine_kernel(const float *seg_emb, int ld_seg, const int32_t *utt_seg0,
+                                                      const int32_t *utt_nseg, const int32_t *seg_len, int n_utts,
+                                                      int embed_dim, float *out) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long long)n_utts * embed_dim) return;
+  const int u = (int)(gid / embed_dim), e = (int)(gid % embed_dim);
+  const int s0 = utt_seg0[u], n = utt_nseg[u];
+  float acc = 0.0f;
+  int total = 0;
+  for (int i = 0; i < n - 1; ++i) {
+    const int len = seg_len[s0 + i];
+    acc = __fadd_rn(acc, __fmul_rn((float)len, seg_emb[(size_t)(s0 + i) * ld_seg + e]));
+    total += len;
+  }
+  const int len = seg_len[s0 + n - 1];
+  total += len;
+  const float last = __fmul_rn((float)len, seg_emb[(size_t)(s0 + n - 1) * ld_seg + e]);
+  out[(size_t)u * embed_dim + e] = __fdiv_rn(__fadd_rn(acc, last), (float)total);
+}
+
+}  // namespace
+
+int launch_rowmap(const int32_t *seg_row0, const int32_t *seg_len, int segments, int rows, int32_t *row_seg,
+                  uint32_t *row_valid, hipStream_t s) {
+  hipLaunchKernelGGL(rowmap_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, seg_row0, seg_len, segments, rows, row_seg, row_valid);
+  ASV_HIP_CHECK(hipGetLastError());
+  return ASV_OK;
+}
+
+int launch_pack_input(const float *feats, int feat_dim, const int32_t *seg_src0, const int32_t *seg_row0,
+                      const int32_t *row_seg, int rows, void *x, int ldx, bool bf16, hipStream_t s) {
+  const int vec = bf16 ? 8 : 4;
+  const long long n = (long long)rows * (ldx / vec);
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (bf16) hipLaunchKernelGGL(pack_input_kernel<true>, grid, block, 0, s, feats, feat_dim, seg_src0, seg_row0, row_seg, rows, x, ldx);
+  else hipLaunchKernelGGL(pack_input_kernel<false>, grid, block, 0, s, feats, feat_dim, seg_src0, seg_row0, row_seg, rows, x, ldx);
+  ASV_HIP_CHECK(hipGetLastError());
+  return ASV_OK;
+}
+
+int launch_unpack_rows(const void *y, int ldy, int channels, const int32_t *seg_src0, const int32_t *seg_row0,
+                       const int32_t *row_seg, int rows, float *out, bool bf16, hipStream_t s) {
+  const long long n = (long long)rows * channels;
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (bf16) hipLaunchKernelGGL(unpack_rows_kernel<true>, grid, block, 0, s, y, ldy, channels, seg_src0, seg_row0, row_seg, rows, out);
+  else hipLaunchKernelGGL(unpack_rows_kernel<false>, grid, block, 0, s, y, ldy, channels, seg_src0, seg_row0, row_seg, rows, out);
+  ASV_HIP_CHECK(hipGetLastError());
+  return ASV_OK;
+}
+
+int launch_stats_pool(const PoolKernelParams &p, int segments, bool bf16, hipStream_t s) {
+  if (segments <= 0) return ASV_OK;
+  const dim3 grid((p.channels + 63) / 64, segments), block(256);
+  if (bf16) hipLaunchKernelGGL(stats_pool_kernel<true>, grid, block, 0, s, p);
+  else hipLaunchKernelGGL(stats_pool_kernel<false>, grid, block, 0, s, p);
+  ASV_HIP_CHECK(hipGetLastError());
+  return ASV_OK;
+}
+
+int launch_attentive_pool(const void *x, int ldx, const void *logits, int ldl, int channels, const int32_t *seg_row0,
+                          const int32_t *seg_len, int segments, float eps, float *out, int ld_out, bool bf16,
+                          hipStream_t s) {
+  if (segments <= 0) return ASV_OK;
+  const dim3 grid((channels + 63) / 64, segments), block(256);
+  if (bf16) hipLaunchKernelGGL(attentive_pool_kernel<true>, grid, block, 0, s, x, ldx, logits, ldl, channels, seg_row0, seg_len, eps, out, ld_out);
+  else hipLaunchKernelGGL(attentive_pool_kernel<false>, grid, block, 0, s, x, ldx, logits, ldl, channels, seg_row0, seg_len, eps, out, ld_out);
+  ASV_HIP_CHECK(hipGetLastError());
+  return ASV_OK;
+}
+
+int launch_eltwise(const EltwiseKernelParams &p, bool bf16, hipStream_t s) {
+  const int vec = bf16 ? 8 : 4;
+  const long long n = (long long)p.rows * (round_up(p.channels, vec) / vec);
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (bf16) hipLaunchKernelGGL(eltwise_kernel<true>, grid, block, 0, s, p);
+  else hipLaunchKernelGGL(eltwise_kernel<false>, grid, block, 0, s, p);
+  ASV_HIP_CHECK(hipGetLastError());
+  return ASV_OK;
+}
+
+int launch_combine(const float *seg_emb, int ld_seg, const int32_t *utt_seg0, const int32_t *utt_nseg,
+                   const int32_t *seg_len, int n_utts, int embed_dim, float *out, hipStream_t s) {
+  const long long n = (long long)n_utts * embed_dim;
+  hipLaunchKernelGGL(combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, seg_emb, ld_seg, utt_seg0, utt_nseg, seg_len, n_utts, embed_dim, out);
+  ASV_HIP_CHECK(hipGetLastError());
+  return ASV_OK;
+}
+
+}  // namespace asv

@@ -1,0 +1,734 @@
+// Host runtime of libasv_amd.so: the layer-program builder (asv_net_*), weight packing,
+// the per-batch segment/row planner and the launch sequencer behind asv_net_extract().
+//
+// Replaces, for the batched device path, what `for_extract_embedding` +
+// `<Model>.extract_embedding` do one utterance at a time in the reference
+// (libs/nnet/framework.py:12-55, model/xvector.py:77-98, model/ecapa_tdnn_xvector.py:403-426).
+#include <stdarg.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <memory>
+#include <vector>
+
+#include "asv_internal.h"
+
+namespace asv {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+}
+
+uint16_t f32_to_bf16_host(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+void pack_tdnn_weight(const float *w, int out_ch, int in_ch, int tot_ctx, int left_ctx, const int *taps, int n_taps,
+                      int cout_pad, int cin_pad, bool bf16, void *dst) {
+  const size_t n = (size_t)cout_pad * n_taps * cin_pad;
+  if (bf16) memset(dst, 0, n * 2); else memset(dst, 0, n * 4);
+  for (int co = 0; co < out_ch; ++co)
+    for (int t = 0; t < n_taps; ++t) {
+      const int k = taps[t] - left_ctx;
+      const size_t base = ((size_t)co * n_taps + t) * cin_pad;
+      for (int ci = 0; ci < in_ch; ++ci) {
+        const float v = w[((size_t)co * in_ch + ci) * tot_ctx + k];
+        if (bf16) reinterpret_cast<uint16_t *>(dst)[base + ci] = f32_to_bf16_host(v);
+        else reinterpret_cast<float *>(dst)[base + ci] = v;
+      }
+    }
+}
+
+namespace {
+
+struct Buffer {
+  int domain, channels, ld;
+};
+
+enum OpKind { OP_TDNN = 0, OP_POOL = 1, OP_ATTPOOL = 2, OP_ELTWISE = 3 };
+
+struct Op {
+  OpKind kind;
+  // common views
+  asv_tdnn_desc_t tdnn;          // host pointers nulled after packing
+  asv_pool_desc_t pool;
+  asv_attpool_desc_t att;
+  asv_eltwise_desc_t elt;
+  // device parameters
+  void *w = nullptr;
+  float *bias = nullptr, *scale = nullptr, *shift = nullptr;
+  int cin_pad = 0, cout_pad = 0, cout_store = 0;
+  bool utts = false;             // op runs in the utts domain (always f32)
+  bool has_affine = false;
+};
+
+struct DevMem {
+  void *ptr = nullptr;
+  size_t cap = 0;
+};
+
+const char *kKernelNames[] = {"tdnn_gemm", "stats_pool", "attentive_pool", "eltwise", "rowmap", "pack_input", "combine"};
+enum { K_TDNN = 0, K_POOL, K_ATT, K_ELT, K_ROWMAP, K_PACK, K_COMBINE, K_COUNT };
+
+}  // namespace
+}  // namespace asv
+
+using namespace asv;
+
+struct asv_net {
+  int device = 0, precision = 0, feat_dim = 0;
+  unsigned flags = 0;
+  bool finalized = false;
+  int out_buf = -1, embed_dim = 0;
+  std::vector<Buffer> bufs;
+  std::vector<Op> ops;
+  std::vector<void *> weight_allocs;
+  size_t weight_bytes = 0;
+  // per-call state
+  std::vector<DevMem> arena;             // one region per buffer
+  DevMem meta_dev;                       // int32 metadata (segments etc.)
+  DevMem rowmeta_dev;                    // row_seg / row_valid for both domains
+  void *meta_host = nullptr;             // pinned staging
+  size_t meta_host_cap = 0;
+  hipEvent_t meta_copied = nullptr;      // H2D of meta_host finished
+  bool meta_inflight = false;
+  // profiling
+  bool profiling = false;
+  struct Stamp { int kclass; double flops; hipEvent_t a, b; };
+  std::vector<Stamp> stamps;
+  std::vector<hipEvent_t> event_pool;
+
+  bool frames_bf16() const { return precision == ASV_PREC_BF16; }
+  size_t elem_size(int domain) const { return (domain == ASV_DOMAIN_FRAMES && frames_bf16()) ? 2 : 4; }
+};
+
+namespace {
+
+int dev_upload(asv_net *net, const void *host, size_t bytes, void **out) {
+  void *d = nullptr;
+  ASV_HIP_CHECK(hipMalloc(&d, bytes));
+  hipError_t e = hipMemcpy(d, host, bytes, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(d);
+    set_error("hipMemcpy H2D failed: %s", hipGetErrorString(e));
+    return ASV_EHIP;
+  }
+  net->weight_allocs.push_back(d);
+  net->weight_bytes += bytes;
+  *out = d;
+  return ASV_OK;
+}
+
+int upload_padded(asv_net *net, const float *src, int n, int n_pad, float fill, float **out) {
+  std::vector<float> tmp((size_t)n_pad, fill);
+  if (src) memcpy(tmp.data(), src, (size_t)n * sizeof(float));
+  void *d = nullptr;
+  int rc = dev_upload(net, tmp.data(), tmp.size() * sizeof(float), &d);
+  *out = reinterpret_cast<float *>(d);
+  return rc;
+}
+
+int check_view(const asv_net *net, int buf, int ch_off, int ch, const char *what) {
+  ASV_REQUIRE(buf >= 0 && buf < (int)net->bufs.size(), "%s: buffer id %d out of range", what, buf);
+  ASV_REQUIRE(ch_off >= 0 && ch_off % kChanAlign == 0, "%s: channel offset %d must be a non-negative multiple of %d", what, ch_off, kChanAlign);
+  ASV_REQUIRE(ch >= 1 && ch_off + ch <= net->bufs[buf].channels, "%s: view [%d,%d) exceeds buffer %d (%d channels)", what, ch_off, ch_off + ch, buf, net->bufs[buf].channels);
+  return ASV_OK;
+}
+
+int ensure(DevMem &m, size_t bytes, hipStream_t s, bool zero) {
+  if (bytes <= m.cap) return ASV_OK;
+  if (m.ptr) {
+    ASV_HIP_CHECK(hipStreamSynchronize(s));
+    ASV_HIP_CHECK(hipFree(m.ptr));
+    m.ptr = nullptr; m.cap = 0;
+  }
+  const size_t cap = bytes + bytes / 8 + 4096;
+  ASV_HIP_CHECK(hipMalloc(&m.ptr, cap));
+  m.cap = cap;
+  if (zero) ASV_HIP_CHECK(hipMemsetAsync(m.ptr, 0, cap, s));
+  return ASV_OK;
+}
+
+struct Prof {
+  asv_net *net; hipStream_t s;
+  int begin(int kclass, double flops) {
+    if (!net->profiling) return ASV_OK;
+    asv_net::Stamp st; st.kclass = kclass; st.flops = flops;
+    for (hipEvent_t *e : {&st.a, &st.b}) {
+      if (!net->event_pool.empty()) { *e = net->event_pool.back(); net->event_pool.pop_back(); }
+      else ASV_HIP_CHECK(hipEventCreate(e));
+    }
+    ASV_HIP_CHECK(hipEventRecord(st.a, s));
+    net->stamps.push_back(st);
+    return ASV_OK;
+  }
+  int end() {
+    if (!net->profiling) return ASV_OK;
+    ASV_HIP_CHECK(hipEventRecord(net->stamps.back().b, s));
+    return ASV_OK;
+  }
+};
+
+// Per-call plan of segments and rows.
+struct BatchPlan {
+  int n_utts = 0, segments = 0, rows = 0, rows_pad = 0, seg_pad = 0;
+  long long frames = 0;
+  std::vector<int32_t> seg_src0, seg_row0, seg_len, utt_seg0, utt_nseg;
+};
+
+int make_plan(const int32_t *offsets, int n_utts, int max_chunk, BatchPlan &bp) {
+  ASV_REQUIRE(offsets != nullptr && n_utts >= 1, "extract: need at least one utterance");
+  ASV_REQUIRE(offsets[0] == 0, "extract: offsets[0] must be 0");
+  if (max_chunk <= 0) max_chunk = 10000;
+  bp.n_utts = n_utts;
+  bp.utt_seg0.resize(n_utts); bp.utt_nseg.resize(n_utts);
+  long long row = kHalo;
+  for (int u = 0; u < n_utts; ++u) {
+    const long long T = (long long)offsets[u + 1] - offsets[u];
+    ASV_REQUIRE(T >= 1, "extract: utterance %d has %lld frames (the reference asserts T >= tot_context, components.py:119)", u, T);
+    // framework.py:34-47
+    const int num_split = (int)((T + max_chunk - 1) / max_chunk);
+    const int split = (int)(T / num_split);
+    bp.utt_seg0[u] = (int32_t)bp.seg_len.size();
+    bp.utt_nseg[u] = num_split;
+    for (int i = 0; i < num_split; ++i) {
+      const int off = i * split;
+      const int len = (i == num_split - 1) ? (int)(T - off) : split;
+      bp.seg_src0.push_back(offsets[u] + off);
+      bp.seg_row0.push_back((int32_t)row);
+      bp.seg_len.push_back(len);
+      row += len + kHalo;
+      ASV_REQUIRE(row < (1ll << 30), "extract: batch too large (%lld rows)", row);
+    }
+    bp.frames += T;
+  }
+  bp.segments = (int)bp.seg_len.size();
+  bp.rows = (int)row;
+  bp.rows_pad = round_up(bp.rows, kRowTile);
+  bp.seg_pad = round_up(bp.segments, kRowTile);
+  return ASV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int asv_version(void) { return ASV_AMD_VERSION; }
+const char *asv_last_error(void) { return g_last_error.c_str(); }
+
+int asv_device_count(int *count) {
+  ASV_REQUIRE(count != nullptr, "asv_device_count: null argument");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { n = 0; (void)hipGetLastError(); }
+  *count = n;
+  return ASV_OK;
+}
+
+int asv_net_create(asv_net_t **out, int device, int precision, unsigned flags, int feat_dim) {
+  ASV_REQUIRE(out != nullptr, "asv_net_create: null out pointer");
+  ASV_REQUIRE(precision == ASV_PREC_F32 || precision == ASV_PREC_BF16, "asv_net_create: unknown precision %d", precision);
+  ASV_REQUIRE(feat_dim >= 1, "asv_net_create: feat_dim %d", feat_dim);
+  int ndev = 0;
+  ASV_HIP_CHECK(hipGetDeviceCount(&ndev));
+  ASV_REQUIRE(device >= 0 && device < ndev, "asv_net_create: device %d of %d", device, ndev);
+  ASV_HIP_CHECK(hipSetDevice(device));
+  asv_net *net = new (std::nothrow) asv_net();
+  if (!net) { set_error("out of host memory"); return ASV_ENOMEM; }
+  net->device = device; net->precision = precision; net->flags = flags; net->feat_dim = feat_dim;
+  net->bufs.push_back({ASV_DOMAIN_FRAMES, feat_dim, round_up(feat_dim, kChanAlign)});
+  *out = net;
+  return ASV_OK;
+}
+
+void asv_net_destroy(asv_net_t *net) {
+  if (!net) return;
+  (void)hipSetDevice(net->device);
+  (void)hipDeviceSynchronize();
+  for (void *p : net->weight_allocs) (void)hipFree(p);
+  for (auto &m : net->arena) if (m.ptr) (void)hipFree(m.ptr);
+  if (net->meta_dev.ptr) (void)hipFree(net->meta_dev.ptr);
+  if (net->rowmeta_dev.ptr) (void)hipFree(net->rowmeta_dev.ptr);
+  if (net->meta_host) (void)hipHostFree(net->meta_host);
+  if (net->meta_copied) (void)hipEventDestroy(net->meta_copied);
+  for (auto &st : net->stamps) { (void)hipEventDestroy(st.a); (void)hipEventDestroy(st.b); }
+  for (auto e : net->event_pool) (void)hipEventDestroy(e);
+  delete net;
+}
+
+int asv_net_new_buffer(asv_net_t *net, int domain, int channels) {
+  ASV_REQUIRE(net && !net->finalized, "asv_net_new_buffer: net is null or finalized");
+  ASV_REQUIRE(domain == ASV_DOMAIN_FRAMES || domain == ASV_DOMAIN_UTTS, "asv_net_new_buffer: domain %d", domain);
+  ASV_REQUIRE(channels >= 1 && channels <= (1 << 20), "asv_net_new_buffer: channels %d", channels);
+  net->bufs.push_back({domain, channels, round_up(channels, kChanAlign)});
+  return (int)net->bufs.size() - 1;
+}
+
+int asv_net_add_tdnn(asv_net_t *net, const asv_tdnn_desc_t *d) {
+  ASV_REQUIRE(net && d && !net->finalized, "asv_net_add_tdnn: net is null or finalized");
+  ASV_REQUIRE(d->struct_size == sizeof(asv_tdnn_desc_t), "asv_net_add_tdnn: struct_size %u != %zu (ABI mismatch)", d->struct_size, sizeof(asv_tdnn_desc_t));
+  int rc;
+  if ((rc = check_view(net, d->in_buf, d->in_ch_off, d->in_ch, "tdnn input"))) return rc;
+  if ((rc = check_view(net, d->out_buf, d->out_ch_off, d->out_ch, "tdnn output"))) return rc;
+  const int dom = net->bufs[d->in_buf].domain;
+  ASV_REQUIRE(net->bufs[d->out_buf].domain == dom, "tdnn: input and output domains differ");
+  // a layer may read and write the same buffer only through disjoint channel slices (tiles of
+  // other workgroups read the halo rows of the input while this one stores its output rows)
+  auto disjoint = [&](int buf, int off, int ch) {
+    return buf != d->out_buf || off + round_up(ch, kChanAlign) <= d->out_ch_off || d->out_ch_off + round_up(d->out_ch, kChanAlign) <= off;
+  };
+  ASV_REQUIRE(d->out_buf != 0, "tdnn: the input feature buffer cannot be an output");
+  ASV_REQUIRE(disjoint(d->in_buf, d->in_ch_off, d->in_ch), "tdnn: output slice overlaps the input slice of the same buffer");
+  if (d->in2_buf >= 0) {
+    if ((rc = check_view(net, d->in2_buf, d->in2_ch_off, d->in_ch, "tdnn second input"))) return rc;
+    ASV_REQUIRE(net->bufs[d->in2_buf].domain == dom, "tdnn: second input domain differs");
+    ASV_REQUIRE(disjoint(d->in2_buf, d->in2_ch_off, d->in_ch), "tdnn: output slice overlaps the second input slice");
+  }
+  if (d->res_buf >= 0) {
+    if ((rc = check_view(net, d->res_buf, d->res_ch_off, d->out_ch, "tdnn residual"))) return rc;
+    ASV_REQUIRE(net->bufs[d->res_buf].domain == dom, "tdnn: residual domain differs");
+    ASV_REQUIRE(disjoint(d->res_buf, d->res_ch_off, d->out_ch), "tdnn: output slice overlaps the residual slice");
+  }
+  for (int sb : {d->seg_bias_buf, d->seg_scale_buf})
+    if (sb >= 0) {
+      ASV_REQUIRE(dom == ASV_DOMAIN_FRAMES, "tdnn: per-segment bias/scale only applies to frames-domain layers");
+      ASV_REQUIRE(sb < (int)net->bufs.size() && net->bufs[sb].domain == ASV_DOMAIN_UTTS && net->bufs[sb].channels >= d->out_ch,
+                  "tdnn: per-segment buffer %d must be an utts-domain buffer with >= %d channels", sb, d->out_ch);
+    }
+  ASV_REQUIRE(d->n_taps >= 1 && d->n_taps <= ASV_MAX_TAPS, "tdnn: n_taps %d", d->n_taps);
+  for (int t = 0; t < d->n_taps; ++t) {
+    ASV_REQUIRE(t == 0 || d->taps[t] > d->taps[t - 1], "tdnn: context must be strictly ascending (components.py:33-35)");
+    ASV_REQUIRE(d->taps[t] >= -kHalo && d->taps[t] <= kHalo, "tdnn: tap offset %d beyond the supported +-%d frames", d->taps[t], kHalo);
+    const int k = d->taps[t] - d->w_left_context;
+    ASV_REQUIRE(k >= 0 && k < d->w_tot_context, "tdnn: tap %d outside the dense kernel [%d, %d)", d->taps[t], d->w_left_context, d->w_left_context + d->w_tot_context);
+  }
+  ASV_REQUIRE(dom == ASV_DOMAIN_FRAMES || (d->n_taps == 1 && d->taps[0] == 0), "tdnn: utts-domain layers have context [0] only");
+  ASV_REQUIRE(d->weight != nullptr, "tdnn: null weight");
+  ASV_REQUIRE((d->scale == nullptr) == (d->shift == nullptr), "tdnn: scale and shift come together");
+  for (int a : {d->act1, d->act2}) ASV_REQUIRE(a >= ASV_ACT_NONE && a <= ASV_ACT_SIGMOID, "tdnn: unknown activation %d", a);
+
+  Op op;
+  op.kind = OP_TDNN;
+  op.tdnn = *d;
+  op.utts = (dom == ASV_DOMAIN_UTTS);
+  const bool bf16 = !op.utts && net->frames_bf16();
+  op.cin_pad = round_up(d->in_ch, kChanAlign);
+  op.cout_pad = round_up(d->out_ch, 128);
+  op.cout_store = round_up(d->out_ch, kChanAlign);
+  ASV_REQUIRE(d->out_ch_off + op.cout_store <= net->bufs[d->out_buf].ld, "tdnn: padded output view exceeds the buffer pitch");
+  ASV_HIP_CHECK(hipSetDevice(net->device));
+  {
+    const size_t n = (size_t)op.cout_pad * d->n_taps * op.cin_pad;
+    std::vector<unsigned char> packed(n * (bf16 ? 2 : 4));
+    pack_tdnn_weight(d->weight, d->out_ch, d->in_ch, d->w_tot_context, d->w_left_context, d->taps, d->n_taps, op.cout_pad,
+                     op.cin_pad, bf16, packed.data());
+    if ((rc = dev_upload(net, packed.data(), packed.size(), &op.w))) return rc;
+  }
+  if ((rc = upload_padded(net, d->bias, d->out_ch, op.cout_pad, 0.0f, &op.bias))) return rc;
+  op.has_affine = d->scale != nullptr;
+  if (op.has_affine) {
+    if ((rc = upload_padded(net, d->scale, d->out_ch, op.cout_pad, 0.0f, &op.scale))) return rc;
+    if ((rc = upload_padded(net, d->shift, d->out_ch, op.cout_pad, 0.0f, &op.shift))) return rc;
+  }
+  op.tdnn.weight = nullptr; op.tdnn.bias = nullptr; op.tdnn.scale = nullptr; op.tdnn.shift = nullptr;
+  net->ops.push_back(op);
+  return ASV_OK;
+}
+
+int asv_net_add_stats_pool(asv_net_t *net, const asv_pool_desc_t *d) {
+  ASV_REQUIRE(net && d && !net->finalized, "asv_net_add_stats_pool: net is null or finalized");
+  ASV_REQUIRE(d->struct_size == sizeof(asv_pool_desc_t), "asv_net_add_stats_pool: struct_size mismatch");
+  int rc;
+  if ((rc = check_view(net, d->in_buf, d->in_ch_off, d->channels, "pool input"))) return rc;
+  const int out_ch = d->channels * (d->stddev ? 2 : 1);
+  ASV_REQUIRE(d->out_buf > 0 && d->out_buf < (int)net->bufs.size(), "pool: output buffer id %d", d->out_buf);
+  ASV_REQUIRE(d->out_ch_off >= 0 && d->out_ch_off + out_ch <= net->bufs[d->out_buf].channels, "pool: output view exceeds buffer");
+  ASV_REQUIRE(net->bufs[d->in_buf].domain == ASV_DOMAIN_FRAMES && net->bufs[d->out_buf].domain == ASV_DOMAIN_UTTS,
+              "pool: goes from the frames domain to the utts domain");
+  ASV_REQUIRE(d->unbiased >= 0 && d->unbiased <= 2 && (d->var_mode == ASV_POOL_VAR_CLAMP || d->var_mode == ASV_POOL_VAR_ADD), "pool: bad mode");
+  Op op; op.kind = OP_POOL; op.pool = *d;
+  net->ops.push_back(op);
+  return ASV_OK;
+}
+
+int asv_net_add_attentive_pool(asv_net_t *net, const asv_attpool_desc_t *d) {
+  ASV_REQUIRE(net && d && !net->finalized, "asv_net_add_attentive_pool: net is null or finalized");
+  ASV_REQUIRE(d->struct_size == sizeof(asv_attpool_desc_t), "asv_net_add_attentive_pool: struct_size mismatch");
+  int rc;
+  if ((rc = check_view(net, d->x_buf, d->x_ch_off, d->channels, "attentive pool x"))) return rc;
+  if ((rc = check_view(net, d->logit_buf, d->logit_ch_off, d->channels, "attentive pool logits"))) return rc;
+  ASV_REQUIRE(d->out_buf > 0 && d->out_buf < (int)net->bufs.size(), "attentive pool: output buffer id %d", d->out_buf);
+  ASV_REQUIRE(d->out_ch_off >= 0 && d->out_ch_off + 2 * d->channels <= net->bufs[d->out_buf].channels, "attentive pool: output view exceeds buffer");
+  ASV_REQUIRE(net->bufs[d->x_buf].domain == ASV_DOMAIN_FRAMES && net->bufs[d->logit_buf].domain == ASV_DOMAIN_FRAMES &&
+              net->bufs[d->out_buf].domain == ASV_DOMAIN_UTTS, "attentive pool: frames -> utts");
+  Op op; op.kind = OP_ATTPOOL; op.att = *d;
+  net->ops.push_back(op);
+  return ASV_OK;
+}
+
+int asv_net_add_eltwise(asv_net_t *net, const asv_eltwise_desc_t *d) {
+  ASV_REQUIRE(net && d && !net->finalized, "asv_net_add_eltwise: net is null or finalized");
+  ASV_REQUIRE(d->struct_size == sizeof(asv_eltwise_desc_t), "asv_net_add_eltwise: struct_size mismatch");
+  int rc;
+  if ((rc = check_view(net, d->a_buf, d->a_ch_off, d->channels, "eltwise a"))) return rc;
+  if ((rc = check_view(net, d->out_buf, d->out_ch_off, d->channels, "eltwise out"))) return rc;
+  const int dom = net->bufs[d->a_buf].domain;
+  ASV_REQUIRE(net->bufs[d->out_buf].domain == dom && d->out_buf != 0, "eltwise: bad output buffer");
+  if (d->b_buf >= 0) { if ((rc = check_view(net, d->b_buf, d->b_ch_off, d->channels, "eltwise b"))) return rc; ASV_REQUIRE(net->bufs[d->b_buf].domain == dom, "eltwise: b domain"); }
+  if (d->c_buf >= 0) { if ((rc = check_view(net, d->c_buf, d->c_ch_off, d->channels, "eltwise c"))) return rc; ASV_REQUIRE(net->bufs[d->c_buf].domain == dom, "eltwise: c domain"); }
+  if (d->seg_scale_buf >= 0)
+    ASV_REQUIRE(dom == ASV_DOMAIN_FRAMES && d->seg_scale_buf < (int)net->bufs.size() && net->bufs[d->seg_scale_buf].domain == ASV_DOMAIN_UTTS &&
+                net->bufs[d->seg_scale_buf].channels >= d->channels, "eltwise: bad per-segment scale buffer");
+  ASV_REQUIRE((d->scale == nullptr) == (d->shift == nullptr), "eltwise: scale and shift come together");
+  const int vec = (dom == ASV_DOMAIN_FRAMES && net->frames_bf16()) ? 8 : 4;
+  ASV_REQUIRE(d->out_ch_off + round_up(d->channels, vec) <= net->bufs[d->out_buf].ld, "eltwise: padded view exceeds pitch");
+  Op op; op.kind = OP_ELTWISE; op.elt = *d; op.utts = (dom == ASV_DOMAIN_UTTS);
+  ASV_HIP_CHECK(hipSetDevice(net->device));
+  if (d->scale) {
+    const int n_pad = round_up(d->channels, kChanAlign);
+    if ((rc = upload_padded(net, d->scale, d->channels, n_pad, 0.0f, &op.scale))) return rc;
+    if ((rc = upload_padded(net, d->shift, d->channels, n_pad, 0.0f, &op.shift))) return rc;
+  }
+  op.elt.scale = nullptr; op.elt.shift = nullptr;
+  net->ops.push_back(op);
+  return ASV_OK;
+}
+
+int asv_net_finalize(asv_net_t *net, int out_buf, int embed_dim) {
+  ASV_REQUIRE(net && !net->finalized, "asv_net_finalize: net is null or already finalized");
+  ASV_REQUIRE(out_buf > 0 && out_buf < (int)net->bufs.size() && net->bufs[out_buf].domain == ASV_DOMAIN_UTTS,
+              "asv_net_finalize: output must be an utts-domain buffer");
+  ASV_REQUIRE(embed_dim >= 1 && embed_dim <= net->bufs[out_buf].channels, "asv_net_finalize: embed_dim %d", embed_dim);
+  ASV_REQUIRE(!net->ops.empty(), "asv_net_finalize: empty program");
+  net->out_buf = out_buf; net->embed_dim = embed_dim; net->finalized = true;
+  net->arena.resize(net->bufs.size());
+  return ASV_OK;
+}
+
+int asv_net_embed_dim(const asv_net_t *net) { return net ? net->embed_dim : ASV_EINVAL; }
+
+size_t asv_net_device_bytes(const asv_net_t *net) {
+  if (!net) return 0;
+  size_t n = net->weight_bytes + net->meta_dev.cap + net->rowmeta_dev.cap;
+  for (auto &m : net->arena) n += m.cap;
+  return n;
+}
+
+int asv_net_describe(const asv_net_t *net, char *buf, size_t cap) {
+  if (!net || !buf || cap == 0) return ASV_EINVAL;
+  std::string s;
+  char line[512];
+  snprintf(line, sizeof(line), "asv_net precision=%s flags=%u feat_dim=%d buffers=%zu ops=%zu out=%d embed_dim=%d\n",
+           net->precision == ASV_PREC_BF16 ? "bf16" : "f32", net->flags, net->feat_dim, net->bufs.size(), net->ops.size(), net->out_buf, net->embed_dim);
+  s += line;
+  for (size_t i = 0; i < net->bufs.size(); ++i) {
+    snprintf(line, sizeof(line), "  buf %zu: %s channels=%d ld=%d\n", i, net->bufs[i].domain == ASV_DOMAIN_FRAMES ? "frames" : "utts", net->bufs[i].channels, net->bufs[i].ld);
+    s += line;
+  }
+  for (size_t i = 0; i < net->ops.size(); ++i) {
+    const Op &op = net->ops[i];
+    switch (op.kind) {
+      case OP_TDNN: {
+        const auto &d = op.tdnn;
+        std::string taps;
+        for (int t = 0; t < d.n_taps; ++t) { taps += (t ? "," : ""); taps += std::to_string(d.taps[t]); }
+        snprintf(line, sizeof(line), "  op %zu: tdnn %d[%d:+%d]%s -> %d[%d:+%d] taps=[%s] act1=%d affine=%d first=%d act2=%d segbias=%d segscale=%d res=%d\n", i,
+                 d.in_buf, d.in_ch_off, d.in_ch, d.in2_buf >= 0 ? "+in2" : "", d.out_buf, d.out_ch_off, d.out_ch, taps.c_str(), d.act1, (int)op.has_affine,
+                 d.affine_first, d.act2, d.seg_bias_buf, d.seg_scale_buf, d.res_buf);
+        break;
+      }
+      case OP_POOL:
+        snprintf(line, sizeof(line), "  op %zu: stats_pool %d[%d:+%d] -> %d[%d] stddev=%d unbiased=%d var_mode=%d eps=%g\n", i, op.pool.in_buf, op.pool.in_ch_off,
+                 op.pool.channels, op.pool.out_buf, op.pool.out_ch_off, op.pool.stddev, op.pool.unbiased, op.pool.var_mode, op.pool.eps);
+        break;
+      case OP_ATTPOOL:
+        snprintf(line, sizeof(line), "  op %zu: attentive_pool x=%d logits=%d channels=%d -> %d[%d] eps=%g\n", i, op.att.x_buf, op.att.logit_buf, op.att.channels,
+                 op.att.out_buf, op.att.out_ch_off, op.att.eps);
+        break;
+      case OP_ELTWISE:
+        snprintf(line, sizeof(line), "  op %zu: eltwise a=%d b=%d c=%d segscale=%d affine=%d channels=%d -> %d[%d]\n", i, op.elt.a_buf, op.elt.b_buf, op.elt.c_buf,
+                 op.elt.seg_scale_buf, op.scale != nullptr, op.elt.channels, op.elt.out_buf, op.elt.out_ch_off);
+        break;
+    }
+    s += line;
+  }
+  const size_t n = std::min(cap - 1, s.size());
+  memcpy(buf, s.data(), n);
+  buf[n] = 0;
+  return (int)n;
+}
+
+int asv_net_set_profiling(asv_net_t *net, int enable) {
+  ASV_REQUIRE(net != nullptr, "asv_net_set_profiling: null net");
+  net->profiling = enable != 0;
+  return ASV_OK;
+}
+
+int asv_net_get_profile(asv_net_t *net, asv_kernel_time_t *rows, int cap, int *n_rows) {
+  ASV_REQUIRE(net && rows && n_rows && cap >= 1, "asv_net_get_profile: bad arguments");
+  ASV_HIP_CHECK(hipSetDevice(net->device));
+  asv_kernel_time_t agg[K_COUNT];
+  memset(agg, 0, sizeof(agg));
+  for (int k = 0; k < K_COUNT; ++k) snprintf(agg[k].name, sizeof(agg[k].name), "%s", kKernelNames[k]);
+  for (auto &st : net->stamps) {
+    ASV_HIP_CHECK(hipEventSynchronize(st.b));
+    float ms = 0.0f;
+    ASV_HIP_CHECK(hipEventElapsedTime(&ms, st.a, st.b));
+    agg[st.kclass].launches += 1;
+    agg[st.kclass].total_ms += ms;
+    agg[st.kclass].flops += st.flops;
+    net->event_pool.push_back(st.a);
+    net->event_pool.push_back(st.b);
+  }
+  net->stamps.clear();
+  int n = 0;
+  for (int k = 0; k < K_COUNT && n < cap; ++k)
+    if (agg[k].launches > 0) rows[n++] = agg[k];
+  *n_rows = n;
+  return ASV_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------
+// the launch sequence of one batch
+namespace {
+
+struct RunCtx {
+  asv_net *net; hipStream_t s; BatchPlan bp;
+  // device metadata views
+  int32_t *seg_src0, *seg_row0, *seg_len, *utt_seg0, *utt_nseg, *one_row0, *one_len;
+  int32_t *row_seg, *urow_seg; uint32_t *row_valid, *urow_valid;
+};
+
+int prepare(RunCtx &c, const int32_t *offsets, int n_utts, int max_chunk) {
+  asv_net *net = c.net;
+  int rc;
+  if ((rc = make_plan(offsets, n_utts, max_chunk, c.bp))) return rc;
+  const BatchPlan &bp = c.bp;
+  const int S = bp.segments, B = bp.n_utts;
+  // ---- int32 metadata: one pinned staging buffer, one H2D copy
+  const size_t n_meta = (size_t)3 * S + 2 * B + 2;
+  const size_t meta_bytes = n_meta * sizeof(int32_t);
+  if (net->meta_inflight) { ASV_HIP_CHECK(hipEventSynchronize(net->meta_copied)); net->meta_inflight = false; }
+  if (meta_bytes > net->meta_host_cap) {
+    if (net->meta_host) ASV_HIP_CHECK(hipHostFree(net->meta_host));
+    net->meta_host = nullptr;
+    net->meta_host_cap = meta_bytes * 2 + 4096;
+    ASV_HIP_CHECK(hipHostMalloc(&net->meta_host, net->meta_host_cap, hipHostMallocDefault));
+  }
+  if (!net->meta_copied) ASV_HIP_CHECK(hipEventCreateWithFlags(&net->meta_copied, hipEventDisableTiming));
+  if ((rc = ensure(net->meta_dev, meta_bytes, c.s, false))) return rc;
+  int32_t *h = reinterpret_cast<int32_t *>(net->meta_host);
+  int32_t *d = reinterpret_cast<int32_t *>(net->meta_dev.ptr);
+  size_t o = 0;
+  auto put = [&](const std::vector<int32_t> &v, int32_t **dev) { memcpy(h + o, v.data(), v.size() * 4); *dev = d + o; o += v.size(); };
+  put(bp.seg_src0, &c.seg_src0); put(bp.seg_row0, &c.seg_row0); put(bp.seg_len, &c.seg_len);
+  put(bp.utt_seg0, &c.utt_seg0); put(bp.utt_nseg, &c.utt_nseg);
+  h[o] = 0; c.one_row0 = d + o; ++o;
+  h[o] = S; c.one_len = d + o; ++o;
+  ASV_HIP_CHECK(hipMemcpyAsync(d, h, meta_bytes, hipMemcpyHostToDevice, c.s));
+  ASV_HIP_CHECK(hipEventRecord(net->meta_copied, c.s));
+  net->meta_inflight = true;
+  // ---- row maps
+  const size_t rm_words = (size_t)bp.rows_pad + bp.rows_pad / 32 + bp.seg_pad + bp.seg_pad / 32;
+  if ((rc = ensure(net->rowmeta_dev, rm_words * 4, c.s, false))) return rc;
+  int32_t *r = reinterpret_cast<int32_t *>(net->rowmeta_dev.ptr);
+  c.row_seg = r; r += bp.rows_pad;
+  c.row_valid = reinterpret_cast<uint32_t *>(r); r += bp.rows_pad / 32;
+  c.urow_seg = r; r += bp.seg_pad;
+  c.urow_valid = reinterpret_cast<uint32_t *>(r);
+  Prof prof{net, c.s};
+  if ((rc = prof.begin(K_ROWMAP, 0))) return rc;
+  if ((rc = launch_rowmap(c.seg_row0, c.seg_len, S, bp.rows_pad, c.row_seg, c.row_valid, c.s))) return rc;
+  if ((rc = launch_rowmap(c.one_row0, c.one_len, 1, bp.seg_pad, c.urow_seg, c.urow_valid, c.s))) return rc;
+  if ((rc = prof.end())) return rc;
+  // ---- activation arena
+  for (size_t i = 0; i < net->bufs.size(); ++i) {
+    const Buffer &b = net->bufs[i];
+    const size_t rows = b.domain == ASV_DOMAIN_FRAMES ? bp.rows_pad : bp.seg_pad;
+    if ((rc = ensure(net->arena[i], rows * b.ld * net->elem_size(b.domain), c.s, true))) return rc;
+  }
+  return ASV_OK;
+}
+
+unsigned char *view(RunCtx &c, int buf, int ch_off) {
+  const Buffer &b = c.net->bufs[buf];
+  return reinterpret_cast<unsigned char *>(c.net->arena[buf].ptr) + (size_t)ch_off * c.net->elem_size(b.domain);
+}
+
+int run_ops(RunCtx &c, size_t n_ops) {
+  asv_net *net = c.net;
+  const BatchPlan &bp = c.bp;
+  Prof prof{net, c.s};
+  int rc;
+  const bool use_ref = (net->flags & ASV_FLAG_REF_KERNELS) != 0;
+  for (size_t i = 0; i < n_ops; ++i) {
+    Op &op = net->ops[i];
+    switch (op.kind) {
+      case OP_TDNN: {
+        const auto &d = op.tdnn;
+        const bool bf16 = !op.utts && net->frames_bf16();
+        TdnnKernelParams p;
+        memset(&p, 0, sizeof(p));
+        p.x = view(c, d.in_buf, d.in_ch_off); p.ldx = net->bufs[d.in_buf].ld;
+        if (d.in2_buf >= 0) { p.x2 = view(c, d.in2_buf, d.in2_ch_off); p.ldx2 = net->bufs[d.in2_buf].ld; }
+        p.w = op.w; p.bias = op.bias; p.scale = op.scale; p.shift = op.shift;
+        if (d.seg_bias_buf >= 0) { p.seg_bias = reinterpret_cast<const float *>(net->arena[d.seg_bias_buf].ptr); p.ld_segbias = net->bufs[d.seg_bias_buf].ld; }
+        if (d.seg_scale_buf >= 0) { p.seg_scale = reinterpret_cast<const float *>(net->arena[d.seg_scale_buf].ptr); p.ld_segscale = net->bufs[d.seg_scale_buf].ld; }
+        if (d.res_buf >= 0) { p.res = view(c, d.res_buf, d.res_ch_off); p.ldres = net->bufs[d.res_buf].ld; }
+        p.y = view(c, d.out_buf, d.out_ch_off); p.ldy = net->bufs[d.out_buf].ld;
+        p.row_seg = op.utts ? c.urow_seg : c.row_seg;
+        p.row_valid = op.utts ? c.urow_valid : c.row_valid;
+        p.rows = op.utts ? bp.seg_pad : bp.rows_pad;
+        p.cin_pad = op.cin_pad; p.cout_store = op.cout_store;
+        p.n_taps = d.n_taps;
+        for (int t = 0; t < d.n_taps; ++t) p.taps[t] = d.taps[t];
+        p.act1 = d.act1; p.act2 = d.act2; p.affine_first = d.affine_first;
+        const double valid_rows = op.utts ? (double)bp.segments : (double)bp.frames;
+        if ((rc = prof.begin(K_TDNN, 2.0 * valid_rows * d.in_ch * d.out_ch * d.n_taps))) return rc;
+        rc = use_ref ? launch_tdnn_ref(p, bf16, !bf16, c.s) : launch_tdnn_mfma(p, bf16, !bf16, c.s);
+        if (rc) return rc;
+        if ((rc = prof.end())) return rc;
+        break;
+      }
+      case OP_POOL: {
+        const auto &d = op.pool;
+        PoolKernelParams p;
+        p.x = view(c, d.in_buf, d.in_ch_off); p.ldx = net->bufs[d.in_buf].ld; p.channels = d.channels;
+        p.seg_row0 = c.seg_row0; p.seg_len = c.seg_len;
+        p.out = reinterpret_cast<float *>(net->arena[d.out_buf].ptr) + d.out_ch_off; p.ld_out = net->bufs[d.out_buf].ld;
+        p.stddev = d.stddev; p.unbiased = d.unbiased; p.var_mode = d.var_mode; p.eps = d.eps;
+        if ((rc = prof.begin(K_POOL, 0))) return rc;
+        if ((rc = launch_stats_pool(p, bp.segments, net->frames_bf16(), c.s))) return rc;
+        if ((rc = prof.end())) return rc;
+        break;
+      }
+      case OP_ATTPOOL: {
+        const auto &d = op.att;
+        if ((rc = prof.begin(K_ATT, 0))) return rc;
+        rc = launch_attentive_pool(view(c, d.x_buf, d.x_ch_off), net->bufs[d.x_buf].ld, view(c, d.logit_buf, d.logit_ch_off), net->bufs[d.logit_buf].ld,
+                                   d.channels, c.seg_row0, c.seg_len, bp.segments, d.eps,
+                                   reinterpret_cast<float *>(net->arena[d.out_buf].ptr) + d.out_ch_off, net->bufs[d.out_buf].ld, net->frames_bf16(), c.s);
+        if (rc) return rc;
+        if ((rc = prof.end())) return rc;
+        break;
+      }
+      case OP_ELTWISE: {
+        const auto &d = op.elt;
+        EltwiseKernelParams p;
+        memset(&p, 0, sizeof(p));
+        p.a = view(c, d.a_buf, d.a_ch_off); p.lda = net->bufs[d.a_buf].ld;
+        if (d.b_buf >= 0) { p.b = view(c, d.b_buf, d.b_ch_off); p.ldb = net->bufs[d.b_buf].ld; }
+        if (d.c_buf >= 0) { p.c = view(c, d.c_buf, d.c_ch_off); p.ldc = net->bufs[d.c_buf].ld; }
+        p.out = view(c, d.out_buf, d.out_ch_off); p.ldo = net->bufs[d.out_buf].ld;
+        p.channels = d.channels;
+        p.scale = op.scale; p.shift = op.shift;
+        if (d.seg_scale_buf >= 0) { p.seg_scale = reinterpret_cast<const float *>(net->arena[d.seg_scale_buf].ptr); p.ld_segscale = net->bufs[d.seg_scale_buf].ld; }
+        if (op.utts) { p.rows = bp.segments; }
+        else { p.rows = bp.rows_pad; p.row_seg = c.row_seg; p.row_valid = c.row_valid; }
+        if ((rc = prof.begin(K_ELT, 0))) return rc;
+        if ((rc = launch_eltwise(p, !op.utts && net->frames_bf16(), c.s))) return rc;
+        if ((rc = prof.end())) return rc;
+        break;
+      }
+    }
+  }
+  return ASV_OK;
+}
+
+int pack_features(RunCtx &c, const float *feats) {
+  Prof prof{c.net, c.s};
+  int rc;
+  if ((rc = prof.begin(K_PACK, 0))) return rc;
+  if ((rc = launch_pack_input(feats, c.net->feat_dim, c.seg_src0, c.seg_row0, c.row_seg, c.bp.rows_pad, c.net->arena[0].ptr, c.net->bufs[0].ld,
+                              c.net->frames_bf16(), c.s))) return rc;
+  return prof.end();
+}
+
+}  // namespace
+
+extern "C" {
+
+int asv_net_extract(asv_net_t *net, const float *feats, const int32_t *offsets, int n_utts, float *out, int max_chunk, void *stream) {
+  ASV_REQUIRE(net && net->finalized, "asv_net_extract: net is null or not finalized");
+  ASV_REQUIRE(feats && out, "asv_net_extract: null feature or output pointer");
+  ASV_HIP_CHECK(hipSetDevice(net->device));
+  RunCtx c;
+  c.net = net; c.s = reinterpret_cast<hipStream_t>(stream);
+  int rc;
+  if ((rc = prepare(c, offsets, n_utts, max_chunk))) return rc;
+  if ((rc = pack_features(c, feats))) return rc;
+  if ((rc = run_ops(c, net->ops.size()))) return rc;
+  Prof prof{net, c.s};
+  if ((rc = prof.begin(K_COMBINE, 0))) return rc;
+  if ((rc = launch_combine(reinterpret_cast<const float *>(net->arena[net->out_buf].ptr), net->bufs[net->out_buf].ld, c.utt_seg0, c.utt_nseg, c.seg_len, n_utts,
+                           net->embed_dim, out, c.s))) return rc;
+  return prof.end();
+}
+
+int asv_tdnn_forward(const asv_tdnn_desc_t *d, int precision, unsigned flags, const float *x, const int32_t *offsets, int n_utts, float *y, void *stream) {
+  ASV_REQUIRE(d && x && y && offsets, "asv_tdnn_forward: null argument");
+  int dev = 0;
+  ASV_HIP_CHECK(hipGetDevice(&dev));
+  asv_net_t *net = nullptr;
+  int rc = asv_net_create(&net, dev, precision, flags, d->in_ch);
+  if (rc) return rc;
+  std::unique_ptr<asv_net_t, void (*)(asv_net_t *)> guard(net, asv_net_destroy);
+  const int ob = asv_net_new_buffer(net, ASV_DOMAIN_FRAMES, d->out_ch);
+  if (ob < 0) return ob;
+  asv_tdnn_desc_t dd = *d;
+  dd.in_buf = 0; dd.in_ch_off = 0; dd.in2_buf = -1; dd.out_buf = ob; dd.out_ch_off = 0;
+  dd.seg_bias_buf = -1; dd.seg_scale_buf = -1; dd.res_buf = -1;
+  if ((rc = asv_net_add_tdnn(net, &dd))) return rc;
+  net->arena.resize(net->bufs.size());
+  RunCtx c;
+  c.net = net; c.s = reinterpret_cast<hipStream_t>(stream);
+  if ((rc = prepare(c, offsets, n_utts, 1 << 30))) return rc;
+  if ((rc = pack_features(c, x))) return rc;
+  if ((rc = run_ops(c, 1))) return rc;
+  if ((rc = launch_unpack_rows(net->arena[ob].ptr, net->bufs[ob].ld, d->out_ch, c.seg_src0, c.seg_row0, c.row_seg, c.bp.rows_pad, y, net->frames_bf16(), c.s))) return rc;
+  ASV_HIP_CHECK(hipStreamSynchronize(c.s));
+  return ASV_OK;
+}
+
+int asv_stats_pool_forward(const float *x, int channels, const int32_t *offsets, int n_utts, int stddev, int unbiased, int var_mode, float eps, float *y,
+                           void *stream) {
+  ASV_REQUIRE(x && y && offsets && channels >= 1, "asv_stats_pool_forward: bad argument");
+  int dev = 0;
+  ASV_HIP_CHECK(hipGetDevice(&dev));
+  asv_net_t *net = nullptr;
+  int rc = asv_net_create(&net, dev, ASV_PREC_F32, 0, channels);
+  if (rc) return rc;
+  std::unique_ptr<asv_net_t, void (*)(asv_net_t *)> guard(net, asv_net_destroy);
+  const int out_ch = channels * (stddev ? 2 : 1);
+  const int ob = asv_net_new_buffer(net, ASV_DOMAIN_UTTS, out_ch);
+  if (ob < 0) return ob;
+  asv_pool_desc_t pd;
+  memset(&pd, 0, sizeof(pd));
+  pd.struct_size = sizeof(pd); pd.in_buf = 0; pd.channels = channels; pd.out_buf = ob; pd.stddev = stddev; pd.unbiased = unbiased; pd.var_mode = var_mode; pd.eps = eps;
+  if ((rc = asv_net_add_stats_pool(net, &pd))) return rc;
+  net->arena.resize(net->bufs.size());
+  RunCtx c;
+  c.net = net; c.s = reinterpret_cast<hipStream_t>(stream);
+  if ((rc = prepare(c, offsets, n_utts, 1 << 30))) return rc;
+  if ((rc = pack_features(c, x))) return rc;
+  if ((rc = run_ops(c, 1))) return rc;
+  ASV_HIP_CHECK(hipMemcpy2DAsync(y, (size_t)out_ch * 4, net->arena[ob].ptr, (size_t)net->bufs[ob].ld * 4, (size_t)out_ch * 4, n_utts, hipMemcpyDeviceToDevice, c.s));
+  ASV_HIP_CHECK(hipStreamSynchronize(c.s));
+  return ASV_OK;
+}
+
+}  // extern "C"

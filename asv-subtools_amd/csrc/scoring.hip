@@ -1,0 +1,328 @@
+// Scoring back-end: length normalisation, global-mean subtraction, the batched
+// enroll x test dot-product GEMM, trial-list gathers, Kaldi-style PLDA transform + LLR and EER.
+//
+// Replaces the Kaldi binaries the reference shells out to (score/process.sh:156-203
+// ivector-mean / ivector-subtract-global-mean / ivector-normalize-length --scaleup=false;
+// score/score.sh:82-121 ivector-compute-dot-products / ivector-plda-scoring), the in-repo
+// Python PLDA they mirror (score/pyplda/plda_base.py:93-136,165-172) and the sort-based EER
+// of computeEER-like-Bosaris.py:50-91.
+#include <hipcub/hipcub.hpp>
+
+#include <string.h>
+#include <vector>
+
+#include "device_utils.h"
+
+namespace asv {
+namespace {
+
+// thread-local device workspace, grown on demand (scoring calls are not on the extract path)
+struct Workspace {
+  void *ptr = nullptr; size_t cap = 0;
+  int get(size_t bytes, void **out) {
+    if (bytes > cap) {
+      if (ptr) { ASV_HIP_CHECK(hipDeviceSynchronize()); ASV_HIP_CHECK(hipFree(ptr)); ptr = nullptr; cap = 0; }
+      ASV_HIP_CHECK(hipMalloc(&ptr, bytes + bytes / 4 + 4096));
+      cap = bytes + bytes / 4 + 4096;
+    }
+    *out = ptr;
+    return ASV_OK;
+  }
+};
+thread_local Workspace g_ws;
+
+__global__ __launch_bounds__(256) void col_mean_kernel(const float *x, int n, int dim, float *mean) {
+  // one block per 64 columns; lanes along columns, 4 waves stride the rows
+  __shared__ float sm[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6;
+  float s = 0.0f;
+  if (col < dim)
+    for (int r = wave; r < n; r += 4) s += x[(size_t)r * dim + col];
+  sm[wave][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (wave == 0 && col < dim) mean[col] = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x])) / (float)n;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// one wave per vector: x <- (x - mean); x <- x / ||x||
+__global__ __launch_bounds__(256) void length_norm_kernel(float *x, int n, int dim, const float *mean, int normalize) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= n) return;
+  float *v = x + (size_t)row * dim;
+  float ss = 0.0f;
+  for (int i = lane; i < dim; i += 64) {
+    float t = v[i];
+    if (mean) t -= mean[i];
+    v[i] = t;
+    ss += t * t;
+  }
+  if (!normalize) return;
+  ss = wave_sum(ss);
+  const float nrm = sqrtf(ss);
+  if (nrm > 0.0f)
+    for (int i = lane; i < dim; i += 64) v[i] = v[i] / nrm;
+}
+
+__global__ __launch_bounds__(256) void dot_trials_kernel(const float *enroll, const float *test, int dim, const int32_t *ei,
+                                                         const int32_t *ti, int n_trials, float *scores) {
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (t >= n_trials) return;
+  const float *a = enroll + (size_t)ei[t] * dim, *b = test + (size_t)ti[t] * dim;
+  float s = 0.0f;
+  for (int i = lane; i < dim; i += 64) s = fmaf(a[i], b[i], s);
+  s = wave_sum(s);
+  if (lane == 0) scores[t] = s;
+}
+
+// rows [n][dim] f32 -> padded [rows_pad][ld] f32 (zero fill), optionally minus mean
+__global__ __launch_bounds__(256) void pad_rows_kernel(const float *src, int n, int dim, const float *mean, float *dst, int rows_pad, int ld) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long long)rows_pad * ld) return;
+  const int r = (int)(gid / ld), c = (int)(gid % ld);
+  float v = 0.0f;
+  if (r < n && c < dim) { v = src[(size_t)r * dim + c]; if (mean) v -= mean[c]; }
+  dst[gid] = v;
+}
+
+__global__ __launch_bounds__(256) void set_valid_kernel(uint32_t *bits, int rows, int rows_pad) {
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= rows_pad / 32) return;
+  uint32_t b = 0;
+  for (int i = 0; i < 32; ++i) if (w * 32 + i < rows) b |= (1u << i);
+  bits[w] = b;
+}
+
+__global__ __launch_bounds__(256) void copy_out_kernel(const float *src, int ld, float *dst, int n, int m) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long long)n * m) return;
+  dst[gid] = src[(size_t)(gid / m) * ld + (gid % m)];
+}
+
+// C[M][N] = A[M][K] . B[N][K]^T through the f32 MFMA GEMM of kernels_tdnn.hip.
+// A gets an optional per-column mean subtracted while being padded.
+int gemm_nt_f32(const float *A, int M, const float *a_mean, const float *B, int N, int K, float *C, hipStream_t s) {
+  const int m_pad = round_up(M, kRowTile), n_pad = round_up(N, 128), k_pad = round_up(K, kChanAlign), ldc = round_up(N, kChanAlign);
+  const size_t bytes = ((size_t)m_pad * k_pad + (size_t)n_pad * k_pad + (size_t)m_pad * ldc + n_pad + m_pad / 32) * 4;
+  void *ws = nullptr;
+  int rc = g_ws.get(bytes, &ws);
+  if (rc) return rc;
+  float *Ap = reinterpret_cast<float *>(ws), *Bp = Ap + (size_t)m_pad * k_pad, *Cp = Bp + (size_t)n_pad * k_pad, *bias = Cp + (size_t)m_pad * ldc;
+  uint32_t *valid = reinterpret_cast<uint32_t *>(bias + n_pad);
+  auto blocks = [](long long n) { return dim3((unsigned)((n + 255) / 256)); };
+  hipLaunchKernelGGL(pad_rows_kernel, blocks((long long)m_pad * k_pad), dim3(256), 0, s, A, M, K, a_mean, Ap, m_pad, k_pad);
+  hipLaunchKernelGGL(pad_rows_kernel, blocks((long long)n_pad * k_pad), dim3(256), 0, s, B, N, K, (const float *)nullptr, Bp, n_pad, k_pad);
+  ASV_HIP_CHECK(hipMemsetAsync(bias, 0, (size_t)n_pad * 4, s));
+  hipLaunchKernelGGL(set_valid_kernel, blocks(m_pad / 32), dim3(256), 0, s, valid, M, m_pad);
+  ASV_HIP_CHECK(hipGetLastError());
+  TdnnKernelParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = Ap; p.ldx = k_pad; p.w = Bp; p.bias = bias; p.y = Cp; p.ldy = ldc; p.row_valid = valid;
+  p.rows = m_pad; p.cin_pad = k_pad; p.cout_store = ldc; p.n_taps = 1; p.taps[0] = 0;
+  if ((rc = launch_tdnn_mfma(p, false, true, s))) return rc;
+  hipLaunchKernelGGL(copy_out_kernel, blocks((long long)M * N), dim3(256), 0, s, Cp, ldc, C, M, N);
+  ASV_HIP_CHECK(hipGetLastError());
+  return ASV_OK;
+}
+
+// PLDA length normalisation (plda_base.py:96-105,165-172), one wave per vector
+__global__ __launch_bounds__(256) void plda_norm_kernel(float *y, int n, int dim, const float *psi, const int32_t *num_examples, int mode) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= n) return;
+  float *v = y + (size_t)row * dim;
+  const double ne = num_examples ? (double)num_examples[row] : 1.0;
+  double acc = 0.0;
+  for (int i = lane; i < dim; i += 64) {
+    const double t = (double)v[i];
+    acc += (mode == ASV_PLDA_NORM_SIMPLE) ? t * t : t * t / ((double)psi[i] + 1.0 / ne);
+  }
+  acc = wave_sum_f64(acc);
+  const double factor = (mode == ASV_PLDA_NORM_SIMPLE) ? sqrt((double)dim) / sqrt(acc) : sqrt((double)dim / acc);
+  for (int i = lane; i < dim; i += 64) v[i] = (float)(factor * (double)v[i]);
+}
+
+// PLDA log-likelihood ratio (plda_base.py:109-136), float64 like the reference
+__global__ __launch_bounds__(256) void plda_llr_kernel(const float *enroll, const float *test, int dim, const float *psi, const int32_t *enroll_n,
+                                                       const int32_t *ei, const int32_t *ti, int n_trials, float *scores) {
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (t >= n_trials) return;
+  const int e = ei[t];
+  const float *g = enroll + (size_t)e * dim, *q = test + (size_t)ti[t] * dim;
+  const double n = enroll_n ? (double)enroll_n[e] : 1.0;
+  double given = 0.0, without = 0.0;
+  for (int i = lane; i < dim; i += 64) {
+    const double ps = (double)psi[i];
+    const double mean = n * ps / (n * ps + 1.0) * (double)g[i];
+    const double var = 1.0 + ps / (n * ps + 1.0);
+    const double d = (double)q[i] - mean;
+    given += log(var) + d * d / var;
+    const double var0 = ps + 1.0;
+    without += log(var0) + (double)q[i] * (double)q[i] / var0;
+  }
+  given = wave_sum_f64(given);
+  without = wave_sum_f64(without);
+  // the M_LOG_2PI*dim terms cancel in the ratio
+  if (lane == 0) scores[t] = (float)(-0.5 * given + 0.5 * without);
+}
+
+// ---- EER --------------------------------------------------------------------------------
+// key = order-preserving uint32 image of the score in the high word, label in the low word:
+// ascending sort == Python's sorted([[score, label], ...]) (computeEER-like-Bosaris.py:64).
+__global__ __launch_bounds__(256) void eer_keys_kernel(const float *scores, const int32_t *labels, int n, unsigned long long *keys) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t u = __float_as_uint(scores[i]);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  keys[i] = ((unsigned long long)u << 32) | (unsigned)(labels[i] != 0);
+}
+__global__ __launch_bounds__(256) void eer_labels_kernel(const unsigned long long *keys, int n, int *lab) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) lab[i] = (int)(keys[i] & 1ull);
+}
+// first sorted index with far <= frr (computeEER-like-Bosaris.py:75-80)
+__global__ __launch_bounds__(256) void eer_cross_kernel(const int *cum_tgt, int n, int num_p, int num_n, int *first) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int fr = cum_tgt[i];                       // targets at or below this score
+  const int fa = num_n - ((i + 1) - fr);           // non-targets above this score
+  // far <= frr  <=>  fa/num_n <= fr/num_p, compared exactly in integers
+  if ((long long)fa * num_p <= (long long)fr * num_n) atomicMin(first, i);
+}
+
+float key_to_score(unsigned long long k) {
+  uint32_t u = (uint32_t)(k >> 32);
+  u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+}  // namespace
+}  // namespace asv
+
+using namespace asv;
+
+extern "C" {
+
+int asv_mean_vec(const float *x, int n, int dim, float *mean, void *stream) {
+  ASV_REQUIRE(x && mean && n >= 1 && dim >= 1, "asv_mean_vec: bad argument");
+  hipLaunchKernelGGL(col_mean_kernel, dim3((dim + 63) / 64), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, n, dim, mean);
+  ASV_HIP_CHECK(hipGetLastError());
+  return ASV_OK;
+}
+
+int asv_length_norm(float *x, int n, int dim, const float *mean, int normalize, void *stream) {
+  ASV_REQUIRE(x && n >= 1 && dim >= 1, "asv_length_norm: bad argument");
+  hipLaunchKernelGGL(length_norm_kernel, dim3((n + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, n, dim, mean, normalize);
+  ASV_HIP_CHECK(hipGetLastError());
+  return ASV_OK;
+}
+
+int asv_dot_score_matrix(const float *enroll, int n_enroll, const float *test, int n_test, int dim, float *scores, void *stream) {
+  ASV_REQUIRE(enroll && test && scores && n_enroll >= 1 && n_test >= 1 && dim >= 1, "asv_dot_score_matrix: bad argument");
+  return gemm_nt_f32(enroll, n_enroll, nullptr, test, n_test, dim, scores, reinterpret_cast<hipStream_t>(stream));
+}
+
+int asv_dot_score_trials(const float *enroll, const float *test, int dim, const int32_t *ei, const int32_t *ti, int n_trials, float *scores, void *stream) {
+  ASV_REQUIRE(enroll && test && ei && ti && scores && dim >= 1 && n_trials >= 0, "asv_dot_score_trials: bad argument");
+  if (n_trials == 0) return ASV_OK;
+  hipLaunchKernelGGL(dot_trials_kernel, dim3((n_trials + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), enroll, test, dim, ei, ti, n_trials, scores);
+  ASV_HIP_CHECK(hipGetLastError());
+  return ASV_OK;
+}
+
+int asv_plda_transform(const float *x, int n, int dim, const float *mean, const float *transform, const float *psi, const int32_t *num_examples,
+                       int length_norm, float *y, void *stream) {
+  ASV_REQUIRE(x && transform && y && n >= 1 && dim >= 1, "asv_plda_transform: bad argument");
+  ASV_REQUIRE(length_norm >= ASV_PLDA_NORM_NONE && length_norm <= ASV_PLDA_NORM_PSI, "asv_plda_transform: length_norm %d", length_norm);
+  ASV_REQUIRE(length_norm != ASV_PLDA_NORM_PSI || psi != nullptr, "asv_plda_transform: psi needed for PLDA length normalisation");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // y[n][d] = sum_k T[d][k] (x[n][k] - mean[k])  (plda_base.py:93-97 with offset = -T mean, 158-163)
+  int rc = gemm_nt_f32(x, n, mean, transform, dim, dim, y, s);
+  if (rc) return rc;
+  if (length_norm != ASV_PLDA_NORM_NONE) {
+    hipLaunchKernelGGL(plda_norm_kernel, dim3((n + 3) / 4), dim3(256), 0, s, y, n, dim, psi, num_examples, length_norm);
+    ASV_HIP_CHECK(hipGetLastError());
+  }
+  return ASV_OK;
+}
+
+int asv_plda_llr_trials(const float *enroll, const float *test, int dim, const float *psi, const int32_t *enroll_n, const int32_t *ei, const int32_t *ti,
+                        int n_trials, float *scores, void *stream) {
+  ASV_REQUIRE(enroll && test && psi && ei && ti && scores && dim >= 1 && n_trials >= 0, "asv_plda_llr_trials: bad argument");
+  if (n_trials == 0) return ASV_OK;
+  hipLaunchKernelGGL(plda_llr_kernel, dim3((n_trials + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), enroll, test, dim, psi, enroll_n, ei, ti,
+                     n_trials, scores);
+  ASV_HIP_CHECK(hipGetLastError());
+  return ASV_OK;
+}
+
+int asv_eer(const float *scores, const int32_t *labels, int n, float *eer_percent, float *threshold, void *stream) {
+  ASV_REQUIRE(scores && labels && eer_percent && threshold && n >= 2, "asv_eer: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  size_t sort_tmp = 0, scan_tmp = 0;
+  ASV_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(nullptr, sort_tmp, (unsigned long long *)nullptr, (unsigned long long *)nullptr, n, 0, 64, s));
+  ASV_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(nullptr, scan_tmp, (int *)nullptr, (int *)nullptr, n, s));
+  const size_t tmp = std::max(sort_tmp, scan_tmp);
+  const size_t n8 = round_up64((int64_t)n * 8, 256), n4 = round_up64((int64_t)n * 4, 256);
+  void *ws = nullptr;
+  int rc = g_ws.get(2 * n8 + 2 * n4 + 256 + tmp, &ws);
+  if (rc) return rc;
+  unsigned char *b = reinterpret_cast<unsigned char *>(ws);
+  unsigned long long *keys = reinterpret_cast<unsigned long long *>(b), *sorted = reinterpret_cast<unsigned long long *>(b + n8);
+  int *lab = reinterpret_cast<int *>(b + 2 * n8), *cum = reinterpret_cast<int *>(b + 2 * n8 + n4);
+  int *first = reinterpret_cast<int *>(b + 2 * n8 + 2 * n4);
+  void *cub_tmp = b + 2 * n8 + 2 * n4 + 256;
+  const dim3 grid((n + 255) / 256), block(256);
+  hipLaunchKernelGGL(eer_keys_kernel, grid, block, 0, s, scores, labels, n, keys);
+  size_t t1 = tmp;
+  ASV_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(cub_tmp, t1, keys, sorted, n, 0, 64, s));
+  hipLaunchKernelGGL(eer_labels_kernel, grid, block, 0, s, sorted, n, lab);
+  size_t t2 = tmp;
+  ASV_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(cub_tmp, t2, lab, cum, n, s));
+  int num_p = 0;
+  ASV_HIP_CHECK(hipMemcpyAsync(&num_p, cum + (n - 1), 4, hipMemcpyDeviceToHost, s));
+  ASV_HIP_CHECK(hipStreamSynchronize(s));
+  const int num_n = n - num_p;
+  ASV_REQUIRE(num_p > 0 && num_n > 0, "asv_eer: need both target and non-target trials (%d / %d)", num_p, num_n);
+  const int init = n;
+  ASV_HIP_CHECK(hipMemcpyAsync(first, &init, 4, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(eer_cross_kernel, grid, block, 0, s, cum, n, num_p, num_n, first);
+  int idx = n;
+  ASV_HIP_CHECK(hipMemcpyAsync(&idx, first, 4, hipMemcpyDeviceToHost, s));
+  ASV_HIP_CHECK(hipStreamSynchronize(s));
+  ASV_REQUIRE(idx < n, "asv_eer: FAR never drops to FRR");
+  // the crossing point and its predecessor ("memory"), computeEER-like-Bosaris.py:78-90
+  int cums[2] = {0, 0};
+  unsigned long long ks[2] = {0, 0};
+  const int lo = idx > 0 ? idx - 1 : idx;
+  ASV_HIP_CHECK(hipMemcpy(cums, cum + lo, 4 * (idx - lo + 1), hipMemcpyDeviceToHost));
+  ASV_HIP_CHECK(hipMemcpy(ks, sorted + lo, 8 * (idx - lo + 1), hipMemcpyDeviceToHost));
+  auto rates = [&](int i, int cum_t, double &far, double &frr) {
+    frr = (double)cum_t / num_p;
+    far = (double)(num_n - ((i + 1) - cum_t)) / num_n;
+  };
+  double far, frr, eer; float thr;
+  rates(idx, cums[idx - lo], far, frr);
+  eer = (far + frr) / 2; thr = key_to_score(ks[idx - lo]);
+  if (idx > 0) {
+    double pfar, pfrr;
+    rates(idx - 1, cums[0], pfar, pfrr);
+    const double lnow = far > frr ? far - frr : frr - far, lmem = pfar > pfrr ? pfar - pfrr : pfrr - pfar;
+    if (!(lnow <= lmem)) { eer = (pfar + pfrr) / 2; thr = key_to_score(ks[0]); }
+  }
+  *eer_percent = (float)(eer * 100.0);
+  *threshold = thr;
+  return ASV_OK;
+}
+
+}  // extern "C"

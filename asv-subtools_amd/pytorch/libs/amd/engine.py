@@ -1,0 +1,234 @@
+# -*- coding:utf-8 -*-
+"""Compiles a recorded layer program (ir.Graph) into an `asv_net_t` of libasv_amd.so and runs
+batched extraction on device-resident feature matrices.
+
+PyTorch is used here for device memory (tensors as allocations), streams and, in shard.py,
+torch.distributed - plumbing only.  All arithmetic happens inside libasv_amd.so.
+"""
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import capi
+from . import ir as _ir
+
+
+PRECISIONS = {"f32": capi.PREC_F32, "fp32": capi.PREC_F32, "float32": capi.PREC_F32,
+              "bf16": capi.PREC_BF16, "bfloat16": capi.PREC_BF16}
+
+
+def default_precision():
+    """'f32' keeps the reference's 1e-4 embedding parity (exact-f32 MFMA); 'bf16' is the
+    throughput mode (bf16 MFMA, f32 accumulate, f32 pooled tail)."""
+    return os.environ.get("ASV_AMD_PRECISION", "f32").lower()
+
+
+def default_flags():
+    flags = 0
+    if os.environ.get("ASV_AMD_REF_KERNELS", "0") not in ("0", "", "false"):
+        flags |= capi.FLAG_REF_KERNELS
+    if os.environ.get("ASV_AMD_NO_FUSE", "0") not in ("0", "", "false"):
+        flags |= capi.FLAG_NO_FUSE
+    return flags
+
+
+def _view_args(v):
+    return (-1, 0) if v is None else (v.tid, v.ch_off)
+
+
+class Engine(object):
+    """One compiled model on one device."""
+
+    def __init__(self, graph, device_index=0, precision=None, flags=None):
+        self.lib = capi.lib()
+        self.graph = graph
+        self.device_index = int(device_index)
+        self.precision = (precision or default_precision()).lower()
+        if self.precision not in PRECISIONS:
+            raise ValueError("unknown precision %r (have %s)" % (precision, sorted(set(PRECISIONS))))
+        self.flags = default_flags() if flags is None else int(flags)
+        self.embed_dim = graph.output.channels
+        self.feat_dim = graph.feat_dim
+        self._net = C.c_void_p()
+        capi.check(self.lib.asv_net_create(C.byref(self._net), self.device_index, PRECISIONS[self.precision],
+                                           self.flags, graph.feat_dim), "asv_net_create")
+        try:
+            self._build()
+        except Exception:
+            self.close()
+            raise
+
+    # ---- program upload ---------------------------------------------------------------
+    def _build(self):
+        L, g = self.lib, self.graph
+        buf_of = {0: 0}
+        # one device buffer per IR tensor that something writes as a whole or in slices
+        written = sorted({op.out.tid for op in g.ops})
+        for tid in written:
+            dom, ch = g.tensors[tid]
+            buf_of[tid] = capi.check(L.asv_net_new_buffer(self._net, dom, ch), "asv_net_new_buffer")
+
+        def bv(v):
+            if v is None:
+                return (-1, 0)
+            return (buf_of[v.tid], v.ch_off)
+
+        for op in g.ops:
+            if op.kind == "tdnn":
+                d = capi.TdnnDesc()
+                d.struct_size = C.sizeof(capi.TdnnDesc)
+                d.in_buf, d.in_ch_off = bv(op.inp)
+                d.in2_buf, d.in2_ch_off = bv(op.inp2)
+                d.out_buf, d.out_ch_off = bv(op.out)
+                d.in_ch, d.out_ch = op.inp.channels, op.out.channels
+                d.n_taps = len(op.taps)
+                for i, t in enumerate(op.taps):
+                    d.taps[i] = t
+                keep = [op.weight, op.bias, op.scale, op.shift]
+                d.weight = capi.f32_ptr(op.weight)
+                d.w_tot_context, d.w_left_context = op.weight.shape[2], op.w_left
+                d.bias = capi.f32_ptr(op.bias) if op.bias is not None else None
+                d.seg_bias_buf = bv(op.seg_bias)[0]
+                d.act1 = capi.ACT_BY_NAME[op.act1]
+                d.scale = capi.f32_ptr(op.scale) if op.scale is not None else None
+                d.shift = capi.f32_ptr(op.shift) if op.shift is not None else None
+                d.affine_first = int(op.affine_first)
+                d.act2 = capi.ACT_BY_NAME[op.act2]
+                d.seg_scale_buf = bv(op.seg_scale)[0]
+                d.res_buf, d.res_ch_off = bv(op.res)
+                capi.check(L.asv_net_add_tdnn(self._net, C.byref(d)), "asv_net_add_tdnn")
+                del keep
+            elif op.kind == "pool":
+                d = capi.PoolDesc()
+                d.struct_size = C.sizeof(capi.PoolDesc)
+                d.in_buf, d.in_ch_off = bv(op.inp)
+                d.channels = op.inp.channels
+                d.out_buf, d.out_ch_off = bv(op.out)
+                d.stddev, d.unbiased, d.var_mode, d.eps = int(op.stddev), op.unbiased, op.var_mode, op.eps
+                capi.check(L.asv_net_add_stats_pool(self._net, C.byref(d)), "asv_net_add_stats_pool")
+            elif op.kind == "attpool":
+                d = capi.AttPoolDesc()
+                d.struct_size = C.sizeof(capi.AttPoolDesc)
+                d.x_buf, d.x_ch_off = bv(op.x)
+                d.logit_buf, d.logit_ch_off = bv(op.logits)
+                d.channels = op.x.channels
+                d.out_buf, d.out_ch_off = bv(op.out)
+                d.eps = op.eps
+                capi.check(L.asv_net_add_attentive_pool(self._net, C.byref(d)), "asv_net_add_attentive_pool")
+            elif op.kind == "eltwise":
+                d = capi.EltwiseDesc()
+                d.struct_size = C.sizeof(capi.EltwiseDesc)
+                d.channels = op.a.channels
+                d.a_buf, d.a_ch_off = bv(op.a)
+                d.b_buf, d.b_ch_off = bv(op.b)
+                d.c_buf, d.c_ch_off = bv(op.c)
+                d.seg_scale_buf = bv(op.seg_scale)[0]
+                d.out_buf, d.out_ch_off = bv(op.out)
+                d.scale = capi.f32_ptr(op.scale) if op.scale is not None else None
+                d.shift = capi.f32_ptr(op.shift) if op.shift is not None else None
+                capi.check(L.asv_net_add_eltwise(self._net, C.byref(d)), "asv_net_add_eltwise")
+            else:
+                raise _ir.TraceError("op kind %r survived graph optimisation" % op.kind)
+        if g.output.ch_off != 0:
+            raise _ir.TraceError("the embedding must start at channel 0 of its buffer")
+        capi.check(L.asv_net_finalize(self._net, buf_of[g.output.tid], g.output.channels), "asv_net_finalize")
+
+    def close(self):
+        if getattr(self, "_net", None) is not None and self._net.value:
+            self.lib.asv_net_destroy(self._net)
+            self._net = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def describe(self):
+        buf = C.create_string_buffer(1 << 16)
+        capi.check(self.lib.asv_net_describe(self._net, buf, len(buf)), "asv_net_describe")
+        return buf.value.decode()
+
+    def device_bytes(self):
+        return int(self.lib.asv_net_device_bytes(self._net))
+
+    # ---- extraction ---------------------------------------------------------------------
+    def extract_device(self, feats, offsets, max_chunk=10000, out=None, stream=None):
+        """feats: torch float32 CUDA tensor [sum T, D] (contiguous, on this engine's device);
+        offsets: int32 numpy [B+1].  Returns a torch CUDA tensor [B, E] (asynchronous on the
+        current torch stream unless `stream` is given)."""
+        import torch
+        assert feats.is_cuda and feats.dtype == torch.float32 and feats.is_contiguous(), "feats must be a contiguous float32 CUDA tensor"
+        assert feats.device.index == self.device_index, "feats live on cuda:%s, engine on cuda:%d" % (feats.device.index, self.device_index)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+        n = len(offsets) - 1
+        assert feats.dim() == 2 and feats.shape[1] == self.feat_dim, "expected [frames, %d] features, got %s" % (self.feat_dim, tuple(feats.shape))
+        assert int(offsets[-1]) == feats.shape[0], "offsets[-1]=%d but feats has %d rows" % (int(offsets[-1]), feats.shape[0])
+        if out is None:
+            out = torch.empty((n, self.embed_dim), dtype=torch.float32, device=feats.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(feats.device).cuda_stream
+        capi.check(self.lib.asv_net_extract(self._net, C.c_void_p(feats.data_ptr()), offsets.ctypes.data_as(capi.c_int32_p), n,
+                                            C.c_void_p(out.data_ptr()), int(max_chunk), C.c_void_p(stream)), "asv_net_extract")
+        return out
+
+    def extract_batch(self, mats, max_chunk=10000):
+        """mats: list of [T_i, D] array-likes (host).  Returns a CPU float32 tensor [B, E]."""
+        import torch
+        mats = [np.asarray(m, dtype=np.float32) for m in mats]
+        for m in mats:
+            if m.ndim != 2 or m.shape[1] != self.feat_dim:
+                raise ValueError("expected [frames, %d] feature matrices, got %s" % (self.feat_dim, m.shape))
+        offsets = np.zeros(len(mats) + 1, dtype=np.int32)
+        np.cumsum([m.shape[0] for m in mats], out=offsets[1:])
+        packed = torch.from_numpy(np.ascontiguousarray(np.concatenate(mats, axis=0)))
+        dev = torch.device("cuda", self.device_index)
+        with torch.cuda.device(dev):
+            out = self.extract_device(packed.to(dev), offsets, max_chunk=max_chunk)
+            return out.cpu()
+
+    # ---- profiling ------------------------------------------------------------------------
+    def set_profiling(self, enable):
+        capi.check(self.lib.asv_net_set_profiling(self._net, int(bool(enable))), "asv_net_set_profiling")
+
+    def get_profile(self):
+        """[{name, launches, total_ms, flops}] of the launches since the last call (hipEvents on
+        the extract stream); synchronises on the recorded events."""
+        rows = (capi.KernelTime * 16)()
+        n = C.c_int(0)
+        capi.check(self.lib.asv_net_get_profile(self._net, rows, 16, C.byref(n)), "asv_net_get_profile")
+        return [dict(name=rows[i].name.decode(), launches=int(rows[i].launches), total_ms=float(rows[i].total_ms),
+                     flops=float(rows[i].flops)) for i in range(n.value)]
+
+
+def compile_model(model, function=None, device_index=None, precision=None, flags=None, feat_dim=None):
+    """Records `function` (default: the body of the model's decorated extract_embedding) and
+    compiles it for `device_index` (default: the device the model's parameters live on)."""
+    import torch
+    if function is None:
+        function = getattr(type(model).extract_embedding, "__wrapped_body__", None)
+        if function is None:
+            raise _ir.TraceError("%s.extract_embedding is not decorated with libs.nnet.for_extract_embedding" % type(model).__name__)
+    if device_index is None:
+        p = next(model.parameters())
+        if not p.is_cuda:
+            raise RuntimeError("the model lives on %s: asv-subtools_amd extracts on a ROCm device only (select_model_device(model, "
+                               "use_gpu='true')); there is no CPU fallback" % p.device)
+        device_index = p.device.index if p.device.index is not None else torch.cuda.current_device()
+    if feat_dim is None:
+        feat_dim = infer_feat_dim(model)
+    graph = _ir.trace(model, function, feat_dim)
+    return Engine(graph, device_index=device_index, precision=precision, flags=flags)
+
+
+def infer_feat_dim(model):
+    """Input feature dimension = in-channels of the first TDNN / conv layer."""
+    for m in model.modules():
+        if hasattr(m, "input_dim") and hasattr(m, "context"):
+            return int(m.input_dim)
+    d = getattr(model, "inputs_dim", None)
+    if d is None:
+        raise _ir.TraceError("cannot infer the feature dimension of %s; pass feat_dim" % type(model).__name__)
+    return int(d)

@@ -1,0 +1,520 @@
+# -*- coding:utf-8 -*-
+"""Layer-program IR and the symbolic recorder that turns a model blueprint's own
+`extract_embedding` body into it.
+
+The reference executes a blueprint eagerly, one torch op at a time, one utterance at a time
+(libs/nnet/framework.py:18-52).  Here the same Python body is run ONCE on a `Sym` handle:
+the `libs.nnet` layer classes (and a few handlers for torch-owned modules) append coarse,
+already-fused ops to a `Graph`, a few graph passes remove copies (concat elision, add
+folding), and `engine.py` hands the result to libasv_amd.so through the C ABI.  Anything
+the recorder does not understand raises - there is no eager fallback.
+
+Tensor semantics mirror the reference's [batch, channels, frames] convention:
+  frames-domain Sym: rank 3, shape (1, C, T)      utts-domain Sym: rank 3 (1, C, 1) or rank 2 (1, C)
+"""
+
+import numpy as np
+
+DOMAIN_FRAMES, DOMAIN_UTTS = 0, 1
+CHAN_ALIGN = 16
+MAX_HALO = 4
+
+
+class TraceError(NotImplementedError):
+    """The blueprint used something the MI355X path does not implement (raised, never bypassed)."""
+
+
+class View(object):
+    """Channel slice [ch_off, ch_off+channels) of IR tensor `tid`."""
+    __slots__ = ("tid", "ch_off", "channels")
+
+    def __init__(self, tid, ch_off, channels):
+        self.tid, self.ch_off, self.channels = int(tid), int(ch_off), int(channels)
+
+    def key(self):
+        return (self.tid, self.ch_off, self.channels)
+
+    def __repr__(self):
+        return "t%d[%d:+%d]" % (self.tid, self.ch_off, self.channels)
+
+
+class Op(object):
+    """kind in {'tdnn','pool','attpool','eltwise','cat'}; `out` is a View covering a whole
+    tensor until concat elision redirects it into a slice of a wider one."""
+
+    def __init__(self, kind, out, **attrs):
+        self.kind, self.out = kind, out
+        self.__dict__.update(attrs)
+
+    def inputs(self):
+        if self.kind == "tdnn":
+            names = ("inp", "inp2", "seg_bias", "seg_scale", "res")
+        elif self.kind == "pool":
+            names = ("inp",)
+        elif self.kind == "attpool":
+            names = ("x", "logits")
+        elif self.kind == "eltwise":
+            names = ("a", "b", "c", "seg_scale")
+        else:
+            return list(self.parts)
+        return [getattr(self, n) for n in names if getattr(self, n, None) is not None]
+
+    def input_names(self):
+        return {"tdnn": ("inp", "inp2", "seg_bias", "seg_scale", "res"), "pool": ("inp",),
+                "attpool": ("x", "logits"), "eltwise": ("a", "b", "c", "seg_scale"), "cat": ()}[self.kind]
+
+
+class Graph(object):
+    def __init__(self, feat_dim):
+        self.tensors = []          # [(domain, channels)]
+        self.ops = []
+        self.feat_dim = int(feat_dim)
+        self.new_tensor(DOMAIN_FRAMES, feat_dim)        # tensor 0 = input features
+        self.output = None                                # View (utts domain)
+
+    def new_tensor(self, domain, channels):
+        self.tensors.append((int(domain), int(channels)))
+        return len(self.tensors) - 1
+
+    def domain(self, tid):
+        return self.tensors[tid][0]
+
+    def full_view(self, tid):
+        return View(tid, 0, self.tensors[tid][1])
+
+    # ---- op constructors -------------------------------------------------------------
+    def tdnn(self, inp, weight, bias, taps, w_left, act1=None, scale=None, shift=None, affine_first=False,
+             act2=None, inp2=None, seg_bias=None, seg_scale=None, res=None):
+        weight = np.ascontiguousarray(weight, dtype=np.float32)
+        assert weight.ndim == 3 and weight.shape[1] == inp.channels, (weight.shape, inp)
+        taps = [int(t) for t in taps]
+        if max(abs(t) for t in taps) > MAX_HALO:
+            raise TraceError("TDNN context %s reaches beyond the +-%d frame halo of the MI355X row layout" % (taps, MAX_HALO))
+        dom = self.domain(inp.tid)
+        if dom == DOMAIN_UTTS and taps != [0]:
+            raise TraceError("a pooled (utterance-level) tensor only supports context [0], got %s" % (taps,))
+        out = self.full_view(self.new_tensor(dom, weight.shape[0]))
+        f32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+        self.ops.append(Op("tdnn", out, inp=inp, inp2=inp2, weight=weight, bias=f32(bias), taps=taps, w_left=int(w_left),
+                           act1=act1 or None, scale=f32(scale), shift=f32(shift), affine_first=bool(affine_first),
+                           act2=act2 or None, seg_bias=seg_bias, seg_scale=seg_scale, res=res))
+        return out
+
+    def pool(self, inp, stddev=True, unbiased=0, var_mode=0, eps=1e-10):
+        out = self.full_view(self.new_tensor(DOMAIN_UTTS, inp.channels * (2 if stddev else 1)))
+        self.ops.append(Op("pool", out, inp=inp, stddev=bool(stddev), unbiased=int(unbiased), var_mode=int(var_mode), eps=float(eps)))
+        return out
+
+    def attpool(self, x, logits, eps=1e-5):
+        out = self.full_view(self.new_tensor(DOMAIN_UTTS, 2 * x.channels))
+        self.ops.append(Op("attpool", out, x=x, logits=logits, eps=float(eps)))
+        return out
+
+    def eltwise(self, a, b=None, c=None, seg_scale=None, scale=None, shift=None):
+        out = self.full_view(self.new_tensor(self.domain(a.tid), a.channels))
+        f32 = lambda v: None if v is None else np.ascontiguousarray(v, dtype=np.float32)
+        self.ops.append(Op("eltwise", out, a=a, b=b, c=c, seg_scale=seg_scale, scale=f32(scale), shift=f32(shift)))
+        return out
+
+    def cat(self, parts):
+        dom = self.domain(parts[0].tid)
+        out = self.full_view(self.new_tensor(dom, sum(p.channels for p in parts)))
+        self.ops.append(Op("cat", out, parts=list(parts)))
+        return out
+
+    # ---- passes ----------------------------------------------------------------------
+    def _use_count(self):
+        uses = {}
+        for op in self.ops:
+            for v in op.inputs():
+                uses[v.tid] = uses.get(v.tid, 0) + 1
+        if self.output is not None:
+            uses[self.output.tid] = uses.get(self.output.tid, 0) + 1
+        return uses
+
+    def _producer(self):
+        return {op.out.tid: op for op in self.ops if op.out.ch_off == 0 and op.out.channels == self.tensors[op.out.tid][1]}
+
+    def _replace_tensor(self, old_tid, new_view):
+        """Every read of tensor `old_tid` (whole or sliced) now reads inside `new_view`."""
+        def fix(v):
+            if v is not None and v.tid == old_tid:
+                return View(new_view.tid, new_view.ch_off + v.ch_off, v.channels)
+            return v
+        for op in self.ops:
+            if op.kind == "cat":
+                op.parts = [fix(v) for v in op.parts]
+            else:
+                for n in op.input_names():
+                    setattr(op, n, fix(getattr(op, n, None)))
+        self.output = fix(self.output)
+
+    def optimize(self):
+        self._cse_adds()
+        self._fold_eltwise_chains()
+        self._fold_adds_into_tdnn()
+        self._elide_cats()
+        self._drop_dead()
+        return self
+
+    def _is_plain_add(self, op):
+        return (op.kind == "eltwise" and op.b is not None and op.c is None and op.seg_scale is None and op.scale is None)
+
+    def _cse_adds(self):
+        seen = {}
+        for op in list(self.ops):
+            if not self._is_plain_add(op):
+                continue
+            key = tuple(sorted([op.a.key(), op.b.key()]))
+            if key in seen:
+                self._replace_tensor(op.out.tid, seen[key].out)
+                self.ops.remove(op)
+            else:
+                seen[key] = op
+
+    def _fold_eltwise_chains(self):
+        """(a*s + b) + c  ->  one eltwise, when the intermediate has a single reader."""
+        changed = True
+        while changed:
+            changed = False
+            uses, prod = self._use_count(), self._producer()
+            for op in self.ops:
+                if not self._is_plain_add(op):
+                    continue
+                for first, other in ((op.a, op.b), (op.b, op.a)):
+                    p = prod.get(first.tid)
+                    if (p is None or p.kind != "eltwise" or p is op or uses.get(first.tid, 0) != 1
+                            or first.channels != self.tensors[first.tid][1] or first.ch_off != 0):
+                        continue
+                    slot = "b" if p.b is None else ("c" if p.c is None else None)
+                    if slot is None:
+                        continue
+                    setattr(p, slot, other)
+                    self._replace_tensor(op.out.tid, p.out)
+                    self.ops.remove(op)
+                    # keep program order valid: p must run after `other`'s producer
+                    self._move_after_inputs(p)
+                    changed = True
+                    break
+                if changed:
+                    break
+
+    def _move_after_inputs(self, op):
+        prod = self._producer()
+        idx = self.ops.index(op)
+        need = max([self.ops.index(prod[v.tid]) for v in op.inputs() if v.tid in prod] + [-1])
+        if need > idx:
+            self.ops.remove(op)
+            self.ops.insert(need, op)        # after removal, index `need` is right behind the last input producer
+
+    def _fold_adds_into_tdnn(self):
+        """tdnn(a + b) -> tdnn(inp=a, inp2=b): the add happens while the window is staged."""
+        uses, prod = self._use_count(), self._producer()
+        for op in list(self.ops):
+            if op.kind != "tdnn" or op.inp2 is not None:
+                continue
+            p = prod.get(op.inp.tid)
+            if p is None or not self._is_plain_add(p) or uses.get(op.inp.tid, 0) != 1:
+                continue
+            if op.inp.ch_off != 0 or op.inp.channels != self.tensors[op.inp.tid][1]:
+                continue
+            op.inp, op.inp2 = p.a, p.b
+            self.ops.remove(p)
+
+    def _elide_cats(self):
+        """torch.cat over channels becomes "producers write into slices of the wide buffer";
+        parts that are views of something else (Res2Net's pass-through group) get one copy."""
+        for op in list(self.ops):
+            if op.kind != "cat":
+                continue
+            prod = self._producer()
+            idx = self.ops.index(op)
+            off = 0
+            new_ops = []
+            for part in op.parts:
+                whole = part.ch_off == 0 and part.channels == self.tensors[part.tid][1]
+                p = prod.get(part.tid)
+                dst = View(op.out.tid, off, part.channels)
+                if whole and p is not None and p.kind != "cat" and part.tid != 0 and off % CHAN_ALIGN == 0:
+                    p.out = dst
+                    self._replace_tensor(part.tid, dst)
+                else:
+                    new_ops.append(Op("eltwise", dst, a=part, b=None, c=None, seg_scale=None, scale=None, shift=None))
+                off += part.channels
+            self.ops[idx:idx + 1] = new_ops
+
+    def _drop_dead(self):
+        changed = True
+        while changed:
+            changed = False
+            live = set()
+            for op in self.ops:
+                for v in op.inputs():
+                    live.add(v.tid)
+            if self.output is not None:
+                live.add(self.output.tid)
+            for op in list(self.ops):
+                if op.out.tid not in live:
+                    self.ops.remove(op)
+                    changed = True
+
+    def describe(self):
+        lines = ["graph: %d tensors, %d ops, output %r" % (len(self.tensors), len(self.ops), self.output)]
+        for i, op in enumerate(self.ops):
+            if op.kind == "tdnn":
+                extra = "taps=%s act1=%s affine=%s%s act2=%s" % (op.taps, op.act1, op.scale is not None, "(first)" if op.affine_first else "", op.act2)
+                ins = "%r%s" % (op.inp, ("+%r" % op.inp2) if op.inp2 is not None else "")
+                for n in ("seg_bias", "seg_scale", "res"):
+                    if getattr(op, n) is not None:
+                        extra += " %s=%r" % (n, getattr(op, n))
+            elif op.kind == "pool":
+                ins, extra = repr(op.inp), "stddev=%s unbiased=%d var_mode=%d eps=%g" % (op.stddev, op.unbiased, op.var_mode, op.eps)
+            elif op.kind == "attpool":
+                ins, extra = "x=%r logits=%r" % (op.x, op.logits), "eps=%g" % op.eps
+            elif op.kind == "eltwise":
+                ins = " ".join("%s=%r" % (n, getattr(op, n)) for n in ("a", "b", "c", "seg_scale") if getattr(op, n) is not None)
+                extra = "affine=%s" % (op.scale is not None)
+            else:
+                ins, extra = repr(op.parts), ""
+            lines.append("  %2d %-8s %s -> %r  %s" % (i, op.kind, ins, op.out, extra))
+        return "\n".join(lines)
+
+    def flops_per_frame(self):
+        """Algorithmic 2*MAC per input frame of the frames-domain layers + per-utterance rest
+        (active taps only)."""
+        per_frame = per_utt = 0
+        for op in self.ops:
+            if op.kind != "tdnn":
+                continue
+            f = 2 * op.inp.channels * op.weight.shape[0] * len(op.taps)
+            if self.domain(op.inp.tid) == DOMAIN_FRAMES:
+                per_frame += f
+            else:
+                per_utt += f
+        return per_frame, per_utt
+
+
+# ------------------------------------------------------------------------------------------
+# symbolic tensor handed to the blueprint's extract_embedding body
+
+class Sym(object):
+    def __init__(self, graph, view, rank=3):
+        self.graph, self.view, self.rank = graph, view, rank
+
+    # -- what blueprint code inspects
+    @property
+    def domain(self):
+        return self.graph.domain(self.view.tid)
+
+    @property
+    def shape(self):
+        if self.rank == 2:
+            return (1, self.view.channels)
+        return (1, self.view.channels, 1 if self.domain == DOMAIN_UTTS else -1)
+
+    def size(self, dim=None):
+        return self.shape if dim is None else self.shape[dim]
+
+    def dim(self):
+        return self.rank
+
+    @property
+    def device(self):
+        return "hip-symbolic"
+
+    def __len__(self):
+        return 1
+
+    # -- shape ops that are free in this layout
+    def unsqueeze(self, dim):
+        if self.rank == 2 and dim in (2, -1) and self.domain == DOMAIN_UTTS:
+            return Sym(self.graph, self.view, 3)
+        raise TraceError("unsqueeze(%r) of a rank-%d %s tensor is not supported" % (dim, self.rank, "utts" if self.domain else "frames"))
+
+    def squeeze(self, dim=None):
+        if self.rank == 3 and self.domain == DOMAIN_UTTS and dim in (None, 2, -1):
+            return Sym(self.graph, self.view, 2)
+        raise TraceError("squeeze(%r) is only supported on pooled tensors" % (dim,))
+
+    def contiguous(self):
+        return self
+
+    def float(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    # -- arithmetic
+    def __add__(self, other):
+        if not isinstance(other, Sym):
+            if isinstance(other, (int, float)) and other == 0:
+                return self
+            raise TraceError("only tensor + tensor is supported on the HIP path (got %r)" % type(other))
+        if other.view.channels != self.view.channels or other.domain != self.domain:
+            raise TraceError("add of mismatched tensors %r + %r" % (self.view, other.view))
+        return Sym(self.graph, self.graph.eltwise(self.view, b=other.view), max(self.rank, other.rank))
+
+    __radd__ = __add__
+
+    def chunk(self, chunks, dim=1):
+        return sym_chunk(self, chunks, dim)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        handler = _torch_handlers().get(func)
+        if handler is None:
+            raise TraceError("torch function %s is not implemented by the MI355X extract path "
+                             "(supported: cat, chunk, add, conv1d(kernel=1), batch_norm(eval), unsqueeze, squeeze)"
+                             % getattr(func, "__name__", func))
+        return handler(*args, **(kwargs or {}))
+
+
+def sym_chunk(x, chunks, dim=1):
+    if dim != 1:
+        raise TraceError("chunk along dim %r: only the channel dim (1) is supported" % (dim,))
+    C = x.view.channels
+    size = (C + chunks - 1) // chunks
+    out, off = [], 0
+    while off < C:
+        n = min(size, C - off)
+        if (x.view.ch_off + off) % CHAN_ALIGN != 0:
+            raise TraceError("channel chunk at offset %d is not %d-aligned" % (off, CHAN_ALIGN))
+        out.append(Sym(x.graph, View(x.view.tid, x.view.ch_off + off, n), x.rank))
+        off += n
+    return tuple(out)
+
+
+def sym_cat(tensors, dim=0, **kw):
+    tensors = list(tensors)
+    if dim != 1 or not all(isinstance(t, Sym) for t in tensors):
+        raise TraceError("cat: only channel-dim (1) concatenation of traced tensors is supported")
+    g = tensors[0].graph
+    return Sym(g, g.cat([t.view for t in tensors]), tensors[0].rank)
+
+
+def fold_batchnorm(running_mean, running_var, weight, bias, eps):
+    """eval BatchNorm -> per-channel (scale, shift), folded in float64."""
+    rm = np.asarray(running_mean, dtype=np.float64)
+    rv = np.asarray(running_var, dtype=np.float64)
+    scale = 1.0 / np.sqrt(rv + float(eps))
+    if weight is not None:
+        scale = scale * np.asarray(weight, dtype=np.float64)
+    shift = -rm * scale
+    if bias is not None:
+        shift = shift + np.asarray(bias, dtype=np.float64)
+    return scale.astype(np.float32), shift.astype(np.float32)
+
+
+def _np(t):
+    return None if t is None else t.detach().cpu().numpy()
+
+
+def sym_batch_norm(x, running_mean, running_var, weight=None, bias=None, training=False, momentum=0.1, eps=1e-5):
+    if training or running_mean is None:
+        raise TraceError("batch_norm in training mode / without running stats cannot be traced")
+    scale, shift = fold_batchnorm(_np(running_mean), _np(running_var), _np(weight), _np(bias), eps)
+    return Sym(x.graph, x.graph.eltwise(x.view, scale=scale, shift=shift), x.rank)
+
+
+def sym_conv1d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
+    one = lambda v: v[0] if isinstance(v, (tuple, list)) else v
+    if weight.shape[2] != 1 or one(stride) != 1 or one(padding) != 0 or groups != 1:
+        raise TraceError("raw conv1d: only kernel_size=1, stride=1, padding=0, groups=1 is supported; "
+                         "use libs.nnet.TdnnAffine for context")
+    return Sym(x.graph, x.graph.tdnn(x.view, _np(weight), _np(bias), [0], 0), 3)
+
+
+_HANDLERS = None
+
+
+def _torch_handlers():
+    global _HANDLERS
+    if _HANDLERS is None:
+        import torch
+        import torch.nn.functional as F
+        _HANDLERS = {
+            torch.cat: sym_cat, torch.concat: sym_cat, torch.concatenate: sym_cat,
+            torch.chunk: sym_chunk, torch.Tensor.chunk: sym_chunk,
+            torch.add: lambda a, b, **k: a + b, torch.Tensor.add: lambda a, b, **k: a + b,
+            F.batch_norm: sym_batch_norm, torch.batch_norm: sym_batch_norm,
+            F.conv1d: sym_conv1d, torch.conv1d: sym_conv1d,
+            torch.unsqueeze: lambda x, dim: x.unsqueeze(dim), torch.squeeze: lambda x, dim=None: x.squeeze(dim),
+        }
+    return _HANDLERS
+
+
+# ------------------------------------------------------------------------------------------
+# handlers for modules that model blueprints define themselves (recognised by class name,
+# semantics per /root/reference/pytorch/model/ecapa_tdnn_xvector.py)
+
+def _handle_se_connect(mod, x):
+    """SE_Connect (ecapa_tdnn_xvector.py:97-111): AdaptiveAvgPool1d(1) -> Conv1d -> ReLU ->
+    Conv1d -> Sigmoid -> channel scale."""
+    import torch
+    seq = mod.se
+    convs = [m for m in seq if isinstance(m, torch.nn.Conv1d)]
+    if len(convs) != 2 or any(c.kernel_size != (1,) for c in convs):
+        raise TraceError("SE_Connect with an unexpected layout: %r" % (seq,))
+    g = x.graph
+    m = g.pool(x.view, stddev=False)
+    h = g.tdnn(m, _np(convs[0].weight), _np(convs[0].bias), [0], 0, act1="relu")
+    s = g.tdnn(h, _np(convs[1].weight), _np(convs[1].bias), [0], 0, act1="sigmoid")
+    return Sym(g, g.eltwise(x.view, seg_scale=s), 3)
+
+
+def _handle_attentive_stats_pool(mod, x):
+    """AttentiveStatsPool (ecapa_tdnn_xvector.py:156-188).  The 3C->bottleneck conv over
+    [x ; mean ; std] is split: the x part runs per frame, the (mean, std) part is constant
+    over an utterance and is hoisted into a per-utterance bias."""
+    import torch
+    att = mod.attention
+    conv1, bn, conv2 = att[0], att[2], att[4]
+    if not (isinstance(conv1, torch.nn.Conv1d) and isinstance(bn, torch.nn.BatchNorm1d) and isinstance(conv2, torch.nn.Conv1d)
+            and isinstance(att[1], torch.nn.ReLU) and isinstance(att[3], torch.nn.Tanh) and isinstance(att[5], torch.nn.Softmax)):
+        raise TraceError("AttentiveStatsPool with an unexpected attention stack: %r" % (att,))
+    g = x.graph
+    C = x.view.channels
+    w1, b1 = _np(conv1.weight), _np(conv1.bias)
+    scale, shift = fold_batchnorm(_np(bn.running_mean), _np(bn.running_var), _np(bn.weight) if bn.affine else None,
+                                  _np(bn.bias) if bn.affine else None, bn.eps)
+    if mod.time_attention:
+        assert w1.shape[1] == 3 * C
+        gstats = g.pool(x.view, stddev=True, unbiased=2, var_mode=1, eps=1e-5)     # torch.var (unbiased) + 1e-5, 176-178
+        ctx = g.tdnn(gstats, w1[:, C:, :], b1, [0], 0)                              # W_mean.mean + W_std.std + b
+        h = g.tdnn(x.view, w1[:, :C, :], None, [0], 0, seg_bias=ctx, act1="relu", scale=scale, shift=shift, act2="tanh")
+    else:
+        h = g.tdnn(x.view, w1, b1, [0], 0, act1="relu", scale=scale, shift=shift, act2="tanh")
+    e = g.tdnn(h, _np(conv2.weight), _np(conv2.bias), [0], 0)
+    return Sym(g, g.attpool(x.view, e, eps=1e-5), 2)
+
+
+MODULE_HANDLERS = {
+    "SE_Connect": _handle_se_connect,
+    "AttentiveStatsPool": _handle_attentive_stats_pool,
+}
+
+
+def trace(model, function, feat_dim):
+    """Runs `function(model, sym_input)` (the blueprint's undecorated extract_embedding) and
+    returns the optimised Graph."""
+    import types
+    g = Graph(feat_dim)
+    patched = []
+    for mod in model.modules():
+        h = MODULE_HANDLERS.get(type(mod).__name__)
+        if h is not None and not getattr(type(mod), "_asv_amd_native", False):
+            patched.append((mod, mod.__dict__.get("forward", None)))
+            mod.forward = types.MethodType(lambda self, x, _h=h: _h(self, x), mod)
+    try:
+        out = function(model, Sym(g, g.full_view(0), 3))
+    finally:
+        for mod, old in patched:
+            if old is None:
+                del mod.forward
+            else:
+                mod.forward = old
+    if not isinstance(out, Sym) or out.domain != DOMAIN_UTTS:
+        raise TraceError("extract_embedding must return a pooled (utterance-level) tensor produced by libs.nnet layers")
+    g.output = out.view
+    return g.optimize()

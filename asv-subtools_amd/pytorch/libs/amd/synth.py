@@ -1,0 +1,97 @@
+# -*- coding:utf-8 -*-
+"""Deterministic synthetic weights and feature matrices.
+
+There are no trained checkpoints and no datasets on the build or GPU machines, so every
+parity test, golden fixture and bench run uses the recipe below.
+It depends on numpy's legacy MT19937 `RandomState` only, so the same seed gives the same
+bytes on every machine - that is what lets the 24 MB x-vector state_dict stay out of the
+repo while the golden *embeddings* (a few hundred KB) are committed.
+
+The recipe is keyed on the state_dict key names of the reference blueprints
+(/root/reference/pytorch/model/xvector.py:28-35, ecapa_tdnn_xvector.py:263-339,
+libs/nnet/resnet.py:212-371) so the reference model and this package load identical
+parameters.
+"""
+
+import zlib
+
+import numpy as np
+
+
+def _rng(key, seed):
+    return np.random.RandomState((zlib.crc32(key.encode("utf-8")) ^ (seed * 2654435761)) & 0x7FFFFFFF)
+
+
+def synth_tensor(key, shape, seed=0):
+    """One state_dict entry. Batch-norm statistics are deliberately non-trivial
+    (default running_mean=0 / running_var=1 would hide BN bugs)."""
+    shape = tuple(int(s) for s in shape)
+    r = _rng(key, seed)
+    leaf = key.rsplit(".", 1)[-1]
+    if leaf == "num_batches_tracked":
+        return np.zeros(shape, dtype=np.int64)
+    if leaf == "running_mean":
+        return (0.5 * r.standard_normal(shape)).astype(np.float32)
+    if leaf == "running_var":
+        return r.uniform(0.5, 2.0, shape).astype(np.float32)
+    if leaf == "weight" and len(shape) == 1:           # BN gamma
+        return r.uniform(0.5, 1.5, shape).astype(np.float32)
+    if leaf == "bias":
+        return (0.2 * r.standard_normal(shape)).astype(np.float32)
+    if len(shape) >= 2:                                # conv / linear weight
+        fan_in = shape[1]
+        for k in shape[2:]:
+            fan_in *= min(int(k), 3)                   # at most 3 active taps per axis
+        std = (2.0 / max(fan_in, 1)) ** 0.5
+        return (std * r.standard_normal(shape)).astype(np.float32)
+    return r.standard_normal(shape).astype(np.float32)
+
+
+def synth_state_dict(shapes, seed=0):
+    """shapes: {key: shape}. Returns {key: np.ndarray} in the same order."""
+    return {k: synth_tensor(k, s, seed) for k, s in shapes.items()}
+
+
+def synth_feats(num_frames, feat_dim, seed):
+    """A CMN-like Kaldi feature matrix [T, D] float32."""
+    return np.random.RandomState(int(seed)).randn(int(num_frames), int(feat_dim)).astype(np.float32)
+
+
+def synth_lengths(n, lo, hi, seed):
+    """Utterance lengths ~ randint(lo, hi] (config C4/C5 stand-ins)."""
+    return np.random.RandomState(int(seed)).randint(int(lo), int(hi) + 1, size=int(n)).astype(np.int64)
+
+
+def synth_speaker_embeddings(n_spk, per_spk, dim, seed, within=1.0, between=1.0):
+    """Planted-speaker embedding set for scoring tests: x = between*m_spk + within*e."""
+    r = np.random.RandomState(int(seed))
+    means = between * r.standard_normal((n_spk, dim))
+    x = means[:, None, :] + within * r.standard_normal((n_spk, per_spk, dim))
+    labels = np.repeat(np.arange(n_spk), per_spk)
+    return x.reshape(n_spk * per_spk, dim).astype(np.float32), labels
+
+
+def synth_trials(labels, n_trials, seed, target_frac=0.5):
+    """Random (enroll_idx, test_idx, is_target) trial list over a labelled set."""
+    r = np.random.RandomState(int(seed))
+    labels = np.asarray(labels)
+    n = len(labels)
+    by_spk = {}
+    for i, l in enumerate(labels):
+        by_spk.setdefault(int(l), []).append(i)
+    enroll = np.empty(n_trials, dtype=np.int64)
+    test = np.empty(n_trials, dtype=np.int64)
+    tgt = np.empty(n_trials, dtype=np.int64)
+    for t in range(n_trials):
+        a = r.randint(n)
+        if r.rand() < target_frac:
+            peers = by_spk[int(labels[a])]
+            b = peers[r.randint(len(peers))]
+            if b == a:
+                b = peers[(peers.index(a) + 1) % len(peers)]
+        else:
+            b = r.randint(n)
+            while labels[b] == labels[a]:
+                b = r.randint(n)
+        enroll[t], test[t], tgt[t] = a, b, int(labels[a] == labels[b])
+    return enroll, test, tgt

@@ -1,0 +1,400 @@
+# -*- coding:utf-8 -*-
+"""Kaldi table I/O (ark / scp / pipes / gzip) for the extraction and scoring path.
+
+Wire-format contract = what the reference reads and writes through its vendored kaldi-io
+(/root/reference/pytorch/libs/support/kaldi_io.py): the `open_or_fd` rspecifier rules
+(43-73), `read_key` (148-163), float vectors (329-399) and float / compressed matrices
+(449-608).  This is an independent implementation with the same function names and
+argument meaning, plus bulk helpers (`read_mat_ark_batched`) that the per-utterance loop of
+the reference does not have.
+
+Binary layouts (little endian):
+    vector : key SP \\0 B  'FV '|'DV '  \\4 <int32 dim>            <dim   x f32|f64>
+    matrix : key SP \\0 B  'FM '|'DM '  \\4 <int32 rows> \\4 <int32 cols>  <rows*cols x f32|f64> (row major)
+    matrix : key SP \\0 B  'CM '  <f32 min><f32 range><int32 rows><int32 cols>
+                            cols x 4 x uint16 percentiles, then cols*rows uint8 column-major
+"""
+
+import gzip
+import io
+import os
+import re
+import struct
+import subprocess
+import sys
+import threading
+
+import numpy as np
+
+
+class UnsupportedDataType(Exception):
+    pass
+
+
+class UnknownVectorHeader(Exception):
+    pass
+
+
+class UnknownMatrixHeader(Exception):
+    pass
+
+
+class BadSampleSize(Exception):
+    pass
+
+
+class BadInputFormat(Exception):
+    pass
+
+
+class SubprocessFailed(Exception):
+    pass
+
+
+_SPECIFIER = re.compile(r"^(ark|scp)(,scp|,b|,t|,n?f|,n?p|,b?o|,n?s|,n?cs)*:")
+_OFFSET = re.compile(r":[0-9]+$")
+
+
+def _split_specifier(name):
+    """'ark,t:foo.ark:123' -> ('ark', 'foo.ark', 123)."""
+    prefix = None
+    if _SPECIFIER.search(name):
+        prefix, name = name.split(":", 1)
+        prefix = prefix.split(",")[0]
+    offset = None
+    if _OFFSET.search(name):
+        name, off = name.rsplit(":", 1)
+        offset = int(off)
+    return prefix, name, offset
+
+
+def popen(cmd, mode="rb"):
+    """Shell pipe as a file object; a watcher thread raises SubprocessFailed on a non-zero exit."""
+    if not isinstance(cmd, str):
+        raise TypeError("invalid cmd type (%s, expected string)" % type(cmd))
+    if mode not in ("r", "w", "rb", "wb"):
+        raise ValueError("invalid mode %s" % mode)
+    reading = mode[0] == "r"
+    proc = subprocess.Popen(cmd, shell=True, stderr=sys.stderr,
+                            stdout=subprocess.PIPE if reading else None,
+                            stdin=None if reading else subprocess.PIPE)
+
+    def _watch():
+        ret = proc.wait()
+        if ret > 0:
+            raise SubprocessFailed("cmd %s returned %d !" % (cmd, ret))
+
+    threading.Thread(target=_watch, daemon=True).start()
+    stream = proc.stdout if reading else proc.stdin
+    return io.TextIOWrapper(stream) if "b" not in mode else stream
+
+
+def open_or_fd(file, mode="rb"):
+    """Opens a file / gzip / 'cmd |' / '| cmd' pipe, or passes an open descriptor through.
+    A trailing ':offset' seeks; a leading 'ark:' / 'scp:' specifier is stripped."""
+    if not isinstance(file, str):
+        return file
+    _, name, offset = _split_specifier(file)
+    if name.endswith("|"):
+        fd = popen(name[:-1], "rb")
+    elif name.startswith("|"):
+        fd = popen(name[1:], "wb")
+    elif name.rsplit(".", 1)[-1] == "gz":
+        fd = gzip.open(name, mode)
+    else:
+        fd = open(name, mode)
+    if offset is not None:
+        fd.seek(offset)
+    return fd
+
+
+def open_with_prefix(file, mode="rb"):
+    """Like open_or_fd but insists on an explicit 'ark:' / 'scp:' prefix and returns it."""
+    if not isinstance(file, str):
+        raise TypeError("{} is not a file.".format(file))
+    prefix, _, _ = _split_specifier(file)
+    if prefix not in ("ark", "scp"):
+        raise TypeError("Specifier of {} is None, please specify this with scp or ark.".format(file))
+    return prefix, open_or_fd(file, mode)
+
+
+def _read_exact(fd, n):
+    buf = fd.read(n)
+    if len(buf) != n:
+        raise BadInputFormat("unexpected end of stream (wanted %d bytes, got %d)" % (n, len(buf)))
+    return buf
+
+
+def read_key(fd):
+    """Next utterance key of an ark stream, or None at end of file."""
+    assert "b" in getattr(fd, "mode", "rb"), "Error: 'fd' was opened in text mode (in python3 use sys.stdin.buffer)"
+    chars = []
+    while True:
+        ch = fd.read(1)
+        if ch == b"" or ch == b" ":
+            break
+        chars.append(ch)
+    key = b"".join(chars).decode("latin1").strip()
+    if key == "":
+        return None
+    assert re.match(r"^\S+$", key) is not None
+    return key
+
+
+# ------------------------------------------------------------------------------- vectors
+
+def _read_vec_flt_binary(fd):
+    header = _read_exact(fd, 3).decode()
+    if header == "FV ":
+        dtype, size = np.float32, 4
+    elif header == "DV ":
+        dtype, size = np.float64, 8
+    else:
+        raise UnknownVectorHeader("The header contained '%s'" % header)
+    assert _read_exact(fd, 1) == b"\4"
+    dim = struct.unpack("<i", _read_exact(fd, 4))[0]
+    if dim == 0:
+        return np.array([], dtype="float32")
+    return np.frombuffer(_read_exact(fd, dim * size), dtype=dtype)
+
+
+def read_vec_flt(file_or_fd):
+    """One float vector, binary or text ('[ 1 2 3 ]')."""
+    fd = open_or_fd(file_or_fd)
+    try:
+        flag = fd.read(2)
+        if flag == b"\0B":
+            return _read_vec_flt_binary(fd)
+        toks = (flag + fd.readline()).decode().strip().split()
+        toks = [t for t in toks if t not in ("[", "]")]
+        return np.array(toks, dtype=float)
+    finally:
+        if fd is not file_or_fd:
+            fd.close()
+
+
+def read_vec_flt_ark(file_or_fd):
+    fd = open_or_fd(file_or_fd)
+    try:
+        key = read_key(fd)
+        while key:
+            yield key, read_vec_flt(fd)
+            key = read_key(fd)
+    finally:
+        if fd is not file_or_fd:
+            fd.close()
+
+
+def read_vec_flt_scp(file_or_fd):
+    fd = open_or_fd(file_or_fd)
+    try:
+        for line in fd:
+            key, rxfile = line.decode().strip().split(" ", 1)
+            yield key, read_vec_flt(rxfile)
+    finally:
+        if fd is not file_or_fd:
+            fd.close()
+
+
+def read_vec_flt_auto(file):
+    """'scp:foo.scp' or 'ark:foo.ark' (the reference's 2020-05-31 addition, kaldi_io.py:273-287)."""
+    prefix, fd = open_with_prefix(file)
+    reader = read_vec_flt_scp if prefix == "scp" else read_vec_flt_ark
+    for key, vec in reader(fd):
+        yield key, vec
+
+
+read_vec = read_vec_flt_auto     # score/pyplda calls kaldi_io.read_vec (shim 5)
+
+
+def write_vec_flt(file_or_fd, v, key=""):
+    """Binary float vector (32 or 64 bit); with `key` it is one ark entry."""
+    assert isinstance(v, np.ndarray)
+    fd = open_or_fd(file_or_fd, mode="wb")
+    try:
+        if v.dtype == np.float32:
+            tag = b"FV "
+        elif v.dtype == np.float64:
+            tag = b"DV "
+        else:
+            raise UnsupportedDataType("'%s', please use 'float32' or 'float64'" % v.dtype)
+        head = (key + " ").encode("latin1") if key != "" else b""
+        fd.write(head + b"\0B" + tag + b"\4" + struct.pack("<I", v.shape[0]) + v.tobytes())
+    finally:
+        if fd is not file_or_fd:
+            fd.close()
+
+
+def read_vec_int(file_or_fd):
+    """One int32 vector (binary: '\\0B' \\4 dim then (\\4 int32)*dim; or text)."""
+    fd = open_or_fd(file_or_fd)
+    try:
+        flag = fd.read(2)
+        if flag == b"\0B":
+            assert _read_exact(fd, 1) == b"\4"
+            dim = struct.unpack("<i", _read_exact(fd, 4))[0]
+            if dim == 0:
+                return np.array([], dtype="int32")
+            rec = np.frombuffer(_read_exact(fd, dim * 5), dtype=[("size", "int8"), ("value", "int32")], count=dim)
+            assert rec[0]["size"] == 4
+            return rec[:]["value"]
+        toks = (flag + fd.readline()).decode().strip().split()
+        toks = [t for t in toks if t not in ("[", "]")]
+        return np.array(toks, dtype=int)
+    finally:
+        if fd is not file_or_fd:
+            fd.close()
+
+
+# ------------------------------------------------------------------------------ matrices
+
+def _read_compressed_mat(fd, fmt, chunk=None):
+    """Kaldi CompressedMatrix 'CM ' (per-column 4-point piecewise-linear uint8 quantiser)."""
+    assert fmt == "CM ", "The formats CM2, CM3 are not supported..."
+    gmin, grange, rows, cols = struct.unpack("<ffii", _read_exact(fd, 16))
+    pct = np.frombuffer(_read_exact(fd, cols * 8), dtype=np.uint16).reshape(cols, 4).astype(np.float32)
+    pct = pct * np.float32(grange) * np.float32(1.52590218966964e-05) + np.float32(gmin)
+    data = np.frombuffer(_read_exact(fd, cols * rows), dtype=np.uint8).reshape(cols, rows).astype(np.float32)
+    p0, p25, p75, p100 = (pct[:, i:i + 1] for i in range(4))
+    lo = p0 + (p25 - p0) / np.float32(64.0) * data
+    mid = p25 + (p75 - p25) / np.float32(128.0) * (data - 64)
+    hi = p75 + (p100 - p75) / np.float32(63.0) * (data - 192)
+    mat = np.where(data <= 64, lo, np.where(data > 192, hi, mid)).astype(np.float32).T
+    if chunk is not None:
+        mat = mat[int(chunk[0]):int(chunk[1]) + 1]
+    return mat
+
+
+def _read_mat_binary(fd, chunk=None):
+    header = _read_exact(fd, 3).decode()
+    if header.startswith("CM"):
+        return _read_compressed_mat(fd, header, chunk=chunk)
+    if header == "FM ":
+        dtype, size = np.float32, 4
+    elif header == "DM ":
+        dtype, size = np.float64, 8
+    else:
+        raise UnknownMatrixHeader("The header contained '%s'" % header)
+    s1, rows, s2, cols = struct.unpack("<bibi", _read_exact(fd, 10))
+    first, last = 0, rows - 1
+    if chunk is not None:
+        first, last = int(chunk[0]), int(chunk[1])
+    if first > 0:
+        if hasattr(fd, "seekable") and fd.seekable():
+            fd.seek(first * cols * size, 1)
+        else:
+            _read_exact(fd, first * cols * size)
+    n = last - first + 1
+    buf = _read_exact(fd, n * cols * size)
+    return np.frombuffer(buf, dtype=dtype).reshape(n, cols)
+
+
+def _read_mat_ascii(fd, chunk=None):
+    rows, count = [], 0
+    first, last = (int(chunk[0]), int(chunk[1])) if chunk is not None else (0, -1)
+    while True:
+        line = fd.readline().decode()
+        if len(line) == 0:
+            raise BadInputFormat("end of stream inside a text matrix")
+        toks = line.strip().split()
+        if not toks:
+            continue
+        closing = toks[-1] == "]"
+        if closing:
+            toks = toks[:-1]
+        if toks and count >= first and (last < 0 or count <= last):
+            rows.append(np.array(toks, dtype="float32"))
+        count += 1 if toks else 0
+        if closing or (last >= 0 and count > last):
+            return np.vstack(rows)
+
+
+def read_mat(file_or_fd, chunk=None):
+    """One float matrix [rows, cols]; `chunk=[first, last]` reads a row range (reference
+    extension used by the egs readers)."""
+    fd = open_or_fd(file_or_fd)
+    try:
+        flag = _read_exact(fd, 2)
+        if flag == b"\0B":
+            return _read_mat_binary(fd, chunk=chunk)
+        assert flag == b" [", flag
+        return _read_mat_ascii(fd, chunk=chunk)
+    finally:
+        if fd is not file_or_fd:
+            fd.close()
+
+
+def read_mat_ark(file_or_fd):
+    fd = open_or_fd(file_or_fd)
+    try:
+        key = read_key(fd)
+        while key:
+            yield key, read_mat(fd)
+            key = read_key(fd)
+    finally:
+        if fd is not file_or_fd:
+            fd.close()
+
+
+def read_mat_scp(file_or_fd):
+    fd = open_or_fd(file_or_fd)
+    try:
+        for line in fd:
+            key, rxfile = line.decode().strip().split(" ", 1)
+            yield key, read_mat(rxfile)
+    finally:
+        if fd is not file_or_fd:
+            fd.close()
+
+
+def read_mat_ark_batched(file_or_fd, max_frames=65536, max_utts=1024):
+    """Bulk reader for the batched extractor: yields (keys, feats [sum T, D] float32,
+    offsets int32 [n+1]) groups of at most `max_frames` frames / `max_utts` utterances -
+    the packed ragged layout asv_net_extract() consumes (include/asv_amd.h)."""
+    keys, mats, frames = [], [], 0
+    for key, mat in read_mat_ark(file_or_fd):
+        if mats and (frames + mat.shape[0] > max_frames or len(mats) >= max_utts):
+            yield _pack_group(keys, mats)
+            keys, mats, frames = [], [], 0
+        keys.append(key)
+        mats.append(mat)
+        frames += mat.shape[0]
+    if mats:
+        yield _pack_group(keys, mats)
+
+
+def _pack_group(keys, mats):
+    offsets = np.zeros(len(mats) + 1, dtype=np.int32)
+    np.cumsum([m.shape[0] for m in mats], out=offsets[1:])
+    feats = np.ascontiguousarray(np.concatenate(mats, axis=0), dtype=np.float32)
+    return keys, feats, offsets
+
+
+def write_mat(file_or_fd, m, key=""):
+    assert isinstance(m, np.ndarray)
+    assert len(m.shape) == 2, "'m' has to be 2d matrix!"
+    fd = open_or_fd(file_or_fd, mode="wb")
+    try:
+        if m.dtype == np.float32:
+            tag = b"FM "
+        elif m.dtype == np.float64:
+            tag = b"DM "
+        else:
+            raise UnsupportedDataType("'%s', please use 'float32' or 'float64'" % m.dtype)
+        head = (key + " ").encode("latin1") if key != "" else b""
+        fd.write(head + b"\0B" + tag + b"\4" + struct.pack("<I", m.shape[0]) + b"\4" + struct.pack("<I", m.shape[1]))
+        fd.write(np.ascontiguousarray(m).tobytes())
+    finally:
+        if fd is not file_or_fd:
+            fd.close()
+
+
+def write_vec_flt_ark_scp(ark_path, scp_path, items):
+    """Writes (key, vector) pairs to `ark_path` and the matching 'key path:offset' lines to
+    `scp_path` - what `copy-vector ark:- ark,scp:...` does in
+    pipeline/extract_xvectors_for_pytorch.sh:120."""
+    with open(ark_path, "wb") as ark, open(scp_path, "w") as scp:
+        for key, vec in items:
+            ark.write((key + " ").encode("latin1"))
+            scp.write("%s %s:%d\n" % (key, os.path.abspath(ark_path), ark.tell()))
+            write_vec_flt(ark, np.ascontiguousarray(vec), key="")

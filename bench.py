@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""Benchmark of the extraction hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic input that is already
+resident in HBM: BASELINE.json configs[1] - standard TDNN x-vector, 80-dim fbank,
+256 utterances x 200 frames per GPU, bf16 MFMA (f32 accumulate, f32 pooled tail).
+Weak scaling: every rank extracts its own 256-utterance shard; with N > 1 the embeddings are
+collected with one RCCL all-gather per step (the path's only exchange).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant
+kernel, hipEvent-timed inside libasv_amd.so on the extract stream, during the timed steps)
+and `cpu_baseline` (torch-CPU port of the reference's per-utterance path, N=1 only).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.join(REPO, "asv-subtools_amd", "pytorch"), REPO]
+
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # dense MFMA peaks, MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--batch", type=int, default=256, help="utterances per GPU per step")
+    ap.add_argument("--frames", type=int, default=200)
+    ap.add_argument("--feat-dim", type=int, default=80)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel hipEvents in the timed region")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import libs.support.utils as utils
+    from libs.amd import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world)
+    assert torch.cuda.is_available(), "bench.py needs a ROCm device"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+
+    # ---- model: the reference's standard x-vector blueprint, synthetic weights ---------------
+    creation = "Xvector(%d,10,training=False)" % args.feat_dim
+    model = utils.create_model_from_py(os.path.join(REPO, "asv-subtools_amd", "pytorch", "model", "xvector.py"), creation)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synth.synth_state_dict(shapes, 0)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model.eval()
+    model.cuda()
+    model.amd_precision = args.precision
+    eng = model._amd_engine()
+
+    # ---- synthetic batch, device resident ----------------------------------------------------
+    B, T, D = args.batch, args.frames, args.feat_dim
+    mats = [synth.synth_feats(T, D, 10_000 * rank + i) for i in range(B)]
+    feats = torch.from_numpy(np.concatenate(mats, axis=0)).to(dev)
+    offsets = (np.arange(B + 1) * T).astype(np.int32)
+    out = torch.empty((B, eng.embed_dim), dtype=torch.float32, device=dev)
+    gathered = torch.empty((world * B, eng.embed_dim), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step():
+        eng.extract_device(feats, offsets, out=out)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, out)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    def timed(n):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+
+    profile = not args.no_profile
+    if profile:
+        eng.set_profiling(True)
+        step(); torch.cuda.synchronize(dev); eng.get_profile()       # create the event pool outside the timed region
+    dt = timed(args.steps)
+    rows = eng.get_profile() if profile else []
+    eng.set_profiling(False)
+    dt_plain = timed(args.steps)                                      # same steps without event recording, for reference
+
+    utts = world * B * args.steps
+    value = utts / dt
+    res = {
+        "metric": "utterances/sec (200-frame) embedding extraction + EER, 1/2/4/8 MI355X",
+        "value": round(value, 1), "unit": "utterances/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: standard TDNN x-vector %s, %d-dim fbank, %d utterances x %d frames per GPU per step, "
+                               "features resident in HBM, f32 embeddings out%s" % (creation, D, B, T, ", + RCCL all-gather of embeddings" if world > 1 else ""),
+                   "global_batch_utts": world * B, "frames_per_utt": T, "parallelism": "utterance shards x%d" % world},
+        "value_without_event_recording": round(utts / dt_plain, 1),
+    }
+    gemm = next((r for r in rows if r["name"] == "tdnn_gemm"), None)
+    if gemm and gemm["total_ms"] > 0:
+        achieved = gemm["flops"] / (gemm["total_ms"] * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[args.precision]
+        per_frame, per_utt = eng.graph.flops_per_frame()
+        res["roofline"] = {"bound": "mfma", "kernel": "tdnn_gemm_kernel (all TDNN/affine layers)", "achieved": round(achieved, 2), "peak": peak,
+                           "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                           "launches": gemm["launches"], "avg_launch_us": round(1e3 * gemm["total_ms"] / gemm["launches"], 2),
+                           "algorithmic_gflop_per_utt": round((per_frame * T + per_utt) / 1e9, 4)}
+        res["kernel_ms_per_step"] = {r["name"]: round(r["total_ms"] / args.steps, 4) for r in rows}
+
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        from oracle import torch_cpu_port as P                        # cpu_baseline leg only
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        ups, n, secs = P.time_cpu_baseline(P.XvectorCpu(sd, "far"), mats[:64], budget_s=args.cpu_seconds)
+        res["cpu_baseline"] = {"value": round(ups, 2), "unit": "utterances/s", "cores": cores, "kind": "port",
+                               "sample": "%d utterances of the same %dx%d workload, batch=1 loop as pipeline/onestep/extract_embeddings.py:73-83, "
+                                         "torch %s CPU, %.1f s" % (n, T, D, torch.__version__, secs)}
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,226 @@
+/*
+ * asv_amd.h - C ABI of libasv_amd.so, the MI355X (gfx950) embedding-extraction and scoring
+ * engine that sits behind asv-subtools' TopVirtualNnet.extract_embedding() boundary.
+ *
+ * Plain C: pointers, sizes and ints only; no torch / HIP types in any signature (a HIP
+ * stream is passed as `void*`, NULL = the default stream).  Every function returns 0 on
+ * success or a negative errno-style code; asv_last_error() returns the thread-local text.
+ * Nothing throws across this boundary.  One asv_net_t belongs to one device; the caller
+ * owns every buffer it passes in.  Pointers documented "device" must be device-accessible
+ * on the current HIP device; "host" pointers are read during the call only.
+ *
+ * Reference interfaces replaced (paths relative to /root/reference/pytorch):
+ *   asv_net_*  builder  <- the nn.Module graph a model blueprint builds in `init()`
+ *                          (model/xvector.py:18-40, model/ecapa_tdnn_xvector.py:201-357),
+ *                          one call per layer object instead of one torch module.
+ *   asv_net_extract     <- `for_extract_embedding` + `<Model>.extract_embedding`
+ *                          (libs/nnet/framework.py:12-55, model/xvector.py:77-98), batched over
+ *                          utterances instead of batch=1 (pipeline/onestep/extract_embeddings.py:73-83).
+ *   asv_tdnn_forward    <- TdnnAffine.forward + _BaseActivationBatchNorm.forward
+ *                          (libs/nnet/components.py:107-149, 418-431) on one layer.
+ *   asv_stats_pool_forward <- StatisticsPooling.forward (libs/nnet/pooling.py:32-69).
+ *   asv_cosine_* / asv_length_norm / asv_plda_* / asv_eer: see the scoring section below.
+ *
+ * Data layout: activations are "frames x channels" row-major (the Kaldi matrix layout,
+ * libs/support/kaldi_io.py:466-496), utterances packed back to back; `offsets[n_utts+1]`
+ * gives each utterance's first row.
+ */
+#ifndef ASV_AMD_H
+#define ASV_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASV_AMD_VERSION 100            /* 0.1.0 */
+
+/* ---- error codes ------------------------------------------------------------------ */
+#define ASV_OK        0
+#define ASV_EINVAL  (-22)              /* bad argument / malformed graph               */
+#define ASV_ENOMEM  (-12)              /* host or device allocation failed             */
+#define ASV_EHIP     (-5)              /* a HIP runtime call failed (see last_error)   */
+#define ASV_ENOTSUP (-95)              /* valid request this build does not implement  */
+#define ASV_ESTATE  (-1)               /* call order violated (e.g. extract before finalize) */
+
+int         asv_version(void);
+const char *asv_last_error(void);      /* thread-local, never NULL                      */
+int         asv_device_count(int *count);
+
+/* ---- enums ------------------------------------------------------------------------ */
+/* arithmetic of the frame layers */
+#define ASV_PREC_F32   0   /* f32 activations/weights, v_mfma_f32_32x32x2_f32 (exact f32 fma chain) */
+#define ASV_PREC_BF16  1   /* bf16 activations/weights, v_mfma_f32_32x32x16_bf16, f32 accumulate   */
+/* flags for asv_net_create */
+#define ASV_FLAG_REF_KERNELS 1u  /* run the plain-VALU self-check kernels instead of MFMA ones */
+#define ASV_FLAG_NO_FUSE     2u  /* disable epilogue fusions (stats pooling into the producer)  */
+
+#define ASV_ACT_NONE    0
+#define ASV_ACT_RELU    1
+#define ASV_ACT_TANH    2
+#define ASV_ACT_SIGMOID 3
+
+#define ASV_DOMAIN_FRAMES 0  /* one row per frame, ragged over utterance segments */
+#define ASV_DOMAIN_UTTS   1  /* one row per utterance segment (after pooling); always f32 */
+
+#define ASV_MAX_TAPS 9
+
+/* ---- net builder ------------------------------------------------------------------ */
+typedef struct asv_net asv_net_t;
+
+/* Creates an empty layer program on HIP device `device`.  Buffer 0 is the input feature
+ * matrix (frames domain, `feat_dim` channels). */
+int  asv_net_create(asv_net_t **net, int device, int precision, unsigned flags, int feat_dim);
+void asv_net_destroy(asv_net_t *net);
+
+/* Declares an activation buffer; returns its id (>= 1) or a negative error. */
+int  asv_net_new_buffer(asv_net_t *net, int domain, int channels);
+
+/* One TdnnAffine [+ activation + eval-BatchNorm] layer (components.py:107-149,418-431):
+ *   z   = sum_taps W[:, :, tap] . (x[t+tap] (+ x2[t+tap]))  + bias (+ seg_bias[segment])
+ *   z   = affine_first ? act1(z*scale+shift) : act1(z)*scale+shift
+ *   y   = act2(z) (* seg_scale[segment]) (+ residual)
+ * Frames outside an utterance segment read as zero at every layer (components.py:116-117).
+ * All host arrays are copied during the call. */
+typedef struct asv_tdnn_desc {
+  uint32_t struct_size;          /* = sizeof(asv_tdnn_desc_t) */
+  int32_t in_buf, in_ch_off;     /* input view: channels [in_ch_off, in_ch_off+in_ch)        */
+  int32_t in2_buf, in2_ch_off;   /* optional second input added to the first, or in2_buf=-1  */
+  int32_t out_buf, out_ch_off;
+  int32_t in_ch, out_ch;
+  int32_t n_taps;
+  int32_t taps[ASV_MAX_TAPS];    /* frame offsets, ascending (the layer's `context`)         */
+  const float *weight;           /* host, dense [out_ch][in_ch][w_tot_context] as in the
+                                    checkpoint; tap offset o lives at index o - w_left_context */
+  int32_t w_tot_context, w_left_context;
+  const float *bias;             /* host [out_ch] or NULL                                     */
+  int32_t seg_bias_buf;          /* utts-domain buffer [segments][out_ch] added to z, or -1  */
+  int32_t act1;
+  const float *scale, *shift;    /* host [out_ch] folded eval-BN (both or neither)            */
+  int32_t affine_first;          /* 1 = the "bn-relu" order (components.py:365-386)           */
+  int32_t act2;
+  int32_t seg_scale_buf;         /* utts-domain buffer [segments][out_ch] multiplier, or -1  */
+  int32_t res_buf, res_ch_off;   /* residual view added last, or res_buf=-1                   */
+} asv_tdnn_desc_t;
+int asv_net_add_tdnn(asv_net_t *net, const asv_tdnn_desc_t *d);
+
+/* Pooling over the frames of each segment -> one utts-domain row (pooling.py:58-67,
+ * ecapa_tdnn_xvector.py:176-178).  out[0:C]=mean, out[C:2C]=std when stddev. */
+#define ASV_POOL_VAR_CLAMP 0     /* std = sqrt(max(var, eps))   (StatisticsPooling)          */
+#define ASV_POOL_VAR_ADD   1     /* std = sqrt(var + eps)       (ECAPA global context)       */
+typedef struct asv_pool_desc {
+  uint32_t struct_size;
+  int32_t in_buf, in_ch_off, channels;
+  int32_t out_buf, out_ch_off;   /* utts domain; needs channels*(1+stddev) columns            */
+  int32_t stddev, unbiased, var_mode;
+  float   eps;
+} asv_pool_desc_t;
+int asv_net_add_stats_pool(asv_net_t *net, const asv_pool_desc_t *d);
+
+/* ECAPA attentive statistics (ecapa_tdnn_xvector.py:182-188): alpha = softmax over the
+ * segment's frames of `logits`; mean = sum alpha*x; std = sqrt(max(sum alpha*x^2 - mean^2, eps)). */
+typedef struct asv_attpool_desc {
+  uint32_t struct_size;
+  int32_t x_buf, x_ch_off, logit_buf, logit_ch_off, channels;
+  int32_t out_buf, out_ch_off;
+  float   eps;
+} asv_attpool_desc_t;
+int asv_net_add_attentive_pool(asv_net_t *net, const asv_attpool_desc_t *d);
+
+/* Elementwise: out = a (* seg_scale[segment]) (+ b) (+ c); any domain; views as above. */
+typedef struct asv_eltwise_desc {
+  uint32_t struct_size;
+  int32_t channels;
+  int32_t a_buf, a_ch_off, b_buf, b_ch_off, c_buf, c_ch_off;   /* b/c: -1 = absent */
+  int32_t seg_scale_buf;                                        /* -1 = absent       */
+  int32_t out_buf, out_ch_off;
+  const float *scale, *shift;    /* optional host per-channel affine applied to `a` first    */
+} asv_eltwise_desc_t;
+int asv_net_add_eltwise(asv_net_t *net, const asv_eltwise_desc_t *d);
+
+/* Freezes the program; `out_buf` must be an utts-domain buffer: its first `embed_dim`
+ * channels are the embedding. */
+int asv_net_finalize(asv_net_t *net, int out_buf, int embed_dim);
+int asv_net_embed_dim(const asv_net_t *net);
+/* Human-readable dump of the program (for logs/tests); returns bytes written. */
+int asv_net_describe(const asv_net_t *net, char *buf, size_t cap);
+
+/* Embeds a packed batch:  feats  device  float32 [offsets[n_utts]][feat_dim] row-major,
+ *                         offsets host   int32   [n_utts+1], offsets[0]=0, non-decreasing,
+ *                         out    device  float32 [n_utts][embed_dim].
+ * Utterances longer than max_chunk frames are split and averaged exactly as
+ * framework.py:34-47 does (max_chunk <= 0: 10000).  Asynchronous on `stream`; `offsets`
+ * is consumed before return.  Zero-length utterances are rejected (the reference asserts,
+ * components.py:119). */
+int asv_net_extract(asv_net_t *net, const float *feats, const int32_t *offsets, int n_utts,
+                    float *out, int max_chunk, void *stream);
+
+/* Bytes of device memory currently held by the net (weights + activation arena). */
+size_t asv_net_device_bytes(const asv_net_t *net);
+
+/* Name + average device time (ms, hipEvent on the extract stream) of the dominant kernel
+ * class of the most recent profiled extract.  asv_net_set_profiling(1) makes extract record
+ * events around every launch (costs a few us per launch). */
+int asv_net_set_profiling(asv_net_t *net, int enable);
+typedef struct asv_kernel_time {
+  char     name[48];
+  int32_t  launches;
+  float    total_ms;
+  double   flops;                /* algorithmic 2*MAC of those launches (active taps only) */
+} asv_kernel_time_t;
+int asv_net_get_profile(asv_net_t *net, asv_kernel_time_t *rows, int cap, int *n_rows);
+
+/* ---- single-layer entry points (kernel parity tests, other callers) ----------------- */
+/* One TDNN layer on a packed ragged batch.  x device [rows][in_ch] f32, y device
+ * [rows][out_ch] f32; computed in `precision`; desc buffers/views are ignored. */
+int asv_tdnn_forward(const asv_tdnn_desc_t *d, int precision, unsigned flags,
+                     const float *x, const int32_t *offsets, int n_utts, float *y, void *stream);
+/* StatisticsPooling on a packed ragged batch: x device [rows][channels] f32 ->
+ * y device [n_utts][channels*(1+stddev)] f32. */
+int asv_stats_pool_forward(const float *x, int channels, const int32_t *offsets, int n_utts,
+                           int stddev, int unbiased, int var_mode, float eps, float *y, void *stream);
+
+/* ---- scoring back-end --------------------------------------------------------------- */
+/* In-place x <- (x - mean) if mean != NULL, then x <- x / ||x||_2 if normalize
+ * (ivector-subtract-global-mean + ivector-normalize-length --scaleup=false,
+ *  score/process.sh:181-203).  x device [n][dim] f32, mean device [dim] f32. */
+int asv_length_norm(float *x, int n, int dim, const float *mean, int normalize, void *stream);
+/* Column means of x device [n][dim] -> mean device [dim] (ivector-mean, process.sh:165,177). */
+int asv_mean_vec(const float *x, int n, int dim, float *mean, void *stream);
+/* Full cosine/dot score matrix S[i][j] = <enroll_i, test_j>; device f32, row-major
+ * (ivector-compute-dot-products over all pairs, score/score.sh:82-97). */
+int asv_dot_score_matrix(const float *enroll, int n_enroll, const float *test, int n_test, int dim,
+                         float *scores, void *stream);
+/* Trial-list scoring: scores[t] = <enroll[ei[t]], test[ti[t]]>; index arrays device int32. */
+int asv_dot_score_trials(const float *enroll, const float *test, int dim, const int32_t *ei,
+                         const int32_t *ti, int n_trials, float *scores, void *stream);
+/* Kaldi-style PLDA scoring (score/pyplda/plda_base.py:93-136, the Python restatement of
+ * Kaldi ivector/plda.cc that score/score.sh:99-121 runs through ivector-plda-scoring).
+ *   asv_plda_transform: y = T (x - mean); then, by length_norm,
+ *       0: nothing;  1: y *= sqrt(dim)/||y||  (simple_length_norm, plda_base.py:99-100);
+ *       2: y *= sqrt(dim / sum_i y_i^2/(psi_i + 1/n))   (get_normalization_factor, 165-172)
+ *     num_examples: device int32 [n] or NULL (= 1 each).
+ *   asv_plda_llr_trials: log-likelihood ratio of plda_base.py:109-136 per trial, evaluated
+ *     in float64 like the reference; enroll_n: device int32 [n_enroll rows] utterances behind
+ *     each enrolment vector, or NULL (= 1). */
+#define ASV_PLDA_NORM_NONE   0
+#define ASV_PLDA_NORM_SIMPLE 1
+#define ASV_PLDA_NORM_PSI    2
+int asv_plda_transform(const float *x, int n, int dim, const float *mean, const float *transform,
+                       const float *psi, const int32_t *num_examples, int length_norm, float *y,
+                       void *stream);
+int asv_plda_llr_trials(const float *enroll, const float *test, int dim, const float *psi,
+                        const int32_t *enroll_n, const int32_t *ei, const int32_t *ti, int n_trials,
+                        float *scores, void *stream);
+/* Equal error rate (score/computeEER-like-Bosaris.py:50-91 semantics) of device scores with
+ * device int32 labels (1 target / 0 non-target).  eer_percent / threshold are host outputs;
+ * the call synchronises `stream`. */
+int asv_eer(const float *scores, const int32_t *labels, int n, float *eer_percent, float *threshold,
+            void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASV_AMD_H */

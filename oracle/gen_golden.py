@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE implementation itself.
+
+Runs only in the build container (needs /root/reference, read-only).  It imports the
+reference's PyTorch extractor with the three import shims of SURVEY.md section 8(c), loads
+the deterministic synthetic weights of `libs/amd/synth.py` into the reference model, runs
+the reference's own `model.extract_embedding()` per utterance on CPU (exactly what
+pipeline/onestep/extract_embeddings.py:73-83 does) and stores the outputs.
+
+The fixtures hold *outputs only* (plus the case description); weights and inputs are
+regenerated from the seed recipe by the tests, so fixtures stay small.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [case ...]
+"""
+
+import os
+import sys
+import types
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def install_shims():
+    """stray imports in the reference tree."""
+    tk = types.ModuleType("tkinter"); tk.N = None; tk.__path__ = []
+    mb = types.ModuleType("tkinter.messagebox"); mb.NO = None
+    tu = types.ModuleType("turtle"); tu.xcor = None
+    sys.modules.setdefault("tkinter", tk)
+    sys.modules.setdefault("tkinter.messagebox", mb)
+    sys.modules.setdefault("turtle", tu)
+    sys.modules.setdefault("scipye", types.ModuleType("scipye"))
+
+
+def load_synth():
+    import importlib.util
+    p = os.path.join(REPO, "asv-subtools_amd", "pytorch", "libs", "amd", "synth.py")
+    spec = importlib.util.spec_from_file_location("asv_synth", p)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+# Each extractor case: blueprint file (under reference pytorch/model), creation string,
+# feature dim, list of (num_frames, seed) utterances, weight seed.
+LAUNCHER_FC2 = ("fc2_params={'nonlinearity':'','bn_params':{'momentum':0.5,'affine':False,"
+                "'track_running_stats':True}}")
+CASES = {
+    # BASELINE config C1: 100 x [200,30], "far" embedding.
+    "xvector_c1": dict(blueprint="xvector.py", creation="Xvector(30,10,training=False)", dim=30,
+                       utts=[(200, i) for i in range(100)], wseed=0),
+    # C2 model on ragged lengths incl. degenerate ones, "near" embedding.
+    "xvector_near_ragged": dict(blueprint="xvector.py",
+                                creation="Xvector(80,10,training=False,extracted_embedding='near')",
+                                dim=80, utts=[(1, 1000), (2, 1001), (5, 1002), (37, 1003), (200, 1004),
+                                              (201, 1005), (640, 1006), (1000, 1007)], wseed=1),
+    # framework.py:34-47 chunking: T > maxChunk (10000) => 2 chunks of 5000/5001; 20001 => 3.
+    "xvector_chunked": dict(blueprint="xvector.py", creation="Xvector(30,10,training=False)", dim=30,
+                            utts=[(10001, 2000), (20001, 2001)], wseed=0),
+    # C3 model, defaults (channels 1024, ecpa-attentive, "near" = fc2 incl. ReLU+BN).
+    "ecapa_c3": dict(blueprint="ecapa_tdnn_xvector.py", creation="ECAPA_TDNN(80,10,training=False)",
+                     dim=80, utts=[(300, 3000), (300, 3001), (2, 3002), (9, 3003), (123, 3004), (517, 3005)],
+                     wseed=2),
+    # launcher variant (runEcapaXvector_online.py:221-247): fc2 without ReLU, BN affine=False.
+    "ecapa_launcher": dict(blueprint="ecapa_tdnn_xvector.py",
+                           creation="ECAPA_TDNN(80,10,training=False,%s)" % LAUNCHER_FC2,
+                           dim=80, utts=[(300, 3100), (411, 3101), (64, 3102)], wseed=3),
+    # smaller ECAPA (C=512, the README's 6.5M model) with fc1 and "far"/"near_affine" positions.
+    "ecapa_c512_fc1_far": dict(blueprint="ecapa_tdnn_xvector.py",
+                               creation="ECAPA_TDNN(80,10,training=False,extracted_embedding='far',fc1=True,"
+                                        "ecapa_params={'channels':512,'embd_dim':192,'mfa_conv':1536})",
+                               dim=80, utts=[(200, 3200), (333, 3201)], wseed=4),
+    "ecapa_c512_near_affine": dict(blueprint="ecapa_tdnn_xvector.py",
+                                   creation="ECAPA_TDNN(80,10,training=False,extracted_embedding='near_affine',"
+                                            "ecapa_params={'channels':512,'embd_dim':192,'mfa_conv':1536})",
+                                   dim=80, utts=[(200, 3300), (150, 3301)], wseed=5),
+}
+
+
+def run_extractor_case(name, case, synth):
+    import numpy as np
+    import torch
+    import libs.support.utils as utils
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    model = utils.create_model_from_py(os.path.join(REF, "pytorch", "model", case["blueprint"]),
+                                       case["creation"])
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synth.synth_state_dict(shapes, case["wseed"])
+    missing = model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model.eval()
+    embs = []
+    for (T, seed) in case["utts"]:
+        x = synth.synth_feats(T, case["dim"], seed)
+        e = model.extract_embedding(x)            # the reference's own wrapper + model
+        embs.append(e.numpy().astype(np.float32))
+    out = dict(
+        embeddings=np.stack(embs),
+        utts=np.asarray(case["utts"], dtype=np.int64),
+        wseed=np.int64(case["wseed"]),
+        dim=np.int64(case["dim"]),
+        creation=np.array(case["creation"]),
+        blueprint=np.array(case["blueprint"]),
+        shape_keys=np.array(list(shapes.keys())),
+        shape_vals=np.array([",".join(str(d) for d in s) for s in shapes.values()]),
+        torch_version=np.array(torch.__version__),
+    )
+    path = os.path.join(GOLDEN, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote %s: embeddings %s, %d params" % (path, out["embeddings"].shape,
+                                                   sum(int(np.prod(s)) for s in shapes.values())))
+
+
+def main(argv):
+    if not os.path.isdir(REF):
+        sys.exit("gen_golden.py needs the reference tree at %s (build container only)" % REF)
+    install_shims()
+    sys.path.insert(0, os.path.join(REF, "pytorch"))
+    os.makedirs(GOLDEN, exist_ok=True)
+    synth = load_synth()
+    names = argv or list(CASES) + list(EXTRA_CASES)
+    for n in names:
+        if n in CASES:
+            run_extractor_case(n, CASES[n], synth)
+        elif n in EXTRA_CASES:
+            EXTRA_CASES[n](n, synth)
+        else:
+            sys.exit("unknown case %s (have: %s)" % (n, ", ".join(list(CASES) + list(EXTRA_CASES))))
+
+
+EXTRA_CASES = {}     # scoring / resnet cases register themselves below
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

@@ -1,0 +1,104 @@
+"""numpy interpreter of a libs.amd.ir.Graph (TEST INFRASTRUCTURE).
+
+Executes the recorded, optimised layer program op by op with the oracle's layer functions,
+one utterance at a time.  It checks on CPU what the GPU cannot be reached for: that the
+recorder + graph passes (concat elision, add folding, hoisted attention bias) preserve the
+reference semantics, before the same program is handed to libasv_amd.so.
+"""
+
+import numpy as np
+
+from oracle import np_oracle as O
+
+
+def _act(x, name):
+    return O._act(x, name)
+
+
+def run_graph(graph, feats, dtype=np.float32):
+    """feats [T, D] -> embedding [E] for ONE utterance segment (no chunking)."""
+    feats = np.asarray(feats, dtype=dtype)
+    T = feats.shape[0]
+    bufs = {0: feats}
+
+    def rows(tid):
+        return T if graph.domain(tid) == 0 else 1
+
+    def get(v):
+        return bufs[v.tid][:, v.ch_off:v.ch_off + v.channels]
+
+    def put(v, val):
+        if v.tid not in bufs:
+            bufs[v.tid] = np.zeros((rows(v.tid), graph.tensors[v.tid][1]), dtype=dtype)
+        bufs[v.tid][:, v.ch_off:v.ch_off + v.channels] = val
+
+    for op in graph.ops:
+        if op.kind == "tdnn":
+            x = get(op.inp)
+            if op.inp2 is not None:
+                x = x + get(op.inp2)
+            z = O.tdnn_affine(x, op.weight.astype(dtype), None if op.bias is None else op.bias.astype(dtype), op.taps) \
+                if op.weight.shape[2] == len(range(min(op.taps + [0]), max(op.taps + [0]) + 1)) and op.w_left == min(op.taps + [0]) \
+                else _tdnn_general(x, op, dtype)
+            if op.seg_bias is not None:
+                z = z + get(op.seg_bias)
+            s = 1 if op.scale is None else op.scale.astype(dtype)
+            t = 0 if op.shift is None else op.shift.astype(dtype)
+            z = _act(z * s + t, op.act1) if op.affine_first else _act(z, op.act1) * s + t
+            z = _act(z, op.act2)
+            if op.seg_scale is not None:
+                z = z * get(op.seg_scale)
+            if op.res is not None:
+                z = z + get(op.res)
+            put(op.out, z.astype(dtype))
+        elif op.kind == "pool":
+            x = get(op.inp)
+            mean = x.mean(axis=0, dtype=dtype)
+            if op.stddev:
+                n = x.shape[0]
+                counts = n - 1 if (op.unbiased == 2 or (op.unbiased == 1 and n > 1)) else n
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    var = ((x - mean) ** 2).sum(axis=0, dtype=dtype) / dtype(counts)
+                std = np.sqrt(var + dtype(op.eps)) if op.var_mode == 1 else np.sqrt(np.maximum(var, dtype(op.eps)))
+                put(op.out, np.concatenate([mean, std])[None, :])
+            else:
+                put(op.out, mean[None, :])
+        elif op.kind == "attpool":
+            x, e = get(op.x), get(op.logits)
+            a = np.exp(e - e.max(axis=0, keepdims=True))
+            a = a / a.sum(axis=0, keepdims=True, dtype=dtype)
+            mean = (a * x).sum(axis=0, dtype=dtype)
+            resid = (a * x * x).sum(axis=0, dtype=dtype) - mean * mean
+            put(op.out, np.concatenate([mean, np.sqrt(np.maximum(resid, dtype(op.eps)))])[None, :])
+        elif op.kind == "eltwise":
+            z = get(op.a)
+            if op.scale is not None:
+                z = z * op.scale.astype(dtype) + op.shift.astype(dtype)
+            if op.seg_scale is not None:
+                z = z * get(op.seg_scale)
+            if op.b is not None:
+                z = z + get(op.b)
+            if op.c is not None:
+                z = z + get(op.c)
+            put(op.out, z.astype(dtype))
+        else:
+            raise AssertionError("unexpected op %s" % op.kind)
+    return get(graph.output)[0]
+
+
+def _tdnn_general(x, op, dtype):
+    """tap-by-tap evaluation for sliced weights (hoisted attention context etc.)."""
+    T = x.shape[0]
+    y = np.zeros((T, op.weight.shape[0]), dtype=dtype)
+    for d in op.taps:
+        k = d - op.w_left
+        lo, hi = max(0, -d), min(T, T - d)
+        if hi > lo:
+            y[lo:hi] += x[lo + d:hi + d] @ op.weight[:, :, k].T.astype(dtype)
+    if op.bias is not None:
+        y += op.bias.astype(dtype)
+    return y
+
+
+def extract(graph, feats, max_chunk=10000, dtype=np.float32):
+    return O.extract_embedding(lambda c: run_graph(graph, c, dtype), feats, max_chunk, dtype)

@@ -1,0 +1,141 @@
+"""Kernel-level parity on the MI355X: every GEMM code path (f32 MFMA, bf16 MFMA and the
+plain-VALU self-check kernels) against the numpy oracle, through the C ABI."""
+
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(arr):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(arr)).cuda()
+
+
+def _tdnn_forward(x, offsets, w, b, context, act, scale, shift, affine_first, precision, flags):
+    import torch
+    from libs.amd import capi
+    L = capi.lib()
+    left = min(0, context[0])
+    d = capi.TdnnDesc()
+    d.struct_size = C.sizeof(capi.TdnnDesc)
+    d.in_ch, d.out_ch = w.shape[1], w.shape[0]
+    d.n_taps = len(context)
+    for i, t in enumerate(context):
+        d.taps[i] = t
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    d.weight = capi.f32_ptr(w)
+    d.w_tot_context, d.w_left_context = w.shape[2], left
+    d.bias = capi.f32_ptr(b) if b is not None else None
+    d.act1 = capi.ACT_BY_NAME[act]
+    d.scale = capi.f32_ptr(scale) if scale is not None else None
+    d.shift = capi.f32_ptr(shift) if shift is not None else None
+    d.affine_first = int(affine_first)
+    d.in2_buf = d.seg_bias_buf = d.seg_scale_buf = d.res_buf = -1
+    xd = _dev(x)
+    yd = torch.empty((x.shape[0], w.shape[0]), dtype=torch.float32, device="cuda")
+    offs = np.ascontiguousarray(offsets, dtype=np.int32)
+    capi.check(L.asv_tdnn_forward(C.byref(d), precision, flags, C.c_void_p(xd.data_ptr()), offs.ctypes.data_as(capi.c_int32_p),
+                                  len(offs) - 1, C.c_void_p(yd.data_ptr()), None), "asv_tdnn_forward")
+    return yd.cpu().numpy()
+
+
+def _oracle_layer(x, offsets, w, b, context, act, scale, shift, affine_first):
+    from oracle import np_oracle as O
+    outs = []
+    for u in range(len(offsets) - 1):
+        seg = x[offsets[u]:offsets[u + 1]].astype(np.float64)
+        z = O.tdnn_affine(seg, w.astype(np.float64), None if b is None else b.astype(np.float64), list(context))
+        s = 1.0 if scale is None else scale.astype(np.float64)
+        t = 0.0 if shift is None else shift.astype(np.float64)
+        z = O._act(z * s + t, act) if affine_first else O._act(z, act) * s + t
+        outs.append(z)
+    return np.concatenate(outs, axis=0)
+
+
+CASES = [
+    # (in_ch, out_ch, context, lengths)
+    (80, 512, [-2, -1, 0, 1, 2], [200, 3, 1, 57, 200, 131]),
+    (30, 512, [-2, -1, 0, 1, 2], [200, 199, 2]),
+    (512, 512, [-2, 0, 2], [200, 200, 64, 300]),
+    (512, 512, [-3, 0, 3], [129, 1, 2, 3, 4, 5, 6, 7, 250]),
+    (512, 1500, [0], [200, 100]),
+    (128, 128, [-4, 0, 4], [300, 9, 8]),
+    (96, 200, [0], [5]),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "%dx%d_ctx%s" % (c[0], c[1], "_".join(map(str, c[2]))))
+@pytest.mark.parametrize("mode", ["f32_mfma", "f32_ref", "bf16_mfma", "bf16_ref"])
+def test_tdnn_layer_vs_oracle(case, mode):
+    from libs.amd import capi
+    cin, cout, ctx, lens = case
+    r = np.random.RandomState(cin * 7 + cout)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    x = r.randn(int(offsets[-1]), cin).astype(np.float32)
+    left, right = min(0, ctx[0]), max(0, ctx[-1])
+    w = (r.randn(cout, cin, right - left + 1) / np.sqrt(cin * len(ctx))).astype(np.float32)   # dense kernel, garbage in masked taps
+    b = (0.1 * r.randn(cout)).astype(np.float32)
+    scale = r.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = (0.2 * r.randn(cout)).astype(np.float32)
+    prec = capi.PREC_F32 if mode.startswith("f32") else capi.PREC_BF16
+    flags = capi.FLAG_REF_KERNELS if mode.endswith("ref") else 0
+    got = _tdnn_forward(x, offsets, w, b, ctx, "relu", scale, shift, False, prec, flags)
+    want = _oracle_layer(x, offsets, w, b, ctx, "relu", scale, shift, False)
+    err = rel_err(got, want)
+    tol = 2e-5 if mode.startswith("f32") else 2e-2       # bf16: 8-bit mantissa operands and outputs
+    assert err < tol, "%s: rel err %g" % (mode, err)
+
+
+def test_bf16_mfma_matches_bf16_ref_closely():
+    """Same bf16-rounded operands, f32 accumulation: only the summation order differs."""
+    from libs.amd import capi
+    r = np.random.RandomState(5)
+    lens = [200, 77, 130]
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    x = r.randn(int(offsets[-1]), 512).astype(np.float32)
+    w = (r.randn(512, 512, 5) / 40).astype(np.float32)
+    a = _tdnn_forward(x, offsets, w, None, [-2, 0, 2], None, None, None, False, capi.PREC_BF16, 0)
+    b = _tdnn_forward(x, offsets, w, None, [-2, 0, 2], None, None, None, False, capi.PREC_BF16, capi.FLAG_REF_KERNELS)
+    # outputs are bf16-rounded: at most one bf16 ulp apart where the f32 sums straddle a rounding boundary
+    assert rel_err(a, b) < 1e-2
+    assert np.mean(a == b) > 0.97
+
+
+def test_bn_relu_order_and_activations():
+    from libs.amd import capi
+    r = np.random.RandomState(11)
+    offsets = np.array([0, 150, 151], dtype=np.int32)
+    x = r.randn(151, 64).astype(np.float32)
+    w = (r.randn(96, 64, 1) / 8).astype(np.float32)
+    b = (0.1 * r.randn(96)).astype(np.float32)
+    scale = r.uniform(0.5, 1.5, 96).astype(np.float32)
+    shift = (0.2 * r.randn(96)).astype(np.float32)
+    for act in ("relu", "tanh", "sigmoid", None):
+        for first in (False, True):
+            got = _tdnn_forward(x, offsets, w, b, [0], act, scale, shift, first, capi.PREC_F32, 0)
+            want = _oracle_layer(x, offsets, w, b, [0], act, scale, shift, first)
+            assert rel_err(got, want) < 2e-5, (act, first)
+
+
+@pytest.mark.parametrize("lens", [[200, 200, 200], [1, 2, 3, 1000, 17], [513]])
+@pytest.mark.parametrize("channels", [1500, 64, 100])
+def test_stats_pool_vs_oracle(lens, channels):
+    import torch
+    from libs.amd import capi
+    from oracle import np_oracle as O
+    L = capi.lib()
+    r = np.random.RandomState(len(lens) + channels)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    x = (r.randn(int(offsets[-1]), channels) * r.uniform(0.1, 3, channels) + r.randn(channels)).astype(np.float32)
+    xd = _dev(x)
+    yd = torch.empty((len(lens), 2 * channels), dtype=torch.float32, device="cuda")
+    capi.check(L.asv_stats_pool_forward(C.c_void_p(xd.data_ptr()), channels, offsets.ctypes.data_as(capi.c_int32_p), len(lens), 1, 0, 0,
+                                        C.c_float(1e-10), C.c_void_p(yd.data_ptr()), None), "asv_stats_pool_forward")
+    got = yd.cpu().numpy()
+    want = np.stack([O.statistics_pooling(x[offsets[u]:offsets[u + 1]].astype(np.float64)) for u in range(len(lens))])
+    assert rel_err(got, want) < 1e-5

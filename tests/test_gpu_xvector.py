@@ -1,0 +1,109 @@
+"""End-to-end parity of the x-vector extractor on the MI355X against the fixtures produced
+by the reference itself (tests/golden, oracle/gen_golden.py) and against the oracle."""
+
+import numpy as np
+import pytest
+
+import helpers
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL_F32 = 1e-4          # BASELINE.json north_star: within 1e-4 relative fp32
+
+
+def _gpu_model(name, precision):
+    g, sd, model = helpers.golden_model(name)
+    model.cuda()
+    model.amd_precision = precision
+    return g, sd, model
+
+
+def test_native_library_is_the_one_running():
+    """No fallback: the engine is the in-tree libasv_amd.so and it is loaded in this process."""
+    from libs.amd import capi
+    lib = capi.lib()
+    assert lib.asv_version() >= 100
+    with open("/proc/self/maps") as f:
+        assert "libasv_amd.so" in f.read()
+
+
+def test_c1_hundred_utts_f32_vs_reference_golden():
+    g, sd, model = _gpu_model("xvector_c1", "f32")
+    mats = helpers.golden_feats(g)
+    got = model.extract_embedding_batch(mats).numpy()
+    assert got.shape == (100, 512)
+    assert rel_err(got, g["embeddings"]) < TOL_F32
+
+
+def test_ragged_near_f32_vs_reference_golden():
+    g, sd, model = _gpu_model("xvector_near_ragged", "f32")
+    got = model.extract_embedding_batch(helpers.golden_feats(g)).numpy()
+    for i, (T, _) in enumerate(g["utts"]):
+        assert rel_err(got[i], g["embeddings"][i]) < TOL_F32, "utterance of %d frames" % T
+
+
+def test_chunked_long_utterances_vs_reference_golden():
+    """T > maxChunk: framework.py:34-47 split + frame-weighted mean."""
+    g, sd, model = _gpu_model("xvector_chunked", "f32")
+    got = model.extract_embedding_batch(helpers.golden_feats(g)).numpy()
+    assert rel_err(got, g["embeddings"]) < TOL_F32
+
+
+def test_single_utterance_api_matches_reference_contract():
+    import torch
+    g, sd, model = _gpu_model("xvector_near_ragged", "f32")
+    x = helpers.golden_feats(g)[4]
+    e = model.extract_embedding(x)
+    assert isinstance(e, torch.Tensor) and e.device.type == "cpu" and e.dtype == torch.float32 and e.shape == (512,)
+    assert rel_err(e.numpy(), g["embeddings"][4]) < TOL_F32
+    # read-only frombuffer views are what kaldi_io hands over (kaldi_io.py:492-495)
+    ro = np.frombuffer(x.tobytes(), dtype=np.float32).reshape(x.shape)
+    assert np.array_equal(model.extract_embedding(ro).numpy(), e.numpy())
+
+
+def test_ref_kernels_agree_with_mfma_kernels(monkeypatch):
+    g, sd, model = _gpu_model("xvector_near_ragged", "f32")
+    mats = helpers.golden_feats(g)[:6]
+    a = model.extract_embedding_batch(mats).numpy()
+    monkeypatch.setenv("ASV_AMD_REF_KERNELS", "1")
+    b = model.extract_embedding_batch(mats).numpy()
+    assert rel_err(b, g["embeddings"][:6]) < TOL_F32
+    assert rel_err(a, b) < 1e-5
+
+
+def test_bf16_mode_is_close_and_eer_equivalent_inputs():
+    g, sd, model = _gpu_model("xvector_c1", "bf16")
+    got = model.extract_embedding_batch(helpers.golden_feats(g)).numpy()
+    ref = g["embeddings"]
+    cos = (got * ref).sum(1) / np.linalg.norm(got, axis=1) / np.linalg.norm(ref, axis=1)
+    assert cos.min() > 0.9995, cos.min()
+    assert rel_err(got, ref) < 3e-2
+
+
+def test_batch_composition_does_not_change_results():
+    """Size-independent property at BASELINE config C2 size (256 x 200 x 80): every utterance's
+    embedding is bit-identical whether it is extracted alone, in a shuffled batch or in the
+    full batch (rows are independent fma chains; pooling is per segment)."""
+    from libs.amd import synth
+    g, sd, model = _gpu_model("xvector_near_ragged", "bf16")
+    mats = [synth.synth_feats(200, 80, 5000 + i) for i in range(256)]
+    full = model.extract_embedding_batch(mats).numpy()
+    assert np.isfinite(full).all()
+    perm = np.random.RandomState(0).permutation(256)
+    shuf = model.extract_embedding_batch([mats[i] for i in perm]).numpy()
+    assert np.array_equal(shuf, full[perm])
+    for i in (0, 101, 255):
+        assert np.array_equal(model.extract_embedding(mats[i]).numpy(), full[i])
+
+
+def test_errors_are_loud():
+    from libs.amd import capi
+    g, sd, model = _gpu_model("xvector_near_ragged", "f32")
+    with pytest.raises(ValueError):
+        model.extract_embedding(np.zeros((10, 79), dtype=np.float32))      # wrong feature dim
+    with pytest.raises(capi.AsvError):
+        model.extract_embedding_batch([np.zeros((0, 80), dtype=np.float32)])   # empty utterance
+    model.cpu()
+    with pytest.raises(RuntimeError):
+        model.extract_embedding(np.zeros((10, 80), dtype=np.float32))      # no CPU fallback

@@ -1,0 +1,67 @@
+"""The oracle is pinned to the reference: numpy restatement, torch-CPU port and the traced
+layer program must all reproduce the fixtures the reference itself produced."""
+
+import numpy as np
+import pytest
+
+import helpers
+import ir_interp
+from helpers import rel_err
+from oracle import np_oracle as O
+from oracle import torch_cpu_port as P
+
+
+def _embed(name, position, limit=None):
+    g, sd = helpers.golden_state_dict(name)
+    mats = helpers.golden_feats(g)[:limit]
+    got = np.stack([O.extract_embedding(lambda c: O.xvector_embed(c, sd, position), m) for m in mats])
+    return got, g["embeddings"][:len(mats)], g, sd, mats
+
+
+def test_np_oracle_c1_matches_reference():
+    got, ref, *_ = _embed("xvector_c1", "far", limit=12)
+    assert rel_err(got, ref) < 5e-6
+
+
+def test_np_oracle_ragged_near_matches_reference():
+    got, ref, *_ = _embed("xvector_near_ragged", "near")
+    assert rel_err(got, ref) < 5e-6
+
+
+@pytest.mark.slow
+def test_np_oracle_chunked_matches_reference():
+    got, ref, *_ = _embed("xvector_chunked", "far", limit=1)
+    assert rel_err(got, ref) < 5e-5
+
+
+def test_float64_oracle_brackets_reference_rounding():
+    g, sd = helpers.golden_state_dict("xvector_near_ragged")
+    sd64 = O.cast_state_dict(sd, np.float64)
+    x = helpers.golden_feats(g)[4]
+    e64 = O.extract_embedding(lambda c: O.xvector_embed(c, sd64, "near"), x, dtype=np.float64)
+    assert rel_err(g["embeddings"][4], e64) < 5e-6
+
+
+def test_torch_cpu_port_is_bit_identical_to_reference():
+    g, sd = helpers.golden_state_dict("xvector_c1")
+    ex = P.XvectorCpu(sd, "far")
+    for x, ref in list(zip(helpers.golden_feats(g), g["embeddings"]))[:5]:
+        assert rel_err(ex.extract_embedding(x).numpy(), ref) < 1e-6
+
+
+def test_chunk_plan_matches_framework_rule():
+    assert O.chunk_plan(200) == [(0, 200)]
+    assert O.chunk_plan(10000) == [(0, 10000)]
+    assert O.chunk_plan(10001) == [(0, 5000), (5000, 5001)]
+    assert O.chunk_plan(20001) == [(0, 6667), (6667, 6667), (13334, 6667)]
+    assert O.chunk_plan(7, 3) == [(0, 2), (2, 2), (4, 3)]
+
+
+def test_traced_program_reproduces_reference_on_cpu():
+    """Blueprint -> recorder -> graph passes -> numpy interpretation == reference output."""
+    from libs.amd import ir
+    g, sd, model = helpers.golden_model("xvector_near_ragged")
+    graph = ir.trace(model, type(model).extract_embedding.__wrapped_body__, int(g["dim"]))
+    assert [op.kind for op in graph.ops] == ["tdnn"] * 5 + ["pool", "tdnn", "tdnn"]
+    for x, ref in zip(helpers.golden_feats(g), g["embeddings"]):
+        assert rel_err(ir_interp.extract(graph, x), ref) < 5e-6
