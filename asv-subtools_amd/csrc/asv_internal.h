@@ -44,7 +44,7 @@ static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m 
 // per-layer zero padding of TdnnAffine (components.py:116-117), with no masks in the GEMM
 // main loop.  Every producer writes zeros into gap rows (row_valid bit clear).
 constexpr int kHalo = 4;           // max |tap offset| supported (ECAPA dilation 4)
-constexpr int kRowTile = 128;      // rows are padded to a multiple of the GEMM M tile
+constexpr int kRowTile = 256;      // rows are padded to a multiple of the largest GEMM M tile
 constexpr int kChanAlign = 16;     // channel pitch granularity (elements)
 
 // ---------------------------------------------------------------------------------------
@@ -65,6 +65,12 @@ struct TdnnKernelParams {
   // fused statistics pooling (optional): per (row tile, channel) partial sums of the valid rows,
   // segmented by utterance; see kernels_tdnn.hip
   float *pool_partial;
+  const void *zero16;   // >= 16 bytes of device zeros: source of masked direct-to-LDS loads
+  // split-K (small-M layers: the pooled domain): blockIdx.y walks `ksplit` slices of the channel
+  // chunks, raw f32 accumulators go to partial[slice][rows][ld_partial]; a second kernel sums
+  // the slices in order and applies the epilogue (deterministic, no atomics)
+  float *partial;
+  int ksplit, ld_partial;
   int ldx, ldx2, ldy, ldres, ld_segbias, ld_segscale;   // pitches in elements
   int rows;             // padded row count (multiple of kRowTile)
   int cin_pad;          // multiple of kChanAlign
@@ -85,6 +91,12 @@ struct PoolKernelParams {
 // launchers (kernels_*.hip).  ElemBF16: activations are bf16 (else f32).
 int launch_tdnn_mfma(const TdnnKernelParams &p, bool bf16, bool out_f32, hipStream_t s);
 int launch_tdnn_ref(const TdnnKernelParams &p, bool bf16, bool out_f32, hipStream_t s);
+int launch_splitk_epilogue(const TdnnKernelParams &p, bool bf16, bool out_f32, hipStream_t s);
+// 256x256-tile bf16 kernel with direct-to-LDS staging (kernels_tdnn_v2.hip); needs weights
+// padded to kBigTileN rows and a plain epilogue (no second input / per-segment terms / residual)
+constexpr int kBigTileN = 256;
+bool tdnn_big_supported(const TdnnKernelParams &p, bool bf16, bool out_f32);
+int launch_tdnn_big(const TdnnKernelParams &p, hipStream_t s);
 int launch_stats_pool(const PoolKernelParams &p, int segments, bool bf16, hipStream_t s);
 int launch_attentive_pool(const void *x, int ldx, const void *logits, int ldl, int channels,
                           const int32_t *seg_row0, const int32_t *seg_len, int segments, float eps,

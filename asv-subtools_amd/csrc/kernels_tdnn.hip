@@ -35,7 +35,7 @@ constexpr int A_STAGE = WIN * ROWB;           // 17408
 constexpr int B_STAGE = BN * ROWB;            // 16384
 constexpr int LDS_BYTES = 2 * A_STAGE + 2 * B_STAGE;   // 67584 -> 2 workgroups / CU
 constexpr int A_PIECES = WIN * 8;             // 1088 16-byte pieces per window
-static_assert(BM == kRowTile, "row padding must match the M tile");
+static_assert(kRowTile % BM == 0, "row padding must be a multiple of the M tile");
 
 __device__ __forceinline__ int swz(int row, int slot) { return slot ^ ((row >> 1) & 7); }
 
@@ -144,16 +144,24 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const TdnnKernelParam
   };
 
   const int nchunks = (p.cin_pad + BK - 1) / BK;
-  const int nsteps = nchunks * p.n_taps;
+  // split-K: this workgroup owns chunks [c_begin, c_end)
+  int c_begin = 0, c_end = nchunks;
+  if (p.ksplit > 1) {
+    c_begin = (int)(((long long)nchunks * blockIdx.y) / p.ksplit);
+    c_end = (int)(((long long)nchunks * (blockIdx.y + 1)) / p.ksplit);
+  }
+  const int nsteps = (c_end - c_begin) * p.n_taps;
 
   // prologue: stage step 0
-  gload_A(0);
-  gload_B(0, 0);
-  sstore_A(0);
-  sstore_B(0);
+  if (nsteps > 0) {
+    gload_A(c_begin);
+    gload_B(c_begin, 0);
+    sstore_A(c_begin & 1);
+    sstore_B(0);
+  }
   __syncthreads();
 
-  int c = 0, t = 0;
+  int c = c_begin, t = 0;
   for (int s = 0; s < nsteps; ++s) {
     int cn = c, tn = t + 1;
     if (tn == p.n_taps) { tn = 0; cn = c + 1; }
@@ -185,6 +193,21 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const TdnnKernelParam
   }
 
   // epilogue.  C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  if (p.ksplit > 1) {
+    float *part = p.partial + (size_t)blockIdx.y * p.rows * p.ld_partial;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ch = n0 + wn * 64 + j * 32 + lr;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (ch < p.ld_partial) part[(size_t)row * p.ld_partial + ch] = acc[i][j][r];
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int ch = n0 + wn * 64 + j * 32 + lr;
@@ -235,7 +258,32 @@ __global__ __launch_bounds__(256) void tdnn_ref_kernel(const TdnnKernelParams p)
   store_elem<OUT_BF16>(p.y, (size_t)row * p.ldy + ch, yv);
 }
 
+// second half of a split-K layer: sum the slices in order, then the usual epilogue
+template <bool BF16, bool OUT_BF16>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const TdnnKernelParams p) {
+  const int ch = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int row = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (row >= p.rows || ch >= p.cout_store) return;
+  float acc = 0.0f;
+  for (int z = 0; z < p.ksplit; ++z) acc += p.partial[((size_t)z * p.rows + row) * p.ld_partial + ch];
+  const bool valid = (p.row_valid[row >> 5] >> (row & 31)) & 1u;
+  const float scale = p.scale ? p.scale[ch] : 1.0f, shift = p.shift ? p.shift[ch] : 0.0f;
+  store_elem<OUT_BF16>(p.y, (size_t)row * p.ldy + ch, tdnn_epilogue<BF16>(p, acc, row, ch, p.bias[ch], scale, shift, valid));
+}
+
 }  // namespace
+
+int launch_splitk_epilogue(const TdnnKernelParams &p, bool bf16, bool out_f32, hipStream_t s) {
+  const dim3 grid((p.cout_store + 63) / 64, (p.rows + 3) / 4), block(256);
+  if (bf16) {
+    if (out_f32) hipLaunchKernelGGL((splitk_epilogue_kernel<true, false>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((splitk_epilogue_kernel<true, true>), grid, block, 0, s, p);
+  } else {
+    hipLaunchKernelGGL((splitk_epilogue_kernel<false, false>), grid, block, 0, s, p);
+  }
+  ASV_HIP_CHECK(hipGetLastError());
+  return ASV_OK;
+}
 
 int launch_tdnn_mfma(const TdnnKernelParams &p, bool bf16, bool out_f32, hipStream_t s) {
   ASV_REQUIRE(p.rows % BM == 0, "tdnn: rows %d not a multiple of %d", p.rows, BM);
@@ -245,7 +293,8 @@ int launch_tdnn_mfma(const TdnnKernelParams &p, bool bf16, bool out_f32, hipStre
     ASV_REQUIRE(p.taps[t] >= -kHalo && p.taps[t] <= kHalo, "tdnn: tap offset %d exceeds the %d-frame halo", p.taps[t], kHalo);
   const int m_tiles = p.rows / BM;
   const int n_tiles = round_up(p.cout_store, BN) / BN;
-  const dim3 grid(m_tiles * n_tiles), block(256);
+  const dim3 grid(m_tiles * n_tiles, p.ksplit > 1 ? p.ksplit : 1), block(256);
+  if (p.ksplit > 1) ASV_REQUIRE(p.partial != nullptr && p.ld_partial >= p.cout_store, "tdnn: split-K needs a partial buffer");
   if (bf16) {
     if (out_f32) hipLaunchKernelGGL((tdnn_gemm_kernel<true, false>), grid, block, 0, s, p, m_tiles, n_tiles);
     else hipLaunchKernelGGL((tdnn_gemm_kernel<true, true>), grid, block, 0, s, p, m_tiles, n_tiles);

@@ -100,13 +100,15 @@ struct asv_net {
   std::vector<DevMem> arena;             // one region per buffer
   DevMem meta_dev;                       // int32 metadata (segments etc.)
   DevMem rowmeta_dev;                    // row_seg / row_valid for both domains
+  DevMem splitk_dev;                     // split-K partial accumulators
+  void *zero_page = nullptr;             // 256 zero bytes (masked direct-to-LDS loads)
   void *meta_host = nullptr;             // pinned staging
   size_t meta_host_cap = 0;
   hipEvent_t meta_copied = nullptr;      // H2D of meta_host finished
   bool meta_inflight = false;
   // profiling
-  bool profiling = false;
-  struct Stamp { int kclass; double flops; hipEvent_t a, b; };
+  int profiling = 0;               // 0 off, 1 per kernel class, 2 per op
+  struct Stamp { int kclass; int op; double flops; hipEvent_t a, b; };
   std::vector<Stamp> stamps;
   std::vector<hipEvent_t> event_pool;
 
@@ -163,9 +165,9 @@ int ensure(DevMem &m, size_t bytes, hipStream_t s, bool zero) {
 
 struct Prof {
   asv_net *net; hipStream_t s;
-  int begin(int kclass, double flops) {
+  int begin(int kclass, double flops, int op = -1) {
     if (!net->profiling) return ASV_OK;
-    asv_net::Stamp st; st.kclass = kclass; st.flops = flops;
+    asv_net::Stamp st; st.kclass = kclass; st.flops = flops; st.op = op;
     for (hipEvent_t *e : {&st.a, &st.b}) {
       if (!net->event_pool.empty()) { *e = net->event_pool.back(); net->event_pool.pop_back(); }
       else ASV_HIP_CHECK(hipEventCreate(e));
@@ -249,6 +251,9 @@ int asv_net_create(asv_net_t **out, int device, int precision, unsigned flags, i
   if (!net) { set_error("out of host memory"); return ASV_ENOMEM; }
   net->device = device; net->precision = precision; net->flags = flags; net->feat_dim = feat_dim;
   net->bufs.push_back({ASV_DOMAIN_FRAMES, feat_dim, round_up(feat_dim, kChanAlign)});
+  hipError_t ze = hipMalloc(&net->zero_page, 256);
+  if (ze == hipSuccess) ze = hipMemset(net->zero_page, 0, 256);
+  if (ze != hipSuccess) { set_error("zero page allocation failed: %s", hipGetErrorString(ze)); delete net; return ASV_EHIP; }
   *out = net;
   return ASV_OK;
 }
@@ -261,6 +266,8 @@ void asv_net_destroy(asv_net_t *net) {
   for (auto &m : net->arena) if (m.ptr) (void)hipFree(m.ptr);
   if (net->meta_dev.ptr) (void)hipFree(net->meta_dev.ptr);
   if (net->rowmeta_dev.ptr) (void)hipFree(net->rowmeta_dev.ptr);
+  if (net->splitk_dev.ptr) (void)hipFree(net->splitk_dev.ptr);
+  if (net->zero_page) (void)hipFree(net->zero_page);
   if (net->meta_host) (void)hipHostFree(net->meta_host);
   if (net->meta_copied) (void)hipEventDestroy(net->meta_copied);
   for (auto &st : net->stamps) { (void)hipEventDestroy(st.a); (void)hipEventDestroy(st.b); }
@@ -325,7 +332,7 @@ int asv_net_add_tdnn(asv_net_t *net, const asv_tdnn_desc_t *d) {
   op.utts = (dom == ASV_DOMAIN_UTTS);
   const bool bf16 = !op.utts && net->frames_bf16();
   op.cin_pad = round_up(d->in_ch, kChanAlign);
-  op.cout_pad = round_up(d->out_ch, 128);
+  op.cout_pad = round_up(d->out_ch, kBigTileN);
   op.cout_store = round_up(d->out_ch, kChanAlign);
   ASV_REQUIRE(d->out_ch_off + op.cout_store <= net->bufs[d->out_buf].ld, "tdnn: padded output view exceeds the buffer pitch");
   ASV_HIP_CHECK(hipSetDevice(net->device));
@@ -472,30 +479,37 @@ int asv_net_describe(const asv_net_t *net, char *buf, size_t cap) {
 
 int asv_net_set_profiling(asv_net_t *net, int enable) {
   ASV_REQUIRE(net != nullptr, "asv_net_set_profiling: null net");
-  net->profiling = enable != 0;
+  net->profiling = enable;
   return ASV_OK;
 }
 
 int asv_net_get_profile(asv_net_t *net, asv_kernel_time_t *rows, int cap, int *n_rows) {
   ASV_REQUIRE(net && rows && n_rows && cap >= 1, "asv_net_get_profile: bad arguments");
   ASV_HIP_CHECK(hipSetDevice(net->device));
-  asv_kernel_time_t agg[K_COUNT];
-  memset(agg, 0, sizeof(agg));
-  for (int k = 0; k < K_COUNT; ++k) snprintf(agg[k].name, sizeof(agg[k].name), "%s", kKernelNames[k]);
+  std::map<std::pair<int, int>, asv_kernel_time_t> agg;      // (kernel class, op or -1)
   for (auto &st : net->stamps) {
     ASV_HIP_CHECK(hipEventSynchronize(st.b));
     float ms = 0.0f;
     ASV_HIP_CHECK(hipEventElapsedTime(&ms, st.a, st.b));
-    agg[st.kclass].launches += 1;
-    agg[st.kclass].total_ms += ms;
-    agg[st.kclass].flops += st.flops;
+    const int op = net->profiling >= 2 ? st.op : -1;
+    auto it = agg.find({st.kclass, op});
+    if (it == agg.end()) {
+      asv_kernel_time_t row;
+      memset(&row, 0, sizeof(row));
+      snprintf(row.name, sizeof(row.name), "%s", kKernelNames[st.kclass]);
+      row.op_index = op;
+      it = agg.emplace(std::make_pair(st.kclass, op), row).first;
+    }
+    it->second.launches += 1;
+    it->second.total_ms += ms;
+    it->second.flops += st.flops;
     net->event_pool.push_back(st.a);
     net->event_pool.push_back(st.b);
   }
   net->stamps.clear();
   int n = 0;
-  for (int k = 0; k < K_COUNT && n < cap; ++k)
-    if (agg[k].launches > 0) rows[n++] = agg[k];
+  for (auto &kv : agg)
+    if (n < cap) rows[n++] = kv.second;
   *n_rows = n;
   return ASV_OK;
 }
@@ -597,9 +611,31 @@ int run_ops(RunCtx &c, size_t n_ops) {
         p.n_taps = d.n_taps;
         for (int t = 0; t < d.n_taps; ++t) p.taps[t] = d.taps[t];
         p.act1 = d.act1; p.act2 = d.act2; p.affine_first = d.affine_first;
+        p.zero16 = net->zero_page;
+        const bool big = !use_ref && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && tdnn_big_supported(p, bf16, !bf16);
+        if (!use_ref && !big) {
+          // few output tiles (pooled-domain layers, short batches): slice K over more workgroups
+          const int tiles = (p.rows / 128) * (round_up(p.cout_store, 128) / 128);
+          const int nchunks = (p.cin_pad + (bf16 ? 64 : 32) - 1) / (bf16 ? 64 : 32);
+          if (tiles < 128 && nchunks >= 4) {
+            p.ksplit = std::min(std::min(nchunks / 2, 64), std::max(1, 512 / tiles));
+            if (p.ksplit > 1) {
+              p.ld_partial = round_up(p.cout_store, 64);
+              if ((rc = ensure(net->splitk_dev, (size_t)p.ksplit * p.rows * p.ld_partial * 4, c.s, false))) return rc;
+              p.partial = reinterpret_cast<float *>(net->splitk_dev.ptr);
+            } else {
+              p.ksplit = 0;
+            }
+          }
+        }
         const double valid_rows = op.utts ? (double)bp.segments : (double)bp.frames;
-        if ((rc = prof.begin(K_TDNN, 2.0 * valid_rows * d.in_ch * d.out_ch * d.n_taps))) return rc;
-        rc = use_ref ? launch_tdnn_ref(p, bf16, !bf16, c.s) : launch_tdnn_mfma(p, bf16, !bf16, c.s);
+        if ((rc = prof.begin(K_TDNN, 2.0 * valid_rows * d.in_ch * d.out_ch * d.n_taps, (int)i))) return rc;
+        if (use_ref) rc = launch_tdnn_ref(p, bf16, !bf16, c.s);
+        else if (big) rc = launch_tdnn_big(p, c.s);
+        else {
+          rc = launch_tdnn_mfma(p, bf16, !bf16, c.s);
+          if (!rc && p.ksplit > 1) rc = launch_splitk_epilogue(p, bf16, !bf16, c.s);
+        }
         if (rc) return rc;
         if ((rc = prof.end())) return rc;
         break;
@@ -611,14 +647,14 @@ int run_ops(RunCtx &c, size_t n_ops) {
         p.seg_row0 = c.seg_row0; p.seg_len = c.seg_len;
         p.out = reinterpret_cast<float *>(net->arena[d.out_buf].ptr) + d.out_ch_off; p.ld_out = net->bufs[d.out_buf].ld;
         p.stddev = d.stddev; p.unbiased = d.unbiased; p.var_mode = d.var_mode; p.eps = d.eps;
-        if ((rc = prof.begin(K_POOL, 0))) return rc;
+        if ((rc = prof.begin(K_POOL, 0, (int)i))) return rc;
         if ((rc = launch_stats_pool(p, bp.segments, net->frames_bf16(), c.s))) return rc;
         if ((rc = prof.end())) return rc;
         break;
       }
       case OP_ATTPOOL: {
         const auto &d = op.att;
-        if ((rc = prof.begin(K_ATT, 0))) return rc;
+        if ((rc = prof.begin(K_ATT, 0, (int)i))) return rc;
         rc = launch_attentive_pool(view(c, d.x_buf, d.x_ch_off), net->bufs[d.x_buf].ld, view(c, d.logit_buf, d.logit_ch_off), net->bufs[d.logit_buf].ld,
                                    d.channels, c.seg_row0, c.seg_len, bp.segments, d.eps,
                                    reinterpret_cast<float *>(net->arena[d.out_buf].ptr) + d.out_ch_off, net->bufs[d.out_buf].ld, net->frames_bf16(), c.s);
@@ -639,7 +675,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         if (d.seg_scale_buf >= 0) { p.seg_scale = reinterpret_cast<const float *>(net->arena[d.seg_scale_buf].ptr); p.ld_segscale = net->bufs[d.seg_scale_buf].ld; }
         if (op.utts) { p.rows = bp.segments; }
         else { p.rows = bp.rows_pad; p.row_seg = c.row_seg; p.row_valid = c.row_valid; }
-        if ((rc = prof.begin(K_ELT, 0))) return rc;
+        if ((rc = prof.begin(K_ELT, 0, (int)i))) return rc;
         if ((rc = launch_eltwise(p, !op.utts && net->frames_bf16(), c.s))) return rc;
         if ((rc = prof.end())) return rc;
         break;

@@ -12,7 +12,7 @@ import os
 
 ASV_OK = 0
 PREC_F32, PREC_BF16 = 0, 1
-FLAG_REF_KERNELS, FLAG_NO_FUSE = 1, 2
+FLAG_REF_KERNELS, FLAG_NO_FUSE, FLAG_SMALL_TILES = 1, 2, 4
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
 DOMAIN_FRAMES, DOMAIN_UTTS = 0, 1
 MAX_TAPS = 9
@@ -79,7 +79,7 @@ class EltwiseDesc(C.Structure):
 
 
 class KernelTime(C.Structure):
-    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int32), ("total_ms", C.c_float), ("flops", C.c_double)]
+    _fields_ = [("name", C.c_char * 48), ("op_index", C.c_int32), ("launches", C.c_int32), ("total_ms", C.c_float), ("flops", C.c_double)]
 
 
 class AsvError(RuntimeError):

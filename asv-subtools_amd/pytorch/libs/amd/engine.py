@@ -31,6 +31,8 @@ def default_flags():
         flags |= capi.FLAG_REF_KERNELS
     if os.environ.get("ASV_AMD_NO_FUSE", "0") not in ("0", "", "false"):
         flags |= capi.FLAG_NO_FUSE
+    if os.environ.get("ASV_AMD_SMALL_TILES", "0") not in ("0", "", "false"):
+        flags |= capi.FLAG_SMALL_TILES
     return flags
 
 
@@ -191,15 +193,17 @@ class Engine(object):
 
     # ---- profiling ------------------------------------------------------------------------
     def set_profiling(self, enable):
-        capi.check(self.lib.asv_net_set_profiling(self._net, int(bool(enable))), "asv_net_set_profiling")
+        """0 off, 1 per kernel class, 2 per program op."""
+        capi.check(self.lib.asv_net_set_profiling(self._net, int(enable)), "asv_net_set_profiling")
 
     def get_profile(self):
         """[{name, launches, total_ms, flops}] of the launches since the last call (hipEvents on
         the extract stream); synchronises on the recorded events."""
-        rows = (capi.KernelTime * 16)()
+        cap = 16 + 2 * len(self.graph.ops)
+        rows = (capi.KernelTime * cap)()
         n = C.c_int(0)
-        capi.check(self.lib.asv_net_get_profile(self._net, rows, 16, C.byref(n)), "asv_net_get_profile")
-        return [dict(name=rows[i].name.decode(), launches=int(rows[i].launches), total_ms=float(rows[i].total_ms),
+        capi.check(self.lib.asv_net_get_profile(self._net, rows, cap, C.byref(n)), "asv_net_get_profile")
+        return [dict(name=rows[i].name.decode(), op_index=int(rows[i].op_index), launches=int(rows[i].launches), total_ms=float(rows[i].total_ms),
                      flops=float(rows[i].flops)) for i in range(n.value)]
 
 

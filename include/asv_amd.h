@@ -56,6 +56,7 @@ int         asv_device_count(int *count);
 /* flags for asv_net_create */
 #define ASV_FLAG_REF_KERNELS 1u  /* run the plain-VALU self-check kernels instead of MFMA ones */
 #define ASV_FLAG_NO_FUSE     2u  /* disable epilogue fusions (stats pooling into the producer)  */
+#define ASV_FLAG_SMALL_TILES 4u  /* never pick the 256x256 direct-to-LDS kernel (A/B testing)   */
 
 #define ASV_ACT_NONE    0
 #define ASV_ACT_RELU    1
@@ -162,10 +163,12 @@ size_t asv_net_device_bytes(const asv_net_t *net);
 
 /* Name + average device time (ms, hipEvent on the extract stream) of the dominant kernel
  * class of the most recent profiled extract.  asv_net_set_profiling(1) makes extract record
- * events around every launch (costs a few us per launch). */
+ * events around every launch (costs a few us per launch); enable = 2 additionally keeps one
+ * row per program op instead of one per kernel class. */
 int asv_net_set_profiling(asv_net_t *net, int enable);
 typedef struct asv_kernel_time {
   char     name[48];
+  int32_t  op_index;             /* program op the row belongs to; -1 = all ops of this kernel class */
   int32_t  launches;
   float    total_ms;
   double   flops;                /* algorithmic 2*MAC of those launches (active taps only) */

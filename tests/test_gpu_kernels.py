@@ -139,3 +139,27 @@ def test_stats_pool_vs_oracle(lens, channels):
     got = yd.cpu().numpy()
     want = np.stack([O.statistics_pooling(x[offsets[u]:offsets[u + 1]].astype(np.float64)) for u in range(len(lens))])
     assert rel_err(got, want) < 1e-5
+
+
+@pytest.mark.parametrize("case", [(512, 512, [-2, 0, 2], [200] * 5 + [77, 3]), (80, 512, [-2, -1, 0, 1, 2], [200, 31]),
+                                  (512, 1500, [0], [255, 257, 1]), (96, 200, [0], [300])],
+                         ids=lambda c: "%dx%d" % (c[0], c[1]))
+def test_big_tile_kernel_matches_small_tile_kernel(case):
+    """The 256x256 direct-to-LDS kernel and the 128x128 register-staged kernel consume the same
+    bf16 operands with f32 accumulation: outputs agree to the last bf16 rounding."""
+    from libs.amd import capi
+    cin, cout, ctx, lens = case
+    r = np.random.RandomState(cin + cout)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    x = r.randn(int(offsets[-1]), cin).astype(np.float32)
+    left, right = min(0, ctx[0]), max(0, ctx[-1])
+    w = (r.randn(cout, cin, right - left + 1) / np.sqrt(cin * len(ctx))).astype(np.float32)
+    b = (0.1 * r.randn(cout)).astype(np.float32)
+    scale = r.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = (0.2 * r.randn(cout)).astype(np.float32)
+    big = _tdnn_forward(x, offsets, w, b, ctx, "relu", scale, shift, False, capi.PREC_BF16, 0)
+    small = _tdnn_forward(x, offsets, w, b, ctx, "relu", scale, shift, False, capi.PREC_BF16, capi.FLAG_SMALL_TILES)
+    want = _oracle_layer(x, offsets, w, b, ctx, "relu", scale, shift, False)
+    assert rel_err(big, want) < 2e-2 and rel_err(small, want) < 2e-2
+    assert rel_err(big, small) < 1e-2
+    assert np.mean(big == small) > 0.97
