@@ -97,6 +97,7 @@ int launch_splitk_epilogue(const TdnnKernelParams &p, bool bf16, bool out_f32, h
 constexpr int kBigTileN = 256;
 bool tdnn_big_supported(const TdnnKernelParams &p, bool bf16, bool out_f32);
 int launch_tdnn_big(const TdnnKernelParams &p, hipStream_t s);
+int launch_tdnn_big_variant(const TdnnKernelParams &p, int variant, hipStream_t s);   // ablations, tools/gemm_ablate
 int launch_stats_pool(const PoolKernelParams &p, int segments, bool bf16, hipStream_t s);
 int launch_attentive_pool(const void *x, int ldx, const void *logits, int ldl, int channels,
                           const int32_t *seg_row0, const int32_t *seg_len, int segments, float eps,

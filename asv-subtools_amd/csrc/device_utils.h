@@ -94,6 +94,15 @@ __device__ __forceinline__ float tdnn_epilogue(const TdnnKernelParams &p, float 
   return z;
 }
 
+// Fast epilogue for the common layer shape (affine -> [ReLU] -> folded BN, no per-segment terms):
+// branch-free, a handful of VALU ops per element.  `lo` = 0 for ReLU, -inf for no activation.
+// The general form above (tanh / sigmoid / "bn-relu" order / per-segment bias and scale / residual)
+// lives in separately instantiated kernels so its large code never sits in the hot kernels.
+__device__ __forceinline__ float tdnn_epilogue_fast(float acc, float bias, float lo, float scale, float shift, bool valid) {
+  const float z = fmaxf(acc + bias, lo) * scale + shift;
+  return valid ? z : 0.0f;
+}
+
 // XCD-aware, bijective remap of a 1-D grid (cdna_hip_programming.md T1): hardware places
 // block b on XCD b % 8; give each XCD a contiguous run of logical tiles so the N tiles that
 // share an A panel hit the same L2.

@@ -39,7 +39,7 @@ static_assert(kRowTile % BM == 0, "row padding must be a multiple of the M tile"
 
 __device__ __forceinline__ int swz(int row, int slot) { return slot ^ ((row >> 1) & 7); }
 
-template <bool BF16, bool OUT_BF16>
+template <bool BF16, bool OUT_BF16, bool GENERIC>
 __global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const TdnnKernelParams p, int m_tiles, int n_tiles) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
   constexpr int ES = BF16 ? 2 : 4;          // element bytes
@@ -215,6 +215,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const TdnnKernelParam
     const float scale = p.scale ? p.scale[ch] : 1.0f;
     const float shift = p.shift ? p.shift[ch] : 0.0f;
     const bool ch_ok = ch < p.cout_store;
+    const float act_lo = (p.act1 == ASV_ACT_RELU) ? 0.0f : -INFINITY;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int rbase = m0 + wm * 64 + i * 32;
@@ -224,7 +225,9 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const TdnnKernelParam
         const int rf = (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int row = rbase + rf;
         const bool valid = (vbits >> rf) & 1u;
-        const float yv = tdnn_epilogue<BF16>(p, acc[i][j][r], row, ch, bias, scale, shift, valid);
+        float yv;
+        if constexpr (GENERIC) yv = tdnn_epilogue<BF16>(p, acc[i][j][r], row, ch, bias, scale, shift, valid);
+        else yv = tdnn_epilogue_fast(acc[i][j][r], bias, act_lo, scale, shift, valid);
         if (ch_ok) store_elem<OUT_BF16>(p.y, (size_t)row * p.ldy + ch, yv);
       }
     }
@@ -295,12 +298,22 @@ int launch_tdnn_mfma(const TdnnKernelParams &p, bool bf16, bool out_f32, hipStre
   const int n_tiles = round_up(p.cout_store, BN) / BN;
   const dim3 grid(m_tiles * n_tiles, p.ksplit > 1 ? p.ksplit : 1), block(256);
   if (p.ksplit > 1) ASV_REQUIRE(p.partial != nullptr && p.ld_partial >= p.cout_store, "tdnn: split-K needs a partial buffer");
+  // the hot instantiations carry the short epilogue only; tanh / sigmoid / per-segment terms /
+  // residual / "bn-relu" order go to the GENERIC ones
+  const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first && p.seg_bias == nullptr &&
+                    p.seg_scale == nullptr && p.res == nullptr;
   if (bf16) {
-    if (out_f32) hipLaunchKernelGGL((tdnn_gemm_kernel<true, false>), grid, block, 0, s, p, m_tiles, n_tiles);
-    else hipLaunchKernelGGL((tdnn_gemm_kernel<true, true>), grid, block, 0, s, p, m_tiles, n_tiles);
+    if (out_f32) {
+      if (fast) hipLaunchKernelGGL((tdnn_gemm_kernel<true, false, false>), grid, block, 0, s, p, m_tiles, n_tiles);
+      else hipLaunchKernelGGL((tdnn_gemm_kernel<true, false, true>), grid, block, 0, s, p, m_tiles, n_tiles);
+    } else {
+      if (fast) hipLaunchKernelGGL((tdnn_gemm_kernel<true, true, false>), grid, block, 0, s, p, m_tiles, n_tiles);
+      else hipLaunchKernelGGL((tdnn_gemm_kernel<true, true, true>), grid, block, 0, s, p, m_tiles, n_tiles);
+    }
   } else {
     ASV_REQUIRE(out_f32, "tdnn: f32 activations always produce f32");
-    hipLaunchKernelGGL((tdnn_gemm_kernel<false, false>), grid, block, 0, s, p, m_tiles, n_tiles);
+    if (fast) hipLaunchKernelGGL((tdnn_gemm_kernel<false, false, false>), grid, block, 0, s, p, m_tiles, n_tiles);
+    else hipLaunchKernelGGL((tdnn_gemm_kernel<false, false, true>), grid, block, 0, s, p, m_tiles, n_tiles);
   }
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;

@@ -56,6 +56,10 @@ __device__ __forceinline__ void wait_all_vmem() { asm volatile("s_waitcnt vmcnt(
 
 __device__ __forceinline__ int swz(int row, int slot) { return slot ^ ((row >> 1) & 7); }
 
+// ABL != 0 builds ablation variants for tools/gemm_ablate (cdna_hip_programming.md 5.4 rule 17):
+//   1 no LDS-DMA after the prologue, 2 additionally no ds_reads in the loop (pure MFMA + barrier),
+//   3 loads + ds_reads but no MFMA, 4 full main loop without the epilogue stores
+template <int ABL, bool GENERIC>
 __global__ __launch_bounds__(512, 2) void tdnn_gemm_big_kernel(const TdnnKernelParams p, int m_tiles, int n_tiles) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -140,7 +144,26 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_big_kernel(const TdnnKernelP
   // one K step = up to 4 k-groups, software pipelined: fragments of group g+1 are read from LDS
   // while the 8 MFMAs of group g run; sched_barrier keeps the compiler from hoisting every
   // ds_read of the step to the top (which spills the accumulators)
+  Frags fa;
+  if (ABL == 2) load_frags(lds, lds + 2 * A_STAGE, 0, 0, fa);
   auto compute_step = [&](const unsigned char *Ab, const unsigned char *Bb, int d) {
+    if (ABL == 2) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) { mma_frags(fa); __builtin_amdgcn_sched_barrier(0); }
+      return;
+    }
+    if (ABL == 3) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        Frags f;
+        load_frags(Ab, Bb, d, g, f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(f.xf[i].x), "v"(f.xf[i].w));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(f.wf[j].x), "v"(f.wf[j].w));
+      }
+      return;
+    }
     Frags f0, f1;
     load_frags(Ab, Bb, d, 0, f0);
     load_frags(Ab, Bb, d, 1, f1);
@@ -167,8 +190,10 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_big_kernel(const TdnnKernelP
   for (int s = 0; s < nsteps; ++s) {
     int cn = c, tn = t + 1;
     if (tn == p.n_taps) { tn = 0; cn = c + 1; }
-    if (s + 1 < nsteps) issue_B(cn, tn, (s + 1) & 1);
-    if (t == 0 && c + 1 < nchunks) issue_A(c + 1, (c + 1) & 1);   // whole chunk of slack for the window
+    if (ABL != 1 && ABL != 2) {
+      if (s + 1 < nsteps) issue_B(cn, tn, (s + 1) & 1);
+      if (t == 0 && c + 1 < nchunks) issue_A(c + 1, (c + 1) & 1);   // whole chunk of slack for the window
+    }
     {
       const unsigned char *Ab = lds + (c & 1) * A_STAGE;
       const unsigned char *Bb = lds + 2 * A_STAGE + (s & 1) * B_STAGE;
@@ -183,6 +208,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_big_kernel(const TdnnKernelP
   // ---- epilogue --------------------------------------------------------------------------
   // acc[i][j][r]: frame = m0 + wm*128 + i*32 + lr, channel = n0 + wn*64 + j*32 + 8*(r>>2) + 4*lh + (r&3)
   unsigned char *scr = lds + wave * 16384;       // [128 frames][64 channels] bf16, 128-B rows, swizzled slots
+  const float act_lo = (p.act1 == ASV_ACT_RELU) ? 0.0f : -INFINITY;
   uint32_t vmask = 0;                            // bit i: this lane's frame of m-fragment i is a real frame
 #pragma unroll
   for (int i = 0; i < 4; ++i) vmask |= ((p.row_valid[(m0 + wm * 128 + i * 32) >> 5] >> lr) & 1u) << i;
@@ -203,10 +229,14 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_big_kernel(const TdnnKernelP
         float y[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float z = acc[i][j][q * 4 + e] + b[e];
-          z = p.affine_first ? apply_act(z * sc[e] + sh[e], p.act1) : apply_act(z, p.act1) * sc[e] + sh[e];
-          z = apply_act(z, p.act2);
-          y[e] = valid ? z : 0.0f;
+          if constexpr (GENERIC) {
+            float z = acc[i][j][q * 4 + e] + b[e];
+            z = p.affine_first ? apply_act(z * sc[e] + sh[e], p.act1) : apply_act(z, p.act1) * sc[e] + sh[e];
+            z = apply_act(z, p.act2);
+            y[e] = valid ? z : 0.0f;
+          } else {
+            y[e] = tdnn_epilogue_fast(acc[i][j][q * 4 + e], b[e], act_lo, sc[e], sh[e], valid);
+          }
         }
         uint2 pk;
         pk.x = pack_bf16x2(y[0], y[1]);
@@ -227,6 +257,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_big_kernel(const TdnnKernelP
       if (frow & 1) v = make_uint4(v.z, v.w, v.x, v.y);
       const int ch = n0 + wn * 64 + slot * 8;
       const int row = m0 + wm * 128 + frow;
+      if (ABL == 4) { asm volatile("" ::"v"(v.x), "v"(v.w)); continue; }
       if (ch < p.cout_store) *reinterpret_cast<uint4 *>(yg + (size_t)row * y_pitch + (size_t)ch * 2) = v;
     }
   }
@@ -245,7 +276,25 @@ int launch_tdnn_big(const TdnnKernelParams &p, hipStream_t s) {
     ASV_REQUIRE(p.taps[t] >= -kHalo && p.taps[t] <= kHalo, "tdnn(big): tap offset %d exceeds the %d-frame halo", p.taps[t], kHalo);
   const int m_tiles = p.rows / BM;
   const int n_tiles = round_up(p.cout_store, BN) / BN;
-  hipLaunchKernelGGL(tdnn_gemm_big_kernel, dim3(m_tiles * n_tiles), dim3(512), 0, s, p, m_tiles, n_tiles);
+  const dim3 grid(m_tiles * n_tiles), block(512);
+  const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first;
+  if (fast) hipLaunchKernelGGL((tdnn_gemm_big_kernel<0, false>), grid, block, 0, s, p, m_tiles, n_tiles);
+  else hipLaunchKernelGGL((tdnn_gemm_big_kernel<0, true>), grid, block, 0, s, p, m_tiles, n_tiles);
+  ASV_HIP_CHECK(hipGetLastError());
+  return ASV_OK;
+}
+
+int launch_tdnn_big_variant(const TdnnKernelParams &p, int variant, hipStream_t s) {
+  const int m_tiles = p.rows / BM, n_tiles = round_up(p.cout_store, BN) / BN;
+  const dim3 grid(m_tiles * n_tiles), block(512);
+  switch (variant) {
+    case 1: hipLaunchKernelGGL((tdnn_gemm_big_kernel<1, false>), grid, block, 0, s, p, m_tiles, n_tiles); break;
+    case 2: hipLaunchKernelGGL((tdnn_gemm_big_kernel<2, false>), grid, block, 0, s, p, m_tiles, n_tiles); break;
+    case 3: hipLaunchKernelGGL((tdnn_gemm_big_kernel<3, false>), grid, block, 0, s, p, m_tiles, n_tiles); break;
+    case 4: hipLaunchKernelGGL((tdnn_gemm_big_kernel<4, false>), grid, block, 0, s, p, m_tiles, n_tiles); break;
+    case 6: hipLaunchKernelGGL((tdnn_gemm_big_kernel<0, true>), grid, block, 0, s, p, m_tiles, n_tiles); break;
+    default: hipLaunchKernelGGL((tdnn_gemm_big_kernel<0, false>), grid, block, 0, s, p, m_tiles, n_tiles); break;
+  }
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }

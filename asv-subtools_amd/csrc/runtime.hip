@@ -164,9 +164,10 @@ int ensure(DevMem &m, size_t bytes, hipStream_t s, bool zero) {
 }
 
 struct Prof {
-  asv_net *net; hipStream_t s;
+  asv_net *net; hipStream_t s; bool active = false;
   int begin(int kclass, double flops, int op = -1) {
-    if (!net->profiling) return ASV_OK;
+    active = net->profiling != 0 && (net->profiling != 3 || kclass == K_TDNN);
+    if (!active) return ASV_OK;
     asv_net::Stamp st; st.kclass = kclass; st.flops = flops; st.op = op;
     for (hipEvent_t *e : {&st.a, &st.b}) {
       if (!net->event_pool.empty()) { *e = net->event_pool.back(); net->event_pool.pop_back(); }
@@ -177,7 +178,7 @@ struct Prof {
     return ASV_OK;
   }
   int end() {
-    if (!net->profiling) return ASV_OK;
+    if (!active) return ASV_OK;
     ASV_HIP_CHECK(hipEventRecord(net->stamps.back().b, s));
     return ASV_OK;
   }

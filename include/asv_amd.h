@@ -164,7 +164,8 @@ size_t asv_net_device_bytes(const asv_net_t *net);
 /* Name + average device time (ms, hipEvent on the extract stream) of the dominant kernel
  * class of the most recent profiled extract.  asv_net_set_profiling(1) makes extract record
  * events around every launch (costs a few us per launch); enable = 2 additionally keeps one
- * row per program op instead of one per kernel class. */
+ * row per program op instead of one per kernel class; enable = 3 records the GEMM launches only
+ * (the roofline's dominant kernel) to keep the instrumentation out of the other launch gaps. */
 int asv_net_set_profiling(asv_net_t *net, int enable);
 typedef struct asv_kernel_time {
   char     name[48];
