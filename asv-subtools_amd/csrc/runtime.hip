@@ -492,7 +492,7 @@ int asv_net_get_profile(asv_net_t *net, asv_kernel_time_t *rows, int cap, int *n
     ASV_HIP_CHECK(hipEventSynchronize(st.b));
     float ms = 0.0f;
     ASV_HIP_CHECK(hipEventElapsedTime(&ms, st.a, st.b));
-    const int op = net->profiling >= 2 ? st.op : -1;
+    const int op = net->profiling == 2 ? st.op : -1;
     auto it = agg.find({st.kclass, op});
     if (it == agg.end()) {
       asv_kernel_time_t row;

@@ -506,9 +506,13 @@ def trace(model, function, feat_dim):
         if h is not None and not getattr(type(mod), "_asv_amd_native", False):
             patched.append((mod, mod.__dict__.get("forward", None)))
             mod.forward = types.MethodType(lambda self, x, _h=h: _h(self, x), mod)
+    was_training = model.training
+    model.eval()                                   # framework.py:24 - extraction always runs in eval mode
     try:
         out = function(model, Sym(g, g.full_view(0), 3))
     finally:
+        if was_training:
+            model.train()
         for mod, old in patched:
             if old is None:
                 del mod.forward

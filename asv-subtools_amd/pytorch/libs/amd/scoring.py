@@ -1,0 +1,207 @@
+# -*- coding:utf-8 -*-
+"""Scoring back-end on the MI355X: cosine (sub-mean + length-norm + dot products), Kaldi-style
+PLDA (transform + log-likelihood ratio) and EER, through the C ABI of libasv_amd.so.
+
+Replaces the process chain the reference runs per scoring job (bash -> Kaldi binaries):
+    score/process.sh:156-203   ivector-mean, ivector-subtract-global-mean, ivector-normalize-length
+    score/score.sh:82-121      ivector-compute-dot-products, ivector-plda-scoring
+    computeEER.sh / computeEER-like-Bosaris.py:50-91
+and the numpy PLDA of score/pyplda/plda_base.py (EM training stays on the host in float64 -
+SURVEY.md 8(f) ranks GPU PLDA training as "next"; scoring is on the device).
+
+All functions take host numpy arrays or CUDA torch tensors; results stay on the device unless
+`.cpu()` is called by the caller.
+"""
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import capi
+
+
+def _dev(x, dtype=None, device=None):
+    import torch
+    if isinstance(x, torch.Tensor):
+        t = x
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(x))
+    if dtype is not None:
+        t = t.to(dtype)
+    if not t.is_cuda:
+        t = t.cuda() if device is None else t.to(device)
+    return t.contiguous()
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream(t):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def mean_vector(x):
+    """ivector-mean over all vectors (score/process.sh:177)."""
+    import torch
+    x = _dev(x, torch.float32)
+    out = torch.empty(x.shape[1], dtype=torch.float32, device=x.device)
+    capi.check(capi.lib().asv_mean_vec(_ptr(x), x.shape[0], x.shape[1], _ptr(out), _stream(x)), "asv_mean_vec")
+    return out
+
+
+def length_normalize(x, mean=None, normalize=True):
+    """[x - mean] then x / ||x|| (ivector-subtract-global-mean + ivector-normalize-length
+    --scaleup=false); returns a new device tensor."""
+    import torch
+    x = _dev(x, torch.float32).clone()
+    m = _dev(mean, torch.float32, x.device) if mean is not None else None
+    capi.check(capi.lib().asv_length_norm(_ptr(x), x.shape[0], x.shape[1], _ptr(m), int(normalize), _stream(x)), "asv_length_norm")
+    return x
+
+
+def score_matrix(enroll, test):
+    """All-pairs dot products S[i, j] = <enroll_i, test_j> (exact-f32 MFMA GEMM)."""
+    import torch
+    e, t = _dev(enroll, torch.float32), _dev(test, torch.float32)
+    assert e.shape[1] == t.shape[1]
+    out = torch.empty((e.shape[0], t.shape[0]), dtype=torch.float32, device=e.device)
+    capi.check(capi.lib().asv_dot_score_matrix(_ptr(e), e.shape[0], _ptr(t), t.shape[0], e.shape[1], _ptr(out), _stream(e)), "asv_dot_score_matrix")
+    return out
+
+
+def score_trials(enroll, test, enroll_idx, test_idx):
+    """Dot product per trial (ivector-compute-dot-products over a trial list)."""
+    import torch
+    e, t = _dev(enroll, torch.float32), _dev(test, torch.float32)
+    ei, ti = _dev(enroll_idx, torch.int32, e.device), _dev(test_idx, torch.int32, e.device)
+    out = torch.empty(ei.shape[0], dtype=torch.float32, device=e.device)
+    capi.check(capi.lib().asv_dot_score_trials(_ptr(e), _ptr(t), e.shape[1], _ptr(ei), _ptr(ti), ei.shape[0], _ptr(out), _stream(e)), "asv_dot_score_trials")
+    return out
+
+
+def cosine_trials(enroll, test, enroll_idx, test_idx, submean=None):
+    """The reference's cosine recipe: [submean] -> norm -> dot (scoreSets.sh "submean-norm" +
+    score.sh cosine).  `submean`: vector to subtract from both sides, or None."""
+    e = length_normalize(enroll, submean)
+    t = length_normalize(test, submean)
+    return score_trials(e, t, enroll_idx, test_idx)
+
+
+def eer(scores, labels):
+    """Equal error rate in percent + threshold (computeEER-like-Bosaris.py semantics)."""
+    import torch
+    s = _dev(scores, torch.float32)
+    l = _dev(labels, torch.int32, s.device)
+    e, thr = C.c_float(0), C.c_float(0)
+    capi.check(capi.lib().asv_eer(_ptr(s), _ptr(l), s.shape[0], C.byref(e), C.byref(thr), _stream(s)), "asv_eer")
+    return float(e.value), float(thr.value)
+
+
+# -------------------------------------------------------------------------------------- PLDA
+
+class Plda(object):
+    """Diagonalised PLDA model: y = transform (x - mean), between-class variances `psi`
+    (plda_base.py PLDA class, Kaldi ivector/plda.h)."""
+
+    def __init__(self, mean, transform, psi):
+        self.mean = np.asarray(mean, dtype=np.float64).reshape(-1)
+        self.transform = np.asarray(transform, dtype=np.float64)
+        self.psi = np.asarray(psi, dtype=np.float64).reshape(-1)
+        self.dim = self.mean.shape[0]
+
+    @classmethod
+    def from_covariances(cls, mean, within_var, between_var):
+        """Simultaneous diagonalisation (plda_base.py:302-335): inv(chol(W)), eigh."""
+        within_var = np.asarray(within_var, dtype=np.float64)
+        t1 = np.linalg.inv(np.linalg.cholesky(within_var))
+        s, U = np.linalg.eigh(t1.dot(np.asarray(between_var, dtype=np.float64)).dot(t1.T))
+        if s.min() <= 0:
+            raise ValueError("between-class covariance is not positive definite after whitening")
+        return cls(mean, U.T.dot(t1), s)
+
+    @classmethod
+    def read_stats_ark(cls, path):
+        """The 'mean' / 'within_var' / 'between_var' ark PldaEstimation.plda_write produces (337-342)."""
+        from libs.support import kaldi_io
+        parts = {k: np.array(v, dtype=np.float64) for k, v in kaldi_io.read_vec_flt_ark(path)}
+        dim = parts["mean"].shape[0]
+        return cls.from_covariances(parts["mean"], parts["within_var"].reshape(dim, dim), parts["between_var"].reshape(dim, dim))
+
+    def write_kaldi_text(self, path):
+        """Kaldi text <Plda> (plda_base.py:216-225) - what ivector-copy-plda / ivector-plda-scoring read."""
+        with open(path, "w") as f:
+            f.write("<Plda>  [ " + " ".join(map(str, self.mean)) + " ]\n [")
+            for row in self.transform:
+                f.write("\n  " + " ".join(map(str, row)))
+            f.write(" ]\n [ " + " ".join(map(str, self.psi)) + " ]\n</Plda> ")
+
+    def transform_vectors(self, x, num_examples=None, normalize_length=True, simple_length_norm=False):
+        """plda_base.py:93-107 for a whole set at once; returns a device tensor [n, dim]."""
+        import torch
+        x = _dev(x, torch.float32)
+        dev = x.device
+        mean = _dev(self.mean.astype(np.float32), device=dev)
+        tr = _dev(self.transform.astype(np.float32), device=dev)
+        psi = _dev(self.psi.astype(np.float32), device=dev)
+        ne = _dev(num_examples, torch.int32, dev) if num_examples is not None else None
+        mode = capi.PLDA_NORM_NONE if not normalize_length else (capi.PLDA_NORM_SIMPLE if simple_length_norm else capi.PLDA_NORM_PSI)
+        out = torch.empty((x.shape[0], self.dim), dtype=torch.float32, device=dev)
+        capi.check(capi.lib().asv_plda_transform(_ptr(x), x.shape[0], self.dim, _ptr(mean), _ptr(tr), _ptr(psi), _ptr(ne), mode, _ptr(out), _stream(x)),
+                   "asv_plda_transform")
+        return out
+
+    def llr_trials(self, enroll_t, test_t, enroll_idx, test_idx, enroll_num_utts=None):
+        """plda_base.py:109-136 per trial on already-transformed vectors."""
+        import torch
+        e, t = _dev(enroll_t, torch.float32), _dev(test_t, torch.float32)
+        dev = e.device
+        psi = _dev(self.psi.astype(np.float32), device=dev)
+        ei, ti = _dev(enroll_idx, torch.int32, dev), _dev(test_idx, torch.int32, dev)
+        en = _dev(enroll_num_utts, torch.int32, dev) if enroll_num_utts is not None else None
+        out = torch.empty(ei.shape[0], dtype=torch.float32, device=dev)
+        capi.check(capi.lib().asv_plda_llr_trials(_ptr(e), _ptr(t), self.dim, _ptr(psi), _ptr(en), _ptr(ei), _ptr(ti), ei.shape[0], _ptr(out), _stream(e)),
+                   "asv_plda_llr_trials")
+        return out
+
+
+def train_plda(vectors, labels, num_iters=10):
+    """PLDA EM (plda_base.py:37-81 stats, 248-300 EM) in float64 on the host, vectorised over the
+    classes that share an example count (one batched inverse per distinct count instead of one
+    per class).  Returns (mean, within_var, between_var)."""
+    x = np.asarray(vectors, dtype=np.float64)
+    labels = np.asarray(labels)
+    dim = x.shape[1]
+    classes, inv, counts = np.unique(labels, return_inverse=True, return_counts=True)
+    K = len(classes)
+    sums = np.zeros((K, dim))
+    np.add.at(sums, inv, x)
+    cmeans = sums / counts[:, None]
+    # offset_scatter = sum_k (X_k^T X_k - n_k m_k m_k^T)
+    offset_scatter = x.T.dot(x) - (cmeans * counts[:, None]).T.dot(cmeans)
+    class_weight = float(K)
+    example_weight = float(counts.sum())
+    gmean = cmeans.sum(axis=0) / class_weight
+    m = cmeans - gmean                                # [K, dim]
+    within, between = np.eye(dim), np.eye(dim)
+    for _ in range(num_iters):
+        w_stats = offset_scatter.copy()
+        w_count = example_weight - class_weight
+        b_stats = np.zeros((dim, dim))
+        b_count = 0.0
+        w_inv, b_inv = np.linalg.inv(within), np.linalg.inv(between)
+        for n in np.unique(counts):
+            sel = counts == n
+            k_n = int(sel.sum())
+            mix = np.linalg.inv(b_inv + n * w_inv)
+            w = (n * m[sel].dot(w_inv.T)).dot(mix.T)   # rows: mix . (n W^-1 m_k)
+            mw = m[sel] - w
+            b_stats += k_n * mix + w.T.dot(w)
+            b_count += k_n
+            w_stats += n * k_n * mix + n * mw.T.dot(mw)
+            w_count += k_n
+        within = w_stats / w_count
+        between = b_stats / b_count
+    return gmean, within, between

@@ -1,0 +1,99 @@
+# -*- coding:utf-8 -*-
+"""Multi-GPU extraction: one process per GPU, utterances sharded by length, embeddings collected
+with ONE all-gather (RCCL over xGMI on the GPU box, gloo in the CPU tests).
+
+The reference shards at the process level: `nj` jobs each run the Python extractor on a
+length-balanced split of feats.scp and the per-job xvector.JOB.scp files are concatenated
+(pipeline/extract_xvectors_for_pytorch.sh:90-100,125-151; splitDataByLength.sh:44-80).  Here
+the same partition is computed identically on every rank (it only depends on the utterance
+lengths), each rank extracts its shard, and `all_gather_into_tensor` replaces `cat`.  Utterances
+are independent in eval mode, so there is no other exchange on the path.
+
+The payload is tiny (VoxCeleb1-O: 4708 x 192 x 4 B = 3.6 MB in total), i.e. latency-bound: one
+collective for the whole run, never one per batch.
+"""
+
+import numpy as np
+
+
+def balance_by_length(lengths, n_shards):
+    """Length-balanced partition (the goal of splitDataByLength.sh:44-80): longest first, each
+    utterance goes to the shard with the fewest frames so far.  Deterministic: ties break on the
+    lower index / lower shard id.  Returns a list of index arrays (ascending inside a shard by
+    descending length, which is also the order the shard is batched in)."""
+    lengths = np.asarray(lengths, dtype=np.int64)
+    if n_shards < 1:
+        raise ValueError("n_shards must be >= 1")
+    order = np.argsort(-lengths, kind="stable")
+    loads = np.zeros(n_shards, dtype=np.int64)
+    shards = [[] for _ in range(n_shards)]
+    for idx in order:
+        s = int(np.argmin(loads))
+        shards[s].append(int(idx))
+        loads[s] += lengths[idx]
+    return [np.asarray(s, dtype=np.int64) for s in shards]
+
+
+def plan_batches(lengths, indices, max_frames=65536, max_utts=1024):
+    """Groups a shard's utterances (already length-sorted) into batches bounded by total frames
+    and count; neighbours have similar length, so the packed ragged batch wastes no padding."""
+    batches, cur, frames = [], [], 0
+    for i in indices:
+        n = int(lengths[i])
+        if cur and (frames + n > max_frames or len(cur) >= max_utts):
+            batches.append(cur)
+            cur, frames = [], 0
+        cur.append(int(i))
+        frames += n
+    if cur:
+        batches.append(cur)
+    return batches
+
+
+def gather_embeddings(local, local_indices, shards, group=None):
+    """local: [n_local, E] tensor of this rank's embeddings in `local_indices` order (== shards[rank]).
+    Returns [n_total, E] in original utterance order on every rank."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    n_total = int(sum(len(s) for s in shards))
+    E = local.shape[1]
+    if world == 1:
+        out = torch.empty((n_total, E), dtype=local.dtype, device=local.device)
+        out[torch.as_tensor(np.asarray(local_indices), device=local.device)] = local
+        return out
+    n_pad = max(len(s) for s in shards)
+    padded = torch.zeros((n_pad, E), dtype=local.dtype, device=local.device)
+    padded[:local.shape[0]] = local
+    gathered = torch.empty((world * n_pad, E), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(gathered, padded, group=group)
+    # every rank knows every shard's index list (same deterministic plan): no index exchange
+    src = np.concatenate([r * n_pad + np.arange(len(s)) for r, s in enumerate(shards)])
+    dst = np.concatenate([np.asarray(s) for s in shards])
+    out = torch.empty((n_total, E), dtype=local.dtype, device=local.device)
+    out[torch.as_tensor(dst, device=local.device)] = gathered[torch.as_tensor(src, device=local.device)]
+    return out
+
+
+def extract_sharded(extract_batch, lengths, load_utt, max_frames=65536, max_utts=1024, group=None, device=None):
+    """Full sharded extraction.
+        extract_batch(list_of_mats) -> [b, E] tensor on `device`     (e.g. Engine.extract_device wrapper)
+        load_utt(i) -> [T_i, D] float32 matrix of utterance i          (only called for this rank's shard)
+    Returns [n_total, E] (original order) on every rank."""
+    import torch
+    import torch.distributed as dist
+    inited = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank(group) if inited else 0
+    world = dist.get_world_size(group) if inited else 1
+    shards = balance_by_length(lengths, world)
+    mine = shards[rank]
+    outs = []
+    for batch in plan_batches(lengths, mine, max_frames, max_utts):
+        outs.append(extract_batch([load_utt(i) for i in batch]))
+    if outs:
+        local = torch.cat(outs, dim=0)
+    else:
+        raise ValueError("rank %d received no utterances (more ranks than utterances)" % rank)
+    if device is not None:
+        local = local.to(device)
+    return gather_embeddings(local, mine, shards, group=group)

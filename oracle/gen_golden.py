@@ -132,7 +132,64 @@ def main(argv):
             sys.exit("unknown case %s (have: %s)" % (n, ", ".join(list(CASES) + list(EXTRA_CASES))))
 
 
-EXTRA_CASES = {}     # scoring / resnet cases register themselves below
+def run_scoring_plda(name, synth):
+    """PLDA EM + transform + LLR of score/pyplda/plda_base.py, the two-covariance scorer of
+    gaussian-plda-scoring.py and the EER of computeEER-like-Bosaris.py, all executed from the
+    reference sources on a planted-speaker embedding set."""
+    import importlib.util
+    import numpy as np
+    import libs.support.kaldi_io as ref_kaldi_io
+    sys.modules["kaldi_io"] = ref_kaldi_io                       # SURVEY.md 8(c) shim 4
+    sys.path.insert(0, os.path.join(REF, "score", "pyplda"))
+    import plda_base as PB
+
+    def load(path, modname):
+        spec = importlib.util.spec_from_file_location(modname, path)
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+    argv, sys.argv = sys.argv, ["x"]
+    try:
+        bosaris = load(os.path.join(REF, "computeEER-like-Bosaris.py"), "ref_bosaris")
+        twocov = load(os.path.join(REF, "score", "pyplda", "gaussian-plda-scoring.py"), "ref_twocov")
+    finally:
+        sys.argv = argv
+
+    dim, n_spk, per_spk = 48, 120, 6
+    train, labels = synth.synth_speaker_embeddings(n_spk, per_spk, dim, seed=11, within=1.0, between=0.8)
+    train = train.astype(np.float64)
+    stats = PB.PldaStats(dim)
+    for spk in range(n_spk):
+        stats.add_samples(1.0, train[labels == spk])
+    assert stats.is_sorted()
+    est = PB.PldaEstimation(stats)
+    est.estimate(num_em_iters=5)
+    plda = est.get_output()
+    # plda_base.py keeps `offset` as a [dim,1] column (152-156); with the 1-D vectors that give
+    # `self.dim = ivector.shape[-1]` its intended value (Kaldi's dim) it must be 1-D too, otherwise
+    # numpy broadcasts T.x + offset to a [dim,dim] matrix.  Same numbers, intended shapes.
+    plda.offset = np.asarray(plda.offset).reshape(-1)
+
+    ev, ev_labels = synth.synth_speaker_embeddings(40, 5, dim, seed=12, within=1.0, between=0.8)
+    ei, ti, tgt = synth.synth_trials(ev_labels, 3000, seed=13)
+    ev64 = ev.astype(np.float64)
+    tr = np.stack([plda.transform_ivector(v, 1) for v in ev64])
+    llr = np.array([float(plda.log_likelihood_ratio(tr[a], 1, tr[b])) for a, b in zip(ei, ti)])
+    gamma, lam, c, k = twocov.CalculateVar(est.between_var, est.within_var + 5e-5 * np.eye(dim), est.mean)
+    tc = np.array([twocov.PLDAScoring(ev64[a].reshape(-1, 1), ev64[b].reshape(-1, 1), gamma, lam, c, k) for a, b in zip(ei, ti)])
+    rows = [[float(s), "target" if t else "nontarget"] for s, t in zip(llr, tgt)]
+    eer, thr = bosaris.compute_eer(rows)
+    out = dict(dim=np.int64(dim), n_spk=np.int64(n_spk), per_spk=np.int64(per_spk),
+               mean=np.asarray(est.mean).reshape(-1), within_var=est.within_var, between_var=est.between_var,
+               transform=plda.transform, psi=plda.psi, offset=np.asarray(plda.offset).reshape(-1),
+               transformed=tr, llr=llr, two_cov=tc, trials_e=ei, trials_t=ti, trials_tgt=tgt,
+               eer=np.float64(eer), eer_threshold=np.float64(thr))
+    path = os.path.join(GOLDEN, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote %s: %d trials, EER %.4f%% thr %.5f" % (path, len(llr), 100 * eer, thr))
+
+
+EXTRA_CASES = {"scoring_plda": run_scoring_plda}
 
 
 if __name__ == "__main__":

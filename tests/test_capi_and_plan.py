@@ -1,0 +1,134 @@
+"""The C ABI library loads, exports every declared symbol, and rejects malformed programs
+without a GPU; the recorder produces the expected programs for the target blueprints."""
+
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import helpers
+import ir_interp
+from helpers import rel_err
+
+
+def test_library_exports_every_declared_symbol(repo_root):
+    from libs.amd import capi
+    lib = capi.lib()
+    hdr = open(os.path.join(repo_root, "include", "asv_amd.h")).read()
+    declared = sorted(set(re.findall(r"\b(asv_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared and set(declared) == set(capi.SYMBOLS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.asv_version() >= 100
+    assert isinstance(lib.asv_last_error(), bytes)
+
+
+def test_struct_layouts_match_the_c_header(repo_root, tmp_path):
+    """sizeof / field offsets of every ABI struct as a C compiler sees include/asv_amd.h == ctypes."""
+    import subprocess
+    from libs.amd import capi
+    src = tmp_path / "sizes.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "asv_amd.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu\n", sizeof(asv_tdnn_desc_t), sizeof(asv_pool_desc_t), sizeof(asv_attpool_desc_t), sizeof(asv_eltwise_desc_t), sizeof(asv_kernel_time_t));
+  printf("%zu %zu %zu %zu\n", offsetof(asv_tdnn_desc_t, weight), offsetof(asv_tdnn_desc_t, scale), offsetof(asv_tdnn_desc_t, res_ch_off), offsetof(asv_eltwise_desc_t, scale));
+  printf("%zu %zu\n", offsetof(asv_kernel_time_t, total_ms), offsetof(asv_kernel_time_t, flops));
+  return 0;
+}''')
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-I", os.path.join(repo_root, "include"), str(src), "-o", str(exe)])
+    lines = subprocess.check_output([str(exe)], text=True).split("\n")
+    sizes = [int(v) for v in lines[0].split()]
+    assert sizes == [C.sizeof(capi.TdnnDesc), C.sizeof(capi.PoolDesc), C.sizeof(capi.AttPoolDesc), C.sizeof(capi.EltwiseDesc), C.sizeof(capi.KernelTime)]
+    offs = [int(v) for v in lines[1].split()]
+    assert offs == [capi.TdnnDesc.weight.offset, capi.TdnnDesc.scale.offset, capi.TdnnDesc.res_ch_off.offset, capi.EltwiseDesc.scale.offset]
+    assert [int(v) for v in lines[2].split()] == [capi.KernelTime.total_ms.offset, capi.KernelTime.flops.offset]
+
+
+def test_no_gpu_calls_fail_loudly_not_silently():
+    from libs.amd import capi
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only behaviour")
+    lib = capi.lib()
+    net = C.c_void_p()
+    rc = lib.asv_net_create(C.byref(net), 0, capi.PREC_F32, 0, 30)
+    assert rc < 0 and lib.asv_last_error()
+    with pytest.raises(capi.AsvError):
+        capi.check(rc, "asv_net_create")
+
+
+def test_xvector_program_shape():
+    from libs.amd import ir
+    model = helpers.build_model("xvector.py", "Xvector(80,10,training=False)")
+    g = ir.trace(model, type(model).extract_embedding.__wrapped_body__, 80)
+    kinds = [op.kind for op in g.ops]
+    assert kinds == ["tdnn"] * 5 + ["pool", "tdnn"]
+    assert [op.taps for op in g.ops if op.kind == "tdnn"][:3] == [[-2, -1, 0, 1, 2], [-2, 0, 2], [-3, 0, 3]]
+    per_frame, per_utt = g.flops_per_frame()
+    assert per_frame == 2 * 2807808 and per_utt == 2 * 3000 * 512       # SURVEY.md 8(d) MAC breakdown
+
+
+def test_ecapa_program_has_no_copies_but_the_res2_passthrough():
+    from libs.amd import ir
+    model = helpers.build_model("ecapa_tdnn_xvector.py", "ECAPA_TDNN(80,10,training=False)")
+    g = ir.trace(model, type(model).extract_embedding.__wrapped_body__, 80)
+    kinds = [op.kind for op in g.ops]
+    assert "cat" not in kinds
+    copies = [op for op in g.ops if op.kind == "eltwise" and op.b is None and op.seg_scale is None and op.scale is None]
+    assert len(copies) == 3 and all(op.a.channels == 128 for op in copies)      # group 0 of each Res2Net block
+    # the 3C->128 attention conv was split: per-frame part reads 1536 channels + a per-utterance bias
+    att = [op for op in g.ops if op.kind == "tdnn" and op.seg_bias is not None]
+    assert len(att) == 1 and att[0].inp.channels == 1536 and att[0].act2 == "tanh"
+    # Res2 branches take (previous branch + next group) as a fused second input
+    assert sum(1 for op in g.ops if op.kind == "tdnn" and op.inp2 is not None) == 18
+
+
+@pytest.mark.parametrize("name,limit", [("ecapa_c3", 3), ("ecapa_launcher", 2), ("ecapa_c512_fc1_far", 2), ("ecapa_c512_near_affine", 2)])
+def test_ecapa_traced_program_reproduces_reference_on_cpu(name, limit):
+    from libs.amd import ir
+    g, sd, model = helpers.golden_model(name)
+    graph = ir.trace(model, type(model).extract_embedding.__wrapped_body__, int(g["dim"]))
+    for x, ref in list(zip(helpers.golden_feats(g), g["embeddings"]))[:limit]:
+        assert rel_err(ir_interp.extract(graph, x), ref) < 2e-5
+
+
+REF_MODEL_DIR = "/root/reference/pytorch/model"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_MODEL_DIR), reason="reference tree only exists in the build container")
+@pytest.mark.parametrize("blueprint,creation,golden", [("xvector.py", "Xvector(30,10,training=False)", "xvector_c1"),
+                                                       ("ecapa_tdnn_xvector.py", "ECAPA_TDNN(80,10,training=False)", "ecapa_c3")])
+def test_unmodified_reference_blueprints_run_on_this_libs_nnet(blueprint, creation, golden):
+    """Drop-in check: the reference's OWN blueprint files import this package's `libs.nnet`,
+    build, load the checkpoint keys and record to a program that reproduces the reference."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, os, types
+sys.dont_write_bytecode = True
+for n, attrs in (("tkinter", {"N": None}), ("tkinter.messagebox", {"NO": None}), ("turtle", {"xcor": None})):
+    m = types.ModuleType(n); m.__dict__.update(attrs); m.__path__ = []; sys.modules[n] = m
+sys.path[:0] = [%(repo)r + "/tests", %(repo)r, %(repo)r + "/asv-subtools_amd/pytorch"]
+import numpy as np, torch
+import helpers, ir_interp
+import libs.support.utils as utils
+from libs.amd import ir
+g, sd = helpers.golden_state_dict(%(golden)r)
+model = utils.create_model_from_py(%(ref)r + "/" + %(bp)r, %(creation)r)
+assert type(model).__module__ in ("xvector", "ecapa_tdnn_xvector") and %(ref)r in sys.modules[type(model).__module__].__file__
+model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+graph = ir.trace(model, type(model).extract_embedding.__wrapped_body__, int(g["dim"]))
+x = helpers.golden_feats(g)[0]
+err = helpers.rel_err(ir_interp.extract(graph, x), g["embeddings"][0])
+print("ERR", err)
+assert err < 2e-5
+''' % dict(repo=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ref=REF_MODEL_DIR, bp=blueprint, creation=creation, golden=golden)
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", PYTHONPYCACHEPREFIX="/tmp/pyc_ref")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr

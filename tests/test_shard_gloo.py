@@ -1,0 +1,84 @@
+"""N > 1 path on CPU: world_size-2 gloo processes shard utterances by length, "extract" with a
+deterministic stand-in and collect with the same all-gather code the GPU run uses."""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from libs.amd import shard
+
+
+def test_balance_by_length_is_a_balanced_partition():
+    r = np.random.RandomState(0)
+    lengths = r.randint(200, 1001, size=997)
+    for n in (1, 2, 3, 8):
+        shards = shard.balance_by_length(lengths, n)
+        allidx = np.sort(np.concatenate(shards))
+        assert np.array_equal(allidx, np.arange(len(lengths)))
+        loads = np.array([lengths[s].sum() for s in shards])
+        assert loads.max() - loads.min() <= lengths.max()          # LPT bound
+        for s in shards:                                           # inside a shard: longest first
+            assert np.all(np.diff(lengths[s]) <= 0)
+
+
+def test_plan_batches_respects_limits():
+    lengths = np.array([500, 400, 300, 300, 200, 100, 100])
+    batches = shard.plan_batches(lengths, np.arange(7), max_frames=900, max_utts=3)
+    assert batches == [[0, 1], [2, 3, 4], [5, 6]]
+    assert shard.plan_batches(lengths, [0], max_frames=10, max_utts=1) == [[0]]     # an over-long utterance still gets a batch
+
+
+def _fake_embedding(mat, dim=16):
+    # deterministic, length- and content-dependent stand-in for the extractor
+    v = np.zeros(dim, dtype=np.float32)
+    v[: min(dim, mat.shape[1])] = mat.mean(axis=0)[:dim]
+    v[-1] = mat.shape[0]
+    return v
+
+
+def _worker(rank, world, port, lengths, out_dir):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from libs.amd import synth
+        load = lambda i: synth.synth_feats(int(lengths[i]), 8, 100 + i)
+        extract = lambda mats: torch.from_numpy(np.stack([_fake_embedding(m) for m in mats]))
+        out = shard.extract_sharded(extract, lengths, load, max_frames=2000, max_utts=4)
+        np.save(os.path.join(out_dir, "rank%d.npy" % rank), out.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_extraction_gathers_in_original_order(tmp_path, world):
+    import torch.multiprocessing as mp
+    from libs.amd import synth
+    lengths = np.random.RandomState(5).randint(20, 400, size=37)
+    mp.spawn(_worker, args=(world, _free_port(), lengths, str(tmp_path)), nprocs=world, join=True)
+    want = np.stack([_fake_embedding(synth.synth_feats(int(n), 8, 100 + i)) for i, n in enumerate(lengths)])
+    for r in range(world):
+        got = np.load(tmp_path / ("rank%d.npy" % r))
+        assert got.shape == want.shape and np.array_equal(got, want), "rank %d" % r
+
+
+def test_single_process_gather_is_a_permutation():
+    import torch
+    lengths = np.array([5, 9, 2, 7])
+    shards = shard.balance_by_length(lengths, 1)
+    local = torch.arange(4, dtype=torch.float32)[:, None] * torch.ones(1, 3)
+    out = shard.gather_embeddings(local, shards[0], shards)
+    # local row j holds utterance shards[0][j]
+    assert [int(out[i, 0]) for i in shards[0]] == [0, 1, 2, 3]
