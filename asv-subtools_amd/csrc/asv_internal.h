@@ -66,6 +66,7 @@ struct TdnnKernelParams {
   // segmented by utterance; see kernels_tdnn.hip
   float *pool_partial;
   const void *zero16;   // >= 16 bytes of device zeros: source of masked direct-to-LDS loads
+  const void *wfrag;    // bf16 weights in MFMA-fragment order [n_frag32][tap][chunk64][k_group][lane][8] or nullptr
   // split-K (small-M layers: the pooled domain): blockIdx.y walks `ksplit` slices of the channel
   // chunks, raw f32 accumulators go to partial[slice][rows][ld_partial]; a second kernel sums
   // the slices in order and applies the epilogue (deterministic, no atomics)
@@ -78,14 +79,18 @@ struct TdnnKernelParams {
   int n_taps;
   int taps[ASV_MAX_TAPS];
   int act1, act2, affine_first;
+  int halo;             // max |tap offset| of this layer (selects the window size of the 128x128 kernel)
 };
 
 struct PoolKernelParams {
   const void *x;  int ldx;  int channels;
   const int32_t *seg_row0;   // [segments] first row of the segment
-  const int32_t *seg_len;    // [segments]
+  const int32_t *seg_len;    // [segments] rows of the segment
   float *out; int ld_out;    // utts-domain row pitch
   int stddev, unbiased, var_mode; float eps;
+  // grid (2-D) inputs: `groups` frequency bins are pooled separately over time; bin g reads rows
+  // row0 + g + k*row_stride (k < len/row_stride) and writes columns [g*C*(1+stddev), ...) of the row
+  int row_stride, groups;
 };
 
 // launchers (kernels_*.hip).  ElemBF16: activations are bf16 (else f32).
@@ -98,12 +103,31 @@ constexpr int kBigTileN = 256;
 bool tdnn_big_supported(const TdnnKernelParams &p, bool bf16, bool out_f32);
 int launch_tdnn_big(const TdnnKernelParams &p, hipStream_t s);
 int launch_tdnn_big_variant(const TdnnKernelParams &p, int variant, hipStream_t s);   // ablations, tools/gemm_ablate
+// variant 3: feature window via LDS-DMA ring, weight fragments straight from L2 (kernels_tdnn_v3.hip)
+bool tdnn_big3_supported(const TdnnKernelParams &p, bool bf16, bool out_f32);
+int launch_tdnn_big3(const TdnnKernelParams &p, hipStream_t s);
+int launch_tdnn_big3_variant(const TdnnKernelParams &p, int variant, hipStream_t s);
+void pack_tdnn_weight_frags(const float *w, int out_ch, int in_ch, int tot_ctx, int left_ctx, const int *taps, int n_taps,
+                            int cout_pad, int cin_pad, uint16_t *dst);
+size_t tdnn_weight_frag_elems(int cout_pad, int cin_pad, int n_taps);
 int launch_stats_pool(const PoolKernelParams &p, int segments, bool bf16, hipStream_t s);
 int launch_attentive_pool(const void *x, int ldx, const void *logits, int ldl, int channels,
                           const int32_t *seg_row0, const int32_t *seg_len, int segments, float eps,
                           float *out, int ld_out, bool bf16, hipStream_t s);
-int launch_rowmap(const int32_t *seg_row0, const int32_t *seg_len, int segments, int rows,
+// row r of a segment is valid iff (r - row0) % pitch < width (frames domain: pitch = width = 1)
+int launch_rowmap(const int32_t *seg_row0, const int32_t *seg_len, int segments, int rows, int pitch, int width,
                   int32_t *row_seg, uint32_t *row_valid, hipStream_t s);
+// frames-domain feature rows [t][f] -> grid rows (t*pitch + f) with one channel (pitch of `out` = ldo)
+int launch_grid_from_frames(const void *x, int ldx, int feat_dim, const int32_t *fr_row0, const int32_t *g_row0, const int32_t *g_row_seg,
+                            const uint32_t *g_row_valid, int g_rows, int pitch, void *out, int ldo, bool bf16, hipStream_t s);
+// im2col gather between grid domains: out[(t',f')][k*C + c] = in[(stride*t'+dt_k, stride*f'+df_k)][c] or 0
+struct Im2colParams {
+  const void *in; void *out; int ldi, ldo, channels, n_taps, stride;
+  int dt[ASV_MAX_TAPS], df[ASV_MAX_TAPS];
+  const int32_t *in_row0, *in_len, *out_row0, *out_row_seg; const uint32_t *out_row_valid;
+  int in_pitch, in_width, out_pitch, out_rows;
+};
+int launch_im2col(const Im2colParams &p, bool bf16, hipStream_t s);
 int launch_pack_input(const float *feats, int feat_dim, const int32_t *seg_src0, const int32_t *seg_row0,
                       const int32_t *row_seg, int rows, void *x, int ldx, bool bf16, hipStream_t s);
 int launch_unpack_rows(const void *y, int ldy, int channels, const int32_t *seg_src0, const int32_t *seg_row0,
@@ -116,6 +140,7 @@ struct EltwiseKernelParams {
   const float *scale, *shift;          // per-channel affine on a (or nullptr)
   const float *seg_scale; int ld_segscale;
   const int32_t *row_seg; const uint32_t *row_valid;   // nullptr in the utts domain
+  int act;                             // activation applied to the final sum
 };
 int launch_eltwise(const EltwiseKernelParams &p, bool bf16, hipStream_t s);
 

@@ -10,7 +10,7 @@ namespace {
 // ---------------------------------------------------------------------------------------
 // row map: for every padded row, which segment it belongs to (-1: gap) + a validity bitmask
 __global__ __launch_bounds__(256) void rowmap_kernel(const int32_t *seg_row0, const int32_t *seg_len, int segments,
-                                                     int rows, int32_t *row_seg, uint32_t *row_valid) {
+                                                     int rows, int pitch, int width, int32_t *row_seg, uint32_t *row_valid) {
   const int row = blockIdx.x * 256 + threadIdx.x;      // rows is a multiple of 128; grid covers it in 64-row waves
   int seg = -1;
   if (row < rows) {
@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void rowmap_kernel(const int32_t *seg_row0, co
       const int mid = (lo + hi) >> 1;
       if (seg_row0[mid] <= row) lo = mid; else hi = mid;
     }
-    if (segments > 0 && seg_row0[lo] <= row && row < seg_row0[lo] + seg_len[lo]) seg = lo;
+    if (segments > 0 && seg_row0[lo] <= row && row < seg_row0[lo] + seg_len[lo] && (row - seg_row0[lo]) % pitch < width) seg = lo;
     row_seg[row] = seg;
   }
   const unsigned long long b = __ballot(seg >= 0);
@@ -124,9 +124,12 @@ __device__ __forceinline__ void load_vec(const void *base, size_t idx, float (&v
   }
 }
 
-// StatisticsPooling (reference libs/nnet/pooling.py:58-67): mean over the segment's frames,
-// TWO-pass variance about that mean (same arithmetic as the reference; the second pass hits
-// L2), std = sqrt(max(var, eps)) or sqrt(var + eps).  grid = (ceil(C/64), segments).
+// StatisticsPooling (reference libs/nnet/pooling.py:58-67): mean and variance over the segment's
+// frames in ONE pass over HBM.  The reference is two-pass (mean, then sum (x-mean)^2); here each
+// channel accumulates sum(x-c) and sum((x-c)^2) about the pivot c = the channel's value in the
+// segment's first frame, which keeps the one-pass form  var = E[(x-c)^2] - (E[x-c])^2  well
+// conditioned (the pivot is within a few std of the mean), then std = sqrt(max(var, eps)) or
+// sqrt(var + eps).  grid = (ceil(C/64), segments).
 template <bool BF16>
 __global__ __launch_bounds__(256) void stats_pool_kernel(const PoolKernelParams p) {
   constexpr int VEC = BF16 ? 8 : 4;
@@ -135,50 +138,57 @@ __global__ __launch_bounds__(256) void stats_pool_kernel(const PoolKernelParams 
   __shared__ float sm[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cg = lane % CG, rs = lane / CG;
-  const int seg = blockIdx.y, ch = blockIdx.x * 64 + cg * VEC;
-  const int row0 = p.seg_row0[seg], len = p.seg_len[seg];
+  const int seg = blockIdx.y / p.groups, grp = blockIdx.y % p.groups, ch = blockIdx.x * 64 + cg * VEC;
+  const int row0 = p.seg_row0[seg] + grp, len = p.seg_len[seg] / p.row_stride;      // rows row0 + k*row_stride, k < len
+  const size_t rstep = (size_t)p.row_stride * p.ldx;
   const bool active = ch < round_up_dev(p.channels, kChanAlign);
 
-  float s[VEC];
+  float pivot[VEC], s[VEC], q[VEC];
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) s[i] = 0.0f;
-  if (active)
-    for (int r = wave * RS + rs; r < len; r += 4 * RS) {
-      float v[VEC];
-      load_vec<BF16, VEC>(p.x, (size_t)(row0 + r) * p.ldx + ch, v);
+  for (int i = 0; i < VEC; ++i) { pivot[i] = 0.0f; s[i] = 0.0f; q[i] = 0.0f; }
+  if (active) {
+    load_vec<BF16, VEC>(p.x, (size_t)row0 * p.ldx + ch, pivot);
+    // 4 independent row streams per lane keep enough 16-byte loads in flight
+    int r = wave * RS + rs;
+    for (; r + 3 * 4 * RS < len; r += 4 * 4 * RS) {
+      float v0[VEC], v1[VEC], v2[VEC], v3[VEC];
+      const size_t base = (size_t)row0 * p.ldx + ch;
+      load_vec<BF16, VEC>(p.x, base + (size_t)r * rstep, v0);
+      load_vec<BF16, VEC>(p.x, base + (size_t)(r + 4 * RS) * rstep, v1);
+      load_vec<BF16, VEC>(p.x, base + (size_t)(r + 8 * RS) * rstep, v2);
+      load_vec<BF16, VEC>(p.x, base + (size_t)(r + 12 * RS) * rstep, v3);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) s[i] += v[i];
-    }
-  block_reduce_rows<VEC, CG>(s, sm, wave, cg, rs);
-  float mean[VEC];
-#pragma unroll
-  for (int i = 0; i < VEC; ++i) mean[i] = s[i] / (float)len;
-
-  float q[VEC];
-#pragma unroll
-  for (int i = 0; i < VEC; ++i) q[i] = 0.0f;
-  if (p.stddev) {
-    if (active)
-      for (int r = wave * RS + rs; r < len; r += 4 * RS) {
-        float v[VEC];
-        load_vec<BF16, VEC>(p.x, (size_t)(row0 + r) * p.ldx + ch, v);
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) { const float dlt = v[i] - mean[i]; q[i] += dlt * dlt; }
+      for (int i = 0; i < VEC; ++i) {
+        const float d0 = v0[i] - pivot[i], d1 = v1[i] - pivot[i], d2 = v2[i] - pivot[i], d3 = v3[i] - pivot[i];
+        s[i] += (d0 + d1) + (d2 + d3);
+        q[i] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
       }
-    block_reduce_rows<VEC, CG>(q, sm, wave, cg, rs);
+    }
+    for (; r < len; r += 4 * RS) {
+      float v[VEC];
+      load_vec<BF16, VEC>(p.x, (size_t)row0 * p.ldx + ch + (size_t)r * rstep, v);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { const float d = v[i] - pivot[i]; s[i] += d; q[i] += d * d; }
+    }
   }
+  block_reduce_rows<VEC, CG>(s, sm, wave, cg, rs);
+  if (p.stddev) block_reduce_rows<VEC, CG>(q, sm, wave, cg, rs);
   if (wave == 0 && rs == 0 && active) {
-    float counts = (float)len;
+    const float n = (float)len;
+    float counts = n;
     if (p.unbiased == 1 && len > 1) counts = (float)(len - 1);      // pooling.py:63-64
     if (p.unbiased == 2) counts = (float)(len - 1);                 // torch.var default (ECAPA), NaN at len 1 like torch
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       if (ch + i >= p.channels) continue;
-      p.out[(size_t)seg * p.ld_out + ch + i] = mean[i];
+      const float dmean = s[i] / n;
+      const size_t ocol = (size_t)grp * p.channels * (p.stddev ? 2 : 1);
+      p.out[(size_t)seg * p.ld_out + ocol + ch + i] = pivot[i] + dmean;
       if (p.stddev) {
-        const float var = q[i] / counts;
+        // sum (x-mean)^2 = sum (x-c)^2 - n (mean-c)^2
+        const float var = fmaxf(q[i] - n * dmean * dmean, 0.0f) / counts;
         const float sd = (p.var_mode == ASV_POOL_VAR_ADD) ? sqrtf(var + p.eps) : sqrtf(fmaxf(var, p.eps));
-        p.out[(size_t)seg * p.ld_out + p.channels + ch + i] = sd;
+        p.out[(size_t)seg * p.ld_out + ocol + p.channels + ch + i] = sd;
       }
     }
   }
@@ -281,8 +291,7 @@ __global__ __launch_bounds__(256) void eltwise_kernel(const EltwiseKernelParams 
       for (int i = 0; i < VEC; ++i) o[i] += t[i];
     }
 #pragma unroll
-    for (int i = 0; i < VEC; ++i)
-      if (ch + i >= p.channels) o[i] = 0.0f;
+    for (int i = 0; i < VEC; ++i) o[i] = (ch + i >= p.channels) ? 0.0f : apply_act(o[i], p.act);
   } else {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) o[i] = 0.0f;
@@ -320,11 +329,76 @@ __global__ __launch_bounds__(256) void combine_kernel(const float *seg_emb, int 
   out[(size_t)u * embed_dim + e] = __fdiv_rn(__fadd_rn(acc, last), (float)total);
 }
 
+// ---------------------------------------------------------------------------------------
+// 2-D (grid) domains: rows are (time, frequency) positions, frequency fastest, `pitch` rows per frame
+// (pitch - width zero rows between frames = the frequency zero padding of a 3x3 convolution).
+
+// frames-domain feature rows [t][f] -> grid rows t*pitch + f with ONE channel (ResNet input unsqueeze)
+template <bool BF16>
+__global__ __launch_bounds__(256) void grid_from_frames_kernel(const void *x, int ldx, int feat_dim, const int32_t *fr_row0, const int32_t *g_row0,
+                                                               const int32_t *g_row_seg, const uint32_t *g_row_valid, int g_rows, int pitch,
+                                                               void *out, int ldo) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= g_rows) return;
+  float v = 0.0f;
+  if ((g_row_valid[row >> 5] >> (row & 31)) & 1u) {
+    const int seg = g_row_seg[row], rel = row - g_row0[seg];
+    const int t = rel / pitch, f = rel % pitch;
+    if (f < feat_dim) v = load_elem<BF16>(x, (size_t)(fr_row0[seg] + t) * ldx + f);
+  }
+  // channel 0 carries the value, the pad channels of the 16-wide pitch stay zero
+  for (int c = 0; c < ldo; ++c) store_elem<BF16>(out, (size_t)row * ldo + c, c == 0 ? v : 0.0f);
+}
+
+// im2col gather for strided convolutions: one thread per (output row, tap, 16-byte piece)
+template <bool BF16>
+__global__ __launch_bounds__(256) void im2col_kernel(const Im2colParams p) {
+  constexpr int VEC = BF16 ? 8 : 4;
+  const int pieces = p.channels / VEC;                  // channels is a multiple of 16
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long per_row = (long long)p.n_taps * pieces;
+  if (gid >= (long long)p.out_rows * per_row) return;
+  const int row = (int)(gid / per_row), rem = (int)(gid % per_row), k = rem / pieces, piece = rem % pieces;
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if ((p.out_row_valid[row >> 5] >> (row & 31)) & 1u) {
+    const int seg = p.out_row_seg[row], rel = row - p.out_row0[seg];
+    const int t = (rel / p.out_pitch) * p.stride + p.dt[k], f = (rel % p.out_pitch) * p.stride + p.df[k];
+    const int in_frames = p.in_len[seg] / p.in_pitch;
+    if (t >= 0 && t < in_frames && f >= 0 && f < p.in_width) {
+      const size_t src = (size_t)(p.in_row0[seg] + t * p.in_pitch + f) * p.ldi + (size_t)piece * VEC;
+      if constexpr (BF16) v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(p.in) + src);
+      else v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const float *>(p.in) + src);
+    }
+  }
+  const size_t dst = (size_t)row * p.ldo + (size_t)k * p.channels + (size_t)piece * VEC;
+  if constexpr (BF16) *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(p.out) + dst) = v;
+  else *reinterpret_cast<uint4 *>(reinterpret_cast<float *>(p.out) + dst) = v;
+}
+
 }  // namespace
 
-int launch_rowmap(const int32_t *seg_row0, const int32_t *seg_len, int segments, int rows, int32_t *row_seg,
+int launch_grid_from_frames(const void *x, int ldx, int feat_dim, const int32_t *fr_row0, const int32_t *g_row0, const int32_t *g_row_seg,
+                            const uint32_t *g_row_valid, int g_rows, int pitch, void *out, int ldo, bool bf16, hipStream_t s) {
+  const dim3 grid((g_rows + 255) / 256), block(256);
+  if (bf16) hipLaunchKernelGGL(grid_from_frames_kernel<true>, grid, block, 0, s, x, ldx, feat_dim, fr_row0, g_row0, g_row_seg, g_row_valid, g_rows, pitch, out, ldo);
+  else hipLaunchKernelGGL(grid_from_frames_kernel<false>, grid, block, 0, s, x, ldx, feat_dim, fr_row0, g_row0, g_row_seg, g_row_valid, g_rows, pitch, out, ldo);
+  ASV_HIP_CHECK(hipGetLastError());
+  return ASV_OK;
+}
+
+int launch_im2col(const Im2colParams &p, bool bf16, hipStream_t s) {
+  const int vec = bf16 ? 8 : 4;
+  const long long n = (long long)p.out_rows * p.n_taps * (p.channels / vec);
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (bf16) hipLaunchKernelGGL(im2col_kernel<true>, grid, block, 0, s, p);
+  else hipLaunchKernelGGL(im2col_kernel<false>, grid, block, 0, s, p);
+  ASV_HIP_CHECK(hipGetLastError());
+  return ASV_OK;
+}
+
+int launch_rowmap(const int32_t *seg_row0, const int32_t *seg_len, int segments, int rows, int pitch, int width, int32_t *row_seg,
                   uint32_t *row_valid, hipStream_t s) {
-  hipLaunchKernelGGL(rowmap_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, seg_row0, seg_len, segments, rows, row_seg, row_valid);
+  hipLaunchKernelGGL(rowmap_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, seg_row0, seg_len, segments, rows, pitch, width, row_seg, row_valid);
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }
@@ -352,7 +426,7 @@ int launch_unpack_rows(const void *y, int ldy, int channels, const int32_t *seg_
 
 int launch_stats_pool(const PoolKernelParams &p, int segments, bool bf16, hipStream_t s) {
   if (segments <= 0) return ASV_OK;
-  const dim3 grid((p.channels + 63) / 64, segments), block(256);
+  const dim3 grid((p.channels + 63) / 64, segments * p.groups), block(256);
   if (bf16) hipLaunchKernelGGL(stats_pool_kernel<true>, grid, block, 0, s, p);
   else hipLaunchKernelGGL(stats_pool_kernel<false>, grid, block, 0, s, p);
   ASV_HIP_CHECK(hipGetLastError());

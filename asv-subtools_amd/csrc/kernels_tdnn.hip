@@ -23,25 +23,36 @@
 //     instruction cancels out.
 //   * Global->register prefetch of the next step is issued before the MFMAs of the current
 //     step and written to the other LDS stage after them (one barrier per step).
+#include <algorithm>
+#include <cstdlib>
+
 #include "device_utils.h"
 
 namespace asv {
 namespace {
 
 constexpr int BM = 128, BN = 128;
-constexpr int WIN = BM + 2 * kHalo;           // 136 staged frames
 constexpr int ROWB = 128;                     // bytes per LDS row = one K chunk
-constexpr int A_STAGE = WIN * ROWB;           // 17408
 constexpr int B_STAGE = BN * ROWB;            // 16384
-constexpr int LDS_BYTES = 2 * A_STAGE + 2 * B_STAGE;   // 67584 -> 2 workgroups / CU
-constexpr int A_PIECES = WIN * 8;             // 1088 16-byte pieces per window
+constexpr int kWideHalo = 84;                 // window halo of the 2-D (grid) instantiations: |tap| <= pitch + 1 <= 84
+// window geometry for a given halo: HALO = 4 -> 136 rows, 67.6 KB of LDS, 2 workgroups / CU;
+// HALO = 84 (3x3 convolutions over row-flattened (time, frequency) grids) -> 296 rows, 108.5 KB
+template <int HALO> struct Geom {
+  static constexpr int WIN = BM + 2 * HALO;
+  static constexpr int A_STAGE = WIN * ROWB;
+  static constexpr int LDS_BYTES = 2 * A_STAGE + 2 * B_STAGE;
+  static constexpr int A_PIECES = WIN * 8;
+  static constexpr int NA = (A_PIECES + 255) / 256;      // 16-byte window pieces per thread
+};
 static_assert(kRowTile % BM == 0, "row padding must be a multiple of the M tile");
 
 __device__ __forceinline__ int swz(int row, int slot) { return slot ^ ((row >> 1) & 7); }
 
-template <bool BF16, bool OUT_BF16, bool GENERIC>
-__global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const TdnnKernelParams p, int m_tiles, int n_tiles) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+template <bool BF16, bool OUT_BF16, bool GENERIC, int HALO>
+__global__ __launch_bounds__(256, HALO <= 4 ? 2 : 1) void tdnn_gemm_kernel(const TdnnKernelParams p, int m_tiles, int n_tiles) {
+  using G = Geom<HALO>;
+  constexpr int A_STAGE = G::A_STAGE, A_PIECES = G::A_PIECES, NA = G::NA;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS_BYTES];
   constexpr int ES = BF16 ? 2 : 4;          // element bytes
   constexpr int BK = ROWB / ES;             // elements per chunk: 64 | 32
   constexpr int E16 = 16 / ES;              // elements per 16-byte piece: 8 | 4
@@ -70,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const TdnnKernelParam
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  uint4 regA[5], regB[4];
+  uint4 regA[NA], regB[4];
 
   auto gload_B = [&](int c, int t) {
 #pragma unroll
@@ -85,9 +96,9 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const TdnnKernelParam
   };
   auto gload_A = [&](int c) {
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < NA; ++i) {
       const int q = i * 256 + tid, w = q >> 3, slot = q & 7;
-      const int row = m0 - kHalo + w, ch = c * BK + slot * E16;
+      const int row = m0 - HALO + w, ch = c * BK + slot * E16;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (q < A_PIECES && row >= 0 && row < p.rows && ch < p.cin_pad) {
         v = *reinterpret_cast<const uint4 *>(xg + (size_t)row * x_pitch + (size_t)ch * ES);
@@ -110,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const TdnnKernelParam
   auto sstore_A = [&](int stage) {
     unsigned char *Ab = lds + stage * A_STAGE;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < NA; ++i) {
       const int q = i * 256 + tid, w = q >> 3, slot = q & 7;
       if (q < A_PIECES) *reinterpret_cast<uint4 *>(Ab + w * ROWB + swz(w, slot) * 16) = regA[i];
     }
@@ -120,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const TdnnKernelParam
     uint4 a[2], b[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int w = wm * 64 + i * 32 + lr + kHalo + d;
+      const int w = wm * 64 + i * 32 + lr + HALO + d;
       a[i] = *reinterpret_cast<const uint4 *>(Ab + w * ROWB + swz(w, slot) * 16);
     }
 #pragma unroll
@@ -292,8 +303,9 @@ int launch_tdnn_mfma(const TdnnKernelParams &p, bool bf16, bool out_f32, hipStre
   ASV_REQUIRE(p.rows % BM == 0, "tdnn: rows %d not a multiple of %d", p.rows, BM);
   ASV_REQUIRE(p.cin_pad % kChanAlign == 0, "tdnn: cin_pad %d not a multiple of %d", p.cin_pad, kChanAlign);
   ASV_REQUIRE(p.n_taps >= 1 && p.n_taps <= ASV_MAX_TAPS, "tdnn: bad tap count %d", p.n_taps);
-  for (int t = 0; t < p.n_taps; ++t)
-    ASV_REQUIRE(p.taps[t] >= -kHalo && p.taps[t] <= kHalo, "tdnn: tap offset %d exceeds the %d-frame halo", p.taps[t], kHalo);
+  int halo = 0;
+  for (int t = 0; t < p.n_taps; ++t) halo = std::max(halo, std::abs(p.taps[t]));
+  ASV_REQUIRE(halo <= kWideHalo, "tdnn: tap offset %d exceeds the widest supported window (%d rows)", halo, kWideHalo);
   const int m_tiles = p.rows / BM;
   const int n_tiles = round_up(p.cout_store, BN) / BN;
   const dim3 grid(m_tiles * n_tiles, p.ksplit > 1 ? p.ksplit : 1), block(256);
@@ -302,18 +314,27 @@ int launch_tdnn_mfma(const TdnnKernelParams &p, bool bf16, bool out_f32, hipStre
   // residual / "bn-relu" order go to the GENERIC ones
   const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first && p.seg_bias == nullptr &&
                     p.seg_scale == nullptr && p.res == nullptr;
-  if (bf16) {
-    if (out_f32) {
-      if (fast) hipLaunchKernelGGL((tdnn_gemm_kernel<true, false, false>), grid, block, 0, s, p, m_tiles, n_tiles);
-      else hipLaunchKernelGGL((tdnn_gemm_kernel<true, false, true>), grid, block, 0, s, p, m_tiles, n_tiles);
+  if (halo > kHalo) {
+    // wide-window instantiations (grid domains): plain epilogue, no second input
+    ASV_REQUIRE(fast && p.x2 == nullptr, "tdnn: layers with |tap| > %d support the plain epilogue only", kHalo);
+    if (bf16) {
+      ASV_REQUIRE(!out_f32, "tdnn: wide-window bf16 layers produce bf16");
+      hipLaunchKernelGGL((tdnn_gemm_kernel<true, true, false, kWideHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
     } else {
-      if (fast) hipLaunchKernelGGL((tdnn_gemm_kernel<true, true, false>), grid, block, 0, s, p, m_tiles, n_tiles);
-      else hipLaunchKernelGGL((tdnn_gemm_kernel<true, true, true>), grid, block, 0, s, p, m_tiles, n_tiles);
+      hipLaunchKernelGGL((tdnn_gemm_kernel<false, false, false, kWideHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
+    }
+  } else if (bf16) {
+    if (out_f32) {
+      if (fast) hipLaunchKernelGGL((tdnn_gemm_kernel<true, false, false, kHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
+      else hipLaunchKernelGGL((tdnn_gemm_kernel<true, false, true, kHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
+    } else {
+      if (fast) hipLaunchKernelGGL((tdnn_gemm_kernel<true, true, false, kHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
+      else hipLaunchKernelGGL((tdnn_gemm_kernel<true, true, true, kHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
     }
   } else {
     ASV_REQUIRE(out_f32, "tdnn: f32 activations always produce f32");
-    if (fast) hipLaunchKernelGGL((tdnn_gemm_kernel<false, false, false>), grid, block, 0, s, p, m_tiles, n_tiles);
-    else hipLaunchKernelGGL((tdnn_gemm_kernel<false, false, true>), grid, block, 0, s, p, m_tiles, n_tiles);
+    if (fast) hipLaunchKernelGGL((tdnn_gemm_kernel<false, false, false, kHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
+    else hipLaunchKernelGGL((tdnn_gemm_kernel<false, false, true, kHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
   }
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;

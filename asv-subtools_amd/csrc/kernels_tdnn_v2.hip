@@ -58,7 +58,9 @@ __device__ __forceinline__ int swz(int row, int slot) { return slot ^ ((row >> 1
 
 // ABL != 0 builds ablation variants for tools/gemm_ablate (cdna_hip_programming.md 5.4 rule 17):
 //   1 no LDS-DMA after the prologue, 2 additionally no ds_reads in the loop (pure MFMA + barrier),
-//   3 loads + ds_reads but no MFMA, 4 full main loop without the epilogue stores
+//   3 loads + ds_reads but no MFMA, 4 full main loop without the epilogue stores,
+//   5 like 3 but every workgroup loads the SAME window / weight tile (cache-hot operands),
+//   7 LDS-DMA + barrier only (no ds_read, no MFMA), 8 ds_read + barrier only
 template <int ABL, bool GENERIC>
 __global__ __launch_bounds__(512, 2) void tdnn_gemm_big_kernel(const TdnnKernelParams p, int m_tiles, int n_tiles) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
@@ -70,6 +72,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_big_kernel(const TdnnKernelP
   const int tile = xcd_swizzle(blockIdx.x, m_tiles * n_tiles);
   const int m0 = (tile / n_tiles) * BM;
   const int n0 = (tile % n_tiles) * BN;
+  const int m0l = (ABL == 5) ? 0 : m0, n0l = (ABL == 5) ? 0 : n0;     // where the operand loads point
 
   const unsigned char *xg = reinterpret_cast<const unsigned char *>(p.x);
   const unsigned char *wg = reinterpret_cast<const unsigned char *>(p.w);
@@ -83,31 +86,35 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_big_kernel(const TdnnKernelP
   // this lane's position inside an 8-row load group
   const int g_row = lane >> 3, g_slot = lane & 7;
 
-  // issue the direct-to-LDS loads of one weight tile (tap t, chunk c) into B stage `st`
-  auto issue_B = [&](int c, int t, int st) {
-#pragma unroll
-    for (int i = 0; i < B_GROUPS / 8; ++i) {
-      const int grp = wave * (B_GROUPS / 8) + i;
-      const int n = grp * 8 + g_row;
-      const int ch = c * BK + swz(n, g_slot) * 8;
-      const unsigned char *src = (ch < p.cin_pad) ? wg + (size_t)(n0 + n) * w_row_pitch + (size_t)t * w_tap_pitch + (size_t)ch * 2 : zero;
-      glds16(src, __builtin_amdgcn_readfirstlane(lds_base + 2 * A_STAGE + st * B_STAGE + grp * 1024));
+  // One weight tile (tap t, chunk c) = 32 eight-row groups -> 4 DMA pieces per wave; one feature
+  // window (chunk c) = 33 groups -> 4 pieces per wave + a 5th for wave 0.  Pieces are issued one
+  // at a time, interleaved with the MFMA groups of the running step (each LDS-DMA costs the
+  // issuing wave ~60-100 cycles of issue time; spread out, the partner wave's MFMAs cover it).
+  auto issue_B_piece = [&](int c, int t, int st, int i) {
+    const int grp = wave * (B_GROUPS / 8) + i;
+    const int n = grp * 8 + g_row;
+    const int ch = c * BK + swz(n, g_slot) * 8;
+    const unsigned char *src = (ch < p.cin_pad) ? wg + (size_t)(n0l + n) * w_row_pitch + (size_t)t * w_tap_pitch + (size_t)ch * 2 : zero;
+    glds16(src, __builtin_amdgcn_readfirstlane(lds_base + 2 * A_STAGE + st * B_STAGE + grp * 1024));
+  };
+  auto issue_A_piece = [&](int c, int st, int i) {
+    const int grp = wave + i * 8;              // 33 groups over 8 waves: wave 0 takes the 33rd
+    if (grp < A_GROUPS) {
+      const int w = grp * 8 + g_row;
+      const int row = m0l - kHalo + w;
+      const int ch = c * BK + swz(w, g_slot) * 8;
+      const bool ok = row >= 0 && row < p.rows && ch < p.cin_pad;
+      const unsigned char *src = ok ? xg + (size_t)row * x_pitch + (size_t)ch * 2 : zero;
+      glds16(src, __builtin_amdgcn_readfirstlane(lds_base + st * A_STAGE + grp * 1024));
     }
   };
-  // ... and of one feature window (chunk c) into A stage `st`
+  auto issue_B = [&](int c, int t, int st) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_B_piece(c, t, st, i);
+  };
   auto issue_A = [&](int c, int st) {
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int grp = wave + i * 8;            // 33 groups over 8 waves: wave 0 takes the 33rd
-      if (grp < A_GROUPS) {
-        const int w = grp * 8 + g_row;
-        const int row = m0 - kHalo + w;
-        const int ch = c * BK + swz(w, g_slot) * 8;
-        const bool ok = row >= 0 && row < p.rows && ch < p.cin_pad;
-        const unsigned char *src = ok ? xg + (size_t)row * x_pitch + (size_t)ch * 2 : zero;
-        glds16(src, __builtin_amdgcn_readfirstlane(lds_base + st * A_STAGE + grp * 1024));
-      }
-    }
+    for (int i = 0; i < 5; ++i) issue_A_piece(c, st, i);
   };
 
   f32x16_t acc[4][2];
@@ -146,13 +153,21 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_big_kernel(const TdnnKernelP
   // ds_read of the step to the top (which spills the accumulators)
   Frags fa;
   if (ABL == 2) load_frags(lds, lds + 2 * A_STAGE, 0, 0, fa);
-  auto compute_step = [&](const unsigned char *Ab, const unsigned char *Bb, int d) {
+  // (cn, tn, bst): next step's weight tile and its stage; (ca, ast): next chunk's window and its stage
+  auto compute_step = [&](const unsigned char *Ab, const unsigned char *Bb, int d, bool do_B, int cn, int tn, int bst, bool do_A, int ca, int ast) {
     if (ABL == 2) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) { mma_frags(fa); __builtin_amdgcn_sched_barrier(0); }
       return;
     }
-    if (ABL == 3) {
+    if (ABL == 7) {
+      if (do_B) issue_B(cn, tn, bst);
+      if (do_A) issue_A(ca, ast);
+      return;
+    }
+    if (ABL == 3 || ABL == 5 || ABL == 8) {
+      if (do_B && ABL != 8) issue_B(cn, tn, bst);
+      if (do_A && ABL != 8) issue_A(ca, ast);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         Frags f;
@@ -166,16 +181,32 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_big_kernel(const TdnnKernelP
     }
     Frags f0, f1;
     load_frags(Ab, Bb, d, 0, f0);
+    if (do_B) issue_B_piece(cn, tn, bst, 0);
+    if (do_A) { issue_A_piece(ca, ast, 0); issue_A_piece(ca, ast, 4); }
     load_frags(Ab, Bb, d, 1, f1);
+    __builtin_amdgcn_s_setprio(1);
     mma_frags(f0);
+    __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
+    if (do_B) issue_B_piece(cn, tn, bst, 1);
+    if (do_A) issue_A_piece(ca, ast, 1);
     load_frags(Ab, Bb, d, 2, f0);
+    __builtin_amdgcn_s_setprio(1);
     mma_frags(f1);
+    __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
+    if (do_B) issue_B_piece(cn, tn, bst, 2);
+    if (do_A) issue_A_piece(ca, ast, 2);
     load_frags(Ab, Bb, d, 3, f1);
+    __builtin_amdgcn_s_setprio(1);
     mma_frags(f0);
+    __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
+    if (do_B) issue_B_piece(cn, tn, bst, 3);
+    if (do_A) issue_A_piece(ca, ast, 3);
+    __builtin_amdgcn_s_setprio(1);
     mma_frags(f1);
+    __builtin_amdgcn_s_setprio(0);
   };
 
   const int nchunks = (p.cin_pad + BK - 1) / BK;
@@ -190,15 +221,13 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_big_kernel(const TdnnKernelP
   for (int s = 0; s < nsteps; ++s) {
     int cn = c, tn = t + 1;
     if (tn == p.n_taps) { tn = 0; cn = c + 1; }
-    if (ABL != 1 && ABL != 2) {
-      if (s + 1 < nsteps) issue_B(cn, tn, (s + 1) & 1);
-      if (t == 0 && c + 1 < nchunks) issue_A(c + 1, (c + 1) & 1);   // whole chunk of slack for the window
-    }
+    const bool do_B = (ABL != 1 && ABL != 2) && (s + 1 < nsteps);
+    const bool do_A = (ABL != 1 && ABL != 2) && (t == 0) && (c + 1 < nchunks);      // whole chunk of slack for the window
     {
       const unsigned char *Ab = lds + (c & 1) * A_STAGE;
       const unsigned char *Bb = lds + 2 * A_STAGE + (s & 1) * B_STAGE;
       const int d = p.taps[t];
-      compute_step(Ab, Bb, d);      // a channel tail (cin_pad % 64) was staged as zeros
+      compute_step(Ab, Bb, d, do_B, cn, tn, (s + 1) & 1, do_A, c + 1, (c + 1) & 1);      // a channel tail (cin_pad % 64) was staged as zeros
     }
     wait_all_vmem();                     // this wave's LDS-DMA of the next step has landed ...
     __syncthreads();                     // ... everyone's has; stages of step s are free
@@ -292,6 +321,9 @@ int launch_tdnn_big_variant(const TdnnKernelParams &p, int variant, hipStream_t 
     case 2: hipLaunchKernelGGL((tdnn_gemm_big_kernel<2, false>), grid, block, 0, s, p, m_tiles, n_tiles); break;
     case 3: hipLaunchKernelGGL((tdnn_gemm_big_kernel<3, false>), grid, block, 0, s, p, m_tiles, n_tiles); break;
     case 4: hipLaunchKernelGGL((tdnn_gemm_big_kernel<4, false>), grid, block, 0, s, p, m_tiles, n_tiles); break;
+    case 5: hipLaunchKernelGGL((tdnn_gemm_big_kernel<5, false>), grid, block, 0, s, p, m_tiles, n_tiles); break;
+    case 7: hipLaunchKernelGGL((tdnn_gemm_big_kernel<7, false>), grid, block, 0, s, p, m_tiles, n_tiles); break;
+    case 8: hipLaunchKernelGGL((tdnn_gemm_big_kernel<8, false>), grid, block, 0, s, p, m_tiles, n_tiles); break;
     case 6: hipLaunchKernelGGL((tdnn_gemm_big_kernel<0, true>), grid, block, 0, s, p, m_tiles, n_tiles); break;
     default: hipLaunchKernelGGL((tdnn_gemm_big_kernel<0, false>), grid, block, 0, s, p, m_tiles, n_tiles); break;
   }

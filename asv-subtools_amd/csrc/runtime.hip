@@ -51,13 +51,46 @@ void pack_tdnn_weight(const float *w, int out_ch, int in_ch, int tot_ctx, int le
     }
 }
 
+size_t tdnn_weight_frag_elems(int cout_pad, int cin_pad, int n_taps) {
+  return (size_t)cout_pad * n_taps * round_up(cin_pad, 64);
+}
+
+// MFMA-fragment order for kernels_tdnn_v3.hip: [n_frag32][tap][chunk64][k_group16][lane][8];
+// lane = (k half lh, channel lr): channel n_frag*32 + lr, k = chunk*64 + k_group*16 + lh*8 + e.
+void pack_tdnn_weight_frags(const float *w, int out_ch, int in_ch, int tot_ctx, int left_ctx, const int *taps, int n_taps,
+                            int cout_pad, int cin_pad, uint16_t *dst) {
+  const int nchunks = round_up(cin_pad, 64) / 64;
+  memset(dst, 0, tdnn_weight_frag_elems(cout_pad, cin_pad, n_taps) * 2);
+  for (int co = 0; co < out_ch; ++co) {
+    const int nf = co / 32, lr = co % 32;
+    for (int t = 0; t < n_taps; ++t) {
+      const int k = taps[t] - left_ctx;
+      for (int ci = 0; ci < in_ch; ++ci) {
+        const int c = ci / 64, kg = (ci % 64) / 16, lh = (ci % 16) / 8, e = ci % 8;
+        const size_t idx = ((((size_t)nf * n_taps + t) * nchunks + c) * 4 + kg) * 512 + (size_t)(lh * 32 + lr) * 8 + e;
+        dst[idx] = f32_to_bf16_host(w[((size_t)co * in_ch + ci) * tot_ctx + k]);
+      }
+    }
+  }
+}
+
 namespace {
 
 struct Buffer {
   int domain, channels, ld;
 };
 
-enum OpKind { OP_TDNN = 0, OP_POOL = 1, OP_ATTPOOL = 2, OP_ELTWISE = 3 };
+// Row domains.  0 = frames (1 row per frame, HALO-row gaps), 1 = utts (1 row per segment),
+// >= 2 = grids for the 2-D ResNet trunk: a segment of T frames owns ceil(T / 2^shift) x pitch rows
+// ((time, frequency), frequency fastest, `width` valid rows per frame) with pitch+2 gap rows around it.
+struct Domain {
+  int kind;                // ASV_DOMAIN_FRAMES / ASV_DOMAIN_UTTS / 2 (grid)
+  int shift = 0, width = 1, pitch = 1;
+  int halo() const { return kind == ASV_DOMAIN_FRAMES ? kHalo : (kind == ASV_DOMAIN_UTTS ? 0 : pitch + 1); }
+  int gap() const { return kind == ASV_DOMAIN_FRAMES ? kHalo : pitch + 2; }
+};
+
+enum OpKind { OP_TDNN = 0, OP_POOL = 1, OP_ATTPOOL = 2, OP_ELTWISE = 3, OP_GRID_INPUT = 4, OP_IM2COL = 5 };
 
 struct Op {
   OpKind kind;
@@ -66,8 +99,11 @@ struct Op {
   asv_pool_desc_t pool;
   asv_attpool_desc_t att;
   asv_eltwise_desc_t elt;
+  asv_grid_input_desc_t gin;
+  asv_im2col_desc_t i2c;
   // device parameters
   void *w = nullptr;
+  void *wfrag = nullptr;         // fragment-ordered copy for the variant-3 kernel (bf16 frame layers)
   float *bias = nullptr, *scale = nullptr, *shift = nullptr;
   int cin_pad = 0, cout_pad = 0, cout_store = 0;
   bool utts = false;             // op runs in the utts domain (always f32)
@@ -79,8 +115,8 @@ struct DevMem {
   size_t cap = 0;
 };
 
-const char *kKernelNames[] = {"tdnn_gemm", "stats_pool", "attentive_pool", "eltwise", "rowmap", "pack_input", "combine"};
-enum { K_TDNN = 0, K_POOL, K_ATT, K_ELT, K_ROWMAP, K_PACK, K_COMBINE, K_COUNT };
+const char *kKernelNames[] = {"tdnn_gemm", "stats_pool", "attentive_pool", "eltwise", "rowmap", "pack_input", "combine", "grid_gather"};
+enum { K_TDNN = 0, K_POOL, K_ATT, K_ELT, K_ROWMAP, K_PACK, K_COMBINE, K_GATHER, K_COUNT };
 
 }  // namespace
 }  // namespace asv
@@ -93,6 +129,7 @@ struct asv_net {
   bool finalized = false;
   int out_buf = -1, embed_dim = 0;
   std::vector<Buffer> bufs;
+  std::vector<Domain> domains;
   std::vector<Op> ops;
   std::vector<void *> weight_allocs;
   size_t weight_bytes = 0;
@@ -113,7 +150,9 @@ struct asv_net {
   std::vector<hipEvent_t> event_pool;
 
   bool frames_bf16() const { return precision == ASV_PREC_BF16; }
-  size_t elem_size(int domain) const { return (domain == ASV_DOMAIN_FRAMES && frames_bf16()) ? 2 : 4; }
+  bool is_utts(int domain) const { return domains[domain].kind == ASV_DOMAIN_UTTS; }
+  bool dom_bf16(int domain) const { return !is_utts(domain) && frames_bf16(); }
+  size_t elem_size(int domain) const { return dom_bf16(domain) ? 2 : 4; }
 };
 
 namespace {
@@ -185,42 +224,64 @@ struct Prof {
 };
 
 // Per-call plan of segments and rows.
+struct DomainPlan {
+  int rows = 0, rows_pad = 0;
+  std::vector<int32_t> seg_row0, seg_len;      // first row / number of rows of each segment in this domain
+};
 struct BatchPlan {
-  int n_utts = 0, segments = 0, rows = 0, rows_pad = 0, seg_pad = 0;
+  int n_utts = 0, segments = 0, seg_pad = 0;
   long long frames = 0;
-  std::vector<int32_t> seg_src0, seg_row0, seg_len, utt_seg0, utt_nseg;
+  std::vector<int32_t> seg_src0, seg_frames, utt_seg0, utt_nseg;
+  std::vector<DomainPlan> dom;                 // indexed like asv_net::domains
 };
 
-int make_plan(const int32_t *offsets, int n_utts, int max_chunk, BatchPlan &bp) {
+int make_plan(const asv_net *net, const int32_t *offsets, int n_utts, int max_chunk, BatchPlan &bp) {
   ASV_REQUIRE(offsets != nullptr && n_utts >= 1, "extract: need at least one utterance");
   ASV_REQUIRE(offsets[0] == 0, "extract: offsets[0] must be 0");
   if (max_chunk <= 0) max_chunk = 10000;
   bp.n_utts = n_utts;
   bp.utt_seg0.resize(n_utts); bp.utt_nseg.resize(n_utts);
-  long long row = kHalo;
   for (int u = 0; u < n_utts; ++u) {
     const long long T = (long long)offsets[u + 1] - offsets[u];
     ASV_REQUIRE(T >= 1, "extract: utterance %d has %lld frames (the reference asserts T >= tot_context, components.py:119)", u, T);
     // framework.py:34-47
     const int num_split = (int)((T + max_chunk - 1) / max_chunk);
     const int split = (int)(T / num_split);
-    bp.utt_seg0[u] = (int32_t)bp.seg_len.size();
+    bp.utt_seg0[u] = (int32_t)bp.seg_frames.size();
     bp.utt_nseg[u] = num_split;
     for (int i = 0; i < num_split; ++i) {
       const int off = i * split;
       const int len = (i == num_split - 1) ? (int)(T - off) : split;
       bp.seg_src0.push_back(offsets[u] + off);
-      bp.seg_row0.push_back((int32_t)row);
-      bp.seg_len.push_back(len);
-      row += len + kHalo;
-      ASV_REQUIRE(row < (1ll << 30), "extract: batch too large (%lld rows)", row);
+      bp.seg_frames.push_back(len);
     }
     bp.frames += T;
   }
-  bp.segments = (int)bp.seg_len.size();
-  bp.rows = (int)row;
-  bp.rows_pad = round_up(bp.rows, kRowTile);
+  bp.segments = (int)bp.seg_frames.size();
   bp.seg_pad = round_up(bp.segments, kRowTile);
+  bp.dom.resize(net->domains.size());
+  for (size_t di = 0; di < net->domains.size(); ++di) {
+    const Domain &dm = net->domains[di];
+    DomainPlan &dp = bp.dom[di];
+    if (dm.kind == ASV_DOMAIN_UTTS) {
+      dp.rows = bp.segments; dp.rows_pad = bp.seg_pad;
+      dp.seg_row0 = {0}; dp.seg_len = {bp.segments};          // one pseudo segment covering the valid rows
+      continue;
+    }
+    long long row = dm.gap();
+    dp.seg_row0.reserve(bp.segments); dp.seg_len.reserve(bp.segments);
+    for (int sidx = 0; sidx < bp.segments; ++sidx) {
+      long long fr = bp.seg_frames[sidx];
+      for (int k = 0; k < dm.shift; ++k) fr = (fr + 1) / 2;       // stride-2 stages: ceil(T/2) each
+      const long long len = fr * dm.pitch;
+      dp.seg_row0.push_back((int32_t)row);
+      dp.seg_len.push_back((int32_t)len);
+      row += len + dm.gap();
+      ASV_REQUIRE(row < (1ll << 30), "extract: batch too large (%lld rows in domain %zu)", row, di);
+    }
+    dp.rows = (int)row;
+    dp.rows_pad = round_up(dp.rows, kRowTile);
+  }
   return ASV_OK;
 }
 
@@ -251,6 +312,8 @@ int asv_net_create(asv_net_t **out, int device, int precision, unsigned flags, i
   asv_net *net = new (std::nothrow) asv_net();
   if (!net) { set_error("out of host memory"); return ASV_ENOMEM; }
   net->device = device; net->precision = precision; net->flags = flags; net->feat_dim = feat_dim;
+  net->domains.push_back(Domain{ASV_DOMAIN_FRAMES});
+  net->domains.push_back(Domain{ASV_DOMAIN_UTTS});
   net->bufs.push_back({ASV_DOMAIN_FRAMES, feat_dim, round_up(feat_dim, kChanAlign)});
   hipError_t ze = hipMalloc(&net->zero_page, 256);
   if (ze == hipSuccess) ze = hipMemset(net->zero_page, 0, 256);
@@ -276,9 +339,19 @@ void asv_net_destroy(asv_net_t *net) {
   delete net;
 }
 
+int asv_net_define_grid(asv_net_t *net, int time_shift, int width, int pitch) {
+  ASV_REQUIRE(net && !net->finalized, "asv_net_define_grid: net is null or finalized");
+  ASV_REQUIRE(time_shift >= 0 && time_shift <= 8, "asv_net_define_grid: time_shift %d", time_shift);
+  ASV_REQUIRE(width >= 1 && pitch >= width + 1 && pitch + 1 <= 84, "asv_net_define_grid: need 1 <= width < pitch <= 83 (got %d, %d)", width, pitch);
+  Domain d{2};
+  d.shift = time_shift; d.width = width; d.pitch = pitch;
+  net->domains.push_back(d);
+  return (int)net->domains.size() - 1;
+}
+
 int asv_net_new_buffer(asv_net_t *net, int domain, int channels) {
   ASV_REQUIRE(net && !net->finalized, "asv_net_new_buffer: net is null or finalized");
-  ASV_REQUIRE(domain == ASV_DOMAIN_FRAMES || domain == ASV_DOMAIN_UTTS, "asv_net_new_buffer: domain %d", domain);
+  ASV_REQUIRE(domain >= 0 && domain < (int)net->domains.size(), "asv_net_new_buffer: domain %d", domain);
   ASV_REQUIRE(channels >= 1 && channels <= (1 << 20), "asv_net_new_buffer: channels %d", channels);
   net->bufs.push_back({domain, channels, round_up(channels, kChanAlign)});
   return (int)net->bufs.size() - 1;
@@ -311,18 +384,19 @@ int asv_net_add_tdnn(asv_net_t *net, const asv_tdnn_desc_t *d) {
   }
   for (int sb : {d->seg_bias_buf, d->seg_scale_buf})
     if (sb >= 0) {
-      ASV_REQUIRE(dom == ASV_DOMAIN_FRAMES, "tdnn: per-segment bias/scale only applies to frames-domain layers");
-      ASV_REQUIRE(sb < (int)net->bufs.size() && net->bufs[sb].domain == ASV_DOMAIN_UTTS && net->bufs[sb].channels >= d->out_ch,
+      ASV_REQUIRE(!net->is_utts(dom), "tdnn: per-segment bias/scale only applies to frame-level layers");
+      ASV_REQUIRE(sb < (int)net->bufs.size() && net->is_utts(net->bufs[sb].domain) && net->bufs[sb].channels >= d->out_ch,
                   "tdnn: per-segment buffer %d must be an utts-domain buffer with >= %d channels", sb, d->out_ch);
     }
   ASV_REQUIRE(d->n_taps >= 1 && d->n_taps <= ASV_MAX_TAPS, "tdnn: n_taps %d", d->n_taps);
   for (int t = 0; t < d->n_taps; ++t) {
     ASV_REQUIRE(t == 0 || d->taps[t] > d->taps[t - 1], "tdnn: context must be strictly ascending (components.py:33-35)");
-    ASV_REQUIRE(d->taps[t] >= -kHalo && d->taps[t] <= kHalo, "tdnn: tap offset %d beyond the supported +-%d frames", d->taps[t], kHalo);
+    ASV_REQUIRE(std::abs(d->taps[t]) <= net->domains[dom].halo() || (net->is_utts(dom) && d->taps[t] == 0),
+                "tdnn: tap offset %d beyond the +-%d rows this domain keeps zero-padded", d->taps[t], net->domains[dom].halo());
     const int k = d->taps[t] - d->w_left_context;
     ASV_REQUIRE(k >= 0 && k < d->w_tot_context, "tdnn: tap %d outside the dense kernel [%d, %d)", d->taps[t], d->w_left_context, d->w_left_context + d->w_tot_context);
   }
-  ASV_REQUIRE(dom == ASV_DOMAIN_FRAMES || (d->n_taps == 1 && d->taps[0] == 0), "tdnn: utts-domain layers have context [0] only");
+  ASV_REQUIRE(!net->is_utts(dom) || (d->n_taps == 1 && d->taps[0] == 0), "tdnn: utts-domain layers have context [0] only");
   ASV_REQUIRE(d->weight != nullptr, "tdnn: null weight");
   ASV_REQUIRE((d->scale == nullptr) == (d->shift == nullptr), "tdnn: scale and shift come together");
   for (int a : {d->act1, d->act2}) ASV_REQUIRE(a >= ASV_ACT_NONE && a <= ASV_ACT_SIGMOID, "tdnn: unknown activation %d", a);
@@ -330,8 +404,8 @@ int asv_net_add_tdnn(asv_net_t *net, const asv_tdnn_desc_t *d) {
   Op op;
   op.kind = OP_TDNN;
   op.tdnn = *d;
-  op.utts = (dom == ASV_DOMAIN_UTTS);
-  const bool bf16 = !op.utts && net->frames_bf16();
+  op.utts = net->is_utts(dom);
+  const bool bf16 = net->dom_bf16(dom);
   op.cin_pad = round_up(d->in_ch, kChanAlign);
   op.cout_pad = round_up(d->out_ch, kBigTileN);
   op.cout_store = round_up(d->out_ch, kChanAlign);
@@ -343,6 +417,11 @@ int asv_net_add_tdnn(asv_net_t *net, const asv_tdnn_desc_t *d) {
     pack_tdnn_weight(d->weight, d->out_ch, d->in_ch, d->w_tot_context, d->w_left_context, d->taps, d->n_taps, op.cout_pad,
                      op.cin_pad, bf16, packed.data());
     if ((rc = dev_upload(net, packed.data(), packed.size(), &op.w))) return rc;
+    if (bf16 && op.cout_store >= 192 && op.cin_pad >= 64) {       // candidates of the 256x256 kernels
+      std::vector<uint16_t> frags(tdnn_weight_frag_elems(op.cout_pad, op.cin_pad, d->n_taps));
+      pack_tdnn_weight_frags(d->weight, d->out_ch, d->in_ch, d->w_tot_context, d->w_left_context, d->taps, d->n_taps, op.cout_pad, op.cin_pad, frags.data());
+      if ((rc = dev_upload(net, frags.data(), frags.size() * 2, &op.wfrag))) return rc;
+    }
   }
   if ((rc = upload_padded(net, d->bias, d->out_ch, op.cout_pad, 0.0f, &op.bias))) return rc;
   op.has_affine = d->scale != nullptr;
@@ -360,11 +439,14 @@ int asv_net_add_stats_pool(asv_net_t *net, const asv_pool_desc_t *d) {
   ASV_REQUIRE(d->struct_size == sizeof(asv_pool_desc_t), "asv_net_add_stats_pool: struct_size mismatch");
   int rc;
   if ((rc = check_view(net, d->in_buf, d->in_ch_off, d->channels, "pool input"))) return rc;
-  const int out_ch = d->channels * (d->stddev ? 2 : 1);
+  int out_ch = d->channels * (d->stddev ? 2 : 1);
+  ASV_REQUIRE(d->in_buf >= 0 && d->in_buf < (int)net->bufs.size(), "pool: input buffer id %d", d->in_buf);
+  if (d->per_bin) out_ch *= net->domains[net->bufs[d->in_buf].domain].width;
   ASV_REQUIRE(d->out_buf > 0 && d->out_buf < (int)net->bufs.size(), "pool: output buffer id %d", d->out_buf);
   ASV_REQUIRE(d->out_ch_off >= 0 && d->out_ch_off + out_ch <= net->bufs[d->out_buf].channels, "pool: output view exceeds buffer");
-  ASV_REQUIRE(net->bufs[d->in_buf].domain == ASV_DOMAIN_FRAMES && net->bufs[d->out_buf].domain == ASV_DOMAIN_UTTS,
-              "pool: goes from the frames domain to the utts domain");
+  ASV_REQUIRE(!net->is_utts(net->bufs[d->in_buf].domain) && net->is_utts(net->bufs[d->out_buf].domain),
+              "pool: goes from a frame-level domain to the utts domain");
+  ASV_REQUIRE(d->per_bin == 0 || net->domains[net->bufs[d->in_buf].domain].kind == 2, "pool: per_bin needs a grid-domain input");
   ASV_REQUIRE(d->unbiased >= 0 && d->unbiased <= 2 && (d->var_mode == ASV_POOL_VAR_CLAMP || d->var_mode == ASV_POOL_VAR_ADD), "pool: bad mode");
   Op op; op.kind = OP_POOL; op.pool = *d;
   net->ops.push_back(op);
@@ -380,7 +462,7 @@ int asv_net_add_attentive_pool(asv_net_t *net, const asv_attpool_desc_t *d) {
   ASV_REQUIRE(d->out_buf > 0 && d->out_buf < (int)net->bufs.size(), "attentive pool: output buffer id %d", d->out_buf);
   ASV_REQUIRE(d->out_ch_off >= 0 && d->out_ch_off + 2 * d->channels <= net->bufs[d->out_buf].channels, "attentive pool: output view exceeds buffer");
   ASV_REQUIRE(net->bufs[d->x_buf].domain == ASV_DOMAIN_FRAMES && net->bufs[d->logit_buf].domain == ASV_DOMAIN_FRAMES &&
-              net->bufs[d->out_buf].domain == ASV_DOMAIN_UTTS, "attentive pool: frames -> utts");
+              net->is_utts(net->bufs[d->out_buf].domain), "attentive pool: frames -> utts");
   Op op; op.kind = OP_ATTPOOL; op.att = *d;
   net->ops.push_back(op);
   return ASV_OK;
@@ -397,12 +479,13 @@ int asv_net_add_eltwise(asv_net_t *net, const asv_eltwise_desc_t *d) {
   if (d->b_buf >= 0) { if ((rc = check_view(net, d->b_buf, d->b_ch_off, d->channels, "eltwise b"))) return rc; ASV_REQUIRE(net->bufs[d->b_buf].domain == dom, "eltwise: b domain"); }
   if (d->c_buf >= 0) { if ((rc = check_view(net, d->c_buf, d->c_ch_off, d->channels, "eltwise c"))) return rc; ASV_REQUIRE(net->bufs[d->c_buf].domain == dom, "eltwise: c domain"); }
   if (d->seg_scale_buf >= 0)
-    ASV_REQUIRE(dom == ASV_DOMAIN_FRAMES && d->seg_scale_buf < (int)net->bufs.size() && net->bufs[d->seg_scale_buf].domain == ASV_DOMAIN_UTTS &&
+    ASV_REQUIRE(!net->is_utts(dom) && d->seg_scale_buf < (int)net->bufs.size() && net->is_utts(net->bufs[d->seg_scale_buf].domain) &&
                 net->bufs[d->seg_scale_buf].channels >= d->channels, "eltwise: bad per-segment scale buffer");
   ASV_REQUIRE((d->scale == nullptr) == (d->shift == nullptr), "eltwise: scale and shift come together");
-  const int vec = (dom == ASV_DOMAIN_FRAMES && net->frames_bf16()) ? 8 : 4;
+  ASV_REQUIRE(d->act >= ASV_ACT_NONE && d->act <= ASV_ACT_SIGMOID, "eltwise: unknown activation %d", d->act);
+  const int vec = net->dom_bf16(dom) ? 8 : 4;
   ASV_REQUIRE(d->out_ch_off + round_up(d->channels, vec) <= net->bufs[d->out_buf].ld, "eltwise: padded view exceeds pitch");
-  Op op; op.kind = OP_ELTWISE; op.elt = *d; op.utts = (dom == ASV_DOMAIN_UTTS);
+  Op op; op.kind = OP_ELTWISE; op.elt = *d; op.utts = net->is_utts(dom);
   ASV_HIP_CHECK(hipSetDevice(net->device));
   if (d->scale) {
     const int n_pad = round_up(d->channels, kChanAlign);
@@ -414,9 +497,37 @@ int asv_net_add_eltwise(asv_net_t *net, const asv_eltwise_desc_t *d) {
   return ASV_OK;
 }
 
+int asv_net_add_grid_input(asv_net_t *net, const asv_grid_input_desc_t *d) {
+  ASV_REQUIRE(net && d && !net->finalized, "asv_net_add_grid_input: net is null or finalized");
+  ASV_REQUIRE(d->struct_size == sizeof(asv_grid_input_desc_t), "asv_net_add_grid_input: struct_size mismatch");
+  ASV_REQUIRE(d->out_buf > 0 && d->out_buf < (int)net->bufs.size(), "grid_input: output buffer id %d", d->out_buf);
+  const Domain &dm = net->domains[net->bufs[d->out_buf].domain];
+  ASV_REQUIRE(dm.kind == 2 && dm.shift == 0 && dm.width == net->feat_dim, "grid_input: output must be a full-resolution grid of width feat_dim (%d)", net->feat_dim);
+  Op op; op.kind = OP_GRID_INPUT; op.gin = *d;
+  net->ops.push_back(op);
+  return ASV_OK;
+}
+
+int asv_net_add_im2col(asv_net_t *net, const asv_im2col_desc_t *d) {
+  ASV_REQUIRE(net && d && !net->finalized, "asv_net_add_im2col: net is null or finalized");
+  ASV_REQUIRE(d->struct_size == sizeof(asv_im2col_desc_t), "asv_net_add_im2col: struct_size mismatch");
+  int rc;
+  if ((rc = check_view(net, d->in_buf, 0, d->channels, "im2col input"))) return rc;
+  ASV_REQUIRE(d->n_taps >= 1 && d->n_taps <= ASV_MAX_TAPS && (d->stride == 1 || d->stride == 2), "im2col: n_taps %d stride %d", d->n_taps, d->stride);
+  ASV_REQUIRE(d->channels % kChanAlign == 0 && d->channels == net->bufs[d->in_buf].channels, "im2col: channels must be the whole input buffer and a multiple of %d", kChanAlign);
+  if ((rc = check_view(net, d->out_buf, 0, d->channels * d->n_taps, "im2col output"))) return rc;
+  const Domain &di = net->domains[net->bufs[d->in_buf].domain], &dq = net->domains[net->bufs[d->out_buf].domain];
+  ASV_REQUIRE(di.kind == 2 && dq.kind == 2 && d->out_buf != d->in_buf && d->out_buf != 0, "im2col: grid -> grid");
+  ASV_REQUIRE(dq.shift == di.shift + (d->stride == 2 ? 1 : 0) && dq.width == (di.width + d->stride - 1) / d->stride,
+              "im2col: output grid (T/%d x %d) does not match stride %d over input grid (T/%d x %d)", 1 << dq.shift, dq.width, d->stride, 1 << di.shift, di.width);
+  Op op; op.kind = OP_IM2COL; op.i2c = *d;
+  net->ops.push_back(op);
+  return ASV_OK;
+}
+
 int asv_net_finalize(asv_net_t *net, int out_buf, int embed_dim) {
   ASV_REQUIRE(net && !net->finalized, "asv_net_finalize: net is null or already finalized");
-  ASV_REQUIRE(out_buf > 0 && out_buf < (int)net->bufs.size() && net->bufs[out_buf].domain == ASV_DOMAIN_UTTS,
+  ASV_REQUIRE(out_buf > 0 && out_buf < (int)net->bufs.size() && net->is_utts(net->bufs[out_buf].domain),
               "asv_net_finalize: output must be an utts-domain buffer");
   ASV_REQUIRE(embed_dim >= 1 && embed_dim <= net->bufs[out_buf].channels, "asv_net_finalize: embed_dim %d", embed_dim);
   ASV_REQUIRE(!net->ops.empty(), "asv_net_finalize: empty program");
@@ -442,7 +553,11 @@ int asv_net_describe(const asv_net_t *net, char *buf, size_t cap) {
            net->precision == ASV_PREC_BF16 ? "bf16" : "f32", net->flags, net->feat_dim, net->bufs.size(), net->ops.size(), net->out_buf, net->embed_dim);
   s += line;
   for (size_t i = 0; i < net->bufs.size(); ++i) {
-    snprintf(line, sizeof(line), "  buf %zu: %s channels=%d ld=%d\n", i, net->bufs[i].domain == ASV_DOMAIN_FRAMES ? "frames" : "utts", net->bufs[i].channels, net->bufs[i].ld);
+    const Domain &dm = net->domains[net->bufs[i].domain];
+    char dname[64];
+    if (dm.kind == 2) snprintf(dname, sizeof(dname), "grid(T/%d x %d, pitch %d)", 1 << dm.shift, dm.width, dm.pitch);
+    else snprintf(dname, sizeof(dname), "%s", dm.kind == ASV_DOMAIN_FRAMES ? "frames" : "utts");
+    snprintf(line, sizeof(line), "  buf %zu: %s channels=%d ld=%d\n", i, dname, net->bufs[i].channels, net->bufs[i].ld);
     s += line;
   }
   for (size_t i = 0; i < net->ops.size(); ++i) {
@@ -464,6 +579,12 @@ int asv_net_describe(const asv_net_t *net, char *buf, size_t cap) {
       case OP_ATTPOOL:
         snprintf(line, sizeof(line), "  op %zu: attentive_pool x=%d logits=%d channels=%d -> %d[%d] eps=%g\n", i, op.att.x_buf, op.att.logit_buf, op.att.channels,
                  op.att.out_buf, op.att.out_ch_off, op.att.eps);
+        break;
+      case OP_GRID_INPUT:
+        snprintf(line, sizeof(line), "  op %zu: grid_input 0 -> %d\n", i, op.gin.out_buf);
+        break;
+      case OP_IM2COL:
+        snprintf(line, sizeof(line), "  op %zu: im2col %d -> %d taps=%d stride=%d channels=%d\n", i, op.i2c.in_buf, op.i2c.out_buf, op.i2c.n_taps, op.i2c.stride, op.i2c.channels);
         break;
       case OP_ELTWISE:
         snprintf(line, sizeof(line), "  op %zu: eltwise a=%d b=%d c=%d segscale=%d affine=%d channels=%d -> %d[%d]\n", i, op.elt.a_buf, op.elt.b_buf, op.elt.c_buf,
@@ -521,21 +642,28 @@ int asv_net_get_profile(asv_net_t *net, asv_kernel_time_t *rows, int cap, int *n
 // the launch sequence of one batch
 namespace {
 
+struct DomainRun {
+  int rows_pad = 0;
+  int32_t *seg_row0 = nullptr, *seg_len = nullptr, *row_seg = nullptr;
+  uint32_t *row_valid = nullptr;
+};
+
 struct RunCtx {
   asv_net *net; hipStream_t s; BatchPlan bp;
-  // device metadata views
-  int32_t *seg_src0, *seg_row0, *seg_len, *utt_seg0, *utt_nseg, *one_row0, *one_len;
-  int32_t *row_seg, *urow_seg; uint32_t *row_valid, *urow_valid;
+  int32_t *seg_src0, *seg_frames, *utt_seg0, *utt_nseg;     // device metadata
+  std::vector<DomainRun> dom;
 };
 
 int prepare(RunCtx &c, const int32_t *offsets, int n_utts, int max_chunk) {
   asv_net *net = c.net;
   int rc;
-  if ((rc = make_plan(offsets, n_utts, max_chunk, c.bp))) return rc;
+  if ((rc = make_plan(net, offsets, n_utts, max_chunk, c.bp))) return rc;
   const BatchPlan &bp = c.bp;
   const int S = bp.segments, B = bp.n_utts;
+  const size_t ndom = net->domains.size();
   // ---- int32 metadata: one pinned staging buffer, one H2D copy
-  const size_t n_meta = (size_t)3 * S + 2 * B + 2;
+  size_t n_meta = (size_t)2 * S + 2 * B;
+  for (auto &dp : bp.dom) n_meta += dp.seg_row0.size() + dp.seg_len.size();
   const size_t meta_bytes = n_meta * sizeof(int32_t);
   if (net->meta_inflight) { ASV_HIP_CHECK(hipEventSynchronize(net->meta_copied)); net->meta_inflight = false; }
   if (meta_bytes > net->meta_host_cap) {
@@ -550,31 +678,37 @@ int prepare(RunCtx &c, const int32_t *offsets, int n_utts, int max_chunk) {
   int32_t *d = reinterpret_cast<int32_t *>(net->meta_dev.ptr);
   size_t o = 0;
   auto put = [&](const std::vector<int32_t> &v, int32_t **dev) { memcpy(h + o, v.data(), v.size() * 4); *dev = d + o; o += v.size(); };
-  put(bp.seg_src0, &c.seg_src0); put(bp.seg_row0, &c.seg_row0); put(bp.seg_len, &c.seg_len);
+  put(bp.seg_src0, &c.seg_src0); put(bp.seg_frames, &c.seg_frames);
   put(bp.utt_seg0, &c.utt_seg0); put(bp.utt_nseg, &c.utt_nseg);
-  h[o] = 0; c.one_row0 = d + o; ++o;
-  h[o] = S; c.one_len = d + o; ++o;
+  c.dom.resize(ndom);
+  size_t rm_words = 0;
+  for (size_t i = 0; i < ndom; ++i) {
+    put(bp.dom[i].seg_row0, &c.dom[i].seg_row0);
+    put(bp.dom[i].seg_len, &c.dom[i].seg_len);
+    c.dom[i].rows_pad = bp.dom[i].rows_pad;
+    rm_words += (size_t)bp.dom[i].rows_pad + bp.dom[i].rows_pad / 32;
+  }
   ASV_HIP_CHECK(hipMemcpyAsync(d, h, meta_bytes, hipMemcpyHostToDevice, c.s));
   ASV_HIP_CHECK(hipEventRecord(net->meta_copied, c.s));
   net->meta_inflight = true;
-  // ---- row maps
-  const size_t rm_words = (size_t)bp.rows_pad + bp.rows_pad / 32 + bp.seg_pad + bp.seg_pad / 32;
+  // ---- row maps of every domain
   if ((rc = ensure(net->rowmeta_dev, rm_words * 4, c.s, false))) return rc;
   int32_t *r = reinterpret_cast<int32_t *>(net->rowmeta_dev.ptr);
-  c.row_seg = r; r += bp.rows_pad;
-  c.row_valid = reinterpret_cast<uint32_t *>(r); r += bp.rows_pad / 32;
-  c.urow_seg = r; r += bp.seg_pad;
-  c.urow_valid = reinterpret_cast<uint32_t *>(r);
   Prof prof{net, c.s};
   if ((rc = prof.begin(K_ROWMAP, 0))) return rc;
-  if ((rc = launch_rowmap(c.seg_row0, c.seg_len, S, bp.rows_pad, c.row_seg, c.row_valid, c.s))) return rc;
-  if ((rc = launch_rowmap(c.one_row0, c.one_len, 1, bp.seg_pad, c.urow_seg, c.urow_valid, c.s))) return rc;
+  for (size_t i = 0; i < ndom; ++i) {
+    const Domain &dm = net->domains[i];
+    c.dom[i].row_seg = r; r += c.dom[i].rows_pad;
+    c.dom[i].row_valid = reinterpret_cast<uint32_t *>(r); r += c.dom[i].rows_pad / 32;
+    const int nseg = (int)bp.dom[i].seg_row0.size();
+    if ((rc = launch_rowmap(c.dom[i].seg_row0, c.dom[i].seg_len, nseg, c.dom[i].rows_pad, dm.kind == 2 ? dm.pitch : 1, dm.kind == 2 ? dm.width : 1,
+                            c.dom[i].row_seg, c.dom[i].row_valid, c.s))) return rc;
+  }
   if ((rc = prof.end())) return rc;
   // ---- activation arena
   for (size_t i = 0; i < net->bufs.size(); ++i) {
     const Buffer &b = net->bufs[i];
-    const size_t rows = b.domain == ASV_DOMAIN_FRAMES ? bp.rows_pad : bp.seg_pad;
-    if ((rc = ensure(net->arena[i], rows * b.ld * net->elem_size(b.domain), c.s, true))) return rc;
+    if ((rc = ensure(net->arena[i], (size_t)c.dom[b.domain].rows_pad * b.ld * net->elem_size(b.domain), c.s, true))) return rc;
   }
   return ASV_OK;
 }
@@ -595,7 +729,9 @@ int run_ops(RunCtx &c, size_t n_ops) {
     switch (op.kind) {
       case OP_TDNN: {
         const auto &d = op.tdnn;
-        const bool bf16 = !op.utts && net->frames_bf16();
+        const int domid = net->bufs[d.in_buf].domain;
+        const DomainRun &dr = c.dom[domid];
+        const bool bf16 = net->dom_bf16(domid);
         TdnnKernelParams p;
         memset(&p, 0, sizeof(p));
         p.x = view(c, d.in_buf, d.in_ch_off); p.ldx = net->bufs[d.in_buf].ld;
@@ -605,16 +741,17 @@ int run_ops(RunCtx &c, size_t n_ops) {
         if (d.seg_scale_buf >= 0) { p.seg_scale = reinterpret_cast<const float *>(net->arena[d.seg_scale_buf].ptr); p.ld_segscale = net->bufs[d.seg_scale_buf].ld; }
         if (d.res_buf >= 0) { p.res = view(c, d.res_buf, d.res_ch_off); p.ldres = net->bufs[d.res_buf].ld; }
         p.y = view(c, d.out_buf, d.out_ch_off); p.ldy = net->bufs[d.out_buf].ld;
-        p.row_seg = op.utts ? c.urow_seg : c.row_seg;
-        p.row_valid = op.utts ? c.urow_valid : c.row_valid;
-        p.rows = op.utts ? bp.seg_pad : bp.rows_pad;
+        p.row_seg = dr.row_seg; p.row_valid = dr.row_valid; p.rows = dr.rows_pad;
         p.cin_pad = op.cin_pad; p.cout_store = op.cout_store;
         p.n_taps = d.n_taps;
-        for (int t = 0; t < d.n_taps; ++t) p.taps[t] = d.taps[t];
+        for (int t = 0; t < d.n_taps; ++t) { p.taps[t] = d.taps[t]; p.halo = std::max(p.halo, std::abs(d.taps[t])); }
         p.act1 = d.act1; p.act2 = d.act2; p.affine_first = d.affine_first;
         p.zero16 = net->zero_page;
-        const bool big = !use_ref && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && tdnn_big_supported(p, bf16, !bf16);
-        if (!use_ref && !big) {
+        p.wfrag = op.wfrag;
+        const bool narrow = p.halo <= kHalo;
+        const bool big3 = !use_ref && narrow && (net->flags & (ASV_FLAG_SMALL_TILES | ASV_FLAG_BIG_V2)) == 0 && tdnn_big3_supported(p, bf16, !bf16);
+        const bool big = !use_ref && narrow && !big3 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && tdnn_big_supported(p, bf16, !bf16);
+        if (!use_ref && !big && !big3) {
           // few output tiles (pooled-domain layers, short batches): slice K over more workgroups
           const int tiles = (p.rows / 128) * (round_up(p.cout_store, 128) / 128);
           const int nchunks = (p.cin_pad + (bf16 ? 64 : 32) - 1) / (bf16 ? 64 : 32);
@@ -629,9 +766,14 @@ int run_ops(RunCtx &c, size_t n_ops) {
             }
           }
         }
-        const double valid_rows = op.utts ? (double)bp.segments : (double)bp.frames;
+        double valid_rows = op.utts ? (double)bp.segments : (double)bp.frames;
+        if (net->domains[domid].kind == 2) {
+          valid_rows = 0;
+          for (int32_t len : bp.dom[domid].seg_len) valid_rows += (double)(len / net->domains[domid].pitch) * net->domains[domid].width;
+        }
         if ((rc = prof.begin(K_TDNN, 2.0 * valid_rows * d.in_ch * d.out_ch * d.n_taps, (int)i))) return rc;
         if (use_ref) rc = launch_tdnn_ref(p, bf16, !bf16, c.s);
+        else if (big3) rc = launch_tdnn_big3(p, c.s);
         else if (big) rc = launch_tdnn_big(p, c.s);
         else {
           rc = launch_tdnn_mfma(p, bf16, !bf16, c.s);
@@ -643,21 +785,26 @@ int run_ops(RunCtx &c, size_t n_ops) {
       }
       case OP_POOL: {
         const auto &d = op.pool;
+        const int domid = net->bufs[d.in_buf].domain;
+        const Domain &dm = net->domains[domid];
         PoolKernelParams p;
         p.x = view(c, d.in_buf, d.in_ch_off); p.ldx = net->bufs[d.in_buf].ld; p.channels = d.channels;
-        p.seg_row0 = c.seg_row0; p.seg_len = c.seg_len;
+        p.seg_row0 = c.dom[domid].seg_row0; p.seg_len = c.dom[domid].seg_len;
         p.out = reinterpret_cast<float *>(net->arena[d.out_buf].ptr) + d.out_ch_off; p.ld_out = net->bufs[d.out_buf].ld;
         p.stddev = d.stddev; p.unbiased = d.unbiased; p.var_mode = d.var_mode; p.eps = d.eps;
+        p.row_stride = d.per_bin ? dm.pitch : 1;
+        p.groups = d.per_bin ? dm.width : 1;
         if ((rc = prof.begin(K_POOL, 0, (int)i))) return rc;
-        if ((rc = launch_stats_pool(p, bp.segments, net->frames_bf16(), c.s))) return rc;
+        if ((rc = launch_stats_pool(p, bp.segments, net->dom_bf16(domid), c.s))) return rc;
         if ((rc = prof.end())) return rc;
         break;
       }
       case OP_ATTPOOL: {
         const auto &d = op.att;
+        const DomainRun &dr = c.dom[ASV_DOMAIN_FRAMES];
         if ((rc = prof.begin(K_ATT, 0, (int)i))) return rc;
         rc = launch_attentive_pool(view(c, d.x_buf, d.x_ch_off), net->bufs[d.x_buf].ld, view(c, d.logit_buf, d.logit_ch_off), net->bufs[d.logit_buf].ld,
-                                   d.channels, c.seg_row0, c.seg_len, bp.segments, d.eps,
+                                   d.channels, dr.seg_row0, dr.seg_len, bp.segments, d.eps,
                                    reinterpret_cast<float *>(net->arena[d.out_buf].ptr) + d.out_ch_off, net->bufs[d.out_buf].ld, net->frames_bf16(), c.s);
         if (rc) return rc;
         if ((rc = prof.end())) return rc;
@@ -665,6 +812,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
       }
       case OP_ELTWISE: {
         const auto &d = op.elt;
+        const int domid = net->bufs[d.a_buf].domain;
         EltwiseKernelParams p;
         memset(&p, 0, sizeof(p));
         p.a = view(c, d.a_buf, d.a_ch_off); p.lda = net->bufs[d.a_buf].ld;
@@ -673,11 +821,40 @@ int run_ops(RunCtx &c, size_t n_ops) {
         p.out = view(c, d.out_buf, d.out_ch_off); p.ldo = net->bufs[d.out_buf].ld;
         p.channels = d.channels;
         p.scale = op.scale; p.shift = op.shift;
+        p.act = d.act;
         if (d.seg_scale_buf >= 0) { p.seg_scale = reinterpret_cast<const float *>(net->arena[d.seg_scale_buf].ptr); p.ld_segscale = net->bufs[d.seg_scale_buf].ld; }
         if (op.utts) { p.rows = bp.segments; }
-        else { p.rows = bp.rows_pad; p.row_seg = c.row_seg; p.row_valid = c.row_valid; }
+        else { p.rows = c.dom[domid].rows_pad; p.row_seg = c.dom[domid].row_seg; p.row_valid = c.dom[domid].row_valid; }
         if ((rc = prof.begin(K_ELT, 0, (int)i))) return rc;
-        if ((rc = launch_eltwise(p, !op.utts && net->frames_bf16(), c.s))) return rc;
+        if ((rc = launch_eltwise(p, net->dom_bf16(domid), c.s))) return rc;
+        if ((rc = prof.end())) return rc;
+        break;
+      }
+      case OP_GRID_INPUT: {
+        const int domid = net->bufs[op.gin.out_buf].domain;
+        const DomainRun &dg = c.dom[domid];
+        if ((rc = prof.begin(K_GATHER, 0, (int)i))) return rc;
+        rc = launch_grid_from_frames(net->arena[0].ptr, net->bufs[0].ld, net->feat_dim, c.dom[ASV_DOMAIN_FRAMES].seg_row0, dg.seg_row0, dg.row_seg, dg.row_valid,
+                                     dg.rows_pad, net->domains[domid].pitch, net->arena[op.gin.out_buf].ptr, net->bufs[op.gin.out_buf].ld, net->frames_bf16(), c.s);
+        if (rc) return rc;
+        if ((rc = prof.end())) return rc;
+        break;
+      }
+      case OP_IM2COL: {
+        const auto &d = op.i2c;
+        const int din = net->bufs[d.in_buf].domain, dout = net->bufs[d.out_buf].domain;
+        Im2colParams p;
+        memset(&p, 0, sizeof(p));
+        p.in = net->arena[d.in_buf].ptr; p.out = net->arena[d.out_buf].ptr;
+        p.ldi = net->bufs[d.in_buf].ld; p.ldo = net->bufs[d.out_buf].ld;
+        p.channels = d.channels; p.n_taps = d.n_taps; p.stride = d.stride;
+        for (int t = 0; t < d.n_taps; ++t) { p.dt[t] = d.dt[t]; p.df[t] = d.df[t]; }
+        p.in_row0 = c.dom[din].seg_row0; p.in_len = c.dom[din].seg_len;
+        p.out_row0 = c.dom[dout].seg_row0; p.out_row_seg = c.dom[dout].row_seg; p.out_row_valid = c.dom[dout].row_valid;
+        p.in_pitch = net->domains[din].pitch; p.in_width = net->domains[din].width;
+        p.out_pitch = net->domains[dout].pitch; p.out_rows = c.dom[dout].rows_pad;
+        if ((rc = prof.begin(K_GATHER, 0, (int)i))) return rc;
+        if ((rc = launch_im2col(p, net->frames_bf16(), c.s))) return rc;
         if ((rc = prof.end())) return rc;
         break;
       }
@@ -689,8 +866,9 @@ int run_ops(RunCtx &c, size_t n_ops) {
 int pack_features(RunCtx &c, const float *feats) {
   Prof prof{c.net, c.s};
   int rc;
+  const DomainRun &dr = c.dom[ASV_DOMAIN_FRAMES];
   if ((rc = prof.begin(K_PACK, 0))) return rc;
-  if ((rc = launch_pack_input(feats, c.net->feat_dim, c.seg_src0, c.seg_row0, c.row_seg, c.bp.rows_pad, c.net->arena[0].ptr, c.net->bufs[0].ld,
+  if ((rc = launch_pack_input(feats, c.net->feat_dim, c.seg_src0, dr.seg_row0, dr.row_seg, dr.rows_pad, c.net->arena[0].ptr, c.net->bufs[0].ld,
                               c.net->frames_bf16(), c.s))) return rc;
   return prof.end();
 }
@@ -711,7 +889,7 @@ int asv_net_extract(asv_net_t *net, const float *feats, const int32_t *offsets, 
   if ((rc = run_ops(c, net->ops.size()))) return rc;
   Prof prof{net, c.s};
   if ((rc = prof.begin(K_COMBINE, 0))) return rc;
-  if ((rc = launch_combine(reinterpret_cast<const float *>(net->arena[net->out_buf].ptr), net->bufs[net->out_buf].ld, c.utt_seg0, c.utt_nseg, c.seg_len, n_utts,
+  if ((rc = launch_combine(reinterpret_cast<const float *>(net->arena[net->out_buf].ptr), net->bufs[net->out_buf].ld, c.utt_seg0, c.utt_nseg, c.seg_frames, n_utts,
                            net->embed_dim, out, c.s))) return rc;
   return prof.end();
 }
@@ -736,7 +914,8 @@ int asv_tdnn_forward(const asv_tdnn_desc_t *d, int precision, unsigned flags, co
   if ((rc = prepare(c, offsets, n_utts, 1 << 30))) return rc;
   if ((rc = pack_features(c, x))) return rc;
   if ((rc = run_ops(c, 1))) return rc;
-  if ((rc = launch_unpack_rows(net->arena[ob].ptr, net->bufs[ob].ld, d->out_ch, c.seg_src0, c.seg_row0, c.row_seg, c.bp.rows_pad, y, net->frames_bf16(), c.s))) return rc;
+  const DomainRun &dr = c.dom[ASV_DOMAIN_FRAMES];
+  if ((rc = launch_unpack_rows(net->arena[ob].ptr, net->bufs[ob].ld, d->out_ch, c.seg_src0, dr.seg_row0, dr.row_seg, dr.rows_pad, y, net->frames_bf16(), c.s))) return rc;
   ASV_HIP_CHECK(hipStreamSynchronize(c.s));
   return ASV_OK;
 }

@@ -12,7 +12,7 @@ import os
 
 ASV_OK = 0
 PREC_F32, PREC_BF16 = 0, 1
-FLAG_REF_KERNELS, FLAG_NO_FUSE, FLAG_SMALL_TILES = 1, 2, 4
+FLAG_REF_KERNELS, FLAG_NO_FUSE, FLAG_SMALL_TILES, FLAG_BIG_V2 = 1, 2, 4, 8
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
 DOMAIN_FRAMES, DOMAIN_UTTS = 0, 1
 MAX_TAPS = 9
@@ -52,6 +52,7 @@ class PoolDesc(C.Structure):
         ("out_buf", C.c_int32), ("out_ch_off", C.c_int32),
         ("stddev", C.c_int32), ("unbiased", C.c_int32), ("var_mode", C.c_int32),
         ("eps", C.c_float),
+        ("per_bin", C.c_int32),
     ]
 
 
@@ -75,6 +76,19 @@ class EltwiseDesc(C.Structure):
         ("seg_scale_buf", C.c_int32),
         ("out_buf", C.c_int32), ("out_ch_off", C.c_int32),
         ("scale", c_float_p), ("shift", c_float_p),
+        ("act", C.c_int32),
+    ]
+
+
+class GridInputDesc(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("out_buf", C.c_int32)]
+
+
+class Im2colDesc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("in_buf", C.c_int32), ("out_buf", C.c_int32), ("channels", C.c_int32), ("n_taps", C.c_int32), ("stride", C.c_int32),
+        ("dt", C.c_int32 * MAX_TAPS), ("df", C.c_int32 * MAX_TAPS),
     ]
 
 
@@ -91,7 +105,8 @@ _LIB = None
 # every symbol include/asv_amd.h declares (tests check the .so exports all of them)
 SYMBOLS = [
     "asv_version", "asv_last_error", "asv_device_count",
-    "asv_net_create", "asv_net_destroy", "asv_net_new_buffer", "asv_net_add_tdnn",
+    "asv_net_create", "asv_net_destroy", "asv_net_define_grid", "asv_net_new_buffer", "asv_net_add_tdnn",
+    "asv_net_add_grid_input", "asv_net_add_im2col",
     "asv_net_add_stats_pool", "asv_net_add_attentive_pool", "asv_net_add_eltwise",
     "asv_net_finalize", "asv_net_embed_dim", "asv_net_describe", "asv_net_extract",
     "asv_net_device_bytes", "asv_net_set_profiling", "asv_net_get_profile",
@@ -130,6 +145,9 @@ def lib():
     L.asv_net_create.argtypes = [C.POINTER(vp), ci, ci, cu, ci]
     L.asv_net_destroy.argtypes = [vp]; L.asv_net_destroy.restype = None
     L.asv_net_new_buffer.argtypes = [vp, ci, ci]
+    L.asv_net_define_grid.argtypes = [vp, ci, ci, ci]
+    L.asv_net_add_grid_input.argtypes = [vp, C.POINTER(GridInputDesc)]
+    L.asv_net_add_im2col.argtypes = [vp, C.POINTER(Im2colDesc)]
     L.asv_net_add_tdnn.argtypes = [vp, C.POINTER(TdnnDesc)]
     L.asv_net_add_stats_pool.argtypes = [vp, C.POINTER(PoolDesc)]
     L.asv_net_add_attentive_pool.argtypes = [vp, C.POINTER(AttPoolDesc)]

@@ -66,11 +66,15 @@ class Engine(object):
     def _build(self):
         L, g = self.lib, self.graph
         buf_of = {0: 0}
+        dom_of = {0: capi.DOMAIN_FRAMES, 1: capi.DOMAIN_UTTS}
+        for i, spec in enumerate(g.domains):
+            if spec[0] == "grid":
+                dom_of[i] = capi.check(L.asv_net_define_grid(self._net, spec[1], spec[2], spec[3]), "asv_net_define_grid")
         # one device buffer per IR tensor that something writes as a whole or in slices
         written = sorted({op.out.tid for op in g.ops})
         for tid in written:
             dom, ch = g.tensors[tid]
-            buf_of[tid] = capi.check(L.asv_net_new_buffer(self._net, dom, ch), "asv_net_new_buffer")
+            buf_of[tid] = capi.check(L.asv_net_new_buffer(self._net, dom_of[dom], ch), "asv_net_new_buffer")
 
         def bv(v):
             if v is None:
@@ -109,6 +113,7 @@ class Engine(object):
                 d.channels = op.inp.channels
                 d.out_buf, d.out_ch_off = bv(op.out)
                 d.stddev, d.unbiased, d.var_mode, d.eps = int(op.stddev), op.unbiased, op.var_mode, op.eps
+                d.per_bin = int(getattr(op, "per_bin", False))
                 capi.check(L.asv_net_add_stats_pool(self._net, C.byref(d)), "asv_net_add_stats_pool")
             elif op.kind == "attpool":
                 d = capi.AttPoolDesc()
@@ -130,7 +135,21 @@ class Engine(object):
                 d.out_buf, d.out_ch_off = bv(op.out)
                 d.scale = capi.f32_ptr(op.scale) if op.scale is not None else None
                 d.shift = capi.f32_ptr(op.shift) if op.shift is not None else None
+                d.act = capi.ACT_BY_NAME[getattr(op, "act", None)]
                 capi.check(L.asv_net_add_eltwise(self._net, C.byref(d)), "asv_net_add_eltwise")
+            elif op.kind == "grid_input":
+                d = capi.GridInputDesc()
+                d.struct_size = C.sizeof(capi.GridInputDesc)
+                d.out_buf = buf_of[op.out.tid]
+                capi.check(L.asv_net_add_grid_input(self._net, C.byref(d)), "asv_net_add_grid_input")
+            elif op.kind == "im2col":
+                d = capi.Im2colDesc()
+                d.struct_size = C.sizeof(capi.Im2colDesc)
+                d.in_buf, d.out_buf = buf_of[op.inp.tid], buf_of[op.out.tid]
+                d.channels, d.n_taps, d.stride = op.inp.channels, len(op.taps), op.stride
+                for i, (dt, df) in enumerate(op.taps):
+                    d.dt[i], d.df[i] = dt, df
+                capi.check(L.asv_net_add_im2col(self._net, C.byref(d)), "asv_net_add_im2col")
             else:
                 raise _ir.TraceError("op kind %r survived graph optimisation" % op.kind)
         if g.output.ch_off != 0:
@@ -229,10 +248,12 @@ def compile_model(model, function=None, device_index=None, precision=None, flags
 
 def infer_feat_dim(model):
     """Input feature dimension = in-channels of the first TDNN / conv layer."""
+    d = getattr(model, "inputs_dim", None)
+    if d is not None:
+        return int(d)
     for m in model.modules():
         if hasattr(m, "input_dim") and hasattr(m, "context"):
             return int(m.input_dim)
-    d = getattr(model, "inputs_dim", None)
     if d is None:
         raise _ir.TraceError("cannot infer the feature dimension of %s; pass feat_dim" % type(model).__name__)
     return int(d)

@@ -39,8 +39,8 @@ class View(object):
 
 
 class Op(object):
-    """kind in {'tdnn','pool','attpool','eltwise','cat'}; `out` is a View covering a whole
-    tensor until concat elision redirects it into a slice of a wider one."""
+    """kind in {'tdnn','pool','attpool','eltwise','cat','grid_input','im2col'}; `out` is a View covering
+    a whole tensor until concat elision redirects it into a slice of a wider one."""
 
     def __init__(self, kind, out, **attrs):
         self.kind, self.out = kind, out
@@ -55,13 +55,16 @@ class Op(object):
             names = ("x", "logits")
         elif self.kind == "eltwise":
             names = ("a", "b", "c", "seg_scale")
+        elif self.kind in ("grid_input", "im2col"):
+            names = ("inp",)
         else:
             return list(self.parts)
         return [getattr(self, n) for n in names if getattr(self, n, None) is not None]
 
     def input_names(self):
         return {"tdnn": ("inp", "inp2", "seg_bias", "seg_scale", "res"), "pool": ("inp",),
-                "attpool": ("x", "logits"), "eltwise": ("a", "b", "c", "seg_scale"), "cat": ()}[self.kind]
+                "attpool": ("x", "logits"), "eltwise": ("a", "b", "c", "seg_scale"), "cat": (), "grid_input": ("inp",),
+                "im2col": ("inp",)}[self.kind]
 
 
 class Graph(object):
@@ -69,6 +72,8 @@ class Graph(object):
         self.tensors = []          # [(domain, channels)]
         self.ops = []
         self.feat_dim = int(feat_dim)
+        # row domains: 0 frames, 1 utts, >= 2 (time, frequency) grids ("grid", time_shift, width, pitch)
+        self.domains = [("frames",), ("utts",)]
         self.new_tensor(DOMAIN_FRAMES, feat_dim)        # tensor 0 = input features
         self.output = None                                # View (utts domain)
 
@@ -82,15 +87,31 @@ class Graph(object):
     def full_view(self, tid):
         return View(tid, 0, self.tensors[tid][1])
 
+    def grid_domain(self, shift, width, pitch=None):
+        spec = ("grid", int(shift), int(width), int(pitch if pitch is not None else width + 1))
+        if spec[3] + 1 > 84:
+            raise TraceError("2-D trunk: %d frequency bins exceed the widest window the MI355X conv kernel stages (82)" % width)
+        if spec not in self.domains:
+            self.domains.append(spec)
+        return self.domains.index(spec)
+
+    def is_utts(self, tid):
+        return self.domains[self.domain(tid)][0] == "utts"
+
+    def grid_spec(self, tid):
+        d = self.domains[self.domain(tid)]
+        return d if d[0] == "grid" else None
+
     # ---- op constructors -------------------------------------------------------------
     def tdnn(self, inp, weight, bias, taps, w_left, act1=None, scale=None, shift=None, affine_first=False,
              act2=None, inp2=None, seg_bias=None, seg_scale=None, res=None):
         weight = np.ascontiguousarray(weight, dtype=np.float32)
         assert weight.ndim == 3 and weight.shape[1] == inp.channels, (weight.shape, inp)
         taps = [int(t) for t in taps]
-        if max(abs(t) for t in taps) > MAX_HALO:
-            raise TraceError("TDNN context %s reaches beyond the +-%d frame halo of the MI355X row layout" % (taps, MAX_HALO))
         dom = self.domain(inp.tid)
+        halo = MAX_HALO if dom == DOMAIN_FRAMES else (self.domains[dom][3] + 1 if self.domains[dom][0] == "grid" else 0)
+        if max(abs(t) for t in taps) > halo and dom != DOMAIN_UTTS:
+            raise TraceError("TDNN context %s reaches beyond the +-%d row halo of the MI355X row layout" % (taps, halo))
         if dom == DOMAIN_UTTS and taps != [0]:
             raise TraceError("a pooled (utterance-level) tensor only supports context [0], got %s" % (taps,))
         out = self.full_view(self.new_tensor(dom, weight.shape[0]))
@@ -100,9 +121,31 @@ class Graph(object):
                            act2=act2 or None, seg_bias=seg_bias, seg_scale=seg_scale, res=res))
         return out
 
-    def pool(self, inp, stddev=True, unbiased=0, var_mode=0, eps=1e-10):
-        out = self.full_view(self.new_tensor(DOMAIN_UTTS, inp.channels * (2 if stddev else 1)))
-        self.ops.append(Op("pool", out, inp=inp, stddev=bool(stddev), unbiased=int(unbiased), var_mode=int(var_mode), eps=float(eps)))
+    def pool(self, inp, stddev=True, unbiased=0, var_mode=0, eps=1e-10, per_bin=False):
+        ch = inp.channels * (2 if stddev else 1)
+        if per_bin:
+            ch *= self.grid_spec(inp.tid)[2]
+        out = self.full_view(self.new_tensor(DOMAIN_UTTS, ch))
+        self.ops.append(Op("pool", out, inp=inp, stddev=bool(stddev), unbiased=int(unbiased), var_mode=int(var_mode), eps=float(eps),
+                           per_bin=bool(per_bin)))
+        return out
+
+    def grid_input(self):
+        """features [T][F] -> one-channel (time, frequency) grid."""
+        dom = self.grid_domain(0, self.feat_dim)
+        out = self.full_view(self.new_tensor(dom, 1))
+        self.ops.append(Op("grid_input", out, inp=self.full_view(0)))
+        return out
+
+    def im2col(self, inp, taps, stride):
+        """taps: [(dt, df)]; output grid = input grid subsampled by `stride` in both axes."""
+        g = self.grid_spec(inp.tid)
+        assert g is not None and inp.ch_off == 0 and inp.channels == self.tensors[inp.tid][1]
+        if inp.channels % CHAN_ALIGN != 0:
+            raise TraceError("strided 2-D convolution over %d channels: the gather needs a multiple of %d" % (inp.channels, CHAN_ALIGN))
+        dom = self.grid_domain(g[1] + (1 if stride == 2 else 0), (g[2] + stride - 1) // stride)
+        out = self.full_view(self.new_tensor(dom, inp.channels * len(taps)))
+        self.ops.append(Op("im2col", out, inp=inp, taps=[(int(a), int(b)) for a, b in taps], stride=int(stride)))
         return out
 
     def attpool(self, x, logits, eps=1e-5):
@@ -110,10 +153,10 @@ class Graph(object):
         self.ops.append(Op("attpool", out, x=x, logits=logits, eps=float(eps)))
         return out
 
-    def eltwise(self, a, b=None, c=None, seg_scale=None, scale=None, shift=None):
+    def eltwise(self, a, b=None, c=None, seg_scale=None, scale=None, shift=None, act=None):
         out = self.full_view(self.new_tensor(self.domain(a.tid), a.channels))
         f32 = lambda v: None if v is None else np.ascontiguousarray(v, dtype=np.float32)
-        self.ops.append(Op("eltwise", out, a=a, b=b, c=c, seg_scale=seg_scale, scale=f32(scale), shift=f32(shift)))
+        self.ops.append(Op("eltwise", out, a=a, b=b, c=c, seg_scale=seg_scale, scale=f32(scale), shift=f32(shift), act=act or None))
         return out
 
     def cat(self, parts):
@@ -158,7 +201,8 @@ class Graph(object):
         return self
 
     def _is_plain_add(self, op):
-        return (op.kind == "eltwise" and op.b is not None and op.c is None and op.seg_scale is None and op.scale is None)
+        return (op.kind == "eltwise" and op.b is not None and op.c is None and op.seg_scale is None and op.scale is None
+                and getattr(op, "act", None) is None)
 
     def _cse_adds(self):
         seen = {}
@@ -183,7 +227,7 @@ class Graph(object):
                     continue
                 for first, other in ((op.a, op.b), (op.b, op.a)):
                     p = prod.get(first.tid)
-                    if (p is None or p.kind != "eltwise" or p is op or uses.get(first.tid, 0) != 1
+                    if (p is None or p.kind != "eltwise" or p is op or uses.get(first.tid, 0) != 1 or getattr(p, "act", None) is not None
                             or first.channels != self.tensors[first.tid][1] or first.ch_off != 0):
                         continue
                     slot = "b" if p.b is None else ("c" if p.c is None else None)
@@ -239,7 +283,7 @@ class Graph(object):
                     p.out = dst
                     self._replace_tensor(part.tid, dst)
                 else:
-                    new_ops.append(Op("eltwise", dst, a=part, b=None, c=None, seg_scale=None, scale=None, shift=None))
+                    new_ops.append(Op("eltwise", dst, a=part, b=None, c=None, seg_scale=None, scale=None, shift=None, act=None))
                 off += part.channels
             self.ops[idx:idx + 1] = new_ops
 
@@ -268,12 +312,16 @@ class Graph(object):
                     if getattr(op, n) is not None:
                         extra += " %s=%r" % (n, getattr(op, n))
             elif op.kind == "pool":
-                ins, extra = repr(op.inp), "stddev=%s unbiased=%d var_mode=%d eps=%g" % (op.stddev, op.unbiased, op.var_mode, op.eps)
+                ins, extra = repr(op.inp), "stddev=%s unbiased=%d var_mode=%d eps=%g per_bin=%s" % (op.stddev, op.unbiased, op.var_mode, op.eps, op.per_bin)
+            elif op.kind == "grid_input":
+                ins, extra = repr(op.inp), ""
+            elif op.kind == "im2col":
+                ins, extra = repr(op.inp), "taps=%d stride=%d" % (len(op.taps), op.stride)
             elif op.kind == "attpool":
                 ins, extra = "x=%r logits=%r" % (op.x, op.logits), "eps=%g" % op.eps
             elif op.kind == "eltwise":
                 ins = " ".join("%s=%r" % (n, getattr(op, n)) for n in ("a", "b", "c", "seg_scale") if getattr(op, n) is not None)
-                extra = "affine=%s" % (op.scale is not None)
+                extra = "affine=%s act=%s" % (op.scale is not None, op.act)
             else:
                 ins, extra = repr(op.parts), ""
             lines.append("  %2d %-8s %s -> %r  %s" % (i, op.kind, ins, op.out, extra))
@@ -287,8 +335,11 @@ class Graph(object):
             if op.kind != "tdnn":
                 continue
             f = 2 * op.inp.channels * op.weight.shape[0] * len(op.taps)
+            g = self.grid_spec(op.inp.tid)
             if self.domain(op.inp.tid) == DOMAIN_FRAMES:
                 per_frame += f
+            elif g is not None:
+                per_frame += f * g[2] / float(1 << g[1])       # width positions per frame, every 2^shift-th frame
             else:
                 per_utt += f
         return per_frame, per_utt
@@ -298,8 +349,13 @@ class Graph(object):
 # symbolic tensor handed to the blueprint's extract_embedding body
 
 class Sym(object):
-    def __init__(self, graph, view, rank=3):
+    """rank 3: [1, C, T] (frames) / [1, C, 1] (pooled); rank 2: [1, C] (pooled); rank 4: [1, C, F, T] on a
+    (time, frequency) grid.  `flat_grid` marks the [1, C*F, T] reshape of a rank-4 tensor; `col_order`
+    (pooled tensors) maps this tensor's columns to the reference's column order."""
+
+    def __init__(self, graph, view, rank=3, flat_grid=False, col_order=None):
         self.graph, self.view, self.rank = graph, view, rank
+        self.flat_grid, self.col_order = flat_grid, col_order
 
     # -- what blueprint code inspects
     @property
@@ -308,6 +364,9 @@ class Sym(object):
 
     @property
     def shape(self):
+        g = self.graph.grid_spec(self.view.tid)
+        if g is not None:
+            return (1, self.view.channels * g[2], -1) if self.flat_grid else (1, self.view.channels, g[2], -1)
         if self.rank == 2:
             return (1, self.view.channels)
         return (1, self.view.channels, 1 if self.domain == DOMAIN_UTTS else -1)
@@ -328,13 +387,23 @@ class Sym(object):
     # -- shape ops that are free in this layout
     def unsqueeze(self, dim):
         if self.rank == 2 and dim in (2, -1) and self.domain == DOMAIN_UTTS:
-            return Sym(self.graph, self.view, 3)
+            return Sym(self.graph, self.view, 3, col_order=self.col_order)
+        if self.rank == 3 and dim == 1 and self.view.tid == 0:
+            # ResNetXvector: [B, F, T] -> [B, 1, F, T] (resnet_xvector.py:191)
+            return Sym(self.graph, self.graph.grid_input(), 4)
         raise TraceError("unsqueeze(%r) of a rank-%d %s tensor is not supported" % (dim, self.rank, "utts" if self.domain else "frames"))
 
     def squeeze(self, dim=None):
         if self.rank == 3 and self.domain == DOMAIN_UTTS and dim in (None, 2, -1):
-            return Sym(self.graph, self.view, 2)
+            return Sym(self.graph, self.view, 2, col_order=self.col_order)
         raise TraceError("squeeze(%r) is only supported on pooled tensors" % (dim,))
+
+    def reshape(self, *shape):
+        shape = shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else shape
+        g = self.graph.grid_spec(self.view.tid)
+        if g is not None and self.rank == 4 and len(shape) == 3 and shape[1] == self.view.channels * g[2]:
+            return Sym(self.graph, self.view, 3, flat_grid=True)       # [B, C*F, T]: channel index c*F + f
+        raise TraceError("reshape%r of this tensor is not supported on the MI355X path" % (tuple(shape),))
 
     def contiguous(self):
         return self

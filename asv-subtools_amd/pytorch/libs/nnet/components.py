@@ -71,6 +71,8 @@ class TdnnAffine(torch.nn.Module):
         if x.view.channels != self.input_dim:
             raise _ir.TraceError("TdnnAffine expects %d input channels, got %d" % (self.input_dim, x.view.channels))
         w = self.weight.detach().cpu().numpy()
+        if getattr(x, "col_order", None) is not None:
+            w = w[:, x.col_order, :]           # the pooled tensor's columns are a permutation of the reference's
         b = self.bias.detach().cpu().numpy() if self.bias is not None else None
         out = x.graph.tdnn(x.view, w, b, self.context, self.left_context, act1=act1, scale=scale, shift=shift,
                            affine_first=affine_first)

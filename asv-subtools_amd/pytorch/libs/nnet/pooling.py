@@ -22,6 +22,19 @@ class StatisticsPooling(torch.nn.Module):
 
     def forward(self, inputs, lengths=None):
         if isinstance(inputs, _ir.Sym):
+            g = inputs.graph.grid_spec(inputs.view.tid)
+            if g is not None:
+                # ResNetXvector: [B, C*F', T'] with channel index c*F' + f (resnet_xvector.py:193).  The device pools
+                # every frequency bin over time and lays the row out bin-major: [f][mean(C) | std(C)]
+                if not inputs.flat_grid or inputs.view.channels * g[2] != self.input_dim:
+                    raise _ir.TraceError("StatisticsPooling over a 2-D tensor expects the [B, C*F, T] reshape with C*F == %d" % self.input_dim)
+                import numpy as np
+                C, F = inputs.view.channels, g[2]
+                nstat = 2 if self.stddev else 1
+                out = inputs.graph.pool(inputs.view, stddev=self.stddev, unbiased=1 if self.unbiased else 0, var_mode=0, eps=self.eps, per_bin=True)
+                mine = np.arange(F * nstat * C)
+                f, stat, c = mine // (nstat * C), (mine // C) % nstat, mine % C
+                return _ir.Sym(inputs.graph, out, 3, col_order=stat * (C * F) + c * F + f)
             if inputs.view.channels != self.input_dim:
                 raise _ir.TraceError("StatisticsPooling expects %d channels, got %d" % (self.input_dim, inputs.view.channels))
             # true per-utterance lengths are always used on the HIP path (ragged batches)

@@ -1,12 +1,191 @@
 # -*- coding:utf-8 -*-
-"""2-D ResNet trunk of ResNetXvector (reference libs/nnet/resnet.py:212-371).
+"""2-D ResNet trunk of ResNetXvector: same class names, constructor arguments and state_dict keys
+as the reference (/root/reference/pytorch/libs/nnet/resnet.py: conv3x3/conv1x1 12-20, BasicBlock
+23-110, ResNet 212-371), parameter holders whose forward() records the trunk for libasv_amd.so.
 
-Status: SURVEY.md section 8 rows a12-a14 (config C5) are not built yet; constructing the
-trunk says so instead of silently running torch convolutions."""
+Mapping to the device program: a [B, C, F, T] tensor is a "grid" buffer whose
+rows are (time, frequency) positions, frequency fastest, with one zero row after the F bins of every
+frame.  A stride-1 3x3 convolution is then a 9-tap layer with row offsets dt*(F+1) + df - the same
+implicit-GEMM kernel as the TDNN layers with a wider staged window; stride-2 convolutions (first block
+of layers 2-4 and their 1x1 down-sampling branch) go through an im2col gather + one GEMM.  Eval
+BatchNorm follows the convolution directly, so it is folded into the weights (scale) and bias (shift).
 
+Implemented: BasicBlock in the original (conv-BN-ReLU) form with optional SE, head conv 3x3 / stride 1,
+no max-pool - the configuration of BASELINE config C5 and of the reference launchers
+(runResnetXvector_online.py:221-260).  Other options raise.
+"""
+
+import numpy as np
 import torch
+import torch.nn as nn
+
+from libs.amd import ir as _ir
+from libs.nnet.components import SEBlock_2D
 
 
-class ResNet(torch.nn.Module):
+def conv3x3(in_planes, out_planes, Conv=nn.Conv2d, stride=1, groups=1, dilation=1):
+    return Conv(in_planes, out_planes, kernel_size=3, stride=stride, padding=dilation, groups=groups, bias=False, dilation=dilation)
+
+
+def conv1x1(in_planes, out_planes, Conv=nn.Conv2d, stride=1):
+    return Conv(in_planes, out_planes, kernel_size=1, stride=stride, bias=False)
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _folded_bn(bn):
+    g = _np(bn.weight) if bn.affine else None
+    b = _np(bn.bias) if bn.affine else None
+    return _ir.fold_batchnorm(_np(bn.running_mean), _np(bn.running_var), g, b, bn.eps)
+
+
+def emit_conv_bn(x, conv, bn, relu):
+    """conv (3x3 pad 1 or 1x1, stride 1|2, no bias) -> eval BN [-> ReLU] on a rank-4 grid Sym."""
+    g = x.graph
+    spec = g.grid_spec(x.view.tid)
+    if spec is None or x.rank != 4:
+        raise _ir.TraceError("2-D convolution applied to a tensor that is not a [B, C, F, T] grid")
+    k, stride = conv.kernel_size[0], conv.stride[0]
+    if conv.kernel_size not in ((3, 3), (1, 1)) or conv.stride[0] != conv.stride[1] or stride not in (1, 2) or conv.groups != 1 \
+            or conv.dilation != (1, 1) or conv.padding != (k // 2, k // 2) or conv.bias is not None:
+        raise _ir.TraceError("Conv2d%r: only 3x3/pad 1 and 1x1 kernels with stride 1 or 2 are implemented" % (conv,))
+    scale, shift = _folded_bn(bn)
+    w = _np(conv.weight).astype(np.float64) * scale.astype(np.float64)[:, None, None, None]       # [Cout, Cin, kF, kT]
+    cout, cin = w.shape[0], w.shape[1]
+    half = k // 2
+    pos = [(dt, df) for df in range(-half, half + 1) for dt in range(-half, half + 1)]             # (time, frequency) offsets
+    act = "relu" if relu else None
+    if stride == 1:
+        pitch = spec[3]
+        taps = sorted(dt * pitch + df for dt, df in pos)
+        left = taps[0]
+        dense = np.zeros((cout, cin, taps[-1] - left + 1), dtype=np.float32)
+        for dt, df in pos:
+            dense[:, :, dt * pitch + df - left] = w[:, :, df + half, dt + half]
+        inp = x.view
+        if cin % _ir.CHAN_ALIGN != 0 and x.view.channels == cin:
+            pass                                                    # e.g. the 1-channel head: the buffer pitch is zero padded
+        out = g.tdnn(inp, dense, shift, taps, left, act1=act)
+    else:
+        cols = g.im2col(x.view, pos, stride)                        # [rows'][k*cin + c]
+        flat = np.zeros((cout, cin * len(pos), 1), dtype=np.float32)
+        for i, (dt, df) in enumerate(pos):
+            flat[:, i * cin:(i + 1) * cin, 0] = w[:, :, df + half, dt + half]
+        out = g.tdnn(cols, flat, shift, [0], 0, act1=act)
+    return _ir.Sym(g, out, 4)
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, Conv=nn.Conv2d, stride=1, downsample=None, groups=1, base_width=64, dilation=1, norm_layer=None,
+                 norm_layer_params={}, full_pre_activation=True, use_se=False, se_ratio=4):
+        super(BasicBlock, self).__init__()
+        if norm_layer is None:
+            norm_layer = nn.BatchNorm2d
+        if groups != 1 or base_width != 64:
+            raise ValueError("BasicBlock only supports groups=1 and base_width=64")
+        if dilation > 1:
+            raise NotImplementedError("Dilation > 1 not supported in BasicBlock")
+        if full_pre_activation:
+            raise NotImplementedError("full_pre_activation=True (BN-ReLU-conv blocks) is not implemented on the MI355X path; "
+                                      "BASELINE config C5 and the reference launchers use full_pre_activation=False")
+        self.downsample = downsample
+        self.stride = stride
+        self.full_pre_activation = full_pre_activation
+        self.conv1 = conv3x3(inplanes, planes, Conv, stride)
+        self.bn1 = norm_layer(planes, **norm_layer_params)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.conv2 = conv3x3(planes, planes, Conv)
+        self.bn2 = norm_layer(planes, **norm_layer_params)
+        self.relu2 = nn.ReLU(inplace=True)
+        self.se = SEBlock_2D(planes, se_ratio) if use_se else nn.Identity()
+
+    def forward(self, x):
+        if not isinstance(x, _ir.Sym):
+            raise NotImplementedError("BasicBlock.forward() on a torch tensor: eager forward is not part of asv-subtools_amd")
+        g = x.graph
+        identity = x if self.downsample is None else emit_conv_bn(x, self.downsample[0], self.downsample[1], relu=False)
+        y = emit_conv_bn(x, self.conv1, self.bn1, relu=True)
+        y = emit_conv_bn(y, self.conv2, self.bn2, relu=False)
+        seg_scale = None
+        if isinstance(self.se, SEBlock_2D):
+            spec = g.grid_spec(y.view.tid)
+            # mean over (F, T): the device pools over all rows of the segment incl. the zero row of each frame,
+            # i.e. sum / (frames * pitch); the factor pitch / width is folded into fc_1
+            m = g.pool(y.view, stddev=False)
+            w1 = _np(self.se.fc_1.weight)[:, :, None] * np.float32(spec[3] / float(spec[2]))
+            h = g.tdnn(m, w1, _np(self.se.fc_1.bias), [0], 0, act1="relu")
+            seg_scale = g.tdnn(h, _np(self.se.fc_2.weight)[:, :, None], _np(self.se.fc_2.bias), [0], 0, act1="sigmoid")
+        out = g.eltwise(y.view, b=identity.view, seg_scale=seg_scale, act="relu")
+        return _ir.Sym(g, out, 4)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
     def __init__(self, *args, **kwargs):
-        raise NotImplementedError("the ResNet34-SE 2-D trunk (config C5) is not implemented on the MI355X path yet")
+        raise NotImplementedError("Bottleneck blocks are not implemented on the MI355X path (the target ResNet34 uses BasicBlock)")
+
+
+class ResNet(nn.Module):
+    """pre-conv + 4 residual stages, no avg-pool / fc (reference resnet.py:212-371)."""
+
+    def __init__(self, head_inplanes, block="BasicBlock", layers=[3, 4, 6, 3], planes=[32, 64, 128, 256], convXd=2, full_pre_activation=True,
+                 use_se=False, se_ratio=4, head_conv=True, head_conv_params={"kernel_size": 3, "stride": 1, "padding": 1}, head_maxpool=True,
+                 head_maxpool_params={"kernel_size": 3, "stride": 1, "padding": 1}, zero_init_residual=False, groups=1, width_per_group=64,
+                 replace_stride_with_dilation=None, norm_layer=None, norm_layer_params={}):
+        super(ResNet, self).__init__()
+        if convXd != 2:
+            raise NotImplementedError("convXd=%r: only the 2-D trunk is implemented on the MI355X path" % (convXd,))
+        if block != "BasicBlock":
+            raise NotImplementedError("block=%r: only BasicBlock is implemented on the MI355X path" % (block,))
+        if head_maxpool or not head_conv or head_conv_params != {"kernel_size": 3, "stride": 1, "padding": 1}:
+            raise NotImplementedError("only the ResNetXvector head (3x3 conv, stride 1, no max-pool) is implemented on the MI355X path")
+        if replace_stride_with_dilation not in (None, [False, False, False]) or groups != 1:
+            raise NotImplementedError("dilated / grouped ResNet variants are not implemented on the MI355X path")
+        norm_layer = norm_layer or nn.BatchNorm2d
+        self._norm_layer = norm_layer
+        self.norm_layer_params = norm_layer_params
+        self.full_pre_activation = full_pre_activation
+        self.head_conv, self.head_maxpool = head_conv, head_maxpool
+        self.Conv = nn.Conv2d
+        self.inplanes = planes[0]
+        self.conv1 = nn.Conv2d(head_inplanes, self.inplanes, bias=False, **head_conv_params)
+        self.bn1 = norm_layer(self.inplanes, **norm_layer_params)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = None
+        self.downsample_multiple = head_conv_params["stride"]
+        self.layer1 = self._make_layer(planes[0], layers[0], 1, use_se, se_ratio)
+        self.layer2 = self._make_layer(planes[1], layers[1], 2, use_se, se_ratio)
+        self.layer3 = self._make_layer(planes[2], layers[2], 2, use_se, se_ratio)
+        self.layer4 = self._make_layer(planes[3], layers[3], 2, use_se, se_ratio)
+        self.downsample_multiple *= 8
+        self.output_planes = planes[3] * BasicBlock.expansion
+
+    def _make_layer(self, planes, blocks, stride, use_se, se_ratio):
+        downsample = None
+        if stride != 1 or self.inplanes != planes:
+            downsample = nn.Sequential(conv1x1(self.inplanes, planes, nn.Conv2d, stride), self._norm_layer(planes, **self.norm_layer_params))
+        kw = dict(norm_layer=self._norm_layer, norm_layer_params=self.norm_layer_params, full_pre_activation=self.full_pre_activation,
+                  use_se=use_se, se_ratio=se_ratio)
+        seq = [BasicBlock(self.inplanes, planes, nn.Conv2d, stride, downsample, **kw)]
+        self.inplanes = planes
+        seq += [BasicBlock(planes, planes, nn.Conv2d, **kw) for _ in range(1, blocks)]
+        return nn.Sequential(*seq)
+
+    def get_downsample_multiple(self):
+        return self.downsample_multiple
+
+    def get_output_planes(self):
+        return self.output_planes
+
+    def forward(self, x):
+        if not isinstance(x, _ir.Sym):
+            raise NotImplementedError("ResNet.forward() on a torch tensor: eager forward is not part of asv-subtools_amd")
+        x = emit_conv_bn(x, self.conv1, self.bn1, relu=True)
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            x = layer(x)
+        return x

@@ -56,7 +56,8 @@ int         asv_device_count(int *count);
 /* flags for asv_net_create */
 #define ASV_FLAG_REF_KERNELS 1u  /* run the plain-VALU self-check kernels instead of MFMA ones */
 #define ASV_FLAG_NO_FUSE     2u  /* disable epilogue fusions (stats pooling into the producer)  */
-#define ASV_FLAG_SMALL_TILES 4u  /* never pick the 256x256 direct-to-LDS kernel (A/B testing)   */
+#define ASV_FLAG_SMALL_TILES 4u  /* never pick the 256x256 kernels (A/B testing)                    */
+#define ASV_FLAG_BIG_V2      8u  /* 256x256 kernel variant 2 (both operands through LDS) instead of 3 */
 
 #define ASV_ACT_NONE    0
 #define ASV_ACT_RELU    1
@@ -65,6 +66,7 @@ int         asv_device_count(int *count);
 
 #define ASV_DOMAIN_FRAMES 0  /* one row per frame, ragged over utterance segments */
 #define ASV_DOMAIN_UTTS   1  /* one row per utterance segment (after pooling); always f32 */
+/* ids >= 2: (time, frequency) grids of the 2-D ResNet trunk, created by asv_net_define_grid() */
 
 #define ASV_MAX_TAPS 9
 
@@ -75,6 +77,13 @@ typedef struct asv_net asv_net_t;
  * matrix (frames domain, `feat_dim` channels). */
 int  asv_net_create(asv_net_t **net, int device, int precision, unsigned flags, int feat_dim);
 void asv_net_destroy(asv_net_t *net);
+
+/* Declares a 2-D row domain for libs/nnet/resnet.py-style trunks: a segment of T frames owns
+ * ceil(T / 2^time_shift) frames x `pitch` rows ((time, frequency) positions, frequency fastest),
+ * of which the first `width` rows of every frame are real and the rest zero padding.  A 3x3
+ * convolution (resnet.py:12-15) over such a buffer is a 9-tap layer with row offsets dt*pitch + df.
+ * Returns the domain id (>= 2). */
+int  asv_net_define_grid(asv_net_t *net, int time_shift, int width, int pitch);
 
 /* Declares an activation buffer; returns its id (>= 1) or a negative error. */
 int  asv_net_new_buffer(asv_net_t *net, int domain, int channels);
@@ -117,6 +126,9 @@ typedef struct asv_pool_desc {
   int32_t out_buf, out_ch_off;   /* utts domain; needs channels*(1+stddev) columns            */
   int32_t stddev, unbiased, var_mode;
   float   eps;
+  int32_t per_bin;               /* grid inputs: 1 = pool every frequency bin separately over time; the
+                                    output row holds [bin][mean(C) | std(C)] (ResNetXvector reshape +
+                                    StatisticsPooling, resnet_xvector.py:193-194, in bin-major order) */
 } asv_pool_desc_t;
 int asv_net_add_stats_pool(asv_net_t *net, const asv_pool_desc_t *d);
 
@@ -138,8 +150,26 @@ typedef struct asv_eltwise_desc {
   int32_t seg_scale_buf;                                        /* -1 = absent       */
   int32_t out_buf, out_ch_off;
   const float *scale, *shift;    /* optional host per-channel affine applied to `a` first    */
+  int32_t act;                   /* activation applied to the sum (BasicBlock's final ReLU)  */
 } asv_eltwise_desc_t;
 int asv_net_add_eltwise(asv_net_t *net, const asv_eltwise_desc_t *d);
+
+/* ResNetXvector's `x.unsqueeze(1)` (resnet_xvector.py:191): the input features [T][F] become a
+ * one-channel grid buffer (domain: time_shift 0, width = feat_dim). */
+typedef struct asv_grid_input_desc {
+  uint32_t struct_size;
+  int32_t out_buf;
+} asv_grid_input_desc_t;
+int asv_net_add_grid_input(asv_net_t *net, const asv_grid_input_desc_t *d);
+
+/* im2col gather between grids for strided convolutions (resnet.py stride-2 conv3x3 / conv1x1
+ * downsample): out[(t', f')][k*C + c] = in[(stride*t' + dt[k], stride*f' + df[k])][c], zero outside. */
+typedef struct asv_im2col_desc {
+  uint32_t struct_size;
+  int32_t in_buf, out_buf, channels, n_taps, stride;
+  int32_t dt[ASV_MAX_TAPS], df[ASV_MAX_TAPS];
+} asv_im2col_desc_t;
+int asv_net_add_im2col(asv_net_t *net, const asv_im2col_desc_t *d);
 
 /* Freezes the program; `out_buf` must be an utts-domain buffer: its first `embed_dim`
  * channels are the embedding. */

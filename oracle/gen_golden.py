@@ -78,6 +78,15 @@ CASES = {
                                    creation="ECAPA_TDNN(80,10,training=False,extracted_embedding='near_affine',"
                                             "ecapa_params={'channels':512,'embd_dim':192,'mfa_conv':1536})",
                                    dim=80, utts=[(200, 3300), (150, 3301)], wseed=5),
+    # BASELINE config C5 extractor: ResNet34-SE (32-64-128-256), launcher-style fc2 (runResnetXvector_online.py:221-260)
+    "resnet34se_c5": dict(blueprint="resnet_xvector.py",
+                          creation="ResNetXvector(80,10,training=False,resnet_params={'use_se':True,'se_ratio':4,'full_pre_activation':False},"
+                                   "fc2_params={'nonlinearity':'','bn_params':{'momentum':0.5,'affine':False,'track_running_stats':True}})",
+                          dim=80, utts=[(200, 5000), (203, 5001), (9, 5002), (64, 5003)], wseed=6),
+    # no SE, default fc2 (ReLU + affine BN), odd feature dim -> ceil division at every stride-2 stage
+    "resnet34_plain": dict(blueprint="resnet_xvector.py",
+                           creation="ResNetXvector(61,10,training=False,resnet_params={'full_pre_activation':False})",
+                           dim=61, utts=[(150, 5100), (77, 5101)], wseed=7),
 }
 
 

@@ -250,3 +250,76 @@ def extract_embedding(embed_fn, feats, max_chunk=10000, dtype=np.float32):
 
 def cast_state_dict(sd, dtype):
     return {k: (v.astype(dtype) if v.dtype.kind == "f" else v) for k, v in sd.items()}
+
+
+# ----------------------------------------------------------------------------- ResNet (2-D)
+
+def conv2d(x, weight, stride=1, padding=1):
+    """nn.Conv2d(bias=False) as used by libs/nnet/resnet.py:12-20.  x [T, F, Cin] (time, frequency,
+    channels - the reference holds [B, C, F, T]); weight [Cout, Cin, kF, kT] exactly as in the
+    checkpoint (kernel height = frequency axis, width = time axis)."""
+    T, F, Cin = x.shape
+    Cout, _, kF, kT = weight.shape
+    xp = np.zeros((T + 2 * padding, F + 2 * padding, Cin), dtype=x.dtype)
+    xp[padding:padding + T, padding:padding + F] = x
+    To = (T + 2 * padding - kT) // stride + 1
+    Fo = (F + 2 * padding - kF) // stride + 1
+    y = np.zeros((To, Fo, Cout), dtype=x.dtype)
+    for df in range(kF):
+        for dt in range(kT):
+            patch = xp[dt:dt + (To - 1) * stride + 1:stride, df:df + (Fo - 1) * stride + 1:stride]
+            y += patch @ weight[:, :, df, dt].T.astype(x.dtype)
+    return y
+
+
+def se_block_2d(x, sd, prefix):
+    """components.py:622-639: global average over (F, T) -> Linear -> ReLU -> Linear -> Sigmoid -> scale."""
+    m = x.mean(axis=(0, 1), dtype=x.dtype)
+    h = np.maximum(m @ sd[prefix + ".fc_1.weight"].T.astype(x.dtype) + sd[prefix + ".fc_1.bias"].astype(x.dtype), 0)
+    s = 1.0 / (1.0 + np.exp(-(h @ sd[prefix + ".fc_2.weight"].T.astype(x.dtype) + sd[prefix + ".fc_2.bias"].astype(x.dtype))))
+    return x * s.astype(x.dtype)
+
+
+def basic_block(x, sd, prefix, stride):
+    """BasicBlock original form (resnet.py:70-85): conv-BN-ReLU-conv-BN-SE-(+identity)-ReLU;
+    downsample = 1x1 conv (stride) + BN when present in the checkpoint."""
+    identity = x
+    y = conv2d(x, sd[prefix + ".conv1.weight"], stride, 1)
+    y = np.maximum(batchnorm_eval(y, sd, prefix + ".bn1"), 0)
+    y = conv2d(y, sd[prefix + ".conv2.weight"], 1, 1)
+    y = batchnorm_eval(y, sd, prefix + ".bn2")
+    if prefix + ".se.fc_1.weight" in sd:
+        y = se_block_2d(y, sd, prefix + ".se")
+    if prefix + ".downsample.0.weight" in sd:
+        identity = batchnorm_eval(conv2d(x, sd[prefix + ".downsample.0.weight"], stride, 0), sd, prefix + ".downsample.1")
+    return np.maximum(y + identity, 0)
+
+
+def resnet_trunk(x, sd, prefix="resnet", layers=(3, 4, 6, 3)):
+    """ResNet._forward_impl (resnet.py:352-368) with head_conv 3x3/stride 1, no max-pool."""
+    y = conv2d(x, sd[prefix + ".conv1.weight"], 1, 1)
+    y = np.maximum(batchnorm_eval(y, sd, prefix + ".bn1"), 0)
+    for li, n in enumerate(layers):
+        for b in range(n):
+            y = basic_block(y, sd, "%s.layer%d.%d" % (prefix, li + 1, b), 2 if (li > 0 and b == 0) else 1)
+    return y
+
+
+def resnet_embed(x, sd, position="near", fc2_nonlinearity="relu", layers=(3, 4, 6, 3)):
+    """model/resnet_xvector.py:183-208.  x [T, D] -> trunk on [T, F=D, 1] -> [T', F', C] ->
+    reshape to channel index c*F' + f (resnet_xvector.py:193) -> StatisticsPooling -> fc2."""
+    y = resnet_trunk(x[:, :, None], sd, "resnet", layers)           # [T', F', C]
+    To, Fo, C = y.shape
+    feat = y.transpose(0, 2, 1).reshape(To, C * Fo)                 # column index c*F' + f
+    s = statistics_pooling(feat)[None, :]
+    has_fc1 = "fc1.affine.weight" in sd
+    if position == "far":
+        assert has_fc1
+        return tdnn_affine(s, sd["fc1.affine.weight"], sd["fc1.affine.bias"], [0])[0]
+    if has_fc1:
+        s = relu_bn_tdnn(s, sd, "fc1")
+    if position == "near_affine":
+        return tdnn_affine(s, sd["fc2.affine.weight"], sd["fc2.affine.bias"], [0])[0]
+    if position == "near":
+        return relu_bn_tdnn(s, sd, "fc2", nonlinearity=fc2_nonlinearity)[0]
+    raise TypeError(position)

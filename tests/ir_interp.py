@@ -21,8 +21,25 @@ def run_graph(graph, feats, dtype=np.float32):
     T = feats.shape[0]
     bufs = {0: feats}
 
+    def grid_dims(tid):
+        g = graph.grid_spec(tid)
+        fr = T
+        for _ in range(g[1]):
+            fr = (fr + 1) // 2
+        return fr, g[2], g[3]                     # frames, width, pitch
+
     def rows(tid):
+        if graph.grid_spec(tid) is not None:
+            fr, _, pitch = grid_dims(tid)
+            return fr * pitch
         return T if graph.domain(tid) == 0 else 1
+
+    def valid_mask(tid):
+        """[rows, 1] 1.0 where the device's row_valid bit is set (grid: first `width` rows of every frame)."""
+        if graph.grid_spec(tid) is None:
+            return 1.0
+        fr, width, pitch = grid_dims(tid)
+        return ((np.arange(fr * pitch) % pitch) < width).astype(dtype)[:, None]
 
     def get(v):
         return bufs[v.tid][:, v.ch_off:v.ch_off + v.channels]
@@ -37,9 +54,7 @@ def run_graph(graph, feats, dtype=np.float32):
             x = get(op.inp)
             if op.inp2 is not None:
                 x = x + get(op.inp2)
-            z = O.tdnn_affine(x, op.weight.astype(dtype), None if op.bias is None else op.bias.astype(dtype), op.taps) \
-                if op.weight.shape[2] == len(range(min(op.taps + [0]), max(op.taps + [0]) + 1)) and op.w_left == min(op.taps + [0]) \
-                else _tdnn_general(x, op, dtype)
+            z = _tdnn_general(x, op, dtype)
             if op.seg_bias is not None:
                 z = z + get(op.seg_bias)
             s = 1 if op.scale is None else op.scale.astype(dtype)
@@ -50,7 +65,36 @@ def run_graph(graph, feats, dtype=np.float32):
                 z = z * get(op.seg_scale)
             if op.res is not None:
                 z = z + get(op.res)
-            put(op.out, z.astype(dtype))
+            put(op.out, (z * valid_mask(op.out.tid)).astype(dtype))
+        elif op.kind == "grid_input":
+            fr, width, pitch = grid_dims(op.out.tid)
+            g = np.zeros((fr * pitch, 1), dtype=dtype)
+            for t in range(fr):
+                g[t * pitch:t * pitch + width, 0] = feats[t, :width]
+            put(op.out, g)
+        elif op.kind == "im2col":
+            x = get(op.inp)
+            fi, wi, pi = grid_dims(op.inp.tid)
+            fo, wo, po = grid_dims(op.out.tid)
+            C = op.inp.channels
+            out = np.zeros((fo * po, C * len(op.taps)), dtype=dtype)
+            for t in range(fo):
+                for f in range(wo):
+                    for k, (dt, df) in enumerate(op.taps):
+                        ti, fi_ = t * op.stride + dt, f * op.stride + df
+                        if 0 <= ti < fi and 0 <= fi_ < wi:
+                            out[t * po + f, k * C:(k + 1) * C] = x[ti * pi + fi_]
+            put(op.out, out)
+        elif op.kind == "pool" and getattr(op, "per_bin", False):
+            x = get(op.inp)
+            fr, width, pitch = grid_dims(op.inp.tid)
+            parts = []
+            for f in range(width):
+                col = x[f::pitch][:fr]
+                mean = col.mean(axis=0, dtype=dtype)
+                var = ((col - mean) ** 2).sum(axis=0, dtype=dtype) / dtype(fr - 1 if (op.unbiased == 1 and fr > 1) else fr)
+                parts += [mean, np.sqrt(np.maximum(var, dtype(op.eps)))] if op.stddev else [mean]
+            put(op.out, np.concatenate(parts)[None, :])
         elif op.kind == "pool":
             x = get(op.inp)
             mean = x.mean(axis=0, dtype=dtype)
@@ -80,7 +124,8 @@ def run_graph(graph, feats, dtype=np.float32):
                 z = z + get(op.b)
             if op.c is not None:
                 z = z + get(op.c)
-            put(op.out, z.astype(dtype))
+            z = _act(z, getattr(op, "act", None))
+            put(op.out, (z * valid_mask(op.out.tid)).astype(dtype))
         else:
             raise AssertionError("unexpected op %s" % op.kind)
     return get(graph.output)[0]

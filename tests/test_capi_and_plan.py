@@ -98,12 +98,28 @@ def test_ecapa_traced_program_reproduces_reference_on_cpu(name, limit):
         assert rel_err(ir_interp.extract(graph, x), ref) < 2e-5
 
 
+@pytest.mark.parametrize("name,idx", [("resnet34se_c5", 2), ("resnet34se_c5", 3), ("resnet34_plain", 1)])
+def test_resnet_traced_program_reproduces_reference_on_cpu(name, idx):
+    """2-D trunk: row-flattened (time, frequency) grids, BN folded into the convolutions, im2col for the
+    stride-2 convolutions, SE with the pitch/width factor folded, per-bin pooling + permuted fc2 columns."""
+    from libs.amd import ir
+    g, sd, model = helpers.golden_model(name)
+    graph = ir.trace(model, type(model).extract_embedding.__wrapped_body__, int(g["dim"]))
+    assert sum(1 for op in graph.ops if op.kind == "im2col") == 6          # 3 strided 3x3 + 3 strided 1x1
+    per_frame, _ = graph.flops_per_frame()
+    if name == "resnet34se_c5":
+        assert abs(per_frame - 45.27e6) < 0.02e6                            # BASELINE.md section 3
+    x = helpers.golden_feats(g)[idx]
+    assert rel_err(ir_interp.extract(graph, x), g["embeddings"][idx]) < 2e-5
+
+
 REF_MODEL_DIR = "/root/reference/pytorch/model"
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_MODEL_DIR), reason="reference tree only exists in the build container")
 @pytest.mark.parametrize("blueprint,creation,golden", [("xvector.py", "Xvector(30,10,training=False)", "xvector_c1"),
-                                                       ("ecapa_tdnn_xvector.py", "ECAPA_TDNN(80,10,training=False)", "ecapa_c3")])
+                                                       ("ecapa_tdnn_xvector.py", "ECAPA_TDNN(80,10,training=False)", "ecapa_c3"),
+                                                       ("resnet_xvector.py", "ResNetXvector(61,10,training=False,resnet_params={'full_pre_activation':False})", "resnet34_plain")])
 def test_unmodified_reference_blueprints_run_on_this_libs_nnet(blueprint, creation, golden):
     """Drop-in check: the reference's OWN blueprint files import this package's `libs.nnet`,
     build, load the checkpoint keys and record to a program that reproduces the reference."""
@@ -121,11 +137,11 @@ import libs.support.utils as utils
 from libs.amd import ir
 g, sd = helpers.golden_state_dict(%(golden)r)
 model = utils.create_model_from_py(%(ref)r + "/" + %(bp)r, %(creation)r)
-assert type(model).__module__ in ("xvector", "ecapa_tdnn_xvector") and %(ref)r in sys.modules[type(model).__module__].__file__
+assert type(model).__module__ in ("xvector", "ecapa_tdnn_xvector", "resnet_xvector") and %(ref)r in sys.modules[type(model).__module__].__file__
 model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
 graph = ir.trace(model, type(model).extract_embedding.__wrapped_body__, int(g["dim"]))
-x = helpers.golden_feats(g)[0]
-err = helpers.rel_err(ir_interp.extract(graph, x), g["embeddings"][0])
+x = helpers.golden_feats(g)[-1]
+err = helpers.rel_err(ir_interp.extract(graph, x), g["embeddings"][-1])
 print("ERR", err)
 assert err < 2e-5
 ''' % dict(repo=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ref=REF_MODEL_DIR, bp=blueprint, creation=creation, golden=golden)

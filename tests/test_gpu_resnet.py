@@ -1,0 +1,40 @@
+"""ResNet34(-SE) 2-D trunk + per-bin statistics pooling on the MI355X (BASELINE config C5
+extractor) against the reference's own outputs (tests/golden/resnet34*.npz)."""
+
+import numpy as np
+import pytest
+
+import helpers
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["resnet34se_c5", "resnet34_plain"])
+def test_resnet_f32_vs_reference_golden(name):
+    g, sd, model = helpers.golden_model(name)
+    model.cuda()
+    model.amd_precision = "f32"
+    got = model.extract_embedding_batch(helpers.golden_feats(g)).numpy()
+    assert got.shape == g["embeddings"].shape
+    for i, (T, _) in enumerate(g["utts"]):
+        assert rel_err(got[i], g["embeddings"][i]) < 1e-4, "%s: utterance of %d frames" % (name, T)
+
+
+def test_resnet_bf16_is_close_and_batch_invariant():
+    from libs.amd import synth
+    g, sd, model = helpers.golden_model("resnet34se_c5")
+    model.cuda()
+    model.amd_precision = "bf16"
+    mats = helpers.golden_feats(g)
+    got = model.extract_embedding_batch(mats).numpy()
+    ref = g["embeddings"]
+    cos = (got * ref).sum(1) / np.linalg.norm(got, axis=1) / np.linalg.norm(ref, axis=1)
+    assert cos.min() > 0.998, cos
+    # variable-length batch (config C5: T in [200, 1000]) - every utterance equals its stand-alone extraction
+    lens = [200, 333, 1000, 201]
+    mats = [synth.synth_feats(T, 80, 9000 + i) for i, T in enumerate(lens)]
+    full = model.extract_embedding_batch(mats).numpy()
+    assert np.isfinite(full).all()
+    for i in (1, 2):
+        assert np.array_equal(model.extract_embedding(mats[i]).numpy(), full[i])
