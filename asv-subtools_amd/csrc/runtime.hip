@@ -751,19 +751,18 @@ int run_ops(RunCtx &c, size_t n_ops) {
         const bool narrow = p.halo <= kHalo;
         const bool big3 = !use_ref && narrow && (net->flags & (ASV_FLAG_SMALL_TILES | ASV_FLAG_BIG_V2)) == 0 && tdnn_big3_supported(p, bf16, !bf16);
         const bool big = !use_ref && narrow && !big3 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && tdnn_big_supported(p, bf16, !bf16);
-        if (!use_ref && !big && !big3) {
-          // few output tiles (pooled-domain layers, short batches): slice K over more workgroups
-          const int tiles = (p.rows / 128) * (round_up(p.cout_store, 128) / 128);
+        if (!use_ref && !big && !big3 && op.utts) {
+          // pooled-domain layers have one row per utterance (M is tiny, K is large): slice K over more
+          // workgroups.  The slice count depends on K only, never on the batch, so an utterance's
+          // embedding is bit-identical whatever batch it is extracted in.
           const int nchunks = (p.cin_pad + (bf16 ? 64 : 32) - 1) / (bf16 ? 64 : 32);
-          if (tiles < 128 && nchunks >= 4) {
-            p.ksplit = std::min(std::min(nchunks / 2, 64), std::max(1, 512 / tiles));
-            if (p.ksplit > 1) {
-              p.ld_partial = round_up(p.cout_store, 64);
-              if ((rc = ensure(net->splitk_dev, (size_t)p.ksplit * p.rows * p.ld_partial * 4, c.s, false))) return rc;
-              p.partial = reinterpret_cast<float *>(net->splitk_dev.ptr);
-            } else {
-              p.ksplit = 0;
-            }
+          p.ksplit = std::min(nchunks / 2, 48);
+          if (p.ksplit > 1) {
+            p.ld_partial = round_up(p.cout_store, 64);
+            if ((rc = ensure(net->splitk_dev, (size_t)p.ksplit * p.rows * p.ld_partial * 4, c.s, false))) return rc;
+            p.partial = reinterpret_cast<float *>(net->splitk_dev.ptr);
+          } else {
+            p.ksplit = 0;
           }
         }
         double valid_rows = op.utts ? (double)bp.segments : (double)bp.frames;
