@@ -64,7 +64,8 @@ struct TdnnKernelParams {
   const uint32_t *row_valid;  // [rows/32] bit r%32 set <=> row r holds a real frame
   // fused statistics pooling (optional): per (row tile, channel) partial sums of the valid rows,
   // segmented by utterance; see kernels_tdnn.hip
-  float *pool_partial;
+  float *pool_partial;  // [rows/128 half-tiles][pool_slots][2 (sum u, sum u^2)][ld_partial]
+  int pool_slots;
   const void *zero16;   // >= 16 bytes of device zeros: source of masked direct-to-LDS loads
   const void *wfrag;    // bf16 weights in MFMA-fragment order [n_frag32][tap][chunk64][k_group][lane][8] or nullptr
   // split-K (small-M layers: the pooled domain): blockIdx.y walks `ksplit` slices of the channel
@@ -111,6 +112,17 @@ void pack_tdnn_weight_frags(const float *w, int out_ch, int in_ch, int tot_ctx, 
                             int cout_pad, int cin_pad, uint16_t *dst);
 size_t tdnn_weight_frag_elems(int cout_pad, int cin_pad, int n_taps);
 int launch_stats_pool(const PoolKernelParams &p, int segments, bool bf16, hipStream_t s);
+// second half of the fused pooling: adds each segment's half-tile partials in row order, adds the BN shift
+// back to the mean and writes mean || std like stats_pool_kernel
+struct PoolFinishParams {
+  const float *partial; int ld_partial, pool_slots;
+  const int32_t *row_seg; int rows;
+  const int32_t *seg_row0, *seg_len;
+  const float *shift;            // per-channel BN shift that the producer left out (or nullptr)
+  float *out; int ld_out, channels;
+  int stddev, unbiased, var_mode; float eps;
+};
+int launch_pool_finish(const PoolFinishParams &p, int segments, hipStream_t s);
 int launch_attentive_pool(const void *x, int ldx, const void *logits, int ldl, int channels,
                           const int32_t *seg_row0, const int32_t *seg_len, int segments, float eps,
                           float *out, int ld_out, bool bf16, hipStream_t s);

@@ -194,6 +194,33 @@ __global__ __launch_bounds__(256) void stats_pool_kernel(const PoolKernelParams 
   }
 }
 
+// Fused-pooling finish (see the POOL epilogue of kernels_tdnn_v3.hip): one wave per (segment, 64 channels).
+__global__ __launch_bounds__(64) void pool_finish_kernel(const PoolFinishParams p) {
+  const int seg = blockIdx.y, ch = blockIdx.x * 64 + threadIdx.x;
+  if (ch >= p.channels) return;
+  const int row0 = p.seg_row0[seg], len = p.seg_len[seg];
+  float s = 0.0f, q = 0.0f;
+  for (int h = row0 >> 7; h <= (row0 + len - 1) >> 7; ++h) {
+    int first = -1;
+    for (int k = 0; k < kHalo + 1 && first < 0; ++k)
+      if (h * 128 + k < p.rows) first = p.row_seg[h * 128 + k];
+    const int slot = seg - first;                       // segments are consecutive in row order
+    const float *src = p.partial + ((size_t)(h * p.pool_slots + slot) * 2) * p.ld_partial + ch;
+    s += src[0];
+    q += src[p.ld_partial];
+  }
+  const float n = (float)len;
+  float counts = n;
+  if (p.unbiased == 1 && len > 1) counts = (float)(len - 1);
+  if (p.unbiased == 2) counts = (float)(len - 1);
+  const float mean_u = s / n;
+  p.out[(size_t)seg * p.ld_out + ch] = mean_u + (p.shift ? p.shift[ch] : 0.0f);
+  if (p.stddev) {
+    const float var = fmaxf(q - n * mean_u * mean_u, 0.0f) / counts;
+    p.out[(size_t)seg * p.ld_out + p.channels + ch] = (p.var_mode == ASV_POOL_VAR_ADD) ? sqrtf(var + p.eps) : sqrtf(fmaxf(var, p.eps));
+  }
+}
+
 // ECAPA attentive statistics (ecapa_tdnn_xvector.py:182-188).
 template <bool BF16>
 __global__ __launch_bounds__(256) void attentive_pool_kernel(const void *x, int ldx, const void *logits, int ldl,
@@ -429,6 +456,13 @@ int launch_stats_pool(const PoolKernelParams &p, int segments, bool bf16, hipStr
   const dim3 grid((p.channels + 63) / 64, segments * p.groups), block(256);
   if (bf16) hipLaunchKernelGGL(stats_pool_kernel<true>, grid, block, 0, s, p);
   else hipLaunchKernelGGL(stats_pool_kernel<false>, grid, block, 0, s, p);
+  ASV_HIP_CHECK(hipGetLastError());
+  return ASV_OK;
+}
+
+int launch_pool_finish(const PoolFinishParams &p, int segments, hipStream_t s) {
+  if (segments <= 0) return ASV_OK;
+  hipLaunchKernelGGL(pool_finish_kernel, dim3((p.channels + 63) / 64, segments), dim3(64), 0, s, p);
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }

@@ -54,7 +54,7 @@ __device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst) {
 }
 
 // ABL: 0 full, 2 MFMA only (no loads of any kind in the loop), 4 no epilogue stores
-template <int ABL, bool GENERIC>
+template <int ABL, bool GENERIC, bool POOL>
 __global__ __launch_bounds__(512, 2) void tdnn_gemm_big3_kernel(const TdnnKernelParams p, int m_tiles, int n_tiles) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -180,6 +180,72 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_big3_kernel(const TdnnKernel
   __builtin_amdgcn_s_barrier();            // every wave is done reading the ring: the epilogue reuses the LDS
   asm volatile("" ::: "memory");
 
+  if constexpr (POOL) {
+    // ---- epilogue with fused statistics pooling (pooling.py:58-67 folded into the producing layer):
+    // the layer's output never reaches HBM.  Each wave owns 128 frames x 64 channels.  Per 32-frame
+    // fragment it writes u = max(acc + b, lo) * scale (the output minus the BN shift: >= 0, well
+    // conditioned for one-pass moments) as f32 to an LDS scratch [32 frames][64 ch], then lane = channel
+    // sums the 32 rows.  The row -> segment lookup is wave-uniform, so a segment boundary is a scalar
+    // branch: flush (sum u, sum u^2) of the finished segment to the partial buffer
+    //   P[half-tile of 128 rows][segment slot][stat][channel]
+    // and continue.  pool_finish_kernel adds the half-tiles of each segment in row order.
+    constexpr int SPITCH = 68;                       // floats per scratch row: 64 + 4 keeps ds_write_b128 conflict-free
+    float *scrf = reinterpret_cast<float *>(lds + wave * (32 * SPITCH * 4));
+    const float act_lo = (p.act1 == ASV_ACT_RELU) ? 0.0f : -INFINITY;
+    const int rbase_w = m0 + wm * 128;
+    const int half = rbase_w >> 7;
+    int first_seg = -1;
+#pragma unroll
+    for (int k = 0; k < kHalo + 1; ++k)
+      if (first_seg < 0 && rbase_w + k < p.rows) first_seg = p.row_seg[rbase_w + k];
+    const int ch_l = n0 + wn * 64 + lane;
+    const int rowseg_lo = p.row_seg[rbase_w + lane], rowseg_hi = p.row_seg[rbase_w + 64 + lane];
+    float ps = 0.0f, pq = 0.0f;
+    int cur_seg = -1;
+    auto flush = [&]() {
+      const int slot = cur_seg - first_seg;
+      if (slot >= 0 && slot < p.pool_slots && ch_l < p.ld_partial) {
+        float *dst = p.pool_partial + ((size_t)(half * p.pool_slots + slot) * 2) * p.ld_partial + ch_l;
+        dst[0] = ps;
+        dst[p.ld_partial] = pq;
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool valid = (p.row_valid[(rbase_w + i * 32) >> 5] >> lr) & 1u;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int ch = n0 + wn * 64 + j * 32 + 8 * q + 4 * lh;
+          const float4 b4 = *reinterpret_cast<const float4 *>(p.bias + ch);
+          const float4 sc4 = p.scale ? *reinterpret_cast<const float4 *>(p.scale + ch) : make_float4(1.f, 1.f, 1.f, 1.f);
+          float4 u;
+          u.x = valid ? fmaxf(acc[i][j][q * 4 + 0] + b4.x, act_lo) * sc4.x : 0.0f;
+          u.y = valid ? fmaxf(acc[i][j][q * 4 + 1] + b4.y, act_lo) * sc4.y : 0.0f;
+          u.z = valid ? fmaxf(acc[i][j][q * 4 + 2] + b4.z, act_lo) * sc4.z : 0.0f;
+          u.w = valid ? fmaxf(acc[i][j][q * 4 + 3] + b4.w, act_lo) * sc4.w : 0.0f;
+          *reinterpret_cast<float4 *>(scrf + lr * SPITCH + j * 32 + 8 * q + 4 * lh) = u;
+        }
+      // column sums of this fragment; rows are consumed in order, segments are contiguous in rows.
+      // rowseg_lo/hi hold row_seg of the wave's 128 rows (lane l: rows l and 64 + l), so the per-row
+      // segment id is a v_readlane with a constant lane: no memory access in the loop.
+      const int rs_vec = (i < 2) ? rowseg_lo : rowseg_hi;
+#pragma unroll
+      for (int r = 0; r < 32; ++r) {
+        const int sg = __builtin_amdgcn_readlane(rs_vec, (i & 1) * 32 + r);          // wave-uniform
+        if (sg >= 0 && sg != cur_seg) {
+          if (cur_seg >= 0) flush();
+          cur_seg = sg; ps = 0.0f; pq = 0.0f;
+        }
+        const float v = scrf[r * SPITCH + lane];
+        ps += v;
+        pq = fmaf(v, v, pq);
+      }
+    }
+    if (cur_seg >= 0) flush();
+    return;
+  }
   // ---- epilogue --------------------------------------------------------------------------
   // acc[i][j][r]: frame = m0 + wm*128 + i*32 + lr, channel = n0 + wn*64 + j*32 + 8*(r>>2) + 4*lh + (r&3)
   unsigned char *scr = lds + wave * 16384;       // [128 frames][64 channels] bf16, 128-B rows, swizzled slots
@@ -241,7 +307,9 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_big3_kernel(const TdnnKernel
 }  // namespace
 
 bool tdnn_big3_supported(const TdnnKernelParams &p, bool bf16, bool out_f32) {
-  return p.wfrag != nullptr && tdnn_big_supported(p, bf16, out_f32);
+  TdnnKernelParams q = p;
+  q.pool_partial = nullptr;                       // the fused-pooling form has the same requirements otherwise
+  return p.wfrag != nullptr && tdnn_big_supported(q, bf16, out_f32);
 }
 
 int launch_tdnn_big3_variant(const TdnnKernelParams &p, int variant, hipStream_t s) {
@@ -250,12 +318,18 @@ int launch_tdnn_big3_variant(const TdnnKernelParams &p, int variant, hipStream_t
   const int m_tiles = p.rows / BM, n_tiles = round_up(p.cout_store, BN) / BN;
   const dim3 grid(m_tiles * n_tiles), block(512);
   const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first;
+  if (p.pool_partial != nullptr) {
+    ASV_REQUIRE(fast && p.row_seg != nullptr && p.pool_slots >= 1, "tdnn(big3): fused pooling needs the plain epilogue and a row map");
+    hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, false, true>), grid, block, 0, s, p, m_tiles, n_tiles);
+    ASV_HIP_CHECK(hipGetLastError());
+    return ASV_OK;
+  }
   switch (variant) {
-    case 2: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<2, false>), grid, block, 0, s, p, m_tiles, n_tiles); break;
-    case 4: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<4, false>), grid, block, 0, s, p, m_tiles, n_tiles); break;
+    case 2: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<2, false, false>), grid, block, 0, s, p, m_tiles, n_tiles); break;
+    case 4: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<4, false, false>), grid, block, 0, s, p, m_tiles, n_tiles); break;
     default:
-      if (fast) hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, false>), grid, block, 0, s, p, m_tiles, n_tiles);
-      else hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, true>), grid, block, 0, s, p, m_tiles, n_tiles);
+      if (fast) hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, false, false>), grid, block, 0, s, p, m_tiles, n_tiles);
+      else hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, true, false>), grid, block, 0, s, p, m_tiles, n_tiles);
   }
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;

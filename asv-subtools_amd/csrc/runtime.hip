@@ -108,6 +108,8 @@ struct Op {
   int cin_pad = 0, cout_pad = 0, cout_store = 0;
   bool utts = false;             // op runs in the utts domain (always f32)
   bool has_affine = false;
+  int fused_pool = -1;           // TDNN op: index of the statistics-pooling op folded into its epilogue
+  bool skipped = false;          // pool op executed by its producer
 };
 
 struct DevMem {
@@ -138,6 +140,7 @@ struct asv_net {
   DevMem meta_dev;                       // int32 metadata (segments etc.)
   DevMem rowmeta_dev;                    // row_seg / row_valid for both domains
   DevMem splitk_dev;                     // split-K partial accumulators
+  DevMem poolpart_dev;                   // fused-pooling partial moments
   void *zero_page = nullptr;             // 256 zero bytes (masked direct-to-LDS loads)
   void *meta_host = nullptr;             // pinned staging
   size_t meta_host_cap = 0;
@@ -331,6 +334,7 @@ void asv_net_destroy(asv_net_t *net) {
   if (net->meta_dev.ptr) (void)hipFree(net->meta_dev.ptr);
   if (net->rowmeta_dev.ptr) (void)hipFree(net->rowmeta_dev.ptr);
   if (net->splitk_dev.ptr) (void)hipFree(net->splitk_dev.ptr);
+  if (net->poolpart_dev.ptr) (void)hipFree(net->poolpart_dev.ptr);
   if (net->zero_page) (void)hipFree(net->zero_page);
   if (net->meta_host) (void)hipHostFree(net->meta_host);
   if (net->meta_copied) (void)hipEventDestroy(net->meta_copied);
@@ -531,6 +535,31 @@ int asv_net_finalize(asv_net_t *net, int out_buf, int embed_dim) {
               "asv_net_finalize: output must be an utts-domain buffer");
   ASV_REQUIRE(embed_dim >= 1 && embed_dim <= net->bufs[out_buf].channels, "asv_net_finalize: embed_dim %d", embed_dim);
   ASV_REQUIRE(!net->ops.empty(), "asv_net_finalize: empty program");
+  // fuse "layer -> StatisticsPooling" when the layer's output has no other reader: the 157 MB tensor
+  // (C2: 52k frames x 1500 channels) is then never written to or re-read from HBM
+  if ((net->flags & ASV_FLAG_NO_FUSE) == 0 && net->frames_bf16()) {
+    for (size_t i = 0; i + 1 < net->ops.size(); ++i) {
+      Op &a = net->ops[i], &b = net->ops[i + 1];
+      if (a.kind != OP_TDNN || b.kind != OP_POOL || a.utts || a.wfrag == nullptr) continue;
+      const auto &d = a.tdnn; const auto &q = b.pool;
+      if (net->bufs[d.in_buf].domain != ASV_DOMAIN_FRAMES || q.in_buf != d.out_buf || q.in_ch_off != d.out_ch_off || q.channels != d.out_ch || q.per_bin) continue;
+      if (d.in2_buf >= 0 || d.seg_bias_buf >= 0 || d.seg_scale_buf >= 0 || d.res_buf >= 0 || d.affine_first || d.act2 != ASV_ACT_NONE ||
+          (d.act1 != ASV_ACT_NONE && d.act1 != ASV_ACT_RELU)) continue;
+      bool other_reader = false;
+      for (size_t k = 0; k < net->ops.size(); ++k) {
+        if (k == i || k == i + 1) continue;
+        const Op &o = net->ops[k];
+        const int reads[] = {o.kind == OP_TDNN ? o.tdnn.in_buf : -1, o.kind == OP_TDNN ? o.tdnn.in2_buf : -1, o.kind == OP_TDNN ? o.tdnn.res_buf : -1,
+                             o.kind == OP_POOL ? o.pool.in_buf : -1, o.kind == OP_ATTPOOL ? o.att.x_buf : -1, o.kind == OP_ATTPOOL ? o.att.logit_buf : -1,
+                             o.kind == OP_ELTWISE ? o.elt.a_buf : -1, o.kind == OP_ELTWISE ? o.elt.b_buf : -1, o.kind == OP_ELTWISE ? o.elt.c_buf : -1,
+                             o.kind == OP_IM2COL ? o.i2c.in_buf : -1};
+        for (int rbuf : reads) other_reader |= (rbuf == d.out_buf);
+      }
+      if (other_reader || d.out_buf == out_buf) continue;
+      a.fused_pool = (int)(i + 1);
+      b.skipped = true;
+    }
+  }
   net->out_buf = out_buf; net->embed_dim = embed_dim; net->finalized = true;
   net->arena.resize(net->bufs.size());
   return ASV_OK;
@@ -749,6 +778,17 @@ int run_ops(RunCtx &c, size_t n_ops) {
         p.zero16 = net->zero_page;
         p.wfrag = op.wfrag;
         const bool narrow = p.halo <= kHalo;
+        // fused statistics pooling: needs few enough segments per 128-row half-tile (i.e. no tiny utterances)
+        int pool_slots = 0;
+        if (op.fused_pool >= 0 && !use_ref && (net->flags & (ASV_FLAG_SMALL_TILES | ASV_FLAG_BIG_V2)) == 0) {
+          const DomainPlan &fp = bp.dom[ASV_DOMAIN_FRAMES];
+          std::vector<int> per_half((size_t)fp.rows_pad / 128 + 1, 0);
+          int worst = 1;
+          for (size_t sidx = 0; sidx < fp.seg_row0.size(); ++sidx)
+            for (int h = fp.seg_row0[sidx] >> 7; h <= (fp.seg_row0[sidx] + fp.seg_len[sidx] - 1) >> 7; ++h) worst = std::max(worst, ++per_half[h]);
+          pool_slots = worst;
+          if (pool_slots > 16) pool_slots = 0;               // many tiny utterances: use the separate pooling kernel
+        }
         const bool big3 = !use_ref && narrow && (net->flags & (ASV_FLAG_SMALL_TILES | ASV_FLAG_BIG_V2)) == 0 && tdnn_big3_supported(p, bf16, !bf16);
         const bool big = !use_ref && narrow && !big3 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && tdnn_big_supported(p, bf16, !bf16);
         if (!use_ref && !big && !big3 && op.utts) {
@@ -771,6 +811,13 @@ int run_ops(RunCtx &c, size_t n_ops) {
           for (int32_t len : bp.dom[domid].seg_len) valid_rows += (double)(len / net->domains[domid].pitch) * net->domains[domid].width;
         }
         if ((rc = prof.begin(K_TDNN, 2.0 * valid_rows * d.in_ch * d.out_ch * d.n_taps, (int)i))) return rc;
+        const bool fuse = big3 && pool_slots > 0;
+        if (fuse) {
+          p.pool_slots = pool_slots;
+          p.ld_partial = op.cout_pad;
+          if ((rc = ensure(net->poolpart_dev, (size_t)(p.rows / 128) * pool_slots * 2 * p.ld_partial * 4, c.s, false))) return rc;
+          p.pool_partial = reinterpret_cast<float *>(net->poolpart_dev.ptr);
+        }
         if (use_ref) rc = launch_tdnn_ref(p, bf16, !bf16, c.s);
         else if (big3) rc = launch_tdnn_big3(p, c.s);
         else if (big) rc = launch_tdnn_big(p, c.s);
@@ -780,9 +827,26 @@ int run_ops(RunCtx &c, size_t n_ops) {
         }
         if (rc) return rc;
         if ((rc = prof.end())) return rc;
+        if (op.fused_pool >= 0) {
+          Op &po = net->ops[op.fused_pool];
+          po.skipped = fuse;
+          if (fuse) {
+            const auto &q = po.pool;
+            PoolFinishParams f;
+            f.partial = p.pool_partial; f.ld_partial = p.ld_partial; f.pool_slots = pool_slots;
+            f.row_seg = dr.row_seg; f.rows = dr.rows_pad; f.seg_row0 = dr.seg_row0; f.seg_len = dr.seg_len;
+            f.shift = op.shift;
+            f.out = reinterpret_cast<float *>(net->arena[q.out_buf].ptr) + q.out_ch_off; f.ld_out = net->bufs[q.out_buf].ld; f.channels = q.channels;
+            f.stddev = q.stddev; f.unbiased = q.unbiased; f.var_mode = q.var_mode; f.eps = q.eps;
+            if ((rc = prof.begin(K_POOL, 0, op.fused_pool))) return rc;
+            if ((rc = launch_pool_finish(f, bp.segments, c.s))) return rc;
+            if ((rc = prof.end())) return rc;
+          }
+        }
         break;
       }
       case OP_POOL: {
+        if (op.skipped) break;                       // folded into the producing layer's epilogue
         const auto &d = op.pool;
         const int domid = net->bufs[d.in_buf].domain;
         const Domain &dm = net->domains[domid];

@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel hipEvents in the timed region")
     ap.add_argument("--per-op", action="store_true", help="also print a per-op timing table to stderr")
+    ap.add_argument("--model", default="xvector", choices=["xvector", "ecapa", "resnet"],
+                    help="xvector = BASELINE configs[1] (the default, the contract's workload); ecapa = configs[2] (C=1024, 300 frames); "
+                         "resnet = the configs[4] extractor (ResNet34-SE)")
     return ap.parse_args()
 
 
@@ -62,8 +65,15 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)      # "nccl" is RCCL on ROCm
 
     # ---- model: the reference's standard x-vector blueprint, synthetic weights ---------------
-    creation = "Xvector(%d,10,training=False)" % args.feat_dim
-    model = utils.create_model_from_py(os.path.join(REPO, "asv-subtools_amd", "pytorch", "model", "xvector.py"), creation)
+    if args.model == "xvector":
+        blueprint, creation = "xvector.py", "Xvector(%d,10,training=False)" % args.feat_dim
+    elif args.model == "ecapa":
+        blueprint, creation = "ecapa_tdnn_xvector.py", "ECAPA_TDNN(%d,10,training=False)" % args.feat_dim
+    else:
+        blueprint = "resnet_xvector.py"
+        creation = ("ResNetXvector(%d,10,training=False,resnet_params={'use_se':True,'se_ratio':4,'full_pre_activation':False},"
+                    "fc2_params={'nonlinearity':'','bn_params':{'momentum':0.5,'affine':False,'track_running_stats':True}})" % args.feat_dim)
+    model = utils.create_model_from_py(os.path.join(REPO, "asv-subtools_amd", "pytorch", "model", blueprint), creation)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     sd = synth.synth_state_dict(shapes, 0)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
@@ -141,8 +151,10 @@ def main():
         "ms_per_step": round(1e3 * dt / args.steps, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.precision, "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: standard TDNN x-vector %s, %d-dim fbank, %d utterances x %d frames per GPU per step, "
-                               "features resident in HBM, f32 embeddings out%s" % (creation, D, B, T, ", + RCCL all-gather of embeddings" if world > 1 else ""),
+        "config": {"workload": "%s: %s, %d-dim fbank, %d utterances x %d frames per GPU per step, "
+                               "features resident in HBM, f32 embeddings out%s" % ({"xvector": "BASELINE configs[1]: standard TDNN x-vector", "ecapa": "BASELINE configs[2]: ECAPA-TDNN C=1024",
+                                                                                   "resnet": "BASELINE configs[4] extractor: ResNet34-SE"}[args.model],
+                                                                                  creation, D, B, T, ", + RCCL all-gather of embeddings" if world > 1 else ""),
                    "global_batch_utts": world * B, "frames_per_utt": T, "parallelism": "utterance shards x%d" % world},
         "value_without_event_recording": round(utts / dt_plain, 1),
     }
@@ -161,6 +173,8 @@ def main():
         from oracle import torch_cpu_port as P                        # cpu_baseline leg only
         # torch's default (one thread per core) collapses on many-core hosts for these small
         # convolutions: probe a few thread counts briefly and time the sample with the best one
+        if args.model != "xvector":
+            raise SystemExit("cpu_baseline is implemented for the default workload only; pass --cpu-seconds 0 with --model %s" % args.model)
         ex = P.XvectorCpu(sd, "far")
         host = os.cpu_count() or 1
         best, cores = 0.0, 1

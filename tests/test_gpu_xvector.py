@@ -81,12 +81,35 @@ def test_bf16_mode_is_close_and_eer_equivalent_inputs():
     assert rel_err(got, ref) < 3e-2
 
 
-def test_batch_composition_does_not_change_results():
+def test_fused_pooling_matches_separate_pooling(monkeypatch):
+    """bf16 mode folds StatisticsPooling into tdnn5's epilogue (the 1500-channel tensor never reaches HBM).
+    The fused path pools the f32 values, the separate kernel the bf16-rounded ones: they agree to bf16
+    rounding of the pooled inputs, and both agree with the reference."""
+    g, sd, model = _gpu_model("xvector_c1", "bf16")
+    mats = helpers.golden_feats(g)[:40] + [helpers.golden_feats(g)[0][:7], helpers.golden_feats(g)[1][:1]]   # incl. tiny utterances
+    fused = model.extract_embedding_batch(mats).numpy()
+    monkeypatch.setenv("ASV_AMD_NO_FUSE", "1")
+    plain = model.extract_embedding_batch(mats).numpy()
+    assert np.isfinite(fused).all()
+    assert rel_err(fused, plain) < 5e-3
+    assert rel_err(fused[:40], g["embeddings"][:40]) < 3e-2
+    assert not np.array_equal(fused, plain)          # the two code paths really are different
+
+
+def test_batch_composition_does_not_change_results(monkeypatch):
     """Size-independent property at BASELINE config C2 size (256 x 200 x 80): every utterance's
     embedding is bit-identical whether it is extracted alone, in a shuffled batch or in the
-    full batch (rows are independent fma chains; pooling is per segment)."""
+    full batch (rows are independent fma chains; pooling is per segment).  With the pooling fused
+    into the producing GEMM the partial sums are grouped by 128-row tile, i.e. by position in the
+    batch, so there the property holds to f32 rounding of the pooled moments instead of bitwise."""
     from libs.amd import synth
     g, sd, model = _gpu_model("xvector_near_ragged", "bf16")
+    mats = [synth.synth_feats(200, 80, 5000 + i) for i in range(256)]
+    fused_full = model.extract_embedding_batch(mats).numpy()
+    perm0 = np.random.RandomState(1).permutation(256)
+    fused_shuf = model.extract_embedding_batch([mats[i] for i in perm0]).numpy()
+    assert rel_err(fused_shuf, fused_full[perm0]) < 1e-5
+    monkeypatch.setenv("ASV_AMD_NO_FUSE", "1")
     mats = [synth.synth_feats(200, 80, 5000 + i) for i in range(256)]
     full = model.extract_embedding_batch(mats).numpy()
     assert np.isfinite(full).all()
