@@ -146,6 +146,13 @@ struct asv_net {
   size_t meta_host_cap = 0;
   hipEvent_t meta_copied = nullptr;      // H2D of meta_host finished
   bool meta_inflight = false;
+  // plan cache: a batch with the same utterance lengths as the previous one reuses the uploaded segment
+  // tables and row maps (steady-state extraction loops over equally shaped batches)
+  std::vector<int32_t> cached_offsets;
+  int cached_max_chunk = -1;
+  bool cache_valid = false;
+  void *plan_cache = nullptr;                 // PlanCache (defined with the launch sequence)
+  void (*plan_cache_free)(void *) = nullptr;
   // profiling
   int profiling = 0;               // 0 off, 1 per kernel class, 2 per op
   struct Stamp { int kclass; int op; double flops; hipEvent_t a, b; };
@@ -336,6 +343,7 @@ void asv_net_destroy(asv_net_t *net) {
   if (net->splitk_dev.ptr) (void)hipFree(net->splitk_dev.ptr);
   if (net->poolpart_dev.ptr) (void)hipFree(net->poolpart_dev.ptr);
   if (net->zero_page) (void)hipFree(net->zero_page);
+  if (net->plan_cache && net->plan_cache_free) net->plan_cache_free(net->plan_cache);
   if (net->meta_host) (void)hipHostFree(net->meta_host);
   if (net->meta_copied) (void)hipEventDestroy(net->meta_copied);
   for (auto &st : net->stamps) { (void)hipEventDestroy(st.a); (void)hipEventDestroy(st.b); }
@@ -683,9 +691,31 @@ struct RunCtx {
   std::vector<DomainRun> dom;
 };
 
+// what prepare() leaves behind for the next call with identical offsets
+struct PlanCache {
+  BatchPlan bp;
+  int32_t *seg_src0, *seg_frames, *utt_seg0, *utt_nseg;
+  std::vector<DomainRun> dom;
+};
+PlanCache &plan_cache_of(asv_net *net) {
+  if (!net->plan_cache) {
+    net->plan_cache = new PlanCache();
+    net->plan_cache_free = [](void *p) { delete reinterpret_cast<PlanCache *>(p); };
+  }
+  return *reinterpret_cast<PlanCache *>(net->plan_cache);
+}
+
 int prepare(RunCtx &c, const int32_t *offsets, int n_utts, int max_chunk) {
   asv_net *net = c.net;
   int rc;
+  ASV_REQUIRE(offsets != nullptr && n_utts >= 1, "extract: need at least one utterance");
+  if (net->cache_valid && net->cached_max_chunk == max_chunk && (int)net->cached_offsets.size() == n_utts + 1 &&
+      memcmp(net->cached_offsets.data(), offsets, (size_t)(n_utts + 1) * 4) == 0) {
+    const PlanCache &pc = plan_cache_of(net);
+    c.bp = pc.bp; c.seg_src0 = pc.seg_src0; c.seg_frames = pc.seg_frames; c.utt_seg0 = pc.utt_seg0; c.utt_nseg = pc.utt_nseg; c.dom = pc.dom;
+    return ASV_OK;                                   // device tables, row maps and arena are still valid
+  }
+  net->cache_valid = false;
   if ((rc = make_plan(net, offsets, n_utts, max_chunk, c.bp))) return rc;
   const BatchPlan &bp = c.bp;
   const int S = bp.segments, B = bp.n_utts;
@@ -739,6 +769,11 @@ int prepare(RunCtx &c, const int32_t *offsets, int n_utts, int max_chunk) {
     const Buffer &b = net->bufs[i];
     if ((rc = ensure(net->arena[i], (size_t)c.dom[b.domain].rows_pad * b.ld * net->elem_size(b.domain), c.s, true))) return rc;
   }
+  PlanCache &pc = plan_cache_of(net);
+  pc.bp = c.bp; pc.seg_src0 = c.seg_src0; pc.seg_frames = c.seg_frames; pc.utt_seg0 = c.utt_seg0; pc.utt_nseg = c.utt_nseg; pc.dom = c.dom;
+  net->cached_offsets.assign(offsets, offsets + n_utts + 1);
+  net->cached_max_chunk = max_chunk;
+  net->cache_valid = true;
   return ASV_OK;
 }
 
@@ -796,7 +831,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
           // workgroups.  The slice count depends on K only, never on the batch, so an utterance's
           // embedding is bit-identical whatever batch it is extracted in.
           const int nchunks = (p.cin_pad + (bf16 ? 64 : 32) - 1) / (bf16 ? 64 : 32);
-          p.ksplit = std::min(nchunks / 2, 48);
+          p.ksplit = std::min(nchunks / 4, 24);
           if (p.ksplit > 1) {
             p.ld_partial = round_up(p.cout_store, 64);
             if ((rc = ensure(net->splitk_dev, (size_t)p.ksplit * p.rows * p.ld_partial * 4, c.s, false))) return rc;

@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--feat-dim", type=int, default=80)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel hipEvents in the timed region")
+    ap.add_argument("--event-stride", type=int, default=4, help="record the per-GEMM hipEvents on every k-th timed step")
     ap.add_argument("--per-op", action="store_true", help="also print a per-op timing table to stderr")
     ap.add_argument("--model", default="xvector", choices=["xvector", "ecapa", "resnet"],
                     help="xvector = BASELINE configs[1] (the default, the contract's workload); ecapa = configs[2] (C=1024, 300 frames); "
@@ -101,10 +102,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    def timed(n):
+    def timed(n, sample_events=0):
+        """sample_events = k > 0: per-GEMM hipEvents are recorded on every k-th step of the timed region
+        (each recorded event is a barrier packet between kernels; sampling keeps that perturbation small)."""
         barrier()
         t0 = time.perf_counter()
-        for _ in range(n):
+        for i in range(n):
+            if sample_events:
+                eng.set_profiling(3 if i % sample_events == 0 else 0)
             step()
         barrier()
         dt = time.perf_counter() - t0
@@ -122,7 +127,7 @@ def main():
     if profile:
         eng.set_profiling(3)                                        # hipEvents around the GEMM launches only
         step(); torch.cuda.synchronize(dev); eng.get_profile()       # create the event pool outside the timed region
-    dt = timed(args.steps)
+    dt = timed(args.steps, sample_events=args.event_stride if profile else 0)
     rows = eng.get_profile() if profile else []
     eng.set_profiling(False)
     if args.per_op and rank == 0:
@@ -167,7 +172,17 @@ def main():
                            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
                            "launches": gemm["launches"], "avg_launch_us": round(1e3 * gemm["total_ms"] / gemm["launches"], 2),
                            "algorithmic_gflop_per_utt": round((per_frame * T + per_utt) / 1e9, 4)}
-        res["gemm_ms_per_step"] = round(gemm["total_ms"] / args.steps, 4)
+        sampled_steps = (args.steps + args.event_stride - 1) // args.event_stride
+        res["roofline"]["sampled_steps"] = sampled_steps
+        res["gemm_ms_per_step"] = round(gemm["total_ms"] / sampled_steps, 4)
+        pmc = os.path.join(REPO, "profiles", "pmc_summary.json")
+        if os.path.exists(pmc) and args.model == "xvector":
+            # HBM traffic of the dominant kernel from a separate rocprofv3 --pmc pass of this same command
+            # (tools/pmc_summary.py; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
+            with open(pmc) as f:
+                info = json.load(f)
+            res["roofline"]["traffic"] = info.get("traffic_bytes_per_launch")
+            res["roofline"]["traffic_source"] = info.get("source")
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         from oracle import torch_cpu_port as P                        # cpu_baseline leg only
