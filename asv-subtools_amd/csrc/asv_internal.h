@@ -153,6 +153,7 @@ struct EltwiseKernelParams {
   const float *seg_scale; int ld_segscale;
   const int32_t *row_seg; const uint32_t *row_valid;   // nullptr in the utts domain
   int act;                             // activation applied to the final sum
+  const float *seg_norm; int ld_segnorm, seg_norm_mode;   // [segments][mean(C) | std(C)]: a <- (a - mean) / std first
 };
 int launch_eltwise(const EltwiseKernelParams &p, bool bf16, hipStream_t s);
 

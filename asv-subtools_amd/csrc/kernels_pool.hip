@@ -300,6 +300,15 @@ __global__ __launch_bounds__(256) void eltwise_kernel(const EltwiseKernelParams 
       for (int i = 0; i < VEC; ++i)
         if (ch + i < p.channels) o[i] = o[i] * p.scale[ch + i] + p.shift[ch + i];
     }
+    if (p.seg_norm != nullptr) {
+      const float *st = p.seg_norm + (size_t)seg * p.ld_segnorm;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i)
+        if (ch + i < p.channels) {
+          if (p.seg_norm_mode & 1) o[i] -= st[ch + i];
+          if (p.seg_norm_mode & 2) o[i] /= st[p.channels + ch + i];
+        }
+    }
     if (p.seg_scale != nullptr) {
 #pragma unroll
       for (int i = 0; i < VEC; ++i)

@@ -494,6 +494,10 @@ int asv_net_add_eltwise(asv_net_t *net, const asv_eltwise_desc_t *d) {
     ASV_REQUIRE(!net->is_utts(dom) && d->seg_scale_buf < (int)net->bufs.size() && net->is_utts(net->bufs[d->seg_scale_buf].domain) &&
                 net->bufs[d->seg_scale_buf].channels >= d->channels, "eltwise: bad per-segment scale buffer");
   ASV_REQUIRE((d->scale == nullptr) == (d->shift == nullptr), "eltwise: scale and shift come together");
+  if (d->seg_norm_buf >= 0)
+    ASV_REQUIRE(!net->is_utts(dom) && d->seg_norm_buf < (int)net->bufs.size() && net->is_utts(net->bufs[d->seg_norm_buf].domain) &&
+                net->bufs[d->seg_norm_buf].channels >= 2 * d->channels && d->seg_norm_mode >= 1 && d->seg_norm_mode <= 3,
+                "eltwise: bad per-segment normalisation buffer / mode");
   ASV_REQUIRE(d->act >= ASV_ACT_NONE && d->act <= ASV_ACT_SIGMOID, "eltwise: unknown activation %d", d->act);
   const int vec = net->dom_bf16(dom) ? 8 : 4;
   ASV_REQUIRE(d->out_ch_off + round_up(d->channels, vec) <= net->bufs[d->out_buf].ld, "eltwise: padded view exceeds pitch");
@@ -513,6 +517,8 @@ int asv_net_add_grid_input(asv_net_t *net, const asv_grid_input_desc_t *d) {
   ASV_REQUIRE(net && d && !net->finalized, "asv_net_add_grid_input: net is null or finalized");
   ASV_REQUIRE(d->struct_size == sizeof(asv_grid_input_desc_t), "asv_net_add_grid_input: struct_size mismatch");
   ASV_REQUIRE(d->out_buf > 0 && d->out_buf < (int)net->bufs.size(), "grid_input: output buffer id %d", d->out_buf);
+  ASV_REQUIRE(d->in_buf >= 0 && d->in_buf < (int)net->bufs.size() && net->bufs[d->in_buf].domain == ASV_DOMAIN_FRAMES && net->bufs[d->in_buf].channels == net->feat_dim,
+              "grid_input: input must be a frames-domain buffer with feat_dim channels");
   const Domain &dm = net->domains[net->bufs[d->out_buf].domain];
   ASV_REQUIRE(dm.kind == 2 && dm.shift == 0 && dm.width == net->feat_dim, "grid_input: output must be a full-resolution grid of width feat_dim (%d)", net->feat_dim);
   Op op; op.kind = OP_GRID_INPUT; op.gin = *d;
@@ -618,7 +624,7 @@ int asv_net_describe(const asv_net_t *net, char *buf, size_t cap) {
                  op.att.out_buf, op.att.out_ch_off, op.att.eps);
         break;
       case OP_GRID_INPUT:
-        snprintf(line, sizeof(line), "  op %zu: grid_input 0 -> %d\n", i, op.gin.out_buf);
+        snprintf(line, sizeof(line), "  op %zu: grid_input %d -> %d\n", i, op.gin.in_buf, op.gin.out_buf);
         break;
       case OP_IM2COL:
         snprintf(line, sizeof(line), "  op %zu: im2col %d -> %d taps=%d stride=%d channels=%d\n", i, op.i2c.in_buf, op.i2c.out_buf, op.i2c.n_taps, op.i2c.stride, op.i2c.channels);
@@ -921,6 +927,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         p.scale = op.scale; p.shift = op.shift;
         p.act = d.act;
         if (d.seg_scale_buf >= 0) { p.seg_scale = reinterpret_cast<const float *>(net->arena[d.seg_scale_buf].ptr); p.ld_segscale = net->bufs[d.seg_scale_buf].ld; }
+        if (d.seg_norm_buf >= 0) { p.seg_norm = reinterpret_cast<const float *>(net->arena[d.seg_norm_buf].ptr); p.ld_segnorm = net->bufs[d.seg_norm_buf].ld; p.seg_norm_mode = d.seg_norm_mode; }
         if (op.utts) { p.rows = bp.segments; }
         else { p.rows = c.dom[domid].rows_pad; p.row_seg = c.dom[domid].row_seg; p.row_valid = c.dom[domid].row_valid; }
         if ((rc = prof.begin(K_ELT, 0, (int)i))) return rc;
@@ -932,7 +939,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         const int domid = net->bufs[op.gin.out_buf].domain;
         const DomainRun &dg = c.dom[domid];
         if ((rc = prof.begin(K_GATHER, 0, (int)i))) return rc;
-        rc = launch_grid_from_frames(net->arena[0].ptr, net->bufs[0].ld, net->feat_dim, c.dom[ASV_DOMAIN_FRAMES].seg_row0, dg.seg_row0, dg.row_seg, dg.row_valid,
+        rc = launch_grid_from_frames(net->arena[op.gin.in_buf].ptr, net->bufs[op.gin.in_buf].ld, net->feat_dim, c.dom[ASV_DOMAIN_FRAMES].seg_row0, dg.seg_row0, dg.row_seg, dg.row_valid,
                                      dg.rows_pad, net->domains[domid].pitch, net->arena[op.gin.out_buf].ptr, net->bufs[op.gin.out_buf].ld, net->frames_bf16(), c.s);
         if (rc) return rc;
         if ((rc = prof.end())) return rc;

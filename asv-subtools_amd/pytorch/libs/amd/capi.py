@@ -77,11 +77,12 @@ class EltwiseDesc(C.Structure):
         ("out_buf", C.c_int32), ("out_ch_off", C.c_int32),
         ("scale", c_float_p), ("shift", c_float_p),
         ("act", C.c_int32),
+        ("seg_norm_buf", C.c_int32), ("seg_norm_mode", C.c_int32),
     ]
 
 
 class GridInputDesc(C.Structure):
-    _fields_ = [("struct_size", C.c_uint32), ("out_buf", C.c_int32)]
+    _fields_ = [("struct_size", C.c_uint32), ("out_buf", C.c_int32), ("in_buf", C.c_int32)]
 
 
 class Im2colDesc(C.Structure):

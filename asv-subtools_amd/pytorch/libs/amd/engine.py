@@ -136,11 +136,14 @@ class Engine(object):
                 d.scale = capi.f32_ptr(op.scale) if op.scale is not None else None
                 d.shift = capi.f32_ptr(op.shift) if op.shift is not None else None
                 d.act = capi.ACT_BY_NAME[getattr(op, "act", None)]
+                d.seg_norm_buf = bv(getattr(op, "seg_norm", None))[0]
+                d.seg_norm_mode = int(getattr(op, "seg_norm_mode", 0))
                 capi.check(L.asv_net_add_eltwise(self._net, C.byref(d)), "asv_net_add_eltwise")
             elif op.kind == "grid_input":
                 d = capi.GridInputDesc()
                 d.struct_size = C.sizeof(capi.GridInputDesc)
                 d.out_buf = buf_of[op.out.tid]
+                d.in_buf = buf_of[op.inp.tid]
                 capi.check(L.asv_net_add_grid_input(self._net, C.byref(d)), "asv_net_add_grid_input")
             elif op.kind == "im2col":
                 d = capi.Im2colDesc()

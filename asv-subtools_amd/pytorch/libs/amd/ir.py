@@ -54,7 +54,7 @@ class Op(object):
         elif self.kind == "attpool":
             names = ("x", "logits")
         elif self.kind == "eltwise":
-            names = ("a", "b", "c", "seg_scale")
+            names = ("a", "b", "c", "seg_scale", "seg_norm")
         elif self.kind in ("grid_input", "im2col"):
             names = ("inp",)
         else:
@@ -63,7 +63,7 @@ class Op(object):
 
     def input_names(self):
         return {"tdnn": ("inp", "inp2", "seg_bias", "seg_scale", "res"), "pool": ("inp",),
-                "attpool": ("x", "logits"), "eltwise": ("a", "b", "c", "seg_scale"), "cat": (), "grid_input": ("inp",),
+                "attpool": ("x", "logits"), "eltwise": ("a", "b", "c", "seg_scale", "seg_norm"), "cat": (), "grid_input": ("inp",),
                 "im2col": ("inp",)}[self.kind]
 
 
@@ -130,11 +130,12 @@ class Graph(object):
                            per_bin=bool(per_bin)))
         return out
 
-    def grid_input(self):
-        """features [T][F] -> one-channel (time, frequency) grid."""
+    def grid_input(self, inp=None):
+        """features [T][F] (raw input or a normalised copy) -> one-channel (time, frequency) grid."""
+        inp = inp or self.full_view(0)
         dom = self.grid_domain(0, self.feat_dim)
         out = self.full_view(self.new_tensor(dom, 1))
-        self.ops.append(Op("grid_input", out, inp=self.full_view(0)))
+        self.ops.append(Op("grid_input", out, inp=inp))
         return out
 
     def im2col(self, inp, taps, stride):
@@ -153,10 +154,11 @@ class Graph(object):
         self.ops.append(Op("attpool", out, x=x, logits=logits, eps=float(eps)))
         return out
 
-    def eltwise(self, a, b=None, c=None, seg_scale=None, scale=None, shift=None, act=None):
+    def eltwise(self, a, b=None, c=None, seg_scale=None, scale=None, shift=None, act=None, seg_norm=None, seg_norm_mode=0):
         out = self.full_view(self.new_tensor(self.domain(a.tid), a.channels))
         f32 = lambda v: None if v is None else np.ascontiguousarray(v, dtype=np.float32)
-        self.ops.append(Op("eltwise", out, a=a, b=b, c=c, seg_scale=seg_scale, scale=f32(scale), shift=f32(shift), act=act or None))
+        self.ops.append(Op("eltwise", out, a=a, b=b, c=c, seg_scale=seg_scale, scale=f32(scale), shift=f32(shift), act=act or None,
+                           seg_norm=seg_norm, seg_norm_mode=int(seg_norm_mode)))
         return out
 
     def cat(self, parts):
@@ -202,7 +204,7 @@ class Graph(object):
 
     def _is_plain_add(self, op):
         return (op.kind == "eltwise" and op.b is not None and op.c is None and op.seg_scale is None and op.scale is None
-                and getattr(op, "act", None) is None)
+                and getattr(op, "act", None) is None and getattr(op, "seg_norm", None) is None)
 
     def _cse_adds(self):
         seen = {}
@@ -283,7 +285,8 @@ class Graph(object):
                     p.out = dst
                     self._replace_tensor(part.tid, dst)
                 else:
-                    new_ops.append(Op("eltwise", dst, a=part, b=None, c=None, seg_scale=None, scale=None, shift=None, act=None))
+                    new_ops.append(Op("eltwise", dst, a=part, b=None, c=None, seg_scale=None, scale=None, shift=None, act=None,
+                                      seg_norm=None, seg_norm_mode=0))
                 off += part.channels
             self.ops[idx:idx + 1] = new_ops
 
@@ -388,9 +391,10 @@ class Sym(object):
     def unsqueeze(self, dim):
         if self.rank == 2 and dim in (2, -1) and self.domain == DOMAIN_UTTS:
             return Sym(self.graph, self.view, 3, col_order=self.col_order)
-        if self.rank == 3 and dim == 1 and self.view.tid == 0:
+        if (self.rank == 3 and dim == 1 and self.domain == DOMAIN_FRAMES and self.view.ch_off == 0
+                and self.view.channels == self.graph.feat_dim == self.graph.tensors[self.view.tid][1]):
             # ResNetXvector: [B, F, T] -> [B, 1, F, T] (resnet_xvector.py:191)
-            return Sym(self.graph, self.graph.grid_input(), 4)
+            return Sym(self.graph, self.graph.grid_input(self.view), 4)
         raise TraceError("unsqueeze(%r) of a rank-%d %s tensor is not supported" % (dim, self.rank, "utts" if self.domain else "frames"))
 
     def squeeze(self, dim=None):

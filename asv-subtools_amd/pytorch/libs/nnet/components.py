@@ -174,3 +174,25 @@ class SEBlock_2D(torch.nn.Module):
 
     def forward(self, inputs):
         _eager_unsupported("SEBlock_2D")
+
+
+class InputSequenceNormalization(torch.nn.Module):
+    """Per-utterance mean (and std) normalisation of the input features over time (reference
+    components.py:751-850, used by ResNetXvector(cmvn=True)): x <- (x - mean_t) / max(std_t, 1e-10) with the
+    UNBIASED std of torch.std.  On the device: one pooling pass per segment + one elementwise pass."""
+
+    def __init__(self, mean_norm=True, std_norm=True):
+        super(InputSequenceNormalization, self).__init__()
+        self.mean_norm, self.std_norm = mean_norm, std_norm
+        self.eps = 1e-10
+
+    def forward(self, x, lengths=None):
+        if not isinstance(x, _ir.Sym):
+            _eager_unsupported("InputSequenceNormalization")
+        if not (self.mean_norm or self.std_norm):
+            return x
+        g = x.graph
+        # std = max(sqrt(var_unbiased), eps) == sqrt(max(var, eps^2))
+        stats = g.pool(x.view, stddev=True, unbiased=2, var_mode=0, eps=self.eps * self.eps)
+        out = g.eltwise(x.view, seg_norm=stats, seg_norm_mode=(1 if self.mean_norm else 0) | (2 if self.std_norm else 0))
+        return _ir.Sym(g, out, x.rank)

@@ -34,15 +34,14 @@ class ResNetXvector(TopVirtualNnet):
                                                    "stddev": True, "temperature": False, "fixed": True}, pooling_params)
         fc1_params = utils.assign_params_dict(fc_defaults, fc1_params)
         fc2_params = utils.assign_params_dict(fc_defaults, fc2_params)
-        if cmvn:
-            raise NotImplementedError("cmvn=True (InputSequenceNormalization) is not implemented on the MI355X path")
+        cmvn_params = utils.assign_params_dict({"mean_norm": True, "std_norm": False}, cmvn_params)
         if pooling not in ("statistics", "stats", None, ""):
             raise NotImplementedError("pooling='%s' is outside the MI355X extraction path (SURVEY.md section 2, row 3)" % pooling)
 
         self.extracted_embedding = extracted_embedding
         self.inputs_dim = inputs_dim
         self.convXd = resnet_params["convXd"]
-        self.cmvn_ = torch.nn.Identity()
+        self.cmvn_ = InputSequenceNormalization(**cmvn_params) if cmvn else torch.nn.Identity()
         self.resnet = ResNet(1 if self.convXd == 2 else inputs_dim, **resnet_params)
         mult = self.resnet.get_downsample_multiple()
         trunk_dim = (inputs_dim + mult - 1) // mult * self.resnet.get_output_planes()

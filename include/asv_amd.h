@@ -151,6 +151,10 @@ typedef struct asv_eltwise_desc {
   int32_t out_buf, out_ch_off;
   const float *scale, *shift;    /* optional host per-channel affine applied to `a` first    */
   int32_t act;                   /* activation applied to the sum (BasicBlock's final ReLU)  */
+  int32_t seg_norm_buf;          /* utts-domain buffer [segments][mean(C) | std(C)] or -1: `a` becomes
+                                    (a - mean) / std per segment first - InputSequenceNormalization,
+                                    components.py:780-842; seg_norm_mode bit 0 = subtract mean, bit 1 = divide by std */
+  int32_t seg_norm_mode;
 } asv_eltwise_desc_t;
 int asv_net_add_eltwise(asv_net_t *net, const asv_eltwise_desc_t *d);
 
@@ -159,6 +163,7 @@ int asv_net_add_eltwise(asv_net_t *net, const asv_eltwise_desc_t *d);
 typedef struct asv_grid_input_desc {
   uint32_t struct_size;
   int32_t out_buf;
+  int32_t in_buf;                /* frames-domain buffer with feat_dim channels (0 = the raw input features) */
 } asv_grid_input_desc_t;
 int asv_net_add_grid_input(asv_net_t *net, const asv_grid_input_desc_t *d);
 

@@ -83,6 +83,11 @@ CASES = {
                           creation="ResNetXvector(80,10,training=False,resnet_params={'use_se':True,'se_ratio':4,'full_pre_activation':False},"
                                    "fc2_params={'nonlinearity':'','bn_params':{'momentum':0.5,'affine':False,'track_running_stats':True}})",
                           dim=80, utts=[(200, 5000), (203, 5001), (9, 5002), (64, 5003)], wseed=6),
+    # cmvn=True: InputSequenceNormalization (mean and std) in front of the trunk
+    "resnet34_cmvn": dict(blueprint="resnet_xvector.py",
+                          creation="ResNetXvector(40,10,training=False,cmvn=True,cmvn_params={'mean_norm':True,'std_norm':True},"
+                                   "resnet_params={'full_pre_activation':False})",
+                          dim=40, utts=[(120, 5200), (45, 5201)], wseed=8),
     # no SE, default fc2 (ReLU + affine BN), odd feature dim -> ceil division at every stride-2 stage
     "resnet34_plain": dict(blueprint="resnet_xvector.py",
                            creation="ResNetXvector(61,10,training=False,resnet_params={'full_pre_activation':False})",

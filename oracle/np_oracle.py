@@ -305,9 +305,21 @@ def resnet_trunk(x, sd, prefix="resnet", layers=(3, 4, 6, 3)):
     return y
 
 
-def resnet_embed(x, sd, position="near", fc2_nonlinearity="relu", layers=(3, 4, 6, 3)):
+def input_sequence_norm(x, mean_norm=True, std_norm=False, eps=1e-10):
+    """components.py:780-842: per-utterance (x - mean_t) / max(std_t, eps) with torch.std's unbiased estimate."""
+    mean = x.mean(axis=0, dtype=x.dtype) if mean_norm else 0.0
+    if std_norm:
+        std = np.maximum(x.std(axis=0, ddof=1, dtype=x.dtype), x.dtype.type(eps))
+    else:
+        std = 1.0
+    return ((x - mean) / std).astype(x.dtype)
+
+
+def resnet_embed(x, sd, position="near", fc2_nonlinearity="relu", layers=(3, 4, 6, 3), cmvn=None):
     """model/resnet_xvector.py:183-208.  x [T, D] -> trunk on [T, F=D, 1] -> [T', F', C] ->
     reshape to channel index c*F' + f (resnet_xvector.py:193) -> StatisticsPooling -> fc2."""
+    if cmvn is not None:
+        x = input_sequence_norm(x, **cmvn)
     y = resnet_trunk(x[:, :, None], sd, "resnet", layers)           # [T', F', C]
     To, Fo, C = y.shape
     feat = y.transpose(0, 2, 1).reshape(To, C * Fo)                 # column index c*F' + f

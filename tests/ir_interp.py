@@ -69,8 +69,9 @@ def run_graph(graph, feats, dtype=np.float32):
         elif op.kind == "grid_input":
             fr, width, pitch = grid_dims(op.out.tid)
             g = np.zeros((fr * pitch, 1), dtype=dtype)
+            src = get(op.inp)
             for t in range(fr):
-                g[t * pitch:t * pitch + width, 0] = feats[t, :width]
+                g[t * pitch:t * pitch + width, 0] = src[t, :width]
             put(op.out, g)
         elif op.kind == "im2col":
             x = get(op.inp)
@@ -118,6 +119,13 @@ def run_graph(graph, feats, dtype=np.float32):
             z = get(op.a)
             if op.scale is not None:
                 z = z * op.scale.astype(dtype) + op.shift.astype(dtype)
+            if getattr(op, "seg_norm", None) is not None:
+                st = get(op.seg_norm)[0]
+                C = op.a.channels
+                if op.seg_norm_mode & 1:
+                    z = z - st[:C]
+                if op.seg_norm_mode & 2:
+                    z = z / st[C:2 * C]
             if op.seg_scale is not None:
                 z = z * get(op.seg_scale)
             if op.b is not None:

@@ -98,7 +98,7 @@ def test_ecapa_traced_program_reproduces_reference_on_cpu(name, limit):
         assert rel_err(ir_interp.extract(graph, x), ref) < 2e-5
 
 
-@pytest.mark.parametrize("name,idx", [("resnet34se_c5", 2), ("resnet34se_c5", 3), ("resnet34_plain", 1)])
+@pytest.mark.parametrize("name,idx", [("resnet34se_c5", 2), ("resnet34se_c5", 3), ("resnet34_plain", 1), ("resnet34_cmvn", 1)])
 def test_resnet_traced_program_reproduces_reference_on_cpu(name, idx):
     """2-D trunk: row-flattened (time, frequency) grids, BN folded into the convolutions, im2col for the
     stride-2 convolutions, SE with the pitch/width factor folded, per-bin pooling + permuted fc2 columns."""
@@ -106,6 +106,8 @@ def test_resnet_traced_program_reproduces_reference_on_cpu(name, idx):
     g, sd, model = helpers.golden_model(name)
     graph = ir.trace(model, type(model).extract_embedding.__wrapped_body__, int(g["dim"]))
     assert sum(1 for op in graph.ops if op.kind == "im2col") == 6          # 3 strided 3x3 + 3 strided 1x1
+    if name == "resnet34_cmvn":
+        assert [op.kind for op in graph.ops[:3]] == ["pool", "eltwise", "grid_input"]   # InputSequenceNormalization
     per_frame, _ = graph.flops_per_frame()
     if name == "resnet34se_c5":
         assert abs(per_frame - 45.27e6) < 0.02e6

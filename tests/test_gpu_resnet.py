@@ -10,7 +10,7 @@ from helpers import rel_err
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["resnet34se_c5", "resnet34_plain"])
+@pytest.mark.parametrize("name", ["resnet34se_c5", "resnet34_plain", "resnet34_cmvn"])
 def test_resnet_f32_vs_reference_golden(name):
     g, sd, model = helpers.golden_model(name)
     model.cuda()
