@@ -24,16 +24,25 @@
 namespace asv {
 namespace {
 
-constexpr int BM = 256, BN = 256;
-constexpr int WIN = BM + 2 * kHalo;          // 264
+constexpr int BN = 256;
 constexpr int ROWB = 128;
-constexpr int A_STAGE = WIN * ROWB;          // 33792
 constexpr int N_STAGES = 3;
-constexpr int LDS_BYTES = 131072;            // 3 window stages (101376 B); the epilogue stages 8 x 16 KiB
-constexpr int A_GROUPS = WIN / 8;            // 33 eight-row groups
 constexpr int BK = 64;
-static_assert(N_STAGES * A_STAGE <= LDS_BYTES, "window ring must fit");
 static_assert(BN == kBigTileN, "weight padding must match the N tile");
+// WM = number of 128-frame wave rows per workgroup:
+//   WM = 2: 256 x 256 tile, 8 waves, 128 KiB LDS, one workgroup per CU
+//   WM = 1: 128 x 256 tile, 4 waves,  64 KiB LDS, TWO workgroups per CU - the prologue (first window + weight
+//           fragments in flight) and the epilogue of one workgroup overlap with the main loop of the other
+template <int WM> struct Geom3 {
+  static constexpr int BM = 128 * WM;
+  static constexpr int WIN = BM + 2 * kHalo;           // 264 | 136
+  static constexpr int A_STAGE = WIN * ROWB;           // 33792 | 17408
+  static constexpr int A_GROUPS = WIN / 8;             // 33 | 17 eight-row groups
+  static constexpr int WAVES = 4 * WM;
+  static constexpr int PIECES = (A_GROUPS + WAVES - 1) / WAVES;   // LDS-DMA pieces per wave per window: 5
+  static constexpr int LDS_BYTES = WAVES * 16384;      // epilogue scratch: 16 KiB per wave; >= 3 window stages
+  static_assert(N_STAGES * A_STAGE <= LDS_BYTES, "window ring must fit");
+};
 
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
 
@@ -54,9 +63,11 @@ __device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst) {
 }
 
 // ABL: 0 full, 2 MFMA only (no loads of any kind in the loop), 4 no epilogue stores
-template <int ABL, bool GENERIC, bool POOL>
-__global__ __launch_bounds__(512, 2) void tdnn_gemm_big3_kernel(const TdnnKernelParams p, int m_tiles, int n_tiles) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+template <int ABL, bool GENERIC, bool POOL, int WM>
+__global__ __launch_bounds__(256 * WM, 2) void tdnn_gemm_big3_kernel(const TdnnKernelParams p, int m_tiles, int n_tiles) {
+  using G = Geom3<WM>;
+  constexpr int BM = G::BM, A_STAGE = G::A_STAGE, A_GROUPS = G::A_GROUPS;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -78,8 +89,8 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_big3_kernel(const TdnnKernel
   // feature window of chunk c -> ring stage st (33 eight-row groups: 4 per wave + a 5th for wave 0)
   auto issue_A = [&](int c, int st) {
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int grp = wave + i * 8;
+    for (int i = 0; i < G::PIECES; ++i) {
+      const int grp = wave + i * G::WAVES;
       if (grp < A_GROUPS) {
         const int w = grp * 8 + g_row;
         const int row = m0 - kHalo + w;
@@ -313,28 +324,42 @@ bool tdnn_big3_supported(const TdnnKernelParams &p, bool bf16, bool out_f32) {
 }
 
 int launch_tdnn_big3_variant(const TdnnKernelParams &p, int variant, hipStream_t s) {
-  ASV_REQUIRE(p.rows % BM == 0, "tdnn(big3): rows %d not a multiple of %d", p.rows, BM);
+  ASV_REQUIRE(p.rows % 256 == 0, "tdnn(big3): rows %d not a multiple of 256", p.rows);
   ASV_REQUIRE(p.wfrag != nullptr, "tdnn(big3): fragment-packed weights missing");
-  const int m_tiles = p.rows / BM, n_tiles = round_up(p.cout_store, BN) / BN;
-  const dim3 grid(m_tiles * n_tiles), block(512);
+  const bool two_per_cu = variant < 100;                 // variants >= 100: the 256x256 / one-workgroup-per-CU geometry
+  if (!two_per_cu) variant -= 100;
+  const int bm = two_per_cu ? 128 : 256;
+  const int m_tiles = p.rows / bm, n_tiles = round_up(p.cout_store, BN) / BN;
+  const dim3 grid(m_tiles * n_tiles), block(two_per_cu ? 256 : 512);
   const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first;
   if (p.pool_partial != nullptr) {
     ASV_REQUIRE(fast && p.row_seg != nullptr && p.pool_slots >= 1, "tdnn(big3): fused pooling needs the plain epilogue and a row map");
-    hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, false, true>), grid, block, 0, s, p, m_tiles, n_tiles);
+    if (two_per_cu) hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, false, true, 1>), grid, block, 0, s, p, m_tiles, n_tiles);
+    else hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, false, true, 2>), grid, block, 0, s, p, m_tiles, n_tiles);
     ASV_HIP_CHECK(hipGetLastError());
     return ASV_OK;
   }
-  switch (variant) {
-    case 2: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<2, false, false>), grid, block, 0, s, p, m_tiles, n_tiles); break;
-    case 4: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<4, false, false>), grid, block, 0, s, p, m_tiles, n_tiles); break;
-    default:
-      if (fast) hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, false, false>), grid, block, 0, s, p, m_tiles, n_tiles);
-      else hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, true, false>), grid, block, 0, s, p, m_tiles, n_tiles);
+  if (two_per_cu) {
+    switch (variant) {
+      case 2: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<2, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles); break;
+      case 4: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<4, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles); break;
+      default:
+        if (fast) hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles);
+        else hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, true, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles);
+    }
+  } else {
+    switch (variant) {
+      case 2: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<2, false, false, 2>), grid, block, 0, s, p, m_tiles, n_tiles); break;
+      case 4: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<4, false, false, 2>), grid, block, 0, s, p, m_tiles, n_tiles); break;
+      default:
+        if (fast) hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, false, false, 2>), grid, block, 0, s, p, m_tiles, n_tiles);
+        else hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, true, false, 2>), grid, block, 0, s, p, m_tiles, n_tiles);
+    }
   }
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }
 
-int launch_tdnn_big3(const TdnnKernelParams &p, hipStream_t s) { return launch_tdnn_big3_variant(p, 0, s); }
+int launch_tdnn_big3(const TdnnKernelParams &p, hipStream_t s) { return launch_tdnn_big3_variant(p, p.big_one_per_cu ? 100 : 0, s); }
 
 }  // namespace asv
