@@ -26,12 +26,12 @@ namespace {
 
 constexpr int BN = 256;
 constexpr int ROWB = 128;
-constexpr int N_STAGES = 3;
+constexpr int N_STAGES = 4;
 constexpr int BK = 64;
 static_assert(BN == kBigTileN, "weight padding must match the N tile");
 // WM = number of 128-frame wave rows per workgroup:
-//   WM = 2: 256 x 256 tile, 8 waves, 128 KiB LDS, one workgroup per CU
-//   WM = 1: 128 x 256 tile, 4 waves,  64 KiB LDS, TWO workgroups per CU - the prologue (first window + weight
+//   WM = 2: 256 x 256 tile, 8 waves, 135 KiB LDS, one workgroup per CU
+//   WM = 1: 128 x 256 tile, 4 waves,  71 KiB LDS, TWO workgroups per CU - the prologue (first window + weight
 //           fragments in flight) and the epilogue of one workgroup overlap with the main loop of the other
 template <int WM> struct Geom3 {
   static constexpr int BM = 128 * WM;
@@ -40,8 +40,10 @@ template <int WM> struct Geom3 {
   static constexpr int A_GROUPS = WIN / 8;             // 33 | 17 eight-row groups
   static constexpr int WAVES = 4 * WM;
   static constexpr int PIECES = (A_GROUPS + WAVES - 1) / WAVES;   // LDS-DMA pieces per wave per window: 5
-  static constexpr int LDS_BYTES = WAVES * 16384;      // epilogue scratch: 16 KiB per wave; >= 3 window stages
-  static_assert(N_STAGES * A_STAGE <= LDS_BYTES, "window ring must fit");
+  static constexpr int RING_BYTES = N_STAGES * A_STAGE; // 4 window stages (135168 | 69632 B) >= epilogue scratch, 16 KiB per wave
+  static constexpr int PARAM_OFF = RING_BYTES;         // bias | scale | shift of the tile's 256 channels (3 KiB)
+  static constexpr int LDS_BYTES = RING_BYTES + 3 * 256 * 4;
+  static_assert(WAVES * 16384 <= RING_BYTES, "epilogue scratch must fit in the ring");
 };
 
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
@@ -62,10 +64,38 @@ __device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst) {
       : "memory");
 }
 
-// ABL: 0 full, 2 MFMA only (no loads of any kind in the loop), 4 no epilogue stores
+// same with a scalar base + 32-bit per-lane byte offset (no 64-bit VALU address arithmetic per piece)
+__device__ __forceinline__ void glds16_s(const void *sbase, uint32_t voff, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_dst)
+      : "memory");
+}
+
+// ABL: 0 full, 2 MFMA only (no loads of any kind in the loop), 4 no epilogue stores,
+//      5 full + per-workgroup phase timestamps into p.partial, 6 MFMA only + timestamps
+#define STAMP3(k)                                                                                                   \
+  if constexpr (ABL >= 5) {                                                                                         \
+    if (tid == 0) {                                                                                                 \
+      unsigned long long *dbg = reinterpret_cast<unsigned long long *>(p.partial) + (size_t)blockIdx.x * 8;          \
+      dbg[k] = __builtin_amdgcn_s_memrealtime();                                                                    \
+      if (k == 1) dbg[5] = __builtin_amdgcn_s_memtime();                                                          \
+      if (k == 2) dbg[6] = __builtin_amdgcn_s_memtime();                                                          \
+      if (k == 0) dbg[4] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492); \
+    }                                                                                                               \
+  }
 template <int ABL, bool GENERIC, bool POOL, int WM>
 __global__ __launch_bounds__(256 * WM, 2) void tdnn_gemm_big3_kernel(const TdnnKernelParams p, int m_tiles, int n_tiles) {
   using G = Geom3<WM>;
+  constexpr bool MFMA_ONLY = (ABL == 2 || ABL == 6);
+  constexpr bool NO_WF = MFMA_ONLY || (ABL >= 16 && (ABL & 1)), NO_X = MFMA_ONLY || (ABL >= 16 && (ABL & 2)), NO_DMA = MFMA_ONLY || (ABL >= 16 && (ABL & 4));
+  constexpr bool X_DUMMY = (ABL >= 16 && (ABL & 8));   // LDS reads issued but their data never feeds an MFMA
   constexpr int BM = G::BM, A_STAGE = G::A_STAGE, A_GROUPS = G::A_GROUPS;
   __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -85,19 +115,45 @@ __global__ __launch_bounds__(256 * WM, 2) void tdnn_gemm_big3_kernel(const TdnnK
 
   const int nchunks = (p.cin_pad + BK - 1) / BK;
   const int n_taps = p.n_taps;
+  STAMP3(0);
 
-  // feature window of chunk c -> ring stage st (33 eight-row groups: 4 per wave + a 5th for wave 0)
+  // Per-channel epilogue constants go to LDS now: fetching them from L2 inside the epilogue put a chain of
+  // dependent ~1 us loads behind every tile (the accumulators leave no registers to prefetch them into).
+  float *lds_par = reinterpret_cast<float *>(lds + G::PARAM_OFF);
+  if (tid < 192) {
+    const int which = tid >> 6, idx = (tid & 63) * 4;
+    float4 v = (which == 1) ? make_float4(1.f, 1.f, 1.f, 1.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float *src = (which == 0) ? p.bias : (which == 1 ? p.scale : p.shift);
+    if (src != nullptr) v = *reinterpret_cast<const float4 *>(src + n0 + idx);
+    *reinterpret_cast<float4 *>(lds_par + which * 256 + idx) = v;
+  }
+
+  // feature window of chunk c -> ring stage st: 33 | 17 eight-row groups, one LDS-DMA instruction each.  Every
+  // wave issues PIECES of them (the odd last group is issued by all waves - identical bytes - so that the
+  // VMEM queue looks the same in every wave).  Rows beyond the ends of the matrix are clamped to its first /
+  // last row, which are gap rows (zeros) in every frames / grid buffer; per piece only a 32-bit byte offset is
+  // kept and the chunk advances the scalar base, so a refill costs ~4 instructions per piece.
+  uint32_t a_off[G::PIECES];
+#pragma unroll
+  for (int i = 0; i < G::PIECES; ++i) {
+    const int grp = min(wave + i * G::WAVES, A_GROUPS - 1);
+    const int w = grp * 8 + g_row;
+    const int row = min(max(m0 - kHalo + w, 0), p.rows - 1);
+    a_off[i] = (uint32_t)row * (uint32_t)x_pitch + (uint32_t)swz(w, g_slot) * 16u;
+  }
   auto issue_A = [&](int c, int st) {
+    const unsigned char *base = xg + (size_t)c * (BK * 2);
+    const bool tail = (c + 1) * BK > p.cin_pad;              // only the last chunk of a cin that is not a multiple of 64
 #pragma unroll
     for (int i = 0; i < G::PIECES; ++i) {
-      const int grp = wave + i * G::WAVES;
-      if (grp < A_GROUPS) {
+      const int grp = min(wave + i * G::WAVES, A_GROUPS - 1);
+      const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + st * A_STAGE + grp * 1024);
+      if (!tail) {
+        glds16_s(base, a_off[i], dst);
+      } else {
         const int w = grp * 8 + g_row;
-        const int row = m0 - kHalo + w;
-        const int ch = c * BK + swz(w, g_slot) * 8;
-        const bool ok = row >= 0 && row < p.rows && ch < p.cin_pad;
-        const unsigned char *src = ok ? xg + (size_t)row * x_pitch + (size_t)ch * 2 : zero;
-        glds16(src, __builtin_amdgcn_readfirstlane(lds_base + st * A_STAGE + grp * 1024));
+        const bool ok = c * BK + swz(w, g_slot) * 8 < p.cin_pad;
+        glds16(ok ? base + a_off[i] : zero, dst);
       }
     }
   };
@@ -130,6 +186,15 @@ __global__ __launch_bounds__(256 * WM, 2) void tdnn_gemm_big3_kernel(const TdnnK
       f.x[i] = *reinterpret_cast<const uint4 *>(Ab + w * ROWB + swz(w, slot) * 16);
     }
   };
+  auto load_x1 = [&](const unsigned char *Ab, int d, int kg, int i, XFrags &f) {
+    const int w = wm * 128 + i * 32 + lr + kHalo + d;
+    f.x[i] = *reinterpret_cast<const uint4 *>(Ab + w * ROWB + swz(w, kg * 2 + lh) * 16);
+  };
+  auto mma2 = [&](const XFrags &f, int kg, int j, int i0) {
+#pragma unroll
+    for (int i = i0; i < i0 + 2; ++i)
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[kg][j]), __builtin_bit_cast(bf16x8_t, f.x[i]), acc[i][j], 0, 0, 0);
+  };
   auto mma = [&](const XFrags &f, int kg) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -139,57 +204,93 @@ __global__ __launch_bounds__(256 * WM, 2) void tdnn_gemm_big3_kernel(const TdnnK
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[kg][j]), __builtin_bit_cast(bf16x8_t, f.x[i]), acc[i][j], 0, 0, 0);
   };
 
-  // ---- prologue: two windows in flight, weight fragments of step 0
+  // ---- prologue: three windows in flight, weight fragments of step 0.  Only window 0 and the fragments are
+  // waited for: VMEM retires in order, so vmcnt(2 * PIECES) leaves exactly windows 1 and 2 outstanding.
   issue_A(0, 0);
-  if (nchunks > 1) issue_A(1, 1);
 #pragma unroll
   for (int kg = 0; kg < 4; ++kg) load_wf(kg, 0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (nchunks > 2) {
+    issue_A(1, 1);
+    issue_A(2, 2);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::PIECES) : "memory");
+  } else {
+    if (nchunks > 1) issue_A(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
-  const int nsteps = nchunks * n_taps;
+  STAMP3(1);
+  // tap offsets live in one VGPR (lane t = tap t) and are fetched with v_readlane: indexing the kernel-argument
+  // array costs an s_load + s_waitcnt lgkmcnt(0) per step, and that wait also drains every LDS read in flight
+  const int v_taps = p.taps[lane < 9 ? lane : 0];
+  const int d_first = __builtin_amdgcn_readlane(v_taps, 0);
   int s = 0;
+  XFrags x0, x1;
+  load_x(lds, d_first, 0, x0);                               // the only LDS latency nothing hides
   for (int c = 0; c < nchunks; ++c) {
     const unsigned char *Ab = lds + (c % N_STAGES) * A_STAGE;
     for (int t = 0; t < n_taps; ++t, ++s) {
+      // Fragments of the NEXT step are fetched unconditionally (the last step re-reads its own: valid memory,
+      // never used).  A conditional fetch makes the compiler assume the short queue at every wait and the
+      // resulting vmcnt(1)/vmcnt(0) stall each step on loads issued a few instructions earlier.
+      const bool last_tap = (t + 1 == n_taps);
       int cn = c, tn = t + 1;
-      if (tn == n_taps) { tn = 0; cn = c + 1; }
-      const bool has_next = (ABL != 2) && (s + 1 < nsteps);
-      const int d = p.taps[t];
-      XFrags x0, x1;
-      if (ABL != 2 || s == 0) load_x(Ab, d, 0, x0);
-      if (ABL != 2) load_x(Ab, d, 1, x1);
-      mma(x0, 0);
-      if (has_next) load_wf(0, cn, tn);
-      __builtin_amdgcn_sched_barrier(0);
-      if (ABL != 2) load_x(Ab, d, 2, x0);
-      mma(ABL == 2 ? x0 : x1, 1);
-      if (has_next) load_wf(1, cn, tn);
-      __builtin_amdgcn_sched_barrier(0);
-      if (ABL != 2) load_x(Ab, d, 3, x1);
-      mma(x0, 2);
-      if (has_next) load_wf(2, cn, tn);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(ABL == 2 ? x0 : x1, 3);
-      if (has_next) load_wf(3, cn, tn);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // chunk boundary: refill the stage chunk c-1 used (free since the previous barrier) with chunk c+2,
-    // then make sure chunk c+1's window has landed everywhere.  Younger than that window in this wave's
-    // VMEM queue are only: the 8 fragment loads of the last step and the 4-5 pieces issued just now.
-    const bool more = (ABL != 2) && (c + 2 < nchunks);
-    if (more) issue_A(c + 2, (c + 2) % N_STAGES);
-    if (c + 1 < nchunks) {
-      if (more) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
+      if (last_tap) { tn = 0; cn = c + 1; }
+      if (cn == nchunks) { cn = c; tn = t; }
+      const int d = __builtin_amdgcn_readlane(v_taps, t);
+      // k-group g = the 8 MFMAs of g with the 4 LDS reads of group g+1 (each with its 2 address VALU ops) and
+      // the 2 fragment fetches of the next step's group g threaded between them: issued as one block after
+      // the MFMAs they cost their full issue time (tools/loop_probe.hip: 324 vs 271 cycles per group), one
+      // read in front of every MFMA pair hides completely.  sched_barrier(0) after every pair pins exactly this
+      // order (sched_group_barrier picks MFMAs in an order of its own and the first MFMA of the next group
+      // then waits for the read issued last).
+      XFrags xd;
+      auto sink = [&]() { if (X_DUMMY) asm volatile("" ::"v"(xd.x[0].x), "v"(xd.x[1].y), "v"(xd.x[2].z), "v"(xd.x[3].w)); };
+      auto group = [&](const XFrags &xc, int kg, XFrags &xn, const unsigned char *An, int dn, int kgn) {
+        const size_t woff = ((size_t)tn * nchunks + cn) * 4096 + (size_t)kg * 1024;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          // pair q: channel fragment j = q / 2 against frame fragments 2 * (q % 2) and + 1; a channel fragment is
+          // re-fetched (for the next step) as soon as its fourth MFMA has been issued
+          if (!NO_X) load_x1(An, dn, kgn, q, X_DUMMY ? xd : xn);
+          mma2(xc, kg, q >> 1, (q & 1) * 2);
+          if (!NO_WF && q == 1) wf[kg][0] = *reinterpret_cast<const uint4 *>(wf_base0 + woff);
+          if (!NO_WF && q == 3) wf[kg][1] = *reinterpret_cast<const uint4 *>(wf_base1 + woff);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        sink();
+        if constexpr (ABL == 5) {
+          if (tid == 0 && s < 32) {
+            unsigned long long *dbg2 = reinterpret_cast<unsigned long long *>(p.partial) + (size_t)gridDim.x * 8 + (size_t)blockIdx.x * 128;
+            dbg2[s * 4 + kg] = __builtin_amdgcn_s_memtime();
+          }
+        }
+      };
+      group(x0, 0, x1, Ab, d, 1);
+      group((NO_X || X_DUMMY) ? x0 : x1, 1, x0, Ab, d, 2);
+      group(x0, 2, x1, Ab, d, 3);
+      // The last k-group already reads the first fragments of the next step.  When that step opens a new chunk
+      // the workgroup meets first: every wave has its pieces of window c+1 in LDS (they are older than the
+      // youngest 8 VMEM operations, all fragment fetches), and behind the barrier nobody reads window c-1
+      // any more, so its stage takes window c+3.  The barrier sits in the shadow of group 2's MFMAs.
+      const unsigned char *An = Ab;
+      int dn = __builtin_amdgcn_readlane(v_taps, last_tap ? t : t + 1);
+      if (last_tap && c + 1 < nchunks) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (!NO_DMA && c + 3 < nchunks) issue_A(c + 3, (c + 3) % N_STAGES);
+        An = lds + ((c + 1) % N_STAGES) * A_STAGE;
+        dn = d_first;
+      }
+      group((NO_X || X_DUMMY) ? x0 : x1, 3, x0, An, dn, 0);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();            // every wave is done reading the ring: the epilogue reuses the LDS
   asm volatile("" ::: "memory");
+  STAMP3(2);
 
   if constexpr (POOL) {
     // ---- epilogue with fused statistics pooling (pooling.py:58-67 folded into the producing layer):
@@ -228,9 +329,9 @@ __global__ __launch_bounds__(256 * WM, 2) void tdnn_gemm_big3_kernel(const TdnnK
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int ch = n0 + wn * 64 + j * 32 + 8 * q + 4 * lh;
-          const float4 b4 = *reinterpret_cast<const float4 *>(p.bias + ch);
-          const float4 sc4 = p.scale ? *reinterpret_cast<const float4 *>(p.scale + ch) : make_float4(1.f, 1.f, 1.f, 1.f);
+          const int chl = wn * 64 + j * 32 + 8 * q + 4 * lh;             // channel inside the tile
+          const float4 b4 = *reinterpret_cast<const float4 *>(lds_par + chl);
+          const float4 sc4 = *reinterpret_cast<const float4 *>(lds_par + 256 + chl);
           float4 u;
           u.x = valid ? fmaxf(acc[i][j][q * 4 + 0] + b4.x, act_lo) * sc4.x : 0.0f;
           u.y = valid ? fmaxf(acc[i][j][q * 4 + 1] + b4.y, act_lo) * sc4.y : 0.0f;
@@ -268,10 +369,10 @@ __global__ __launch_bounds__(256 * WM, 2) void tdnn_gemm_big3_kernel(const TdnnK
   for (int j = 0; j < 2; ++j) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int ch = n0 + wn * 64 + j * 32 + 8 * q + 4 * lh;
-      const float4 b4 = *reinterpret_cast<const float4 *>(p.bias + ch);
-      const float4 sc4 = p.scale ? *reinterpret_cast<const float4 *>(p.scale + ch) : make_float4(1.f, 1.f, 1.f, 1.f);
-      const float4 sh4 = p.shift ? *reinterpret_cast<const float4 *>(p.shift + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int chl = wn * 64 + j * 32 + 8 * q + 4 * lh;                 // channel inside the tile
+      const float4 b4 = *reinterpret_cast<const float4 *>(lds_par + chl);
+      const float4 sc4 = *reinterpret_cast<const float4 *>(lds_par + 256 + chl);
+      const float4 sh4 = *reinterpret_cast<const float4 *>(lds_par + 512 + chl);
       const float b[4] = {b4.x, b4.y, b4.z, b4.w}, sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
       const int slot = j * 4 + q;                // channel offset j*32 + 8*q + 4*lh -> 16-B slot, 8-B half lh
 #pragma unroll
@@ -313,6 +414,11 @@ __global__ __launch_bounds__(256 * WM, 2) void tdnn_gemm_big3_kernel(const TdnnK
       if (ch < p.cout_store) *reinterpret_cast<uint4 *>(yg + (size_t)row * y_pitch + (size_t)ch * 2) = v;
     }
   }
+  if constexpr (ABL >= 5) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    STAMP3(3);
+  }
 }
 
 }  // namespace
@@ -343,6 +449,16 @@ int launch_tdnn_big3_variant(const TdnnKernelParams &p, int variant, hipStream_t
     switch (variant) {
       case 2: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<2, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles); break;
       case 4: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<4, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles); break;
+      case 5: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<5, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles); break;
+      case 6: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<6, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles); break;
+      case 17: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<17, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles); break;
+      case 18: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<18, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles); break;
+      case 20: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<20, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles); break;
+      case 19: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<19, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles); break;
+      case 21: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<21, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles); break;
+      case 24: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<24, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles); break;
+      case 29: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<29, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles); break;
+      case 22: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<22, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles); break;
       default:
         if (fast) hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles);
         else hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, true, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles);

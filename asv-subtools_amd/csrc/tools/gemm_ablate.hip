@@ -3,6 +3,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <algorithm>
 #include "../asv_internal.h"
 
 using namespace asv;
@@ -50,7 +51,7 @@ int main(int argc, char **argv) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   printf("rows=%d cin=%d cout=%d taps=%d xpad=%d  (%.1f GFLOP)\n", rows, cin, cout, ntaps, xpad, flops / 1e9);
   const char *names[] = {"big: full", "big: no LDS-DMA in loop", "big: MFMA + barrier only", "big: DMA + ds_read, no MFMA", "big: no epilogue stores", "big: DMA (cache-hot) + ds_read", "small 128x128 (v1)", "big: DMA + barrier only", "big: ds_read + barrier only", "big3 (2 WG/CU): full", "big3 (2 WG/CU): MFMA only", "big3 (2 WG/CU): no epilogue stores", "big3 (1 WG/CU): full", "big3 (1 WG/CU): MFMA only"};
-  for (int v = 0; v <= 13; ++v) {
+  for (int v = 9; v <= 13; ++v) {
     for (int rep = 0; rep < 2; ++rep) {
       CK(hipEventRecord(a, 0));
       for (int i = 0; i < iters; ++i) {
@@ -61,6 +62,63 @@ int main(int argc, char **argv) {
       float ms; CK(hipEventElapsedTime(&ms, a, b));
       if (rep == 1) printf("  %-30s %9.1f us  %8.1f TFLOP/s\n", names[v], 1e3 * ms / iters, flops * iters / (ms * 1e-3) / 1e12);
     }
+  }
+  // ---- per-workgroup phase timeline of the default kernel (variants 5 / 6 write s_memrealtime stamps)
+  const int tl_variants[] = {5, 6, 17, 18, 20, 19, 21, 22, 24, 29};
+  const char *tl_names[] = {"full", "MFMA only", "no wf loads", "no ds_reads", "no DMA in loop", "no wf, no ds_reads", "no wf, no DMA", "no ds_reads, no DMA", "ds_reads to dummy regs", "ds_reads to dummy, no wf, no DMA"};
+  for (int vi = 0; vi < 10; ++vi) {
+    const int variant = tl_variants[vi];
+    const int n_wg = (rows / 128) * (cout_pad / 256);
+    unsigned long long *dbg; CK(hipMalloc(&dbg, (size_t)n_wg * (64 + 1024))); CK(hipMemset(dbg, 0, (size_t)n_wg * (64 + 1024)));
+    p.partial = reinterpret_cast<float *>(dbg);
+    if (getenv("ABLATE_HOT")) for (int i = 0; i < atoi(getenv("ABLATE_HOT")); ++i) launch_tdnn_big3_variant(p, 0, 0);   // sustained load first
+    for (int i = 0; i < 3; ++i) if (launch_tdnn_big3_variant(p, variant, 0)) { printf("launch failed: %s\n", asv_last_error()); return 1; }
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> h((size_t)n_wg * 8);
+    CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (int w = 0; w < n_wg; ++w) { if (h[w * 8] < t0) t0 = h[w * 8]; if (h[w * 8 + 3] > t1) t1 = h[w * 8 + 3]; }
+    printf("timeline (%s): %d workgroups, first start -> last end %.2f us (100 MHz ticks)\n", tl_names[vi], n_wg, (t1 - t0) * 0.01);
+    {
+      double cyc = 0, us = 0;
+      for (int w = 0; w < n_wg; ++w) { cyc += (double)(h[w * 8 + 6] - h[w * 8 + 5]); us += (h[w * 8 + 2] - h[w * 8 + 1]) * 0.01; }
+      printf("  shader clock inside the main loops: %.2f GHz (s_memtime ticks / s_memrealtime)\n", cyc / us * 1e-3);
+    }
+    double sp = 0, sl = 0, se = 0, sl2 = 0; int late = 0;
+    for (int w = 0; w < n_wg; ++w) {
+      sp += (h[w * 8 + 1] - h[w * 8]) * 0.01; se += (h[w * 8 + 3] - h[w * 8 + 2]) * 0.01;
+      if ((h[w * 8] - t0) * 0.01 > 5.0) { ++late; sl2 += (h[w * 8 + 2] - h[w * 8 + 1]) * 0.01; } else sl += (h[w * 8 + 2] - h[w * 8 + 1]) * 0.01;
+    }
+    printf("  mean per workgroup: prologue %.2f us, epilogue %.2f us; main loop %.2f us in the first wave of %d workgroups, %.2f us in the %d later ones\n", sp / n_wg, se / n_wg, sl / (n_wg - late), n_wg - late, late ? sl2 / late : 0.0, late);
+    FILE *f = variant > 6 ? nullptr : fopen(variant == 5 ? "gpurun_out/timeline_full.csv" : "gpurun_out/timeline_mfma.csv", "w");
+    if (f) {
+      fprintf(f, "wg,start_us,prologue_end_us,loop_end_us,end_us,xcc_id,hw_id\n");
+      for (int w = 0; w < n_wg; ++w)
+        fprintf(f, "%d,%.2f,%.2f,%.2f,%.2f,%u,%u\n", w, (h[w * 8] - t0) * 0.01, (h[w * 8 + 1] - t0) * 0.01, (h[w * 8 + 2] - t0) * 0.01, (h[w * 8 + 3] - t0) * 0.01,
+                (unsigned)(h[w * 8 + 4] >> 32), (unsigned)(h[w * 8 + 4] & 0xffffffffu));
+      fclose(f);
+    }
+    if (variant == 5) {
+      // shader-clock stamps of wave 0 after every k-group of the first 32 steps: mean cycles per group by position
+      std::vector<unsigned long long> g((size_t)n_wg * 128);
+      CK(hipMemcpy(g.data(), dbg + (size_t)n_wg * 8, g.size() * 8, hipMemcpyDeviceToHost));
+      const int nst = std::min(32, ntaps * ((cin + 63) / 64));
+      for (int pass = 0; pass < 2; ++pass) {
+        printf("  cycles per k-group, wave 0, %s workgroups:", pass == 0 ? "first-wave" : "later");
+        for (int k = 1; k < nst * 4; ++k) {
+          double m = 0; int n = 0;
+          for (int w = 0; w < n_wg; ++w) {
+            const bool late = (h[w * 8] - t0) * 0.01 > 5.0;
+            if (late != (pass == 1)) continue;
+            m += (double)(g[(size_t)w * 128 + k] - g[(size_t)w * 128 + k - 1]); ++n;
+          }
+          if (k % 4 == 0) printf(" |");
+          printf(" %.0f", n ? m / n : 0.0);
+        }
+        printf("\n");
+      }
+    }
+    CK(hipFree(dbg));
   }
   return 0;
 }
