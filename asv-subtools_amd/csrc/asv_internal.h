@@ -67,7 +67,9 @@ struct TdnnKernelParams {
   float *pool_partial;  // [rows/128 half-tiles][pool_slots][2 (sum u, sum u^2)][ld_partial]
   int pool_slots;
   const void *zero16;   // >= 16 bytes of device zeros: source of masked direct-to-LDS loads
-  const void *wfrag;    // bf16 weights in MFMA-fragment order [n_frag32][tap][chunk64][k_group][lane][8] or nullptr
+  const void *wfrag;    // bf16 weights in MFMA-fragment order [n_frag32][tap][chunk64][k_group][lane][8] or nullptr;
+                        // pooled-domain layers (kernels_utts.hip): the bf16 'hi' halves of the f32 weights, [cout_pad][cin_pad]
+  const void *wlo;      // pooled-domain layers: the bf16 'lo' halves (w - hi), same layout, or nullptr
   // split-K (small-M layers: the pooled domain): blockIdx.y walks `ksplit` slices of the channel
   // chunks, raw f32 accumulators go to partial[slice][rows][ld_partial]; a second kernel sums
   // the slices in order and applies the epilogue (deterministic, no atomics)
@@ -80,6 +82,7 @@ struct TdnnKernelParams {
   int n_taps;
   int taps[ASV_MAX_TAPS];
   int act1, act2, affine_first;
+  int tune;             // experiment knobs of the variant-3 kernel (tools/gemm_ablate): priorities / start stagger
   int big_one_per_cu;   // variant-3 kernel: 256x256 tiles, one workgroup per CU (default: 128x256, two per CU)
   int halo;             // max |tap offset| of this layer (selects the window size of the 128x128 kernel)
 };
@@ -98,6 +101,7 @@ struct PoolKernelParams {
 // launchers (kernels_*.hip).  ElemBF16: activations are bf16 (else f32).
 int launch_tdnn_mfma(const TdnnKernelParams &p, bool bf16, bool out_f32, hipStream_t s);
 int launch_tdnn_ref(const TdnnKernelParams &p, bool bf16, bool out_f32, hipStream_t s);
+int launch_utts_gemm(const TdnnKernelParams &p, int rows_valid, bool split, hipStream_t s);
 int launch_splitk_epilogue(const TdnnKernelParams &p, bool bf16, bool out_f32, hipStream_t s);
 // 256x256-tile bf16 kernel with direct-to-LDS staging (kernels_tdnn_v2.hip); needs weights
 // padded to kBigTileN rows and a plain epilogue (no second input / per-segment terms / residual)

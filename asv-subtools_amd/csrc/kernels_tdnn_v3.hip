@@ -116,6 +116,15 @@ __global__ __launch_bounds__(256 * WM, 2) void tdnn_gemm_big3_kernel(const TdnnK
   const int nchunks = (p.cin_pad + BK - 1) / BK;
   const int n_taps = p.n_taps;
   STAMP3(0);
+  if (p.tune) {
+    // which of the (up to) two co-resident workgroups of this CU am I: the first one gets LDS base 0
+    const int second = (__builtin_amdgcn_s_getreg(14342) != 0);
+    const int prio = (p.tune >> (second ? 2 : 0)) & 3;
+    if (prio == 1) __builtin_amdgcn_s_setprio(1);
+    if (prio == 2) __builtin_amdgcn_s_setprio(2);
+    if (prio == 3) __builtin_amdgcn_s_setprio(3);
+    if (second) for (int k = 0; k < ((p.tune >> 8) & 0xff); ++k) __builtin_amdgcn_s_sleep(127);   // ~127*64 cycles each
+  }
 
   // Per-channel epilogue constants go to LDS now: fetching them from L2 inside the epilogue put a chain of
   // dependent ~1 us loads behind every tile (the accumulators leave no registers to prefetch them into).
@@ -195,15 +204,6 @@ __global__ __launch_bounds__(256 * WM, 2) void tdnn_gemm_big3_kernel(const TdnnK
     for (int i = i0; i < i0 + 2; ++i)
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[kg][j]), __builtin_bit_cast(bf16x8_t, f.x[i]), acc[i][j], 0, 0, 0);
   };
-  auto mma = [&](const XFrags &f, int kg) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        // A operand = weights (rows = channels), B operand = frames (cols = frames)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[kg][j]), __builtin_bit_cast(bf16x8_t, f.x[i]), acc[i][j], 0, 0, 0);
-  };
-
   // ---- prologue: three windows in flight, weight fragments of step 0.  Only window 0 and the fragments are
   // waited for: VMEM retires in order, so vmcnt(2 * PIECES) leaves exactly windows 1 and 2 outstanding.
   issue_A(0, 0);

@@ -51,6 +51,13 @@ void pack_tdnn_weight(const float *w, int out_ch, int in_ch, int tot_ctx, int le
     }
 }
 
+static float bf16_to_f32_host(uint16_t h) {
+  const uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
 size_t tdnn_weight_frag_elems(int cout_pad, int cin_pad, int n_taps) {
   return (size_t)cout_pad * n_taps * round_up(cin_pad, 64);
 }
@@ -103,7 +110,8 @@ struct Op {
   asv_im2col_desc_t i2c;
   // device parameters
   void *w = nullptr;
-  void *wfrag = nullptr;         // fragment-ordered copy for the variant-3 kernel (bf16 frame layers)
+  void *wfrag = nullptr;         // fragment-ordered copy for the variant-3 kernel (bf16 frame layers); pooled layers: bf16 hi halves
+  void *wlo = nullptr;           // pooled layers in bf16 precision mode: bf16 lo halves (kernels_utts.hip)
   float *bias = nullptr, *scale = nullptr, *shift = nullptr;
   int cin_pad = 0, cout_pad = 0, cout_store = 0;
   bool utts = false;             // op runs in the utts domain (always f32)
@@ -433,6 +441,25 @@ int asv_net_add_tdnn(asv_net_t *net, const asv_tdnn_desc_t *d) {
       std::vector<uint16_t> frags(tdnn_weight_frag_elems(op.cout_pad, op.cin_pad, d->n_taps));
       pack_tdnn_weight_frags(d->weight, d->out_ch, d->in_ch, d->w_tot_context, d->w_left_context, d->taps, d->n_taps, op.cout_pad, op.cin_pad, frags.data());
       if ((rc = dev_upload(net, frags.data(), frags.size() * 2, &op.wfrag))) return rc;
+    }
+    if (op.utts && net->frames_bf16()) {
+      // pooled-domain layers keep f32 activations; their GEMM runs on the bf16 matrix cores with every
+      // operand split into two bf16 halves, the weight halves in the fragment order kernels_utts.hip walks:
+      // [32-channel fragment][32-k step][j][lane = (k half lh, channel lr)][8], k = 32 * step + 16 * lh + 8 * j + e
+      const float *wf = reinterpret_cast<const float *>(packed.data());
+      const int ksteps = (op.cin_pad + 31) / 32;
+      const size_t nfrag = (size_t)(op.cout_pad / 32) * ksteps * 1024;
+      std::vector<uint16_t> hi(nfrag, 0), lo(nfrag, 0);
+      for (int co = 0; co < d->out_ch; ++co)
+        for (int ci = 0; ci < d->in_ch; ++ci) {
+          const float v = wf[(size_t)co * op.cin_pad + ci];
+          const int r = ci % 32;
+          const size_t idx = (((size_t)(co / 32) * ksteps + ci / 32) * 2 + (r % 16) / 8) * 512 + (size_t)((r / 16) * 32 + co % 32) * 8 + r % 8;
+          hi[idx] = f32_to_bf16_host(v);
+          lo[idx] = f32_to_bf16_host(v - bf16_to_f32_host(hi[idx]));
+        }
+      if ((rc = dev_upload(net, hi.data(), nfrag * 2, &op.wfrag))) return rc;
+      if ((rc = dev_upload(net, lo.data(), nfrag * 2, &op.wlo))) return rc;
     }
   }
   if ((rc = upload_padded(net, d->bias, d->out_ch, op.cout_pad, 0.0f, &op.bias))) return rc;
@@ -817,7 +844,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         for (int t = 0; t < d.n_taps; ++t) { p.taps[t] = d.taps[t]; p.halo = std::max(p.halo, std::abs(d.taps[t])); }
         p.act1 = d.act1; p.act2 = d.act2; p.affine_first = d.affine_first;
         p.zero16 = net->zero_page;
-        p.wfrag = op.wfrag;
+        p.wfrag = op.wfrag; p.wlo = op.wlo;
         const bool narrow = p.halo <= kHalo;
         // fused statistics pooling: needs few enough segments per 128-row half-tile (i.e. no tiny utterances)
         int pool_slots = 0;
@@ -832,7 +859,8 @@ int run_ops(RunCtx &c, size_t n_ops) {
         }
         const bool big3 = !use_ref && narrow && (net->flags & (ASV_FLAG_SMALL_TILES | ASV_FLAG_BIG_V2)) == 0 && tdnn_big3_supported(p, bf16, !bf16);
         const bool big = !use_ref && narrow && !big3 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && tdnn_big_supported(p, bf16, !bf16);
-        if (!use_ref && !big && !big3 && op.utts) {
+        const bool utts_kernel = !use_ref && op.utts;
+        if (!use_ref && !big && !big3 && op.utts && !utts_kernel) {
           // pooled-domain layers have one row per utterance (M is tiny, K is large): slice K over more
           // workgroups.  The slice count depends on K only, never on the batch, so an utterance's
           // embedding is bit-identical whatever batch it is extracted in.
@@ -860,6 +888,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
           p.pool_partial = reinterpret_cast<float *>(net->poolpart_dev.ptr);
         }
         if (use_ref) rc = launch_tdnn_ref(p, bf16, !bf16, c.s);
+        else if (utts_kernel) rc = launch_utts_gemm(p, bp.segments, net->frames_bf16(), c.s);
         else if (big3) rc = launch_tdnn_big3(p, c.s);
         else if (big) rc = launch_tdnn_big(p, c.s);
         else {

@@ -47,6 +47,7 @@ int main(int argc, char **argv) {
   const int tapsets[5][5] = {{0}, {-1, 1}, {-2, 0, 2}, {-3, -1, 1, 3}, {-2, -1, 0, 1, 2}};
   for (int t = 0; t < ntaps; ++t) p.taps[t] = tapsets[ntaps - 1][t];
   p.act1 = ASV_ACT_RELU;
+  p.tune = getenv("ABLATE_TUNE") ? (int)strtol(getenv("ABLATE_TUNE"), nullptr, 0) : 0;
   const double flops = 2.0 * rows * cin * cout * ntaps;
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   printf("rows=%d cin=%d cout=%d taps=%d xpad=%d  (%.1f GFLOP)\n", rows, cin, cout, ntaps, xpad, flops / 1e9);
