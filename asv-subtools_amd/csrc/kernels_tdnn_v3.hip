@@ -78,7 +78,7 @@ __device__ __forceinline__ void glds16_s(const void *sbase, uint32_t voff, uint3
       : "memory");
 }
 
-// ABL: 0 full, 2 MFMA only (no loads of any kind in the loop), 4 no epilogue stores,
+// ABL: 0 full, 1 full + short loop for a partial last chunk (cin % 64 != 0), 2 MFMA only (no loads of any kind in the loop), 4 no epilogue stores,
 //      5 full + per-workgroup phase timestamps into p.partial, 6 MFMA only + timestamps
 #define STAMP3(k)                                                                                                   \
   if constexpr (ABL >= 5) {                                                                                         \
@@ -228,7 +228,11 @@ __global__ __launch_bounds__(256 * WM, 2) void tdnn_gemm_big3_kernel(const TdnnK
   int s = 0;
   XFrags x0, x1;
   load_x(lds, d_first, 0, x0);                               // the only LDS latency nothing hides
-  for (int c = 0; c < nchunks; ++c) {
+  // chunks of 64 input channels; a last chunk with only 16 / 32 / 48 of them (cin = 80: the fbank input layer)
+  // runs 1 / 2 / 3 k-groups per tap in the short loop behind this one instead of 4 mostly-zero ones
+  const int tail_groups = (ABL == 1) ? ((p.cin_pad % BK) / 16) : 0;    // ABL 1 = the instantiation with the short tail loop
+  const int nfull = tail_groups ? nchunks - 1 : nchunks;
+  for (int c = 0; c < nfull; ++c) {
     const unsigned char *Ab = lds + (c % N_STAGES) * A_STAGE;
     for (int t = 0; t < n_taps; ++t, ++s) {
       // Fragments of the NEXT step are fetched unconditionally (the last step re-reads its own: valid memory,
@@ -285,6 +289,37 @@ __global__ __launch_bounds__(256 * WM, 2) void tdnn_gemm_big3_kernel(const TdnnK
         dn = d_first;
       }
       group((NO_X || X_DUMMY) ? x0 : x1, 3, x0, An, dn, 0);
+    }
+  }
+  if (ABL == 1 && tail_groups) {
+    // x0 and wf[0] already hold (tail chunk, tap 0, k-group 0) - prefetched by the last full step, or by the
+    // prologue when the layer has no full chunk; the rest alternates between the two register sets
+    const int c = nfull;
+    const unsigned char *Ab = lds + (c % N_STAGES) * A_STAGE;
+    const int n_it = n_taps * tail_groups;
+    // two iterations per trip, straight-line: every MFMA is unconditional (an accumulator touched inside a branch
+    // costs the register allocator copies of all 128 of them); an iteration that does not exist gets zero weights
+    auto prefetch = [&](int i, XFrags &xn, uint4 &w0, uint4 &w1) {
+      const bool live = i < n_it;
+      const int ii = live ? i : n_it - 1;
+      const int t2 = ii / tail_groups, kg2 = ii - t2 * tail_groups;
+      load_x(Ab, __builtin_amdgcn_readlane(v_taps, t2), kg2, xn);
+      const size_t woff = ((size_t)t2 * nchunks + c) * 4096 + (size_t)kg2 * 1024;
+      w0 = *reinterpret_cast<const uint4 *>(wf_base0 + woff);
+      w1 = *reinterpret_cast<const uint4 *>(wf_base1 + woff);
+      if (!live) { w0 = make_uint4(0, 0, 0, 0); w1 = make_uint4(0, 0, 0, 0); }
+    };
+    for (int it = 0; it < n_it; it += 2) {
+      prefetch(it + 1, x1, wf[1][0], wf[1][1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mma2(x0, 0, q >> 1, (q & 1) * 2);
+      __builtin_amdgcn_sched_barrier(0);
+      prefetch(it + 2, x0, wf[0][0], wf[0][1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mma2(x1, 1, q >> 1, (q & 1) * 2);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -460,7 +495,8 @@ int launch_tdnn_big3_variant(const TdnnKernelParams &p, int variant, hipStream_t
       case 29: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<29, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles); break;
       case 22: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<22, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles); break;
       default:
-        if (fast) hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles);
+        if (fast && p.cin_pad % BK != 0) hipLaunchKernelGGL((tdnn_gemm_big3_kernel<1, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles);
+        else if (fast) hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles);
         else hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, true, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles);
     }
   } else {
