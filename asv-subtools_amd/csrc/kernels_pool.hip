@@ -46,9 +46,19 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float *feats, int
   for (int i = 0; i < VEC; ++i) v[i] = 0.0f;
   if (seg >= 0) {
     const float *src = feats + (size_t)(seg_src0[seg] + (row - seg_row0[seg])) * feat_dim;
+    if ((feat_dim & 3) == 0) {
+      // Kaldi matrices with a feature dimension that is a multiple of 4 (80, 40, 64 ...): whole 16-byte pieces
 #pragma unroll
-    for (int i = 0; i < VEC; ++i)
-      if (ch0 + i < feat_dim) v[i] = src[ch0 + i];
+      for (int q = 0; q < VEC / 4; ++q)
+        if (ch0 + 4 * q < feat_dim) {
+          const float4 t = *reinterpret_cast<const float4 *>(src + ch0 + 4 * q);
+          v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i)
+        if (ch0 + i < feat_dim) v[i] = src[ch0 + i];
+    }
   }
   if constexpr (BF16) {
     uint4 o;
