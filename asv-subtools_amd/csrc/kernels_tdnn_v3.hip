@@ -378,16 +378,37 @@ __global__ __launch_bounds__(256 * WM, 2) void tdnn_gemm_big3_kernel(const TdnnK
       // rowseg_lo/hi hold row_seg of the wave's 128 rows (lane l: rows l and 64 + l), so the per-row
       // segment id is a v_readlane with a constant lane: no memory access in the loop.
       const int rs_vec = (i < 2) ? rowseg_lo : rowseg_hi;
-#pragma unroll
-      for (int r = 0; r < 32; ++r) {
-        const int sg = __builtin_amdgcn_readlane(rs_vec, (i & 1) * 32 + r);          // wave-uniform
-        if (sg >= 0 && sg != cur_seg) {
+      // 84 % of the 32-frame fragments of a 200-frame batch lie inside one utterance (gap rows carry zeros and
+      // belong to nobody): those are summed branch-free; only a fragment that straddles two utterances walks
+      // its rows one by one
+      const unsigned long long in_frag = 0xffffffffull << ((i & 1) * 32);
+      const unsigned long long m_valid = __builtin_amdgcn_ballot_w64(rs_vec >= 0) & in_frag;
+      if (m_valid == 0) continue;                                                  // gap rows only
+      const int sg0 = __builtin_amdgcn_readlane(rs_vec, __builtin_ctzll(m_valid));
+      const unsigned long long m_same = __builtin_amdgcn_ballot_w64(rs_vec == sg0) & in_frag;
+      if (m_same == m_valid) {
+        if (sg0 != cur_seg) {
           if (cur_seg >= 0) flush();
-          cur_seg = sg; ps = 0.0f; pq = 0.0f;
+          cur_seg = sg0; ps = 0.0f; pq = 0.0f;
         }
-        const float v = scrf[r * SPITCH + lane];
-        ps += v;
-        pq = fmaf(v, v, pq);
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+          const float v = scrf[r * SPITCH + lane];
+          ps += v;
+          pq = fmaf(v, v, pq);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+          const int sg = __builtin_amdgcn_readlane(rs_vec, (i & 1) * 32 + r);          // wave-uniform
+          if (sg >= 0 && sg != cur_seg) {
+            if (cur_seg >= 0) flush();
+            cur_seg = sg; ps = 0.0f; pq = 0.0f;
+          }
+          const float v = scrf[r * SPITCH + lane];
+          ps += v;
+          pq = fmaf(v, v, pq);
+        }
       }
     }
     if (cur_seg >= 0) flush();
