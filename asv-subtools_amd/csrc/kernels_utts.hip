@@ -19,7 +19,7 @@
 namespace asv {
 namespace {
 
-constexpr int UW = 8;                 // waves per workgroup = K slices
+constexpr int UW = 8;                 // waves per workgroup = K slices (16 waves measured 16 us vs 11 us)
 
 // One iteration covers 32 consecutive k.  A wave fetches its [32 rows][32 k] f32 tile with four fully coalesced
 // loads (8 lanes = one 128-byte line of a row; reading "lane = row" straight from global costs 64 line
@@ -32,8 +32,10 @@ constexpr int TP = 36;                // floats per row of the transposition til
 
 template <bool SPLIT>
 __global__ __launch_bounds__(UW * 64) void utts_gemm_kernel(const TdnnKernelParams p, int m_tiles) {
-  __shared__ float red[UW][16][64];
-  __shared__ __attribute__((aligned(16))) float turn[UW][(SPLIT ? 1 : 2) * 32 * TP];
+  // transposition tiles during the K loop, the partial accumulators after it (behind a barrier)
+  constexpr int TURN_FLOATS = (SPLIT ? 1 : 2) * 32 * TP;
+  static_assert(TURN_FLOATS >= 16 * 64, "the reduction buffer reuses the transposition tiles");
+  __shared__ __attribute__((aligned(16))) float turn[UW][TURN_FLOATS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
@@ -89,23 +91,24 @@ __global__ __launch_bounds__(UW * 64) void utts_gemm_kernel(const TdnnKernelPara
       const size_t frag = (size_t)(n0 / 32) * ksteps;              // 1024 bf16 (hi) per (fragment, step)
       const uint16_t *whi = reinterpret_cast<const uint16_t *>(p.wfrag) + frag * 1024 + lane * 8;
       const uint16_t *wlo = reinterpret_cast<const uint16_t *>(p.wlo) + frag * 1024 + lane * 8;
-      uint4 wh[2], wl[2];
-      auto fetch_w = [&](int st) {
+      struct WFr { uint4 h[2], l[2]; };
+      auto fetch_w = [&](int st, WFr &w) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          wh[j] = *reinterpret_cast<const uint4 *>(whi + (size_t)st * 1024 + j * 512);
-          wl[j] = *reinterpret_cast<const uint4 *>(wlo + (size_t)st * 1024 + j * 512);
+          w.h[j] = *reinterpret_cast<const uint4 *>(whi + (size_t)st * 1024 + j * 512);
+          w.l[j] = *reinterpret_cast<const uint4 *>(wlo + (size_t)st * 1024 + j * 512);
         }
       };
-      fetch_w(s_begin);
-      for (int st = s_begin; st < s_end; ++st) {
+      // two steps in flight per wave (the operands come from L2 / HBM with ~1-2 us latency and a step is short):
+      // a step consumes its register set, then re-fetches it for the step two ahead; steps past the end re-fetch
+      // the last one (no branch, never used)
+      auto step = [&](Raw &xq, WFr &wq, int refetch) {
         float xv[16];
-        if (!(p.tune & 8)) turn16(xr, tx, xv);
-        else { for (int q = 0; q < 4; ++q) { xv[4 * q] = xr.v[q].x; xv[4 * q + 1] = xr.v[q].y; xv[4 * q + 2] = xr.v[q].z; xv[4 * q + 3] = xr.v[q].w; } }
-        const uint4 ch0 = wh[0], ch1 = wh[1], cl0 = wl[0], cl1 = wl[1];
-        const int nx = min(st + 1, s_end - 1);                     // the last step re-fetches itself: no branch, never used
-        if (!(p.tune & 1)) fetch(xg, x2g, p.ldx, p.ldx2, nx * 32, xr);
-        if (!(p.tune & 2)) fetch_w(nx);
+        turn16(xq, tx, xv);
+        const WFr wc = wq;
+        const int nx = min(refetch, s_end - 1);
+        fetch(xg, x2g, p.ldx, p.ldx2, nx * 32, xq);
+        fetch_w(nx, wq);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           uint32_t xh[4], xl[4];
@@ -116,14 +119,20 @@ __global__ __launch_bounds__(UW * 64) void utts_gemm_kernel(const TdnnKernelPara
             xl[e] = pack_bf16x2(v0 - __uint_as_float(xh[e] << 16), v1 - __uint_as_float(xh[e] & 0xffff0000u));
           }
           const uint4 xhv = make_uint4(xh[0], xh[1], xh[2], xh[3]), xlv = make_uint4(xl[0], xl[1], xl[2], xl[3]);
-          const uint4 whj = j ? ch1 : ch0, wlj = j ? cl1 : cl0;
           // A operand = weights (rows = channels), B operand = utterances (columns); small terms first
-          if (!(p.tune & 4)) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wlj), __builtin_bit_cast(bf16x8_t, xhv), acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, whj), __builtin_bit_cast(bf16x8_t, xlv), acc, 0, 0, 0);
-          }
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, whj), __builtin_bit_cast(bf16x8_t, xhv), acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wc.l[j]), __builtin_bit_cast(bf16x8_t, xhv), acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wc.h[j]), __builtin_bit_cast(bf16x8_t, xlv), acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wc.h[j]), __builtin_bit_cast(bf16x8_t, xhv), acc, 0, 0, 0);
         }
+      };
+      Raw xr2;
+      WFr wa, wb;
+      fetch_w(s_begin, wa);
+      fetch(xg, x2g, p.ldx, p.ldx2, min(s_begin + 1, s_end - 1) * 32, xr2);
+      fetch_w(min(s_begin + 1, s_end - 1), wb);
+      for (int st = s_begin; st < s_end; st += 2) {
+        step(xr, wa, st + 2);
+        if (st + 1 < s_end) step(xr2, wb, st + 3);
       }
     } else {
       const float *wg = reinterpret_cast<const float *>(p.w) + (size_t)(n0 + crow) * p.cin_pad + ck;
@@ -142,16 +151,17 @@ __global__ __launch_bounds__(UW * 64) void utts_gemm_kernel(const TdnnKernelPara
       }
     }
   }
+  __syncthreads();                                    // every wave is done with its transposition tile
 #pragma unroll
-  for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+  for (int r = 0; r < 16; ++r) turn[wave][r * 64 + lane] = acc[r];
   __syncthreads();
   // acc[r] of lane (lh, lr): channel n0 + (r & 3) + 8 * (r >> 2) + 4 * lh, utterance m0 + lr
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
+  for (int it = 0; it < 1024 / (UW * 64); ++it) {
     const int idx = it * (UW * 64) + tid, r = idx >> 6, l = idx & 63;
     float s = 0.0f;
 #pragma unroll
-    for (int w = 0; w < UW; ++w) s += red[w][r][l];
+    for (int w = 0; w < UW; ++w) s += turn[w][r * 64 + l];
     const int ch = n0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), row = m0 + (l & 31);
     if (ch < p.cout_store) {
       const bool valid = (p.row_valid[row >> 5] >> (row & 31)) & 1u;
