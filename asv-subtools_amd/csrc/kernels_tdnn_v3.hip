@@ -33,17 +33,22 @@ static_assert(BN == kBigTileN, "weight padding must match the N tile");
 //   WM = 2: 256 x 256 tile, 8 waves, 135 KiB LDS, one workgroup per CU
 //   WM = 1: 128 x 256 tile, 4 waves,  71 KiB LDS, TWO workgroups per CU - the prologue (first window + weight
 //           fragments in flight) and the epilogue of one workgroup overlap with the main loop of the other
+//   WM = 0:  64 x 256 tile, 4 waves (wave tile 64 x 64 = 2 x 2 accumulators), 39 KiB LDS, <= 168 VGPRs: THREE
+//           workgroups per CU.  For layers whose tile count does not fill whole rounds of 512 workgroups: 816
+//           tiles of 128 rows are 2 rounds (1.59 used), 1632 tiles of 64 rows on 768 slots are 3 half-rounds.
 template <int WM> struct Geom3 {
-  static constexpr int BM = 128 * WM;
+  static constexpr int MF = WM == 0 ? 2 : 4;           // 32-frame accumulator fragments per wave
+  static constexpr int BM = WM == 0 ? 64 : 128 * WM;
   static constexpr int WIN = BM + 2 * kHalo;           // 264 | 136
   static constexpr int A_STAGE = WIN * ROWB;           // 33792 | 17408
   static constexpr int A_GROUPS = WIN / 8;             // 33 | 17 eight-row groups
-  static constexpr int WAVES = 4 * WM;
+  static constexpr int WAVES = WM == 0 ? 4 : 4 * WM;
+  static constexpr int SCRATCH = MF * 32 * ROWB;       // epilogue scratch per wave: [MF * 32 frames][64 channels] bf16
   static constexpr int PIECES = (A_GROUPS + WAVES - 1) / WAVES;   // LDS-DMA pieces per wave per window: 5
   static constexpr int RING_BYTES = N_STAGES * A_STAGE; // 4 window stages (135168 | 69632 B) >= epilogue scratch, 16 KiB per wave
   static constexpr int PARAM_OFF = RING_BYTES;         // bias | scale | shift of the tile's 256 channels (3 KiB)
   static constexpr int LDS_BYTES = RING_BYTES + 3 * 256 * 4;
-  static_assert(WAVES * 16384 <= RING_BYTES, "epilogue scratch must fit in the ring");
+  static_assert(WAVES * SCRATCH <= RING_BYTES, "epilogue scratch must fit in the ring");
 };
 
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
@@ -91,12 +96,13 @@ __device__ __forceinline__ void glds16_s(const void *sbase, uint32_t voff, uint3
     }                                                                                                               \
   }
 template <int ABL, bool GENERIC, bool POOL, int WM>
-__global__ __launch_bounds__(256 * WM, 2) void tdnn_gemm_big3_kernel(const TdnnKernelParams p, int m_tiles, int n_tiles) {
+__global__ __launch_bounds__(Geom3<WM>::WAVES * 64, WM == 0 ? 3 : 2) void tdnn_gemm_big3_kernel(const TdnnKernelParams p, int m_tiles, int n_tiles) {
   using G = Geom3<WM>;
   constexpr bool MFMA_ONLY = (ABL == 2 || ABL == 6);
   constexpr bool NO_WF = MFMA_ONLY || (ABL >= 16 && (ABL & 1)), NO_X = MFMA_ONLY || (ABL >= 16 && (ABL & 2)), NO_DMA = MFMA_ONLY || (ABL >= 16 && (ABL & 4));
   constexpr bool X_DUMMY = (ABL >= 16 && (ABL & 8));   // LDS reads issued but their data never feeds an MFMA
-  constexpr int BM = G::BM, A_STAGE = G::A_STAGE, A_GROUPS = G::A_GROUPS;
+  constexpr int BM = G::BM, A_STAGE = G::A_STAGE, A_GROUPS = G::A_GROUPS, MF = G::MF;
+  static_assert(!(POOL && WM == 0), "the fused pooling epilogue works on 128-row half tiles");
   __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -178,25 +184,25 @@ __global__ __launch_bounds__(256 * WM, 2) void tdnn_gemm_big3_kernel(const TdnnK
     wf[kg][1] = *reinterpret_cast<const uint4 *>(wf_base1 + off);
   };
 
-  f32x16_t acc[4][2];
+  f32x16_t acc[MF][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MF; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  struct XFrags { uint4 x[4]; };
+  struct XFrags { uint4 x[MF]; };
   auto load_x = [&](const unsigned char *Ab, int d, int kg, XFrags &f) {
     const int slot = kg * 2 + lh;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int w = wm * 128 + i * 32 + lr + kHalo + d;
+    for (int i = 0; i < MF; ++i) {
+      const int w = wm * (MF * 32) + i * 32 + lr + kHalo + d;
       f.x[i] = *reinterpret_cast<const uint4 *>(Ab + w * ROWB + swz(w, slot) * 16);
     }
   };
   auto load_x1 = [&](const unsigned char *Ab, int d, int kg, int i, XFrags &f) {
-    const int w = wm * 128 + i * 32 + lr + kHalo + d;
+    const int w = wm * (MF * 32) + i * 32 + lr + kHalo + d;
     f.x[i] = *reinterpret_cast<const uint4 *>(Ab + w * ROWB + swz(w, kg * 2 + lh) * 16);
   };
   auto mma2 = [&](const XFrags &f, int kg, int j, int i0) {
@@ -250,17 +256,17 @@ __global__ __launch_bounds__(256 * WM, 2) void tdnn_gemm_big3_kernel(const TdnnK
       // order (sched_group_barrier picks MFMAs in an order of its own and the first MFMA of the next group
       // then waits for the read issued last).
       XFrags xd;
-      auto sink = [&]() { if (X_DUMMY) asm volatile("" ::"v"(xd.x[0].x), "v"(xd.x[1].y), "v"(xd.x[2].z), "v"(xd.x[3].w)); };
+      auto sink = [&]() { if (X_DUMMY) asm volatile("" ::"v"(xd.x[0].x), "v"(xd.x[1].y), "v"(xd.x[MF - 2].z), "v"(xd.x[MF - 1].w)); };
       auto group = [&](const XFrags &xc, int kg, XFrags &xn, const unsigned char *An, int dn, int kgn) {
         const size_t woff = ((size_t)tn * nchunks + cn) * 4096 + (size_t)kg * 1024;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          // pair q: channel fragment j = q / 2 against frame fragments 2 * (q % 2) and + 1; a channel fragment is
-          // re-fetched (for the next step) as soon as its fourth MFMA has been issued
+        for (int q = 0; q < MF; ++q) {
+          // pair q: channel fragment j = q / (MF/2) against frame fragments 2 * (q % (MF/2)) and + 1; a channel
+          // fragment is re-fetched (for the next step) as soon as its last MFMA has been issued
           if (!NO_X) load_x1(An, dn, kgn, q, X_DUMMY ? xd : xn);
-          mma2(xc, kg, q >> 1, (q & 1) * 2);
-          if (!NO_WF && q == 1) wf[kg][0] = *reinterpret_cast<const uint4 *>(wf_base0 + woff);
-          if (!NO_WF && q == 3) wf[kg][1] = *reinterpret_cast<const uint4 *>(wf_base1 + woff);
+          mma2(xc, kg, q / (MF / 2), (q % (MF / 2)) * 2);
+          if (!NO_WF && q == MF / 2 - 1) wf[kg][0] = *reinterpret_cast<const uint4 *>(wf_base0 + woff);
+          if (!NO_WF && q == MF - 1) wf[kg][1] = *reinterpret_cast<const uint4 *>(wf_base1 + woff);
           __builtin_amdgcn_sched_barrier(0);
         }
         sink();
@@ -313,12 +319,12 @@ __global__ __launch_bounds__(256 * WM, 2) void tdnn_gemm_big3_kernel(const TdnnK
       prefetch(it + 1, x1, wf[1][0], wf[1][1]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) mma2(x0, 0, q >> 1, (q & 1) * 2);
+      for (int q = 0; q < MF; ++q) mma2(x0, 0, q / (MF / 2), (q % (MF / 2)) * 2);
       __builtin_amdgcn_sched_barrier(0);
       prefetch(it + 2, x0, wf[0][0], wf[0][1]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) mma2(x1, 1, q >> 1, (q & 1) * 2);
+      for (int q = 0; q < MF; ++q) mma2(x1, 1, q / (MF / 2), (q % (MF / 2)) * 2);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -416,11 +422,11 @@ __global__ __launch_bounds__(256 * WM, 2) void tdnn_gemm_big3_kernel(const TdnnK
   }
   // ---- epilogue --------------------------------------------------------------------------
   // acc[i][j][r]: frame = m0 + wm*128 + i*32 + lr, channel = n0 + wn*64 + j*32 + 8*(r>>2) + 4*lh + (r&3)
-  unsigned char *scr = lds + wave * 16384;       // [128 frames][64 channels] bf16, 128-B rows, swizzled slots
+  unsigned char *scr = lds + wave * G::SCRATCH;  // [MF * 32 frames][64 channels] bf16, 128-B rows, swizzled slots
   const float act_lo = (p.act1 == ASV_ACT_RELU) ? 0.0f : -INFINITY;
   uint32_t vmask = 0;                            // bit i: this lane's frame of m-fragment i is a real frame
 #pragma unroll
-  for (int i = 0; i < 4; ++i) vmask |= ((p.row_valid[(m0 + wm * 128 + i * 32) >> 5] >> lr) & 1u) << i;
+  for (int i = 0; i < MF; ++i) vmask |= ((p.row_valid[(m0 + wm * (MF * 32) + i * 32) >> 5] >> lr) & 1u) << i;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -432,7 +438,7 @@ __global__ __launch_bounds__(256 * WM, 2) void tdnn_gemm_big3_kernel(const TdnnK
       const float b[4] = {b4.x, b4.y, b4.z, b4.w}, sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
       const int slot = j * 4 + q;                // channel offset j*32 + 8*q + 4*lh -> 16-B slot, 8-B half lh
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < MF; ++i) {
         const bool valid = (vmask >> i) & 1u;
         const int frow = i * 32 + lr;            // row inside the wave's scratch tile
         float y[4];
@@ -460,12 +466,12 @@ __global__ __launch_bounds__(256 * WM, 2) void tdnn_gemm_big3_kernel(const TdnnK
     unsigned char *yg = reinterpret_cast<unsigned char *>(p.y);
     const size_t y_pitch = (size_t)p.ldy * 2;
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
+    for (int it = 0; it < MF * 4; ++it) {
       const int piece = it * 64 + lane, frow = piece >> 3, slot = piece & 7;
       uint4 v = *reinterpret_cast<const uint4 *>(scr + frow * ROWB + swz(frow, slot) * 16);
       if (frow & 1) v = make_uint4(v.z, v.w, v.x, v.y);
       const int ch = n0 + wn * 64 + slot * 8;
-      const int row = m0 + wm * 128 + frow;
+      const int row = m0 + wm * (MF * 32) + frow;
       if (ABL == 4) { asm volatile("" ::"v"(v.x), "v"(v.w)); continue; }
       if (ch < p.cout_store) *reinterpret_cast<uint4 *>(yg + (size_t)row * y_pitch + (size_t)ch * 2) = v;
     }
@@ -485,54 +491,83 @@ bool tdnn_big3_supported(const TdnnKernelParams &p, bool bf16, bool out_f32) {
   return p.wfrag != nullptr && tdnn_big_supported(q, bf16, out_f32);
 }
 
+// variant = geometry * 100 + ablation code; geometry 0: 128 x 256 tiles (two workgroups per CU), 1: 256 x 256 (one),
+// 2: 64 x 256 (three)
 int launch_tdnn_big3_variant(const TdnnKernelParams &p, int variant, hipStream_t s) {
   ASV_REQUIRE(p.rows % 256 == 0, "tdnn(big3): rows %d not a multiple of 256", p.rows);
   ASV_REQUIRE(p.wfrag != nullptr, "tdnn(big3): fragment-packed weights missing");
-  const bool two_per_cu = variant < 100;                 // variants >= 100: the 256x256 / one-workgroup-per-CU geometry
-  if (!two_per_cu) variant -= 100;
-  const int bm = two_per_cu ? 128 : 256;
+  const int geom = variant / 100;
+  variant %= 100;
+  const int bm = geom == 0 ? 128 : (geom == 1 ? 256 : 64);
   const int m_tiles = p.rows / bm, n_tiles = round_up(p.cout_store, BN) / BN;
-  const dim3 grid(m_tiles * n_tiles), block(two_per_cu ? 256 : 512);
+  const dim3 grid(m_tiles * n_tiles), block(geom == 1 ? 512 : 256);
   const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first;
   if (p.pool_partial != nullptr) {
-    ASV_REQUIRE(fast && p.row_seg != nullptr && p.pool_slots >= 1, "tdnn(big3): fused pooling needs the plain epilogue and a row map");
-    if (two_per_cu) hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, false, true, 1>), grid, block, 0, s, p, m_tiles, n_tiles);
+    ASV_REQUIRE(fast && p.row_seg != nullptr && p.pool_slots >= 1 && geom != 2, "tdnn(big3): fused pooling needs the plain epilogue, a row map and 128-row wave tiles");
+    if (geom == 0) hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, false, true, 1>), grid, block, 0, s, p, m_tiles, n_tiles);
     else hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, false, true, 2>), grid, block, 0, s, p, m_tiles, n_tiles);
     ASV_HIP_CHECK(hipGetLastError());
     return ASV_OK;
   }
-  if (two_per_cu) {
+#define ASV_BIG3(ABLV, GENV, WMV) hipLaunchKernelGGL((tdnn_gemm_big3_kernel<ABLV, GENV, false, WMV>), grid, block, 0, s, p, m_tiles, n_tiles)
+  const bool tail = fast && p.cin_pad % BK != 0;
+  if (geom == 0) {
     switch (variant) {
-      case 2: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<2, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles); break;
-      case 4: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<4, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles); break;
-      case 5: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<5, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles); break;
-      case 6: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<6, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles); break;
-      case 17: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<17, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles); break;
-      case 18: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<18, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles); break;
-      case 20: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<20, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles); break;
-      case 19: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<19, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles); break;
-      case 21: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<21, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles); break;
-      case 24: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<24, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles); break;
-      case 29: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<29, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles); break;
-      case 22: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<22, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles); break;
+      case 2: ASV_BIG3(2, false, 1); break;
+      case 4: ASV_BIG3(4, false, 1); break;
+      case 5: ASV_BIG3(5, false, 1); break;
+      case 6: ASV_BIG3(6, false, 1); break;
+      case 17: ASV_BIG3(17, false, 1); break;
+      case 18: ASV_BIG3(18, false, 1); break;
+      case 20: ASV_BIG3(20, false, 1); break;
+      case 19: ASV_BIG3(19, false, 1); break;
+      case 21: ASV_BIG3(21, false, 1); break;
+      case 24: ASV_BIG3(24, false, 1); break;
+      case 29: ASV_BIG3(29, false, 1); break;
+      case 22: ASV_BIG3(22, false, 1); break;
       default:
-        if (fast && p.cin_pad % BK != 0) hipLaunchKernelGGL((tdnn_gemm_big3_kernel<1, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles);
-        else if (fast) hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, false, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles);
-        else hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, true, false, 1>), grid, block, 0, s, p, m_tiles, n_tiles);
+        if (tail) ASV_BIG3(1, false, 1);
+        else if (fast) ASV_BIG3(0, false, 1);
+        else ASV_BIG3(0, true, 1);
+    }
+  } else if (geom == 1) {
+    switch (variant) {
+      case 2: ASV_BIG3(2, false, 2); break;
+      case 4: ASV_BIG3(4, false, 2); break;
+      default:
+        if (fast) ASV_BIG3(0, false, 2);
+        else ASV_BIG3(0, true, 2);
     }
   } else {
     switch (variant) {
-      case 2: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<2, false, false, 2>), grid, block, 0, s, p, m_tiles, n_tiles); break;
-      case 4: hipLaunchKernelGGL((tdnn_gemm_big3_kernel<4, false, false, 2>), grid, block, 0, s, p, m_tiles, n_tiles); break;
+      case 2: ASV_BIG3(2, false, 0); break;
+      case 5: ASV_BIG3(5, false, 0); break;
+      case 6: ASV_BIG3(6, false, 0); break;
       default:
-        if (fast) hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, false, false, 2>), grid, block, 0, s, p, m_tiles, n_tiles);
-        else hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, true, false, 2>), grid, block, 0, s, p, m_tiles, n_tiles);
+        if (tail) ASV_BIG3(1, false, 0);
+        else if (fast) ASV_BIG3(0, false, 0);
+        else ASV_BIG3(0, true, 0);
     }
   }
+#undef ASV_BIG3
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }
 
-int launch_tdnn_big3(const TdnnKernelParams &p, hipStream_t s) { return launch_tdnn_big3_variant(p, p.big_one_per_cu ? 100 : 0, s); }
+// Geometry choice.  64-row tiles (three workgroups per CU) fix the round quantisation on paper (816 tiles of 128 rows =
+// 2 rounds at 80 %, 1632 tiles of 64 rows = 3 half rounds) and their MFMA-only skeleton is 17 % faster, but every wave
+// then fetches its 8 KiB of weight fragments per step for 16 instead of 32 MFMAs: at three waves per SIMD that is
+// ~62 B/clk/CU from L2, the L1 fill limit, and the full kernel is 3 % slower on the C2 shapes (tools/gemm_ablate).
+// They win when the 128-row tiles cannot occupy the chip: measured 24.6 -> 17.5 us at 6656 rows x 512 channels,
+// break-even at 13056 rows.
+int tdnn_big3_pick_geometry(const TdnnKernelParams &p) {
+  if (p.big_one_per_cu) return 1;
+  if (p.pool_partial != nullptr) return 0;
+  const long long n_tiles = round_up(p.cout_store, BN) / BN;
+  const long long t128 = (long long)(p.rows / 128) * n_tiles;
+  return t128 <= 160 ? 2 : 0;
+}
+
+int launch_tdnn_big3(const TdnnKernelParams &p, hipStream_t s) { return launch_tdnn_big3_variant(p, tdnn_big3_pick_geometry(p) * 100, s); }
 
 }  // namespace asv

@@ -51,12 +51,12 @@ int main(int argc, char **argv) {
   const double flops = 2.0 * rows * cin * cout * ntaps;
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   printf("rows=%d cin=%d cout=%d taps=%d xpad=%d  (%.1f GFLOP)\n", rows, cin, cout, ntaps, xpad, flops / 1e9);
-  const char *names[] = {"big: full", "big: no LDS-DMA in loop", "big: MFMA + barrier only", "big: DMA + ds_read, no MFMA", "big: no epilogue stores", "big: DMA (cache-hot) + ds_read", "small 128x128 (v1)", "big: DMA + barrier only", "big: ds_read + barrier only", "big3 (2 WG/CU): full", "big3 (2 WG/CU): MFMA only", "big3 (2 WG/CU): no epilogue stores", "big3 (1 WG/CU): full", "big3 (1 WG/CU): MFMA only"};
-  for (int v = 9; v <= 13; ++v) {
+  const char *names[] = {"big: full", "big: no LDS-DMA in loop", "big: MFMA + barrier only", "big: DMA + ds_read, no MFMA", "big: no epilogue stores", "big: DMA (cache-hot) + ds_read", "small 128x128 (v1)", "big: DMA + barrier only", "big: ds_read + barrier only", "big3 (2 WG/CU): full", "big3 (2 WG/CU): MFMA only", "big3 (2 WG/CU): no epilogue stores", "big3 (1 WG/CU): full", "big3 (1 WG/CU): MFMA only", "big3 64-row (3 WG/CU): full", "big3 64-row (3 WG/CU): MFMA only"};
+  for (int v = 9; v <= 15; ++v) {
     for (int rep = 0; rep < 2; ++rep) {
       CK(hipEventRecord(a, 0));
       for (int i = 0; i < iters; ++i) {
-        int rc = v == 6 ? launch_tdnn_mfma(p, true, false, 0) : v == 9 ? launch_tdnn_big3_variant(p, 0, 0) : v == 10 ? launch_tdnn_big3_variant(p, 2, 0) : v == 11 ? launch_tdnn_big3_variant(p, 4, 0) : v == 12 ? launch_tdnn_big3_variant(p, 100, 0) : v == 13 ? launch_tdnn_big3_variant(p, 102, 0) : launch_tdnn_big_variant(p, v, 0);
+        int rc = v == 6 ? launch_tdnn_mfma(p, true, false, 0) : v == 9 ? launch_tdnn_big3_variant(p, 0, 0) : v == 10 ? launch_tdnn_big3_variant(p, 2, 0) : v == 11 ? launch_tdnn_big3_variant(p, 4, 0) : v == 12 ? launch_tdnn_big3_variant(p, 100, 0) : v == 13 ? launch_tdnn_big3_variant(p, 102, 0) : v == 14 ? launch_tdnn_big3_variant(p, 200, 0) : v == 15 ? launch_tdnn_big3_variant(p, 202, 0) : launch_tdnn_big_variant(p, v, 0);
         if (rc) { printf("launch failed: %s\n", asv_last_error()); return 1; }
       }
       CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));

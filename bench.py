@@ -88,15 +88,27 @@ def main():
     mats = [synth.synth_feats(T, D, 10_000 * rank + i) for i in range(B)]
     feats = torch.from_numpy(np.concatenate(mats, axis=0)).to(dev)
     offsets = (np.arange(B + 1) * T).astype(np.int32)
-    out = torch.empty((B, eng.embed_dim), dtype=torch.float32, device=dev)
-    gathered = torch.empty((world * B, eng.embed_dim), dtype=torch.float32, device=dev) if world > 1 else None
+    # two output / gather buffer pairs: the all-gather of step i runs on RCCL's stream while step i+1 computes
+    outs = [torch.empty((B, eng.embed_dim), dtype=torch.float32, device=dev) for _ in range(2)]
+    gathered = [torch.empty((world * B, eng.embed_dim), dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
+    pending = [None, None]
+    counter = [0]
 
     def step():
-        eng.extract_device(feats, offsets, out=out)
+        k = counter[0] & 1
+        counter[0] += 1
+        if pending[k] is not None:                                  # buffer pair k is free once its gather has finished
+            pending[k].wait()                                       # (stream-side wait, the host does not block)
+            pending[k] = None
+        eng.extract_device(feats, offsets, out=outs[k])
         if world > 1:
-            dist.all_gather_into_tensor(gathered, out)
+            pending[k] = dist.all_gather_into_tensor(gathered[k], outs[k], async_op=True)
 
     def barrier():
+        for k in range(2):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
