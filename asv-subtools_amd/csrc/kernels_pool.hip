@@ -305,24 +305,46 @@ __global__ __launch_bounds__(256) void eltwise_kernel(const EltwiseKernelParams 
   }
   if (valid) {
     load_vec<BF16, VEC>(p.a, (size_t)row * p.lda + ch, o);
-    if (p.scale != nullptr) {
+    // per-channel / per-segment f32 tables: 16-byte loads when the whole piece is inside the channel range (all
+    // table pitches and channel offsets are multiples of 4 floats), element-wise only for the ragged last piece
+    const bool whole = ch + VEC <= p.channels;
+    auto table = [&](const float *t, float (&v)[VEC]) {
+      if (whole) {
 #pragma unroll
-      for (int i = 0; i < VEC; ++i)
-        if (ch + i < p.channels) o[i] = o[i] * p.scale[ch + i] + p.shift[ch + i];
+        for (int q = 0; q < VEC / 4; ++q) {
+          const float4 f = *reinterpret_cast<const float4 *>(t + ch + 4 * q);
+          v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v[i] = (ch + i < p.channels) ? t[ch + i] : 0.0f;
+      }
+    };
+    if (p.scale != nullptr) {
+      float sc[VEC], sh[VEC];
+      table(p.scale, sc); table(p.shift, sh);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) o[i] = o[i] * sc[i] + sh[i];
     }
     if (p.seg_norm != nullptr) {
       const float *st = p.seg_norm + (size_t)seg * p.ld_segnorm;
+      if (p.seg_norm_mode & 1) {
+        float m[VEC];
+        table(st, m);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i)
-        if (ch + i < p.channels) {
-          if (p.seg_norm_mode & 1) o[i] -= st[ch + i];
-          if (p.seg_norm_mode & 2) o[i] /= st[p.channels + ch + i];
-        }
+        for (int i = 0; i < VEC; ++i) o[i] -= m[i];
+      }
+      if (p.seg_norm_mode & 2) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i)
+          if (ch + i < p.channels) o[i] /= st[p.channels + ch + i];
+      }
     }
     if (p.seg_scale != nullptr) {
+      float ss[VEC];
+      table(p.seg_scale + (size_t)seg * p.ld_segscale, ss);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i)
-        if (ch + i < p.channels) o[i] *= p.seg_scale[(size_t)seg * p.ld_segscale + ch + i];
+      for (int i = 0; i < VEC; ++i) o[i] *= ss[i];
     }
     if (p.b != nullptr) {
       float t[VEC];

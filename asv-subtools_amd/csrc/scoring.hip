@@ -211,6 +211,134 @@ float key_to_score(unsigned long long k) {
 
 using namespace asv;
 
+// ---------------------------------------------------------------------------------------
+// Score normalisation (S-norm / AS-norm, reference score/ScoreNormalization.py:70-179: a pandas sort + groupby +
+// per-trial Python loop).  Here: one workgroup per enrol / test vector selects its top_n cohort scores with a
+// 4-pass radix select over order-preserving keys (no sort), then mean and sample standard deviation (ddof = 1) in
+// float64 like pandas; trials are one thread each, or one wave each for cross-select (statistics per trial).
+namespace {
+
+__device__ __forceinline__ uint32_t score_key(float x) {
+  const uint32_t u = __float_as_uint(x);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);            // larger score <=> larger key
+}
+__device__ __forceinline__ float key_score(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+__device__ __forceinline__ double block_sum256(double v, double *sh) {   // sh: 4 doubles; all 256 threads get the total
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void cohort_topn_kernel(const float *S, int C, int n_sel, double *mean, double *sdev, int32_t *top_idx) {
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t sh_digit, sh_above, sh_cnt;
+  __shared__ uint32_t wave_tot[4];
+  __shared__ double sh[4];
+  const int tid = threadIdx.x, row = blockIdx.x;
+  const float *r = S + (size_t)row * C;
+  uint32_t thr = 0, need_eq = 0;                                  // n_sel == C: every key is > 0 (no NaN scores)
+  if (n_sel < C) {
+    uint32_t prefix = 0, mask = 0, remaining = (uint32_t)n_sel;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      hist[tid] = 0;
+      __syncthreads();
+      for (int c = tid; c < C; c += 256) {
+        const uint32_t k = score_key(r[c]);
+        if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        uint32_t above = 0;
+        int d = 255;
+        while (d > 0 && above + hist[d] < remaining) { above += hist[d]; --d; }
+        sh_digit = (uint32_t)d; sh_above = above;
+      }
+      __syncthreads();
+      prefix |= sh_digit << shift;
+      mask |= 255u << shift;
+      remaining -= sh_above;
+      __syncthreads();
+    }
+    thr = prefix;                                                 // key of the n_sel-th largest score
+    need_eq = remaining;                                          // how many scores equal to it are inside the top
+  }
+  const double thr_v = need_eq ? (double)key_score(thr) : 0.0;     // nothing taken at the threshold: the term is void
+  double acc = 0.0;
+  for (int c = tid; c < C; c += 256) { const float x = r[c]; if (score_key(x) > thr) acc += (double)x; }
+  const double mu = (block_sum256(acc, sh) + (double)need_eq * thr_v) / (double)n_sel;
+  acc = 0.0;
+  for (int c = tid; c < C; c += 256) { const float x = r[c]; if (score_key(x) > thr) { const double d = (double)x - mu; acc += d * d; } }
+  const double ss = block_sum256(acc, sh) + (double)need_eq * (thr_v - mu) * (thr_v - mu);
+  if (tid == 0) {
+    mean[row] = mu;
+    sdev[row] = sqrt(ss / (double)(n_sel - 1));                  // one selected score: 0/0 = NaN, like pandas
+  }
+  if (top_idx != nullptr) {
+    // cohort ids of the selection: the scores above the threshold in any order, then the first need_eq equal
+    // ones in cohort order (a stable descending sort would pick the same set)
+    int32_t *dst = top_idx + (size_t)row * n_sel;
+    const uint32_t n_gt = (uint32_t)n_sel - need_eq;
+    if (tid == 0) sh_cnt = 0;
+    __syncthreads();
+    uint32_t eq_base = 0;
+    for (int c0 = 0; c0 < C; c0 += 256) {
+      const int c = c0 + tid;
+      const uint32_t k = c < C ? score_key(r[c]) : 0u;
+      const bool gt = c < C && k > thr, eq = c < C && k == thr && n_sel < C;
+      if (gt) dst[atomicAdd(&sh_cnt, 1u)] = c;
+      const unsigned long long b = __builtin_amdgcn_ballot_w64(eq);
+      const uint32_t in_wave = (uint32_t)__builtin_popcountll(b & ((1ull << (tid & 63)) - 1ull));
+      if ((tid & 63) == 0) wave_tot[tid >> 6] = (uint32_t)__builtin_popcountll(b);
+      __syncthreads();
+      uint32_t before = eq_base;
+      for (int w = 0; w < (tid >> 6); ++w) before += wave_tot[w];
+      const uint32_t rank = before + in_wave;
+      if (eq && rank < need_eq) dst[n_gt + rank] = c;
+      eq_base += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void score_norm_trials_kernel(const float *scores, const int32_t *ei, const int32_t *ti, int n, const double *mu_e,
+                                                                const double *sd_e, const double *mu_t, const double *sd_t, float *out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double s = (double)scores[i];
+  const int e = ei[i], t = ti[i];
+  out[i] = (float)(0.5 * ((s - mu_e[e]) / sd_e[e] + (s - mu_t[t]) / sd_t[t]));
+}
+
+// cross-select: the enrol-side statistics of trial (e, t) run over e's scores against the cohort vectors that are
+// top_n for t, and vice versa (ScoreNormalization.py:139-148).  One wave per trial.
+__global__ __launch_bounds__(256) void score_norm_cross_kernel(const float *ec, const float *tc, int C, int n_sel, const int32_t *top_e, const int32_t *top_t,
+                                                               const float *scores, const int32_t *ei, const int32_t *ti, int n, float *out) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n) return;
+  const int e = ei[i], t = ti[i];
+  const float *er = ec + (size_t)e * C, *tr = tc + (size_t)t * C;
+  const int32_t *ie = top_e + (size_t)e * n_sel, *it = top_t + (size_t)t * n_sel;
+  double se = 0.0, st = 0.0;
+  for (int k = lane; k < n_sel; k += 64) { se += (double)er[it[k]]; st += (double)tr[ie[k]]; }
+  for (int o = 32; o > 0; o >>= 1) { se += __shfl_xor(se, o); st += __shfl_xor(st, o); }
+  const double me = se / n_sel, mt = st / n_sel;
+  double qe = 0.0, qt = 0.0;
+  for (int k = lane; k < n_sel; k += 64) {
+    const double a = (double)er[it[k]] - me, b = (double)tr[ie[k]] - mt;
+    qe += a * a; qt += b * b;
+  }
+  for (int o = 32; o > 0; o >>= 1) { qe += __shfl_xor(qe, o); qt += __shfl_xor(qt, o); }
+  if (lane == 0) {
+    const double s = (double)scores[i];
+    out[i] = (float)(0.5 * ((s - me) / sqrt(qe / (double)(n_sel - 1)) + (s - mt) / sqrt(qt / (double)(n_sel - 1))));
+  }
+}
+
+}  // namespace
+
 extern "C" {
 
 int asv_mean_vec(const float *x, int n, int dim, float *mean, void *stream) {
@@ -322,6 +450,33 @@ int asv_eer(const float *scores, const int32_t *labels, int n, float *eer_percen
   }
   *eer_percent = (float)(eer * 100.0);
   *threshold = thr;
+  return ASV_OK;
+}
+
+int asv_score_norm(const float *enroll_cohort, int n_enroll, const float *test_cohort, int n_test, int n_cohort, const int32_t *ei, const int32_t *ti,
+                   const float *scores, int n_trials, int top_n, int cross_select, float *normed, void *stream) {
+  ASV_REQUIRE(enroll_cohort && test_cohort && ei && ti && scores && normed && n_enroll >= 1 && n_test >= 1 && n_cohort >= 1 && n_trials >= 0,
+              "asv_score_norm: bad argument");
+  if (n_trials == 0) return ASV_OK;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int n_sel = (top_n <= 0 || top_n > n_cohort) ? n_cohort : top_n;
+  const int rows = n_enroll + n_test;
+  const size_t stat_bytes = round_up64((int64_t)rows * 2 * 8, 256);
+  const size_t idx_bytes = cross_select ? round_up64((int64_t)rows * n_sel * 4, 256) : 0;
+  void *ws = nullptr;
+  int rc = g_ws.get(stat_bytes + idx_bytes, &ws);
+  if (rc) return rc;
+  double *mu_e = reinterpret_cast<double *>(ws), *sd_e = mu_e + n_enroll, *mu_t = sd_e + n_enroll, *sd_t = mu_t + n_test;
+  int32_t *top_e = cross_select ? reinterpret_cast<int32_t *>(reinterpret_cast<unsigned char *>(ws) + stat_bytes) : nullptr;
+  int32_t *top_t = cross_select ? top_e + (size_t)n_enroll * n_sel : nullptr;
+  hipLaunchKernelGGL(cohort_topn_kernel, dim3(n_enroll), dim3(256), 0, s, enroll_cohort, n_cohort, n_sel, mu_e, sd_e, top_e);
+  hipLaunchKernelGGL(cohort_topn_kernel, dim3(n_test), dim3(256), 0, s, test_cohort, n_cohort, n_sel, mu_t, sd_t, top_t);
+  if (cross_select)
+    hipLaunchKernelGGL(score_norm_cross_kernel, dim3((n_trials + 3) / 4), dim3(256), 0, s, enroll_cohort, test_cohort, n_cohort, n_sel, top_e, top_t, scores, ei, ti,
+                       n_trials, normed);
+  else
+    hipLaunchKernelGGL(score_norm_trials_kernel, dim3((n_trials + 255) / 256), dim3(256), 0, s, scores, ei, ti, n_trials, mu_e, sd_e, mu_t, sd_t, normed);
+  ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }
 

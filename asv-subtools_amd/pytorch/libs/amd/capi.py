@@ -113,7 +113,7 @@ SYMBOLS = [
     "asv_net_device_bytes", "asv_net_set_profiling", "asv_net_get_profile",
     "asv_tdnn_forward", "asv_stats_pool_forward",
     "asv_length_norm", "asv_mean_vec", "asv_dot_score_matrix", "asv_dot_score_trials",
-    "asv_plda_transform", "asv_plda_llr_trials", "asv_eer",
+    "asv_plda_transform", "asv_plda_llr_trials", "asv_eer", "asv_score_norm",
 ]
 
 
@@ -169,6 +169,7 @@ def lib():
     L.asv_plda_transform.argtypes = [vp, ci, ci, vp, vp, vp, vp, ci, vp, vp]
     L.asv_plda_llr_trials.argtypes = [vp, vp, ci, vp, vp, vp, vp, ci, vp, vp]
     L.asv_eer.argtypes = [vp, vp, ci, c_float_p, c_float_p, vp]
+    L.asv_score_norm.argtypes = [vp, ci, vp, ci, ci, vp, vp, vp, ci, ci, ci, vp, vp]
     for name in SYMBOLS:
         fn = getattr(L, name)          # AttributeError here = header/.so mismatch
         if name not in ("asv_last_error", "asv_net_destroy", "asv_net_device_bytes"):

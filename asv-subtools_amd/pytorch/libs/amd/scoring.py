@@ -100,6 +100,31 @@ def eer(scores, labels):
     return float(e.value), float(thr.value)
 
 
+def score_normalize(scores, enroll_cohort, test_cohort, enroll_idx, test_idx, top_n=300, cross_select=False):
+    """S-norm / AS-norm of trial scores (reference score/ScoreNormalization.py:70-179, there a pandas groupby +
+    per-trial loop over text score files).  enroll_cohort [E, C] / test_cohort [T, C]: scores of every enrolment /
+    test vector against the cohort (e.g. `score_matrix(enroll, cohort)`); top_n <= 0 selects S-norm (all cohort
+    scores), otherwise AS-norm over the top_n largest; cross_select as in the reference's --cross-select."""
+    import torch
+    s = _dev(scores, torch.float32)
+    ec, tc = _dev(enroll_cohort, torch.float32, s.device), _dev(test_cohort, torch.float32, s.device)
+    assert ec.dim() == 2 and tc.dim() == 2 and ec.shape[1] == tc.shape[1], "cohort score matrices must share the cohort axis"
+    ei, ti = _dev(enroll_idx, torch.int32, s.device), _dev(test_idx, torch.int32, s.device)
+    assert ei.shape[0] == s.shape[0] == ti.shape[0]
+    out = torch.empty_like(s)
+    capi.check(capi.lib().asv_score_norm(_ptr(ec), ec.shape[0], _ptr(tc), tc.shape[0], ec.shape[1], _ptr(ei), _ptr(ti), _ptr(s), s.shape[0],
+                                         int(top_n), int(bool(cross_select)), _ptr(out), _stream(s)), "asv_score_norm")
+    return out
+
+
+def cosine_asnorm_trials(enroll, test, cohort, enroll_idx, test_idx, submean=None, top_n=300, cross_select=False):
+    """The published-EER protocol (recipe/voxcelebSRC/gather_results_from_epochs.sh:103-183): submean -> norm ->
+    cosine for the trials and for enrol x cohort / test x cohort, then AS-norm, all on the device."""
+    e, t, c = length_normalize(enroll, submean), length_normalize(test, submean), length_normalize(cohort, submean)
+    raw = score_trials(e, t, enroll_idx, test_idx)
+    return score_normalize(raw, score_matrix(e, c), score_matrix(t, c), enroll_idx, test_idx, top_n=top_n, cross_select=cross_select)
+
+
 # -------------------------------------------------------------------------------------- PLDA
 
 class Plda(object):

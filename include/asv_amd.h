@@ -258,6 +258,16 @@ int asv_plda_llr_trials(const float *enroll, const float *test, int dim, const f
  * the call synchronises `stream`. */
 int asv_eer(const float *scores, const int32_t *labels, int n, float *eer_percent, float *threshold,
             void *stream);
+/* Score normalisation (score/ScoreNormalization.py:70-179; protocol recipe/voxcelebSRC/gather_results_from_epochs.sh:103-183).
+ *   enroll_cohort device [n_enroll][n_cohort], test_cohort device [n_test][n_cohort]: scores of every enrolment / test
+ *   vector against every cohort vector (e.g. from asv_dot_score_matrix); ei / ti / scores: the trials (device).
+ *   top_n <= 0 or >= n_cohort: S-norm (all cohort scores, lines 70-109); otherwise AS-norm over the top_n largest
+ *   cohort scores of each vector (111-179); cross_select != 0: statistics per trial over the other side's top
+ *   cohort (139-148).  Mean and sample standard deviation (ddof = 1) in float64 like pandas;
+ *   normed[t] = 0.5 * ((s - mu_e) / sd_e + (s - mu_t) / sd_t).  Asynchronous on `stream`. */
+int asv_score_norm(const float *enroll_cohort, int n_enroll, const float *test_cohort, int n_test, int n_cohort,
+                   const int32_t *ei, const int32_t *ti, const float *scores, int n_trials, int top_n,
+                   int cross_select, float *normed, void *stream);
 
 #ifdef __cplusplus
 }

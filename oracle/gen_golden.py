@@ -203,7 +203,58 @@ def run_scoring_plda(name, synth):
     print("wrote %s: %d trials, EER %.4f%% thr %.5f" % (path, len(llr), 100 * eer, thr))
 
 
-EXTRA_CASES = {"scoring_plda": run_scoring_plda}
+def run_score_norm(name, synth):
+    """S-norm / AS-norm of score/ScoreNormalization.py:70-179 executed from the reference source (pandas) on
+    cosine scores of a planted-speaker set: text score files in, text score files out, exactly as
+    recipe/voxcelebSRC/gather_results_from_epochs.sh:103-183 drives it.  Inputs are stored as the f32 values
+    that were written (repr-exact), outputs as the f64 the reference printed."""
+    import importlib.util
+    import tempfile
+    import types
+    import numpy as np
+    spec = importlib.util.spec_from_file_location("ref_score_norm", os.path.join(REF, "score", "ScoreNormalization.py"))
+    sn = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sn)
+
+    dim = 32
+    emb, labels = synth.synth_speaker_embeddings(30, 4, dim, seed=21, within=1.0, between=0.9)
+    emb = emb / np.linalg.norm(emb, axis=1, keepdims=True)
+    enroll, test, cohort = emb[:24], emb[24:72], emb[72:]            # 24 enrol, 48 test, 48 cohort vectors
+    ec = (enroll @ cohort.T).astype(np.float32)
+    tc = (test @ cohort.T).astype(np.float32)
+    rng = np.random.RandomState(5)
+    n_trials = 400
+    # distinct (enrol, test) pairs, like a real trial list: the cross-select merge of the reference multiplies the
+    # cohort rows of a trial that is listed twice (and so changes its ddof=1 std)
+    pairs = rng.permutation(len(enroll) * len(test))[:n_trials]
+    ei = (pairs // len(test)).astype(np.int32)
+    ti = (pairs % len(test)).astype(np.int32)
+    sc = np.einsum("ij,ij->i", enroll[ei], test[ti]).astype(np.float32)
+    out = dict(enroll_cohort=ec, test_cohort=tc, trials_e=ei, trials_t=ti, scores=sc)
+    with tempfile.TemporaryDirectory() as td:
+        def write(path, rows):
+            with open(path, "w") as f:
+                for a, b, v in rows:
+                    f.write("%s %s %s\n" % (a, b, repr(float(np.float32(v)))))
+        write(os.path.join(td, "et"), [("e%d" % a, "t%d" % b, v) for a, b, v in zip(ei, ti, sc)])
+        write(os.path.join(td, "ec"), [("e%d" % a, "c%d" % c, ec[a, c]) for a in range(ec.shape[0]) for c in range(ec.shape[1])])
+        write(os.path.join(td, "tc"), [("t%d" % b, "c%d" % c, tc[b, c]) for b in range(tc.shape[0]) for c in range(tc.shape[1])])
+        for tag, method, top_n, cross in (("snorm", "snorm", 0, "false"), ("asnorm10", "asnorm", 10, "false"), ("asnorm10x", "asnorm", 10, "true"),
+                                          ("asnorm_all", "asnorm", 300, "false")):
+            args = types.SimpleNamespace(method=method, top_n=top_n, second_cohort="true", cross_select=cross, input_score=os.path.join(td, "et"),
+                                         enroll_cohort_score=os.path.join(td, "ec"), test_cohort_score=os.path.join(td, "tc"),
+                                         output_score=os.path.join(td, "out_" + tag))
+            (sn.snorm if method == "snorm" else sn.asnorm)(args)
+            vals = [float(line.split()[2]) for line in open(args.output_score)]
+            keys = [tuple(line.split()[:2]) for line in open(args.output_score)]
+            assert keys == [("e%d" % a, "t%d" % b) for a, b in zip(ei, ti)], "the reference keeps the trial order"
+            out[tag] = np.asarray(vals, dtype=np.float64)
+    path = os.path.join(GOLDEN, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote %s: %d trials, %d cohort vectors; mean |snorm| %.3f" % (path, n_trials, ec.shape[1], float(np.abs(out["snorm"]).mean())))
+
+
+EXTRA_CASES = {"scoring_plda": run_scoring_plda, "score_norm": run_score_norm}
 
 
 if __name__ == "__main__":

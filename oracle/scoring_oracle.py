@@ -166,3 +166,37 @@ def compute_eer(scores, labels):
             return (memory[0] + memory[1]) / 2, memory[2]
         memory = (far, frr, score)
     raise ValueError("FAR never drops to FRR")
+
+
+# ------------------------------------------------------------------- score normalisation
+
+def score_norm(enroll_cohort, test_cohort, ei, ti, scores, top_n=0, cross_select=False):
+    """S-norm (top_n <= 0) / AS-norm of score/ScoreNormalization.py:70-179 on dense score matrices
+    enroll_cohort [E, C], test_cohort [T, C] (the reference works on <key, key, score> text rows; the recipe
+    scores every enrol / test vector against every cohort vector, gather_results_from_epochs.sh:103-183).
+    pandas semantics: mean and *sample* std (ddof = 1) of the selected cohort scores, float64;
+    normed = 0.5 * ((s - mu_e) / sd_e + (s - mu_t) / sd_t)                       (lines 104-105, 171-175).
+    AS-norm: the top_n largest cohort scores per row (124-126, 150-151); cross_select: the enrol-side statistics
+    of trial (e, t) use the cohort vectors that are top_n for t and vice versa (139-148)."""
+    ec = np.asarray(enroll_cohort, dtype=np.float64)
+    tc = np.asarray(test_cohort, dtype=np.float64)
+    s = np.asarray(scores, dtype=np.float64)
+    n_c = ec.shape[1]
+    n = n_c if top_n <= 0 else min(int(top_n), n_c)
+
+    def top_idx(m):
+        # stable descending order: among equal scores the lower cohort index first
+        return np.argsort(-m, axis=1, kind="stable")[:, :n]
+
+    def stats(v):
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return v.mean(axis=-1), v.std(axis=-1, ddof=1)
+
+    ie, it = top_idx(ec), top_idx(tc)
+    if not cross_select:
+        mu_e, sd_e = stats(np.take_along_axis(ec, ie, axis=1))
+        mu_t, sd_t = stats(np.take_along_axis(tc, it, axis=1))
+        return 0.5 * ((s - mu_e[ei]) / sd_e[ei] + (s - mu_t[ti]) / sd_t[ti])
+    mu_e, sd_e = stats(np.take_along_axis(ec[ei], it[ti], axis=1))       # enrol scores at the test's top cohort
+    mu_t, sd_t = stats(np.take_along_axis(tc[ti], ie[ei], axis=1))
+    return 0.5 * ((s - mu_e) / sd_e + (s - mu_t) / sd_t)

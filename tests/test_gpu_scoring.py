@@ -96,3 +96,83 @@ def test_eer_delta_between_extractor_precisions_is_negligible():
         scores = scoring.cosine_trials(emb, emb, ei, ti, submean=scoring.mean_vector(emb))
         eers[prec], _ = scoring.eer(scores, tgt)
     assert abs(eers["f32"] - eers["bf16"]) < 0.25, eers        # a handful of trials of 4000 may flip at the threshold
+
+
+def test_score_norm_vs_reference_fixture_and_oracle():
+    """asv_score_norm against the outputs of the reference's ScoreNormalization.py (fixture) and, on a cohort of
+    realistic size with ties on the selection boundary, against the oracle."""
+    from libs.amd import scoring
+    from oracle import scoring_oracle as S
+    g = np.load(helpers.GOLDEN + "/score_norm.npz")
+    for tag, top_n, cross in (("snorm", 0, False), ("asnorm10", 10, False), ("asnorm10x", 10, True), ("asnorm_all", 300, False)):
+        got = scoring.score_normalize(g["scores"], g["enroll_cohort"], g["test_cohort"], g["trials_e"], g["trials_t"], top_n=top_n,
+                                      cross_select=cross).cpu().numpy()
+        assert np.abs(got - g[tag]).max() < 2e-6 * max(1.0, np.abs(g[tag]).max()), tag
+    rng = np.random.RandomState(7)
+    ec = rng.standard_normal((37, 2500)).astype(np.float32)
+    tc = rng.standard_normal((53, 2500)).astype(np.float32)
+    ec[:, ::7] = np.round(ec[:, ::7], 1)                               # plenty of exactly equal scores
+    tc[:, ::5] = np.round(tc[:, ::5], 1)
+    ei = rng.randint(0, 37, 4000).astype(np.int32)
+    ti = rng.randint(0, 53, 4000).astype(np.int32)
+    sc = rng.standard_normal(4000).astype(np.float32)
+    for top_n, cross in ((300, False), (300, True), (1, False), (2, True), (2500, False), (0, False)):
+        got = scoring.score_normalize(sc, ec, tc, ei, ti, top_n=top_n, cross_select=cross).cpu().numpy()
+        want = S.score_norm(ec, tc, ei, ti, sc, top_n, cross)
+        if top_n == 1:
+            assert np.isnan(got).all() and np.isnan(want).all()
+        else:
+            fin = np.isfinite(want)                                     # two equal scores in a top-2: sd = 0, +-inf like pandas
+            assert fin.mean() > 0.9 and np.array_equal(fin, np.isfinite(got)), (top_n, cross)
+            assert np.array_equal(np.sign(want[~fin]), np.sign(got[~fin])), (top_n, cross)
+            assert np.abs(got[fin] - want[fin]).max() < 5e-6 * max(1.0, np.abs(want[fin]).max()), (top_n, cross)
+
+
+def test_cosine_asnorm_pipeline_improves_or_keeps_eer():
+    """submean -> norm -> cosine -> AS-norm on the device end to end (the published-EER protocol) equals the
+    oracle chain and yields a finite EER."""
+    from libs.amd import scoring, synth
+    from oracle import scoring_oracle as S
+    x, labels, ei, ti, tgt = _sets(dim=96, seed=9)
+    cohort, _ = synth.synth_speaker_embeddings(80, 5, 96, seed=31, within=1.0, between=0.7)
+    mean = S.global_mean(cohort)
+    got = scoring.cosine_asnorm_trials(x, x, cohort, ei, ti, submean=mean, top_n=100).cpu().numpy()
+    xn, cn = S.length_normalize(x, mean), S.length_normalize(cohort, mean)
+    raw = S.dot_trials(xn, xn, ei, ti)
+    want = S.score_norm(xn.dot(cn.T).astype(np.float32), xn.dot(cn.T).astype(np.float32), ei, ti, raw.astype(np.float32), 100)
+    assert np.abs(got - want).max() < 2e-3                              # f32 cosine scores feed a ~1/sd amplification
+    e1, _ = scoring.eer(got, tgt)
+    assert 0.0 <= e1 < 50.0
+
+
+def test_score_normalization_cli_matches_reference_outputs(tmp_path):
+    """asv-subtools_amd/score/ScoreNormalization.py (same CLI as the reference script) on the fixture's text files."""
+    import os
+    import subprocess
+    import sys
+    g = np.load(helpers.GOLDEN + "/score_norm.npz")
+    ec, tc, ei, ti, sc = g["enroll_cohort"], g["test_cohort"], g["trials_e"], g["trials_t"], g["scores"]
+
+    def write(path, rows):
+        with open(path, "w") as f:
+            for a, b, v in rows:
+                f.write("%s %s %r\n" % (a, b, float(np.float32(v))))
+    write(tmp_path / "et", [("e%d" % a, "t%d" % b, v) for a, b, v in zip(ei, ti, sc)])
+    write(tmp_path / "ec", [("e%d" % a, "c%d" % c, ec[a, c]) for a in range(ec.shape[0]) for c in range(ec.shape[1])])
+    # cohort columns listed in another order for the test side: the script aligns them by key
+    write(tmp_path / "tc", [("t%d" % b, "c%d" % c, tc[b, c]) for b in range(tc.shape[0]) for c in reversed(range(tc.shape[1]))])
+    script = os.path.join(helpers.REPO, "asv-subtools_amd", "score", "ScoreNormalization.py")
+    for tag, extra in (("snorm", ["--method=snorm"]), ("asnorm10", ["--top-n=10"]), ("asnorm10x", ["--top-n=10", "--cross-select=true"])):
+        out = tmp_path / ("out_" + tag)
+        r = subprocess.run([sys.executable, script] + extra + [str(tmp_path / "et"), str(tmp_path / "ec"), str(tmp_path / "tc"), str(out)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        rows = [line.split() for line in open(out)]
+        assert [(a, b) for a, b, _ in rows] == [("e%d" % a, "t%d" % b) for a, b in zip(ei, ti)]
+        got = np.array([float(v) for _, _, v in rows])
+        assert np.abs(got - g[tag]).max() < 2e-6 * max(1.0, np.abs(g[tag]).max()), tag
+    # a missing pair is an error, not a silent partial normalisation
+    lines = open(tmp_path / "ec").read().splitlines()
+    open(tmp_path / "ec_bad", "w").write("\n".join(lines[:-1]) + "\n")
+    r = subprocess.run([sys.executable, script, str(tmp_path / "et"), str(tmp_path / "ec_bad"), str(tmp_path / "tc"), str(tmp_path / "o")], capture_output=True, text=True)
+    assert r.returncode == 1 and "every cohort key" in r.stderr

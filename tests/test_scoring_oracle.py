@@ -73,3 +73,23 @@ def test_plda_kaldi_text_roundtrip(tmp_path):
     nums = txt.replace("<Plda>", "").replace("</Plda>", "").replace("[", " ").replace("]", " ").split()
     assert len(nums) == dim + dim * dim + dim
     assert abs(float(nums[0]) - plda.mean[0]) < 1e-12
+
+
+def test_score_norm_oracle_matches_reference_script():
+    """S-norm / AS-norm / cross-select AS-norm restated in numpy against the outputs of the reference's
+    score/ScoreNormalization.py on the same text score files (oracle/gen_golden.py score_norm)."""
+    g = np.load(helpers.GOLDEN + "/score_norm.npz")
+    for tag, top_n, cross in (("snorm", 0, False), ("asnorm10", 10, False), ("asnorm10x", 10, True), ("asnorm_all", 300, False)):
+        got = S.score_norm(g["enroll_cohort"], g["test_cohort"], g["trials_e"], g["trials_t"], g["scores"], top_n, cross)
+        assert np.abs(got - g[tag]).max() < 1e-12, tag
+    assert np.abs(g["snorm"] - g["asnorm_all"]).max() < 1e-12          # top_n beyond the cohort = every cohort score
+
+
+def test_score_norm_oracle_edge_cases():
+    ec = np.array([[0.5, 0.5, 0.1, 0.9]], dtype=np.float32)           # a tie that straddles the top-2 boundary
+    tc = np.array([[0.2, 0.4, 0.6, 0.8]], dtype=np.float32)
+    out = S.score_norm(ec, tc, [0], [0], [0.7], top_n=2)
+    mu_e, sd_e = (0.9 + 0.5) / 2, np.std([np.float32(0.9), np.float32(0.5)], ddof=1)
+    mu_t, sd_t = (0.8 + 0.6) / 2, np.std([np.float32(0.8), np.float32(0.6)], ddof=1)
+    assert abs(out[0] - 0.5 * ((0.7 - mu_e) / sd_e + (0.7 - mu_t) / sd_t)) < 1e-6
+    assert np.isnan(S.score_norm(ec, tc, [0], [0], [0.7], top_n=1)[0])   # one score: sample std undefined, NaN like pandas
