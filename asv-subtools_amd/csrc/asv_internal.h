@@ -102,6 +102,10 @@ struct PoolKernelParams {
 int launch_tdnn_mfma(const TdnnKernelParams &p, bool bf16, bool out_f32, hipStream_t s);
 int launch_tdnn_ref(const TdnnKernelParams &p, bool bf16, bool out_f32, hipStream_t s);
 int launch_utts_gemm(const TdnnKernelParams &p, int rows_valid, bool split, hipStream_t s);
+// kernels_conv2d.hip: 3x3 grid convolutions with 32 / 64 channels (weights in p.wfrag, [tap][k-group][n-frag][lane][8])
+bool grid_conv_narrow_supported(const TdnnKernelParams &p, bool bf16);
+size_t grid_conv_frag_elems(int cin_pad, int cout_pad32);
+int launch_grid_conv_narrow(const TdnnKernelParams &p, hipStream_t s);
 int launch_splitk_epilogue(const TdnnKernelParams &p, bool bf16, bool out_f32, hipStream_t s);
 // 256x256-tile bf16 kernel with direct-to-LDS staging (kernels_tdnn_v2.hip); needs weights
 // padded to kBigTileN rows and a plain epilogue (no second input / per-segment terms / residual)

@@ -1,0 +1,202 @@
+// 3x3 convolutions of the ResNet34 trunk with few channels (C = 32 / 64: 13 of its 32 convolutions and 60 % of its
+// time on the generic 128 x 128 GEMM tile, which wastes 3/4 of its columns at N = 32 and half of its K chunk at
+// C = 32) - reference libs/nnet/resnet.py:12-20 (conv3x3) inside BasicBlock (resnet.py:30-76), eval BatchNorm folded.
+//
+// The grid domain stores [B, C, F, T] as rows = (time, frequency) positions, frequency fastest, pitch F + 1, so a
+// stride-1 3x3 convolution is 9 row-offset taps dt * pitch + df of a [rows][C] matrix (runtime.hip).
+// With C <= 64 the whole K extent of a tile is ONE window:
+//   workgroup = 256 output rows x all output channels; window = 256 + 2 * halo rows x C channels (27 | 54 KiB) brought
+//   in once by LDS-DMA; the nine taps read it shifted - no K-chunk loop, no barrier after the first.
+//   Weights: C = 32: all 9 x 2 MFMA fragments of the layer live in 72 VGPRs for the whole kernel;
+//            C = 64: 8 fragments per tap stream from L2 one tap ahead (fragment order, 1 KiB wave loads).
+//   wave = 64 rows (2 accumulator fragments) x all channels; per tap and 16-channel k-group one ds_read_b128 feeds
+//   one (C = 32) or two (C = 64) MFMAs - LDS-read bound by construction, HBM bound at the kernel level
+//   (64 B in + 64 B out per row against 18.4 kFLOP).
+// LDS rows are C * 2 bytes; 16-byte slot s of window row w sits at s ^ ((w >> 2) & 3) (64-byte rows) or
+// s ^ ((w >> 1) & 7) (128-byte rows): conflict-free ds_read_b128 for any tap shift; the DMA applies the same
+// permutation on the source side.
+#include "device_utils.h"
+
+namespace asv {
+namespace {
+
+constexpr int CBM = 256;              // output rows per workgroup
+constexpr int CHALO = 88;             // window halo: >= pitch + 1 (<= 84), a multiple of 8
+constexpr int CWIN = CBM + 2 * CHALO;  // 432 window rows
+
+typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
+
+template <int CIN> __device__ __forceinline__ int cswz(int row, int slot) {
+  return CIN == 32 ? (slot ^ ((row >> 2) & 3)) : (slot ^ ((row >> 1) & 7));
+}
+
+__device__ __forceinline__ void conv_glds16(const void *gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
+// weights: [tap][k-group][n-fragment][lane = (k half lh, channel lr)][8] bf16, k = kg * 16 + lh * 8 + e
+template <int CIN, int NF, bool GENERIC>
+__global__ __launch_bounds__(256, CIN == 32 ? 3 : 2) void grid_conv_narrow_kernel(const TdnnKernelParams p) {
+  constexpr int ROWB = CIN * 2;                       // bytes per window row
+  constexpr int SLOTS = ROWB / 16;                    // 4 | 8
+  constexpr int RPP = 1024 / ROWB;                    // window rows per 1 KiB DMA piece: 16 | 8
+  constexpr int PIECES = CWIN / RPP;                  // 27 | 54
+  constexpr int KG = CIN / 16;                        // k-groups per tap: 2 | 4
+  __shared__ __attribute__((aligned(16))) unsigned char win[CWIN * ROWB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+  const int m0 = xcd_swizzle(blockIdx.x, gridDim.x) * CBM;
+
+  // ---- window: one LDS-DMA instruction per 1 KiB piece, rows clamped onto the matrix (its first / last rows are gaps)
+  const unsigned char *xg = reinterpret_cast<const unsigned char *>(p.x);
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_byte_t *)win);
+  for (int piece = wave; piece < PIECES; piece += 4) {
+    const int w = piece * RPP + lane / SLOTS;
+    const int row = min(max(m0 - CHALO + w, 0), p.rows - 1);
+    const int src_slot = cswz<CIN>(w, lane % SLOTS);
+    conv_glds16(xg + (size_t)row * ((size_t)p.ldx * 2) + src_slot * 16, __builtin_amdgcn_readfirstlane(lds_base + piece * 1024));
+  }
+  const int v_taps = p.taps[lane < 9 ? lane : 0];
+  const uint4 *wf = reinterpret_cast<const uint4 *>(p.wfrag) + lane;            // fragment f at wf[f * 64]
+
+  f32x16_t acc[2][NF];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int n = 0; n < NF; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.0f;
+
+  auto read_x = [&](int d, int kg, int i) {
+    const int w = CHALO + wave * 64 + i * 32 + lr + d;
+    return *reinterpret_cast<const uint4 *>(win + w * ROWB + cswz<CIN>(w, kg * 2 + lh) * 16);
+  };
+
+  if constexpr (CIN == 32) {
+    uint4 wr[9][KG][NF];                              // the whole layer: 18 fragments
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+        for (int n = 0; n < NF; ++n) wr[t][kg][n] = wf[((t * KG + kg) * NF + n) * 64];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int d = __builtin_amdgcn_readlane(v_taps, t);
+#pragma unroll
+      for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const uint4 x = read_x(d, kg, i);
+#pragma unroll
+          for (int n = 0; n < NF; ++n)
+            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wr[t][kg][n]), __builtin_bit_cast(bf16x8_t, x), acc[i][n], 0, 0, 0);
+        }
+    }
+  } else {
+    uint4 wa[KG][NF], wb[KG][NF];
+    auto fetch = [&](int t, uint4 (&w)[KG][NF]) {
+#pragma unroll
+      for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+        for (int n = 0; n < NF; ++n) w[kg][n] = wf[((t * KG + kg) * NF + n) * 64];
+    };
+    auto tap = [&](int t, const uint4 (&w)[KG][NF]) {
+      const int d = __builtin_amdgcn_readlane(v_taps, t);
+#pragma unroll
+      for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const uint4 x = read_x(d, kg, i);
+#pragma unroll
+          for (int n = 0; n < NF; ++n)
+            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w[kg][n]), __builtin_bit_cast(bf16x8_t, x), acc[i][n], 0, 0, 0);
+        }
+    };
+    fetch(0, wa);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < 8; t += 2) {                  // taps 0..7 in pairs, the other register set one tap ahead
+      fetch(t + 1, wb);
+      tap(t, wa);
+      fetch(t + 2, wa);
+      tap(t + 1, wb);
+    }
+    tap(8, wa);
+  }
+
+  // ---- epilogue: acc[i][n][r] = row m0 + wave*64 + i*32 + lr, channel n*32 + 8*(r>>2) + 4*lh + (r&3): 8-byte stores
+  const float act_lo = (p.act1 == ASV_ACT_RELU) ? 0.0f : -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = m0 + wave * 64 + i * 32 + lr;
+    const bool valid = (p.row_valid[row >> 5] >> (row & 31)) & 1u;
+#pragma unroll
+    for (int n = 0; n < NF; ++n)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ch = n * 32 + 8 * q + 4 * lh;
+        if (ch >= p.cout_store) continue;
+        const float4 b4 = *reinterpret_cast<const float4 *>(p.bias + ch);
+        const float4 sc4 = p.scale ? *reinterpret_cast<const float4 *>(p.scale + ch) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 sh4 = p.shift ? *reinterpret_cast<const float4 *>(p.shift + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float b[4] = {b4.x, b4.y, b4.z, b4.w}, sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if constexpr (GENERIC) y[e] = tdnn_epilogue<true>(p, acc[i][n][q * 4 + e], row, ch + e, b[e], sc[e], sh[e], valid);
+          else y[e] = tdnn_epilogue_fast(acc[i][n][q * 4 + e], b[e], act_lo, sc[e], sh[e], valid);
+        }
+        uint2 pk;
+        pk.x = pack_bf16x2(y[0], y[1]);
+        pk.y = pack_bf16x2(y[2], y[3]);
+        *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(p.y) + (size_t)row * p.ldy + ch) = pk;
+      }
+  }
+}
+
+}  // namespace
+
+bool grid_conv_narrow_supported(const TdnnKernelParams &p, bool bf16) {
+  if (!bf16 || p.n_taps != 9 || p.x2 != nullptr || p.wfrag == nullptr) return false;
+  if (p.cin_pad != 32 && p.cin_pad != 64) return false;
+  if (p.cout_store != p.cin_pad) return false;                 // the trunk's 3x3 convolutions keep the channel count
+  if (p.halo > CHALO || p.rows % CBM != 0 || p.ldx % 8 != 0 || p.ldy % 4 != 0) return false;
+  return true;
+}
+
+// elements of the fragment-ordered weight copy for this kernel
+size_t grid_conv_frag_elems(int cin_pad, int cout_pad32) { return (size_t)9 * (cin_pad / 16) * (cout_pad32 / 32) * 512; }
+
+int launch_grid_conv_narrow(const TdnnKernelParams &p, hipStream_t s) {
+  ASV_REQUIRE(grid_conv_narrow_supported(p, true), "grid conv (narrow): unsupported layer");
+  const dim3 grid(p.rows / CBM), block(256);
+  const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first && p.seg_bias == nullptr &&
+                    p.seg_scale == nullptr && p.res == nullptr;
+  if (p.cin_pad == 32) {
+    if (fast) hipLaunchKernelGGL((grid_conv_narrow_kernel<32, 1, false>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((grid_conv_narrow_kernel<32, 1, true>), grid, block, 0, s, p);
+  } else {
+    if (fast) hipLaunchKernelGGL((grid_conv_narrow_kernel<64, 2, false>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((grid_conv_narrow_kernel<64, 2, true>), grid, block, 0, s, p);
+  }
+  ASV_HIP_CHECK(hipGetLastError());
+  return ASV_OK;
+}
+
+}  // namespace asv

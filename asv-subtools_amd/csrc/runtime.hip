@@ -442,6 +442,23 @@ int asv_net_add_tdnn(asv_net_t *net, const asv_tdnn_desc_t *d) {
       pack_tdnn_weight_frags(d->weight, d->out_ch, d->in_ch, d->w_tot_context, d->w_left_context, d->taps, d->n_taps, op.cout_pad, op.cin_pad, frags.data());
       if ((rc = dev_upload(net, frags.data(), frags.size() * 2, &op.wfrag))) return rc;
     }
+    if (bf16 && net->domains[dom].kind == 2 && d->n_taps == 9 && (op.cin_pad == 32 || op.cin_pad == 64) && d->in_ch == op.cin_pad &&
+        d->out_ch == d->in_ch) {
+      // 3x3 trunk convolutions with 32 / 64 channels: fragment order of kernels_conv2d.hip,
+      // [tap][k-group][n-fragment][lane = (k half lh, channel lr)][8], k = kg * 16 + lh * 8 + e
+      const int kgs = op.cin_pad / 16, nfs = op.cin_pad / 32;
+      std::vector<uint16_t> frags(grid_conv_frag_elems(op.cin_pad, op.cin_pad), 0);
+      for (int t = 0; t < 9; ++t) {
+        const int k = d->taps[t] - d->w_left_context;
+        for (int co = 0; co < d->out_ch; ++co)
+          for (int ci = 0; ci < d->in_ch; ++ci) {
+            const int kg = ci / 16, lh = (ci % 16) / 8, e = ci % 8, nf = co / 32, lr = co % 32;
+            frags[((size_t)(t * kgs + kg) * nfs + nf) * 512 + (size_t)(lh * 32 + lr) * 8 + e] =
+                f32_to_bf16_host(d->weight[((size_t)co * d->in_ch + ci) * d->w_tot_context + k]);
+          }
+      }
+      if ((rc = dev_upload(net, frags.data(), frags.size() * 2, &op.wfrag))) return rc;
+    }
     if (op.utts && net->frames_bf16()) {
       // pooled-domain layers keep f32 activations; their GEMM runs on the bf16 matrix cores with every
       // operand split into two bf16 halves, the weight halves in the fragment order kernels_utts.hip walks:
@@ -860,6 +877,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         const bool big3 = !use_ref && narrow && (net->flags & (ASV_FLAG_SMALL_TILES | ASV_FLAG_BIG_V2)) == 0 && tdnn_big3_supported(p, bf16, !bf16);
         const bool big = !use_ref && narrow && !big3 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && tdnn_big_supported(p, bf16, !bf16);
         const bool utts_kernel = !use_ref && op.utts;
+        const bool narrow_conv = !use_ref && net->domains[domid].kind == 2 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && grid_conv_narrow_supported(p, bf16);
         if (!use_ref && !big && !big3 && op.utts && !utts_kernel) {
           // pooled-domain layers have one row per utterance (M is tiny, K is large): slice K over more
           // workgroups.  The slice count depends on K only, never on the batch, so an utterance's
@@ -889,6 +907,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         }
         if (use_ref) rc = launch_tdnn_ref(p, bf16, !bf16, c.s);
         else if (utts_kernel) rc = launch_utts_gemm(p, bp.segments, net->frames_bf16(), c.s);
+        else if (narrow_conv) rc = launch_grid_conv_narrow(p, c.s);
         else if (big3) rc = launch_tdnn_big3(p, c.s);
         else if (big) rc = launch_tdnn_big(p, c.s);
         else {

@@ -46,10 +46,29 @@ int main(int argc, char **argv) {
   p.ldx = cin + xpad; p.ldy = cout_pad; p.rows = rows; p.cin_pad = cin; p.cout_store = round_up(cout, 16); p.n_taps = ntaps;
   const int tapsets[5][5] = {{0}, {-1, 1}, {-2, 0, 2}, {-3, -1, 1, 3}, {-2, -1, 0, 1, 2}};
   for (int t = 0; t < ntaps; ++t) p.taps[t] = tapsets[ntaps - 1][t];
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  if (getenv("ABLATE_GRID")) {
+    // 3x3 convolution over a row-flattened (time, frequency) grid of pitch P: 9 row offsets dt * P + df; v1 kernel only
+    const int P = atoi(getenv("ABLATE_GRID"));
+    ntaps = 9; p.n_taps = 9;
+    for (int dt = -1, t = 0; dt <= 1; ++dt) for (int df = -1; df <= 1; ++df) p.taps[t++] = dt * P + df;
+    std::vector<uint16_t> hw9((size_t)cout_pad * 9 * cin);
+    for (auto &v : hw9) v = f32_to_bf16_host(((rand() / (float)RAND_MAX) * 2 - 1) * 0.05f);
+    void *w9; CK(hipMalloc(&w9, hw9.size() * 2)); CK(hipMemcpy(w9, hw9.data(), hw9.size() * 2, hipMemcpyHostToDevice));
+    p.w = w9;
+    const double fl = 2.0 * rows * cin * cout * 9;
+    for (int rep = 0; rep < 2; ++rep) {
+      CK(hipEventRecord(a, 0));
+      for (int i = 0; i < iters; ++i) if (launch_tdnn_mfma(p, true, false, 0)) { printf("launch failed: %s\n", asv_last_error()); return 1; }
+      CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
+      float ms; CK(hipEventElapsedTime(&ms, a, b));
+      if (rep == 1) printf("  v1 128x128, 3x3 grid taps (pitch %d)  %9.1f us  %8.1f TFLOP/s\n", P, 1e3 * ms / iters, fl * iters / (ms * 1e-3) / 1e12);
+    }
+    return 0;
+  }
   p.act1 = ASV_ACT_RELU;
   p.tune = getenv("ABLATE_TUNE") ? (int)strtol(getenv("ABLATE_TUNE"), nullptr, 0) : 0;
   const double flops = 2.0 * rows * cin * cout * ntaps;
-  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   printf("rows=%d cin=%d cout=%d taps=%d xpad=%d  (%.1f GFLOP)\n", rows, cin, cout, ntaps, xpad, flops / 1e9);
   const char *names[] = {"big: full", "big: no LDS-DMA in loop", "big: MFMA + barrier only", "big: DMA + ds_read, no MFMA", "big: no epilogue stores", "big: DMA (cache-hot) + ds_read", "small 128x128 (v1)", "big: DMA + barrier only", "big: ds_read + barrier only", "big3 (2 WG/CU): full", "big3 (2 WG/CU): MFMA only", "big3 (2 WG/CU): no epilogue stores", "big3 (1 WG/CU): full", "big3 (1 WG/CU): MFMA only", "big3 64-row (3 WG/CU): full", "big3 64-row (3 WG/CU): MFMA only"};
   for (int v = 9; v <= 15; ++v) {

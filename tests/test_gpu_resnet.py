@@ -38,3 +38,18 @@ def test_resnet_bf16_is_close_and_batch_invariant():
     assert np.isfinite(full).all()
     for i in (1, 2):
         assert np.array_equal(model.extract_embedding(mats[i]).numpy(), full[i])
+
+
+def test_narrow_grid_conv_kernel_agrees_with_generic_gemm_tile(monkeypatch):
+    """The C = 32 / 64 stages run on kernels_conv2d.hip in bf16 mode; ASV_AMD_SMALL_TILES=1 sends them back to the
+    generic 128 x 128 implicit-GEMM kernel.  Both walk K as (tap, 16-channel group) with the same MFMA instruction,
+    so the f32 accumulation order - and therefore every bit of the embeddings - is the same."""
+    from libs.amd import synth
+    g, sd, model = helpers.golden_model("resnet34se_c5")
+    model.cuda()
+    model.amd_precision = "bf16"
+    mats = [synth.synth_feats(T, 80, 7000 + i) for i, T in enumerate([200, 257, 640])]
+    fast = model.extract_embedding_batch(mats).numpy()
+    monkeypatch.setenv("ASV_AMD_SMALL_TILES", "1")
+    slow = model.extract_embedding_batch(mats).numpy()                     # new flags = new engine (framework.py caches per flag set)
+    assert np.isfinite(fast).all() and np.array_equal(fast, slow)
