@@ -106,6 +106,8 @@ int launch_utts_gemm(const TdnnKernelParams &p, int rows_valid, bool split, hipS
 bool grid_conv_narrow_supported(const TdnnKernelParams &p, bool bf16);
 size_t grid_conv_frag_elems(int cin_pad, int cout_pad32);
 int launch_grid_conv_narrow(const TdnnKernelParams &p, hipStream_t s);
+bool grid_conv_c1_supported(const TdnnKernelParams &p, bool bf16, int in_ch);
+int launch_grid_conv_c1(const TdnnKernelParams &p, hipStream_t s);
 int launch_splitk_epilogue(const TdnnKernelParams &p, bool bf16, bool out_f32, hipStream_t s);
 // 256x256-tile bf16 kernel with direct-to-LDS staging (kernels_tdnn_v2.hip); needs weights
 // padded to kBigTileN rows and a plain epilogue (no second input / per-segment terms / residual)

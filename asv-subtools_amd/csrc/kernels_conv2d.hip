@@ -170,6 +170,42 @@ __global__ __launch_bounds__(256, CIN == 32 ? 3 : 2) void grid_conv_narrow_kerne
   }
 }
 
+// The first convolution of the trunk: ONE input channel (the fbank map itself), 3x3, 32 output channels
+// (resnet.py:96-99).  9 multiply-adds per output - nothing for a matrix core: one thread per (row, 8 channels), the nine
+// bf16 inputs of the row gathered through L1, weights in registers, f32 fma in tap order (bit-identical to the MFMA
+// path, whose other 15 k-lanes are zeros), 16-byte coalesced stores.  HBM bound on the 64 B it writes per row.
+template <bool GENERIC>
+__global__ __launch_bounds__(256) void grid_conv_c1_kernel(const TdnnKernelParams p) {
+  const int chunks = p.cout_store / 8;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long long)p.rows * chunks) return;
+  const int row = (int)(gid / chunks), ch = (int)(gid % chunks) * 8;
+  const uint16_t *x = reinterpret_cast<const uint16_t *>(p.x);
+  const uint16_t *w = reinterpret_cast<const uint16_t *>(p.w);                 // [cout_pad][n_taps][cin_pad] bf16
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+  const bool valid = (p.row_valid[row >> 5] >> (row & 31)) & 1u;
+  if (valid) {
+    for (int t = 0; t < p.n_taps; ++t) {
+      const int r = row + p.taps[t];
+      const float xv = (r >= 0 && r < p.rows) ? bf16_bits_to_f32(x[(size_t)r * p.ldx]) : 0.0f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(bf16_bits_to_f32(w[((size_t)(ch + e) * p.n_taps + t) * p.cin_pad]), xv, acc[e]);
+    }
+  }
+  float y[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float scale = p.scale ? p.scale[ch + e] : 1.0f, shift = p.shift ? p.shift[ch + e] : 0.0f;
+    if constexpr (GENERIC) y[e] = tdnn_epilogue<true>(p, acc[e], row, ch + e, p.bias[ch + e], scale, shift, valid);
+    else y[e] = tdnn_epilogue_fast(acc[e], p.bias[ch + e], (p.act1 == ASV_ACT_RELU) ? 0.0f : -INFINITY, scale, shift, valid);
+  }
+  uint4 o;
+  o.x = pack_bf16x2(y[0], y[1]); o.y = pack_bf16x2(y[2], y[3]); o.z = pack_bf16x2(y[4], y[5]); o.w = pack_bf16x2(y[6], y[7]);
+  *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(p.y) + (size_t)row * p.ldy + ch) = o;
+}
+
 }  // namespace
 
 bool grid_conv_narrow_supported(const TdnnKernelParams &p, bool bf16) {
@@ -195,6 +231,21 @@ int launch_grid_conv_narrow(const TdnnKernelParams &p, hipStream_t s) {
     if (fast) hipLaunchKernelGGL((grid_conv_narrow_kernel<64, 2, false>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((grid_conv_narrow_kernel<64, 2, true>), grid, block, 0, s, p);
   }
+  ASV_HIP_CHECK(hipGetLastError());
+  return ASV_OK;
+}
+
+bool grid_conv_c1_supported(const TdnnKernelParams &p, bool bf16, int in_ch) {
+  return bf16 && in_ch == 1 && p.x2 == nullptr && p.w != nullptr && p.cout_store % 8 == 0 && p.cout_store <= 64 && p.ldy % 8 == 0 && p.n_taps <= 9;
+}
+
+int launch_grid_conv_c1(const TdnnKernelParams &p, hipStream_t s) {
+  const long long n = (long long)p.rows * (p.cout_store / 8);
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first && p.seg_bias == nullptr &&
+                    p.seg_scale == nullptr && p.res == nullptr;
+  if (fast) hipLaunchKernelGGL((grid_conv_c1_kernel<false>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((grid_conv_c1_kernel<true>), grid, block, 0, s, p);
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }

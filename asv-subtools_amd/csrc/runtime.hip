@@ -877,6 +877,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         const bool big3 = !use_ref && narrow && (net->flags & (ASV_FLAG_SMALL_TILES | ASV_FLAG_BIG_V2)) == 0 && tdnn_big3_supported(p, bf16, !bf16);
         const bool big = !use_ref && narrow && !big3 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && tdnn_big_supported(p, bf16, !bf16);
         const bool utts_kernel = !use_ref && op.utts;
+        const bool c1_conv = !use_ref && net->domains[domid].kind == 2 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && grid_conv_c1_supported(p, bf16, d.in_ch);
         const bool narrow_conv = !use_ref && net->domains[domid].kind == 2 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && grid_conv_narrow_supported(p, bf16);
         if (!use_ref && !big && !big3 && op.utts && !utts_kernel) {
           // pooled-domain layers have one row per utterance (M is tiny, K is large): slice K over more
@@ -908,6 +909,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         if (use_ref) rc = launch_tdnn_ref(p, bf16, !bf16, c.s);
         else if (utts_kernel) rc = launch_utts_gemm(p, bp.segments, net->frames_bf16(), c.s);
         else if (narrow_conv) rc = launch_grid_conv_narrow(p, c.s);
+        else if (c1_conv) rc = launch_grid_conv_c1(p, c.s);
         else if (big3) rc = launch_tdnn_big3(p, c.s);
         else if (big) rc = launch_tdnn_big(p, c.s);
         else {
