@@ -82,6 +82,7 @@ struct TdnnKernelParams {
   int n_taps;
   int taps[ASV_MAX_TAPS];
   int act1, act2, affine_first;
+  int row_begin, row_count;   // variant-3 kernel: the launch covers rows [row_begin, row_begin + row_count) (0, 0 = all rows)
   int tune;             // experiment knobs of the variant-3 kernel (tools/gemm_ablate): priorities / start stagger
   int big_one_per_cu;   // variant-3 kernel: 256x256 tiles, one workgroup per CU (default: 128x256, two per CU)
   int halo;             // max |tap offset| of this layer (selects the window size of the 128x128 kernel)

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(Geom3<WM>::WAVES * 64, WM == 0 ? 3 : 2) void tdnn_g
   const int lr = lane & 31, lh = lane >> 5;
 
   const int tile = xcd_swizzle(blockIdx.x, m_tiles * n_tiles);
-  const int m0 = (tile / n_tiles) * BM;
+  const int m0 = p.row_begin + (tile / n_tiles) * BM;
   const int n0 = (tile % n_tiles) * BN;
 
   const unsigned char *xg = reinterpret_cast<const unsigned char *>(p.x);
@@ -499,7 +499,9 @@ int launch_tdnn_big3_variant(const TdnnKernelParams &p, int variant, hipStream_t
   const int geom = variant / 100;
   variant %= 100;
   const int bm = geom == 0 ? 128 : (geom == 1 ? 256 : 64);
-  const int m_tiles = p.rows / bm, n_tiles = round_up(p.cout_store, BN) / BN;
+  const int row_count = p.row_count > 0 ? p.row_count : p.rows;
+  ASV_REQUIRE(p.row_begin % bm == 0 && row_count % bm == 0 && p.row_begin + row_count <= p.rows, "tdnn(big3): row range [%d, +%d) does not fit %d-row tiles", p.row_begin, row_count, bm);
+  const int m_tiles = row_count / bm, n_tiles = round_up(p.cout_store, BN) / BN;
   const dim3 grid(m_tiles * n_tiles), block(geom == 1 ? 512 : 256);
   const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first;
   if (p.pool_partial != nullptr) {
@@ -568,6 +570,11 @@ int tdnn_big3_pick_geometry(const TdnnKernelParams &p) {
   return t128 <= 160 ? 2 : 0;
 }
 
+// Default entry.  Tried and dropped: giving the rows of a poorly filled last round (C2: 816 tiles = 512 + 304) to the 64-row
+// geometry in a second launch (one full round at two workgroups per CU, then a half-height round at three).  The second
+// kernel cannot start before the first has drained, the overlap between the tail of round one and the head of round two is
+// lost, and the result is 4-6 us slower on every C2 layer (89 vs 85 us on the 3-tap 512 -> 512 layer).  The row-range
+// parameters (row_begin / row_count) stay for tools/gemm_ablate.
 int launch_tdnn_big3(const TdnnKernelParams &p, hipStream_t s) { return launch_tdnn_big3_variant(p, tdnn_big3_pick_geometry(p) * 100, s); }
 
 }  // namespace asv
