@@ -78,6 +78,12 @@ CASES = {
                                    creation="ECAPA_TDNN(80,10,training=False,extracted_embedding='near_affine',"
                                             "ecapa_params={'channels':512,'embd_dim':192,'mfa_conv':1536})",
                                    dim=80, utts=[(200, 3300), (150, 3301)], wseed=5),
+    # the extended TDNN (E-TDNN) blueprint, both embedding positions, ragged lengths
+    "extended_far": dict(blueprint="extended_xvector.py", creation="ExtendedXvector(40,10,training=False)", dim=40,
+                         utts=[(200, 6000), (9, 6001), (333, 6002), (1, 6003)], wseed=9),
+    "extended_near_plain": dict(blueprint="extended_xvector.py",
+                                creation="ExtendedXvector(40,10,extend=False,training=False,extracted_embedding='near')", dim=40,
+                                utts=[(150, 6100), (64, 6101)], wseed=10),
     # BASELINE config C5 extractor: ResNet34-SE (32-64-128-256), launcher-style fc2 (runResnetXvector_online.py:221-260)
     "resnet34se_c5": dict(blueprint="resnet_xvector.py",
                           creation="ResNetXvector(80,10,training=False,resnet_params={'use_se':True,'se_ratio':4,'full_pre_activation':False},"

@@ -130,3 +130,19 @@ def test_errors_are_loud():
     model.cpu()
     with pytest.raises(RuntimeError):
         model.extract_embedding(np.zeros((10, 80), dtype=np.float32))      # no CPU fallback
+
+
+@pytest.mark.parametrize("name", ["extended_far", "extended_near_plain"])
+def test_extended_xvector_vs_reference_golden(name):
+    """E-TDNN blueprint on the device: f32 within 1e-4 of the reference, bf16 close and batch-invariant."""
+    g, sd, model = _gpu_model(name, "f32")
+    mats = helpers.golden_feats(g)
+    got = model.extract_embedding_batch(mats).numpy()
+    for i, (T, _) in enumerate(g["utts"]):
+        assert rel_err(got[i], g["embeddings"][i]) < TOL_F32, "%s: utterance of %d frames" % (name, T)
+    model.amd_precision = "bf16"
+    b = model.extract_embedding_batch(mats).numpy()
+    long_ones = [i for i, (T, _) in enumerate(g["utts"]) if T >= 64]
+    cos = [(b[i] * g["embeddings"][i]).sum() / np.linalg.norm(b[i]) / np.linalg.norm(g["embeddings"][i]) for i in long_ones]
+    assert min(cos) > 0.999, cos
+    assert np.array_equal(model.extract_embedding(mats[long_ones[0]]).numpy(), b[long_ones[0]])

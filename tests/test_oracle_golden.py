@@ -65,3 +65,16 @@ def test_traced_program_reproduces_reference_on_cpu():
     assert [op.kind for op in graph.ops] == ["tdnn"] * 5 + ["pool", "tdnn", "tdnn"]
     for x, ref in zip(helpers.golden_feats(g), g["embeddings"]):
         assert rel_err(ir_interp.extract(graph, x), ref) < 5e-6
+
+
+def test_extended_xvector_program_reproduces_reference_on_cpu():
+    """the E-TDNN blueprint (this repo's copy AND the traced program) against the embeddings the
+    reference's own model/extended_xvector.py produced (oracle/gen_golden.py extended_*)."""
+    from libs.amd import ir
+    for name, n_frame_layers in (("extended_far", 10), ("extended_near_plain", 5)):
+        g, sd, model = helpers.golden_model(name)                      # strict state_dict load = same keys and shapes
+        graph = ir.trace(model, type(model).extract_embedding.__wrapped_body__, int(g["dim"]))
+        kinds = [op.kind for op in graph.ops]
+        assert kinds[:n_frame_layers + 1] == ["tdnn"] * n_frame_layers + ["pool"] and set(kinds[n_frame_layers + 1:]) == {"tdnn"}
+        for x, ref in zip(helpers.golden_feats(g), g["embeddings"]):
+            assert rel_err(ir_interp.extract(graph, x), ref) < 5e-6, name
