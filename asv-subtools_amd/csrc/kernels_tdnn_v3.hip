@@ -418,6 +418,11 @@ __global__ __launch_bounds__(Geom3<WM>::WAVES * 64, WM == 0 ? 3 : 2) void tdnn_g
       }
     }
     if (cur_seg >= 0) flush();
+    if constexpr (ABL >= 5) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      STAMP3(3);
+    }
     return;
   }
   // ---- epilogue --------------------------------------------------------------------------
@@ -488,7 +493,10 @@ __global__ __launch_bounds__(Geom3<WM>::WAVES * 64, WM == 0 ? 3 : 2) void tdnn_g
 bool tdnn_big3_supported(const TdnnKernelParams &p, bool bf16, bool out_f32) {
   TdnnKernelParams q = p;
   q.pool_partial = nullptr;                       // the fused-pooling form has the same requirements otherwise
-  return p.wfrag != nullptr && tdnn_big_supported(q, bf16, out_f32);
+  // the window refill addresses rows with 32-bit byte offsets from a scalar base: activation matrices of 4 GiB and more
+  // (2 M rows x 1536 channels) go to the kernels with 64-bit addressing
+  const bool fits32 = (unsigned long long)p.rows * (unsigned long long)p.ldx * 2ull < (1ull << 32);
+  return p.wfrag != nullptr && fits32 && tdnn_big_supported(q, bf16, out_f32);
 }
 
 // variant = geometry * 100 + ablation code; geometry 0: 128 x 256 tiles (two workgroups per CU), 1: 256 x 256 (one),
@@ -506,7 +514,8 @@ int launch_tdnn_big3_variant(const TdnnKernelParams &p, int variant, hipStream_t
   const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first;
   if (p.pool_partial != nullptr) {
     ASV_REQUIRE(fast && p.row_seg != nullptr && p.pool_slots >= 1 && geom != 2, "tdnn(big3): fused pooling needs the plain epilogue, a row map and 128-row wave tiles");
-    if (geom == 0) hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, false, true, 1>), grid, block, 0, s, p, m_tiles, n_tiles);
+    if (geom == 0 && variant == 5) hipLaunchKernelGGL((tdnn_gemm_big3_kernel<5, false, true, 1>), grid, block, 0, s, p, m_tiles, n_tiles);
+    else if (geom == 0) hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, false, true, 1>), grid, block, 0, s, p, m_tiles, n_tiles);
     else hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, false, true, 2>), grid, block, 0, s, p, m_tiles, n_tiles);
     ASV_HIP_CHECK(hipGetLastError());
     return ASV_OK;

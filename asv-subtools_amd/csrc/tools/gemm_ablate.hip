@@ -67,11 +67,24 @@ int main(int argc, char **argv) {
     return 0;
   }
   p.act1 = ASV_ACT_RELU;
+  const bool pool_mode = getenv("ABLATE_POOL") != nullptr;
+  if (pool_mode) {
+    // utterances of 200 frames with 4 gap rows between them, like a C2 batch; fused statistics pooling epilogue
+    std::vector<int32_t> rs(rows, -1);
+    int seg = 0;
+    for (int r = 4; r + 200 <= rows; r += 204, ++seg) for (int k = 0; k < 200; ++k) rs[r + k] = seg;
+    std::vector<uint32_t> vb(rows / 32, 0);
+    for (int r = 0; r < rows; ++r) if (rs[r] >= 0) vb[r >> 5] |= 1u << (r & 31);
+    int32_t *drs; CK(hipMalloc(&drs, rows * 4)); CK(hipMemcpy(drs, rs.data(), rows * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(valid, vb.data(), rows / 8, hipMemcpyHostToDevice));
+    p.row_seg = drs; p.pool_slots = 2; p.ld_partial = cout_pad;
+    float *pp; CK(hipMalloc(&pp, (size_t)(rows / 128) * 2 * 2 * cout_pad * 4)); p.pool_partial = pp;
+  }
   p.tune = getenv("ABLATE_TUNE") ? (int)strtol(getenv("ABLATE_TUNE"), nullptr, 0) : 0;
   const double flops = 2.0 * rows * cin * cout * ntaps;
   printf("rows=%d cin=%d cout=%d taps=%d xpad=%d  (%.1f GFLOP)\n", rows, cin, cout, ntaps, xpad, flops / 1e9);
   const char *names[] = {"big: full", "big: no LDS-DMA in loop", "big: MFMA + barrier only", "big: DMA + ds_read, no MFMA", "big: no epilogue stores", "big: DMA (cache-hot) + ds_read", "small 128x128 (v1)", "big: DMA + barrier only", "big: ds_read + barrier only", "big3 (2 WG/CU): full", "big3 (2 WG/CU): MFMA only", "big3 (2 WG/CU): no epilogue stores", "big3 (1 WG/CU): full", "big3 (1 WG/CU): MFMA only", "big3 64-row (3 WG/CU): full", "big3 64-row (3 WG/CU): MFMA only"};
-  for (int v = 9; v <= 15; ++v) {
+  for (int v = 9; v <= (pool_mode ? 9 : 15); ++v) {
     for (int rep = 0; rep < 2; ++rep) {
       CK(hipEventRecord(a, 0));
       for (int i = 0; i < iters; ++i) {
@@ -86,7 +99,7 @@ int main(int argc, char **argv) {
   // ---- per-workgroup phase timeline of the default kernel (variants 5 / 6 write s_memrealtime stamps)
   const int tl_variants[] = {5, 6, 17, 18, 20, 19, 21, 22, 24, 29};
   const char *tl_names[] = {"full", "MFMA only", "no wf loads", "no ds_reads", "no DMA in loop", "no wf, no ds_reads", "no wf, no DMA", "no ds_reads, no DMA", "ds_reads to dummy regs", "ds_reads to dummy, no wf, no DMA"};
-  for (int vi = 0; vi < 10; ++vi) {
+  for (int vi = 0; vi < (pool_mode ? 1 : 10); ++vi) {
     const int variant = tl_variants[vi];
     const int n_wg = (rows / 128) * (cout_pad / 256);
     unsigned long long *dbg; CK(hipMalloc(&dbg, (size_t)n_wg * (64 + 1024))); CK(hipMemset(dbg, 0, (size_t)n_wg * (64 + 1024)));

@@ -146,3 +146,33 @@ def test_extended_xvector_vs_reference_golden(name):
     cos = [(b[i] * g["embeddings"][i]).sum() / np.linalg.norm(b[i]) / np.linalg.norm(g["embeddings"][i]) for i in long_ones]
     assert min(cos) > 0.999, cos
     assert np.array_equal(model.extract_embedding(mats[long_ones[0]]).numpy(), b[long_ones[0]])
+
+
+def test_full_size_c2_batch_properties():
+    """BASELINE configs[1] at full size (256 utterances x 200 frames x 80, bf16): the 128-row tile geometry with two
+    workgroups per CU and the fused pooling epilogue run here (small batches take the 64-row geometry).  No reference
+    output exists at this size, so the checks are size-independent properties: an utterance's embedding does not depend
+    on where it sits in the batch nor on the batch around it (up to the f32 summation order of the pooled statistics),
+    and a permuted batch gives the permuted result."""
+    from libs.amd import synth
+    g, sd, model = _gpu_model("xvector_near_ragged", "bf16")          # the C2 blueprint (80-dim), "near" position
+    base = [synth.synth_feats(200, 80, 40_000 + i) for i in range(64)]
+    probe = synth.synth_feats(200, 80, 41_000)
+    mats = [base[i % 64] for i in range(256)]
+    for pos in (0, 1, 100, 255):
+        mats[pos] = probe
+    full = model.extract_embedding_batch(mats).numpy()
+    assert full.shape == (256, 512) and np.isfinite(full).all()
+    alone = model.extract_embedding(probe).numpy()
+    for pos in (0, 1, 100, 255):
+        assert rel_err(full[pos], alone) < 2e-5, pos
+    # repeated utterances: rows 64 apart in the list hold the same features
+    assert rel_err(full[2], full[66]) < 2e-5 and rel_err(full[3], full[131]) < 2e-5
+    perm = np.random.RandomState(0).permutation(256)
+    again = model.extract_embedding_batch([mats[i] for i in perm]).numpy()
+    assert rel_err(again, full[perm]) < 2e-5
+    # and against f32 extraction of the same utterances: bf16 noise only
+    model.amd_precision = "f32"
+    ref = model.extract_embedding_batch([probe, base[2]]).numpy()
+    for a, b in ((full[0], ref[0]), (full[2], ref[1])):
+        assert (a * b).sum() / np.linalg.norm(a) / np.linalg.norm(b) > 0.9995
