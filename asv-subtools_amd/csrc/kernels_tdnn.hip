@@ -35,6 +35,7 @@ constexpr int BM = 128, BN = 128;
 constexpr int ROWB = 128;                     // bytes per LDS row = one K chunk
 constexpr int B_STAGE = BN * ROWB;            // 16384
 constexpr int kWideHalo = 84;                 // window halo of the 2-D (grid) instantiations: |tap| <= pitch + 1 <= 84
+constexpr int kMidHalo = 24;                  // grids of pitch <= 23 (ResNet stages 3 and 4 at 80-dim input: pitch 21 / 11): 176-row window, 77 KB, two workgroups per CU
 // window geometry for a given halo: HALO = 4 -> 136 rows, 67.6 KB of LDS, 2 workgroups / CU;
 // HALO = 84 (3x3 convolutions over row-flattened (time, frequency) grids) -> 296 rows, 108.5 KB
 template <int HALO> struct Geom {
@@ -49,7 +50,7 @@ static_assert(kRowTile % BM == 0, "row padding must be a multiple of the M tile"
 __device__ __forceinline__ int swz(int row, int slot) { return slot ^ ((row >> 1) & 7); }
 
 template <bool BF16, bool OUT_BF16, bool GENERIC, int HALO>
-__global__ __launch_bounds__(256, HALO <= 4 ? 2 : 1) void tdnn_gemm_kernel(const TdnnKernelParams p, int m_tiles, int n_tiles) {
+__global__ __launch_bounds__(256, HALO <= 24 ? 2 : 1) void tdnn_gemm_kernel(const TdnnKernelParams p, int m_tiles, int n_tiles) {
   using G = Geom<HALO>;
   constexpr int A_STAGE = G::A_STAGE, A_PIECES = G::A_PIECES, NA = G::NA;
   __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS_BYTES];
@@ -319,9 +320,11 @@ int launch_tdnn_mfma(const TdnnKernelParams &p, bool bf16, bool out_f32, hipStre
     ASV_REQUIRE(fast && p.x2 == nullptr, "tdnn: layers with |tap| > %d support the plain epilogue only", kHalo);
     if (bf16) {
       ASV_REQUIRE(!out_f32, "tdnn: wide-window bf16 layers produce bf16");
-      hipLaunchKernelGGL((tdnn_gemm_kernel<true, true, false, kWideHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
+      if (halo <= kMidHalo) hipLaunchKernelGGL((tdnn_gemm_kernel<true, true, false, kMidHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
+      else hipLaunchKernelGGL((tdnn_gemm_kernel<true, true, false, kWideHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
     } else {
-      hipLaunchKernelGGL((tdnn_gemm_kernel<false, false, false, kWideHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
+      if (halo <= kMidHalo) hipLaunchKernelGGL((tdnn_gemm_kernel<false, false, false, kMidHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
+      else hipLaunchKernelGGL((tdnn_gemm_kernel<false, false, false, kWideHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
     }
   } else if (bf16) {
     if (out_f32) {
