@@ -125,8 +125,8 @@ struct DevMem {
   size_t cap = 0;
 };
 
-const char *kKernelNames[] = {"tdnn_gemm", "stats_pool", "attentive_pool", "eltwise", "rowmap", "pack_input", "combine", "grid_gather"};
-enum { K_TDNN = 0, K_POOL, K_ATT, K_ELT, K_ROWMAP, K_PACK, K_COMBINE, K_GATHER, K_COUNT };
+const char *kKernelNames[] = {"tdnn_gemm", "stats_pool", "attentive_pool", "eltwise", "rowmap", "pack_input", "combine", "grid_gather", "utts_gemm"};
+enum { K_TDNN = 0, K_POOL, K_ATT, K_ELT, K_ROWMAP, K_PACK, K_COMBINE, K_GATHER, K_UTTS, K_COUNT };   // K_UTTS: affine layers of the pooled domain
 
 }  // namespace
 }  // namespace asv
@@ -898,7 +898,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
           valid_rows = 0;
           for (int32_t len : bp.dom[domid].seg_len) valid_rows += (double)(len / net->domains[domid].pitch) * net->domains[domid].width;
         }
-        if ((rc = prof.begin(K_TDNN, 2.0 * valid_rows * d.in_ch * d.out_ch * d.n_taps, (int)i))) return rc;
+        if ((rc = prof.begin(op.utts ? K_UTTS : K_TDNN, 2.0 * valid_rows * d.in_ch * d.out_ch * d.n_taps, (int)i))) return rc;
         const bool fuse = big3 && pool_slots > 0;
         if (fuse) {
           p.pool_slots = pool_slots;

@@ -180,7 +180,10 @@ def main():
         achieved = gemm["flops"] / (gemm["total_ms"] * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.precision]
         per_frame, per_utt = eng.graph.flops_per_frame()
-        res["roofline"] = {"bound": "mfma", "kernel": "tdnn_gemm_kernel (all TDNN/affine layers)", "achieved": round(achieved, 2), "peak": peak,
+        kname = {"xvector": "tdnn_gemm_big3_kernel (the frame-level layers tdnn1-5: 5 launches per step, the last one with the fused pooling epilogue)",
+                 "ecapa": "frame-level GEMM launches (tdnn_gemm_big3_kernel for the wide layers, tdnn_gemm_kernel for the 128-channel ones)",
+                 "resnet": "frame-level GEMM launches (grid_conv_narrow_kernel / tdnn_gemm_kernel)"}[args.model]
+        res["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": peak,
                            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
                            "launches": gemm["launches"], "avg_launch_us": round(1e3 * gemm["total_ms"] / gemm["launches"], 2),
                            "algorithmic_gflop_per_utt": round((per_frame * T + per_utt) / 1e9, 4)}
