@@ -202,6 +202,8 @@ class Engine(object):
         """mats: list of [T_i, D] array-likes (host).  Returns a CPU float32 tensor [B, E]."""
         import torch
         mats = [np.asarray(m, dtype=np.float32) for m in mats]
+        if not mats:                                  # an empty feature archive is not an error in the reference's loop either
+            return torch.empty((0, self.embed_dim), dtype=torch.float32)
         for m in mats:
             if m.ndim != 2 or m.shape[1] != self.feat_dim:
                 raise ValueError("expected [frames, %d] feature matrices, got %s" % (self.feat_dim, m.shape))

@@ -176,3 +176,15 @@ def test_full_size_c2_batch_properties():
     ref = model.extract_embedding_batch([probe, base[2]]).numpy()
     for a, b in ((full[0], ref[0]), (full[2], ref[1])):
         assert (a * b).sum() / np.linalg.norm(a) / np.linalg.norm(b) > 0.9995
+
+
+def test_empty_batch_and_zero_frame_utterance():
+    """An empty list is an empty result (the reference's loop simply does not run); an utterance without frames is an
+    error there (conv1d on an empty axis) and an exception here, not a crash or a silent zero vector."""
+    g, sd, model = _gpu_model("xvector_near_ragged", "f32")
+    out = model.extract_embedding_batch([])
+    assert tuple(out.shape) == (0, 512)
+    with pytest.raises(Exception):
+        model.extract_embedding_batch([np.zeros((0, 80), dtype=np.float32)])
+    ok = model.extract_embedding_batch(helpers.golden_feats(g)[:2]).numpy()   # the engine is still usable afterwards
+    assert rel_err(ok, g["embeddings"][:2]) < TOL_F32
