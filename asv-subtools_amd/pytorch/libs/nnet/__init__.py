@@ -8,7 +8,7 @@ resolves to a placeholder that raises when constructed (libs/nnet/loss.py)."""
 import importlib as _importlib
 
 # order matters only for readability: boundary first, then layers, pooling, 2-D trunk, placeholders
-_SUBMODULES = ("framework", "activation", "components", "pooling", "resnet", "loss")
+_SUBMODULES = ("framework", "activation", "components", "dropout", "pooling", "resnet", "loss")
 
 for _name in _SUBMODULES:
     _mod = _importlib.import_module("." + _name, __name__)

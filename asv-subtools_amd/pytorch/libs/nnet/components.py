@@ -159,6 +159,32 @@ class ReluBatchNormTdnnLayer(_BaseActivationBatchNorm):
         self.add_relu_bn(output_dim, options=options)
 
 
+class SEBlock(torch.nn.Module):
+    """Squeeze-and-excitation over time for [B, C, T] (reference components.py:565-598): mean over the frames of the
+    utterance -> TdnnAffine C -> C/ratio -> ReLU -> TdnnAffine -> Sigmoid -> channel scale.  On the device: one mean
+    pooling pass, two pooled-domain GEMMs and one elementwise pass with a per-utterance scale (the same ops the
+    ECAPA blueprint's own SE_Connect lowers to)."""
+
+    def __init__(self, input_dim, ratio=16, inplace=True):
+        super(SEBlock, self).__init__()
+        self.input_dim = input_dim
+        self.fc_1 = TdnnAffine(input_dim, input_dim // ratio)
+        self.relu = torch.nn.ReLU(inplace=inplace)
+        self.fc_2 = TdnnAffine(input_dim // ratio, input_dim)
+        self.sigmoid = torch.nn.Sigmoid()
+
+    def forward(self, inputs):
+        if not isinstance(inputs, _ir.Sym):
+            _eager_unsupported("SEBlock")
+        if inputs.view.channels != self.input_dim:
+            raise _ir.TraceError("SEBlock expects %d channels, got %d" % (self.input_dim, inputs.view.channels))
+        g = inputs.graph
+        squeezed = _ir.Sym(g, g.pool(inputs.view, stddev=False), 3)
+        hidden = self.fc_1.emit(squeezed, act1="relu")
+        gate = self.fc_2.emit(hidden, act1="sigmoid")
+        return _ir.Sym(g, g.eltwise(inputs.view, seg_scale=gate.view), 3)
+
+
 class SEBlock_2D(torch.nn.Module):
     """Squeeze-and-excitation over [B, C, F, T] (reference components.py:600-639):
     global average over (F, T) -> Linear C->C/ratio -> ReLU -> Linear -> Sigmoid -> scale.

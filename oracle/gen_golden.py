@@ -84,6 +84,14 @@ CASES = {
     "extended_near_plain": dict(blueprint="extended_xvector.py",
                                 creation="ExtendedXvector(40,10,extend=False,training=False,extracted_embedding='near')", dim=40,
                                 utts=[(150, 6100), (64, 6101)], wseed=10),
+    # the composite ("snowdar") x-vector: defaults; every structural option at once; no tdnn6
+    "snowdar_default": dict(blueprint="snowdar_xvector.py", creation="Xvector(40,10,training=False)", dim=40,
+                            utts=[(200, 6200), (31, 6201)], wseed=11),
+    "snowdar_full_near": dict(blueprint="snowdar_xvector.py",
+                              creation="Xvector(40,10,training=False,extend=True,skip_connection=True,SE=True,extracted_embedding='near')", dim=40,
+                              utts=[(200, 6300), (77, 6301), (3, 6302)], wseed=12),
+    "snowdar_no_tdnn6": dict(blueprint="snowdar_xvector.py", creation="Xvector(40,10,training=False,tdnn6=False,extracted_embedding='near_affine')",
+                             dim=40, utts=[(120, 6400)], wseed=13),
     # BASELINE config C5 extractor: ResNet34-SE (32-64-128-256), launcher-style fc2 (runResnetXvector_online.py:221-260)
     "resnet34se_c5": dict(blueprint="resnet_xvector.py",
                           creation="ResNetXvector(80,10,training=False,resnet_params={'use_se':True,'se_ratio':4,'full_pre_activation':False},"

@@ -188,3 +188,17 @@ def test_empty_batch_and_zero_frame_utterance():
         model.extract_embedding_batch([np.zeros((0, 80), dtype=np.float32)])
     ok = model.extract_embedding_batch(helpers.golden_feats(g)[:2]).numpy()   # the engine is still usable afterwards
     assert rel_err(ok, g["embeddings"][:2]) < TOL_F32
+
+
+@pytest.mark.parametrize("name", ["snowdar_default", "snowdar_full_near", "snowdar_no_tdnn6"])
+def test_snowdar_xvector_vs_reference_golden(name):
+    """Composite x-vector blueprint on the device: f32 within 1e-4 of the reference; bf16 close."""
+    g, sd, model = _gpu_model(name, "f32")
+    mats = helpers.golden_feats(g)
+    got = model.extract_embedding_batch(mats).numpy()
+    for i, (T, _) in enumerate(g["utts"]):
+        assert rel_err(got[i], g["embeddings"][i]) < TOL_F32, "%s: utterance of %d frames" % (name, T)
+    model.amd_precision = "bf16"
+    b = model.extract_embedding_batch(mats).numpy()
+    i = 0                                                              # the first utterance of every case is a long one
+    assert (b[i] * g["embeddings"][i]).sum() / np.linalg.norm(b[i]) / np.linalg.norm(g["embeddings"][i]) > 0.999

@@ -78,3 +78,16 @@ def test_extended_xvector_program_reproduces_reference_on_cpu():
         assert kinds[:n_frame_layers + 1] == ["tdnn"] * n_frame_layers + ["pool"] and set(kinds[n_frame_layers + 1:]) == {"tdnn"}
         for x, ref in zip(helpers.golden_feats(g), g["embeddings"]):
             assert rel_err(ir_interp.extract(graph, x), ref) < 5e-6, name
+
+
+def test_snowdar_xvector_program_reproduces_reference_on_cpu():
+    """the composite x-vector blueprint (extension layers, 1-D SE blocks, skip connection, optional
+    tdnn6, three embedding positions) against the reference's own model/snowdar_xvector.py outputs."""
+    from libs.amd import ir
+    for name in ("snowdar_default", "snowdar_full_near", "snowdar_no_tdnn6"):
+        g, sd, model = helpers.golden_model(name)                      # strict load: same state_dict keys and shapes
+        graph = ir.trace(model, type(model).extract_embedding.__wrapped_body__, int(g["dim"]))
+        if name == "snowdar_full_near":
+            assert [op.kind for op in graph.ops].count("eltwise") == 4     # four SE gates; the skip add rides on tdnn5's loader
+        for x, ref in zip(helpers.golden_feats(g), g["embeddings"]):
+            assert rel_err(ir_interp.extract(graph, x), ref) < 1e-5, name
