@@ -21,6 +21,10 @@ import os
 import sys
 import time
 
+# RCCL / device-tensor sharing across the ranks of one node needs dmabuf IPC on these hosts (already exported by the
+# launch environment; set here too so a bare `torchrun bench.py` works)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [os.path.join(REPO, "asv-subtools_amd", "pytorch"), REPO]
 
