@@ -159,6 +159,42 @@ class ReluBatchNormTdnnLayer(_BaseActivationBatchNorm):
         self.add_relu_bn(output_dim, options=options)
 
 
+class FTdnnBlock(torch.nn.Module):
+    """Factorised TDNN block (reference components.py:168-212): a bias-free `factor` affine into a bottleneck over the
+    left half of the context, an `affine` back out over the right half, ReLU, BatchNorm, and `bypass_scale` times the
+    block input added on top.  On the device: two fused TDNN GEMMs (the second one carries ReLU + folded BN) and, when
+    there is a bypass, one elementwise pass  identity * bypass_scale + out.  The semi-orthogonal constraint is a
+    training-time weight update and has no extraction counterpart."""
+
+    def __init__(self, input_dim, output_dim, bottleneck_dim, context_size=0, bypass_scale=0.66, pad=True):
+        super(FTdnnBlock, self).__init__()
+        self.input_dim, self.output_dim, self.bottleneck_dim = input_dim, output_dim, bottleneck_dim
+        self.context_size, self.bypass_scale, self.pad = context_size, bypass_scale, pad
+        left, right = ([-context_size, 0], [0, context_size]) if context_size > 0 else ([0], [0])
+        self.factor = TdnnAffine(input_dim, bottleneck_dim, left, pad=pad, bias=False)
+        self.affine = TdnnAffine(bottleneck_dim, output_dim, right, pad=pad, bias=True)
+        self.relu = torch.nn.ReLU(inplace=True)
+        self.bn = torch.nn.BatchNorm1d(output_dim, momentum=0.1, affine=True, track_running_stats=True)
+
+    def forward(self, inputs):
+        if not isinstance(inputs, _ir.Sym):
+            _eager_unsupported("FTdnnBlock")
+        if self.bypass_scale != 0 and self.input_dim != self.output_dim:
+            raise _ir.TraceError("FTdnnBlock: a bypass needs equal input and output widths (%d vs %d)" % (self.input_dim, self.output_dim))
+        bn = self.bn
+        scale, shift = _ir.fold_batchnorm(bn.running_mean.detach().cpu().numpy(), bn.running_var.detach().cpu().numpy(),
+                                          bn.weight.detach().cpu().numpy() if bn.affine else None,
+                                          bn.bias.detach().cpu().numpy() if bn.affine else None, bn.eps)
+        out = self.affine.emit(self.factor.emit(inputs), act1="relu", scale=scale, shift=shift)
+        if self.bypass_scale == 0:
+            return out
+        import numpy as np
+        g = inputs.graph
+        c = inputs.view.channels
+        mixed = g.eltwise(inputs.view, b=out.view, scale=np.full(c, self.bypass_scale, dtype=np.float32), shift=np.zeros(c, dtype=np.float32))
+        return _ir.Sym(g, mixed, 3)
+
+
 class SEBlock(torch.nn.Module):
     """Squeeze-and-excitation over time for [B, C, T] (reference components.py:565-598): mean over the frames of the
     utterance -> TdnnAffine C -> C/ratio -> ReLU -> TdnnAffine -> Sigmoid -> channel scale.  On the device: one mean

@@ -92,6 +92,11 @@ CASES = {
                               utts=[(200, 6300), (77, 6301), (3, 6302)], wseed=12),
     "snowdar_no_tdnn6": dict(blueprint="snowdar_xvector.py", creation="Xvector(40,10,training=False,tdnn6=False,extracted_embedding='near_affine')",
                              dim=40, utts=[(120, 6400)], wseed=13),
+    # the factorised TDNN (TDNN-F) x-vector with its dense skip wiring, both positions
+    "factored_far": dict(blueprint="factored_xvector.py", creation="Xvector(40,10,training=False)", dim=40,
+                         utts=[(200, 6500), (45, 6501), (7, 6502)], wseed=14),
+    "factored_near": dict(blueprint="factored_xvector.py", creation="Xvector(40,10,training=False,extracted_embedding='near',embd_dim=256)", dim=40,
+                          utts=[(150, 6600)], wseed=15),
     # BASELINE config C5 extractor: ResNet34-SE (32-64-128-256), launcher-style fc2 (runResnetXvector_online.py:221-260)
     "resnet34se_c5": dict(blueprint="resnet_xvector.py",
                           creation="ResNetXvector(80,10,training=False,resnet_params={'use_se':True,'se_ratio':4,'full_pre_activation':False},"

@@ -124,7 +124,8 @@ REF_MODEL_DIR = "/root/reference/pytorch/model"
                                                        ("resnet_xvector.py", "ResNetXvector(61,10,training=False,resnet_params={'full_pre_activation':False})", "resnet34_plain"),
                                                        ("extended_xvector.py", "ExtendedXvector(40,10,training=False)", "extended_far"),
                                                        ("snowdar_xvector.py", "Xvector(40,10,training=False,extend=True,skip_connection=True,SE=True,extracted_embedding='near')",
-                                                        "snowdar_full_near")])
+                                                        "snowdar_full_near"),
+                                                       ("factored_xvector.py", "Xvector(40,10,training=False)", "factored_far")])
 def test_unmodified_reference_blueprints_run_on_this_libs_nnet(blueprint, creation, golden):
     """Drop-in check: the reference's OWN blueprint files import this package's `libs.nnet`,
     build, load the checkpoint keys and record to a program that reproduces the reference."""
@@ -142,7 +143,7 @@ import libs.support.utils as utils
 from libs.amd import ir
 g, sd = helpers.golden_state_dict(%(golden)r)
 model = utils.create_model_from_py(%(ref)r + "/" + %(bp)r, %(creation)r)
-assert type(model).__module__ in ("xvector", "ecapa_tdnn_xvector", "resnet_xvector", "extended_xvector", "snowdar_xvector") and %(ref)r in sys.modules[type(model).__module__].__file__
+assert type(model).__module__ in ("xvector", "ecapa_tdnn_xvector", "resnet_xvector", "extended_xvector", "snowdar_xvector", "factored_xvector") and %(ref)r in sys.modules[type(model).__module__].__file__
 model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
 graph = ir.trace(model, type(model).extract_embedding.__wrapped_body__, int(g["dim"]))
 x = helpers.golden_feats(g)[-1]

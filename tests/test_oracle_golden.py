@@ -91,3 +91,15 @@ def test_snowdar_xvector_program_reproduces_reference_on_cpu():
             assert [op.kind for op in graph.ops].count("eltwise") == 4     # four SE gates; the skip add rides on tdnn5's loader
         for x, ref in zip(helpers.golden_feats(g), g["embeddings"]):
             assert rel_err(ir_interp.extract(graph, x), ref) < 1e-5, name
+
+
+def test_factored_xvector_program_reproduces_reference_on_cpu():
+    """the TDNN-F blueprint (FTdnnBlock = factor + affine + ReLU + BN + scaled bypass, dense skips by
+    concatenation) against the reference's own model/factored_xvector.py outputs."""
+    from libs.amd import ir
+    for name in ("factored_far", "factored_near"):
+        g, sd, model = helpers.golden_model(name)
+        graph = ir.trace(model, type(model).extract_embedding.__wrapped_body__, int(g["dim"]))
+        assert [op.kind for op in graph.ops].count("tdnn") >= 19            # 1 + 8 x 2 + layer10 + embedding layer(s)
+        for x, ref in zip(helpers.golden_feats(g), g["embeddings"]):
+            assert rel_err(ir_interp.extract(graph, x), ref) < 1e-5, name
