@@ -363,6 +363,177 @@ def read_mat_ark_batched(file_or_fd, max_frames=65536, max_utts=1024):
         yield _pack_group(keys, mats)
 
 
+class PackedArkReader(object):
+    """Sequential reader of a float-matrix ark stream into caller-owned packed buffers - the feed of the batched
+    extractor (pinned host memory the H2D copy starts from).  Keys and headers are parsed out of small block reads (8 KiB);
+    the bulk of every uncompressed float32 payload lies past the block and is `readinto` straight into the destination
+    rows (one copy, page cache -> pinned buffer): no per-utterance Python objects besides the key.  float64, compressed ('CM ') and text matrices
+    take the generic decoders above and are converted on the way in.
+
+        rd = PackedArkReader(fd)
+        dim = rd.peek_dim()                                   # feature dimension of the first matrix (None: empty stream)
+        keys, offsets, n = rd.read_group(feats, max_utts)     # fills feats[:n]; keys == [] at end of stream
+    """
+
+    def __init__(self, fd, block=1 << 13):
+        self.fd = fd
+        self.block = block
+        self.buf = b""
+        self.pos = 0
+        self.eof = False
+        self._pending = None                                  # (key, rows, cols, kind) parsed but not consumed yet
+
+    # -- byte supply ---------------------------------------------------------------------------------
+    def _avail(self):
+        return len(self.buf) - self.pos
+
+    def _fill(self, need):
+        """Makes at least `need` bytes available at self.pos (fewer only at end of stream)."""
+        while self._avail() < need and not self.eof:
+            chunk = self.fd.read(max(self.block, need - self._avail()))
+            if not chunk:
+                self.eof = True
+                break
+            self.buf = self.buf[self.pos:] + chunk if self._avail() else chunk
+            self.pos = 0
+        return self._avail() >= need
+
+    def read(self, n):                                        # file-like face for the generic decoders
+        self._fill(n)
+        out = self.buf[self.pos:self.pos + n]
+        self.pos += len(out)
+        return out
+
+    def readline(self):
+        while True:
+            k = self.buf.find(b"\n", self.pos)
+            if k >= 0 or self.eof:
+                break
+            self._fill(self._avail() + 1)
+        end = len(self.buf) if k < 0 else k + 1
+        out = self.buf[self.pos:end]
+        self.pos = end
+        return out
+
+    # -- records --------------------------------------------------------------------------------------
+    def _next_header(self):
+        if self._pending is not None:
+            return self._pending
+        while True:                                           # key: bytes up to the first space
+            k = self.buf.find(b" ", self.pos)
+            if k >= 0 or self.eof:
+                break
+            self._fill(self._avail() + 1)
+        if k < 0:
+            if self.buf[self.pos:].strip():
+                raise BadInputFormat("trailing bytes without a key terminator at the end of the ark stream")
+            return None
+        key = self.buf[self.pos:k].decode("latin1").strip()
+        self.pos = k + 1
+        if key == "":
+            return None
+        if not self._fill(2):
+            raise BadInputFormat("ark entry '%s' ends after its key" % key)
+        flag = self.buf[self.pos:self.pos + 2]
+        if flag != b"\0B":                                     # text matrix: leave the stream at the ' [' for read_mat
+            self._pending = (key, -1, -1, "generic")
+            return self._pending
+        if not self._fill(5):
+            raise BadInputFormat("ark entry '%s': truncated header" % key)
+        tag = self.buf[self.pos + 2:self.pos + 5]
+        if tag in (b"FM ", b"DM "):
+            if not self._fill(15):
+                raise BadInputFormat("ark entry '%s': truncated header" % key)
+            s1, rows, s2, cols = struct.unpack_from("<bibi", self.buf, self.pos + 5)
+            self.pos += 15
+            self._pending = (key, rows, cols, "f4" if tag == b"FM " else "f8")
+        else:
+            self._pending = (key, -1, -1, "generic")          # 'CM ' and friends: decoded by read_mat
+        return self._pending
+
+    def peek_dim(self):
+        h = self._next_header()
+        if h is None:
+            return None
+        if h[3] == "generic":                                 # decode it now, keep the matrix for read_group
+            m = np.ascontiguousarray(read_mat(self), dtype=np.float32)
+            self._pending = (h[0], m.shape[0], m.shape[1], m)
+            return m.shape[1]
+        return h[2]
+
+    def _payload_into(self, dst, nbytes):
+        """nbytes of payload -> the writable byte view `dst`."""
+        have = min(self._avail(), nbytes)
+        if have:
+            dst[:have] = np.frombuffer(self.buf, dtype=np.uint8, count=have, offset=self.pos)
+            self.pos += have
+        got = have
+        while got < nbytes:                                   # past the block: straight from the stream
+            if hasattr(self.fd, "readinto"):
+                k = self.fd.readinto(dst[got:nbytes])
+            else:
+                chunk = self.fd.read(nbytes - got)
+                k = len(chunk)
+                dst[got:got + k] = np.frombuffer(chunk, dtype=np.uint8)
+            if not k:
+                raise BadInputFormat("unexpected end of stream inside a matrix (wanted %d more bytes)" % (nbytes - got))
+            got += k
+
+    def read_group(self, feats, max_utts=1024):
+        """Fills feats [capacity, D] float32 (C-contiguous) with the next utterances that fit; returns
+        (keys, offsets int32 [n+1], frames).  An utterance longer than the whole buffer is returned alone as
+        (keys=[key], offsets, its own array) - the caller sees `frames > capacity` and uses the third value as the data."""
+        cap, dim = feats.shape
+        flat = feats.reshape(-1).view(np.uint8)
+        keys, offs, used = [], [0], 0
+        while len(keys) < max_utts:
+            h = self._next_header()
+            if h is None:
+                break
+            key, rows, cols, kind = h
+            if kind == "generic":
+                m = np.ascontiguousarray(read_mat(self), dtype=np.float32)
+                self._pending = h = (key, m.shape[0], m.shape[1], m)
+                key, rows, cols, kind = h
+            if cols != dim:
+                raise BadInputFormat("ark entry '%s' has %d columns, the stream started with %d" % (key, cols, dim))
+            if rows > cap:
+                if keys:
+                    break                                     # flush what we have first
+                self._pending = None
+                if isinstance(kind, np.ndarray):
+                    big = kind
+                else:
+                    big = np.empty((rows, cols), dtype=np.float32 if kind == "f4" else np.float64)
+                    self._payload_into(big.reshape(-1).view(np.uint8), big.nbytes)
+                    big = big.astype(np.float32, copy=False)
+                return [key], np.array([0, rows], dtype=np.int32), big
+            if used + rows > cap:
+                break
+            self._pending = None
+            if isinstance(kind, np.ndarray):
+                feats[used:used + rows] = kind
+            elif kind == "f4":
+                self._payload_into(flat[used * dim * 4:(used + rows) * dim * 4], rows * dim * 4)
+            else:
+                tmp = np.empty((rows, cols), dtype=np.float64)
+                self._payload_into(tmp.reshape(-1).view(np.uint8), tmp.nbytes)
+                feats[used:used + rows] = tmp
+            keys.append(key)
+            used += rows
+            offs.append(used)
+        return keys, np.asarray(offs, dtype=np.int32), used
+
+
+def vec_flt_ark_bytes(keys, vectors):
+    """One bytes object holding the binary ark entries `key SP \\0B FV \\4 dim data` of float32 row vectors [n, dim]
+    (write_vec_flt's format, assembled per batch instead of written per key)."""
+    vectors = np.ascontiguousarray(vectors, dtype=np.float32)
+    head = b"\0BFV \4" + struct.pack("<I", vectors.shape[1])
+    rows = vectors.view(np.uint8).reshape(vectors.shape[0], -1)
+    return b"".join([(k + " ").encode("latin1") + head + rows[i].tobytes() for i, k in enumerate(keys)])
+
+
 def _pack_group(keys, mats):
     offsets = np.zeros(len(mats) + 1, dtype=np.int32)
     np.cumsum([m.shape[0] for m in mats], out=offsets[1:])

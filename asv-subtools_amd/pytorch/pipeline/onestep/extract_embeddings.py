@@ -48,6 +48,87 @@ def get_args(argv=None):
     return parser.parse_args(argv)
 
 
+def extract_stream(model, r, w, batch_frames, batch_utts, max_chunk, verbose=False):
+    """feature ark stream -> embedding ark stream, pipelined in three stages over two buffer sets:
+      reader thread   next packed batch -> pinned host buffer   (kaldi_io.PackedArkReader: block reads, no per-utterance arrays)
+      device          async H2D, asv_net_extract, async D2H into a pinned result buffer   (one stream, in order)
+      writer          previous batch's vectors -> one write() of the assembled ark bytes
+    so reading batch i+1 and writing batch i-1 overlap the device work of batch i.  Output order = input order."""
+    import queue
+    import threading
+    engine = model._amd_engine()
+    method = type(model).extract_embedding
+    if max_chunk is None:
+        max_chunk = getattr(method, "max_chunk", 10000)
+    reader = kaldi_io.PackedArkReader(r)
+    dim = reader.peek_dim()
+    if dim is None:
+        return 0
+    if dim != engine.feat_dim:
+        raise ValueError("the archive holds %d-dimensional features, the model expects %d" % (dim, engine.feat_dim))
+    dev = torch.device("cuda", engine.device_index)
+    n_sets = 2
+    host_in = [torch.empty((batch_frames, dim), dtype=torch.float32).pin_memory() for _ in range(n_sets)]
+    host_np = [t.numpy() for t in host_in]
+    dev_in = [torch.empty((batch_frames, dim), dtype=torch.float32, device=dev) for _ in range(n_sets)]
+    dev_out = [torch.empty((batch_utts, engine.embed_dim), dtype=torch.float32, device=dev) for _ in range(n_sets)]
+    host_out = [torch.empty((batch_utts, engine.embed_dim), dtype=torch.float32).pin_memory() for _ in range(n_sets)]
+    done = [torch.cuda.Event() for _ in range(n_sets)]
+    free_sets, batches = queue.Queue(), queue.Queue()
+    for k in range(n_sets):
+        free_sets.put(k)
+
+    def produce():
+        try:
+            while True:
+                k = free_sets.get()
+                keys, offsets, frames = reader.read_group(host_np[k], batch_utts)
+                batches.put((k, keys, offsets, frames))
+                if not keys:
+                    return
+        except BaseException as e:                    # surfaces in the consumer
+            batches.put(e)
+
+    t = threading.Thread(target=produce, daemon=True)
+    t.start()
+    n_done, in_flight = 0, None
+
+    def finish(item):
+        k, keys, n = item
+        done[k].synchronize()
+        if verbose:
+            for key in keys:
+                print("Process utterance for key {0}".format(key))
+        w.write(kaldi_io.vec_flt_ark_bytes(keys, host_out[k][:n].numpy()))
+        free_sets.put(k)
+        return n
+
+    with torch.cuda.device(dev):
+        while True:
+            item = batches.get()
+            if isinstance(item, BaseException):
+                raise item
+            k, keys, offsets, frames = item
+            if not keys:
+                break
+            n = len(keys)
+            if isinstance(frames, np.ndarray):        # one utterance longer than a whole batch buffer
+                feats = torch.from_numpy(frames).to(dev)
+            else:
+                feats = dev_in[k][:frames]
+                feats.copy_(host_in[k][:frames], non_blocking=True)
+            out = engine.extract_device(feats, offsets, max_chunk=max_chunk, out=dev_out[k][:n])
+            host_out[k][:n].copy_(out, non_blocking=True)
+            done[k].record()
+            if in_flight is not None:
+                n_done += finish(in_flight)
+            in_flight = (k, keys, n)
+        if in_flight is not None:
+            n_done += finish(in_flight)
+    t.join()
+    return n_done
+
+
 def main(argv=None):
     print(" ".join(sys.argv))
     args = get_args(argv)
@@ -70,14 +151,7 @@ def main(argv=None):
 
         n_done = 0
         with kaldi_io.open_or_fd(args.feats_rspecifier, "rb") as r, kaldi_io.open_or_fd(args.vectors_wspecifier, "wb") as w:
-            for keys, feats, offsets in kaldi_io.read_mat_ark_batched(r, max_frames=args.batch_frames, max_utts=args.batch_utts):
-                mats = [feats[offsets[i]:offsets[i + 1]] for i in range(len(keys))]
-                emb = model.extract_embedding_batch(mats, max_chunk=max_chunk).numpy()
-                for key, vec in zip(keys, emb):
-                    if verbose:
-                        print("Process utterance for key {0}".format(key))
-                    kaldi_io.write_vec_flt(w, np.ascontiguousarray(vec), key=key)
-                n_done += len(keys)
+            n_done = extract_stream(model, r, w, args.batch_frames, args.batch_utts, max_chunk, verbose)
         print("Extracted {0} embeddings.".format(n_done))
     except BaseException as e:
         if not isinstance(e, KeyboardInterrupt):

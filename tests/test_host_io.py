@@ -156,3 +156,54 @@ def test_training_side_is_absent_not_faked():
         model.tdnn1(torch.zeros(1, 30, 50))
     with pytest.raises(RuntimeError):                     # CPU model: no fallback
         model.extract_embedding(np.zeros((50, 30), dtype=np.float32))
+
+
+def test_packed_ark_reader_and_batch_vector_writer():
+    """The bulk feed of the extraction script: block-parsed headers, payloads copied / read straight into a caller-owned
+    packed buffer; float64 entries, entries longer than the buffer, group limits, streams without readinto; the batch
+    vector writer emits exactly write_vec_flt's bytes."""
+    import io
+    from libs.support import kaldi_io as K
+    rng = np.random.RandomState(0)
+    mats = [rng.randn(t, 7).astype(np.float32) for t in (3, 1, 50, 200, 17, 999, 5)]
+    bio = io.BytesIO()
+    for i, m in enumerate(mats):
+        K.write_mat(bio, m.astype(np.float64) if i == 2 else m, key="k%d" % i)
+    data = bio.getvalue()
+
+    class ReadOnly(object):
+        def __init__(self, b):
+            self.b = io.BytesIO(b)
+
+        def read(self, n):
+            return self.b.read(n)
+
+    for block in (16, 1000, 1 << 20):
+        for make in (io.BytesIO, ReadOnly):
+            rd = K.PackedArkReader(make(data), block=block)
+            assert rd.peek_dim() == 7
+            buf, got, sizes = np.empty((256, 7), np.float32), [], []
+            while True:
+                keys, offs, n = rd.read_group(buf, max_utts=3)
+                if not keys:
+                    break
+                sizes.append(len(keys))
+                if isinstance(n, np.ndarray):                        # 999 frames do not fit the 256-frame buffer
+                    got.append((keys[0], n.copy()))
+                else:
+                    got.extend((k, buf[offs[j]:offs[j + 1]].copy()) for j, k in enumerate(keys))
+            assert [k for k, _ in got] == ["k%d" % i for i in range(7)] and max(sizes) <= 3
+            for (k, g), m in zip(got, mats):
+                assert np.array_equal(g, m), k
+    assert K.PackedArkReader(io.BytesIO(b"")).peek_dim() is None
+    with pytest.raises(K.BadInputFormat):
+        rd = K.PackedArkReader(io.BytesIO(data[:-5]))
+        rd.peek_dim()
+        while rd.read_group(np.empty((2048, 7), np.float32))[0]:
+            pass
+    v = rng.randn(4, 5).astype(np.float32)
+    blob = K.vec_flt_ark_bytes(["a", "bb", "c", "d"], v)
+    ref = io.BytesIO()
+    for i, k in enumerate(["a", "bb", "c", "d"]):
+        K.write_vec_flt(ref, v[i], key=k)
+    assert blob == ref.getvalue()
