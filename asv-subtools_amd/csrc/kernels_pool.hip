@@ -231,11 +231,12 @@ __global__ __launch_bounds__(64) void pool_finish_kernel(const PoolFinishParams 
   }
 }
 
-// ECAPA attentive statistics (ecapa_tdnn_xvector.py:182-188).
+// ECAPA attentive statistics (ecapa_tdnn_xvector.py:182-188) and, with `shared`, the single shared head of
+// AttentiveStatisticsPooling (libs/nnet/pooling.py:322-370): one logit per frame (column 0 of `logits`) for all channels.
 template <bool BF16>
 __global__ __launch_bounds__(256) void attentive_pool_kernel(const void *x, int ldx, const void *logits, int ldl,
                                                              int channels, const int32_t *seg_row0,
-                                                             const int32_t *seg_len, float eps, float *out, int ld_out) {
+                                                             const int32_t *seg_len, float eps, float *out, int ld_out, int shared) {
   constexpr int VEC = BF16 ? 8 : 4;
   constexpr int CG = 64 / VEC;
   constexpr int RS = 64 / CG;
@@ -252,7 +253,13 @@ __global__ __launch_bounds__(256) void attentive_pool_kernel(const void *x, int 
   if (active)
     for (int r = wave * RS + rs; r < len; r += 4 * RS) {
       float e[VEC];
-      load_vec<BF16, VEC>(logits, (size_t)(row0 + r) * ldl + ch, e);
+      if (shared) {
+        const float e0 = load_elem<BF16>(logits, (size_t)(row0 + r) * ldl);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) e[i] = e0;
+      } else {
+        load_vec<BF16, VEC>(logits, (size_t)(row0 + r) * ldl + ch, e);
+      }
 #pragma unroll
       for (int i = 0; i < VEC; ++i) mx[i] = fmaxf(mx[i], e[i]);
     }
@@ -264,7 +271,13 @@ __global__ __launch_bounds__(256) void attentive_pool_kernel(const void *x, int 
   if (active)
     for (int r = wave * RS + rs; r < len; r += 4 * RS) {
       float e[VEC], v[VEC];
-      load_vec<BF16, VEC>(logits, (size_t)(row0 + r) * ldl + ch, e);
+      if (shared) {
+        const float e0 = load_elem<BF16>(logits, (size_t)(row0 + r) * ldl);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) e[i] = e0;
+      } else {
+        load_vec<BF16, VEC>(logits, (size_t)(row0 + r) * ldl + ch, e);
+      }
       load_vec<BF16, VEC>(x, (size_t)(row0 + r) * ldx + ch, v);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
@@ -509,12 +522,13 @@ int launch_pool_finish(const PoolFinishParams &p, int segments, hipStream_t s) {
 }
 
 int launch_attentive_pool(const void *x, int ldx, const void *logits, int ldl, int channels, const int32_t *seg_row0,
-                          const int32_t *seg_len, int segments, float eps, float *out, int ld_out, bool bf16,
+                          const int32_t *seg_len, int segments, float eps, float *out, int ld_out, bool bf16, bool shared_logits,
                           hipStream_t s) {
   if (segments <= 0) return ASV_OK;
   const dim3 grid((channels + 63) / 64, segments), block(256);
-  if (bf16) hipLaunchKernelGGL(attentive_pool_kernel<true>, grid, block, 0, s, x, ldx, logits, ldl, channels, seg_row0, seg_len, eps, out, ld_out);
-  else hipLaunchKernelGGL(attentive_pool_kernel<false>, grid, block, 0, s, x, ldx, logits, ldl, channels, seg_row0, seg_len, eps, out, ld_out);
+  const int sh = shared_logits ? 1 : 0;
+  if (bf16) hipLaunchKernelGGL(attentive_pool_kernel<true>, grid, block, 0, s, x, ldx, logits, ldl, channels, seg_row0, seg_len, eps, out, ld_out, sh);
+  else hipLaunchKernelGGL(attentive_pool_kernel<false>, grid, block, 0, s, x, ldx, logits, ldl, channels, seg_row0, seg_len, eps, out, ld_out, sh);
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }

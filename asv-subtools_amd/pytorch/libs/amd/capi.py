@@ -63,6 +63,7 @@ class AttPoolDesc(C.Structure):
         ("logit_buf", C.c_int32), ("logit_ch_off", C.c_int32), ("channels", C.c_int32),
         ("out_buf", C.c_int32), ("out_ch_off", C.c_int32),
         ("eps", C.c_float),
+        ("shared_logits", C.c_int32),
     ]
 
 

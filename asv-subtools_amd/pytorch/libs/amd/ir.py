@@ -149,9 +149,12 @@ class Graph(object):
         self.ops.append(Op("im2col", out, inp=inp, taps=[(int(a), int(b)) for a, b in taps], stride=int(stride)))
         return out
 
-    def attpool(self, x, logits, eps=1e-5):
+    def attpool(self, x, logits, eps=1e-5, shared=False):
+        """softmax-over-frames weighted mean / std of x; `shared`: logits has ONE channel that weights every channel of x."""
+        if shared and logits.channels != 1:
+            raise TraceError("shared attention logits must have one channel, got %d" % logits.channels)
         out = self.full_view(self.new_tensor(DOMAIN_UTTS, 2 * x.channels))
-        self.ops.append(Op("attpool", out, x=x, logits=logits, eps=float(eps)))
+        self.ops.append(Op("attpool", out, x=x, logits=logits, eps=float(eps), shared=bool(shared)))
         return out
 
     def eltwise(self, a, b=None, c=None, seg_scale=None, scale=None, shift=None, act=None, seg_norm=None, seg_norm_mode=0):

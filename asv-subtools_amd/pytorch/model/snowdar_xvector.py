@@ -6,7 +6,7 @@ Constructor signature, sub-module names (=> state_dict keys) and the three `extr
 reference blueprint (/root/reference/pytorch/model/snowdar_xvector.py:13-278); that file also traces unmodified against
 this package's `libs.nnet`.  What is an extraction-time no-op there (mixup, SpecAugment, dropouts, margin / step
 parameters) is accepted and ignored; what would change the extraction graph in a way that is not built yet (the
-attentive / multi-head / LDE / xi-vector poolings) raises at construction.
+multi-head / LDE / xi-vector poolings) raises at construction.
 """
 
 import sys
@@ -42,8 +42,8 @@ class Xvector(TopVirtualNnet):
         layer_params = utils.assign_params_dict(_TDNN_DEFAULTS, tdnn_layer_params)
         last_params = utils.assign_params_dict(layer_params, tdnn7_params)
         pool_params = utils.assign_params_dict(_POOLING_DEFAULTS, pooling_params)
-        if pooling != "statistics":
-            raise NotImplementedError("pooling='%s': only statistics pooling is built on the MI355X path (SURVEY.md 8(f) rank 3)" % pooling)
+        if pooling not in ("statistics", "attentive"):
+            raise NotImplementedError("pooling='%s': statistics and attentive pooling are built on the MI355X path (SURVEY.md 8(f) rank 3)" % pooling)
         if training:
             raise NotImplementedError("this blueprint is the extraction graph only (training=False)")
         self.extracted_embedding = extracted_embedding
@@ -60,7 +60,11 @@ class Xvector(TopVirtualNnet):
             else:
                 setattr(self, name, SEBlock(dim, ratio=se_ratio))
         self.tdnn5 = ReluBatchNormTdnnLayer(512, pool_params["num_nodes"], **layer_params)
-        self.stats = StatisticsPooling(pool_params["num_nodes"], stddev=pool_params["stddev"])
+        if pooling == "attentive":
+            self.stats = AttentiveStatisticsPooling(pool_params["num_nodes"], affine_layers=pool_params["affine_layers"], hidden_size=pool_params["hidden_size"],
+                                                    context=pool_params["context"], stddev=pool_params["stddev"])
+        else:
+            self.stats = StatisticsPooling(pool_params["num_nodes"], stddev=pool_params["stddev"])
         stats_dim = self.stats.get_output_dim()
         self.tdnn6 = ReluBatchNormTdnnLayer(stats_dim, 512, **layer_params) if tdnn6 else None
         if last_params["nonlinearity"] == "default":

@@ -139,6 +139,8 @@ typedef struct asv_attpool_desc {
   int32_t x_buf, x_ch_off, logit_buf, logit_ch_off, channels;
   int32_t out_buf, out_ch_off;
   float   eps;
+  int32_t shared_logits;         /* != 0: ONE logit per frame (column logit_ch_off of logit_buf) weights every channel -
+                                    AttentiveStatisticsPooling with its shared single head, libs/nnet/pooling.py:322-370 */
 } asv_attpool_desc_t;
 int asv_net_add_attentive_pool(asv_net_t *net, const asv_attpool_desc_t *d);
 

@@ -92,6 +92,14 @@ CASES = {
                               utts=[(200, 6300), (77, 6301), (3, 6302)], wseed=12),
     "snowdar_no_tdnn6": dict(blueprint="snowdar_xvector.py", creation="Xvector(40,10,training=False,tdnn6=False,extracted_embedding='near_affine')",
                              dim=40, utts=[(120, 6400)], wseed=13),
+    # SURVEY 8(f) rank 3, alternative poolings: attentive statistics pooling (single shared head), two affine layers with a
+    # time context in the attention / one affine layer and mean only
+    "snowdar_attentive": dict(blueprint="snowdar_xvector.py",
+                              creation="Xvector(40,10,training=False,pooling='attentive',pooling_params={'affine_layers':2,'hidden_size':64,'context':[-1,0,1]})",
+                              dim=40, utts=[(200, 6700), (33, 6701), (2, 6702)], wseed=16),
+    "snowdar_attentive_mean": dict(blueprint="snowdar_xvector.py",
+                                   creation="Xvector(40,10,training=False,pooling='attentive',pooling_params={'affine_layers':1,'stddev':False},extracted_embedding='near')",
+                                   dim=40, utts=[(120, 6800)], wseed=17),
     # the factorised TDNN (TDNN-F) x-vector with its dense skip wiring, both positions
     "factored_far": dict(blueprint="factored_xvector.py", creation="Xvector(40,10,training=False)", dim=40,
                          utts=[(200, 6500), (45, 6501), (7, 6502)], wseed=14),

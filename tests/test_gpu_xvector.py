@@ -190,7 +190,8 @@ def test_empty_batch_and_zero_frame_utterance():
     assert rel_err(ok, g["embeddings"][:2]) < TOL_F32
 
 
-@pytest.mark.parametrize("name", ["snowdar_default", "snowdar_full_near", "snowdar_no_tdnn6", "factored_far", "factored_near"])
+@pytest.mark.parametrize("name", ["snowdar_default", "snowdar_full_near", "snowdar_no_tdnn6", "snowdar_attentive", "snowdar_attentive_mean",
+                                  "factored_far", "factored_near"])
 def test_snowdar_and_factored_xvector_vs_reference_golden(name):
     """Composite and factorised x-vector blueprints on the device: f32 within 1e-4 of the reference; bf16 close."""
     g, sd, model = _gpu_model(name, "f32")
