@@ -82,6 +82,9 @@ struct TdnnKernelParams {
   int n_taps;
   int taps[ASV_MAX_TAPS];
   int act1, act2, affine_first;
+  // pooled-domain kernel, last layer of a program whose utterances are all one chunk: also write the caller's result
+  // [utterance][final_ld] with the frame-weighted-mean arithmetic of combine_kernel ((len * e) / len), saving that launch
+  float *final_out; int final_ld; const int32_t *final_len;
   int row_begin, row_count;   // variant-3 kernel: the launch covers rows [row_begin, row_begin + row_count) (0, 0 = all rows)
   int tune;             // experiment knobs of the variant-3 kernel (tools/gemm_ablate): priorities / start stagger
   int big_one_per_cu;   // variant-3 kernel: 256x256 tiles, one workgroup per CU (default: 128x256, two per CU)

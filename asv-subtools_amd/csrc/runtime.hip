@@ -737,6 +737,8 @@ struct DomainRun {
 
 struct RunCtx {
   asv_net *net; hipStream_t s; BatchPlan bp;
+  float *final_out = nullptr;      // asv_net_extract: the caller's result matrix (lets the last layer write it directly)
+  bool final_written = false;
   int32_t *seg_src0, *seg_frames, *utt_seg0, *utt_nseg;     // device metadata
   std::vector<DomainRun> dom;
 };
@@ -907,7 +909,15 @@ int run_ops(RunCtx &c, size_t n_ops) {
           p.pool_partial = reinterpret_cast<float *>(net->poolpart_dev.ptr);
         }
         if (use_ref) rc = launch_tdnn_ref(p, bf16, !bf16, c.s);
-        else if (utts_kernel) rc = launch_utts_gemm(p, bp.segments, net->frames_bf16(), c.s);
+        else if (utts_kernel) {
+          // last layer, every utterance a single chunk: the kernel also produces the caller's [utterance][embed_dim] result
+          if (c.final_out != nullptr && i + 1 == net->ops.size() && d.out_buf == net->out_buf && d.out_ch_off == 0 && d.out_ch == net->embed_dim &&
+              bp.segments == bp.n_utts) {
+            p.final_out = c.final_out; p.final_ld = net->embed_dim; p.final_len = c.seg_frames;
+            c.final_written = true;
+          }
+          rc = launch_utts_gemm(p, bp.segments, net->frames_bf16(), c.s);
+        }
         else if (narrow_conv) rc = launch_grid_conv_narrow(p, c.s);
         else if (c1_conv) rc = launch_grid_conv_c1(p, c.s);
         else if (big3) rc = launch_tdnn_big3(p, c.s);
@@ -1041,7 +1051,9 @@ int asv_net_extract(asv_net_t *net, const float *feats, const int32_t *offsets, 
   int rc;
   if ((rc = prepare(c, offsets, n_utts, max_chunk))) return rc;
   if ((rc = pack_features(c, feats))) return rc;
+  c.final_out = out;
   if ((rc = run_ops(c, net->ops.size()))) return rc;
+  if (c.final_written) return ASV_OK;               // the last layer wrote `out` itself (single-chunk utterances)
   Prof prof{net, c.s};
   if ((rc = prof.begin(K_COMBINE, 0))) return rc;
   if ((rc = launch_combine(reinterpret_cast<const float *>(net->arena[net->out_buf].ptr), net->bufs[net->out_buf].ld, c.utt_seg0, c.utt_nseg, c.seg_frames, n_utts,
