@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--batch", type=int, default=256, help="utterances per GPU per step")
-    ap.add_argument("--frames", type=int, default=200)
+    ap.add_argument("--frames", type=int, default=None, help="frames per utterance (default: 200; 300 for --model ecapa, BASELINE configs[2])")
     ap.add_argument("--feat-dim", type=int, default=80)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel hipEvents in the timed region")
@@ -88,6 +88,8 @@ def main():
     eng = model._amd_engine()
 
     # ---- synthetic batch, device resident ----------------------------------------------------
+    if args.frames is None:
+        args.frames = 300 if args.model == "ecapa" else 200
     B, T, D = args.batch, args.frames, args.feat_dim
     mats = [synth.synth_feats(T, D, 10_000 * rank + i) for i in range(B)]
     feats = torch.from_numpy(np.concatenate(mats, axis=0)).to(dev)
