@@ -1,0 +1,569 @@
+// Kaldi-compatible log-mel filterbank front-end on the device: waveform samples ->
+// [frames][num_bins (+ energy)] features, the matrices the extraction path starts from.  Replaces
+// torchaudio.compliance.kaldi.fbank in reference pytorch/libs/egs/kaldi_features.py:72-137 and the kaldifeat C++ copy in
+// reference runtime/kaldifeat/csrc (feature-window.cc, feature-fbank.cc, mel-computations.cc), whose float arithmetic the
+// host-side tables below follow line by line (that code is compiled in place as the parity reference, oracle/Makefile.ref).
+//
+// One wave per frame, four frames per workgroup, everything of a frame in LDS:
+//   gather the window (mirror-padded when snip_edges is off) -> mean removal -> raw log energy -> pre-emphasis ->
+//   window function -> zero padding -> in-place radix-2 complex FFT (bit-reversed load, log2(N) butterfly passes; a
+//   single wave needs no barrier between passes: its LDS operations complete in order) -> |X|^2 or |X| of bins 0..N/2-1
+//   -> triangular mel filters (lane = mel bin, each bin walks its own contiguous range of FFT bins) -> log, floor.
+// HBM: 4 bytes per sample in (frames overlap 2.5x, the re-reads hit L2), 4 * num_bins bytes per frame out.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "asv_internal.h"
+
+namespace asv {
+namespace {
+
+constexpr int kMaxFft = 2048;
+
+struct FbankKernelParams {
+  const float *wave;            // all utterances, packed
+  const long long *sample_off;  // [n_utts + 1]
+  const long long *frame_off;   // [n_utts + 1]
+  int n_utts;
+  long long total_frames;
+  int length, shift, padded, log2n;
+  float preemph;
+  int remove_dc, snip_edges, use_energy, raw_energy, htk_compat, use_log, use_power;
+  float log_energy_floor;       // -inf when there is no floor
+  int num_bins;
+  const float *window;          // [length]
+  const float2 *twiddle;        // [padded / 2]: exp(-2 pi i k / padded)
+  const float *mel_w;           // [num_bins][mel_stride] weights of FFT bins first[b] .. first[b] + count[b] - 1
+  const int *mel_first, *mel_count;
+  int mel_stride;
+  // the same filters cut into segments of <= 8 consecutive FFT bins (fbank512_kernel: one lane per segment)
+  const float *seg_w;           // [n_seg][8], zero padded
+  const int *seg_first;         // [n_seg]
+  const int *bin_seg;           // [num_bins + 1]: segments of bin b are bin_seg[b] .. bin_seg[b + 1] - 1
+  int n_seg;
+  float *out;                   // [total_frames][dim]
+};
+
+// Sum over the 64 lanes, the same value in every lane: four DPP steps inside each row of 16 (quad xor 1, quad xor 2,
+// half-row mirror, row mirror), then the four row totals through v_readlane.
+__device__ __forceinline__ float wave_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));  // row_mirror
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+
+__global__ __launch_bounds__(256) void fbank_kernel(const FbankKernelParams p) {
+  extern __shared__ float lds[];                       // per wave: re[padded] | im[padded]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long frame = (long long)blockIdx.x * 4 + wave;
+  if (frame >= p.total_frames) return;
+  float *re = lds + (size_t)wave * 2 * p.padded, *im = re + p.padded;
+  // which utterance: binary search in the frame offsets (wave-uniform)
+  int lo = 0, hi = p.n_utts;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (p.frame_off[mid] <= frame) lo = mid; else hi = mid;
+  }
+  const long long s0 = p.sample_off[lo], ns = p.sample_off[lo + 1] - s0;
+  const long long f = frame - p.frame_off[lo];
+  long long first = f * p.shift;
+  // The reference pads snip_edges=false input by mirroring (feature-window.cc:116-133): padded[i] for i < left is
+  // wave[left - 1 - i]; past the end it is wave[n - 1 - (i - left - n)].  With left = (length - shift) / 2 the frame start
+  // in the padded signal is f * shift, i.e. first sample index (unpadded) = f * shift - left.
+  const long long left = (p.length - p.shift) / 2;
+  if (!p.snip_edges) first = f * p.shift - left;
+  float sum = 0.0f;
+  for (int i = lane; i < p.length; i += 64) {
+    long long k = first + i;
+    if (k < 0) k = -k - 1;
+    if (k >= ns) k = 2 * ns - 1 - k;
+    const float v = p.wave[s0 + k];
+    re[i] = v;
+    sum += v;
+  }
+  if (p.remove_dc) {
+    const float mean = wave_sum(sum) / (float)p.length;
+    for (int i = lane; i < p.length; i += 64) re[i] -= mean;
+  }
+  float log_energy = 0.0f;
+  if (p.use_energy && p.raw_energy) {
+    float e = 0.0f;
+    for (int i = lane; i < p.length; i += 64) e += re[i] * re[i];
+    log_energy = logf(fmaxf(wave_sum(e), 1.1920928955078125e-07f));
+  }
+  // pre-emphasis (needs the left neighbour: read everything first, then write) and window
+  {
+    float cur[kMaxFft / 64], prev[kMaxFft / 64];
+    int n = 0;
+    for (int i = lane; i < p.length; i += 64, ++n) { cur[n] = re[i]; prev[n] = i > 0 ? re[i - 1] : 0.0f; }
+    n = 0;
+    for (int i = lane; i < p.length; i += 64, ++n) {
+      float y = cur[n];
+      if (p.preemph != 0.0f) y = (i > 0) ? cur[n] - p.preemph * prev[n] : cur[n] * (1.0f - p.preemph);
+      im[i] = y * p.window[i];                          // staged in `im`, moved to bit-reversed `re` below
+    }
+  }
+  float e2 = 0.0f;
+  if (p.use_energy && !p.raw_energy) {
+    for (int i = lane; i < p.length; i += 64) e2 += im[i] * im[i];
+    log_energy = logf(fmaxf(wave_sum(e2), 1.1920928955078125e-07f));
+  }
+  // bit-reversed copy into re (zero padding beyond the window), im <- 0 afterwards
+  {
+    float tmp[kMaxFft / 64];
+    int n = 0;
+    for (int i = lane; i < p.padded; i += 64, ++n) tmp[n] = i < p.length ? im[i] : 0.0f;
+    n = 0;
+    for (int i = lane; i < p.padded; i += 64, ++n) re[__brev((unsigned)i) >> (32 - p.log2n)] = tmp[n];
+    for (int i = lane; i < p.padded; i += 64) im[i] = 0.0f;
+  }
+  // radix-2 decimation-in-time butterflies
+  const int half = p.padded >> 1;
+  for (int s = 0; s < p.log2n; ++s) {
+    const int span = 1 << s;                            // butterfly distance
+    for (int b = lane; b < half; b += 64) {
+      const int j = b & (span - 1), base = ((b >> s) << (s + 1)) + j;
+      const float2 w = p.twiddle[j << (p.log2n - 1 - s)];
+      const float ar = re[base], ai = im[base], br = re[base + span], bi = im[base + span];
+      const float tr = br * w.x - bi * w.y, ti = br * w.y + bi * w.x;
+      re[base] = ar + tr; im[base] = ai + ti;
+      re[base + span] = ar - tr; im[base + span] = ai - ti;
+    }
+  }
+  // spectrum of bins 0 .. N/2 - 1 (the reference drops the Nyquist bin, feature-fbank.cc:66-68)
+  for (int i = lane; i < half; i += 64) {
+    const float pw = re[i] * re[i] + im[i] * im[i];
+    re[i] = p.use_power ? pw : sqrtf(pw);
+  }
+  const int dim = p.num_bins + (p.use_energy ? 1 : 0);
+  float *dst = p.out + (size_t)frame * dim;
+  for (int b = lane; b < p.num_bins; b += 64) {
+    const float *w = p.mel_w + (size_t)b * p.mel_stride;
+    const int i0 = p.mel_first[b], cnt = p.mel_count[b];
+    float acc = 0.0f;
+    for (int k = 0; k < cnt; ++k) acc = fmaf(re[i0 + k], w[k], acc);
+    if (p.use_log) acc = logf(fmaxf(acc, 1.1920928955078125e-07f));
+    dst[b + ((p.use_energy && !p.htk_compat) ? 1 : 0)] = acc;
+  }
+  if (p.use_energy && lane == 0) dst[p.htk_compat ? p.num_bins : 0] = fmaxf(log_energy, p.log_energy_floor);
+}
+
+
+// ---- the 16 kHz kernel: 512-point frames (windows of 257..512 samples) -------------------------------------------------
+// One wave per frame, a wave walks FPW consecutive frames (their windows overlap, the re-reads hit L1/L2).  The real
+// 512-point transform is a 256-point complex one over (even, odd) sample pairs + a split step:
+//   z[n] = x[2n] + i x[2n+1];  Z = FFT256(z);  X[k] = (Z[k] + Z*[256-k]) / 2  -  i W512^k (Z[k] - Z*[256-k]) / 2.
+// FFT256 is a radix-4 Stockham: 64 lanes = 64 butterflies per pass, 4 passes; lane j holds points j + 64 r, which is
+// both the order the samples are loaded in and the order the last pass leaves the bins in, so only the three exchanges
+// between passes go through LDS (2 KiB per wave, in place: a wave's LDS operations complete in order).  Window values,
+// pass twiddles and split twiddles depend on the lane only and live in registers across the frames of the wave.
+struct cplx { float x, y; };
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ void dft4(cplx v[4]) {
+  const cplx a0 = {v[0].x + v[2].x, v[0].y + v[2].y}, a1 = {v[0].x - v[2].x, v[0].y - v[2].y};
+  const cplx a2 = {v[1].x + v[3].x, v[1].y + v[3].y}, a3 = {v[1].y - v[3].y, v[3].x - v[1].x};      // (v1 - v3) * -i
+  v[0] = {a0.x + a2.x, a0.y + a2.y}; v[1] = {a1.x + a3.x, a1.y + a3.y};
+  v[2] = {a0.x - a2.x, a0.y - a2.y}; v[3] = {a1.x - a3.x, a1.y - a3.y};
+}
+// orders a wave's LDS writes before its following LDS reads of other lanes' data (no instruction beyond the wait)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ cplx tw512(const float2 *t, int idx) {          // W512^idx for idx < 512 from the 256-entry table
+  const float2 w = t[idx & 255];
+  return (idx & 256) ? cplx{-w.x, -w.y} : cplx{w.x, w.y};
+}
+
+constexpr int kFastFpw = 4;          // frames per wave
+constexpr int kFastMaxSeg = 256;     // mel filter segments (<= 8 FFT bins each) the kernel has room for: 4 lanes-passes
+
+__global__ __launch_bounds__(256) void fbank512_kernel(const FbankKernelParams p) {
+  __shared__ float2 xch[4][264];          // 256 points; later |X|^2 [256] + 8 zeros + segment sums [256]
+  __shared__ float4 segw[kFastMaxSeg][2];
+  __shared__ int segk[kFastMaxSeg];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < p.n_seg; i += 256) {
+    segw[i][0] = reinterpret_cast<const float4 *>(p.seg_w)[2 * i];
+    segw[i][1] = reinterpret_cast<const float4 *>(p.seg_w)[2 * i + 1];
+    segk[i] = p.seg_first[i];
+  }
+  __syncthreads();
+  const long long frame0 = ((long long)blockIdx.x * 4 + wave) * kFastFpw;
+  if (frame0 >= p.total_frames) return;
+  float2 *my = xch[wave];
+  float *pw = reinterpret_cast<float *>(my);
+  // lane constants
+  float we[4], wo[4];
+  cplx t2[3], t3[3], t4[3], ts[4];
+  for (int r = 0; r < 4; ++r) {
+    const int i = 2 * (lane + 64 * r);
+    we[r] = i < p.length ? p.window[i] : 0.0f;
+    wo[r] = i + 1 < p.length ? p.window[i + 1] : 0.0f;
+    ts[r] = tw512(p.twiddle, lane + 64 * r);
+  }
+  for (int r = 1; r < 4; ++r) {
+    t2[r - 1] = tw512(p.twiddle, (lane & 3) * r * 32);                    // W16^(k r) = W512^(32 k r)
+    t3[r - 1] = tw512(p.twiddle, (lane & 15) * r * 8);                    // W64^(k r)
+    t4[r - 1] = tw512(p.twiddle, lane * r * 2);                           // W256^(k r)
+  }
+  const int o2 = ((lane >> 2) << 4) + (lane & 3), o3 = ((lane >> 4) << 6) + (lane & 15);
+  const int partner = (64 - lane) & 63;
+  // utterance of the first frame
+  int u = 0;
+  {
+    int hi = p.n_utts;
+    while (hi - u > 1) {
+      const int mid = (u + hi) >> 1;
+      if (p.frame_off[mid] <= frame0) u = mid; else hi = mid;
+    }
+  }
+  long long f_begin = p.frame_off[u], f_end = p.frame_off[u + 1], s0 = p.sample_off[u], ns = p.sample_off[u + 1] - s0;
+  const long long left = p.snip_edges ? 0 : (p.length - p.shift) / 2;
+  const int dim = p.num_bins + (p.use_energy ? 1 : 0);
+  const float inv_len = 1.0f / (float)p.length;
+  for (int it = 0; it < kFastFpw; ++it) {
+    const long long frame = frame0 + it;
+    if (frame >= p.total_frames) break;
+    while (frame >= f_end) {                                                // empty utterances have f_begin == f_end
+      ++u;
+      f_begin = f_end; f_end = p.frame_off[u + 1]; s0 = p.sample_off[u]; ns = p.sample_off[u + 1] - s0;
+    }
+    const long long first = (frame - f_begin) * p.shift - left;
+    const float *src = p.wave + s0;
+    float e[4], o[4];
+    if (first >= 0 && first + p.length <= ns) {
+      for (int r = 0; r < 4; ++r) {
+        const int i = 2 * (lane + 64 * r);
+        e[r] = i < p.length ? src[first + i] : 0.0f;
+        o[r] = i + 1 < p.length ? src[first + i + 1] : 0.0f;
+      }
+    } else {                                                                // mirrored edges (snip_edges off)
+      for (int r = 0; r < 4; ++r) {
+        const int i = 2 * (lane + 64 * r);
+        long long k0 = first + i, k1 = first + i + 1;
+        if (k0 < 0) k0 = -k0 - 1;
+        if (k0 >= ns) k0 = 2 * ns - 1 - k0;
+        if (k1 < 0) k1 = -k1 - 1;
+        if (k1 >= ns) k1 = 2 * ns - 1 - k1;
+        e[r] = i < p.length ? src[k0] : 0.0f;
+        o[r] = i + 1 < p.length ? src[k1] : 0.0f;
+      }
+    }
+    if (p.remove_dc) {
+      const float mean = wave_sum((e[0] + o[0]) + (e[1] + o[1]) + (e[2] + o[2]) + (e[3] + o[3])) * inv_len;
+      for (int r = 0; r < 4; ++r) {
+        const int i = 2 * (lane + 64 * r);
+        e[r] = i < p.length ? e[r] - mean : 0.0f;
+        o[r] = i + 1 < p.length ? o[r] - mean : 0.0f;
+      }
+    }
+    float log_energy = 0.0f;
+    if (p.use_energy && p.raw_energy) {
+      float q = 0.0f;
+      for (int r = 0; r < 4; ++r) q += e[r] * e[r] + o[r] * o[r];
+      log_energy = logf(fmaxf(wave_sum(q), 1.1920928955078125e-07f));
+    }
+    cplx v[4];
+    {
+      // pre-emphasis: the left neighbour of even sample 2n is the odd sample of point n - 1 (lane - 1, or lane 63 of r - 1)
+      float prev[4];
+      for (int r = 0; r < 4; ++r) {
+        const float up = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, o[r]), 0x138, 0xf, 0xf, false));   // wave_shr:1
+        const float wrap = r > 0 ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, o[r - 1]), 63)) : e[0];   // sample 0 is its own left neighbour (Kaldi)
+        prev[r] = lane == 0 ? wrap : up;
+      }
+      for (int r = 0; r < 4; ++r) {
+        const float ye = e[r] - p.preemph * prev[r], yo = o[r] - p.preemph * e[r];
+        v[r] = {ye * we[r], yo * wo[r]};
+      }
+    }
+    if (p.use_energy && !p.raw_energy) {
+      float q = 0.0f;
+      for (int r = 0; r < 4; ++r) q += v[r].x * v[r].x + v[r].y * v[r].y;
+      log_energy = logf(fmaxf(wave_sum(q), 1.1920928955078125e-07f));
+    }
+    // pass 1 (Ns = 1, no twiddles)
+    dft4(v);
+    *reinterpret_cast<float4 *>(&my[4 * lane]) = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
+    *reinterpret_cast<float4 *>(&my[4 * lane + 2]) = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
+    wave_lds_sync();
+    // pass 2 (Ns = 4)
+    for (int r = 0; r < 4; ++r) { const float2 t = my[lane + 64 * r]; v[r] = {t.x, t.y}; }
+    for (int r = 1; r < 4; ++r) v[r] = cmul(v[r], t2[r - 1]);
+    dft4(v);
+    wave_lds_sync();
+    for (int r = 0; r < 4; ++r) my[o2 + 4 * r] = make_float2(v[r].x, v[r].y);
+    wave_lds_sync();
+    // pass 3 (Ns = 16)
+    for (int r = 0; r < 4; ++r) { const float2 t = my[lane + 64 * r]; v[r] = {t.x, t.y}; }
+    for (int r = 1; r < 4; ++r) v[r] = cmul(v[r], t3[r - 1]);
+    dft4(v);
+    wave_lds_sync();
+    for (int r = 0; r < 4; ++r) my[o3 + 16 * r] = make_float2(v[r].x, v[r].y);
+    wave_lds_sync();
+    // pass 4 (Ns = 64): bins lane + 64 r stay in registers
+    for (int r = 0; r < 4; ++r) { const float2 t = my[lane + 64 * r]; v[r] = {t.x, t.y}; }
+    for (int r = 1; r < 4; ++r) v[r] = cmul(v[r], t4[r - 1]);
+    dft4(v);
+    wave_lds_sync();
+    // split step: Z[256 - k] of bin k = lane + 64 r sits in lane (64 - lane) & 63 at 3 - r (lane 0: itself at (4 - r) & 3)
+    for (int r = 0; r < 4; ++r) {
+      const float qx = __shfl(v[3 - r].x, partner), qy = __shfl(v[3 - r].y, partner);
+      const cplx self = v[(4 - r) & 3];
+      const cplx zp = lane == 0 ? cplx{self.x, -self.y} : cplx{qx, -qy};    // conj Z[256 - k]
+      const cplx ev = {0.5f * (v[r].x + zp.x), 0.5f * (v[r].y + zp.y)};
+      const cplx d = {0.5f * (v[r].x - zp.x), 0.5f * (v[r].y - zp.y)};
+      const cplx od = cmul(cplx{d.y, -d.x}, ts[r]);                          // -i d W512^k
+      const float xr = ev.x + od.x, xi = ev.y + od.y;
+      const float pwr = xr * xr + xi * xi;
+      pw[lane + 64 * r] = p.use_power ? pwr : sqrtf(pwr);                    // overwrites pass-4 inputs, already consumed
+    }
+    if (lane < 8) pw[256 + lane] = 0.0f;
+    wave_lds_sync();
+    // mel filters: one lane per segment of <= 8 FFT bins, partial sums to LDS, then one lane per mel bin adds its segments
+    float *part = pw + 256 + 8;                                              // pw[256 .. 263] is read (times 0) by the last segments
+    for (int sg = lane; sg < p.n_seg; sg += 64) {
+      const float4 w0 = segw[sg][0], w1 = segw[sg][1];
+      const float *q = pw + segk[sg];
+      float acc = q[0] * w0.x;
+      acc = fmaf(q[1], w0.y, acc); acc = fmaf(q[2], w0.z, acc); acc = fmaf(q[3], w0.w, acc);
+      acc = fmaf(q[4], w1.x, acc); acc = fmaf(q[5], w1.y, acc); acc = fmaf(q[6], w1.z, acc); acc = fmaf(q[7], w1.w, acc);
+      part[sg] = acc;
+    }
+    wave_lds_sync();
+    float *dst = p.out + (size_t)frame * dim;
+    for (int b = lane; b < p.num_bins; b += 64) {
+      const int s_lo = p.bin_seg[b], s_hi = p.bin_seg[b + 1];
+      float acc = part[s_lo];
+      for (int sg = s_lo + 1; sg < s_hi; ++sg) acc += part[sg];
+      if (p.use_log) acc = logf(fmaxf(acc, 1.1920928955078125e-07f));
+      dst[b + ((p.use_energy && !p.htk_compat) ? 1 : 0)] = acc;
+    }
+    if (p.use_energy && lane == 0) dst[p.htk_compat ? p.num_bins : 0] = fmaxf(log_energy, p.log_energy_floor);
+    wave_lds_sync();                                                         // the next frame's pass 1 overwrites pw
+  }
+}
+
+// Per-utterance mean (and optionally variance) normalisation of every feature column, in place: reference
+// kaldi_features.py:11-66 InputSequenceNormalization (torch.mean / unbiased torch.std over the frames, std floored at eps).
+// One workgroup per (utterance, 64-column block); 4 row lanes x 64 columns, sums in f64.
+__global__ __launch_bounds__(256) void cmvn_kernel(float *feats, const long long *frame_off, int dim, int mean_norm, int std_norm, float eps) {
+  __shared__ double red[2][4][64];
+  const int u = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
+  const long long f0 = frame_off[u], n = frame_off[u + 1] - f0;
+  if (n <= 0) return;
+  float *base = feats + (size_t)f0 * dim;
+  double s = 0.0;
+  if (c < dim) for (long long t = r; t < n; t += 4) s += (double)base[(size_t)t * dim + c];
+  red[0][r][threadIdx.x & 63] = s;
+  __syncthreads();
+  const double mean = (red[0][0][threadIdx.x & 63] + red[0][1][threadIdx.x & 63] + red[0][2][threadIdx.x & 63] + red[0][3][threadIdx.x & 63]) / (double)n;
+  double inv = 1.0;
+  if (std_norm) {
+    double q = 0.0;
+    if (c < dim) for (long long t = r; t < n; t += 4) { const double d = (double)base[(size_t)t * dim + c] - mean; q += d * d; }
+    red[1][r][threadIdx.x & 63] = q;
+    __syncthreads();
+    const double var = (red[1][0][threadIdx.x & 63] + red[1][1][threadIdx.x & 63] + red[1][2][threadIdx.x & 63] + red[1][3][threadIdx.x & 63]) / (double)(n > 1 ? n - 1 : 1);
+    inv = 1.0 / fmax(sqrt(var), (double)eps);
+  }
+  const double m = mean_norm ? mean : 0.0;
+  if (c < dim) for (long long t = r; t < n; t += 4) {
+    float *v = base + (size_t)t * dim + c;
+    *v = (float)(((double)*v - m) * inv);
+  }
+}
+
+float mel_scale(float f) { return 1127.0f * logf(1.0f + f / 700.0f); }
+
+thread_local std::vector<void *> g_front_dev;            // device tables of the last option set (tiny; rebuilt on change)
+thread_local asv_fbank_opts_t g_front_opts;
+thread_local bool g_front_valid = false;
+struct FrontTables { float *window; float2 *twiddle; float *mel_w; int *mel_first, *mel_count; int mel_stride; float *seg_w; int *seg_first, *bin_seg; int n_seg; long long *offs; size_t offs_cap; };
+thread_local FrontTables g_tab = {};
+
+int window_size(const asv_fbank_opts_t &o, float ms) { return (int)(o.sample_rate * 0.001f * ms); }
+
+}  // namespace
+}  // namespace asv
+
+using namespace asv;
+
+extern "C" {
+
+long long asv_fbank_num_frames(const asv_fbank_opts_t *o, long long num_samples) {
+  if (!o || o->struct_size != sizeof(asv_fbank_opts_t)) return -1;
+  const long long length = window_size(*o, o->frame_length_ms), shift = window_size(*o, o->frame_shift_ms);
+  if (length <= 0 || shift <= 0) return -1;
+  if (o->snip_edges) return num_samples < length ? 0 : 1 + (num_samples - length) / shift;
+  return (num_samples + shift / 2) / shift;
+}
+
+int asv_fbank(const asv_fbank_opts_t *o, const float *wave, const long long *sample_offsets, int n_utts, float *feats, void *stream) {
+  ASV_REQUIRE(o && o->struct_size == sizeof(asv_fbank_opts_t), "asv_fbank: struct_size mismatch");
+  ASV_REQUIRE(wave && sample_offsets && feats && n_utts >= 1, "asv_fbank: bad argument");
+  ASV_REQUIRE(o->num_bins >= 3 && o->num_bins <= 512, "asv_fbank: num_bins %d", o->num_bins);
+  ASV_REQUIRE(o->window_type >= ASV_WINDOW_POVEY && o->window_type <= ASV_WINDOW_SINE, "asv_fbank: window type %d", o->window_type);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int length = window_size(*o, o->frame_length_ms), shift = window_size(*o, o->frame_shift_ms);
+  ASV_REQUIRE(length >= 2 && shift >= 1, "asv_fbank: frame length %d / shift %d samples", length, shift);
+  int padded = length, log2n = 0;
+  { int pw = 1; while (pw < length) { pw *= 2; } padded = pw; }
+  ASV_REQUIRE(padded <= kMaxFft, "asv_fbank: windows of more than %d samples are not supported", kMaxFft);
+  ASV_REQUIRE(o->round_to_power_of_two || padded == length, "asv_fbank: round_to_power_of_two=false needs a power-of-two window (got %d samples)", length);
+  while ((1 << log2n) < padded) ++log2n;
+  // ---- tables (host arithmetic in the reference's types: float mel scale, double window phase)
+  if (!g_front_valid || memcmp(&g_front_opts, o, sizeof(*o)) != 0) {
+    for (void *ptr : g_front_dev) (void)hipFree(ptr);
+    g_front_dev.clear();
+    g_front_valid = false;
+    std::vector<float> win(length);
+    const double a = 6.283185307179586476925286766559005 / (length - 1);
+    for (int i = 0; i < length; ++i) {
+      const double x = (double)i;
+      switch (o->window_type) {
+        case ASV_WINDOW_HANNING: win[i] = (float)(0.5 - 0.5 * cos(a * x)); break;
+        case ASV_WINDOW_SINE: win[i] = (float)sin(0.5 * a * x); break;
+        case ASV_WINDOW_HAMMING: win[i] = (float)(0.54 - 0.46 * cos(a * x)); break;
+        case ASV_WINDOW_RECTANGULAR: win[i] = 1.0f; break;
+        default: win[i] = (float)pow(0.5 - 0.5 * cos(a * x), 0.85); break;          // povey
+      }
+    }
+    std::vector<float2> tw(padded / 2);
+    for (int k = 0; k < padded / 2; ++k) {
+      const double ang = -6.283185307179586476925286766559005 * k / padded;
+      tw[k] = make_float2((float)cos(ang), (float)sin(ang));
+    }
+    // mel filters, mel-computations.cc:60-141 with vtln warp 1
+    const float nyquist = 0.5f * o->sample_rate;
+    const float high = o->high_freq > 0.0f ? o->high_freq : nyquist + o->high_freq;
+    ASV_REQUIRE(!(o->low_freq < 0.0f || o->low_freq >= nyquist || high <= 0.0f || high > nyquist || high <= o->low_freq),
+                "asv_fbank: bad low-freq %g / high-freq %g vs nyquist %g", o->low_freq, high, nyquist);
+    const int n_fft = padded / 2;
+    const float width = o->sample_rate / padded;
+    const float mel_low = mel_scale(o->low_freq), mel_high = mel_scale(high);
+    const float delta = (mel_high - mel_low) / (o->num_bins + 1);
+    std::vector<int> first(o->num_bins, -1), count(o->num_bins, 0);
+    std::vector<std::vector<float>> rows(o->num_bins);
+    int stride = 1;
+    for (int b = 0; b < o->num_bins; ++b) {
+      const float left = mel_low + b * delta, center = mel_low + (b + 1) * delta, right = mel_low + (b + 2) * delta;
+      int last = -1;
+      std::vector<float> dense(n_fft, 0.0f);
+      for (int i = 0; i < n_fft; ++i) {
+        const float mel = mel_scale(width * i);
+        if (mel > left && mel < right) {
+          dense[i] = mel <= center ? (mel - left) / (center - left) : (right - mel) / (right - center);
+          if (first[b] < 0) first[b] = i;
+          last = i;
+        }
+      }
+      ASV_REQUIRE(first[b] >= 0, "asv_fbank: num_bins %d is too large for %d FFT bins", o->num_bins, n_fft);
+      count[b] = last - first[b] + 1;
+      rows[b].assign(dense.begin() + first[b], dense.begin() + last + 1);
+      stride = std::max(stride, count[b]);
+    }
+    std::vector<float> melw((size_t)o->num_bins * stride, 0.0f);
+    for (int b = 0; b < o->num_bins; ++b) memcpy(&melw[(size_t)b * stride], rows[b].data(), rows[b].size() * 4);
+    auto up = [&](const void *h, size_t bytes, void **d) -> int {
+      ASV_HIP_CHECK(hipMalloc(d, bytes));
+      g_front_dev.push_back(*d);
+      ASV_HIP_CHECK(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
+      return ASV_OK;
+    };
+    int rc;
+    if ((rc = up(win.data(), win.size() * 4, reinterpret_cast<void **>(&g_tab.window)))) return rc;
+    if ((rc = up(tw.data(), tw.size() * 8, reinterpret_cast<void **>(&g_tab.twiddle)))) return rc;
+    if ((rc = up(melw.data(), melw.size() * 4, reinterpret_cast<void **>(&g_tab.mel_w)))) return rc;
+    if ((rc = up(first.data(), first.size() * 4, reinterpret_cast<void **>(&g_tab.mel_first)))) return rc;
+    if ((rc = up(count.data(), count.size() * 4, reinterpret_cast<void **>(&g_tab.mel_count)))) return rc;
+    g_tab.mel_stride = stride;
+    std::vector<float> segw;
+    std::vector<int> segk, binseg(1, 0);
+    for (int b = 0; b < o->num_bins; ++b) {
+      for (int k = 0; k < count[b]; k += 8) {
+        segk.push_back(first[b] + k);
+        for (int t = 0; t < 8; ++t) segw.push_back(k + t < count[b] ? rows[b][k + t] : 0.0f);
+      }
+      binseg.push_back((int)segk.size());
+    }
+    if ((rc = up(segw.data(), segw.size() * 4, reinterpret_cast<void **>(&g_tab.seg_w)))) return rc;
+    if ((rc = up(segk.data(), segk.size() * 4, reinterpret_cast<void **>(&g_tab.seg_first)))) return rc;
+    if ((rc = up(binseg.data(), binseg.size() * 4, reinterpret_cast<void **>(&g_tab.bin_seg)))) return rc;
+    g_tab.n_seg = (int)segk.size();
+    g_tab.offs = nullptr; g_tab.offs_cap = 0;
+    g_front_opts = *o;
+    g_front_valid = true;
+  }
+  // ---- offsets
+  std::vector<long long> offs(2 * (size_t)(n_utts + 1));
+  long long total = 0;
+  ASV_REQUIRE(sample_offsets[0] == 0, "asv_fbank: sample_offsets[0] must be 0");
+  for (int u = 0; u <= n_utts; ++u) {
+    offs[u] = sample_offsets[u];
+    if (u > 0) ASV_REQUIRE(sample_offsets[u] >= sample_offsets[u - 1], "asv_fbank: sample offsets must not decrease");
+    offs[n_utts + 1 + u] = total;
+    if (u < n_utts) {
+      const long long fr = asv_fbank_num_frames(o, sample_offsets[u + 1] - sample_offsets[u]);
+      ASV_REQUIRE(!(fr > 0 && !o->snip_edges && sample_offsets[u + 1] - sample_offsets[u] < length), "asv_fbank: utterance %d is shorter than one window", u);
+      total += fr;
+    }
+  }
+  if (total == 0) return ASV_OK;
+  if (offs.size() * 8 > g_tab.offs_cap) {
+    long long *d = nullptr;
+    ASV_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d), offs.size() * 16));
+    g_front_dev.push_back(d);
+    g_tab.offs = d; g_tab.offs_cap = offs.size() * 16;
+  }
+  ASV_HIP_CHECK(hipMemcpyAsync(g_tab.offs, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, s));
+  ASV_HIP_CHECK(hipStreamSynchronize(s));                  // `offs` is a local; the copy must finish before it dies
+  FbankKernelParams p;
+  memset(&p, 0, sizeof(p));
+  p.wave = wave; p.sample_off = g_tab.offs; p.frame_off = g_tab.offs + (n_utts + 1); p.n_utts = n_utts; p.total_frames = total;
+  p.length = length; p.shift = shift; p.padded = padded; p.log2n = log2n; p.preemph = o->preemph;
+  p.remove_dc = o->remove_dc_offset; p.snip_edges = o->snip_edges; p.use_energy = o->use_energy; p.raw_energy = o->raw_energy;
+  p.htk_compat = o->htk_compat; p.use_log = o->use_log_fbank; p.use_power = o->use_power;
+  p.log_energy_floor = o->energy_floor > 0.0f ? logf(o->energy_floor) : -INFINITY;
+  p.num_bins = o->num_bins; p.window = g_tab.window; p.twiddle = g_tab.twiddle; p.mel_w = g_tab.mel_w;
+  p.mel_first = g_tab.mel_first; p.mel_count = g_tab.mel_count; p.mel_stride = g_tab.mel_stride; p.out = feats;
+  p.seg_w = g_tab.seg_w; p.seg_first = g_tab.seg_first; p.bin_seg = g_tab.bin_seg; p.n_seg = g_tab.n_seg;
+  static const bool generic_only = getenv("ASV_AMD_FBANK_GENERIC") != nullptr;
+  if (padded == 512 && g_tab.n_seg <= kFastMaxSeg && !generic_only) {
+    const long long per_wg = 4 * kFastFpw;
+    hipLaunchKernelGGL(fbank512_kernel, dim3((unsigned)((total + per_wg - 1) / per_wg)), dim3(256), 0, s, p);
+    ASV_HIP_CHECK(hipGetLastError());
+    return ASV_OK;
+  }
+  const size_t lds_bytes = (size_t)4 * 2 * padded * 4;
+  hipLaunchKernelGGL(fbank_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), lds_bytes, s, p);
+  ASV_HIP_CHECK(hipGetLastError());
+  return ASV_OK;
+}
+
+int asv_cmvn(float *feats, const long long *frame_offsets, int n_utts, int dim, int mean_norm, int std_norm, float eps, void *stream) {
+  ASV_REQUIRE(feats && frame_offsets && n_utts >= 1 && dim >= 1, "asv_cmvn: bad argument");
+  ASV_REQUIRE(frame_offsets[0] == 0, "asv_cmvn: frame_offsets[0] must be 0");
+  if (!mean_norm && !std_norm) return ASV_OK;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  long long *d = nullptr;
+  ASV_HIP_CHECK(hipMallocAsync(reinterpret_cast<void **>(&d), (size_t)(n_utts + 1) * 8, s));
+  ASV_HIP_CHECK(hipMemcpyAsync(d, frame_offsets, (size_t)(n_utts + 1) * 8, hipMemcpyHostToDevice, s));
+  ASV_HIP_CHECK(hipStreamSynchronize(s));                  // the caller's offsets array may be a temporary
+  hipLaunchKernelGGL(cmvn_kernel, dim3((unsigned)n_utts, (unsigned)((dim + 63) / 64)), dim3(256), 0, s, feats, d, dim, mean_norm, std_norm, eps);
+  ASV_HIP_CHECK(hipGetLastError());
+  ASV_HIP_CHECK(hipFreeAsync(d, s));
+  return ASV_OK;
+}
+
+}  // extern "C"

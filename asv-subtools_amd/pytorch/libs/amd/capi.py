@@ -94,6 +94,20 @@ class Im2colDesc(C.Structure):
     ]
 
 
+class FbankOpts(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("sample_rate", C.c_float), ("frame_length_ms", C.c_float), ("frame_shift_ms", C.c_float), ("preemph", C.c_float),
+        ("remove_dc_offset", C.c_int32), ("window_type", C.c_int32), ("round_to_power_of_two", C.c_int32), ("snip_edges", C.c_int32),
+        ("num_bins", C.c_int32), ("low_freq", C.c_float), ("high_freq", C.c_float),
+        ("use_energy", C.c_int32), ("energy_floor", C.c_float), ("raw_energy", C.c_int32), ("htk_compat", C.c_int32),
+        ("use_log_fbank", C.c_int32), ("use_power", C.c_int32),
+    ]
+
+
+WINDOW_TYPES = {"povey": 0, "hamming": 1, "hanning": 2, "rectangular": 3, "sine": 4}
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("op_index", C.c_int32), ("launches", C.c_int32), ("total_ms", C.c_float), ("flops", C.c_double)]
 
@@ -115,6 +129,7 @@ SYMBOLS = [
     "asv_tdnn_forward", "asv_stats_pool_forward",
     "asv_length_norm", "asv_mean_vec", "asv_dot_score_matrix", "asv_dot_score_trials",
     "asv_plda_transform", "asv_plda_llr_trials", "asv_eer", "asv_score_norm",
+    "asv_fbank_num_frames", "asv_fbank", "asv_cmvn",
 ]
 
 
@@ -171,9 +186,12 @@ def lib():
     L.asv_plda_llr_trials.argtypes = [vp, vp, ci, vp, vp, vp, vp, ci, vp, vp]
     L.asv_eer.argtypes = [vp, vp, ci, c_float_p, c_float_p, vp]
     L.asv_score_norm.argtypes = [vp, ci, vp, ci, ci, vp, vp, vp, ci, ci, ci, vp, vp]
+    L.asv_fbank_num_frames.argtypes = [C.POINTER(FbankOpts), C.c_longlong]; L.asv_fbank_num_frames.restype = C.c_longlong
+    L.asv_fbank.argtypes = [C.POINTER(FbankOpts), vp, C.POINTER(C.c_longlong), ci, vp, vp]
+    L.asv_cmvn.argtypes = [vp, C.POINTER(C.c_longlong), ci, ci, ci, ci, C.c_float, vp]
     for name in SYMBOLS:
         fn = getattr(L, name)          # AttributeError here = header/.so mismatch
-        if name not in ("asv_last_error", "asv_net_destroy", "asv_net_device_bytes"):
+        if name not in ("asv_last_error", "asv_net_destroy", "asv_net_device_bytes", "asv_fbank_num_frames"):
             fn.restype = ci
     _LIB = L
     return L

@@ -200,11 +200,23 @@ class Engine(object):
         return out
 
     def extract_batch(self, mats, max_chunk=10000):
-        """mats: list of [T_i, D] array-likes (host).  Returns a CPU float32 tensor [B, E]."""
+        """mats: list of [T_i, D] array-likes (host), or of CUDA tensors (e.g. libs.amd.frontend.fbank output - packed on
+        the device, no host round trip).  Returns a CPU float32 tensor [B, E]."""
         import torch
-        mats = [np.asarray(m, dtype=np.float32) for m in mats]
+        mats = list(mats)
         if not mats:                                  # an empty feature archive is not an error in the reference's loop either
             return torch.empty((0, self.embed_dim), dtype=torch.float32)
+        if all(isinstance(m, torch.Tensor) and m.is_cuda for m in mats):
+            dev = torch.device("cuda", self.device_index)
+            for m in mats:
+                if m.dim() != 2 or m.shape[1] != self.feat_dim:
+                    raise ValueError("expected [frames, %d] feature matrices, got %s" % (self.feat_dim, tuple(m.shape)))
+            offsets = np.zeros(len(mats) + 1, dtype=np.int32)
+            np.cumsum([m.shape[0] for m in mats], out=offsets[1:])
+            with torch.cuda.device(dev):
+                packed = torch.cat([m.to(dev, torch.float32) for m in mats], dim=0) if len(mats) > 1 else mats[0].to(dev, torch.float32).contiguous()
+                return self.extract_device(packed, offsets, max_chunk=max_chunk).cpu()
+        mats = [np.asarray(m.cpu() if isinstance(m, torch.Tensor) else m, dtype=np.float32) for m in mats]
         for m in mats:
             if m.ndim != 2 or m.shape[1] != self.feat_dim:
                 raise ValueError("expected [frames, %d] feature matrices, got %s" % (self.feat_dim, m.shape))

@@ -57,6 +57,20 @@ def synth_feats(num_frames, feat_dim, seed):
     return np.random.RandomState(int(seed)).randn(int(num_frames), int(feat_dim)).astype(np.float32)
 
 
+def synth_wave(num_samples, seed, sample_rate=16000.0):
+    """A speech-like waveform: a few drifting harmonics under a slow envelope plus noise, rounded to int16 values and
+    returned as float32 (Kaldi WaveData convention).  Includes a DC offset so remove_dc_offset matters."""
+    r = np.random.RandomState(int(seed))
+    t = np.arange(int(num_samples), dtype=np.float64) / sample_rate
+    f0 = r.uniform(90.0, 220.0)
+    x = np.zeros_like(t)
+    for h in range(1, 12):
+        x += r.uniform(0.2, 1.0) / h * np.sin(2 * np.pi * h * f0 * t * (1.0 + 0.02 * np.sin(2 * np.pi * 3.0 * t)) + r.uniform(0, 6.28))
+    env = 0.55 + 0.45 * np.sin(2 * np.pi * r.uniform(2.0, 5.0) * t + r.uniform(0, 6.28))
+    x = 3000.0 * env * x + 400.0 * r.standard_normal(t.shape) + r.uniform(-50.0, 50.0)
+    return np.clip(np.rint(x), -32768, 32767).astype(np.float32)
+
+
 def synth_lengths(n, lo, hi, seed):
     """Utterance lengths ~ randint(lo, hi] (config C4/C5 stand-ins)."""
     return np.random.RandomState(int(seed)).randint(int(lo), int(hi) + 1, size=int(n)).astype(np.int64)

@@ -271,6 +271,48 @@ int asv_score_norm(const float *enroll_cohort, int n_enroll, const float *test_c
                    const int32_t *ei, const int32_t *ti, const float *scores, int n_trials, int top_n,
                    int cross_select, float *normed, void *stream);
 
+/* ---- acoustic front-end -------------------------------------------
+ * Kaldi-compatible log-mel filterbank features of packed waveforms on the device: what
+ * torchaudio.compliance.kaldi.fbank computes in pytorch/libs/egs/kaldi_features.py:72-137 and kaldifeat::Fbank in
+ * runtime/kaldifeat/csrc/feature-fbank.cc (the field names and defaults below are FbankOptions / FrameExtractionOptions /
+ * MelBanksOptions of that code).  Samples are floats in the int16 value range (Kaldi WaveData); dither is not offered
+ * (it is the one random step; extraction configs set it to 0); VTLN warp is 1. */
+#define ASV_WINDOW_POVEY       0
+#define ASV_WINDOW_HAMMING     1
+#define ASV_WINDOW_HANNING     2
+#define ASV_WINDOW_RECTANGULAR 3
+#define ASV_WINDOW_SINE        4
+typedef struct asv_fbank_opts {
+  uint32_t struct_size;
+  float   sample_rate;          /* 16000 */
+  float   frame_length_ms;      /* 25    */
+  float   frame_shift_ms;       /* 10    */
+  float   preemph;              /* 0.97  */
+  int32_t remove_dc_offset;     /* 1     */
+  int32_t window_type;          /* ASV_WINDOW_POVEY */
+  int32_t round_to_power_of_two;/* 1     */
+  int32_t snip_edges;           /* 1     */
+  int32_t num_bins;             /* 23    */
+  float   low_freq;             /* 20    */
+  float   high_freq;            /* 0: Nyquist; negative: offset from Nyquist */
+  int32_t use_energy;           /* 0     */
+  float   energy_floor;         /* 0: none */
+  int32_t raw_energy;           /* 1     */
+  int32_t htk_compat;           /* 0: energy first */
+  int32_t use_log_fbank;        /* 1     */
+  int32_t use_power;            /* 1     */
+} asv_fbank_opts_t;
+/* Frames an utterance of num_samples yields (feature-window.cc:71-114); -1 on bad options. */
+long long asv_fbank_num_frames(const asv_fbank_opts_t *opts, long long num_samples);
+/* wave: device floats, utterance u = samples [sample_offsets[u], sample_offsets[u+1]) (host int64 [n_utts+1]);
+ * feats: device [sum of frames][num_bins + use_energy] f32, utterances back to back in order. */
+int asv_fbank(const asv_fbank_opts_t *opts, const float *wave, const long long *sample_offsets, int n_utts,
+              float *feats, void *stream);
+/* Per-utterance mean / variance normalisation of every column, in place (kaldi_features.py:11-66
+ * InputSequenceNormalization: mean over the frames, unbiased std floored at eps).  frame_offsets: host int64 [n_utts+1]. */
+int asv_cmvn(float *feats, const long long *frame_offsets, int n_utts, int dim, int mean_norm, int std_norm, float eps,
+             void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,134 @@
+"""numpy restatement of the Kaldi-compatible log-mel filterbank front-end (TEST INFRASTRUCTURE - see oracle/__init__.py).
+
+SURVEY.md section 8(f) rank 2: the step in front of the extraction path.  The reference computes it with
+torchaudio.compliance.kaldi.fbank in Python (pytorch/libs/egs/kaldi_features.py:72-137; torchaudio is absent here) and
+with its C++ copy of kaldifeat in the runtime (runtime/kaldifeat/csrc).  This file follows the C++ sources, which ARE
+in the reference tree and are compiled in place into oracle/_ref/libkaldifeat_ref.so (oracle/Makefile.ref) to pin it:
+  framing / snip_edges                runtime/kaldifeat/csrc/feature-window.cc:60-133
+  dc removal, raw log energy          runtime/kaldifeat/csrc/feature-common-inl.h:32-47
+  pre-emphasis                        runtime/kaldifeat/csrc/feature-window.cc:150-170
+  window functions (povey, ...)       runtime/kaldifeat/csrc/feature-window.cc:21-51
+  |rfft|^2 without the Nyquist bin    runtime/kaldifeat/csrc/feature-fbank.cc:63-72
+  mel filterbank matrix               runtime/kaldifeat/csrc/mel-computations.cc:60-141 (MelScale = 1127 ln(1 + f / 700))
+  log with floor FLT_EPSILON          runtime/kaldifeat/csrc/feature-fbank.cc:74-77
+Dither must be 0 (the only random step); VTLN warping is not restated (warp factor 1).
+"""
+
+import numpy as np
+
+FLT_EPS = np.float32(1.1920928955078125e-07)
+
+
+def window_size(sample_rate, frame_length_ms):
+    return int(sample_rate * 0.001 * frame_length_ms)
+
+
+def padded_size(n, round_to_power_of_two=True):
+    if not round_to_power_of_two:
+        return n
+    p = 1
+    while p < n:
+        p *= 2
+    return p
+
+
+def num_frames(num_samples, sample_rate=16000.0, frame_length_ms=25.0, frame_shift_ms=10.0, snip_edges=True):
+    length, shift = window_size(sample_rate, frame_length_ms), window_size(sample_rate, frame_shift_ms)
+    if snip_edges:
+        return 0 if num_samples < length else 1 + (num_samples - length) // shift
+    return (num_samples + shift // 2) // shift
+
+
+def window_function(n, kind="povey", blackman_coeff=0.42):
+    a = 2.0 * np.pi / (n - 1)
+    i = np.arange(n, dtype=np.float64)
+    if kind == "hanning":
+        w = 0.5 - 0.5 * np.cos(a * i)
+    elif kind == "sine":
+        w = np.sin(0.5 * a * i)
+    elif kind == "hamming":
+        w = 0.54 - 0.46 * np.cos(a * i)
+    elif kind == "povey":
+        w = np.power(0.5 - 0.5 * np.cos(a * i), 0.85)
+    elif kind == "rectangular":
+        w = np.ones(n)
+    elif kind == "blackman":
+        w = blackman_coeff - 0.5 * np.cos(a * i) + (0.5 - blackman_coeff) * np.cos(2 * a * i)
+    else:
+        raise ValueError("Invalid window type " + kind)
+    return w.astype(np.float32)
+
+
+def mel_scale(f):
+    return np.float32(1127.0) * np.log(np.float32(1.0) + np.asarray(f, dtype=np.float32) / np.float32(700.0), dtype=np.float32)
+
+
+def mel_banks(num_bins, padded, sample_rate=16000.0, low_freq=20.0, high_freq=0.0):
+    """[padded / 2, num_bins] float32 triangular filters on the mel scale (mel-computations.cc:60-141, vtln warp 1)."""
+    nyquist = 0.5 * sample_rate
+    high = high_freq if high_freq > 0.0 else nyquist + high_freq
+    if low_freq < 0.0 or low_freq >= nyquist or high <= 0.0 or high > nyquist or high <= low_freq:
+        raise ValueError("Bad values in options: low-freq %s and high-freq %s vs. nyquist %s" % (low_freq, high, nyquist))
+    n_fft = padded // 2
+    width = np.float32(sample_rate / padded)
+    mel_low, mel_high = mel_scale(low_freq), mel_scale(high)
+    delta = np.float32((mel_high - mel_low) / np.float32(num_bins + 1))
+    mel = mel_scale(width * np.arange(n_fft, dtype=np.float32))
+    out = np.zeros((n_fft, num_bins), dtype=np.float32)
+    for b in range(num_bins):
+        left = np.float32(mel_low + np.float32(b) * delta)
+        center = np.float32(mel_low + np.float32(b + 1) * delta)
+        right = np.float32(mel_low + np.float32(b + 2) * delta)
+        inside = (mel > left) & (mel < right)
+        if not inside.any():
+            raise ValueError("You may have set num_mel_bins too large.")
+        up = (mel - left) / (center - left)
+        down = (right - mel) / (right - center)
+        out[:, b] = np.where(inside, np.where(mel <= center, up, down), np.float32(0.0))
+    return out
+
+
+def fbank(wave, sample_rate=16000.0, frame_length_ms=25.0, frame_shift_ms=10.0, preemph=0.97, remove_dc_offset=True, window_type="povey",
+          round_to_power_of_two=True, snip_edges=True, num_bins=23, low_freq=20.0, high_freq=0.0, use_energy=False, energy_floor=0.0,
+          raw_energy=True, htk_compat=False, use_log_fbank=True, use_power=True, dtype=np.float32):
+    """wave: 1-D samples in the int16 value range (Kaldi WaveData convention).  Returns [frames, num_bins (+1)]."""
+    wave = np.asarray(wave, dtype=np.float32)
+    length, shift = window_size(sample_rate, frame_length_ms), window_size(sample_rate, frame_shift_ms)
+    n = num_frames(len(wave), sample_rate, frame_length_ms, frame_shift_ms, snip_edges)
+    dim = num_bins + (1 if use_energy else 0)
+    if n == 0:
+        return np.zeros((0, dim), dtype=np.float32)
+    if not snip_edges:
+        pad = (n - 1) * shift + length - len(wave)
+        left = (length - shift) // 2
+        right = pad - left
+        wave = np.concatenate([wave[:left][::-1], wave, wave[len(wave) - right:][::-1] if right > 0 else wave[:0]])
+    idx = np.arange(n)[:, None] * shift + np.arange(length)[None, :]
+    frames = wave[idx].astype(dtype)
+    if remove_dc_offset:
+        frames = frames - frames.mean(axis=1, keepdims=True, dtype=dtype)
+    log_energy = None
+    if use_energy and raw_energy:
+        log_energy = np.log(np.maximum((frames * frames).sum(axis=1, dtype=dtype), FLT_EPS))
+    if preemph != 0.0:
+        out = np.empty_like(frames)
+        out[:, 1:] = frames[:, 1:] - dtype(preemph) * frames[:, :-1]
+        out[:, 0] = frames[:, 0] * dtype(1.0 - np.float32(preemph)) if dtype == np.float32 else frames[:, 0] * (1.0 - preemph)
+        frames = out
+    frames = frames * window_function(length, window_type).astype(dtype)[None, :]
+    padded = padded_size(length, round_to_power_of_two)
+    if padded > length:
+        frames = np.concatenate([frames, np.zeros((n, padded - length), dtype=dtype)], axis=1)
+    if use_energy and not raw_energy:
+        log_energy = np.log(np.maximum((frames * frames).sum(axis=1, dtype=dtype), FLT_EPS))
+    spec = np.abs(np.fft.rfft(frames.astype(np.float64), axis=1))[:, :-1]
+    if use_power:
+        spec = spec * spec
+    mel = spec.astype(dtype) @ mel_banks(num_bins, padded, sample_rate, low_freq, high_freq).astype(dtype)
+    if use_log_fbank:
+        mel = np.log(np.maximum(mel, FLT_EPS))
+    if use_energy:
+        if energy_floor > 0.0:
+            log_energy = np.maximum(log_energy, np.log(np.float32(energy_floor)))
+        mel = np.concatenate([mel, log_energy[:, None]] if htk_compat else [log_energy[:, None], mel], axis=1)
+    return mel.astype(np.float32)

@@ -1,0 +1,46 @@
+// C wrapper around the reference's own feature code (runtime/kaldifeat/csrc, compiled in place by oracle/Makefile.ref
+// into oracle/_ref/libkaldifeat_ref.so - TEST INFRASTRUCTURE, build container only).  It exposes the fbank computation
+// that runtime/extractor feeds the model with (feature_pipeline -> kaldifeat::Fbank), so the numpy restatement in
+// oracle/fbank_oracle.py and the HIP front-end can be pinned to outputs of the reference itself.
+#include <cstdint>
+#include <cstring>
+
+#include "kaldifeat/csrc/feature-fbank.h"
+
+extern "C" {
+
+// wave: n samples (float, in the int16 range like Kaldi's WaveData); out: [frames][num_bins] row-major, capacity cap_frames.
+// Returns the number of frames, or -1 if out is too small.
+int kaldifeat_ref_fbank(const float *wave, int n, float sample_rate, float frame_length_ms, float frame_shift_ms, float dither,
+                        float preemph, int remove_dc_offset, const char *window_type, int round_to_power_of_two, int snip_edges,
+                        int num_bins, float low_freq, float high_freq, int use_energy, float energy_floor, int raw_energy,
+                        int htk_compat, int use_log_fbank, int use_power, float *out, int cap_frames) {
+  kaldifeat::FbankOptions opts;
+  opts.frame_opts.samp_freq = sample_rate;
+  opts.frame_opts.frame_length_ms = frame_length_ms;
+  opts.frame_opts.frame_shift_ms = frame_shift_ms;
+  opts.frame_opts.dither = dither;
+  opts.frame_opts.preemph_coeff = preemph;
+  opts.frame_opts.remove_dc_offset = remove_dc_offset != 0;
+  opts.frame_opts.window_type = window_type;
+  opts.frame_opts.round_to_power_of_two = round_to_power_of_two != 0;
+  opts.frame_opts.snip_edges = snip_edges != 0;
+  opts.mel_opts.num_bins = num_bins;
+  opts.mel_opts.low_freq = low_freq;
+  opts.mel_opts.high_freq = high_freq;
+  opts.use_energy = use_energy != 0;
+  opts.energy_floor = energy_floor;
+  opts.raw_energy = raw_energy != 0;
+  opts.htk_compat = htk_compat != 0;
+  opts.use_log_fbank = use_log_fbank != 0;
+  opts.use_power = use_power != 0;
+  kaldifeat::Fbank fbank(opts);
+  torch::Tensor w = torch::from_blob(const_cast<float *>(wave), {n}, torch::kFloat).clone();
+  torch::Tensor feats = fbank.ComputeFeatures(w, 1.0f).contiguous();
+  const int frames = (int)feats.size(0), dim = (int)feats.size(1);
+  if (frames > cap_frames) return -1;
+  std::memcpy(out, feats.data_ptr<float>(), sizeof(float) * (size_t)frames * dim);
+  return frames;
+}
+
+}  // extern "C"

@@ -49,3 +49,23 @@ def rel_err(a, b):
     """max |a-b| / max |b|  (the 'relative fp32' metric of BASELINE.json's north_star)."""
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def fbank_cases():
+    """tests/golden/fbank.npz: outputs of the reference's kaldifeat code (oracle/gen_fbank_golden.py) ->
+    [(name, waveform regenerated from its seed, option dict, reference features)]."""
+    import json
+    from libs.amd import synth
+    g = np.load(os.path.join(GOLDEN, "fbank.npz"))
+    return [(name, synth.synth_wave(samples, seed, kw.get("sample_rate", 16000.0)), kw, g[name]) for name, samples, seed, kw in json.loads(str(g["cases"]))]
+
+
+# asv_fbank_opts_t / oracle names -> torchaudio.compliance.kaldi.fbank keywords (what libs.amd.frontend takes)
+FBANK_KW = dict(sample_rate="sample_frequency", frame_length_ms="frame_length", frame_shift_ms="frame_shift", preemph="preemphasis_coefficient",
+                num_bins="num_mel_bins")
+
+
+def fbank_torchaudio_kw(kw, energy_floor_default=0.0):
+    out = {FBANK_KW.get(k, k): v for k, v in kw.items()}
+    out.setdefault("energy_floor", energy_floor_default)          # kaldifeat's default (torchaudio's is 1.0)
+    return out
