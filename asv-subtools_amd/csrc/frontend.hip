@@ -45,6 +45,10 @@ struct FbankKernelParams {
   const int *seg_first;         // [n_seg]
   const int *bin_seg;           // [num_bins + 1]: segments of bin b are bin_seg[b] .. bin_seg[b + 1] - 1
   int n_seg;
+  int fpw;                      // consecutive frames one wave of fbank512_kernel walks
+  int num_ceps;                 // > 0: MFCC output
+  const float *dct;             // [num_ceps][num_bins], rows scaled by the lifter
+  float c0_scale;               // sqrt 2 for htk_compat without energy, else 1
   float *out;                   // [total_frames][dim]
 };
 
@@ -59,6 +63,19 @@ __device__ __forceinline__ float wave_sum(float v) {
   const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
   const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
   return (r0 + r1) + (r2 + r3);
+}
+
+
+// Cepstra of one frame from its log mel energies in LDS (feature-mfcc.cc:118-148): lane c sums row c of the liftered DCT
+// matrix; C0 is replaced by the log energy when asked for; htk_compat rotates C0 / the energy to the last column.
+__device__ __forceinline__ void write_cepstra(const FbankKernelParams &p, const float *logmel, float log_energy, float *dst, int lane) {
+  for (int c = lane; c < p.num_ceps; c += 64) {
+    const float *row = p.dct + (size_t)c * p.num_bins;
+    float acc = 0.0f;
+    for (int b = 0; b < p.num_bins; ++b) acc = fmaf(logmel[b], row[b], acc);
+    if (c == 0) acc = p.use_energy ? fmaxf(log_energy, p.log_energy_floor) : acc * p.c0_scale;
+    dst[p.htk_compat ? (c == 0 ? p.num_ceps - 1 : c - 1) : c] = acc;
+  }
 }
 
 __global__ __launch_bounds__(256) void fbank_kernel(const FbankKernelParams p) {
@@ -144,16 +161,19 @@ __global__ __launch_bounds__(256) void fbank_kernel(const FbankKernelParams p) {
     const float pw = re[i] * re[i] + im[i] * im[i];
     re[i] = p.use_power ? pw : sqrtf(pw);
   }
-  const int dim = p.num_bins + (p.use_energy ? 1 : 0);
+  const int dim = p.num_ceps > 0 ? p.num_ceps : p.num_bins + (p.use_energy ? 1 : 0);
   float *dst = p.out + (size_t)frame * dim;
+  const bool take_log = p.use_log || p.num_ceps > 0;
   for (int b = lane; b < p.num_bins; b += 64) {
     const float *w = p.mel_w + (size_t)b * p.mel_stride;
     const int i0 = p.mel_first[b], cnt = p.mel_count[b];
     float acc = 0.0f;
     for (int k = 0; k < cnt; ++k) acc = fmaf(re[i0 + k], w[k], acc);
-    if (p.use_log) acc = logf(fmaxf(acc, 1.1920928955078125e-07f));
-    dst[b + ((p.use_energy && !p.htk_compat) ? 1 : 0)] = acc;
+    if (take_log) acc = logf(fmaxf(acc, 1.1920928955078125e-07f));
+    if (p.num_ceps > 0) im[b] = acc;
+    else dst[b + ((p.use_energy && !p.htk_compat) ? 1 : 0)] = acc;
   }
+  if (p.num_ceps > 0) { write_cepstra(p, im, log_energy, dst, lane); return; }
   if (p.use_energy && lane == 0) dst[p.htk_compat ? p.num_bins : 0] = fmaxf(log_energy, p.log_energy_floor);
 }
 
@@ -179,26 +199,32 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
+// Exchange buffer indices (float2 slots).  A ds_write_b64 is served 16 consecutive lanes at a time over 32 banks, so the
+// 16 slots of a lane group must differ mod 16; the reads (lane + 64 r) stay contiguous per 32 lanes under each padding.
+//   pass 1 writes 4 j + r, pass 2 writes 16 (j / 4) + j % 4 + 4 r, pass 3 writes 64 (j / 16) + j % 16 + 16 r.
+__device__ __forceinline__ int pad1(int i) { return i + (i >> 4); }          // 16 lanes: 4 j + (j >> 2) -> all residues mod 16
+__device__ __forceinline__ int pad2(int i) { return i + ((i >> 4) << 2); }   // groups of 4 at 16 g -> 20 g: 0,4,8,12 mod 16
+__device__ __forceinline__ int pad3(int i) { return i; }                     // 16 consecutive slots already
 __device__ __forceinline__ cplx tw512(const float2 *t, int idx) {          // W512^idx for idx < 512 from the 256-entry table
   const float2 w = t[idx & 255];
   return (idx & 256) ? cplx{-w.x, -w.y} : cplx{w.x, w.y};
 }
 
-constexpr int kFastFpw = 4;          // frames per wave
 constexpr int kFastMaxSeg = 256;     // mel filter segments (<= 8 FFT bins each) the kernel has room for: 4 lanes-passes
 
+template <bool MFCC>
 __global__ __launch_bounds__(256) void fbank512_kernel(const FbankKernelParams p) {
-  __shared__ float2 xch[4][264];          // 256 points; later |X|^2 [256] + 8 zeros + segment sums [256]
-  __shared__ float4 segw[kFastMaxSeg][2];
+  __shared__ float2 xch[4][320];          // 256 points (padded to 316 slots); later |X|^2 [256] + 8 zeros + segment sums [256]
+  __shared__ float4 segw[2][kFastMaxSeg];
   __shared__ int segk[kFastMaxSeg];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < p.n_seg; i += 256) {
-    segw[i][0] = reinterpret_cast<const float4 *>(p.seg_w)[2 * i];
-    segw[i][1] = reinterpret_cast<const float4 *>(p.seg_w)[2 * i + 1];
+    segw[0][i] = reinterpret_cast<const float4 *>(p.seg_w)[2 * i];
+    segw[1][i] = reinterpret_cast<const float4 *>(p.seg_w)[2 * i + 1];
     segk[i] = p.seg_first[i];
   }
   __syncthreads();
-  const long long frame0 = ((long long)blockIdx.x * 4 + wave) * kFastFpw;
+  const long long frame0 = ((long long)blockIdx.x * 4 + wave) * p.fpw;
   if (frame0 >= p.total_frames) return;
   float2 *my = xch[wave];
   float *pw = reinterpret_cast<float *>(my);
@@ -229,36 +255,50 @@ __global__ __launch_bounds__(256) void fbank512_kernel(const FbankKernelParams p
   }
   long long f_begin = p.frame_off[u], f_end = p.frame_off[u + 1], s0 = p.sample_off[u], ns = p.sample_off[u + 1] - s0;
   const long long left = p.snip_edges ? 0 : (p.length - p.shift) / 2;
-  const int dim = p.num_bins + (p.use_energy ? 1 : 0);
+  const int dim = MFCC ? p.num_ceps : p.num_bins + (p.use_energy ? 1 : 0);
+  const bool take_log = MFCC || p.use_log;
   const float inv_len = 1.0f / (float)p.length;
-  for (int it = 0; it < kFastFpw; ++it) {
-    const long long frame = frame0 + it;
-    if (frame >= p.total_frames) break;
+  // the samples of frame `frame` (utterances are walked forwards) -> e[r] = x[2 (lane + 64 r)], o[r] = x[2 (lane + 64 r) + 1]
+  auto fetch = [&](long long frame, float e[4], float o[4]) {
     while (frame >= f_end) {                                                // empty utterances have f_begin == f_end
       ++u;
       f_begin = f_end; f_end = p.frame_off[u + 1]; s0 = p.sample_off[u]; ns = p.sample_off[u + 1] - s0;
     }
     const long long first = (frame - f_begin) * p.shift - left;
     const float *src = p.wave + s0;
-    float e[4], o[4];
+    // loads are unconditional (indices clamped into the window), the values past the window are masked afterwards
     if (first >= 0 && first + p.length <= ns) {
+      const float *q = src + first;
       for (int r = 0; r < 4; ++r) {
         const int i = 2 * (lane + 64 * r);
-        e[r] = i < p.length ? src[first + i] : 0.0f;
-        o[r] = i + 1 < p.length ? src[first + i + 1] : 0.0f;
+        e[r] = q[min(i, p.length - 1)];
+        o[r] = q[min(i + 1, p.length - 1)];
       }
     } else {                                                                // mirrored edges (snip_edges off)
       for (int r = 0; r < 4; ++r) {
         const int i = 2 * (lane + 64 * r);
-        long long k0 = first + i, k1 = first + i + 1;
-        if (k0 < 0) k0 = -k0 - 1;
-        if (k0 >= ns) k0 = 2 * ns - 1 - k0;
-        if (k1 < 0) k1 = -k1 - 1;
-        if (k1 >= ns) k1 = 2 * ns - 1 - k1;
-        e[r] = i < p.length ? src[k0] : 0.0f;
-        o[r] = i + 1 < p.length ? src[k1] : 0.0f;
+        long long k0 = first + min(i, p.length - 1), k1 = first + min(i + 1, p.length - 1);
+        k0 = k0 < 0 ? -k0 - 1 : k0;
+        k0 = k0 >= ns ? 2 * ns - 1 - k0 : k0;
+        k1 = k1 < 0 ? -k1 - 1 : k1;
+        k1 = k1 >= ns ? 2 * ns - 1 - k1 : k1;
+        e[r] = src[k0];
+        o[r] = src[k1];
       }
     }
+  };
+  float en[4], on[4];                                                       // next frame's samples, in flight during this frame
+  fetch(frame0, en, on);
+  for (int it = 0; it < p.fpw; ++it) {
+    const long long frame = frame0 + it;
+    if (frame >= p.total_frames) break;
+    float e[4], o[4];
+    for (int r = 0; r < 4; ++r) {
+      const int i = 2 * (lane + 64 * r);
+      e[r] = i < p.length ? en[r] : 0.0f;
+      o[r] = i + 1 < p.length ? on[r] : 0.0f;
+    }
+    if (it + 1 < p.fpw && frame + 1 < p.total_frames) fetch(frame + 1, en, on);
     if (p.remove_dc) {
       const float mean = wave_sum((e[0] + o[0]) + (e[1] + o[1]) + (e[2] + o[2]) + (e[3] + o[3])) * inv_len;
       for (int r = 0; r < 4; ++r) {
@@ -294,25 +334,24 @@ __global__ __launch_bounds__(256) void fbank512_kernel(const FbankKernelParams p
     }
     // pass 1 (Ns = 1, no twiddles)
     dft4(v);
-    *reinterpret_cast<float4 *>(&my[4 * lane]) = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
-    *reinterpret_cast<float4 *>(&my[4 * lane + 2]) = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
+    for (int r = 0; r < 4; ++r) my[pad1(4 * lane + r)] = make_float2(v[r].x, v[r].y);
     wave_lds_sync();
     // pass 2 (Ns = 4)
-    for (int r = 0; r < 4; ++r) { const float2 t = my[lane + 64 * r]; v[r] = {t.x, t.y}; }
+    for (int r = 0; r < 4; ++r) { const float2 t = my[pad1(lane + 64 * r)]; v[r] = {t.x, t.y}; }
     for (int r = 1; r < 4; ++r) v[r] = cmul(v[r], t2[r - 1]);
     dft4(v);
     wave_lds_sync();
-    for (int r = 0; r < 4; ++r) my[o2 + 4 * r] = make_float2(v[r].x, v[r].y);
+    for (int r = 0; r < 4; ++r) my[pad2(o2 + 4 * r)] = make_float2(v[r].x, v[r].y);
     wave_lds_sync();
     // pass 3 (Ns = 16)
-    for (int r = 0; r < 4; ++r) { const float2 t = my[lane + 64 * r]; v[r] = {t.x, t.y}; }
+    for (int r = 0; r < 4; ++r) { const float2 t = my[pad2(lane + 64 * r)]; v[r] = {t.x, t.y}; }
     for (int r = 1; r < 4; ++r) v[r] = cmul(v[r], t3[r - 1]);
     dft4(v);
     wave_lds_sync();
-    for (int r = 0; r < 4; ++r) my[o3 + 16 * r] = make_float2(v[r].x, v[r].y);
+    for (int r = 0; r < 4; ++r) my[pad3(o3 + 16 * r)] = make_float2(v[r].x, v[r].y);
     wave_lds_sync();
     // pass 4 (Ns = 64): bins lane + 64 r stay in registers
-    for (int r = 0; r < 4; ++r) { const float2 t = my[lane + 64 * r]; v[r] = {t.x, t.y}; }
+    for (int r = 0; r < 4; ++r) { const float2 t = my[pad3(lane + 64 * r)]; v[r] = {t.x, t.y}; }
     for (int r = 1; r < 4; ++r) v[r] = cmul(v[r], t4[r - 1]);
     dft4(v);
     wave_lds_sync();
@@ -326,14 +365,14 @@ __global__ __launch_bounds__(256) void fbank512_kernel(const FbankKernelParams p
       const cplx od = cmul(cplx{d.y, -d.x}, ts[r]);                          // -i d W512^k
       const float xr = ev.x + od.x, xi = ev.y + od.y;
       const float pwr = xr * xr + xi * xi;
-      pw[lane + 64 * r] = p.use_power ? pwr : sqrtf(pwr);                    // overwrites pass-4 inputs, already consumed
+      pw[lane + 64 * r] = (MFCC || p.use_power) ? pwr : sqrtf(pwr);                    // overwrites pass-4 inputs, already consumed
     }
     if (lane < 8) pw[256 + lane] = 0.0f;
     wave_lds_sync();
     // mel filters: one lane per segment of <= 8 FFT bins, partial sums to LDS, then one lane per mel bin adds its segments
     float *part = pw + 256 + 8;                                              // pw[256 .. 263] is read (times 0) by the last segments
     for (int sg = lane; sg < p.n_seg; sg += 64) {
-      const float4 w0 = segw[sg][0], w1 = segw[sg][1];
+      const float4 w0 = segw[0][sg], w1 = segw[1][sg];
       const float *q = pw + segk[sg];
       float acc = q[0] * w0.x;
       acc = fmaf(q[1], w0.y, acc); acc = fmaf(q[2], w0.z, acc); acc = fmaf(q[3], w0.w, acc);
@@ -346,10 +385,14 @@ __global__ __launch_bounds__(256) void fbank512_kernel(const FbankKernelParams p
       const int s_lo = p.bin_seg[b], s_hi = p.bin_seg[b + 1];
       float acc = part[s_lo];
       for (int sg = s_lo + 1; sg < s_hi; ++sg) acc += part[sg];
-      if (p.use_log) acc = logf(fmaxf(acc, 1.1920928955078125e-07f));
-      dst[b + ((p.use_energy && !p.htk_compat) ? 1 : 0)] = acc;
+      if (take_log) acc = logf(fmaxf(acc, 1.1920928955078125e-07f));
+      if (MFCC) pw[b] = acc;                                       // |X|^2 is consumed; num_bins <= 256 here
+      else dst[b + ((p.use_energy && !p.htk_compat) ? 1 : 0)] = acc;
     }
-    if (p.use_energy && lane == 0) dst[p.htk_compat ? p.num_bins : 0] = fmaxf(log_energy, p.log_energy_floor);
+    if (MFCC) {
+      wave_lds_sync();
+      write_cepstra(p, pw, log_energy, dst, lane);
+    } else if (p.use_energy && lane == 0) dst[p.htk_compat ? p.num_bins : 0] = fmaxf(log_energy, p.log_energy_floor);
     wave_lds_sync();                                                         // the next frame's pass 1 overwrites pw
   }
 }
@@ -389,7 +432,7 @@ float mel_scale(float f) { return 1127.0f * logf(1.0f + f / 700.0f); }
 thread_local std::vector<void *> g_front_dev;            // device tables of the last option set (tiny; rebuilt on change)
 thread_local asv_fbank_opts_t g_front_opts;
 thread_local bool g_front_valid = false;
-struct FrontTables { float *window; float2 *twiddle; float *mel_w; int *mel_first, *mel_count; int mel_stride; float *seg_w; int *seg_first, *bin_seg; int n_seg; long long *offs; size_t offs_cap; };
+struct FrontTables { float *dct; float *window; float2 *twiddle; float *mel_w; int *mel_first, *mel_count; int mel_stride; float *seg_w; int *seg_first, *bin_seg; int n_seg; long long *offs; size_t offs_cap; };
 thread_local FrontTables g_tab = {};
 
 int window_size(const asv_fbank_opts_t &o, float ms) { return (int)(o.sample_rate * 0.001f * ms); }
@@ -413,6 +456,7 @@ int asv_fbank(const asv_fbank_opts_t *o, const float *wave, const long long *sam
   ASV_REQUIRE(o && o->struct_size == sizeof(asv_fbank_opts_t), "asv_fbank: struct_size mismatch");
   ASV_REQUIRE(wave && sample_offsets && feats && n_utts >= 1, "asv_fbank: bad argument");
   ASV_REQUIRE(o->num_bins >= 3 && o->num_bins <= 512, "asv_fbank: num_bins %d", o->num_bins);
+  ASV_REQUIRE(o->num_ceps >= 0 && o->num_ceps <= o->num_bins, "asv_fbank: num_ceps %d must not exceed num_bins %d", o->num_ceps, o->num_bins);
   ASV_REQUIRE(o->window_type >= ASV_WINDOW_POVEY && o->window_type <= ASV_WINDOW_SINE, "asv_fbank: window type %d", o->window_type);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int length = window_size(*o, o->frame_length_ms), shift = window_size(*o, o->frame_shift_ms);
@@ -501,6 +545,20 @@ int asv_fbank(const asv_fbank_opts_t *o, const float *wave, const long long *sam
     if ((rc = up(segk.data(), segk.size() * 4, reinterpret_cast<void **>(&g_tab.seg_first)))) return rc;
     if ((rc = up(binseg.data(), binseg.size() * 4, reinterpret_cast<void **>(&g_tab.bin_seg)))) return rc;
     g_tab.n_seg = (int)segk.size();
+    g_tab.dct = nullptr;
+    if (o->num_ceps > 0) {
+      // matrix-functions.cc:15-43 (DCT-II rows, float normalisers, double cosine) x mel-computations.cc:203-212 (lifter)
+      const int nb = o->num_bins;
+      std::vector<float> dct((size_t)o->num_ceps * nb);
+      for (int c = 0; c < o->num_ceps; ++c) {
+        const float lift = o->cepstral_lifter != 0.0f ? (float)(1.0 + 0.5 * o->cepstral_lifter * sin(M_PI * c / o->cepstral_lifter)) : 1.0f;
+        for (int b = 0; b < nb; ++b) {
+          const float v = c == 0 ? sqrtf(1.0f / nb) : sqrtf(2.0f / nb) * (float)cos(M_PI / nb * (b + 0.5) * c);
+          dct[(size_t)c * nb + b] = v * lift;
+        }
+      }
+      if ((rc = up(dct.data(), dct.size() * 4, reinterpret_cast<void **>(&g_tab.dct)))) return rc;
+    }
     g_tab.offs = nullptr; g_tab.offs_cap = 0;
     g_front_opts = *o;
     g_front_valid = true;
@@ -533,15 +591,25 @@ int asv_fbank(const asv_fbank_opts_t *o, const float *wave, const long long *sam
   p.wave = wave; p.sample_off = g_tab.offs; p.frame_off = g_tab.offs + (n_utts + 1); p.n_utts = n_utts; p.total_frames = total;
   p.length = length; p.shift = shift; p.padded = padded; p.log2n = log2n; p.preemph = o->preemph;
   p.remove_dc = o->remove_dc_offset; p.snip_edges = o->snip_edges; p.use_energy = o->use_energy; p.raw_energy = o->raw_energy;
-  p.htk_compat = o->htk_compat; p.use_log = o->use_log_fbank; p.use_power = o->use_power;
+  p.htk_compat = o->htk_compat; p.use_log = o->use_log_fbank || o->num_ceps > 0; p.use_power = o->use_power || o->num_ceps > 0;
   p.log_energy_floor = o->energy_floor > 0.0f ? logf(o->energy_floor) : -INFINITY;
   p.num_bins = o->num_bins; p.window = g_tab.window; p.twiddle = g_tab.twiddle; p.mel_w = g_tab.mel_w;
   p.mel_first = g_tab.mel_first; p.mel_count = g_tab.mel_count; p.mel_stride = g_tab.mel_stride; p.out = feats;
+  p.num_ceps = o->num_ceps; p.dct = g_tab.dct; p.c0_scale = (o->htk_compat && !o->use_energy) ? (float)M_SQRT2 : 1.0f;
   p.seg_w = g_tab.seg_w; p.seg_first = g_tab.seg_first; p.bin_seg = g_tab.bin_seg; p.n_seg = g_tab.n_seg;
   static const bool generic_only = getenv("ASV_AMD_FBANK_GENERIC") != nullptr;
-  if (padded == 512 && g_tab.n_seg <= kFastMaxSeg && !generic_only) {
-    const long long per_wg = 4 * kFastFpw;
-    hipLaunchKernelGGL(fbank512_kernel, dim3((unsigned)((total + per_wg - 1) / per_wg)), dim3(256), 0, s, p);
+  if (padded == 512 && g_tab.n_seg <= kFastMaxSeg && o->num_bins <= 256 && !generic_only) {
+    // every wave gets the same number of consecutive frames: enough workgroups for 4 per CU, at least 4 frames each so
+    // that the per-wave set-up (lane constants, utterance search) is shared
+    static const int cus = [] {
+      int dev = 0, n = 0;
+      return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }();
+    const long long waves = (long long)cus * 4 * 4;
+    p.fpw = (int)std::max<long long>(4, (total + waves - 1) / waves);
+    const long long per_wg = 4LL * p.fpw;
+    if (o->num_ceps > 0) hipLaunchKernelGGL(fbank512_kernel<true>, dim3((unsigned)((total + per_wg - 1) / per_wg)), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(fbank512_kernel<false>, dim3((unsigned)((total + per_wg - 1) / per_wg)), dim3(256), 0, s, p);
     ASV_HIP_CHECK(hipGetLastError());
     return ASV_OK;
   }

@@ -102,6 +102,7 @@ class FbankOpts(C.Structure):
         ("num_bins", C.c_int32), ("low_freq", C.c_float), ("high_freq", C.c_float),
         ("use_energy", C.c_int32), ("energy_floor", C.c_float), ("raw_energy", C.c_int32), ("htk_compat", C.c_int32),
         ("use_log_fbank", C.c_int32), ("use_power", C.c_int32),
+        ("num_ceps", C.c_int32), ("cepstral_lifter", C.c_float),
     ]
 
 

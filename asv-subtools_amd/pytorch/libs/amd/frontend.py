@@ -21,12 +21,24 @@ _DEFAULTS = dict(
     use_energy=False, use_log_fbank=True, use_power=True, vtln_high=-500.0, vtln_low=100.0, vtln_warp=1.0, window_type="povey")
 
 
-def fbank_options(**kw):
+# torchaudio.compliance.kaldi.mfcc: the same framing / mel options, no use_log_fbank / use_power, plus the cepstral ones
+_MFCC_DEFAULTS = dict({k: v for k, v in _DEFAULTS.items() if k not in ("use_log_fbank", "use_power")}, num_ceps=13, cepstral_lifter=22.0)
+
+
+def fbank_options(_kind="fbank", **kw):
     """A filled asv_fbank_opts_t from torchaudio-style keywords; refuses what the device path does not compute."""
-    unknown = set(kw) - set(_DEFAULTS)
+    defaults = _DEFAULTS if _kind == "fbank" else _MFCC_DEFAULTS
+    unknown = set(kw) - set(defaults)
     if unknown:
-        raise TypeError("fbank: unknown option(s) %s" % sorted(unknown))
-    o = dict(_DEFAULTS, **kw)
+        raise TypeError("%s: unknown option(s) %s" % (_kind, sorted(unknown)))
+    o = dict(defaults, **kw)
+    o.setdefault("use_log_fbank", True)
+    o.setdefault("use_power", True)
+    o.setdefault("num_ceps", 0)
+    o.setdefault("cepstral_lifter", 0.0)
+    o["dim"] = o["num_ceps"] if _kind == "mfcc" else o["num_mel_bins"] + int(o["use_energy"])
+    if _kind == "mfcc" and not 1 <= o["num_ceps"] <= o["num_mel_bins"]:
+        raise ValueError("mfcc: num_ceps %d must be in [1, num_mel_bins = %d]" % (o["num_ceps"], o["num_mel_bins"]))
     if o["dither"] != 0.0:
         raise ValueError("fbank: dither is random noise and is not offered on the device path; set dither=0.0 (extraction configs do)")
     if o["vtln_warp"] != 1.0:
@@ -52,11 +64,17 @@ def fbank_options(**kw):
     opts.htk_compat = int(o["htk_compat"])
     opts.use_log_fbank = int(o["use_log_fbank"])
     opts.use_power = int(o["use_power"])
+    opts.num_ceps = o["num_ceps"]
+    opts.cepstral_lifter = o["cepstral_lifter"]
     return opts, o
 
 
+def mfcc_options(**kw):
+    return fbank_options("mfcc", **kw)
+
+
 def num_frames(num_samples, **kw):
-    opts, _ = fbank_options(**kw)
+    opts, _ = fbank_options("fbank", **kw)
     n = capi.lib().asv_fbank_num_frames(C.byref(opts), int(num_samples))
     if n < 0:
         raise capi.AsvError("asv_fbank_num_frames: bad options")
@@ -73,11 +91,11 @@ def _frame_counts(lens, o):
     return (lens + shift // 2) // shift
 
 
-def fbank_device(wave, sample_off, mean_norm=False, std_norm=False, eps=1e-10, **kw):
+def fbank_device(wave, sample_off, mean_norm=False, std_norm=False, eps=1e-10, kind="fbank", **kw):
     """wave: 1-D f32 CUDA tensor holding all utterances back to back, sample_off: int64 numpy [n+1].
-    Returns (feats [sum frames, dim] f32 CUDA tensor, frame_offsets int64 numpy [n+1])."""
+    Returns (feats [sum frames, dim] f32 CUDA tensor, frame_offsets int64 numpy [n+1]).  kind="mfcc": cepstra."""
     import torch
-    opts, o = fbank_options(**kw)
+    opts, o = fbank_options(kind, **kw)
     lib = capi.lib()
     sample_off = np.ascontiguousarray(sample_off, dtype=np.int64)
     n = len(sample_off) - 1
@@ -85,7 +103,7 @@ def fbank_device(wave, sample_off, mean_norm=False, std_norm=False, eps=1e-10, *
         raise ValueError("fbank_device: wave must be a contiguous 1-D f32 CUDA tensor of sample_off[-1] samples")
     frame_off = np.zeros(n + 1, dtype=np.int64)
     np.cumsum(_frame_counts(np.diff(sample_off), o), out=frame_off[1:])
-    dim = o["num_mel_bins"] + int(o["use_energy"])
+    dim = o["dim"]
     feats = torch.empty((int(frame_off[-1]), dim), dtype=torch.float32, device=wave.device)
     stream = C.c_void_p(torch.cuda.current_stream(wave.device).cuda_stream)
     with torch.cuda.device(wave.device):
@@ -125,3 +143,8 @@ def fbank(waveforms, **kw):
     """List of per-utterance [frames, dim] CUDA tensors (views of one packed allocation)."""
     feats, off = fbank_packed(waveforms, **kw)
     return [feats[int(a):int(b)] for a, b in zip(off[:-1], off[1:])]
+
+
+def mfcc(waveforms, **kw):
+    """torchaudio.compliance.kaldi.mfcc for a batch: list of [frames, num_ceps] CUDA tensors."""
+    return fbank(waveforms, kind="mfcc", **kw)

@@ -32,13 +32,10 @@ class InputSequenceNormalization(object):
 class KaldiFeature(object):
     def __init__(self, feature_type='mfcc', kaldi_featset={}, mean_var_conf={}):
         assert feature_type in ['mfcc', 'fbank']
-        if feature_type == 'mfcc':
-            raise NotImplementedError("KaldiFeature: only feature_type='fbank' runs on the device path (the fbank recipes of "
-                                      "SURVEY.md 8); MFCC is not built yet")
         self.feat_type = feature_type
         self.kaldi_featset = dict(kaldi_featset)
         self.mean_var_conf = dict(mean_var_conf)
-        frontend.fbank_options(**self.kaldi_featset)                      # option errors at construction, like a bad config should
+        frontend.fbank_options(feature_type, **self.kaldi_featset)        # option errors at construction, like a bad config should
 
     def __call__(self, waveforms, lengths=None):
         """waveforms: [batch, time] (or [batch, time, 1]) tensor, lengths: relative lengths [batch] or None."""
@@ -55,4 +52,4 @@ class KaldiFeature(object):
             waves.append(wav[:n])
         mv = self.mean_var_conf
         return frontend.fbank(waves, mean_norm=bool(mv.get('mean_norm', True)) if mv else False,
-                              std_norm=bool(mv.get('std_norm', False)) if mv else False, **self.kaldi_featset)
+                              std_norm=bool(mv.get('std_norm', False)) if mv else False, kind=self.feat_type, **self.kaldi_featset)

@@ -301,11 +301,16 @@ typedef struct asv_fbank_opts {
   int32_t htk_compat;           /* 0: energy first */
   int32_t use_log_fbank;        /* 1     */
   int32_t use_power;            /* 1     */
+  /* MFCC (feature-mfcc.cc:78-150): num_ceps > 0 turns the output into num_ceps cepstra = DCT-II of the log mel energies
+   * (always log of power; use_log_fbank / use_power are ignored), liftered; with use_energy C0 is replaced by the log
+   * energy; htk_compat moves C0 / the energy last (C0 scaled by sqrt 2 when it is not the energy). */
+  int32_t num_ceps;             /* 0: filterbank output */
+  float   cepstral_lifter;      /* 22    */
 } asv_fbank_opts_t;
 /* Frames an utterance of num_samples yields (feature-window.cc:71-114); -1 on bad options. */
 long long asv_fbank_num_frames(const asv_fbank_opts_t *opts, long long num_samples);
 /* wave: device floats, utterance u = samples [sample_offsets[u], sample_offsets[u+1]) (host int64 [n_utts+1]);
- * feats: device [sum of frames][num_bins + use_energy] f32, utterances back to back in order. */
+ * feats: device [sum of frames][dim] f32, utterances back to back in order; dim = num_bins + use_energy, or num_ceps. */
 int asv_fbank(const asv_fbank_opts_t *opts, const float *wave, const long long *sample_offsets, int n_utts,
               float *feats, void *stream);
 /* Per-utterance mean / variance normalisation of every column, in place (kaldi_features.py:11-66

@@ -132,3 +132,36 @@ def fbank(wave, sample_rate=16000.0, frame_length_ms=25.0, frame_shift_ms=10.0, 
             log_energy = np.maximum(log_energy, np.log(np.float32(energy_floor)))
         mel = np.concatenate([mel, log_energy[:, None]] if htk_compat else [log_energy[:, None], mel], axis=1)
     return mel.astype(np.float32)
+
+
+def dct_matrix(num_ceps, num_bins):
+    """Rows 0..num_ceps-1 of the orthonormal DCT-II (reference matrix-functions.cc:15-43: float normalisers, double cosine)."""
+    out = np.empty((num_ceps, num_bins), dtype=np.float32)
+    out[0, :] = np.sqrt(np.float32(1.0) / np.float32(num_bins))
+    norm = np.sqrt(np.float32(2.0) / np.float32(num_bins))
+    for r in range(1, num_ceps):
+        out[r, :] = norm * np.cos(np.pi / num_bins * (np.arange(num_bins) + 0.5) * r).astype(np.float32)
+    return out
+
+
+def lifter_coeffs(q, n):
+    """1 + Q/2 sin(pi i / Q) (reference mel-computations.cc:203-212)."""
+    return (1.0 + 0.5 * q * np.sin(np.pi * np.arange(n) / q)).astype(np.float32)
+
+
+def mfcc(wave, num_ceps=13, cepstral_lifter=22.0, use_energy=True, energy_floor=0.0, raw_energy=True, htk_compat=False, num_bins=23, **kw):
+    """Reference feature-mfcc.cc:78-150: log mel energies of the power spectrum -> DCT -> lifter; C0 replaced by the log
+    energy (use_energy); htk_compat rolls C0 / the energy to the last column (C0 times sqrt 2 when it is not the energy)."""
+    both = fbank(wave, num_bins=num_bins, use_energy=True, energy_floor=energy_floor, raw_energy=raw_energy, htk_compat=False,
+                 use_log_fbank=True, use_power=True, **kw)
+    log_energy, logmel = both[:, 0], both[:, 1:]
+    feats = logmel @ dct_matrix(num_ceps, num_bins).T
+    if cepstral_lifter != 0.0:
+        feats = feats * lifter_coeffs(cepstral_lifter, num_ceps)[None, :]
+    if use_energy:
+        feats[:, 0] = log_energy
+    if htk_compat:
+        feats = np.roll(feats, -1, axis=1)
+        if not use_energy:
+            feats[:, -1] *= np.float32(np.sqrt(2.0))
+    return feats.astype(np.float32)

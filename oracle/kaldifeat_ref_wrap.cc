@@ -6,6 +6,7 @@
 #include <cstring>
 
 #include "kaldifeat/csrc/feature-fbank.h"
+#include "kaldifeat/csrc/feature-mfcc.h"
 
 extern "C" {
 
@@ -37,6 +38,40 @@ int kaldifeat_ref_fbank(const float *wave, int n, float sample_rate, float frame
   kaldifeat::Fbank fbank(opts);
   torch::Tensor w = torch::from_blob(const_cast<float *>(wave), {n}, torch::kFloat).clone();
   torch::Tensor feats = fbank.ComputeFeatures(w, 1.0f).contiguous();
+  const int frames = (int)feats.size(0), dim = (int)feats.size(1);
+  if (frames > cap_frames) return -1;
+  std::memcpy(out, feats.data_ptr<float>(), sizeof(float) * (size_t)frames * dim);
+  return frames;
+}
+
+
+// kaldifeat::Mfcc with the same calling convention; out: [frames][num_ceps].
+int kaldifeat_ref_mfcc(const float *wave, int n, float sample_rate, float frame_length_ms, float frame_shift_ms, float preemph,
+                       int remove_dc_offset, const char *window_type, int round_to_power_of_two, int snip_edges, int num_bins,
+                       float low_freq, float high_freq, int num_ceps, float cepstral_lifter, int use_energy, float energy_floor,
+                       int raw_energy, int htk_compat, float *out, int cap_frames) {
+  kaldifeat::MfccOptions opts;
+  opts.frame_opts.samp_freq = sample_rate;
+  opts.frame_opts.frame_length_ms = frame_length_ms;
+  opts.frame_opts.frame_shift_ms = frame_shift_ms;
+  opts.frame_opts.dither = 0.0f;
+  opts.frame_opts.preemph_coeff = preemph;
+  opts.frame_opts.remove_dc_offset = remove_dc_offset != 0;
+  opts.frame_opts.window_type = window_type;
+  opts.frame_opts.round_to_power_of_two = round_to_power_of_two != 0;
+  opts.frame_opts.snip_edges = snip_edges != 0;
+  opts.mel_opts.num_bins = num_bins;
+  opts.mel_opts.low_freq = low_freq;
+  opts.mel_opts.high_freq = high_freq;
+  opts.num_ceps = num_ceps;
+  opts.cepstral_lifter = cepstral_lifter;
+  opts.use_energy = use_energy != 0;
+  opts.energy_floor = energy_floor;
+  opts.raw_energy = raw_energy != 0;
+  opts.htk_compat = htk_compat != 0;
+  kaldifeat::Mfcc mfcc(opts);
+  torch::Tensor w = torch::from_blob(const_cast<float *>(wave), {n}, torch::kFloat).clone();
+  torch::Tensor feats = mfcc.ComputeFeatures(w, 1.0f).contiguous();
   const int frames = (int)feats.size(0), dim = (int)feats.size(1);
   if (frames > cap_frames) return -1;
   std::memcpy(out, feats.data_ptr<float>(), sizeof(float) * (size_t)frames * dim);

@@ -60,9 +60,17 @@ def fbank_cases():
     return [(name, synth.synth_wave(samples, seed, kw.get("sample_rate", 16000.0)), kw, g[name]) for name, samples, seed, kw in json.loads(str(g["cases"]))]
 
 
+def mfcc_cases():
+    import json
+    from libs.amd import synth
+    g = np.load(os.path.join(GOLDEN, "fbank.npz"))
+    return [(name, synth.synth_wave(samples, seed, kw.get("sample_rate", 16000.0)), kw, g[name]) for name, samples, seed, kw in json.loads(str(g["mfcc_cases"]))]
+
+
 # asv_fbank_opts_t / oracle names -> torchaudio.compliance.kaldi.fbank keywords (what libs.amd.frontend takes)
 FBANK_KW = dict(sample_rate="sample_frequency", frame_length_ms="frame_length", frame_shift_ms="frame_shift", preemph="preemphasis_coefficient",
                 num_bins="num_mel_bins")
+MFCC_REF_DEFAULTS = dict(use_energy=True, energy_floor=0.0)           # kaldifeat's MfccOptions (torchaudio: False, 1.0)
 
 
 def fbank_torchaudio_kw(kw, energy_floor_default=0.0):

@@ -21,6 +21,14 @@ def test_oracle_matches_reference_kaldifeat_outputs():
             assert helpers.rel_err(got, ref) < 1e-5, name
 
 
+def test_mfcc_oracle_matches_reference_kaldifeat_outputs():
+    cases = helpers.mfcc_cases()
+    assert len(cases) >= 5
+    for name, wave, kw, ref in cases:
+        got = fbank_oracle.mfcc(wave, **kw)
+        assert got.shape == ref.shape and np.abs(got - ref).max() < 5e-4, (name, np.abs(got - ref).max())
+
+
 def test_frame_counts_of_the_c_abi_match_the_oracle():
     from libs.amd import frontend
     for n in (0, 1, 399, 400, 401, 559, 560, 561, 16000, 123457):
@@ -38,7 +46,9 @@ def test_unsupported_options_are_refused_up_front():
         frontend.fbank_options(window_type="blackman")
     with pytest.raises(TypeError):
         frontend.fbank_options(num_bins=80)                      # torchaudio spells it num_mel_bins
-    with pytest.raises(NotImplementedError):
-        KaldiFeature("mfcc")
+    with pytest.raises(ValueError):
+        KaldiFeature("mfcc", {"num_ceps": 30})                   # > num_mel_bins (23)
+    with pytest.raises(TypeError):
+        KaldiFeature("mfcc", {"use_power": False})               # torchaudio's mfcc has no such option
     with pytest.raises(ValueError):
         KaldiFeature("fbank", {"dither": 0.5})

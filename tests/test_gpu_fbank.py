@@ -27,6 +27,21 @@ def test_fbank_matches_reference_kaldifeat_outputs():
             assert helpers.rel_err(got, ref) < 2e-5, name
 
 
+def test_mfcc_matches_reference_kaldifeat_outputs():
+    from libs.amd import frontend
+    for name, wave, kw, ref in helpers.mfcc_cases():
+        full = dict(helpers.MFCC_REF_DEFAULTS, **kw)
+        got = frontend.mfcc([wave], **{helpers.FBANK_KW.get(k, k): v for k, v in full.items()})[0].cpu().numpy()
+        assert got.shape == ref.shape, name
+        assert np.abs(got - ref).max() < LOG_TOL and np.abs(got - ref).mean() < 5e-5, (name, np.abs(got - ref).max())
+    # the reference's class interface with its default feature type
+    import torch
+    from libs.egs.kaldi_features import KaldiFeature
+    name, wave, kw, ref = helpers.mfcc_cases()[0]
+    feats = KaldiFeature("mfcc", {"use_energy": True, "energy_floor": 0.0, "dither": 0.0})(torch.from_numpy(wave)[None, :])
+    assert np.abs(feats[0].cpu().numpy() - ref).max() < LOG_TOL
+
+
 def test_ragged_batch_equals_per_utterance_and_the_oracle():
     from libs.amd import frontend, synth
     lens = [16000, 400, 399, 48000, 1234, 31999, 0, 560]
