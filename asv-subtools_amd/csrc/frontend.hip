@@ -25,7 +25,7 @@ namespace {
 constexpr int kMaxFft = 2048;
 
 struct FbankKernelParams {
-  const float *wave;            // all utterances, packed
+  const void *wave;             // all utterances, packed: float or int16 samples (the kernels' SAMPLE type)
   const long long *sample_off;  // [n_utts + 1]
   const long long *frame_off;   // [n_utts + 1]
   int n_utts;
@@ -78,6 +78,7 @@ __device__ __forceinline__ void write_cepstra(const FbankKernelParams &p, const 
   }
 }
 
+template <typename SAMPLE>
 __global__ __launch_bounds__(256) void fbank_kernel(const FbankKernelParams p) {
   extern __shared__ float lds[];                       // per wave: re[padded] | im[padded]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256) void fbank_kernel(const FbankKernelParams p) {
     long long k = first + i;
     if (k < 0) k = -k - 1;
     if (k >= ns) k = 2 * ns - 1 - k;
-    const float v = p.wave[s0 + k];
+    const float v = (float)static_cast<const SAMPLE *>(p.wave)[s0 + k];
     re[i] = v;
     sum += v;
   }
@@ -212,7 +213,7 @@ __device__ __forceinline__ cplx tw512(const float2 *t, int idx) {          // W5
 
 constexpr int kFastMaxSeg = 256;     // mel filter segments (<= 8 FFT bins each) the kernel has room for: 4 lanes-passes
 
-template <bool MFCC>
+template <bool MFCC, typename SAMPLE>
 __global__ __launch_bounds__(256) void fbank512_kernel(const FbankKernelParams p) {
   __shared__ float2 xch[4][320];          // 256 points (padded to 316 slots); later |X|^2 [256] + 8 zeros + segment sums [256]
   __shared__ float4 segw[2][kFastMaxSeg];
@@ -265,14 +266,14 @@ __global__ __launch_bounds__(256) void fbank512_kernel(const FbankKernelParams p
       f_begin = f_end; f_end = p.frame_off[u + 1]; s0 = p.sample_off[u]; ns = p.sample_off[u + 1] - s0;
     }
     const long long first = (frame - f_begin) * p.shift - left;
-    const float *src = p.wave + s0;
+    const SAMPLE *src = static_cast<const SAMPLE *>(p.wave) + s0;
     // loads are unconditional (indices clamped into the window), the values past the window are masked afterwards
     if (first >= 0 && first + p.length <= ns) {
-      const float *q = src + first;
+      const SAMPLE *q = src + first;
       for (int r = 0; r < 4; ++r) {
         const int i = 2 * (lane + 64 * r);
-        e[r] = q[min(i, p.length - 1)];
-        o[r] = q[min(i + 1, p.length - 1)];
+        e[r] = (float)q[min(i, p.length - 1)];
+        o[r] = (float)q[min(i + 1, p.length - 1)];
       }
     } else {                                                                // mirrored edges (snip_edges off)
       for (int r = 0; r < 4; ++r) {
@@ -282,8 +283,8 @@ __global__ __launch_bounds__(256) void fbank512_kernel(const FbankKernelParams p
         k0 = k0 >= ns ? 2 * ns - 1 - k0 : k0;
         k1 = k1 < 0 ? -k1 - 1 : k1;
         k1 = k1 >= ns ? 2 * ns - 1 - k1 : k1;
-        e[r] = src[k0];
-        o[r] = src[k1];
+        e[r] = (float)src[k0];
+        o[r] = (float)src[k1];
       }
     }
   };
@@ -427,6 +428,122 @@ __global__ __launch_bounds__(256) void cmvn_kernel(float *feats, const long long
   }
 }
 
+
+// Kaldi's sliding-window mean (/ variance) normalisation: the `apply-cmvn-sliding --cmn-window=300 --center=true` stage of
+// the reference's offline pipeline (pytorch/pipeline/extract_xvectors_for_pytorch.sh:105-118).  Window rule of Kaldi's
+// SlidingWindowCmnInternal (feat/feature-functions.cc; Kaldi itself is not vendored in the reference): centred windows
+// [t - W/2, t - W/2 + W), causal ones [t - W, t + 1) grown to min_window, shifted to stay inside the utterance; f64 sums.
+// One thread per (segment of 32 frames, column): the first window is summed directly, the following ones slide.
+__device__ __forceinline__ void cmn_window_of(int t, int n, int window, int min_window, int center, int *ws, int *we) {
+  int a, b;
+  if (center) { a = t - window / 2; b = a + window; } else { a = t - window; b = t + 1; }
+  if (a < 0) { b -= a; a = 0; }
+  if (!center && b > t) b = max(t + 1, min_window);
+  if (b > n) { a -= b - n; b = n; if (a < 0) a = 0; }
+  *ws = a; *we = b;
+}
+
+constexpr int kSlideSeg = 32;
+__global__ __launch_bounds__(256) void cmvn_sliding_kernel(const float *in, float *out, const long long *frame_off, int dim, int window,
+                                                           int min_window, int center, int norm_vars) {
+  const int u = blockIdx.x, c = blockIdx.z * 64 + (threadIdx.x & 63);
+  const long long f0 = frame_off[u];
+  const int n = (int)(frame_off[u + 1] - f0);
+  const int seg = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int t0 = seg * kSlideSeg;
+  if (t0 >= n || c >= dim) return;
+  const float *x = in + (size_t)f0 * dim + c;
+  float *y = out + (size_t)f0 * dim + c;
+  int ws, we;
+  cmn_window_of(t0, n, window, min_window, center, &ws, &we);
+  double sum = 0.0, sumsq = 0.0;
+  for (int k = ws; k < we; ++k) { const double v = x[(size_t)k * dim]; sum += v; sumsq += v * v; }
+  const int t1 = min(n, t0 + kSlideSeg);
+  for (int t = t0; t < t1; ++t) {
+    int a, b;
+    cmn_window_of(t, n, window, min_window, center, &a, &b);
+    while (ws < a) { const double v = x[(size_t)ws * dim]; sum -= v; sumsq -= v * v; ++ws; }
+    while (we < b) { const double v = x[(size_t)we * dim]; sum += v; sumsq += v * v; ++we; }
+    const double frames = (double)(we - ws);
+    double v = (double)x[(size_t)t * dim] - sum / frames;
+    if (norm_vars) {
+      if (we - ws == 1) v = 0.0;
+      else {
+        double var = sumsq / frames - (sum / frames) * (sum / frames);
+        var = fmax(var, 1.0e-10);
+        v *= 1.0 / sqrt(var);
+      }
+    }
+    y[(size_t)t * dim] = (float)v;
+  }
+}
+
+// Energy-based voice activity decision, reference runtime/extractor/torch_asv_extractor.cc:14-62 (= Kaldi
+// compute-vad-decision): column 0 is the log energy; threshold = vad_energy_threshold + mean_scale * mean(log energy);
+// a frame is voiced when at least proportion_threshold of the frames within +-context of it are above the threshold.
+// One workgroup per utterance; the per-utterance voiced count goes to counts[u].
+__global__ __launch_bounds__(256) void vad_energy_kernel(const float *feats, const long long *frame_off, int dim, float threshold, float mean_scale,
+                                                         int context, float proportion, unsigned char *voiced, long long *counts) {
+  __shared__ double red[256];
+  __shared__ int cnt[256];
+  const int u = blockIdx.x;
+  const long long f0 = frame_off[u];
+  const int n = (int)(frame_off[u + 1] - f0);
+  const float *e = feats + (size_t)f0 * dim;
+  double s = 0.0;
+  for (int t = threadIdx.x; t < n; t += 256) s += (double)e[(size_t)t * dim];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  float thr = threshold;
+  if (mean_scale != 0.0f && n > 0) thr += mean_scale * (float)red[0] / (float)n;
+  int mine = 0;
+  for (int t = threadIdx.x; t < n; t += 256) {
+    int num = 0, den = 0;
+    for (int t2 = t - context; t2 <= t + context; ++t2)
+      if (t2 >= 0 && t2 < n) { ++den; num += e[(size_t)t2 * dim] > thr ? 1 : 0; }
+    const unsigned char v = (float)num >= (float)den * proportion ? 1 : 0;
+    voiced[f0 + t] = v;
+    mine += v;
+  }
+  cnt[threadIdx.x] = mine;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) cnt[threadIdx.x] += cnt[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) counts[u] = cnt[0];
+}
+
+// Source row of every kept row (select-voiced-frames / index_select(nonzero(vad)), torch_asv_extractor.cc:104-108): one
+// workgroup per utterance walks its flags 256 at a time, ranks by ballot + popcount, in frame order.
+__global__ __launch_bounds__(256) void voiced_rows_kernel(const unsigned char *voiced, const long long *frame_off, const long long *out_off, long long *src_row) {
+  __shared__ int wave_cnt[4];
+  __shared__ int base_sh;
+  const int u = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long f0 = frame_off[u];
+  const int n = (int)(frame_off[u + 1] - f0);
+  long long base = out_off[u];
+  for (int t0 = 0; t0 < n; t0 += 256) {
+    const int t = t0 + threadIdx.x;
+    const bool v = t < n && voiced[f0 + t] != 0;
+    const unsigned long long m = __ballot(v);
+    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < wave; ++w) before += wave_cnt[w];
+    if (v) src_row[base + before + __popcll(m & ((1ull << lane) - 1))] = f0 + t;
+    if (threadIdx.x == 0) base_sh = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+    base += base_sh;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float *in, const long long *src_row, long long rows, int dim, float *out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * dim) return;
+  const long long r = i / dim;
+  out[i] = in[src_row[r] * dim + (i - r * dim)];
+}
+
 float mel_scale(float f) { return 1127.0f * logf(1.0f + f / 700.0f); }
 
 thread_local std::vector<void *> g_front_dev;            // device tables of the last option set (tiny; rebuilt on change)
@@ -452,7 +569,7 @@ long long asv_fbank_num_frames(const asv_fbank_opts_t *o, long long num_samples)
   return (num_samples + shift / 2) / shift;
 }
 
-int asv_fbank(const asv_fbank_opts_t *o, const float *wave, const long long *sample_offsets, int n_utts, float *feats, void *stream) {
+static int fbank_entry(const asv_fbank_opts_t *o, const void *wave, bool pcm16, const long long *sample_offsets, int n_utts, float *feats, void *stream) {
   ASV_REQUIRE(o && o->struct_size == sizeof(asv_fbank_opts_t), "asv_fbank: struct_size mismatch");
   ASV_REQUIRE(wave && sample_offsets && feats && n_utts >= 1, "asv_fbank: bad argument");
   ASV_REQUIRE(o->num_bins >= 3 && o->num_bins <= 512, "asv_fbank: num_bins %d", o->num_bins);
@@ -608,14 +725,98 @@ int asv_fbank(const asv_fbank_opts_t *o, const float *wave, const long long *sam
     const long long waves = (long long)cus * 4 * 4;
     p.fpw = (int)std::max<long long>(4, (total + waves - 1) / waves);
     const long long per_wg = 4LL * p.fpw;
-    if (o->num_ceps > 0) hipLaunchKernelGGL(fbank512_kernel<true>, dim3((unsigned)((total + per_wg - 1) / per_wg)), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(fbank512_kernel<false>, dim3((unsigned)((total + per_wg - 1) / per_wg)), dim3(256), 0, s, p);
+    const dim3 grid((unsigned)((total + per_wg - 1) / per_wg));
+    if (o->num_ceps > 0 && pcm16) hipLaunchKernelGGL((fbank512_kernel<true, short>), grid, dim3(256), 0, s, p);
+    else if (o->num_ceps > 0) hipLaunchKernelGGL((fbank512_kernel<true, float>), grid, dim3(256), 0, s, p);
+    else if (pcm16) hipLaunchKernelGGL((fbank512_kernel<false, short>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((fbank512_kernel<false, float>), grid, dim3(256), 0, s, p);
     ASV_HIP_CHECK(hipGetLastError());
     return ASV_OK;
   }
   const size_t lds_bytes = (size_t)4 * 2 * padded * 4;
-  hipLaunchKernelGGL(fbank_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), lds_bytes, s, p);
+  if (pcm16) hipLaunchKernelGGL(fbank_kernel<short>, dim3((unsigned)((total + 3) / 4)), dim3(256), lds_bytes, s, p);
+  else hipLaunchKernelGGL(fbank_kernel<float>, dim3((unsigned)((total + 3) / 4)), dim3(256), lds_bytes, s, p);
   ASV_HIP_CHECK(hipGetLastError());
+  return ASV_OK;
+}
+
+
+int asv_fbank(const asv_fbank_opts_t *o, const float *wave, const long long *sample_offsets, int n_utts, float *feats, void *stream) {
+  return fbank_entry(o, wave, false, sample_offsets, n_utts, feats, stream);
+}
+
+int asv_fbank_pcm16(const asv_fbank_opts_t *o, const short *wave, const long long *sample_offsets, int n_utts, float *feats, void *stream) {
+  return fbank_entry(o, wave, true, sample_offsets, n_utts, feats, stream);
+}
+
+// uploads a host int64 array for the duration of one call
+static int upload_offsets(const long long *host, size_t count, hipStream_t s, long long **dev) {
+  ASV_HIP_CHECK(hipMallocAsync(reinterpret_cast<void **>(dev), count * 8, s));
+  ASV_HIP_CHECK(hipMemcpyAsync(*dev, host, count * 8, hipMemcpyHostToDevice, s));
+  ASV_HIP_CHECK(hipStreamSynchronize(s));                  // the caller's array may be a temporary
+  return ASV_OK;
+}
+
+int asv_cmvn_sliding(const float *feats, float *out, const long long *frame_offsets, int n_utts, int dim, int cmn_window, int min_window,
+                     int center, int norm_vars, void *stream) {
+  ASV_REQUIRE(feats && out && feats != out && frame_offsets && n_utts >= 1 && dim >= 1, "asv_cmvn_sliding: bad argument (in-place is not supported)");
+  ASV_REQUIRE(cmn_window > 0 && (center || (min_window > 0 && min_window <= cmn_window)), "asv_cmvn_sliding: cmn_window %d / min_window %d", cmn_window, min_window);
+  ASV_REQUIRE(frame_offsets[0] == 0, "asv_cmvn_sliding: frame_offsets[0] must be 0");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  long long longest = 0;
+  for (int u = 0; u < n_utts; ++u) longest = std::max(longest, frame_offsets[u + 1] - frame_offsets[u]);
+  if (longest == 0) return ASV_OK;
+  ASV_REQUIRE(longest < (1LL << 31), "asv_cmvn_sliding: utterance too long");
+  long long *d = nullptr;
+  int rc = upload_offsets(frame_offsets, (size_t)n_utts + 1, s, &d);
+  if (rc) return rc;
+  const unsigned segs = (unsigned)((longest + 4 * kSlideSeg - 1) / (4 * kSlideSeg));
+  hipLaunchKernelGGL(cmvn_sliding_kernel, dim3((unsigned)n_utts, segs, (unsigned)((dim + 63) / 64)), dim3(256), 0, s, feats, out, d, dim, cmn_window,
+                     min_window, center, norm_vars);
+  ASV_HIP_CHECK(hipGetLastError());
+  ASV_HIP_CHECK(hipFreeAsync(d, s));
+  return ASV_OK;
+}
+
+int asv_vad_energy(const float *feats, const long long *frame_offsets, int n_utts, int dim, float energy_threshold, float energy_mean_scale,
+                   int frames_context, float proportion_threshold, unsigned char *voiced, long long *voiced_counts, void *stream) {
+  ASV_REQUIRE(feats && frame_offsets && voiced && voiced_counts && n_utts >= 1 && dim >= 1, "asv_vad_energy: bad argument");
+  ASV_REQUIRE(energy_mean_scale >= 0.0f && frames_context >= 0 && proportion_threshold > 0.0f && proportion_threshold < 1.0f,
+              "asv_vad_energy: mean scale %g / context %d / proportion %g", energy_mean_scale, frames_context, proportion_threshold);
+  ASV_REQUIRE(frame_offsets[0] == 0, "asv_vad_energy: frame_offsets[0] must be 0");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  long long *d = nullptr;
+  ASV_HIP_CHECK(hipMallocAsync(reinterpret_cast<void **>(&d), ((size_t)2 * n_utts + 1) * 8, s));
+  ASV_HIP_CHECK(hipMemcpyAsync(d, frame_offsets, ((size_t)n_utts + 1) * 8, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(vad_energy_kernel, dim3((unsigned)n_utts), dim3(256), 0, s, feats, d, dim, energy_threshold, energy_mean_scale, frames_context,
+                     proportion_threshold, voiced, d + n_utts + 1);
+  ASV_HIP_CHECK(hipGetLastError());
+  ASV_HIP_CHECK(hipMemcpyAsync(voiced_counts, d + n_utts + 1, (size_t)n_utts * 8, hipMemcpyDeviceToHost, s));
+  ASV_HIP_CHECK(hipStreamSynchronize(s));
+  ASV_HIP_CHECK(hipFreeAsync(d, s));
+  return ASV_OK;
+}
+
+int asv_select_frames(const float *feats, const unsigned char *voiced, const long long *frame_offsets, const long long *out_offsets, int n_utts,
+                      int dim, float *out, void *stream) {
+  ASV_REQUIRE(feats && voiced && frame_offsets && out_offsets && out && n_utts >= 1 && dim >= 1, "asv_select_frames: bad argument");
+  ASV_REQUIRE(frame_offsets[0] == 0 && out_offsets[0] == 0, "asv_select_frames: offsets must start at 0");
+  const long long rows = out_offsets[n_utts];
+  if (rows == 0) return ASV_OK;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  std::vector<long long> both(2 * ((size_t)n_utts + 1));
+  memcpy(both.data(), frame_offsets, ((size_t)n_utts + 1) * 8);
+  memcpy(both.data() + n_utts + 1, out_offsets, ((size_t)n_utts + 1) * 8);
+  long long *d = nullptr;
+  ASV_HIP_CHECK(hipMallocAsync(reinterpret_cast<void **>(&d), (both.size() + (size_t)rows) * 8, s));
+  ASV_HIP_CHECK(hipMemcpyAsync(d, both.data(), both.size() * 8, hipMemcpyHostToDevice, s));
+  ASV_HIP_CHECK(hipStreamSynchronize(s));
+  long long *src_row = d + both.size();
+  hipLaunchKernelGGL(voiced_rows_kernel, dim3((unsigned)n_utts), dim3(256), 0, s, voiced, d, d + n_utts + 1, src_row);
+  const long long elems = rows * dim;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, feats, src_row, rows, dim, out);
+  ASV_HIP_CHECK(hipGetLastError());
+  ASV_HIP_CHECK(hipFreeAsync(d, s));
   return ASV_OK;
 }
 

@@ -130,7 +130,7 @@ SYMBOLS = [
     "asv_tdnn_forward", "asv_stats_pool_forward",
     "asv_length_norm", "asv_mean_vec", "asv_dot_score_matrix", "asv_dot_score_trials",
     "asv_plda_transform", "asv_plda_llr_trials", "asv_eer", "asv_score_norm",
-    "asv_fbank_num_frames", "asv_fbank", "asv_cmvn",
+    "asv_fbank_num_frames", "asv_fbank", "asv_fbank_pcm16", "asv_cmvn", "asv_cmvn_sliding", "asv_vad_energy", "asv_select_frames",
 ]
 
 
@@ -189,6 +189,10 @@ def lib():
     L.asv_score_norm.argtypes = [vp, ci, vp, ci, ci, vp, vp, vp, ci, ci, ci, vp, vp]
     L.asv_fbank_num_frames.argtypes = [C.POINTER(FbankOpts), C.c_longlong]; L.asv_fbank_num_frames.restype = C.c_longlong
     L.asv_fbank.argtypes = [C.POINTER(FbankOpts), vp, C.POINTER(C.c_longlong), ci, vp, vp]
+    L.asv_fbank_pcm16.argtypes = [C.POINTER(FbankOpts), vp, C.POINTER(C.c_longlong), ci, vp, vp]
+    L.asv_cmvn_sliding.argtypes = [vp, vp, C.POINTER(C.c_longlong), ci, ci, ci, ci, ci, ci, vp]
+    L.asv_vad_energy.argtypes = [vp, C.POINTER(C.c_longlong), ci, ci, C.c_float, C.c_float, ci, C.c_float, vp, C.POINTER(C.c_longlong), vp]
+    L.asv_select_frames.argtypes = [vp, vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), ci, ci, vp, vp]
     L.asv_cmvn.argtypes = [vp, C.POINTER(C.c_longlong), ci, ci, ci, ci, C.c_float, vp]
     for name in SYMBOLS:
         fn = getattr(L, name)          # AttributeError here = header/.so mismatch

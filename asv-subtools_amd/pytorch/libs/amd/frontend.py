@@ -92,23 +92,24 @@ def _frame_counts(lens, o):
 
 
 def fbank_device(wave, sample_off, mean_norm=False, std_norm=False, eps=1e-10, kind="fbank", **kw):
-    """wave: 1-D f32 CUDA tensor holding all utterances back to back, sample_off: int64 numpy [n+1].
+    """wave: 1-D f32 or int16 (16-bit PCM) CUDA tensor holding all utterances back to back, sample_off: int64 numpy [n+1].
     Returns (feats [sum frames, dim] f32 CUDA tensor, frame_offsets int64 numpy [n+1]).  kind="mfcc": cepstra."""
     import torch
     opts, o = fbank_options(kind, **kw)
     lib = capi.lib()
     sample_off = np.ascontiguousarray(sample_off, dtype=np.int64)
     n = len(sample_off) - 1
-    if n < 1 or wave.dim() != 1 or wave.dtype != torch.float32 or not wave.is_cuda or not wave.is_contiguous() or int(sample_off[-1]) != wave.shape[0]:
-        raise ValueError("fbank_device: wave must be a contiguous 1-D f32 CUDA tensor of sample_off[-1] samples")
+    if n < 1 or wave.dim() != 1 or wave.dtype not in (torch.float32, torch.int16) or not wave.is_cuda or not wave.is_contiguous() or int(sample_off[-1]) != wave.shape[0]:
+        raise ValueError("fbank_device: wave must be a contiguous 1-D f32 / int16 CUDA tensor of sample_off[-1] samples")
+    entry = lib.asv_fbank if wave.dtype == torch.float32 else lib.asv_fbank_pcm16
     frame_off = np.zeros(n + 1, dtype=np.int64)
     np.cumsum(_frame_counts(np.diff(sample_off), o), out=frame_off[1:])
     dim = o["dim"]
     feats = torch.empty((int(frame_off[-1]), dim), dtype=torch.float32, device=wave.device)
     stream = C.c_void_p(torch.cuda.current_stream(wave.device).cuda_stream)
     with torch.cuda.device(wave.device):
-        capi.check(lib.asv_fbank(C.byref(opts), C.c_void_p(wave.data_ptr()), sample_off.ctypes.data_as(C.POINTER(C.c_longlong)),
-                                 n, C.c_void_p(feats.data_ptr()), stream), "asv_fbank")
+        capi.check(entry(C.byref(opts), C.c_void_p(wave.data_ptr()), sample_off.ctypes.data_as(C.POINTER(C.c_longlong)),
+                         n, C.c_void_p(feats.data_ptr()), stream), "asv_fbank")
         if (o["subtract_mean"] or mean_norm or std_norm) and feats.shape[0] > 0:
             capi.check(lib.asv_cmvn(C.c_void_p(feats.data_ptr()), frame_off.ctypes.data_as(C.POINTER(C.c_longlong)), n, dim,
                                     int(bool(o["subtract_mean"] or mean_norm)), int(bool(std_norm)), float(eps), stream), "asv_cmvn")
@@ -128,13 +129,15 @@ def fbank_packed(waveforms, device=None, **kw):
             raise ValueError("fbank: every waveform must be 1-D (one channel), got shape %s" % (tuple(w.shape),))
     sample_off = np.zeros(len(waveforms) + 1, dtype=np.int64)
     np.cumsum([int(w.shape[0]) for w in waveforms], out=sample_off[1:])
+    pcm16 = all((w.dtype == torch.int16) if isinstance(w, torch.Tensor) else (np.asarray(w).dtype == np.int16) for w in waveforms)
+    dt = torch.int16 if pcm16 else torch.float32                      # 16-bit PCM is shipped and read as it is (half the ingest)
     if all(isinstance(w, torch.Tensor) and w.is_cuda for w in waveforms):
-        wave = torch.cat([w.to(torch.float32) for w in waveforms]) if len(waveforms) > 1 else waveforms[0].to(torch.float32).contiguous()
+        wave = torch.cat([w.to(dt) for w in waveforms]) if len(waveforms) > 1 else waveforms[0].to(dt).contiguous()
     else:
-        host = torch.empty(int(sample_off[-1]), dtype=torch.float32).pin_memory()
+        host = torch.empty(int(sample_off[-1]), dtype=dt).pin_memory()
         hv = host.numpy()
         for w, a, b in zip(waveforms, sample_off[:-1], sample_off[1:]):
-            hv[a:b] = w.detach().cpu().numpy() if isinstance(w, torch.Tensor) else np.asarray(w, dtype=np.float32)
+            hv[a:b] = w.detach().cpu().numpy() if isinstance(w, torch.Tensor) else np.asarray(w)
         wave = host.to(dev, non_blocking=True)
     return fbank_device(wave, sample_off, **kw)
 
@@ -148,3 +151,54 @@ def fbank(waveforms, **kw):
 def mfcc(waveforms, **kw):
     """torchaudio.compliance.kaldi.mfcc for a batch: list of [frames, num_ceps] CUDA tensors."""
     return fbank(waveforms, kind="mfcc", **kw)
+
+
+def _off(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _i64p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_longlong))
+
+
+def cmvn_sliding(feats, frame_off, cmn_window=600, min_window=100, center=False, norm_vars=False):
+    """Kaldi apply-cmvn-sliding on packed device features (defaults are Kaldi's; the reference's extraction pipeline uses
+    cmn_window=300, center=True: extract_xvectors_for_pytorch.sh:105-118).  Returns a new tensor."""
+    import torch
+    frame_off = _off(frame_off)
+    out = torch.empty_like(feats)
+    with torch.cuda.device(feats.device):
+        capi.check(capi.lib().asv_cmvn_sliding(C.c_void_p(feats.data_ptr()), C.c_void_p(out.data_ptr()), _i64p(frame_off), len(frame_off) - 1,
+                                               feats.shape[1], int(cmn_window), int(min_window), int(center), int(norm_vars),
+                                               C.c_void_p(torch.cuda.current_stream(feats.device).cuda_stream)), "asv_cmvn_sliding")
+    return out
+
+
+def vad_energy(feats, frame_off, vad_energy_threshold=5.0, vad_energy_mean_scale=0.5, vad_frames_context=2, vad_proportion_threshold=0.12):
+    """Energy VAD on column 0 (defaults: VadEnergyOptions of runtime/extractor/torch_asv_extractor.h:24-27).
+    Returns (voiced uint8 CUDA tensor [frames], voiced_counts int64 numpy [n])."""
+    import torch
+    frame_off = _off(frame_off)
+    n = len(frame_off) - 1
+    voiced = torch.empty(feats.shape[0], dtype=torch.uint8, device=feats.device)
+    counts = np.zeros(n, dtype=np.int64)
+    with torch.cuda.device(feats.device):
+        capi.check(capi.lib().asv_vad_energy(C.c_void_p(feats.data_ptr()), _i64p(frame_off), n, feats.shape[1], float(vad_energy_threshold),
+                                             float(vad_energy_mean_scale), int(vad_frames_context), float(vad_proportion_threshold),
+                                             C.c_void_p(voiced.data_ptr()), _i64p(counts),
+                                             C.c_void_p(torch.cuda.current_stream(feats.device).cuda_stream)), "asv_vad_energy")
+    return voiced, counts
+
+
+def select_voiced(feats, voiced, frame_off, counts):
+    """select-voiced-frames: (kept rows packed [sum counts, dim], new offsets int64 [n+1])."""
+    import torch
+    frame_off = _off(frame_off)
+    out_off = np.zeros(len(frame_off), dtype=np.int64)
+    np.cumsum(counts, out=out_off[1:])
+    out = torch.empty((int(out_off[-1]), feats.shape[1]), dtype=torch.float32, device=feats.device)
+    with torch.cuda.device(feats.device):
+        capi.check(capi.lib().asv_select_frames(C.c_void_p(feats.data_ptr()), C.c_void_p(voiced.data_ptr()), _i64p(frame_off), _i64p(out_off),
+                                                len(frame_off) - 1, feats.shape[1], C.c_void_p(out.data_ptr()),
+                                                C.c_void_p(torch.cuda.current_stream(feats.device).cuda_stream)), "asv_select_frames")
+    return out, out_off

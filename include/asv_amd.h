@@ -313,6 +313,23 @@ long long asv_fbank_num_frames(const asv_fbank_opts_t *opts, long long num_sampl
  * feats: device [sum of frames][dim] f32, utterances back to back in order; dim = num_bins + use_energy, or num_ceps. */
 int asv_fbank(const asv_fbank_opts_t *opts, const float *wave, const long long *sample_offsets, int n_utts,
               float *feats, void *stream);
+/* The same with 16-bit PCM samples in HBM (half the ingest; SURVEY.md 8(f) rank 2 "ship int16 PCM"). */
+int asv_fbank_pcm16(const asv_fbank_opts_t *opts, const short *wave, const long long *sample_offsets, int n_utts,
+                    float *feats, void *stream);
+/* Kaldi apply-cmvn-sliding (pipeline/extract_xvectors_for_pytorch.sh:105-118 runs it with --cmn-window=300 --center=true
+ * in front of the extractor): every frame minus the mean of its window, optionally divided by the window's standard
+ * deviation; out must not alias feats. */
+int asv_cmvn_sliding(const float *feats, float *out, const long long *frame_offsets, int n_utts, int dim, int cmn_window,
+                     int min_window, int center, int norm_vars, void *stream);
+/* Energy VAD of runtime/extractor/torch_asv_extractor.cc:14-62 (Kaldi compute-vad-decision) on column 0 of the
+ * features: voiced[frame] = 0/1 (device bytes), voiced_counts[u] (HOST int64 [n_utts], filled before returning). */
+int asv_vad_energy(const float *feats, const long long *frame_offsets, int n_utts, int dim, float energy_threshold,
+                   float energy_mean_scale, int frames_context, float proportion_threshold, unsigned char *voiced,
+                   long long *voiced_counts, void *stream);
+/* Keeps the voiced rows, in order (select-voiced-frames; torch_asv_extractor.cc:104-108): out_offsets = host int64
+ * [n_utts+1] running sum of voiced_counts; out: device [out_offsets[n_utts]][dim]. */
+int asv_select_frames(const float *feats, const unsigned char *voiced, const long long *frame_offsets,
+                      const long long *out_offsets, int n_utts, int dim, float *out, void *stream);
 /* Per-utterance mean / variance normalisation of every column, in place (kaldi_features.py:11-66
  * InputSequenceNormalization: mean over the frames, unbiased std floored at eps).  frame_offsets: host int64 [n_utts+1]. */
 int asv_cmvn(float *feats, const long long *frame_offsets, int n_utts, int dim, int mean_norm, int std_norm, float eps,

@@ -165,3 +165,53 @@ def mfcc(wave, num_ceps=13, cepstral_lifter=22.0, use_energy=True, energy_floor=
         if not use_energy:
             feats[:, -1] *= np.float32(np.sqrt(2.0))
     return feats.astype(np.float32)
+
+
+def sliding_cmn(x, cmn_window=600, min_window=100, center=False, norm_vars=False):
+    """Kaldi SlidingWindowCmnInternal (feat/feature-functions.cc of Kaldi 5.5; Kaldi is NOT vendored in /root/reference, whose
+    pipeline only calls the binary: extract_xvectors_for_pytorch.sh:105-118) - PARITY UNPINNED: restated from the published
+    algorithm, no reference-side fixture exists.  Double precision like Kaldi."""
+    x = np.asarray(x, dtype=np.float64)
+    n = x.shape[0]
+    out = np.empty_like(x)
+    for t in range(n):
+        if center:
+            ws = t - cmn_window // 2
+            we = ws + cmn_window
+        else:
+            ws, we = t - cmn_window, t + 1
+        if ws < 0:
+            we -= ws
+            ws = 0
+        if not center and we > t:
+            we = max(t + 1, min_window)
+        if we > n:
+            ws -= we - n
+            we = n
+            ws = max(ws, 0)
+        w = x[ws:we]
+        v = x[t] - w.mean(axis=0)
+        if norm_vars:
+            if we - ws == 1:
+                v = np.zeros_like(v)
+            else:
+                var = np.maximum((w * w).mean(axis=0) - w.mean(axis=0) ** 2, 1.0e-10)
+                v = v / np.sqrt(var)
+        out[t] = v
+    return out.astype(np.float32)
+
+
+def vad_energy(feats, vad_energy_threshold=5.0, vad_energy_mean_scale=0.5, vad_frames_context=2, vad_proportion_threshold=0.12):
+    """Reference runtime/extractor/torch_asv_extractor.cc:14-62 (the C++ needs glog/gflags/yaml-cpp fetched from the network,
+    so it cannot be compiled here: restated line by line).  Returns a 0/1 vector."""
+    e = np.asarray(feats, dtype=np.float32)[:, 0]
+    n = len(e)
+    thr = np.float32(vad_energy_threshold)
+    if vad_energy_mean_scale != 0.0:
+        thr = np.float32(thr + np.float32(vad_energy_mean_scale) * np.float32(e.sum(dtype=np.float64)) / np.float32(n))
+    out = np.zeros(n, dtype=np.uint8)
+    above = e > thr
+    for t in range(n):
+        lo, hi = max(0, t - vad_frames_context), min(n, t + vad_frames_context + 1)
+        out[t] = 1 if above[lo:hi].sum() >= np.float32(hi - lo) * np.float32(vad_proportion_threshold) else 0
+    return out

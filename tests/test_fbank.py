@@ -52,3 +52,28 @@ def test_unsupported_options_are_refused_up_front():
         KaldiFeature("mfcc", {"use_power": False})               # torchaudio's mfcc has no such option
     with pytest.raises(ValueError):
         KaldiFeature("fbank", {"dither": 0.5})
+
+
+def test_sliding_cmn_and_vad_restatements_known_answers():
+    """Kaldi / runtime algorithms with no reference-side fixture (parity unpinned): hand-checkable cases."""
+    rng = np.random.RandomState(3)
+    x = rng.randn(50, 4).astype(np.float32) + 2.0
+    # a window covering the whole utterance is plain mean subtraction, centred or not
+    for center in (True, False):
+        got = fbank_oracle.sliding_cmn(x, cmn_window=600, min_window=100, center=center)
+        assert np.abs(got - (x - x.mean(0))).max() < 1e-5
+    # centred window of 4 on a ramp: interior frames see [t-2, t+2) -> mean t-0.5; the edges see the shifted window
+    ramp = np.arange(10, dtype=np.float32)[:, None]
+    got = fbank_oracle.sliding_cmn(ramp, cmn_window=4, center=True)[:, 0]
+    assert np.allclose(got, [-1.5, -0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 1.5])
+    # causal window of 3 with min_window 2: frame 0 uses frames [0,2), then [0,2), [0,3), [1,4) ...
+    got = fbank_oracle.sliding_cmn(ramp, cmn_window=3, min_window=2, center=False)[:, 0]
+    assert np.allclose(got[:5], [-0.5, 0.5, 1.0, 1.5, 1.5])
+    # single-frame windows give zeros under variance normalisation
+    assert np.all(fbank_oracle.sliding_cmn(ramp[:1], cmn_window=4, center=True, norm_vars=True) == 0)
+    # VAD: threshold 5 + 0.5 * mean; context 1, proportion 0.6 -> a frame needs 2 of its 3 neighbours (edges: 2 of 2)
+    e = np.array([10, 10, 0, 10, 0, 0, 0, 10, 10, 10], dtype=np.float32)[:, None]
+    v = fbank_oracle.vad_energy(e, vad_energy_threshold=5.0, vad_energy_mean_scale=0.0, vad_frames_context=1, vad_proportion_threshold=0.6)
+    assert list(v) == [1, 1, 1, 0, 0, 0, 0, 1, 1, 1]
+    v = fbank_oracle.vad_energy(e, vad_energy_threshold=1.0, vad_energy_mean_scale=0.5, vad_frames_context=0, vad_proportion_threshold=0.5)
+    assert list(v) == [1, 1, 0, 1, 0, 0, 0, 1, 1, 1]                        # threshold 1 + 0.5 * 6 = 4

@@ -105,3 +105,54 @@ def test_waveforms_to_embeddings_stay_on_the_device():
     emb = model.extract_embedding_batch(feats).numpy()
     host = model.extract_embedding_batch([f.cpu().numpy() for f in feats]).numpy()
     assert np.isfinite(emb).all() and np.array_equal(emb, host)
+
+
+def test_pcm16_input_is_bit_identical_to_float_input():
+    import torch
+    from libs.amd import frontend, synth
+    waves = [synth.synth_wave(n, 600 + i) for i, n in enumerate([16000, 4001, 9999])]
+    as_f32 = frontend.fbank(waves, num_mel_bins=80, snip_edges=False)
+    as_i16 = frontend.fbank([w.astype(np.int16) for w in waves], num_mel_bins=80, snip_edges=False)
+    assert all(torch.equal(a, b) for a, b in zip(as_f32, as_i16))
+    m32 = frontend.mfcc(waves, sample_frequency=8000.0)
+    m16 = frontend.mfcc([torch.from_numpy(w.astype(np.int16)).cuda() for w in waves], sample_frequency=8000.0)
+    assert all(torch.equal(a, b) for a, b in zip(m32, m16))
+
+
+def test_sliding_cmn_matches_the_kaldi_restatement():
+    import torch
+    from libs.amd import synth
+    from libs.amd import frontend
+    lens = [650, 299, 300, 301, 1, 37, 0, 1200]
+    mats = [synth.synth_feats(T, 30, 40 + i) * 3.0 + 1.5 for i, T in enumerate(lens)]
+    off = np.concatenate([[0], np.cumsum(lens)])
+    packed = torch.from_numpy(np.concatenate(mats, axis=0)).cuda()
+    for kw in (dict(cmn_window=300, center=True), dict(), dict(cmn_window=100, min_window=20, norm_vars=True), dict(cmn_window=64, center=True, norm_vars=True)):
+        got = frontend.cmvn_sliding(packed, off, **kw).cpu().numpy()
+        for i, m in enumerate(mats):
+            if len(m):
+                want = fbank_oracle.sliding_cmn(m, **kw)
+                assert np.abs(got[off[i]:off[i + 1]] - want).max() < 2e-5, (kw, lens[i])
+
+
+def test_energy_vad_and_voiced_frame_selection():
+    import torch
+    from libs.amd import frontend, synth
+    lens = [32000, 8000, 16000, 400, 24000]
+    waves = []
+    for i, n in enumerate(lens):
+        w = synth.synth_wave(n, 700 + i)
+        gate = (np.sin(np.arange(n) / 16000.0 * 2 * np.pi * 1.3 + i) > -0.2).astype(np.float32)       # silences of a few hundred ms
+        waves.append(np.rint(w * gate + 3.0 * np.random.RandomState(i).standard_normal(n)).astype(np.float32))
+    feats, off = frontend.fbank_packed(waves, kind="mfcc", use_energy=True, energy_floor=0.0, num_ceps=20, num_mel_bins=30)
+    host = feats.cpu().numpy()
+    for kw in (dict(), dict(vad_energy_threshold=5.5, vad_frames_context=0, vad_proportion_threshold=0.6), dict(vad_energy_mean_scale=0.0, vad_energy_threshold=9.0)):
+        voiced, counts = frontend.vad_energy(feats, off, **kw)
+        v = voiced.cpu().numpy()
+        for i in range(len(lens)):
+            want = fbank_oracle.vad_energy(host[off[i]:off[i + 1]], **kw)
+            assert np.array_equal(v[off[i]:off[i + 1]], want), (kw, i)
+            assert counts[i] == want.sum()
+        assert 0 < counts.sum() < len(v)                                     # the gate really produced both classes
+        kept, koff = frontend.select_voiced(feats, voiced, off, counts)
+        assert np.array_equal(kept.cpu().numpy(), host[v.astype(bool)]) and list(np.diff(koff)) == list(counts)
