@@ -2,6 +2,9 @@
 of the reference's own kaldifeat code (tests/golden/fbank.npz, made by oracle/gen_fbank_golden.py from
 oracle/_ref/libkaldifeat_ref.so), and the host half of the C ABI (frame counts, option checking) agrees with it."""
 
+import glob
+import os
+
 import numpy as np
 import pytest
 
@@ -77,3 +80,30 @@ def test_sliding_cmn_and_vad_restatements_known_answers():
     assert list(v) == [1, 1, 1, 0, 0, 0, 0, 1, 1, 1]
     v = fbank_oracle.vad_energy(e, vad_energy_threshold=1.0, vad_energy_mean_scale=0.5, vad_frames_context=0, vad_proportion_threshold=0.5)
     assert list(v) == [1, 1, 0, 1, 0, 0, 0, 1, 1, 1]                        # threshold 1 + 0.5 * 6 = 4
+
+
+REF_WAVS = "/root/reference/runtime/test/wav"
+
+
+@pytest.mark.skipif(not (os.path.isdir(REF_WAVS) and os.path.exists(os.path.join(helpers.REPO, "oracle", "_ref", "libkaldifeat_ref.so"))),
+                    reason="build container only: needs the reference's test wavs and oracle/_ref (make -C oracle -f Makefile.ref)")
+def test_oracle_matches_the_compiled_reference_on_the_reference_test_wavs():
+    """The reference's own 16 kHz recordings (runtime/test/wav), fbank-80 as its runtime config computes it, straight through
+    the compiled kaldifeat code vs the numpy restatement - real speech instead of synthetic harmonics."""
+    import ctypes as C
+    import wave
+    from oracle import gen_fbank_golden as G
+    lib = C.CDLL(os.path.join(helpers.REPO, "oracle", "_ref", "libkaldifeat_ref.so"))
+    lib.kaldifeat_ref_fbank.restype = C.c_int
+    paths = sorted(glob.glob(os.path.join(REF_WAVS, "*.wav")))[:4]
+    assert paths
+    for path in paths:
+        with wave.open(path, "rb") as f:
+            assert f.getsampwidth() == 2
+            sr = f.getframerate()
+            x = np.frombuffer(f.readframes(min(f.getnframes(), 5 * sr)), dtype="<i2").reshape(-1, f.getnchannels())[:, 0].astype(np.float32)
+        kw = dict(num_bins=80, sample_rate=float(sr))
+        ref = G.reference_fbank(lib, x, **kw)
+        got = fbank_oracle.fbank(x, **kw)
+        assert got.shape == ref.shape and len(ref) > 100
+        assert np.abs(got - ref).max() < 2e-3 and np.abs(got - ref).mean() < 2e-5, (path, np.abs(got - ref).max())

@@ -52,3 +52,53 @@ def test_script_fails_loudly(tmp_path):
     res = subprocess.run([sys.executable, script, "--model-blueprint", "/nonexistent.py", "--model-creation", "X()", "nomodel", "ark:/dev/null", "ark:/dev/null"],
                          capture_output=True, text=True, timeout=300)
     assert res.returncode == 1 and "Error" in res.stderr
+
+
+def test_online_script_wav_scp_to_ark(tmp_path):
+    """wav.scp + feat yaml -> embeddings: the script output equals front-end + extractor called directly, and the oracle
+    (numpy fbank restatement -> CMN -> numpy x-vector) within the f32 bar."""
+    import wave
+    import torch
+    import yaml
+    from libs.amd import frontend, synth
+    from libs.support import kaldi_io
+    import libs.support.utils as utils
+    from oracle import fbank_oracle, np_oracle as O
+    g, sd = helpers.golden_state_dict("xvector_c1")                # Xvector(30, ...)
+    lens = [16000, 48000, 300, 24000, 20011]                       # the third is shorter than one 25 ms window: skipped with a warning
+    waves = [synth.synth_wave(n, 800 + i).astype(np.int16) for i, n in enumerate(lens)]
+    scp = tmp_path / "wav.scp"
+    with open(scp, "w") as f:
+        for i, wv in enumerate(waves):
+            path = tmp_path / ("u%d.wav" % i)
+            with wave.open(str(path), "wb") as wf:
+                wf.setnchannels(1); wf.setsampwidth(2); wf.setframerate(16000)
+                wf.writeframes(wv.tobytes())
+            f.write("utt%d %s\n" % (i, path))
+    featset = {"num_mel_bins": 30, "dither": 0.0, "energy_floor": 0.0}
+    conf = tmp_path / "feat.yaml"
+    conf.write_text(yaml.safe_dump({"feature_type": "fbank", "kaldi_featset": featset, "mean_var_conf": {"mean_norm": True, "std_norm": False}}))
+    params = tmp_path / "final.params"
+    torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, str(params))
+    cfg = tmp_path / "nnet.config"
+    utils.write_nnet_config(os.path.join(helpers.MODEL_DIR, "xvector.py"), str(g["creation"]), str(cfg))
+    out_ark = tmp_path / "xvector.ark"
+    script = os.path.join(helpers.REPO, "asv-subtools_amd", "pytorch", "pipeline", "onestep", "extract_embeddings_online.py")
+    env = dict(os.environ, ASV_AMD_PRECISION="f32")
+    res = subprocess.run([sys.executable, script, "--nnet-config", str(cfg), "--data-type", "raw", "--feat-config", str(conf), "--gpu-id", "0",
+                          "--batch-utts", "2", str(params), str(scp), str(out_ark)], capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "RTF:" in res.stdout and "utt2 is shorter than one frame" in res.stdout
+    got = list(kaldi_io.read_vec_flt_ark(str(out_ark)))
+    assert [k for k, _ in got] == ["utt0", "utt1", "utt3", "utt4"]
+    model = helpers.build_model("xvector.py", str(g["creation"]), sd)
+    model.cuda()
+    model.amd_precision = "f32"
+    kept = [waves[i] for i in (0, 1, 3, 4)]
+    direct = model.extract_embedding_batch(frontend.fbank(kept, mean_norm=True, **featset)).numpy()
+    for (k, v), d, wv in zip(got, direct, kept):
+        assert np.array_equal(v, d), k
+        feat = fbank_oracle.fbank(wv.astype(np.float32), num_bins=30)
+        feat = feat - feat.mean(0)
+        want = O.extract_embedding(lambda c: O.xvector_embed(c, sd, "far"), feat)
+        assert rel_err(v, want) < 1e-4, k
