@@ -549,7 +549,31 @@ float mel_scale(float f) { return 1127.0f * logf(1.0f + f / 700.0f); }
 thread_local std::vector<void *> g_front_dev;            // device tables of the last option set (tiny; rebuilt on change)
 thread_local asv_fbank_opts_t g_front_opts;
 thread_local bool g_front_valid = false;
-struct FrontTables { float *dct; float *window; float2 *twiddle; float *mel_w; int *mel_first, *mel_count; int mel_stride; float *seg_w; int *seg_first, *bin_seg; int n_seg; long long *offs; size_t offs_cap; };
+// Host offset arrays are small and usually the same from call to call (fixed batch shapes): the last upload is kept per
+// calling thread and reused when the contents are unchanged, which also removes the stream synchronisation a fresh upload
+// needs (the source is a caller-owned / local array).  Calls of one thread are expected on one stream.
+struct OffsetCache {
+  std::vector<long long> host;
+  long long *dev = nullptr;
+  size_t cap = 0;
+  int get(const long long *src, size_t count, hipStream_t s, const long long **out) {
+    if (dev && host.size() == count && memcmp(host.data(), src, count * 8) == 0) { *out = dev; return ASV_OK; }
+    if (count > cap) {
+      if (dev) ASV_HIP_CHECK(hipFree(dev));
+      dev = nullptr; cap = 0; host.clear();
+      ASV_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&dev), count * 16));
+      cap = count * 2;
+    }
+    host.assign(src, src + count);
+    ASV_HIP_CHECK(hipMemcpyAsync(dev, host.data(), count * 8, hipMemcpyHostToDevice, s));
+    ASV_HIP_CHECK(hipStreamSynchronize(s));
+    *out = dev;
+    return ASV_OK;
+  }
+};
+thread_local OffsetCache g_fbank_offs, g_cmvn_offs;
+
+struct FrontTables { float *dct; float *window; float2 *twiddle; float *mel_w; int *mel_first, *mel_count; int mel_stride; float *seg_w; int *seg_first, *bin_seg; int n_seg; };
 thread_local FrontTables g_tab = {};
 
 int window_size(const asv_fbank_opts_t &o, float ms) { return (int)(o.sample_rate * 0.001f * ms); }
@@ -676,7 +700,6 @@ static int fbank_entry(const asv_fbank_opts_t *o, const void *wave, bool pcm16, 
       }
       if ((rc = up(dct.data(), dct.size() * 4, reinterpret_cast<void **>(&g_tab.dct)))) return rc;
     }
-    g_tab.offs = nullptr; g_tab.offs_cap = 0;
     g_front_opts = *o;
     g_front_valid = true;
   }
@@ -695,17 +718,11 @@ static int fbank_entry(const asv_fbank_opts_t *o, const void *wave, bool pcm16, 
     }
   }
   if (total == 0) return ASV_OK;
-  if (offs.size() * 8 > g_tab.offs_cap) {
-    long long *d = nullptr;
-    ASV_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d), offs.size() * 16));
-    g_front_dev.push_back(d);
-    g_tab.offs = d; g_tab.offs_cap = offs.size() * 16;
-  }
-  ASV_HIP_CHECK(hipMemcpyAsync(g_tab.offs, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, s));
-  ASV_HIP_CHECK(hipStreamSynchronize(s));                  // `offs` is a local; the copy must finish before it dies
+  const long long *d_offs = nullptr;
+  { const int rc = g_fbank_offs.get(offs.data(), offs.size(), s, &d_offs); if (rc) return rc; }
   FbankKernelParams p;
   memset(&p, 0, sizeof(p));
-  p.wave = wave; p.sample_off = g_tab.offs; p.frame_off = g_tab.offs + (n_utts + 1); p.n_utts = n_utts; p.total_frames = total;
+  p.wave = wave; p.sample_off = d_offs; p.frame_off = d_offs + (n_utts + 1); p.n_utts = n_utts; p.total_frames = total;
   p.length = length; p.shift = shift; p.padded = padded; p.log2n = log2n; p.preemph = o->preemph;
   p.remove_dc = o->remove_dc_offset; p.snip_edges = o->snip_edges; p.use_energy = o->use_energy; p.raw_energy = o->raw_energy;
   p.htk_compat = o->htk_compat; p.use_log = o->use_log_fbank || o->num_ceps > 0; p.use_power = o->use_power || o->num_ceps > 0;
@@ -825,13 +842,10 @@ int asv_cmvn(float *feats, const long long *frame_offsets, int n_utts, int dim, 
   ASV_REQUIRE(frame_offsets[0] == 0, "asv_cmvn: frame_offsets[0] must be 0");
   if (!mean_norm && !std_norm) return ASV_OK;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  long long *d = nullptr;
-  ASV_HIP_CHECK(hipMallocAsync(reinterpret_cast<void **>(&d), (size_t)(n_utts + 1) * 8, s));
-  ASV_HIP_CHECK(hipMemcpyAsync(d, frame_offsets, (size_t)(n_utts + 1) * 8, hipMemcpyHostToDevice, s));
-  ASV_HIP_CHECK(hipStreamSynchronize(s));                  // the caller's offsets array may be a temporary
+  const long long *d = nullptr;
+  { const int rc = g_cmvn_offs.get(frame_offsets, (size_t)n_utts + 1, s, &d); if (rc) return rc; }
   hipLaunchKernelGGL(cmvn_kernel, dim3((unsigned)n_utts, (unsigned)((dim + 63) / 64)), dim3(256), 0, s, feats, d, dim, mean_norm, std_norm, eps);
   ASV_HIP_CHECK(hipGetLastError());
-  ASV_HIP_CHECK(hipFreeAsync(d, s));
   return ASV_OK;
 }
 

@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--settle-seconds", type=float, default=0.5,
                     help="untimed steps run for this long before the W warmup steps: the power management needs ~100 ms of sustained load "
                          "to reach the steady clock; the first 100 steps after idle are 30 %% slower than the steady state")
+    ap.add_argument("--from-wav", action="store_true",
+                    help="start every step from 16-bit PCM in HBM: asv_fbank_pcm16 (log-mel, --feat-dim bins) + asv_cmvn + extraction "
+                         "(SURVEY.md 8(f) rank 2; the headline metric starts from feature matrices, this is a supplementary line)")
     ap.add_argument("--model", default="xvector", choices=["xvector", "ecapa", "resnet"],
                     help="xvector = BASELINE configs[1] (the default, the contract's workload); ecapa = configs[2] (C=1024, 300 frames); "
                          "resnet = the configs[4] extractor (ResNet34-SE)")
@@ -103,13 +106,27 @@ def main():
     pending = [None, None]
     counter = [0]
 
+    if args.from_wav:
+        from libs.amd import frontend
+        n_samp = 400 + (T - 1) * 160                                # 25 ms windows, 10 ms shift at 16 kHz: exactly T frames
+        wave_dev = torch.from_numpy(np.concatenate([synth.synth_wave(n_samp, 10_000 * rank + i).astype(np.int16) for i in range(B)])).to(dev)
+        sample_off = np.arange(B + 1, dtype=np.int64) * n_samp
+        fe_kw = dict(num_mel_bins=D, energy_floor=0.0, mean_norm=True)
+
+    def extract_once(out):
+        if args.from_wav:
+            f, _ = frontend.fbank_device(wave_dev, sample_off, **fe_kw)
+            eng.extract_device(f, offsets, out=out)
+        else:
+            eng.extract_device(feats, offsets, out=out)
+
     def step():
         k = counter[0] & 1
         counter[0] += 1
         if pending[k] is not None:                                  # buffer pair k is free once its gather has finished
             pending[k].wait()                                       # (stream-side wait, the host does not block)
             pending[k] = None
-        eng.extract_device(feats, offsets, out=outs[k])
+        extract_once(outs[k])
         if world > 1:
             pending[k] = dist.all_gather_into_tensor(gathered[k], outs[k], async_op=True)
 
@@ -143,7 +160,7 @@ def main():
     t_settle = time.perf_counter()
     while time.perf_counter() - t_settle < args.settle_seconds:       # untimed: bring the device to its steady clock
         for _ in range(50):
-            eng.extract_device(feats, offsets, out=outs[0])          # local work only: the count differs between ranks,
+            extract_once(outs[0])                                    # local work only: the count differs between ranks,
         torch.cuda.synchronize(dev)                                   # so no collective may be issued here
     for _ in range(args.warmup):
         step()
@@ -187,9 +204,10 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.precision, "data": "synthetic",
         "config": {"workload": "%s: %s, %d-dim fbank, %d utterances x %d frames per GPU per step, "
-                               "features resident in HBM, f32 embeddings out%s" % ({"xvector": "BASELINE configs[1]: standard TDNN x-vector", "ecapa": "BASELINE configs[2]: ECAPA-TDNN C=1024",
+                               "%s resident in HBM, f32 embeddings out%s" % ({"xvector": "BASELINE configs[1]: standard TDNN x-vector", "ecapa": "BASELINE configs[2]: ECAPA-TDNN C=1024",
                                                                                    "resnet": "BASELINE configs[4] extractor: ResNet34-SE"}[args.model],
-                                                                                  creation, D, B, T, ", + RCCL all-gather of embeddings" if world > 1 else ""),
+                                                                                  creation, D, B, T, "16-bit PCM (fbank + CMN computed on the device in every step)" if args.from_wav else "features",
+                                                                                  ", + RCCL all-gather of embeddings" if world > 1 else ""),
                    "global_batch_utts": world * B, "frames_per_utt": T, "parallelism": "utterance shards x%d" % world},
         "value_without_event_recording": round(utts / dt_plain, 1),
         "settle_seconds": args.settle_seconds,
