@@ -231,12 +231,13 @@ __global__ __launch_bounds__(64) void pool_finish_kernel(const PoolFinishParams 
   }
 }
 
-// ECAPA attentive statistics (ecapa_tdnn_xvector.py:182-188) and, with `shared`, the single shared head of
-// AttentiveStatisticsPooling (libs/nnet/pooling.py:322-370): one logit per frame (column 0 of `logits`) for all channels.
+// ECAPA attentive statistics (ecapa_tdnn_xvector.py:182-188; group 1: a logit per channel) and the shared-weight heads of
+// libs/nnet/pooling.py:322-587: every `group` consecutive channels use one logit column (group = channels: the single head of
+// AttentiveStatisticsPooling, column 0; group = channels / heads: MultiHeadAttentionPooling).
 template <bool BF16>
 __global__ __launch_bounds__(256) void attentive_pool_kernel(const void *x, int ldx, const void *logits, int ldl,
                                                              int channels, const int32_t *seg_row0,
-                                                             const int32_t *seg_len, float eps, float *out, int ld_out, int shared) {
+                                                             const int32_t *seg_len, float eps, float *out, int ld_out, int group) {
   constexpr int VEC = BF16 ? 8 : 4;
   constexpr int CG = 64 / VEC;
   constexpr int RS = 64 / CG;
@@ -253,10 +254,13 @@ __global__ __launch_bounds__(256) void attentive_pool_kernel(const void *x, int 
   if (active)
     for (int r = wave * RS + rs; r < len; r += 4 * RS) {
       float e[VEC];
-      if (shared) {
+      if (group >= channels) {                                  // one head: column 0 weights every channel
         const float e0 = load_elem<BF16>(logits, (size_t)(row0 + r) * ldl);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) e[i] = e0;
+      } else if (group > 1) {                                   // heads over channel groups: column (channel / group)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) e[i] = load_elem<BF16>(logits, (size_t)(row0 + r) * ldl + min(ch + i, channels - 1) / group);
       } else {
         load_vec<BF16, VEC>(logits, (size_t)(row0 + r) * ldl + ch, e);
       }
@@ -271,10 +275,13 @@ __global__ __launch_bounds__(256) void attentive_pool_kernel(const void *x, int 
   if (active)
     for (int r = wave * RS + rs; r < len; r += 4 * RS) {
       float e[VEC], v[VEC];
-      if (shared) {
+      if (group >= channels) {                                  // one head: column 0 weights every channel
         const float e0 = load_elem<BF16>(logits, (size_t)(row0 + r) * ldl);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) e[i] = e0;
+      } else if (group > 1) {                                   // heads over channel groups: column (channel / group)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) e[i] = load_elem<BF16>(logits, (size_t)(row0 + r) * ldl + min(ch + i, channels - 1) / group);
       } else {
         load_vec<BF16, VEC>(logits, (size_t)(row0 + r) * ldl + ch, e);
       }
@@ -293,7 +300,10 @@ __global__ __launch_bounds__(256) void attentive_pool_kernel(const void *x, int 
     for (int i = 0; i < VEC; ++i) {
       if (ch + i >= channels) continue;
       const float mean = sx[i] / se[i];
-      const float resid = sxx[i] / se[i] - mean * mean;
+      // no fma contraction: with one frame (alpha = 1) x^2 - x * x must cancel exactly, as it does in the reference
+      float m2 = mean * mean;
+      asm volatile("" : "+v"(m2));                            // (HIP's __fmul_rn is a plain multiply and would be contracted)
+      const float resid = sxx[i] / se[i] - m2;
       out[(size_t)seg * ld_out + ch + i] = mean;
       out[(size_t)seg * ld_out + channels + ch + i] = sqrtf(fmaxf(resid, eps));
     }
@@ -522,13 +532,12 @@ int launch_pool_finish(const PoolFinishParams &p, int segments, hipStream_t s) {
 }
 
 int launch_attentive_pool(const void *x, int ldx, const void *logits, int ldl, int channels, const int32_t *seg_row0,
-                          const int32_t *seg_len, int segments, float eps, float *out, int ld_out, bool bf16, bool shared_logits,
+                          const int32_t *seg_len, int segments, float eps, float *out, int ld_out, bool bf16, int group,
                           hipStream_t s) {
   if (segments <= 0) return ASV_OK;
   const dim3 grid((channels + 63) / 64, segments), block(256);
-  const int sh = shared_logits ? 1 : 0;
-  if (bf16) hipLaunchKernelGGL(attentive_pool_kernel<true>, grid, block, 0, s, x, ldx, logits, ldl, channels, seg_row0, seg_len, eps, out, ld_out, sh);
-  else hipLaunchKernelGGL(attentive_pool_kernel<false>, grid, block, 0, s, x, ldx, logits, ldl, channels, seg_row0, seg_len, eps, out, ld_out, sh);
+  if (bf16) hipLaunchKernelGGL(attentive_pool_kernel<true>, grid, block, 0, s, x, ldx, logits, ldl, channels, seg_row0, seg_len, eps, out, ld_out, group);
+  else hipLaunchKernelGGL(attentive_pool_kernel<false>, grid, block, 0, s, x, ldx, logits, ldl, channels, seg_row0, seg_len, eps, out, ld_out, group);
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }

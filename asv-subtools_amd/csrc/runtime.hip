@@ -541,7 +541,13 @@ int asv_net_add_attentive_pool(asv_net_t *net, const asv_attpool_desc_t *d) {
   ASV_REQUIRE(d->struct_size == sizeof(asv_attpool_desc_t), "asv_net_add_attentive_pool: struct_size mismatch");
   int rc;
   if ((rc = check_view(net, d->x_buf, d->x_ch_off, d->channels, "attentive pool x"))) return rc;
-  if ((rc = check_view(net, d->logit_buf, d->logit_ch_off, d->shared_logits ? 1 : d->channels, "attentive pool logits"))) return rc;
+  ASV_REQUIRE(d->logit_group >= 0 && d->logit_group <= d->channels, "attentive pool: logit_group %d", d->logit_group);
+  const int group = d->logit_group > 1 ? d->logit_group : (d->shared_logits ? d->channels : 1);
+  if (group > 1) {                 // head logits are read one element at a time: any column offset (head h of the global poolings)
+    ASV_REQUIRE(d->logit_buf >= 0 && d->logit_buf < (int)net->bufs.size() && d->logit_ch_off >= 0 &&
+                d->logit_ch_off + (d->channels + group - 1) / group <= net->bufs[d->logit_buf].channels,
+                "attentive pool logits: columns [%d,%d) exceed buffer %d", d->logit_ch_off, d->logit_ch_off + (d->channels + group - 1) / group, d->logit_buf);
+  } else if ((rc = check_view(net, d->logit_buf, d->logit_ch_off, d->channels, "attentive pool logits"))) return rc;
   ASV_REQUIRE(d->out_buf > 0 && d->out_buf < (int)net->bufs.size(), "attentive pool: output buffer id %d", d->out_buf);
   ASV_REQUIRE(d->out_ch_off >= 0 && d->out_ch_off + 2 * d->channels <= net->bufs[d->out_buf].channels, "attentive pool: output view exceeds buffer");
   ASV_REQUIRE(net->bufs[d->x_buf].domain == ASV_DOMAIN_FRAMES && net->bufs[d->logit_buf].domain == ASV_DOMAIN_FRAMES &&
@@ -994,9 +1000,10 @@ int run_ops(RunCtx &c, size_t n_ops) {
         const auto &d = op.att;
         const DomainRun &dr = c.dom[ASV_DOMAIN_FRAMES];
         if ((rc = prof.begin(K_ATT, 0, (int)i))) return rc;
+        const int group = d.logit_group > 1 ? d.logit_group : (d.shared_logits ? d.channels : 1);
         rc = launch_attentive_pool(view(c, d.x_buf, d.x_ch_off), net->bufs[d.x_buf].ld, view(c, d.logit_buf, d.logit_ch_off), net->bufs[d.logit_buf].ld,
                                    d.channels, dr.seg_row0, dr.seg_len, bp.segments, d.eps,
-                                   reinterpret_cast<float *>(net->arena[d.out_buf].ptr) + d.out_ch_off, net->bufs[d.out_buf].ld, net->frames_bf16(), d.shared_logits != 0, c.s);
+                                   reinterpret_cast<float *>(net->arena[d.out_buf].ptr) + d.out_ch_off, net->bufs[d.out_buf].ld, net->frames_bf16(), group, c.s);
         if (rc) return rc;
         if ((rc = prof.end())) return rc;
         break;

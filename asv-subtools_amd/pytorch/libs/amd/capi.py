@@ -64,6 +64,7 @@ class AttPoolDesc(C.Structure):
         ("out_buf", C.c_int32), ("out_ch_off", C.c_int32),
         ("eps", C.c_float),
         ("shared_logits", C.c_int32),
+        ("logit_group", C.c_int32),
     ]
 
 

@@ -124,6 +124,7 @@ class Engine(object):
                 d.out_buf, d.out_ch_off = bv(op.out)
                 d.eps = op.eps
                 d.shared_logits = int(getattr(op, "shared", False))
+                d.logit_group = int(getattr(op, "group", 0))
                 capi.check(L.asv_net_add_attentive_pool(self._net, C.byref(d)), "asv_net_add_attentive_pool")
             elif op.kind == "eltwise":
                 d = capi.EltwiseDesc()

@@ -149,12 +149,15 @@ class Graph(object):
         self.ops.append(Op("im2col", out, inp=inp, taps=[(int(a), int(b)) for a, b in taps], stride=int(stride)))
         return out
 
-    def attpool(self, x, logits, eps=1e-5, shared=False):
-        """softmax-over-frames weighted mean / std of x; `shared`: logits has ONE channel that weights every channel of x."""
-        if shared and logits.channels != 1:
-            raise TraceError("shared attention logits must have one channel, got %d" % logits.channels)
+    def attpool(self, x, logits, eps=1e-5, shared=False, group=0):
+        """softmax-over-frames weighted mean / std of x -> [mean | std].  `shared`: logits has ONE channel that weights every
+        channel of x; `group` > 1: every `group` consecutive channels of x share logit column (channel // group)."""
+        group = int(group)
+        n_logits = 1 if shared else (-(-x.channels // group) if group > 1 else x.channels)
+        if logits.channels != n_logits:
+            raise TraceError("attention logits must have %d channel(s), got %d" % (n_logits, logits.channels))
         out = self.full_view(self.new_tensor(DOMAIN_UTTS, 2 * x.channels))
-        self.ops.append(Op("attpool", out, x=x, logits=logits, eps=float(eps), shared=bool(shared)))
+        self.ops.append(Op("attpool", out, x=x, logits=logits, eps=float(eps), shared=bool(shared), group=group))
         return out
 
     def eltwise(self, a, b=None, c=None, seg_scale=None, scale=None, shift=None, act=None, seg_norm=None, seg_norm_mode=0):
@@ -164,10 +167,13 @@ class Graph(object):
                            seg_norm=seg_norm, seg_norm_mode=int(seg_norm_mode)))
         return out
 
-    def cat(self, parts):
+    def cat(self, parts, align=1):
+        """Channel concatenation; with `align` every part starts at a multiple of it (the gaps are never written and stay
+        zero in the device arena: the consumer gives them zero weights, see Sym.col_order)."""
         dom = self.domain(parts[0].tid)
-        out = self.full_view(self.new_tensor(dom, sum(p.channels for p in parts)))
-        self.ops.append(Op("cat", out, parts=list(parts)))
+        width = sum(-(-p.channels // align) * align for p in parts[:-1]) + parts[-1].channels
+        out = self.full_view(self.new_tensor(dom, width))
+        self.ops.append(Op("cat", out, parts=list(parts), align=int(align)))
         return out
 
     # ---- passes ----------------------------------------------------------------------
@@ -290,7 +296,8 @@ class Graph(object):
                 else:
                     new_ops.append(Op("eltwise", dst, a=part, b=None, c=None, seg_scale=None, scale=None, shift=None, act=None,
                                       seg_norm=None, seg_norm_mode=0))
-                off += part.channels
+                align = getattr(op, "align", 1)
+                off += -(-part.channels // align) * align
             self.ops[idx:idx + 1] = new_ops
 
     def _drop_dead(self):

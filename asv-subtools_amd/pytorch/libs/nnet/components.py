@@ -60,20 +60,47 @@ class TdnnAffine(torch.nn.Module):
             torch.nn.init.constant_(self.bias, 0.0)
 
     def _check_supported(self):
-        if not self.pad or self.stride != 1 or self.groups != 1 or self.norm_w or self.norm_f:
-            raise _ir.TraceError("TdnnAffine(pad=%s, stride=%s, groups=%s, norm_w=%s, norm_f=%s): only pad=True, stride=1, "
-                                 "groups=1 without weight/feature normalisation is implemented on the MI355X path"
-                                 % (self.pad, self.stride, self.groups, self.norm_w, self.norm_f))
+        if not self.pad or self.stride != 1 or self.norm_w or self.norm_f:
+            raise _ir.TraceError("TdnnAffine(pad=%s, stride=%s, norm_w=%s, norm_f=%s): only pad=True, stride=1 "
+                                 "without weight/feature normalisation is implemented on the MI355X path"
+                                 % (self.pad, self.stride, self.norm_w, self.norm_f))
 
-    def emit(self, x, act1=None, scale=None, shift=None, affine_first=False):
-        """Appends this affine (+ fused epilogue) to the program of the symbolic tensor `x`."""
+    def emit(self, x, act1=None, scale=None, shift=None, affine_first=False, row_scale=None, row_map=None):
+        """Appends this affine (+ fused epilogue) to the program of the symbolic tensor `x`.  A grouped affine (the attention
+        heads of pooling.py:279-296) becomes the block-diagonal dense matrix it is; `row_scale` multiplies output rows
+        (weights and bias) by constants."""
         self._check_supported()
-        if x.view.channels != self.input_dim:
-            raise _ir.TraceError("TdnnAffine expects %d input channels, got %d" % (self.input_dim, x.view.channels))
+        order = getattr(x, "col_order", None)
+        have = x.view.channels if order is None else int((order >= 0).sum())
+        if have != self.input_dim:
+            raise _ir.TraceError("TdnnAffine expects %d input channels, got %d" % (self.input_dim, have))
         w = self.weight.detach().cpu().numpy()
-        if getattr(x, "col_order", None) is not None:
-            w = w[:, x.col_order, :]           # the pooled tensor's columns are a permutation of the reference's
+        if self.groups != 1:
+            import numpy as np
+            go, gi = self.output_dim // self.groups, self.input_dim // self.groups
+            dense = np.zeros((self.output_dim, self.input_dim, w.shape[2]), dtype=w.dtype)
+            for g in range(self.groups):
+                dense[g * go:(g + 1) * go, g * gi:(g + 1) * gi, :] = w[g * go:(g + 1) * go]
+            w = dense
+        if order is not None:                  # the pooled tensor's columns are a permutation of the reference's; -1: padding
+            import numpy as np
+            w = np.where((order >= 0)[None, :, None], w[:, np.maximum(order, 0), :], 0).astype(w.dtype)
         b = self.bias.detach().cpu().numpy() if self.bias is not None else None
+        if row_scale is not None:
+            import numpy as np
+            rs = np.asarray(row_scale, dtype=np.float64)
+            w = (w.astype(np.float64) * rs[:, None, None]).astype(np.float32)
+            b = None if b is None else (b.astype(np.float64).reshape(-1) * rs).astype(np.float32)
+        if row_map is not None:                       # (destination rows, total rows): spread the outputs, zero rows between
+            import numpy as np
+            dst, total = row_map
+            w2 = np.zeros((total,) + w.shape[1:], dtype=w.dtype)
+            w2[dst] = w
+            b2 = None
+            if b is not None:
+                b2 = np.zeros(total, dtype=b.dtype)
+                b2[dst] = b.reshape(-1)
+            w, b = w2, b2
         out = x.graph.tdnn(x.view, w, b, self.context, self.left_context, act1=act1, scale=scale, shift=shift,
                            affine_first=affine_first)
         return _ir.Sym(x.graph, out, 3)

@@ -42,8 +42,9 @@ class Xvector(TopVirtualNnet):
         layer_params = utils.assign_params_dict(_TDNN_DEFAULTS, tdnn_layer_params)
         last_params = utils.assign_params_dict(layer_params, tdnn7_params)
         pool_params = utils.assign_params_dict(_POOLING_DEFAULTS, pooling_params)
-        if pooling not in ("statistics", "attentive"):
-            raise NotImplementedError("pooling='%s': statistics and attentive pooling are built on the MI355X path (SURVEY.md 8(f) rank 3)" % pooling)
+        if pooling in ("lde", "xi-postmean-softplus2", "xi-postdist-softplus2"):
+            raise NotImplementedError("pooling='%s': statistics, attentive, multi-head and multi-resolution pooling are built on the MI355X "
+                                      "path (SURVEY.md 8(f) rank 3)" % pooling)
         if training:
             raise NotImplementedError("this blueprint is the extraction graph only (training=False)")
         self.extracted_embedding = extracted_embedding
@@ -60,9 +61,14 @@ class Xvector(TopVirtualNnet):
             else:
                 setattr(self, name, SEBlock(dim, ratio=se_ratio))
         self.tdnn5 = ReluBatchNormTdnnLayer(512, pool_params["num_nodes"], **layer_params)
+        head_params = {k: v for k, v in pool_params.items() if k not in ("num_nodes", "stddev")}       # reference :116-130
         if pooling == "attentive":
             self.stats = AttentiveStatisticsPooling(pool_params["num_nodes"], affine_layers=pool_params["affine_layers"], hidden_size=pool_params["hidden_size"],
                                                     context=pool_params["context"], stddev=pool_params["stddev"])
+        elif pooling == "multi-head":
+            self.stats = MultiHeadAttentionPooling(pool_params["num_nodes"], stddev=pool_params["stddev"], **head_params)
+        elif pooling == "multi-resolution":
+            self.stats = MultiResolutionMultiHeadAttentionPooling(pool_params["num_nodes"], **head_params)
         else:
             self.stats = StatisticsPooling(pool_params["num_nodes"], stddev=pool_params["stddev"])
         stats_dim = self.stats.get_output_dim()

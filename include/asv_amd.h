@@ -141,6 +141,9 @@ typedef struct asv_attpool_desc {
   float   eps;
   int32_t shared_logits;         /* != 0: ONE logit per frame (column logit_ch_off of logit_buf) weights every channel -
                                     AttentiveStatisticsPooling with its shared single head, libs/nnet/pooling.py:322-370 */
+  int32_t logit_group;           /* > 1: every logit_group consecutive channels share logit column (channel / logit_group) -
+                                    MultiHeadAttentionPooling with shared weights, pooling.py:371-438 (channels / num_head);
+                                    0: per shared_logits */
 } asv_attpool_desc_t;
 int asv_net_add_attentive_pool(asv_net_t *net, const asv_attpool_desc_t *d);
 

@@ -100,6 +100,23 @@ CASES = {
     "snowdar_attentive_mean": dict(blueprint="snowdar_xvector.py",
                                    creation="Xvector(40,10,training=False,pooling='attentive',pooling_params={'affine_layers':1,'stddev':False},extracted_embedding='near')",
                                    dim=40, utts=[(120, 6800)], wseed=17),
+    # multi-head poolings (pooling.py:371-587): heads over channel splits (shared: a logit per head; un-shared: per channel,
+    # two grouped affine layers), global heads with fixed / learned temperatures (shared and un-shared)
+    "snowdar_multihead": dict(blueprint="snowdar_xvector.py",
+                              creation="Xvector(40,10,training=False,pooling='multi-head',pooling_params={'num_head':4})",
+                              dim=40, utts=[(200, 6900), (41, 6901), (3, 6902)], wseed=18),
+    "snowdar_multihead_unshared": dict(blueprint="snowdar_xvector.py",
+                                       creation="Xvector(40,10,training=False,pooling='multi-head',pooling_params={'num_head':3,'share':False,"
+                                                "'affine_layers':2,'hidden_size':32,'num_nodes':600,'context':[-1,0,1]},extracted_embedding='near')",
+                                       dim=40, utts=[(150, 6910), (20, 6911)], wseed=19),
+    "snowdar_multires": dict(blueprint="snowdar_xvector.py",
+                             creation="Xvector(40,10,training=False,pooling='multi-resolution',pooling_params={'num_head':4,'temperature':True,"
+                                      "'affine_layers':2,'hidden_size':16,'num_nodes':600})",
+                             dim=40, utts=[(180, 6920), (29, 6921), (1, 6922)], wseed=20),
+    "snowdar_multires_learned": dict(blueprint="snowdar_xvector.py",
+                                     creation="Xvector(40,10,training=False,pooling='multi-resolution',pooling_params={'num_head':3,'temperature':True,"
+                                              "'fixed':False,'share':False,'affine_layers':1,'num_nodes':300},extracted_embedding='near')",
+                                     dim=40, utts=[(160, 6930), (12, 6931)], wseed=21),
     # the factorised TDNN (TDNN-F) x-vector with its dense skip wiring, both positions
     "factored_far": dict(blueprint="factored_xvector.py", creation="Xvector(40,10,training=False)", dim=40,
                          utts=[(200, 6500), (45, 6501), (7, 6502)], wseed=14),

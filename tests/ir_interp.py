@@ -110,6 +110,8 @@ def run_graph(graph, feats, dtype=np.float32):
                 put(op.out, mean[None, :])
         elif op.kind == "attpool":
             x, e = get(op.x), get(op.logits)                       # e: [T, C], or [T, 1] broadcast over the channels when shared
+            if getattr(op, "group", 0) > 1:
+                e = e[:, np.arange(x.shape[1]) // op.group]        # heads over channel groups
             a = np.exp(e - e.max(axis=0, keepdims=True))
             a = a / a.sum(axis=0, keepdims=True, dtype=dtype)
             mean = (a * x).sum(axis=0, dtype=dtype)

@@ -98,6 +98,26 @@ def test_snowdar_xvector_program_reproduces_reference_on_cpu():
             assert rel_err(ir_interp.extract(graph, x), ref) < tol, name
 
 
+@pytest.mark.parametrize("name,n_pool,kind", [("snowdar_multihead", 1, "group"), ("snowdar_multihead_unshared", 1, "channel"),
+                                               ("snowdar_multires", 4, "shared"), ("snowdar_multires_learned", 3, "channel")])
+def test_multi_head_poolings_reproduce_reference_on_cpu(name, n_pool, kind):
+    """SURVEY 8(f) rank 3, alternative poolings (pooling.py:371-587): heads over channel splits / global heads with
+    temperatures, shared and un-shared last affine, grouped attention affines - against the reference's own outputs."""
+    from libs.amd import ir
+    g, sd, model = helpers.golden_model(name)                          # strict load: the reference's parameter names and shapes
+    graph = ir.trace(model, type(model).extract_embedding.__wrapped_body__, int(g["dim"]))
+    att = [op for op in graph.ops if op.kind == "attpool"]
+    assert len(att) == n_pool
+    if kind == "group":
+        assert att[0].group == 375 and att[0].logits.channels == 4
+    elif kind == "shared":
+        assert all(op.shared and op.logits.channels == 1 for op in att)
+    else:
+        assert all(not op.shared and op.group <= 1 and op.logits.channels == op.x.channels for op in att)
+    for x, ref in zip(helpers.golden_feats(g), g["embeddings"]):
+        assert rel_err(ir_interp.extract(graph, x), ref) < 1e-4, name
+
+
 def test_factored_xvector_program_reproduces_reference_on_cpu():
     """the TDNN-F blueprint (FTdnnBlock = factor + affine + ReLU + BN + scaled bypass, dense skips by
     concatenation) against the reference's own model/factored_xvector.py outputs."""
