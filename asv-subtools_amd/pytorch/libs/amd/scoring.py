@@ -6,8 +6,8 @@ Replaces the process chain the reference runs per scoring job (bash -> Kaldi bin
     score/process.sh:156-203   ivector-mean, ivector-subtract-global-mean, ivector-normalize-length
     score/score.sh:82-121      ivector-compute-dot-products, ivector-plda-scoring
     computeEER.sh / computeEER-like-Bosaris.py:50-91
-and the numpy PLDA of score/pyplda/plda_base.py (EM training stays on the host in float64 -
-SURVEY.md 8(f) ranks GPU PLDA training as "next"; scoring is on the device).
+and the numpy PLDA of score/pyplda/plda_base.py: statistics + EM training (asv_plda_train, float64 on the device -
+SURVEY.md 8(f) rank 4) and scoring; only the final D x D diagonalisation (Cholesky + eigh) is host numpy.
 
 All functions take host numpy arrays or CUDA torch tensors; results stay on the device unless
 `.cpu()` is called by the caller.
@@ -193,40 +193,27 @@ class Plda(object):
 
 
 def train_plda(vectors, labels, num_iters=10):
-    """PLDA EM (plda_base.py:37-81 stats, 248-300 EM) in float64 on the host, vectorised over the
-    classes that share an example count (one batched inverse per distinct count instead of one
-    per class).  Returns (mean, within_var, between_var)."""
-    x = np.asarray(vectors, dtype=np.float64)
+    """PLDA statistics + EM (plda_base.py:37-81, 227-300) in float64 on the device (asv_plda_train): vectors [N, dim]
+    (host array or CUDA tensor, f32 like the extracted embeddings), labels [N] (any hashable ids).  The host only groups
+    row indices by class and orders the classes by size, as the reference's sorted PldaStats does.
+    Returns (mean [dim], within_var [dim, dim], between_var [dim, dim]) float64 numpy arrays."""
+    import torch
+    x = _dev(vectors, torch.float32)
     labels = np.asarray(labels)
-    dim = x.shape[1]
+    if labels.shape[0] != x.shape[0]:
+        raise ValueError("train_plda: %d vectors but %d labels" % (x.shape[0], labels.shape[0]))
     classes, inv, counts = np.unique(labels, return_inverse=True, return_counts=True)
-    K = len(classes)
-    sums = np.zeros((K, dim))
-    np.add.at(sums, inv, x)
-    cmeans = sums / counts[:, None]
-    # offset_scatter = sum_k (X_k^T X_k - n_k m_k m_k^T)
-    offset_scatter = x.T.dot(x) - (cmeans * counts[:, None]).T.dot(cmeans)
-    class_weight = float(K)
-    example_weight = float(counts.sum())
-    gmean = cmeans.sum(axis=0) / class_weight
-    m = cmeans - gmean                                # [K, dim]
-    within, between = np.eye(dim), np.eye(dim)
-    for _ in range(num_iters):
-        w_stats = offset_scatter.copy()
-        w_count = example_weight - class_weight
-        b_stats = np.zeros((dim, dim))
-        b_count = 0.0
-        w_inv, b_inv = np.linalg.inv(within), np.linalg.inv(between)
-        for n in np.unique(counts):
-            sel = counts == n
-            k_n = int(sel.sum())
-            mix = np.linalg.inv(b_inv + n * w_inv)
-            w = (n * m[sel].dot(w_inv.T)).dot(mix.T)   # rows: mix . (n W^-1 m_k)
-            mw = m[sel] - w
-            b_stats += k_n * mix + w.T.dot(w)
-            b_count += k_n
-            w_stats += n * k_n * mix + n * mw.T.dot(mw)
-            w_count += k_n
-        within = w_stats / w_count
-        between = b_stats / b_count
-    return gmean, within, between
+    by_size = np.argsort(counts, kind="stable")                  # classes in ascending size
+    rank = np.empty(len(classes), dtype=np.int64)
+    rank[by_size] = np.arange(len(classes))
+    order = np.argsort(rank[inv], kind="stable").astype(np.int32)  # row indices grouped by class, classes by size
+    offsets = np.zeros(len(classes) + 1, dtype=np.int64)
+    np.cumsum(counts[by_size], out=offsets[1:])
+    dim = x.shape[1]
+    mean, within, between = np.zeros(dim), np.zeros((dim, dim)), np.zeros((dim, dim))
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().asv_plda_train(_ptr(x), x.stride(0), x.shape[0], dim, order.ctypes.data_as(C.POINTER(C.c_int32)),
+                                             offsets.ctypes.data_as(C.POINTER(C.c_longlong)), len(classes), int(num_iters),
+                                             dp(mean), dp(within), dp(between), _stream(x)), "asv_plda_train")
+    return mean, within, between

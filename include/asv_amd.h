@@ -274,6 +274,15 @@ int asv_score_norm(const float *enroll_cohort, int n_enroll, const float *test_c
                    const int32_t *ei, const int32_t *ti, const float *scores, int n_trials, int top_n,
                    int cross_select, float *normed, void *stream);
 
+/* ---- PLDA training --------------------------------------------------
+ * Statistics + EM of score/pyplda/plda_base.py:37-81, 227-300 in float64 on the device.  x: device f32 [n_rows][ldx]
+ * embeddings; order (host int32 [n_rows]): row indices grouped by class; class_offsets (host int64 [n_classes+1]): class k
+ * owns order[class_offsets[k] .. class_offsets[k+1]), classes in ascending size like the reference's sorted stats.
+ * Outputs (host float64): mean [dim] (mean of the class means), within_var and between_var [dim][dim] after num_iters EM
+ * iterations - what PldaEstimation.plda_write stores and Plda.from_covariances diagonalises. */
+int asv_plda_train(const float *x, int ldx, int n_rows, int dim, const int *order, const long long *class_offsets, int n_classes,
+                   int num_iters, double *mean_out, double *within_out, double *between_out, void *stream);
+
 /* ---- acoustic front-end -------------------------------------------
  * Kaldi-compatible log-mel filterbank features of packed waveforms on the device: what
  * torchaudio.compliance.kaldi.fbank computes in pytorch/libs/egs/kaldi_features.py:72-137 and kaldifeat::Fbank in

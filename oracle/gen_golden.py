@@ -298,7 +298,32 @@ def run_score_norm(name, synth):
     print("wrote %s: %d trials, %d cohort vectors; mean |snorm| %.3f" % (path, n_trials, ec.shape[1], float(np.abs(out["snorm"]).mean())))
 
 
-EXTRA_CASES = {"scoring_plda": run_scoring_plda, "score_norm": run_score_norm}
+def run_plda_ragged(name, synth):
+    """plda_base.py PldaStats + PldaEstimation on classes of different sizes (2..9 examples), stats added in ascending size."""
+    import numpy as np
+    import libs.support.kaldi_io as ref_kaldi_io
+    sys.modules["kaldi_io"] = ref_kaldi_io                       # SURVEY.md 8(c) shim 4
+    sys.path.insert(0, os.path.join(REF, "score", "pyplda"))
+    import plda_base as PB
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import helpers
+    meta = dict(n_spk=150, per_spk_max=9, dim=40, seed=31, num_iters=6)
+    train, labels = helpers.plda_ragged_set(meta, synth)
+    train = train.astype(np.float64)
+    stats = PB.PldaStats(meta["dim"])
+    counts = np.bincount(labels)
+    for spk in np.unique(labels)[np.argsort(counts, kind="stable")]:
+        stats.add_samples(1.0, train[labels == spk])
+    assert stats.is_sorted()
+    est = PB.PldaEstimation(stats)
+    est.estimate(num_em_iters=meta["num_iters"])
+    out = dict(meta, mean=np.asarray(est.mean).reshape(-1), within_var=est.within_var, between_var=est.between_var)
+    path = os.path.join(GOLDEN, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote %s: %d vectors, %d classes, sizes %s" % (path, len(labels), len(counts), sorted(set(counts.tolist()))))
+
+
+EXTRA_CASES = {"scoring_plda": run_scoring_plda, "score_norm": run_score_norm, "plda_ragged": run_plda_ragged}
 
 
 if __name__ == "__main__":

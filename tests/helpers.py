@@ -77,3 +77,15 @@ def fbank_torchaudio_kw(kw, energy_floor_default=0.0):
     out = {FBANK_KW.get(k, k): v for k, v in kw.items()}
     out.setdefault("energy_floor", energy_floor_default)          # kaldifeat's default (torchaudio's is 1.0)
     return out
+
+
+def plda_ragged_set(g, synth=None):
+    """Training set of tests/golden/plda_ragged.npz: planted speaker embeddings, a different number of examples per speaker."""
+    if synth is None:
+        from libs.amd import synth
+    x, labels = synth.synth_speaker_embeddings(int(g["n_spk"]), int(g["per_spk_max"]), int(g["dim"]), seed=int(g["seed"]), within=1.0, between=0.7)
+    keep = np.zeros(len(labels), dtype=bool)
+    sizes = np.random.RandomState(int(g["seed"]) + 1).randint(2, int(g["per_spk_max"]) + 1, size=int(g["n_spk"]))
+    for spk, n in enumerate(sizes):
+        keep[np.flatnonzero(labels == spk)[:n]] = True
+    return x[keep], labels[keep]

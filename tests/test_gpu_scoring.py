@@ -176,3 +176,53 @@ def test_score_normalization_cli_matches_reference_outputs(tmp_path):
     open(tmp_path / "ec_bad", "w").write("\n".join(lines[:-1]) + "\n")
     r = subprocess.run([sys.executable, script, str(tmp_path / "et"), str(tmp_path / "ec_bad"), str(tmp_path / "tc"), str(tmp_path / "o")], capture_output=True, text=True)
     assert r.returncode == 1 and "every cohort key" in r.stderr
+
+
+def test_plda_training_on_the_device_matches_the_reference_em():
+    """asv_plda_train (f64 statistics + EM on the device) against plda_base.py's own EM: equal class sizes
+    (tests/golden/scoring_plda.npz) and ragged ones (plda_ragged.npz)."""
+    import os
+    from libs.amd import scoring, synth
+    g = np.load(os.path.join(helpers.GOLDEN, "scoring_plda.npz"))
+    train, labels = synth.synth_speaker_embeddings(120, 6, 48, seed=11, within=1.0, between=0.8)
+    mean, within, between = scoring.train_plda(train, labels, num_iters=5)
+    assert np.abs(mean - g["mean"]).max() < 1e-10
+    assert np.abs(within - g["within_var"]).max() < 1e-9 and np.abs(between - g["between_var"]).max() < 1e-9
+    plda = scoring.Plda.from_covariances(mean, within, between)
+    assert np.abs(plda.psi - g["psi"]).max() < 1e-9
+    g = np.load(os.path.join(helpers.GOLDEN, "plda_ragged.npz"))
+    train, labels = helpers.plda_ragged_set(g)
+    perm = np.random.RandomState(0).permutation(len(labels))            # rows in any order, labels need not be 0..K-1
+    mean, within, between = scoring.train_plda(train[perm], (labels[perm] * 7 + 3), num_iters=int(g["num_iters"]))
+    assert np.abs(mean - g["mean"]).max() < 1e-10
+    assert np.abs(within - g["within_var"]).max() < 1e-9 and np.abs(between - g["between_var"]).max() < 1e-9
+
+
+def test_plda_training_at_embedding_scale_vs_oracle():
+    """128-dimensional (post-LDA sized) embeddings, 800 speakers of 3..12 utterances: device EM == float64 oracle EM, which
+    inverts one matrix per speaker and iteration like the reference."""
+    import time
+    from libs.amd import scoring, synth
+    from oracle import scoring_oracle as S
+    dim, n_spk = 128, 800
+    x, labels = synth.synth_speaker_embeddings(n_spk, 12, dim, seed=41, within=1.0, between=0.6)
+    sizes = np.random.RandomState(42).randint(3, 13, size=n_spk)
+    keep = np.zeros(len(labels), dtype=bool)
+    for spk, n in enumerate(sizes):
+        keep[np.flatnonzero(labels == spk)[:n]] = True
+    x, labels = x[keep], labels[keep]
+    t0 = time.time()
+    mean, within, between = scoring.train_plda(x, labels, num_iters=4)
+    t_dev = time.time() - t0
+    stats = S.PldaStats(dim)
+    counts = np.bincount(labels)
+    for spk in np.argsort(counts, kind="stable"):
+        stats.add_samples(1.0, x[labels == spk].astype(np.float64))
+    t0 = time.time()
+    m_ref, w_ref, b_ref = S.plda_em(stats, 4)
+    t_ref = time.time() - t0
+    print("plda EM: device %.3f s, oracle %.1f s" % (t_dev, t_ref))
+    assert np.abs(mean - m_ref.reshape(-1)).max() < 1e-10
+    assert np.abs(within - w_ref).max() / np.abs(w_ref).max() < 1e-9 and np.abs(between - b_ref).max() / np.abs(b_ref).max() < 1e-9
+    with pytest.raises(ValueError):
+        scoring.train_plda(x[:40], labels[:39], num_iters=2)

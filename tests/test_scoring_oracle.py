@@ -1,6 +1,8 @@
 """Scoring oracle pinned to the reference's own PLDA / EER code (tests/golden/scoring_plda.npz)
 and the host-side PLDA trainer of the package checked against it."""
 
+import os
+
 import numpy as np
 
 import helpers
@@ -41,15 +43,16 @@ def test_oracle_transform_llr_twocov_eer_match_reference():
     assert abs(eer - float(g["eer"])) < 1e-12 and abs(thr - float(g["eer_threshold"])) < 1e-12
 
 
-def test_package_plda_trainer_matches_reference_em():
-    """libs.amd.scoring.train_plda (vectorised host EM) == plda_base.py EM."""
-    from libs.amd import scoring
-    g, dim, train, labels, ev = _golden()
-    mean, within, between = scoring.train_plda(train, labels, num_iters=5)
-    assert np.abs(mean - g["mean"]).max() < 1e-10
-    assert np.abs(within - g["within_var"]).max() < 1e-9 and np.abs(between - g["between_var"]).max() < 1e-9
-    plda = scoring.Plda.from_covariances(mean, within, between)
-    assert np.abs(plda.psi - g["psi"]).max() < 1e-9
+def test_oracle_em_matches_reference_em_with_ragged_classes():
+    """plda_base.py EM on classes of different sizes (tests/golden/plda_ragged.npz, made by the reference itself)."""
+    g = np.load(os.path.join(helpers.GOLDEN, "plda_ragged.npz"))
+    train, labels = helpers.plda_ragged_set(g)
+    stats = S.PldaStats(train.shape[1])
+    for spk in np.unique(labels)[np.argsort(np.bincount(labels), kind="stable")]:
+        stats.add_samples(1.0, train[labels == spk].astype(np.float64))
+    mean, within, between = S.plda_em(stats, int(g["num_iters"]))
+    assert np.abs(mean.reshape(-1) - g["mean"]).max() < 1e-12
+    assert np.abs(within - g["within_var"]).max() < 1e-10 and np.abs(between - g["between_var"]).max() < 1e-10
 
 
 def test_eer_edge_cases():
