@@ -369,3 +369,29 @@ extern "C" int asv_plda_train(const float *x, int ldx, int n_rows, int dim, cons
 #undef TRY
   return ASV_OK;
 }
+
+
+// Sum and second moment of a set of vectors in float64: what PldaUnsupervisedAdaptor.add_stats accumulates vector by vector
+// (plda_base.py:360-367) and the covariance ZCA whitening starts from (score/whiten/train_ZCA_Whitening.py:46-47).
+extern "C" int asv_scatter_f64(const float *x, int ldx, int n_rows, int dim, double *sum_out, double *xtx_out, void *stream) {
+  ASV_REQUIRE(x && sum_out && xtx_out && n_rows >= 1 && dim >= 1 && ldx >= dim, "asv_scatter_f64: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  DevBuf d_xtx, d_sum, d_ones, partials;
+  size_t partial_cap = 0;
+  int rc;
+  if ((rc = d_xtx.alloc((size_t)dim * dim * 8)) || (rc = d_sum.alloc((size_t)dim * 8))) return rc;
+  Gemm64Params g; memset(&g, 0, sizeof(g));
+  g.a = x; g.b = x; g.c = d_xtx.as<double>(); g.sa_i = 1; g.sa_k = ldx; g.sb_k = ldx; g.sb_j = 1;
+  g.m = dim; g.n = dim; g.k = n_rows; g.ldc = dim; g.alpha = 1.0; g.beta = 0.0;
+  if ((rc = gemm64<float, float>(g, 1, partials, partial_cap, s))) return rc;
+  // column sums = X^T 1: the same kernel with a one-column right operand of ones (stride 0)
+  if ((rc = d_ones.alloc(8))) return rc;
+  const float one = 1.0f;
+  ASV_HIP_CHECK(hipMemcpyAsync(d_ones.p, &one, 4, hipMemcpyHostToDevice, s));
+  g.b = d_ones.p; g.sb_k = 0; g.sb_j = 0; g.n = 1; g.c = d_sum.as<double>(); g.ldc = 1;
+  if ((rc = gemm64<float, float>(g, 1, partials, partial_cap, s))) return rc;
+  ASV_HIP_CHECK(hipMemcpyAsync(sum_out, d_sum.p, (size_t)dim * 8, hipMemcpyDeviceToHost, s));
+  ASV_HIP_CHECK(hipMemcpyAsync(xtx_out, d_xtx.p, (size_t)dim * dim * 8, hipMemcpyDeviceToHost, s));
+  ASV_HIP_CHECK(hipStreamSynchronize(s));
+  return ASV_OK;
+}

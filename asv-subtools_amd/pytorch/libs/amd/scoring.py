@@ -163,6 +163,34 @@ class Plda(object):
                 f.write("\n  " + " ".join(map(str, row)))
             f.write(" ]\n [ " + " ".join(map(str, self.psi)) + " ]\n</Plda> ")
 
+    def adapt_unsupervised(self, vectors, mean_diff_scale=1.0, within_covar_scale=0.3, between_covar_scale=0.7):
+        """Kaldi-style unsupervised domain adaptation, plda_base.py:344-485 (PldaUnsupervisedAdaptor.add_stats + update_plda):
+        the statistics of the adaptation vectors come from the device (asv_scatter_f64), the dim x dim algebra follows the
+        reference step by step in float64 (its np.linalg.eig calls on symmetric matrices are eigh here: same spectrum, ordered).
+        Returns a new Plda; eigenvalue order / eigenvector signs are free, scores are not affected."""
+        total, xtx = second_moments(vectors)
+        n = float(vectors.shape[0])
+        dim = self.dim
+        mean = total / n
+        variance = xtx / n - np.outer(mean, mean)
+        mean_diff = mean - self.mean
+        variance = variance + mean_diff_scale * np.outer(mean_diff, mean_diff)
+        transform_mod = self.transform / np.sqrt(1.0 + self.psi)[:, None]
+        variance_proj = transform_mod.dot(variance).dot(transform_mod.T)
+        s, P = np.linalg.eigh(0.5 * (variance_proj + variance_proj.T))
+        W = np.diag(1.0 / (1.0 + self.psi))
+        B = np.diag(self.psi / (1.0 + self.psi))
+        Wp, Bp = P.T.dot(W).dot(P), P.T.dot(B).dot(P)
+        excess = np.clip(s - 1.0, 0.0, None)
+        Wp[np.arange(dim), np.arange(dim)] += excess * within_covar_scale
+        Bp[np.arange(dim), np.arange(dim)] += excess * between_covar_scale
+        inv = np.linalg.inv(P.T.dot(transform_mod))
+        Wmod, Bmod = inv.dot(Wp).dot(inv.T), inv.dot(Bp).dot(inv.T)
+        c_inv = np.linalg.inv(np.linalg.cholesky(0.5 * (Wmod + Wmod.T)))
+        bproj = c_inv.dot(Bmod).dot(c_inv.T)
+        psi_new, Q = np.linalg.eigh(0.5 * (bproj + bproj.T))
+        return Plda(mean, Q.T.dot(c_inv), psi_new)
+
     def transform_vectors(self, x, num_examples=None, normalize_length=True, simple_length_norm=False):
         """plda_base.py:93-107 for a whole set at once; returns a device tensor [n, dim]."""
         import torch
@@ -190,6 +218,50 @@ class Plda(object):
         capi.check(capi.lib().asv_plda_llr_trials(_ptr(e), _ptr(t), self.dim, _ptr(psi), _ptr(en), _ptr(ei), _ptr(ti), ei.shape[0], _ptr(out), _stream(e)),
                    "asv_plda_llr_trials")
         return out
+
+
+def second_moments(vectors):
+    """(sum [dim], X^T X [dim, dim]) of a set of vectors, accumulated in float64 on the device (asv_scatter_f64)."""
+    import torch
+    x = _dev(vectors, torch.float32)
+    dim = x.shape[1]
+    total, xtx = np.zeros(dim), np.zeros((dim, dim))
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().asv_scatter_f64(_ptr(x), x.stride(0), x.shape[0], dim, dp(total), dp(xtx), _stream(x)), "asv_scatter_f64")
+    return total, xtx
+
+
+def zca_whitening(vectors, regularization=1e-6, center=True):
+    """ZCA whitening matrices of score/whiten/*.py (class ZCA.fit): covariance X^T X / (n - 1) of the [centred] vectors from
+    the device statistics, eigen-decomposition of the dim x dim covariance on the host.  train_ZCA_Whitening.py does not
+    centre (center=False), do_ZCA_Whitening.py does.  Returns (mean or zeros, whiten, dewhiten); apply with
+    linear_transform(x, whiten, mean)."""
+    total, xtx = second_moments(vectors)
+    n = np.asarray(vectors).shape[0] if not hasattr(vectors, "shape") else vectors.shape[0]
+    mean = total / n if center else np.zeros_like(total)
+    cov = (xtx - n * np.outer(mean, mean)) / (n - 1) if center else xtx / (n - 1)
+    cov = 0.5 * (cov + cov.T)
+    S, U = np.linalg.eigh(cov)                     # symmetric PSD: the SVD of the reference (scipy.linalg.svd) up to ordering / signs
+    s = np.sqrt(np.clip(S, regularization, None))
+    return mean, (U / s).dot(U.T), (U * s).dot(U.T)
+
+
+def linear_transform(x, matrix, mean=None):
+    """y = matrix (x - mean) for every row, on the device (the transform kernel of the PLDA back-end without normalisation)."""
+    import torch
+    x = _dev(x, torch.float32)
+    dev = x.device
+    matrix = np.asarray(matrix, dtype=np.float32)
+    if matrix.shape[0] != matrix.shape[1] or matrix.shape[1] != x.shape[1]:
+        raise ValueError("linear_transform: a square [dim, dim] matrix is expected (dimension-reducing transforms: slice the result)")
+    m = _dev(np.zeros(x.shape[1], dtype=np.float32) if mean is None else np.asarray(mean, dtype=np.float32), device=dev)
+    tr = _dev(matrix, device=dev)
+    psi = _dev(np.ones(x.shape[1], dtype=np.float32), device=dev)
+    out = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=dev)
+    capi.check(capi.lib().asv_plda_transform(_ptr(x), x.shape[0], x.shape[1], _ptr(m), _ptr(tr), _ptr(psi), None, capi.PLDA_NORM_NONE, _ptr(out), _stream(x)),
+               "asv_plda_transform")
+    return out
 
 
 def train_plda(vectors, labels, num_iters=10):

@@ -283,6 +283,10 @@ int asv_score_norm(const float *enroll_cohort, int n_enroll, const float *test_c
 int asv_plda_train(const float *x, int ldx, int n_rows, int dim, const int *order, const long long *class_offsets, int n_classes,
                    int num_iters, double *mean_out, double *within_out, double *between_out, void *stream);
 
+/* Sum [dim] and second moment X^T X [dim][dim] of device f32 vectors, accumulated in float64 (host outputs): the statistics of
+ * PldaUnsupervisedAdaptor.add_stats (plda_base.py:360-367) and of ZCA whitening (score/whiten/train_ZCA_Whitening.py:46-47). */
+int asv_scatter_f64(const float *x, int ldx, int n_rows, int dim, double *sum_out, double *xtx_out, void *stream);
+
 /* ---- acoustic front-end -------------------------------------------
  * Kaldi-compatible log-mel filterbank features of packed waveforms on the device: what
  * torchaudio.compliance.kaldi.fbank computes in pytorch/libs/egs/kaldi_features.py:72-137 and kaldifeat::Fbank in

@@ -323,7 +323,60 @@ def run_plda_ragged(name, synth):
     print("wrote %s: %d vectors, %d classes, sizes %s" % (path, len(labels), len(counts), sorted(set(counts.tolist()))))
 
 
-EXTRA_CASES = {"scoring_plda": run_scoring_plda, "score_norm": run_score_norm, "plda_ragged": run_plda_ragged}
+def run_plda_adapt(name, synth):
+    """PldaUnsupervisedAdaptor (plda_base.py:344-485) on a shifted / stretched in-domain set, and the ZCA class of
+    score/whiten/{train,do}_ZCA_Whitening.py - the reference code itself."""
+    import importlib.util
+    import numpy as np
+    import libs.support.kaldi_io as ref_kaldi_io
+    sys.modules["kaldi_io"] = ref_kaldi_io
+    sys.path.insert(0, os.path.join(REF, "score", "pyplda"))
+    import plda_base as PB
+    dim, seed = 32, 51
+    train, labels = synth.synth_speaker_embeddings(100, 5, dim, seed=seed, within=1.0, between=0.8)
+    train = train.astype(np.float64)
+    stats = PB.PldaStats(dim)
+    for spk in range(100):
+        stats.add_samples(1.0, train[labels == spk])
+    est = PB.PldaEstimation(stats)
+    est.estimate(num_em_iters=4)
+    plda = est.get_output()
+    base = dict(mean=np.asarray(plda.mean).reshape(-1).copy(), transform=np.array(plda.transform), psi=np.array(plda.psi))
+    adapt, _ = synth.synth_speaker_embeddings(60, 4, dim, seed=seed + 1, within=1.3, between=1.1)
+    adapt = (adapt * np.linspace(0.8, 1.6, dim)[None, :] + 0.3).astype(np.float32)           # a different domain
+    ad = PB.PldaUnsupervisedAdaptor(mean_diff_scale=1.0, within_covar_scale=0.3, between_covar_scale=0.7)
+    for v in adapt.astype(np.float64):
+        ad.add_stats(1.0, v)
+    plda.mean = np.asarray(plda.mean).reshape(-1, 1)
+    ad.update_plda(plda)
+    plda.mean = np.asarray(plda.mean).reshape(-1)
+    plda.compute_derived_vars()
+    plda.offset = np.asarray(plda.offset).reshape(-1)
+    ev, ev_labels = synth.synth_speaker_embeddings(30, 4, dim, seed=seed + 2, within=1.3, between=1.1)
+    ev = (ev * np.linspace(0.8, 1.6, dim)[None, :] + 0.3).astype(np.float32)
+    ei, ti, tgt = synth.synth_trials(ev_labels, 1500, seed=seed + 3)
+    tr = np.stack([plda.transform_ivector(v.astype(np.float64), 1) for v in ev])
+    llr = np.array([float(plda.log_likelihood_ratio(tr[a], 1, tr[b])) for a, b in zip(ei, ti)])
+
+    def load(path, modname):
+        """The scripts run their command line at import time: execute the class definition part only (up to their own
+        '## class defined end ##' marker), from the reference file where it lies."""
+        import types
+        src = open(path, encoding="utf8").read().split("## class defined end ##")[0]
+        m = types.ModuleType(modname)
+        exec(compile(src, path, "exec"), m.__dict__)
+        return m
+    z1 = load(os.path.join(REF, "score", "whiten", "train_ZCA_Whitening.py"), "ref_zca_train").ZCA().fit(adapt.astype(np.float64))
+    z2 = load(os.path.join(REF, "score", "whiten", "do_ZCA_Whitening.py"), "ref_zca_do").ZCA().fit(adapt.astype(np.float64))
+    out = dict(dim=dim, seed=seed, base_mean=base["mean"], base_transform=base["transform"], base_psi=base["psi"],
+               adapted_mean=np.asarray(plda.mean).reshape(-1), adapted_psi_sorted=np.sort(np.real(np.asarray(plda.psi))), llr=llr,
+               trials_e=ei, trials_t=ti, zca_train_whiten=z1.whiten_, zca_do_whiten=z2.whiten_, zca_do_mean=z2.mean_)
+    path = os.path.join(GOLDEN, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote %s: psi %s..%s" % (path, out["adapted_psi_sorted"][0], out["adapted_psi_sorted"][-1]))
+
+
+EXTRA_CASES = {"plda_adapt": run_plda_adapt, "scoring_plda": run_scoring_plda, "score_norm": run_score_norm, "plda_ragged": run_plda_ragged}
 
 
 if __name__ == "__main__":

@@ -226,3 +226,40 @@ def test_plda_training_at_embedding_scale_vs_oracle():
     assert np.abs(within - w_ref).max() / np.abs(w_ref).max() < 1e-9 and np.abs(between - b_ref).max() / np.abs(b_ref).max() < 1e-9
     with pytest.raises(ValueError):
         scoring.train_plda(x[:40], labels[:39], num_iters=2)
+
+
+def _adapt_sets(g):
+    from libs.amd import synth
+    dim, seed = int(g["dim"]), int(g["seed"])
+    adapt, _ = synth.synth_speaker_embeddings(60, 4, dim, seed=seed + 1, within=1.3, between=1.1)
+    adapt = (adapt * np.linspace(0.8, 1.6, dim)[None, :] + 0.3).astype(np.float32)
+    ev, _ = synth.synth_speaker_embeddings(30, 4, dim, seed=seed + 2, within=1.3, between=1.1)
+    ev = (ev * np.linspace(0.8, 1.6, dim)[None, :] + 0.3).astype(np.float32)
+    return adapt, ev
+
+
+def test_unsupervised_plda_adaptation_and_zca_match_the_reference():
+    """Device statistics (asv_scatter_f64) + the reference's D x D algebra: adapted PLDA == PldaUnsupervisedAdaptor
+    (plda_base.py:344-485) in spectrum and in every trial score; ZCA matrices == score/whiten's ZCA class."""
+    import os
+    from libs.amd import scoring
+    g = np.load(os.path.join(helpers.GOLDEN, "plda_adapt.npz"))
+    adapt, ev = _adapt_sets(g)
+    total, xtx = scoring.second_moments(adapt)
+    a64 = adapt.astype(np.float64)
+    assert np.abs(total - a64.sum(0)).max() < 1e-9 and np.abs(xtx - a64.T.dot(a64)).max() < 1e-9
+    base = scoring.Plda(g["base_mean"], g["base_transform"], g["base_psi"])
+    new = base.adapt_unsupervised(adapt, mean_diff_scale=1.0, within_covar_scale=0.3, between_covar_scale=0.7)
+    assert np.abs(new.mean - g["adapted_mean"]).max() < 1e-10
+    assert np.abs(np.sort(new.psi) - g["adapted_psi_sorted"]).max() < 1e-8
+    t = new.transform_vectors(ev)
+    llr = new.llr_trials(t, t, g["trials_e"], g["trials_t"]).cpu().numpy()
+    assert np.abs(llr - g["llr"]).max() < 2e-3 * max(1.0, np.abs(g["llr"]).max() / 10)      # f32 scoring kernels vs the f64 reference
+    mean, whiten, _ = scoring.zca_whitening(adapt, center=False)
+    assert np.abs(whiten - g["zca_train_whiten"]).max() < 1e-8 and not mean.any()
+    mean, whiten, dewhiten = scoring.zca_whitening(adapt, center=True)
+    assert np.abs(whiten - g["zca_do_whiten"]).max() < 1e-8 and np.abs(mean - g["zca_do_mean"]).max() < 1e-10
+    assert np.abs(whiten.dot(dewhiten) - np.eye(len(mean))).max() < 1e-9
+    y = scoring.linear_transform(adapt, whiten, mean).cpu().numpy()
+    assert np.abs(y - (a64 - mean).dot(whiten.T)).max() < 1e-4
+    assert np.abs(np.cov(y.T) - np.eye(len(mean))).max() < 1e-3          # whitened
