@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""PLDA training throughput: asv_plda_train (f64 statistics + EM on the device) on a planted-speaker set.
-    python tools/bench_plda.py [--speakers 6000] [--per-speaker 30] [--dim 256] [--iters 10]
+"""(lives under tests/ because it times the oracle as well: only tests/ may import oracle/)
+PLDA training throughput: asv_plda_train (f64 statistics + EM on the device) on a planted-speaker set.
+    python tests/perf_plda.py [--speakers 6000] [--per-speaker 30] [--dim 256] [--iters 10]
 Prints one JSON line; --cpu-classes N also times the numpy oracle EM (one inverse per class, like the reference) on the
 first N classes for scale."""
 import argparse

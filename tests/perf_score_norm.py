@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Throughput of the device score normalisation (asv_score_norm) at VoxCeleb1-O scale, next to the numpy oracle on the
+"""(lives under tests/ because it times the oracle as well: only tests/ may import oracle/)
+Throughput of the device score normalisation (asv_score_norm) at VoxCeleb1-O scale, next to the numpy oracle on the
 host (the reference itself is a pandas groupby + a Python loop over the trials).  Prints one JSON line.
 
-    python tools/bench_score_norm.py [--enroll 4708] [--test 4708] [--cohort 3000] [--trials 37720] [--top-n 300]
+    python tests/perf_score_norm.py [--enroll 4708] [--test 4708] [--cohort 3000] [--trials 37720] [--top-n 300]
 """
 import argparse
 import json
