@@ -4,12 +4,18 @@
 // reference runtime/kaldifeat/csrc (feature-window.cc, feature-fbank.cc, mel-computations.cc), whose float arithmetic the
 // host-side tables below follow line by line (that code is compiled in place as the parity reference, oracle/Makefile.ref).
 //
-// One wave per frame, four frames per workgroup, everything of a frame in LDS:
-//   gather the window (mirror-padded when snip_edges is off) -> mean removal -> raw log energy -> pre-emphasis ->
-//   window function -> zero padding -> in-place radix-2 complex FFT (bit-reversed load, log2(N) butterfly passes; a
-//   single wave needs no barrier between passes: its LDS operations complete in order) -> |X|^2 or |X| of bins 0..N/2-1
-//   -> triangular mel filters (lane = mel bin, each bin walks its own contiguous range of FFT bins) -> log, floor.
-// HBM: 4 bytes per sample in (frames overlap 2.5x, the re-reads hit L2), 4 * num_bins bytes per frame out.
+// Also here: MFCC output (feature-mfcc.cc), 16-bit PCM input, per-utterance and Kaldi sliding-window CMVN, the energy VAD of
+// runtime/extractor/torch_asv_extractor.cc:14-62 and voiced-frame selection.
+//
+// Two feature kernels, one wave per frame in both:
+//   fbank512_kernel  16 kHz windows (257..512 samples): samples, window, pre-emphasis and a radix-4 Stockham FFT in
+//                    registers with three LDS exchanges, segmented mel filters (details at the kernel)
+//   fbank_kernel     any other window up to 2048 samples: everything of a frame in LDS - gather the window (mirror-padded
+//                    when snip_edges is off) -> mean removal -> raw log energy -> pre-emphasis -> window function -> zero
+//                    padding -> in-place radix-2 complex FFT (bit-reversed load, log2(N) butterfly passes; a single wave
+//                    needs no barrier between passes: its LDS operations complete in order) -> |X|^2 or |X| of bins
+//                    0..N/2-1 -> triangular mel filters (lane = mel bin over its own range of FFT bins) -> log, floor
+// HBM: 4 (2 for PCM16) bytes per sample in (frames overlap 2.5x, the re-reads hit L1/L2), 4 * dim bytes per frame out.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdlib.h>

@@ -37,7 +37,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--batch", type=int, default=256, help="utterances per GPU per step")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="utterances per GPU per step (default: 640 for the x-vector - 640 x 204 padded rows = 1020 row tiles of 128, two "
+                         "column tiles each, fill the 512 workgroup slots of the device in whole rounds, +15 %% over 256; 256 for the others)")
     ap.add_argument("--frames", type=int, default=None, help="frames per utterance (default: 200; 300 for --model ecapa, BASELINE configs[2])")
     ap.add_argument("--feat-dim", type=int, default=80)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
@@ -96,6 +98,8 @@ def main():
     # ---- synthetic batch, device resident ----------------------------------------------------
     if args.frames is None:
         args.frames = 300 if args.model == "ecapa" else 200
+    if args.batch is None:
+        args.batch = 640 if args.model == "xvector" else 256
     B, T, D = args.batch, args.frames, args.feat_dim
     mats = [synth.synth_feats(T, D, 10_000 * rank + i) for i in range(B)]
     feats = torch.from_numpy(np.concatenate(mats, axis=0)).to(dev)
