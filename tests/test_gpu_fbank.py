@@ -156,3 +156,24 @@ def test_energy_vad_and_voiced_frame_selection():
         assert 0 < counts.sum() < len(v)                                     # the gate really produced both classes
         kept, koff = frontend.select_voiced(feats, voiced, off, counts)
         assert np.array_equal(kept.cpu().numpy(), host[v.astype(bool)]) and list(np.diff(koff)) == list(counts)
+
+
+def test_full_size_properties_shift_and_batch_invariance():
+    """BASELINE-sized batch (512 utterances x 200 frames, too slow for the numpy oracle): properties the domain offers.
+    Dropping the first frame shift of samples drops exactly the first frame (snip_edges on), whatever the batch around it;
+    an utterance's frames do not depend on its neighbours or on its sample alignment in the packed buffer."""
+    import torch
+    from libs.amd import frontend, synth
+    n = 400 + 199 * 160
+    base = [synth.synth_wave(n + 160 + (i % 3), 4000 + i) for i in range(16)]            # odd lengths: odd packed offsets
+    waves = [base[i % 16] for i in range(512)]
+    feats, off = frontend.fbank_packed(waves, num_mel_bins=80)
+    assert feats.shape == (int(off[-1]), 80) and off[-1] == 512 * 201 and torch.isfinite(feats).all()
+    shifted, off2 = frontend.fbank_packed([w[160:] for w in waves], num_mel_bins=80)
+    assert list(np.diff(off2)) == [200] * 512
+    a = feats.view(512, 201, 80)[:, 1:, :]
+    assert torch.equal(a, shifted.view(512, 200, 80))
+    for i in (0, 17, 511):                                                                # copies of one utterance at different places
+        assert torch.equal(feats[off[i]:off[i + 1]], feats[off[i % 16]:off[i % 16 + 1]])
+    want = fbank_oracle.fbank(base[5], num_bins=80)
+    assert np.abs(feats[off[5]:off[6]].cpu().numpy() - want).max() < LOG_TOL
