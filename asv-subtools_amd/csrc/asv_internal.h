@@ -140,7 +140,8 @@ struct PoolFinishParams {
 int launch_pool_finish(const PoolFinishParams &p, int segments, hipStream_t s);
 int launch_attentive_pool(const void *x, int ldx, const void *logits, int ldl, int channels,
                           const int32_t *seg_row0, const int32_t *seg_len, int segments, float eps,
-                          float *out, int ld_out, bool bf16, int group, hipStream_t s);
+                          float *out, int ld_out, bool bf16, int group, int softplus2, const float *prior_logit, const float *prior_value,
+                          hipStream_t s);
 // row r of a segment is valid iff (r - row0) % pitch < width (frames domain: pitch = width = 1)
 int launch_rowmap(const int32_t *seg_row0, const int32_t *seg_len, int segments, int rows, int pitch, int width,
                   int32_t *row_seg, uint32_t *row_valid, hipStream_t s);

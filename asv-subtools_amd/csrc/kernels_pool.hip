@@ -237,7 +237,8 @@ __global__ __launch_bounds__(64) void pool_finish_kernel(const PoolFinishParams 
 template <bool BF16>
 __global__ __launch_bounds__(256) void attentive_pool_kernel(const void *x, int ldx, const void *logits, int ldl,
                                                              int channels, const int32_t *seg_row0,
-                                                             const int32_t *seg_len, float eps, float *out, int ld_out, int group) {
+                                                             const int32_t *seg_len, float eps, float *out, int ld_out, int group,
+                                                             int softplus2, const float *prior_logit, const float *prior_value) {
   constexpr int VEC = BF16 ? 8 : 4;
   constexpr int CG = 64 / VEC;
   constexpr int RS = 64 / CG;
@@ -263,11 +264,19 @@ __global__ __launch_bounds__(256) void attentive_pool_kernel(const void *x, int 
         for (int i = 0; i < VEC; ++i) e[i] = load_elem<BF16>(logits, (size_t)(row0 + r) * ldl + min(ch + i, channels - 1) / group);
       } else {
         load_vec<BF16, VEC>(logits, (size_t)(row0 + r) * ldl + ch, e);
+        if (softplus2) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) e[i] = 2.0f * logf(e[i] > 20.0f ? e[i] : log1pf(expf(e[i])));   // Softplus(beta 1, threshold 20), squared, log
+        }
       }
 #pragma unroll
       for (int i = 0; i < VEC; ++i) mx[i] = fmaxf(mx[i], e[i]);
     }
   block_max_rows<VEC, CG>(mx, sm, wave, cg, rs);
+  if (prior_logit && active) {                                 // the prior is one more frame of every utterance
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) mx[i] = fmaxf(mx[i], prior_logit[min(ch + i, channels - 1)]);
+  }
 
   float se[VEC], sx[VEC], sxx[VEC];
 #pragma unroll
@@ -284,6 +293,10 @@ __global__ __launch_bounds__(256) void attentive_pool_kernel(const void *x, int 
         for (int i = 0; i < VEC; ++i) e[i] = load_elem<BF16>(logits, (size_t)(row0 + r) * ldl + min(ch + i, channels - 1) / group);
       } else {
         load_vec<BF16, VEC>(logits, (size_t)(row0 + r) * ldl + ch, e);
+        if (softplus2) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) e[i] = 2.0f * logf(e[i] > 20.0f ? e[i] : log1pf(expf(e[i])));   // Softplus(beta 1, threshold 20), squared, log
+        }
       }
       load_vec<BF16, VEC>(x, (size_t)(row0 + r) * ldx + ch, v);
 #pragma unroll
@@ -299,6 +312,10 @@ __global__ __launch_bounds__(256) void attentive_pool_kernel(const void *x, int 
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       if (ch + i >= channels) continue;
+      if (prior_logit) {
+        const float w = expf(prior_logit[ch + i] - mx[i]), v = prior_value[ch + i];
+        se[i] += w; sx[i] += w * v; sxx[i] += w * v * v;
+      }
       const float mean = sx[i] / se[i];
       // no fma contraction: with one frame (alpha = 1) x^2 - x * x must cancel exactly, as it does in the reference
       float m2 = mean * mean;
@@ -532,12 +549,12 @@ int launch_pool_finish(const PoolFinishParams &p, int segments, hipStream_t s) {
 }
 
 int launch_attentive_pool(const void *x, int ldx, const void *logits, int ldl, int channels, const int32_t *seg_row0,
-                          const int32_t *seg_len, int segments, float eps, float *out, int ld_out, bool bf16, int group,
+                          const int32_t *seg_len, int segments, float eps, float *out, int ld_out, bool bf16, int group, int softplus2, const float *prior_logit, const float *prior_value,
                           hipStream_t s) {
   if (segments <= 0) return ASV_OK;
   const dim3 grid((channels + 63) / 64, segments), block(256);
-  if (bf16) hipLaunchKernelGGL(attentive_pool_kernel<true>, grid, block, 0, s, x, ldx, logits, ldl, channels, seg_row0, seg_len, eps, out, ld_out, group);
-  else hipLaunchKernelGGL(attentive_pool_kernel<false>, grid, block, 0, s, x, ldx, logits, ldl, channels, seg_row0, seg_len, eps, out, ld_out, group);
+  if (bf16) hipLaunchKernelGGL(attentive_pool_kernel<true>, grid, block, 0, s, x, ldx, logits, ldl, channels, seg_row0, seg_len, eps, out, ld_out, group, softplus2, prior_logit, prior_value);
+  else hipLaunchKernelGGL(attentive_pool_kernel<false>, grid, block, 0, s, x, ldx, logits, ldl, channels, seg_row0, seg_len, eps, out, ld_out, group, softplus2, prior_logit, prior_value);
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }

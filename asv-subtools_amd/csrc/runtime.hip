@@ -552,7 +552,15 @@ int asv_net_add_attentive_pool(asv_net_t *net, const asv_attpool_desc_t *d) {
   ASV_REQUIRE(d->out_ch_off >= 0 && d->out_ch_off + 2 * d->channels <= net->bufs[d->out_buf].channels, "attentive pool: output view exceeds buffer");
   ASV_REQUIRE(net->bufs[d->x_buf].domain == ASV_DOMAIN_FRAMES && net->bufs[d->logit_buf].domain == ASV_DOMAIN_FRAMES &&
               net->is_utts(net->bufs[d->out_buf].domain), "attentive pool: frames -> utts");
+  ASV_REQUIRE((d->prior_logit == nullptr) == (d->prior_value == nullptr), "attentive pool: prior logits and values come together");
+  ASV_REQUIRE(!(d->logit_softplus2 || d->prior_logit) || group == 1, "attentive pool: the xi-vector options need per-channel logits");
   Op op; op.kind = OP_ATTPOOL; op.att = *d;
+  if (d->prior_logit) {                                         // parked in the scale / shift slots of the op
+    ASV_HIP_CHECK(hipSetDevice(net->device));
+    if ((rc = upload_padded(net, d->prior_logit, d->channels, round_up(d->channels, kChanAlign), 0.0f, &op.scale))) return rc;
+    if ((rc = upload_padded(net, d->prior_value, d->channels, round_up(d->channels, kChanAlign), 0.0f, &op.shift))) return rc;
+  }
+  op.att.prior_logit = nullptr; op.att.prior_value = nullptr;
   net->ops.push_back(op);
   return ASV_OK;
 }
@@ -1003,7 +1011,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         const int group = d.logit_group > 1 ? d.logit_group : (d.shared_logits ? d.channels : 1);
         rc = launch_attentive_pool(view(c, d.x_buf, d.x_ch_off), net->bufs[d.x_buf].ld, view(c, d.logit_buf, d.logit_ch_off), net->bufs[d.logit_buf].ld,
                                    d.channels, dr.seg_row0, dr.seg_len, bp.segments, d.eps,
-                                   reinterpret_cast<float *>(net->arena[d.out_buf].ptr) + d.out_ch_off, net->bufs[d.out_buf].ld, net->frames_bf16(), group, c.s);
+                                   reinterpret_cast<float *>(net->arena[d.out_buf].ptr) + d.out_ch_off, net->bufs[d.out_buf].ld, net->frames_bf16(), group, d.logit_softplus2 != 0, op.scale, op.shift, c.s);
         if (rc) return rc;
         if ((rc = prof.end())) return rc;
         break;

@@ -65,6 +65,7 @@ class AttPoolDesc(C.Structure):
         ("eps", C.c_float),
         ("shared_logits", C.c_int32),
         ("logit_group", C.c_int32),
+        ("logit_softplus2", C.c_int32), ("prior_logit", c_float_p), ("prior_value", c_float_p),
     ]
 
 

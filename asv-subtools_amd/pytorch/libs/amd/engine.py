@@ -125,6 +125,10 @@ class Engine(object):
                 d.eps = op.eps
                 d.shared_logits = int(getattr(op, "shared", False))
                 d.logit_group = int(getattr(op, "group", 0))
+                d.logit_softplus2 = int(getattr(op, "softplus2", False))
+                if getattr(op, "prior_logit", None) is not None:
+                    d.prior_logit = op.prior_logit.ctypes.data_as(capi.c_float_p)
+                    d.prior_value = op.prior_value.ctypes.data_as(capi.c_float_p)
                 capi.check(L.asv_net_add_attentive_pool(self._net, C.byref(d)), "asv_net_add_attentive_pool")
             elif op.kind == "eltwise":
                 d = capi.EltwiseDesc()

@@ -149,15 +149,21 @@ class Graph(object):
         self.ops.append(Op("im2col", out, inp=inp, taps=[(int(a), int(b)) for a, b in taps], stride=int(stride)))
         return out
 
-    def attpool(self, x, logits, eps=1e-5, shared=False, group=0):
+    def attpool(self, x, logits, eps=1e-5, shared=False, group=0, softplus2=False, prior_logit=None, prior_value=None):
         """softmax-over-frames weighted mean / std of x -> [mean | std].  `shared`: logits has ONE channel that weights every
-        channel of x; `group` > 1: every `group` consecutive channels of x share logit column (channel // group)."""
+        channel of x; `group` > 1: every `group` consecutive channels of x share logit column (channel // group).
+        xi-vector options (per-channel logits): `softplus2` turns the stored values z into logits 2 log(softplus(z));
+        `prior_logit` / `prior_value` [channels] add one more frame with these logits (untransformed) and values."""
         group = int(group)
+        if (softplus2 or prior_logit is not None) and (shared or group > 1):
+            raise TraceError("the xi-vector pooling options need per-channel logits")
         n_logits = 1 if shared else (-(-x.channels // group) if group > 1 else x.channels)
         if logits.channels != n_logits:
             raise TraceError("attention logits must have %d channel(s), got %d" % (n_logits, logits.channels))
         out = self.full_view(self.new_tensor(DOMAIN_UTTS, 2 * x.channels))
-        self.ops.append(Op("attpool", out, x=x, logits=logits, eps=float(eps), shared=bool(shared), group=group))
+        f32 = lambda v: None if v is None else np.ascontiguousarray(v, dtype=np.float32).reshape(-1)
+        self.ops.append(Op("attpool", out, x=x, logits=logits, eps=float(eps), shared=bool(shared), group=group, softplus2=bool(softplus2),
+                           prior_logit=f32(prior_logit), prior_value=f32(prior_value)))
         return out
 
     def eltwise(self, a, b=None, c=None, seg_scale=None, scale=None, shift=None, act=None, seg_norm=None, seg_norm_mode=0):

@@ -32,6 +32,8 @@ def synth_tensor(key, shape, seed=0):
         return np.zeros(shape, dtype=np.int64)
     if leaf == "t":                                    # attention temperatures (pooling.py:242-252): positive, not tiny
         return r.uniform(1.0, 5.0, shape).astype(np.float32)
+    if leaf in ("prior_mean", "prior_logprec"):        # xi-vector prior (pooling.py:178-179): zeros at init, make them matter
+        return (0.5 * r.standard_normal(shape)).astype(np.float32)
     if leaf == "running_mean":
         return (0.5 * r.standard_normal(shape)).astype(np.float32)
     if leaf == "running_var":

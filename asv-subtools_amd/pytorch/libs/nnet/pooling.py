@@ -239,6 +239,38 @@ class MultiResolutionMultiHeadAttentionPooling(GlobalMultiHeadAttentionPooling):
     _temperature = True
 
 
+class xivec_stdinit_softplus2_prec_pooling(torch.nn.Module):
+    """xi-vector posterior inference pooling (reference pooling.py:165-218): a per-channel frame precision
+    softplus(lin2(ReLU-BN(lin1 x)))^2 weights the frames, a learned Gaussian prior (mean, log-precision) joins as one more
+    frame; output = posterior mean [and std].  Two frame-level GEMMs for the precision estimator, then the attentive pooling
+    kernel with the 2 log softplus transform and the prior frame."""
+
+    def __init__(self, input_dim, hidden_size=256, context=[0], stddev=False, train_mean=True, train_prec=True):
+        super(xivec_stdinit_softplus2_prec_pooling, self).__init__()
+        from .components import ReluBatchNormTdnnLayer, TdnnAffine
+        self.input_dim, self.stddev = input_dim, stddev
+        self.output_dim = 2 * input_dim if stddev else input_dim
+        self.prior_mean = torch.nn.Parameter(torch.zeros(1, input_dim), requires_grad=train_mean)
+        self.prior_logprec = torch.nn.Parameter(torch.zeros(1, input_dim), requires_grad=train_prec)
+        self.softmax = torch.nn.Softmax(dim=2)
+        self.lin1_relu_bn = ReluBatchNormTdnnLayer(input_dim, hidden_size, context)
+        self.lin2 = TdnnAffine(hidden_size, input_dim, context=context)
+        self.softplus2 = torch.nn.Softplus(beta=1, threshold=20)
+
+    def forward(self, inputs):
+        _attentive_stats(inputs, self.input_dim, "xivec_stdinit_softplus2_prec_pooling")
+        g = inputs.graph
+        prec = self.lin2(self.lin1_relu_bn(inputs))
+        both = g.attpool(inputs.view, prec.view, eps=1.0e-10, softplus2=True,
+                         prior_logit=self.prior_logprec.detach().cpu().numpy(), prior_value=self.prior_mean.detach().cpu().numpy())
+        if self.stddev:
+            return _ir.Sym(g, both, 3)
+        return _ir.Sym(g, _ir.View(both.tid, both.ch_off, self.input_dim), 3)
+
+    def get_output_dim(self):
+        return self.output_dim
+
+
 def _not_on_hot_path(name, where):
     class _Unsupported(torch.nn.Module):
         def __init__(self, *args, **kwargs):

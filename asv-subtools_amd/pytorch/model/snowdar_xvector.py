@@ -42,9 +42,9 @@ class Xvector(TopVirtualNnet):
         layer_params = utils.assign_params_dict(_TDNN_DEFAULTS, tdnn_layer_params)
         last_params = utils.assign_params_dict(layer_params, tdnn7_params)
         pool_params = utils.assign_params_dict(_POOLING_DEFAULTS, pooling_params)
-        if pooling in ("lde", "xi-postmean-softplus2", "xi-postdist-softplus2"):
-            raise NotImplementedError("pooling='%s': statistics, attentive, multi-head and multi-resolution pooling are built on the MI355X "
-                                      "path (SURVEY.md 8(f) rank 3)" % pooling)
+        if pooling == "lde":
+            raise NotImplementedError("pooling='lde': statistics, attentive, multi-head, multi-resolution and xi-vector pooling are built on the "
+                                      "MI355X path (SURVEY.md 8(f) rank 3)")
         if training:
             raise NotImplementedError("this blueprint is the extraction graph only (training=False)")
         self.extracted_embedding = extracted_embedding
@@ -67,6 +67,9 @@ class Xvector(TopVirtualNnet):
                                                     context=pool_params["context"], stddev=pool_params["stddev"])
         elif pooling == "multi-head":
             self.stats = MultiHeadAttentionPooling(pool_params["num_nodes"], stddev=pool_params["stddev"], **head_params)
+        elif pooling in ("xi-postmean-softplus2", "xi-postdist-softplus2"):
+            self.stats = xivec_stdinit_softplus2_prec_pooling(pool_params["num_nodes"], hidden_size=pool_params["hidden_size"],
+                                                              stddev=pooling == "xi-postdist-softplus2")
         elif pooling == "multi-resolution":
             self.stats = MultiResolutionMultiHeadAttentionPooling(pool_params["num_nodes"], **head_params)
         else:

@@ -144,6 +144,10 @@ typedef struct asv_attpool_desc {
   int32_t logit_group;           /* > 1: every logit_group consecutive channels share logit column (channel / logit_group) -
                                     MultiHeadAttentionPooling with shared weights, pooling.py:371-438 (channels / num_head);
                                     0: per shared_logits */
+  /* xi-vector posterior pooling (pooling.py:165-218, per-channel logits only): */
+  int32_t logit_softplus2;       /* != 0: the stored logits are raw precisions z; the weight logit is 2 log(softplus(z)) */
+  const float *prior_logit;      /* host [channels] or NULL: one more "frame" per utterance with these logits ...        */
+  const float *prior_value;      /* ... and these values (prior_logprec / prior_mean), not transformed                  */
 } asv_attpool_desc_t;
 int asv_net_add_attentive_pool(asv_net_t *net, const asv_attpool_desc_t *d);
 

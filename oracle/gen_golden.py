@@ -117,6 +117,13 @@ CASES = {
                                      creation="Xvector(40,10,training=False,pooling='multi-resolution',pooling_params={'num_head':3,'temperature':True,"
                                               "'fixed':False,'share':False,'affine_layers':1,'num_nodes':300},extracted_embedding='near')",
                                      dim=40, utts=[(160, 6930), (12, 6931)], wseed=21),
+    # xi-vector posterior pooling (pooling.py:165-218): posterior mean only / mean + std
+    "snowdar_xi_mean": dict(blueprint="snowdar_xvector.py",
+                            creation="Xvector(40,10,training=False,pooling='xi-postmean-softplus2',pooling_params={'hidden_size':64,'num_nodes':600})",
+                            dim=40, utts=[(200, 6940), (37, 6941), (1, 6942)], wseed=22),
+    "snowdar_xi_dist": dict(blueprint="snowdar_xvector.py",
+                            creation="Xvector(40,10,training=False,pooling='xi-postdist-softplus2',pooling_params={'hidden_size':32},extracted_embedding='near')",
+                            dim=40, utts=[(150, 6950), (9, 6951)], wseed=23),
     # the factorised TDNN (TDNN-F) x-vector with its dense skip wiring, both positions
     "factored_far": dict(blueprint="factored_xvector.py", creation="Xvector(40,10,training=False)", dim=40,
                          utts=[(200, 6500), (45, 6501), (7, 6502)], wseed=14),

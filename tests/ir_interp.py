@@ -112,6 +112,11 @@ def run_graph(graph, feats, dtype=np.float32):
             x, e = get(op.x), get(op.logits)                       # e: [T, C], or [T, 1] broadcast over the channels when shared
             if getattr(op, "group", 0) > 1:
                 e = e[:, np.arange(x.shape[1]) // op.group]        # heads over channel groups
+            if getattr(op, "softplus2", False):                    # xi-vector: precision estimate -> 2 log softplus
+                e = dtype(2.0) * np.log(np.where(e > 20, e, np.log1p(np.exp(np.minimum(e, 20)))))
+            if getattr(op, "prior_logit", None) is not None:       # the prior is one more frame
+                e = np.concatenate([e, op.prior_logit.astype(dtype)[None, :]], axis=0)
+                x = np.concatenate([x, op.prior_value.astype(dtype)[None, :]], axis=0)
             a = np.exp(e - e.max(axis=0, keepdims=True))
             a = a / a.sum(axis=0, keepdims=True, dtype=dtype)
             mean = (a * x).sum(axis=0, dtype=dtype)

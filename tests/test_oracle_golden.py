@@ -118,6 +118,19 @@ def test_multi_head_poolings_reproduce_reference_on_cpu(name, n_pool, kind):
         assert rel_err(ir_interp.extract(graph, x), ref) < 1e-4, name
 
 
+@pytest.mark.parametrize("name", ["snowdar_xi_mean", "snowdar_xi_dist"])
+def test_xi_vector_pooling_reproduces_reference_on_cpu(name):
+    """xi-vector posterior pooling (pooling.py:165-218): precision estimator, 2 log softplus logits, the learned prior as one
+    more frame - against the reference's own outputs (incl. a one-frame utterance, where the prior matters most)."""
+    from libs.amd import ir
+    g, sd, model = helpers.golden_model(name)
+    graph = ir.trace(model, type(model).extract_embedding.__wrapped_body__, int(g["dim"]))
+    att = [op for op in graph.ops if op.kind == "attpool"]
+    assert len(att) == 1 and att[0].softplus2 and att[0].prior_logit is not None and att[0].logits.channels == att[0].x.channels
+    for x, ref in zip(helpers.golden_feats(g), g["embeddings"]):
+        assert rel_err(ir_interp.extract(graph, x), ref) < 1e-4, name
+
+
 def test_factored_xvector_program_reproduces_reference_on_cpu():
     """the TDNN-F blueprint (FTdnnBlock = factor + affine + ReLU + BN + scaled bypass, dense skips by
     concatenation) against the reference's own model/factored_xvector.py outputs."""
