@@ -264,6 +264,20 @@ def linear_transform(x, matrix, mean=None):
     return out
 
 
+def group_rows_by_class(labels):
+    """Host bookkeeping of train_plda: (order int32 [N]: row indices grouped by class, the classes in ascending size as the
+    reference's sorted PldaStats wants them (plda_base.py:68-81, 236-240); offsets int64 [K+1] into `order`)."""
+    labels = np.asarray(labels)
+    classes, inv, counts = np.unique(labels, return_inverse=True, return_counts=True)
+    by_size = np.argsort(counts, kind="stable")                  # classes in ascending size
+    rank = np.empty(len(classes), dtype=np.int64)
+    rank[by_size] = np.arange(len(classes))
+    order = np.argsort(rank[inv], kind="stable").astype(np.int32)
+    offsets = np.zeros(len(classes) + 1, dtype=np.int64)
+    np.cumsum(counts[by_size], out=offsets[1:])
+    return order, offsets
+
+
 def train_plda(vectors, labels, num_iters=10):
     """PLDA statistics + EM (plda_base.py:37-81, 227-300) in float64 on the device (asv_plda_train): vectors [N, dim]
     (host array or CUDA tensor, f32 like the extracted embeddings), labels [N] (any hashable ids).  The host only groups
@@ -274,18 +288,12 @@ def train_plda(vectors, labels, num_iters=10):
     labels = np.asarray(labels)
     if labels.shape[0] != x.shape[0]:
         raise ValueError("train_plda: %d vectors but %d labels" % (x.shape[0], labels.shape[0]))
-    classes, inv, counts = np.unique(labels, return_inverse=True, return_counts=True)
-    by_size = np.argsort(counts, kind="stable")                  # classes in ascending size
-    rank = np.empty(len(classes), dtype=np.int64)
-    rank[by_size] = np.arange(len(classes))
-    order = np.argsort(rank[inv], kind="stable").astype(np.int32)  # row indices grouped by class, classes by size
-    offsets = np.zeros(len(classes) + 1, dtype=np.int64)
-    np.cumsum(counts[by_size], out=offsets[1:])
+    order, offsets = group_rows_by_class(labels)
     dim = x.shape[1]
     mean, within, between = np.zeros(dim), np.zeros((dim, dim)), np.zeros((dim, dim))
     dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
     with torch.cuda.device(x.device):
         capi.check(capi.lib().asv_plda_train(_ptr(x), x.stride(0), x.shape[0], dim, order.ctypes.data_as(C.POINTER(C.c_int32)),
-                                             offsets.ctypes.data_as(C.POINTER(C.c_longlong)), len(classes), int(num_iters),
+                                             offsets.ctypes.data_as(C.POINTER(C.c_longlong)), len(offsets) - 1, int(num_iters),
                                              dp(mean), dp(within), dp(between), _stream(x)), "asv_plda_train")
     return mean, within, between

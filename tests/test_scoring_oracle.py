@@ -55,6 +55,18 @@ def test_oracle_em_matches_reference_em_with_ragged_classes():
     assert np.abs(within - g["within_var"]).max() < 1e-10 and np.abs(between - g["between_var"]).max() < 1e-10
 
 
+def test_class_grouping_for_the_device_trainer():
+    from libs.amd import scoring
+    labels = np.array(["b", "a", "c", "a", "b", "a", "d", "c", "a"])
+    order, off = scoring.group_rows_by_class(labels)
+    sizes = np.diff(off)
+    assert list(sizes) == sorted(sizes) == [1, 2, 2, 4] and off[0] == 0 and off[-1] == len(labels)
+    assert sorted(order.tolist()) == list(range(len(labels))) and order.dtype == np.int32
+    for k in range(len(sizes)):
+        assert len(set(labels[order[off[k]:off[k + 1]]])) == 1               # one class per group
+    assert list(labels[order[off[3]:off[4]]]) == ["a"] * 4
+
+
 def test_eer_edge_cases():
     # perfectly separable: FAR hits 0 at the first target
     eer, thr = S.compute_eer([0.1, 0.2, 0.8, 0.9], [0, 0, 1, 1])
