@@ -395,3 +395,38 @@ extern "C" int asv_scatter_f64(const float *x, int ldx, int n_rows, int dim, dou
   ASV_HIP_CHECK(hipStreamSynchronize(s));
   return ASV_OK;
 }
+
+
+// Class-level second moments: sum_k n_k mu_k mu_k^T (mu_k = mean of class k) next to the global sum and X^T X - the
+// CovarianceStats of Kaldi's ivector-compute-lda, which score/process.sh:218-229 calls for the LDA stage of the scoring chain.
+extern "C" int asv_class_scatter_f64(const float *x, int ldx, int n_rows, int dim, const int *order, const long long *class_offsets, int n_classes,
+                                     double *sum_out, double *xtx_out, double *class_scatter_out, void *stream) {
+  ASV_REQUIRE(x && order && class_offsets && sum_out && xtx_out && class_scatter_out, "asv_class_scatter_f64: null argument");
+  ASV_REQUIRE(n_rows >= 1 && dim >= 1 && ldx >= dim && n_classes >= 1, "asv_class_scatter_f64: bad sizes");
+  ASV_REQUIRE(class_offsets[0] == 0 && class_offsets[n_classes] == n_rows, "asv_class_scatter_f64: class_offsets must run from 0 to n_rows");
+  int rc = asv_scatter_f64(x, ldx, n_rows, dim, sum_out, xtx_out, stream);
+  if (rc) return rc;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int D = dim, K = n_classes;
+  std::vector<double> sizes(K);
+  for (int k = 0; k < K; ++k) {
+    sizes[k] = (double)(class_offsets[k + 1] - class_offsets[k]);
+    ASV_REQUIRE(sizes[k] >= 1.0, "asv_class_scatter_f64: class %d is empty", k);
+  }
+  DevBuf d_order, d_off, d_cmeans, d_sizes, d_out, partials;
+  size_t partial_cap = 0;
+  if ((rc = d_order.alloc((size_t)n_rows * 4)) || (rc = d_off.alloc(((size_t)K + 1) * 8)) || (rc = d_cmeans.alloc((size_t)K * D * 8)) ||
+      (rc = d_sizes.alloc((size_t)K * 8)) || (rc = d_out.alloc((size_t)D * D * 8))) return rc;
+  ASV_HIP_CHECK(hipMemcpyAsync(d_order.p, order, (size_t)n_rows * 4, hipMemcpyHostToDevice, s));
+  ASV_HIP_CHECK(hipMemcpyAsync(d_off.p, class_offsets, ((size_t)K + 1) * 8, hipMemcpyHostToDevice, s));
+  ASV_HIP_CHECK(hipMemcpyAsync(d_sizes.p, sizes.data(), (size_t)K * 8, hipMemcpyHostToDevice, s));
+  ASV_HIP_CHECK(hipStreamSynchronize(s));
+  hipLaunchKernelGGL(class_mean_kernel, dim3((unsigned)K, (unsigned)((D + 63) / 64)), dim3(256), 0, s, x, ldx, d_order.as<int>(), d_off.as<long long>(), D, d_cmeans.as<double>());
+  Gemm64Params g; memset(&g, 0, sizeof(g));
+  g.a = d_cmeans.p; g.b = d_cmeans.p; g.c = d_out.as<double>(); g.sa_i = 1; g.sa_k = D; g.sb_k = D; g.sb_j = 1; g.kscale = d_sizes.as<double>();
+  g.m = D; g.n = D; g.k = K; g.ldc = D; g.alpha = 1.0; g.beta = 0.0;
+  if ((rc = gemm64<double, double>(g, 1, partials, partial_cap, s))) return rc;
+  ASV_HIP_CHECK(hipMemcpyAsync(class_scatter_out, d_out.p, (size_t)D * D * 8, hipMemcpyDeviceToHost, s));
+  ASV_HIP_CHECK(hipStreamSynchronize(s));
+  return ASV_OK;
+}

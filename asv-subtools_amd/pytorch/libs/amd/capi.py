@@ -132,7 +132,7 @@ SYMBOLS = [
     "asv_tdnn_forward", "asv_stats_pool_forward",
     "asv_length_norm", "asv_mean_vec", "asv_dot_score_matrix", "asv_dot_score_trials",
     "asv_plda_transform", "asv_plda_llr_trials", "asv_eer", "asv_score_norm",
-    "asv_plda_train", "asv_scatter_f64",
+    "asv_plda_train", "asv_scatter_f64", "asv_class_scatter_f64",
     "asv_fbank_num_frames", "asv_fbank", "asv_fbank_pcm16", "asv_cmvn", "asv_cmvn_sliding", "asv_vad_energy", "asv_select_frames",
 ]
 
@@ -193,6 +193,8 @@ def lib():
     L.asv_plda_train.argtypes = [vp, ci, ci, ci, C.POINTER(C.c_int32), C.POINTER(C.c_longlong), ci, ci,
                                  C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), vp]
     L.asv_scatter_f64.argtypes = [vp, ci, ci, ci, C.POINTER(C.c_double), C.POINTER(C.c_double), vp]
+    L.asv_class_scatter_f64.argtypes = [vp, ci, ci, ci, C.POINTER(C.c_int32), C.POINTER(C.c_longlong), ci,
+                                        C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), vp]
     L.asv_fbank_num_frames.argtypes = [C.POINTER(FbankOpts), C.c_longlong]; L.asv_fbank_num_frames.restype = C.c_longlong
     L.asv_fbank.argtypes = [C.POINTER(FbankOpts), vp, C.POINTER(C.c_longlong), ci, vp, vp]
     L.asv_fbank_pcm16.argtypes = [C.POINTER(FbankOpts), vp, C.POINTER(C.c_longlong), ci, vp, vp]

@@ -232,6 +232,55 @@ def second_moments(vectors):
     return total, xtx
 
 
+def train_lda(vectors, labels, lda_dim, total_covariance_factor=0.0, covariance_floor=1.0e-6):
+    """Kaldi ivector-compute-lda (score/process.sh:218-229 runs it with --total-covariance-factor=0.1; Kaldi itself is not
+    vendored in the reference: restated from ivectorbin/ivector-compute-lda.cc, PARITY UNPINNED).  Class statistics come from
+    the device (asv_class_scatter_f64); the dim x dim algebra is host float64: subtract the global mean, whiten
+    factor * total + (1 - factor) * within covariance (eigenvalues floored at floor * largest), diagonalise the projected
+    between-class covariance, keep the lda_dim strongest directions.  Returns the [lda_dim, dim + 1] affine matrix
+    ivector-transform applies (last column = offset -A mean); apply_affine(x, mat) applies it on the device."""
+    import torch
+    x = _dev(vectors, torch.float32)
+    order, offsets = group_rows_by_class(labels)
+    dim, n = x.shape[1], x.shape[0]
+    total, xtx, cls = np.zeros(dim), np.zeros((dim, dim)), np.zeros((dim, dim))
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().asv_class_scatter_f64(_ptr(x), x.stride(0), n, dim, order.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                    offsets.ctypes.data_as(C.POINTER(C.c_longlong)), len(offsets) - 1, dp(total), dp(xtx), dp(cls),
+                                                    _stream(x)), "asv_class_scatter_f64")
+    mean = total / n
+    mm = n * np.outer(mean, mean)
+    total_covar = (xtx - mm) / n
+    between = (cls - mm) / n
+    within = total_covar - between
+    mat = total_covariance_factor * total_covar + (1.0 - total_covariance_factor) * within
+    s, U = np.linalg.eigh(0.5 * (mat + mat.T))
+    s = np.maximum(s, covariance_floor * s.max())
+    T = (U / np.sqrt(s)).T                                        # diag(s^-1/2) U^T: T mat T^T = I
+    proj = T.dot(between).dot(T.T)
+    e, V = np.linalg.eigh(0.5 * (proj + proj.T))
+    keep = np.argsort(-e)[:lda_dim]
+    A = V[:, keep].T.dot(T)
+    return np.concatenate([A, -A.dot(mean)[:, None]], axis=1)
+
+
+def apply_affine(x, mat):
+    """ivector-transform with a [rows, dim + 1] matrix (last column = offset) or a [rows, dim] linear one, rows <= dim, on the
+    device; returns [n, rows]."""
+    mat = np.asarray(mat, dtype=np.float64)
+    dim = np.asarray(x.shape)[1]
+    rows = mat.shape[0]
+    if mat.shape[1] not in (dim, dim + 1) or rows > dim:
+        raise ValueError("apply_affine: matrix %s does not fit %d-dimensional vectors" % (mat.shape, dim))
+    A = np.zeros((dim, dim))
+    A[:rows] = mat[:, :dim]
+    shift = None
+    if mat.shape[1] == dim + 1:                                   # A x + b = A (x - m) with A m = -b (b lies in the row space image of A)
+        shift = np.linalg.lstsq(mat[:, :dim], -mat[:, dim], rcond=None)[0]
+    return linear_transform(x, A, shift)[:, :rows]
+
+
 def zca_whitening(vectors, regularization=1e-6, center=True):
     """ZCA whitening matrices of score/whiten/*.py (class ZCA.fit): covariance X^T X / (n - 1) of the [centred] vectors from
     the device statistics, eigen-decomposition of the dim x dim covariance on the host.  train_ZCA_Whitening.py does not

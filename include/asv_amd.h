@@ -291,6 +291,11 @@ int asv_plda_train(const float *x, int ldx, int n_rows, int dim, const int *orde
  * PldaUnsupervisedAdaptor.add_stats (plda_base.py:360-367) and of ZCA whitening (score/whiten/train_ZCA_Whitening.py:46-47). */
 int asv_scatter_f64(const float *x, int ldx, int n_rows, int dim, double *sum_out, double *xtx_out, void *stream);
 
+/* The same plus sum_k n_k mu_k mu_k^T over the class means (order / class_offsets as in asv_plda_train, any class order): the
+ * CovarianceStats of Kaldi's ivector-compute-lda, the LDA stage of the scoring chain (score/process.sh:218-229). */
+int asv_class_scatter_f64(const float *x, int ldx, int n_rows, int dim, const int *order, const long long *class_offsets, int n_classes,
+                          double *sum_out, double *xtx_out, double *class_scatter_out, void *stream);
+
 /* ---- acoustic front-end -------------------------------------------
  * Kaldi-compatible log-mel filterbank features of packed waveforms on the device: what
  * torchaudio.compliance.kaldi.fbank computes in pytorch/libs/egs/kaldi_features.py:72-137 and kaldifeat::Fbank in

@@ -263,3 +263,33 @@ def test_unsupervised_plda_adaptation_and_zca_match_the_reference():
     y = scoring.linear_transform(adapt, whiten, mean).cpu().numpy()
     assert np.abs(y - (a64 - mean).dot(whiten.T)).max() < 1e-4
     assert np.abs(np.cov(y.T) - np.eye(len(mean))).max() < 1e-3          # whitened
+
+
+def test_lda_training_and_affine_transform():
+    """Kaldi-style LDA (ivector-compute-lda restated; parity unpinned): device class statistics == float64 numpy, the
+    transform whitens the chosen covariance mix, orders directions by between-class variance, and its offset centres the data."""
+    from libs.amd import scoring, synth
+    dim, lda_dim = 64, 20
+    x, labels = synth.synth_speaker_embeddings(200, 8, dim, seed=61, within=1.0, between=0.9)
+    x = (x * np.linspace(0.5, 2.0, dim)[None, :] + 0.7).astype(np.float32)
+    mat = scoring.train_lda(x, labels, lda_dim, total_covariance_factor=0.1)
+    assert mat.shape == (lda_dim, dim + 1)
+    x64 = x.astype(np.float64)
+    mean = x64.mean(0)
+    xc = x64 - mean
+    total = xc.T.dot(xc) / len(x)
+    mus = np.stack([xc[labels == k].mean(0) for k in range(200)])
+    between = (mus * 8).T.dot(mus) / len(x)
+    within = total - between
+    A = mat[:, :dim]
+    mix = 0.1 * total + 0.9 * within
+    assert np.abs(A.dot(mix).dot(A.T) - np.eye(lda_dim)).max() < 1e-8                   # whitened
+    bp = A.dot(between).dot(A.T)
+    assert np.abs(bp - np.diag(np.diag(bp))).max() < 1e-8 and np.all(np.diff(np.diag(bp)) <= 1e-12)   # diagonal, descending
+    # the kept directions are the strongest generalised eigen-directions
+    ev = np.sort(np.linalg.eigvals(np.linalg.solve(mix, between)).real)[::-1]
+    assert np.abs(np.diag(bp) - ev[:lda_dim]).max() < 1e-8
+    assert np.abs(mat[:, dim] + A.dot(mean)).max() < 1e-9
+    y = scoring.apply_affine(x, mat).cpu().numpy()
+    assert y.shape == (len(x), lda_dim) and np.abs(y - (x64.dot(A.T) + mat[:, dim])).max() < 1e-4
+    assert np.abs(y.mean(0)).max() < 1e-4
