@@ -171,6 +171,8 @@ struct EltwiseKernelParams {
   int act;                             // activation applied to the final sum
   const float *seg_norm; int ld_segnorm, seg_norm_mode;   // [segments][mean(C) | std(C)]: a <- (a - mean) / std first
 };
+int launch_lde_pool(const void *x, int ldx, int channels, int rows, const float *mu, const float *beta, int n_centres, float *weights,
+                    const int32_t *seg_row0, const int32_t *seg_len, int segments, float *out, int ld_out, bool bf16, hipStream_t s);
 int launch_eltwise(const EltwiseKernelParams &p, bool bf16, hipStream_t s);
 
 // weight packing (host): dense checkpoint kernel -> [cout_pad][n_taps][cin_pad] in element type

@@ -327,6 +327,85 @@ __global__ __launch_bounds__(256) void attentive_pool_kernel(const void *x, int 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Learnable dictionary encoding pooling (libs/nnet/pooling.py:130-162).
+// lde_weights_kernel: 8 frame rows per workgroup staged in LDS; thread (k = centre, s = channel slice) accumulates the
+// squared distances |x_t - mu_k|^2 of its slice for the 8 rows (one mu load feeds 8 rows), the slices are summed through
+// LDS, wave 0 turns every row's n_centres distances into softmax(-beta_k d_k) over the centres (one centre per lane).
+constexpr int kLdeRows = 8;
+template <bool BF16>
+__global__ __launch_bounds__(256) void lde_weights_kernel(const void *x, int ldx, int channels, int rows, const float *mu, const float *beta, int n_centres,
+                                                          float *weights) {
+  extern __shared__ float lde_sh[];                      // xs[kLdeRows][channels] | part[4][kLdeRows][64]
+  float *xs = lde_sh, *part = lde_sh + (size_t)kLdeRows * channels;
+  const int row0 = blockIdx.x * kLdeRows;
+  for (int i = threadIdx.x; i < kLdeRows * channels; i += 256) {
+    const int f = i / channels, c = i - f * channels;
+    xs[i] = row0 + f < rows ? load_elem<BF16>(x, (size_t)(row0 + f) * ldx + c) : 0.0f;
+  }
+  __syncthreads();
+  const int k = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  float d[kLdeRows];
+#pragma unroll
+  for (int f = 0; f < kLdeRows; ++f) d[f] = 0.0f;
+  if (k < n_centres)
+    for (int c = sl; c < channels; c += 4) {
+      const float m = mu[(size_t)c * n_centres + k];
+#pragma unroll
+      for (int f = 0; f < kLdeRows; ++f) { const float r = xs[f * channels + c] - m; d[f] = fmaf(r, r, d[f]); }
+    }
+#pragma unroll
+  for (int f = 0; f < kLdeRows; ++f) part[(sl * kLdeRows + f) * 64 + k] = d[f];
+  __syncthreads();
+  if (sl == 0) {
+    const float b = k < n_centres ? beta[k] : 0.0f;
+    for (int f = 0; f < kLdeRows; ++f) {
+      if (row0 + f >= rows) break;
+      const float dist = part[f * 64 + k] + part[(kLdeRows + f) * 64 + k] + part[(2 * kLdeRows + f) * 64 + k] + part[(3 * kLdeRows + f) * 64 + k];
+      const float l = k < n_centres ? -b * dist : -INFINITY;
+      float mx = l;
+      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+      const float e = k < n_centres ? expf(l - mx) : 0.0f;
+      float se = e;
+      for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
+      weights[(size_t)(row0 + f) * 64 + k] = e / se;
+    }
+  }
+}
+
+// lde_accumulate_kernel: one workgroup per (64 channels, segment); lane = channel, the 4 waves split the frames;
+// acc[k] += w[t][k] x[t][c] and s0[k] += w[t][k] for KMAX >= n_centres centres (zero weights beyond), summed over the
+// waves through LDS; out[c * n_centres + k] = (acc[k] - mu[c][k] s0[k]) / frames.
+template <bool BF16, int KMAX>
+__global__ __launch_bounds__(256) void lde_accumulate_kernel(const void *x, int ldx, int channels, const float *weights, const float *mu, int n_centres,
+                                                             const int32_t *seg_row0, const int32_t *seg_len, float *out, int ld_out) {
+  __shared__ float red[4][2 * KMAX][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int seg = blockIdx.y, c = blockIdx.x * 64 + lane;
+  const int row0 = seg_row0[seg], len = seg_len[seg];
+  float acc[KMAX], s0[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) { acc[k] = 0.0f; s0[k] = 0.0f; }
+  for (int r = wave; r < len; r += 4) {
+    const float v = c < channels ? load_elem<BF16>(x, (size_t)(row0 + r) * ldx + c) : 0.0f;
+    const float *w = weights + (size_t)(row0 + r) * 64;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) { const float wk = w[k]; acc[k] = fmaf(wk, v, acc[k]); s0[k] += wk; }
+  }
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) { red[wave][k][lane] = acc[k]; red[wave][KMAX + k][lane] = s0[k]; }
+  __syncthreads();
+  if (wave == 0 && c < channels) {
+    const float inv = 1.0f / (float)len;
+    for (int k = 0; k < n_centres; ++k) {
+      const float a = red[0][k][lane] + red[1][k][lane] + red[2][k][lane] + red[3][k][lane];
+      const float z = red[0][KMAX + k][lane] + red[1][KMAX + k][lane] + red[2][KMAX + k][lane] + red[3][KMAX + k][lane];
+      out[(size_t)seg * ld_out + (size_t)c * n_centres + k] = (a - mu[(size_t)c * n_centres + k] * z) * inv;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // elementwise: out = (a [*scale+shift]) (* seg_scale[seg]) (+ b) (+ c); gap rows -> 0
 template <bool BF16>
@@ -555,6 +634,25 @@ int launch_attentive_pool(const void *x, int ldx, const void *logits, int ldl, i
   const dim3 grid((channels + 63) / 64, segments), block(256);
   if (bf16) hipLaunchKernelGGL(attentive_pool_kernel<true>, grid, block, 0, s, x, ldx, logits, ldl, channels, seg_row0, seg_len, eps, out, ld_out, group, softplus2, prior_logit, prior_value);
   else hipLaunchKernelGGL(attentive_pool_kernel<false>, grid, block, 0, s, x, ldx, logits, ldl, channels, seg_row0, seg_len, eps, out, ld_out, group, softplus2, prior_logit, prior_value);
+  ASV_HIP_CHECK(hipGetLastError());
+  return ASV_OK;
+}
+
+
+int launch_lde_pool(const void *x, int ldx, int channels, int rows, const float *mu, const float *beta, int n_centres, float *weights,
+                    const int32_t *seg_row0, const int32_t *seg_len, int segments, float *out, int ld_out, bool bf16, hipStream_t s) {
+  if (segments <= 0 || rows <= 0) return ASV_OK;
+  const size_t lds = ((size_t)kLdeRows * channels + 4 * kLdeRows * 64) * sizeof(float);
+  ASV_REQUIRE(lds <= 64 * 1024, "lde pooling: %d channels need %zu bytes of LDS per workgroup (limit 64 KiB)", channels, lds);
+  const dim3 g1((rows + kLdeRows - 1) / kLdeRows), g2((channels + 63) / 64, segments);
+  if (bf16) hipLaunchKernelGGL(lde_weights_kernel<true>, g1, dim3(256), lds, s, x, ldx, channels, rows, mu, beta, n_centres, weights);
+  else hipLaunchKernelGGL(lde_weights_kernel<false>, g1, dim3(256), lds, s, x, ldx, channels, rows, mu, beta, n_centres, weights);
+#define ASV_LDE_ACC(B, K) hipLaunchKernelGGL((lde_accumulate_kernel<B, K>), g2, dim3(256), 0, s, x, ldx, channels, weights, mu, n_centres, seg_row0, seg_len, out, ld_out)
+  if (n_centres <= 8) { if (bf16) ASV_LDE_ACC(true, 8); else ASV_LDE_ACC(false, 8); }
+  else if (n_centres <= 16) { if (bf16) ASV_LDE_ACC(true, 16); else ASV_LDE_ACC(false, 16); }
+  else if (n_centres <= 32) { if (bf16) ASV_LDE_ACC(true, 32); else ASV_LDE_ACC(false, 32); }
+  else { if (bf16) ASV_LDE_ACC(true, 64); else ASV_LDE_ACC(false, 64); }
+#undef ASV_LDE_ACC
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }

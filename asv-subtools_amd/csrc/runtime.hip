@@ -97,7 +97,7 @@ struct Domain {
   int gap() const { return kind == ASV_DOMAIN_FRAMES ? kHalo : pitch + 2; }
 };
 
-enum OpKind { OP_TDNN = 0, OP_POOL = 1, OP_ATTPOOL = 2, OP_ELTWISE = 3, OP_GRID_INPUT = 4, OP_IM2COL = 5 };
+enum OpKind { OP_TDNN = 0, OP_POOL = 1, OP_ATTPOOL = 2, OP_ELTWISE = 3, OP_GRID_INPUT = 4, OP_IM2COL = 5, OP_LDE = 6 };
 
 struct Op {
   OpKind kind;
@@ -108,6 +108,7 @@ struct Op {
   asv_eltwise_desc_t elt;
   asv_grid_input_desc_t gin;
   asv_im2col_desc_t i2c;
+  asv_lde_desc_t lde;            // mu / beta live in `scale` / `shift` on the device
   // device parameters
   void *w = nullptr;
   void *wfrag = nullptr;         // fragment-ordered copy for the variant-3 kernel (bf16 frame layers); pooled layers: bf16 hi halves
@@ -149,6 +150,7 @@ struct asv_net {
   DevMem rowmeta_dev;                    // row_seg / row_valid for both domains
   DevMem splitk_dev;                     // split-K partial accumulators
   DevMem poolpart_dev;                   // fused-pooling partial moments
+  DevMem lde_dev;                        // LDE pooling: per-row centre weights [rows][64]
   void *zero_page = nullptr;             // 256 zero bytes (masked direct-to-LDS loads)
   void *meta_host = nullptr;             // pinned staging
   size_t meta_host_cap = 0;
@@ -377,6 +379,7 @@ void asv_net_destroy(asv_net_t *net) {
   if (net->rowmeta_dev.ptr) (void)hipFree(net->rowmeta_dev.ptr);
   if (net->splitk_dev.ptr) (void)hipFree(net->splitk_dev.ptr);
   if (net->poolpart_dev.ptr) (void)hipFree(net->poolpart_dev.ptr);
+  if (net->lde_dev.ptr) (void)hipFree(net->lde_dev.ptr);
   if (net->zero_page) (void)hipFree(net->zero_page);
   if (net->plan_cache && net->plan_cache_free) net->plan_cache_free(net->plan_cache);
   if (net->meta_host) (void)hipHostFree(net->meta_host);
@@ -565,6 +568,25 @@ int asv_net_add_attentive_pool(asv_net_t *net, const asv_attpool_desc_t *d) {
   return ASV_OK;
 }
 
+int asv_net_add_lde_pool(asv_net_t *net, const asv_lde_desc_t *d) {
+  ASV_REQUIRE(net && d && !net->finalized, "asv_net_add_lde_pool: net is null or finalized");
+  ASV_REQUIRE(d->struct_size == sizeof(asv_lde_desc_t), "asv_net_add_lde_pool: struct_size mismatch");
+  ASV_REQUIRE(d->mu && d->beta && d->n_centres >= 1 && d->n_centres <= 64, "lde pool: mu / beta are required and 1 <= n_centres <= 64 (got %d)", d->n_centres);
+  int rc;
+  if ((rc = check_view(net, d->x_buf, d->x_ch_off, d->channels, "lde pool x"))) return rc;
+  ASV_REQUIRE(d->out_buf > 0 && d->out_buf < (int)net->bufs.size(), "lde pool: output buffer id %d", d->out_buf);
+  ASV_REQUIRE(d->out_ch_off >= 0 && d->out_ch_off + d->channels * d->n_centres <= net->bufs[d->out_buf].channels, "lde pool: output view exceeds buffer");
+  ASV_REQUIRE(net->bufs[d->x_buf].domain == ASV_DOMAIN_FRAMES && net->is_utts(net->bufs[d->out_buf].domain), "lde pool: frames -> utts");
+  Op op; op.kind = OP_LDE; op.lde = *d;
+  ASV_HIP_CHECK(hipSetDevice(net->device));
+  const int n = d->channels * d->n_centres;
+  if ((rc = upload_padded(net, d->mu, n, round_up(n, kChanAlign), 0.0f, &op.scale))) return rc;
+  if ((rc = upload_padded(net, d->beta, d->n_centres, 64, 0.0f, &op.shift))) return rc;
+  op.lde.mu = nullptr; op.lde.beta = nullptr;
+  net->ops.push_back(op);
+  return ASV_OK;
+}
+
 int asv_net_add_eltwise(asv_net_t *net, const asv_eltwise_desc_t *d) {
   ASV_REQUIRE(net && d && !net->finalized, "asv_net_add_eltwise: net is null or finalized");
   ASV_REQUIRE(d->struct_size == sizeof(asv_eltwise_desc_t), "asv_net_add_eltwise: struct_size mismatch");
@@ -651,7 +673,7 @@ int asv_net_finalize(asv_net_t *net, int out_buf, int embed_dim) {
         const int reads[] = {o.kind == OP_TDNN ? o.tdnn.in_buf : -1, o.kind == OP_TDNN ? o.tdnn.in2_buf : -1, o.kind == OP_TDNN ? o.tdnn.res_buf : -1,
                              o.kind == OP_POOL ? o.pool.in_buf : -1, o.kind == OP_ATTPOOL ? o.att.x_buf : -1, o.kind == OP_ATTPOOL ? o.att.logit_buf : -1,
                              o.kind == OP_ELTWISE ? o.elt.a_buf : -1, o.kind == OP_ELTWISE ? o.elt.b_buf : -1, o.kind == OP_ELTWISE ? o.elt.c_buf : -1,
-                             o.kind == OP_IM2COL ? o.i2c.in_buf : -1};
+                             o.kind == OP_IM2COL ? o.i2c.in_buf : -1, o.kind == OP_LDE ? o.lde.x_buf : -1};
         for (int rbuf : reads) other_reader |= (rbuf == d.out_buf);
       }
       if (other_reader || d.out_buf == out_buf) continue;
@@ -707,6 +729,10 @@ int asv_net_describe(const asv_net_t *net, char *buf, size_t cap) {
       case OP_ATTPOOL:
         snprintf(line, sizeof(line), "  op %zu: attentive_pool x=%d logits=%d channels=%d -> %d[%d] eps=%g\n", i, op.att.x_buf, op.att.logit_buf, op.att.channels,
                  op.att.out_buf, op.att.out_ch_off, op.att.eps);
+        break;
+      case OP_LDE:
+        snprintf(line, sizeof(line), "  op %zu: lde_pool x=%d channels=%d centres=%d -> %d[%d]\n", i, op.lde.x_buf, op.lde.channels, op.lde.n_centres, op.lde.out_buf,
+                 op.lde.out_ch_off);
         break;
       case OP_GRID_INPUT:
         snprintf(line, sizeof(line), "  op %zu: grid_input %d -> %d\n", i, op.gin.in_buf, op.gin.out_buf);
@@ -1012,6 +1038,18 @@ int run_ops(RunCtx &c, size_t n_ops) {
         rc = launch_attentive_pool(view(c, d.x_buf, d.x_ch_off), net->bufs[d.x_buf].ld, view(c, d.logit_buf, d.logit_ch_off), net->bufs[d.logit_buf].ld,
                                    d.channels, dr.seg_row0, dr.seg_len, bp.segments, d.eps,
                                    reinterpret_cast<float *>(net->arena[d.out_buf].ptr) + d.out_ch_off, net->bufs[d.out_buf].ld, net->frames_bf16(), group, d.logit_softplus2 != 0, op.scale, op.shift, c.s);
+        if (rc) return rc;
+        if ((rc = prof.end())) return rc;
+        break;
+      }
+      case OP_LDE: {
+        const auto &d = op.lde;
+        const DomainRun &dr = c.dom[ASV_DOMAIN_FRAMES];
+        if ((rc = ensure(net->lde_dev, (size_t)dr.rows_pad * 64 * 4, c.s, false))) return rc;
+        if ((rc = prof.begin(K_ATT, 0, (int)i))) return rc;
+        rc = launch_lde_pool(view(c, d.x_buf, d.x_ch_off), net->bufs[d.x_buf].ld, d.channels, dr.rows_pad, op.scale, op.shift, d.n_centres,
+                             reinterpret_cast<float *>(net->lde_dev.ptr), dr.seg_row0, dr.seg_len, bp.segments,
+                             reinterpret_cast<float *>(net->arena[d.out_buf].ptr) + d.out_ch_off, net->bufs[d.out_buf].ld, net->frames_bf16(), c.s);
         if (rc) return rc;
         if ((rc = prof.end())) return rc;
         break;

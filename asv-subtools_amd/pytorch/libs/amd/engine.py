@@ -130,6 +130,15 @@ class Engine(object):
                     d.prior_logit = op.prior_logit.ctypes.data_as(capi.c_float_p)
                     d.prior_value = op.prior_value.ctypes.data_as(capi.c_float_p)
                 capi.check(L.asv_net_add_attentive_pool(self._net, C.byref(d)), "asv_net_add_attentive_pool")
+            elif op.kind == "lde":
+                d = capi.LdeDesc()
+                d.struct_size = C.sizeof(capi.LdeDesc)
+                d.x_buf, d.x_ch_off = bv(op.x)
+                d.channels, d.n_centres = op.x.channels, len(op.beta)
+                d.out_buf, d.out_ch_off = bv(op.out)
+                d.mu = op.mu.ctypes.data_as(capi.c_float_p)
+                d.beta = op.beta.ctypes.data_as(capi.c_float_p)
+                capi.check(L.asv_net_add_lde_pool(self._net, C.byref(d)), "asv_net_add_lde_pool")
             elif op.kind == "eltwise":
                 d = capi.EltwiseDesc()
                 d.struct_size = C.sizeof(capi.EltwiseDesc)

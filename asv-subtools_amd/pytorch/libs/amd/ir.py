@@ -53,6 +53,8 @@ class Op(object):
             names = ("inp",)
         elif self.kind == "attpool":
             names = ("x", "logits")
+        elif self.kind == "lde":
+            names = ("x",)
         elif self.kind == "eltwise":
             names = ("a", "b", "c", "seg_scale", "seg_norm")
         elif self.kind in ("grid_input", "im2col"):
@@ -63,7 +65,7 @@ class Op(object):
 
     def input_names(self):
         return {"tdnn": ("inp", "inp2", "seg_bias", "seg_scale", "res"), "pool": ("inp",),
-                "attpool": ("x", "logits"), "eltwise": ("a", "b", "c", "seg_scale", "seg_norm"), "cat": (), "grid_input": ("inp",),
+                "attpool": ("x", "logits"), "lde": ("x",), "eltwise": ("a", "b", "c", "seg_scale", "seg_norm"), "cat": (), "grid_input": ("inp",),
                 "im2col": ("inp",)}[self.kind]
 
 
@@ -164,6 +166,17 @@ class Graph(object):
         f32 = lambda v: None if v is None else np.ascontiguousarray(v, dtype=np.float32).reshape(-1)
         self.ops.append(Op("attpool", out, x=x, logits=logits, eps=float(eps), shared=bool(shared), group=group, softplus2=bool(softplus2),
                            prior_logit=f32(prior_logit), prior_value=f32(prior_value)))
+        return out
+
+    def lde(self, x, mu, beta):
+        """Learnable dictionary encoding pooling: mu [channels, centres], beta [centres] -> [channels * centres] per utterance
+        (column c * centres + k)."""
+        mu = np.ascontiguousarray(mu, dtype=np.float32)
+        beta = np.ascontiguousarray(beta, dtype=np.float32).reshape(-1)
+        if mu.shape != (x.channels, beta.shape[0]) or not 1 <= beta.shape[0] <= 64:
+            raise TraceError("lde: mu %s / beta %s do not fit %d channels (at most 64 centres)" % (mu.shape, beta.shape, x.channels))
+        out = self.full_view(self.new_tensor(DOMAIN_UTTS, x.channels * beta.shape[0]))
+        self.ops.append(Op("lde", out, x=x, mu=mu, beta=beta))
         return out
 
     def eltwise(self, a, b=None, c=None, seg_scale=None, scale=None, shift=None, act=None, seg_norm=None, seg_norm_mode=0):
@@ -338,6 +351,8 @@ class Graph(object):
                 ins, extra = repr(op.inp), "taps=%d stride=%d" % (len(op.taps), op.stride)
             elif op.kind == "attpool":
                 ins, extra = "x=%r logits=%r" % (op.x, op.logits), "eps=%g" % op.eps
+            elif op.kind == "lde":
+                ins, extra = "x=%r" % (op.x,), "centres=%d" % len(op.beta)
             elif op.kind == "eltwise":
                 ins = " ".join("%s=%r" % (n, getattr(op, n)) for n in ("a", "b", "c", "seg_scale") if getattr(op, n) is not None)
                 extra = "affine=%s act=%s" % (op.scale is not None, op.act)

@@ -34,6 +34,8 @@ def synth_tensor(key, shape, seed=0):
         return r.uniform(1.0, 5.0, shape).astype(np.float32)
     if leaf in ("prior_mean", "prior_logprec"):        # xi-vector prior (pooling.py:178-179): zeros at init, make them matter
         return (0.5 * r.standard_normal(shape)).astype(np.float32)
+    if leaf == "s" and len(shape) == 1:               # LDE scale (pooling.py:143): small, so that the soft assignment stays soft
+        return r.uniform(0.02, 0.06, shape).astype(np.float32)
     if leaf == "running_mean":
         return (0.5 * r.standard_normal(shape)).astype(np.float32)
     if leaf == "running_var":

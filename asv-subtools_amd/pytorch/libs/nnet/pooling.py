@@ -271,6 +271,27 @@ class xivec_stdinit_softplus2_prec_pooling(torch.nn.Module):
         return self.output_dim
 
 
+class LDEPooling(torch.nn.Module):
+    """Learnable dictionary encoding (reference pooling.py:130-162): soft assignment of every frame to c_num centres by its
+    scaled squared distance, output = mean residual to each centre, [input_dim * c_num] with column c * c_num + k."""
+
+    def __init__(self, input_dim, c_num=64, eps=1.0e-10):
+        super(LDEPooling, self).__init__()
+        self.input_dim, self.output_dim, self.eps = input_dim, input_dim * c_num, eps
+        self.mu = torch.nn.Parameter(torch.randn(input_dim, c_num))
+        self.s = torch.nn.Parameter(torch.ones(c_num))
+        self.softmax_for_w = torch.nn.Softmax(dim=3)
+
+    def forward(self, inputs):
+        _attentive_stats(inputs, self.input_dim, "LDEPooling")
+        s = self.s.detach().cpu().numpy().astype("float32")
+        out = inputs.graph.lde(inputs.view, self.mu.detach().cpu().numpy(), s * s + self.eps)
+        return _ir.Sym(inputs.graph, out, 3)
+
+    def get_output_dim(self):
+        return self.output_dim
+
+
 def _not_on_hot_path(name, where):
     class _Unsupported(torch.nn.Module):
         def __init__(self, *args, **kwargs):
@@ -281,5 +302,4 @@ def _not_on_hot_path(name, where):
 
 
 FreeStatisticsPooling = _not_on_hot_path("FreeStatisticsPooling", "pooling.py:78")
-LDEPooling = _not_on_hot_path("LDEPooling", "pooling.py:112")
 MQMHASP = _not_on_hot_path("MQMHASP", "pooling.py:590-701")

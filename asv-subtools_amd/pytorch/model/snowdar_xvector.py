@@ -42,9 +42,6 @@ class Xvector(TopVirtualNnet):
         layer_params = utils.assign_params_dict(_TDNN_DEFAULTS, tdnn_layer_params)
         last_params = utils.assign_params_dict(layer_params, tdnn7_params)
         pool_params = utils.assign_params_dict(_POOLING_DEFAULTS, pooling_params)
-        if pooling == "lde":
-            raise NotImplementedError("pooling='lde': statistics, attentive, multi-head, multi-resolution and xi-vector pooling are built on the "
-                                      "MI355X path (SURVEY.md 8(f) rank 3)")
         if training:
             raise NotImplementedError("this blueprint is the extraction graph only (training=False)")
         self.extracted_embedding = extracted_embedding
@@ -62,7 +59,9 @@ class Xvector(TopVirtualNnet):
                 setattr(self, name, SEBlock(dim, ratio=se_ratio))
         self.tdnn5 = ReluBatchNormTdnnLayer(512, pool_params["num_nodes"], **layer_params)
         head_params = {k: v for k, v in pool_params.items() if k not in ("num_nodes", "stddev")}       # reference :116-130
-        if pooling == "attentive":
+        if pooling == "lde":
+            self.stats = LDEPooling(pool_params["num_nodes"], c_num=pool_params["num_head"])
+        elif pooling == "attentive":
             self.stats = AttentiveStatisticsPooling(pool_params["num_nodes"], affine_layers=pool_params["affine_layers"], hidden_size=pool_params["hidden_size"],
                                                     context=pool_params["context"], stddev=pool_params["stddev"])
         elif pooling == "multi-head":

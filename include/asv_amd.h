@@ -151,6 +151,18 @@ typedef struct asv_attpool_desc {
 } asv_attpool_desc_t;
 int asv_net_add_attentive_pool(asv_net_t *net, const asv_attpool_desc_t *d);
 
+/* Learnable dictionary encoding pooling (libs/nnet/pooling.py:130-162, LDEPooling): with r = x_t - mu_k,
+ * w[t][k] = softmax over the centres k of -beta_k |r|^2, out[c * n_centres + k] = mean over the frames of w[t][k] r[c].
+ * mu: host [channels][n_centres]; beta: host [n_centres] (= s^2 + eps); n_centres <= 64; the output view takes
+ * channels * n_centres columns of an utterance-domain buffer. */
+typedef struct asv_lde_desc {
+  uint32_t struct_size;
+  int32_t x_buf, x_ch_off, channels, n_centres;
+  int32_t out_buf, out_ch_off;
+  const float *mu, *beta;
+} asv_lde_desc_t;
+int asv_net_add_lde_pool(asv_net_t *net, const asv_lde_desc_t *d);
+
 /* Elementwise: out = a (* seg_scale[segment]) (+ b) (+ c); any domain; views as above. */
 typedef struct asv_eltwise_desc {
   uint32_t struct_size;

@@ -117,6 +117,13 @@ CASES = {
                                      creation="Xvector(40,10,training=False,pooling='multi-resolution',pooling_params={'num_head':3,'temperature':True,"
                                               "'fixed':False,'share':False,'affine_layers':1,'num_nodes':300},extracted_embedding='near')",
                                      dim=40, utts=[(160, 6930), (12, 6931)], wseed=21),
+    # learnable dictionary encoding pooling (pooling.py:130-162): 8 and 40 centres
+    "snowdar_lde": dict(blueprint="snowdar_xvector.py",
+                        creation="Xvector(40,10,training=False,pooling='lde',pooling_params={'num_head':8,'num_nodes':400})",
+                        dim=40, utts=[(200, 6960), (23, 6961), (1, 6962)], wseed=24),
+    "snowdar_lde40": dict(blueprint="snowdar_xvector.py",
+                          creation="Xvector(40,10,training=False,pooling='lde',pooling_params={'num_head':40,'num_nodes':120},extracted_embedding='near')",
+                          dim=40, utts=[(90, 6970), (11, 6971)], wseed=25),
     # xi-vector posterior pooling (pooling.py:165-218): posterior mean only / mean + std
     "snowdar_xi_mean": dict(blueprint="snowdar_xvector.py",
                             creation="Xvector(40,10,training=False,pooling='xi-postmean-softplus2',pooling_params={'hidden_size':64,'num_nodes':600})",

@@ -122,6 +122,13 @@ def run_graph(graph, feats, dtype=np.float32):
             mean = (a * x).sum(axis=0, dtype=dtype)
             resid = (a * x * x).sum(axis=0, dtype=dtype) - mean * mean
             put(op.out, np.concatenate([mean, np.sqrt(np.maximum(resid, dtype(op.eps)))])[None, :])
+        elif op.kind == "lde":
+            x = get(op.x)                                          # [T, C]
+            r = x[:, :, None] - op.mu.astype(dtype)[None, :, :]    # [T, C, K]
+            l = -op.beta.astype(dtype)[None, :] * (r * r).sum(axis=1, dtype=dtype)
+            w = np.exp(l - l.max(axis=1, keepdims=True))
+            w = w / w.sum(axis=1, keepdims=True, dtype=dtype)
+            put(op.out, (w[:, None, :] * r).mean(axis=0, dtype=dtype).reshape(1, -1))
         elif op.kind == "eltwise":
             z = get(op.a)
             if op.scale is not None:

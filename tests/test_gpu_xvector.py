@@ -192,7 +192,7 @@ def test_empty_batch_and_zero_frame_utterance():
 
 @pytest.mark.parametrize("name", ["snowdar_default", "snowdar_full_near", "snowdar_no_tdnn6", "snowdar_attentive", "snowdar_attentive_mean",
                                   "snowdar_multihead", "snowdar_multihead_unshared", "snowdar_multires", "snowdar_multires_learned",
-                                  "snowdar_xi_mean", "snowdar_xi_dist",
+                                  "snowdar_xi_mean", "snowdar_xi_dist", "snowdar_lde", "snowdar_lde40",
                                   "factored_far", "factored_near"])
 def test_snowdar_and_factored_xvector_vs_reference_golden(name):
     """Composite and factorised x-vector blueprints on the device: f32 within 1e-4 of the reference; bf16 close."""

@@ -131,6 +131,18 @@ def test_xi_vector_pooling_reproduces_reference_on_cpu(name):
         assert rel_err(ir_interp.extract(graph, x), ref) < 1e-4, name
 
 
+@pytest.mark.parametrize("name,centres", [("snowdar_lde", 8), ("snowdar_lde40", 40)])
+def test_lde_pooling_reproduces_reference_on_cpu(name, centres):
+    """Learnable dictionary encoding pooling (pooling.py:130-162) against the reference's own outputs."""
+    from libs.amd import ir
+    g, sd, model = helpers.golden_model(name)
+    graph = ir.trace(model, type(model).extract_embedding.__wrapped_body__, int(g["dim"]))
+    lde = [op for op in graph.ops if op.kind == "lde"]
+    assert len(lde) == 1 and len(lde[0].beta) == centres and lde[0].out.channels == lde[0].x.channels * centres
+    for x, ref in zip(helpers.golden_feats(g), g["embeddings"]):
+        assert rel_err(ir_interp.extract(graph, x), ref) < 1e-4, name
+
+
 def test_factored_xvector_program_reproduces_reference_on_cpu():
     """the TDNN-F blueprint (FTdnnBlock = factor + affine + ReLU + BN + scaled bypass, dense skips by
     concatenation) against the reference's own model/factored_xvector.py outputs."""
