@@ -107,3 +107,8 @@ def test_oracle_matches_the_compiled_reference_on_the_reference_test_wavs():
         got = fbank_oracle.fbank(x, **kw)
         assert got.shape == ref.shape and len(ref) > 100
         assert np.abs(got - ref).max() < 2e-3 and np.abs(got - ref).mean() < 2e-5, (path, np.abs(got - ref).max())
+        lib.kaldifeat_ref_mfcc.restype = C.c_int
+        mkw = dict(num_ceps=20, num_bins=30, sample_rate=float(sr))
+        ref = G.reference_mfcc(lib, x, **mkw)
+        got = fbank_oracle.mfcc(x, **mkw)
+        assert got.shape == ref.shape and np.abs(got - ref).max() < 2e-3 and np.abs(got - ref).mean() < 5e-5, path
