@@ -68,8 +68,48 @@ def _split_specifier(name):
     return prefix, name, offset
 
 
+class _PipeWriter(io.RawIOBase):
+    """Write end of a `| cmd` pipe.  close() closes the child's stdin, WAITS for the child and raises
+    SubprocessFailed on a non-zero exit status: with the standard wspecifier `ark:| copy-vector ark:- ark,scp:...`
+    (pipeline/extract_xvectors_for_pytorch.sh:120) the ark/scp pair is complete on disk when close() returns, and a
+    failing child is an exception in the caller instead of a lost status."""
+
+    mode = "wb"
+
+    def __init__(self, proc, cmd):
+        io.RawIOBase.__init__(self)
+        self._proc, self._cmd, self._stream = proc, cmd, proc.stdin
+
+    def write(self, data):
+        return self._stream.write(data)
+
+    def flush(self):
+        if not self._stream.closed:
+            self._stream.flush()
+
+    def fileno(self):
+        return self._stream.fileno()
+
+    def writable(self):
+        return True
+
+    def close(self):
+        if self.closed:
+            return
+        try:
+            io.RawIOBase.close(self)                  # flushes, marks closed
+            self._stream.close()
+        finally:
+            ret = self._proc.wait()
+        if ret != 0:
+            raise SubprocessFailed("cmd %s returned %d !" % (self._cmd, ret))
+
+
 def popen(cmd, mode="rb"):
-    """Shell pipe as a file object; a watcher thread raises SubprocessFailed on a non-zero exit."""
+    """Shell pipe as a file object.  As in the reference (kaldi_io.py:76-113) a NON-daemon watcher thread waits for
+    the child, so the interpreter does not exit (and run.pl does not return) while e.g. copy-vector is still writing,
+    and a non-zero exit raises SubprocessFailed in that thread; the write end additionally waits and raises in
+    close() (see _PipeWriter)."""
     if not isinstance(cmd, str):
         raise TypeError("invalid cmd type (%s, expected string)" % type(cmd))
     if mode not in ("r", "w", "rb", "wb"):
@@ -81,12 +121,14 @@ def popen(cmd, mode="rb"):
 
     def _watch():
         ret = proc.wait()
-        if ret > 0:
+        if ret > 0 and reading:                       # the write end reports through close()
             raise SubprocessFailed("cmd %s returned %d !" % (cmd, ret))
 
-    threading.Thread(target=_watch, daemon=True).start()
-    stream = proc.stdout if reading else proc.stdin
-    return io.TextIOWrapper(stream) if "b" not in mode else stream
+    threading.Thread(target=_watch, daemon=False).start()
+    if reading:
+        return io.TextIOWrapper(proc.stdout) if "b" not in mode else proc.stdout
+    w = _PipeWriter(proc, cmd)
+    return io.TextIOWrapper(w) if "b" not in mode else w
 
 
 def open_or_fd(file, mode="rb"):
@@ -455,6 +497,8 @@ class PackedArkReader(object):
         h = self._next_header()
         if h is None:
             return None
+        if isinstance(h[3], np.ndarray):                      # already decoded by an earlier peek
+            return h[2]
         if h[3] == "generic":                                 # decode it now, keep the matrix for read_group
             m = np.ascontiguousarray(read_mat(self), dtype=np.float32)
             self._pending = (h[0], m.shape[0], m.shape[1], m)
@@ -491,7 +535,9 @@ class PackedArkReader(object):
             if h is None:
                 break
             key, rows, cols, kind = h
-            if kind == "generic":
+            # `kind` is a tag string, or the decoded matrix itself once peek_dim() / an earlier call has decoded a
+            # text or compressed entry that did not fit its batch (ndarray == str is an array on numpy >= 2)
+            if isinstance(kind, str) and kind == "generic":
                 m = np.ascontiguousarray(read_mat(self), dtype=np.float32)
                 self._pending = h = (key, m.shape[0], m.shape[1], m)
                 key, rows, cols, kind = h

@@ -207,3 +207,111 @@ def test_packed_ark_reader_and_batch_vector_writer():
     for i, k in enumerate(["a", "bb", "c", "d"]):
         K.write_vec_flt(ref, v[i], key=k)
     assert blob == ref.getvalue()
+
+
+def _cm_entry(key, mat_u8, pct, gmin, grange):
+    """One 'CM ' ark entry from explicit quantiser tables (what Kaldi's copy-feats --compress=true stores)."""
+    cols, rows = mat_u8.shape
+    return (key + " ").encode() + b"\0BCM " + struct.pack("<ffii", gmin, grange, rows, cols) + pct.astype(np.uint16).tobytes() + mat_u8.astype(np.uint8).tobytes()
+
+
+def test_packed_ark_reader_generic_entries_after_peek_and_deferred():
+    """compressed ('CM ', Kaldi's default for stored features) and text entries go through the generic
+    decoder; peek_dim() decodes the first one early and an entry that does not fit the batch is deferred to the next
+    read_group() - both leave a decoded ndarray in the pending slot, which must not be compared with a string."""
+    from libs.support import kaldi_io as K
+    rng = np.random.RandomState(5)
+    cols = 6
+    pct = np.sort(rng.randint(0, 65536, size=(cols, 4)), axis=1)
+    q = [rng.randint(0, 256, size=(cols, rows)) for rows in (40, 30, 50, 3)]
+    blob = b"".join(_cm_entry("c%d" % i, m, pct, -3.0, 9.0) for i, m in enumerate(q))
+    blob += b"t0  [\n  " + b"\n  ".join(b" ".join(b"%g" % v for v in row) for row in np.arange(24).reshape(4, 6)) + b" ]\n"
+    want = [K.read_mat(io.BytesIO(_cm_entry("", m, pct, -3.0, 9.0)[1:])) for m in q] + [np.arange(24, dtype=np.float32).reshape(4, 6)]
+    for block in (16, 1 << 13):
+        rd = K.PackedArkReader(io.BytesIO(blob), block=block)
+        assert rd.peek_dim() == cols and rd.peek_dim() == cols          # peeking twice is harmless
+        buf, got = np.empty((64, cols), np.float32), []
+        while True:
+            keys, offs, n = rd.read_group(buf)                          # 40 + 30 > 64: 'c1' is decoded, then deferred
+            if not keys:
+                break
+            got.extend((k, buf[offs[j]:offs[j + 1]].copy()) for j, k in enumerate(keys))
+        assert [k for k, _ in got] == ["c0", "c1", "c2", "c3", "t0"]
+        for (k, g), w in zip(got, want):
+            assert g.shape == w.shape and np.array_equal(g, w), k
+    # a text ark whose first entry is peeked, with a buffer smaller than that entry
+    rd = K.PackedArkReader(io.BytesIO(blob[blob.index(b"t0 "):]))
+    assert rd.peek_dim() == cols
+    keys, offs, big = rd.read_group(np.empty((2, cols), np.float32))
+    assert keys == ["t0"] and isinstance(big, np.ndarray) and np.array_equal(big, want[-1])
+
+
+def test_pipe_writer_waits_for_the_child_and_reports_its_status(tmp_path):
+    """`ark:| copy-vector ark:- ark,scp:...` - close() returns only when the child has finished writing, and a
+    failing child raises in the caller (the reference waits in a non-daemon thread, kaldi_io.py:76-113)."""
+    from libs.support import kaldi_io as K
+    out = tmp_path / "slow.ark"
+    w = K.open_or_fd("ark:| sleep 0.4; cat > %s" % out, "wb")
+    K.write_vec_flt(w, np.arange(3, dtype=np.float32), key="u")
+    w.close()
+    assert out.exists() and out.stat().st_size == 2 + 6 + 4 + 12        # complete the moment close() returns, no polling
+    w.close()                                                            # idempotent
+    bad = K.open_or_fd("ark:| cat > /dev/null; exit 7", "wb")
+    K.write_vec_flt(bad, np.arange(3, dtype=np.float32), key="u")
+    with pytest.raises(K.SubprocessFailed):
+        bad.close()
+
+
+REF_KALDI_IO = "/root/reference/pytorch/libs/support/kaldi_io.py"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_KALDI_IO), reason="reference tree only exists in the build container")
+def test_wire_format_against_the_reference_kaldi_io(tmp_path):
+    """pin libs.support.kaldi_io to the reference's own vendored module (kaldi_io.py:329-608), in a
+    subprocess that imports it from /root/reference: bytes written by either side are equal, and each side reads what
+    the other wrote - float / double matrices and vectors, text matrices, and the 'CM ' decode."""
+    import subprocess
+    import sys
+    rng = np.random.RandomState(7)
+    cols = 5
+    pct = np.sort(rng.randint(0, 65536, size=(cols, 4)), axis=1)
+    cm = _cm_entry("cm", rng.randint(0, 256, size=(cols, 33)), pct, -1.5, 4.25)
+    (tmp_path / "cm.ark").write_bytes(cm)
+    (tmp_path / "txt.ark").write_bytes(b"tx  [\n  1.5 -2 3\n  4 5 6.25 ]\n")
+    np.save(tmp_path / "m32.npy", rng.randn(9, 4).astype(np.float32))
+    np.save(tmp_path / "m64.npy", rng.randn(3, 7))
+    np.save(tmp_path / "v32.npy", rng.randn(192).astype(np.float32))
+    code = r'''
+import sys, os, importlib.util, numpy as np
+sys.dont_write_bytecode = True
+spec = importlib.util.spec_from_file_location("ref_kaldi_io", %(ref)r)
+R = importlib.util.module_from_spec(spec); spec.loader.exec_module(R)
+d = %(d)r
+m32, m64, v32 = np.load(d + "/m32.npy"), np.load(d + "/m64.npy"), np.load(d + "/v32.npy")
+with open(d + "/ref_out.ark", "wb") as f:
+    R.write_mat(f, m32, key="a"); R.write_mat(f, m64, key="b"); R.write_vec_flt(f, v32, key="v")
+np.save(d + "/ref_cm.npy", dict(R.read_mat_ark(d + "/cm.ark"))["cm"])
+np.save(d + "/ref_txt.npy", dict(R.read_mat_ark(d + "/txt.ark"))["tx"])
+# the reference reads what this repo wrote
+got = {}
+with open(d + "/mine_out.ark", "rb") as f:
+    k = R.read_key(f); got[k] = R.read_mat(f)
+    k = R.read_key(f); got[k] = R.read_mat(f)
+    k = R.read_key(f); got[k] = R.read_vec_flt(f)
+assert np.array_equal(got["a"], m32) and np.array_equal(got["b"], m64) and np.array_equal(got["v"], v32)
+print("REF-OK")
+''' % dict(ref=REF_KALDI_IO, d=str(tmp_path))
+    m32, m64, v32 = np.load(tmp_path / "m32.npy"), np.load(tmp_path / "m64.npy"), np.load(tmp_path / "v32.npy")
+    with open(tmp_path / "mine_out.ark", "wb") as f:
+        kaldi_io.write_mat(f, m32, key="a"); kaldi_io.write_mat(f, m64, key="b"); kaldi_io.write_vec_flt(f, v32, key="v")
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", PYTHONPYCACHEPREFIX="/tmp/pyc_ref")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0 and "REF-OK" in out.stdout, out.stdout + out.stderr
+    assert (tmp_path / "ref_out.ark").read_bytes() == (tmp_path / "mine_out.ark").read_bytes()         # bytes equal
+    assert np.array_equal(dict(kaldi_io.read_mat_ark(str(tmp_path / "cm.ark")))["cm"], np.load(tmp_path / "ref_cm.npy"))   # 'CM ' decode equal
+    assert np.array_equal(dict(kaldi_io.read_mat_ark(str(tmp_path / "txt.ark")))["tx"], np.load(tmp_path / "ref_txt.npy"))
+    rd = kaldi_io.PackedArkReader(open(tmp_path / "cm.ark", "rb"))
+    assert rd.peek_dim() == cols
+    buf = np.empty((64, cols), np.float32)
+    keys, offs, n = rd.read_group(buf)
+    assert keys == ["cm"] and np.array_equal(buf[:n], np.load(tmp_path / "ref_cm.npy"))
