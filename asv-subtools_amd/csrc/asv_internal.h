@@ -64,12 +64,12 @@ struct TdnnKernelParams {
   const uint32_t *row_valid;  // [rows/32] bit r%32 set <=> row r holds a real frame
   // fused statistics pooling (optional): per (row tile, channel) partial sums of the valid rows,
   // segmented by utterance; see kernels_tdnn.hip
-  float *pool_partial;  // [rows/128 half-tiles][pool_slots][2 (sum u, sum u^2)][ld_partial]
+  float *pool_partial;  // [rows/128 half-tiles][pool_slots][3 (sum (u-pv), sum (u-pv)^2, pivot pv)][ld_partial]
   int pool_slots;
   const void *zero16;   // >= 16 bytes of device zeros: source of masked direct-to-LDS loads
   const void *wfrag;    // bf16 weights in MFMA-fragment order [n_frag32][tap][chunk64][k_group][lane][8] or nullptr;
                         // pooled-domain layers (kernels_utts.hip): the bf16 'hi' halves of the f32 weights, [cout_pad][cin_pad]
-  const void *wlo;      // pooled-domain layers: the bf16 'lo' halves (w - hi), same layout, or nullptr
+  const void *wlo;      // pooled-domain layers and the f32x frame kernel: the bf16 'lo' halves (w - hi), same layout as wfrag, or nullptr
   // split-K (small-M layers: the pooled domain): blockIdx.y walks `ksplit` slices of the channel
   // chunks, raw f32 accumulators go to partial[slice][rows][ld_partial]; a second kernel sums
   // the slices in order and applies the epilogue (deterministic, no atomics)
@@ -124,7 +124,10 @@ bool tdnn_big3_supported(const TdnnKernelParams &p, bool bf16, bool out_f32);
 int launch_tdnn_big3(const TdnnKernelParams &p, hipStream_t s);
 int launch_tdnn_big3_variant(const TdnnKernelParams &p, int variant, hipStream_t s);
 void pack_tdnn_weight_frags(const float *w, int out_ch, int in_ch, int tot_ctx, int left_ctx, const int *taps, int n_taps,
-                            int cout_pad, int cin_pad, uint16_t *dst);
+                            int cout_pad, int cin_pad, uint16_t *dst, uint16_t *dst_lo = nullptr);
+// f32-grade split-bf16 kernel of the f32x precision mode (kernels_tdnn_x3.hip): f32 activations, hi / lo weight fragments
+bool tdnn_x3_supported(const TdnnKernelParams &p);
+int launch_tdnn_x3(const TdnnKernelParams &p, hipStream_t s);
 size_t tdnn_weight_frag_elems(int cout_pad, int cin_pad, int n_taps);
 int launch_stats_pool(const PoolKernelParams &p, int segments, bool bf16, hipStream_t s);
 // second half of the fused pooling: adds each segment's half-tile partials in row order, adds the BN shift

@@ -209,24 +209,30 @@ __global__ __launch_bounds__(64) void pool_finish_kernel(const PoolFinishParams 
   const int seg = blockIdx.y, ch = blockIdx.x * 64 + threadIdx.x;
   if (ch >= p.channels) return;
   const int row0 = p.seg_row0[seg], len = p.seg_len[seg];
-  float s = 0.0f, q = 0.0f;
+  // merge (count, mean, M2) of the segment's half tiles in row order (Chan et al. pairwise update, float64: a handful of
+  // terms per channel); every partial holds sum (u - pv), sum (u - pv)^2 about its own pivot pv
+  double n_acc = 0.0, mean = 0.0, m2 = 0.0;
   for (int h = row0 >> 7; h <= (row0 + len - 1) >> 7; ++h) {
     int first = -1;
     for (int k = 0; k < kHalo + 1 && first < 0; ++k)
       if (h * 128 + k < p.rows) first = p.row_seg[h * 128 + k];
     const int slot = seg - first;                       // segments are consecutive in row order
-    const float *src = p.partial + ((size_t)(h * p.pool_slots + slot) * 2) * p.ld_partial + ch;
-    s += src[0];
-    q += src[p.ld_partial];
+    const float *src = p.partial + ((size_t)(h * p.pool_slots + slot) * 3) * p.ld_partial + ch;
+    const double nh = (double)(min(row0 + len, (h + 1) * 128) - max(row0, h * 128));
+    const double sh = (double)src[0], qh = (double)src[p.ld_partial], pv = (double)src[2 * p.ld_partial];
+    const double mean_h = pv + sh / nh, m2_h = fmax(qh - sh * sh / nh, 0.0);
+    const double tot = n_acc + nh, delta = mean_h - mean;
+    mean += delta * nh / tot;
+    m2 += m2_h + delta * delta * n_acc * nh / tot;
+    n_acc = tot;
   }
   const float n = (float)len;
   float counts = n;
   if (p.unbiased == 1 && len > 1) counts = (float)(len - 1);
   if (p.unbiased == 2) counts = (float)(len - 1);
-  const float mean_u = s / n;
-  p.out[(size_t)seg * p.ld_out + ch] = mean_u + (p.shift ? p.shift[ch] : 0.0f);
+  p.out[(size_t)seg * p.ld_out + ch] = (float)mean + (p.shift ? p.shift[ch] : 0.0f);
   if (p.stddev) {
-    const float var = fmaxf(q - n * mean_u * mean_u, 0.0f) / counts;
+    const float var = (float)m2 / counts;
     p.out[(size_t)seg * p.ld_out + p.channels + ch] = (p.var_mode == ASV_POOL_VAR_ADD) ? sqrtf(var + p.eps) : sqrtf(fmaxf(var, p.eps));
   }
 }

@@ -339,8 +339,8 @@ __global__ __launch_bounds__(Geom3<WM>::WAVES * 64, WM == 0 ? 3 : 2) void tdnn_g
     // fragment it writes u = max(acc + b, lo) * scale (the output minus the BN shift: >= 0, well
     // conditioned for one-pass moments) as f32 to an LDS scratch [32 frames][64 ch], then lane = channel
     // sums the 32 rows.  The row -> segment lookup is wave-uniform, so a segment boundary is a scalar
-    // branch: flush (sum u, sum u^2) of the finished segment to the partial buffer
-    //   P[half-tile of 128 rows][segment slot][stat][channel]
+    // branch: flush (sum (u - pv), sum (u - pv)^2, pivot pv) of the finished segment to the partial buffer
+    //   P[half-tile of 128 rows][segment slot][3 stats][channel]
     // and continue.  pool_finish_kernel adds the half-tiles of each segment in row order.
     constexpr int SPITCH = 68;                       // floats per scratch row: 64 + 4 keeps ds_write_b128 conflict-free
     float *scrf = reinterpret_cast<float *>(lds + wave * (32 * SPITCH * 4));
@@ -353,14 +353,19 @@ __global__ __launch_bounds__(Geom3<WM>::WAVES * 64, WM == 0 ? 3 : 2) void tdnn_g
       if (first_seg < 0 && rbase_w + k < p.rows) first_seg = p.row_seg[rbase_w + k];
     const int ch_l = n0 + wn * 64 + lane;
     const int rowseg_lo = p.row_seg[rbase_w + lane], rowseg_hi = p.row_seg[rbase_w + 64 + lane];
-    float ps = 0.0f, pq = 0.0f;
+    // One-pass moments are taken about a pivot (the segment's first value in this half tile), the way the separate
+    // pooling kernel does it: sum (u - pv) and sum (u - pv)^2 stay small for a channel that barely moves in time, where
+    // sum u^2 - (sum u)^2 / T would cancel (the reference is two-pass, pooling.py:58-66).  pool_finish_kernel merges the
+    // (count, mean, M2) of the half tiles of a segment with the pairwise update of Chan et al.
+    float ps = 0.0f, pq = 0.0f, pv = 0.0f;
     int cur_seg = -1;
     auto flush = [&]() {
       const int slot = cur_seg - first_seg;
       if (slot >= 0 && slot < p.pool_slots && ch_l < p.ld_partial) {
-        float *dst = p.pool_partial + ((size_t)(half * p.pool_slots + slot) * 2) * p.ld_partial + ch_l;
+        float *dst = p.pool_partial + ((size_t)(half * p.pool_slots + slot) * 3) * p.ld_partial + ch_l;
         dst[0] = ps;
         dst[p.ld_partial] = pq;
+        dst[2 * p.ld_partial] = pv;
       }
     };
 #pragma unroll
@@ -384,36 +389,37 @@ __global__ __launch_bounds__(Geom3<WM>::WAVES * 64, WM == 0 ? 3 : 2) void tdnn_g
       // rowseg_lo/hi hold row_seg of the wave's 128 rows (lane l: rows l and 64 + l), so the per-row
       // segment id is a v_readlane with a constant lane: no memory access in the loop.
       const int rs_vec = (i < 2) ? rowseg_lo : rowseg_hi;
-      // 84 % of the 32-frame fragments of a 200-frame batch lie inside one utterance (gap rows carry zeros and
-      // belong to nobody): those are summed branch-free; only a fragment that straddles two utterances walks
-      // its rows one by one
+      // ~80 % of the 32-frame fragments of a 200-frame batch lie inside one utterance (gap rows belong to nobody and
+      // are skipped): those are summed branch-free; a fragment with a gap row or two utterances walks its rows one by one
       const unsigned long long in_frag = 0xffffffffull << ((i & 1) * 32);
       const unsigned long long m_valid = __builtin_amdgcn_ballot_w64(rs_vec >= 0) & in_frag;
       if (m_valid == 0) continue;                                                  // gap rows only
       const int sg0 = __builtin_amdgcn_readlane(rs_vec, __builtin_ctzll(m_valid));
       const unsigned long long m_same = __builtin_amdgcn_ballot_w64(rs_vec == sg0) & in_frag;
-      if (m_same == m_valid) {
+      if (m_same == in_frag) {
         if (sg0 != cur_seg) {
           if (cur_seg >= 0) flush();
-          cur_seg = sg0; ps = 0.0f; pq = 0.0f;
+          cur_seg = sg0; ps = 0.0f; pq = 0.0f; pv = scrf[lane];
         }
 #pragma unroll
         for (int r = 0; r < 32; ++r) {
-          const float v = scrf[r * SPITCH + lane];
-          ps += v;
-          pq = fmaf(v, v, pq);
+          const float d = scrf[r * SPITCH + lane] - pv;
+          ps += d;
+          pq = fmaf(d, d, pq);
         }
       } else {
 #pragma unroll
         for (int r = 0; r < 32; ++r) {
           const int sg = __builtin_amdgcn_readlane(rs_vec, (i & 1) * 32 + r);          // wave-uniform
-          if (sg >= 0 && sg != cur_seg) {
-            if (cur_seg >= 0) flush();
-            cur_seg = sg; ps = 0.0f; pq = 0.0f;
-          }
+          if (sg < 0) continue;                                                          // gap row
           const float v = scrf[r * SPITCH + lane];
-          ps += v;
-          pq = fmaf(v, v, pq);
+          if (sg != cur_seg) {
+            if (cur_seg >= 0) flush();
+            cur_seg = sg; ps = 0.0f; pq = 0.0f; pv = v;
+          }
+          const float d = v - pv;
+          ps += d;
+          pq = fmaf(d, d, pq);
         }
       }
     }

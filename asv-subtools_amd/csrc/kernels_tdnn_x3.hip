@@ -1,0 +1,294 @@
+// f32-grade TDNN / 1x1-conv implicit GEMM on the bf16 matrix cores ("f32x" precision mode).
+//
+// Activations stay f32 in HBM (every other kernel of the f32 mode works on them unchanged).  This kernel
+// splits both operands into two bf16 halves, x = xh + xl, w = wh + wl, and accumulates
+//     wh*xh + wh*xl + wl*xh                       (the dropped wl*xl term is ~2^-16 of a product)
+// in the f32 accumulators of v_mfma_f32_32x32x16_bf16: three matrix instructions per product instead of the
+// exact-f32 v_mfma_f32_32x32x2_f32, whose rate is 1/16 of the bf16 one (MI355X_MICROARCH.md: 157 vs 2500 TFLOP/s).
+// The same split is what kernels_utts.hip does for the pooled-domain layers.  Replaces, for the wide frame
+// layers of the parity mode, F.conv1d + ReLU + eval BN of components.py:107-149, 410-431.
+//
+// Structure = kernels_tdnn_v3.hip with smaller pieces:
+//   * the f32 feature window of a 32-channel chunk (72 frames x 128 B, shared by all taps) goes through a 4-stage
+//     LDS ring by LDS-DMA (global_load_lds_dwordx4, XOR-swizzled 16-byte slots, one barrier per chunk);
+//   * a lane's 8 consecutive k values are two ds_read_b128; the hi / lo split runs on the VALU
+//     (v_cvt_pk_bf16_f32: hi; x - hi is exact in f32; v_cvt_pk_bf16_f32 again: lo) next to the MFMAs of the
+//     previous k-group - the matrix and vector pipes issue independently;
+//   * the weights are split once on the host into two fragment-ordered bf16 arrays (the layout of
+//     pack_tdnn_weight_frags) and come straight from L2 as 1 KiB wave loads;
+//   * 64 frames x 256 channels per workgroup, 4 waves (64 x 64 each = 2 x 2 accumulators), <= 168 VGPRs:
+//     three workgroups per CU.
+#include "device_utils.h"
+
+namespace asv {
+namespace {
+
+constexpr int XBN = 256;            // channels per workgroup
+constexpr int XBM = 64;             // frames per workgroup
+constexpr int XBK = 32;             // channels per chunk (128-byte f32 rows in LDS)
+constexpr int XROWB = 128;
+constexpr int XSTAGES = 4;
+constexpr int XWIN = XBM + 2 * kHalo;          // 72 window rows
+constexpr int XGROUPS = XWIN / 8;              // 9 eight-row DMA pieces
+constexpr int XPIECES = (XGROUPS + 3) / 4;     // 3 per wave
+constexpr int XSTAGE = XWIN * XROWB;           // 9216 B
+constexpr int XRING = XSTAGES * XSTAGE;        // 36864 B
+constexpr int XSPITCH = 68;                    // floats per epilogue scratch row
+static_assert(4 * 32 * XSPITCH * 4 <= XRING, "epilogue scratch must fit in the ring");
+static_assert(XBN == kBigTileN, "weight padding must match the N tile");
+
+typedef __attribute__((address_space(3))) unsigned char x3_lds_byte;
+
+__device__ __forceinline__ int xswz(int row, int slot) { return slot ^ ((row >> 1) & 7); }
+
+__device__ __forceinline__ void x3_glds16(const void *gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
+struct X3Frag { uint4 hi, lo; };     // 8 k values of one lane: bf16 halves
+
+// 8 f32 -> bf16 hi + bf16 lo (x - hi is exact: hi keeps the top 8 mantissa bits of x)
+__device__ __forceinline__ X3Frag x3_split(const uint4 a, const uint4 b) {
+  const float v[8] = {__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w),
+                      __uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w)};
+  uint32_t h[4], l[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    h[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
+    const float r0 = v[2 * k] - __uint_as_float(h[k] << 16);
+    const float r1 = v[2 * k + 1] - __uint_as_float(h[k] & 0xffff0000u);
+    l[k] = pack_bf16x2(r0, r1);
+  }
+  X3Frag f;
+  f.hi = make_uint4(h[0], h[1], h[2], h[3]);
+  f.lo = make_uint4(l[0], l[1], l[2], l[3]);
+  return f;
+}
+
+template <bool GENERIC>
+__global__ __launch_bounds__(256, 3) void tdnn_gemm_x3_kernel(const TdnnKernelParams p, int m_tiles, int n_tiles) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[XRING + 3 * 256 * 4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+
+  const int tile = xcd_swizzle(blockIdx.x, m_tiles * n_tiles);
+  const int m0 = (tile / n_tiles) * XBM;
+  const int n0 = (tile % n_tiles) * XBN;
+
+  const unsigned char *xg = reinterpret_cast<const unsigned char *>(p.x);
+  const unsigned char *zero = reinterpret_cast<const unsigned char *>(p.zero16);
+  const size_t x_pitch = (size_t)p.ldx * 4;
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(x3_lds_byte *)lds);
+  const int g_row = lane >> 3, g_slot = lane & 7;
+
+  const int nchunks = (p.cin_pad + XBK - 1) / XBK;
+  const int n_taps = p.n_taps;
+  const int nkg = ((p.cin_pad + 63) / 64) * 4;                  // 16-channel k-groups per tap in the fragment arrays
+
+  float *lds_par = reinterpret_cast<float *>(lds + XRING);
+  if (tid < 192) {
+    const int which = tid >> 6, idx = (tid & 63) * 4;
+    float4 v = (which == 1) ? make_float4(1.f, 1.f, 1.f, 1.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float *src = (which == 0) ? p.bias : (which == 1 ? p.scale : p.shift);
+    if (src != nullptr) v = *reinterpret_cast<const float4 *>(src + n0 + idx);
+    *reinterpret_cast<float4 *>(lds_par + which * 256 + idx) = v;
+  }
+
+  // feature window of chunk c -> ring stage st (see kernels_tdnn_v3.hip: clamped rows are zero gap rows)
+  size_t a_off[XPIECES];
+#pragma unroll
+  for (int i = 0; i < XPIECES; ++i) {
+    const int grp = min(wn + i * 4, XGROUPS - 1);
+    const int w = grp * 8 + g_row;
+    const int row = min(max(m0 - kHalo + w, 0), p.rows - 1);
+    a_off[i] = (size_t)row * x_pitch + (size_t)xswz(w, g_slot) * 16u;
+  }
+  auto issue_A = [&](int c, int st) {
+    const unsigned char *base = xg + (size_t)c * XROWB;
+    const bool tail = (c + 1) * XBK > p.cin_pad;
+#pragma unroll
+    for (int i = 0; i < XPIECES; ++i) {
+      const int grp = min(wn + i * 4, XGROUPS - 1);
+      const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + st * XSTAGE + grp * 1024);
+      const int w = grp * 8 + g_row;
+      const bool ok = !tail || (c * XBK + xswz(w, g_slot) * 4 < p.cin_pad);
+      x3_glds16(ok ? base + a_off[i] : zero, dst);
+    }
+  };
+
+  const size_t frag_stride = (size_t)n_taps * nkg * 1024;      // bytes per 32-channel fragment
+  const size_t wf_off0 = (size_t)((n0 + wn * 64) / 32) * frag_stride + (size_t)lane * 16;
+  const unsigned char *wh_base = reinterpret_cast<const unsigned char *>(p.wfrag) + wf_off0;
+  const unsigned char *wl_base = reinterpret_cast<const unsigned char *>(p.wlo) + wf_off0;
+
+  struct WFrags { uint4 h[2], l[2]; };
+  struct XFrags { X3Frag f[2]; };
+  // k-group index g runs over (chunk, tap, half): g = (c * n_taps + t) * 2 + kg
+  auto load_w = [&](int c, int t, int kg, WFrags &w) {
+    const size_t off = ((size_t)t * nkg + (size_t)c * 2 + kg) * 1024;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      w.h[j] = *reinterpret_cast<const uint4 *>(wh_base + j * frag_stride + off);
+      w.l[j] = *reinterpret_cast<const uint4 *>(wl_base + j * frag_stride + off);
+    }
+  };
+  auto load_x = [&](int c, int d, int kg, XFrags &x) {
+    const unsigned char *Ab = lds + (c % XSTAGES) * XSTAGE;
+    const int s0 = kg * 4 + lh * 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int w = i * 32 + lr + kHalo + d;
+      const uint4 a = *reinterpret_cast<const uint4 *>(Ab + w * XROWB + xswz(w, s0) * 16);
+      const uint4 b = *reinterpret_cast<const uint4 *>(Ab + w * XROWB + xswz(w, s0 + 1) * 16);
+      x.f[i] = x3_split(a, b);
+    }
+  };
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  auto mma = [&](const XFrags &x, const WFrags &w) {
+    // term-major order: every accumulator is touched once per 4 MFMAs (no back-to-back dependency)
+#pragma unroll
+    for (int term = 0; term < 3; ++term)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const uint4 a = (term == 2) ? w.l[j] : w.h[j];
+          const uint4 b = (term == 1) ? x.f[i].lo : x.f[i].hi;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc[i][j], 0, 0, 0);
+        }
+  };
+
+  // ---- prologue: windows 0..2 in flight, fragments of k-group 0; wait for window 0 only
+  const int v_taps = p.taps[lane < 9 ? lane : 0];
+  issue_A(0, 0);
+  WFrags w0, w1;
+  XFrags x0, x1;
+  load_w(0, 0, 0, w0);
+  if (nchunks > 1) issue_A(1, 1);
+  if (nchunks > 2) issue_A(2, 2);
+  if (nchunks > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * XPIECES) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  load_x(0, __builtin_amdgcn_readlane(v_taps, 0), 0, x0);
+
+  // ---- main loop over k-groups, two per trip (register sets 0 / 1 alternate: static indices only)
+  const int per_chunk = n_taps * 2;
+  const int G = nchunks * per_chunk;
+  int c = 0, t = 0;                      // position of the k-group in flight (kg = g & 1)
+  auto advance = [&](int g, XFrags &xn, WFrags &wn_) {
+    // fetch k-group g + 1 (if any) into (xn, wn_); crossing into a new chunk first meets the workgroup
+    const int kg = g & 1;
+    int c2 = c, t2 = t, kg2 = kg + 1;
+    if (kg2 == 2) { kg2 = 0; t2 = t + 1; if (t2 == n_taps) { t2 = 0; c2 = c + 1; } }
+    if (g + 1 < G) {
+      if (c2 != c) {
+        // VMEM retires in order: everything but the youngest 4 operations (the fragments of k-group g, fetched one
+        // k-group ago) has landed, in particular this wave's pieces of window c+1 (>= 7 operations old: the pieces of
+        // window c+2 and at least one group of fragments were issued behind them)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (c + 3 < nchunks) issue_A(c + 3, (c + 3) % XSTAGES);       // nobody reads window c-1 any more
+      }
+      load_w(c2, t2, kg2, wn_);
+      load_x(c2, __builtin_amdgcn_readlane(v_taps, t2), kg2, xn);
+    }
+    c = c2; t = t2;
+  };
+  for (int g = 0; g < G; g += 2) {
+    advance(g, x1, w1);
+    mma(x0, w0);
+    if (g + 1 < G) {
+      advance(g + 1, x0, w0);
+      mma(x1, w1);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();            // the ring becomes epilogue scratch
+  asm volatile("" ::: "memory");
+
+  // ---- epilogue: acc[i][j][r]: frame = m0 + i*32 + lr, channel = n0 + wn*64 + j*32 + 8*(r>>2) + 4*lh + (r&3)
+  float *scr = reinterpret_cast<float *>(lds) + wn * (32 * XSPITCH);
+  const float act_lo = (p.act1 == ASV_ACT_RELU) ? 0.0f : -INFINITY;
+  float *yg = reinterpret_cast<float *>(p.y);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const bool valid = (p.row_valid[(m0 + i * 32) >> 5] >> lr) & 1u;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int chl = wn * 64 + j * 32 + 8 * q + 4 * lh;
+        const float4 b4 = *reinterpret_cast<const float4 *>(lds_par + chl);
+        const float4 sc4 = *reinterpret_cast<const float4 *>(lds_par + 256 + chl);
+        const float4 sh4 = *reinterpret_cast<const float4 *>(lds_par + 512 + chl);
+        const float b[4] = {b4.x, b4.y, b4.z, b4.w}, sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if constexpr (GENERIC) {
+            float z = acc[i][j][q * 4 + e] + b[e];
+            z = p.affine_first ? apply_act(z * sc[e] + sh[e], p.act1) : apply_act(z, p.act1) * sc[e] + sh[e];
+            z = apply_act(z, p.act2);
+            y[e] = valid ? z : 0.0f;
+          } else {
+            y[e] = tdnn_epilogue_fast(acc[i][j][q * 4 + e], b[e], act_lo, sc[e], sh[e], valid);
+          }
+        }
+        *reinterpret_cast<float4 *>(scr + lr * XSPITCH + j * 32 + 8 * q + 4 * lh) = make_float4(y[0], y[1], y[2], y[3]);
+      }
+    // the scratch tile is wave-private: LDS operations of one wave complete in order
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int frow = it * 4 + (lane >> 4), slot = lane & 15;
+      const float4 v = *reinterpret_cast<const float4 *>(scr + frow * XSPITCH + slot * 4);
+      const int ch = n0 + wn * 64 + slot * 4;
+      const int row = m0 + i * 32 + frow;
+      if (ch < p.cout_store) *reinterpret_cast<float4 *>(yg + (size_t)row * p.ldy + ch) = v;
+    }
+  }
+}
+
+}  // namespace
+
+bool tdnn_x3_supported(const TdnnKernelParams &p) {
+  const bool fits32 = (unsigned long long)p.rows * (unsigned long long)p.ldx * 4ull < (1ull << 40);
+  return p.wfrag != nullptr && p.wlo != nullptr && p.x2 == nullptr && p.seg_bias == nullptr && p.seg_scale == nullptr && p.res == nullptr &&
+         p.pool_partial == nullptr && p.zero16 != nullptr && p.rows % XBM == 0 && p.cout_store % 4 == 0 && p.cout_store >= 192 && p.cin_pad >= 32 &&
+         p.halo <= kHalo && p.ksplit <= 1 && fits32;
+}
+
+int launch_tdnn_x3(const TdnnKernelParams &p, hipStream_t s) {
+  ASV_REQUIRE(p.rows % XBM == 0, "tdnn(x3): rows %d not a multiple of %d", p.rows, XBM);
+  ASV_REQUIRE(p.wfrag != nullptr && p.wlo != nullptr, "tdnn(x3): split fragment-packed weights missing");
+  for (int t = 0; t < p.n_taps; ++t)
+    ASV_REQUIRE(p.taps[t] >= -kHalo && p.taps[t] <= kHalo, "tdnn(x3): tap offset %d exceeds the %d-frame halo", p.taps[t], kHalo);
+  const int m_tiles = p.rows / XBM, n_tiles = round_up(p.cout_store, XBN) / XBN;
+  const dim3 grid(m_tiles * n_tiles), block(256);
+  const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first;
+  if (fast) hipLaunchKernelGGL((tdnn_gemm_x3_kernel<false>), grid, block, 0, s, p, m_tiles, n_tiles);
+  else hipLaunchKernelGGL((tdnn_gemm_x3_kernel<true>), grid, block, 0, s, p, m_tiles, n_tiles);
+  ASV_HIP_CHECK(hipGetLastError());
+  return ASV_OK;
+}
+
+}  // namespace asv

@@ -207,6 +207,27 @@ __global__ __launch_bounds__(256) void scale_kernel(double *m, long long n, doub
   if (e < n) m[e] *= f;
 }
 
+// one wave per trial: s = <EL[e], t> + <TL[t], e> + <EG[e], e> + <TG[t], t> + <e + t, c>   (gaussian-plda-scoring.py:23-29)
+__global__ __launch_bounds__(256) void two_cov_trials_kernel(const float *enroll, const float *test, int dim, const double *el, const double *tl, const double *eg,
+                                                             const double *tg, const double *c, const int32_t *ei, const int32_t *ti, int n_trials, double *scores) {
+  const int tr = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (tr >= n_trials) return;
+  const size_t eo = (size_t)ei[tr] * dim, to = (size_t)ti[tr] * dim;
+  double s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0;
+  for (int d = lane; d < dim; d += 64) {
+    const double e = (double)enroll[eo + d], t = (double)test[to + d];
+    s1 += el[eo + d] * t;
+    s2 += tl[to + d] * e;
+    s3 += eg[eo + d] * e;
+    s4 += tg[to + d] * t;
+    s5 += (e + t) * c[d];
+  }
+  double s = (((s1 + s2) + s3) + s4) + s5;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+  if (lane == 0) scores[tr] = s;
+}
+
 struct DevBuf {
   void *p = nullptr;
   ~DevBuf() { if (p) (void)hipFree(p); }
@@ -428,5 +449,39 @@ extern "C" int asv_class_scatter_f64(const float *x, int ldx, int n_rows, int di
   if ((rc = gemm64<double, double>(g, 1, partials, partial_cap, s))) return rc;
   ASV_HIP_CHECK(hipMemcpyAsync(class_scatter_out, d_out.p, (size_t)D * D * 8, hipMemcpyDeviceToHost, s));
   ASV_HIP_CHECK(hipStreamSynchronize(s));
+  return ASV_OK;
+}
+
+
+// Two-covariance PLDA scorer (score/pyplda/gaussian-plda-scoring.py:23-50): see include/asv_amd.h.
+extern "C" int asv_two_cov_trials(const float *enroll, int n_enroll, const float *test, int n_test, int dim, const double *gamma, const double *lambda,
+                                  const double *c, const int32_t *ei, const int32_t *ti, int n_trials, double *scores, void *stream) {
+  ASV_REQUIRE(enroll && test && gamma && lambda && c && ei && ti && scores, "asv_two_cov_trials: null argument");
+  ASV_REQUIRE(n_enroll >= 1 && n_test >= 1 && dim >= 1 && dim <= 4096 && n_trials >= 0, "asv_two_cov_trials: bad sizes");
+  if (n_trials == 0) return ASV_OK;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const size_t DD = (size_t)dim * dim;
+  DevBuf d_g, d_l, d_c, d_el, d_tl, d_eg, d_tg, partials;
+  size_t partial_cap = 0;
+  int rc;
+  if ((rc = d_g.alloc(DD * 8)) || (rc = d_l.alloc(DD * 8)) || (rc = d_c.alloc((size_t)dim * 8)) || (rc = d_el.alloc((size_t)n_enroll * dim * 8)) ||
+      (rc = d_eg.alloc((size_t)n_enroll * dim * 8)) || (rc = d_tl.alloc((size_t)n_test * dim * 8)) || (rc = d_tg.alloc((size_t)n_test * dim * 8))) return rc;
+  ASV_HIP_CHECK(hipMemcpyAsync(d_g.p, gamma, DD * 8, hipMemcpyHostToDevice, s));
+  ASV_HIP_CHECK(hipMemcpyAsync(d_l.p, lambda, DD * 8, hipMemcpyHostToDevice, s));
+  ASV_HIP_CHECK(hipMemcpyAsync(d_c.p, c, (size_t)dim * 8, hipMemcpyHostToDevice, s));
+  // rows x matrix products: (V M)[i][j] = sum_k V[i][k] M[k][j]
+  auto rows_times = [&](const float *v, int n, const DevBuf &m, DevBuf &out) {
+    Gemm64Params g; memset(&g, 0, sizeof(g));
+    g.a = v; g.sa_i = dim; g.sa_k = 1; g.b = m.p; g.sb_k = dim; g.sb_j = 1; g.c = out.as<double>();
+    g.m = n; g.n = dim; g.k = dim; g.ldc = dim; g.alpha = 1.0; g.beta = 0.0;
+    return gemm64<float, double>(g, 1, partials, partial_cap, s);
+  };
+  // e^T L t = sum_j (sum_i e_i L_ij) t_j = <(E L)[e], t>;   t^T L e = <(T L)[t], e>
+  if ((rc = rows_times(enroll, n_enroll, d_l, d_el)) || (rc = rows_times(test, n_test, d_l, d_tl)) || (rc = rows_times(enroll, n_enroll, d_g, d_eg)) ||
+      (rc = rows_times(test, n_test, d_g, d_tg))) return rc;
+  hipLaunchKernelGGL(two_cov_trials_kernel, dim3((n_trials + 3) / 4), dim3(256), 0, s, enroll, test, dim, d_el.as<double>(), d_tl.as<double>(), d_eg.as<double>(),
+                     d_tg.as<double>(), d_c.as<double>(), ei, ti, n_trials, scores);
+  ASV_HIP_CHECK(hipGetLastError());
+  ASV_HIP_CHECK(hipStreamSynchronize(s));            // the scratch products are freed on return
   return ASV_OK;
 }

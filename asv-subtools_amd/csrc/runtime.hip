@@ -35,6 +35,13 @@ uint16_t f32_to_bf16_host(float f) {
   return (uint16_t)(u >> 16);
 }
 
+static float bf16_to_f32_host(uint16_t h) {
+  const uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
 void pack_tdnn_weight(const float *w, int out_ch, int in_ch, int tot_ctx, int left_ctx, const int *taps, int n_taps,
                       int cout_pad, int cin_pad, bool bf16, void *dst) {
   const size_t n = (size_t)cout_pad * n_taps * cin_pad;
@@ -51,13 +58,6 @@ void pack_tdnn_weight(const float *w, int out_ch, int in_ch, int tot_ctx, int le
     }
 }
 
-static float bf16_to_f32_host(uint16_t h) {
-  const uint32_t u = (uint32_t)h << 16;
-  float f;
-  memcpy(&f, &u, 4);
-  return f;
-}
-
 size_t tdnn_weight_frag_elems(int cout_pad, int cin_pad, int n_taps) {
   return (size_t)cout_pad * n_taps * round_up(cin_pad, 64);
 }
@@ -65,9 +65,10 @@ size_t tdnn_weight_frag_elems(int cout_pad, int cin_pad, int n_taps) {
 // MFMA-fragment order for kernels_tdnn_v3.hip: [n_frag32][tap][chunk64][k_group16][lane][8];
 // lane = (k half lh, channel lr): channel n_frag*32 + lr, k = chunk*64 + k_group*16 + lh*8 + e.
 void pack_tdnn_weight_frags(const float *w, int out_ch, int in_ch, int tot_ctx, int left_ctx, const int *taps, int n_taps,
-                            int cout_pad, int cin_pad, uint16_t *dst) {
+                            int cout_pad, int cin_pad, uint16_t *dst, uint16_t *dst_lo) {
   const int nchunks = round_up(cin_pad, 64) / 64;
   memset(dst, 0, tdnn_weight_frag_elems(cout_pad, cin_pad, n_taps) * 2);
+  if (dst_lo) memset(dst_lo, 0, tdnn_weight_frag_elems(cout_pad, cin_pad, n_taps) * 2);
   for (int co = 0; co < out_ch; ++co) {
     const int nf = co / 32, lr = co % 32;
     for (int t = 0; t < n_taps; ++t) {
@@ -75,7 +76,9 @@ void pack_tdnn_weight_frags(const float *w, int out_ch, int in_ch, int tot_ctx, 
       for (int ci = 0; ci < in_ch; ++ci) {
         const int c = ci / 64, kg = (ci % 64) / 16, lh = (ci % 16) / 8, e = ci % 8;
         const size_t idx = ((((size_t)nf * n_taps + t) * nchunks + c) * 4 + kg) * 512 + (size_t)(lh * 32 + lr) * 8 + e;
-        dst[idx] = f32_to_bf16_host(w[((size_t)co * in_ch + ci) * tot_ctx + k]);
+        const float v = w[((size_t)co * in_ch + ci) * tot_ctx + k];
+        dst[idx] = f32_to_bf16_host(v);
+        if (dst_lo) dst_lo[idx] = f32_to_bf16_host(v - bf16_to_f32_host(dst[idx]));      // f32x mode: w = hi + lo
       }
     }
   }
@@ -171,6 +174,7 @@ struct asv_net {
   std::vector<hipEvent_t> event_pool;
 
   bool frames_bf16() const { return precision == ASV_PREC_BF16; }
+  bool x3() const { return precision == ASV_PREC_F32X; }        // f32 storage, split-bf16 matrix products
   bool is_utts(int domain) const { return domains[domain].kind == ASV_DOMAIN_UTTS; }
   bool dom_bf16(int domain) const { return !is_utts(domain) && frames_bf16(); }
   size_t elem_size(int domain) const { return dom_bf16(domain) ? 2 : 4; }
@@ -350,7 +354,7 @@ int asv_device_count(int *count) {
 
 int asv_net_create(asv_net_t **out, int device, int precision, unsigned flags, int feat_dim) {
   ASV_REQUIRE(out != nullptr, "asv_net_create: null out pointer");
-  ASV_REQUIRE(precision == ASV_PREC_F32 || precision == ASV_PREC_BF16, "asv_net_create: unknown precision %d", precision);
+  ASV_REQUIRE(precision == ASV_PREC_F32 || precision == ASV_PREC_BF16 || precision == ASV_PREC_F32X, "asv_net_create: unknown precision %d", precision);
   ASV_REQUIRE(feat_dim >= 1, "asv_net_create: feat_dim %d", feat_dim);
   int ndev = 0;
   ASV_HIP_CHECK(hipGetDeviceCount(&ndev));
@@ -472,6 +476,13 @@ int asv_net_add_tdnn(asv_net_t *net, const asv_tdnn_desc_t *d) {
       pack_tdnn_weight_frags(d->weight, d->out_ch, d->in_ch, d->w_tot_context, d->w_left_context, d->taps, d->n_taps, op.cout_pad, op.cin_pad, frags.data());
       if ((rc = dev_upload(net, frags.data(), frags.size() * 2, &op.wfrag))) return rc;
     }
+    if (net->x3() && !op.utts && net->domains[dom].kind == ASV_DOMAIN_FRAMES && op.cout_store >= 192 && op.cin_pad >= 32) {
+      // f32x mode: hi / lo bf16 halves of the weights in the same fragment order (kernels_tdnn_x3.hip)
+      std::vector<uint16_t> hi(tdnn_weight_frag_elems(op.cout_pad, op.cin_pad, d->n_taps)), lo(hi.size());
+      pack_tdnn_weight_frags(d->weight, d->out_ch, d->in_ch, d->w_tot_context, d->w_left_context, d->taps, d->n_taps, op.cout_pad, op.cin_pad, hi.data(), lo.data());
+      if ((rc = dev_upload(net, hi.data(), hi.size() * 2, &op.wfrag))) return rc;
+      if ((rc = dev_upload(net, lo.data(), lo.size() * 2, &op.wlo))) return rc;
+    }
     if (bf16 && net->domains[dom].kind == 2 && d->n_taps == 9 && (op.cin_pad == 32 || op.cin_pad == 64) && d->in_ch == op.cin_pad &&
         d->out_ch == d->in_ch) {
       // 3x3 trunk convolutions with 32 / 64 channels: fragment order of kernels_conv2d.hip,
@@ -489,7 +500,7 @@ int asv_net_add_tdnn(asv_net_t *net, const asv_tdnn_desc_t *d) {
       }
       if ((rc = dev_upload(net, frags.data(), frags.size() * 2, &op.wfrag))) return rc;
     }
-    if (op.utts && net->frames_bf16()) {
+    if (op.utts && (net->frames_bf16() || net->x3())) {
       // pooled-domain layers keep f32 activations; their GEMM runs on the bf16 matrix cores with every
       // operand split into two bf16 halves, the weight halves in the fragment order kernels_utts.hip walks:
       // [32-channel fragment][32-k step][j][lane = (k half lh, channel lr)][8], k = 32 * step + 16 * lh + 8 * j + e
@@ -700,7 +711,7 @@ int asv_net_describe(const asv_net_t *net, char *buf, size_t cap) {
   std::string s;
   char line[512];
   snprintf(line, sizeof(line), "asv_net precision=%s flags=%u feat_dim=%d buffers=%zu ops=%zu out=%d embed_dim=%d\n",
-           net->precision == ASV_PREC_BF16 ? "bf16" : "f32", net->flags, net->feat_dim, net->bufs.size(), net->ops.size(), net->out_buf, net->embed_dim);
+           net->precision == ASV_PREC_BF16 ? "bf16" : (net->precision == ASV_PREC_F32X ? "f32x" : "f32"), net->flags, net->feat_dim, net->bufs.size(), net->ops.size(), net->out_buf, net->embed_dim);
   s += line;
   for (size_t i = 0; i < net->bufs.size(); ++i) {
     const Domain &dm = net->domains[net->bufs[i].domain];
@@ -946,6 +957,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         const bool big3 = !use_ref && narrow && (net->flags & (ASV_FLAG_SMALL_TILES | ASV_FLAG_BIG_V2)) == 0 && tdnn_big3_supported(p, bf16, !bf16);
         const bool big = !use_ref && narrow && !big3 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && tdnn_big_supported(p, bf16, !bf16);
         const bool utts_kernel = !use_ref && op.utts;
+        const bool x3 = !use_ref && !op.utts && net->x3() && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && tdnn_x3_supported(p);
         const bool c1_conv = !use_ref && net->domains[domid].kind == 2 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && grid_conv_c1_supported(p, bf16, d.in_ch);
         const bool narrow_conv = !use_ref && net->domains[domid].kind == 2 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && grid_conv_narrow_supported(p, bf16);
         if (!use_ref && !big && !big3 && op.utts && !utts_kernel) {
@@ -972,7 +984,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         if (fuse) {
           p.pool_slots = pool_slots;
           p.ld_partial = op.cout_pad;
-          if ((rc = ensure(net->poolpart_dev, (size_t)(p.rows / 128) * pool_slots * 2 * p.ld_partial * 4, c.s, false))) return rc;
+          if ((rc = ensure(net->poolpart_dev, (size_t)(p.rows / 128) * pool_slots * 3 * p.ld_partial * 4, c.s, false))) return rc;
           p.pool_partial = reinterpret_cast<float *>(net->poolpart_dev.ptr);
         }
         if (use_ref) rc = launch_tdnn_ref(p, bf16, !bf16, c.s);
@@ -983,10 +995,11 @@ int run_ops(RunCtx &c, size_t n_ops) {
             p.final_out = c.final_out; p.final_ld = net->embed_dim; p.final_len = c.seg_frames;
             c.final_written = true;
           }
-          rc = launch_utts_gemm(p, bp.segments, net->frames_bf16(), c.s);
+          rc = launch_utts_gemm(p, bp.segments, net->frames_bf16() || net->x3(), c.s);
         }
         else if (narrow_conv) rc = launch_grid_conv_narrow(p, c.s);
         else if (c1_conv) rc = launch_grid_conv_c1(p, c.s);
+        else if (x3) rc = launch_tdnn_x3(p, c.s);
         else if (big3) rc = launch_tdnn_big3(p, c.s);
         else if (big) rc = launch_tdnn_big(p, c.s);
         else {

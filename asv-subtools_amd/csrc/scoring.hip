@@ -16,20 +16,29 @@
 namespace asv {
 namespace {
 
-// thread-local device workspace, grown on demand (scoring calls are not on the extract path)
+// Scratch memory of one call: stream-ordered (hipMallocAsync / hipFreeAsync on the caller's stream, served from the
+// device's memory pool after the first use), so it belongs to the device the call runs on and to this stream only -
+// back-to-back calls on different streams or devices never share it, and nothing outlives the call.
 struct Workspace {
-  void *ptr = nullptr; size_t cap = 0;
-  int get(size_t bytes, void **out) {
-    if (bytes > cap) {
-      if (ptr) { ASV_HIP_CHECK(hipDeviceSynchronize()); ASV_HIP_CHECK(hipFree(ptr)); ptr = nullptr; cap = 0; }
-      ASV_HIP_CHECK(hipMalloc(&ptr, bytes + bytes / 4 + 4096));
-      cap = bytes + bytes / 4 + 4096;
-    }
+  void *ptr = nullptr; hipStream_t s = nullptr;
+  ~Workspace() { if (ptr) (void)hipFreeAsync(ptr, s); }
+  int get(size_t bytes, hipStream_t stream, void **out) {
+    s = stream;
+    ASV_HIP_CHECK(hipMallocAsync(&ptr, bytes + 256, stream));
     *out = ptr;
     return ASV_OK;
   }
 };
-thread_local Workspace g_ws;
+
+// Every entry point runs on the device that owns its (first) device pointer, whatever the caller's current device is.
+int enter_device_of(const void *dev_ptr) {
+  hipPointerAttribute_t attr;
+  ASV_HIP_CHECK(hipPointerGetAttributes(&attr, dev_ptr));
+  ASV_REQUIRE(attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged, "scoring: pointer %p is not device memory", dev_ptr);
+  ASV_HIP_CHECK(hipSetDevice(attr.device));
+  return ASV_OK;
+}
+#define ASV_ENTER(ptr) do { int _rc = enter_device_of(ptr); if (_rc) return _rc; } while (0)
 
 __global__ __launch_bounds__(256) void col_mean_kernel(const float *x, int n, int dim, float *mean) {
   // one block per 64 columns; lanes along columns, 4 waves stride the rows
@@ -41,6 +50,20 @@ __global__ __launch_bounds__(256) void col_mean_kernel(const float *x, int n, in
   sm[wave][threadIdx.x & 63] = s;
   __syncthreads();
   if (wave == 0 && col < dim) mean[col] = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x])) / (float)n;
+}
+
+// ivector-mean with a spk2utt map: thread = column, rows of the group added in list order (f32), then scaled by 1 / n
+__global__ __launch_bounds__(256) void group_mean_kernel(const float *x, int n, int dim, const int32_t *order, const int32_t *offsets, float *means, int32_t *counts) {
+  const int g = blockIdx.x, col = blockIdx.y * 256 + threadIdx.x;
+  const int b = offsets[g], e = offsets[g + 1];
+  if (col == 0) counts[g] = e - b;
+  if (col >= dim) return;
+  float s = 0.0f;
+  for (int k = b; k < e; ++k) {
+    const int r = order[k];
+    if (r >= 0 && r < n) s += x[(size_t)r * dim + col];
+  }
+  means[(size_t)g * dim + col] = (e > b) ? s * (float)(1.0 / (double)(e - b)) : 0.0f;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -113,8 +136,9 @@ __global__ __launch_bounds__(256) void copy_out_kernel(const float *src, int ld,
 int gemm_nt_f32(const float *A, int M, const float *a_mean, const float *B, int N, int K, float *C, hipStream_t s) {
   const int m_pad = round_up(M, kRowTile), n_pad = round_up(N, 128), k_pad = round_up(K, kChanAlign), ldc = round_up(N, kChanAlign);
   const size_t bytes = ((size_t)m_pad * k_pad + (size_t)n_pad * k_pad + (size_t)m_pad * ldc + n_pad + m_pad / 32) * 4;
+  Workspace g_ws;
   void *ws = nullptr;
-  int rc = g_ws.get(bytes, &ws);
+  int rc = g_ws.get(bytes, s, &ws);
   if (rc) return rc;
   float *Ap = reinterpret_cast<float *>(ws), *Bp = Ap + (size_t)m_pad * k_pad, *Cp = Bp + (size_t)n_pad * k_pad, *bias = Cp + (size_t)m_pad * ldc;
   uint32_t *valid = reinterpret_cast<uint32_t *>(bias + n_pad);
@@ -343,6 +367,7 @@ extern "C" {
 
 int asv_mean_vec(const float *x, int n, int dim, float *mean, void *stream) {
   ASV_REQUIRE(x && mean && n >= 1 && dim >= 1, "asv_mean_vec: bad argument");
+  ASV_ENTER(x);
   hipLaunchKernelGGL(col_mean_kernel, dim3((dim + 63) / 64), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, n, dim, mean);
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
@@ -350,6 +375,7 @@ int asv_mean_vec(const float *x, int n, int dim, float *mean, void *stream) {
 
 int asv_length_norm(float *x, int n, int dim, const float *mean, int normalize, void *stream) {
   ASV_REQUIRE(x && n >= 1 && dim >= 1, "asv_length_norm: bad argument");
+  ASV_ENTER(x);
   hipLaunchKernelGGL(length_norm_kernel, dim3((n + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, n, dim, mean, normalize);
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
@@ -357,11 +383,13 @@ int asv_length_norm(float *x, int n, int dim, const float *mean, int normalize, 
 
 int asv_dot_score_matrix(const float *enroll, int n_enroll, const float *test, int n_test, int dim, float *scores, void *stream) {
   ASV_REQUIRE(enroll && test && scores && n_enroll >= 1 && n_test >= 1 && dim >= 1, "asv_dot_score_matrix: bad argument");
+  ASV_ENTER(enroll);
   return gemm_nt_f32(enroll, n_enroll, nullptr, test, n_test, dim, scores, reinterpret_cast<hipStream_t>(stream));
 }
 
 int asv_dot_score_trials(const float *enroll, const float *test, int dim, const int32_t *ei, const int32_t *ti, int n_trials, float *scores, void *stream) {
   ASV_REQUIRE(enroll && test && ei && ti && scores && dim >= 1 && n_trials >= 0, "asv_dot_score_trials: bad argument");
+  ASV_ENTER(enroll);
   if (n_trials == 0) return ASV_OK;
   hipLaunchKernelGGL(dot_trials_kernel, dim3((n_trials + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), enroll, test, dim, ei, ti, n_trials, scores);
   ASV_HIP_CHECK(hipGetLastError());
@@ -371,6 +399,7 @@ int asv_dot_score_trials(const float *enroll, const float *test, int dim, const 
 int asv_plda_transform(const float *x, int n, int dim, const float *mean, const float *transform, const float *psi, const int32_t *num_examples,
                        int length_norm, float *y, void *stream) {
   ASV_REQUIRE(x && transform && y && n >= 1 && dim >= 1, "asv_plda_transform: bad argument");
+  ASV_ENTER(x);
   ASV_REQUIRE(length_norm >= ASV_PLDA_NORM_NONE && length_norm <= ASV_PLDA_NORM_PSI, "asv_plda_transform: length_norm %d", length_norm);
   ASV_REQUIRE(length_norm != ASV_PLDA_NORM_PSI || psi != nullptr, "asv_plda_transform: psi needed for PLDA length normalisation");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -387,6 +416,7 @@ int asv_plda_transform(const float *x, int n, int dim, const float *mean, const 
 int asv_plda_llr_trials(const float *enroll, const float *test, int dim, const float *psi, const int32_t *enroll_n, const int32_t *ei, const int32_t *ti,
                         int n_trials, float *scores, void *stream) {
   ASV_REQUIRE(enroll && test && psi && ei && ti && scores && dim >= 1 && n_trials >= 0, "asv_plda_llr_trials: bad argument");
+  ASV_ENTER(enroll);
   if (n_trials == 0) return ASV_OK;
   hipLaunchKernelGGL(plda_llr_kernel, dim3((n_trials + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), enroll, test, dim, psi, enroll_n, ei, ti,
                      n_trials, scores);
@@ -394,16 +424,27 @@ int asv_plda_llr_trials(const float *enroll, const float *test, int dim, const f
   return ASV_OK;
 }
 
+int asv_group_mean(const float *x, int n, int dim, const int32_t *order, const int32_t *offsets, int n_groups, float *means, int32_t *counts, void *stream) {
+  ASV_REQUIRE(x && order && offsets && means && counts && n >= 1 && dim >= 1 && n_groups >= 0, "asv_group_mean: bad argument");
+  ASV_ENTER(x);
+  if (n_groups == 0) return ASV_OK;
+  hipLaunchKernelGGL(group_mean_kernel, dim3(n_groups, (dim + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, n, dim, order, offsets, means, counts);
+  ASV_HIP_CHECK(hipGetLastError());
+  return ASV_OK;
+}
+
 int asv_eer(const float *scores, const int32_t *labels, int n, float *eer_percent, float *threshold, void *stream) {
   ASV_REQUIRE(scores && labels && eer_percent && threshold && n >= 2, "asv_eer: bad argument");
+  ASV_ENTER(scores);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   size_t sort_tmp = 0, scan_tmp = 0;
   ASV_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(nullptr, sort_tmp, (unsigned long long *)nullptr, (unsigned long long *)nullptr, n, 0, 64, s));
   ASV_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(nullptr, scan_tmp, (int *)nullptr, (int *)nullptr, n, s));
   const size_t tmp = std::max(sort_tmp, scan_tmp);
   const size_t n8 = round_up64((int64_t)n * 8, 256), n4 = round_up64((int64_t)n * 4, 256);
+  Workspace g_ws;
   void *ws = nullptr;
-  int rc = g_ws.get(2 * n8 + 2 * n4 + 256 + tmp, &ws);
+  int rc = g_ws.get(2 * n8 + 2 * n4 + 256 + tmp, s, &ws);
   if (rc) return rc;
   unsigned char *b = reinterpret_cast<unsigned char *>(ws);
   unsigned long long *keys = reinterpret_cast<unsigned long long *>(b), *sorted = reinterpret_cast<unsigned long long *>(b + n8);
@@ -457,14 +498,16 @@ int asv_score_norm(const float *enroll_cohort, int n_enroll, const float *test_c
                    const float *scores, int n_trials, int top_n, int cross_select, float *normed, void *stream) {
   ASV_REQUIRE(enroll_cohort && test_cohort && ei && ti && scores && normed && n_enroll >= 1 && n_test >= 1 && n_cohort >= 1 && n_trials >= 0,
               "asv_score_norm: bad argument");
+  ASV_ENTER(scores);
   if (n_trials == 0) return ASV_OK;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int n_sel = (top_n <= 0 || top_n > n_cohort) ? n_cohort : top_n;
   const int rows = n_enroll + n_test;
   const size_t stat_bytes = round_up64((int64_t)rows * 2 * 8, 256);
   const size_t idx_bytes = cross_select ? round_up64((int64_t)rows * n_sel * 4, 256) : 0;
+  Workspace g_ws;
   void *ws = nullptr;
-  int rc = g_ws.get(stat_bytes + idx_bytes, &ws);
+  int rc = g_ws.get(stat_bytes + idx_bytes, s, &ws);
   if (rc) return rc;
   double *mu_e = reinterpret_cast<double *>(ws), *sd_e = mu_e + n_enroll, *mu_t = sd_e + n_enroll, *sd_t = mu_t + n_test;
   int32_t *top_e = cross_select ? reinterpret_cast<int32_t *>(reinterpret_cast<unsigned char *>(ws) + stat_bytes) : nullptr;

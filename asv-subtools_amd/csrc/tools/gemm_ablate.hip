@@ -78,7 +78,7 @@ int main(int argc, char **argv) {
     int32_t *drs; CK(hipMalloc(&drs, rows * 4)); CK(hipMemcpy(drs, rs.data(), rows * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(valid, vb.data(), rows / 8, hipMemcpyHostToDevice));
     p.row_seg = drs; p.pool_slots = 2; p.ld_partial = cout_pad;
-    float *pp; CK(hipMalloc(&pp, (size_t)(rows / 128) * 2 * 2 * cout_pad * 4)); p.pool_partial = pp;
+    float *pp; CK(hipMalloc(&pp, (size_t)(rows / 128) * 2 * 3 * cout_pad * 4)); p.pool_partial = pp;
   }
   p.tune = getenv("ABLATE_TUNE") ? (int)strtol(getenv("ABLATE_TUNE"), nullptr, 0) : 0;
   const double flops = 2.0 * rows * cin * cout * ntaps;

@@ -11,7 +11,7 @@ import ctypes as C
 import os
 
 ASV_OK = 0
-PREC_F32, PREC_BF16 = 0, 1
+PREC_F32, PREC_BF16, PREC_F32X = 0, 1, 2
 FLAG_REF_KERNELS, FLAG_NO_FUSE, FLAG_SMALL_TILES, FLAG_BIG_V2 = 1, 2, 4, 8
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
 DOMAIN_FRAMES, DOMAIN_UTTS = 0, 1
@@ -140,7 +140,7 @@ SYMBOLS = [
     "asv_net_device_bytes", "asv_net_set_profiling", "asv_net_get_profile",
     "asv_tdnn_forward", "asv_stats_pool_forward",
     "asv_length_norm", "asv_mean_vec", "asv_dot_score_matrix", "asv_dot_score_trials",
-    "asv_plda_transform", "asv_plda_llr_trials", "asv_eer", "asv_score_norm",
+    "asv_plda_transform", "asv_plda_llr_trials", "asv_eer", "asv_score_norm", "asv_group_mean", "asv_two_cov_trials",
     "asv_plda_train", "asv_scatter_f64", "asv_class_scatter_f64",
     "asv_fbank_num_frames", "asv_fbank", "asv_fbank_pcm16", "asv_cmvn", "asv_cmvn_sliding", "asv_vad_energy", "asv_select_frames",
 ]
@@ -199,6 +199,8 @@ def lib():
     L.asv_plda_transform.argtypes = [vp, ci, ci, vp, vp, vp, vp, ci, vp, vp]
     L.asv_plda_llr_trials.argtypes = [vp, vp, ci, vp, vp, vp, vp, ci, vp, vp]
     L.asv_eer.argtypes = [vp, vp, ci, c_float_p, c_float_p, vp]
+    L.asv_group_mean.argtypes = [vp, ci, ci, vp, vp, ci, vp, vp, vp]
+    L.asv_two_cov_trials.argtypes = [vp, ci, vp, ci, ci, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), vp, vp, ci, vp, vp]
     L.asv_score_norm.argtypes = [vp, ci, vp, ci, ci, vp, vp, vp, ci, ci, ci, vp, vp]
     L.asv_plda_train.argtypes = [vp, ci, ci, ci, C.POINTER(C.c_int32), C.POINTER(C.c_longlong), ci, ci,
                                  C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), vp]

@@ -16,7 +16,8 @@ from . import ir as _ir
 
 
 PRECISIONS = {"f32": capi.PREC_F32, "fp32": capi.PREC_F32, "float32": capi.PREC_F32,
-              "bf16": capi.PREC_BF16, "bfloat16": capi.PREC_BF16}
+              "bf16": capi.PREC_BF16, "bfloat16": capi.PREC_BF16,
+              "f32x": capi.PREC_F32X, "bf16x3": capi.PREC_F32X}
 
 
 def default_precision():

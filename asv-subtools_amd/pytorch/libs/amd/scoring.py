@@ -43,6 +43,16 @@ def _stream(t):
     return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
+def _check_index(idx, n, what):
+    """Trial indices address device rows directly (`enroll + ei * dim`): reject anything outside [0, n) here, on the
+    device (one reduction + one scalar read-back), instead of reading out of bounds in the kernel."""
+    if idx.numel() == 0:
+        return
+    lo, hi = int(idx.min().item()), int(idx.max().item())
+    if lo < 0 or hi >= n:
+        raise ValueError("%s: trial index range [%d, %d] outside the %d vectors" % (what, lo, hi, n))
+
+
 def mean_vector(x):
     """ivector-mean over all vectors (score/process.sh:177)."""
     import torch
@@ -77,9 +87,48 @@ def score_trials(enroll, test, enroll_idx, test_idx):
     import torch
     e, t = _dev(enroll, torch.float32), _dev(test, torch.float32)
     ei, ti = _dev(enroll_idx, torch.int32, e.device), _dev(test_idx, torch.int32, e.device)
+    _check_index(ei, e.shape[0], "score_trials (enrol)")
+    _check_index(ti, t.shape[0], "score_trials (test)")
     out = torch.empty(ei.shape[0], dtype=torch.float32, device=e.device)
     capi.check(capi.lib().asv_dot_score_trials(_ptr(e), _ptr(t), e.shape[1], _ptr(ei), _ptr(ti), ei.shape[0], _ptr(out), _stream(e)), "asv_dot_score_trials")
     return out
+
+
+def speaker_mean(vectors, groups):
+    """Speaker-level enrolment vectors: `ivector-mean ark:spk2utt ...` of score/process.sh:156-167.  groups: one sequence of
+    row indices per speaker (the spk2utt map resolved to rows of `vectors`).  Returns (means [G, dim] f32 device tensor,
+    num_utts [G] int32 device tensor - what score.sh:99-121 hands to ivector-plda-scoring as --num-utts and what
+    Plda.transform_vectors(num_examples=...) / llr_trials(enroll_num_utts=...) take)."""
+    import torch
+    x = _dev(vectors, torch.float32)
+    groups = [np.asarray(g, dtype=np.int64).reshape(-1) for g in groups]
+    for g in groups:
+        if g.size == 0:
+            raise ValueError("speaker_mean: a speaker without utterances (ivector-mean skips it with a warning; drop it from spk2utt)")
+        if g.min() < 0 or g.max() >= x.shape[0]:
+            raise ValueError("speaker_mean: utterance index outside the %d vectors" % x.shape[0])
+    offsets = np.zeros(len(groups) + 1, dtype=np.int32)
+    np.cumsum([g.size for g in groups], out=offsets[1:])
+    order = np.concatenate(groups).astype(np.int32) if groups else np.zeros(0, dtype=np.int32)
+    od, of = _dev(order, torch.int32, x.device), _dev(offsets, torch.int32, x.device)
+    means = torch.empty((len(groups), x.shape[1]), dtype=torch.float32, device=x.device)
+    counts = torch.empty(len(groups), dtype=torch.int32, device=x.device)
+    capi.check(capi.lib().asv_group_mean(_ptr(x), x.shape[0], x.shape[1], _ptr(od), _ptr(of), len(groups), _ptr(means), _ptr(counts), _stream(x)),
+               "asv_group_mean")
+    return means, counts
+
+
+def read_spk2utt(path, utt_keys):
+    """Kaldi spk2utt text ('spk utt1 utt2 ...') -> (speaker ids, groups of row indices into `utt_keys`)."""
+    row = {k: i for i, k in enumerate(utt_keys)}
+    spks, groups = [], []
+    with open(path) as f:
+        for line in f:
+            toks = line.split()
+            if len(toks) >= 2:
+                spks.append(toks[0])
+                groups.append([row[u] for u in toks[1:]])
+    return spks, groups
 
 
 def cosine_trials(enroll, test, enroll_idx, test_idx, submean=None):
@@ -111,6 +160,11 @@ def score_normalize(scores, enroll_cohort, test_cohort, enroll_idx, test_idx, to
     assert ec.dim() == 2 and tc.dim() == 2 and ec.shape[1] == tc.shape[1], "cohort score matrices must share the cohort axis"
     ei, ti = _dev(enroll_idx, torch.int32, s.device), _dev(test_idx, torch.int32, s.device)
     assert ei.shape[0] == s.shape[0] == ti.shape[0]
+    _check_index(ei, ec.shape[0], "score_normalize (enrol)")
+    _check_index(ti, tc.shape[0], "score_normalize (test)")
+    if bool(torch.isnan(ec).any().item()) or bool(torch.isnan(tc).any().item()):
+        raise ValueError("score_normalize: NaN in the cohort scores (pandas would propagate it into every statistic; the device "
+                         "selection orders keys and would silently skip it)")
     out = torch.empty_like(s)
     capi.check(capi.lib().asv_score_norm(_ptr(ec), ec.shape[0], _ptr(tc), tc.shape[0], ec.shape[1], _ptr(ei), _ptr(ti), _ptr(s), s.shape[0],
                                          int(top_n), int(bool(cross_select)), _ptr(out), _stream(s)), "asv_score_norm")
@@ -214,9 +268,54 @@ class Plda(object):
         psi = _dev(self.psi.astype(np.float32), device=dev)
         ei, ti = _dev(enroll_idx, torch.int32, dev), _dev(test_idx, torch.int32, dev)
         en = _dev(enroll_num_utts, torch.int32, dev) if enroll_num_utts is not None else None
+        _check_index(ei, e.shape[0], "llr_trials (enrol)")
+        _check_index(ti, t.shape[0], "llr_trials (test)")
+        if en is not None and en.shape[0] != e.shape[0]:
+            raise ValueError("llr_trials: %d enrolment vectors but %d num_utts entries" % (e.shape[0], en.shape[0]))
         out = torch.empty(ei.shape[0], dtype=torch.float32, device=dev)
         capi.check(capi.lib().asv_plda_llr_trials(_ptr(e), _ptr(t), self.dim, _ptr(psi), _ptr(en), _ptr(ei), _ptr(ti), ei.shape[0], _ptr(out), _stream(e)),
                    "asv_plda_llr_trials")
+        return out
+
+
+class TwoCovPlda(object):
+    """Two-covariance PLDA scorer of score/pyplda/gaussian-plda-scoring.py: Gamma / Lambda / c from (mean, within, between)
+    as CalculateVar does (31-50; main() adds 5e-5 I to within_var first, 66) on the host in float64 - D x D, once per model -
+    and the per-trial form (23-29) on the device in float64 (asv_two_cov_trials)."""
+
+    def __init__(self, mean, within_var, between_var, within_ridge=5e-5):
+        mean = np.asarray(mean, dtype=np.float64).reshape(-1)
+        within = np.asarray(within_var, dtype=np.float64) + within_ridge * np.eye(mean.shape[0])
+        between = np.asarray(between_var, dtype=np.float64)
+        tot_inv = np.linalg.inv(between + within)
+        w2b_inv = np.linalg.inv(within + 2 * between)
+        w_inv = np.linalg.inv(within)
+        self.dim = mean.shape[0]
+        self.gamma = np.ascontiguousarray((-1 / 4) * (w2b_inv + w_inv) + (1 / 2) * tot_inv)
+        self.lam = np.ascontiguousarray((-1 / 4) * (w2b_inv - w_inv))
+        self.c = np.ascontiguousarray((w2b_inv - tot_inv).dot(mean))
+
+    @classmethod
+    def read_stats_ark(cls, path, within_ridge=5e-5):
+        from libs.support import kaldi_io
+        parts = {k: np.array(v, dtype=np.float64) for k, v in kaldi_io.read_vec_flt_ark(path)}
+        dim = parts["mean"].shape[0]
+        return cls(parts["mean"], parts["within_var"].reshape(dim, dim), parts["between_var"].reshape(dim, dim), within_ridge)
+
+    def score_trials(self, enroll, test, enroll_idx, test_idx):
+        """float64 device tensor [n_trials]."""
+        import torch
+        e, t = _dev(enroll, torch.float32), _dev(test, torch.float32)
+        ei, ti = _dev(enroll_idx, torch.int32, e.device), _dev(test_idx, torch.int32, e.device)
+        _check_index(ei, e.shape[0], "two_cov (enrol)")
+        _check_index(ti, t.shape[0], "two_cov (test)")
+        if e.shape[1] != self.dim or t.shape[1] != self.dim:
+            raise ValueError("two_cov: %d-dimensional model, vectors of %d / %d" % (self.dim, e.shape[1], t.shape[1]))
+        out = torch.empty(ei.shape[0], dtype=torch.float64, device=e.device)
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        with torch.cuda.device(e.device):
+            capi.check(capi.lib().asv_two_cov_trials(_ptr(e), e.shape[0], _ptr(t), t.shape[0], self.dim, dp(self.gamma), dp(self.lam), dp(self.c),
+                                                     _ptr(ei), _ptr(ti), ei.shape[0], _ptr(out), _stream(e)), "asv_two_cov_trials")
         return out
 
 

@@ -53,6 +53,9 @@ int         asv_device_count(int *count);
 /* arithmetic of the frame layers */
 #define ASV_PREC_F32   0   /* f32 activations/weights, v_mfma_f32_32x32x2_f32 (exact f32 fma chain) */
 #define ASV_PREC_BF16  1   /* bf16 activations/weights, v_mfma_f32_32x32x16_bf16, f32 accumulate   */
+#define ASV_PREC_F32X  2   /* f32 activations; the wide frame layers and the pooled layers run on the bf16 matrix cores with both
+                            * operands split into bf16 hi + lo halves (hi*hi + hi*lo + lo*hi, f32 accumulate): f32-grade results
+                            * (<= 1e-4 of the reference) at ~1/3 of the bf16 rate instead of the 1/16 of the f32-input MFMA */
 /* flags for asv_net_create */
 #define ASV_FLAG_REF_KERNELS 1u  /* run the plain-VALU self-check kernels instead of MFMA ones */
 #define ASV_FLAG_NO_FUSE     2u  /* disable epilogue fusions (stats pooling into the producer)  */
@@ -274,6 +277,20 @@ int asv_plda_transform(const float *x, int n, int dim, const float *mean, const 
 int asv_plda_llr_trials(const float *enroll, const float *test, int dim, const float *psi,
                         const int32_t *enroll_n, const int32_t *ei, const int32_t *ti, int n_trials,
                         float *scores, void *stream);
+/* Speaker-level enrolment (score/process.sh:156-167: `ivector-mean ark:spk2utt <vectors> ark:<spk means> ark,t:<num_utts>`):
+ * means[g] = (sum of x[order[k]], offsets[g] <= k < offsets[g+1], added in that order in f32) * (float)(1 / n_g) - Kaldi's
+ * AddVec / Scale sequence - and counts[g] = n_g, the num_utts that asv_plda_transform / asv_plda_llr_trials take
+ * (score/score.sh:99-121 --num-utts).  order: device int32 [offsets[n_groups]], offsets: device int32 [n_groups + 1]. */
+int asv_group_mean(const float *x, int n, int dim, const int32_t *order, const int32_t *offsets, int n_groups,
+                   float *means, int32_t *counts, void *stream);
+/* Two-covariance PLDA scorer (score/pyplda/gaussian-plda-scoring.py:23-50) per trial, in float64 like the reference:
+ *   s = e^T L t + t^T L e + e^T G e + t^T G t + (e + t)^T c          (k = 0 as in the reference)
+ * gamma (G) / lambda (L): HOST float64 [dim][dim], c: HOST float64 [dim] (CalculateVar's outputs, D x D algebra done once per
+ * model on the host); enroll / test: device f32 vectors; ei / ti: device int32 trial indices; scores: device float64 [n_trials].
+ * The quadratic and bilinear forms are four f64 GEMMs (vectors x G, vectors x L) + one wave per trial. */
+int asv_two_cov_trials(const float *enroll, int n_enroll, const float *test, int n_test, int dim, const double *gamma,
+                       const double *lambda, const double *c, const int32_t *ei, const int32_t *ti, int n_trials,
+                       double *scores, void *stream);
 /* Equal error rate (score/computeEER-like-Bosaris.py:50-91 semantics) of device scores with
  * device int32 labels (1 target / 0 non-target).  eer_percent / threshold are host outputs;
  * the call synchronises `stream`. */

@@ -70,7 +70,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "%dx%d_ctx%s" % (c[0], c[1], "_".join(map(str, c[2]))))
-@pytest.mark.parametrize("mode", ["f32_mfma", "f32_ref", "bf16_mfma", "bf16_ref"])
+@pytest.mark.parametrize("mode", ["f32_mfma", "f32_ref", "bf16_mfma", "bf16_ref", "f32x_mfma"])
 def test_tdnn_layer_vs_oracle(case, mode):
     from libs.amd import capi
     cin, cout, ctx, lens = case
@@ -82,12 +82,13 @@ def test_tdnn_layer_vs_oracle(case, mode):
     b = (0.1 * r.randn(cout)).astype(np.float32)
     scale = r.uniform(0.5, 1.5, cout).astype(np.float32)
     shift = (0.2 * r.randn(cout)).astype(np.float32)
-    prec = capi.PREC_F32 if mode.startswith("f32") else capi.PREC_BF16
+    prec = capi.PREC_F32X if mode.startswith("f32x") else (capi.PREC_F32 if mode.startswith("f32") else capi.PREC_BF16)
     flags = capi.FLAG_REF_KERNELS if mode.endswith("ref") else 0
     got = _tdnn_forward(x, offsets, w, b, ctx, "relu", scale, shift, False, prec, flags)
     want = _oracle_layer(x, offsets, w, b, ctx, "relu", scale, shift, False)
     err = rel_err(got, want)
-    tol = 2e-5 if mode.startswith("f32") else 2e-2       # bf16: 8-bit mantissa operands and outputs
+    # bf16: 8-bit mantissa operands and outputs; f32x: bf16 hi + lo operand halves (16 mantissa bits, the lo * lo term dropped)
+    tol = 2e-2 if mode.startswith("bf16") else 2e-5
     assert err < tol, "%s: rel err %g" % (mode, err)
 
 
@@ -163,3 +164,33 @@ def test_big_tile_kernel_matches_small_tile_kernel(case):
     assert rel_err(big, want) < 2e-2 and rel_err(small, want) < 2e-2
     assert rel_err(big, small) < 1e-2
     assert np.mean(big == small) > 0.97
+
+
+def test_f32x_split_kernel_is_f32_grade_on_hard_inputs():
+    """The f32x kernel (kernels_tdnn_x3.hip: w_hi x_hi + w_hi x_lo + w_lo x_hi on the bf16 matrix cores) against the float64
+    oracle on inputs that punish a plain bf16 product: a large common offset on every input channel (the information sits in
+    the low mantissa bits), wide dynamic range across channels, a 1536-deep contraction, ragged segments with one-frame
+    utterances, and the generic epilogue (tanh, BN before the activation)."""
+    from libs.amd import capi
+    r = np.random.RandomState(21)
+    lens = [200, 1, 64, 65, 300, 2]
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    cin, cout, ctx = 512, 512, [-3, 0, 3]
+    x = (r.randn(int(offsets[-1]), cin) * np.exp(r.uniform(-3, 3, cin)) + 40.0 * r.randn(cin)).astype(np.float32)
+    w = (r.randn(cout, cin, 7) / np.sqrt(3 * cin)).astype(np.float32)
+    b = (0.1 * r.randn(cout)).astype(np.float32)
+    scale = r.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = (0.2 * r.randn(cout)).astype(np.float32)
+    want = _oracle_layer(x, offsets, w, b, ctx, None, scale, shift, False)
+    got = _tdnn_forward(x, offsets, w, b, ctx, None, scale, shift, False, capi.PREC_F32X, 0)
+    exact = _tdnn_forward(x, offsets, w, b, ctx, None, scale, shift, False, capi.PREC_F32, 0)
+    plain = _tdnn_forward(x, offsets, w, b, ctx, None, scale, shift, False, capi.PREC_BF16, 0)
+    assert rel_err(exact, want) < 2e-6
+    assert rel_err(got, want) < 2e-5, rel_err(got, want)
+    assert rel_err(plain, want) > 20 * rel_err(got, want)              # the split is what buys the accuracy
+    for act, first in (("tanh", True), ("sigmoid", False)):
+        x2 = r.randn(int(offsets[-1]), 256).astype(np.float32)
+        w2 = (r.randn(256, 256, 1) / 16).astype(np.float32)
+        got = _tdnn_forward(x2, offsets, w2, b[:256], [0], act, scale[:256], shift[:256], first, capi.PREC_F32X, 0)
+        want = _oracle_layer(x2, offsets, w2, b[:256], [0], act, scale[:256], shift[:256], first)
+        assert rel_err(got, want) < 2e-5, (act, first)
