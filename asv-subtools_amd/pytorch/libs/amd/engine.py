@@ -21,9 +21,11 @@ PRECISIONS = {"f32": capi.PREC_F32, "fp32": capi.PREC_F32, "float32": capi.PREC_
 
 
 def default_precision():
-    """'f32' keeps the reference's 1e-4 embedding parity (exact-f32 MFMA); 'bf16' is the
-    throughput mode (bf16 MFMA, f32 accumulate, f32 pooled tail)."""
-    return os.environ.get("ASV_AMD_PRECISION", "f32").lower()
+    """'f32x' (the default): f32 storage, matrix products on the bf16 cores with both operands split into bf16 hi + lo
+    halves - within the reference's 1e-4 embedding gate and the 0.01 % EER gate at ~3x the rate of 'f32' (exact f32-input
+    MFMA, the bit-for-bit fma chain); 'bf16' is the throughput mode (bf16 storage and products, f32 accumulate, f32 pooled
+    tail; measured EER delta 0.024 % on the 50 000-trial gate, tests/test_gpu_eer_gate.py)."""
+    return os.environ.get("ASV_AMD_PRECISION", "f32x").lower()
 
 
 def default_flags():

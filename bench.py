@@ -1,23 +1,29 @@
 #!/usr/bin/env python3
 """Benchmark of the extraction hot path on MI355X.
 
-One "step" = one pass of the hot path over one batch of synthetic input that is already
-resident in HBM: BASELINE.json configs[1] - standard TDNN x-vector, 80-dim fbank,
-256 utterances x 200 frames per GPU, bf16 MFMA (f32 accumulate, f32 pooled tail).
-Weak scaling: every rank extracts its own 256-utterance shard; with N > 1 the embeddings are
-collected with one RCCL all-gather per step (the path's only exchange).
+One "step" = one pass of the hot path over one batch of synthetic input that is already resident in HBM:
+BASELINE.json configs[1] - standard TDNN x-vector, 80-dim fbank, 200-frame utterances, bf16 MFMA (f32 accumulate,
+f32 pooled tail) - 640 utterances per GPU per step (whole rounds of workgroups); the figure at the
+256 utterances configs[1] names is reported in the same line (`value_at_b256`, `roofline_at_b256`).
+Weak scaling: every rank extracts its own shard; with N > 1 the embeddings are collected with one RCCL all-gather per
+step (the path's only exchange).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]        (N > 1 without a launcher: bench.py spawns its own ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant
-kernel, hipEvent-timed inside libasv_amd.so on the extract stream, during the timed steps)
-and `cpu_baseline` (torch-CPU port of the reference's per-utterance path, N=1 only).
+Prints ONE JSON line on rank 0 (contract in the task statement): `value` from the MEDIAN of `repeats` back-to-back
+timed regions of exactly K steps each (one region is ~16 ms: the regions are repeated until >= 1 s has been measured),
+`roofline` (frame-level GEMM launches, hipEvent-timed inside libasv_amd.so on the extract stream during timed steps),
+`parity` (utterances of the timed batch against the CPU port of the reference), `cpu_baseline` (N = 1 only) and, at
+N = 1, `supplementary` records: the same workload in the f32x / f32 precision modes and the configs[2] / configs[4]
+extractors (ECAPA-TDNN C = 1024, ResNet34-SE).
 """
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,22 +34,35 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [os.path.join(REPO, "asv-subtools_amd", "pytorch"), REPO]
 
-PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # dense MFMA peaks, MI355X_MICROARCH.md
+# dense MFMA peaks, MI355X_MICROARCH.md.  f32x issues 3 bf16 matrix instructions per product: its roofline is the bf16 one / 3.
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "f32x": 2500.0 / 3.0}
+
+MODELS = {
+    "xvector": ("xvector.py", "Xvector(%d,10,training=False)", "BASELINE configs[1]: standard TDNN x-vector"),
+    "ecapa": ("ecapa_tdnn_xvector.py", "ECAPA_TDNN(%d,10,training=False)", "BASELINE configs[2]: ECAPA-TDNN C=1024"),
+    "resnet": ("resnet_xvector.py", "ResNetXvector(%d,10,training=False,resnet_params={'use_se':True,'se_ratio':4,'full_pre_activation':False},"
+               "fc2_params={'nonlinearity':'','bn_params':{'momentum':0.5,'affine':False,'track_running_stats':True}})", "BASELINE configs[4] extractor: ResNet34-SE"),
+}
+KERNEL_NAMES = {"xvector": "tdnn_gemm_big3_kernel (the frame-level layers tdnn1-5: 5 launches per step, the last one with the fused pooling epilogue)",
+                "ecapa": "frame-level GEMM launches (tdnn_gemm_big3_kernel for the wide layers, res2_chain / tdnn_gemm_kernel for the 128-channel ones)",
+                "resnet": "frame-level GEMM launches (grid_conv_narrow_kernel / tdnn_gemm_kernel)"}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32", "f32x"])
     ap.add_argument("--batch", type=int, default=None,
                     help="utterances per GPU per step (default: 640 for the x-vector - 640 x 204 padded rows = 1020 row tiles of 128, two "
                          "column tiles each, fill the 512 workgroup slots of the device in whole rounds, +15 %% over 256; 256 for the others)")
     ap.add_argument("--frames", type=int, default=None, help="frames per utterance (default: 200; 300 for --model ecapa, BASELINE configs[2])")
     ap.add_argument("--feat-dim", type=int, default=80)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="the K-step timed region is repeated until this much time has been measured")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel hipEvents in the timed region")
+    ap.add_argument("--no-supplementary", action="store_true", help="skip the b256 / f32x / f32 / ECAPA / ResNet sub-records")
     ap.add_argument("--event-stride", type=int, default=8, help="record the per-GEMM hipEvents on every k-th timed step")
     ap.add_argument("--per-op", action="store_true", help="also print a per-op timing table to stderr")
     ap.add_argument("--settle-seconds", type=float, default=0.5,
@@ -52,24 +71,65 @@ def parse():
     ap.add_argument("--from-wav", action="store_true",
                     help="start every step from 16-bit PCM in HBM: asv_fbank_pcm16 (log-mel, --feat-dim bins) + asv_cmvn + extraction "
                          "(SURVEY.md 8(f) rank 2; the headline metric starts from feature matrices, this is a supplementary line)")
-    ap.add_argument("--model", default="xvector", choices=["xvector", "ecapa", "resnet"],
+    ap.add_argument("--model", default="xvector", choices=sorted(MODELS),
                     help="xvector = BASELINE configs[1] (the default, the contract's workload); ecapa = configs[2] (C=1024, 300 frames); "
                          "resnet = the configs[4] extractor (ResNet34-SE)")
     return ap.parse_args()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: re-execute under torch.distributed.run, one rank
+    per GPU, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+class Workload(object):
+    """One model in one precision mode on this rank's device, with a device-resident synthetic batch."""
+
+    def __init__(self, args, kind, precision, batch, frames, rank, dev):
+        import numpy as np
+        import torch
+        import libs.support.utils as utils
+        from libs.amd import synth
+        self.kind, self.precision, self.B, self.T, self.D = kind, precision, batch, frames, args.feat_dim
+        blueprint, creation, self.title = MODELS[kind]
+        self.creation = creation % args.feat_dim
+        model = utils.create_model_from_py(os.path.join(REPO, "asv-subtools_amd", "pytorch", "model", blueprint), self.creation)
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        self.sd = synth.synth_state_dict(shapes, 0)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in self.sd.items()})
+        model.eval()
+        model.cuda()
+        model.amd_precision = precision
+        self.model, self.eng = model, model._amd_engine()
+        self.mats = [synth.synth_feats(frames, self.D, 10_000 * rank + i) for i in range(batch)]
+        self.feats = torch.from_numpy(np.concatenate(self.mats, axis=0)).to(dev)
+        self.offsets = (np.arange(batch + 1) * frames).astype(np.int32)
+        self.dev = dev
+
+    def extract(self, out):
+        self.eng.extract_device(self.feats, self.offsets, out=out)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     import numpy as np
     import torch
     import torch.distributed as dist
-    import libs.support.utils as utils
     from libs.amd import synth
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world)
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a ROCm device"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -77,168 +137,224 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)      # "nccl" is RCCL on ROCm
 
-    # ---- model: the reference's standard x-vector blueprint, synthetic weights ---------------
-    if args.model == "xvector":
-        blueprint, creation = "xvector.py", "Xvector(%d,10,training=False)" % args.feat_dim
-    elif args.model == "ecapa":
-        blueprint, creation = "ecapa_tdnn_xvector.py", "ECAPA_TDNN(%d,10,training=False)" % args.feat_dim
-    else:
-        blueprint = "resnet_xvector.py"
-        creation = ("ResNetXvector(%d,10,training=False,resnet_params={'use_se':True,'se_ratio':4,'full_pre_activation':False},"
-                    "fc2_params={'nonlinearity':'','bn_params':{'momentum':0.5,'affine':False,'track_running_stats':True}})" % args.feat_dim)
-    model = utils.create_model_from_py(os.path.join(REPO, "asv-subtools_amd", "pytorch", "model", blueprint), creation)
-    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-    sd = synth.synth_state_dict(shapes, 0)
-    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
-    model.eval()
-    model.cuda()
-    model.amd_precision = args.precision
-    eng = model._amd_engine()
-
-    # ---- synthetic batch, device resident ----------------------------------------------------
     if args.frames is None:
         args.frames = 300 if args.model == "ecapa" else 200
     if args.batch is None:
         args.batch = 640 if args.model == "xvector" else 256
-    B, T, D = args.batch, args.frames, args.feat_dim
-    mats = [synth.synth_feats(T, D, 10_000 * rank + i) for i in range(B)]
-    feats = torch.from_numpy(np.concatenate(mats, axis=0)).to(dev)
-    offsets = (np.arange(B + 1) * T).astype(np.int32)
-    # two output / gather buffer pairs: the all-gather of step i runs on RCCL's stream while step i+1 computes
-    outs = [torch.empty((B, eng.embed_dim), dtype=torch.float32, device=dev) for _ in range(2)]
-    gathered = [torch.empty((world * B, eng.embed_dim), dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
-    pending = [None, None]
-    counter = [0]
 
-    if args.from_wav:
-        from libs.amd import frontend
-        n_samp = 400 + (T - 1) * 160                                # 25 ms windows, 10 ms shift at 16 kHz: exactly T frames
-        wave_dev = torch.from_numpy(np.concatenate([synth.synth_wave(n_samp, 10_000 * rank + i).astype(np.int16) for i in range(B)])).to(dev)
-        sample_off = np.arange(B + 1, dtype=np.int64) * n_samp
-        fe_kw = dict(num_mel_bins=D, energy_floor=0.0, mean_norm=True)
+    def measure(wl, steps, warmup, min_seconds, profile, collective, per_op=False, from_wav=False):
+        """settle -> warmup -> `repeats` timed regions of exactly `steps` steps (barrier + synchronize on both sides, MAX over
+        ranks); returns the record of the median region."""
+        eng, B = wl.eng, wl.B
+        # two output / gather buffer pairs: the all-gather of step i runs on RCCL's stream while step i+1 computes
+        outs = [torch.empty((B, eng.embed_dim), dtype=torch.float32, device=dev) for _ in range(2)]
+        gathered = [torch.empty((world * B, eng.embed_dim), dtype=torch.float32, device=dev) for _ in range(2)] if collective else None
+        pending, counter = [None, None], [0]
+        if from_wav:
+            from libs.amd import frontend
+            n_samp = 400 + (wl.T - 1) * 160                             # 25 ms windows, 10 ms shift at 16 kHz: exactly T frames
+            wave_dev = torch.from_numpy(np.concatenate([synth.synth_wave(n_samp, 10_000 * rank + i).astype(np.int16) for i in range(B)])).to(dev)
+            sample_off = np.arange(B + 1, dtype=np.int64) * n_samp
+            fe_kw = dict(num_mel_bins=wl.D, energy_floor=0.0, mean_norm=True)
 
-    def extract_once(out):
-        if args.from_wav:
-            f, _ = frontend.fbank_device(wave_dev, sample_off, **fe_kw)
-            eng.extract_device(f, offsets, out=out)
-        else:
-            eng.extract_device(feats, offsets, out=out)
+        def extract_once(out):
+            if from_wav:
+                f, _ = frontend.fbank_device(wave_dev, sample_off, **fe_kw)
+                eng.extract_device(f, wl.offsets, out=out)
+            else:
+                wl.extract(out)
 
-    def step():
-        k = counter[0] & 1
-        counter[0] += 1
-        if pending[k] is not None:                                  # buffer pair k is free once its gather has finished
-            pending[k].wait()                                       # (stream-side wait, the host does not block)
-            pending[k] = None
-        extract_once(outs[k])
-        if world > 1:
-            pending[k] = dist.all_gather_into_tensor(gathered[k], outs[k], async_op=True)
-
-    def barrier():
-        for k in range(2):
-            if pending[k] is not None:
-                pending[k].wait()
+        def step():
+            k = counter[0] & 1
+            counter[0] += 1
+            if pending[k] is not None:                                  # buffer pair k is free once its gather has finished
+                pending[k].wait()                                       # (stream-side wait, the host does not block)
                 pending[k] = None
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
+            extract_once(outs[k])
+            if collective:
+                pending[k] = dist.all_gather_into_tensor(gathered[k], outs[k], async_op=True)
+
+        def barrier():
+            for k in range(2):
+                if pending[k] is not None:
+                    pending[k].wait()
+                    pending[k] = None
             torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+                torch.cuda.synchronize(dev)
 
-    def timed(n, sample_events=0):
-        """sample_events = k > 0: per-GEMM hipEvents are recorded on every k-th step of the timed region
-        (each recorded event is a barrier packet between kernels; sampling keeps that perturbation small)."""
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(n):
-            if sample_events:
-                eng.set_profiling(4 if i % sample_events == 0 else 0)
+        def timed(n, sample_events=0):
+            """sample_events = k > 0: per-GEMM hipEvents are recorded on every k-th step of the timed region
+            (each recorded event is a barrier packet between kernels; sampling keeps that perturbation small)."""
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(n):
+                if sample_events:
+                    eng.set_profiling(4 if i % sample_events == 0 else 0)
+                step()
+            barrier()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dt], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            return dt
+
+        t_settle = time.perf_counter()
+        while time.perf_counter() - t_settle < args.settle_seconds:       # untimed: bring the device to its steady clock
+            for _ in range(50):
+                extract_once(outs[0])                                    # local work only: the count differs between ranks,
+            torch.cuda.synchronize(dev)                                   # so no collective may be issued here
+        for _ in range(warmup):
             step()
         barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
-
-    t_settle = time.perf_counter()
-    while time.perf_counter() - t_settle < args.settle_seconds:       # untimed: bring the device to its steady clock
-        for _ in range(50):
-            extract_once(outs[0])                                    # local work only: the count differs between ranks,
-        torch.cuda.synchronize(dev)                                   # so no collective may be issued here
-    for _ in range(args.warmup):
-        step()
-    barrier()
-
-    profile = not args.no_profile
-    if profile:
-        eng.set_profiling(4)                                        # one hipEvent pair around each run of frame-level GEMM launches
-        # create the whole event pool outside the timed region: one profiled step per step that will be sampled
-        # (hipEventCreate inside the timed steps cost 5-30 % of the measured rate, erratically)
-        for _ in range((args.steps + args.event_stride - 1) // args.event_stride):
-            step()
-        barrier(); eng.get_profile()
-    dt = timed(args.steps, sample_events=args.event_stride if profile else 0)
-    rows = eng.get_profile() if profile else []
-    eng.set_profiling(False)
-    if args.per_op and rank == 0:
-        eng.set_profiling(2)
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize(dev)
-        ops = eng.graph.ops
-        for r in sorted(eng.get_profile(), key=lambda r: r["op_index"]):
-            i = r["op_index"]
-            desc = ""
-            if 0 <= i < len(ops) and ops[i].kind == "tdnn":
-                desc = "%d->%d taps=%s" % (ops[i].inp.channels, ops[i].out.channels, ops[i].taps)
-            us = 1e3 * r["total_ms"] / max(r["launches"], 1)
-            tf = r["flops"] / (r["total_ms"] * 1e-3) / 1e12 if r["total_ms"] > 0 else 0.0
-            print("  op %3d %-14s %-28s %9.1f us  %8.1f TFLOP/s" % (i, r["name"], desc, us, tf), file=sys.stderr)
+        # one probe region decides how many regions make up min_seconds (the same number on every rank)
+        probe = timed(steps)
+        repeats = max(3, int(min_seconds / max(probe, 1e-6)) + 1)
+        stride = max(1, args.event_stride)
+        rows = []
+        if profile:
+            eng.set_profiling(4)                                        # one hipEvent pair around each run of frame-level GEMM launches
+            # create the whole event pool outside the timed regions: one profiled step per step that will be sampled
+            # (hipEventCreate inside the timed steps cost 5-30 % of the measured rate, erratically)
+            for _ in range((steps + stride - 1) // stride):
+                step()
+            barrier(); eng.get_profile()
+        # every 4th region samples hipEvents; the others run bare.  Both kinds are K-step regions under the contract's timing.
+        dts, dts_sampled = [], []
+        for r in range(repeats):
+            sampled = profile and (r % 4 == 0)
+            dt = timed(steps, sample_events=stride if sampled else 0)
+            (dts_sampled if sampled else dts).append(dt)
+            if sampled:
+                rows.extend(eng.get_profile())
         eng.set_profiling(False)
-    dt_plain = timed(args.steps)                                      # same steps without event recording, for reference
+        allr = sorted(dts + dts_sampled)
+        med = allr[len(allr) // 2]
+        rec = {"value": round(world * B * steps / med, 1), "ms_per_step": round(1e3 * med / steps, 4), "repeats": len(allr),
+               "timed_seconds": round(sum(allr), 3),
+               "ms_per_step_min_max": [round(1e3 * allr[0] / steps, 4), round(1e3 * allr[-1] / steps, 4)]}
+        if dts and dts_sampled:
+            rec["value_without_event_recording"] = round(world * B * steps / sorted(dts)[len(dts) // 2], 1)
+        gemm_ms = sum(r["total_ms"] for r in rows if r["name"] == "tdnn_gemm")
+        gemm_fl = sum(r["flops"] for r in rows if r["name"] == "tdnn_gemm")
+        gemm_n = sum(r["launches"] for r in rows if r["name"] == "tdnn_gemm")
+        if gemm_ms > 0:
+            achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12
+            peak = PEAK_TFLOPS[wl.precision]
+            per_frame, per_utt = eng.graph.flops_per_frame()
+            sampled_steps = len(dts_sampled) * ((steps + stride - 1) // stride)
+            rec["roofline"] = {"bound": "mfma", "kernel": KERNEL_NAMES[wl.kind], "achieved": round(achieved, 2), "peak": round(peak, 1),
+                               "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                               "launches": gemm_n, "avg_launch_us": round(1e3 * gemm_ms / gemm_n, 2),
+                               "algorithmic_gflop_per_utt": round((per_frame * wl.T + per_utt) / 1e9, 4), "sampled_steps": sampled_steps,
+                               "gemm_ms_per_step": round(gemm_ms / sampled_steps, 4)}
+        if per_op and rank == 0:
+            eng.set_profiling(2)
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize(dev)
+            ops = eng.graph.ops
+            for r in sorted(eng.get_profile(), key=lambda r: r["op_index"]):
+                i = r["op_index"]
+                desc = ""
+                if 0 <= i < len(ops) and ops[i].kind == "tdnn":
+                    desc = "%d->%d taps=%s" % (ops[i].inp.channels, ops[i].out.channels, ops[i].taps)
+                us = 1e3 * r["total_ms"] / max(r["launches"], 1)
+                tf = r["flops"] / (r["total_ms"] * 1e-3) / 1e12 if r["total_ms"] > 0 else 0.0
+                print("  op %3d %-14s %-28s %9.1f us  %8.1f TFLOP/s" % (i, r["name"], desc, us, tf), file=sys.stderr)
+            eng.set_profiling(False)
+            barrier()
+        return rec
 
-    utts = world * B * args.steps
-    value = utts / dt
+    def parity_of(wl, n=4):
+        """A few utterances of the timed batch against the CPU port of the reference's call sequence (checker leg only;
+        x-vector only - the port restates model/xvector.py)."""
+        from oracle import torch_cpu_port as P
+        ex = P.XvectorCpu(wl.sd, "far")
+        pos = [0, 1, wl.B // 2, wl.B - 1][:n]
+        got = wl.eng.extract_device(wl.feats, wl.offsets).cpu().numpy()[pos]
+        want = np.stack([ex.extract_embedding(wl.mats[i]).numpy() for i in pos])
+        rel = float(np.abs(got - want).max() / np.abs(want).max())
+        cos = float(((got * want).sum(1) / np.linalg.norm(got, axis=1) / np.linalg.norm(want, axis=1)).min())
+        return {"max_rel_err": float("%.3g" % rel), "min_cosine": round(cos, 6), "n": len(pos), "against": "oracle/torch_cpu_port.py (the reference's torch CPU call "
+                "sequence, pinned to the reference's own outputs by tests/test_oracle_golden.py)", "metric": "max|a-b| / max|b| over the sampled embeddings"}
+
+    # ---- the headline workload ------------------------------------------------------------------
+    wl = Workload(args, args.model, args.precision, args.batch, args.frames, rank, dev)
+    head = measure(wl, args.steps, args.warmup, args.min_seconds, not args.no_profile, world > 1, per_op=args.per_op, from_wav=args.from_wav)
     res = {
         "metric": "utterances/sec (200-frame) embedding extraction + EER, 1/2/4/8 MI355X",
-        "value": round(value, 1), "unit": "utterances/s",
+        "value": head["value"], "unit": "utterances/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * dt / args.steps, 4),
+        "ms_per_step": head["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.precision, "data": "synthetic",
         "config": {"workload": "%s: %s, %d-dim fbank, %d utterances x %d frames per GPU per step, "
-                               "%s resident in HBM, f32 embeddings out%s" % ({"xvector": "BASELINE configs[1]: standard TDNN x-vector", "ecapa": "BASELINE configs[2]: ECAPA-TDNN C=1024",
-                                                                                   "resnet": "BASELINE configs[4] extractor: ResNet34-SE"}[args.model],
-                                                                                  creation, D, B, T, "16-bit PCM (fbank + CMN computed on the device in every step)" if args.from_wav else "features",
-                                                                                  ", + RCCL all-gather of embeddings" if world > 1 else ""),
-                   "global_batch_utts": world * B, "frames_per_utt": T, "parallelism": "utterance shards x%d" % world},
-        "value_without_event_recording": round(utts / dt_plain, 1),
+                               "%s resident in HBM, f32 embeddings out%s" % (wl.title, wl.creation, wl.D, wl.B, wl.T,
+                                                                             "16-bit PCM (fbank + CMN computed on the device in every step)" if args.from_wav else "features",
+                                                                             ", + RCCL all-gather of embeddings" if world > 1 else ""),
+                   "global_batch_utts": world * wl.B, "frames_per_utt": wl.T, "parallelism": "utterance shards x%d" % world},
+        "timing": {"regions": head["repeats"], "steps_per_region": args.steps, "timed_seconds": head["timed_seconds"], "value_from": "median region",
+                   "ms_per_step_min_max": head["ms_per_step_min_max"]},
         "settle_seconds": args.settle_seconds,
     }
-    gemm = next((r for r in rows if r["name"] == "tdnn_gemm"), None)
-    if gemm and gemm["total_ms"] > 0:
-        achieved = gemm["flops"] / (gemm["total_ms"] * 1e-3) / 1e12
-        peak = PEAK_TFLOPS[args.precision]
-        per_frame, per_utt = eng.graph.flops_per_frame()
-        kname = {"xvector": "tdnn_gemm_big3_kernel (the frame-level layers tdnn1-5: 5 launches per step, the last one with the fused pooling epilogue)",
-                 "ecapa": "frame-level GEMM launches (tdnn_gemm_big3_kernel for the wide layers, tdnn_gemm_kernel for the 128-channel ones)",
-                 "resnet": "frame-level GEMM launches (grid_conv_narrow_kernel / tdnn_gemm_kernel)"}[args.model]
-        res["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": peak,
-                           "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
-                           "launches": gemm["launches"], "avg_launch_us": round(1e3 * gemm["total_ms"] / gemm["launches"], 2),
-                           "algorithmic_gflop_per_utt": round((per_frame * T + per_utt) / 1e9, 4)}
-        sampled_steps = (args.steps + args.event_stride - 1) // args.event_stride
-        res["roofline"]["sampled_steps"] = sampled_steps
-        res["gemm_ms_per_step"] = round(gemm["total_ms"] / sampled_steps, 4)
+    if "value_without_event_recording" in head:
+        res["value_without_event_recording"] = head["value_without_event_recording"]
+    if "roofline" in head:
+        res["roofline"] = head["roofline"]
+        res["gemm_ms_per_step"] = head["roofline"].pop("gemm_ms_per_step")
         pmc = os.path.join(REPO, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc) and args.model == "xvector":
-            # HBM traffic of the dominant kernel from a separate rocprofv3 --pmc pass of this same command
-            # (tools/pmc_summary.py; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
+        if os.path.exists(pmc) and args.model == "xvector" and args.precision == "bf16":
+            # NOT measured in this run: HBM traffic of the dominant kernel from the committed rocprofv3 --pmc passes of this
+            # same command (tools/collect_profiles.sh -> tools/pmc_summary.py; FETCH_SIZE doubled as MI355X_MICROARCH.md
+            # prescribes for gfx950)
             with open(pmc) as f:
                 info = json.load(f)
             res["roofline"]["traffic"] = info.get("traffic_bytes_per_launch")
-            res["roofline"]["traffic_source"] = info.get("source")
+            res["roofline"]["traffic_source"] = "static: profiles/pmc_summary.json (" + str(info.get("source")) + "); not re-measured by bench.py"
+
+    if rank == 0 and args.model == "xvector":
+        res["parity"] = parity_of(wl)
+    if rank == 0 and world == 1 and not args.no_supplementary and args.model == "xvector" and not args.from_wav:
+        # ---- supplementary records, same harness (shorter: 0.4 s of timed regions each) --------------
+        sup = {}
+        w256 = Workload(args, "xvector", args.precision, 256, args.frames, rank, dev)
+        r = measure(w256, args.steps, 2, 0.4, not args.no_profile, False)
+        res["value_at_b256"] = r["value"]
+        if "roofline" in r:
+            r["roofline"].pop("gemm_ms_per_step", None)
+            res["roofline_at_b256"] = {k: r["roofline"][k] for k in ("achieved", "peak", "unit", "frac", "avg_launch_us")}
+        res["config"]["configs1_batch_note"] = "BASELINE configs[1] names batch=256: value_at_b256 / roofline_at_b256 are that figure; `value` uses 640 utterances per step"
+        del w256
+        for prec in ("f32x", "f32"):
+            if prec == args.precision:
+                continue
+            w = Workload(args, "xvector", prec, args.batch, args.frames, rank, dev)
+            r = measure(w, args.steps, 2, 0.4, not args.no_profile, False)
+            rec = {"value": r["value"], "unit": "utterances/s", "ms_per_step": r["ms_per_step"], "parity": parity_of(w)}
+            if "roofline" in r:
+                rec["gemm_tflops"] = r["roofline"]["achieved"]
+                rec["frac_of_mode_peak"] = r["roofline"]["frac"]
+                rec["mode_peak_tflops"] = r["roofline"]["peak"]
+            sup["xvector_" + prec] = rec
+            del w
+        for kind, key, frames in (("ecapa", "ecapa_c3", 300), ("resnet", "resnet_c5", 200)):
+            try:
+                w = Workload(args, kind, args.precision, 256, frames, rank, dev)
+                r = measure(w, max(4, args.steps // 4), 2, 0.4, not args.no_profile, False)
+                rec = {"value": r["value"], "unit": "utterances/s", "ms_per_step": r["ms_per_step"], "workload": "%s: %s, 256 utterances x %d frames, %s" % (w.title, w.creation, frames, args.precision)}
+                if "roofline" in r:
+                    rec["gemm_tflops"] = r["roofline"]["achieved"]
+                    rec["frac"] = r["roofline"]["frac"]
+                    rec["algorithmic_gflop_per_utt"] = r["roofline"]["algorithmic_gflop_per_utt"]
+                    rec["whole_step_tflops"] = round(rec["algorithmic_gflop_per_utt"] * r["value"] / 1e3, 1)
+                sup[key] = rec
+                del w
+            except Exception as e:                                        # a supplementary record must never take the headline down
+                sup[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+        res["supplementary"] = sup
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         from oracle import torch_cpu_port as P                        # cpu_baseline leg only
@@ -246,19 +362,21 @@ def main():
         # convolutions: probe a few thread counts briefly and time the sample with the best one
         if args.model != "xvector":
             raise SystemExit("cpu_baseline is implemented for the default workload only; pass --cpu-seconds 0 with --model %s" % args.model)
-        ex = P.XvectorCpu(sd, "far")
+        ex = P.XvectorCpu(wl.sd, "far")
         host = os.cpu_count() or 1
         best, cores = 0.0, 1
         for th in sorted({1, min(8, host), min(16, host), min(32, host)}):
             torch.set_num_threads(th)
-            ups, _, _ = P.time_cpu_baseline(ex, mats[:8], budget_s=min(1.5, args.cpu_seconds / 6.0), min_utts=2)
+            ups, _, _ = P.time_cpu_baseline(ex, wl.mats[:8], budget_s=min(1.5, args.cpu_seconds / 6.0), min_utts=2)
             if ups > best:
                 best, cores = ups, th
         torch.set_num_threads(cores)
-        ups, n, secs = P.time_cpu_baseline(ex, mats[:64], budget_s=args.cpu_seconds)
+        ups, n, secs = P.time_cpu_baseline(ex, wl.mats[:64], budget_s=args.cpu_seconds)
         res["cpu_baseline"] = {"value": round(ups, 2), "unit": "utterances/s", "cores": cores, "kind": "port",
                                "sample": "%d utterances of the same %dx%d workload, batch=1 loop as pipeline/onestep/extract_embeddings.py:73-83, "
-                                         "torch %s CPU with the best of {1,8,16,32} threads on a %d-core host, %.1f s" % (n, T, D, torch.__version__, host, secs)}
+                                         "torch %s CPU with the best of {1,8,16,32} threads on a %d-core host, %.1f s" % (n, wl.T, wl.D, torch.__version__, host, secs),
+                               "why_port": "the reference tree cannot travel to the GPU box; oracle/torch_cpu_port.py issues the reference's exact torch "
+                                           "calls (dense masked conv1d, in-place ReLU, eval batch_norm, two-pass pooling) and is pinned to the reference's outputs"}
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:
