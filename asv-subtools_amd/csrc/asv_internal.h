@@ -123,6 +123,20 @@ int launch_tdnn_big_variant(const TdnnKernelParams &p, int variant, hipStream_t 
 bool tdnn_big3_supported(const TdnnKernelParams &p, bool bf16, bool out_f32);
 int launch_tdnn_big3(const TdnnKernelParams &p, hipStream_t s);
 int launch_tdnn_big3_variant(const TdnnKernelParams &p, int variant, hipStream_t s);
+// tdnn -> [1-tap 512 -> 512]* -> 1-tap + fused statistics pooling in one kernel, the 128 x 512 intermediate tiles resident in
+// LDS (kernels_tdnn_chain.hip).  Weight fragments as for the variant-3 kernel.
+constexpr int kChainWidth = 512;
+struct TdnnChainLayer {
+  const void *wfrag; const float *bias, *scale, *shift;   // scale / shift may be nullptr (1, 0)
+  int relu, cout_pad;
+};
+struct TdnnChainParams {
+  const void *x; int ldx, rows, cin_pad, n_taps; int taps[ASV_MAX_TAPS];     // input of the first layer (bf16 rows)
+  TdnnChainLayer first; int n_mid; TdnnChainLayer mid[2]; TdnnChainLayer last;
+  float *pool_partial; int pool_slots, ld_partial; const int32_t *row_seg;    // as in TdnnKernelParams
+  unsigned long long *dbg;      // developer aid (ASV_AMD_CHAIN_DBG=1): [workgroup][wave][16] s_memtime stamps at the phase boundaries, or nullptr
+};
+int launch_tdnn_chain(const TdnnChainParams &p, hipStream_t s);
 void pack_tdnn_weight_frags(const float *w, int out_ch, int in_ch, int tot_ctx, int left_ctx, const int *taps, int n_taps,
                             int cout_pad, int cin_pad, uint16_t *dst, uint16_t *dst_lo = nullptr);
 // f32-grade split-bf16 kernel of the f32x precision mode (kernels_tdnn_x3.hip): f32 activations, hi / lo weight fragments

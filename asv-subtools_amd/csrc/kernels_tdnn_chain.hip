@@ -1,0 +1,395 @@
+// Back-to-back TDNN layers of one 128-frame tile in ONE kernel: layer A (any taps, -> 512 channels), up to two
+// 1-tap 512 -> 512 layers, and a last 1-tap layer (-> any width) whose output goes straight into the fused
+// statistics pooling.  For the standard x-vector this is tdnn3 -> tdnn4 -> tdnn5 -> StatisticsPooling
+// (model/xvector.py:77-98; components.py:107-149, 410-431; pooling.py:58-67): 65 % of the network's FLOPs, of which
+// nothing but the per-tile pooling moments reaches HBM.
+//
+// Why: a 1-tap 512 -> 512 layer is a K = 512 GEMM - per 128 x 256 tile a 14 us main loop under 5.6 us of prologue +
+// epilogue, with a workgroup barrier every 64 channels for the LDS window ring (profiles/r1_*: 0.32 of the bf16 MFMA peak
+// against 0.43 for the 3-tap layers).  Here the 128 x 512 bf16 output tile of a layer stays in LDS (128 KiB, "Y") and is
+// the B operand of the next layer's MFMAs directly:
+//   * phase 1 (layer A): kernels_tdnn_v3.hip's loop - feature window through a 4-stage LDS-DMA ring (which lives inside
+//     the not yet used Y region), weight fragments from L2 - with 8 waves, each 128 frames x 64 channels; epilogue
+//     (bias, ReLU, folded BN, bf16) writes Y;
+//   * middle layers: K = 512 comes from Y - no LDS-DMA, no ring, NO barrier in the main loop; one barrier before the
+//     epilogue overwrites Y in place;
+//   * last layer: the output channels are cut into 64-channel units, unit u = pass * 8 + wave; a wave runs its units
+//     back to back without ever meeting the others, so the matrix work of one wave of a SIMD overlaps the pooling
+//     epilogue of its partner.  The epilogue transposes raw accumulators through a wave-private 4 KiB scratch
+//     (16 frames x 64 channels) and accumulates pivoted moments per utterance (lane = channel), as the POOL epilogue
+//     of kernels_tdnn_v3.hip does; pool_finish_kernel merges the tiles.
+// One workgroup (512 threads, 160 KiB LDS) per CU.
+#include "device_utils.h"
+
+namespace asv {
+namespace {
+
+constexpr int CM = 128;                   // frames per workgroup
+constexpr int CN = kChainWidth;           // channels of the resident tile (512)
+constexpr int CBK = 64;
+constexpr int CROWB = 128;                // window row: 64 bf16
+constexpr int CSTAGES = 4;
+constexpr int CWIN = CM + 2 * kHalo;      // 136
+constexpr int CSTAGE = CWIN * CROWB;      // 17408 B
+constexpr int CGROUPS = CWIN / 8;         // 17 eight-row DMA pieces
+constexpr int CPIECES = (CGROUPS + 7) / 8;   // 3 per wave
+constexpr int YROWB = CN * 2;             // 1024 B per Y row
+constexpr int Y_BYTES = CM * YROWB;       // 131072
+constexpr int SCR_OFF = Y_BYTES;          // 32 KiB: epilogue constants (phases 1, 2) | 8 x 4 KiB pooling scratch (last phase)
+constexpr int CHAIN_LDS = Y_BYTES + 32768;
+static_assert(CSTAGES * CSTAGE <= Y_BYTES, "the window ring lives inside the Y region");
+static_assert(CHAIN_LDS <= 163840, "160 KiB of LDS per CU");
+
+typedef __attribute__((address_space(3))) unsigned char chain_lds_byte;
+
+__device__ __forceinline__ int cswz(int row, int slot) { return slot ^ ((row >> 1) & 7); }
+
+__device__ __forceinline__ void chain_glds16_s(const void *sbase, uint32_t voff, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_dst)
+      : "memory");
+}
+
+__global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[CHAIN_LDS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // 0..7: channel slice of phases 1-2, unit index of the last
+  const int lr = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.x * CM;
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(chain_lds_byte *)lds);
+  float *par = reinterpret_cast<float *>(lds + SCR_OFF);            // bias[512] | scale[512] | shift[512] of the layer in flight
+
+  int n_stamp = 0;
+  auto stamp = [&]() {
+    if (p.dbg != nullptr && lane == 0 && n_stamp < 16) p.dbg[((size_t)blockIdx.x * 8 + wave) * 16 + n_stamp] = __builtin_amdgcn_s_memtime();
+    ++n_stamp;
+  };
+  stamp();                                                       // 0: start
+  auto stage_params = [&](const TdnnChainLayer &L) {
+    if (tid < 384) {
+      const int which = tid >> 7, idx = (tid & 127) * 4;
+      float4 v = (which == 1) ? make_float4(1.f, 1.f, 1.f, 1.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float *src = (which == 0) ? L.bias : (which == 1 ? L.scale : L.shift);
+      if (src != nullptr) v = *reinterpret_cast<const float4 *>(src + idx);
+      *reinterpret_cast<float4 *>(par + which * CN + idx) = v;
+    }
+  };
+
+  uint4 wf[4][2];
+  f32x16_t acc[4][2];
+  struct XFrags { uint4 x[4]; };
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  };
+  auto mma2 = [&](const XFrags &f, int kg, int j, int i0) {
+#pragma unroll
+    for (int i = i0; i < i0 + 2; ++i)
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[kg][j]), __builtin_bit_cast(bf16x8_t, f.x[i]), acc[i][j], 0, 0, 0);
+  };
+
+  // ================================ phase 1: layer A through the window ring ================================
+  stage_params(p.first);
+  {
+    const unsigned char *xg = reinterpret_cast<const unsigned char *>(p.x);
+    const size_t x_pitch = (size_t)p.ldx * 2;
+    const int g_row = lane >> 3, g_slot = lane & 7;
+    const int nchunks = p.cin_pad / CBK;
+    const int n_taps = p.n_taps;
+    uint32_t a_off[CPIECES];
+#pragma unroll
+    for (int i = 0; i < CPIECES; ++i) {
+      const int grp = min(wave + i * 8, CGROUPS - 1);
+      const int w = grp * 8 + g_row;
+      const int row = min(max(m0 - kHalo + w, 0), p.rows - 1);
+      a_off[i] = (uint32_t)row * (uint32_t)x_pitch + (uint32_t)cswz(w, g_slot) * 16u;
+    }
+    auto issue_A = [&](int c, int st) {
+      const unsigned char *base = xg + (size_t)c * (CBK * 2);
+#pragma unroll
+      for (int i = 0; i < CPIECES; ++i) {
+        const int grp = min(wave + i * 8, CGROUPS - 1);
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + st * CSTAGE + grp * 1024);
+        chain_glds16_s(base, a_off[i], dst);
+      }
+    };
+    const size_t frag_stride = (size_t)n_taps * nchunks * 4096;
+    const unsigned char *wf_base0 = reinterpret_cast<const unsigned char *>(p.first.wfrag) + (size_t)(wave * 2) * frag_stride + (size_t)lane * 16;
+    const unsigned char *wf_base1 = wf_base0 + frag_stride;
+    auto load_x1 = [&](const unsigned char *Ab, int d, int kg, int i, XFrags &f) {
+      const int w = i * 32 + lr + kHalo + d;
+      f.x[i] = *reinterpret_cast<const uint4 *>(Ab + w * CROWB + cswz(w, kg * 2 + lh) * 16);
+    };
+    zero_acc();
+    issue_A(0, 0);
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+      wf[kg][0] = *reinterpret_cast<const uint4 *>(wf_base0 + (size_t)kg * 1024);
+      wf[kg][1] = *reinterpret_cast<const uint4 *>(wf_base1 + (size_t)kg * 1024);
+    }
+    if (nchunks > 2) {
+      issue_A(1, 1);
+      issue_A(2, 2);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CPIECES) : "memory");
+    } else {
+      if (nchunks > 1) issue_A(1, 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    stamp();                                                     // 1: first window + fragments in
+    const int v_taps = p.taps[lane < 9 ? lane : 0];
+    const int d_first = __builtin_amdgcn_readlane(v_taps, 0);
+    XFrags x0, x1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_x1(lds, d_first, 0, i, x0);
+#pragma unroll 1
+    for (int c = 0; c < nchunks; ++c) {
+      const unsigned char *Ab = lds + (c % CSTAGES) * CSTAGE;
+      for (int t = 0; t < n_taps; ++t) {
+        const bool last_tap = (t + 1 == n_taps);
+        int cn = c, tn = t + 1;
+        if (last_tap) { tn = 0; cn = c + 1; }
+        if (cn == nchunks) { cn = c; tn = t; }               // the last step re-fetches its own fragments (never used)
+        const int d = __builtin_amdgcn_readlane(v_taps, t);
+        auto group = [&](const XFrags &xc, int kg, XFrags &xn, const unsigned char *An, int dn, int kgn) {
+          const size_t woff = ((size_t)tn * nchunks + cn) * 4096 + (size_t)kg * 1024;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            load_x1(An, dn, kgn, q, xn);
+            mma2(xc, kg, q / 2, (q % 2) * 2);
+            if (q == 1) wf[kg][0] = *reinterpret_cast<const uint4 *>(wf_base0 + woff);
+            if (q == 3) wf[kg][1] = *reinterpret_cast<const uint4 *>(wf_base1 + woff);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        };
+        group(x0, 0, x1, Ab, d, 1);
+        group(x1, 1, x0, Ab, d, 2);
+        group(x0, 2, x1, Ab, d, 3);
+        const unsigned char *An = Ab;
+        int dn = __builtin_amdgcn_readlane(v_taps, last_tap ? t : t + 1);
+        if (last_tap && c + 1 < nchunks) {
+          // see kernels_tdnn_v3.hip: the youngest 8 VMEM operations are fragment fetches; window c+1 is older
+          asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          if (c + 3 < nchunks) issue_A(c + 3, (c + 3) % CSTAGES);
+          An = lds + ((c + 1) % CSTAGES) * CSTAGE;
+          dn = d_first;
+        }
+        group(x1, 3, x0, An, dn, 0);
+      }
+    }
+  }
+
+  // epilogue of a 512-wide layer: bias, [ReLU], folded BN, bf16 -> Y (row-major, 16-byte slots XOR-swizzled by row & 15)
+  auto store_Y = [&](int relu) {
+    const float act_lo = relu ? 0.0f : -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int chl = wave * 64 + j * 32 + 8 * q + 4 * lh;
+        const float4 b4 = *reinterpret_cast<const float4 *>(par + chl);
+        const float4 sc4 = *reinterpret_cast<const float4 *>(par + CN + chl);
+        const float4 sh4 = *reinterpret_cast<const float4 *>(par + 2 * CN + chl);
+        const float b[4] = {b4.x, b4.y, b4.z, b4.w}, sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+        const int slot = wave * 8 + j * 4 + q;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float y[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) y[e] = fmaxf(acc[i][j][q * 4 + e] + b[e], act_lo) * sc[e] + sh[e];
+          uint2 pk;
+          pk.x = pack_bf16x2(y[0], y[1]);
+          pk.y = pack_bf16x2(y[2], y[3]);
+          const int row = i * 32 + lr;
+          *reinterpret_cast<uint2 *>(lds + row * YROWB + ((slot ^ (lr & 15)) << 4) + lh * 8) = pk;
+        }
+      }
+  };
+
+  // main loop of a layer whose input is Y: K = 512 = 8 steps of 4 k-groups, fragments of the next step prefetched, no barrier
+  auto yloop = [&](const unsigned char *wf_base0, const unsigned char *wf_base1) {
+    auto load_y1 = [&](int c, int kg, int i, XFrags &f) {
+      const int s = c * 8 + kg * 2 + lh;
+      f.x[i] = *reinterpret_cast<const uint4 *>(lds + (i * 32 + lr) * YROWB + ((s ^ (lr & 15)) << 4));
+    };
+    zero_acc();
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+      wf[kg][0] = *reinterpret_cast<const uint4 *>(wf_base0 + (size_t)kg * 1024);
+      wf[kg][1] = *reinterpret_cast<const uint4 *>(wf_base1 + (size_t)kg * 1024);
+    }
+    XFrags x0, x1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_y1(0, 0, i, x0);
+#pragma unroll 1
+    for (int c = 0; c < CN / CBK; ++c) {
+      const int cn = min(c + 1, CN / CBK - 1);
+      auto group = [&](const XFrags &xc, int kg, XFrags &xn, int c2, int kgn) {
+        const size_t woff = (size_t)cn * 4096 + (size_t)kg * 1024;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          load_y1(c2, kgn, q, xn);
+          mma2(xc, kg, q / 2, (q % 2) * 2);
+          if (q == 1) wf[kg][0] = *reinterpret_cast<const uint4 *>(wf_base0 + woff);
+          if (q == 3) wf[kg][1] = *reinterpret_cast<const uint4 *>(wf_base1 + woff);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      group(x0, 0, x1, c, 1);
+      group(x1, 1, x0, c, 2);
+      group(x0, 2, x1, c, 3);
+      group(x1, 3, x0, cn, 0);
+    }
+  };
+
+  stamp();                                 // 2: main loop of layer A done
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();            // every wave is done with the ring: Y may be written
+  asm volatile("" ::: "memory");
+  stamp();                                 // 3
+  store_Y(p.first.relu);
+  __builtin_amdgcn_s_barrier();            // Y complete; the constants of layer A are dead
+  asm volatile("" ::: "memory");
+  stamp();                                 // 4: Y of layer A complete
+
+  // ================================ middle layers: Y -> Y ================================
+#pragma unroll 1
+  for (int m = 0; m < p.n_mid; ++m) {
+    const TdnnChainLayer &L = p.mid[m];
+    stage_params(L);
+    const size_t frag_stride = (size_t)(CN / CBK) * 4096;
+    const unsigned char *wb = reinterpret_cast<const unsigned char *>(L.wfrag) + (size_t)(wave * 2) * frag_stride + (size_t)lane * 16;
+    yloop(wb, wb + frag_stride);
+    stamp();                               // 5: main loop of the middle layer done
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // nobody reads the old Y any more (and the staged constants are visible)
+    asm volatile("" ::: "memory");
+    store_Y(L.relu);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    stamp();                               // 6: Y of the middle layer complete
+  }
+
+  // ================================ last layer + fused statistics pooling ================================
+  {
+    const TdnnChainLayer &L = p.last;
+    const float act_lo = L.relu ? 0.0f : -INFINITY;
+    float *scr = reinterpret_cast<float *>(lds + SCR_OFF + wave * 4096);     // [16 frames][64 channels] f32, slots swizzled by row
+    const int half = m0 >> 7;
+    int first_seg = -1;
+#pragma unroll
+    for (int k = 0; k < kHalo + 1; ++k)
+      if (first_seg < 0 && m0 + k < p.rows) first_seg = p.row_seg[m0 + k];
+    const int rowseg_lo = p.row_seg[m0 + lane], rowseg_hi = p.row_seg[m0 + 64 + lane];
+    const size_t frag_stride = (size_t)(CN / CBK) * 4096;
+#pragma unroll 1
+    for (int cb = wave * 64; cb < L.cout_pad; cb += 512) {
+      const unsigned char *wb = reinterpret_cast<const unsigned char *>(L.wfrag) + (size_t)(cb / 32) * frag_stride + (size_t)lane * 16;
+      const float b_c = L.bias[cb + lane];
+      const float sc_c = L.scale != nullptr ? L.scale[cb + lane] : 1.0f;
+      yloop(wb, wb + frag_stride);
+      stamp();                             // 7, 9, 11: main loop of a unit done
+      const int ch_l = cb + lane;
+      float ps = 0.0f, pq = 0.0f, pv = 0.0f;
+      int cur_seg = -1;
+      auto flush = [&]() {
+        const int slot = cur_seg - first_seg;
+        if (slot >= 0 && slot < p.pool_slots && ch_l < p.ld_partial) {
+          float *dst = p.pool_partial + ((size_t)(half * p.pool_slots + slot) * 3) * p.ld_partial + ch_l;
+          dst[0] = ps;
+          dst[p.ld_partial] = pq;
+          dst[2 * p.ld_partial] = pv;
+        }
+      };
+      auto u_of = [&](int r) {          // channel `lane` of scratch row r: u = act(acc + b) * scale (the BN shift is added by pool_finish)
+        const float v = scr[r * 64 + ((((lane >> 2) ^ r) << 2) | (lane & 3))];
+        return fmaxf(v + b_c, act_lo) * sc_c;
+      };
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          // rows i*32 + h*16 .. +15 sit in the lanes with (lr >> 4) == h; raw accumulators go to the scratch
+          if ((lr >> 4) == h) {
+            const int r = lr & 15;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int slot = j * 8 + q * 2 + lh;
+                *reinterpret_cast<float4 *>(scr + r * 64 + ((slot ^ r) << 2)) =
+                    make_float4(acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
+              }
+          }
+          const int rg = i * 32 + h * 16;                       // first row of the group inside the tile
+          const int rs_vec = (rg < 64) ? rowseg_lo : rowseg_hi;
+          const unsigned long long in_grp = 0xffffull << (rg & 63);
+          const unsigned long long m_valid = __builtin_amdgcn_ballot_w64(rs_vec >= 0) & in_grp;
+          if (m_valid == 0) continue;                            // gap rows only
+          const int sg0 = __builtin_amdgcn_readlane(rs_vec, __builtin_ctzll(m_valid));
+          const unsigned long long m_same = __builtin_amdgcn_ballot_w64(rs_vec == sg0) & in_grp;
+          if (m_same == in_grp) {
+            if (sg0 != cur_seg) {
+              if (cur_seg >= 0) flush();
+              cur_seg = sg0; ps = 0.0f; pq = 0.0f; pv = u_of(0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float dlt = u_of(r) - pv;
+              ps += dlt;
+              pq = fmaf(dlt, dlt, pq);
+            }
+          } else {
+            // rare (a gap row or an utterance seam inside the group): a ROLLED loop - unrolled, the 8 groups' row-by-row
+            // code with its flush() copies was 50 KiB of instructions around the fast path and thrashed the instruction cache
+#pragma unroll 1
+            for (int r = 0; r < 16; ++r) {
+              const int sg = __builtin_amdgcn_readlane(rs_vec, (rg & 63) + r);       // wave-uniform
+              if (sg < 0) continue;                                                   // gap row
+              const float u = u_of(r);
+              if (sg != cur_seg) {
+                if (cur_seg >= 0) flush();
+                cur_seg = sg; ps = 0.0f; pq = 0.0f; pv = u;
+              }
+              const float dlt = u - pv;
+              ps += dlt;
+              pq = fmaf(dlt, dlt, pq);
+            }
+          }
+        }
+      }
+      if (cur_seg >= 0) flush();
+      stamp();                             // 8, 10, 12: pooling epilogue of the unit done
+    }
+  }
+}
+
+}  // namespace
+
+int launch_tdnn_chain(const TdnnChainParams &p, hipStream_t s) {
+  ASV_REQUIRE(p.rows % CM == 0 && p.rows >= CM, "tdnn(chain): rows %d not a multiple of %d", p.rows, CM);
+  ASV_REQUIRE(p.cin_pad % CBK == 0 && p.cin_pad >= CBK && p.n_taps >= 1 && p.n_taps <= ASV_MAX_TAPS, "tdnn(chain): first layer with %d channels / %d taps", p.cin_pad, p.n_taps);
+  ASV_REQUIRE((unsigned long long)p.rows * (unsigned long long)p.ldx * 2ull < (1ull << 32), "tdnn(chain): input matrix beyond 32-bit offsets");
+  ASV_REQUIRE(p.first.wfrag && p.last.wfrag && p.last.bias && p.n_mid >= 0 && p.n_mid <= 2 && p.last.cout_pad % 64 == 0, "tdnn(chain): incomplete layer description");
+  ASV_REQUIRE(p.pool_partial && p.row_seg && p.pool_slots >= 1, "tdnn(chain): the last layer feeds the fused pooling (partials / row map missing)");
+  for (int t = 0; t < p.n_taps; ++t) ASV_REQUIRE(p.taps[t] >= -kHalo && p.taps[t] <= kHalo, "tdnn(chain): tap offset %d exceeds the %d-frame halo", p.taps[t], kHalo);
+  hipLaunchKernelGGL(tdnn_chain_kernel, dim3(p.rows / CM), dim3(512), 0, s, p);
+  ASV_HIP_CHECK(hipGetLastError());
+  return ASV_OK;
+}
+
+}  // namespace asv

@@ -408,7 +408,9 @@ __global__ __launch_bounds__(Geom3<WM>::WAVES * 64, WM == 0 ? 3 : 2) void tdnn_g
           pq = fmaf(d, d, pq);
         }
       } else {
-#pragma unroll
+        // rolled on purpose: unrolled, the four fragments' row-by-row code with its flush() copies is tens of KiB of
+        // instructions around the fast path (instruction-cache misses in every epilogue)
+#pragma unroll 1
         for (int r = 0; r < 32; ++r) {
           const int sg = __builtin_amdgcn_readlane(rs_vec, (i & 1) * 32 + r);          // wave-uniform
           if (sg < 0) continue;                                                          // gap row

@@ -5,6 +5,7 @@
 // `<Model>.extract_embedding` do one utterance at a time in the reference
 // (libs/nnet/framework.py:12-55, model/xvector.py:77-98, model/ecapa_tdnn_xvector.py:403-426).
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -121,6 +122,7 @@ struct Op {
   bool utts = false;             // op runs in the utts domain (always f32)
   bool has_affine = false;
   int fused_pool = -1;           // TDNN op: index of the statistics-pooling op folded into its epilogue
+  int chain_last = -1;           // TDNN op heading a chain (kernels_tdnn_chain.hip): index of the chain's last layer
   bool skipped = false;          // pool op executed by its producer
 };
 
@@ -692,6 +694,52 @@ int asv_net_finalize(asv_net_t *net, int out_buf, int embed_dim) {
       b.skipped = true;
     }
   }
+  // chains "layer -> 512, [1-tap 512 -> 512]*, 1-tap + fused pooling" whose intermediate tensors nobody else reads run as
+  // ONE kernel with the 128 x 512 tiles resident in LDS (x-vector: tdnn3 -> tdnn4 -> tdnn5 -> pooling)
+  if ((net->flags & (ASV_FLAG_NO_FUSE | ASV_FLAG_NO_CHAIN)) == 0 && net->frames_bf16()) {
+    auto plain = [&](const Op &o) {
+      const auto &d = o.tdnn;
+      return o.kind == OP_TDNN && !o.utts && o.wfrag != nullptr && net->bufs[d.in_buf].domain == ASV_DOMAIN_FRAMES && d.in2_buf < 0 && d.seg_bias_buf < 0 &&
+             d.seg_scale_buf < 0 && d.res_buf < 0 && !d.affine_first && d.act2 == ASV_ACT_NONE && (d.act1 == ASV_ACT_NONE || d.act1 == ASV_ACT_RELU);
+    };
+    auto from_resident = [&](const Op &o) {            // 1-tap layer that consumes a whole 512-channel buffer
+      const auto &d = o.tdnn;
+      return d.n_taps == 1 && d.taps[0] == 0 && d.in_ch == kChainWidth && d.in_ch_off == 0 && net->bufs[d.in_buf].channels == kChainWidth;
+    };
+    auto sole_reader = [&](int buf, size_t reader) {
+      if (buf == out_buf) return false;
+      for (size_t k = 0; k < net->ops.size(); ++k) {
+        if (k == reader) continue;
+        const Op &o = net->ops[k];
+        const int reads[] = {o.kind == OP_TDNN ? o.tdnn.in_buf : -1, o.kind == OP_TDNN ? o.tdnn.in2_buf : -1, o.kind == OP_TDNN ? o.tdnn.res_buf : -1,
+                             o.kind == OP_TDNN ? o.tdnn.seg_bias_buf : -1, o.kind == OP_TDNN ? o.tdnn.seg_scale_buf : -1,
+                             o.kind == OP_POOL ? o.pool.in_buf : -1, o.kind == OP_ATTPOOL ? o.att.x_buf : -1, o.kind == OP_ATTPOOL ? o.att.logit_buf : -1,
+                             o.kind == OP_ELTWISE ? o.elt.a_buf : -1, o.kind == OP_ELTWISE ? o.elt.b_buf : -1, o.kind == OP_ELTWISE ? o.elt.c_buf : -1,
+                             o.kind == OP_ELTWISE ? o.elt.seg_scale_buf : -1, o.kind == OP_ELTWISE ? o.elt.seg_norm_buf : -1,
+                             o.kind == OP_IM2COL ? o.i2c.in_buf : -1, o.kind == OP_LDE ? o.lde.x_buf : -1, o.kind == OP_GRID_INPUT ? o.gin.in_buf : -1};
+        for (int rbuf : reads) if (rbuf == buf) return false;
+      }
+      return true;
+    };
+    for (size_t l = 1; l < net->ops.size(); ++l) {
+      Op &last = net->ops[l];
+      if (!plain(last) || last.fused_pool < 0 || !from_resident(last)) continue;
+      size_t head = l;
+      while (head > 0 && l - head < 3) {
+        const Op &prev = net->ops[head - 1], &cur = net->ops[head];
+        if (!plain(prev) || prev.fused_pool >= 0 || prev.tdnn.out_buf != cur.tdnn.in_buf || prev.tdnn.out_ch_off != 0 || prev.tdnn.out_ch != kChainWidth ||
+            prev.cout_pad != kChainWidth || !sole_reader(prev.tdnn.out_buf, head)) break;
+        --head;
+        if (!from_resident(prev)) break;               // any-tap layer: it can only be the chain's first
+      }
+      const Op &first = net->ops[head];
+      if (head == l || first.cin_pad % 64 != 0 || first.cin_pad < 64) continue;
+      bool mids_ok = true;
+      for (size_t k = head + 1; k < l; ++k) mids_ok &= from_resident(net->ops[k]);
+      if (!mids_ok) continue;
+      net->ops[head].chain_last = (int)l;
+    }
+  }
   net->out_buf = out_buf; net->embed_dim = embed_dim; net->finalized = true;
   net->arena.resize(net->bufs.size());
   return ASV_OK;
@@ -942,6 +990,74 @@ int run_ops(RunCtx &c, size_t n_ops) {
         p.act1 = d.act1; p.act2 = d.act2; p.affine_first = d.affine_first;
         p.zero16 = net->zero_page;
         p.wfrag = op.wfrag; p.wlo = op.wlo;
+        if (op.chain_last >= 0 && !use_ref && bf16 && p.halo <= kHalo && (net->flags & (ASV_FLAG_SMALL_TILES | ASV_FLAG_BIG_V2)) == 0 &&
+            (unsigned long long)p.rows * (unsigned long long)p.ldx * 2ull < (1ull << 32)) {
+          // tdnn -> [1-tap]* -> 1-tap + pooling in one kernel, if the batch allows the fused pooling (no crowd of tiny utterances)
+          const DomainPlan &fp = bp.dom[ASV_DOMAIN_FRAMES];
+          std::vector<int> per_half((size_t)fp.rows_pad / 128 + 1, 0);
+          int slots = 1;
+          for (size_t sidx = 0; sidx < fp.seg_row0.size(); ++sidx)
+            for (int h = fp.seg_row0[sidx] >> 7; h <= (fp.seg_row0[sidx] + fp.seg_len[sidx] - 1) >> 7; ++h) slots = std::max(slots, ++per_half[h]);
+          if (slots <= 16) {
+            const size_t l = (size_t)op.chain_last;
+            Op &lo = net->ops[l];
+            TdnnChainParams cp;
+            memset(&cp, 0, sizeof(cp));
+            cp.x = p.x; cp.ldx = p.ldx; cp.rows = p.rows; cp.cin_pad = p.cin_pad; cp.n_taps = p.n_taps;
+            for (int t = 0; t < p.n_taps; ++t) cp.taps[t] = p.taps[t];
+            auto layer_of = [&](const Op &o) { TdnnChainLayer L; L.wfrag = o.wfrag; L.bias = o.bias; L.scale = o.scale; L.shift = o.shift;
+                                               L.relu = o.tdnn.act1 == ASV_ACT_RELU; L.cout_pad = o.cout_pad; return L; };
+            cp.first = layer_of(op);
+            cp.n_mid = (int)(l - i - 1);
+            for (size_t k = i + 1; k < l; ++k) cp.mid[k - i - 1] = layer_of(net->ops[k]);
+            cp.last = layer_of(lo);
+            cp.pool_slots = slots; cp.ld_partial = lo.cout_pad; cp.row_seg = dr.row_seg;
+            if ((rc = ensure(net->poolpart_dev, (size_t)(p.rows / 128) * slots * 3 * cp.ld_partial * 4, c.s, false))) return rc;
+            cp.pool_partial = reinterpret_cast<float *>(net->poolpart_dev.ptr);
+            double fl = 0.0;
+            for (size_t k = i; k <= l; ++k) fl += 2.0 * (double)bp.frames * net->ops[k].tdnn.in_ch * net->ops[k].tdnn.out_ch * net->ops[k].tdnn.n_taps;
+            if ((rc = prof.begin(K_TDNN, fl, (int)i))) return rc;
+            static const bool chain_dbg = getenv("ASV_AMD_CHAIN_DBG") != nullptr;        // developer aid: phase durations to stderr
+            DevMem dbg;
+            if (chain_dbg) {
+              if ((rc = ensure(dbg, (size_t)(p.rows / 128) * 8 * 16 * 8, c.s, true))) return rc;
+              cp.dbg = reinterpret_cast<unsigned long long *>(dbg.ptr);
+            }
+            if ((rc = launch_tdnn_chain(cp, c.s))) return rc;
+            if ((rc = prof.end())) return rc;
+            if (chain_dbg) {
+              const size_t nwg = (size_t)(p.rows / 128);
+              std::vector<unsigned long long> h(nwg * 8 * 16);
+              ASV_HIP_CHECK(hipStreamSynchronize(c.s));
+              ASV_HIP_CHECK(hipMemcpy(h.data(), dbg.ptr, h.size() * 8, hipMemcpyDeviceToHost));
+              ASV_HIP_CHECK(hipFree(dbg.ptr));
+              double sum[16] = {0}; size_t cnt = 0;
+              for (size_t w = 0; w < nwg * 8; ++w) {
+                const unsigned long long *t = &h[w * 16];
+                if (t[0] == 0) continue;
+                for (int k = 1; k < 13; ++k) if (t[k] > t[k - 1]) sum[k] += (double)(t[k] - t[k - 1]);
+                ++cnt;
+              }
+              fprintf(stderr, "[chain dbg] %zu waves, mean cycles per phase:", cnt);
+              for (int k = 1; k < 13; ++k) fprintf(stderr, " %d:%.0f", k, sum[k] / (double)std::max<size_t>(cnt, 1));
+              fprintf(stderr, "\n");
+            }
+            Op &po = net->ops[lo.fused_pool];
+            po.skipped = true;
+            const auto &q = po.pool;
+            PoolFinishParams f;
+            f.partial = cp.pool_partial; f.ld_partial = cp.ld_partial; f.pool_slots = slots;
+            f.row_seg = dr.row_seg; f.rows = dr.rows_pad; f.seg_row0 = dr.seg_row0; f.seg_len = dr.seg_len;
+            f.shift = lo.shift;
+            f.out = reinterpret_cast<float *>(net->arena[q.out_buf].ptr) + q.out_ch_off; f.ld_out = net->bufs[q.out_buf].ld; f.channels = q.channels;
+            f.stddev = q.stddev; f.unbiased = q.unbiased; f.var_mode = q.var_mode; f.eps = q.eps;
+            if ((rc = prof.begin(K_POOL, 0, lo.fused_pool))) return rc;
+            if ((rc = launch_pool_finish(f, bp.segments, c.s))) return rc;
+            if ((rc = prof.end())) return rc;
+            i = l;                                       // the chain's other layers ran inside the kernel
+            break;
+          }
+        }
         const bool narrow = p.halo <= kHalo;
         // fused statistics pooling: needs few enough segments per 128-row half-tile (i.e. no tiny utterances)
         int pool_slots = 0;

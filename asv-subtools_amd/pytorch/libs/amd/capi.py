@@ -12,7 +12,7 @@ import os
 
 ASV_OK = 0
 PREC_F32, PREC_BF16, PREC_F32X = 0, 1, 2
-FLAG_REF_KERNELS, FLAG_NO_FUSE, FLAG_SMALL_TILES, FLAG_BIG_V2 = 1, 2, 4, 8
+FLAG_REF_KERNELS, FLAG_NO_FUSE, FLAG_SMALL_TILES, FLAG_BIG_V2, FLAG_NO_CHAIN = 1, 2, 4, 8, 16
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
 DOMAIN_FRAMES, DOMAIN_UTTS = 0, 1
 MAX_TAPS = 9

@@ -34,6 +34,8 @@ def default_flags():
         flags |= capi.FLAG_REF_KERNELS
     if os.environ.get("ASV_AMD_NO_FUSE", "0") not in ("0", "", "false"):
         flags |= capi.FLAG_NO_FUSE
+    if os.environ.get("ASV_AMD_NO_CHAIN", "0") not in ("0", "", "false"):
+        flags |= capi.FLAG_NO_CHAIN
     if os.environ.get("ASV_AMD_SMALL_TILES", "0") not in ("0", "", "false"):
         flags |= capi.FLAG_SMALL_TILES
     return flags

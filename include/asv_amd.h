@@ -61,6 +61,7 @@ int         asv_device_count(int *count);
 #define ASV_FLAG_NO_FUSE     2u  /* disable epilogue fusions (stats pooling into the producer)  */
 #define ASV_FLAG_SMALL_TILES 4u  /* never pick the 256x256 kernels (A/B testing)                    */
 #define ASV_FLAG_BIG_V2      8u  /* 256x256 kernel variant 2 (both operands through LDS) instead of 3 */
+#define ASV_FLAG_NO_CHAIN   16u  /* one launch per layer: do not run tdnn -> 1-tap tdnn -> ... -> pooling chains in one kernel */
 
 #define ASV_ACT_NONE    0
 #define ASV_ACT_RELU    1

