@@ -148,6 +148,7 @@ int launch_stats_pool(const PoolKernelParams &p, int segments, bool bf16, hipStr
 // back to the mean and writes mean || std like stats_pool_kernel
 struct PoolFinishParams {
   const float *partial; int ld_partial, pool_slots;
+  int lh_split;                  // partials of the chain kernel: [tile][slot][lh][3][ld], lh = bit 2 of the row index of the frames summed
   const int32_t *row_seg; int rows;
   const int32_t *seg_row0, *seg_len;
   const float *shift;            // per-channel BN shift that the producer left out (or nullptr)

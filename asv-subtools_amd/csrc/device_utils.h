@@ -52,6 +52,16 @@ __device__ __forceinline__ uint4 add_f32x4(uint4 a, uint4 b) {
   return r;
 }
 
+// max(v, lo) as ONE instruction.  fmaxf() costs three on this target: IEEE mode makes the compiler quiet both operands
+// (v_max_f32 x, x, x) in front of the real v_max_f32 (and it folds __builtin_amdgcn_fmed3f(v, lo, inf) back into the same) - 256
+// extra VALU operations in a 128-register epilogue, next to a partner wave whose MFMA stream leaves a VALU operation ~14 cycles.
+// lo = 0 (ReLU) or -inf (no activation); the accumulators are finite.
+__device__ __forceinline__ float max_lo(float v, float lo) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(lo));
+  return r;
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
     case ASV_ACT_RELU: return fmaxf(v, 0.0f);

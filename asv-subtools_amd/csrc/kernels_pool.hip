@@ -217,14 +217,24 @@ __global__ __launch_bounds__(64) void pool_finish_kernel(const PoolFinishParams 
     for (int k = 0; k < kHalo + 1 && first < 0; ++k)
       if (h * 128 + k < p.rows) first = p.row_seg[h * 128 + k];
     const int slot = seg - first;                       // segments are consecutive in row order
-    const float *src = p.partial + ((size_t)(h * p.pool_slots + slot) * 3) * p.ld_partial + ch;
-    const double nh = (double)(min(row0 + len, (h + 1) * 128) - max(row0, h * 128));
-    const double sh = (double)src[0], qh = (double)src[p.ld_partial], pv = (double)src[2 * p.ld_partial];
-    const double mean_h = pv + sh / nh, m2_h = fmax(qh - sh * sh / nh, 0.0);
-    const double tot = n_acc + nh, delta = mean_h - mean;
-    mean += delta * nh / tot;
-    m2 += m2_h + delta * delta * n_acc * nh / tot;
-    n_acc = tot;
+    const int a = max(row0, h * 128), b = min(row0 + len, (h + 1) * 128);
+    const int parts = p.lh_split ? 2 : 1;
+    for (int part = 0; part < parts; ++part) {
+      int cnt = b - a;
+      if (p.lh_split) {                                 // this part holds the rows whose index has bit 2 == part
+        cnt = 0;
+        for (int r = a; r < b; ++r) cnt += (((r >> 2) & 1) == part);
+      }
+      if (cnt == 0) continue;
+      const float *src = p.partial + ((size_t)((h * p.pool_slots + slot) * parts + part) * 3) * p.ld_partial + ch;
+      const double nh = (double)cnt;
+      const double sh = (double)src[0], qh = (double)src[p.ld_partial], pv = (double)src[2 * p.ld_partial];
+      const double mean_h = pv + sh / nh, m2_h = fmax(qh - sh * sh / nh, 0.0);
+      const double tot = n_acc + nh, delta = mean_h - mean;
+      mean += delta * nh / tot;
+      m2 += m2_h + delta * delta * n_acc * nh / tot;
+      n_acc = tot;
+    }
   }
   const float n = (float)len;
   float counts = n;

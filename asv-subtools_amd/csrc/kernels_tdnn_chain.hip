@@ -15,9 +15,16 @@
 //     epilogue overwrites Y in place;
 //   * last layer: the output channels are cut into 64-channel units, unit u = pass * 8 + wave; a wave runs its units
 //     back to back without ever meeting the others, so the matrix work of one wave of a SIMD overlaps the pooling
-//     epilogue of its partner.  The epilogue transposes raw accumulators through a wave-private 4 KiB scratch
-//     (16 frames x 64 channels) and accumulates pivoted moments per utterance (lane = channel), as the POOL epilogue
-//     of kernels_tdnn_v3.hip does; pool_finish_kernel merges the tiles.
+//     epilogue of its partner.  Its MFMAs take the operands in the other order (D = X W^T): the accumulator then has
+//     lane = channel, registers = frames, and the pooling epilogue sums pivoted moments per utterance inside a lane -
+//     no LDS transposition (the first version went through a scratch tile like the POOL epilogue of kernels_tdnn_v3.hip:
+//     15.6k instead of 11.5k cycles per unit); pool_finish_kernel merges the tiles.
+// Measured (profiles/r2_*, 640 x 200 frames): 433 us against 190 + 84 + 253 us for the three launches it replaces.  Per tile
+// (s_memtime stamps, ASV_AMD_CHAIN_DBG=1): layer A 57.7k cycles for 49.2k of MFMA issue, middle layer 18.3k (16.4k), last
+// layer 3 x (11.6k loop + 12k epilogue next to the partner's loop); the shader clock inside the kernel is 1.76 GHz.
+// Tried without effect (in-process A/B, tools/chain_ab.py): s_setprio around either phase, four partial sums instead of
+// the 16-deep chains, 22 instead of 48 instructions per k-group (one address register per step): the loops sit at the
+// matrix pipe's rate, the epilogue at ~14 cycles per VALU operation beside a streaming partner.
 // One workgroup (512 threads, 160 KiB LDS) per CU.
 #include "device_utils.h"
 
@@ -41,6 +48,8 @@ static_assert(CSTAGES * CSTAGE <= Y_BYTES, "the window ring lives inside the Y r
 static_assert(CHAIN_LDS <= 163840, "160 KiB of LDS per CU");
 
 typedef __attribute__((address_space(3))) unsigned char chain_lds_byte;
+struct TrNo { static constexpr bool value = false; };
+struct TrYes { static constexpr bool value = true; };
 
 __device__ __forceinline__ int cswz(int row, int slot) { return slot ^ ((row >> 1) & 7); }
 
@@ -72,6 +81,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
     ++n_stamp;
   };
   stamp();                                                       // 0: start
+  if (p.dbg != nullptr && lane == 0) p.dbg[((size_t)blockIdx.x * 8 + wave) * 16 + 14] = __builtin_amdgcn_s_memrealtime();
   auto stage_params = [&](const TdnnChainLayer &L) {
     if (tid < 384) {
       const int which = tid >> 7, idx = (tid & 127) * 4;
@@ -85,19 +95,34 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
   uint4 wf[4][2];
   f32x16_t acc[4][2];
   struct XFrags { uint4 x[4]; };
-  auto zero_acc = [&]() {
+  // the accumulators start from the bias (one v_mov per register either way; saves the add in every epilogue):
+  // acc[i][j][4 q + e] belongs to channel j * 32 + 8 q + 4 lh + e of the wave's 64-channel slice, for every frame fragment i
+  auto init_acc = [&](const float *bias64) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int q = 0; q < 4; ++q) {
+        const float4 b4 = *reinterpret_cast<const float4 *>(bias64 + j * 32 + 8 * q + 4 * lh);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        for (int i = 0; i < 4; ++i) {
+          acc[i][j][q * 4 + 0] = b4.x; acc[i][j][q * 4 + 1] = b4.y; acc[i][j][q * 4 + 2] = b4.z; acc[i][j][q * 4 + 3] = b4.w;
+        }
+      }
   };
-  auto mma2 = [&](const XFrags &f, int kg, int j, int i0) {
+  // TR = false: D = W X^T, accumulator lane = frame, registers = channels (4 consecutive channels per lane and row: what
+  //              the row-major Y store wants);
+  // TR = true:  D = X W^T, accumulator lane = CHANNEL (column j*32 + lr), registers = frames 8 (r >> 2) + 4 lh + (r & 3) of
+  //              fragment i - the pooling epilogue then sums over frames inside a lane, without any transposition.
+  auto mma2 = [&](const XFrags &f, int kg, int j, int i0, auto tr) {
 #pragma unroll
-    for (int i = i0; i < i0 + 2; ++i)
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[kg][j]), __builtin_bit_cast(bf16x8_t, f.x[i]), acc[i][j], 0, 0, 0);
+    for (int i = i0; i < i0 + 2; ++i) {
+      if constexpr (decltype(tr)::value)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, f.x[i]), __builtin_bit_cast(bf16x8_t, wf[kg][j]), acc[i][j], 0, 0, 0);
+      else
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[kg][j]), __builtin_bit_cast(bf16x8_t, f.x[i]), acc[i][j], 0, 0, 0);
+    }
   };
+
 
   // ================================ phase 1: layer A through the window ring ================================
   stage_params(p.first);
@@ -124,19 +149,27 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
         chain_glds16_s(base, a_off[i], dst);
       }
     };
+    // Instruction diet (the SIMD's issue slots are what two co-resident waves really share - a wave in an epilogue gets
+    // what the partner's main loop leaves): the four frame fragments of a k-group sit 32 window rows = 4096 B apart and
+    // share their swizzle term ((row >> 1) & 7 is blind to +32), so ONE address register per (chunk, tap) step serves all
+    // of them through immediate offsets, and the k-group enters as an XOR of bits 5-6; weight fragments use a scalar
+    // base + the constant lane offset.
     const size_t frag_stride = (size_t)n_taps * nchunks * 4096;
-    const unsigned char *wf_base0 = reinterpret_cast<const unsigned char *>(p.first.wfrag) + (size_t)(wave * 2) * frag_stride + (size_t)lane * 16;
-    const unsigned char *wf_base1 = wf_base0 + frag_stride;
-    auto load_x1 = [&](const unsigned char *Ab, int d, int kg, int i, XFrags &f) {
-      const int w = i * 32 + lr + kHalo + d;
-      f.x[i] = *reinterpret_cast<const uint4 *>(Ab + w * CROWB + cswz(w, kg * 2 + lh) * 16);
+    const unsigned char *wA0 = reinterpret_cast<const unsigned char *>(p.first.wfrag) + (size_t)(wave * 2) * frag_stride;   // wave-uniform
+    const unsigned char *wA1 = wA0 + frag_stride;
+    const uint32_t lane16 = (uint32_t)lane * 16u;
+    auto x_base = [&](int c, int d) -> uint32_t {
+      const int wrow = lr + kHalo + d;
+      return (uint32_t)((c % CSTAGES) * CSTAGE + wrow * CROWB + ((lh ^ ((wrow >> 1) & 7)) << 4));
     };
-    zero_acc();
+    auto load_x4 = [&](uint32_t xb, int kg, int i, XFrags &f) {
+      f.x[i] = *reinterpret_cast<const uint4 *>(lds + (xb ^ (uint32_t)(kg << 5)) + i * 4096);
+    };
     issue_A(0, 0);
 #pragma unroll
     for (int kg = 0; kg < 4; ++kg) {
-      wf[kg][0] = *reinterpret_cast<const uint4 *>(wf_base0 + (size_t)kg * 1024);
-      wf[kg][1] = *reinterpret_cast<const uint4 *>(wf_base1 + (size_t)kg * 1024);
+      wf[kg][0] = *reinterpret_cast<const uint4 *>(wA0 + (size_t)kg * 1024 + lane16);
+      wf[kg][1] = *reinterpret_cast<const uint4 *>(wA1 + (size_t)kg * 1024 + lane16);
     }
     if (nchunks > 2) {
       issue_A(1, 1);
@@ -149,103 +182,114 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     stamp();                                                     // 1: first window + fragments in
+    init_acc(p.first.bias + wave * 64);
     const int v_taps = p.taps[lane < 9 ? lane : 0];
     const int d_first = __builtin_amdgcn_readlane(v_taps, 0);
     XFrags x0, x1;
+    uint32_t xb = x_base(0, d_first);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) load_x1(lds, d_first, 0, i, x0);
+    for (int i = 0; i < 4; ++i) load_x4(xb, 0, i, x0);
 #pragma unroll 1
     for (int c = 0; c < nchunks; ++c) {
-      const unsigned char *Ab = lds + (c % CSTAGES) * CSTAGE;
       for (int t = 0; t < n_taps; ++t) {
         const bool last_tap = (t + 1 == n_taps);
         int cn = c, tn = t + 1;
         if (last_tap) { tn = 0; cn = c + 1; }
-        if (cn == nchunks) { cn = c; tn = t; }               // the last step re-fetches its own fragments (never used)
-        const int d = __builtin_amdgcn_readlane(v_taps, t);
-        auto group = [&](const XFrags &xc, int kg, XFrags &xn, const unsigned char *An, int dn, int kgn) {
-          const size_t woff = ((size_t)tn * nchunks + cn) * 4096 + (size_t)kg * 1024;
+        const bool more = cn < nchunks;
+        if (!more) { cn = c; tn = t; }                       // the last step re-fetches its own fragments (never used)
+        const size_t wnext = ((size_t)tn * nchunks + cn) * 4096;
+        auto group = [&](const XFrags &xc, int kg, XFrags &xn, uint32_t xbn, int kgn) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            load_x1(An, dn, kgn, q, xn);
-            mma2(xc, kg, q / 2, (q % 2) * 2);
-            if (q == 1) wf[kg][0] = *reinterpret_cast<const uint4 *>(wf_base0 + woff);
-            if (q == 3) wf[kg][1] = *reinterpret_cast<const uint4 *>(wf_base1 + woff);
+            load_x4(xbn, kgn, q, xn);
+            mma2(xc, kg, q / 2, (q % 2) * 2, TrNo{});
+            if (q == 1) wf[kg][0] = *reinterpret_cast<const uint4 *>(wA0 + wnext + (size_t)kg * 1024 + lane16);
+            if (q == 3) wf[kg][1] = *reinterpret_cast<const uint4 *>(wA1 + wnext + (size_t)kg * 1024 + lane16);
             __builtin_amdgcn_sched_barrier(0);
           }
         };
-        group(x0, 0, x1, Ab, d, 1);
-        group(x1, 1, x0, Ab, d, 2);
-        group(x0, 2, x1, Ab, d, 3);
-        const unsigned char *An = Ab;
-        int dn = __builtin_amdgcn_readlane(v_taps, last_tap ? t : t + 1);
+        group(x0, 0, x1, xb, 1);
+        group(x1, 1, x0, xb, 2);
+        group(x0, 2, x1, xb, 3);
         if (last_tap && c + 1 < nchunks) {
           // see kernels_tdnn_v3.hip: the youngest 8 VMEM operations are fragment fetches; window c+1 is older
           asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
           __builtin_amdgcn_s_barrier();
           asm volatile("" ::: "memory");
           if (c + 3 < nchunks) issue_A(c + 3, (c + 3) % CSTAGES);
-          An = lds + ((c + 1) % CSTAGES) * CSTAGE;
-          dn = d_first;
         }
-        group(x1, 3, x0, An, dn, 0);
+        const uint32_t xbn = x_base(cn, __builtin_amdgcn_readlane(v_taps, tn));   // next step (the last one: itself, harmless)
+        group(x1, 3, x0, xbn, 0);
+        xb = xbn;
       }
     }
   }
 
-  // epilogue of a 512-wide layer: bias, [ReLU], folded BN, bf16 -> Y (row-major, 16-byte slots XOR-swizzled by row & 15)
+  // epilogue of a 512-wide layer: [ReLU], folded BN, bf16 -> Y (row-major, 16-byte slots XOR-swizzled by row & 15); the bias
+  // is in the accumulators already
   auto store_Y = [&](int relu) {
     const float act_lo = relu ? 0.0f : -INFINITY;
+    unsigned char *yrow = lds + lr * YROWB + lh * 8;
+    const int rx = lr & 15;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int chl = wave * 64 + j * 32 + 8 * q + 4 * lh;
-        const float4 b4 = *reinterpret_cast<const float4 *>(par + chl);
         const float4 sc4 = *reinterpret_cast<const float4 *>(par + CN + chl);
         const float4 sh4 = *reinterpret_cast<const float4 *>(par + 2 * CN + chl);
-        const float b[4] = {b4.x, b4.y, b4.z, b4.w}, sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
-        const int slot = wave * 8 + j * 4 + q;
+        const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+        unsigned char *dst = yrow + (((wave * 8 + j * 4 + q) ^ rx) << 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float y[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) y[e] = fmaxf(acc[i][j][q * 4 + e] + b[e], act_lo) * sc[e] + sh[e];
+          for (int e = 0; e < 4; ++e) y[e] = fmaf(max_lo(acc[i][j][q * 4 + e], act_lo), sc[e], sh[e]);
           uint2 pk;
           pk.x = pack_bf16x2(y[0], y[1]);
           pk.y = pack_bf16x2(y[2], y[3]);
-          const int row = i * 32 + lr;
-          *reinterpret_cast<uint2 *>(lds + row * YROWB + ((slot ^ (lr & 15)) << 4) + lh * 8) = pk;
+          *reinterpret_cast<uint2 *>(dst + i * 32 * YROWB) = pk;
         }
       }
   };
 
-  // main loop of a layer whose input is Y: K = 512 = 8 steps of 4 k-groups, fragments of the next step prefetched, no barrier
-  auto yloop = [&](const unsigned char *wf_base0, const unsigned char *wf_base1) {
-    auto load_y1 = [&](int c, int kg, int i, XFrags &f) {
-      const int s = c * 8 + kg * 2 + lh;
-      f.x[i] = *reinterpret_cast<const uint4 *>(lds + (i * 32 + lr) * YROWB + ((s ^ (lr & 15)) << 4));
+  // main loop of a layer whose input is Y: K = 512 = 8 steps of 4 k-groups, fragments of the next step prefetched, no barrier.
+  // wb0 / wb1: wave-uniform fragment bases; bias64: the 64 biases of this wave's output channels (global)
+  auto yloop = [&](const unsigned char *wb0, const unsigned char *wb1, const float *bias64, auto tr) {
+    const uint32_t lane16 = (uint32_t)lane * 16u;
+    const uint32_t yb = (uint32_t)(lr * YROWB);                  // fragment i: + i * 32 KiB (immediate offsets)
+    const uint32_t sx = (uint32_t)(lh ^ (lr & 15));
+    auto load_y4 = [&](int c, int kg, int i, XFrags &f) {       // slot (c*8 + kg*2 + lh) ^ (lr & 15) = (c*8 + kg*2) ^ sx
+      f.x[i] = *reinterpret_cast<const uint4 *>(lds + yb + ((((uint32_t)(c * 8 + kg * 2)) ^ sx) << 4) + i * 32 * YROWB);
     };
-    zero_acc();
 #pragma unroll
     for (int kg = 0; kg < 4; ++kg) {
-      wf[kg][0] = *reinterpret_cast<const uint4 *>(wf_base0 + (size_t)kg * 1024);
-      wf[kg][1] = *reinterpret_cast<const uint4 *>(wf_base1 + (size_t)kg * 1024);
+      wf[kg][0] = *reinterpret_cast<const uint4 *>(wb0 + (size_t)kg * 1024 + lane16);
+      wf[kg][1] = *reinterpret_cast<const uint4 *>(wb1 + (size_t)kg * 1024 + lane16);
+    }
+    if constexpr (decltype(tr)::value) {                        // lane = channel: one bias per lane and channel fragment
+      const float b0 = bias64[lr], b1 = bias64[32 + lr];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[i][0][r] = b0; acc[i][1][r] = b1; }
+    } else {
+      init_acc(bias64);
     }
     XFrags x0, x1;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) load_y1(0, 0, i, x0);
+    for (int i = 0; i < 4; ++i) load_y4(0, 0, i, x0);
 #pragma unroll 1
     for (int c = 0; c < CN / CBK; ++c) {
       const int cn = min(c + 1, CN / CBK - 1);
+      const size_t wnext = (size_t)cn * 4096;
       auto group = [&](const XFrags &xc, int kg, XFrags &xn, int c2, int kgn) {
-        const size_t woff = (size_t)cn * 4096 + (size_t)kg * 1024;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          load_y1(c2, kgn, q, xn);
-          mma2(xc, kg, q / 2, (q % 2) * 2);
-          if (q == 1) wf[kg][0] = *reinterpret_cast<const uint4 *>(wf_base0 + woff);
-          if (q == 3) wf[kg][1] = *reinterpret_cast<const uint4 *>(wf_base1 + woff);
+          load_y4(c2, kgn, q, xn);
+          mma2(xc, kg, q / 2, (q % 2) * 2, tr);
+          if (q == 1) wf[kg][0] = *reinterpret_cast<const uint4 *>(wb0 + wnext + (size_t)kg * 1024 + lane16);
+          if (q == 3) wf[kg][1] = *reinterpret_cast<const uint4 *>(wb1 + wnext + (size_t)kg * 1024 + lane16);
           __builtin_amdgcn_sched_barrier(0);
         }
       };
@@ -272,8 +316,8 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
     const TdnnChainLayer &L = p.mid[m];
     stage_params(L);
     const size_t frag_stride = (size_t)(CN / CBK) * 4096;
-    const unsigned char *wb = reinterpret_cast<const unsigned char *>(L.wfrag) + (size_t)(wave * 2) * frag_stride + (size_t)lane * 16;
-    yloop(wb, wb + frag_stride);
+    const unsigned char *wb = reinterpret_cast<const unsigned char *>(L.wfrag) + (size_t)(wave * 2) * frag_stride;
+    yloop(wb, wb + frag_stride, L.bias + wave * 64, TrNo{});
     stamp();                               // 5: main loop of the middle layer done
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();          // nobody reads the old Y any more (and the staged constants are visible)
@@ -288,7 +332,6 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
   {
     const TdnnChainLayer &L = p.last;
     const float act_lo = L.relu ? 0.0f : -INFINITY;
-    float *scr = reinterpret_cast<float *>(lds + SCR_OFF + wave * 4096);     // [16 frames][64 channels] f32, slots swizzled by row
     const int half = m0 >> 7;
     int first_seg = -1;
 #pragma unroll
@@ -298,83 +341,95 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
     const size_t frag_stride = (size_t)(CN / CBK) * 4096;
 #pragma unroll 1
     for (int cb = wave * 64; cb < L.cout_pad; cb += 512) {
-      const unsigned char *wb = reinterpret_cast<const unsigned char *>(L.wfrag) + (size_t)(cb / 32) * frag_stride + (size_t)lane * 16;
-      const float b_c = L.bias[cb + lane];
-      const float sc_c = L.scale != nullptr ? L.scale[cb + lane] : 1.0f;
-      yloop(wb, wb + frag_stride);
+      const unsigned char *wb = reinterpret_cast<const unsigned char *>(L.wfrag) + (size_t)(cb / 32) * frag_stride;
+      yloop(wb, wb + frag_stride, L.bias + cb, TrYes{});
       stamp();                             // 7, 9, 11: main loop of a unit done
-      const int ch_l = cb + lane;
-      float ps = 0.0f, pq = 0.0f, pv = 0.0f;
-      int cur_seg = -1;
-      auto flush = [&]() {
+      // Pooling epilogue, registers only.  acc[i][j][r] = channel cb + j*32 + lr, frame i*32 + 8 (r >> 2) + 4 lh + (r & 3): a
+      // lane sums its own frames (those with bit 2 of the row index == lh) per utterance, about the pivot of its first
+      // frame; the two lane halves publish separate partials
+      //   P[tile][segment slot][lh][3 = sum (u - pv), sum (u - pv)^2, pv][channel]
+      // which pool_finish_kernel merges (Chan et al.), knowing how many frames each half holds.  The BN scale multiplies the
+      // three moments at publication (u = scale * act(acc): moments about a pivot are linear / quadratic in it); the BN
+      // shift is added to the mean by pool_finish.
+      const float sc[2] = {L.scale != nullptr ? L.scale[cb + lr] : 1.0f, L.scale != nullptr ? L.scale[cb + 32 + lr] : 1.0f};
+      float ps[2] = {0.f, 0.f}, pq[2] = {0.f, 0.f}, pv[2] = {0.f, 0.f};
+      int cur_seg = -1;                    // per lane: the halves cross an utterance seam at different registers
+      auto publish = [&](bool mine) {      // lanes with `mine` write the moments of their current segment
         const int slot = cur_seg - first_seg;
-        if (slot >= 0 && slot < p.pool_slots && ch_l < p.ld_partial) {
-          float *dst = p.pool_partial + ((size_t)(half * p.pool_slots + slot) * 3) * p.ld_partial + ch_l;
-          dst[0] = ps;
-          dst[p.ld_partial] = pq;
-          dst[2 * p.ld_partial] = pv;
+        if (mine && cur_seg >= 0 && slot >= 0 && slot < p.pool_slots) {
+          float *dst = p.pool_partial + ((size_t)((half * p.pool_slots + slot) * 2 + lh) * 3) * p.ld_partial + cb + lr;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            if (cb + j * 32 + lr < p.ld_partial) {
+              dst[j * 32] = ps[j] * sc[j];
+              dst[j * 32 + p.ld_partial] = pq[j] * sc[j] * sc[j];
+              dst[j * 32 + 2 * p.ld_partial] = pv[j] * sc[j];
+            }
         }
-      };
-      auto u_of = [&](int r) {          // channel `lane` of scratch row r: u = act(acc + b) * scale (the BN shift is added by pool_finish)
-        const float v = scr[r * 64 + ((((lane >> 2) ^ r) << 2) | (lane & 3))];
-        return fmaxf(v + b_c, act_lo) * sc_c;
       };
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
+        const int rs_vec = (i < 2) ? rowseg_lo : rowseg_hi;
+        const unsigned long long in_frag = 0xffffffffull << ((i & 1) * 32);
+        const unsigned long long m_valid = __builtin_amdgcn_ballot_w64(rs_vec >= 0) & in_frag;
+        if (m_valid == 0) continue;                                                  // gap rows only
+        const int sg0 = __builtin_amdgcn_readlane(rs_vec, __builtin_ctzll(m_valid));
+        const unsigned long long m_same = __builtin_amdgcn_ballot_w64(rs_vec == sg0) & in_frag;
+        if (m_same == in_frag) {
+          // the 32 frames of the fragment belong to one utterance: 4 VALU operations per accumulator register
+          const bool chg = cur_seg != sg0;
+          if (__builtin_amdgcn_ballot_w64(chg) != 0) {
+            publish(chg);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          // rows i*32 + h*16 .. +15 sit in the lanes with (lr >> 4) == h; raw accumulators go to the scratch
-          if ((lr >> 4) == h) {
-            const int r = lr & 15;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const int slot = j * 8 + q * 2 + lh;
-                *reinterpret_cast<float4 *>(scr + r * 64 + ((slot ^ r) << 2)) =
-                    make_float4(acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
-              }
+            for (int j = 0; j < 2; ++j) {
+              const float v0 = max_lo(acc[i][j][0], act_lo);
+              ps[j] = chg ? 0.0f : ps[j]; pq[j] = chg ? 0.0f : pq[j]; pv[j] = chg ? v0 : pv[j];
+            }
+            cur_seg = chg ? sg0 : cur_seg;
           }
-          const int rg = i * 32 + h * 16;                       // first row of the group inside the tile
-          const int rs_vec = (rg < 64) ? rowseg_lo : rowseg_hi;
-          const unsigned long long in_grp = 0xffffull << (rg & 63);
-          const unsigned long long m_valid = __builtin_amdgcn_ballot_w64(rs_vec >= 0) & in_grp;
-          if (m_valid == 0) continue;                            // gap rows only
-          const int sg0 = __builtin_amdgcn_readlane(rs_vec, __builtin_ctzll(m_valid));
-          const unsigned long long m_same = __builtin_amdgcn_ballot_w64(rs_vec == sg0) & in_grp;
-          if (m_same == in_grp) {
-            if (sg0 != cur_seg) {
-              if (cur_seg >= 0) flush();
-              cur_seg = sg0; ps = 0.0f; pq = 0.0f; pv = u_of(0);
-            }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const float dlt = u_of(r) - pv;
-              ps += dlt;
-              pq = fmaf(dlt, dlt, pq);
+              const float dlt = max_lo(acc[i][j][r], act_lo) - pv[j];
+              s4[r & 3] += dlt;
+              q4[r & 3] = fmaf(dlt, dlt, q4[r & 3]);
             }
-          } else {
-            // rare (a gap row or an utterance seam inside the group): a ROLLED loop - unrolled, the 8 groups' row-by-row
-            // code with its flush() copies was 50 KiB of instructions around the fast path and thrashed the instruction cache
-#pragma unroll 1
-            for (int r = 0; r < 16; ++r) {
-              const int sg = __builtin_amdgcn_readlane(rs_vec, (rg & 63) + r);       // wave-uniform
-              if (sg < 0) continue;                                                   // gap row
-              const float u = u_of(r);
-              if (sg != cur_seg) {
-                if (cur_seg >= 0) flush();
-                cur_seg = sg; ps = 0.0f; pq = 0.0f; pv = u;
+            ps[j] += (s4[0] + s4[1]) + (s4[2] + s4[3]);
+            pq[j] += (q4[0] + q4[1]) + (q4[2] + q4[3]);
+          }
+        } else {
+          // an utterance seam or gap rows inside the fragment: register by register (frames ascend with r inside a half)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int f = (i & 1) * 32 + 8 * (r >> 2) + (r & 3);                    // lane index of the frame of half 0
+            const int sg_a = __builtin_amdgcn_readlane(rs_vec, f), sg_b = __builtin_amdgcn_readlane(rs_vec, f + 4);
+            const int sg = lh ? sg_b : sg_a;
+            const bool ok = sg >= 0;
+            const bool chg = ok && sg != cur_seg;
+            if (__builtin_amdgcn_ballot_w64(chg) != 0) {
+              publish(chg);
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                const float v0 = max_lo(acc[i][j][r], act_lo);
+                ps[j] = chg ? 0.0f : ps[j]; pq[j] = chg ? 0.0f : pq[j]; pv[j] = chg ? v0 : pv[j];
               }
-              const float dlt = u - pv;
-              ps += dlt;
-              pq = fmaf(dlt, dlt, pq);
+              cur_seg = chg ? sg : cur_seg;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const float dlt = ok ? max_lo(acc[i][j][r], act_lo) - pv[j] : 0.0f;
+              ps[j] += dlt;
+              pq[j] = fmaf(dlt, dlt, pq[j]);
             }
           }
         }
       }
-      if (cur_seg >= 0) flush();
+      publish(true);
       stamp();                             // 8, 10, 12: pooling epilogue of the unit done
     }
+    if (p.dbg != nullptr && lane == 0) p.dbg[((size_t)blockIdx.x * 8 + wave) * 16 + 15] = __builtin_amdgcn_s_memrealtime();
   }
 }
 

@@ -1012,7 +1012,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
             for (size_t k = i + 1; k < l; ++k) cp.mid[k - i - 1] = layer_of(net->ops[k]);
             cp.last = layer_of(lo);
             cp.pool_slots = slots; cp.ld_partial = lo.cout_pad; cp.row_seg = dr.row_seg;
-            if ((rc = ensure(net->poolpart_dev, (size_t)(p.rows / 128) * slots * 3 * cp.ld_partial * 4, c.s, false))) return rc;
+            if ((rc = ensure(net->poolpart_dev, (size_t)(p.rows / 128) * slots * 2 * 3 * cp.ld_partial * 4, c.s, false))) return rc;
             cp.pool_partial = reinterpret_cast<float *>(net->poolpart_dev.ptr);
             double fl = 0.0;
             for (size_t k = i; k <= l; ++k) fl += 2.0 * (double)bp.frames * net->ops[k].tdnn.in_ch * net->ops[k].tdnn.out_ch * net->ops[k].tdnn.n_taps;
@@ -1031,14 +1031,16 @@ int run_ops(RunCtx &c, size_t n_ops) {
               ASV_HIP_CHECK(hipStreamSynchronize(c.s));
               ASV_HIP_CHECK(hipMemcpy(h.data(), dbg.ptr, h.size() * 8, hipMemcpyDeviceToHost));
               ASV_HIP_CHECK(hipFree(dbg.ptr));
-              double sum[16] = {0}; size_t cnt = 0;
+              double sum[16] = {0}; size_t cnt = 0; double cyc = 0, rt = 0;
               for (size_t w = 0; w < nwg * 8; ++w) {
                 const unsigned long long *t = &h[w * 16];
                 if (t[0] == 0) continue;
                 for (int k = 1; k < 13; ++k) if (t[k] > t[k - 1]) sum[k] += (double)(t[k] - t[k - 1]);
+                if (t[12] > t[0] && t[15] > t[14]) { cyc += (double)(t[12] - t[0]); rt += (double)(t[15] - t[14]); }
                 ++cnt;
               }
               fprintf(stderr, "[chain dbg] %zu waves, mean cycles per phase:", cnt);
+              fprintf(stderr, " [shader clock %.0f MHz, %.1f us per workgroup]", rt > 0 ? 100.0 * cyc / rt : 0.0, cnt ? rt / 100.0 / (double)cnt : 0.0);
               for (int k = 1; k < 13; ++k) fprintf(stderr, " %d:%.0f", k, sum[k] / (double)std::max<size_t>(cnt, 1));
               fprintf(stderr, "\n");
             }
@@ -1046,7 +1048,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
             po.skipped = true;
             const auto &q = po.pool;
             PoolFinishParams f;
-            f.partial = cp.pool_partial; f.ld_partial = cp.ld_partial; f.pool_slots = slots;
+            f.partial = cp.pool_partial; f.ld_partial = cp.ld_partial; f.pool_slots = slots; f.lh_split = 1;
             f.row_seg = dr.row_seg; f.rows = dr.rows_pad; f.seg_row0 = dr.seg_row0; f.seg_len = dr.seg_len;
             f.shift = lo.shift;
             f.out = reinterpret_cast<float *>(net->arena[q.out_buf].ptr) + q.out_ch_off; f.ld_out = net->bufs[q.out_buf].ld; f.channels = q.channels;
@@ -1130,7 +1132,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
           if (fuse) {
             const auto &q = po.pool;
             PoolFinishParams f;
-            f.partial = p.pool_partial; f.ld_partial = p.ld_partial; f.pool_slots = pool_slots;
+            f.partial = p.pool_partial; f.ld_partial = p.ld_partial; f.pool_slots = pool_slots; f.lh_split = 0;
             f.row_seg = dr.row_seg; f.rows = dr.rows_pad; f.seg_row0 = dr.seg_row0; f.seg_len = dr.seg_len;
             f.shift = op.shift;
             f.out = reinterpret_cast<float *>(net->arena[q.out_buf].ptr) + q.out_ch_off; f.ld_out = net->bufs[q.out_buf].ld; f.channels = q.channels;
