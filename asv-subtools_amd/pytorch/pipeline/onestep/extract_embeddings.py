@@ -14,6 +14,13 @@ calling shell script greps the log for "Error".
 
 Extra options: --batch-frames / --batch-utts bound a batch; --verbose true restores the reference's
 per-utterance "Process utterance for key ..." line (a measurable cost at >100k utterances/s).
+
+Multi-GPU (--sharded true, launched as `python -m torch.distributed.run --nproc-per-node N ... extract_embeddings.py ...`, one
+process per GPU): replaces the reference's `nj` jobs over a length-balanced split of feats.scp and the final
+`cat xvector.JOB.scp` (pipeline/extract_xvectors_for_pytorch.sh:90-100,125-151; splitDataByLength.sh:44-80).  Every rank reads
+the scp (feats-rspecifier must be `scp:...`; lengths from --utt2num-frames or from the matrix headers), takes its shard of
+libs.amd.shard.balance_by_length, extracts it, ONE all-gather (RCCL over xGMI) collects the embeddings and rank 0 writes the
+vectors in scp order.
 """
 
 import argparse
@@ -42,6 +49,9 @@ def get_args(argv=None):
     parser.add_argument("--batch-utts", type=int, default=1024, help="Upper bound of utterances per packed batch.")
     parser.add_argument("--max-chunk", type=int, default=0, help="Override the model's maxChunk (0 = the decorator's value).")
     parser.add_argument("--verbose", type=str, default="false", choices=["true", "false"])
+    parser.add_argument("--sharded", type=str, default="false", choices=["true", "false"],
+                        help="One process per GPU under torch.distributed.run: shard the scp by length, all-gather, rank 0 writes.")
+    parser.add_argument("--utt2num-frames", type=str, default="", help="Kaldi utt2num_frames of the scp (sharded mode; default: read the matrix headers).")
     parser.add_argument("model_path", metavar="model-path", type=str, help="The model used to extract embeddings.")
     parser.add_argument("feats_rspecifier", metavar="feats-rspecifier", type=str, help="")
     parser.add_argument("vectors_wspecifier", metavar="vectors-wspecifier", type=str, help="")
@@ -129,6 +139,83 @@ def extract_stream(model, r, w, batch_frames, batch_utts, max_chunk, verbose=Fal
     return n_done
 
 
+def read_scp(path):
+    """[(key, rxfile)] of a Kaldi scp ('scp:' prefix optional)."""
+    name = path.split(":", 1)[1] if path.startswith("scp:") else path
+    with open(name) as f:
+        return [tuple(line.strip().split(None, 1)) for line in f if line.strip()]
+
+
+def matrix_rows(rxfile):
+    """Number of rows of the matrix behind an scp entry, from its header only (FM / DM / CM), or by decoding it (text)."""
+    import struct
+    fd = kaldi_io.open_or_fd(rxfile, "rb")
+    try:
+        head = fd.read(2)
+        if head != b"\0B":
+            fd.close()
+            return int(kaldi_io.read_mat(rxfile).shape[0])
+        tag = fd.read(3)
+        if tag in (b"FM ", b"DM "):
+            return struct.unpack("<bibi", fd.read(10))[1]
+        if tag == b"CM ":
+            return struct.unpack("<ffii", fd.read(16))[2]
+        raise kaldi_io.UnknownMatrixHeader("The header contained '%s'" % tag)
+    finally:
+        fd.close()
+
+
+def extract_sharded_scp(extract_batch, entries, lengths, w, batch_frames, batch_utts, verbose=False, device=None):
+    """Sharded extraction of scp entries (one call per rank, torch.distributed initialised or not):
+        extract_batch(list of [T, D] float32 matrices) -> [b, E] tensor
+    Every rank extracts its length-balanced shard; one all-gather; rank 0 writes the ark entries to `w` in scp order.
+    Returns the number of embeddings (on every rank)."""
+    import torch.distributed as dist
+    from libs.amd import shard
+    rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+    load = lambda i: np.ascontiguousarray(kaldi_io.read_mat(entries[i][1]), dtype=np.float32)
+    emb = shard.extract_sharded(extract_batch, lengths, load, max_frames=batch_frames, max_utts=batch_utts, device=device)
+    if rank == 0:
+        keys = [k for k, _ in entries]
+        if verbose:
+            for key in keys:
+                print("Process utterance for key {0}".format(key))
+        w.write(kaldi_io.vec_flt_ark_bytes(keys, emb.cpu().numpy()))
+    return int(emb.shape[0])
+
+
+def run_sharded(args, model, max_chunk, verbose):
+    import torch.distributed as dist
+    if not args.feats_rspecifier.startswith("scp:"):
+        raise ValueError("--sharded needs random access to the features: pass 'scp:feats.scp' (the reference shards feats.scp too, "
+                         "splitDataByLength.sh:44-80), not %r" % args.feats_rspecifier)
+    entries = read_scp(args.feats_rspecifier)
+    if args.utt2num_frames:
+        table = dict(line.split() for line in open(args.utt2num_frames) if line.strip())
+        lengths = np.array([int(table[k]) for k, _ in entries], dtype=np.int64)
+    else:
+        lengths = np.array([matrix_rows(rx) for _, rx in entries], dtype=np.int64)
+    engine = model._amd_engine()
+    dev = torch.device("cuda", engine.device_index)
+    if max_chunk is None:
+        max_chunk = getattr(type(model).extract_embedding, "max_chunk", 10000)
+
+    def extract_batch(mats):
+        offs = np.zeros(len(mats) + 1, dtype=np.int32)
+        np.cumsum([m.shape[0] for m in mats], out=offs[1:])
+        feats = torch.from_numpy(np.concatenate(mats, axis=0)).to(dev)
+        return engine.extract_device(feats, offs, max_chunk=max_chunk)
+
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    w = kaldi_io.open_or_fd(args.vectors_wspecifier, "wb") if rank == 0 else None
+    try:
+        with torch.cuda.device(dev):
+            return extract_sharded_scp(extract_batch, entries, lengths, w, args.batch_frames, args.batch_utts, verbose, device=dev)
+    finally:
+        if w is not None:
+            w.close()
+
+
 def main(argv=None):
     print(" ".join(sys.argv))
     args = get_args(argv)
@@ -142,6 +229,18 @@ def main(argv=None):
         if not utils.to_bool(args.use_gpu):
             raise RuntimeError("asv-subtools_amd extracts on a ROCm device only (--use-gpu=true); there is no CPU path")
 
+        sharded = utils.to_bool(args.sharded)
+        if sharded:
+            import torch.distributed as dist
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC for RCCL on these hosts
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+            if args.gpu_id == "":
+                args.gpu_id = str(local_rank)                               # one process per GPU
+            torch.cuda.set_device(int(args.gpu_id))
+            if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", int(args.gpu_id)))   # "nccl" is RCCL on ROCm
+
         model = utils.create_model_from_py(model_blueprint, model_creation)
         model.load_state_dict(torch.load(args.model_path, map_location="cpu"), strict=False)
         model = utils.select_model_device(model, args.use_gpu, gpu_id=args.gpu_id)
@@ -150,8 +249,15 @@ def main(argv=None):
         verbose = utils.to_bool(args.verbose)
 
         n_done = 0
-        with kaldi_io.open_or_fd(args.feats_rspecifier, "rb") as r, kaldi_io.open_or_fd(args.vectors_wspecifier, "wb") as w:
-            n_done = extract_stream(model, r, w, args.batch_frames, args.batch_utts, max_chunk, verbose)
+        if sharded:
+            import torch.distributed as dist
+            n_done = run_sharded(args, model, max_chunk, verbose)
+            if dist.is_initialized():
+                dist.barrier()
+                dist.destroy_process_group()
+        else:
+            with kaldi_io.open_or_fd(args.feats_rspecifier, "rb") as r, kaldi_io.open_or_fd(args.vectors_wspecifier, "wb") as w:
+                n_done = extract_stream(model, r, w, args.batch_frames, args.batch_utts, max_chunk, verbose)
         print("Extracted {0} embeddings.".format(n_done))
     except BaseException as e:
         if not isinstance(e, KeyboardInterrupt):

@@ -102,3 +102,52 @@ def test_online_script_wav_scp_to_ark(tmp_path):
         feat = feat - feat.mean(0)
         want = O.extract_embedding(lambda c: O.xvector_embed(c, sd, "far"), feat)
         assert rel_err(v, want) < 1e-4, k
+
+
+def test_extract_embeddings_script_sharded_mode_matches_stream_mode(tmp_path):
+    """--sharded true (here: one rank, no launcher; the world-2 control flow runs under gloo in tests/test_sharded_script_gloo.py):
+    scp in, length-balanced batches, vectors in scp order - the same embeddings as the streaming mode and the reference."""
+    import torch
+    from libs.support import kaldi_io
+    import libs.support.utils as utils
+    g, sd = helpers.golden_state_dict("xvector_near_ragged")
+    mats = helpers.golden_feats(g)
+    keys = ["utt%03d" % i for i in range(len(mats))]
+    feats_ark, feats_scp = tmp_path / "feats.ark", tmp_path / "feats.scp"
+    with open(feats_ark, "wb") as f, open(feats_scp, "w") as s:
+        for k, m in zip(keys, mats):
+            f.write((k + " ").encode())
+            s.write("%s %s:%d\n" % (k, feats_ark, f.tell()))
+            kaldi_io.write_mat(f, m)
+    params = tmp_path / "final.params"
+    torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, str(params))
+    cfg = tmp_path / "nnet.config"
+    utils.write_nnet_config(os.path.join(helpers.MODEL_DIR, "xvector.py"), str(g["creation"]), str(cfg))
+    out_ark = tmp_path / "xvector.ark"
+    script = os.path.join(helpers.REPO, "asv-subtools_amd", "pytorch", "pipeline", "onestep", "extract_embeddings.py")
+    res = subprocess.run([sys.executable, script, "--nnet-config", str(cfg), "--use-gpu", "true", "--sharded", "true", "--batch-frames", "700",
+                          str(params), "scp:%s" % feats_scp, "ark:%s" % out_ark], capture_output=True, text=True, timeout=600)     # default precision (f32x)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "Extracted %d embeddings." % len(keys) in res.stdout
+    got = list(kaldi_io.read_vec_flt_ark(str(out_ark)))
+    assert [k for k, _ in got] == keys
+    for (k, v), ref in zip(got, g["embeddings"]):
+        assert rel_err(v, ref) < 1e-4, k
+
+
+def test_c4_standin_full_size_single_gpu():
+    """BASELINE configs[3] at SURVEY 8(d) size on one GPU (the 8-GPU run is the same script under torch.distributed.run):
+    4 708 ECAPA-TDNN utterances of 400..1500 frames, 37 720 trials; the parity-grade f32x mode meets the north-star EER gate
+    against reference-equivalent (f32, oracle-checked) embeddings; the bf16 throughput mode is reported and bounded."""
+    import json
+    script = os.path.join(helpers.REPO, "tests", "c4_standin.py")
+    out = {}
+    for prec in ("f32x", "bf16"):
+        res = subprocess.run([sys.executable, script, "--precision", prec, "--oracle-checks", "2" if prec == "f32x" else "0"], capture_output=True, text=True, timeout=1500)
+        assert res.returncode == 0, res.stdout + res.stderr
+        out[prec] = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+        print(out[prec])
+    assert out["f32x"]["oracle_max_rel_err_f32"] < 1e-4
+    assert 0.5 < out["f32x"]["eer_reference_equivalent_percent"] < 40.0
+    assert abs(out["f32x"]["eer_delta_percent"]) < 0.01, out["f32x"]
+    assert abs(out["bf16"]["eer_delta_percent"]) < 0.1, out["bf16"]
