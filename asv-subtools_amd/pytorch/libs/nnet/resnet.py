@@ -10,9 +10,9 @@ implicit-GEMM kernel as the TDNN layers with a wider staged window; stride-2 con
 of layers 2-4 and their 1x1 down-sampling branch) go through an im2col gather + one GEMM.  Eval
 BatchNorm follows the convolution directly, so it is folded into the weights (scale) and bias (shift).
 
-Implemented: BasicBlock in the original (conv-BN-ReLU) form with optional SE, head conv 3x3 / stride 1,
-no max-pool - the configuration of BASELINE config C5 and of the reference launchers
-(runResnetXvector_online.py:221-260).  Other options raise.
+Implemented: BasicBlock in both forms - the original conv-BN-ReLU one (BASELINE config C5 and the reference launchers,
+runResnetXvector_online.py:221-260) and the full pre-activation BN-ReLU-conv one (the blueprint's default,
+resnet_xvector.py:38; resnet.py:59-104) - with optional SE, head conv 3x3 / stride 1, no max-pool.  Other options raise.
 """
 
 import numpy as np
@@ -42,7 +42,8 @@ def _folded_bn(bn):
 
 
 def emit_conv_bn(x, conv, bn, relu):
-    """conv (3x3 pad 1 or 1x1, stride 1|2, no bias) -> eval BN [-> ReLU] on a rank-4 grid Sym."""
+    """conv (3x3 pad 1 or 1x1, stride 1|2, no bias) -> [eval BN] [-> ReLU] on a rank-4 grid Sym (bn=None: the bare
+    convolution, as the second one of a pre-activation block)."""
     g = x.graph
     spec = g.grid_spec(x.view.tid)
     if spec is None or x.rank != 4:
@@ -51,7 +52,10 @@ def emit_conv_bn(x, conv, bn, relu):
     if conv.kernel_size not in ((3, 3), (1, 1)) or conv.stride[0] != conv.stride[1] or stride not in (1, 2) or conv.groups != 1 \
             or conv.dilation != (1, 1) or conv.padding != (k // 2, k // 2) or conv.bias is not None:
         raise _ir.TraceError("Conv2d%r: only 3x3/pad 1 and 1x1 kernels with stride 1 or 2 are implemented" % (conv,))
-    scale, shift = _folded_bn(bn)
+    if bn is not None:
+        scale, shift = _folded_bn(bn)
+    else:
+        scale, shift = np.ones(conv.out_channels, dtype=np.float32), np.zeros(conv.out_channels, dtype=np.float32)
     w = _np(conv.weight).astype(np.float64) * scale.astype(np.float64)[:, None, None, None]       # [Cout, Cin, kF, kT]
     cout, cin = w.shape[0], w.shape[1]
     half = k // 2
@@ -89,18 +93,23 @@ class BasicBlock(nn.Module):
             raise ValueError("BasicBlock only supports groups=1 and base_width=64")
         if dilation > 1:
             raise NotImplementedError("Dilation > 1 not supported in BasicBlock")
-        if full_pre_activation:
-            raise NotImplementedError("full_pre_activation=True (BN-ReLU-conv blocks) is not implemented on the MI355X path; "
-                                      "BASELINE config C5 and the reference launchers use full_pre_activation=False")
         self.downsample = downsample
         self.stride = stride
         self.full_pre_activation = full_pre_activation
-        self.conv1 = conv3x3(inplanes, planes, Conv, stride)
-        self.bn1 = norm_layer(planes, **norm_layer_params)
-        self.relu1 = nn.ReLU(inplace=True)
-        self.conv2 = conv3x3(planes, planes, Conv)
-        self.bn2 = norm_layer(planes, **norm_layer_params)
-        self.relu2 = nn.ReLU(inplace=True)
+        if full_pre_activation:                          # resnet.py:59-68: BN-ReLU-conv, BN-ReLU-conv (module order = state_dict order)
+            self.bn1 = norm_layer(inplanes, **norm_layer_params)
+            self.relu1 = nn.ReLU(inplace=True)
+            self.conv1 = conv3x3(inplanes, planes, Conv, stride)
+            self.bn2 = norm_layer(planes, **norm_layer_params)
+            self.relu2 = nn.ReLU(inplace=True)
+            self.conv2 = conv3x3(planes, planes, Conv)
+        else:                                            # resnet.py:46-56
+            self.conv1 = conv3x3(inplanes, planes, Conv, stride)
+            self.bn1 = norm_layer(planes, **norm_layer_params)
+            self.relu1 = nn.ReLU(inplace=True)
+            self.conv2 = conv3x3(planes, planes, Conv)
+            self.bn2 = norm_layer(planes, **norm_layer_params)
+            self.relu2 = nn.ReLU(inplace=True)
         self.se = SEBlock_2D(planes, se_ratio) if use_se else nn.Identity()
 
     def forward(self, x):
@@ -108,8 +117,16 @@ class BasicBlock(nn.Module):
             raise NotImplementedError("BasicBlock.forward() on a torch tensor: eager forward is not part of asv-subtools_amd")
         g = x.graph
         identity = x if self.downsample is None else emit_conv_bn(x, self.downsample[0], self.downsample[1], relu=False)
-        y = emit_conv_bn(x, self.conv1, self.bn1, relu=True)
-        y = emit_conv_bn(y, self.conv2, self.bn2, relu=False)
+        if self.full_pre_activation:
+            # resnet.py:87-104: relu(bn1(x)) is one elementwise pass (gap rows stay zero: the next convolution pads with
+            # zeros AFTER the activation); bn2 + ReLU follow conv1 directly and fold into its weights / epilogue; conv2 is bare
+            s1, t1 = _folded_bn(self.bn1)
+            a = _ir.Sym(g, g.eltwise(x.view, scale=s1, shift=t1, act="relu"), 4)
+            y = emit_conv_bn(a, self.conv1, self.bn2, relu=True)
+            y = emit_conv_bn(y, self.conv2, None, relu=False)
+        else:
+            y = emit_conv_bn(x, self.conv1, self.bn1, relu=True)
+            y = emit_conv_bn(y, self.conv2, self.bn2, relu=False)
         seg_scale = None
         if isinstance(self.se, SEBlock_2D):
             spec = g.grid_spec(y.view.tid)
@@ -119,7 +136,7 @@ class BasicBlock(nn.Module):
             w1 = _np(self.se.fc_1.weight)[:, :, None] * np.float32(spec[3] / float(spec[2]))
             h = g.tdnn(m, w1, _np(self.se.fc_1.bias), [0], 0, act1="relu")
             seg_scale = g.tdnn(h, _np(self.se.fc_2.weight)[:, :, None], _np(self.se.fc_2.bias), [0], 0, act1="sigmoid")
-        out = g.eltwise(y.view, b=identity.view, seg_scale=seg_scale, act="relu")
+        out = g.eltwise(y.view, b=identity.view, seg_scale=seg_scale, act=None if self.full_pre_activation else "relu")
         return _ir.Sym(g, out, 4)
 
 

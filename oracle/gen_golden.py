@@ -146,6 +146,13 @@ CASES = {
                           creation="ResNetXvector(40,10,training=False,cmvn=True,cmvn_params={'mean_norm':True,'std_norm':True},"
                                    "resnet_params={'full_pre_activation':False})",
                           dim=40, utts=[(120, 5200), (45, 5201)], wseed=8),
+    # the blueprint's DEFAULT resnet_params: full pre-activation blocks (BN-ReLU-conv), no SE, default fc2
+    "resnet34_preact": dict(blueprint="resnet_xvector.py", creation="ResNetXvector(80,10,training=False)",
+                            dim=80, utts=[(200, 5300), (131, 5301), (9, 5302)], wseed=9),
+    # pre-activation + SE, odd feature dim
+    "resnet34se_preact": dict(blueprint="resnet_xvector.py",
+                              creation="ResNetXvector(45,10,training=False,resnet_params={'use_se':True,'se_ratio':4})",
+                              dim=45, utts=[(120, 5400), (64, 5401)], wseed=10),
     # no SE, default fc2 (ReLU + affine BN), odd feature dim -> ceil division at every stride-2 stage
     "resnet34_plain": dict(blueprint="resnet_xvector.py",
                            creation="ResNetXvector(61,10,training=False,resnet_params={'full_pre_activation':False})",

@@ -280,6 +280,21 @@ def se_block_2d(x, sd, prefix):
     return x * s.astype(x.dtype)
 
 
+def basic_block_preact(x, sd, prefix, stride):
+    """BasicBlock full pre-activation form (resnet.py:87-104): BN-ReLU-conv, BN-ReLU-conv, SE, + identity (no final ReLU);
+    the down-sampling branch works on the raw block input."""
+    identity = x
+    y = np.maximum(batchnorm_eval(x, sd, prefix + ".bn1"), 0)
+    y = conv2d(y, sd[prefix + ".conv1.weight"], stride, 1)
+    y = np.maximum(batchnorm_eval(y, sd, prefix + ".bn2"), 0)
+    y = conv2d(y, sd[prefix + ".conv2.weight"], 1, 1)
+    if prefix + ".se.fc_1.weight" in sd:
+        y = se_block_2d(y, sd, prefix + ".se")
+    if prefix + ".downsample.0.weight" in sd:
+        identity = batchnorm_eval(conv2d(x, sd[prefix + ".downsample.0.weight"], stride, 0), sd, prefix + ".downsample.1")
+    return y + identity
+
+
 def basic_block(x, sd, prefix, stride):
     """BasicBlock original form (resnet.py:70-85): conv-BN-ReLU-conv-BN-SE-(+identity)-ReLU;
     downsample = 1x1 conv (stride) + BN when present in the checkpoint."""
@@ -295,13 +310,14 @@ def basic_block(x, sd, prefix, stride):
     return np.maximum(y + identity, 0)
 
 
-def resnet_trunk(x, sd, prefix="resnet", layers=(3, 4, 6, 3)):
+def resnet_trunk(x, sd, prefix="resnet", layers=(3, 4, 6, 3), preact=False):
     """ResNet._forward_impl (resnet.py:352-368) with head_conv 3x3/stride 1, no max-pool."""
     y = conv2d(x, sd[prefix + ".conv1.weight"], 1, 1)
     y = np.maximum(batchnorm_eval(y, sd, prefix + ".bn1"), 0)
+    block = basic_block_preact if preact else basic_block
     for li, n in enumerate(layers):
         for b in range(n):
-            y = basic_block(y, sd, "%s.layer%d.%d" % (prefix, li + 1, b), 2 if (li > 0 and b == 0) else 1)
+            y = block(y, sd, "%s.layer%d.%d" % (prefix, li + 1, b), 2 if (li > 0 and b == 0) else 1)
     return y
 
 
@@ -315,12 +331,12 @@ def input_sequence_norm(x, mean_norm=True, std_norm=False, eps=1e-10):
     return ((x - mean) / std).astype(x.dtype)
 
 
-def resnet_embed(x, sd, position="near", fc2_nonlinearity="relu", layers=(3, 4, 6, 3), cmvn=None):
+def resnet_embed(x, sd, position="near", fc2_nonlinearity="relu", layers=(3, 4, 6, 3), cmvn=None, preact=False):
     """model/resnet_xvector.py:183-208.  x [T, D] -> trunk on [T, F=D, 1] -> [T', F', C] ->
     reshape to channel index c*F' + f (resnet_xvector.py:193) -> StatisticsPooling -> fc2."""
     if cmvn is not None:
         x = input_sequence_norm(x, **cmvn)
-    y = resnet_trunk(x[:, :, None], sd, "resnet", layers)           # [T', F', C]
+    y = resnet_trunk(x[:, :, None], sd, "resnet", layers, preact)   # [T', F', C]
     To, Fo, C = y.shape
     feat = y.transpose(0, 2, 1).reshape(To, C * Fo)                 # column index c*F' + f
     s = statistics_pooling(feat)[None, :]

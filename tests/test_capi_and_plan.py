@@ -98,7 +98,8 @@ def test_ecapa_traced_program_reproduces_reference_on_cpu(name, limit):
         assert rel_err(ir_interp.extract(graph, x), ref) < 2e-5
 
 
-@pytest.mark.parametrize("name,idx", [("resnet34se_c5", 2), ("resnet34se_c5", 3), ("resnet34_plain", 1), ("resnet34_cmvn", 1)])
+@pytest.mark.parametrize("name,idx", [("resnet34se_c5", 2), ("resnet34se_c5", 3), ("resnet34_plain", 1), ("resnet34_cmvn", 1), ("resnet34_preact", 2),
+                                      ("resnet34se_preact", 1)])
 def test_resnet_traced_program_reproduces_reference_on_cpu(name, idx):
     """2-D trunk: row-flattened (time, frequency) grids, BN folded into the convolutions, im2col for the
     stride-2 convolutions, SE with the pitch/width factor folded, per-bin pooling + permuted fc2 columns."""

@@ -10,11 +10,13 @@ from helpers import rel_err
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["resnet34se_c5", "resnet34_plain", "resnet34_cmvn"])
-def test_resnet_f32_vs_reference_golden(name):
+@pytest.mark.parametrize("precision", ["f32", "f32x"])
+@pytest.mark.parametrize("name", ["resnet34se_c5", "resnet34_plain", "resnet34_cmvn", "resnet34_preact", "resnet34se_preact"])
+def test_resnet_f32_vs_reference_golden(name, precision):
+    """incl. the blueprint's default configuration: full pre-activation blocks (resnet34_preact = ResNetXvector(80, 10, training=False))"""
     g, sd, model = helpers.golden_model(name)
     model.cuda()
-    model.amd_precision = "f32"
+    model.amd_precision = precision
     got = model.extract_embedding_batch(helpers.golden_feats(g)).numpy()
     assert got.shape == g["embeddings"].shape
     for i, (T, _) in enumerate(g["utts"]):
@@ -53,3 +55,13 @@ def test_narrow_grid_conv_kernel_agrees_with_generic_gemm_tile(monkeypatch):
     monkeypatch.setenv("ASV_AMD_SMALL_TILES", "1")
     slow = model.extract_embedding_batch(mats).numpy()                     # new flags = new engine (framework.py caches per flag set)
     assert np.isfinite(fast).all() and np.array_equal(fast, slow)
+
+
+def test_resnet_preactivation_bf16_is_close():
+    g, sd, model = helpers.golden_model("resnet34_preact")
+    model.cuda()
+    model.amd_precision = "bf16"
+    got = model.extract_embedding_batch(helpers.golden_feats(g)).numpy()
+    ref = g["embeddings"]
+    cos = (got * ref).sum(1) / np.linalg.norm(got, axis=1) / np.linalg.norm(ref, axis=1)
+    assert cos.min() > 0.998, cos

@@ -153,3 +153,14 @@ def test_factored_xvector_program_reproduces_reference_on_cpu():
         assert [op.kind for op in graph.ops].count("tdnn") >= 19            # 1 + 8 x 2 + layer10 + embedding layer(s)
         for x, ref in zip(helpers.golden_feats(g), g["embeddings"]):
             assert rel_err(ir_interp.extract(graph, x), ref) < 1e-5, name
+
+
+@pytest.mark.parametrize("name,preact,fc2_act,idx", [("resnet34se_c5", False, "", 2), ("resnet34_plain", False, "relu", 1), ("resnet34_preact", True, "relu", 2),
+                                                     ("resnet34se_preact", True, "relu", 1)])
+def test_np_oracle_resnet_matches_reference(name, preact, fc2_act, idx):
+    """The numpy ResNet restatement - original (resnet.py:70-85) and full pre-activation (87-104, the blueprint's default) blocks -
+    against the reference's own outputs."""
+    g, sd = helpers.golden_state_dict(name)
+    x = helpers.golden_feats(g)[idx]
+    got = O.extract_embedding(lambda c: O.resnet_embed(c, sd, "near", fc2_act, preact=preact), x)
+    assert rel_err(got, g["embeddings"][idx]) < 2e-5, name
