@@ -137,6 +137,16 @@ struct TdnnChainParams {
   unsigned long long *dbg;      // developer aid (ASV_AMD_CHAIN_DBG=1): [workgroup][wave][16] s_memtime stamps at the phase boundaries, or nullptr
 };
 int launch_tdnn_chain(const TdnnChainParams &p, hipStream_t s);
+// ECAPA Res2NetBlock as one kernel (kernels_res2.hip)
+constexpr int kRes2Width = 128;
+struct Res2KernelParams {
+  const void *x; void *y; int ldx, ldy, rows;       // bf16 rows; x / y already offset to their channel views
+  const void *wfrag;                                 // [branches][4 n-frag][3 taps][2 chunks][4 k-groups][lane][8] bf16
+  const float *bias, *scale, *shift;                 // [branches][128]
+  const uint32_t *row_valid;
+  int branches, dilation;
+};
+int launch_res2_chain(const Res2KernelParams &p, hipStream_t s);
 void pack_tdnn_weight_frags(const float *w, int out_ch, int in_ch, int tot_ctx, int left_ctx, const int *taps, int n_taps,
                             int cout_pad, int cin_pad, uint16_t *dst, uint16_t *dst_lo = nullptr);
 // f32-grade split-bf16 kernel of the f32x precision mode (kernels_tdnn_x3.hip): f32 activations, hi / lo weight fragments

@@ -1,0 +1,205 @@
+// ECAPA-TDNN Res2NetBlock (model/ecapa_tdnn_xvector.py:42-75 of the reference) as ONE kernel.
+//
+//   x_0 .. x_7 = the eight 128-channel groups of the block input;  y_0 = x_0;
+//   y_i = BN(ReLU(TDNN_{[-d, 0, d]}(y_{i-1} + x_i)))   (i = 1: TDNN(x_1));   output = cat(y_0 .. y_7)
+//
+// Seven dependent 128 -> 128 convolutions: as seven launches (the r1 path) each one reads two and writes one
+// 76800 x 128 bf16 slice through HBM / L2 for 98 kFLOP per row - 37 us per launch at 200 TFLOP/s, 21 % of an ECAPA
+// step.  Here a workgroup owns 128 output rows and walks the seven branches with the running tensor in LDS:
+//   * window = 128 rows + 32 recomputed rows on each side (branch i needs y_{i-1} at rows +-d: after seven branches
+//     7 d <= 28 rows of the margin are stale, the 128 central rows are exact; +19 % MFMA work at d = 4);
+//   * three LDS images of the window, [row][128 ch] bf16 with the 16-byte slots XOR-swizzled by (row & 15):
+//       A  input of the running convolution (read with the three taps as shifted rows; 4 zero rows above / below),
+//       B  its output y_i (written by the epilogue, streamed to HBM in full 256-byte rows afterwards),
+//       X  the next group x_{i+1}, fetched by LDS-DMA while the convolution runs;
+//     the epilogue adds X to y_i and writes A for the next branch (bf16(bf16(y) + x): the rounding of the per-layer path);
+//   * 8 waves = 4 channel fragments x 2 row halves, each 96 rows x 32 channels (3 accumulators), K = 3 taps x 128 as
+//     24 k-groups: weight fragments from L2 (fragment order of pack_tdnn_weight_frags), 3 ds_read_b128 per 3 MFMAs;
+//   * two barriers per branch.  One workgroup (512 threads, 147 KiB LDS) per CU.
+#include "device_utils.h"
+
+namespace asv {
+namespace {
+
+constexpr int RW = kRes2Width;            // 128 channels per branch
+constexpr int RM = 128;                   // output rows per workgroup
+constexpr int RMARGIN = 32;               // recomputed rows per side (>= 7 branches x dilation 4)
+constexpr int RWIN = RM + 2 * RMARGIN;    // 192 = 6 row fragments
+constexpr int RPAD = 4;                   // zero rows around A (taps of the outermost window rows)
+constexpr int RROWB = RW * 2;             // 256 B per row
+constexpr int A_BYTES = (RWIN + 2 * RPAD) * RROWB;   // 51200
+constexpr int B_OFF = A_BYTES, X_OFF = B_OFF + RWIN * RROWB;
+constexpr int RES2_LDS = X_OFF + RWIN * RROWB;        // 149504
+static_assert(RES2_LDS <= 163840, "160 KiB of LDS per CU");
+static_assert(7 * kHalo <= RMARGIN && kHalo <= RPAD, "margin must cover seven branches of the largest dilation");
+
+typedef __attribute__((address_space(3))) unsigned char res2_lds_byte;
+
+__device__ __forceinline__ void res2_glds16(const void *gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
+__global__ __launch_bounds__(512, 2) void res2_chain_kernel(const Res2KernelParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[RES2_LDS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nf = wave & 3, rh = wave >> 2;               // channel fragment, row half
+  const int lr = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.x * RM;
+  const int d = p.dilation;
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(res2_lds_byte *)lds);
+  const unsigned char *hg = reinterpret_cast<const unsigned char *>(p.x);
+  unsigned char *og = reinterpret_cast<unsigned char *>(p.y);
+  const size_t x_pitch = (size_t)p.ldx * 2, y_pitch = (size_t)p.ldy * 2;
+
+  // window of group g -> LDS image at `off` whose first row has buffer index `row0` (the swizzle uses the buffer row)
+  auto issue_window = [&](int g, uint32_t off, int row0) {
+#pragma unroll
+    for (int i = 0; i < RWIN / 4 / 8; ++i) {                 // 48 four-row pieces, 6 per wave
+      const int piece = wave + i * 8;
+      const int r = piece * 4 + (lane >> 4);                  // window row
+      const int grow = min(max(m0 - RMARGIN + r, 0), p.rows - 1);   // beyond the ends: the first / last row are zero gap rows
+      const int slot = (lane & 15) ^ ((row0 + r) & 15);
+      const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + off + (uint32_t)(row0 * RROWB) + (uint32_t)piece * 1024u);
+      res2_glds16(hg + (size_t)grow * x_pitch + (size_t)g * RROWB + (size_t)slot * 16, dst);
+    }
+  };
+
+  issue_window(1, 0, RPAD);                                   // A = x_1
+  if (p.branches > 1) issue_window(2, X_OFF, 0);              // X = x_2
+  if (tid < 2 * RPAD * 16) {                                  // the zero rows of A
+    const int r = tid >> 4, row = r < RPAD ? r : RWIN + r;
+    *reinterpret_cast<uint4 *>(lds + row * RROWB + (tid & 15) * 16) = make_uint4(0, 0, 0, 0);
+  }
+  // y_0 = x_0: the pass-through group, 128 rows x 256 B
+#pragma unroll
+  for (int it = 0; it < RM * 16 / 512; ++it) {
+    const int idx = it * 512 + tid, row = m0 + (idx >> 4), slot = idx & 15;
+    *reinterpret_cast<uint4 *>(og + (size_t)row * y_pitch + slot * 16) = *reinterpret_cast<const uint4 *>(hg + (size_t)row * x_pitch + slot * 16);
+  }
+  // validity of this lane's three window rows (gap rows and rows outside the matrix produce zeros)
+  bool valid[3];
+#pragma unroll
+  for (int rf = 0; rf < 3; ++rf) {
+    const int grow = m0 - RMARGIN + rh * 96 + rf * 32 + lr;
+    valid[rf] = grow >= 0 && grow < p.rows && ((p.row_valid[grow >> 5] >> (grow & 31)) & 1u);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  const uint32_t lane16 = (uint32_t)lane * 16u;
+#pragma unroll 1
+  for (int b = 1; b <= p.branches; ++b) {
+    const unsigned char *wb = reinterpret_cast<const unsigned char *>(p.wfrag) + (size_t)(b - 1) * (4 * 3 * 2 * 4 * 1024) + (size_t)nf * (3 * 2 * 4 * 1024);
+    const float *bias = p.bias + (b - 1) * RW + nf * 32 + 4 * lh, *scale = p.scale + (b - 1) * RW + nf * 32 + 4 * lh,
+                *shift = p.shift + (b - 1) * RW + nf * 32 + 4 * lh;
+    // accumulators start from the bias: acc[rf][4 q + e] = channel nf*32 + 8 q + 4 lh + e of row rh*96 + rf*32 + lr
+    f32x16_t acc[3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 b4 = *reinterpret_cast<const float4 *>(bias + 8 * q);
+#pragma unroll
+      for (int rf = 0; rf < 3; ++rf) { acc[rf][q * 4 + 0] = b4.x; acc[rf][q * 4 + 1] = b4.y; acc[rf][q * 4 + 2] = b4.z; acc[rf][q * 4 + 3] = b4.w; }
+    }
+    // K loop: k-group g = (tap t, 64-channel chunk c, 16-channel group kg); fragments fetched 4 k-groups ahead, rows 1 ahead
+    uint4 wf[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wf[k] = *reinterpret_cast<const uint4 *>(wb + (size_t)k * 1024 + lane16);
+    auto x_addr = [&](int t) -> uint32_t {                     // fragment 0 of tap t, slot lh (k-group bits enter by XOR)
+      const int row = RPAD + rh * 96 + lr + (t - 1) * d;
+      return (uint32_t)(row * RROWB + ((lh ^ (row & 15)) << 4));
+    };
+    uint4 xc[3], xn[3];
+    uint32_t xa = x_addr(0);
+#pragma unroll
+    for (int rf = 0; rf < 3; ++rf) xc[rf] = *reinterpret_cast<const uint4 *>(lds + xa + rf * 32 * RROWB);
+#pragma unroll 1
+    for (int tc = 0; tc < 6; ++tc) {                            // (tap, chunk): 4 k-groups each
+      const int t = tc >> 1, c = tc & 1;
+      const uint32_t xa_next = x_addr(tc + 1 < 6 ? (tc + 1) >> 1 : t);
+      const int c_next = (tc + 1) & 1;
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg) {
+        // rows of the next k-group
+        const bool wrap = kg == 3;
+        const uint32_t a = (wrap ? xa_next : xa) ^ (uint32_t)((((wrap ? c_next : c) * 8 + ((kg + 1) & 3) * 2)) << 4);
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf) xn[rf] = *reinterpret_cast<const uint4 *>(lds + a + rf * 32 * RROWB);
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf)
+          acc[rf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[kg]), __builtin_bit_cast(bf16x8_t, xc[rf]), acc[rf], 0, 0, 0);
+        // this fragment register is free: fetch the k-group 4 ahead (the last (tap, chunk) re-reads its own)
+        const int tcn = tc + 1 < 6 ? tc + 1 : tc;
+        wf[kg] = *reinterpret_cast<const uint4 *>(wb + (size_t)(tcn * 4 + kg) * 1024 + lane16);
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf) xc[rf] = xn[rf];
+      }
+      xa = xa_next;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's pieces of X (issued a branch ago) have landed
+    __builtin_amdgcn_s_barrier();                               // nobody reads A any more; X is complete
+    asm volatile("" ::: "memory");
+
+    // epilogue: y = BN(ReLU(acc)) (zeros in gap rows) -> B; y + x_{b+1} -> A for the next branch
+    const bool more = b < p.branches;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 sc4 = *reinterpret_cast<const float4 *>(scale + 8 * q), sh4 = *reinterpret_cast<const float4 *>(shift + 8 * q);
+      const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+      const int slot = nf * 4 + q;
+#pragma unroll
+      for (int rf = 0; rf < 3; ++rf) {
+        const int rw = rh * 96 + rf * 32 + lr;
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = valid[rf] ? fmaf(max_lo(acc[rf][q * 4 + e], 0.0f), sc[e], sh[e]) : 0.0f;
+        uint2 pk;
+        pk.x = pack_bf16x2(y[0], y[1]);
+        pk.y = pack_bf16x2(y[2], y[3]);
+        const uint32_t boff = (uint32_t)(rw * RROWB + ((slot ^ (rw & 15)) << 4) + lh * 8);
+        *reinterpret_cast<uint2 *>(lds + B_OFF + boff) = pk;
+        if (more) {
+          const uint2 xv = *reinterpret_cast<const uint2 *>(lds + X_OFF + boff);
+          uint2 sv;
+          sv.x = pack_bf16x2(bf16_bits_to_f32(pk.x & 0xffffu) + bf16_bits_to_f32(xv.x & 0xffffu), bf16_bits_to_f32(pk.x >> 16) + bf16_bits_to_f32(xv.x >> 16));
+          sv.y = pack_bf16x2(bf16_bits_to_f32(pk.y & 0xffffu) + bf16_bits_to_f32(xv.y & 0xffffu), bf16_bits_to_f32(pk.y >> 16) + bf16_bits_to_f32(xv.y >> 16));
+          const int ra = RPAD + rw;
+          *reinterpret_cast<uint2 *>(lds + ra * RROWB + ((slot ^ (ra & 15)) << 4) + lh * 8) = sv;
+        }
+      }
+    }
+    __builtin_amdgcn_s_barrier();                               // B and A complete; X consumed
+    asm volatile("" ::: "memory");
+    if (b + 2 <= p.branches) issue_window(b + 2, X_OFF, 0);     // lands during the next branch's K loop
+    // y_b: the 128 central rows of B -> HBM, 256-byte rows
+#pragma unroll
+    for (int it = 0; it < RM * 16 / 512; ++it) {
+      const int idx = it * 512 + tid, rw = RMARGIN + (idx >> 4), slot = idx & 15;
+      const uint4 v = *reinterpret_cast<const uint4 *>(lds + B_OFF + rw * RROWB + ((slot ^ (rw & 15)) << 4));
+      *reinterpret_cast<uint4 *>(og + (size_t)(m0 + (idx >> 4)) * y_pitch + (size_t)b * RROWB + slot * 16) = v;
+    }
+  }
+}
+
+}  // namespace
+
+int launch_res2_chain(const Res2KernelParams &p, hipStream_t s) {
+  ASV_REQUIRE(p.rows % RM == 0 && p.rows >= RM, "res2: rows %d not a multiple of %d", p.rows, RM);
+  ASV_REQUIRE(p.branches >= 1 && p.branches <= 7 && p.dilation >= 1 && p.dilation <= kHalo, "res2: %d branches, dilation %d", p.branches, p.dilation);
+  ASV_REQUIRE(p.x && p.y && p.wfrag && p.bias && p.scale && p.shift && p.row_valid, "res2: null argument");
+  hipLaunchKernelGGL(res2_chain_kernel, dim3(p.rows / RM), dim3(512), 0, s, p);
+  ASV_HIP_CHECK(hipGetLastError());
+  return ASV_OK;
+}
+
+}  // namespace asv

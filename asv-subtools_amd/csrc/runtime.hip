@@ -101,7 +101,7 @@ struct Domain {
   int gap() const { return kind == ASV_DOMAIN_FRAMES ? kHalo : pitch + 2; }
 };
 
-enum OpKind { OP_TDNN = 0, OP_POOL = 1, OP_ATTPOOL = 2, OP_ELTWISE = 3, OP_GRID_INPUT = 4, OP_IM2COL = 5, OP_LDE = 6 };
+enum OpKind { OP_TDNN = 0, OP_POOL = 1, OP_ATTPOOL = 2, OP_ELTWISE = 3, OP_GRID_INPUT = 4, OP_IM2COL = 5, OP_LDE = 6, OP_RES2 = 7 };
 
 struct Op {
   OpKind kind;
@@ -113,6 +113,7 @@ struct Op {
   asv_grid_input_desc_t gin;
   asv_im2col_desc_t i2c;
   asv_lde_desc_t lde;            // mu / beta live in `scale` / `shift` on the device
+  asv_res2_desc_t res2;          // fragments in `wfrag`, per-branch constants in bias / scale / shift
   // device parameters
   void *w = nullptr;
   void *wfrag = nullptr;         // fragment-ordered copy for the variant-3 kernel (bf16 frame layers); pooled layers: bf16 hi halves
@@ -600,6 +601,36 @@ int asv_net_add_lde_pool(asv_net_t *net, const asv_lde_desc_t *d) {
   return ASV_OK;
 }
 
+int asv_net_add_res2(asv_net_t *net, const asv_res2_desc_t *d) {
+  ASV_REQUIRE(net && d && !net->finalized, "asv_net_add_res2: net is null or finalized");
+  ASV_REQUIRE(d->struct_size == sizeof(asv_res2_desc_t), "asv_net_add_res2: struct_size mismatch");
+  ASV_REQUIRE(net->frames_bf16(), "res2: the one-kernel Res2NetBlock exists for the bf16 precision mode only");
+  ASV_REQUIRE(d->branches >= 1 && d->branches <= 7 && d->dilation >= 1 && d->dilation <= kHalo, "res2: %d branches, dilation %d", d->branches, d->dilation);
+  ASV_REQUIRE(d->weight && d->bias && d->scale && d->shift, "res2: weight / bias / scale / shift are required");
+  const int ch = (d->branches + 1) * kRes2Width;
+  int rc;
+  if ((rc = check_view(net, d->in_buf, d->in_ch_off, ch, "res2 input"))) return rc;
+  if ((rc = check_view(net, d->out_buf, d->out_ch_off, ch, "res2 output"))) return rc;
+  ASV_REQUIRE(net->bufs[d->in_buf].domain == ASV_DOMAIN_FRAMES && net->bufs[d->out_buf].domain == ASV_DOMAIN_FRAMES && d->out_buf != d->in_buf && d->out_buf != 0,
+              "res2: frames-domain input and a different frames-domain output buffer");
+  ASV_REQUIRE(d->in_ch_off % 8 == 0 && d->out_ch_off % 8 == 0, "res2: channel offsets must be multiples of 8 (16-byte rows pieces)");
+  Op op; op.kind = OP_RES2; op.res2 = *d;
+  ASV_HIP_CHECK(hipSetDevice(net->device));
+  const int W = kRes2Width, tot = 2 * d->dilation + 1;
+  const int taps[3] = {-d->dilation, 0, d->dilation};
+  const size_t per_branch = tdnn_weight_frag_elems(W, W, 3);
+  std::vector<uint16_t> frags(per_branch * d->branches);
+  for (int b = 0; b < d->branches; ++b)
+    pack_tdnn_weight_frags(d->weight + (size_t)b * W * W * tot, W, W, tot, -d->dilation, taps, 3, W, W, frags.data() + per_branch * b);
+  if ((rc = dev_upload(net, frags.data(), frags.size() * 2, &op.wfrag))) return rc;
+  if ((rc = upload_padded(net, d->bias, d->branches * W, d->branches * W, 0.0f, &op.bias))) return rc;
+  if ((rc = upload_padded(net, d->scale, d->branches * W, d->branches * W, 0.0f, &op.scale))) return rc;
+  if ((rc = upload_padded(net, d->shift, d->branches * W, d->branches * W, 0.0f, &op.shift))) return rc;
+  op.res2.weight = nullptr; op.res2.bias = nullptr; op.res2.scale = nullptr; op.res2.shift = nullptr;
+  net->ops.push_back(op);
+  return ASV_OK;
+}
+
 int asv_net_add_eltwise(asv_net_t *net, const asv_eltwise_desc_t *d) {
   ASV_REQUIRE(net && d && !net->finalized, "asv_net_add_eltwise: net is null or finalized");
   ASV_REQUIRE(d->struct_size == sizeof(asv_eltwise_desc_t), "asv_net_add_eltwise: struct_size mismatch");
@@ -686,7 +717,7 @@ int asv_net_finalize(asv_net_t *net, int out_buf, int embed_dim) {
         const int reads[] = {o.kind == OP_TDNN ? o.tdnn.in_buf : -1, o.kind == OP_TDNN ? o.tdnn.in2_buf : -1, o.kind == OP_TDNN ? o.tdnn.res_buf : -1,
                              o.kind == OP_POOL ? o.pool.in_buf : -1, o.kind == OP_ATTPOOL ? o.att.x_buf : -1, o.kind == OP_ATTPOOL ? o.att.logit_buf : -1,
                              o.kind == OP_ELTWISE ? o.elt.a_buf : -1, o.kind == OP_ELTWISE ? o.elt.b_buf : -1, o.kind == OP_ELTWISE ? o.elt.c_buf : -1,
-                             o.kind == OP_IM2COL ? o.i2c.in_buf : -1, o.kind == OP_LDE ? o.lde.x_buf : -1};
+                             o.kind == OP_IM2COL ? o.i2c.in_buf : -1, o.kind == OP_LDE ? o.lde.x_buf : -1, o.kind == OP_RES2 ? o.res2.in_buf : -1};
         for (int rbuf : reads) other_reader |= (rbuf == d.out_buf);
       }
       if (other_reader || d.out_buf == out_buf) continue;
@@ -716,7 +747,8 @@ int asv_net_finalize(asv_net_t *net, int out_buf, int embed_dim) {
                              o.kind == OP_POOL ? o.pool.in_buf : -1, o.kind == OP_ATTPOOL ? o.att.x_buf : -1, o.kind == OP_ATTPOOL ? o.att.logit_buf : -1,
                              o.kind == OP_ELTWISE ? o.elt.a_buf : -1, o.kind == OP_ELTWISE ? o.elt.b_buf : -1, o.kind == OP_ELTWISE ? o.elt.c_buf : -1,
                              o.kind == OP_ELTWISE ? o.elt.seg_scale_buf : -1, o.kind == OP_ELTWISE ? o.elt.seg_norm_buf : -1,
-                             o.kind == OP_IM2COL ? o.i2c.in_buf : -1, o.kind == OP_LDE ? o.lde.x_buf : -1, o.kind == OP_GRID_INPUT ? o.gin.in_buf : -1};
+                             o.kind == OP_IM2COL ? o.i2c.in_buf : -1, o.kind == OP_LDE ? o.lde.x_buf : -1, o.kind == OP_GRID_INPUT ? o.gin.in_buf : -1,
+                             o.kind == OP_RES2 ? o.res2.in_buf : -1};
         for (int rbuf : reads) if (rbuf == buf) return false;
       }
       return true;
@@ -792,6 +824,10 @@ int asv_net_describe(const asv_net_t *net, char *buf, size_t cap) {
       case OP_LDE:
         snprintf(line, sizeof(line), "  op %zu: lde_pool x=%d channels=%d centres=%d -> %d[%d]\n", i, op.lde.x_buf, op.lde.channels, op.lde.n_centres, op.lde.out_buf,
                  op.lde.out_ch_off);
+        break;
+      case OP_RES2:
+        snprintf(line, sizeof(line), "  op %zu: res2 %d[%d] -> %d[%d] branches=%d dilation=%d\n", i, op.res2.in_buf, op.res2.in_ch_off, op.res2.out_buf, op.res2.out_ch_off,
+                 op.res2.branches, op.res2.dilation);
         break;
       case OP_GRID_INPUT:
         snprintf(line, sizeof(line), "  op %zu: grid_input %d -> %d\n", i, op.gin.in_buf, op.gin.out_buf);
@@ -1203,6 +1239,20 @@ int run_ops(RunCtx &c, size_t n_ops) {
         else { p.rows = c.dom[domid].rows_pad; p.row_seg = c.dom[domid].row_seg; p.row_valid = c.dom[domid].row_valid; }
         if ((rc = prof.begin(K_ELT, 0, (int)i))) return rc;
         if ((rc = launch_eltwise(p, net->dom_bf16(domid), c.s))) return rc;
+        if ((rc = prof.end())) return rc;
+        break;
+      }
+      case OP_RES2: {
+        const auto &d = op.res2;
+        const DomainRun &dr = c.dom[ASV_DOMAIN_FRAMES];
+        Res2KernelParams p;
+        memset(&p, 0, sizeof(p));
+        p.x = view(c, d.in_buf, d.in_ch_off); p.ldx = net->bufs[d.in_buf].ld;
+        p.y = view(c, d.out_buf, d.out_ch_off); p.ldy = net->bufs[d.out_buf].ld;
+        p.rows = dr.rows_pad; p.wfrag = op.wfrag; p.bias = op.bias; p.scale = op.scale; p.shift = op.shift; p.row_valid = dr.row_valid;
+        p.branches = d.branches; p.dilation = d.dilation;
+        if ((rc = prof.begin(K_TDNN, 2.0 * (double)bp.frames * kRes2Width * kRes2Width * 3 * d.branches, (int)i))) return rc;
+        if ((rc = launch_res2_chain(p, c.s))) return rc;
         if ((rc = prof.end())) return rc;
         break;
       }

@@ -78,6 +78,16 @@ class LdeDesc(C.Structure):
     ]
 
 
+class Res2Desc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("in_buf", C.c_int32), ("in_ch_off", C.c_int32),
+        ("out_buf", C.c_int32), ("out_ch_off", C.c_int32),
+        ("branches", C.c_int32), ("dilation", C.c_int32),
+        ("weight", c_float_p), ("bias", c_float_p), ("scale", c_float_p), ("shift", c_float_p),
+    ]
+
+
 class EltwiseDesc(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32),
@@ -135,7 +145,7 @@ SYMBOLS = [
     "asv_version", "asv_last_error", "asv_device_count",
     "asv_net_create", "asv_net_destroy", "asv_net_define_grid", "asv_net_new_buffer", "asv_net_add_tdnn",
     "asv_net_add_grid_input", "asv_net_add_im2col",
-    "asv_net_add_stats_pool", "asv_net_add_attentive_pool", "asv_net_add_lde_pool", "asv_net_add_eltwise",
+    "asv_net_add_stats_pool", "asv_net_add_attentive_pool", "asv_net_add_lde_pool", "asv_net_add_eltwise", "asv_net_add_res2",
     "asv_net_finalize", "asv_net_embed_dim", "asv_net_describe", "asv_net_extract",
     "asv_net_device_bytes", "asv_net_set_profiling", "asv_net_get_profile",
     "asv_tdnn_forward", "asv_stats_pool_forward",
@@ -183,6 +193,7 @@ def lib():
     L.asv_net_add_attentive_pool.argtypes = [vp, C.POINTER(AttPoolDesc)]
     L.asv_net_add_lde_pool.argtypes = [vp, C.POINTER(LdeDesc)]
     L.asv_net_add_eltwise.argtypes = [vp, C.POINTER(EltwiseDesc)]
+    L.asv_net_add_res2.argtypes = [vp, C.POINTER(Res2Desc)]
     L.asv_net_finalize.argtypes = [vp, ci, ci]
     L.asv_net_embed_dim.argtypes = [vp]
     L.asv_net_describe.argtypes = [vp, C.c_char_p, C.c_size_t]

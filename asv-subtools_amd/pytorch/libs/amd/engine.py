@@ -76,7 +76,11 @@ class Engine(object):
             if spec[0] == "grid":
                 dom_of[i] = capi.check(L.asv_net_define_grid(self._net, spec[1], spec[2], spec[3]), "asv_net_define_grid")
         # one device buffer per IR tensor that something writes as a whole or in slices
-        written = sorted({op.out.tid for op in g.ops})
+        # bf16 engines run every Res2NetBlock as one kernel (kernels_res2.hip); the parity modes keep one layer per branch
+        fuse = self.precision in ("bf16", "bfloat16") and (self.flags & (capi.FLAG_REF_KERNELS | capi.FLAG_NO_FUSE | capi.FLAG_SMALL_TILES)) == 0
+        ops = g.fused_res2_ops() if fuse else g.ops
+        self.ops = ops                               # the program as uploaded (op indices of the profiling rows refer to it)
+        written = sorted({op.out.tid for op in ops})
         for tid in written:
             dom, ch = g.tensors[tid]
             buf_of[tid] = capi.check(L.asv_net_new_buffer(self._net, dom_of[dom], ch), "asv_net_new_buffer")
@@ -86,8 +90,18 @@ class Engine(object):
                 return (-1, 0)
             return (buf_of[v.tid], v.ch_off)
 
-        for op in g.ops:
-            if op.kind == "tdnn":
+        for op in ops:
+            if op.kind == "res2":
+                d = capi.Res2Desc()
+                d.struct_size = C.sizeof(capi.Res2Desc)
+                d.in_buf, d.in_ch_off = bv(op.inp)
+                d.out_buf, d.out_ch_off = bv(op.out)
+                d.branches, d.dilation = op.branches, op.dilation
+                keep = [op.weight, op.bias, op.scale, op.shift]
+                d.weight, d.bias, d.scale, d.shift = (capi.f32_ptr(a) for a in keep)
+                capi.check(L.asv_net_add_res2(self._net, C.byref(d)), "asv_net_add_res2")
+                del keep
+            elif op.kind == "tdnn":
                 d = capi.TdnnDesc()
                 d.struct_size = C.sizeof(capi.TdnnDesc)
                 d.in_buf, d.in_ch_off = bv(op.inp)

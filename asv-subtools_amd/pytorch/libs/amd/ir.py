@@ -34,6 +34,15 @@ class View(object):
     def key(self):
         return (self.tid, self.ch_off, self.channels)
 
+    def __eq__(self, other):
+        return isinstance(other, View) and self.key() == other.key()
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    def __hash__(self):
+        return hash(self.key())
+
     def __repr__(self):
         return "t%d[%d:+%d]" % (self.tid, self.ch_off, self.channels)
 
@@ -57,7 +66,7 @@ class Op(object):
             names = ("x",)
         elif self.kind == "eltwise":
             names = ("a", "b", "c", "seg_scale", "seg_norm")
-        elif self.kind in ("grid_input", "im2col"):
+        elif self.kind in ("grid_input", "im2col", "res2"):
             names = ("inp",)
         else:
             return list(self.parts)
@@ -66,7 +75,7 @@ class Op(object):
     def input_names(self):
         return {"tdnn": ("inp", "inp2", "seg_bias", "seg_scale", "res"), "pool": ("inp",),
                 "attpool": ("x", "logits"), "lde": ("x",), "eltwise": ("a", "b", "c", "seg_scale", "seg_norm"), "cat": (), "grid_input": ("inp",),
-                "im2col": ("inp",)}[self.kind]
+                "im2col": ("inp",), "res2": ("inp",)}[self.kind]
 
 
 class Graph(object):
@@ -333,6 +342,48 @@ class Graph(object):
                 if op.out.tid not in live:
                     self.ops.remove(op)
                     changed = True
+
+    def fused_res2_ops(self, width=128, max_branches=7):
+        """The op list with every Res2NetBlock (ecapa_tdnn_xvector.py:61-75 - after cat elision: n dependent `width`-channel
+        TDNN ops `y_k = f(y_{k-1} + x_k)` writing slices of one buffer plus the pass-through copy of group 0) replaced by ONE
+        'res2' op (kernels_res2.hip).  Engines use it in bf16 mode; anything that does not match exactly is left alone."""
+        ops, out, i = self.ops, [], 0
+        plain = lambda o: (o.kind == "tdnn" and o.act1 == "relu" and o.scale is not None and not o.affine_first and o.act2 is None
+                           and o.seg_bias is None and o.seg_scale is None and o.res is None and o.bias is not None)
+        while i < len(ops):
+            first = ops[i]
+            grp = None
+            if (plain(first) and first.inp2 is None and first.inp.channels == width and first.out.channels == width and len(first.taps) == 3
+                    and first.taps[1] == 0 and first.taps[0] == -first.taps[2] and 1 <= first.taps[2] <= MAX_HALO and first.inp.ch_off == width
+                    and first.out.ch_off == width and self.domain(first.inp.tid) == DOMAIN_FRAMES and first.inp.tid != first.out.tid):
+                H, O, d = first.inp.tid, first.out.tid, first.taps[2]
+                n = self.tensors[H][1] // width - 1
+                ok = (self.tensors[H][1] == (n + 1) * width and self.tensors[O][1] == (n + 1) * width and 1 <= n <= max_branches and i + n < len(ops)
+                      and first.weight.shape == (width, width, 2 * d + 1) and first.w_left == -d)
+                k = 2
+                while ok and k <= n:
+                    o = ops[i + k - 1]
+                    ok = (plain(o) and o.taps == first.taps and o.inp == View(O, (k - 1) * width, width) and o.inp2 == View(H, k * width, width)
+                          and o.out == View(O, k * width, width) and o.weight.shape == first.weight.shape and o.w_left == -d)
+                    k += 1
+                if ok:
+                    cp = ops[i + n]
+                    ok = (cp.kind == "eltwise" and cp.a == View(H, 0, width) and cp.out == View(O, 0, width) and cp.b is None and cp.c is None
+                          and cp.seg_scale is None and cp.scale is None and getattr(cp, "act", None) is None and getattr(cp, "seg_norm", None) is None)
+                if ok:
+                    br = ops[i:i + n]
+                    grp = Op("res2", View(O, 0, (n + 1) * width), inp=View(H, 0, (n + 1) * width), branches=n, dilation=d,
+                             weight=np.ascontiguousarray(np.stack([o.weight for o in br]), dtype=np.float32),
+                             bias=np.ascontiguousarray(np.stack([o.bias for o in br]), dtype=np.float32),
+                             scale=np.ascontiguousarray(np.stack([o.scale for o in br]), dtype=np.float32),
+                             shift=np.ascontiguousarray(np.stack([o.shift for o in br]), dtype=np.float32))
+            if grp is not None:
+                out.append(grp)
+                i += grp.branches + 1
+            else:
+                out.append(first)
+                i += 1
+        return out
 
     def describe(self):
         lines = ["graph: %d tensors, %d ops, output %r" % (len(self.tensors), len(self.ops), self.output)]

@@ -255,12 +255,14 @@ def main():
             for _ in range(steps):
                 step()
             torch.cuda.synchronize(dev)
-            ops = eng.graph.ops
+            ops = getattr(eng, "ops", eng.graph.ops)
             for r in sorted(eng.get_profile(), key=lambda r: r["op_index"]):
                 i = r["op_index"]
                 desc = ""
                 if 0 <= i < len(ops) and ops[i].kind == "tdnn":
                     desc = "%d->%d taps=%s" % (ops[i].inp.channels, ops[i].out.channels, ops[i].taps)
+                elif 0 <= i < len(ops) and ops[i].kind == "res2":
+                    desc = "res2 %d x 128->128 dilation %d" % (ops[i].branches, ops[i].dilation)
                 us = 1e3 * r["total_ms"] / max(r["launches"], 1)
                 tf = r["flops"] / (r["total_ms"] * 1e-3) / 1e12 if r["total_ms"] > 0 else 0.0
                 print("  op %3d %-14s %-28s %9.1f us  %8.1f TFLOP/s" % (i, r["name"], desc, us, tf), file=sys.stderr)

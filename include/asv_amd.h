@@ -167,6 +167,20 @@ typedef struct asv_lde_desc {
 } asv_lde_desc_t;
 int asv_net_add_lde_pool(asv_net_t *net, const asv_lde_desc_t *d);
 
+/* Res2NetBlock of ECAPA-TDNN (reference model/ecapa_tdnn_xvector.py:42-75) as one op: the input view holds `branches + 1`
+ * groups of 128 channels x_0 .. x_n; y_0 = x_0, y_i = BN(ReLU(TDNN_{[-d,0,d]}(y_{i-1} + x_i))) (i = 1: TDNN(x_1)); the output view
+ * receives cat(y_0 .. y_n).  bf16 precision mode only (the other modes keep one TDNN layer per branch).
+ * weight: host f32 [branches][128][128][2 d + 1] - the checkpoint's dense kernels, one after the other (masked positions are
+ * ignored, as for asv_tdnn_desc_t); bias / scale / shift: host f32 [branches][128] (scale / shift = the folded eval BN). */
+typedef struct asv_res2_desc {
+  uint32_t struct_size;
+  int32_t in_buf, in_ch_off;
+  int32_t out_buf, out_ch_off;
+  int32_t branches, dilation;
+  const float *weight, *bias, *scale, *shift;
+} asv_res2_desc_t;
+int asv_net_add_res2(asv_net_t *net, const asv_res2_desc_t *d);
+
 /* Elementwise: out = a (* seg_scale[segment]) (+ b) (+ c); any domain; views as above. */
 typedef struct asv_eltwise_desc {
   uint32_t struct_size;

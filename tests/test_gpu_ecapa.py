@@ -59,3 +59,27 @@ def test_ecapa_batch_composition_invariance():
     assert np.isfinite(full).all()
     for i in (0, 3, 6):
         assert np.array_equal(model.extract_embedding(mats[i]).numpy(), full[i])
+
+
+def test_res2_block_kernel_matches_per_branch_layers(monkeypatch):
+    """bf16 mode runs every Res2NetBlock (ecapa_tdnn_xvector.py:61-75) as one kernel with the running tensor in LDS
+    (kernels_res2.hip); ASV_AMD_NO_FUSE=1 keeps one launch per branch.  Same bf16 operands and the same bf16 rounding of every
+    intermediate: the embeddings agree to the f32 summation order - on ragged batches with tiny utterances, at all three
+    dilations - and both agree with the reference."""
+    from libs.amd import synth
+    g, sd, model = helpers.golden_model("ecapa_launcher")
+    model.cuda()
+    model.amd_precision = "bf16"
+    mats = helpers.golden_feats(g) + [synth.synth_feats(T, 80, 7100 + i) for i, T in enumerate([1, 2, 7, 33, 129, 300, 517, 64, 300])]
+    fused = model.extract_embedding_batch(mats).numpy()
+    assert "res2" in model._amd_engine().describe()
+    monkeypatch.setenv("ASV_AMD_NO_FUSE", "1")
+    plain = model.extract_embedding_batch(mats).numpy()
+    assert "res2" not in model._amd_engine().describe()
+    assert np.isfinite(fused).all()
+    cos = (fused * plain).sum(1) / np.linalg.norm(fused, axis=1) / np.linalg.norm(plain, axis=1)
+    assert cos.min() > 0.9999 and rel_err(fused, plain) < 1e-2, (cos.min(), rel_err(fused, plain))
+    ref = g["embeddings"]
+    n = len(ref)
+    cos_ref = (fused[:n] * ref).sum(1) / np.linalg.norm(fused[:n], axis=1) / np.linalg.norm(ref, axis=1)
+    assert cos_ref.min() > 0.999, cos_ref
