@@ -172,16 +172,32 @@ __global__ __launch_bounds__(256, CIN == 32 ? 3 : 2) void grid_conv_narrow_kerne
 
 // The first convolution of the trunk: ONE input channel (the fbank map itself), 3x3, 32 output channels
 // (resnet.py:96-99).  9 multiply-adds per output - nothing for a matrix core: one thread per (row, 8 channels), the nine
-// bf16 inputs of the row gathered through L1, weights in registers, f32 fma in tap order (bit-identical to the MFMA
-// path, whose other 15 k-lanes are zeros), 16-byte coalesced stores.  HBM bound on the 64 B it writes per row.
+// bf16 inputs of the row gathered through L1, f32 fma in tap order (bit-identical to the MFMA path, whose other 15
+// k-lanes are zeros), 16-byte coalesced stores.  HBM bound on the 64 B it writes per row - once the weights and the
+// per-channel constants sit in LDS as f32 ([tap][channel]: two ds_read_b128 per tap, broadcast across the rows of a wave);
+// fetched per thread from global memory (72 two-byte loads for 8 outputs) the kernel took 600 us on 4.3 M rows (r2a profile).
 template <bool GENERIC>
 __global__ __launch_bounds__(256) void grid_conv_c1_kernel(const TdnnKernelParams p) {
+  __shared__ __attribute__((aligned(16))) float w_s[9 * 64];
+  __shared__ __attribute__((aligned(16))) float c_s[3 * 64];                   // bias | scale | shift
   const int chunks = p.cout_store / 8;
+  {
+    const uint16_t *w = reinterpret_cast<const uint16_t *>(p.w);               // [cout_pad][n_taps][cin_pad] bf16
+    for (int i = threadIdx.x; i < p.n_taps * p.cout_store; i += 256) {
+      const int t = i / p.cout_store, c = i % p.cout_store;
+      w_s[t * 64 + c] = bf16_bits_to_f32(w[((size_t)c * p.n_taps + t) * p.cin_pad]);
+    }
+    for (int c = threadIdx.x; c < p.cout_store; c += 256) {
+      c_s[c] = p.bias[c];
+      c_s[64 + c] = p.scale ? p.scale[c] : 1.0f;
+      c_s[128 + c] = p.shift ? p.shift[c] : 0.0f;
+    }
+  }
+  __syncthreads();
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
   if (gid >= (long long)p.rows * chunks) return;
   const int row = (int)(gid / chunks), ch = (int)(gid % chunks) * 8;
   const uint16_t *x = reinterpret_cast<const uint16_t *>(p.x);
-  const uint16_t *w = reinterpret_cast<const uint16_t *>(p.w);                 // [cout_pad][n_taps][cin_pad] bf16
   float acc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
@@ -190,16 +206,18 @@ __global__ __launch_bounds__(256) void grid_conv_c1_kernel(const TdnnKernelParam
     for (int t = 0; t < p.n_taps; ++t) {
       const int r = row + p.taps[t];
       const float xv = (r >= 0 && r < p.rows) ? bf16_bits_to_f32(x[(size_t)r * p.ldx]) : 0.0f;
+      const float4 w0 = *reinterpret_cast<const float4 *>(w_s + t * 64 + ch), w1 = *reinterpret_cast<const float4 *>(w_s + t * 64 + ch + 4);
+      const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] = fmaf(bf16_bits_to_f32(w[((size_t)(ch + e) * p.n_taps + t) * p.cin_pad]), xv, acc[e]);
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(wv[e], xv, acc[e]);
     }
   }
   float y[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const float scale = p.scale ? p.scale[ch + e] : 1.0f, shift = p.shift ? p.shift[ch + e] : 0.0f;
-    if constexpr (GENERIC) y[e] = tdnn_epilogue<true>(p, acc[e], row, ch + e, p.bias[ch + e], scale, shift, valid);
-    else y[e] = tdnn_epilogue_fast(acc[e], p.bias[ch + e], (p.act1 == ASV_ACT_RELU) ? 0.0f : -INFINITY, scale, shift, valid);
+    const float bias = c_s[ch + e], scale = c_s[64 + ch + e], shift = c_s[128 + ch + e];
+    if constexpr (GENERIC) y[e] = tdnn_epilogue<true>(p, acc[e], row, ch + e, bias, scale, shift, valid);
+    else y[e] = tdnn_epilogue_fast(acc[e], bias, (p.act1 == ASV_ACT_RELU) ? 0.0f : -INFINITY, scale, shift, valid);
   }
   uint4 o;
   o.x = pack_bf16x2(y[0], y[1]); o.y = pack_bf16x2(y[2], y[3]); o.z = pack_bf16x2(y[4], y[5]); o.w = pack_bf16x2(y[6], y[7]);

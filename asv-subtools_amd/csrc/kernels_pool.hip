@@ -222,8 +222,10 @@ __global__ __launch_bounds__(64) void pool_finish_kernel(const PoolFinishParams 
     for (int part = 0; part < parts; ++part) {
       int cnt = b - a;
       if (p.lh_split) {                                 // this part holds the rows whose index has bit 2 == part
-        cnt = 0;
-        for (int r = a; r < b; ++r) cnt += (((r >> 2) & 1) == part);
+        // rows below x with bit 2 set: 4 per complete group of 8 + what the started group holds beyond its first 4
+        // (closed form: the row-by-row count this replaces made the kernel 96 us for 640 utterances, r2a profile)
+        const int hi_b = (b >> 3) * 4 + max((b & 7) - 4, 0), hi_a = (a >> 3) * 4 + max((a & 7) - 4, 0);
+        cnt = part ? hi_b - hi_a : (b - a) - (hi_b - hi_a);
       }
       if (cnt == 0) continue;
       const float *src = p.partial + ((size_t)((h * p.pool_slots + slot) * parts + part) * 3) * p.ld_partial + ch;

@@ -26,6 +26,8 @@
 // the 16-deep chains, 22 instead of 48 instructions per k-group (one address register per step): the loops sit at the
 // matrix pipe's rate, the epilogue at ~14 cycles per VALU operation beside a streaming partner.
 // One workgroup (512 threads, 160 KiB LDS) per CU.
+#include <cstdlib>
+
 #include "device_utils.h"
 
 namespace asv {
@@ -48,6 +50,7 @@ static_assert(CSTAGES * CSTAGE <= Y_BYTES, "the window ring lives inside the Y r
 static_assert(CHAIN_LDS <= 163840, "160 KiB of LDS per CU");
 
 typedef __attribute__((address_space(3))) unsigned char chain_lds_byte;
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 struct TrNo { static constexpr bool value = false; };
 struct TrYes { static constexpr bool value = true; };
 
@@ -66,6 +69,10 @@ __device__ __forceinline__ void chain_glds16_s(const void *sbase, uint32_t voff,
       : "memory");
 }
 
+// POOLV: pooling epilogue of the last layer.  0 = first version (per-lane segment tracking, register-by-register seams);
+//        1 = run-based (default): every utterance inside a 32-frame fragment is one masked run over all 16 registers,
+//            packed f32 arithmetic (v_pk_add_f32 / v_pk_fma_f32).  ASV_AMD_CHAIN_POOLV selects at launch (A/B aid).
+template <int POOLV>
 __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[CHAIN_LDS];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -352,81 +359,173 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
       // three moments at publication (u = scale * act(acc): moments about a pivot are linear / quadratic in it); the BN
       // shift is added to the mean by pool_finish.
       const float sc[2] = {L.scale != nullptr ? L.scale[cb + lr] : 1.0f, L.scale != nullptr ? L.scale[cb + 32 + lr] : 1.0f};
-      float ps[2] = {0.f, 0.f}, pq[2] = {0.f, 0.f}, pv[2] = {0.f, 0.f};
-      int cur_seg = -1;                    // per lane: the halves cross an utterance seam at different registers
-      auto publish = [&](bool mine) {      // lanes with `mine` write the moments of their current segment
-        const int slot = cur_seg - first_seg;
-        if (mine && cur_seg >= 0 && slot >= 0 && slot < p.pool_slots) {
-          float *dst = p.pool_partial + ((size_t)((half * p.pool_slots + slot) * 2 + lh) * 3) * p.ld_partial + cb + lr;
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            if (cb + j * 32 + lr < p.ld_partial) {
-              dst[j * 32] = ps[j] * sc[j];
-              dst[j * 32 + p.ld_partial] = pq[j] * sc[j] * sc[j];
-              dst[j * 32 + 2 * p.ld_partial] = pv[j] * sc[j];
-            }
-        }
-      };
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int rs_vec = (i < 2) ? rowseg_lo : rowseg_hi;
-        const unsigned long long in_frag = 0xffffffffull << ((i & 1) * 32);
-        const unsigned long long m_valid = __builtin_amdgcn_ballot_w64(rs_vec >= 0) & in_frag;
-        if (m_valid == 0) continue;                                                  // gap rows only
-        const int sg0 = __builtin_amdgcn_readlane(rs_vec, __builtin_ctzll(m_valid));
-        const unsigned long long m_same = __builtin_amdgcn_ballot_w64(rs_vec == sg0) & in_frag;
-        if (m_same == in_frag) {
-          // the 32 frames of the fragment belong to one utterance: 4 VALU operations per accumulator register
-          const bool chg = cur_seg != sg0;
-          if (__builtin_amdgcn_ballot_w64(chg) != 0) {
-            publish(chg);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              const float v0 = max_lo(acc[i][j][0], act_lo);
-              ps[j] = chg ? 0.0f : ps[j]; pq[j] = chg ? 0.0f : pq[j]; pv[j] = chg ? v0 : pv[j];
-            }
-            cur_seg = chg ? sg0 : cur_seg;
+      if constexpr (POOLV == 0) {
+        float ps[2] = {0.f, 0.f}, pq[2] = {0.f, 0.f}, pv[2] = {0.f, 0.f};
+        int cur_seg = -1;                    // per lane: the halves cross an utterance seam at different registers
+        auto publish = [&](bool mine) {      // lanes with `mine` write the moments of their current segment
+          const int slot = cur_seg - first_seg;
+          if (mine && cur_seg >= 0 && slot >= 0 && slot < p.pool_slots) {
+            float *dst = p.pool_partial + ((size_t)((half * p.pool_slots + slot) * 2 + lh) * 3) * p.ld_partial + cb + lr;
+  #pragma unroll
+            for (int j = 0; j < 2; ++j)
+              if (cb + j * 32 + lr < p.ld_partial) {
+                dst[j * 32] = ps[j] * sc[j];
+                dst[j * 32 + p.ld_partial] = pq[j] * sc[j] * sc[j];
+                dst[j * 32 + 2 * p.ld_partial] = pv[j] * sc[j];
+              }
           }
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const float dlt = max_lo(acc[i][j][r], act_lo) - pv[j];
-              s4[r & 3] += dlt;
-              q4[r & 3] = fmaf(dlt, dlt, q4[r & 3]);
-            }
-            ps[j] += (s4[0] + s4[1]) + (s4[2] + s4[3]);
-            pq[j] += (q4[0] + q4[1]) + (q4[2] + q4[3]);
-          }
-        } else {
-          // an utterance seam or gap rows inside the fragment: register by register (frames ascend with r inside a half)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int f = (i & 1) * 32 + 8 * (r >> 2) + (r & 3);                    // lane index of the frame of half 0
-            const int sg_a = __builtin_amdgcn_readlane(rs_vec, f), sg_b = __builtin_amdgcn_readlane(rs_vec, f + 4);
-            const int sg = lh ? sg_b : sg_a;
-            const bool ok = sg >= 0;
-            const bool chg = ok && sg != cur_seg;
+        };
+  #pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int rs_vec = (i < 2) ? rowseg_lo : rowseg_hi;
+          const unsigned long long in_frag = 0xffffffffull << ((i & 1) * 32);
+          const unsigned long long m_valid = __builtin_amdgcn_ballot_w64(rs_vec >= 0) & in_frag;
+          if (m_valid == 0) continue;                                                  // gap rows only
+          const int sg0 = __builtin_amdgcn_readlane(rs_vec, __builtin_ctzll(m_valid));
+          const unsigned long long m_same = __builtin_amdgcn_ballot_w64(rs_vec == sg0) & in_frag;
+          if (m_same == in_frag) {
+            // the 32 frames of the fragment belong to one utterance: 4 VALU operations per accumulator register
+            const bool chg = cur_seg != sg0;
             if (__builtin_amdgcn_ballot_w64(chg) != 0) {
               publish(chg);
-#pragma unroll
+  #pragma unroll
               for (int j = 0; j < 2; ++j) {
-                const float v0 = max_lo(acc[i][j][r], act_lo);
+                const float v0 = max_lo(acc[i][j][0], act_lo);
                 ps[j] = chg ? 0.0f : ps[j]; pq[j] = chg ? 0.0f : pq[j]; pv[j] = chg ? v0 : pv[j];
               }
-              cur_seg = chg ? sg : cur_seg;
+              cur_seg = chg ? sg0 : cur_seg;
             }
-#pragma unroll
+  #pragma unroll
             for (int j = 0; j < 2; ++j) {
-              const float dlt = ok ? max_lo(acc[i][j][r], act_lo) - pv[j] : 0.0f;
-              ps[j] += dlt;
-              pq[j] = fmaf(dlt, dlt, pq[j]);
+              float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+  #pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const float dlt = max_lo(acc[i][j][r], act_lo) - pv[j];
+                s4[r & 3] += dlt;
+                q4[r & 3] = fmaf(dlt, dlt, q4[r & 3]);
+              }
+              ps[j] += (s4[0] + s4[1]) + (s4[2] + s4[3]);
+              pq[j] += (q4[0] + q4[1]) + (q4[2] + q4[3]);
+            }
+          } else {
+            // an utterance seam or gap rows inside the fragment: register by register (frames ascend with r inside a half)
+  #pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int f = (i & 1) * 32 + 8 * (r >> 2) + (r & 3);                    // lane index of the frame of half 0
+              const int sg_a = __builtin_amdgcn_readlane(rs_vec, f), sg_b = __builtin_amdgcn_readlane(rs_vec, f + 4);
+              const int sg = lh ? sg_b : sg_a;
+              const bool ok = sg >= 0;
+              const bool chg = ok && sg != cur_seg;
+              if (__builtin_amdgcn_ballot_w64(chg) != 0) {
+                publish(chg);
+  #pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                  const float v0 = max_lo(acc[i][j][r], act_lo);
+                  ps[j] = chg ? 0.0f : ps[j]; pq[j] = chg ? 0.0f : pq[j]; pv[j] = chg ? v0 : pv[j];
+                }
+                cur_seg = chg ? sg : cur_seg;
+              }
+  #pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                const float dlt = ok ? max_lo(acc[i][j][r], act_lo) - pv[j] : 0.0f;
+                ps[j] += dlt;
+                pq[j] = fmaf(dlt, dlt, pq[j]);
+              }
             }
           }
         }
+        publish(true);
+      } else {
+        float ps[2] = {0.f, 0.f}, pq[2] = {0.f, 0.f}, pv[2] = {0.f, 0.f};
+        int cur_seg = -1;                    // uniform: all lanes walk the utterances of the tile together
+        auto publish = [&]() {
+          const int slot = cur_seg - first_seg;
+          if (cur_seg >= 0 && slot >= 0 && slot < p.pool_slots) {
+            float *dst = p.pool_partial + ((size_t)((half * p.pool_slots + slot) * 2 + lh) * 3) * p.ld_partial + cb + lr;
+  #pragma unroll
+            for (int j = 0; j < 2; ++j)
+              if (cb + j * 32 + lr < p.ld_partial) {
+                dst[j * 32] = ps[j] * sc[j];
+                dst[j * 32 + p.ld_partial] = pq[j] * sc[j] * sc[j];
+                dst[j * 32 + 2 * p.ld_partial] = pv[j] * sc[j];
+              }
+          }
+        };
+  #pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int rs_vec = (i < 2) ? rowseg_lo : rowseg_hi;
+          const int shift = (i & 1) * 32;
+          uint32_t rem = (uint32_t)(__builtin_amdgcn_ballot_w64(rs_vec >= 0) >> shift);       // rows of the fragment that belong to an utterance
+          if (rem == 0) continue;                                                              // gap rows only
+          // u = act(acc) once per fragment (one v_max_f32 each; the accumulators of the fragment die here)
+          float u[2][16];
+  #pragma unroll
+          for (int j = 0; j < 2; ++j)
+  #pragma unroll
+            for (int r = 0; r < 16; ++r) u[j][r] = max_lo(acc[i][j][r], act_lo);
+          // one run per utterance present, in row order (ctz).  bits = its rows inside the fragment.
+          while (rem != 0) {
+            const int sg = __builtin_amdgcn_readlane(rs_vec, shift + __builtin_ctz(rem));
+            const uint32_t bits = (uint32_t)(__builtin_amdgcn_ballot_w64(rs_vec == sg) >> shift) & rem;
+            rem &= ~bits;
+            const bool fresh = sg != cur_seg;
+            if (fresh) {
+              publish();
+              cur_seg = sg;
+  #pragma unroll
+              for (int j = 0; j < 2; ++j) { ps[j] = 0.0f; pq[j] = 0.0f; }
+            }
+            if (bits == 0xffffffffu) {
+              // the whole fragment is one utterance (84 % of the fragments at 200 frames): 2.5 VALU operations per value
+  #pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                if (fresh) pv[j] = u[j][0];
+                const f32x2_t pv2 = {pv[j], pv[j]};
+                f32x2_t s2[2] = {{0.f, 0.f}, {0.f, 0.f}}, q2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+  #pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                  const f32x2_t uu = {u[j][r], u[j][r + 1]};
+                  const f32x2_t d = uu - pv2;
+                  s2[(r >> 1) & 1] += d;
+                  q2[(r >> 1) & 1] = __builtin_elementwise_fma(d, d, q2[(r >> 1) & 1]);
+                }
+                const f32x2_t st = s2[0] + s2[1], qt = q2[0] + q2[1];
+                ps[j] += st.x + st.y;
+                pq[j] += qt.x + qt.y;
+              }
+            } else {
+              // a seam or gap rows: register r of this lane holds frame 8 (r >> 2) + 4 lh + (r & 3) -> bit r of the lane's mask
+              const uint32_t x = bits >> (4 * lh);
+              const uint32_t lm = (x & 0xfu) | ((x >> 4) & 0xf0u) | ((x >> 8) & 0xf00u) | ((x >> 12) & 0xf000u);
+              if (fresh) {
+                // pivot = the lane's first frame of the utterance (a lane half without frames keeps a stale pivot; pool_finish
+                // skips parts without frames)
+                const int rsel = lm != 0 ? __builtin_ctz(lm) : 16;
+  #pragma unroll
+                for (int r = 15; r >= 0; --r) {
+                  const bool hit = rsel == r;
+                  pv[0] = hit ? u[0][r] : pv[0];
+                  pv[1] = hit ? u[1][r] : pv[1];
+                }
+              }
+              f32x2_t s2[2] = {{0.f, 0.f}, {0.f, 0.f}}, q2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+              const f32x2_t pva = {pv[0], pv[0]}, pvb = {pv[1], pv[1]};
+  #pragma unroll
+              for (int r = 0; r < 16; r += 2) {
+                const int t0 = (int)(lm << (31 - r)) >> 31, t1 = (int)(lm << (30 - r)) >> 31;      // all ones where the frame is in the run
+                f32x2_t da = (f32x2_t){u[0][r], u[0][r + 1]} - pva, db = (f32x2_t){u[1][r], u[1][r + 1]} - pvb;
+                da.x = __int_as_float(__float_as_int(da.x) & t0); da.y = __int_as_float(__float_as_int(da.y) & t1);
+                db.x = __int_as_float(__float_as_int(db.x) & t0); db.y = __int_as_float(__float_as_int(db.y) & t1);
+                s2[0] += da; q2[0] = __builtin_elementwise_fma(da, da, q2[0]);
+                s2[1] += db; q2[1] = __builtin_elementwise_fma(db, db, q2[1]);
+              }
+              ps[0] += s2[0].x + s2[0].y; pq[0] += q2[0].x + q2[0].y;
+              ps[1] += s2[1].x + s2[1].y; pq[1] += q2[1].x + q2[1].y;
+            }
+          }
+        }
+        publish();
       }
-      publish(true);
       stamp();                             // 8, 10, 12: pooling epilogue of the unit done
     }
     if (p.dbg != nullptr && lane == 0) p.dbg[((size_t)blockIdx.x * 8 + wave) * 16 + 15] = __builtin_amdgcn_s_memrealtime();
@@ -442,7 +541,9 @@ int launch_tdnn_chain(const TdnnChainParams &p, hipStream_t s) {
   ASV_REQUIRE(p.first.wfrag && p.last.wfrag && p.last.bias && p.n_mid >= 0 && p.n_mid <= 2 && p.last.cout_pad % 64 == 0, "tdnn(chain): incomplete layer description");
   ASV_REQUIRE(p.pool_partial && p.row_seg && p.pool_slots >= 1, "tdnn(chain): the last layer feeds the fused pooling (partials / row map missing)");
   for (int t = 0; t < p.n_taps; ++t) ASV_REQUIRE(p.taps[t] >= -kHalo && p.taps[t] <= kHalo, "tdnn(chain): tap offset %d exceeds the %d-frame halo", p.taps[t], kHalo);
-  hipLaunchKernelGGL(tdnn_chain_kernel, dim3(p.rows / CM), dim3(512), 0, s, p);
+  const char *pv = getenv("ASV_AMD_CHAIN_POOLV");                // read at every launch: in-process A/B (tools/chain_ab.py)
+  if (pv != nullptr && pv[0] == '0') hipLaunchKernelGGL(tdnn_chain_kernel<0>, dim3(p.rows / CM), dim3(512), 0, s, p);
+  else hipLaunchKernelGGL(tdnn_chain_kernel<1>, dim3(p.rows / CM), dim3(512), 0, s, p);
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }

@@ -202,8 +202,9 @@ def sliding_cmn(x, cmn_window=600, min_window=100, center=False, norm_vars=False
 
 
 def vad_energy(feats, vad_energy_threshold=5.0, vad_energy_mean_scale=0.5, vad_frames_context=2, vad_proportion_threshold=0.12):
-    """Reference runtime/extractor/torch_asv_extractor.cc:14-62 (the C++ needs glog/gflags/yaml-cpp fetched from the network,
-    so it cannot be compiled here: restated line by line).  Returns a 0/1 vector."""
+    """Reference runtime/extractor/torch_asv_extractor.cc:14-62, restated.  Pinned to the reference's own decisions:
+    tests/golden/vad.npz comes from that file compiled in place (oracle/Makefile.ref, oracle/gen_vad_golden.py).
+    Returns a 0/1 vector."""
     e = np.asarray(feats, dtype=np.float32)[:, 0]
     n = len(e)
     thr = np.float32(vad_energy_threshold)

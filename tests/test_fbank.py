@@ -112,3 +112,37 @@ def test_oracle_matches_the_compiled_reference_on_the_reference_test_wavs():
         ref = G.reference_mfcc(lib, x, **mkw)
         got = fbank_oracle.mfcc(x, **mkw)
         assert got.shape == ref.shape and np.abs(got - ref).max() < 2e-3 and np.abs(got - ref).mean() < 5e-5, path
+
+
+def test_vad_restatement_matches_the_compiled_reference():
+    """tests/golden/vad.npz holds the decisions of the reference's own ComputeVadEnergy (runtime/extractor/torch_asv_extractor.cc:14-62,
+    compiled in place by oracle/Makefile.ref; oracle/gen_vad_golden.py): thresholds with ties, contexts wider than the
+    utterance, one- and two-frame inputs, nothing voiced."""
+    import json
+    g = np.load(os.path.join(helpers.REPO, "tests", "golden", "vad.npz"))
+    meta = json.loads(str(g["meta"]))
+    assert len(meta) >= 10
+    for case in meta:
+        e = g[case["name"] + "/energy"]
+        feats = np.stack([e, np.zeros_like(e)], axis=1)
+        got = fbank_oracle.vad_energy(feats, **case["options"])
+        assert np.array_equal(got, g[case["name"] + "/voiced"]), case["name"]
+
+
+def test_vad_reference_library_reproduces_the_fixture():
+    """Build container only: the compiled reference itself still yields the committed fixture."""
+    lib_path = os.path.join(helpers.REPO, "oracle", "_ref", "libextractor_ref.so")
+    if not os.path.exists(lib_path) or not os.path.isdir("/root/reference"):
+        pytest.skip("oracle/_ref/libextractor_ref.so is built in the build container only (make -C oracle -f Makefile.ref)")
+    import ctypes as C
+    import json
+    lib = C.CDLL(lib_path)
+    g = np.load(os.path.join(helpers.REPO, "tests", "golden", "vad.npz"))
+    for case in json.loads(str(g["meta"])):
+        e = np.ascontiguousarray(g[case["name"] + "/energy"].reshape(-1, 1))
+        o = case["options"]
+        voiced = np.zeros(len(e), dtype=np.float32)
+        rc = lib.extractor_ref_vad_energy(e.ctypes.data_as(C.c_void_p), len(e), 1, C.c_float(o["vad_energy_threshold"]), C.c_float(o["vad_energy_mean_scale"]),
+                                          int(o["vad_frames_context"]), C.c_float(o["vad_proportion_threshold"]), voiced.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        assert np.array_equal(voiced.astype(np.uint8), g[case["name"] + "/voiced"]), case["name"]

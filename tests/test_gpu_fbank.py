@@ -1,6 +1,8 @@
 """asv_fbank / asv_cmvn on the MI355X against the reference's kaldifeat outputs (tests/golden/fbank.npz) and the numpy
 oracle; batching, ragged lengths, mean/variance normalisation, and waveform -> embedding without a host round trip."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -156,6 +158,35 @@ def test_energy_vad_and_voiced_frame_selection():
         assert 0 < counts.sum() < len(v)                                     # the gate really produced both classes
         kept, koff = frontend.select_voiced(feats, voiced, off, counts)
         assert np.array_equal(kept.cpu().numpy(), host[v.astype(bool)]) and list(np.diff(koff)) == list(counts)
+
+
+def test_energy_vad_matches_the_compiled_reference():
+    """The device VAD against the decisions of the reference's own ComputeVadEnergy (tests/golden/vad.npz,
+    runtime/extractor/torch_asv_extractor.cc:14-62 compiled in place in the build container): all cases of one option set in
+    one packed launch."""
+    import json
+    import torch
+    from libs.amd import frontend
+    g = np.load(os.path.join(helpers.REPO, "tests", "golden", "vad.npz"))
+    meta = json.loads(str(g["meta"]))
+    by_opts = {}
+    for case in meta:
+        by_opts.setdefault(json.dumps(case["options"], sort_keys=True), []).append(case)
+    n_checked = 0
+    for key, cases in by_opts.items():
+        cols = [g[c["name"] + "/energy"] for c in cases]
+        off = np.concatenate([[0], np.cumsum([len(c) for c in cols])]).astype(np.int64)
+        feats = np.zeros((int(off[-1]), 4), dtype=np.float32)
+        feats[:, 0] = np.concatenate(cols)
+        feats[:, 1:] = np.random.RandomState(0).standard_normal((len(feats), 3))
+        voiced, counts = frontend.vad_energy(torch.from_numpy(feats).cuda(), off, **json.loads(key))
+        v = voiced.cpu().numpy()
+        for i, c in enumerate(cases):
+            want = g[c["name"] + "/voiced"]
+            assert np.array_equal(v[off[i]:off[i + 1]], want), c["name"]
+            assert counts[i] == want.sum()
+            n_checked += 1
+    assert n_checked == len(meta)
 
 
 def test_full_size_properties_shift_and_batch_invariance():

@@ -233,3 +233,18 @@ def test_layer_chain_kernel_matches_per_layer_kernels(monkeypatch):
     monkeypatch.setenv("ASV_AMD_NO_CHAIN", "1")
     b = model2.extract_embedding_batch(mats2).numpy()
     assert rel_err(a, b) < 2e-3, rel_err(a, b)
+    # many utterances per 32-frame fragment (several masked runs per fragment, lane halves without frames, single-frame
+    # utterances), both pooling epilogues of the chain kernel (ASV_AMD_CHAIN_POOLV is read at every launch)
+    lens = [1, 2, 3, 5, 4, 7, 1, 9, 13, 21, 2, 34, 6, 55, 3, 89, 11, 144, 1, 1, 8, 233, 17, 2, 40, 31, 32, 33, 64, 63, 65, 12] * 6
+    mats3 = [synth.synth_feats(T, 80, 9000 + i) for i, T in enumerate(lens)]
+    ref = model2.extract_embedding_batch(mats3).numpy()                  # per-layer kernels
+    monkeypatch.delenv("ASV_AMD_NO_CHAIN")
+    outs = {}
+    for v in ("0", "1"):
+        monkeypatch.setenv("ASV_AMD_CHAIN_POOLV", v)
+        outs[v] = model2.extract_embedding_batch(mats3).numpy()
+        assert np.isfinite(outs[v]).all()
+        assert rel_err(outs[v], ref) < 2e-3, (v, rel_err(outs[v], ref))
+        a200 = model2.extract_embedding_batch(mats2).numpy()
+        assert rel_err(a200, b) < 2e-3, (v, rel_err(a200, b))
+    assert rel_err(outs["0"], outs["1"]) < 1e-4, rel_err(outs["0"], outs["1"])   # same moments, other summation order
