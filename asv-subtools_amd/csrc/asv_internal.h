@@ -113,12 +113,8 @@ int launch_grid_conv_narrow(const TdnnKernelParams &p, hipStream_t s);
 bool grid_conv_c1_supported(const TdnnKernelParams &p, bool bf16, int in_ch);
 int launch_grid_conv_c1(const TdnnKernelParams &p, hipStream_t s);
 int launch_splitk_epilogue(const TdnnKernelParams &p, bool bf16, bool out_f32, hipStream_t s);
-// 256x256-tile bf16 kernel with direct-to-LDS staging (kernels_tdnn_v2.hip); needs weights
-// padded to kBigTileN rows and a plain epilogue (no second input / per-segment terms / residual)
+// 256-channel tiles of the bf16 frame-layer kernel (kernels_tdnn_v3.hip): weights are padded to kBigTileN output channels
 constexpr int kBigTileN = 256;
-bool tdnn_big_supported(const TdnnKernelParams &p, bool bf16, bool out_f32);
-int launch_tdnn_big(const TdnnKernelParams &p, hipStream_t s);
-int launch_tdnn_big_variant(const TdnnKernelParams &p, int variant, hipStream_t s);   // ablations, tools/gemm_ablate
 // variant 3: feature window via LDS-DMA ring, weight fragments straight from L2 (kernels_tdnn_v3.hip)
 bool tdnn_big3_supported(const TdnnKernelParams &p, bool bf16, bool out_f32);
 int launch_tdnn_big3(const TdnnKernelParams &p, hipStream_t s);
@@ -198,6 +194,7 @@ struct EltwiseKernelParams {
   const int32_t *row_seg; const uint32_t *row_valid;   // nullptr in the utts domain
   int act;                             // activation applied to the final sum
   const float *seg_norm; int ld_segnorm, seg_norm_mode;   // [segments][mean(C) | std(C)]: a <- (a - mean) / std first
+  const void *d; void *out2; int ldd, ldo2;              // second output: out2 = (out as stored) + d, or nullptr
 };
 int launch_lde_pool(const void *x, int ldx, int channels, int rows, const float *mu, const float *beta, int n_centres, float *weights,
                     const int32_t *seg_row0, const int32_t *seg_len, int segments, float *out, int ld_out, bool bf16, hipStream_t s);

@@ -171,57 +171,85 @@ __global__ __launch_bounds__(256, CIN == 32 ? 3 : 2) void grid_conv_narrow_kerne
 }
 
 // The first convolution of the trunk: ONE input channel (the fbank map itself), 3x3, 32 output channels
-// (resnet.py:96-99).  9 multiply-adds per output - nothing for a matrix core: one thread per (row, 8 channels), the nine
-// bf16 inputs of the row gathered through L1, f32 fma in tap order (bit-identical to the MFMA path, whose other 15
-// k-lanes are zeros), 16-byte coalesced stores.  HBM bound on the 64 B it writes per row - once the weights and the
-// per-channel constants sit in LDS as f32 ([tap][channel]: two ds_read_b128 per tap, broadcast across the rows of a wave);
-// fetched per thread from global memory (72 two-byte loads for 8 outputs) the kernel took 600 us on 4.3 M rows (r2a profile).
+// (resnet.py:96-99).  9 multiply-adds per output - nothing for a matrix core: f32 fma in tap order (bit-identical to the
+// MFMA path, whose other 15 k-lanes are zeros).  A workgroup owns C1_SPAN consecutive rows: their inputs (the span plus
+// C1_HALO rows on each side) go to LDS once as f32; a thread owns 8 output channels - their 9 x 8 weights and per-channel
+// constants sit in registers - and walks C1_ROWS rows, a wave covering 16 consecutive rows x 4 channel chunks per step
+// (1 KiB of contiguous 16-byte stores).  HBM bound on the 64 B it writes per row.  History (4.3 M rows): weights fetched per
+// thread from global memory 600 us; weights from LDS per row 220 us (18 ds_read_b128 per 72 fma: LDS bound); weights in
+// registers but the nine inputs of a row gathered from global memory inside the row loop 319 us (a dependent ~2 us load per
+// step); inputs staged in LDS: see profiles/.
+constexpr int C1_ROWS = 8;
+constexpr int C1_HALO = 84;                      // >= pitch + 1 of the widest grid (ir.py: 82 frequency bins + 2)
 template <bool GENERIC>
 __global__ __launch_bounds__(256) void grid_conv_c1_kernel(const TdnnKernelParams p) {
   __shared__ __attribute__((aligned(16))) float w_s[9 * 64];
   __shared__ __attribute__((aligned(16))) float c_s[3 * 64];                   // bias | scale | shift
-  const int chunks = p.cout_store / 8;
+  __shared__ float x_s[64 * C1_ROWS + 2 * C1_HALO];                             // span of the widest case (4 chunks: 64 rows per step)
+  const int chunks = p.cout_store / 8;                                         // 4 (32 channels) .. 8
+  const int rows_per_step = 256 / chunks, span = rows_per_step * C1_ROWS;
+  const long long base = (long long)blockIdx.x * span;
   {
     const uint16_t *w = reinterpret_cast<const uint16_t *>(p.w);               // [cout_pad][n_taps][cin_pad] bf16
-    for (int i = threadIdx.x; i < p.n_taps * p.cout_store; i += 256) {
-      const int t = i / p.cout_store, c = i % p.cout_store;
-      w_s[t * 64 + c] = bf16_bits_to_f32(w[((size_t)c * p.n_taps + t) * p.cin_pad]);
+    for (int i = threadIdx.x; i < 9 * 64; i += 256) {
+      const int t = i / 64, c = i % 64;
+      w_s[i] = (t < p.n_taps && c < p.cout_store) ? bf16_bits_to_f32(w[((size_t)c * p.n_taps + t) * p.cin_pad]) : 0.0f;
     }
-    for (int c = threadIdx.x; c < p.cout_store; c += 256) {
-      c_s[c] = p.bias[c];
-      c_s[64 + c] = p.scale ? p.scale[c] : 1.0f;
-      c_s[128 + c] = p.shift ? p.shift[c] : 0.0f;
+    for (int c = threadIdx.x; c < 64; c += 256) {
+      const bool ok = c < p.cout_store;
+      c_s[c] = ok ? p.bias[c] : 0.0f;
+      c_s[64 + c] = (ok && p.scale) ? p.scale[c] : 1.0f;
+      c_s[128 + c] = (ok && p.shift) ? p.shift[c] : 0.0f;
+    }
+    const uint16_t *x = reinterpret_cast<const uint16_t *>(p.x);
+    for (int i = threadIdx.x; i < span + 2 * C1_HALO; i += 256) {
+      const long long r = base - C1_HALO + i;
+      x_s[i] = (r >= 0 && r < p.rows) ? bf16_bits_to_f32(x[(size_t)r * p.ldx]) : 0.0f;
     }
   }
   __syncthreads();
-  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= (long long)p.rows * chunks) return;
-  const int row = (int)(gid / chunks), ch = (int)(gid % chunks) * 8;
-  const uint16_t *x = reinterpret_cast<const uint16_t *>(p.x);
-  float acc[8];
+  const int slot = threadIdx.x / chunks, ch = (threadIdx.x % chunks) * 8;
+  if (slot >= rows_per_step) return;                                           // chunks that do not divide 256 leave idle threads
+  float wv[9][8], cb[8], cs[8], ct[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
-  const bool valid = (p.row_valid[row >> 5] >> (row & 31)) & 1u;
-  if (valid) {
-    for (int t = 0; t < p.n_taps; ++t) {
-      const int r = row + p.taps[t];
-      const float xv = (r >= 0 && r < p.rows) ? bf16_bits_to_f32(x[(size_t)r * p.ldx]) : 0.0f;
-      const float4 w0 = *reinterpret_cast<const float4 *>(w_s + t * 64 + ch), w1 = *reinterpret_cast<const float4 *>(w_s + t * 64 + ch + 4);
-      const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+  for (int t = 0; t < 9; ++t) {
+    const float4 w0 = *reinterpret_cast<const float4 *>(w_s + t * 64 + ch), w1 = *reinterpret_cast<const float4 *>(w_s + t * 64 + ch + 4);
+    wv[t][0] = w0.x; wv[t][1] = w0.y; wv[t][2] = w0.z; wv[t][3] = w0.w; wv[t][4] = w1.x; wv[t][5] = w1.y; wv[t][6] = w1.z; wv[t][7] = w1.w;
+  }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] = fmaf(wv[e], xv, acc[e]);
+  for (int e = 0; e < 8; ++e) { cb[e] = c_s[ch + e]; cs[e] = c_s[64 + ch + e]; ct[e] = c_s[128 + ch + e]; }
+  int tap[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) tap[t] = t < p.n_taps ? p.taps[t] : 0;          // unused taps carry zero weights
+  const float act_lo = (p.act1 == ASV_ACT_RELU) ? 0.0f : -INFINITY;
+#pragma unroll 2
+  for (int k = 0; k < C1_ROWS; ++k) {
+    const int local = k * rows_per_step + slot;
+    const long long rl = base + local;
+    if (rl >= p.rows) break;
+    const int row = (int)rl;
+    const bool valid = (p.row_valid[row >> 5] >> (row & 31)) & 1u;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+    if (valid) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float xv = x_s[local + C1_HALO + tap[t]];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(wv[t][e], xv, acc[e]);
+      }
     }
-  }
-  float y[8];
+    float y[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const float bias = c_s[ch + e], scale = c_s[64 + ch + e], shift = c_s[128 + ch + e];
-    if constexpr (GENERIC) y[e] = tdnn_epilogue<true>(p, acc[e], row, ch + e, bias, scale, shift, valid);
-    else y[e] = tdnn_epilogue_fast(acc[e], bias, (p.act1 == ASV_ACT_RELU) ? 0.0f : -INFINITY, scale, shift, valid);
+    for (int e = 0; e < 8; ++e) {
+      if constexpr (GENERIC) y[e] = tdnn_epilogue<true>(p, acc[e], row, ch + e, cb[e], cs[e], ct[e], valid);
+      else y[e] = tdnn_epilogue_fast(acc[e], cb[e], act_lo, cs[e], ct[e], valid);
+    }
+    uint4 o;
+    o.x = pack_bf16x2(y[0], y[1]); o.y = pack_bf16x2(y[2], y[3]); o.z = pack_bf16x2(y[4], y[5]); o.w = pack_bf16x2(y[6], y[7]);
+    *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(p.y) + (size_t)row * p.ldy + ch) = o;
   }
-  uint4 o;
-  o.x = pack_bf16x2(y[0], y[1]); o.y = pack_bf16x2(y[2], y[3]); o.z = pack_bf16x2(y[4], y[5]); o.w = pack_bf16x2(y[6], y[7]);
-  *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(p.y) + (size_t)row * p.ldy + ch) = o;
 }
 
 }  // namespace
@@ -254,12 +282,13 @@ int launch_grid_conv_narrow(const TdnnKernelParams &p, hipStream_t s) {
 }
 
 bool grid_conv_c1_supported(const TdnnKernelParams &p, bool bf16, int in_ch) {
-  return bf16 && in_ch == 1 && p.x2 == nullptr && p.w != nullptr && p.cout_store % 8 == 0 && p.cout_store <= 64 && p.ldy % 8 == 0 && p.n_taps <= 9;
+  return bf16 && in_ch == 1 && p.x2 == nullptr && p.w != nullptr && p.cout_store % 8 == 0 && p.cout_store >= 32 && p.cout_store <= 64 && p.ldy % 8 == 0 &&
+         p.n_taps <= 9 && p.halo <= C1_HALO;
 }
 
 int launch_grid_conv_c1(const TdnnKernelParams &p, hipStream_t s) {
-  const long long n = (long long)p.rows * (p.cout_store / 8);
-  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  const int chunks = p.cout_store / 8, rows_per_wg = (256 / chunks) * C1_ROWS;
+  const dim3 grid((unsigned)((p.rows + rows_per_wg - 1) / rows_per_wg)), block(256);
   const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first && p.seg_bias == nullptr &&
                     p.seg_scale == nullptr && p.res == nullptr;
   if (fast) hipLaunchKernelGGL((grid_conv_c1_kernel<false>), grid, block, 0, s, p);

@@ -140,6 +140,10 @@ __device__ __forceinline__ void load_vec(const void *base, size_t idx, float (&v
 // segment's first frame, which keeps the one-pass form  var = E[(x-c)^2] - (E[x-c])^2  well
 // conditioned (the pivot is within a few std of the mean), then std = sqrt(max(var, eps)) or
 // sqrt(var + eps).  grid = (ceil(C/64), segments).
+// Tried and dropped (r2c): several workgroups per (segment, 64 channels) for the few, long segments of the ResNet trunk's SE
+// means, meeting through a ticket - the device-scope fence in front of the ticket writes the whole L2 back (the producing
+// convolution's output is still dirty in it): 220 us instead of 110 us, and a split count that depends on the batch breaks
+// the bit-for-bit batch invariance of an utterance's embedding.
 template <bool BF16>
 __global__ __launch_bounds__(256) void stats_pool_kernel(const PoolKernelParams p) {
   constexpr int VEC = BF16 ? 8 : 4;
@@ -433,7 +437,7 @@ __global__ __launch_bounds__(256) void eltwise_kernel(const EltwiseKernelParams 
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
   if (gid >= (long long)p.rows * pieces) return;
   const int row = (int)(gid / pieces), ch = (int)(gid % pieces) * VEC;
-  float o[VEC];
+  float o[VEC], tb[VEC];
   bool valid = true;
   int seg = row;
   if (p.row_valid != nullptr) {
@@ -484,10 +488,9 @@ __global__ __launch_bounds__(256) void eltwise_kernel(const EltwiseKernelParams 
       for (int i = 0; i < VEC; ++i) o[i] *= ss[i];
     }
     if (p.b != nullptr) {
-      float t[VEC];
-      load_vec<BF16, VEC>(p.b, (size_t)row * p.ldb + ch, t);
+      load_vec<BF16, VEC>(p.b, (size_t)row * p.ldb + ch, tb);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) o[i] += t[i];
+      for (int i = 0; i < VEC; ++i) o[i] += tb[i];
     }
     if (p.c != nullptr) {
       float t[VEC];
@@ -506,8 +509,34 @@ __global__ __launch_bounds__(256) void eltwise_kernel(const EltwiseKernelParams 
     u.x = pack_bf16x2(o[0], o[1]); u.y = pack_bf16x2(o[2], o[3]);
     u.z = pack_bf16x2(o[4], o[5]); u.w = pack_bf16x2(o[6], o[7]);
     *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(p.out) + (size_t)row * p.ldo + ch) = u;
+    if (p.out2 != nullptr) {
+      // the value a separate addition would read back: the bf16 just stored
+      o[0] = bf16_bits_to_f32(u.x & 0xffffu); o[1] = bf16_bits_to_f32(u.x >> 16); o[2] = bf16_bits_to_f32(u.y & 0xffffu); o[3] = bf16_bits_to_f32(u.y >> 16);
+      o[4] = bf16_bits_to_f32(u.z & 0xffffu); o[5] = bf16_bits_to_f32(u.z >> 16); o[6] = bf16_bits_to_f32(u.w & 0xffffu); o[7] = bf16_bits_to_f32(u.w >> 16);
+    }
   } else {
     *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.out) + (size_t)row * p.ldo + ch) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+  if (p.out2 != nullptr) {
+    if (valid) {
+      float t[VEC];
+      if (p.d == p.b && p.ldd == p.ldb) {          // the addend is the residual already loaded (ECAPA: next input = residual + block output)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) t[i] = tb[i];
+      } else {
+        load_vec<BF16, VEC>(p.d, (size_t)row * p.ldd + ch, t);
+      }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) o[i] = (ch + i >= p.channels) ? 0.0f : o[i] + t[i];
+    }
+    if constexpr (BF16) {
+      uint4 u;
+      u.x = pack_bf16x2(o[0], o[1]); u.y = pack_bf16x2(o[2], o[3]);
+      u.z = pack_bf16x2(o[4], o[5]); u.w = pack_bf16x2(o[6], o[7]);
+      *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(p.out2) + (size_t)row * p.ldo2 + ch) = u;
+    } else {
+      *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.out2) + (size_t)row * p.ldo2 + ch) = make_float4(o[0], o[1], o[2], o[3]);
+    }
   }
 }
 

@@ -19,6 +19,8 @@
 //     weight fragments / window pieces issued during the last step.
 //   * 4 LDS fragment reads per 8 MFMAs; epilogue as in variant 2 (4 consecutive channels per lane,
 //     LDS-staged 16-byte stores).
+#include <cstdlib>
+
 #include "device_utils.h"
 
 namespace asv {
@@ -212,10 +214,20 @@ __global__ __launch_bounds__(Geom3<WM>::WAVES * 64, WM == 0 ? 3 : 2) void tdnn_g
   };
   // ---- prologue: three windows in flight, weight fragments of step 0.  Only window 0 and the fragments are
   // waited for: VMEM retires in order, so vmcnt(2 * PIECES) leaves exactly windows 1 and 2 outstanding.
+  // 1-tap layers (a chunk is only 4 k-groups = 32 MFMAs per wave) meet at the workgroup barrier every SECOND chunk: all four
+  // stages are in flight from the start, windows c and c+1 are read between two barriers, and the barrier that ends chunk c
+  // (c odd) refills their stages with windows c+3 and c+4 (r2: the per-chunk barrier held the 1024 -> 1024 layers of ECAPA
+  // at 0.37 of the bf16 peak against 0.46 for the 3-tap layers).
+  const bool pair = (p.tune & 0x10000) == 0 && n_taps == 1 && nchunks >= 4 && ABL != 1;
   issue_A(0, 0);
 #pragma unroll
   for (int kg = 0; kg < 4; ++kg) load_wf(kg, 0, 0);
-  if (nchunks > 2) {
+  if (pair) {
+    issue_A(1, 1);
+    issue_A(2, 2);
+    issue_A(3, 3);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::PIECES) : "memory");      // windows 0 and 1 (and the fragments) are in
+  } else if (nchunks > 2) {
     issue_A(1, 1);
     issue_A(2, 2);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::PIECES) : "memory");
@@ -287,10 +299,18 @@ __global__ __launch_bounds__(Geom3<WM>::WAVES * 64, WM == 0 ? 3 : 2) void tdnn_g
       const unsigned char *An = Ab;
       int dn = __builtin_amdgcn_readlane(v_taps, last_tap ? t : t + 1);
       if (last_tap && c + 1 < nchunks) {
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (!NO_DMA && c + 3 < nchunks) issue_A(c + 3, (c + 3) % N_STAGES);
+        if (!pair) {
+          asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          if (!NO_DMA && c + 3 < nchunks) issue_A(c + 3, (c + 3) % N_STAGES);
+        } else if (c & 1) {
+          asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          if (!NO_DMA && c + 3 < nchunks) issue_A(c + 3, (c + 3) % N_STAGES);
+          if (!NO_DMA && c + 4 < nchunks) issue_A(c + 4, (c + 4) % N_STAGES);
+        }
         An = lds + ((c + 1) % N_STAGES) * A_STAGE;
         dn = d_first;
       }
@@ -440,6 +460,17 @@ __global__ __launch_bounds__(Geom3<WM>::WAVES * 64, WM == 0 ? 3 : 2) void tdnn_g
   uint32_t vmask = 0;                            // bit i: this lane's frame of m-fragment i is a real frame
 #pragma unroll
   for (int i = 0; i < MF; ++i) vmask |= ((p.row_valid[(m0 + wm * (MF * 32) + i * 32) >> 5] >> lr) & 1u) << i;
+  // generic epilogue only: per-utterance bias rows (the hoisted global-context part of ECAPA's attention layer,
+  // ecapa_tdnn_xvector.py:176-181), one float4 per (frame, 4 channels) from L2
+  const float *segb[MF];
+  if constexpr (GENERIC) {
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+      segb[i] = nullptr;
+      if (p.seg_bias != nullptr && ((vmask >> i) & 1u))
+        segb[i] = p.seg_bias + (size_t)p.row_seg[m0 + wm * (MF * 32) + i * 32 + lr] * p.ld_segbias + n0;
+    }
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -459,6 +490,7 @@ __global__ __launch_bounds__(Geom3<WM>::WAVES * 64, WM == 0 ? 3 : 2) void tdnn_g
         for (int e = 0; e < 4; ++e) {
           if constexpr (GENERIC) {
             float z = acc[i][j][q * 4 + e] + b[e];
+            if (segb[i] != nullptr && n0 + chl + e < p.cout_store) z += segb[i][chl + e];
             z = p.affine_first ? apply_act(z * sc[e] + sh[e], p.act1) : apply_act(z, p.act1) * sc[e] + sh[e];
             z = apply_act(z, p.act2);
             y[e] = valid ? z : 0.0f;
@@ -499,12 +531,16 @@ __global__ __launch_bounds__(Geom3<WM>::WAVES * 64, WM == 0 ? 3 : 2) void tdnn_g
 }  // namespace
 
 bool tdnn_big3_supported(const TdnnKernelParams &p, bool bf16, bool out_f32) {
-  TdnnKernelParams q = p;
-  q.pool_partial = nullptr;                       // the fused-pooling form has the same requirements otherwise
   // the window refill addresses rows with 32-bit byte offsets from a scalar base: activation matrices of 4 GiB and more
   // (2 M rows x 1536 channels) go to the kernels with 64-bit addressing
   const bool fits32 = (unsigned long long)p.rows * (unsigned long long)p.ldx * 2ull < (1ull << 32);
-  return p.wfrag != nullptr && fits32 && tdnn_big_supported(q, bf16, out_f32);
+  // Tried and dropped (r2c): 128-channel layers with a deep K (ECAPA's attention bottleneck 1536 -> 128, the im2col'd 576 -> 128
+  // convolution) on half-filled 256-channel tiles: 600 workgroups are 1.17 rounds of the 512 resident ones and every one of
+  // them multiplies 128 channels of zeros: 231 us against 172 us on the 128 x 128 register-staged tile.
+  const bool wide_enough = p.cout_store >= 192;
+  // a per-utterance bias (seg_bias) is part of the generic epilogue; the fused pooling has the plain one
+  return p.wfrag != nullptr && fits32 && bf16 && !out_f32 && p.x2 == nullptr && (p.seg_bias == nullptr || (p.pool_partial == nullptr && p.row_seg != nullptr)) &&
+         p.seg_scale == nullptr && p.res == nullptr && p.zero16 != nullptr && p.rows % 256 == 0 && p.cout_store % 8 == 0 && wide_enough && p.cin_pad >= 64;
 }
 
 // variant = geometry * 100 + ablation code; geometry 0: 128 x 256 tiles (two workgroups per CU), 1: 256 x 256 (one),
@@ -519,7 +555,7 @@ int launch_tdnn_big3_variant(const TdnnKernelParams &p, int variant, hipStream_t
   ASV_REQUIRE(p.row_begin % bm == 0 && row_count % bm == 0 && p.row_begin + row_count <= p.rows, "tdnn(big3): row range [%d, +%d) does not fit %d-row tiles", p.row_begin, row_count, bm);
   const int m_tiles = row_count / bm, n_tiles = round_up(p.cout_store, BN) / BN;
   const dim3 grid(m_tiles * n_tiles), block(geom == 1 ? 512 : 256);
-  const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first;
+  const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first && p.seg_bias == nullptr;
   if (p.pool_partial != nullptr) {
     ASV_REQUIRE(fast && p.row_seg != nullptr && p.pool_slots >= 1 && geom != 2, "tdnn(big3): fused pooling needs the plain epilogue, a row map and 128-row wave tiles");
     if (geom == 0 && variant == 5) hipLaunchKernelGGL((tdnn_gemm_big3_kernel<5, false, true, 1>), grid, block, 0, s, p, m_tiles, n_tiles);
@@ -592,6 +628,14 @@ int tdnn_big3_pick_geometry(const TdnnKernelParams &p) {
 // kernel cannot start before the first has drained, the overlap between the tail of round one and the head of round two is
 // lost, and the result is 4-6 us slower on every C2 layer (89 vs 85 us on the 3-tap 512 -> 512 layer).  The row-range
 // parameters (row_begin / row_count) stay for tools/gemm_ablate.
-int launch_tdnn_big3(const TdnnKernelParams &p, hipStream_t s) { return launch_tdnn_big3_variant(p, tdnn_big3_pick_geometry(p) * 100, s); }
+int launch_tdnn_big3(const TdnnKernelParams &p, hipStream_t s) {
+  const char *tune = getenv("ASV_AMD_BIG3_TUNE");            // developer aid, read at every launch: in-process A/B (tools/chain_ab.py)
+  if (tune != nullptr && p.tune == 0) {
+    TdnnKernelParams q = p;
+    q.tune = atoi(tune);
+    return launch_tdnn_big3_variant(q, tdnn_big3_pick_geometry(q) * 100, s);
+  }
+  return launch_tdnn_big3_variant(p, tdnn_big3_pick_geometry(p) * 100, s);
+}
 
 }  // namespace asv

@@ -474,7 +474,7 @@ int asv_net_add_tdnn(asv_net_t *net, const asv_tdnn_desc_t *d) {
     pack_tdnn_weight(d->weight, d->out_ch, d->in_ch, d->w_tot_context, d->w_left_context, d->taps, d->n_taps, op.cout_pad,
                      op.cin_pad, bf16, packed.data());
     if ((rc = dev_upload(net, packed.data(), packed.size(), &op.w))) return rc;
-    if (bf16 && op.cout_store >= 192 && op.cin_pad >= 64) {       // candidates of the 256x256 kernels
+    if (bf16 && op.cout_store >= 192 && op.cin_pad >= 64) {       // candidates of the 256-channel tiles (kernels_tdnn_v3.hip)
       std::vector<uint16_t> frags(tdnn_weight_frag_elems(op.cout_pad, op.cin_pad, d->n_taps));
       pack_tdnn_weight_frags(d->weight, d->out_ch, d->in_ch, d->w_tot_context, d->w_left_context, d->taps, d->n_taps, op.cout_pad, op.cin_pad, frags.data());
       if ((rc = dev_upload(net, frags.data(), frags.size() * 2, &op.wfrag))) return rc;
@@ -652,6 +652,14 @@ int asv_net_add_eltwise(asv_net_t *net, const asv_eltwise_desc_t *d) {
   ASV_REQUIRE(d->act >= ASV_ACT_NONE && d->act <= ASV_ACT_SIGMOID, "eltwise: unknown activation %d", d->act);
   const int vec = net->dom_bf16(dom) ? 8 : 4;
   ASV_REQUIRE(d->out_ch_off + round_up(d->channels, vec) <= net->bufs[d->out_buf].ld, "eltwise: padded view exceeds pitch");
+  ASV_REQUIRE((d->out2_buf >= 0) == (d->d_buf >= 0), "eltwise: the second output and its addend come together");
+  if (d->out2_buf >= 0) {
+    if ((rc = check_view(net, d->d_buf, d->d_ch_off, d->channels, "eltwise d"))) return rc;
+    if ((rc = check_view(net, d->out2_buf, d->out2_ch_off, d->channels, "eltwise out2"))) return rc;
+    ASV_REQUIRE(net->bufs[d->d_buf].domain == dom && net->bufs[d->out2_buf].domain == dom && d->out2_buf != 0 && d->out2_buf != d->out_buf,
+                "eltwise: bad second output / addend buffer");
+    ASV_REQUIRE(d->out2_ch_off + round_up(d->channels, vec) <= net->bufs[d->out2_buf].ld, "eltwise: padded second view exceeds pitch");
+  }
   Op op; op.kind = OP_ELTWISE; op.elt = *d; op.utts = net->is_utts(dom);
   ASV_HIP_CHECK(hipSetDevice(net->device));
   if (d->scale) {
@@ -717,6 +725,7 @@ int asv_net_finalize(asv_net_t *net, int out_buf, int embed_dim) {
         const int reads[] = {o.kind == OP_TDNN ? o.tdnn.in_buf : -1, o.kind == OP_TDNN ? o.tdnn.in2_buf : -1, o.kind == OP_TDNN ? o.tdnn.res_buf : -1,
                              o.kind == OP_POOL ? o.pool.in_buf : -1, o.kind == OP_ATTPOOL ? o.att.x_buf : -1, o.kind == OP_ATTPOOL ? o.att.logit_buf : -1,
                              o.kind == OP_ELTWISE ? o.elt.a_buf : -1, o.kind == OP_ELTWISE ? o.elt.b_buf : -1, o.kind == OP_ELTWISE ? o.elt.c_buf : -1,
+                             o.kind == OP_ELTWISE ? o.elt.d_buf : -1,
                              o.kind == OP_IM2COL ? o.i2c.in_buf : -1, o.kind == OP_LDE ? o.lde.x_buf : -1, o.kind == OP_RES2 ? o.res2.in_buf : -1};
         for (int rbuf : reads) other_reader |= (rbuf == d.out_buf);
       }
@@ -746,7 +755,7 @@ int asv_net_finalize(asv_net_t *net, int out_buf, int embed_dim) {
                              o.kind == OP_TDNN ? o.tdnn.seg_bias_buf : -1, o.kind == OP_TDNN ? o.tdnn.seg_scale_buf : -1,
                              o.kind == OP_POOL ? o.pool.in_buf : -1, o.kind == OP_ATTPOOL ? o.att.x_buf : -1, o.kind == OP_ATTPOOL ? o.att.logit_buf : -1,
                              o.kind == OP_ELTWISE ? o.elt.a_buf : -1, o.kind == OP_ELTWISE ? o.elt.b_buf : -1, o.kind == OP_ELTWISE ? o.elt.c_buf : -1,
-                             o.kind == OP_ELTWISE ? o.elt.seg_scale_buf : -1, o.kind == OP_ELTWISE ? o.elt.seg_norm_buf : -1,
+                             o.kind == OP_ELTWISE ? o.elt.seg_scale_buf : -1, o.kind == OP_ELTWISE ? o.elt.seg_norm_buf : -1, o.kind == OP_ELTWISE ? o.elt.d_buf : -1,
                              o.kind == OP_IM2COL ? o.i2c.in_buf : -1, o.kind == OP_LDE ? o.lde.x_buf : -1, o.kind == OP_GRID_INPUT ? o.gin.in_buf : -1,
                              o.kind == OP_RES2 ? o.res2.in_buf : -1};
         for (int rbuf : reads) if (rbuf == buf) return false;
@@ -836,8 +845,8 @@ int asv_net_describe(const asv_net_t *net, char *buf, size_t cap) {
         snprintf(line, sizeof(line), "  op %zu: im2col %d -> %d taps=%d stride=%d channels=%d\n", i, op.i2c.in_buf, op.i2c.out_buf, op.i2c.n_taps, op.i2c.stride, op.i2c.channels);
         break;
       case OP_ELTWISE:
-        snprintf(line, sizeof(line), "  op %zu: eltwise a=%d b=%d c=%d segscale=%d affine=%d channels=%d -> %d[%d]\n", i, op.elt.a_buf, op.elt.b_buf, op.elt.c_buf,
-                 op.elt.seg_scale_buf, op.scale != nullptr, op.elt.channels, op.elt.out_buf, op.elt.out_ch_off);
+        snprintf(line, sizeof(line), "  op %zu: eltwise a=%d b=%d c=%d segscale=%d affine=%d channels=%d -> %d[%d]%s\n", i, op.elt.a_buf, op.elt.b_buf, op.elt.c_buf,
+                 op.elt.seg_scale_buf, op.scale != nullptr, op.elt.channels, op.elt.out_buf, op.elt.out_ch_off, op.elt.out2_buf >= 0 ? " (+ second output)" : "");
         break;
     }
     s += line;
@@ -1026,7 +1035,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         p.act1 = d.act1; p.act2 = d.act2; p.affine_first = d.affine_first;
         p.zero16 = net->zero_page;
         p.wfrag = op.wfrag; p.wlo = op.wlo;
-        if (op.chain_last >= 0 && !use_ref && bf16 && p.halo <= kHalo && (net->flags & (ASV_FLAG_SMALL_TILES | ASV_FLAG_BIG_V2)) == 0 &&
+        if (op.chain_last >= 0 && !use_ref && bf16 && p.halo <= kHalo && (net->flags & ASV_FLAG_SMALL_TILES) == 0 &&
             (unsigned long long)p.rows * (unsigned long long)p.ldx * 2ull < (1ull << 32)) {
           // tdnn -> [1-tap]* -> 1-tap + pooling in one kernel, if the batch allows the fused pooling (no crowd of tiny utterances)
           const DomainPlan &fp = bp.dom[ASV_DOMAIN_FRAMES];
@@ -1099,7 +1108,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         const bool narrow = p.halo <= kHalo;
         // fused statistics pooling: needs few enough segments per 128-row half-tile (i.e. no tiny utterances)
         int pool_slots = 0;
-        if (op.fused_pool >= 0 && !use_ref && (net->flags & (ASV_FLAG_SMALL_TILES | ASV_FLAG_BIG_V2)) == 0) {
+        if (op.fused_pool >= 0 && !use_ref && (net->flags & ASV_FLAG_SMALL_TILES) == 0) {
           const DomainPlan &fp = bp.dom[ASV_DOMAIN_FRAMES];
           std::vector<int> per_half((size_t)fp.rows_pad / 128 + 1, 0);
           int worst = 1;
@@ -1108,13 +1117,12 @@ int run_ops(RunCtx &c, size_t n_ops) {
           pool_slots = worst;
           if (pool_slots > 16) pool_slots = 0;               // many tiny utterances: use the separate pooling kernel
         }
-        const bool big3 = !use_ref && narrow && (net->flags & (ASV_FLAG_SMALL_TILES | ASV_FLAG_BIG_V2)) == 0 && tdnn_big3_supported(p, bf16, !bf16);
-        const bool big = !use_ref && narrow && !big3 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && tdnn_big_supported(p, bf16, !bf16);
+        const bool big3 = !use_ref && narrow && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && tdnn_big3_supported(p, bf16, !bf16);
         const bool utts_kernel = !use_ref && op.utts;
         const bool x3 = !use_ref && !op.utts && net->x3() && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && tdnn_x3_supported(p);
         const bool c1_conv = !use_ref && net->domains[domid].kind == 2 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && grid_conv_c1_supported(p, bf16, d.in_ch);
         const bool narrow_conv = !use_ref && net->domains[domid].kind == 2 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && grid_conv_narrow_supported(p, bf16);
-        if (!use_ref && !big && !big3 && op.utts && !utts_kernel) {
+        if (!use_ref && !big3 && op.utts && !utts_kernel) {
           // pooled-domain layers have one row per utterance (M is tiny, K is large): slice K over more
           // workgroups.  The slice count depends on K only, never on the batch, so an utterance's
           // embedding is bit-identical whatever batch it is extracted in.
@@ -1155,7 +1163,6 @@ int run_ops(RunCtx &c, size_t n_ops) {
         else if (c1_conv) rc = launch_grid_conv_c1(p, c.s);
         else if (x3) rc = launch_tdnn_x3(p, c.s);
         else if (big3) rc = launch_tdnn_big3(p, c.s);
-        else if (big) rc = launch_tdnn_big(p, c.s);
         else {
           rc = launch_tdnn_mfma(p, bf16, !bf16, c.s);
           if (!rc && p.ksplit > 1) rc = launch_splitk_epilogue(p, bf16, !bf16, c.s);
@@ -1235,6 +1242,10 @@ int run_ops(RunCtx &c, size_t n_ops) {
         p.act = d.act;
         if (d.seg_scale_buf >= 0) { p.seg_scale = reinterpret_cast<const float *>(net->arena[d.seg_scale_buf].ptr); p.ld_segscale = net->bufs[d.seg_scale_buf].ld; }
         if (d.seg_norm_buf >= 0) { p.seg_norm = reinterpret_cast<const float *>(net->arena[d.seg_norm_buf].ptr); p.ld_segnorm = net->bufs[d.seg_norm_buf].ld; p.seg_norm_mode = d.seg_norm_mode; }
+        if (d.out2_buf >= 0) {
+          p.d = view(c, d.d_buf, d.d_ch_off); p.ldd = net->bufs[d.d_buf].ld;
+          p.out2 = view(c, d.out2_buf, d.out2_ch_off); p.ldo2 = net->bufs[d.out2_buf].ld;
+        }
         if (op.utts) { p.rows = bp.segments; }
         else { p.rows = c.dom[domid].rows_pad; p.row_seg = c.dom[domid].row_seg; p.row_valid = c.dom[domid].row_valid; }
         if ((rc = prof.begin(K_ELT, 0, (int)i))) return rc;

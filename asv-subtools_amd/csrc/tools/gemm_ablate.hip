@@ -88,7 +88,7 @@ int main(int argc, char **argv) {
     for (int rep = 0; rep < 2; ++rep) {
       CK(hipEventRecord(a, 0));
       for (int i = 0; i < iters; ++i) {
-        int rc = v == 6 ? launch_tdnn_mfma(p, true, false, 0) : v == 9 ? launch_tdnn_big3_variant(p, 0, 0) : v == 10 ? launch_tdnn_big3_variant(p, 2, 0) : v == 11 ? launch_tdnn_big3_variant(p, 4, 0) : v == 12 ? launch_tdnn_big3_variant(p, 100, 0) : v == 13 ? launch_tdnn_big3_variant(p, 102, 0) : v == 14 ? launch_tdnn_big3_variant(p, 200, 0) : v == 15 ? launch_tdnn_big3_variant(p, 202, 0) : launch_tdnn_big_variant(p, v, 0);
+        int rc = v == 6 ? launch_tdnn_mfma(p, true, false, 0) : v == 9 ? launch_tdnn_big3_variant(p, 0, 0) : v == 10 ? launch_tdnn_big3_variant(p, 2, 0) : v == 11 ? launch_tdnn_big3_variant(p, 4, 0) : v == 12 ? launch_tdnn_big3_variant(p, 100, 0) : v == 13 ? launch_tdnn_big3_variant(p, 102, 0) : v == 14 ? launch_tdnn_big3_variant(p, 200, 0) : v == 15 ? launch_tdnn_big3_variant(p, 202, 0) : ASV_EINVAL;   // (variants 0-5, 7, 8 belonged to the removed 256x256 both-operands-through-LDS kernel)
         if (rc) { printf("launch failed: %s\n", asv_last_error()); return 1; }
       }
       CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));

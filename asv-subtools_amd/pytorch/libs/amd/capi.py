@@ -100,6 +100,7 @@ class EltwiseDesc(C.Structure):
         ("scale", c_float_p), ("shift", c_float_p),
         ("act", C.c_int32),
         ("seg_norm_buf", C.c_int32), ("seg_norm_mode", C.c_int32),
+        ("d_buf", C.c_int32), ("d_ch_off", C.c_int32), ("out2_buf", C.c_int32), ("out2_ch_off", C.c_int32),
     ]
 
 

@@ -79,8 +79,10 @@ class Engine(object):
         # bf16 engines run every Res2NetBlock as one kernel (kernels_res2.hip); the parity modes keep one layer per branch
         fuse = self.precision in ("bf16", "bfloat16") and (self.flags & (capi.FLAG_REF_KERNELS | capi.FLAG_NO_FUSE | capi.FLAG_SMALL_TILES)) == 0
         ops = g.fused_res2_ops() if fuse else g.ops
+        if (self.flags & (capi.FLAG_REF_KERNELS | capi.FLAG_NO_FUSE)) == 0:
+            ops = g.fused_add_ops(ops)               # exact in every precision mode (see its docstring)
         self.ops = ops                               # the program as uploaded (op indices of the profiling rows refer to it)
-        written = sorted({op.out.tid for op in ops})
+        written = sorted({op.out.tid for op in ops} | {op.out2.tid for op in ops if getattr(op, "out2", None) is not None})
         for tid in written:
             dom, ch = g.tensors[tid]
             buf_of[tid] = capi.check(L.asv_net_new_buffer(self._net, dom_of[dom], ch), "asv_net_new_buffer")
@@ -172,6 +174,8 @@ class Engine(object):
                 d.act = capi.ACT_BY_NAME[getattr(op, "act", None)]
                 d.seg_norm_buf = bv(getattr(op, "seg_norm", None))[0]
                 d.seg_norm_mode = int(getattr(op, "seg_norm_mode", 0))
+                d.d_buf, d.d_ch_off = bv(getattr(op, "d", None))
+                d.out2_buf, d.out2_ch_off = bv(getattr(op, "out2", None))
                 capi.check(L.asv_net_add_eltwise(self._net, C.byref(d)), "asv_net_add_eltwise")
             elif op.kind == "grid_input":
                 d = capi.GridInputDesc()

@@ -65,7 +65,7 @@ class Op(object):
         elif self.kind == "lde":
             names = ("x",)
         elif self.kind == "eltwise":
-            names = ("a", "b", "c", "seg_scale", "seg_norm")
+            names = ("a", "b", "c", "seg_scale", "seg_norm", "d")
         elif self.kind in ("grid_input", "im2col", "res2"):
             names = ("inp",)
         else:
@@ -74,7 +74,7 @@ class Op(object):
 
     def input_names(self):
         return {"tdnn": ("inp", "inp2", "seg_bias", "seg_scale", "res"), "pool": ("inp",),
-                "attpool": ("x", "logits"), "lde": ("x",), "eltwise": ("a", "b", "c", "seg_scale", "seg_norm"), "cat": (), "grid_input": ("inp",),
+                "attpool": ("x", "logits"), "lde": ("x",), "eltwise": ("a", "b", "c", "seg_scale", "seg_norm", "d"), "cat": (), "grid_input": ("inp",),
                 "im2col": ("inp",), "res2": ("inp",)}[self.kind]
 
 
@@ -383,6 +383,35 @@ class Graph(object):
             else:
                 out.append(first)
                 i += 1
+        return out
+
+    def fused_add_ops(self, ops=None):
+        """The op list with every plain addition `q = p.out + w` that directly follows its producer `p` (an eltwise op)
+        folded into `p` as a second output (`out2`, addend `d`): ECAPA's running sum of block outputs
+        (ecapa_tdnn_xvector.py:262-268: out_k = SE_Res2Block(...); next input = previous input + out_k) then costs two
+        reads and two writes per block instead of three + three.  The second output adds to the value as STORED (rounded
+        to the buffer's element type), so every bit of both tensors is what the two separate passes produce."""
+        ops = list(self.ops if ops is None else ops)
+        out = []
+        position = {}
+        for idx, op in enumerate(ops):
+            position.setdefault(op.out.tid, idx)
+        skip = set()
+        for idx, op in enumerate(ops):
+            if idx in skip:
+                continue
+            nxt = ops[idx + 1] if idx + 1 < len(ops) else None
+            if (op.kind == "eltwise" and getattr(op, "out2", None) is None and nxt is not None and self._is_plain_add(nxt)
+                    and self.domain(op.out.tid) == self.domain(nxt.out.tid)):
+                other = nxt.b if nxt.a == op.out else (nxt.a if nxt.b == op.out else None)
+                ready = other is not None and other.tid != op.out.tid and (other.tid == 0 or position.get(other.tid, len(ops)) < idx)
+                if ready and other.channels == op.out.channels and nxt.out.tid != op.out.tid:
+                    fused = Op("eltwise", op.out, **{k: v for k, v in op.__dict__.items() if k not in ("kind", "out")})
+                    fused.d, fused.out2 = other, nxt.out
+                    out.append(fused)
+                    skip.add(idx + 1)
+                    continue
+            out.append(op)
         return out
 
     def describe(self):

@@ -60,7 +60,7 @@ int         asv_device_count(int *count);
 #define ASV_FLAG_REF_KERNELS 1u  /* run the plain-VALU self-check kernels instead of MFMA ones */
 #define ASV_FLAG_NO_FUSE     2u  /* disable epilogue fusions (stats pooling into the producer)  */
 #define ASV_FLAG_SMALL_TILES 4u  /* never pick the 256x256 kernels (A/B testing)                    */
-#define ASV_FLAG_BIG_V2      8u  /* 256x256 kernel variant 2 (both operands through LDS) instead of 3 */
+#define ASV_FLAG_BIG_V2      8u  /* reserved, ignored: the 256x256 both-operands-through-LDS kernel it selected was removed in round 2 */
 #define ASV_FLAG_NO_CHAIN   16u  /* one launch per layer: do not run tdnn -> 1-tap tdnn -> ... -> pooling chains in one kernel */
 
 #define ASV_ACT_NONE    0
@@ -194,6 +194,9 @@ typedef struct asv_eltwise_desc {
                                     (a - mean) / std per segment first - InputSequenceNormalization,
                                     components.py:780-842; seg_norm_mode bit 0 = subtract mean, bit 1 = divide by std */
   int32_t seg_norm_mode;
+  int32_t d_buf, d_ch_off;       /* optional SECOND output: out2 = out (as stored, i.e. rounded to the buffer's element  */
+  int32_t out2_buf, out2_ch_off; /* type) + d - a following plain addition folded into this pass (ECAPA's running sum of
+                                    block outputs, ecapa_tdnn_xvector.py:262-268); -1 / -1 = absent                        */
 } asv_eltwise_desc_t;
 int asv_net_add_eltwise(asv_net_t *net, const asv_eltwise_desc_t *d);
 
