@@ -141,6 +141,7 @@ struct Res2KernelParams {
   const float *bias, *scale, *shift;                 // [branches][128]
   const uint32_t *row_valid;
   int branches, dilation;
+  unsigned long long *dbg;      // developer aid (ASV_AMD_RES2_DBG=1): [workgroup][wave][16] s_memtime stamps, or nullptr
 };
 int launch_res2_chain(const Res2KernelParams &p, hipStream_t s);
 void pack_tdnn_weight_frags(const float *w, int out_ch, int in_ch, int tot_ctx, int left_ctx, const int *taps, int n_taps,

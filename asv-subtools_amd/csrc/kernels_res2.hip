@@ -16,6 +16,14 @@
 //   * 8 waves = 4 channel fragments x 2 row halves, each 96 rows x 32 channels (3 accumulators), K = 3 taps x 128 as
 //     24 k-groups: weight fragments from L2 (fragment order of pack_tdnn_weight_frags), 3 ds_read_b128 per 3 MFMAs;
 //   * two barriers per branch.  One workgroup (512 threads, 147 KiB LDS) per CU.
+//   * ALL 24 weight fragments of a branch live in registers (96 VGPRs), fetched during the previous branch's epilogue and
+//     issued BEFORE that epilogue's window DMA: the vector-memory counter retires in order, so a K loop that fetches its
+//     fragments a few k-groups ahead (the first version) waits at its first s_waitcnt for the 48 KiB window of the next group
+//     that was issued just before it - measured (ASV_AMD_RES2_DBG, r2f): 20 k cycles per K loop for 4.6 k of MFMA issue.
+//     Now the K loop has no vector-memory operation at all and the window really lands behind it.  The fragment loads are
+//     inline asm with counted s_waitcnt (hipcc's own waits would count only the loads it knows of and so, in hardware terms,
+//     wait for the younger DMA pieces as well); for the same reason the per-channel constants of all branches are staged in
+//     LDS once (a global load inside the loop is the youngest vector-memory operation: consuming it drains the DMA).
 #include "device_utils.h"
 
 namespace asv {
@@ -29,8 +37,10 @@ constexpr int RPAD = 4;                   // zero rows around A (taps of the out
 constexpr int RROWB = RW * 2;             // 256 B per row
 constexpr int A_BYTES = (RWIN + 2 * RPAD) * RROWB;   // 51200
 constexpr int B_OFF = A_BYTES, X_OFF = B_OFF + RWIN * RROWB;
-constexpr int RES2_LDS = X_OFF + RWIN * RROWB;        // 149504
+constexpr int PAR_OFF = X_OFF + RWIN * RROWB;         // 149504: bias | scale | shift of all (<= 7) branches, f32 [branch][3][128]
+constexpr int RES2_LDS = PAR_OFF + 7 * 3 * RW * 4;    // 160256
 static_assert(RES2_LDS <= 163840, "160 KiB of LDS per CU");
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 static_assert(7 * kHalo <= RMARGIN && kHalo <= RPAD, "margin must cover seven branches of the largest dilation");
 
 typedef __attribute__((address_space(3))) unsigned char res2_lds_byte;
@@ -74,6 +84,36 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(const Res2KernelPara
     }
   };
 
+  int n_stamp = 0;
+  auto stamp = [&]() {
+    if (p.dbg != nullptr && lane == 0 && n_stamp < 14) p.dbg[((size_t)blockIdx.x * 8 + wave) * 16 + n_stamp] = __builtin_amdgcn_s_memtime();
+    ++n_stamp;
+  };
+  stamp();                                                    // 0
+  if (p.dbg != nullptr && lane == 0) p.dbg[((size_t)blockIdx.x * 8 + wave) * 16 + 14] = __builtin_amdgcn_s_memrealtime();
+  // weight fragments of one branch: [tap][chunk][k-group] = 24 blocks of 1 KiB per 32-channel fragment
+  u32x4_t wf[24];
+  const uint32_t lane16 = (uint32_t)lane * 16u;
+  auto load_weights = [&](int b) {
+    const unsigned char *wb = reinterpret_cast<const unsigned char *>(p.wfrag) + (size_t)(b - 1) * (4 * 3 * 2 * 4 * 1024) + (size_t)nf * (3 * 2 * 4 * 1024);
+#pragma unroll
+    for (int k = 0; k < 24; ++k)
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(wf[k]) : "v"(lane16), "s"(wb + (size_t)k * 1024) : "memory");
+  };
+  // after a counted s_waitcnt: pins every later use of the fragments behind it (volatile asm statements keep their order)
+  auto fragments_ready = [&]() {
+#pragma unroll
+    for (int k = 0; k < 24; ++k) asm volatile("" : "+v"(wf[k]));
+  };
+  load_weights(1);
+  {
+    float *par = reinterpret_cast<float *>(lds + PAR_OFF);
+    for (int i = tid; i < p.branches * 3 * (RW / 4); i += 512) {
+      const int br = i / (3 * (RW / 4)), which = (i / (RW / 4)) % 3, c4 = (i % (RW / 4)) * 4;
+      const float *src = (which == 0 ? p.bias : (which == 1 ? p.scale : p.shift)) + br * RW + c4;
+      *reinterpret_cast<float4 *>(par + (br * 3 + which) * RW + c4) = *reinterpret_cast<const float4 *>(src);
+    }
+  }
   issue_window(1, 0, RPAD);                                   // A = x_1
   if (p.branches > 1) issue_window(2, X_OFF, 0);              // X = x_2
   if (tid < 2 * RPAD * 16) {                                  // the zero rows of A
@@ -97,12 +137,11 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(const Res2KernelPara
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
-  const uint32_t lane16 = (uint32_t)lane * 16u;
+  stamp();                                                    // 1: first windows in
+  bool dma_behind = false;                                    // a window DMA was issued after this branch's weight fetch
 #pragma unroll 1
   for (int b = 1; b <= p.branches; ++b) {
-    const unsigned char *wb = reinterpret_cast<const unsigned char *>(p.wfrag) + (size_t)(b - 1) * (4 * 3 * 2 * 4 * 1024) + (size_t)nf * (3 * 2 * 4 * 1024);
-    const float *bias = p.bias + (b - 1) * RW + nf * 32 + 4 * lh, *scale = p.scale + (b - 1) * RW + nf * 32 + 4 * lh,
-                *shift = p.shift + (b - 1) * RW + nf * 32 + 4 * lh;
+    const float *bias = reinterpret_cast<const float *>(lds + PAR_OFF) + (b - 1) * 3 * RW + nf * 32 + 4 * lh, *scale = bias + RW, *shift = bias + 2 * RW;
     // accumulators start from the bias: acc[rf][4 q + e] = channel nf*32 + 8 q + 4 lh + e of row rh*96 + rf*32 + lr
     f32x16_t acc[3];
 #pragma unroll
@@ -111,10 +150,13 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(const Res2KernelPara
 #pragma unroll
       for (int rf = 0; rf < 3; ++rf) { acc[rf][q * 4 + 0] = b4.x; acc[rf][q * 4 + 1] = b4.y; acc[rf][q * 4 + 2] = b4.z; acc[rf][q * 4 + 3] = b4.w; }
     }
-    // K loop: k-group g = (tap t, 64-channel chunk c, 16-channel group kg); fragments fetched 4 k-groups ahead, rows 1 ahead
-    uint4 wf[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) wf[k] = *reinterpret_cast<const uint4 *>(wb + (size_t)k * 1024 + lane16);
+    // the fragments are older than everything issued behind them (a branch > 1: this wave's 6 window pieces if a window was
+    // fetched, then its 4 row stores): wait for exactly those to remain.  Branch 1: the start-up wait below covered them.
+    if (b > 1) {
+      if (dma_behind) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
+    fragments_ready();
     auto x_addr = [&](int t) -> uint32_t {                     // fragment 0 of tap t, slot lh (k-group bits enter by XOR)
       const int row = RPAD + rh * 96 + lr + (t - 1) * d;
       return (uint32_t)(row * RROWB + ((lh ^ (row & 15)) << 4));
@@ -123,32 +165,37 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(const Res2KernelPara
     uint32_t xa = x_addr(0);
 #pragma unroll
     for (int rf = 0; rf < 3; ++rf) xc[rf] = *reinterpret_cast<const uint4 *>(lds + xa + rf * 32 * RROWB);
-#pragma unroll 1
-    for (int tc = 0; tc < 6; ++tc) {                            // (tap, chunk): 4 k-groups each
+    // K loop: k-group g = (tap t, 64-channel chunk c, 16-channel group kg), fully unrolled (24 x 3 MFMAs); rows one k-group ahead
+#pragma unroll
+    for (int tc = 0; tc < 6; ++tc) {
       const int t = tc >> 1, c = tc & 1;
       const uint32_t xa_next = x_addr(tc + 1 < 6 ? (tc + 1) >> 1 : t);
       const int c_next = (tc + 1) & 1;
 #pragma unroll
       for (int kg = 0; kg < 4; ++kg) {
-        // rows of the next k-group
         const bool wrap = kg == 3;
         const uint32_t a = (wrap ? xa_next : xa) ^ (uint32_t)((((wrap ? c_next : c) * 8 + ((kg + 1) & 3) * 2)) << 4);
+        if (!(tc == 5 && kg == 3)) {
 #pragma unroll
-        for (int rf = 0; rf < 3; ++rf) xn[rf] = *reinterpret_cast<const uint4 *>(lds + a + rf * 32 * RROWB);
+          for (int rf = 0; rf < 3; ++rf) xn[rf] = *reinterpret_cast<const uint4 *>(lds + a + rf * 32 * RROWB);
+        }
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf)
-          acc[rf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[kg]), __builtin_bit_cast(bf16x8_t, xc[rf]), acc[rf], 0, 0, 0);
-        // this fragment register is free: fetch the k-group 4 ahead (the last (tap, chunk) re-reads its own)
-        const int tcn = tc + 1 < 6 ? tc + 1 : tc;
-        wf[kg] = *reinterpret_cast<const uint4 *>(wb + (size_t)(tcn * 4 + kg) * 1024 + lane16);
+          acc[rf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[tc * 4 + kg]), __builtin_bit_cast(bf16x8_t, xc[rf]), acc[rf], 0, 0, 0);
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf) xc[rf] = xn[rf];
       }
       xa = xa_next;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's pieces of X (issued a branch ago) have landed
+    // the fragment registers are free: fetch the next branch's (they fly during the epilogue; issued BEFORE the window DMA below)
+    if (b < p.branches) load_weights(b + 1);
+    if (b <= 3) stamp();                                        // 2, 6, 10: K loop done
+    // this wave's pieces of X (issued a branch ago) have landed: everything older than the 24 fragment loads just issued
+    if (b < p.branches) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                               // nobody reads A any more; X is complete
     asm volatile("" ::: "memory");
+    if (b <= 3) stamp();                                        // 3, 7, 11: wait + barrier
 
     // epilogue: y = BN(ReLU(acc)) (zeros in gap rows) -> B; y + x_{b+1} -> A for the next branch
     const bool more = b < p.branches;
@@ -178,9 +225,12 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(const Res2KernelPara
         }
       }
     }
+    if (b <= 3) stamp();                                        // 4, 8, 12: epilogue
     __builtin_amdgcn_s_barrier();                               // B and A complete; X consumed
     asm volatile("" ::: "memory");
-    if (b + 2 <= p.branches) issue_window(b + 2, X_OFF, 0);     // lands during the next branch's K loop
+    if (b <= 3) stamp();                                        // 5, 9, 13: barrier
+    dma_behind = b + 2 <= p.branches;
+    if (dma_behind) issue_window(b + 2, X_OFF, 0);              // lands during the next branch's K loop
     // y_b: the 128 central rows of B -> HBM, 256-byte rows
 #pragma unroll
     for (int it = 0; it < RM * 16 / 512; ++it) {
@@ -188,6 +238,10 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(const Res2KernelPara
       const uint4 v = *reinterpret_cast<const uint4 *>(lds + B_OFF + rw * RROWB + ((slot ^ (rw & 15)) << 4));
       *reinterpret_cast<uint4 *>(og + (size_t)(m0 + (idx >> 4)) * y_pitch + (size_t)b * RROWB + slot * 16) = v;
     }
+  }
+  if (p.dbg != nullptr && lane == 0) {
+    p.dbg[((size_t)blockIdx.x * 8 + wave) * 16 + 13] = __builtin_amdgcn_s_memtime();            // end (overwrites stamp 13)
+    p.dbg[((size_t)blockIdx.x * 8 + wave) * 16 + 15] = __builtin_amdgcn_s_memrealtime();
   }
 }
 

@@ -214,20 +214,13 @@ __global__ __launch_bounds__(Geom3<WM>::WAVES * 64, WM == 0 ? 3 : 2) void tdnn_g
   };
   // ---- prologue: three windows in flight, weight fragments of step 0.  Only window 0 and the fragments are
   // waited for: VMEM retires in order, so vmcnt(2 * PIECES) leaves exactly windows 1 and 2 outstanding.
-  // 1-tap layers (a chunk is only 4 k-groups = 32 MFMAs per wave) meet at the workgroup barrier every SECOND chunk: all four
-  // stages are in flight from the start, windows c and c+1 are read between two barriers, and the barrier that ends chunk c
-  // (c odd) refills their stages with windows c+3 and c+4 (r2: the per-chunk barrier held the 1024 -> 1024 layers of ECAPA
-  // at 0.37 of the bf16 peak against 0.46 for the 3-tap layers).
-  const bool pair = (p.tune & 0x10000) == 0 && n_taps == 1 && nchunks >= 4 && ABL != 1;
+  // Tried and dropped (r2e, in-process A/B on ECAPA): 1-tap layers meeting at the workgroup barrier every SECOND chunk (all four
+  // stages in flight, two windows read between barriers): 3556 vs 3532 us per step - the per-chunk barrier is not what holds
+  // the 1024 -> 1024 layers at 0.37 of the bf16 peak.
   issue_A(0, 0);
 #pragma unroll
   for (int kg = 0; kg < 4; ++kg) load_wf(kg, 0, 0);
-  if (pair) {
-    issue_A(1, 1);
-    issue_A(2, 2);
-    issue_A(3, 3);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::PIECES) : "memory");      // windows 0 and 1 (and the fragments) are in
-  } else if (nchunks > 2) {
+  if (nchunks > 2) {
     issue_A(1, 1);
     issue_A(2, 2);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::PIECES) : "memory");
@@ -299,18 +292,10 @@ __global__ __launch_bounds__(Geom3<WM>::WAVES * 64, WM == 0 ? 3 : 2) void tdnn_g
       const unsigned char *An = Ab;
       int dn = __builtin_amdgcn_readlane(v_taps, last_tap ? t : t + 1);
       if (last_tap && c + 1 < nchunks) {
-        if (!pair) {
-          asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-          __builtin_amdgcn_s_barrier();
-          asm volatile("" ::: "memory");
-          if (!NO_DMA && c + 3 < nchunks) issue_A(c + 3, (c + 3) % N_STAGES);
-        } else if (c & 1) {
-          asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-          __builtin_amdgcn_s_barrier();
-          asm volatile("" ::: "memory");
-          if (!NO_DMA && c + 3 < nchunks) issue_A(c + 3, (c + 3) % N_STAGES);
-          if (!NO_DMA && c + 4 < nchunks) issue_A(c + 4, (c + 4) % N_STAGES);
-        }
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (!NO_DMA && c + 3 < nchunks) issue_A(c + 3, (c + 3) % N_STAGES);
         An = lds + ((c + 1) % N_STAGES) * A_STAGE;
         dn = d_first;
       }

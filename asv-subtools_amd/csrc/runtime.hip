@@ -1263,8 +1263,33 @@ int run_ops(RunCtx &c, size_t n_ops) {
         p.rows = dr.rows_pad; p.wfrag = op.wfrag; p.bias = op.bias; p.scale = op.scale; p.shift = op.shift; p.row_valid = dr.row_valid;
         p.branches = d.branches; p.dilation = d.dilation;
         if ((rc = prof.begin(K_TDNN, 2.0 * (double)bp.frames * kRes2Width * kRes2Width * 3 * d.branches, (int)i))) return rc;
+        static const bool res2_dbg = getenv("ASV_AMD_RES2_DBG") != nullptr;          // developer aid: phase durations to stderr
+        DevMem dbg;
+        if (res2_dbg) {
+          if ((rc = ensure(dbg, (size_t)(p.rows / 128) * 8 * 16 * 8, c.s, true))) return rc;
+          p.dbg = reinterpret_cast<unsigned long long *>(dbg.ptr);
+        }
         if ((rc = launch_res2_chain(p, c.s))) return rc;
         if ((rc = prof.end())) return rc;
+        if (res2_dbg) {
+          const size_t nwg = (size_t)(p.rows / 128);
+          std::vector<unsigned long long> h(nwg * 8 * 16);
+          ASV_HIP_CHECK(hipStreamSynchronize(c.s));
+          ASV_HIP_CHECK(hipMemcpy(h.data(), dbg.ptr, h.size() * 8, hipMemcpyDeviceToHost));
+          ASV_HIP_CHECK(hipFree(dbg.ptr));
+          double sum[16] = {0}; size_t cnt = 0; double cyc = 0, rt = 0;
+          for (size_t w = 0; w < nwg * 8; ++w) {
+            const unsigned long long *t = &h[w * 16];
+            if (t[0] == 0) continue;
+            for (int k = 1; k < 14; ++k) if (t[k] > t[k - 1]) sum[k] += (double)(t[k] - t[k - 1]);
+            if (t[13] > t[0] && t[15] > t[14]) { cyc += (double)(t[13] - t[0]); rt += (double)(t[15] - t[14]); }
+            ++cnt;
+          }
+          fprintf(stderr, "[res2 dbg] %zu waves [shader clock %.0f MHz, %.1f us per workgroup] 1 = first windows; per branch (1..3): K loop, wait + barrier, epilogue, "
+                  "barrier; 13 = branches 4.. + end:", cnt, rt > 0 ? 100.0 * cyc / rt : 0.0, cnt ? rt / 100.0 / (double)cnt : 0.0);
+          for (int k = 1; k < 14; ++k) fprintf(stderr, " %d:%.0f", k, sum[k] / (double)std::max<size_t>(cnt, 1));
+          fprintf(stderr, "\n");
+        }
         break;
       }
       case OP_GRID_INPUT: {

@@ -85,31 +85,43 @@ def extract_wavs(model, items, w, feat_conf, max_chunk, batch_seconds=1200.0, ba
     dev = torch.device("cuda", engine.device_index)
     batches = queue.Queue(maxsize=2)
 
+    free_bufs = queue.Queue()                    # two pinned staging buffers rotate between the producer and the consumer
+    for _ in range(2):
+        free_bufs.put(None)
+
     def produce():
+        """Every file is read and decoded ONCE: decoded utterances that do not fit the audio budget of the batch being built
+        stay in `pending` for the next one (the first version re-read the tail of every 512-file group 3-4 times)."""
         try:
             with ThreadPoolExecutor(max_workers=max(1, num_readers)) as pool:
-                pos = 0
-                while pos < len(items):
-                    group = items[pos:pos + batch_utts]
-                    waves = list(pool.map(lambda it: read_wav_pcm16(it[1]), group))
-                    # cut the group at the audio budget (at least one utterance)
+                pending, pos = [], 0              # [(key, samples, rate)]
+                while pos < len(items) or pending:
+                    # decode ahead until the pending audio certainly fills one batch (or the list ends)
+                    while pos < len(items) and (len(pending) < batch_utts and sum(len(wv) / float(sr) for _, wv, sr in pending) <= batch_seconds):
+                        group = items[pos:pos + max(8, num_readers * 4)]
+                        for (key, _), (wav, sr) in zip(group, pool.map(lambda it: read_wav_pcm16(it[1]), group)):
+                            pending.append((key, wav, sr))
+                        pos += len(group)
+                    # cut at the audio budget / utterance cap (at least one utterance)
                     total, n = 0.0, 0
-                    for wav, sr in waves:
+                    for _, wav, sr in pending[:batch_utts]:
                         if n > 0 and total + len(wav) / float(sr) > batch_seconds:
                             break
                         total += len(wav) / float(sr)
                         n += 1
-                    rates = {sr for _, sr in waves[:n]}
+                    take, pending = pending[:n], pending[n:]
+                    rates = {sr for _, _, sr in take}
                     if len(rates) != 1:
                         raise ValueError("mixed sample rates in one batch: %s" % sorted(rates))
                     off = np.zeros(n + 1, dtype=np.int64)
-                    np.cumsum([len(wav) for wav, _ in waves[:n]], out=off[1:])
-                    host = torch.empty(int(off[-1]), dtype=torch.int16).pin_memory()
+                    np.cumsum([len(wav) for _, wav, _ in take], out=off[1:])
+                    host = free_bufs.get()        # blocks until the consumer has uploaded the batch that used it
+                    if host is None or host.numel() < int(off[-1]):
+                        host = torch.empty(max(int(off[-1]), int(batch_seconds * 16000)), dtype=torch.int16).pin_memory()
                     hv = host.numpy()
-                    for (wav, _), a, b in zip(waves[:n], off[:-1], off[1:]):
+                    for (_, wav, _), a, b in zip(take, off[:-1], off[1:]):
                         hv[a:b] = wav
-                    batches.put(([k for k, _ in group[:n]], host, off, rates.pop()))
-                    pos += n
+                    batches.put(([k for k, _, _ in take], host, off, rates.pop()))
             batches.put(None)
         except BaseException as e:
             batches.put(e)
@@ -126,7 +138,9 @@ def extract_wavs(model, items, w, feat_conf, max_chunk, batch_seconds=1200.0, ba
             if isinstance(item, BaseException):
                 raise item
             keys, host, off, sr = item
-            wave_dev = host.to(dev, non_blocking=True)
+            wave_dev = host[:int(off[-1])].to(dev, non_blocking=True)
+            torch.cuda.current_stream(dev).synchronize()             # the upload has read the pinned buffer: hand it back
+            free_bufs.put(host)
             e0.record()
             feats, frame_off = frontend.fbank_device(wave_dev, off, kind=kind, mean_norm=mean_norm, std_norm=std_norm,
                                                      **dict(featset, sample_frequency=float(sr)))    # processor.py:428
