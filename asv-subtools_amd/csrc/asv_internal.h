@@ -110,6 +110,8 @@ int launch_utts_gemm(const TdnnKernelParams &p, int rows_valid, bool split, hipS
 bool grid_conv_narrow_supported(const TdnnKernelParams &p, bool bf16);
 size_t grid_conv_frag_elems(int cin_pad, int cout_pad32);
 int launch_grid_conv_narrow(const TdnnKernelParams &p, hipStream_t s);
+bool grid_conv_wide_supported(const TdnnKernelParams &p, bool bf16);      // the C = 128 / 256 stages (same fragment order)
+int launch_grid_conv_wide(const TdnnKernelParams &p, hipStream_t s);
 bool grid_conv_c1_supported(const TdnnKernelParams &p, bool bf16, int in_ch);
 int launch_grid_conv_c1(const TdnnKernelParams &p, hipStream_t s);
 int launch_splitk_epilogue(const TdnnKernelParams &p, bool bf16, bool out_f32, hipStream_t s);

@@ -170,6 +170,145 @@ __global__ __launch_bounds__(256, CIN == 32 ? 3 : 2) void grid_conv_narrow_kerne
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The C = 128 / 256 stages (17 of the trunk's 32 convolutions, 2.0 of the 7.5 ms of a ResNet34-SE step on the generic
+// 128 x 128 register-staged tile at ~600 TFLOP/s).  Same idea as above - the whole K extent of a tile is ONE LDS window, no
+// K-chunk ring, no barrier after the first - with the wave tiling of the wide frame-layer kernel (kernels_tdnn_v3.hip):
+//   wave = 128 rows x 64 channels (4 x 2 accumulators): one 1 KiB weight fragment from L2 feeds 4 MFMAs, one ds_read_b128
+//   feeds 2 - half the LDS-read and L2 traffic per MFMA of 64-row waves;
+//   C = 128: workgroup = 256 rows x 128 channels (2 x 2 waves), window (256 + 2 x 24) rows x 256 B = 76 KiB;
+//   C = 256: workgroup = 128 rows x 256 channels (1 x 4 waves), window (128 + 2 x 16) rows x 512 B = 80 KiB;
+//   two workgroups per CU either way.  The halo (>= pitch + 1 of the stage's grid: 21-bin grids at C = 128, 11-bin grids at
+//   C = 256 for the 82 frequency bins the trunk accepts at most) bounds the layers this kernel takes; others stay on the
+//   generic tile.
+//   K walks 64-channel chunks x taps in steps of 4 k-groups; the fragments of a step's k-group are re-fetched for the next step as soon
+//   as their MFMAs have issued (8 fragments = 32 VGPRs in flight), rows are read one k-group ahead.  Same (tap, k-group)
+//   accumulation order as the generic tile: bit-identical outputs (tests/test_gpu_resnet.py).
+//   16-byte slot s of window row w sits at s ^ (w & 15): conflict-free ds_read_b128 for any tap shift.
+template <int CIN> struct WideGeom {
+  static constexpr int HALO = CIN == 128 ? 24 : 16;
+  static constexpr int BM = CIN == 128 ? 256 : 128;
+  static constexpr int WMS = BM / 128, WNS = 4 / WMS;             // waves along rows / along channels
+  static constexpr int WIN = BM + 2 * HALO;                        // 304 | 160 rows
+  static constexpr int ROWB = CIN * 2;                             // 256 | 512 bytes
+  static constexpr int SLOTS = ROWB / 16;                          // 16 | 32
+  static constexpr int RPP = 1024 / ROWB;                          // window rows per 1 KiB DMA piece: 4 | 2
+  static constexpr int PIECES = WIN / RPP;                         // 76 | 80
+  static constexpr int KG = CIN / 16;                              // k-groups per tap: 8 | 16
+  static constexpr int NFR = CIN / 32;                             // 32-channel output fragments of the layer: 4 | 8
+  static constexpr int STEPS = 9 * KG / 4;                         // 18 | 36 steps of 4 k-groups
+  static_assert(WNS * 64 == CIN && WIN % RPP == 0 && WIN * ROWB <= 81920, "wide grid conv geometry");
+};
+
+template <int CIN, bool GENERIC>
+__global__ __launch_bounds__(256, 2) void grid_conv_wide_kernel(const TdnnKernelParams p) {
+  using G = WideGeom<CIN>;
+  __shared__ __attribute__((aligned(16))) unsigned char win[G::WIN * G::ROWB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / G::WNS, wn = wave % G::WNS;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int m0 = xcd_swizzle(blockIdx.x, gridDim.x) * G::BM;
+
+  // ---- window: one LDS-DMA instruction per 1 KiB piece, rows clamped onto the matrix (its first / last rows are gaps)
+  const unsigned char *xg = reinterpret_cast<const unsigned char *>(p.x);
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_byte_t *)win);
+  for (int piece = wave; piece < G::PIECES; piece += 4) {
+    const int w = piece * G::RPP + lane / G::SLOTS;
+    const int row = min(max(m0 - G::HALO + w, 0), p.rows - 1);
+    const int src_slot = (lane % G::SLOTS) ^ (w & 15);
+    conv_glds16(xg + (size_t)row * ((size_t)p.ldx * 2) + src_slot * 16, __builtin_amdgcn_readfirstlane(lds_base + piece * 1024));
+  }
+  const int v_taps = p.taps[lane < 9 ? lane : 0];
+  // weights: [tap][k-group][n-fragment][lane][8]; this wave's two fragments are n-fragments wn * 2 and wn * 2 + 1
+  const unsigned char *wbase = reinterpret_cast<const unsigned char *>(p.wfrag) + (size_t)(wn * 2) * 1024 + (size_t)lane * 16;
+  auto frag_ptr = [&](int t, int kg, int j) { return wbase + ((size_t)(t * G::KG + kg) * G::NFR + j) * 1024; };
+
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  struct XF { uint4 x[4]; };
+  auto read_x1 = [&](int d, int kg_abs, int i, XF &f) {           // kg_abs: k-group within the tap (0 .. KG-1)
+    const int w = G::HALO + wm * 128 + i * 32 + lr + d;
+    f.x[i] = *reinterpret_cast<const uint4 *>(win + w * G::ROWB + (((kg_abs * 2 + lh) ^ (w & 15)) << 4));
+  };
+  uint4 wf[4][2];
+#pragma unroll
+  for (int kg = 0; kg < 4; ++kg) {
+    wf[kg][0] = *reinterpret_cast<const uint4 *>(frag_ptr(0, kg, 0));
+    wf[kg][1] = *reinterpret_cast<const uint4 *>(frag_ptr(0, kg, 1));
+  }
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");              // the window pieces are older than the 8 fragment loads
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  XF x0, x1;
+  {
+    const int d0 = __builtin_amdgcn_readlane(v_taps, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) read_x1(d0, 0, i, x0);
+  }
+#pragma unroll 1
+  for (int st = 0; st < G::STEPS; ++st) {
+    // 64-channel chunk outermost, taps inside it: the K order of the generic tile (kernels_tdnn.hip), hence the same bits
+    const int c4 = st / 9, t = st % 9;
+    const int stn = st + 1 < G::STEPS ? st + 1 : st;               // the last step re-fetches its own fragments (never used)
+    const int c4n = stn / 9, tn = stn % 9;
+    const int d = __builtin_amdgcn_readlane(v_taps, t), dn = __builtin_amdgcn_readlane(v_taps, tn);
+    auto group = [&](const XF &xc, int kg, XF &xn, int d_next, int kg_abs_next) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        // pair q: channel fragment j = q / 2 against row fragments 2 (q % 2) and + 1; one row read of the next k-group in
+        // front of every pair, the fragment of the next step behind its last pair (the order of kernels_tdnn_v3.hip)
+        read_x1(d_next, kg_abs_next, q, xn);
+#pragma unroll
+        for (int i = (q % 2) * 2; i < (q % 2) * 2 + 2; ++i)
+          acc[i][q / 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[kg][q / 2]), __builtin_bit_cast(bf16x8_t, xc.x[i]), acc[i][q / 2], 0, 0, 0);
+        if (q == 1) wf[kg][0] = *reinterpret_cast<const uint4 *>(frag_ptr(tn, c4n * 4 + kg, 0));
+        if (q == 3) wf[kg][1] = *reinterpret_cast<const uint4 *>(frag_ptr(tn, c4n * 4 + kg, 1));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    group(x0, 0, x1, d, c4 * 4 + 1);
+    group(x1, 1, x0, d, c4 * 4 + 2);
+    group(x0, 2, x1, d, c4 * 4 + 3);
+    group(x1, 3, x0, dn, c4n * 4);
+  }
+
+  // ---- epilogue: acc[i][j][r] = row m0 + wm*128 + i*32 + lr, channel wn*64 + j*32 + 8*(r>>2) + 4*lh + (r&3): 8-byte stores
+  const float act_lo = (p.act1 == ASV_ACT_RELU) ? 0.0f : -INFINITY;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ch = wn * 64 + j * 32 + 8 * q + 4 * lh;
+      const float4 b4 = *reinterpret_cast<const float4 *>(p.bias + ch);
+      const float4 sc4 = p.scale ? *reinterpret_cast<const float4 *>(p.scale + ch) : make_float4(1.f, 1.f, 1.f, 1.f);
+      const float4 sh4 = p.shift ? *reinterpret_cast<const float4 *>(p.shift + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float b[4] = {b4.x, b4.y, b4.z, b4.w}, sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = m0 + wm * 128 + i * 32 + lr;
+        const bool valid = (p.row_valid[row >> 5] >> (row & 31)) & 1u;
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if constexpr (GENERIC) y[e] = tdnn_epilogue<true>(p, acc[i][j][q * 4 + e], row, ch + e, b[e], sc[e], sh[e], valid);
+          else y[e] = tdnn_epilogue_fast(acc[i][j][q * 4 + e], b[e], act_lo, sc[e], sh[e], valid);
+        }
+        uint2 pk;
+        pk.x = pack_bf16x2(y[0], y[1]);
+        pk.y = pack_bf16x2(y[2], y[3]);
+        *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(p.y) + (size_t)row * p.ldy + ch) = pk;
+      }
+    }
+}
+
 // The first convolution of the trunk: ONE input channel (the fbank map itself), 3x3, 32 output channels
 // (resnet.py:96-99).  9 multiply-adds per output - nothing for a matrix core: f32 fma in tap order (bit-identical to the
 // MFMA path, whose other 15 k-lanes are zeros).  A workgroup owns C1_SPAN consecutive rows: their inputs (the span plus
@@ -276,6 +415,33 @@ int launch_grid_conv_narrow(const TdnnKernelParams &p, hipStream_t s) {
   } else {
     if (fast) hipLaunchKernelGGL((grid_conv_narrow_kernel<64, 2, false>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((grid_conv_narrow_kernel<64, 2, true>), grid, block, 0, s, p);
+  }
+  ASV_HIP_CHECK(hipGetLastError());
+  return ASV_OK;
+}
+
+bool grid_conv_wide_supported(const TdnnKernelParams &p, bool bf16) {
+  if (!bf16 || p.n_taps != 9 || p.x2 != nullptr || p.wfrag == nullptr) return false;
+  if (p.cin_pad != 128 && p.cin_pad != 256) return false;
+  if (p.cout_store != p.cin_pad) return false;                 // the trunk's 3x3 convolutions keep the channel count
+  const int halo_max = p.cin_pad == 128 ? WideGeom<128>::HALO : WideGeom<256>::HALO;
+  const int bm = p.cin_pad == 128 ? WideGeom<128>::BM : WideGeom<256>::BM;
+  if (p.halo > halo_max || p.rows % bm != 0 || p.ldx % 8 != 0 || p.ldy % 4 != 0) return false;
+  return true;
+}
+
+int launch_grid_conv_wide(const TdnnKernelParams &p, hipStream_t s) {
+  ASV_REQUIRE(grid_conv_wide_supported(p, true), "grid conv (wide): unsupported layer");
+  const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first && p.seg_bias == nullptr &&
+                    p.seg_scale == nullptr && p.res == nullptr;
+  if (p.cin_pad == 128) {
+    const dim3 grid(p.rows / WideGeom<128>::BM), block(256);
+    if (fast) hipLaunchKernelGGL((grid_conv_wide_kernel<128, false>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((grid_conv_wide_kernel<128, true>), grid, block, 0, s, p);
+  } else {
+    const dim3 grid(p.rows / WideGeom<256>::BM), block(256);
+    if (fast) hipLaunchKernelGGL((grid_conv_wide_kernel<256, false>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((grid_conv_wide_kernel<256, true>), grid, block, 0, s, p);
   }
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;

@@ -214,6 +214,11 @@ __global__ __launch_bounds__(Geom3<WM>::WAVES * 64, WM == 0 ? 3 : 2) void tdnn_g
   };
   // ---- prologue: three windows in flight, weight fragments of step 0.  Only window 0 and the fragments are
   // waited for: VMEM retires in order, so vmcnt(2 * PIECES) leaves exactly windows 1 and 2 outstanding.
+  // Tried and dropped (r2i, in-process A/B): the fragment fetches as inline-asm loads with counted s_waitcnt and the window DMA
+  // issued behind a step's last fetch - what doubled the rate of the Res2NetBlock kernel's K loop (kernels_res2.hip: there the
+  // compiler-visible loads sat right behind a 48 KiB DMA).  Here the window is fetched three chunks ahead and hipcc's own
+  // waits next to the pinned MFMA / ds_read interleave are the better schedule: 711 vs 721 us per x-vector step, 3181 vs
+  // 3334 us per ECAPA step in favour of the compiler-visible loads (profiles/r2i_ab_big3_*.txt); same on the chain kernel.
   // Tried and dropped (r2e, in-process A/B on ECAPA): 1-tap layers meeting at the workgroup barrier every SECOND chunk (all four
   // stages in flight, two windows read between barriers): 3556 vs 3532 us per step - the per-chunk barrier is not what holds
   // the 1024 -> 1024 layers at 0.37 of the bf16 peak.
@@ -445,17 +450,6 @@ __global__ __launch_bounds__(Geom3<WM>::WAVES * 64, WM == 0 ? 3 : 2) void tdnn_g
   uint32_t vmask = 0;                            // bit i: this lane's frame of m-fragment i is a real frame
 #pragma unroll
   for (int i = 0; i < MF; ++i) vmask |= ((p.row_valid[(m0 + wm * (MF * 32) + i * 32) >> 5] >> lr) & 1u) << i;
-  // generic epilogue only: per-utterance bias rows (the hoisted global-context part of ECAPA's attention layer,
-  // ecapa_tdnn_xvector.py:176-181), one float4 per (frame, 4 channels) from L2
-  const float *segb[MF];
-  if constexpr (GENERIC) {
-#pragma unroll
-    for (int i = 0; i < MF; ++i) {
-      segb[i] = nullptr;
-      if (p.seg_bias != nullptr && ((vmask >> i) & 1u))
-        segb[i] = p.seg_bias + (size_t)p.row_seg[m0 + wm * (MF * 32) + i * 32 + lr] * p.ld_segbias + n0;
-    }
-  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -475,7 +469,6 @@ __global__ __launch_bounds__(Geom3<WM>::WAVES * 64, WM == 0 ? 3 : 2) void tdnn_g
         for (int e = 0; e < 4; ++e) {
           if constexpr (GENERIC) {
             float z = acc[i][j][q * 4 + e] + b[e];
-            if (segb[i] != nullptr && n0 + chl + e < p.cout_store) z += segb[i][chl + e];
             z = p.affine_first ? apply_act(z * sc[e] + sh[e], p.act1) : apply_act(z, p.act1) * sc[e] + sh[e];
             z = apply_act(z, p.act2);
             y[e] = valid ? z : 0.0f;
@@ -523,9 +516,7 @@ bool tdnn_big3_supported(const TdnnKernelParams &p, bool bf16, bool out_f32) {
   // convolution) on half-filled 256-channel tiles: 600 workgroups are 1.17 rounds of the 512 resident ones and every one of
   // them multiplies 128 channels of zeros: 231 us against 172 us on the 128 x 128 register-staged tile.
   const bool wide_enough = p.cout_store >= 192;
-  // a per-utterance bias (seg_bias) is part of the generic epilogue; the fused pooling has the plain one
-  return p.wfrag != nullptr && fits32 && bf16 && !out_f32 && p.x2 == nullptr && (p.seg_bias == nullptr || (p.pool_partial == nullptr && p.row_seg != nullptr)) &&
-         p.seg_scale == nullptr && p.res == nullptr && p.zero16 != nullptr && p.rows % 256 == 0 && p.cout_store % 8 == 0 && wide_enough && p.cin_pad >= 64;
+  return p.wfrag != nullptr && fits32 && bf16 && !out_f32 && p.x2 == nullptr && p.seg_bias == nullptr && p.seg_scale == nullptr && p.res == nullptr && p.zero16 != nullptr && p.rows % 256 == 0 && p.cout_store % 8 == 0 && wide_enough && p.cin_pad >= 64;
 }
 
 // variant = geometry * 100 + ablation code; geometry 0: 128 x 256 tiles (two workgroups per CU), 1: 256 x 256 (one),
@@ -540,7 +531,7 @@ int launch_tdnn_big3_variant(const TdnnKernelParams &p, int variant, hipStream_t
   ASV_REQUIRE(p.row_begin % bm == 0 && row_count % bm == 0 && p.row_begin + row_count <= p.rows, "tdnn(big3): row range [%d, +%d) does not fit %d-row tiles", p.row_begin, row_count, bm);
   const int m_tiles = row_count / bm, n_tiles = round_up(p.cout_store, BN) / BN;
   const dim3 grid(m_tiles * n_tiles), block(geom == 1 ? 512 : 256);
-  const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first && p.seg_bias == nullptr;
+  const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first;
   if (p.pool_partial != nullptr) {
     ASV_REQUIRE(fast && p.row_seg != nullptr && p.pool_slots >= 1 && geom != 2, "tdnn(big3): fused pooling needs the plain epilogue, a row map and 128-row wave tiles");
     if (geom == 0 && variant == 5) hipLaunchKernelGGL((tdnn_gemm_big3_kernel<5, false, true, 1>), grid, block, 0, s, p, m_tiles, n_tiles);

@@ -486,8 +486,8 @@ int asv_net_add_tdnn(asv_net_t *net, const asv_tdnn_desc_t *d) {
       if ((rc = dev_upload(net, hi.data(), hi.size() * 2, &op.wfrag))) return rc;
       if ((rc = dev_upload(net, lo.data(), lo.size() * 2, &op.wlo))) return rc;
     }
-    if (bf16 && net->domains[dom].kind == 2 && d->n_taps == 9 && (op.cin_pad == 32 || op.cin_pad == 64) && d->in_ch == op.cin_pad &&
-        d->out_ch == d->in_ch) {
+    if (bf16 && net->domains[dom].kind == 2 && d->n_taps == 9 && (op.cin_pad == 32 || op.cin_pad == 64 || op.cin_pad == 128 || op.cin_pad == 256) &&
+        d->in_ch == op.cin_pad && d->out_ch == d->in_ch) {
       // 3x3 trunk convolutions with 32 / 64 channels: fragment order of kernels_conv2d.hip,
       // [tap][k-group][n-fragment][lane = (k half lh, channel lr)][8], k = kg * 16 + lh * 8 + e
       const int kgs = op.cin_pad / 16, nfs = op.cin_pad / 32;
@@ -1122,6 +1122,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         const bool x3 = !use_ref && !op.utts && net->x3() && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && tdnn_x3_supported(p);
         const bool c1_conv = !use_ref && net->domains[domid].kind == 2 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && grid_conv_c1_supported(p, bf16, d.in_ch);
         const bool narrow_conv = !use_ref && net->domains[domid].kind == 2 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && grid_conv_narrow_supported(p, bf16);
+        const bool wide_conv = !use_ref && net->domains[domid].kind == 2 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && grid_conv_wide_supported(p, bf16);
         if (!use_ref && !big3 && op.utts && !utts_kernel) {
           // pooled-domain layers have one row per utterance (M is tiny, K is large): slice K over more
           // workgroups.  The slice count depends on K only, never on the batch, so an utterance's
@@ -1160,6 +1161,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
           rc = launch_utts_gemm(p, bp.segments, net->frames_bf16() || net->x3(), c.s);
         }
         else if (narrow_conv) rc = launch_grid_conv_narrow(p, c.s);
+        else if (wide_conv) rc = launch_grid_conv_wide(p, c.s);
         else if (c1_conv) rc = launch_grid_conv_c1(p, c.s);
         else if (x3) rc = launch_tdnn_x3(p, c.s);
         else if (big3) rc = launch_tdnn_big3(p, c.s);
