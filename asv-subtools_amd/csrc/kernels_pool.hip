@@ -144,15 +144,18 @@ __device__ __forceinline__ void load_vec(const void *base, size_t idx, float (&v
 // means, meeting through a ticket - the device-scope fence in front of the ticket writes the whole L2 back (the producing
 // convolution's output is still dirty in it): 220 us instead of 110 us, and a split count that depends on the batch breaks
 // the bit-for-bit batch invariance of an utterance's embedding.
-template <bool BF16>
+// NARROW (<= 32 channels in bf16: the SE means of the ResNet trunk's first stage): 4 lanes cover the channels and a wave
+// takes 16 rows per step instead of leaving half of its lanes idle (the row order per lane changes with the channel count
+// only - an utterance's result does not depend on the batch).
+template <bool BF16, bool NARROW>
 __global__ __launch_bounds__(256) void stats_pool_kernel(const PoolKernelParams p) {
   constexpr int VEC = BF16 ? 8 : 4;
-  constexpr int CG = 64 / VEC;          // lanes along channels
+  constexpr int CG = NARROW ? 4 : 64 / VEC;          // lanes along channels
   constexpr int RS = 64 / CG;           // row slots per wave
   __shared__ float sm[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cg = lane % CG, rs = lane / CG;
-  const int seg = blockIdx.y / p.groups, grp = blockIdx.y % p.groups, ch = blockIdx.x * 64 + cg * VEC;
+  const int seg = blockIdx.y / p.groups, grp = blockIdx.y % p.groups, ch = blockIdx.x * (CG * VEC) + cg * VEC;
   const int row0 = p.seg_row0[seg] + grp, len = p.seg_len[seg] / p.row_stride;      // rows row0 + k*row_stride, k < len
   const size_t rstep = (size_t)p.row_stride * p.ldx;
   const bool active = ch < round_up_dev(p.channels, kChanAlign);
@@ -584,7 +587,10 @@ __global__ __launch_bounds__(256) void grid_from_frames_kernel(const void *x, in
   for (int c = 0; c < ldo; ++c) store_elem<BF16>(out, (size_t)row * ldo + c, c == 0 ? v : 0.0f);
 }
 
-// im2col gather for strided convolutions: one thread per (output row, tap, 16-byte piece)
+// im2col gather for strided convolutions: one thread per (output row, tap, 16-byte piece).
+// Tried and dropped (r2k): one thread per (row, piece) walking the nine taps (the row's four dependent table lookups paid
+// once): the stores of a wave then scatter over 16 rows x 64 B instead of covering 576 contiguous bytes per row -
+// 598 vs 344 us on the 32 -> 64 stage.
 template <bool BF16>
 __global__ __launch_bounds__(256) void im2col_kernel(const Im2colParams p) {
   constexpr int VEC = BF16 ? 8 : 4;
@@ -661,8 +667,9 @@ int launch_unpack_rows(const void *y, int ldy, int channels, const int32_t *seg_
 int launch_stats_pool(const PoolKernelParams &p, int segments, bool bf16, hipStream_t s) {
   if (segments <= 0) return ASV_OK;
   const dim3 grid((p.channels + 63) / 64, segments * p.groups), block(256);
-  if (bf16) hipLaunchKernelGGL(stats_pool_kernel<true>, grid, block, 0, s, p);
-  else hipLaunchKernelGGL(stats_pool_kernel<false>, grid, block, 0, s, p);
+  if (bf16 && p.channels <= 32) hipLaunchKernelGGL((stats_pool_kernel<true, true>), dim3(1, segments * p.groups), block, 0, s, p);
+  else if (bf16) hipLaunchKernelGGL((stats_pool_kernel<true, false>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((stats_pool_kernel<false, false>), grid, block, 0, s, p);
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }

@@ -43,7 +43,8 @@ MODELS = {
     "resnet": ("resnet_xvector.py", "ResNetXvector(%d,10,training=False,resnet_params={'use_se':True,'se_ratio':4,'full_pre_activation':False},"
                "fc2_params={'nonlinearity':'','bn_params':{'momentum':0.5,'affine':False,'track_running_stats':True}})", "BASELINE configs[4] extractor: ResNet34-SE"),
 }
-KERNEL_NAMES = {"xvector": "tdnn_gemm_big3_kernel (the frame-level layers tdnn1-5: 5 launches per step, the last one with the fused pooling epilogue)",
+KERNEL_NAMES = {"xvector": "the 3 frame-level GEMM launches of a step: tdnn_chain_kernel (tdnn3 -> tdnn4 -> tdnn5 -> statistics pooling in one launch, the dominant "
+                           "kernel: 65 % of the FLOPs) and tdnn_gemm_big3_kernel (tdnn1, tdnn2); `per_launch` lists each one",
                 "ecapa": "frame-level GEMM launches (tdnn_gemm_big3_kernel for the wide layers, res2_chain / tdnn_gemm_kernel for the 128-channel ones)",
                 "resnet": "frame-level GEMM launches (grid_conv_narrow_kernel / tdnn_gemm_kernel)"}
 
@@ -250,6 +251,31 @@ def main():
                                "launches": gemm_n, "avg_launch_us": round(1e3 * gemm_ms / gemm_n, 2),
                                "algorithmic_gflop_per_utt": round((per_frame * wl.T + per_utt) / 1e9, 4), "sampled_steps": sampled_steps,
                                "gemm_ms_per_step": round(gemm_ms / sampled_steps, 4)}
+        if profile and rank == 0 and "roofline" in rec:
+            # every frame-level GEMM launch on its own (one hipEvent pair per launch: a few untimed steps after the timed regions)
+            eng.set_profiling(2)
+            for _ in range(8):
+                step()
+            torch.cuda.synchronize(dev)
+            ops = getattr(eng, "ops", eng.graph.ops)
+            per = []
+            for r in sorted(eng.get_profile(), key=lambda r: r["op_index"]):
+                if r["name"] != "tdnn_gemm" or r["total_ms"] <= 0:
+                    continue
+                i = r["op_index"]
+                what = "op %d" % i
+                if 0 <= i < len(ops) and ops[i].kind == "tdnn":
+                    own = 2.0 * wl.B * wl.T * ops[i].inp.channels * ops[i].out.channels * len(ops[i].taps)      # this layer alone, per launch
+                    chained = r["flops"] / max(r["launches"], 1) > 1.5 * own
+                    what = "%d->%d taps=%d%s" % (ops[i].inp.channels, ops[i].out.channels, len(ops[i].taps), " + the layers chained behind it (tdnn_chain_kernel)" if chained else "")
+                elif 0 <= i < len(ops) and ops[i].kind == "res2":
+                    what = "res2 %d x 128->128" % ops[i].branches
+                us = 1e3 * r["total_ms"] / max(r["launches"], 1)
+                per.append({"layer": what, "us": round(us, 1), "tflops": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 1)})
+            if len(per) <= 12:
+                rec["roofline"]["per_launch"] = per
+            eng.set_profiling(False)
+            barrier()
         if per_op and rank == 0:
             eng.set_profiling(2)
             for _ in range(steps):

@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_gpu_resnet.py tests/test_gpu_end_to_end.py -q -x 2>&1 | tail -12 > gpurun_out/r2j_pytest.txt
-python bench.py --model resnet --cpu-seconds 0 --no-supplementary --per-op > gpurun_out/r2j_resnet.json 2> gpurun_out/r2j_resnet_perop.txt
-tail -4 gpurun_out/r2j_pytest.txt; cut -c1-220 gpurun_out/r2j_resnet.json; grep -E "128->128|256->256" gpurun_out/r2j_resnet_perop.txt | head -4
+timeout 600 python -m pytest tests/test_gpu_resnet.py tests/test_gpu_end_to_end.py tests/test_gpu_kernels.py -q -x 2>&1 | tail -6 > gpurun_out/r2k_pytest.txt
+python bench.py --model resnet --cpu-seconds 0 --no-supplementary --per-op > gpurun_out/r2k_resnet.json 2> gpurun_out/r2k_resnet_perop.txt
+tail -3 gpurun_out/r2k_pytest.txt; cut -c1-220 gpurun_out/r2k_resnet.json; grep -E "grid_gather|stats_pool" gpurun_out/r2k_resnet_perop.txt | head -12
