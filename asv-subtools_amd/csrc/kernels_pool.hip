@@ -274,62 +274,86 @@ __global__ __launch_bounds__(256) void attentive_pool_kernel(const void *x, int 
   const int row0 = seg_row0[seg], len = seg_len[seg];
   const bool active = ch < round_up_dev(channels, kChanAlign);
 
-  float mx[VEC];
+  // the logits of frame r for this lane's VEC channels
+  auto load_logits = [&](int r, float (&e)[VEC]) {
+    if (group >= channels) {                                  // one head: column 0 weights every channel
+      const float e0 = load_elem<BF16>(logits, (size_t)(row0 + r) * ldl);
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) mx[i] = -INFINITY;
-  if (active)
-    for (int r = wave * RS + rs; r < len; r += 4 * RS) {
-      float e[VEC];
-      if (group >= channels) {                                  // one head: column 0 weights every channel
-        const float e0 = load_elem<BF16>(logits, (size_t)(row0 + r) * ldl);
+      for (int i = 0; i < VEC; ++i) e[i] = e0;
+    } else if (group > 1) {                                   // heads over channel groups: column (channel / group)
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) e[i] = e0;
-      } else if (group > 1) {                                   // heads over channel groups: column (channel / group)
+      for (int i = 0; i < VEC; ++i) e[i] = load_elem<BF16>(logits, (size_t)(row0 + r) * ldl + min(ch + i, channels - 1) / group);
+    } else {
+      load_vec<BF16, VEC>(logits, (size_t)(row0 + r) * ldl + ch, e);
+      if (softplus2) {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) e[i] = load_elem<BF16>(logits, (size_t)(row0 + r) * ldl + min(ch + i, channels - 1) / group);
-      } else {
-        load_vec<BF16, VEC>(logits, (size_t)(row0 + r) * ldl + ch, e);
-        if (softplus2) {
+        for (int i = 0; i < VEC; ++i) e[i] = 2.0f * logf(e[i] > 20.0f ? e[i] : log1pf(expf(e[i])));   // Softplus(beta 1, threshold 20), squared, log
+      }
+    }
+  };
+  float mx[VEC], se[VEC], sx[VEC], sxx[VEC];
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) e[i] = 2.0f * logf(e[i] > 20.0f ? e[i] : log1pf(expf(e[i])));   // Softplus(beta 1, threshold 20), squared, log
+  for (int i = 0; i < VEC; ++i) { mx[i] = -INFINITY; se[i] = 0.0f; sx[i] = 0.0f; sxx[i] = 0.0f; }
+  if constexpr (BF16) {
+    // throughput mode: ONE pass over logits and x (r2: the two passes + libm expf made this kernel 164 us on ECAPA C3).  Every
+    // lane keeps a running maximum of its own frames and rescales its sums when it moves (v_exp_f32-based exponentials);
+    // the lanes' partial sums are brought to the utterance's maximum before they are added.
+    float lm[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) lm[i] = -INFINITY;
+    if (active)
+      for (int r = wave * RS + rs; r < len; r += 4 * RS) {
+        float e[VEC], v[VEC];
+        load_logits(r, e);
+        load_vec<BF16, VEC>(x, (size_t)(row0 + r) * ldx + ch, v);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const float mn = fmaxf(lm[i], e[i]);
+          const float sc = __expf(lm[i] - mn), w = __expf(e[i] - mn);      // first frame: exp(-inf) = 0 clears the (zero) sums
+          se[i] = fmaf(se[i], sc, w);
+          sx[i] = fmaf(sx[i], sc, w * v[i]);
+          sxx[i] = fmaf(sxx[i], sc, w * v[i] * v[i]);
+          lm[i] = mn;
         }
       }
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) mx[i] = fmaxf(mx[i], e[i]);
-    }
-  block_max_rows<VEC, CG>(mx, sm, wave, cg, rs);
-  if (prior_logit && active) {                                 // the prior is one more frame of every utterance
+    for (int i = 0; i < VEC; ++i) mx[i] = lm[i];
+    block_max_rows<VEC, CG>(mx, sm, wave, cg, rs);
+    if (prior_logit && active) {
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) mx[i] = fmaxf(mx[i], prior_logit[min(ch + i, channels - 1)]);
+      for (int i = 0; i < VEC; ++i) mx[i] = fmaxf(mx[i], prior_logit[min(ch + i, channels - 1)]);
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const float f = lm[i] == -INFINITY ? 0.0f : __expf(lm[i] - mx[i]);   // a lane without frames contributes nothing
+      se[i] *= f; sx[i] *= f; sxx[i] *= f;
+    }
+  } else {
+    // parity modes: the reference's own two steps (softmax over the frames, then the weighted moments), libm exponentials
+    if (active)
+      for (int r = wave * RS + rs; r < len; r += 4 * RS) {
+        float e[VEC];
+        load_logits(r, e);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) mx[i] = fmaxf(mx[i], e[i]);
+      }
+    block_max_rows<VEC, CG>(mx, sm, wave, cg, rs);
+    if (prior_logit && active) {                                 // the prior is one more frame of every utterance
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) mx[i] = fmaxf(mx[i], prior_logit[min(ch + i, channels - 1)]);
+    }
+    if (active)
+      for (int r = wave * RS + rs; r < len; r += 4 * RS) {
+        float e[VEC], v[VEC];
+        load_logits(r, e);
+        load_vec<BF16, VEC>(x, (size_t)(row0 + r) * ldx + ch, v);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const float w = expf(e[i] - mx[i]);
+          se[i] += w; sx[i] += w * v[i]; sxx[i] += w * v[i] * v[i];
+        }
+      }
   }
-
-  float se[VEC], sx[VEC], sxx[VEC];
-#pragma unroll
-  for (int i = 0; i < VEC; ++i) { se[i] = 0.0f; sx[i] = 0.0f; sxx[i] = 0.0f; }
-  if (active)
-    for (int r = wave * RS + rs; r < len; r += 4 * RS) {
-      float e[VEC], v[VEC];
-      if (group >= channels) {                                  // one head: column 0 weights every channel
-        const float e0 = load_elem<BF16>(logits, (size_t)(row0 + r) * ldl);
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) e[i] = e0;
-      } else if (group > 1) {                                   // heads over channel groups: column (channel / group)
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) e[i] = load_elem<BF16>(logits, (size_t)(row0 + r) * ldl + min(ch + i, channels - 1) / group);
-      } else {
-        load_vec<BF16, VEC>(logits, (size_t)(row0 + r) * ldl + ch, e);
-        if (softplus2) {
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) e[i] = 2.0f * logf(e[i] > 20.0f ? e[i] : log1pf(expf(e[i])));   // Softplus(beta 1, threshold 20), squared, log
-        }
-      }
-      load_vec<BF16, VEC>(x, (size_t)(row0 + r) * ldx + ch, v);
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        const float w = expf(e[i] - mx[i]);
-        se[i] += w; sx[i] += w * v[i]; sxx[i] += w * v[i] * v[i];
-      }
-    }
   block_reduce_rows<VEC, CG>(se, sm, wave, cg, rs);
   block_reduce_rows<VEC, CG>(sx, sm, wave, cg, rs);
   block_reduce_rows<VEC, CG>(sxx, sm, wave, cg, rs);

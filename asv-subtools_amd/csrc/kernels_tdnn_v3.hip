@@ -38,13 +38,19 @@ static_assert(BN == kBigTileN, "weight padding must match the N tile");
 //   WM = 0:  64 x 256 tile, 4 waves (wave tile 64 x 64 = 2 x 2 accumulators), 39 KiB LDS, <= 168 VGPRs: THREE
 //           workgroups per CU.  For layers whose tile count does not fill whole rounds of 512 workgroups: 816
 //           tiles of 128 rows are 2 rounds (1.59 used), 1632 tiles of 64 rows on 768 slots are 3 half-rounds.
+//   WM = 3: 128 x 128 tile, 4 waves = 2 x 2 of 64 rows x 64 channels, two workgroups per CU: layers with 97..128 output
+//           channels and a deep K (ECAPA's attention bottleneck 1536 -> 128 + per-utterance bias + tanh, the im2col'd
+//           576 -> 128 convolution of the ResNet trunk).  On half-filled 256-channel tiles they were slower than on the
+//           128 x 128 register-staged tile (231 vs 172 us, r2c); with 128-row x 32-channel waves every row read fed one
+//           MFMA only and the LDS was the limit (138 us, r2l).
 template <int WM> struct Geom3 {
-  static constexpr int MF = WM == 0 ? 2 : 4;           // 32-frame accumulator fragments per wave
-  static constexpr int BM = WM == 0 ? 64 : 128 * WM;
+  static constexpr int MF = (WM == 0 || WM == 3) ? 2 : 4;   // 32-frame accumulator fragments per wave
+  static constexpr int WNS = WM == 3 ? 2 : 4;          // waves along the channels (64 each)
+  static constexpr int BM = WM == 0 ? 64 : (WM == 3 ? 128 : 128 * WM);
   static constexpr int WIN = BM + 2 * kHalo;           // 264 | 136
   static constexpr int A_STAGE = WIN * ROWB;           // 33792 | 17408
   static constexpr int A_GROUPS = WIN / 8;             // 33 | 17 eight-row groups
-  static constexpr int WAVES = WM == 0 ? 4 : 4 * WM;
+  static constexpr int WAVES = (WM == 0 || WM == 3) ? 4 : 4 * WM;
   static constexpr int SCRATCH = MF * 32 * ROWB;       // epilogue scratch per wave: [MF * 32 frames][64 channels] bf16
   static constexpr int PIECES = (A_GROUPS + WAVES - 1) / WAVES;   // LDS-DMA pieces per wave per window: 5
   static constexpr int RING_BYTES = N_STAGES * A_STAGE; // 4 window stages (135168 | 69632 B) >= epilogue scratch, 16 KiB per wave
@@ -104,16 +110,16 @@ __global__ __launch_bounds__(Geom3<WM>::WAVES * 64, WM == 0 ? 3 : 2) void tdnn_g
   constexpr bool NO_WF = MFMA_ONLY || (ABL >= 16 && (ABL & 1)), NO_X = MFMA_ONLY || (ABL >= 16 && (ABL & 2)), NO_DMA = MFMA_ONLY || (ABL >= 16 && (ABL & 4));
   constexpr bool X_DUMMY = (ABL >= 16 && (ABL & 8));   // LDS reads issued but their data never feeds an MFMA
   constexpr int BM = G::BM, A_STAGE = G::A_STAGE, A_GROUPS = G::A_GROUPS, MF = G::MF;
-  static_assert(!(POOL && WM == 0), "the fused pooling epilogue works on 128-row half tiles");
+  static_assert(!(POOL && (WM == 0 || WM == 3)), "the fused pooling epilogue works on 128-row half tiles");
   __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = wave / G::WNS, wn = wave % G::WNS;
   const int lr = lane & 31, lh = lane >> 5;
 
   const int tile = xcd_swizzle(blockIdx.x, m_tiles * n_tiles);
   const int m0 = p.row_begin + (tile / n_tiles) * BM;
-  const int n0 = (tile % n_tiles) * BN;
+  const int n0 = (tile % n_tiles) * (G::WNS * 64);
 
   const unsigned char *xg = reinterpret_cast<const unsigned char *>(p.x);
   const unsigned char *zero = reinterpret_cast<const unsigned char *>(p.zero16);
@@ -450,6 +456,26 @@ __global__ __launch_bounds__(Geom3<WM>::WAVES * 64, WM == 0 ? 3 : 2) void tdnn_g
   uint32_t vmask = 0;                            // bit i: this lane's frame of m-fragment i is a real frame
 #pragma unroll
   for (int i = 0; i < MF; ++i) vmask |= ((p.row_valid[(m0 + wm * (MF * 32) + i * 32) >> 5] >> lr) & 1u) << i;
+  // generic epilogue only: per-utterance bias rows (the hoisted global-context part of ECAPA's attention layer,
+  // ecapa_tdnn_xvector.py:176-181), one float4 per (frame, 4 channels) from L2; tanh / sigmoid on v_exp_f32 + v_rcp_f32 (the
+  // output is rounded to bf16; libm's tanhf was ~60 VALU operations per value - more than the tile's whole main loop)
+  const float *segb[MF];
+  auto act_fast = [](float v, int act) -> float {
+    switch (act) {
+      case ASV_ACT_RELU: return fmaxf(v, 0.0f);
+      case ASV_ACT_TANH: return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * v));        // exp overflow -> rcp(inf) = 0 -> 1
+      case ASV_ACT_SIGMOID: return __frcp_rn(1.0f + __expf(-v));
+      default: return v;
+    }
+  };
+  if constexpr (GENERIC) {
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+      segb[i] = nullptr;
+      if (p.seg_bias != nullptr && ((vmask >> i) & 1u))
+        segb[i] = p.seg_bias + (size_t)p.row_seg[m0 + wm * (MF * 32) + i * 32 + lr] * p.ld_segbias + n0;
+    }
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -469,8 +495,9 @@ __global__ __launch_bounds__(Geom3<WM>::WAVES * 64, WM == 0 ? 3 : 2) void tdnn_g
         for (int e = 0; e < 4; ++e) {
           if constexpr (GENERIC) {
             float z = acc[i][j][q * 4 + e] + b[e];
-            z = p.affine_first ? apply_act(z * sc[e] + sh[e], p.act1) : apply_act(z, p.act1) * sc[e] + sh[e];
-            z = apply_act(z, p.act2);
+            if (segb[i] != nullptr && n0 + chl + e < p.cout_store) z += segb[i][chl + e];
+            z = p.affine_first ? act_fast(z * sc[e] + sh[e], p.act1) : act_fast(z, p.act1) * sc[e] + sh[e];
+            z = act_fast(z, p.act2);
             y[e] = valid ? z : 0.0f;
           } else {
             y[e] = tdnn_epilogue_fast(acc[i][j][q * 4 + e], b[e], act_lo, sc[e], sh[e], valid);
@@ -515,8 +542,10 @@ bool tdnn_big3_supported(const TdnnKernelParams &p, bool bf16, bool out_f32) {
   // Tried and dropped (r2c): 128-channel layers with a deep K (ECAPA's attention bottleneck 1536 -> 128, the im2col'd 576 -> 128
   // convolution) on half-filled 256-channel tiles: 600 workgroups are 1.17 rounds of the 512 resident ones and every one of
   // them multiplies 128 channels of zeros: 231 us against 172 us on the 128 x 128 register-staged tile.
-  const bool wide_enough = p.cout_store >= 192;
-  return p.wfrag != nullptr && fits32 && bf16 && !out_f32 && p.x2 == nullptr && p.seg_bias == nullptr && p.seg_scale == nullptr && p.res == nullptr && p.zero16 != nullptr && p.rows % 256 == 0 && p.cout_store % 8 == 0 && wide_enough && p.cin_pad >= 64;
+  // 97..128 output channels with K >= 512: the 128 x 128 geometry; a per-utterance bias (seg_bias) is part of the generic
+  // epilogue (the fused pooling has the plain one)
+  const bool wide_enough = p.cout_store >= 192 || (p.cout_store > 96 && p.cout_store <= 128 && p.cin_pad * p.n_taps >= 512 && p.pool_partial == nullptr);
+  return p.wfrag != nullptr && fits32 && bf16 && !out_f32 && p.x2 == nullptr && (p.seg_bias == nullptr || (p.pool_partial == nullptr && p.row_seg != nullptr)) && p.seg_scale == nullptr && p.res == nullptr && p.zero16 != nullptr && p.rows % 256 == 0 && p.cout_store % 8 == 0 && wide_enough && p.cin_pad >= 64;
 }
 
 // variant = geometry * 100 + ablation code; geometry 0: 128 x 256 tiles (two workgroups per CU), 1: 256 x 256 (one),
@@ -526,12 +555,14 @@ int launch_tdnn_big3_variant(const TdnnKernelParams &p, int variant, hipStream_t
   ASV_REQUIRE(p.wfrag != nullptr, "tdnn(big3): fragment-packed weights missing");
   const int geom = variant / 100;
   variant %= 100;
-  const int bm = geom == 0 ? 128 : (geom == 1 ? 256 : 64);
+  const int bm = (geom == 0 || geom == 3) ? 128 : (geom == 1 ? 256 : 64);
   const int row_count = p.row_count > 0 ? p.row_count : p.rows;
   ASV_REQUIRE(p.row_begin % bm == 0 && row_count % bm == 0 && p.row_begin + row_count <= p.rows, "tdnn(big3): row range [%d, +%d) does not fit %d-row tiles", p.row_begin, row_count, bm);
-  const int m_tiles = row_count / bm, n_tiles = round_up(p.cout_store, BN) / BN;
+  const int bne = geom == 3 ? 128 : BN;
+  const int m_tiles = row_count / bm, n_tiles = round_up(p.cout_store, bne) / bne;
   const dim3 grid(m_tiles * n_tiles), block(geom == 1 ? 512 : 256);
-  const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first;
+  const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first && p.seg_bias == nullptr;
+  ASV_REQUIRE(geom != 3 || p.pool_partial == nullptr, "tdnn(big3): the 128 x 128 geometry has no fused pooling form");
   if (p.pool_partial != nullptr) {
     ASV_REQUIRE(fast && p.row_seg != nullptr && p.pool_slots >= 1 && geom != 2, "tdnn(big3): fused pooling needs the plain epilogue, a row map and 128-row wave tiles");
     if (geom == 0 && variant == 5) hipLaunchKernelGGL((tdnn_gemm_big3_kernel<5, false, true, 1>), grid, block, 0, s, p, m_tiles, n_tiles);
@@ -561,6 +592,10 @@ int launch_tdnn_big3_variant(const TdnnKernelParams &p, int variant, hipStream_t
         else if (fast) ASV_BIG3(0, false, 1);
         else ASV_BIG3(0, true, 1);
     }
+  } else if (geom == 3) {
+    if (tail) ASV_BIG3(1, false, 3);
+    else if (fast) ASV_BIG3(0, false, 3);
+    else ASV_BIG3(0, true, 3);
   } else if (geom == 1) {
     switch (variant) {
       case 2: ASV_BIG3(2, false, 2); break;
@@ -594,6 +629,7 @@ int launch_tdnn_big3_variant(const TdnnKernelParams &p, int variant, hipStream_t
 int tdnn_big3_pick_geometry(const TdnnKernelParams &p) {
   if (p.big_one_per_cu) return 1;
   if (p.pool_partial != nullptr) return 0;
+  if (p.cout_store <= 128) return 3;
   const long long n_tiles = round_up(p.cout_store, BN) / BN;
   const long long t128 = (long long)(p.rows / 128) * n_tiles;
   return t128 <= 160 ? 2 : 0;

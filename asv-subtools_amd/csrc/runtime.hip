@@ -474,7 +474,7 @@ int asv_net_add_tdnn(asv_net_t *net, const asv_tdnn_desc_t *d) {
     pack_tdnn_weight(d->weight, d->out_ch, d->in_ch, d->w_tot_context, d->w_left_context, d->taps, d->n_taps, op.cout_pad,
                      op.cin_pad, bf16, packed.data());
     if ((rc = dev_upload(net, packed.data(), packed.size(), &op.w))) return rc;
-    if (bf16 && op.cout_store >= 192 && op.cin_pad >= 64) {       // candidates of the 256-channel tiles (kernels_tdnn_v3.hip)
+    if (bf16 && op.cout_store > 96 && op.cin_pad >= 64) {         // candidates of the 256- / 128-channel tiles (kernels_tdnn_v3.hip)
       std::vector<uint16_t> frags(tdnn_weight_frag_elems(op.cout_pad, op.cin_pad, d->n_taps));
       pack_tdnn_weight_frags(d->weight, d->out_ch, d->in_ch, d->w_tot_context, d->w_left_context, d->taps, d->n_taps, op.cout_pad, op.cin_pad, frags.data());
       if ((rc = dev_upload(net, frags.data(), frags.size() * 2, &op.wfrag))) return rc;
