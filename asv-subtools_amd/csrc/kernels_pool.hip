@@ -301,21 +301,40 @@ __global__ __launch_bounds__(256) void attentive_pool_kernel(const void *x, int 
     float lm[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) lm[i] = -INFINITY;
-    if (active)
-      for (int r = wave * RS + rs; r < len; r += 4 * RS) {
+    if (active) {
+      // two frames per trip: four 16-byte loads in flight per lane, one rescale of the sums for both frames
+      int r = wave * RS + rs;
+      for (; r + 4 * RS < len; r += 8 * RS) {
+        float e0[VEC], v0[VEC], e1[VEC], v1[VEC];
+        load_logits(r, e0);
+        load_logits(r + 4 * RS, e1);
+        load_vec<BF16, VEC>(x, (size_t)(row0 + r) * ldx + ch, v0);
+        load_vec<BF16, VEC>(x, (size_t)(row0 + r + 4 * RS) * ldx + ch, v1);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const float mn = fmaxf(lm[i], fmaxf(e0[i], e1[i]));
+          const float sc = __expf(lm[i] - mn), w0 = __expf(e0[i] - mn), w1 = __expf(e1[i] - mn);   // first trip: exp(-inf) = 0
+          se[i] = fmaf(se[i], sc, w0 + w1);
+          sx[i] = fmaf(sx[i], sc, fmaf(w0, v0[i], w1 * v1[i]));
+          sxx[i] = fmaf(sxx[i], sc, fmaf(w0 * v0[i], v0[i], w1 * v1[i] * v1[i]));
+          lm[i] = mn;
+        }
+      }
+      for (; r < len; r += 4 * RS) {
         float e[VEC], v[VEC];
         load_logits(r, e);
         load_vec<BF16, VEC>(x, (size_t)(row0 + r) * ldx + ch, v);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
           const float mn = fmaxf(lm[i], e[i]);
-          const float sc = __expf(lm[i] - mn), w = __expf(e[i] - mn);      // first frame: exp(-inf) = 0 clears the (zero) sums
+          const float sc = __expf(lm[i] - mn), w = __expf(e[i] - mn);
           se[i] = fmaf(se[i], sc, w);
           sx[i] = fmaf(sx[i], sc, w * v[i]);
           sxx[i] = fmaf(sxx[i], sc, w * v[i] * v[i]);
           lm[i] = mn;
         }
       }
+    }
 #pragma unroll
     for (int i = 0; i < VEC; ++i) mx[i] = lm[i];
     block_max_rows<VEC, CG>(mx, sm, wave, cg, rs);

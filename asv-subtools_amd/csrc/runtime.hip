@@ -1142,7 +1142,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
           valid_rows = 0;
           for (int32_t len : bp.dom[domid].seg_len) valid_rows += (double)(len / net->domains[domid].pitch) * net->domains[domid].width;
         }
-        if ((rc = prof.begin(op.utts ? K_UTTS : K_TDNN, 2.0 * valid_rows * d.in_ch * d.out_ch * d.n_taps, (int)i))) return rc;
+        if ((rc = prof.begin(op.utts ? K_UTTS : K_TDNN, 2.0 * valid_rows * d.in_ch * d.out_ch * d.n_taps * (d.alg_fraction > 0.0f ? (double)d.alg_fraction : 1.0), (int)i))) return rc;
         const bool fuse = big3 && pool_slots > 0;
         if (fuse) {
           p.pool_slots = pool_slots;

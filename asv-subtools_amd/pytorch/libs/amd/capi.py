@@ -42,6 +42,7 @@ class TdnnDesc(C.Structure):
         ("affine_first", C.c_int32), ("act2", C.c_int32),
         ("seg_scale_buf", C.c_int32),
         ("res_buf", C.c_int32), ("res_ch_off", C.c_int32),
+        ("alg_fraction", C.c_float),
     ]
 
 

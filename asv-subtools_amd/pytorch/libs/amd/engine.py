@@ -125,6 +125,7 @@ class Engine(object):
                 d.act2 = capi.ACT_BY_NAME[op.act2]
                 d.seg_scale_buf = bv(op.seg_scale)[0]
                 d.res_buf, d.res_ch_off = bv(op.res)
+                d.alg_fraction = float(getattr(op, "alg_fraction", 0.0) or 0.0)
                 capi.check(L.asv_net_add_tdnn(self._net, C.byref(d)), "asv_net_add_tdnn")
                 del keep
             elif op.kind == "pool":

@@ -448,7 +448,7 @@ class Graph(object):
         for op in self.ops:
             if op.kind != "tdnn":
                 continue
-            f = 2 * op.inp.channels * op.weight.shape[0] * len(op.taps)
+            f = 2 * op.inp.channels * op.weight.shape[0] * len(op.taps) * (getattr(op, "alg_fraction", None) or 1.0)
             g = self.grid_spec(op.inp.tid)
             if self.domain(op.inp.tid) == DOMAIN_FRAMES:
                 per_frame += f

@@ -41,6 +41,31 @@ def _folded_bn(bn):
     return _ir.fold_batchnorm(_np(bn.running_mean), _np(bn.running_var), g, b, bn.eps)
 
 
+# Stride-2 convolutions with this many input channels are lowered as space-to-depth gather + 2 x 2 convolution on the output
+# grid (see emit_conv_bn).  Measured on the ResNet34 trunk (r2n, 256 x 200 frames): 64 -> 128: gather 181 + 22 -> 84 us, convolution
+# 97 -> 123 us (its 256 -> 128 4-tap form runs on the generic 128 x 128 tile): -93 us; 32 -> 64: gather 344 + 46 -> 157 us but
+# the 128 -> 64 4-tap form falls to 87 TFLOP/s on that tile (233 -> 436 us): not taken; 128 -> 256: the 512-channel form would
+# not beat im2col + the 256-channel tiles: not taken.
+S2D_CIN = (64,)
+
+
+def s2d_kernel(w, pitch_out):
+    """3 x 3 stride-2 kernel w [Cout, Cin, kF, kT] -> (taps, left, dense [Cout, 4 Cin, taps[-1] - left + 1]) of the equivalent
+    2 x 2 stride-1 convolution over the space-to-depth tensor [rows'][(pt * 2 + pf) * Cin + c] on the output grid of pitch
+    `pitch_out` (see emit_conv_bn): input offset dt in {-1, 0, 1} is phase |dt| of output-row offset (dt < 0 ? -1 : 0)."""
+    cout, cin = w.shape[0], w.shape[1]
+    taps = sorted(a * pitch_out + b for a in (-1, 0) for b in (-1, 0))
+    left = taps[0]
+    dense = np.zeros((cout, 4 * cin, taps[-1] - left + 1), dtype=np.float32)
+    for dt in (-1, 0, 1):
+        for df in (-1, 0, 1):
+            a, pt = (-1, 1) if dt < 0 else (0, dt)
+            b, pf = (-1, 1) if df < 0 else (0, df)
+            ph = pt * 2 + pf
+            dense[:, ph * cin:(ph + 1) * cin, a * pitch_out + b - left] = w[:, :, df + 1, dt + 1]
+    return taps, left, dense
+
+
 def emit_conv_bn(x, conv, bn, relu):
     """conv (3x3 pad 1 or 1x1, stride 1|2, no bias) -> [eval BN] [-> ReLU] on a rank-4 grid Sym (bn=None: the bare
     convolution, as the second one of a pre-activation block)."""
@@ -72,6 +97,27 @@ def emit_conv_bn(x, conv, bn, relu):
         if cin % _ir.CHAN_ALIGN != 0 and x.view.channels == cin:
             pass                                                    # e.g. the 1-channel head: the buffer pitch is zero padded
         out = g.tdnn(inp, dense, shift, taps, left, act1=act)
+    elif cin in S2D_CIN:
+        # Stride 2 as "space to depth": ONE gather brings the four phases (2t'+pt, 2f'+pf), pt, pf in {0, 1}, of the input
+        # grid side by side into the output grid ([rows'][phase * cin + c]: 4 cin columns instead of the 9 cin of an im2col of
+        # all taps, and both stride-2 convolutions of a down-sampling block - the 3 x 3 one and the 1 x 1 shortcut - read the
+        # same tensor).  Input row 2t' + dt is phase pt = |dt| of output row t' + (dt < 0 ? -1 : 0), so the 3 x 3 kernel
+        # becomes a 2 x 2 one on the output grid, taps (a, b) in {-1, 0}^2 = row offsets a * pitch' + b, with 9 of its
+        # 16 (tap, phase) weight blocks filled; the 1 x 1 shortcut is a 1-tap layer on the phase (0, 0) channel slice.
+        # Zero padding: rows above / left of the utterance are gap rows / the gap column of the output grid, input positions
+        # beyond the utterance are zero-filled by the gather - the same zeros as the reference's padding=1.
+        phases = [(0, 0), (0, 1), (1, 0), (1, 1)]                   # (pt, pf), phase index = pt * 2 + pf
+        cache = g.__dict__.setdefault("_s2d_cache", {})
+        key = x.view.key()
+        if key not in cache:
+            cache[key] = g.im2col(x.view, phases, stride)           # [rows'][phase * cin + c]
+        cols = cache[key]
+        if k == 1:
+            out = g.tdnn(_ir.View(cols.tid, 0, cin), w[:, :, 0, 0].astype(np.float32)[:, :, None], shift, [0], 0, act1=act)
+        else:
+            taps, left, dense = s2d_kernel(w, g.grid_spec(cols.tid)[3])
+            out = g.tdnn(cols, dense, shift, taps, left, act1=act)
+            g.ops[-1].alg_fraction = 9.0 / 16.0                      # 9 of the 16 (tap, phase) blocks carry weights: FLOP accounting
     else:
         cols = g.im2col(x.view, pos, stride)                        # [rows'][k*cin + c]
         flat = np.zeros((cout, cin * len(pos), 1), dtype=np.float32)

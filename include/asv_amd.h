@@ -117,6 +117,9 @@ typedef struct asv_tdnn_desc {
   int32_t act2;
   int32_t seg_scale_buf;         /* utts-domain buffer [segments][out_ch] multiplier, or -1  */
   int32_t res_buf, res_ch_off;   /* residual view added last, or res_buf=-1                   */
+  float alg_fraction;            /* profiling only: share of the layer's taps x in_ch weight blocks that are not structurally zero
+                                    (a stride-2 3x3 convolution lowered as 2x2 over four gathered phases: 9/16); the algorithmic
+                                    FLOPs reported for the layer are this x 2 in_ch out_ch n_taps per row.  0 = 1              */
 } asv_tdnn_desc_t;
 int asv_net_add_tdnn(asv_net_t *net, const asv_tdnn_desc_t *d);
 

@@ -106,7 +106,9 @@ def test_resnet_traced_program_reproduces_reference_on_cpu(name, idx):
     from libs.amd import ir
     g, sd, model = helpers.golden_model(name)
     graph = ir.trace(model, type(model).extract_embedding.__wrapped_body__, int(g["dim"]))
-    assert sum(1 for op in graph.ops if op.kind == "im2col") == 6          # 3 strided 3x3 + 3 strided 1x1
+    # the 64 -> 128 transition: one space-to-depth gather feeds the strided 3x3 and the strided 1x1 shortcut; the other two: im2col
+    # of all taps + 1x1 gather (the pre-activation block feeds its two strided convolutions from different tensors: no sharing)
+    assert sum(1 for op in graph.ops if op.kind == "im2col") == (6 if "preact" in name else 5)
     if name == "resnet34_cmvn":
         assert [op.kind for op in graph.ops[:3]] == ["pool", "eltwise", "grid_input"]   # InputSequenceNormalization
     per_frame, _ = graph.flops_per_frame()
@@ -155,3 +157,43 @@ assert err < 2e-5
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", PYTHONPYCACHEPREFIX="/tmp/pyc_ref")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_space_to_depth_form_of_a_stride2_convolution_equals_the_convolution():
+    """libs/nnet/resnet.py lowers 3 x 3 / stride 2 / pad 1 convolutions as a gather of the four input phases into the output
+    grid followed by a 2 x 2 stride-1 convolution with re-arranged weights (s2d_kernel).  Plain numpy on the grid row layout
+    (rows = (time, frequency), pitch = width + 1, zero gap column and gap rows): the form equals the convolution itself, odd
+    sizes included."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(helpers.REPO, "asv-subtools_amd", "pytorch"))
+    from libs.nnet.resnet import s2d_kernel
+    r = np.random.RandomState(5)
+    for T, F in ((7, 10), (8, 9), (1, 4), (5, 5)):
+        cin, cout = 3, 4
+        x = r.standard_normal((cin, F, T)).astype(np.float32)                 # [C, F, T] like the reference's [B, C, F, T]
+        w = r.standard_normal((cout, cin, 3, 3)).astype(np.float32)            # [Cout, Cin, kF, kT]
+        want = torch.nn.functional.conv2d(torch.from_numpy(x)[None], torch.from_numpy(w), stride=2, padding=1)[0].numpy()   # [Cout, F', T']
+        Fo, To = (F + 1) // 2, (T + 1) // 2
+        assert want.shape == (cout, Fo, To)
+        pitch = Fo + 1
+        # the gather (im2col_kernel with the four phase taps): rows (t', f'), zero outside the input / in the gap column
+        halo = pitch + 2
+        cols = np.zeros((halo + To * pitch + halo, 4 * cin), dtype=np.float32)
+        for tp in range(To):
+            for fp in range(Fo):
+                for pt in (0, 1):
+                    for pf in (0, 1):
+                        t, f = 2 * tp + pt, 2 * fp + pf
+                        if t < T and f < F:
+                            cols[halo + tp * pitch + fp, (pt * 2 + pf) * cin:(pt * 2 + pf + 1) * cin] = x[:, f, t]
+        taps, left, dense = s2d_kernel(w, pitch)
+        got = np.zeros((cout, Fo, To), dtype=np.float32)
+        for tp in range(To):
+            for fp in range(Fo):
+                row = halo + tp * pitch + fp
+                acc = np.zeros(cout, dtype=np.float64)
+                for tap in taps:
+                    acc += dense[:, :, tap - left].astype(np.float64) @ cols[row + tap].astype(np.float64)
+                got[:, fp, tp] = acc
+        assert np.abs(got - want).max() < 1e-5, (T, F, np.abs(got - want).max())
