@@ -604,7 +604,7 @@ static int fbank_entry(const asv_fbank_opts_t *o, const void *wave, bool pcm16, 
   ASV_REQUIRE(wave && sample_offsets && feats && n_utts >= 1, "asv_fbank: bad argument");
   ASV_REQUIRE(o->num_bins >= 3 && o->num_bins <= 512, "asv_fbank: num_bins %d", o->num_bins);
   ASV_REQUIRE(o->num_ceps >= 0 && o->num_ceps <= o->num_bins, "asv_fbank: num_ceps %d must not exceed num_bins %d", o->num_ceps, o->num_bins);
-  ASV_REQUIRE(o->window_type >= ASV_WINDOW_POVEY && o->window_type <= ASV_WINDOW_SINE, "asv_fbank: window type %d", o->window_type);
+  ASV_REQUIRE(o->window_type >= ASV_WINDOW_POVEY && o->window_type <= ASV_WINDOW_BLACKMAN, "asv_fbank: window type %d", o->window_type);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int length = window_size(*o, o->frame_length_ms), shift = window_size(*o, o->frame_shift_ms);
   ASV_REQUIRE(length >= 2 && shift >= 1, "asv_fbank: frame length %d / shift %d samples", length, shift);
@@ -627,6 +627,7 @@ static int fbank_entry(const asv_fbank_opts_t *o, const void *wave, bool pcm16, 
         case ASV_WINDOW_SINE: win[i] = (float)sin(0.5 * a * x); break;
         case ASV_WINDOW_HAMMING: win[i] = (float)(0.54 - 0.46 * cos(a * x)); break;
         case ASV_WINDOW_RECTANGULAR: win[i] = 1.0f; break;
+        case ASV_WINDOW_BLACKMAN: win[i] = (float)(o->blackman_coeff - 0.5 * cos(a * x) + (0.5 - o->blackman_coeff) * cos(2 * a * x)); break;
         default: win[i] = (float)pow(0.5 - 0.5 * cos(a * x), 0.85); break;          // povey
       }
     }
@@ -635,11 +636,29 @@ static int fbank_entry(const asv_fbank_opts_t *o, const void *wave, bool pcm16, 
       const double ang = -6.283185307179586476925286766559005 * k / padded;
       tw[k] = make_float2((float)cos(ang), (float)sin(ang));
     }
-    // mel filters, mel-computations.cc:60-141 with vtln warp 1
+    // mel filters, mel-computations.cc:91-200; VTLN: the bin edges go through the piecewise-linear warp of :20-89
     const float nyquist = 0.5f * o->sample_rate;
     const float high = o->high_freq > 0.0f ? o->high_freq : nyquist + o->high_freq;
     ASV_REQUIRE(!(o->low_freq < 0.0f || o->low_freq >= nyquist || high <= 0.0f || high > nyquist || high <= o->low_freq),
                 "asv_fbank: bad low-freq %g / high-freq %g vs nyquist %g", o->low_freq, high, nyquist);
+    const float warp = o->vtln_warp == 0.0f ? 1.0f : o->vtln_warp;       // a zero-filled options block means "no warp"
+    const float vt_low = o->vtln_low, vt_high = o->vtln_high < 0.0f ? o->vtln_high + nyquist : o->vtln_high;
+    ASV_REQUIRE(warp == 1.0f || !(vt_low < 0.0f || vt_low <= o->low_freq || vt_low >= high || vt_high <= 0.0f || vt_high >= high || vt_high <= vt_low),
+                "asv_fbank: bad vtln-low %g / vtln-high %g vs low-freq %g / high-freq %g", vt_low, vt_high, o->low_freq, high);
+    auto warp_mel = [&](float mel) -> float {
+      if (warp == 1.0f) return mel;
+      const float freq = 700.0f * (expf(mel / 1127.0f) - 1.0f);
+      float out = freq;
+      if (!(freq < o->low_freq || freq > high)) {
+        const float l = vt_low * std::max(1.0f, warp), h = vt_high * std::min(1.0f, warp), scale = 1.0f / warp;
+        const float Fl = scale * l, Fh = scale * h;
+        const float scale_left = (Fl - o->low_freq) / (l - o->low_freq), scale_right = (high - Fh) / (high - h);
+        if (freq < l) out = o->low_freq + scale_left * (freq - o->low_freq);
+        else if (freq < h) out = scale * freq;
+        else out = high + scale_right * (freq - high);
+      }
+      return mel_scale(out);
+    };
     const int n_fft = padded / 2;
     const float width = o->sample_rate / padded;
     const float mel_low = mel_scale(o->low_freq), mel_high = mel_scale(high);
@@ -648,7 +667,7 @@ static int fbank_entry(const asv_fbank_opts_t *o, const void *wave, bool pcm16, 
     std::vector<std::vector<float>> rows(o->num_bins);
     int stride = 1;
     for (int b = 0; b < o->num_bins; ++b) {
-      const float left = mel_low + b * delta, center = mel_low + (b + 1) * delta, right = mel_low + (b + 2) * delta;
+      const float left = warp_mel(mel_low + b * delta), center = warp_mel(mel_low + (b + 1) * delta), right = warp_mel(mel_low + (b + 2) * delta);
       int last = -1;
       std::vector<float> dense(n_fft, 0.0f);
       for (int i = 0; i < n_fft; ++i) {

@@ -126,10 +126,11 @@ class FbankOpts(C.Structure):
         ("use_energy", C.c_int32), ("energy_floor", C.c_float), ("raw_energy", C.c_int32), ("htk_compat", C.c_int32),
         ("use_log_fbank", C.c_int32), ("use_power", C.c_int32),
         ("num_ceps", C.c_int32), ("cepstral_lifter", C.c_float),
+        ("blackman_coeff", C.c_float), ("vtln_warp", C.c_float), ("vtln_low", C.c_float), ("vtln_high", C.c_float),
     ]
 
 
-WINDOW_TYPES = {"povey": 0, "hamming": 1, "hanning": 2, "rectangular": 3, "sine": 4}
+WINDOW_TYPES = {"povey": 0, "hamming": 1, "hanning": 2, "rectangular": 3, "sine": 4, "blackman": 5}
 
 
 class KernelTime(C.Structure):

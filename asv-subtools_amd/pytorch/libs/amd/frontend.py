@@ -41,10 +41,8 @@ def fbank_options(_kind="fbank", **kw):
         raise ValueError("mfcc: num_ceps %d must be in [1, num_mel_bins = %d]" % (o["num_ceps"], o["num_mel_bins"]))
     if o["dither"] != 0.0:
         raise ValueError("fbank: dither is random noise and is not offered on the device path; set dither=0.0 (extraction configs do)")
-    if o["vtln_warp"] != 1.0:
-        raise ValueError("fbank: vtln_warp != 1.0 is not supported")
     if o["window_type"] not in capi.WINDOW_TYPES:
-        raise ValueError("fbank: window_type %r (blackman is not supported)" % (o["window_type"],))
+        raise ValueError("fbank: unknown window_type %r" % (o["window_type"],))
     if o["channel"] not in (-1, 0):
         raise ValueError("fbank: pass one channel per utterance")
     opts = capi.FbankOpts()
@@ -66,6 +64,8 @@ def fbank_options(_kind="fbank", **kw):
     opts.use_power = int(o["use_power"])
     opts.num_ceps = o["num_ceps"]
     opts.cepstral_lifter = o["cepstral_lifter"]
+    opts.blackman_coeff = o["blackman_coeff"]
+    opts.vtln_warp, opts.vtln_low, opts.vtln_high = o["vtln_warp"], o["vtln_low"], o["vtln_high"]
     return opts, o
 
 

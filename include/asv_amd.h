@@ -351,12 +351,13 @@ int asv_class_scatter_f64(const float *x, int ldx, int n_rows, int dim, const in
  * torchaudio.compliance.kaldi.fbank computes in pytorch/libs/egs/kaldi_features.py:72-137 and kaldifeat::Fbank in
  * runtime/kaldifeat/csrc/feature-fbank.cc (the field names and defaults below are FbankOptions / FrameExtractionOptions /
  * MelBanksOptions of that code).  Samples are floats in the int16 value range (Kaldi WaveData); dither is not offered
- * (it is the one random step; extraction configs set it to 0); VTLN warp is 1. */
+ * (it is the one random step; extraction configs set it to 0). */
 #define ASV_WINDOW_POVEY       0
 #define ASV_WINDOW_HAMMING     1
 #define ASV_WINDOW_HANNING     2
 #define ASV_WINDOW_RECTANGULAR 3
 #define ASV_WINDOW_SINE        4
+#define ASV_WINDOW_BLACKMAN    5
 typedef struct asv_fbank_opts {
   uint32_t struct_size;
   float   sample_rate;          /* 16000 */
@@ -381,6 +382,9 @@ typedef struct asv_fbank_opts {
    * energy; htk_compat moves C0 / the energy last (C0 scaled by sqrt 2 when it is not the energy). */
   int32_t num_ceps;             /* 0: filterbank output */
   float   cepstral_lifter;      /* 22    */
+  float   blackman_coeff;       /* 0.42 (ASV_WINDOW_BLACKMAN, feature-window.cc:47-49)                                   */
+  float   vtln_warp;            /* 1: none.  VTLN warping of the mel bin edges (mel-computations.cc:20-89, 129-161)      */
+  float   vtln_low, vtln_high;  /* 100 / -500 (negative: offset from Nyquist): the cut-offs of the piecewise-linear warp */
 } asv_fbank_opts_t;
 /* Frames an utterance of num_samples yields (feature-window.cc:71-114); -1 on bad options. */
 long long asv_fbank_num_frames(const asv_fbank_opts_t *opts, long long num_samples);

@@ -11,7 +11,7 @@ in the reference tree and are compiled in place into oracle/_ref/libkaldifeat_re
   |rfft|^2 without the Nyquist bin    runtime/kaldifeat/csrc/feature-fbank.cc:63-72
   mel filterbank matrix               runtime/kaldifeat/csrc/mel-computations.cc:60-141 (MelScale = 1127 ln(1 + f / 700))
   log with floor FLT_EPSILON          runtime/kaldifeat/csrc/feature-fbank.cc:74-77
-Dither must be 0 (the only random step); VTLN warping is not restated (warp factor 1).
+Dither must be 0 (the only random step).
 """
 
 import numpy as np
@@ -63,12 +63,45 @@ def mel_scale(f):
     return np.float32(1127.0) * np.log(np.float32(1.0) + np.asarray(f, dtype=np.float32) / np.float32(700.0), dtype=np.float32)
 
 
-def mel_banks(num_bins, padded, sample_rate=16000.0, low_freq=20.0, high_freq=0.0):
-    """[padded / 2, num_bins] float32 triangular filters on the mel scale (mel-computations.cc:60-141, vtln warp 1)."""
+def inverse_mel_scale(m):
+    return np.float32(700.0) * (np.exp(np.float32(m) / np.float32(1127.0), dtype=np.float32) - np.float32(1.0))
+
+
+def vtln_warp_freq(vtln_low, vtln_high, low_freq, high_freq, warp, freq):
+    """mel-computations.cc:20-79: continuous piecewise-linear warp with F(low) = low, F(high) = high, slope 1/warp between
+    the inflection points l = vtln_low * max(1, warp) and h = vtln_high * min(1, warp); float arithmetic like the reference."""
+    f32 = np.float32
+    freq, low_freq, high_freq, warp = f32(freq), f32(low_freq), f32(high_freq), f32(warp)
+    if freq < low_freq or freq > high_freq:
+        return freq
+    l = f32(vtln_low) * max(f32(1.0), warp)
+    h = f32(vtln_high) * min(f32(1.0), warp)
+    scale = f32(1.0) / warp
+    Fl, Fh = scale * l, scale * h
+    scale_left = (Fl - low_freq) / (l - low_freq)
+    scale_right = (high_freq - Fh) / (high_freq - h)
+    if freq < l:
+        return low_freq + scale_left * (freq - low_freq)
+    if freq < h:
+        return scale * freq
+    return high_freq + scale_right * (freq - high_freq)
+
+
+def mel_banks(num_bins, padded, sample_rate=16000.0, low_freq=20.0, high_freq=0.0, vtln_warp=1.0, vtln_low=100.0, vtln_high=-500.0):
+    """[padded / 2, num_bins] float32 triangular filters on the mel scale (mel-computations.cc:91-200); with vtln_warp != 1 the
+    three edges of every bin go through the VTLN warp (:129-161)."""
     nyquist = 0.5 * sample_rate
     high = high_freq if high_freq > 0.0 else nyquist + high_freq
     if low_freq < 0.0 or low_freq >= nyquist or high <= 0.0 or high > nyquist or high <= low_freq:
         raise ValueError("Bad values in options: low-freq %s and high-freq %s vs. nyquist %s" % (low_freq, high, nyquist))
+    vt_high = vtln_high + nyquist if vtln_high < 0.0 else vtln_high
+    if vtln_warp != 1.0 and (vtln_low < 0.0 or vtln_low <= low_freq or vtln_low >= high or vt_high <= 0.0 or vt_high >= high or vt_high <= vtln_low):
+        raise ValueError("Bad values in options: vtln-low %s and vtln-high %s, versus low-freq %s and high-freq %s" % (vtln_low, vt_high, low_freq, high))
+
+    def warp_mel(m):
+        if vtln_warp == 1.0:
+            return np.float32(m)
+        return mel_scale(vtln_warp_freq(vtln_low, vt_high, low_freq, high, vtln_warp, inverse_mel_scale(m)))
     n_fft = padded // 2
     width = np.float32(sample_rate / padded)
     mel_low, mel_high = mel_scale(low_freq), mel_scale(high)
@@ -76,9 +109,9 @@ def mel_banks(num_bins, padded, sample_rate=16000.0, low_freq=20.0, high_freq=0.
     mel = mel_scale(width * np.arange(n_fft, dtype=np.float32))
     out = np.zeros((n_fft, num_bins), dtype=np.float32)
     for b in range(num_bins):
-        left = np.float32(mel_low + np.float32(b) * delta)
-        center = np.float32(mel_low + np.float32(b + 1) * delta)
-        right = np.float32(mel_low + np.float32(b + 2) * delta)
+        left = warp_mel(np.float32(mel_low + np.float32(b) * delta))
+        center = warp_mel(np.float32(mel_low + np.float32(b + 1) * delta))
+        right = warp_mel(np.float32(mel_low + np.float32(b + 2) * delta))
         inside = (mel > left) & (mel < right)
         if not inside.any():
             raise ValueError("You may have set num_mel_bins too large.")
@@ -90,7 +123,8 @@ def mel_banks(num_bins, padded, sample_rate=16000.0, low_freq=20.0, high_freq=0.
 
 def fbank(wave, sample_rate=16000.0, frame_length_ms=25.0, frame_shift_ms=10.0, preemph=0.97, remove_dc_offset=True, window_type="povey",
           round_to_power_of_two=True, snip_edges=True, num_bins=23, low_freq=20.0, high_freq=0.0, use_energy=False, energy_floor=0.0,
-          raw_energy=True, htk_compat=False, use_log_fbank=True, use_power=True, dtype=np.float32):
+          raw_energy=True, htk_compat=False, use_log_fbank=True, use_power=True, blackman_coeff=0.42, vtln_warp=1.0, vtln_low=100.0,
+          vtln_high=-500.0, dtype=np.float32):
     """wave: 1-D samples in the int16 value range (Kaldi WaveData convention).  Returns [frames, num_bins (+1)]."""
     wave = np.asarray(wave, dtype=np.float32)
     length, shift = window_size(sample_rate, frame_length_ms), window_size(sample_rate, frame_shift_ms)
@@ -115,7 +149,7 @@ def fbank(wave, sample_rate=16000.0, frame_length_ms=25.0, frame_shift_ms=10.0, 
         out[:, 1:] = frames[:, 1:] - dtype(preemph) * frames[:, :-1]
         out[:, 0] = frames[:, 0] * dtype(1.0 - np.float32(preemph)) if dtype == np.float32 else frames[:, 0] * (1.0 - preemph)
         frames = out
-    frames = frames * window_function(length, window_type).astype(dtype)[None, :]
+    frames = frames * window_function(length, window_type, blackman_coeff).astype(dtype)[None, :]
     padded = padded_size(length, round_to_power_of_two)
     if padded > length:
         frames = np.concatenate([frames, np.zeros((n, padded - length), dtype=dtype)], axis=1)
@@ -124,7 +158,7 @@ def fbank(wave, sample_rate=16000.0, frame_length_ms=25.0, frame_shift_ms=10.0, 
     spec = np.abs(np.fft.rfft(frames.astype(np.float64), axis=1))[:, :-1]
     if use_power:
         spec = spec * spec
-    mel = spec.astype(dtype) @ mel_banks(num_bins, padded, sample_rate, low_freq, high_freq).astype(dtype)
+    mel = spec.astype(dtype) @ mel_banks(num_bins, padded, sample_rate, low_freq, high_freq, vtln_warp, vtln_low, vtln_high).astype(dtype)
     if use_log_fbank:
         mel = np.log(np.maximum(mel, FLT_EPS))
     if use_energy:

@@ -8,7 +8,17 @@
 #include "kaldifeat/csrc/feature-fbank.h"
 #include "kaldifeat/csrc/feature-mfcc.h"
 
+namespace {
+// options that came later (blackman coefficient, VTLN): set before a call, reset to the reference's defaults afterwards
+struct Extras { float blackman_coeff = 0.42f, vtln_warp = 1.0f, vtln_low = 100.0f, vtln_high = -500.0f; };
+Extras g_extras;
+}  // namespace
+
 extern "C" {
+
+void kaldifeat_ref_set_extras(float blackman_coeff, float vtln_warp, float vtln_low, float vtln_high) {
+  g_extras.blackman_coeff = blackman_coeff; g_extras.vtln_warp = vtln_warp; g_extras.vtln_low = vtln_low; g_extras.vtln_high = vtln_high;
+}
 
 // wave: n samples (float, in the int16 range like Kaldi's WaveData); out: [frames][num_bins] row-major, capacity cap_frames.
 // Returns the number of frames, or -1 if out is too small.
@@ -29,6 +39,9 @@ int kaldifeat_ref_fbank(const float *wave, int n, float sample_rate, float frame
   opts.mel_opts.num_bins = num_bins;
   opts.mel_opts.low_freq = low_freq;
   opts.mel_opts.high_freq = high_freq;
+  opts.frame_opts.blackman_coeff = g_extras.blackman_coeff;
+  opts.mel_opts.vtln_low = g_extras.vtln_low;
+  opts.mel_opts.vtln_high = g_extras.vtln_high;
   opts.use_energy = use_energy != 0;
   opts.energy_floor = energy_floor;
   opts.raw_energy = raw_energy != 0;
@@ -37,7 +50,7 @@ int kaldifeat_ref_fbank(const float *wave, int n, float sample_rate, float frame
   opts.use_power = use_power != 0;
   kaldifeat::Fbank fbank(opts);
   torch::Tensor w = torch::from_blob(const_cast<float *>(wave), {n}, torch::kFloat).clone();
-  torch::Tensor feats = fbank.ComputeFeatures(w, 1.0f).contiguous();
+  torch::Tensor feats = fbank.ComputeFeatures(w, g_extras.vtln_warp).contiguous();
   const int frames = (int)feats.size(0), dim = (int)feats.size(1);
   if (frames > cap_frames) return -1;
   std::memcpy(out, feats.data_ptr<float>(), sizeof(float) * (size_t)frames * dim);
@@ -63,6 +76,9 @@ int kaldifeat_ref_mfcc(const float *wave, int n, float sample_rate, float frame_
   opts.mel_opts.num_bins = num_bins;
   opts.mel_opts.low_freq = low_freq;
   opts.mel_opts.high_freq = high_freq;
+  opts.frame_opts.blackman_coeff = g_extras.blackman_coeff;
+  opts.mel_opts.vtln_low = g_extras.vtln_low;
+  opts.mel_opts.vtln_high = g_extras.vtln_high;
   opts.num_ceps = num_ceps;
   opts.cepstral_lifter = cepstral_lifter;
   opts.use_energy = use_energy != 0;
@@ -71,7 +87,7 @@ int kaldifeat_ref_mfcc(const float *wave, int n, float sample_rate, float frame_
   opts.htk_compat = htk_compat != 0;
   kaldifeat::Mfcc mfcc(opts);
   torch::Tensor w = torch::from_blob(const_cast<float *>(wave), {n}, torch::kFloat).clone();
-  torch::Tensor feats = mfcc.ComputeFeatures(w, 1.0f).contiguous();
+  torch::Tensor feats = mfcc.ComputeFeatures(w, g_extras.vtln_warp).contiguous();
   const int frames = (int)feats.size(0), dim = (int)feats.size(1);
   if (frames > cap_frames) return -1;
   std::memcpy(out, feats.data_ptr<float>(), sizeof(float) * (size_t)frames * dim);

@@ -46,7 +46,9 @@ def test_unsupported_options_are_refused_up_front():
     with pytest.raises(ValueError):
         frontend.fbank_options(dither=1.0)
     with pytest.raises(ValueError):
-        frontend.fbank_options(window_type="blackman")
+        frontend.fbank_options(window_type="kaiser")
+    opts, _ = frontend.fbank_options(window_type="blackman", blackman_coeff=0.4, vtln_warp=1.1)     # offered since round 2
+    assert opts.window_type == 5 and abs(opts.blackman_coeff - 0.4) < 1e-7 and abs(opts.vtln_warp - 1.1) < 1e-7
     with pytest.raises(TypeError):
         frontend.fbank_options(num_bins=80)                      # torchaudio spells it num_mel_bins
     with pytest.raises(ValueError):
