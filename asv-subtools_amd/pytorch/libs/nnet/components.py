@@ -60,10 +60,10 @@ class TdnnAffine(torch.nn.Module):
             torch.nn.init.constant_(self.bias, 0.0)
 
     def _check_supported(self):
-        if not self.pad or self.stride != 1 or self.norm_w or self.norm_f:
-            raise _ir.TraceError("TdnnAffine(pad=%s, stride=%s, norm_w=%s, norm_f=%s): only pad=True, stride=1 "
-                                 "without weight/feature normalisation is implemented on the MI355X path"
-                                 % (self.pad, self.stride, self.norm_w, self.norm_f))
+        if not self.pad or self.stride != 1 or self.norm_f:
+            raise _ir.TraceError("TdnnAffine(pad=%s, stride=%s, norm_f=%s): only pad=True, stride=1 without feature "
+                                 "normalisation is implemented on the MI355X path (norm_w is: it is folded into the weights)"
+                                 % (self.pad, self.stride, self.norm_f))
 
     def emit(self, x, act1=None, scale=None, shift=None, affine_first=False, row_scale=None, row_map=None):
         """Appends this affine (+ fused epilogue) to the program of the symbolic tensor `x`.  A grouped affine (the attention
@@ -75,6 +75,13 @@ class TdnnAffine(torch.nn.Module):
         if have != self.input_dim:
             raise _ir.TraceError("TdnnAffine expects %d input channels, got %d" % (self.input_dim, have))
         w = self.weight.detach().cpu().numpy()
+        if self.norm_w:
+            # components.py:139-143: F.normalize(weight * mask, dim=1) - every (output channel, tap) column is scaled to unit L2
+            # norm over its input channels (eps 1e-12); inactive taps are zero before and after, so the packed active taps get
+            # the same numbers.  A constant of the model: folded into the weights here.
+            import numpy as np
+            wm = w if self.mask is None else w * self.mask.numpy().astype(w.dtype)
+            w = (wm / np.maximum(np.sqrt((wm.astype(np.float64) ** 2).sum(axis=1, keepdims=True)), 1e-12)).astype(np.float32)
         if self.groups != 1:
             import numpy as np
             go, gi = self.output_dim // self.groups, self.input_dim // self.groups

@@ -50,6 +50,26 @@ class StatisticsPooling(torch.nn.Module):
         return "{input_dim}, {output_dim}, stddev={stddev}, unbiased={unbiased}, eps={eps}".format(**self.__dict__)
 
 
+class FreeStatisticsPooling(StatisticsPooling):
+    """The reference's StatisticsPooling without a declared width (pooling.py:92-127): flattens everything between the batch
+    and the frame axis and pools it - the same device op; the width is taken from the tensor it is applied to."""
+
+    def __init__(self, stddev=True, unbiased=False, eps=1.0e-10):
+        super(FreeStatisticsPooling, self).__init__(0, stddev=stddev, unbiased=unbiased, eps=eps)
+
+    def forward(self, inputs, lengths=None):
+        if isinstance(inputs, _ir.Sym):
+            g = inputs.graph.grid_spec(inputs.view.tid)
+            self.input_dim = inputs.view.channels * (g[2] if g is not None else 1)
+            self.output_dim = 2 * self.input_dim if self.stddev else self.input_dim
+            if g is not None and not inputs.flat_grid:
+                inputs = inputs.reshape(1, self.input_dim, -1)          # its own reshape(B, -1, T)
+        return super(FreeStatisticsPooling, self).forward(inputs, lengths)
+
+    def extra_repr(self):
+        return "stddev={stddev}, unbiased={unbiased}, eps={eps}".format(**self.__dict__)
+
+
 class AttentionAlphaComponent(torch.nn.Module):
     """Frame weights alpha = softmax over time of [ReLU(first_affine(x))] -> last_affine [/ temperature]
     (reference pooling.py:220-319), in all its configurations: one or several heads, heads over channel splits
@@ -301,5 +321,4 @@ def _not_on_hot_path(name, where):
     return _Unsupported
 
 
-FreeStatisticsPooling = _not_on_hot_path("FreeStatisticsPooling", "pooling.py:78")
 MQMHASP = _not_on_hot_path("MQMHASP", "pooling.py:590-701")

@@ -197,3 +197,35 @@ def test_space_to_depth_form_of_a_stride2_convolution_equals_the_convolution():
                     acc += dense[:, :, tap - left].astype(np.float64) @ cols[row + tap].astype(np.float64)
                 got[:, fp, tp] = acc
         assert np.abs(got - want).max() < 1e-5, (T, F, np.abs(got - want).max())
+
+
+def test_free_statistics_pooling_and_weight_normalised_affine_trace_like_their_plain_forms():
+    """FreeStatisticsPooling (pooling.py:92-127) = StatisticsPooling without a declared width; TdnnAffine(norm_w=True)
+    (components.py:139-143) = the affine with every (output, tap) weight column scaled to unit norm over its input channels:
+    both are checked on the CPU interpreter of the layer program against their definition in torch."""
+    import torch
+    from libs.amd import ir
+    from libs.nnet import TopVirtualNnet, TdnnAffine, FreeStatisticsPooling, for_extract_embedding
+
+    class Tiny(TopVirtualNnet):
+        def init(self, dim):
+            self.a = TdnnAffine(dim, 24, context=[-2, 0, 2], norm_w=True)
+            self.pool = FreeStatisticsPooling(stddev=True, unbiased=True)
+
+        @for_extract_embedding(maxChunk=10000, isMatrix=True)
+        def extract_embedding(self, inputs):
+            return self.pool(self.a(inputs))
+
+    torch.manual_seed(3)
+    m = Tiny(10)
+    with torch.no_grad():
+        m.a.weight.normal_(0, 1.0); m.a.bias.normal_(0, 0.1)
+    graph = ir.trace(m, type(m).extract_embedding.__wrapped_body__, 10)
+    x = np.random.RandomState(0).standard_normal((37, 10)).astype(np.float32)
+    got = ir_interp.extract(graph, x)
+    with torch.no_grad():
+        w = torch.nn.functional.normalize(m.a.weight * m.a.mask, dim=1)
+        xin = torch.nn.functional.pad(torch.from_numpy(x.T)[None], (2, 2))
+        y = torch.nn.functional.conv1d(xin, w, m.a.bias)
+        want = torch.cat([y.mean(2), y.std(2, unbiased=True)], dim=1)[0].numpy()
+    assert rel_err(got, want) < 1e-5
