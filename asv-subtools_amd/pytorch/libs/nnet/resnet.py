@@ -186,11 +186,75 @@ class BasicBlock(nn.Module):
         return _ir.Sym(g, out, 4)
 
 
+def _emit_se_and_join(g, y, identity, se, pre_activation):
+    """SE scale (resnet.py: SEBlock_2D) + residual (+ the final ReLU of the original form) as one elementwise pass."""
+    seg_scale = None
+    if isinstance(se, SEBlock_2D):
+        spec = g.grid_spec(y.view.tid)
+        # mean over (F, T): the device pools over all rows of the segment incl. the zero row of each frame,
+        # i.e. sum / (frames * pitch); the factor pitch / width is folded into fc_1
+        m = g.pool(y.view, stddev=False)
+        w1 = _np(se.fc_1.weight)[:, :, None] * np.float32(spec[3] / float(spec[2]))
+        h = g.tdnn(m, w1, _np(se.fc_1.bias), [0], 0, act1="relu")
+        seg_scale = g.tdnn(h, _np(se.fc_2.weight)[:, :, None], _np(se.fc_2.bias), [0], 0, act1="sigmoid")
+    return _ir.Sym(g, g.eltwise(y.view, b=identity.view, seg_scale=seg_scale, act=None if pre_activation else "relu"), 4)
+
+
 class Bottleneck(nn.Module):
+    """1x1 -> 3x3 (stride) -> 1x1 (x4) residual block in both forms of the reference (resnet.py:113-208), optional SE: the
+    same fused pieces as BasicBlock - every convolution carries its eval BatchNorm (and ReLU) in weights / epilogue, the
+    pre-activation form starts with one elementwise relu(bn1(x)) pass."""
     expansion = 4
 
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError("Bottleneck blocks are not implemented on the MI355X path (the target ResNet34 uses BasicBlock)")
+    def __init__(self, inplanes, planes, Conv=nn.Conv2d, stride=1, downsample=None, groups=1, base_width=64, dilation=1, norm_layer=None,
+                 norm_layer_params={}, full_pre_activation=False, use_se=False, se_ratio=4):
+        super(Bottleneck, self).__init__()
+        if norm_layer is None:
+            norm_layer = nn.BatchNorm2d
+        if groups != 1 or dilation > 1:
+            raise NotImplementedError("grouped / dilated Bottleneck blocks are not implemented on the MI355X path")
+        width = int(planes * (base_width / 64.)) * groups
+        self.downsample = downsample
+        self.stride = stride
+        self.full_pre_activation = full_pre_activation
+        if full_pre_activation:                          # resnet.py:149-162 (module order = state_dict order)
+            self.bn1 = norm_layer(inplanes, **norm_layer_params)
+            self.relu1 = nn.ReLU(inplace=True)
+            self.conv1 = conv1x1(inplanes, width, Conv)
+            self.bn2 = norm_layer(width, **norm_layer_params)
+            self.relu2 = nn.ReLU(inplace=True)
+            self.conv2 = conv3x3(width, width, Conv, stride)
+            self.bn3 = norm_layer(width, **norm_layer_params)
+            self.relu3 = nn.ReLU(inplace=True)
+            self.conv3 = conv1x1(width, planes * self.expansion, Conv)
+        else:                                            # resnet.py:133-147
+            self.conv1 = conv1x1(inplanes, width, Conv)
+            self.bn1 = norm_layer(width, **norm_layer_params)
+            self.relu1 = nn.ReLU(inplace=True)
+            self.conv2 = conv3x3(width, width, Conv, stride)
+            self.bn2 = norm_layer(width, **norm_layer_params)
+            self.relu2 = nn.ReLU(inplace=True)
+            self.conv3 = conv1x1(width, planes * self.expansion, Conv)
+            self.bn3 = norm_layer(planes * self.expansion, **norm_layer_params)
+            self.relu3 = nn.ReLU(inplace=True)
+        self.se = SEBlock_2D(planes * self.expansion, se_ratio) if use_se else nn.Identity()
+
+    def forward(self, x):
+        if not isinstance(x, _ir.Sym):
+            raise NotImplementedError("Bottleneck.forward() on a torch tensor: eager forward is not part of asv-subtools_amd")
+        g = x.graph
+        identity = x if self.downsample is None else emit_conv_bn(x, self.downsample[0], self.downsample[1], relu=False)
+        if self.full_pre_activation:                     # resnet.py:185-202
+            s1, t1 = _folded_bn(self.bn1)
+            a = _ir.Sym(g, g.eltwise(x.view, scale=s1, shift=t1, act="relu"), 4)
+            y = emit_conv_bn(a, self.conv1, self.bn2, relu=True)
+            y = emit_conv_bn(y, self.conv2, self.bn3, relu=True)
+            y = emit_conv_bn(y, self.conv3, None, relu=False)
+        else:                                            # resnet.py:164-183
+            y = emit_conv_bn(x, self.conv1, self.bn1, relu=True)
+            y = emit_conv_bn(y, self.conv2, self.bn2, relu=True)
+            y = emit_conv_bn(y, self.conv3, self.bn3, relu=False)
+        return _emit_se_and_join(g, y, identity, self.se, self.full_pre_activation)
 
 
 class ResNet(nn.Module):
@@ -203,8 +267,9 @@ class ResNet(nn.Module):
         super(ResNet, self).__init__()
         if convXd != 2:
             raise NotImplementedError("convXd=%r: only the 2-D trunk is implemented on the MI355X path" % (convXd,))
-        if block != "BasicBlock":
-            raise NotImplementedError("block=%r: only BasicBlock is implemented on the MI355X path" % (block,))
+        if block not in ("BasicBlock", "Bottleneck"):
+            raise NotImplementedError("block=%r: BasicBlock and Bottleneck are implemented on the MI355X path" % (block,))
+        self.block = Bottleneck if block == "Bottleneck" else BasicBlock
         if head_maxpool or not head_conv or head_conv_params != {"kernel_size": 3, "stride": 1, "padding": 1}:
             raise NotImplementedError("only the ResNetXvector head (3x3 conv, stride 1, no max-pool) is implemented on the MI355X path")
         if replace_stride_with_dilation not in (None, [False, False, False]) or groups != 1:
@@ -226,17 +291,19 @@ class ResNet(nn.Module):
         self.layer3 = self._make_layer(planes[2], layers[2], 2, use_se, se_ratio)
         self.layer4 = self._make_layer(planes[3], layers[3], 2, use_se, se_ratio)
         self.downsample_multiple *= 8
-        self.output_planes = planes[3] * BasicBlock.expansion
+        self.output_planes = planes[3] * self.block.expansion
 
     def _make_layer(self, planes, blocks, stride, use_se, se_ratio):
         downsample = None
-        if stride != 1 or self.inplanes != planes:
-            downsample = nn.Sequential(conv1x1(self.inplanes, planes, nn.Conv2d, stride), self._norm_layer(planes, **self.norm_layer_params))
+        block = self.block
+        if stride != 1 or self.inplanes != planes * block.expansion:       # resnet.py:318-322
+            downsample = nn.Sequential(conv1x1(self.inplanes, planes * block.expansion, nn.Conv2d, stride),
+                                       self._norm_layer(planes * block.expansion, **self.norm_layer_params))
         kw = dict(norm_layer=self._norm_layer, norm_layer_params=self.norm_layer_params, full_pre_activation=self.full_pre_activation,
                   use_se=use_se, se_ratio=se_ratio)
-        seq = [BasicBlock(self.inplanes, planes, nn.Conv2d, stride, downsample, **kw)]
-        self.inplanes = planes
-        seq += [BasicBlock(planes, planes, nn.Conv2d, **kw) for _ in range(1, blocks)]
+        seq = [block(self.inplanes, planes, nn.Conv2d, stride, downsample, **kw)]
+        self.inplanes = planes * block.expansion
+        seq += [block(self.inplanes, planes, nn.Conv2d, **kw) for _ in range(1, blocks)]
         return nn.Sequential(*seq)
 
     def get_downsample_multiple(self):

@@ -154,6 +154,14 @@ CASES = {
                               creation="ResNetXvector(45,10,training=False,resnet_params={'use_se':True,'se_ratio':4})",
                               dim=45, utts=[(120, 5400), (64, 5401)], wseed=10),
     # no SE, default fc2 (ReLU + affine BN), odd feature dim -> ceil division at every stride-2 stage
+    # Bottleneck blocks (resnet.py:113-208), original form + SE, and the pre-activation form; small widths, odd feature dim
+    "resnet_bottleneck_se": dict(blueprint="resnet_xvector.py",
+                                 creation="ResNetXvector(40,10,training=False,resnet_params={'block':'Bottleneck','layers':[1,2,1,1],'planes':[16,32,64,128],"
+                                          "'use_se':True,'se_ratio':4,'full_pre_activation':False})",
+                                 dim=40, utts=[(90, 5500), (33, 5501)], wseed=11),
+    "resnet_bottleneck_preact": dict(blueprint="resnet_xvector.py",
+                                     creation="ResNetXvector(33,10,training=False,resnet_params={'block':'Bottleneck','layers':[1,1,1,1],'planes':[16,32,64,128]})",
+                                     dim=33, utts=[(70, 5600), (21, 5601)], wseed=12),
     "resnet34_plain": dict(blueprint="resnet_xvector.py",
                            creation="ResNetXvector(61,10,training=False,resnet_params={'full_pre_activation':False})",
                            dim=61, utts=[(150, 5100), (77, 5101)], wseed=7),

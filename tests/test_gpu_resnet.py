@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("precision", ["f32", "f32x"])
-@pytest.mark.parametrize("name", ["resnet34se_c5", "resnet34_plain", "resnet34_cmvn", "resnet34_preact", "resnet34se_preact"])
+@pytest.mark.parametrize("name", ["resnet34se_c5", "resnet34_plain", "resnet34_cmvn", "resnet34_preact", "resnet34se_preact", "resnet_bottleneck_se",
+                                  "resnet_bottleneck_preact"])
 def test_resnet_f32_vs_reference_golden(name, precision):
     """incl. the blueprint's default configuration: full pre-activation blocks (resnet34_preact = ResNetXvector(80, 10, training=False))"""
     g, sd, model = helpers.golden_model(name)
