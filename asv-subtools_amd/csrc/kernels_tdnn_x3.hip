@@ -18,6 +18,11 @@
 //     pack_tdnn_weight_frags) and come straight from L2 as 1 KiB wave loads;
 //   * 64 frames x 256 channels per workgroup, 4 waves (64 x 64 each = 2 x 2 accumulators), <= 168 VGPRs:
 //     three workgroups per CU.
+// Tried and dropped (r2p): splitting the f32 window ONCE per workgroup and chunk into a [hi | lo] bf16 image in a second LDS
+// buffer (no VALU work in front of the k-groups instead of 48 operations per 12 MFMAs): 237.6 k vs 241.4 k utt/s on C2 - the
+// kernel is not bound by the split but by what it streams: 4 KiB of weight fragments per 12 MFMAs and wave (64-row waves,
+// hi + lo halves: 341 B per MFMA against 256 B in the bf16 kernel with 128-row waves) and f32 windows / outputs (the 1-tap
+// 512 -> 1500 layer moves 1.05 GB per launch).  The next step for this mode is the 128-row wave tile of kernels_tdnn_v3.hip.
 #include "device_utils.h"
 
 namespace asv {
