@@ -216,9 +216,10 @@ __global__ __launch_bounds__(64) void pool_finish_kernel(const PoolFinishParams 
   const int seg = blockIdx.y, ch = blockIdx.x * 64 + threadIdx.x;
   if (ch >= p.channels) return;
   const int row0 = p.seg_row0[seg], len = p.seg_len[seg];
-  // merge (count, mean, M2) of the segment's half tiles in row order (Chan et al. pairwise update, float64: a handful of
-  // terms per channel); every partial holds sum (u - pv), sum (u - pv)^2 about its own pivot pv
-  double n_acc = 0.0, mean = 0.0, m2 = 0.0;
+  // merge (count, mean, M2) of the segment's half tiles in row order (Chan et al. pairwise update: sums of non-negative terms
+  // and one difference of nearby means - well conditioned in f32; the float64 version of this loop was 20 of the x-vector
+  // step's 700 us, most of it double-precision divisions); every partial holds sum (u - pv), sum (u - pv)^2 about its own pivot pv
+  float n_acc = 0.0f, mean = 0.0f, m2 = 0.0f;
   for (int h = row0 >> 7; h <= (row0 + len - 1) >> 7; ++h) {
     int first = -1;
     for (int k = 0; k < kHalo + 1 && first < 0; ++k)
@@ -236,12 +237,13 @@ __global__ __launch_bounds__(64) void pool_finish_kernel(const PoolFinishParams 
       }
       if (cnt == 0) continue;
       const float *src = p.partial + ((size_t)((h * p.pool_slots + slot) * parts + part) * 3) * p.ld_partial + ch;
-      const double nh = (double)cnt;
-      const double sh = (double)src[0], qh = (double)src[p.ld_partial], pv = (double)src[2 * p.ld_partial];
-      const double mean_h = pv + sh / nh, m2_h = fmax(qh - sh * sh / nh, 0.0);
-      const double tot = n_acc + nh, delta = mean_h - mean;
-      mean += delta * nh / tot;
-      m2 += m2_h + delta * delta * n_acc * nh / tot;
+      const float nh = (float)cnt, inv_nh = 1.0f / nh;
+      const float sh = src[0], qh = src[p.ld_partial], pv = src[2 * p.ld_partial];
+      const float dm = sh * inv_nh;                                     // mean of the part minus its pivot
+      const float mean_h = pv + dm, m2_h = fmaxf(qh - sh * dm, 0.0f);
+      const float tot = n_acc + nh, inv_tot = 1.0f / tot, delta = mean_h - mean;
+      mean += delta * nh * inv_tot;
+      m2 += m2_h + delta * delta * n_acc * nh * inv_tot;
       n_acc = tot;
     }
   }
@@ -249,9 +251,9 @@ __global__ __launch_bounds__(64) void pool_finish_kernel(const PoolFinishParams 
   float counts = n;
   if (p.unbiased == 1 && len > 1) counts = (float)(len - 1);
   if (p.unbiased == 2) counts = (float)(len - 1);
-  p.out[(size_t)seg * p.ld_out + ch] = (float)mean + (p.shift ? p.shift[ch] : 0.0f);
+  p.out[(size_t)seg * p.ld_out + ch] = mean + (p.shift ? p.shift[ch] : 0.0f);
   if (p.stddev) {
-    const float var = (float)m2 / counts;
+    const float var = m2 / counts;
     p.out[(size_t)seg * p.ld_out + p.channels + ch] = (p.var_mode == ASV_POOL_VAR_ADD) ? sqrtf(var + p.eps) : sqrtf(fmaxf(var, p.eps));
   }
 }

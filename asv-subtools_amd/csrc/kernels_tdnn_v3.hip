@@ -192,13 +192,20 @@ __global__ __launch_bounds__(Geom3<WM>::WAVES * 64, WM == 0 ? 3 : 2) void tdnn_g
     wf[kg][1] = *reinterpret_cast<const uint4 *>(wf_base1 + off);
   };
 
+  // Plain epilogue (ABL 3 = the first form, for in-process A/B): the accumulators start from the bias (behind the first barrier,
+  // once the staged constants are visible) and the gap-row mask is applied to the packed bf16 pairs - a saturating MFMA stream
+  // leaves the SIMD's VALU no issue slot, so every VALU instruction of an epilogue is paid in full:
+  // 736 -> ~520 VALU operations per wave tile.
+  constexpr bool BIAS_IN_ACC = !GENERIC && !POOL && ABL != 3;
   f32x16_t acc[MF][2];
+  if constexpr (!BIAS_IN_ACC) {
 #pragma unroll
-  for (int i = 0; i < MF; ++i)
+    for (int i = 0; i < MF; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  }
 
   struct XFrags { uint4 x[MF]; };
   auto load_x = [&](const unsigned char *Ab, int d, int kg, XFrags &f) {
@@ -241,6 +248,19 @@ __global__ __launch_bounds__(Geom3<WM>::WAVES * 64, WM == 0 ? 3 : 2) void tdnn_g
   }
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  if constexpr (BIAS_IN_ACC) {
+    // acc[i][j][4 q + e] belongs to channel wn*64 + j*32 + 8 q + 4 lh + e of the tile, for every frame fragment i
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 b4 = *reinterpret_cast<const float4 *>(lds_par + wn * 64 + j * 32 + 8 * q + 4 * lh);
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+          acc[i][j][q * 4 + 0] = b4.x; acc[i][j][q * 4 + 1] = b4.y; acc[i][j][q * 4 + 2] = b4.z; acc[i][j][q * 4 + 3] = b4.w;
+        }
+      }
+  }
 
   STAMP3(1);
   // tap offsets live in one VGPR (lane t = tap t) and are fetched with v_readlane: indexing the kernel-argument
@@ -499,6 +519,8 @@ __global__ __launch_bounds__(Geom3<WM>::WAVES * 64, WM == 0 ? 3 : 2) void tdnn_g
             z = p.affine_first ? act_fast(z * sc[e] + sh[e], p.act1) : act_fast(z, p.act1) * sc[e] + sh[e];
             z = act_fast(z, p.act2);
             y[e] = valid ? z : 0.0f;
+          } else if constexpr (BIAS_IN_ACC) {
+            y[e] = fmaf(max_lo(acc[i][j][q * 4 + e], act_lo), sc[e], sh[e]);
           } else {
             y[e] = tdnn_epilogue_fast(acc[i][j][q * 4 + e], b[e], act_lo, sc[e], sh[e], valid);
           }
@@ -506,6 +528,10 @@ __global__ __launch_bounds__(Geom3<WM>::WAVES * 64, WM == 0 ? 3 : 2) void tdnn_g
         uint2 pk;
         pk.x = pack_bf16x2(y[0], y[1]);
         pk.y = pack_bf16x2(y[2], y[3]);
+        if constexpr (BIAS_IN_ACC) {               // gap rows are zeros: on the packed pairs, 2 selects per 4 values
+          pk.x = valid ? pk.x : 0u;
+          pk.y = valid ? pk.y : 0u;
+        }
         // odd rows keep their two 8-byte halves swapped so rows r, r+1 (same slot) hit different banks
         *reinterpret_cast<uint2 *>(scr + frow * ROWB + swz(frow, slot) * 16 + ((lh ^ (frow & 1)) * 8)) = pk;
       }
@@ -587,6 +613,9 @@ int launch_tdnn_big3_variant(const TdnnKernelParams &p, int variant, hipStream_t
       case 24: ASV_BIG3(24, false, 1); break;
       case 29: ASV_BIG3(29, false, 1); break;
       case 22: ASV_BIG3(22, false, 1); break;
+      case 3:
+        if (fast && !tail) { ASV_BIG3(3, false, 1); break; }       // A/B: the first form of the plain epilogue
+        [[fallthrough]];
       default:
         if (tail) ASV_BIG3(1, false, 1);
         else if (fast) ASV_BIG3(0, false, 1);
@@ -645,7 +674,8 @@ int launch_tdnn_big3(const TdnnKernelParams &p, hipStream_t s) {
   if (tune != nullptr && p.tune == 0) {
     TdnnKernelParams q = p;
     q.tune = atoi(tune);
-    return launch_tdnn_big3_variant(q, tdnn_big3_pick_geometry(q) * 100, s);
+    const int geom = tdnn_big3_pick_geometry(q);
+    return launch_tdnn_big3_variant(q, geom * 100 + ((q.tune & 0x20000) && geom == 0 && q.pool_partial == nullptr ? 3 : 0), s);
   }
   return launch_tdnn_big3_variant(p, tdnn_big3_pick_geometry(p) * 100, s);
 }

@@ -66,6 +66,8 @@ CASES = [
     (512, 1500, [0], [200, 100]),
     (128, 128, [-4, 0, 4], [300, 9, 8]),
     (96, 200, [0], [5]),
+    (1536, 128, [0], [300, 200, 77]),          # bf16: the 128 x 128 geometry of the wide kernel (ECAPA's attention bottleneck)
+    (576, 128, [0], [260, 130, 1]),            # (the im2col'd 64 -> 128 convolution of the ResNet trunk)
 ]
 
 
@@ -123,6 +125,28 @@ def test_bn_relu_order_and_activations():
             # 256 products of unit-scale operands, each carrying the 2^-17 representation error of a bf16 pair: ~3e-5 at the
         # worst of 160 000 outputs (the embedding-level 1e-4 gate is tests/test_gpu_full_size_parity.py)
         assert rel_err(got, want) < 5e-5, (act, first)
+
+
+def test_bf16_generic_epilogue_of_the_wide_kernel_tanh_sigmoid():
+    """bf16 layers with tanh / sigmoid (or the bn-relu order) and >= 97 output channels run on the wide kernel's generic
+    epilogue, whose tanh / sigmoid are built on v_exp_f32 + v_rcp_f32: against the numpy oracle at bf16 tolerance, on the
+    128 x 128 geometry (128 channels) and the 128 x 256 one (512 channels), saturating arguments included."""
+    from libs.amd import capi
+    r = np.random.RandomState(21)
+    offsets = np.array([0, 200, 333, 334], dtype=np.int32)
+    for cin, cout in ((1024, 128), (512, 512)):
+        x = r.randn(334, cin).astype(np.float32)
+        w = (r.randn(cout, cin, 1) / np.sqrt(cin)).astype(np.float32)                  # unit-scale pre-activations (bf16 operands: ~3e-3 absolute)
+        b = (0.5 * r.randn(cout)).astype(np.float32)
+        b[:8] = [15.0, -15.0, 40.0, -40.0, 90.0, -90.0, 200.0, -200.0]                  # saturated channels: exp overflow / underflow inside the fast forms
+        scale = r.uniform(0.5, 1.5, cout).astype(np.float32)
+        shift = (0.2 * r.randn(cout)).astype(np.float32)
+        for act in ("tanh", "sigmoid"):
+            for first in (False, True):
+                got = _tdnn_forward(x, offsets, w, b, [0], act, scale, shift, first, capi.PREC_BF16, 0)
+                want = _oracle_layer(x, offsets, w, b, [0], act, scale, shift, first)
+                assert np.isfinite(got).all(), (cin, cout, act, first)
+                assert rel_err(got, want) < 2e-2, (cin, cout, act, first, rel_err(got, want))
 
 
 @pytest.mark.parametrize("lens", [[200, 200, 200], [1, 2, 3, 1000, 17], [513]])
