@@ -192,11 +192,15 @@ __global__ __launch_bounds__(Geom3<WM>::WAVES * 64, WM == 0 ? 3 : 2) void tdnn_g
     wf[kg][1] = *reinterpret_cast<const uint4 *>(wf_base1 + off);
   };
 
-  // Plain epilogue (ABL 3 = the first form, for in-process A/B): the accumulators start from the bias (behind the first barrier,
-  // once the staged constants are visible) and the gap-row mask is applied to the packed bf16 pairs - a saturating MFMA stream
-  // leaves the SIMD's VALU no issue slot, so every VALU instruction of an epilogue is paid in full:
-  // 736 -> ~520 VALU operations per wave tile.
-  constexpr bool BIAS_IN_ACC = !GENERIC && !POOL && ABL != 3;
+  // Plain epilogue (ABL 3 = the first form, for in-process A/B): the gap-row mask is applied to the packed bf16 pairs (2 selects
+  // per 4 values instead of 4) - a saturating MFMA stream leaves the SIMD's VALU no issue slot, so every VALU instruction of an
+  // epilogue is paid in full.  Starting the accumulators from the bias saves another 128 additions
+  // per wave tile (736 -> 449 VALU operations, +0.2 % / +0.6 % per x-vector / ECAPA step in the A/B of profiles/r2q_*) but moves
+  // the bias to the front of the f32 sum: the outputs are then no longer bit-identical to the generic tile's, which layer
+  // shapes beyond this kernel's 32-bit row offsets fall back to - an utterance's bits would depend on the batch it is in.
+  // Not taken: BIAS_IN_ACC stays off.
+  constexpr bool PACKED_MASK = !GENERIC && !POOL && ABL != 3;
+  constexpr bool BIAS_IN_ACC = false;
   f32x16_t acc[MF][2];
   if constexpr (!BIAS_IN_ACC) {
 #pragma unroll
@@ -522,13 +526,13 @@ __global__ __launch_bounds__(Geom3<WM>::WAVES * 64, WM == 0 ? 3 : 2) void tdnn_g
           } else if constexpr (BIAS_IN_ACC) {
             y[e] = fmaf(max_lo(acc[i][j][q * 4 + e], act_lo), sc[e], sh[e]);
           } else {
-            y[e] = tdnn_epilogue_fast(acc[i][j][q * 4 + e], b[e], act_lo, sc[e], sh[e], valid);
+            y[e] = tdnn_epilogue_fast(acc[i][j][q * 4 + e], b[e], act_lo, sc[e], sh[e], PACKED_MASK ? true : valid);
           }
         }
         uint2 pk;
         pk.x = pack_bf16x2(y[0], y[1]);
         pk.y = pack_bf16x2(y[2], y[3]);
-        if constexpr (BIAS_IN_ACC) {               // gap rows are zeros: on the packed pairs, 2 selects per 4 values
+        if constexpr (PACKED_MASK) {               // gap rows are zeros: on the packed pairs, 2 selects per 4 values
           pk.x = valid ? pk.x : 0u;
           pk.y = valid ? pk.y : 0u;
         }
