@@ -15,8 +15,9 @@ def _act(x, name):
     return O._act(x, name)
 
 
-def run_graph(graph, feats, dtype=np.float32):
-    """feats [T, D] -> embedding [E] for ONE utterance segment (no chunking)."""
+def run_graph(graph, feats, dtype=np.float32, ops=None):
+    """feats [T, D] -> embedding [E] for ONE utterance segment (no chunking).  `ops` replaces graph.ops (the engine-level
+    late passes fused_res2_ops / fused_add_ops return such lists)."""
     feats = np.asarray(feats, dtype=dtype)
     T = feats.shape[0]
     bufs = {0: feats}
@@ -49,7 +50,7 @@ def run_graph(graph, feats, dtype=np.float32):
             bufs[v.tid] = np.zeros((rows(v.tid), graph.tensors[v.tid][1]), dtype=dtype)
         bufs[v.tid][:, v.ch_off:v.ch_off + v.channels] = val
 
-    for op in graph.ops:
+    for op in (graph.ops if ops is None else ops):
         if op.kind == "tdnn":
             x = get(op.inp)
             if op.inp2 is not None:
@@ -148,6 +149,26 @@ def run_graph(graph, feats, dtype=np.float32):
                 z = z + get(op.c)
             z = _act(z, getattr(op, "act", None))
             put(op.out, (z * valid_mask(op.out.tid)).astype(dtype))
+            if getattr(op, "out2", None) is not None:              # second output: the STORED value + d
+                put(op.out2, ((get(op.out) + get(op.d)) * valid_mask(op.out2.tid)).astype(dtype))
+        elif op.kind == "res2":
+            # one Res2NetBlock: group 0 passes through, y_k = affine(relu(conv_k(y_{k-1} + x_k))) with y_0 = 0
+            W = op.weight.shape[1]
+            x = get(op.inp)
+            T = x.shape[0]
+            y = np.zeros((T, (op.branches + 1) * W), dtype=dtype)
+            y[:, :W] = x[:, :W]
+            prev = np.zeros((T, W), dtype=dtype)
+            for k in range(1, op.branches + 1):
+                u = x[:, k * W:(k + 1) * W] + prev
+                z = np.zeros((T, W), dtype=dtype)
+                for d in (-op.dilation, 0, op.dilation):           # dense (2d+1)-tap kernels with three live taps
+                    lo, hi = max(0, -d), min(T, T - d)
+                    if hi > lo:
+                        z[lo:hi] += u[lo + d:hi + d] @ op.weight[k - 1][:, :, d + op.dilation].T.astype(dtype)
+                z = np.maximum(z + op.bias[k - 1].astype(dtype), 0) * op.scale[k - 1].astype(dtype) + op.shift[k - 1].astype(dtype)
+                y[:, k * W:(k + 1) * W] = prev = z.astype(dtype)
+            put(op.out, y)
         else:
             raise AssertionError("unexpected op %s" % op.kind)
     return get(graph.output)[0]
@@ -167,5 +188,5 @@ def _tdnn_general(x, op, dtype):
     return y
 
 
-def extract(graph, feats, max_chunk=10000, dtype=np.float32):
-    return O.extract_embedding(lambda c: run_graph(graph, c, dtype), feats, max_chunk, dtype)
+def extract(graph, feats, max_chunk=10000, dtype=np.float32, ops=None):
+    return O.extract_embedding(lambda c: run_graph(graph, c, dtype, ops), feats, max_chunk, dtype)

@@ -98,6 +98,24 @@ def test_ecapa_traced_program_reproduces_reference_on_cpu(name, limit):
         assert rel_err(ir_interp.extract(graph, x), ref) < 2e-5
 
 
+@pytest.mark.parametrize("name", ["ecapa_c3", "ecapa_c512_fc1_far"])
+def test_ecapa_late_fusion_passes_preserve_the_program(name):
+    """The engine-level passes (one 'res2' op per Res2NetBlock, the running block sum as a second eltwise output) are
+    rewrites of the op list only: interpreted on CPU, the fused list gives the unfused list's embedding."""
+    from libs.amd import ir
+    g, sd, model = helpers.golden_model(name)
+    graph = ir.trace(model, type(model).extract_embedding.__wrapped_body__, int(g["dim"]))
+    fused = graph.fused_add_ops(graph.fused_res2_ops())
+    kinds = [op.kind for op in fused]
+    n_res2 = 3 if name == "ecapa_c3" else 0                  # kernels_res2.hip is written for 128-channel groups (C = 1024, scale 8)
+    assert kinds.count("res2") == n_res2 and len(fused) <= len(graph.ops) - n_res2 * 7 - 2
+    assert sum(1 for op in fused if getattr(op, "out2", None) is not None) >= 2
+    x = helpers.golden_feats(g)[0]
+    plain = ir_interp.extract(graph, x)
+    assert np.array_equal(ir_interp.extract(graph, x, ops=graph.fused_add_ops()), plain)       # same arithmetic, same order
+    assert rel_err(ir_interp.extract(graph, x, ops=fused), plain) < 1e-6
+
+
 @pytest.mark.parametrize("name,idx", [("resnet34se_c5", 2), ("resnet34se_c5", 3), ("resnet34_plain", 1), ("resnet34_cmvn", 1), ("resnet34_preact", 2),
                                       ("resnet34se_preact", 1), ("resnet_bottleneck_se", 0), ("resnet_bottleneck_se", 1), ("resnet_bottleneck_preact", 0)])
 def test_resnet_traced_program_reproduces_reference_on_cpu(name, idx):
