@@ -19,7 +19,8 @@
 //     lane = channel, registers = frames, and the pooling epilogue sums pivoted moments per utterance inside a lane -
 //     no LDS transposition (the first version went through a scratch tile like the POOL epilogue of kernels_tdnn_v3.hip:
 //     15.6k instead of 11.5k cycles per unit); pool_finish_kernel merges the tiles.
-// Measured (profiles/r2_*, 640 x 200 frames): 433 us against 190 + 84 + 253 us for the three launches it replaces.  Per tile
+// Measured (640 x 200 frames): 385 us (profiles/r2_*) - 405 us (profiles/r2final_*, another box) against 190 + 84 + 253 us for
+// the three launches it replaces (433 us before the run-based pooling epilogue, profiles/r2a_*).  Per tile
 // (s_memtime stamps, ASV_AMD_CHAIN_DBG=1): layer A 57.7k cycles for 49.2k of MFMA issue, middle layer 18.3k (16.4k), last
 // layer 3 x (11.6k loop + 12k epilogue next to the partner's loop); the shader clock inside the kernel is 1.76 GHz.
 // Tried without effect (in-process A/B, tools/chain_ab.py): s_setprio around either phase, four partial sums instead of
