@@ -1088,6 +1088,20 @@ int run_ops(RunCtx &c, size_t n_ops) {
               fprintf(stderr, " [shader clock %.0f MHz, %.1f us per workgroup]", rt > 0 ? 100.0 * cyc / rt : 0.0, cnt ? rt / 100.0 / (double)cnt : 0.0);
               for (int k = 1; k < 13; ++k) fprintf(stderr, " %d:%.0f", k, sum[k] / (double)std::max<size_t>(cnt, 1));
               fprintf(stderr, "\n");
+              static const int chain_dbg_level = atoi(getenv("ASV_AMD_CHAIN_DBG"));
+              if (chain_dbg_level >= 2) {                 // raw timelines of two workgroups: waves w and w + 4 share a SIMD
+                const size_t picks[2] = {nwg / 4, nwg / 2 + 1};
+                for (size_t wg : picks) {
+                  if (wg >= nwg) continue;
+                  unsigned long long t0 = ~0ull;
+                  for (int w = 0; w < 8; ++w) if (h[(wg * 8 + w) * 16] != 0) t0 = std::min(t0, h[(wg * 8 + w) * 16]);
+                  for (int w = 0; w < 8; ++w) {
+                    fprintf(stderr, "[chain dbg] workgroup %zu wave %d stamps (cycles since the first wave's stamp 0):", wg, w);
+                    for (int k = 0; k < 13; ++k) fprintf(stderr, " %lld", (long long)(h[(wg * 8 + w) * 16 + k] - t0));
+                    fprintf(stderr, "\n");
+                  }
+                }
+              }
             }
             Op &po = net->ops[lo.fused_pool];
             po.skipped = true;
