@@ -26,6 +26,12 @@
 // Tried without effect (in-process A/B, tools/chain_ab.py): s_setprio around either phase, four partial sums instead of
 // the 16-deep chains, 22 instead of 48 instructions per k-group (one address register per step): the loops sit at the
 // matrix pipe's rate, the epilogue at ~14 cycles per VALU operation beside a streaming partner.
+// Where the last layer's time goes (ASV_AMD_CHAIN_DBG=2, profiles/r2t_chain_timeline.txt; tools/coissue_probe2.hip,
+// profiles/r2r_coissue2.txt): the two waves of a SIMD do alternate loop / epilogue, a loop takes 10.3k cycles with or without a
+// computing partner, an epilogue 12 - 15k next to a partner's loop and 4.0k alone - the epilogue sets the period.  Its packed f32
+// operations only issue in the gaps of the partner's MFMA stream, plain ones would at ~8 cycles each (twice as many: no gain,
+// profiles/r2s_lib_ab_packed_fp32.txt); behind a wave's OWN MFMAs a plain VALU operation costs ~0.5 cycle.  Next step (DESIGN.md
+// section 8): the pooling arithmetic of unit u interleaved into the MFMA loop of unit u + 1 of the same wave.
 // One workgroup (512 threads, 160 KiB LDS) per CU.
 #include <cstdlib>
 
