@@ -32,6 +32,9 @@
 // operations only issue in the gaps of the partner's MFMA stream, plain ones would at ~8 cycles each (twice as many: no gain,
 // profiles/r2s_lib_ab_packed_fp32.txt); behind a wave's OWN MFMAs a plain VALU operation costs ~0.5 cycle.  Next step (DESIGN.md
 // section 8): the pooling arithmetic of unit u interleaved into the MFMA loop of unit u + 1 of the same wave.
+// Tried and dropped at the end of round 2 (profiles/r2v_ab_chain_prefetch.txt): bias / BN scale of the NEXT unit loaded before a
+// unit's K loop and the next unit's first weight fragments fetched by the last K step (no memory round trip at the start of a
+// unit or of its epilogue): bit-identical, 703.6 -> 702.5 us per step - those waits are not what stretches the phase.
 // One workgroup (512 threads, 160 KiB LDS) per CU.
 #include <cstdlib>
 

@@ -37,3 +37,11 @@ for r in range(rounds):
         run(20); res[v].append(run(150))
 for v in variants:
     a = sorted(res[v]); print("%s=%s: median %.1f us/step  min %.1f  max %.1f  (%.0f utt/s)" % (env, v, 1e6 * a[len(a) // 2], 1e6 * a[0], 1e6 * a[-1], B / a[len(a) // 2]))
+# the variants must agree bit for bit unless the experiment says otherwise
+outs = {}
+for v in variants:
+    os.environ[env] = v
+    outs[v] = eng.extract_device(feats, offs).float().cpu().numpy().copy()
+for v in variants[1:]:
+    d = np.abs(outs[v] - outs[variants[0]])
+    print("%s=%s vs %s: max |diff| %.3g (%s)" % (env, v, variants[0], d.max(), "bit-identical" if np.array_equal(outs[v], outs[variants[0]]) else "DIFFERENT"))
