@@ -35,6 +35,11 @@
 // Tried and dropped at the end of round 2 (profiles/r2v_ab_chain_prefetch.txt): bias / BN scale of the NEXT unit loaded before a
 // unit's K loop and the next unit's first weight fragments fetched by the last K step (no memory round trip at the start of a
 // unit or of its epilogue): bit-identical, 703.6 -> 702.5 us per step - those waits are not what stretches the phase.
+// Likewise (profiles/r2w_ab_chain_pin.txt): hipcc orders the eight fragment loads ahead of a Y-fed K loop by base address
+// (a0 a1 a2 a3 b1 b2 b0 b3), and because the loop's waits must also hold on the path from its entry, the wait in front of b0's
+// first use is vmcnt(2) where the steady state needs vmcnt(7) - every K step waits for fragments fetched 8 MFMAs earlier.  With the
+// entry loads pinned to the loop's order all waits become vmcnt(7): bit-identical, 705.8 -> 708.4 us per step (L2 hits return
+// within those 256 cycles) - dropped.
 // One workgroup (512 threads, 160 KiB LDS) per CU.
 #include <cstdlib>
 
