@@ -98,6 +98,28 @@ def test_ecapa_traced_program_reproduces_reference_on_cpu(name, limit):
         assert rel_err(ir_interp.extract(graph, x), ref) < 2e-5
 
 
+TDNN_FAMILY_GOLDENS = ["xvector_c1", "xvector_chunked", "xvector_near_ragged", "extended_far", "extended_near_plain", "factored_far", "factored_near",
+                       "snowdar_default", "snowdar_full_near", "snowdar_no_tdnn6", "snowdar_attentive", "snowdar_attentive_mean", "snowdar_multihead",
+                       "snowdar_multihead_unshared", "snowdar_multires", "snowdar_multires_learned", "snowdar_xi_mean", "snowdar_xi_dist", "snowdar_lde",
+                       "snowdar_lde40"]
+
+
+@pytest.mark.parametrize("name", TDNN_FAMILY_GOLDENS)
+def test_tdnn_family_traced_programs_reproduce_the_reference_on_cpu(name):
+    """Every TDNN-family blueprint and pooling of SURVEY.md 8(a)/(f3) - standard / extended / composite / factorised x-vector with
+    statistics, attentive, multi-head, multi-resolution, xi-vector and LDE pooling; far / near positions; chunked long inputs and
+    one-frame utterances - traced into the layer program and interpreted with the numpy oracle's layer functions: what the device
+    is handed is the reference's computation (north_star tolerance 1e-4), before any kernel runs."""
+    from libs.amd import ir
+    g, sd, model = helpers.golden_model(name)
+    graph = ir.trace(model, type(model).extract_embedding.__wrapped_body__, int(g["dim"]))
+    feats = helpers.golden_feats(g)
+    pairs = list(zip(feats, g["embeddings"]))
+    picks = pairs[:2] + ([min(pairs, key=lambda p: len(p[0]))] if len(pairs) > 2 else [])        # + the shortest utterance of the set
+    for x, ref in picks:
+        assert rel_err(ir_interp.extract(graph, x), ref) < 1e-4, (name, len(x))
+
+
 @pytest.mark.parametrize("name", ["ecapa_c3", "ecapa_c512_fc1_far"])
 def test_ecapa_late_fusion_passes_preserve_the_program(name):
     """The engine-level passes (one 'res2' op per Res2NetBlock, the running block sum as a second eltwise output) are
