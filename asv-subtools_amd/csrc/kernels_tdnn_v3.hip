@@ -595,16 +595,22 @@ int launch_tdnn_big3_variant(const TdnnKernelParams &p, int variant, hipStream_t
   ASV_REQUIRE(geom != 3 || p.pool_partial == nullptr, "tdnn(big3): the 128 x 128 geometry has no fused pooling form");
   if (p.pool_partial != nullptr) {
     ASV_REQUIRE(fast && p.row_seg != nullptr && p.pool_slots >= 1 && geom != 2, "tdnn(big3): fused pooling needs the plain epilogue, a row map and 128-row wave tiles");
+#ifdef ASV_WITH_ABLATION
     if (geom == 0 && variant == 5) hipLaunchKernelGGL((tdnn_gemm_big3_kernel<5, false, true, 1>), grid, block, 0, s, p, m_tiles, n_tiles);
-    else if (geom == 0) hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, false, true, 1>), grid, block, 0, s, p, m_tiles, n_tiles);
+    else
+#endif
+    if (geom == 0) hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, false, true, 1>), grid, block, 0, s, p, m_tiles, n_tiles);
     else hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, false, true, 2>), grid, block, 0, s, p, m_tiles, n_tiles);
     ASV_HIP_CHECK(hipGetLastError());
     return ASV_OK;
   }
+  // The ablation instantiations (parts of the kernel compiled out: tools/gemm_ablate.hip, `make tools`) are built into the
+  // tools' own object only (-DASV_WITH_ABLATION); the library carries the production forms and the one A/B variant (3).
 #define ASV_BIG3(ABLV, GENV, WMV) hipLaunchKernelGGL((tdnn_gemm_big3_kernel<ABLV, GENV, false, WMV>), grid, block, 0, s, p, m_tiles, n_tiles)
   const bool tail = fast && p.cin_pad % BK != 0;
   if (geom == 0) {
     switch (variant) {
+#ifdef ASV_WITH_ABLATION
       case 2: ASV_BIG3(2, false, 1); break;
       case 4: ASV_BIG3(4, false, 1); break;
       case 5: ASV_BIG3(5, false, 1); break;
@@ -617,6 +623,7 @@ int launch_tdnn_big3_variant(const TdnnKernelParams &p, int variant, hipStream_t
       case 24: ASV_BIG3(24, false, 1); break;
       case 29: ASV_BIG3(29, false, 1); break;
       case 22: ASV_BIG3(22, false, 1); break;
+#endif
       case 3:
         if (fast && !tail) { ASV_BIG3(3, false, 1); break; }       // A/B: the first form of the plain epilogue
         [[fallthrough]];
@@ -631,17 +638,21 @@ int launch_tdnn_big3_variant(const TdnnKernelParams &p, int variant, hipStream_t
     else ASV_BIG3(0, true, 3);
   } else if (geom == 1) {
     switch (variant) {
+#ifdef ASV_WITH_ABLATION
       case 2: ASV_BIG3(2, false, 2); break;
       case 4: ASV_BIG3(4, false, 2); break;
+#endif
       default:
         if (fast) ASV_BIG3(0, false, 2);
         else ASV_BIG3(0, true, 2);
     }
   } else {
     switch (variant) {
+#ifdef ASV_WITH_ABLATION
       case 2: ASV_BIG3(2, false, 0); break;
       case 5: ASV_BIG3(5, false, 0); break;
       case 6: ASV_BIG3(6, false, 0); break;
+#endif
       default:
         if (tail) ASV_BIG3(1, false, 0);
         else if (fast) ASV_BIG3(0, false, 0);
