@@ -168,7 +168,7 @@ CASES = {
 }
 
 
-def run_extractor_case(name, case, synth):
+def run_extractor_case(name, case, synth, path=None):
     import numpy as np
     import torch
     import libs.support.utils as utils
@@ -196,7 +196,7 @@ def run_extractor_case(name, case, synth):
         shape_vals=np.array([",".join(str(d) for d in s) for s in shapes.values()]),
         torch_version=np.array(torch.__version__),
     )
-    path = os.path.join(GOLDEN, name + ".npz")
+    path = path or os.path.join(GOLDEN, name + ".npz")
     np.savez_compressed(path, **out)
     print("wrote %s: embeddings %s, %d params" % (path, out["embeddings"].shape,
                                                    sum(int(np.prod(s)) for s in shapes.values())))
@@ -209,6 +209,14 @@ def main(argv):
     sys.path.insert(0, os.path.join(REF, "pytorch"))
     os.makedirs(GOLDEN, exist_ok=True)
     synth = load_synth()
+    if argv and argv[0] == "--adhoc":
+        # python oracle/gen_golden.py --adhoc '<json case>' <out.npz>: one extractor case that is not a committed fixture (the
+        # build-container differential test tests/test_reference_differential.py drives the reference through this)
+        import json
+        case = json.loads(argv[1])
+        case["utts"] = [tuple(u) for u in case["utts"]]
+        run_extractor_case("adhoc", case, synth, path=argv[2])
+        return
     names = argv or list(CASES) + list(EXTRA_CASES)
     for n in names:
         if n in CASES:
