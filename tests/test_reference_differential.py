@@ -46,6 +46,23 @@ CASES = [
                           "pooling_params={'stddev':False})" % SMALL_RESNET, 24, [(40, 5), (9, 6)], 41, 1e-4),
     ("resnet_xvector.py", "ResNetXvector(24,10,training=False,resnet_params={'layers':[1,2,1,1],%s,'zero_init_residual':True},"
                           "extracted_embedding='near_affine')" % SMALL_RESNET, 24, [(40, 5)], 42, 1e-4),
+    # training-time wrappers that must vanish at extraction: context / hidden / input dropout, mixup, SpecAugment
+    ("snowdar_xvector.py", "Xvector(24,10,training=False,context_dropout=0.1,hidden_dropout=0.2,aug_dropout=0.1,"
+                           "dropout_params={'type':'random','start_p':0.1})", 24, [(60, 1)], 51, 1e-4),
+    ("snowdar_xvector.py", "Xvector(24,10,training=False,mixup=True,specaugment=True)", 24, [(60, 1)], 56, 1e-4),
+    ("ecapa_tdnn_xvector.py", "ECAPA_TDNN(40,10,training=False,aug_dropout=0.1,tail_dropout=0.2,mixup=True,%s)" % SMALL_ECAPA, 40, [(80, 5)], 60, 1e-4),
+    # poolings with non-default shapes
+    ("snowdar_xvector.py", "Xvector(24,10,training=False,pooling='multi-head',pooling_params={'num_head':2,'stddev':False,'num_nodes':256})", 24, [(60, 1), (2, 2)], 52, 1e-4),
+    ("snowdar_xvector.py", "Xvector(24,10,training=False,pooling='attentive',pooling_params={'affine_layers':2,'hidden_size':16,'context':[-2,0,2],"
+                           "'num_nodes':300},extend=True,SE=True)", 24, [(60, 1), (3, 2)], 54, 1e-4),
+    ("snowdar_xvector.py", "Xvector(24,10,training=False,pooling='lde',pooling_params={'num_head':16,'num_nodes':128},tdnn6=False,"
+                           "extracted_embedding='near')", 24, [(60, 1), (1, 2)], 55, 1e-4),
+    # input normalisation variants in front of the 2-D trunk; ECAPA beyond maxChunk (framework.py:34-47: two chunks, weighted mean)
+    ("resnet_xvector.py", "ResNetXvector(24,10,training=False,cmvn=True,cmvn_params={'mean_norm':True,'std_norm':False},resnet_params={'layers':[1,1,1,1],%s})"
+                          % SMALL_RESNET, 24, [(40, 5), (1, 6)], 57, 1e-4),
+    ("resnet_xvector.py", "ResNetXvector(24,10,training=False,cmvn=True,cmvn_params={'mean_norm':False,'std_norm':True},resnet_params={'layers':[1,1,1,1],%s,"
+                          "'full_pre_activation':False})" % SMALL_RESNET, 24, [(40, 5)], 58, 1e-4),
+    ("ecapa_tdnn_xvector.py", "ECAPA_TDNN(40,10,training=False,%s)" % SMALL_ECAPA, 40, [(10003, 5)], 61, 1e-4),
 ]
 
 
