@@ -32,6 +32,36 @@ void set_error(const char *fmt, ...);
     }                                                                                         \
   } while (0)
 
+// ---------------------------------------------------------------------------------------
+// Every C-ABI entry point runs on the device that owns its handle / its first device pointer and leaves the calling
+// thread's current HIP device as it found it, on every return path (a multi-GPU torch process calls these with tensors of
+// cuda:1 while cuda:0 is current: a stray hipSetDevice would silently move its later allocations and streams).
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  int enter(int device) {
+    ASV_HIP_CHECK(hipGetDevice(&prev));
+    if (prev != device) {
+      ASV_HIP_CHECK(hipSetDevice(device));
+      switched = true;
+    }
+    return ASV_OK;
+  }
+  // the device that owns `dev_ptr` (device or managed memory only)
+  int enter_owner(const void *dev_ptr, const char *what) {
+    hipPointerAttribute_t attr;
+    ASV_HIP_CHECK(hipPointerGetAttributes(&attr, dev_ptr));
+    ASV_REQUIRE(attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged, "%s: pointer %p is not device memory", what, dev_ptr);
+    return enter(attr.device);
+  }
+  ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+  DeviceGuard() = default;
+  DeviceGuard(const DeviceGuard &) = delete;
+  DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define ASV_ON_DEVICE(dev) ::asv::DeviceGuard _asv_dev_guard; do { int _rc = _asv_dev_guard.enter(dev); if (_rc) return _rc; } while (0)
+#define ASV_ON_OWNER(ptr, what) ::asv::DeviceGuard _asv_dev_guard; do { int _rc = _asv_dev_guard.enter_owner(ptr, what); if (_rc) return _rc; } while (0)
+
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
@@ -69,6 +99,8 @@ struct TdnnKernelParams {
   const void *zero16;   // >= 16 bytes of device zeros: source of masked direct-to-LDS loads
   const void *wfrag;    // bf16 weights in MFMA-fragment order [n_frag32][tap][chunk64][k_group][lane][8] or nullptr;
                         // pooled-domain layers (kernels_utts.hip): the bf16 'hi' halves of the f32 weights, [cout_pad][cin_pad]
+  const void *wconv;    // 3x3 grid convolutions (kernels_conv2d.hip): bf16 weights in THAT kernel family's fragment order [tap][k-group][n-frag][lane][8]
+                        // - its own pointer, so that neither family can ever be handed the other's layout - or nullptr
   const void *wlo;      // pooled-domain layers and the f32x frame kernel: the bf16 'lo' halves (w - hi), same layout as wfrag, or nullptr
   // split-K (small-M layers: the pooled domain): blockIdx.y walks `ksplit` slices of the channel
   // chunks, raw f32 accumulators go to partial[slice][rows][ld_partial]; a second kernel sums

@@ -555,6 +555,7 @@ float mel_scale(float f) { return 1127.0f * logf(1.0f + f / 700.0f); }
 thread_local std::vector<void *> g_front_dev;            // device tables of the last option set (tiny; rebuilt on change)
 thread_local asv_fbank_opts_t g_front_opts;
 thread_local bool g_front_valid = false;
+thread_local int g_front_device = -1;                     // the device the cached tables live on
 // Host offset arrays are small and usually the same from call to call (fixed batch shapes): the last upload is kept per
 // calling thread and reused when the contents are unchanged, which also removes the stream synchronisation a fresh upload
 // needs (the source is a caller-owned / local array).  Calls of one thread are expected on one stream.
@@ -562,13 +563,17 @@ struct OffsetCache {
   std::vector<long long> host;
   long long *dev = nullptr;
   size_t cap = 0;
+  int device = -1;
   int get(const long long *src, size_t count, hipStream_t s, const long long **out) {
-    if (dev && host.size() == count && memcmp(host.data(), src, count * 8) == 0) { *out = dev; return ASV_OK; }
-    if (count > cap) {
+    int cur = 0;
+    ASV_HIP_CHECK(hipGetDevice(&cur));
+    if (dev && device == cur && host.size() == count && memcmp(host.data(), src, count * 8) == 0) { *out = dev; return ASV_OK; }
+    if (count > cap || device != cur) {
       if (dev) ASV_HIP_CHECK(hipFree(dev));
       dev = nullptr; cap = 0; host.clear();
       ASV_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&dev), count * 16));
       cap = count * 2;
+      device = cur;
     }
     host.assign(src, src + count);
     ASV_HIP_CHECK(hipMemcpyAsync(dev, host.data(), count * 8, hipMemcpyHostToDevice, s));
@@ -602,6 +607,7 @@ long long asv_fbank_num_frames(const asv_fbank_opts_t *o, long long num_samples)
 static int fbank_entry(const asv_fbank_opts_t *o, const void *wave, bool pcm16, const long long *sample_offsets, int n_utts, float *feats, void *stream) {
   ASV_REQUIRE(o && o->struct_size == sizeof(asv_fbank_opts_t), "asv_fbank: struct_size mismatch");
   ASV_REQUIRE(wave && sample_offsets && feats && n_utts >= 1, "asv_fbank: bad argument");
+  ASV_ON_OWNER(feats, "asv_fbank");
   ASV_REQUIRE(o->num_bins >= 3 && o->num_bins <= 512, "asv_fbank: num_bins %d", o->num_bins);
   ASV_REQUIRE(o->num_ceps >= 0 && o->num_ceps <= o->num_bins, "asv_fbank: num_ceps %d must not exceed num_bins %d", o->num_ceps, o->num_bins);
   ASV_REQUIRE(o->window_type >= ASV_WINDOW_POVEY && o->window_type <= ASV_WINDOW_BLACKMAN, "asv_fbank: window type %d", o->window_type);
@@ -614,7 +620,10 @@ static int fbank_entry(const asv_fbank_opts_t *o, const void *wave, bool pcm16, 
   ASV_REQUIRE(o->round_to_power_of_two || padded == length, "asv_fbank: round_to_power_of_two=false needs a power-of-two window (got %d samples)", length);
   while ((1 << log2n) < padded) ++log2n;
   // ---- tables (host arithmetic in the reference's types: float mel scale, double window phase)
-  if (!g_front_valid || memcmp(&g_front_opts, o, sizeof(*o)) != 0) {
+  int cur_dev = 0;
+  ASV_HIP_CHECK(hipGetDevice(&cur_dev));                   // = the owner of `feats` (guard above)
+  const double blackman = o->blackman_coeff != 0.0f ? (double)o->blackman_coeff : 0.42;      // 0 (a zero-filled struct) = Kaldi's default
+  if (!g_front_valid || g_front_device != cur_dev || memcmp(&g_front_opts, o, sizeof(*o)) != 0) {
     for (void *ptr : g_front_dev) (void)hipFree(ptr);
     g_front_dev.clear();
     g_front_valid = false;
@@ -627,7 +636,7 @@ static int fbank_entry(const asv_fbank_opts_t *o, const void *wave, bool pcm16, 
         case ASV_WINDOW_SINE: win[i] = (float)sin(0.5 * a * x); break;
         case ASV_WINDOW_HAMMING: win[i] = (float)(0.54 - 0.46 * cos(a * x)); break;
         case ASV_WINDOW_RECTANGULAR: win[i] = 1.0f; break;
-        case ASV_WINDOW_BLACKMAN: win[i] = (float)(o->blackman_coeff - 0.5 * cos(a * x) + (0.5 - o->blackman_coeff) * cos(2 * a * x)); break;
+        case ASV_WINDOW_BLACKMAN: win[i] = (float)(blackman - 0.5 * cos(a * x) + (0.5 - blackman) * cos(2 * a * x)); break;
         default: win[i] = (float)pow(0.5 - 0.5 * cos(a * x), 0.85); break;          // povey
       }
     }
@@ -726,6 +735,7 @@ static int fbank_entry(const asv_fbank_opts_t *o, const void *wave, bool pcm16, 
       if ((rc = up(dct.data(), dct.size() * 4, reinterpret_cast<void **>(&g_tab.dct)))) return rc;
     }
     g_front_opts = *o;
+    g_front_device = cur_dev;
     g_front_valid = true;
   }
   // ---- offsets
@@ -804,6 +814,7 @@ int asv_cmvn_sliding(const float *feats, float *out, const long long *frame_offs
   ASV_REQUIRE(feats && out && feats != out && frame_offsets && n_utts >= 1 && dim >= 1, "asv_cmvn_sliding: bad argument (in-place is not supported)");
   ASV_REQUIRE(cmn_window > 0 && (center || (min_window > 0 && min_window <= cmn_window)), "asv_cmvn_sliding: cmn_window %d / min_window %d", cmn_window, min_window);
   ASV_REQUIRE(frame_offsets[0] == 0, "asv_cmvn_sliding: frame_offsets[0] must be 0");
+  ASV_ON_OWNER(feats, "asv_cmvn_sliding");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   long long longest = 0;
   for (int u = 0; u < n_utts; ++u) longest = std::max(longest, frame_offsets[u + 1] - frame_offsets[u]);
@@ -826,6 +837,7 @@ int asv_vad_energy(const float *feats, const long long *frame_offsets, int n_utt
   ASV_REQUIRE(energy_mean_scale >= 0.0f && frames_context >= 0 && proportion_threshold > 0.0f && proportion_threshold < 1.0f,
               "asv_vad_energy: mean scale %g / context %d / proportion %g", energy_mean_scale, frames_context, proportion_threshold);
   ASV_REQUIRE(frame_offsets[0] == 0, "asv_vad_energy: frame_offsets[0] must be 0");
+  ASV_ON_OWNER(feats, "asv_vad_energy");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   long long *d = nullptr;
   ASV_HIP_CHECK(hipMallocAsync(reinterpret_cast<void **>(&d), ((size_t)2 * n_utts + 1) * 8, s));
@@ -843,6 +855,7 @@ int asv_select_frames(const float *feats, const unsigned char *voiced, const lon
                       int dim, float *out, void *stream) {
   ASV_REQUIRE(feats && voiced && frame_offsets && out_offsets && out && n_utts >= 1 && dim >= 1, "asv_select_frames: bad argument");
   ASV_REQUIRE(frame_offsets[0] == 0 && out_offsets[0] == 0, "asv_select_frames: offsets must start at 0");
+  ASV_ON_OWNER(feats, "asv_select_frames");
   const long long rows = out_offsets[n_utts];
   if (rows == 0) return ASV_OK;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -865,6 +878,7 @@ int asv_select_frames(const float *feats, const unsigned char *voiced, const lon
 int asv_cmvn(float *feats, const long long *frame_offsets, int n_utts, int dim, int mean_norm, int std_norm, float eps, void *stream) {
   ASV_REQUIRE(feats && frame_offsets && n_utts >= 1 && dim >= 1, "asv_cmvn: bad argument");
   ASV_REQUIRE(frame_offsets[0] == 0, "asv_cmvn: frame_offsets[0] must be 0");
+  ASV_ON_OWNER(feats, "asv_cmvn");
   if (!mean_norm && !std_norm) return ASV_OK;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const long long *d = nullptr;

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256, CIN == 32 ? 3 : 2) void grid_conv_narrow_kerne
     conv_glds16(xg + (size_t)row * ((size_t)p.ldx * 2) + src_slot * 16, __builtin_amdgcn_readfirstlane(lds_base + piece * 1024));
   }
   const int v_taps = p.taps[lane < 9 ? lane : 0];
-  const uint4 *wf = reinterpret_cast<const uint4 *>(p.wfrag) + lane;            // fragment f at wf[f * 64]
+  const uint4 *wf = reinterpret_cast<const uint4 *>(p.wconv) + lane;            // fragment f at wf[f * 64]
 
   f32x16_t acc[2][NF];
 #pragma unroll
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void grid_conv_wide_kernel(const TdnnKernel
   }
   const int v_taps = p.taps[lane < 9 ? lane : 0];
   // weights: [tap][k-group][n-fragment][lane][8]; this wave's two fragments are n-fragments wn * 2 and wn * 2 + 1
-  const unsigned char *wbase = reinterpret_cast<const unsigned char *>(p.wfrag) + (size_t)(wn * 2) * 1024 + (size_t)lane * 16;
+  const unsigned char *wbase = reinterpret_cast<const unsigned char *>(p.wconv) + (size_t)(wn * 2) * 1024 + (size_t)lane * 16;
   auto frag_ptr = [&](int t, int kg, int j) { return wbase + ((size_t)(t * G::KG + kg) * G::NFR + j) * 1024; };
 
   f32x16_t acc[4][2];
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void grid_conv_c1_kernel(const TdnnKernelParam
 }  // namespace
 
 bool grid_conv_narrow_supported(const TdnnKernelParams &p, bool bf16) {
-  if (!bf16 || p.n_taps != 9 || p.x2 != nullptr || p.wfrag == nullptr) return false;
+  if (!bf16 || p.n_taps != 9 || p.x2 != nullptr || p.wconv == nullptr) return false;
   if (p.cin_pad != 32 && p.cin_pad != 64) return false;
   if (p.cout_store != p.cin_pad) return false;                 // the trunk's 3x3 convolutions keep the channel count
   if (p.halo > CHALO || p.rows % CBM != 0 || p.ldx % 8 != 0 || p.ldy % 4 != 0) return false;
@@ -421,7 +421,7 @@ int launch_grid_conv_narrow(const TdnnKernelParams &p, hipStream_t s) {
 }
 
 bool grid_conv_wide_supported(const TdnnKernelParams &p, bool bf16) {
-  if (!bf16 || p.n_taps != 9 || p.x2 != nullptr || p.wfrag == nullptr) return false;
+  if (!bf16 || p.n_taps != 9 || p.x2 != nullptr || p.wconv == nullptr) return false;
   if (p.cin_pad != 128 && p.cin_pad != 256) return false;
   if (p.cout_store != p.cin_pad) return false;                 // the trunk's 3x3 convolutions keep the channel count
   const int halo_max = p.cin_pad == 128 ? WideGeom<128>::HALO : WideGeom<256>::HALO;

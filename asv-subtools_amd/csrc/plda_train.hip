@@ -273,6 +273,7 @@ using namespace asv;
 extern "C" int asv_plda_train(const float *x, int ldx, int n_rows, int dim, const int *order, const long long *class_offsets, int n_classes,
                               int num_iters, double *mean_out, double *within_out, double *between_out, void *stream) {
   ASV_REQUIRE(x && order && class_offsets && mean_out && within_out && between_out, "asv_plda_train: null argument");
+  ASV_ON_OWNER(x, "asv_plda_train");
   ASV_REQUIRE(dim >= 1 && dim <= 4096 && ldx >= dim && n_classes >= 2 && num_iters >= 0, "asv_plda_train: dim %d / ld %d / classes %d / iterations %d", dim, ldx, n_classes, num_iters);
   ASV_REQUIRE(class_offsets[0] == 0 && class_offsets[n_classes] == n_rows, "asv_plda_train: class_offsets must run from 0 to n_rows");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -396,6 +397,7 @@ extern "C" int asv_plda_train(const float *x, int ldx, int n_rows, int dim, cons
 // (plda_base.py:360-367) and the covariance ZCA whitening starts from (score/whiten/train_ZCA_Whitening.py:46-47).
 extern "C" int asv_scatter_f64(const float *x, int ldx, int n_rows, int dim, double *sum_out, double *xtx_out, void *stream) {
   ASV_REQUIRE(x && sum_out && xtx_out && n_rows >= 1 && dim >= 1 && ldx >= dim, "asv_scatter_f64: bad argument");
+  ASV_ON_OWNER(x, "asv_scatter_f64");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   DevBuf d_xtx, d_sum, d_ones, partials;
   size_t partial_cap = 0;
@@ -423,6 +425,7 @@ extern "C" int asv_scatter_f64(const float *x, int ldx, int n_rows, int dim, dou
 extern "C" int asv_class_scatter_f64(const float *x, int ldx, int n_rows, int dim, const int *order, const long long *class_offsets, int n_classes,
                                      double *sum_out, double *xtx_out, double *class_scatter_out, void *stream) {
   ASV_REQUIRE(x && order && class_offsets && sum_out && xtx_out && class_scatter_out, "asv_class_scatter_f64: null argument");
+  ASV_ON_OWNER(x, "asv_class_scatter_f64");
   ASV_REQUIRE(n_rows >= 1 && dim >= 1 && ldx >= dim && n_classes >= 1, "asv_class_scatter_f64: bad sizes");
   ASV_REQUIRE(class_offsets[0] == 0 && class_offsets[n_classes] == n_rows, "asv_class_scatter_f64: class_offsets must run from 0 to n_rows");
   int rc = asv_scatter_f64(x, ldx, n_rows, dim, sum_out, xtx_out, stream);
@@ -457,6 +460,7 @@ extern "C" int asv_class_scatter_f64(const float *x, int ldx, int n_rows, int di
 extern "C" int asv_two_cov_trials(const float *enroll, int n_enroll, const float *test, int n_test, int dim, const double *gamma, const double *lambda,
                                   const double *c, const int32_t *ei, const int32_t *ti, int n_trials, double *scores, void *stream) {
   ASV_REQUIRE(enroll && test && gamma && lambda && c && ei && ti && scores, "asv_two_cov_trials: null argument");
+  ASV_ON_OWNER(enroll, "asv_two_cov_trials");
   ASV_REQUIRE(n_enroll >= 1 && n_test >= 1 && dim >= 1 && dim <= 4096 && n_trials >= 0, "asv_two_cov_trials: bad sizes");
   if (n_trials == 0) return ASV_OK;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -117,6 +117,7 @@ struct Op {
   // device parameters
   void *w = nullptr;
   void *wfrag = nullptr;         // fragment-ordered copy for the variant-3 kernel (bf16 frame layers); pooled layers: bf16 hi halves
+  void *wconv = nullptr;         // 3x3 trunk convolutions with 32 / 64 / 128 / 256 channels: fragment order of kernels_conv2d.hip
   void *wlo = nullptr;           // pooled layers in bf16 precision mode: bf16 lo halves (kernels_utts.hip)
   float *bias = nullptr, *scale = nullptr, *shift = nullptr;
   int cin_pad = 0, cout_pad = 0, cout_store = 0;
@@ -362,7 +363,7 @@ int asv_net_create(asv_net_t **out, int device, int precision, unsigned flags, i
   int ndev = 0;
   ASV_HIP_CHECK(hipGetDeviceCount(&ndev));
   ASV_REQUIRE(device >= 0 && device < ndev, "asv_net_create: device %d of %d", device, ndev);
-  ASV_HIP_CHECK(hipSetDevice(device));
+  ASV_ON_DEVICE(device);
   asv_net *net = new (std::nothrow) asv_net();
   if (!net) { set_error("out of host memory"); return ASV_ENOMEM; }
   net->device = device; net->precision = precision; net->flags = flags; net->feat_dim = feat_dim;
@@ -378,7 +379,8 @@ int asv_net_create(asv_net_t **out, int device, int precision, unsigned flags, i
 
 void asv_net_destroy(asv_net_t *net) {
   if (!net) return;
-  (void)hipSetDevice(net->device);
+  DeviceGuard guard;
+  (void)guard.enter(net->device);
   (void)hipDeviceSynchronize();
   for (void *p : net->weight_allocs) (void)hipFree(p);
   for (auto &m : net->arena) if (m.ptr) (void)hipFree(m.ptr);
@@ -467,14 +469,18 @@ int asv_net_add_tdnn(asv_net_t *net, const asv_tdnn_desc_t *d) {
   op.cout_pad = round_up(d->out_ch, kBigTileN);
   op.cout_store = round_up(d->out_ch, kChanAlign);
   ASV_REQUIRE(d->out_ch_off + op.cout_store <= net->bufs[d->out_buf].ld, "tdnn: padded output view exceeds the buffer pitch");
-  ASV_HIP_CHECK(hipSetDevice(net->device));
+  ASV_ON_DEVICE(net->device);
   {
     const size_t n = (size_t)op.cout_pad * d->n_taps * op.cin_pad;
     std::vector<unsigned char> packed(n * (bf16 ? 2 : 4));
     pack_tdnn_weight(d->weight, d->out_ch, d->in_ch, d->w_tot_context, d->w_left_context, d->taps, d->n_taps, op.cout_pad,
                      op.cin_pad, bf16, packed.data());
     if ((rc = dev_upload(net, packed.data(), packed.size(), &op.w))) return rc;
-    if (bf16 && op.cout_store > 96 && op.cin_pad >= 64) {         // candidates of the 256- / 128-channel tiles (kernels_tdnn_v3.hip)
+    // the two fragment orders are mutually exclusive per layer: a 3x3 trunk convolution the conv2d kernels take never needs
+    // the v3 order (grid_conv_* precede big3 in the dispatch and accept every such layer), and each family has its own pointer
+    const bool conv2d_pack = bf16 && net->domains[dom].kind == 2 && d->n_taps == 9 && (op.cin_pad == 32 || op.cin_pad == 64 || op.cin_pad == 128 || op.cin_pad == 256) &&
+                             d->in_ch == op.cin_pad && d->out_ch == d->in_ch;
+    if (bf16 && !conv2d_pack && op.cout_store > 96 && op.cin_pad >= 64) {         // candidates of the 256- / 128-channel tiles (kernels_tdnn_v3.hip)
       std::vector<uint16_t> frags(tdnn_weight_frag_elems(op.cout_pad, op.cin_pad, d->n_taps));
       pack_tdnn_weight_frags(d->weight, d->out_ch, d->in_ch, d->w_tot_context, d->w_left_context, d->taps, d->n_taps, op.cout_pad, op.cin_pad, frags.data());
       if ((rc = dev_upload(net, frags.data(), frags.size() * 2, &op.wfrag))) return rc;
@@ -486,8 +492,7 @@ int asv_net_add_tdnn(asv_net_t *net, const asv_tdnn_desc_t *d) {
       if ((rc = dev_upload(net, hi.data(), hi.size() * 2, &op.wfrag))) return rc;
       if ((rc = dev_upload(net, lo.data(), lo.size() * 2, &op.wlo))) return rc;
     }
-    if (bf16 && net->domains[dom].kind == 2 && d->n_taps == 9 && (op.cin_pad == 32 || op.cin_pad == 64 || op.cin_pad == 128 || op.cin_pad == 256) &&
-        d->in_ch == op.cin_pad && d->out_ch == d->in_ch) {
+    if (conv2d_pack) {
       // 3x3 trunk convolutions with 32 / 64 channels: fragment order of kernels_conv2d.hip,
       // [tap][k-group][n-fragment][lane = (k half lh, channel lr)][8], k = kg * 16 + lh * 8 + e
       const int kgs = op.cin_pad / 16, nfs = op.cin_pad / 32;
@@ -501,7 +506,7 @@ int asv_net_add_tdnn(asv_net_t *net, const asv_tdnn_desc_t *d) {
                 f32_to_bf16_host(d->weight[((size_t)co * d->in_ch + ci) * d->w_tot_context + k]);
           }
       }
-      if ((rc = dev_upload(net, frags.data(), frags.size() * 2, &op.wfrag))) return rc;
+      if ((rc = dev_upload(net, frags.data(), frags.size() * 2, &op.wconv))) return rc;
     }
     if (op.utts && (net->frames_bf16() || net->x3())) {
       // pooled-domain layers keep f32 activations; their GEMM runs on the bf16 matrix cores with every
@@ -573,7 +578,7 @@ int asv_net_add_attentive_pool(asv_net_t *net, const asv_attpool_desc_t *d) {
   ASV_REQUIRE(!(d->logit_softplus2 || d->prior_logit) || group == 1, "attentive pool: the xi-vector options need per-channel logits");
   Op op; op.kind = OP_ATTPOOL; op.att = *d;
   if (d->prior_logit) {                                         // parked in the scale / shift slots of the op
-    ASV_HIP_CHECK(hipSetDevice(net->device));
+    ASV_ON_DEVICE(net->device);
     if ((rc = upload_padded(net, d->prior_logit, d->channels, round_up(d->channels, kChanAlign), 0.0f, &op.scale))) return rc;
     if ((rc = upload_padded(net, d->prior_value, d->channels, round_up(d->channels, kChanAlign), 0.0f, &op.shift))) return rc;
   }
@@ -592,7 +597,7 @@ int asv_net_add_lde_pool(asv_net_t *net, const asv_lde_desc_t *d) {
   ASV_REQUIRE(d->out_ch_off >= 0 && d->out_ch_off + d->channels * d->n_centres <= net->bufs[d->out_buf].channels, "lde pool: output view exceeds buffer");
   ASV_REQUIRE(net->bufs[d->x_buf].domain == ASV_DOMAIN_FRAMES && net->is_utts(net->bufs[d->out_buf].domain), "lde pool: frames -> utts");
   Op op; op.kind = OP_LDE; op.lde = *d;
-  ASV_HIP_CHECK(hipSetDevice(net->device));
+  ASV_ON_DEVICE(net->device);
   const int n = d->channels * d->n_centres;
   if ((rc = upload_padded(net, d->mu, n, round_up(n, kChanAlign), 0.0f, &op.scale))) return rc;
   if ((rc = upload_padded(net, d->beta, d->n_centres, 64, 0.0f, &op.shift))) return rc;
@@ -615,7 +620,7 @@ int asv_net_add_res2(asv_net_t *net, const asv_res2_desc_t *d) {
               "res2: frames-domain input and a different frames-domain output buffer");
   ASV_REQUIRE(d->in_ch_off % 8 == 0 && d->out_ch_off % 8 == 0, "res2: channel offsets must be multiples of 8 (16-byte rows pieces)");
   Op op; op.kind = OP_RES2; op.res2 = *d;
-  ASV_HIP_CHECK(hipSetDevice(net->device));
+  ASV_ON_DEVICE(net->device);
   const int W = kRes2Width, tot = 2 * d->dilation + 1;
   const int taps[3] = {-d->dilation, 0, d->dilation};
   const size_t per_branch = tdnn_weight_frag_elems(W, W, 3);
@@ -661,7 +666,7 @@ int asv_net_add_eltwise(asv_net_t *net, const asv_eltwise_desc_t *d) {
     ASV_REQUIRE(d->out2_ch_off + round_up(d->channels, vec) <= net->bufs[d->out2_buf].ld, "eltwise: padded second view exceeds pitch");
   }
   Op op; op.kind = OP_ELTWISE; op.elt = *d; op.utts = net->is_utts(dom);
-  ASV_HIP_CHECK(hipSetDevice(net->device));
+  ASV_ON_DEVICE(net->device);
   if (d->scale) {
     const int n_pad = round_up(d->channels, kChanAlign);
     if ((rc = upload_padded(net, d->scale, d->channels, n_pad, 0.0f, &op.scale))) return rc;
@@ -865,7 +870,7 @@ int asv_net_set_profiling(asv_net_t *net, int enable) {
 
 int asv_net_get_profile(asv_net_t *net, asv_kernel_time_t *rows, int cap, int *n_rows) {
   ASV_REQUIRE(net && rows && n_rows && cap >= 1, "asv_net_get_profile: bad arguments");
-  ASV_HIP_CHECK(hipSetDevice(net->device));
+  ASV_ON_DEVICE(net->device);
   std::map<std::pair<int, int>, asv_kernel_time_t> agg;      // (kernel class, op or -1)
   for (auto &st : net->stamps) {
     ASV_HIP_CHECK(hipEventSynchronize(st.b));
@@ -1034,7 +1039,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         for (int t = 0; t < d.n_taps; ++t) { p.taps[t] = d.taps[t]; p.halo = std::max(p.halo, std::abs(d.taps[t])); }
         p.act1 = d.act1; p.act2 = d.act2; p.affine_first = d.affine_first;
         p.zero16 = net->zero_page;
-        p.wfrag = op.wfrag; p.wlo = op.wlo;
+        p.wfrag = op.wfrag; p.wlo = op.wlo; p.wconv = op.wconv;
         if (op.chain_last >= 0 && !use_ref && bf16 && p.halo <= kHalo && (net->flags & ASV_FLAG_SMALL_TILES) == 0 &&
             (unsigned long long)p.rows * (unsigned long long)p.ldx * 2ull < (1ull << 32)) {
           // tdnn -> [1-tap]* -> 1-tap + pooling in one kernel, if the batch allows the fused pooling (no crowd of tiny utterances)
@@ -1358,7 +1363,7 @@ extern "C" {
 int asv_net_extract(asv_net_t *net, const float *feats, const int32_t *offsets, int n_utts, float *out, int max_chunk, void *stream) {
   ASV_REQUIRE(net && net->finalized, "asv_net_extract: net is null or not finalized");
   ASV_REQUIRE(feats && out, "asv_net_extract: null feature or output pointer");
-  ASV_HIP_CHECK(hipSetDevice(net->device));
+  ASV_ON_DEVICE(net->device);
   RunCtx c;
   c.net = net; c.s = reinterpret_cast<hipStream_t>(stream);
   int rc;

@@ -30,15 +30,9 @@ struct Workspace {
   }
 };
 
-// Every entry point runs on the device that owns its (first) device pointer, whatever the caller's current device is.
-int enter_device_of(const void *dev_ptr) {
-  hipPointerAttribute_t attr;
-  ASV_HIP_CHECK(hipPointerGetAttributes(&attr, dev_ptr));
-  ASV_REQUIRE(attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged, "scoring: pointer %p is not device memory", dev_ptr);
-  ASV_HIP_CHECK(hipSetDevice(attr.device));
-  return ASV_OK;
-}
-#define ASV_ENTER(ptr) do { int _rc = enter_device_of(ptr); if (_rc) return _rc; } while (0)
+// Every entry point runs on the device that owns its (first) device pointer, whatever the caller's current device is, and
+// restores the caller's current device when it returns (asv_internal.h DeviceGuard).
+#define ASV_ENTER(ptr) ASV_ON_OWNER(ptr, "scoring")
 
 __global__ __launch_bounds__(256) void col_mean_kernel(const float *x, int n, int dim, float *mean) {
   // one block per 64 columns; lanes along columns, 4 waves stride the rows

@@ -15,6 +15,7 @@ All functions take host numpy arrays or CUDA torch tensors; results stay on the 
 
 import ctypes as C
 import math
+import os
 
 import numpy as np
 
@@ -43,14 +44,34 @@ def _stream(t):
     return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
-def _check_index(idx, n, what):
-    """Trial indices address device rows directly (`enroll + ei * dim`): reject anything outside [0, n) here, on the
-    device (one reduction + one scalar read-back), instead of reading out of bounds in the kernel."""
-    if idx.numel() == 0:
-        return
-    lo, hi = int(idx.min().item()), int(idx.max().item())
-    if lo < 0 or hi >= n:
-        raise ValueError("%s: trial index range [%d, %d] outside the %d vectors" % (what, lo, hi, n))
+def _debug_checks():
+    return os.environ.get("ASV_AMD_DEBUG_CHECKS", "0") not in ("0", "", "false")
+
+
+def _trial_indices(enroll_idx, n_enroll, test_idx, n_test, device, what):
+    """Trial indices address device rows directly (`enroll + ei * dim`): anything outside [0, n) is rejected BEFORE a kernel
+    can read out of bounds.  A trial list is host data in every caller of the reference chain (it is parsed from the trials
+    file): it is validated here on the host - numpy, no device work, no synchronisation - and then uploaded, so scoring
+    stays asynchronous on the stream.  Lists that already live on the device are checked with ONE combined reduction and ONE
+    read-back for both of them."""
+    import torch
+    pairs = ((enroll_idx, n_enroll, "enrol"), (test_idx, n_test, "test"))
+    on_device = [isinstance(i, torch.Tensor) and i.is_cuda for i, _, _ in pairs]
+    for (idx, n, side), dev_side in zip(pairs, on_device):
+        if dev_side:
+            continue
+        a = idx.numpy() if isinstance(idx, torch.Tensor) else np.asarray(idx)
+        if a.size and (int(a.min()) < 0 or int(a.max()) >= n):
+            raise ValueError("%s (%s): trial index range [%d, %d] outside the %d vectors" % (what, side, int(a.min()), int(a.max()), n))
+    ei, ti = _dev(enroll_idx, torch.int32, device), _dev(test_idx, torch.int32, device)
+    dev_lists = [(t, n, side) for t, (_, n, side), d in zip((ei, ti), pairs, on_device) if d and t.numel()]
+    if dev_lists:
+        stats = torch.stack([x for t, _, _ in dev_lists for x in (t.min(), t.max())]).cpu().tolist()      # one read-back
+        for k, (_, n, side) in enumerate(dev_lists):
+            lo, hi = int(stats[2 * k]), int(stats[2 * k + 1])
+            if lo < 0 or hi >= n:
+                raise ValueError("%s (%s): trial index range [%d, %d] outside the %d vectors" % (what, side, lo, hi, n))
+    return ei, ti
 
 
 def mean_vector(x):
@@ -86,9 +107,7 @@ def score_trials(enroll, test, enroll_idx, test_idx):
     """Dot product per trial (ivector-compute-dot-products over a trial list)."""
     import torch
     e, t = _dev(enroll, torch.float32), _dev(test, torch.float32)
-    ei, ti = _dev(enroll_idx, torch.int32, e.device), _dev(test_idx, torch.int32, e.device)
-    _check_index(ei, e.shape[0], "score_trials (enrol)")
-    _check_index(ti, t.shape[0], "score_trials (test)")
+    ei, ti = _trial_indices(enroll_idx, e.shape[0], test_idx, t.shape[0], e.device, "score_trials")
     out = torch.empty(ei.shape[0], dtype=torch.float32, device=e.device)
     capi.check(capi.lib().asv_dot_score_trials(_ptr(e), _ptr(t), e.shape[1], _ptr(ei), _ptr(ti), ei.shape[0], _ptr(out), _stream(e)), "asv_dot_score_trials")
     return out
@@ -158,11 +177,11 @@ def score_normalize(scores, enroll_cohort, test_cohort, enroll_idx, test_idx, to
     s = _dev(scores, torch.float32)
     ec, tc = _dev(enroll_cohort, torch.float32, s.device), _dev(test_cohort, torch.float32, s.device)
     assert ec.dim() == 2 and tc.dim() == 2 and ec.shape[1] == tc.shape[1], "cohort score matrices must share the cohort axis"
-    ei, ti = _dev(enroll_idx, torch.int32, s.device), _dev(test_idx, torch.int32, s.device)
+    ei, ti = _trial_indices(enroll_idx, ec.shape[0], test_idx, tc.shape[0], s.device, "score_normalize")
     assert ei.shape[0] == s.shape[0] == ti.shape[0]
-    _check_index(ei, ec.shape[0], "score_normalize (enrol)")
-    _check_index(ti, tc.shape[0], "score_normalize (test)")
-    if bool(torch.isnan(ec).any().item()) or bool(torch.isnan(tc).any().item()):
+    # two full passes + two blocking read-backs: debug switch only (ASV_AMD_DEBUG_CHECKS=1); cohort scores are dot products of
+    # finite, length-normalised vectors in every caller of this module
+    if _debug_checks() and (bool(torch.isnan(ec).any().item()) or bool(torch.isnan(tc).any().item())):
         raise ValueError("score_normalize: NaN in the cohort scores (pandas would propagate it into every statistic; the device "
                          "selection orders keys and would silently skip it)")
     out = torch.empty_like(s)
@@ -266,10 +285,8 @@ class Plda(object):
         e, t = _dev(enroll_t, torch.float32), _dev(test_t, torch.float32)
         dev = e.device
         psi = _dev(self.psi.astype(np.float32), device=dev)
-        ei, ti = _dev(enroll_idx, torch.int32, dev), _dev(test_idx, torch.int32, dev)
+        ei, ti = _trial_indices(enroll_idx, e.shape[0], test_idx, t.shape[0], dev, "llr_trials")
         en = _dev(enroll_num_utts, torch.int32, dev) if enroll_num_utts is not None else None
-        _check_index(ei, e.shape[0], "llr_trials (enrol)")
-        _check_index(ti, t.shape[0], "llr_trials (test)")
         if en is not None and en.shape[0] != e.shape[0]:
             raise ValueError("llr_trials: %d enrolment vectors but %d num_utts entries" % (e.shape[0], en.shape[0]))
         out = torch.empty(ei.shape[0], dtype=torch.float32, device=dev)
@@ -306,9 +323,7 @@ class TwoCovPlda(object):
         """float64 device tensor [n_trials]."""
         import torch
         e, t = _dev(enroll, torch.float32), _dev(test, torch.float32)
-        ei, ti = _dev(enroll_idx, torch.int32, e.device), _dev(test_idx, torch.int32, e.device)
-        _check_index(ei, e.shape[0], "two_cov (enrol)")
-        _check_index(ti, t.shape[0], "two_cov (test)")
+        ei, ti = _trial_indices(enroll_idx, e.shape[0], test_idx, t.shape[0], e.device, "two_cov")
         if e.shape[1] != self.dim or t.shape[1] != self.dim:
             raise ValueError("two_cov: %d-dimensional model, vectors of %d / %d" % (self.dim, e.shape[1], t.shape[1]))
         out = torch.empty(ei.shape[0], dtype=torch.float64, device=e.device)

@@ -75,11 +75,30 @@ def gather_embeddings(local, local_indices, shards, group=None):
     return out
 
 
+def _agree_or_raise(err, embed_dim, device, group, rank, world):
+    """One tiny all-reduce (MAX over [failed, E]) in front of the gather: a rank whose read or extraction failed must not leave
+    the others blocked in the all-gather until the collective's timeout, and a rank without utterances learns the
+    embedding width from the others.  Every rank raises when any rank failed."""
+    import torch
+    import torch.distributed as dist
+    flag = torch.tensor([1 if err is not None else 0, int(embed_dim)], dtype=torch.int64, device=device if device is not None else "cpu")
+    if world > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    failed, width = (int(v) for v in flag.cpu().tolist())
+    if err is not None:
+        raise err
+    if failed:
+        raise RuntimeError("sharded extraction: another rank failed (this is rank %d of %d); see its log" % (rank, world))
+    return width
+
+
 def extract_sharded(extract_batch, lengths, load_utt, max_frames=65536, max_utts=1024, group=None, device=None):
     """Full sharded extraction.
         extract_batch(list_of_mats) -> [b, E] tensor on `device`     (e.g. Engine.extract_device wrapper)
         load_utt(i) -> [T_i, D] float32 matrix of utterance i          (only called for this rank's shard)
-    Returns [n_total, E] (original order) on every rank."""
+    Returns [n_total, E] (original order) on every rank.  A rank with an empty shard (more ranks than utterances) contributes
+    zero rows; a rank whose read / extraction raises makes EVERY rank raise before the all-gather (no rank is left waiting in a
+    collective)."""
     import torch
     import torch.distributed as dist
     inited = dist.is_available() and dist.is_initialized()
@@ -87,13 +106,18 @@ def extract_sharded(extract_batch, lengths, load_utt, max_frames=65536, max_utts
     world = dist.get_world_size(group) if inited else 1
     shards = balance_by_length(lengths, world)
     mine = shards[rank]
-    outs = []
-    for batch in plan_batches(lengths, mine, max_frames, max_utts):
-        outs.append(extract_batch([load_utt(i) for i in batch]))
-    if outs:
-        local = torch.cat(outs, dim=0)
-    else:
-        raise ValueError("rank %d received no utterances (more ranks than utterances)" % rank)
+    outs, err = [], None
+    try:
+        for batch in plan_batches(lengths, mine, max_frames, max_utts):
+            outs.append(extract_batch([load_utt(i) for i in batch]))
+    except Exception as e:                            # reported to every rank below, then re-raised here
+        err = e
+    local = torch.cat(outs, dim=0) if (outs and err is None) else None
+    width = _agree_or_raise(err, local.shape[1] if local is not None else 0, device, group, rank, world)
+    if local is None:
+        if width == 0:
+            raise ValueError("sharded extraction: no utterances at all")
+        local = torch.zeros((0, width), dtype=torch.float32)
     if device is not None:
         local = local.to(device)
     return gather_embeddings(local, mine, shards, group=group)

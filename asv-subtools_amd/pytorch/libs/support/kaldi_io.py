@@ -96,13 +96,25 @@ class _PipeWriter(io.RawIOBase):
     def close(self):
         if self.closed:
             return
+        # Whatever the flush does (BrokenPipeError once the child has died), the child's stdin is closed BEFORE waiting for
+        # it - a live child would otherwise never see end-of-file and wait() would hang - and a failed child is reported as
+        # SubprocessFailed with its exit status, the write error chained behind it.
+        err = None
         try:
             io.RawIOBase.close(self)                  # flushes, marks closed
-            self._stream.close()
+        except OSError as e:
+            err = e
         finally:
-            ret = self._proc.wait()
+            try:
+                self._stream.close()
+            except OSError as e:
+                err = err or e
+            finally:
+                ret = self._proc.wait()
         if ret != 0:
-            raise SubprocessFailed("cmd %s returned %d !" % (self._cmd, ret))
+            raise SubprocessFailed("cmd %s returned %d !" % (self._cmd, ret)) from err
+        if err is not None:
+            raise err
 
 
 def popen(cmd, mode="rb"):

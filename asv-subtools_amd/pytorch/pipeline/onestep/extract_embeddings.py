@@ -25,6 +25,7 @@ vectors in scp order.
 
 import argparse
 import os
+import re
 import sys
 import traceback
 
@@ -146,23 +147,53 @@ def read_scp(path):
         return [tuple(line.strip().split(None, 1)) for line in f if line.strip()]
 
 
+_RANGE = re.compile(r"\[([0-9]*):?([0-9]*)(?:,([0-9]*):?([0-9]*))?\]$")
+
+
+def split_range(rxfile):
+    """Kaldi scp range specifier 'file.ark:123[r0:r1]' / '[r0:r1,c0:c1]' (both ends inclusive, either part may be empty) ->
+    (rxfile without it, row slice, column slice).  The nj-job splits of the reference go through Kaldi's copy-feats, which
+    accepts such entries."""
+    m = _RANGE.search(rxfile)
+    if not m:
+        return rxfile, slice(None), slice(None)
+    def sl(a, b):
+        return slice(int(a) if a else None, int(b) + 1 if b else None)
+    body = rxfile[:m.start()]
+    return body, sl(m.group(1), m.group(2)), sl(m.group(3), m.group(4))
+
+
+def read_matrix(rxfile):
+    """float32 matrix behind an scp entry, range specifier applied."""
+    body, rows, cols = split_range(rxfile)
+    return np.ascontiguousarray(kaldi_io.read_mat(body)[rows, cols], dtype=np.float32)
+
+
 def matrix_rows(rxfile):
-    """Number of rows of the matrix behind an scp entry, from its header only (FM / DM / CM), or by decoding it (text)."""
+    """Number of rows of the matrix behind an scp entry, from its header only (FM / DM / CM / CM2 / CM3 - the compressed
+    formats share the GlobalHeader), or by decoding it (text); a range specifier is applied to the count."""
     import struct
-    fd = kaldi_io.open_or_fd(rxfile, "rb")
+    body, rows, _ = split_range(rxfile)
+    fd = kaldi_io.open_or_fd(body, "rb")
     try:
         head = fd.read(2)
         if head != b"\0B":
             fd.close()
-            return int(kaldi_io.read_mat(rxfile).shape[0])
-        tag = fd.read(3)
-        if tag in (b"FM ", b"DM "):
-            return struct.unpack("<bibi", fd.read(10))[1]
-        if tag == b"CM ":
-            return struct.unpack("<ffii", fd.read(16))[2]
-        raise kaldi_io.UnknownMatrixHeader("The header contained '%s'" % tag)
+            n = int(kaldi_io.read_mat(body).shape[0])
+        else:
+            tag = fd.read(3)
+            if tag in (b"FM ", b"DM "):
+                n = struct.unpack("<bibi", fd.read(10))[1]
+            elif tag == b"CM ":
+                n = struct.unpack("<ffii", fd.read(16))[2]
+            elif tag in (b"CM2", b"CM3"):
+                fd.read(1)                                # the space behind the 3-letter token
+                n = struct.unpack("<ffii", fd.read(16))[2]
+            else:
+                raise kaldi_io.UnknownMatrixHeader("The header contained '%s'" % tag)
     finally:
         fd.close()
+    return len(range(*rows.indices(n)))
 
 
 def extract_sharded_scp(extract_batch, entries, lengths, w, batch_frames, batch_utts, verbose=False, device=None):
@@ -173,7 +204,7 @@ def extract_sharded_scp(extract_batch, entries, lengths, w, batch_frames, batch_
     import torch.distributed as dist
     from libs.amd import shard
     rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
-    load = lambda i: np.ascontiguousarray(kaldi_io.read_mat(entries[i][1]), dtype=np.float32)
+    load = lambda i: read_matrix(entries[i][1])
     emb = shard.extract_sharded(extract_batch, lengths, load, max_frames=batch_frames, max_utts=batch_utts, device=device)
     if rank == 0:
         keys = [k for k, _ in entries]

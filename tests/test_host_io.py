@@ -315,3 +315,33 @@ print("REF-OK")
     buf = np.empty((64, cols), np.float32)
     keys, offs, n = rd.read_group(buf)
     assert keys == ["cm"] and np.array_equal(buf[:n], np.load(tmp_path / "ref_cm.npy"))
+
+
+def test_matrix_rows_reads_compressed_headers_and_scp_ranges(tmp_path):
+    """the length pass of --sharded reads rows from the header of FM / CM / CM2 / CM3 matrices (the compressed
+    formats share the GlobalHeader) and honours Kaldi's scp range specifiers."""
+    import struct
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("extract_embeddings_script", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "asv-subtools_amd", "pytorch",
+                                                                                          "pipeline", "onestep", "extract_embeddings.py"))
+    X = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(X)
+    from libs.support import kaldi_io as K
+    m = np.arange(35, dtype=np.float32).reshape(7, 5)
+    fm = tmp_path / "fm.ark"
+    with open(fm, "wb") as f:
+        f.write(b"u ")
+        off = f.tell()
+        K.write_mat(f, m)
+    rx = "%s:%d" % (fm, off)
+    assert X.matrix_rows(rx) == 7
+    assert X.matrix_rows(rx + "[2:4]") == 3 and X.matrix_rows(rx + "[:3]") == 4 and X.matrix_rows(rx + "[5:]") == 2
+    assert np.array_equal(X.read_matrix(rx + "[2:4]"), m[2:5]) and np.array_equal(X.read_matrix(rx + "[1:2,0:1]"), m[1:3, 0:2])
+    for tag in (b"CM ", b"CM2 ", b"CM3 "):
+        p = tmp_path / ("c%d.ark" % len(tag))
+        with open(p, "wb") as f:
+            f.write(b"u ")
+            off = f.tell()
+            f.write(b"\0B" + tag + struct.pack("<ffii", 0.0, 1.0, 11, 4))
+        assert X.matrix_rows("%s:%d" % (p, off)) == 11
+        assert X.matrix_rows("%s:%d[3:9]" % (p, off)) == 7

@@ -82,3 +82,47 @@ def test_single_process_gather_is_a_permutation():
     out = shard.gather_embeddings(local, shards[0], shards)
     # local row j holds utterance shards[0][j]
     assert [int(out[i, 0]) for i in shards[0]] == [0, 1, 2, 3]
+
+
+def _worker_edge(rank, world, port, lengths, out_dir, fail_rank):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from libs.amd import synth
+
+        def load(i):
+            if rank == fail_rank:
+                raise IOError("rank %d cannot read utterance %d" % (rank, i))
+            return synth.synth_feats(int(lengths[i]), 8, 100 + i)
+        extract = lambda mats: torch.from_numpy(np.stack([_fake_embedding(m) for m in mats]))
+        try:
+            out = shard.extract_sharded(extract, lengths, load, max_frames=2000, max_utts=4)
+            np.save(os.path.join(out_dir, "rank%d.npy" % rank), out.numpy())
+        except Exception as e:
+            with open(os.path.join(out_dir, "rank%d.err" % rank), "w") as f:
+                f.write("%s: %s" % (type(e).__name__, e))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_more_ranks_than_utterances_contributes_empty_shards(tmp_path):
+    """a rank without utterances adds zero rows to the gather instead of raising in front of the collective."""
+    import torch.multiprocessing as mp
+    from libs.amd import synth
+    lengths = np.array([50, 30])
+    mp.spawn(_worker_edge, args=(3, _free_port(), lengths, str(tmp_path), -1), nprocs=3, join=True)
+    want = np.stack([_fake_embedding(synth.synth_feats(int(n), 8, 100 + i)) for i, n in enumerate(lengths)])
+    for r in range(3):
+        assert np.array_equal(np.load(tmp_path / ("rank%d.npy" % r)), want), "rank %d" % r
+
+
+def test_a_failing_rank_makes_every_rank_raise_before_the_gather(tmp_path):
+    """a per-rank read error is agreed on with one tiny all-reduce; nobody waits in the all-gather for a timeout."""
+    import torch.multiprocessing as mp
+    lengths = np.random.RandomState(6).randint(20, 100, size=9)
+    mp.spawn(_worker_edge, args=(2, _free_port(), lengths, str(tmp_path), 1), nprocs=2, join=True)
+    e0, e1 = (tmp_path / "rank0.err").read_text(), (tmp_path / "rank1.err").read_text()
+    assert e1.startswith("OSError: rank 1 cannot read") and "another rank failed" in e0, (e0, e1)
