@@ -121,6 +121,11 @@ struct TdnnKernelParams {
   int tune;             // experiment knobs of the variant-3 kernel (tools/gemm_ablate): priorities / start stagger
   int big_one_per_cu;   // variant-3 kernel: 256x256 tiles, one workgroup per CU (default: 128x256, two per CU)
   int halo;             // max |tap offset| of this layer (selects the window size of the 128x128 kernel)
+  int x3_et, x3_terms;  // f32x kernel (kernels_tdnn_x3.hip): 16-bit type of the operand halves (ET_BF16 / ET_F16) and which products run -
+                        // bit 0: w_hi x_hi, bit 1: w_hi x_lo, bit 2: w_lo x_hi (7 = the f32-grade mode; the others are the measured
+                        // "why not two matrix instructions" variants)
+  float w_unscale;      // f32x kernel: the accumulators are multiplied by this (1 / the power of two the host scaled the weights by)
+  int et;               // ET_*: element type of x / x2 / res / y rows and of the packed weights (the launchers without an `et` argument read it)
 };
 
 struct PoolKernelParams {
@@ -134,23 +139,27 @@ struct PoolKernelParams {
   int row_stride, groups;
 };
 
-// launchers (kernels_*.hip).  ElemBF16: activations are bf16 (else f32).
-int launch_tdnn_mfma(const TdnnKernelParams &p, bool bf16, bool out_f32, hipStream_t s);
-int launch_tdnn_ref(const TdnnKernelParams &p, bool bf16, bool out_f32, hipStream_t s);
+// Element type of frames-domain storage and of the matrix operands: the launchers' `et` argument (a former `bool bf16`
+// converts to the first two values).
+enum : int { ET_F32 = 0, ET_BF16 = 1, ET_F16 = 2 };
+
+// launchers (kernels_*.hip).  et: element type of the activations (ET_*).
+int launch_tdnn_mfma(const TdnnKernelParams &p, int et, bool out_f32, hipStream_t s);
+int launch_tdnn_ref(const TdnnKernelParams &p, int et, bool out_f32, hipStream_t s);
 int launch_utts_gemm(const TdnnKernelParams &p, int rows_valid, bool split, hipStream_t s);
 // kernels_conv2d.hip: 3x3 grid convolutions with 32 / 64 channels (weights in p.wfrag, [tap][k-group][n-frag][lane][8])
-bool grid_conv_narrow_supported(const TdnnKernelParams &p, bool bf16);
+bool grid_conv_narrow_supported(const TdnnKernelParams &p, int et);
 size_t grid_conv_frag_elems(int cin_pad, int cout_pad32);
 int launch_grid_conv_narrow(const TdnnKernelParams &p, hipStream_t s);
-bool grid_conv_wide_supported(const TdnnKernelParams &p, bool bf16);      // the C = 128 / 256 stages (same fragment order)
+bool grid_conv_wide_supported(const TdnnKernelParams &p, int et);      // the C = 128 / 256 stages (same fragment order)
 int launch_grid_conv_wide(const TdnnKernelParams &p, hipStream_t s);
-bool grid_conv_c1_supported(const TdnnKernelParams &p, bool bf16, int in_ch);
+bool grid_conv_c1_supported(const TdnnKernelParams &p, int et, int in_ch);
 int launch_grid_conv_c1(const TdnnKernelParams &p, hipStream_t s);
-int launch_splitk_epilogue(const TdnnKernelParams &p, bool bf16, bool out_f32, hipStream_t s);
+int launch_splitk_epilogue(const TdnnKernelParams &p, int et, bool out_f32, hipStream_t s);
 // 256-channel tiles of the bf16 frame-layer kernel (kernels_tdnn_v3.hip): weights are padded to kBigTileN output channels
 constexpr int kBigTileN = 256;
 // variant 3: feature window via LDS-DMA ring, weight fragments straight from L2 (kernels_tdnn_v3.hip)
-bool tdnn_big3_supported(const TdnnKernelParams &p, bool bf16, bool out_f32);
+bool tdnn_big3_supported(const TdnnKernelParams &p, int et, bool out_f32);
 int launch_tdnn_big3(const TdnnKernelParams &p, hipStream_t s);
 int launch_tdnn_big3_variant(const TdnnKernelParams &p, int variant, hipStream_t s);
 // tdnn -> [1-tap 512 -> 512]* -> 1-tap + fused statistics pooling in one kernel, the 128 x 512 intermediate tiles resident in
@@ -165,6 +174,7 @@ struct TdnnChainParams {
   TdnnChainLayer first; int n_mid; TdnnChainLayer mid[2]; TdnnChainLayer last;
   float *pool_partial; int pool_slots, ld_partial; const int32_t *row_seg;    // as in TdnnKernelParams
   unsigned long long *dbg;      // developer aid (ASV_AMD_CHAIN_DBG=1): [workgroup][wave][16] s_memtime stamps at the phase boundaries, or nullptr
+  int et;                       // ET_BF16 / ET_F16: element type of the rows and of every layer's weight fragments
 };
 int launch_tdnn_chain(const TdnnChainParams &p, hipStream_t s);
 // ECAPA Res2NetBlock as one kernel (kernels_res2.hip)
@@ -176,15 +186,16 @@ struct Res2KernelParams {
   const uint32_t *row_valid;
   int branches, dilation;
   unsigned long long *dbg;      // developer aid (ASV_AMD_RES2_DBG=1): [workgroup][wave][16] s_memtime stamps, or nullptr
+  int et;                       // ET_BF16 / ET_F16
 };
 int launch_res2_chain(const Res2KernelParams &p, hipStream_t s);
 void pack_tdnn_weight_frags(const float *w, int out_ch, int in_ch, int tot_ctx, int left_ctx, const int *taps, int n_taps,
-                            int cout_pad, int cin_pad, uint16_t *dst, uint16_t *dst_lo = nullptr);
+                            int cout_pad, int cin_pad, uint16_t *dst, uint16_t *dst_lo = nullptr, int et = ET_BF16, float scale = 1.0f);
 // f32-grade split-bf16 kernel of the f32x precision mode (kernels_tdnn_x3.hip): f32 activations, hi / lo weight fragments
 bool tdnn_x3_supported(const TdnnKernelParams &p);
 int launch_tdnn_x3(const TdnnKernelParams &p, hipStream_t s);
 size_t tdnn_weight_frag_elems(int cout_pad, int cin_pad, int n_taps);
-int launch_stats_pool(const PoolKernelParams &p, int segments, bool bf16, hipStream_t s);
+int launch_stats_pool(const PoolKernelParams &p, int segments, int et, hipStream_t s);
 // second half of the fused pooling: adds each segment's half-tile partials in row order, adds the BN shift
 // back to the mean and writes mean || std like stats_pool_kernel
 struct PoolFinishParams {
@@ -199,14 +210,14 @@ struct PoolFinishParams {
 int launch_pool_finish(const PoolFinishParams &p, int segments, hipStream_t s);
 int launch_attentive_pool(const void *x, int ldx, const void *logits, int ldl, int channels,
                           const int32_t *seg_row0, const int32_t *seg_len, int segments, float eps,
-                          float *out, int ld_out, bool bf16, int group, int softplus2, const float *prior_logit, const float *prior_value,
+                          float *out, int ld_out, int et, int group, int softplus2, const float *prior_logit, const float *prior_value,
                           hipStream_t s);
 // row r of a segment is valid iff (r - row0) % pitch < width (frames domain: pitch = width = 1)
 int launch_rowmap(const int32_t *seg_row0, const int32_t *seg_len, int segments, int rows, int pitch, int width,
                   int32_t *row_seg, uint32_t *row_valid, hipStream_t s);
 // frames-domain feature rows [t][f] -> grid rows (t*pitch + f) with one channel (pitch of `out` = ldo)
 int launch_grid_from_frames(const void *x, int ldx, int feat_dim, const int32_t *fr_row0, const int32_t *g_row0, const int32_t *g_row_seg,
-                            const uint32_t *g_row_valid, int g_rows, int pitch, void *out, int ldo, bool bf16, hipStream_t s);
+                            const uint32_t *g_row_valid, int g_rows, int pitch, void *out, int ldo, int et, hipStream_t s);
 // im2col gather between grid domains: out[(t',f')][k*C + c] = in[(stride*t'+dt_k, stride*f'+df_k)][c] or 0
 struct Im2colParams {
   const void *in; void *out; int ldi, ldo, channels, n_taps, stride;
@@ -214,11 +225,11 @@ struct Im2colParams {
   const int32_t *in_row0, *in_len, *out_row0, *out_row_seg; const uint32_t *out_row_valid;
   int in_pitch, in_width, out_pitch, out_rows;
 };
-int launch_im2col(const Im2colParams &p, bool bf16, hipStream_t s);
+int launch_im2col(const Im2colParams &p, int et, hipStream_t s);
 int launch_pack_input(const float *feats, int feat_dim, const int32_t *seg_src0, const int32_t *seg_row0,
-                      const int32_t *row_seg, int rows, void *x, int ldx, bool bf16, hipStream_t s);
+                      const int32_t *row_seg, int rows, void *x, int ldx, int et, hipStream_t s);
 int launch_unpack_rows(const void *y, int ldy, int channels, const int32_t *seg_src0, const int32_t *seg_row0,
-                       const int32_t *row_seg, int rows, float *out, bool bf16, hipStream_t s);
+                       const int32_t *row_seg, int rows, float *out, int et, hipStream_t s);
 int launch_combine(const float *seg_emb, int ld_seg, const int32_t *utt_seg0, const int32_t *utt_nseg,
                    const int32_t *seg_len, int n_utts, int embed_dim, float *out, hipStream_t s);
 struct EltwiseKernelParams {
@@ -232,12 +243,12 @@ struct EltwiseKernelParams {
   const void *d; void *out2; int ldd, ldo2;              // second output: out2 = (out as stored) + d, or nullptr
 };
 int launch_lde_pool(const void *x, int ldx, int channels, int rows, const float *mu, const float *beta, int n_centres, float *weights,
-                    const int32_t *seg_row0, const int32_t *seg_len, int segments, float *out, int ld_out, bool bf16, hipStream_t s);
-int launch_eltwise(const EltwiseKernelParams &p, bool bf16, hipStream_t s);
+                    const int32_t *seg_row0, const int32_t *seg_len, int segments, float *out, int ld_out, int et, hipStream_t s);
+int launch_eltwise(const EltwiseKernelParams &p, int et, hipStream_t s);
 
 // weight packing (host): dense checkpoint kernel -> [cout_pad][n_taps][cin_pad] in element type
 void pack_tdnn_weight(const float *w, int out_ch, int in_ch, int tot_ctx, int left_ctx, const int *taps,
-                      int n_taps, int cout_pad, int cin_pad, bool bf16, void *dst);
-uint16_t f32_to_bf16_host(float f);
+                      int n_taps, int cout_pad, int cin_pad, int et, void *dst);
+// f32 <-> bf16 / IEEE half on the host: host_convert.h
 
 }  // namespace asv

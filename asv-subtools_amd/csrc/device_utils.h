@@ -13,6 +13,14 @@ typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4_t;
 
 __host__ __device__ __forceinline__ int round_up_dev(int x, int m) { return (x + m - 1) / m * m; }
 
+// Element type of frames-domain storage and of the MFMA operands.  As a template argument it takes the place of the former
+// `bool BF16` (false = 0 = f32, true = 1 = bf16); 2 = IEEE half: the same matrix rate and footprint as bf16 with an 11-bit
+// significand (8x less operand rounding), range +-65504 - activations behind eval BatchNorm and CMN'd features are O(1..100);
+// a value beyond the range becomes inf and the embedding NaN (loud, never silently saturated).
+// (the enum lives in asv_internal.h: the host runtime passes it to the launchers)
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 asv_f16x2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
 
 // f32 -> bf16, round-to-nearest-even: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32, two values per
@@ -28,20 +36,72 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 
 __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) { return pack_bf16x2(f, 0.0f) & 0xffffu; }
 
-// elementwise add of two 16-byte pieces holding 8 bf16 (f32 add, RNE back to bf16)
-__device__ __forceinline__ uint4 add_bf16x8(uint4 a, uint4 b) {
-  uint4 r;
-  const uint32_t *pa = reinterpret_cast<const uint32_t *>(&a);
-  const uint32_t *pb = reinterpret_cast<const uint32_t *>(&b);
-  uint32_t *pr = reinterpret_cast<uint32_t *>(&r);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float lo = bf16_bits_to_f32(pa[i] & 0xffffu) + bf16_bits_to_f32(pb[i] & 0xffffu);
-    float hi = bf16_bits_to_f32(pa[i] >> 16) + bf16_bits_to_f32(pb[i] >> 16);
-    pr[i] = pack_bf16x2(lo, hi);
-  }
-  return r;
+// two f32 -> one packed pair of 16-bit elements (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32, RNE) and back
+template <int ET>
+__device__ __forceinline__ uint32_t pack_h16x2(float lo, float hi) {
+  static_assert(ET == ET_BF16 || ET == ET_F16, "16-bit element types only");
+  const asv_f32x2 v = {lo, hi};
+  if constexpr (ET == ET_BF16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, asv_bf16x2));
+  else return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, asv_f16x2));
 }
+template <int ET>
+__device__ __forceinline__ void unpack_h16x2(uint32_t w, float &lo, float &hi) {
+  static_assert(ET == ET_BF16 || ET == ET_F16, "16-bit element types only");
+  if constexpr (ET == ET_BF16) {
+    lo = __uint_as_float(w << 16);
+    hi = __uint_as_float(w & 0xffff0000u);
+  } else {
+    const asv_f32x2 f = __builtin_convertvector(__builtin_bit_cast(asv_f16x2, w), asv_f32x2);
+    lo = f.x; hi = f.y;
+  }
+}
+template <int ET>
+__device__ __forceinline__ float h16_bits_to_f32(uint32_t h) {       // the low 16 bits of h
+  float lo, hi;
+  unpack_h16x2<ET>(h, lo, hi);
+  return lo;
+}
+template <int ET>
+__device__ __forceinline__ uint32_t f32_to_h16_bits(float f) { return pack_h16x2<ET>(f, 0.0f) & 0xffffu; }
+
+// 8 elements (one 16-byte piece) <-> 8 f32
+template <int ET>
+__device__ __forceinline__ void unpack_h16x8(const uint4 u, float *v) {
+  unpack_h16x2<ET>(u.x, v[0], v[1]); unpack_h16x2<ET>(u.y, v[2], v[3]);
+  unpack_h16x2<ET>(u.z, v[4], v[5]); unpack_h16x2<ET>(u.w, v[6], v[7]);
+}
+template <int ET>
+__device__ __forceinline__ uint4 pack_h16x8(const float *v) {
+  return make_uint4(pack_h16x2<ET>(v[0], v[1]), pack_h16x2<ET>(v[2], v[3]), pack_h16x2<ET>(v[4], v[5]), pack_h16x2<ET>(v[6], v[7]));
+}
+
+// the matrix instruction of a 16-bit element type: D = A (32 x 16) . B (16 x 32) + C, f32 accumulate
+template <int ET>
+__device__ __forceinline__ f32x16_t mfma16(const uint4 a, const uint4 b, const f32x16_t c) {
+  static_assert(ET == ET_BF16 || ET == ET_F16, "16-bit element types only");
+  if constexpr (ET == ET_BF16) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
+// ReLU of a packed pair of 16-bit floats as ONE integer instruction (v_pk_max_i16 x, 0): a negative float of either format has
+// its sign bit set = a negative int16, non-negative ones are unchanged (-0 -> +0; a NaN with the sign bit becomes 0)
+__device__ __forceinline__ uint32_t relu_h16x2(uint32_t w) {
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  const s16x2 z = {0, 0};
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, w), z));
+}
+
+// elementwise add of two 16-byte pieces holding 8 16-bit elements (f32 add, RNE back)
+template <int ET>
+__device__ __forceinline__ uint4 add_h16x8(uint4 a, uint4 b) {
+  float va[8], vb[8];
+  unpack_h16x8<ET>(a, va);
+  unpack_h16x8<ET>(b, vb);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) va[i] += vb[i];
+  return pack_h16x8<ET>(va);
+}
+__device__ __forceinline__ uint4 add_bf16x8(uint4 a, uint4 b) { return add_h16x8<ET_BF16>(a, b); }
 
 __device__ __forceinline__ uint4 add_f32x4(uint4 a, uint4 b) {
   uint4 r;
@@ -71,22 +131,22 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
-template <bool BF16>
+template <int ET>
 __device__ __forceinline__ float load_elem(const void *base, size_t idx) {
-  if constexpr (BF16) return bf16_bits_to_f32(reinterpret_cast<const uint16_t *>(base)[idx]);
+  if constexpr (ET != ET_F32) return h16_bits_to_f32<ET>(reinterpret_cast<const uint16_t *>(base)[idx]);
   else return reinterpret_cast<const float *>(base)[idx];
 }
 
-template <bool BF16>
+template <int ET>
 __device__ __forceinline__ void store_elem(void *base, size_t idx, float v) {
-  if constexpr (BF16) reinterpret_cast<uint16_t *>(base)[idx] = (uint16_t)f32_to_bf16_bits(v);
+  if constexpr (ET != ET_F32) reinterpret_cast<uint16_t *>(base)[idx] = (uint16_t)f32_to_h16_bits<ET>(v);
   else reinterpret_cast<float *>(base)[idx] = v;
 }
 
 // The shared epilogue of one output element of a TDNN layer (asv_amd.h asv_tdnn_desc_t):
 //   z = acc + bias (+ seg_bias);  z = affine_first ? act1(z*s+t) : act1(z)*s+t;
 //   y = act2(z) (* seg_scale) (+ residual);  gap rows produce 0.
-template <bool RES_BF16>
+template <int RES_ET>
 __device__ __forceinline__ float tdnn_epilogue(const TdnnKernelParams &p, float acc, int row, int ch,
                                                float bias, float scale, float shift, bool valid) {
   if (!valid) return 0.0f;
@@ -101,7 +161,7 @@ __device__ __forceinline__ float tdnn_epilogue(const TdnnKernelParams &p, float 
   }
   z = apply_act(z, p.act2);
   if (p.seg_scale != nullptr) z *= p.seg_scale[(size_t)seg * p.ld_segscale + ch];
-  if (p.res != nullptr) z += load_elem<RES_BF16>(p.res, (size_t)row * p.ldres + ch);
+  if (p.res != nullptr) z += load_elem<RES_ET>(p.res, (size_t)row * p.ldres + ch);
   return z;
 }
 

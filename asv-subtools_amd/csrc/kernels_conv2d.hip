@@ -44,7 +44,7 @@ __device__ __forceinline__ void conv_glds16(const void *gsrc, uint32_t lds_dst) 
 }
 
 // weights: [tap][k-group][n-fragment][lane = (k half lh, channel lr)][8] bf16, k = kg * 16 + lh * 8 + e
-template <int CIN, int NF, bool GENERIC>
+template <int CIN, int NF, bool GENERIC, int ET = ET_BF16>
 __global__ __launch_bounds__(256, CIN == 32 ? 3 : 2) void grid_conv_narrow_kernel(const TdnnKernelParams p) {
   constexpr int ROWB = CIN * 2;                       // bytes per window row
   constexpr int SLOTS = ROWB / 16;                    // 4 | 8
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256, CIN == 32 ? 3 : 2) void grid_conv_narrow_kerne
           const uint4 x = read_x(d, kg, i);
 #pragma unroll
           for (int n = 0; n < NF; ++n)
-            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wr[t][kg][n]), __builtin_bit_cast(bf16x8_t, x), acc[i][n], 0, 0, 0);
+            acc[i][n] = mfma16<ET>(wr[t][kg][n], x, acc[i][n]);
         }
     }
   } else {
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256, CIN == 32 ? 3 : 2) void grid_conv_narrow_kerne
           const uint4 x = read_x(d, kg, i);
 #pragma unroll
           for (int n = 0; n < NF; ++n)
-            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w[kg][n]), __builtin_bit_cast(bf16x8_t, x), acc[i][n], 0, 0, 0);
+            acc[i][n] = mfma16<ET>(w[kg][n], x, acc[i][n]);
         }
     };
     fetch(0, wa);
@@ -163,8 +163,8 @@ __global__ __launch_bounds__(256, CIN == 32 ? 3 : 2) void grid_conv_narrow_kerne
           else y[e] = tdnn_epilogue_fast(acc[i][n][q * 4 + e], b[e], act_lo, sc[e], sh[e], valid);
         }
         uint2 pk;
-        pk.x = pack_bf16x2(y[0], y[1]);
-        pk.y = pack_bf16x2(y[2], y[3]);
+        pk.x = pack_h16x2<ET>(y[0], y[1]);
+        pk.y = pack_h16x2<ET>(y[2], y[3]);
         *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(p.y) + (size_t)row * p.ldy + ch) = pk;
       }
   }
@@ -200,7 +200,7 @@ template <int CIN> struct WideGeom {
   static_assert(WNS * 64 == CIN && WIN % RPP == 0 && WIN * ROWB <= 81920, "wide grid conv geometry");
 };
 
-template <int CIN, bool GENERIC>
+template <int CIN, bool GENERIC, int ET = ET_BF16>
 __global__ __launch_bounds__(256, 2) void grid_conv_wide_kernel(const TdnnKernelParams p) {
   using G = WideGeom<CIN>;
   __shared__ __attribute__((aligned(16))) unsigned char win[G::WIN * G::ROWB];
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void grid_conv_wide_kernel(const TdnnKernel
         read_x1(d_next, kg_abs_next, q, xn);
 #pragma unroll
         for (int i = (q % 2) * 2; i < (q % 2) * 2 + 2; ++i)
-          acc[i][q / 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[kg][q / 2]), __builtin_bit_cast(bf16x8_t, xc.x[i]), acc[i][q / 2], 0, 0, 0);
+          acc[i][q / 2] = mfma16<ET>(wf[kg][q / 2], xc.x[i], acc[i][q / 2]);
         if (q == 1) wf[kg][0] = *reinterpret_cast<const uint4 *>(frag_ptr(tn, c4n * 4 + kg, 0));
         if (q == 3) wf[kg][1] = *reinterpret_cast<const uint4 *>(frag_ptr(tn, c4n * 4 + kg, 1));
         __builtin_amdgcn_sched_barrier(0);
@@ -302,8 +302,8 @@ __global__ __launch_bounds__(256, 2) void grid_conv_wide_kernel(const TdnnKernel
           else y[e] = tdnn_epilogue_fast(acc[i][j][q * 4 + e], b[e], act_lo, sc[e], sh[e], valid);
         }
         uint2 pk;
-        pk.x = pack_bf16x2(y[0], y[1]);
-        pk.y = pack_bf16x2(y[2], y[3]);
+        pk.x = pack_h16x2<ET>(y[0], y[1]);
+        pk.y = pack_h16x2<ET>(y[2], y[3]);
         *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(p.y) + (size_t)row * p.ldy + ch) = pk;
       }
     }
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void grid_conv_wide_kernel(const TdnnKernel
 // step); inputs staged in LDS: see profiles/.
 constexpr int C1_ROWS = 8;
 constexpr int C1_HALO = 84;                      // >= pitch + 1 of the widest grid (ir.py: 82 frequency bins + 2)
-template <bool GENERIC>
+template <bool GENERIC, int ET = ET_BF16>
 __global__ __launch_bounds__(256) void grid_conv_c1_kernel(const TdnnKernelParams p) {
   __shared__ __attribute__((aligned(16))) float w_s[9 * 64];
   __shared__ __attribute__((aligned(16))) float c_s[3 * 64];                   // bias | scale | shift
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void grid_conv_c1_kernel(const TdnnKernelParam
     const uint16_t *w = reinterpret_cast<const uint16_t *>(p.w);               // [cout_pad][n_taps][cin_pad] bf16
     for (int i = threadIdx.x; i < 9 * 64; i += 256) {
       const int t = i / 64, c = i % 64;
-      w_s[i] = (t < p.n_taps && c < p.cout_store) ? bf16_bits_to_f32(w[((size_t)c * p.n_taps + t) * p.cin_pad]) : 0.0f;
+      w_s[i] = (t < p.n_taps && c < p.cout_store) ? h16_bits_to_f32<ET>(w[((size_t)c * p.n_taps + t) * p.cin_pad]) : 0.0f;
     }
     for (int c = threadIdx.x; c < 64; c += 256) {
       const bool ok = c < p.cout_store;
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void grid_conv_c1_kernel(const TdnnKernelParam
     const uint16_t *x = reinterpret_cast<const uint16_t *>(p.x);
     for (int i = threadIdx.x; i < span + 2 * C1_HALO; i += 256) {
       const long long r = base - C1_HALO + i;
-      x_s[i] = (r >= 0 && r < p.rows) ? bf16_bits_to_f32(x[(size_t)r * p.ldx]) : 0.0f;
+      x_s[i] = (r >= 0 && r < p.rows) ? h16_bits_to_f32<ET>(x[(size_t)r * p.ldx]) : 0.0f;
     }
   }
   __syncthreads();
@@ -386,15 +386,18 @@ __global__ __launch_bounds__(256) void grid_conv_c1_kernel(const TdnnKernelParam
       else y[e] = tdnn_epilogue_fast(acc[e], cb[e], act_lo, cs[e], ct[e], valid);
     }
     uint4 o;
-    o.x = pack_bf16x2(y[0], y[1]); o.y = pack_bf16x2(y[2], y[3]); o.z = pack_bf16x2(y[4], y[5]); o.w = pack_bf16x2(y[6], y[7]);
+    o.x = pack_h16x2<ET>(y[0], y[1]); o.y = pack_h16x2<ET>(y[2], y[3]); o.z = pack_h16x2<ET>(y[4], y[5]); o.w = pack_h16x2<ET>(y[6], y[7]);
     *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(p.y) + (size_t)row * p.ldy + ch) = o;
   }
 }
 
 }  // namespace
 
-bool grid_conv_narrow_supported(const TdnnKernelParams &p, bool bf16) {
-  if (!bf16 || p.n_taps != 9 || p.x2 != nullptr || p.wconv == nullptr) return false;
+// one launch, instantiated for the rows' element type (p.et: bf16, or IEEE half in the f16 precision mode)
+#define ASV_CONV_ET(...) do { if (p.et == ET_F16) hipLaunchKernelGGL((__VA_ARGS__, ET_F16>), grid, block, 0, s, p); \
+                              else hipLaunchKernelGGL((__VA_ARGS__, ET_BF16>), grid, block, 0, s, p); } while (0)
+bool grid_conv_narrow_supported(const TdnnKernelParams &p, int et) {
+  if (et == ET_F32 || p.n_taps != 9 || p.x2 != nullptr || p.wconv == nullptr) return false;
   if (p.cin_pad != 32 && p.cin_pad != 64) return false;
   if (p.cout_store != p.cin_pad) return false;                 // the trunk's 3x3 convolutions keep the channel count
   if (p.halo > CHALO || p.rows % CBM != 0 || p.ldx % 8 != 0 || p.ldy % 4 != 0) return false;
@@ -410,18 +413,18 @@ int launch_grid_conv_narrow(const TdnnKernelParams &p, hipStream_t s) {
   const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first && p.seg_bias == nullptr &&
                     p.seg_scale == nullptr && p.res == nullptr;
   if (p.cin_pad == 32) {
-    if (fast) hipLaunchKernelGGL((grid_conv_narrow_kernel<32, 1, false>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((grid_conv_narrow_kernel<32, 1, true>), grid, block, 0, s, p);
+    if (fast) ASV_CONV_ET(grid_conv_narrow_kernel<32, 1, false);
+    else ASV_CONV_ET(grid_conv_narrow_kernel<32, 1, true);
   } else {
-    if (fast) hipLaunchKernelGGL((grid_conv_narrow_kernel<64, 2, false>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((grid_conv_narrow_kernel<64, 2, true>), grid, block, 0, s, p);
+    if (fast) ASV_CONV_ET(grid_conv_narrow_kernel<64, 2, false);
+    else ASV_CONV_ET(grid_conv_narrow_kernel<64, 2, true);
   }
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }
 
-bool grid_conv_wide_supported(const TdnnKernelParams &p, bool bf16) {
-  if (!bf16 || p.n_taps != 9 || p.x2 != nullptr || p.wconv == nullptr) return false;
+bool grid_conv_wide_supported(const TdnnKernelParams &p, int et) {
+  if (et == ET_F32 || p.n_taps != 9 || p.x2 != nullptr || p.wconv == nullptr) return false;
   if (p.cin_pad != 128 && p.cin_pad != 256) return false;
   if (p.cout_store != p.cin_pad) return false;                 // the trunk's 3x3 convolutions keep the channel count
   const int halo_max = p.cin_pad == 128 ? WideGeom<128>::HALO : WideGeom<256>::HALO;
@@ -436,19 +439,19 @@ int launch_grid_conv_wide(const TdnnKernelParams &p, hipStream_t s) {
                     p.seg_scale == nullptr && p.res == nullptr;
   if (p.cin_pad == 128) {
     const dim3 grid(p.rows / WideGeom<128>::BM), block(256);
-    if (fast) hipLaunchKernelGGL((grid_conv_wide_kernel<128, false>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((grid_conv_wide_kernel<128, true>), grid, block, 0, s, p);
+    if (fast) ASV_CONV_ET(grid_conv_wide_kernel<128, false);
+    else ASV_CONV_ET(grid_conv_wide_kernel<128, true);
   } else {
     const dim3 grid(p.rows / WideGeom<256>::BM), block(256);
-    if (fast) hipLaunchKernelGGL((grid_conv_wide_kernel<256, false>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((grid_conv_wide_kernel<256, true>), grid, block, 0, s, p);
+    if (fast) ASV_CONV_ET(grid_conv_wide_kernel<256, false);
+    else ASV_CONV_ET(grid_conv_wide_kernel<256, true);
   }
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }
 
-bool grid_conv_c1_supported(const TdnnKernelParams &p, bool bf16, int in_ch) {
-  return bf16 && in_ch == 1 && p.x2 == nullptr && p.w != nullptr && p.cout_store % 8 == 0 && p.cout_store >= 32 && p.cout_store <= 64 && p.ldy % 8 == 0 &&
+bool grid_conv_c1_supported(const TdnnKernelParams &p, int et, int in_ch) {
+  return et != ET_F32 && in_ch == 1 && p.x2 == nullptr && p.w != nullptr && p.cout_store % 8 == 0 && p.cout_store >= 32 && p.cout_store <= 64 && p.ldy % 8 == 0 &&
          p.n_taps <= 9 && p.halo <= C1_HALO;
 }
 
@@ -457,8 +460,8 @@ int launch_grid_conv_c1(const TdnnKernelParams &p, hipStream_t s) {
   const dim3 grid((unsigned)((p.rows + rows_per_wg - 1) / rows_per_wg)), block(256);
   const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first && p.seg_bias == nullptr &&
                     p.seg_scale == nullptr && p.res == nullptr;
-  if (fast) hipLaunchKernelGGL((grid_conv_c1_kernel<false>), grid, block, 0, s, p);
-  else hipLaunchKernelGGL((grid_conv_c1_kernel<true>), grid, block, 0, s, p);
+  if (fast) ASV_CONV_ET(grid_conv_c1_kernel<false);
+  else ASV_CONV_ET(grid_conv_c1_kernel<true);
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }

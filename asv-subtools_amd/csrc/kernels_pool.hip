@@ -31,11 +31,11 @@ __global__ __launch_bounds__(256) void rowmap_kernel(const int32_t *seg_row0, co
 
 // ---------------------------------------------------------------------------------------
 // Kaldi float matrix [T_total][D] f32 (packed utterances) -> padded row layout, activation type
-template <bool BF16>
+template <int ET>
 __global__ __launch_bounds__(256) void pack_input_kernel(const float *feats, int feat_dim, const int32_t *seg_src0,
                                                          const int32_t *seg_row0, const int32_t *row_seg, int rows,
                                                          void *x, int ldx) {
-  constexpr int VEC = BF16 ? 8 : 4;
+  constexpr int VEC = (ET != ET_F32) ? 8 : 4;
   const int pieces = ldx / VEC;
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
   if (gid >= (long long)rows * pieces) return;
@@ -60,10 +60,10 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float *feats, int
         if (ch0 + i < feat_dim) v[i] = src[ch0 + i];
     }
   }
-  if constexpr (BF16) {
+  if constexpr (ET != ET_F32) {
     uint4 o;
-    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
-    o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+    o.x = pack_h16x2<ET>(v[0], v[1]); o.y = pack_h16x2<ET>(v[2], v[3]);
+    o.z = pack_h16x2<ET>(v[4], v[5]); o.w = pack_h16x2<ET>(v[6], v[7]);
     *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(x) + (size_t)row * ldx + ch0) = o;
   } else {
     *reinterpret_cast<float4 *>(reinterpret_cast<float *>(x) + (size_t)row * ldx + ch0) = make_float4(v[0], v[1], v[2], v[3]);
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float *feats, int
 }
 
 // padded row layout -> packed [T_total][channels] f32 (single-layer entry point / tests)
-template <bool BF16>
+template <int ET>
 __global__ __launch_bounds__(256) void unpack_rows_kernel(const void *y, int ldy, int channels, const int32_t *seg_src0,
                                                           const int32_t *seg_row0, const int32_t *row_seg, int rows,
                                                           float *out) {
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void unpack_rows_kernel(const void *y, int ldy
   const int row = (int)(gid / channels), ch = (int)(gid % channels);
   const int seg = row_seg[row];
   if (seg < 0) return;
-  out[(size_t)(seg_src0[seg] + (row - seg_row0[seg])) * channels + ch] = load_elem<BF16>(y, (size_t)row * ldy + ch);
+  out[(size_t)(seg_src0[seg] + (row - seg_row0[seg])) * channels + ch] = load_elem<ET>(y, (size_t)row * ldy + ch);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -120,14 +120,11 @@ __device__ __forceinline__ void block_max_rows(float (&v)[VEC], float (*sm)[64],
     v[i] = fmaxf(fmaxf(sm[0][cg * VEC + i], sm[1][cg * VEC + i]), fmaxf(sm[2][cg * VEC + i], sm[3][cg * VEC + i]));
 }
 
-template <bool BF16, int VEC>
+template <int ET, int VEC>
 __device__ __forceinline__ void load_vec(const void *base, size_t idx, float (&v)[VEC]) {
-  if constexpr (BF16) {
+  if constexpr (ET != ET_F32) {
     const uint4 u = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(base) + idx);
-    v[0] = bf16_bits_to_f32(u.x & 0xffffu); v[1] = bf16_bits_to_f32(u.x >> 16);
-    v[2] = bf16_bits_to_f32(u.y & 0xffffu); v[3] = bf16_bits_to_f32(u.y >> 16);
-    v[4] = bf16_bits_to_f32(u.z & 0xffffu); v[5] = bf16_bits_to_f32(u.z >> 16);
-    v[6] = bf16_bits_to_f32(u.w & 0xffffu); v[7] = bf16_bits_to_f32(u.w >> 16);
+    unpack_h16x8<ET>(u, v);
   } else {
     const float4 f = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(base) + idx);
     v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
@@ -147,9 +144,9 @@ __device__ __forceinline__ void load_vec(const void *base, size_t idx, float (&v
 // NARROW (<= 32 channels in bf16: the SE means of the ResNet trunk's first stage): 4 lanes cover the channels and a wave
 // takes 16 rows per step instead of leaving half of its lanes idle (the row order per lane changes with the channel count
 // only - an utterance's result does not depend on the batch).
-template <bool BF16, bool NARROW>
+template <int ET, bool NARROW>
 __global__ __launch_bounds__(256) void stats_pool_kernel(const PoolKernelParams p) {
-  constexpr int VEC = BF16 ? 8 : 4;
+  constexpr int VEC = (ET != ET_F32) ? 8 : 4;
   constexpr int CG = NARROW ? 4 : 64 / VEC;          // lanes along channels
   constexpr int RS = 64 / CG;           // row slots per wave
   __shared__ float sm[4][64];
@@ -164,16 +161,16 @@ __global__ __launch_bounds__(256) void stats_pool_kernel(const PoolKernelParams 
 #pragma unroll
   for (int i = 0; i < VEC; ++i) { pivot[i] = 0.0f; s[i] = 0.0f; q[i] = 0.0f; }
   if (active) {
-    load_vec<BF16, VEC>(p.x, (size_t)row0 * p.ldx + ch, pivot);
+    load_vec<ET, VEC>(p.x, (size_t)row0 * p.ldx + ch, pivot);
     // 4 independent row streams per lane keep enough 16-byte loads in flight
     int r = wave * RS + rs;
     for (; r + 3 * 4 * RS < len; r += 4 * 4 * RS) {
       float v0[VEC], v1[VEC], v2[VEC], v3[VEC];
       const size_t base = (size_t)row0 * p.ldx + ch;
-      load_vec<BF16, VEC>(p.x, base + (size_t)r * rstep, v0);
-      load_vec<BF16, VEC>(p.x, base + (size_t)(r + 4 * RS) * rstep, v1);
-      load_vec<BF16, VEC>(p.x, base + (size_t)(r + 8 * RS) * rstep, v2);
-      load_vec<BF16, VEC>(p.x, base + (size_t)(r + 12 * RS) * rstep, v3);
+      load_vec<ET, VEC>(p.x, base + (size_t)r * rstep, v0);
+      load_vec<ET, VEC>(p.x, base + (size_t)(r + 4 * RS) * rstep, v1);
+      load_vec<ET, VEC>(p.x, base + (size_t)(r + 8 * RS) * rstep, v2);
+      load_vec<ET, VEC>(p.x, base + (size_t)(r + 12 * RS) * rstep, v3);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         const float d0 = v0[i] - pivot[i], d1 = v1[i] - pivot[i], d2 = v2[i] - pivot[i], d3 = v3[i] - pivot[i];
@@ -183,7 +180,7 @@ __global__ __launch_bounds__(256) void stats_pool_kernel(const PoolKernelParams 
     }
     for (; r < len; r += 4 * RS) {
       float v[VEC];
-      load_vec<BF16, VEC>(p.x, (size_t)row0 * p.ldx + ch + (size_t)r * rstep, v);
+      load_vec<ET, VEC>(p.x, (size_t)row0 * p.ldx + ch + (size_t)r * rstep, v);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) { const float d = v[i] - pivot[i]; s[i] += d; q[i] += d * d; }
     }
@@ -261,12 +258,12 @@ __global__ __launch_bounds__(64) void pool_finish_kernel(const PoolFinishParams 
 // ECAPA attentive statistics (ecapa_tdnn_xvector.py:182-188; group 1: a logit per channel) and the shared-weight heads of
 // libs/nnet/pooling.py:322-587: every `group` consecutive channels use one logit column (group = channels: the single head of
 // AttentiveStatisticsPooling, column 0; group = channels / heads: MultiHeadAttentionPooling).
-template <bool BF16>
+template <int ET>
 __global__ __launch_bounds__(256) void attentive_pool_kernel(const void *x, int ldx, const void *logits, int ldl,
                                                              int channels, const int32_t *seg_row0,
                                                              const int32_t *seg_len, float eps, float *out, int ld_out, int group,
                                                              int softplus2, const float *prior_logit, const float *prior_value) {
-  constexpr int VEC = BF16 ? 8 : 4;
+  constexpr int VEC = (ET != ET_F32) ? 8 : 4;
   constexpr int CG = 64 / VEC;
   constexpr int RS = 64 / CG;
   __shared__ float sm[4][64];
@@ -279,14 +276,14 @@ __global__ __launch_bounds__(256) void attentive_pool_kernel(const void *x, int 
   // the logits of frame r for this lane's VEC channels
   auto load_logits = [&](int r, float (&e)[VEC]) {
     if (group >= channels) {                                  // one head: column 0 weights every channel
-      const float e0 = load_elem<BF16>(logits, (size_t)(row0 + r) * ldl);
+      const float e0 = load_elem<ET>(logits, (size_t)(row0 + r) * ldl);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) e[i] = e0;
     } else if (group > 1) {                                   // heads over channel groups: column (channel / group)
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) e[i] = load_elem<BF16>(logits, (size_t)(row0 + r) * ldl + min(ch + i, channels - 1) / group);
+      for (int i = 0; i < VEC; ++i) e[i] = load_elem<ET>(logits, (size_t)(row0 + r) * ldl + min(ch + i, channels - 1) / group);
     } else {
-      load_vec<BF16, VEC>(logits, (size_t)(row0 + r) * ldl + ch, e);
+      load_vec<ET, VEC>(logits, (size_t)(row0 + r) * ldl + ch, e);
       if (softplus2) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) e[i] = 2.0f * logf(e[i] > 20.0f ? e[i] : log1pf(expf(e[i])));   // Softplus(beta 1, threshold 20), squared, log
@@ -296,7 +293,7 @@ __global__ __launch_bounds__(256) void attentive_pool_kernel(const void *x, int 
   float mx[VEC], se[VEC], sx[VEC], sxx[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) { mx[i] = -INFINITY; se[i] = 0.0f; sx[i] = 0.0f; sxx[i] = 0.0f; }
-  if constexpr (BF16) {
+  if constexpr (ET != ET_F32) {
     // throughput mode: ONE pass over logits and x (r2: the two passes + libm expf made this kernel 164 us on ECAPA C3).  Every
     // lane keeps a running maximum of its own frames and rescales its sums when it moves (v_exp_f32-based exponentials);
     // the lanes' partial sums are brought to the utterance's maximum before they are added.
@@ -310,8 +307,8 @@ __global__ __launch_bounds__(256) void attentive_pool_kernel(const void *x, int 
         float e0[VEC], v0[VEC], e1[VEC], v1[VEC];
         load_logits(r, e0);
         load_logits(r + 4 * RS, e1);
-        load_vec<BF16, VEC>(x, (size_t)(row0 + r) * ldx + ch, v0);
-        load_vec<BF16, VEC>(x, (size_t)(row0 + r + 4 * RS) * ldx + ch, v1);
+        load_vec<ET, VEC>(x, (size_t)(row0 + r) * ldx + ch, v0);
+        load_vec<ET, VEC>(x, (size_t)(row0 + r + 4 * RS) * ldx + ch, v1);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
           const float mn = fmaxf(lm[i], fmaxf(e0[i], e1[i]));
@@ -325,7 +322,7 @@ __global__ __launch_bounds__(256) void attentive_pool_kernel(const void *x, int 
       for (; r < len; r += 4 * RS) {
         float e[VEC], v[VEC];
         load_logits(r, e);
-        load_vec<BF16, VEC>(x, (size_t)(row0 + r) * ldx + ch, v);
+        load_vec<ET, VEC>(x, (size_t)(row0 + r) * ldx + ch, v);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
           const float mn = fmaxf(lm[i], e[i]);
@@ -367,7 +364,7 @@ __global__ __launch_bounds__(256) void attentive_pool_kernel(const void *x, int 
       for (int r = wave * RS + rs; r < len; r += 4 * RS) {
         float e[VEC], v[VEC];
         load_logits(r, e);
-        load_vec<BF16, VEC>(x, (size_t)(row0 + r) * ldx + ch, v);
+        load_vec<ET, VEC>(x, (size_t)(row0 + r) * ldx + ch, v);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
           const float w = expf(e[i] - mx[i]);
@@ -404,7 +401,7 @@ __global__ __launch_bounds__(256) void attentive_pool_kernel(const void *x, int 
 // squared distances |x_t - mu_k|^2 of its slice for the 8 rows (one mu load feeds 8 rows), the slices are summed through
 // LDS, wave 0 turns every row's n_centres distances into softmax(-beta_k d_k) over the centres (one centre per lane).
 constexpr int kLdeRows = 8;
-template <bool BF16>
+template <int ET>
 __global__ __launch_bounds__(256) void lde_weights_kernel(const void *x, int ldx, int channels, int rows, const float *mu, const float *beta, int n_centres,
                                                           float *weights) {
   extern __shared__ float lde_sh[];                      // xs[kLdeRows][channels] | part[4][kLdeRows][64]
@@ -412,7 +409,7 @@ __global__ __launch_bounds__(256) void lde_weights_kernel(const void *x, int ldx
   const int row0 = blockIdx.x * kLdeRows;
   for (int i = threadIdx.x; i < kLdeRows * channels; i += 256) {
     const int f = i / channels, c = i - f * channels;
-    xs[i] = row0 + f < rows ? load_elem<BF16>(x, (size_t)(row0 + f) * ldx + c) : 0.0f;
+    xs[i] = row0 + f < rows ? load_elem<ET>(x, (size_t)(row0 + f) * ldx + c) : 0.0f;
   }
   __syncthreads();
   const int k = threadIdx.x & 63, sl = threadIdx.x >> 6;
@@ -447,7 +444,7 @@ __global__ __launch_bounds__(256) void lde_weights_kernel(const void *x, int ldx
 // lde_accumulate_kernel: one workgroup per (64 channels, segment); lane = channel, the 4 waves split the frames;
 // acc[k] += w[t][k] x[t][c] and s0[k] += w[t][k] for KMAX >= n_centres centres (zero weights beyond), summed over the
 // waves through LDS; out[c * n_centres + k] = (acc[k] - mu[c][k] s0[k]) / frames.
-template <bool BF16, int KMAX>
+template <int ET, int KMAX>
 __global__ __launch_bounds__(256) void lde_accumulate_kernel(const void *x, int ldx, int channels, const float *weights, const float *mu, int n_centres,
                                                              const int32_t *seg_row0, const int32_t *seg_len, float *out, int ld_out) {
   __shared__ float red[4][2 * KMAX][64];
@@ -458,7 +455,7 @@ __global__ __launch_bounds__(256) void lde_accumulate_kernel(const void *x, int 
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) { acc[k] = 0.0f; s0[k] = 0.0f; }
   for (int r = wave; r < len; r += 4) {
-    const float v = c < channels ? load_elem<BF16>(x, (size_t)(row0 + r) * ldx + c) : 0.0f;
+    const float v = c < channels ? load_elem<ET>(x, (size_t)(row0 + r) * ldx + c) : 0.0f;
     const float *w = weights + (size_t)(row0 + r) * 64;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) { const float wk = w[k]; acc[k] = fmaf(wk, v, acc[k]); s0[k] += wk; }
@@ -478,9 +475,9 @@ __global__ __launch_bounds__(256) void lde_accumulate_kernel(const void *x, int 
 
 // ---------------------------------------------------------------------------------------
 // elementwise: out = (a [*scale+shift]) (* seg_scale[seg]) (+ b) (+ c); gap rows -> 0
-template <bool BF16>
+template <int ET>
 __global__ __launch_bounds__(256) void eltwise_kernel(const EltwiseKernelParams p) {
-  constexpr int VEC = BF16 ? 8 : 4;
+  constexpr int VEC = (ET != ET_F32) ? 8 : 4;
   const int pieces = round_up_dev(p.channels, VEC) / VEC;
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
   if (gid >= (long long)p.rows * pieces) return;
@@ -493,7 +490,7 @@ __global__ __launch_bounds__(256) void eltwise_kernel(const EltwiseKernelParams 
     seg = valid ? p.row_seg[row] : 0;
   }
   if (valid) {
-    load_vec<BF16, VEC>(p.a, (size_t)row * p.lda + ch, o);
+    load_vec<ET, VEC>(p.a, (size_t)row * p.lda + ch, o);
     // per-channel / per-segment f32 tables: 16-byte loads when the whole piece is inside the channel range (all
     // table pitches and channel offsets are multiples of 4 floats), element-wise only for the ragged last piece
     const bool whole = ch + VEC <= p.channels;
@@ -536,13 +533,13 @@ __global__ __launch_bounds__(256) void eltwise_kernel(const EltwiseKernelParams 
       for (int i = 0; i < VEC; ++i) o[i] *= ss[i];
     }
     if (p.b != nullptr) {
-      load_vec<BF16, VEC>(p.b, (size_t)row * p.ldb + ch, tb);
+      load_vec<ET, VEC>(p.b, (size_t)row * p.ldb + ch, tb);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) o[i] += tb[i];
     }
     if (p.c != nullptr) {
       float t[VEC];
-      load_vec<BF16, VEC>(p.c, (size_t)row * p.ldc + ch, t);
+      load_vec<ET, VEC>(p.c, (size_t)row * p.ldc + ch, t);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) o[i] += t[i];
     }
@@ -552,15 +549,14 @@ __global__ __launch_bounds__(256) void eltwise_kernel(const EltwiseKernelParams 
 #pragma unroll
     for (int i = 0; i < VEC; ++i) o[i] = 0.0f;
   }
-  if constexpr (BF16) {
+  if constexpr (ET != ET_F32) {
     uint4 u;
-    u.x = pack_bf16x2(o[0], o[1]); u.y = pack_bf16x2(o[2], o[3]);
-    u.z = pack_bf16x2(o[4], o[5]); u.w = pack_bf16x2(o[6], o[7]);
+    u.x = pack_h16x2<ET>(o[0], o[1]); u.y = pack_h16x2<ET>(o[2], o[3]);
+    u.z = pack_h16x2<ET>(o[4], o[5]); u.w = pack_h16x2<ET>(o[6], o[7]);
     *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(p.out) + (size_t)row * p.ldo + ch) = u;
     if (p.out2 != nullptr) {
       // the value a separate addition would read back: the bf16 just stored
-      o[0] = bf16_bits_to_f32(u.x & 0xffffu); o[1] = bf16_bits_to_f32(u.x >> 16); o[2] = bf16_bits_to_f32(u.y & 0xffffu); o[3] = bf16_bits_to_f32(u.y >> 16);
-      o[4] = bf16_bits_to_f32(u.z & 0xffffu); o[5] = bf16_bits_to_f32(u.z >> 16); o[6] = bf16_bits_to_f32(u.w & 0xffffu); o[7] = bf16_bits_to_f32(u.w >> 16);
+      unpack_h16x8<ET>(u, o);
     }
   } else {
     *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.out) + (size_t)row * p.ldo + ch) = make_float4(o[0], o[1], o[2], o[3]);
@@ -572,15 +568,15 @@ __global__ __launch_bounds__(256) void eltwise_kernel(const EltwiseKernelParams 
 #pragma unroll
         for (int i = 0; i < VEC; ++i) t[i] = tb[i];
       } else {
-        load_vec<BF16, VEC>(p.d, (size_t)row * p.ldd + ch, t);
+        load_vec<ET, VEC>(p.d, (size_t)row * p.ldd + ch, t);
       }
 #pragma unroll
       for (int i = 0; i < VEC; ++i) o[i] = (ch + i >= p.channels) ? 0.0f : o[i] + t[i];
     }
-    if constexpr (BF16) {
+    if constexpr (ET != ET_F32) {
       uint4 u;
-      u.x = pack_bf16x2(o[0], o[1]); u.y = pack_bf16x2(o[2], o[3]);
-      u.z = pack_bf16x2(o[4], o[5]); u.w = pack_bf16x2(o[6], o[7]);
+      u.x = pack_h16x2<ET>(o[0], o[1]); u.y = pack_h16x2<ET>(o[2], o[3]);
+      u.z = pack_h16x2<ET>(o[4], o[5]); u.w = pack_h16x2<ET>(o[6], o[7]);
       *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(p.out2) + (size_t)row * p.ldo2 + ch) = u;
     } else {
       *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.out2) + (size_t)row * p.ldo2 + ch) = make_float4(o[0], o[1], o[2], o[3]);
@@ -616,7 +612,7 @@ __global__ __launch_bounds__(256) void combine_kernel(const float *seg_emb, int 
 // (pitch - width zero rows between frames = the frequency zero padding of a 3x3 convolution).
 
 // frames-domain feature rows [t][f] -> grid rows t*pitch + f with ONE channel (ResNet input unsqueeze)
-template <bool BF16>
+template <int ET>
 __global__ __launch_bounds__(256) void grid_from_frames_kernel(const void *x, int ldx, int feat_dim, const int32_t *fr_row0, const int32_t *g_row0,
                                                                const int32_t *g_row_seg, const uint32_t *g_row_valid, int g_rows, int pitch,
                                                                void *out, int ldo) {
@@ -626,19 +622,19 @@ __global__ __launch_bounds__(256) void grid_from_frames_kernel(const void *x, in
   if ((g_row_valid[row >> 5] >> (row & 31)) & 1u) {
     const int seg = g_row_seg[row], rel = row - g_row0[seg];
     const int t = rel / pitch, f = rel % pitch;
-    if (f < feat_dim) v = load_elem<BF16>(x, (size_t)(fr_row0[seg] + t) * ldx + f);
+    if (f < feat_dim) v = load_elem<ET>(x, (size_t)(fr_row0[seg] + t) * ldx + f);
   }
   // channel 0 carries the value, the pad channels of the 16-wide pitch stay zero
-  for (int c = 0; c < ldo; ++c) store_elem<BF16>(out, (size_t)row * ldo + c, c == 0 ? v : 0.0f);
+  for (int c = 0; c < ldo; ++c) store_elem<ET>(out, (size_t)row * ldo + c, c == 0 ? v : 0.0f);
 }
 
 // im2col gather for strided convolutions: one thread per (output row, tap, 16-byte piece).
 // Tried and dropped (r2k): one thread per (row, piece) walking the nine taps (the row's four dependent table lookups paid
 // once): the stores of a wave then scatter over 16 rows x 64 B instead of covering 576 contiguous bytes per row -
 // 598 vs 344 us on the 32 -> 64 stage.
-template <bool BF16>
+template <int ET>
 __global__ __launch_bounds__(256) void im2col_kernel(const Im2colParams p) {
-  constexpr int VEC = BF16 ? 8 : 4;
+  constexpr int VEC = (ET != ET_F32) ? 8 : 4;
   const int pieces = p.channels / VEC;                  // channels is a multiple of 16
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long per_row = (long long)p.n_taps * pieces;
@@ -651,32 +647,34 @@ __global__ __launch_bounds__(256) void im2col_kernel(const Im2colParams p) {
     const int in_frames = p.in_len[seg] / p.in_pitch;
     if (t >= 0 && t < in_frames && f >= 0 && f < p.in_width) {
       const size_t src = (size_t)(p.in_row0[seg] + t * p.in_pitch + f) * p.ldi + (size_t)piece * VEC;
-      if constexpr (BF16) v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(p.in) + src);
+      if constexpr (ET != ET_F32) v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(p.in) + src);
       else v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const float *>(p.in) + src);
     }
   }
   const size_t dst = (size_t)row * p.ldo + (size_t)k * p.channels + (size_t)piece * VEC;
-  if constexpr (BF16) *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(p.out) + dst) = v;
+  if constexpr (ET != ET_F32) *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(p.out) + dst) = v;
   else *reinterpret_cast<uint4 *>(reinterpret_cast<float *>(p.out) + dst) = v;
 }
 
 }  // namespace
 
 int launch_grid_from_frames(const void *x, int ldx, int feat_dim, const int32_t *fr_row0, const int32_t *g_row0, const int32_t *g_row_seg,
-                            const uint32_t *g_row_valid, int g_rows, int pitch, void *out, int ldo, bool bf16, hipStream_t s) {
+                            const uint32_t *g_row_valid, int g_rows, int pitch, void *out, int ldo, int et, hipStream_t s) {
   const dim3 grid((g_rows + 255) / 256), block(256);
-  if (bf16) hipLaunchKernelGGL(grid_from_frames_kernel<true>, grid, block, 0, s, x, ldx, feat_dim, fr_row0, g_row0, g_row_seg, g_row_valid, g_rows, pitch, out, ldo);
-  else hipLaunchKernelGGL(grid_from_frames_kernel<false>, grid, block, 0, s, x, ldx, feat_dim, fr_row0, g_row0, g_row_seg, g_row_valid, g_rows, pitch, out, ldo);
+  if (et == ET_BF16) hipLaunchKernelGGL(grid_from_frames_kernel<ET_BF16>, grid, block, 0, s, x, ldx, feat_dim, fr_row0, g_row0, g_row_seg, g_row_valid, g_rows, pitch, out, ldo);
+  else if (et == ET_F16) hipLaunchKernelGGL(grid_from_frames_kernel<ET_F16>, grid, block, 0, s, x, ldx, feat_dim, fr_row0, g_row0, g_row_seg, g_row_valid, g_rows, pitch, out, ldo);
+  else hipLaunchKernelGGL(grid_from_frames_kernel<ET_F32>, grid, block, 0, s, x, ldx, feat_dim, fr_row0, g_row0, g_row_seg, g_row_valid, g_rows, pitch, out, ldo);
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }
 
-int launch_im2col(const Im2colParams &p, bool bf16, hipStream_t s) {
-  const int vec = bf16 ? 8 : 4;
+int launch_im2col(const Im2colParams &p, int et, hipStream_t s) {
+  const int vec = et != ET_F32 ? 8 : 4;
   const long long n = (long long)p.out_rows * p.n_taps * (p.channels / vec);
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-  if (bf16) hipLaunchKernelGGL(im2col_kernel<true>, grid, block, 0, s, p);
-  else hipLaunchKernelGGL(im2col_kernel<false>, grid, block, 0, s, p);
+  if (et == ET_BF16) hipLaunchKernelGGL(im2col_kernel<ET_BF16>, grid, block, 0, s, p);
+  else if (et == ET_F16) hipLaunchKernelGGL(im2col_kernel<ET_F16>, grid, block, 0, s, p);
+  else hipLaunchKernelGGL(im2col_kernel<ET_F32>, grid, block, 0, s, p);
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }
@@ -689,32 +687,36 @@ int launch_rowmap(const int32_t *seg_row0, const int32_t *seg_len, int segments,
 }
 
 int launch_pack_input(const float *feats, int feat_dim, const int32_t *seg_src0, const int32_t *seg_row0,
-                      const int32_t *row_seg, int rows, void *x, int ldx, bool bf16, hipStream_t s) {
-  const int vec = bf16 ? 8 : 4;
+                      const int32_t *row_seg, int rows, void *x, int ldx, int et, hipStream_t s) {
+  const int vec = et != ET_F32 ? 8 : 4;
   const long long n = (long long)rows * (ldx / vec);
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-  if (bf16) hipLaunchKernelGGL(pack_input_kernel<true>, grid, block, 0, s, feats, feat_dim, seg_src0, seg_row0, row_seg, rows, x, ldx);
-  else hipLaunchKernelGGL(pack_input_kernel<false>, grid, block, 0, s, feats, feat_dim, seg_src0, seg_row0, row_seg, rows, x, ldx);
+  if (et == ET_BF16) hipLaunchKernelGGL(pack_input_kernel<ET_BF16>, grid, block, 0, s, feats, feat_dim, seg_src0, seg_row0, row_seg, rows, x, ldx);
+  else if (et == ET_F16) hipLaunchKernelGGL(pack_input_kernel<ET_F16>, grid, block, 0, s, feats, feat_dim, seg_src0, seg_row0, row_seg, rows, x, ldx);
+  else hipLaunchKernelGGL(pack_input_kernel<ET_F32>, grid, block, 0, s, feats, feat_dim, seg_src0, seg_row0, row_seg, rows, x, ldx);
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }
 
 int launch_unpack_rows(const void *y, int ldy, int channels, const int32_t *seg_src0, const int32_t *seg_row0,
-                       const int32_t *row_seg, int rows, float *out, bool bf16, hipStream_t s) {
+                       const int32_t *row_seg, int rows, float *out, int et, hipStream_t s) {
   const long long n = (long long)rows * channels;
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-  if (bf16) hipLaunchKernelGGL(unpack_rows_kernel<true>, grid, block, 0, s, y, ldy, channels, seg_src0, seg_row0, row_seg, rows, out);
-  else hipLaunchKernelGGL(unpack_rows_kernel<false>, grid, block, 0, s, y, ldy, channels, seg_src0, seg_row0, row_seg, rows, out);
+  if (et == ET_BF16) hipLaunchKernelGGL(unpack_rows_kernel<ET_BF16>, grid, block, 0, s, y, ldy, channels, seg_src0, seg_row0, row_seg, rows, out);
+  else if (et == ET_F16) hipLaunchKernelGGL(unpack_rows_kernel<ET_F16>, grid, block, 0, s, y, ldy, channels, seg_src0, seg_row0, row_seg, rows, out);
+  else hipLaunchKernelGGL(unpack_rows_kernel<ET_F32>, grid, block, 0, s, y, ldy, channels, seg_src0, seg_row0, row_seg, rows, out);
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }
 
-int launch_stats_pool(const PoolKernelParams &p, int segments, bool bf16, hipStream_t s) {
+int launch_stats_pool(const PoolKernelParams &p, int segments, int et, hipStream_t s) {
   if (segments <= 0) return ASV_OK;
   const dim3 grid((p.channels + 63) / 64, segments * p.groups), block(256);
-  if (bf16 && p.channels <= 32) hipLaunchKernelGGL((stats_pool_kernel<true, true>), dim3(1, segments * p.groups), block, 0, s, p);
-  else if (bf16) hipLaunchKernelGGL((stats_pool_kernel<true, false>), grid, block, 0, s, p);
-  else hipLaunchKernelGGL((stats_pool_kernel<false, false>), grid, block, 0, s, p);
+  if (et == ET_BF16 && p.channels <= 32) hipLaunchKernelGGL((stats_pool_kernel<ET_BF16, true>), dim3(1, segments * p.groups), block, 0, s, p);
+  else if (et == ET_F16 && p.channels <= 32) hipLaunchKernelGGL((stats_pool_kernel<ET_F16, true>), dim3(1, segments * p.groups), block, 0, s, p);
+  else if (et == ET_BF16) hipLaunchKernelGGL((stats_pool_kernel<ET_BF16, false>), grid, block, 0, s, p);
+  else if (et == ET_F16) hipLaunchKernelGGL((stats_pool_kernel<ET_F16, false>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((stats_pool_kernel<ET_F32, false>), grid, block, 0, s, p);
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }
@@ -727,41 +729,46 @@ int launch_pool_finish(const PoolFinishParams &p, int segments, hipStream_t s) {
 }
 
 int launch_attentive_pool(const void *x, int ldx, const void *logits, int ldl, int channels, const int32_t *seg_row0,
-                          const int32_t *seg_len, int segments, float eps, float *out, int ld_out, bool bf16, int group, int softplus2, const float *prior_logit, const float *prior_value,
+                          const int32_t *seg_len, int segments, float eps, float *out, int ld_out, int et, int group, int softplus2, const float *prior_logit, const float *prior_value,
                           hipStream_t s) {
   if (segments <= 0) return ASV_OK;
   const dim3 grid((channels + 63) / 64, segments), block(256);
-  if (bf16) hipLaunchKernelGGL(attentive_pool_kernel<true>, grid, block, 0, s, x, ldx, logits, ldl, channels, seg_row0, seg_len, eps, out, ld_out, group, softplus2, prior_logit, prior_value);
-  else hipLaunchKernelGGL(attentive_pool_kernel<false>, grid, block, 0, s, x, ldx, logits, ldl, channels, seg_row0, seg_len, eps, out, ld_out, group, softplus2, prior_logit, prior_value);
+  if (et == ET_BF16) hipLaunchKernelGGL(attentive_pool_kernel<ET_BF16>, grid, block, 0, s, x, ldx, logits, ldl, channels, seg_row0, seg_len, eps, out, ld_out, group, softplus2, prior_logit, prior_value);
+  else if (et == ET_F16) hipLaunchKernelGGL(attentive_pool_kernel<ET_F16>, grid, block, 0, s, x, ldx, logits, ldl, channels, seg_row0, seg_len, eps, out, ld_out, group, softplus2, prior_logit, prior_value);
+  else hipLaunchKernelGGL(attentive_pool_kernel<ET_F32>, grid, block, 0, s, x, ldx, logits, ldl, channels, seg_row0, seg_len, eps, out, ld_out, group, softplus2, prior_logit, prior_value);
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }
 
 
 int launch_lde_pool(const void *x, int ldx, int channels, int rows, const float *mu, const float *beta, int n_centres, float *weights,
-                    const int32_t *seg_row0, const int32_t *seg_len, int segments, float *out, int ld_out, bool bf16, hipStream_t s) {
+                    const int32_t *seg_row0, const int32_t *seg_len, int segments, float *out, int ld_out, int et, hipStream_t s) {
   if (segments <= 0 || rows <= 0) return ASV_OK;
   const size_t lds = ((size_t)kLdeRows * channels + 4 * kLdeRows * 64) * sizeof(float);
   ASV_REQUIRE(lds <= 64 * 1024, "lde pooling: %d channels need %zu bytes of LDS per workgroup (limit 64 KiB)", channels, lds);
   const dim3 g1((rows + kLdeRows - 1) / kLdeRows), g2((channels + 63) / 64, segments);
-  if (bf16) hipLaunchKernelGGL(lde_weights_kernel<true>, g1, dim3(256), lds, s, x, ldx, channels, rows, mu, beta, n_centres, weights);
-  else hipLaunchKernelGGL(lde_weights_kernel<false>, g1, dim3(256), lds, s, x, ldx, channels, rows, mu, beta, n_centres, weights);
+  if (et == ET_BF16) hipLaunchKernelGGL(lde_weights_kernel<ET_BF16>, g1, dim3(256), lds, s, x, ldx, channels, rows, mu, beta, n_centres, weights);
+  else if (et == ET_F16) hipLaunchKernelGGL(lde_weights_kernel<ET_F16>, g1, dim3(256), lds, s, x, ldx, channels, rows, mu, beta, n_centres, weights);
+  else hipLaunchKernelGGL(lde_weights_kernel<ET_F32>, g1, dim3(256), lds, s, x, ldx, channels, rows, mu, beta, n_centres, weights);
 #define ASV_LDE_ACC(B, K) hipLaunchKernelGGL((lde_accumulate_kernel<B, K>), g2, dim3(256), 0, s, x, ldx, channels, weights, mu, n_centres, seg_row0, seg_len, out, ld_out)
-  if (n_centres <= 8) { if (bf16) ASV_LDE_ACC(true, 8); else ASV_LDE_ACC(false, 8); }
-  else if (n_centres <= 16) { if (bf16) ASV_LDE_ACC(true, 16); else ASV_LDE_ACC(false, 16); }
-  else if (n_centres <= 32) { if (bf16) ASV_LDE_ACC(true, 32); else ASV_LDE_ACC(false, 32); }
-  else { if (bf16) ASV_LDE_ACC(true, 64); else ASV_LDE_ACC(false, 64); }
+#define ASV_LDE_ET(K) do { if (et == ET_BF16) ASV_LDE_ACC(ET_BF16, K); else if (et == ET_F16) ASV_LDE_ACC(ET_F16, K); else ASV_LDE_ACC(ET_F32, K); } while (0)
+  if (n_centres <= 8) ASV_LDE_ET(8);
+  else if (n_centres <= 16) ASV_LDE_ET(16);
+  else if (n_centres <= 32) ASV_LDE_ET(32);
+  else ASV_LDE_ET(64);
+#undef ASV_LDE_ET
 #undef ASV_LDE_ACC
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }
 
-int launch_eltwise(const EltwiseKernelParams &p, bool bf16, hipStream_t s) {
-  const int vec = bf16 ? 8 : 4;
+int launch_eltwise(const EltwiseKernelParams &p, int et, hipStream_t s) {
+  const int vec = et != ET_F32 ? 8 : 4;
   const long long n = (long long)p.rows * (round_up(p.channels, vec) / vec);
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-  if (bf16) hipLaunchKernelGGL(eltwise_kernel<true>, grid, block, 0, s, p);
-  else hipLaunchKernelGGL(eltwise_kernel<false>, grid, block, 0, s, p);
+  if (et == ET_BF16) hipLaunchKernelGGL(eltwise_kernel<ET_BF16>, grid, block, 0, s, p);
+  else if (et == ET_F16) hipLaunchKernelGGL(eltwise_kernel<ET_F16>, grid, block, 0, s, p);
+  else hipLaunchKernelGGL(eltwise_kernel<ET_F32>, grid, block, 0, s, p);
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }

@@ -58,6 +58,7 @@ __device__ __forceinline__ void res2_glds16(const void *gsrc, uint32_t lds_dst) 
       : "memory");
 }
 
+template <int ET>
 __global__ __launch_bounds__(512, 2) void res2_chain_kernel(const Res2KernelParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[RES2_LDS];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(const Res2KernelPara
         }
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf)
-          acc[rf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[tc * 4 + kg]), __builtin_bit_cast(bf16x8_t, xc[rf]), acc[rf], 0, 0, 0);
+          acc[rf] = mfma16<ET>(__builtin_bit_cast(uint4, wf[tc * 4 + kg]), xc[rf], acc[rf]);
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf) xc[rf] = xn[rf];
       }
@@ -211,15 +212,18 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(const Res2KernelPara
 #pragma unroll
         for (int e = 0; e < 4; ++e) y[e] = valid[rf] ? fmaf(max_lo(acc[rf][q * 4 + e], 0.0f), sc[e], sh[e]) : 0.0f;
         uint2 pk;
-        pk.x = pack_bf16x2(y[0], y[1]);
-        pk.y = pack_bf16x2(y[2], y[3]);
+        pk.x = pack_h16x2<ET>(y[0], y[1]);
+        pk.y = pack_h16x2<ET>(y[2], y[3]);
         const uint32_t boff = (uint32_t)(rw * RROWB + ((slot ^ (rw & 15)) << 4) + lh * 8);
         *reinterpret_cast<uint2 *>(lds + B_OFF + boff) = pk;
         if (more) {
           const uint2 xv = *reinterpret_cast<const uint2 *>(lds + X_OFF + boff);
           uint2 sv;
-          sv.x = pack_bf16x2(bf16_bits_to_f32(pk.x & 0xffffu) + bf16_bits_to_f32(xv.x & 0xffffu), bf16_bits_to_f32(pk.x >> 16) + bf16_bits_to_f32(xv.x >> 16));
-          sv.y = pack_bf16x2(bf16_bits_to_f32(pk.y & 0xffffu) + bf16_bits_to_f32(xv.y & 0xffffu), bf16_bits_to_f32(pk.y >> 16) + bf16_bits_to_f32(xv.y >> 16));
+          float p0, p1, p2, p3, x0, x1, x2, x3;
+          unpack_h16x2<ET>(pk.x, p0, p1); unpack_h16x2<ET>(pk.y, p2, p3);
+          unpack_h16x2<ET>(xv.x, x0, x1); unpack_h16x2<ET>(xv.y, x2, x3);
+          sv.x = pack_h16x2<ET>(p0 + x0, p1 + x1);
+          sv.y = pack_h16x2<ET>(p2 + x2, p3 + x3);
           const int ra = RPAD + rw;
           *reinterpret_cast<uint2 *>(lds + ra * RROWB + ((slot ^ (ra & 15)) << 4) + lh * 8) = sv;
         }
@@ -251,7 +255,8 @@ int launch_res2_chain(const Res2KernelParams &p, hipStream_t s) {
   ASV_REQUIRE(p.rows % RM == 0 && p.rows >= RM, "res2: rows %d not a multiple of %d", p.rows, RM);
   ASV_REQUIRE(p.branches >= 1 && p.branches <= 7 && p.dilation >= 1 && p.dilation <= kHalo, "res2: %d branches, dilation %d", p.branches, p.dilation);
   ASV_REQUIRE(p.x && p.y && p.wfrag && p.bias && p.scale && p.shift && p.row_valid, "res2: null argument");
-  hipLaunchKernelGGL(res2_chain_kernel, dim3(p.rows / RM), dim3(512), 0, s, p);
+  if (p.et == ET_F16) hipLaunchKernelGGL(res2_chain_kernel<ET_F16>, dim3(p.rows / RM), dim3(512), 0, s, p);
+  else hipLaunchKernelGGL(res2_chain_kernel<ET_BF16>, dim3(p.rows / RM), dim3(512), 0, s, p);
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }

@@ -49,12 +49,14 @@ static_assert(kRowTile % BM == 0, "row padding must be a multiple of the M tile"
 
 __device__ __forceinline__ int swz(int row, int slot) { return slot ^ ((row >> 1) & 7); }
 
-template <bool BF16, bool OUT_BF16, bool GENERIC, int HALO>
+template <int ET, bool OUT16, bool GENERIC, int HALO>
 __global__ __launch_bounds__(256, HALO <= 24 ? 2 : 1) void tdnn_gemm_kernel(const TdnnKernelParams p, int m_tiles, int n_tiles) {
   using G = Geom<HALO>;
   constexpr int A_STAGE = G::A_STAGE, A_PIECES = G::A_PIECES, NA = G::NA;
   __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS_BYTES];
-  constexpr int ES = BF16 ? 2 : 4;          // element bytes
+  constexpr bool H16 = ET != ET_F32;        // 16-bit elements (bf16 / f16) on the 32x32x16 matrix instruction; f32 on the exact 32x32x2 one
+  constexpr int OUT_ET = OUT16 ? ET : ET_F32;
+  constexpr int ES = H16 ? 2 : 4;           // element bytes
   constexpr int BK = ROWB / ES;             // elements per chunk: 64 | 32
   constexpr int E16 = 16 / ES;              // elements per 16-byte piece: 8 | 4
   constexpr int KGE = 2 * E16;              // elements per k-group (both lane halves): 16 | 8
@@ -105,7 +107,8 @@ __global__ __launch_bounds__(256, HALO <= 24 ? 2 : 1) void tdnn_gemm_kernel(cons
         v = *reinterpret_cast<const uint4 *>(xg + (size_t)row * x_pitch + (size_t)ch * ES);
         if (x2g != nullptr) {
           const uint4 v2 = *reinterpret_cast<const uint4 *>(x2g + (size_t)row * x2_pitch + (size_t)ch * ES);
-          v = BF16 ? add_bf16x8(v, v2) : add_f32x4(v, v2);
+          if constexpr (H16) v = add_h16x8<ET>(v, v2);
+          else v = add_f32x4(v, v2);
         }
       }
       regA[i] = v;
@@ -144,9 +147,8 @@ __global__ __launch_bounds__(256, HALO <= 24 ? 2 : 1) void tdnn_gemm_kernel(cons
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        if constexpr (BF16) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[i]),
-                                                              __builtin_bit_cast(bf16x8_t, b[j]), acc[i][j], 0, 0, 0);
+        if constexpr (H16) {
+          acc[i][j] = mfma16<ET>(a[i], b[j], acc[i][j]);
         } else {
           const f32x4_t af = __builtin_bit_cast(f32x4_t, a[i]), bf = __builtin_bit_cast(f32x4_t, b[j]);
 #pragma unroll
@@ -238,9 +240,9 @@ __global__ __launch_bounds__(256, HALO <= 24 ? 2 : 1) void tdnn_gemm_kernel(cons
         const int row = rbase + rf;
         const bool valid = (vbits >> rf) & 1u;
         float yv;
-        if constexpr (GENERIC) yv = tdnn_epilogue<BF16>(p, acc[i][j][r], row, ch, bias, scale, shift, valid);
+        if constexpr (GENERIC) yv = tdnn_epilogue<ET>(p, acc[i][j][r], row, ch, bias, scale, shift, valid);
         else yv = tdnn_epilogue_fast(acc[i][j][r], bias, act_lo, scale, shift, valid);
-        if (ch_ok) store_elem<OUT_BF16>(p.y, (size_t)row * p.ldy + ch, yv);
+        if (ch_ok) store_elem<OUT_ET>(p.y, (size_t)row * p.ldy + ch, yv);
       }
     }
   }
@@ -248,8 +250,9 @@ __global__ __launch_bounds__(256, HALO <= 24 ? 2 : 1) void tdnn_gemm_kernel(cons
 
 // Plain-VALU self-check kernel: one thread per output element, natural k order, same packed
 // weights and the same epilogue.  Used by ASV_FLAG_REF_KERNELS and the kernel parity tests.
-template <bool BF16, bool OUT_BF16>
+template <int ET, bool OUT16>
 __global__ __launch_bounds__(256) void tdnn_ref_kernel(const TdnnKernelParams p) {
+  constexpr int OUT_ET = OUT16 ? ET : ET_F32;
   const int ch = blockIdx.x * 64 + (threadIdx.x & 63);
   const int row = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (row >= p.rows || ch >= p.cout_store) return;
@@ -259,23 +262,24 @@ __global__ __launch_bounds__(256) void tdnn_ref_kernel(const TdnnKernelParams p)
     if (rr < 0 || rr >= p.rows) continue;
     const size_t wbase = ((size_t)ch * p.n_taps + t) * p.cin_pad;
     for (int ci = 0; ci < p.cin_pad; ++ci) {
-      float xv = load_elem<BF16>(p.x, (size_t)rr * p.ldx + ci);
+      float xv = load_elem<ET>(p.x, (size_t)rr * p.ldx + ci);
       if (p.x2 != nullptr) {
-        xv += load_elem<BF16>(p.x2, (size_t)rr * p.ldx2 + ci);
-        if (BF16) xv = bf16_bits_to_f32(f32_to_bf16_bits(xv));
+        xv += load_elem<ET>(p.x2, (size_t)rr * p.ldx2 + ci);
+        if constexpr (ET != ET_F32) xv = h16_bits_to_f32<ET>(f32_to_h16_bits<ET>(xv));
       }
-      acc = fmaf(xv, load_elem<BF16>(p.w, wbase + ci), acc);
+      acc = fmaf(xv, load_elem<ET>(p.w, wbase + ci), acc);
     }
   }
   const bool valid = (p.row_valid[row >> 5] >> (row & 31)) & 1u;
   const float scale = p.scale ? p.scale[ch] : 1.0f, shift = p.shift ? p.shift[ch] : 0.0f;
-  const float yv = tdnn_epilogue<BF16>(p, acc, row, ch, p.bias[ch], scale, shift, valid);
-  store_elem<OUT_BF16>(p.y, (size_t)row * p.ldy + ch, yv);
+  const float yv = tdnn_epilogue<ET>(p, acc, row, ch, p.bias[ch], scale, shift, valid);
+  store_elem<OUT_ET>(p.y, (size_t)row * p.ldy + ch, yv);
 }
 
 // second half of a split-K layer: sum the slices in order, then the usual epilogue
-template <bool BF16, bool OUT_BF16>
+template <int ET, bool OUT16>
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const TdnnKernelParams p) {
+  constexpr int OUT_ET = OUT16 ? ET : ET_F32;
   const int ch = blockIdx.x * 64 + (threadIdx.x & 63);
   const int row = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (row >= p.rows || ch >= p.cout_store) return;
@@ -283,24 +287,57 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const TdnnKernelPa
   for (int z = 0; z < p.ksplit; ++z) acc += p.partial[((size_t)z * p.rows + row) * p.ld_partial + ch];
   const bool valid = (p.row_valid[row >> 5] >> (row & 31)) & 1u;
   const float scale = p.scale ? p.scale[ch] : 1.0f, shift = p.shift ? p.shift[ch] : 0.0f;
-  store_elem<OUT_BF16>(p.y, (size_t)row * p.ldy + ch, tdnn_epilogue<BF16>(p, acc, row, ch, p.bias[ch], scale, shift, valid));
+  store_elem<OUT_ET>(p.y, (size_t)row * p.ldy + ch, tdnn_epilogue<ET>(p, acc, row, ch, p.bias[ch], scale, shift, valid));
 }
 
 }  // namespace
 
-int launch_splitk_epilogue(const TdnnKernelParams &p, bool bf16, bool out_f32, hipStream_t s) {
+// et: ET_F32 / ET_BF16 / ET_F16 = element type of the activations and packed weights (a `bool bf16` converts to the first two)
+int launch_splitk_epilogue(const TdnnKernelParams &p, int et, bool out_f32, hipStream_t s) {
   const dim3 grid((p.cout_store + 63) / 64, (p.rows + 3) / 4), block(256);
-  if (bf16) {
-    if (out_f32) hipLaunchKernelGGL((splitk_epilogue_kernel<true, false>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((splitk_epilogue_kernel<true, true>), grid, block, 0, s, p);
-  } else {
-    hipLaunchKernelGGL((splitk_epilogue_kernel<false, false>), grid, block, 0, s, p);
-  }
+#define ASV_SPLITK(ETV) do { if (out_f32) hipLaunchKernelGGL((splitk_epilogue_kernel<ETV, false>), grid, block, 0, s, p); \
+                             else hipLaunchKernelGGL((splitk_epilogue_kernel<ETV, true>), grid, block, 0, s, p); } while (0)
+  if (et == ET_BF16) ASV_SPLITK(ET_BF16);
+  else if (et == ET_F16) ASV_SPLITK(ET_F16);
+  else hipLaunchKernelGGL((splitk_epilogue_kernel<ET_F32, false>), grid, block, 0, s, p);
+#undef ASV_SPLITK
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }
 
-int launch_tdnn_mfma(const TdnnKernelParams &p, bool bf16, bool out_f32, hipStream_t s) {
+namespace {
+template <int ET>
+int launch_tdnn_mfma_et(const TdnnKernelParams &p, bool out_f32, bool fast, int halo, dim3 grid, dim3 block, int m_tiles, int n_tiles, hipStream_t s) {
+  if (halo > kHalo) {
+    // wide-window instantiations (grid domains): plain epilogue, no second input
+    ASV_REQUIRE(fast && p.x2 == nullptr, "tdnn: layers with |tap| > %d support the plain epilogue only", kHalo);
+    if constexpr (ET != ET_F32) {
+      ASV_REQUIRE(!out_f32, "tdnn: wide-window 16-bit layers produce 16-bit rows");
+      if (halo <= kMidHalo) hipLaunchKernelGGL((tdnn_gemm_kernel<ET, true, false, kMidHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
+      else hipLaunchKernelGGL((tdnn_gemm_kernel<ET, true, false, kWideHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
+    } else {
+      if (halo <= kMidHalo) hipLaunchKernelGGL((tdnn_gemm_kernel<ET_F32, false, false, kMidHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
+      else hipLaunchKernelGGL((tdnn_gemm_kernel<ET_F32, false, false, kWideHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
+    }
+  } else if constexpr (ET != ET_F32) {
+    if (out_f32) {
+      if (fast) hipLaunchKernelGGL((tdnn_gemm_kernel<ET, false, false, kHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
+      else hipLaunchKernelGGL((tdnn_gemm_kernel<ET, false, true, kHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
+    } else {
+      if (fast) hipLaunchKernelGGL((tdnn_gemm_kernel<ET, true, false, kHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
+      else hipLaunchKernelGGL((tdnn_gemm_kernel<ET, true, true, kHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
+    }
+  } else {
+    ASV_REQUIRE(out_f32, "tdnn: f32 activations always produce f32");
+    if (fast) hipLaunchKernelGGL((tdnn_gemm_kernel<ET_F32, false, false, kHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
+    else hipLaunchKernelGGL((tdnn_gemm_kernel<ET_F32, false, true, kHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
+  }
+  ASV_HIP_CHECK(hipGetLastError());
+  return ASV_OK;
+}
+}  // namespace
+
+int launch_tdnn_mfma(const TdnnKernelParams &p, int et, bool out_f32, hipStream_t s) {
   ASV_REQUIRE(p.rows % BM == 0, "tdnn: rows %d not a multiple of %d", p.rows, BM);
   ASV_REQUIRE(p.cin_pad % kChanAlign == 0, "tdnn: cin_pad %d not a multiple of %d", p.cin_pad, kChanAlign);
   ASV_REQUIRE(p.n_taps >= 1 && p.n_taps <= ASV_MAX_TAPS, "tdnn: bad tap count %d", p.n_taps);
@@ -315,42 +352,19 @@ int launch_tdnn_mfma(const TdnnKernelParams &p, bool bf16, bool out_f32, hipStre
   // residual / "bn-relu" order go to the GENERIC ones
   const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first && p.seg_bias == nullptr &&
                     p.seg_scale == nullptr && p.res == nullptr;
-  if (halo > kHalo) {
-    // wide-window instantiations (grid domains): plain epilogue, no second input
-    ASV_REQUIRE(fast && p.x2 == nullptr, "tdnn: layers with |tap| > %d support the plain epilogue only", kHalo);
-    if (bf16) {
-      ASV_REQUIRE(!out_f32, "tdnn: wide-window bf16 layers produce bf16");
-      if (halo <= kMidHalo) hipLaunchKernelGGL((tdnn_gemm_kernel<true, true, false, kMidHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
-      else hipLaunchKernelGGL((tdnn_gemm_kernel<true, true, false, kWideHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
-    } else {
-      if (halo <= kMidHalo) hipLaunchKernelGGL((tdnn_gemm_kernel<false, false, false, kMidHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
-      else hipLaunchKernelGGL((tdnn_gemm_kernel<false, false, false, kWideHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
-    }
-  } else if (bf16) {
-    if (out_f32) {
-      if (fast) hipLaunchKernelGGL((tdnn_gemm_kernel<true, false, false, kHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
-      else hipLaunchKernelGGL((tdnn_gemm_kernel<true, false, true, kHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
-    } else {
-      if (fast) hipLaunchKernelGGL((tdnn_gemm_kernel<true, true, false, kHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
-      else hipLaunchKernelGGL((tdnn_gemm_kernel<true, true, true, kHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
-    }
-  } else {
-    ASV_REQUIRE(out_f32, "tdnn: f32 activations always produce f32");
-    if (fast) hipLaunchKernelGGL((tdnn_gemm_kernel<false, false, false, kHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
-    else hipLaunchKernelGGL((tdnn_gemm_kernel<false, false, true, kHalo>), grid, block, 0, s, p, m_tiles, n_tiles);
-  }
-  ASV_HIP_CHECK(hipGetLastError());
-  return ASV_OK;
+  if (et == ET_BF16) return launch_tdnn_mfma_et<ET_BF16>(p, out_f32, fast, halo, grid, block, m_tiles, n_tiles, s);
+  if (et == ET_F16) return launch_tdnn_mfma_et<ET_F16>(p, out_f32, fast, halo, grid, block, m_tiles, n_tiles, s);
+  return launch_tdnn_mfma_et<ET_F32>(p, out_f32, fast, halo, grid, block, m_tiles, n_tiles, s);
 }
 
-int launch_tdnn_ref(const TdnnKernelParams &p, bool bf16, bool out_f32, hipStream_t s) {
+int launch_tdnn_ref(const TdnnKernelParams &p, int et, bool out_f32, hipStream_t s) {
   const dim3 grid((p.cout_store + 63) / 64, (p.rows + 3) / 4), block(256);
-  if (bf16) {
-    if (out_f32) hipLaunchKernelGGL((tdnn_ref_kernel<true, false>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((tdnn_ref_kernel<true, true>), grid, block, 0, s, p);
-  } else {
-    hipLaunchKernelGGL((tdnn_ref_kernel<false, false>), grid, block, 0, s, p);
-  }
+#define ASV_REF(ETV) do { if (out_f32) hipLaunchKernelGGL((tdnn_ref_kernel<ETV, false>), grid, block, 0, s, p); \
+                          else hipLaunchKernelGGL((tdnn_ref_kernel<ETV, true>), grid, block, 0, s, p); } while (0)
+  if (et == ET_BF16) ASV_REF(ET_BF16);
+  else if (et == ET_F16) ASV_REF(ET_F16);
+  else hipLaunchKernelGGL((tdnn_ref_kernel<ET_F32, false>), grid, block, 0, s, p);
+#undef ASV_REF
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }

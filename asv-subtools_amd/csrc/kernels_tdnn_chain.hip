@@ -87,7 +87,7 @@ __device__ __forceinline__ void chain_glds16_s(const void *sbase, uint32_t voff,
 // POOLV: pooling epilogue of the last layer.  0 = first version (per-lane segment tracking, register-by-register seams);
 //        1 = run-based (default): every utterance inside a 32-frame fragment is one masked run over all 16 registers,
 //            packed f32 arithmetic (v_pk_add_f32 / v_pk_fma_f32).  ASV_AMD_CHAIN_POOLV selects at launch (A/B aid).
-template <int POOLV>
+template <int POOLV, int ET = ET_BF16>
 __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[CHAIN_LDS];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -138,10 +138,8 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
   auto mma2 = [&](const XFrags &f, int kg, int j, int i0, auto tr) {
 #pragma unroll
     for (int i = i0; i < i0 + 2; ++i) {
-      if constexpr (decltype(tr)::value)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, f.x[i]), __builtin_bit_cast(bf16x8_t, wf[kg][j]), acc[i][j], 0, 0, 0);
-      else
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[kg][j]), __builtin_bit_cast(bf16x8_t, f.x[i]), acc[i][j], 0, 0, 0);
+      if constexpr (decltype(tr)::value) acc[i][j] = mfma16<ET>(f.x[i], wf[kg][j], acc[i][j]);
+      else acc[i][j] = mfma16<ET>(wf[kg][j], f.x[i], acc[i][j]);
     }
   };
 
@@ -268,8 +266,8 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
 #pragma unroll
           for (int e = 0; e < 4; ++e) y[e] = fmaf(max_lo(acc[i][j][q * 4 + e], act_lo), sc[e], sh[e]);
           uint2 pk;
-          pk.x = pack_bf16x2(y[0], y[1]);
-          pk.y = pack_bf16x2(y[2], y[3]);
+          pk.x = pack_h16x2<ET>(y[0], y[1]);
+          pk.y = pack_h16x2<ET>(y[2], y[3]);
           *reinterpret_cast<uint2 *>(dst + i * 32 * YROWB) = pk;
         }
       }
@@ -557,7 +555,8 @@ int launch_tdnn_chain(const TdnnChainParams &p, hipStream_t s) {
   ASV_REQUIRE(p.pool_partial && p.row_seg && p.pool_slots >= 1, "tdnn(chain): the last layer feeds the fused pooling (partials / row map missing)");
   for (int t = 0; t < p.n_taps; ++t) ASV_REQUIRE(p.taps[t] >= -kHalo && p.taps[t] <= kHalo, "tdnn(chain): tap offset %d exceeds the %d-frame halo", p.taps[t], kHalo);
   const char *pv = getenv("ASV_AMD_CHAIN_POOLV");                // read at every launch: in-process A/B (tools/chain_ab.py)
-  if (pv != nullptr && pv[0] == '0') hipLaunchKernelGGL(tdnn_chain_kernel<0>, dim3(p.rows / CM), dim3(512), 0, s, p);
+  if (p.et == ET_F16) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_F16>), dim3(p.rows / CM), dim3(512), 0, s, p);
+  else if (pv != nullptr && pv[0] == '0') hipLaunchKernelGGL(tdnn_chain_kernel<0>, dim3(p.rows / CM), dim3(512), 0, s, p);
   else hipLaunchKernelGGL(tdnn_chain_kernel<1>, dim3(p.rows / CM), dim3(512), 0, s, p);
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;

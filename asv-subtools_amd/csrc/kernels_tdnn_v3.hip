@@ -103,7 +103,7 @@ __device__ __forceinline__ void glds16_s(const void *sbase, uint32_t voff, uint3
       if (k == 0) dbg[4] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492); \
     }                                                                                                               \
   }
-template <int ABL, bool GENERIC, bool POOL, int WM>
+template <int ABL, bool GENERIC, bool POOL, int WM, int ET = ET_BF16>
 __global__ __launch_bounds__(Geom3<WM>::WAVES * 64, WM == 0 ? 3 : 2) void tdnn_gemm_big3_kernel(const TdnnKernelParams p, int m_tiles, int n_tiles) {
   using G = Geom3<WM>;
   constexpr bool MFMA_ONLY = (ABL == 2 || ABL == 6);
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(Geom3<WM>::WAVES * 64, WM == 0 ? 3 : 2) void tdnn_g
   auto mma2 = [&](const XFrags &f, int kg, int j, int i0) {
 #pragma unroll
     for (int i = i0; i < i0 + 2; ++i)
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[kg][j]), __builtin_bit_cast(bf16x8_t, f.x[i]), acc[i][j], 0, 0, 0);
+      acc[i][j] = mfma16<ET>(wf[kg][j], f.x[i], acc[i][j]);
   };
   // ---- prologue: three windows in flight, weight fragments of step 0.  Only window 0 and the fragments are
   // waited for: VMEM retires in order, so vmcnt(2 * PIECES) leaves exactly windows 1 and 2 outstanding.
@@ -530,8 +530,8 @@ __global__ __launch_bounds__(Geom3<WM>::WAVES * 64, WM == 0 ? 3 : 2) void tdnn_g
           }
         }
         uint2 pk;
-        pk.x = pack_bf16x2(y[0], y[1]);
-        pk.y = pack_bf16x2(y[2], y[3]);
+        pk.x = pack_h16x2<ET>(y[0], y[1]);
+        pk.y = pack_h16x2<ET>(y[2], y[3]);
         if constexpr (PACKED_MASK) {               // gap rows are zeros: on the packed pairs, 2 selects per 4 values
           pk.x = valid ? pk.x : 0u;
           pk.y = valid ? pk.y : 0u;
@@ -565,7 +565,8 @@ __global__ __launch_bounds__(Geom3<WM>::WAVES * 64, WM == 0 ? 3 : 2) void tdnn_g
 
 }  // namespace
 
-bool tdnn_big3_supported(const TdnnKernelParams &p, bool bf16, bool out_f32) {
+bool tdnn_big3_supported(const TdnnKernelParams &p, int et, bool out_f32) {
+  const bool bf16 = et != ET_F32;      // either 16-bit element type (p.et selects the instantiation at launch)
   // the window refill addresses rows with 32-bit byte offsets from a scalar base: activation matrices of 4 GiB and more
   // (2 M rows x 1536 channels) go to the kernels with 64-bit addressing
   const bool fits32 = (unsigned long long)p.rows * (unsigned long long)p.ldx * 2ull < (1ull << 32);
@@ -592,6 +593,7 @@ int launch_tdnn_big3_variant(const TdnnKernelParams &p, int variant, hipStream_t
   const int m_tiles = row_count / bm, n_tiles = round_up(p.cout_store, bne) / bne;
   const dim3 grid(m_tiles * n_tiles), block(geom == 1 ? 512 : 256);
   const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first && p.seg_bias == nullptr;
+  const bool f16 = p.et == ET_F16;       // IEEE-half operands / rows: the production forms only (the ablation and A/B instantiations are bf16)
   ASV_REQUIRE(geom != 3 || p.pool_partial == nullptr, "tdnn(big3): the 128 x 128 geometry has no fused pooling form");
   if (p.pool_partial != nullptr) {
     ASV_REQUIRE(fast && p.row_seg != nullptr && p.pool_slots >= 1 && geom != 2, "tdnn(big3): fused pooling needs the plain epilogue, a row map and 128-row wave tiles");
@@ -599,14 +601,17 @@ int launch_tdnn_big3_variant(const TdnnKernelParams &p, int variant, hipStream_t
     if (geom == 0 && variant == 5) hipLaunchKernelGGL((tdnn_gemm_big3_kernel<5, false, true, 1>), grid, block, 0, s, p, m_tiles, n_tiles);
     else
 #endif
-    if (geom == 0) hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, false, true, 1>), grid, block, 0, s, p, m_tiles, n_tiles);
+    if (geom == 0 && f16) hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, false, true, 1, ET_F16>), grid, block, 0, s, p, m_tiles, n_tiles);
+    else if (geom == 0) hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, false, true, 1>), grid, block, 0, s, p, m_tiles, n_tiles);
+    else if (f16) hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, false, true, 2, ET_F16>), grid, block, 0, s, p, m_tiles, n_tiles);
     else hipLaunchKernelGGL((tdnn_gemm_big3_kernel<0, false, true, 2>), grid, block, 0, s, p, m_tiles, n_tiles);
     ASV_HIP_CHECK(hipGetLastError());
     return ASV_OK;
   }
   // The ablation instantiations (parts of the kernel compiled out: tools/gemm_ablate.hip, `make tools`) are built into the
   // tools' own object only (-DASV_WITH_ABLATION); the library carries the production forms and the one A/B variant (3).
-#define ASV_BIG3(ABLV, GENV, WMV) hipLaunchKernelGGL((tdnn_gemm_big3_kernel<ABLV, GENV, false, WMV>), grid, block, 0, s, p, m_tiles, n_tiles)
+#define ASV_BIG3(ABLV, GENV, WMV) do { if (f16 && (ABLV) <= 1) hipLaunchKernelGGL((tdnn_gemm_big3_kernel<((ABLV) <= 1 ? (ABLV) : 0), GENV, false, WMV, ET_F16>), grid, block, 0, s, p, m_tiles, n_tiles); \
+                                       else hipLaunchKernelGGL((tdnn_gemm_big3_kernel<ABLV, GENV, false, WMV>), grid, block, 0, s, p, m_tiles, n_tiles); } while (0)
   const bool tail = fast && p.cin_pad % BK != 0;
   if (geom == 0) {
     switch (variant) {
@@ -625,7 +630,7 @@ int launch_tdnn_big3_variant(const TdnnKernelParams &p, int variant, hipStream_t
       case 22: ASV_BIG3(22, false, 1); break;
 #endif
       case 3:
-        if (fast && !tail) { ASV_BIG3(3, false, 1); break; }       // A/B: the first form of the plain epilogue
+        if (fast && !tail && !f16) { ASV_BIG3(3, false, 1); break; }       // A/B: the first form of the plain epilogue
         [[fallthrough]];
       default:
         if (tail) ASV_BIG3(1, false, 1);

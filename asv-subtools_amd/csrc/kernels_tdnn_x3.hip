@@ -1,9 +1,10 @@
-// f32-grade TDNN / 1x1-conv implicit GEMM on the bf16 matrix cores ("f32x" precision mode).
+// f32-grade TDNN / 1x1-conv implicit GEMM on the 16-bit matrix cores ("f32x" precision mode).
 //
 // Activations stay f32 in HBM (every other kernel of the f32 mode works on them unchanged).  This kernel
-// splits both operands into two bf16 halves, x = xh + xl, w = wh + wl, and accumulates
-//     wh*xh + wh*xl + wl*xh                       (the dropped wl*xl term is ~2^-16 of a product)
-// in the f32 accumulators of v_mfma_f32_32x32x16_bf16: three matrix instructions per product instead of the
+// splits both operands into two 16-bit halves, x = xh + xl, w = wh + wl, and accumulates
+//     wh*xh + wh*xl + wl*xh                       (the dropped wl*xl term is ~2^-16 of a product for bf16 halves, ~2^-22 for
+//                                                  IEEE-half ones - the default since round 3: asv_amd.h ASV_FLAG_X3_SPLIT_*)
+// in the f32 accumulators of v_mfma_f32_32x32x16_{f16,bf16}: three matrix instructions per product instead of the
 // exact-f32 v_mfma_f32_32x32x2_f32, whose rate is 1/16 of the bf16 one (MI355X_MICROARCH.md: 157 vs 2500 TFLOP/s).
 // The same split is what kernels_utts.hip does for the pooled-domain layers.  Replaces, for the wide frame
 // layers of the parity mode, F.conv1d + ReLU + eval BN of components.py:107-149, 410-431.
@@ -59,19 +60,27 @@ __device__ __forceinline__ void x3_glds16(const void *gsrc, uint32_t lds_dst) {
       : "memory");
 }
 
-struct X3Frag { uint4 hi, lo; };     // 8 k values of one lane: bf16 halves
+struct X3Frag { uint4 hi, lo; };     // 8 k values of one lane: the two 16-bit halves
 
-// 8 f32 -> bf16 hi + bf16 lo (x - hi is exact: hi keeps the top 8 mantissa bits of x)
+// 8 f32 -> hi + lo in the 16-bit type ET (x - hi is exact in f32: hi keeps the leading 8 / 11 significand bits of x).
+// ET_BF16: 16 significant bits together, the whole f32 exponent range.  ET_F16: 22 bits together for |x| >= 2^-2 (lo is a
+// normal half there), an absolute error <= 2^-25 below (lo a subnormal half; the matrix cores keep subnormal inputs - checked
+// on the device by tests/test_gpu_kernels.py), |x| <= 65504.  WITH_LO = false: one rounding, no second half (the measured
+// two-instruction variants).
+template <int ET, bool WITH_LO>
 __device__ __forceinline__ X3Frag x3_split(const uint4 a, const uint4 b) {
   const float v[8] = {__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w),
                       __uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w)};
   uint32_t h[4], l[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    h[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
-    const float r0 = v[2 * k] - __uint_as_float(h[k] << 16);
-    const float r1 = v[2 * k + 1] - __uint_as_float(h[k] & 0xffff0000u);
-    l[k] = pack_bf16x2(r0, r1);
+    h[k] = pack_h16x2<ET>(v[2 * k], v[2 * k + 1]);
+    l[k] = 0u;
+    if constexpr (WITH_LO) {
+      float h0, h1;
+      unpack_h16x2<ET>(h[k], h0, h1);
+      l[k] = pack_h16x2<ET>(v[2 * k] - h0, v[2 * k + 1] - h1);
+    }
   }
   X3Frag f;
   f.hi = make_uint4(h[0], h[1], h[2], h[3]);
@@ -79,7 +88,8 @@ __device__ __forceinline__ X3Frag x3_split(const uint4 a, const uint4 b) {
   return f;
 }
 
-template <bool GENERIC>
+// ET: the 16-bit type of the operand halves; TERMS: bit 0 = w_hi x_hi, bit 1 = w_hi x_lo, bit 2 = w_lo x_hi
+template <bool GENERIC, int ET, int TERMS>
 __global__ __launch_bounds__(256, 3) void tdnn_gemm_x3_kernel(const TdnnKernelParams p, int m_tiles, int n_tiles) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[XRING + 3 * 256 * 4];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -144,7 +154,8 @@ __global__ __launch_bounds__(256, 3) void tdnn_gemm_x3_kernel(const TdnnKernelPa
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       w.h[j] = *reinterpret_cast<const uint4 *>(wh_base + j * frag_stride + off);
-      w.l[j] = *reinterpret_cast<const uint4 *>(wl_base + j * frag_stride + off);
+      if constexpr ((TERMS & 4) != 0) w.l[j] = *reinterpret_cast<const uint4 *>(wl_base + j * frag_stride + off);
+      else w.l[j] = make_uint4(0, 0, 0, 0);
     }
   };
   auto load_x = [&](int c, int d, int kg, XFrags &x) {
@@ -155,7 +166,7 @@ __global__ __launch_bounds__(256, 3) void tdnn_gemm_x3_kernel(const TdnnKernelPa
       const int w = i * 32 + lr + kHalo + d;
       const uint4 a = *reinterpret_cast<const uint4 *>(Ab + w * XROWB + xswz(w, s0) * 16);
       const uint4 b = *reinterpret_cast<const uint4 *>(Ab + w * XROWB + xswz(w, s0 + 1) * 16);
-      x.f[i] = x3_split(a, b);
+      x.f[i] = x3_split<ET, (TERMS & 2) != 0>(a, b);
     }
   };
 
@@ -170,15 +181,17 @@ __global__ __launch_bounds__(256, 3) void tdnn_gemm_x3_kernel(const TdnnKernelPa
   auto mma = [&](const XFrags &x, const WFrags &w) {
     // term-major order: every accumulator is touched once per 4 MFMAs (no back-to-back dependency)
 #pragma unroll
-    for (int term = 0; term < 3; ++term)
+    for (int term = 0; term < 3; ++term) {
+      if (((TERMS >> term) & 1) == 0) continue;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const uint4 a = (term == 2) ? w.l[j] : w.h[j];
           const uint4 b = (term == 1) ? x.f[i].lo : x.f[i].hi;
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<ET>(a, b, acc[i][j]);
         }
+    }
   };
 
   // ---- prologue: windows 0..2 in flight, fragments of k-group 0; wait for window 0 only
@@ -234,6 +247,7 @@ __global__ __launch_bounds__(256, 3) void tdnn_gemm_x3_kernel(const TdnnKernelPa
   // ---- epilogue: acc[i][j][r]: frame = m0 + i*32 + lr, channel = n0 + wn*64 + j*32 + 8*(r>>2) + 4*lh + (r&3)
   float *scr = reinterpret_cast<float *>(lds) + wn * (32 * XSPITCH);
   const float act_lo = (p.act1 == ASV_ACT_RELU) ? 0.0f : -INFINITY;
+  const float unscale = p.w_unscale;           // 1 / the power of two the host multiplied the weights by (exact; 1 for the bf16 split)
   float *yg = reinterpret_cast<float *>(p.y);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -251,12 +265,13 @@ __global__ __launch_bounds__(256, 3) void tdnn_gemm_x3_kernel(const TdnnKernelPa
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           if constexpr (GENERIC) {
-            float z = acc[i][j][q * 4 + e] + b[e];
+            float z = fmaf(acc[i][j][q * 4 + e], unscale, b[e]);
             z = p.affine_first ? apply_act(z * sc[e] + sh[e], p.act1) : apply_act(z, p.act1) * sc[e] + sh[e];
             z = apply_act(z, p.act2);
             y[e] = valid ? z : 0.0f;
           } else {
-            y[e] = tdnn_epilogue_fast(acc[i][j][q * 4 + e], b[e], act_lo, sc[e], sh[e], valid);
+            const float z = fmaxf(fmaf(acc[i][j][q * 4 + e], unscale, b[e]), act_lo) * sc[e] + sh[e];      // = tdnn_epilogue_fast for unscale = 1
+            y[e] = valid ? z : 0.0f;
           }
         }
         *reinterpret_cast<float4 *>(scr + lr * XSPITCH + j * 32 + 8 * q + 4 * lh) = make_float4(y[0], y[1], y[2], y[3]);
@@ -290,8 +305,17 @@ int launch_tdnn_x3(const TdnnKernelParams &p, hipStream_t s) {
   const int m_tiles = p.rows / XBM, n_tiles = round_up(p.cout_store, XBN) / XBN;
   const dim3 grid(m_tiles * n_tiles), block(256);
   const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first;
-  if (fast) hipLaunchKernelGGL((tdnn_gemm_x3_kernel<false>), grid, block, 0, s, p, m_tiles, n_tiles);
-  else hipLaunchKernelGGL((tdnn_gemm_x3_kernel<true>), grid, block, 0, s, p, m_tiles, n_tiles);
+  const int terms = (p.x3_terms & 7) | 1;
+  ASV_REQUIRE(p.x3_et == ET_BF16 || p.x3_et == ET_F16, "tdnn(x3): split type %d", p.x3_et);
+  ASV_REQUIRE(p.w_unscale > 0.0f, "tdnn(x3): weight scale missing");
+#define ASV_X3(GENV, ETV, TV) hipLaunchKernelGGL((tdnn_gemm_x3_kernel<GENV, ETV, TV>), grid, block, 0, s, p, m_tiles, n_tiles)
+  // the reduced-product measurement variants exist for the plain epilogue only (a layer with another one runs all three products)
+#define ASV_X3_ET(ETV) do { if (!fast) ASV_X3(true, ETV, 7); else if (terms == 7) ASV_X3(false, ETV, 7); else if (terms == 3) ASV_X3(false, ETV, 3); \
+                            else if (terms == 5) ASV_X3(false, ETV, 5); else ASV_X3(false, ETV, 1); } while (0)
+  if (p.x3_et == ET_F16) ASV_X3_ET(ET_F16);
+  else ASV_X3_ET(ET_BF16);
+#undef ASV_X3_ET
+#undef ASV_X3
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }

@@ -9,11 +9,13 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cmath>
 #include <map>
 #include <memory>
 #include <vector>
 
 #include "asv_internal.h"
+#include "host_convert.h"
 
 namespace asv {
 
@@ -28,32 +30,20 @@ void set_error(const char *fmt, ...) {
   g_last_error = buf;
 }
 
-uint16_t f32_to_bf16_host(float f) {
-  uint32_t u;
-  memcpy(&u, &f, 4);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
-}
-
-static float bf16_to_f32_host(uint16_t h) {
-  const uint32_t u = (uint32_t)h << 16;
-  float f;
-  memcpy(&f, &u, 4);
-  return f;
-}
+static uint16_t f32_to_h16_host(float f, int et) { return et == ET_F16 ? f32_to_f16_host(f) : f32_to_bf16_host(f); }
+static float h16_to_f32_host(uint16_t h, int et) { return et == ET_F16 ? f16_to_f32_host(h) : bf16_to_f32_host(h); }
 
 void pack_tdnn_weight(const float *w, int out_ch, int in_ch, int tot_ctx, int left_ctx, const int *taps, int n_taps,
-                      int cout_pad, int cin_pad, bool bf16, void *dst) {
+                      int cout_pad, int cin_pad, int et, void *dst) {
   const size_t n = (size_t)cout_pad * n_taps * cin_pad;
-  if (bf16) memset(dst, 0, n * 2); else memset(dst, 0, n * 4);
+  if (et != ET_F32) memset(dst, 0, n * 2); else memset(dst, 0, n * 4);
   for (int co = 0; co < out_ch; ++co)
     for (int t = 0; t < n_taps; ++t) {
       const int k = taps[t] - left_ctx;
       const size_t base = ((size_t)co * n_taps + t) * cin_pad;
       for (int ci = 0; ci < in_ch; ++ci) {
         const float v = w[((size_t)co * in_ch + ci) * tot_ctx + k];
-        if (bf16) reinterpret_cast<uint16_t *>(dst)[base + ci] = f32_to_bf16_host(v);
+        if (et != ET_F32) reinterpret_cast<uint16_t *>(dst)[base + ci] = f32_to_h16_host(v, et);
         else reinterpret_cast<float *>(dst)[base + ci] = v;
       }
     }
@@ -65,8 +55,12 @@ size_t tdnn_weight_frag_elems(int cout_pad, int cin_pad, int n_taps) {
 
 // MFMA-fragment order for kernels_tdnn_v3.hip: [n_frag32][tap][chunk64][k_group16][lane][8];
 // lane = (k half lh, channel lr): channel n_frag*32 + lr, k = chunk*64 + k_group*16 + lh*8 + e.
+// et: ET_BF16 / ET_F16 = the 16-bit type of the fragments.  dst_lo (the f32x mode): the second halves w * scale - hi;
+// `scale` (a power of two, exact) multiplies every weight first - the half-precision split uses it to lift the weights of a
+// layer into the upper part of the half range, where hi AND lo are normal numbers (22 significant bits together); the
+// kernel's epilogue multiplies the accumulator by 1 / scale (exact).
 void pack_tdnn_weight_frags(const float *w, int out_ch, int in_ch, int tot_ctx, int left_ctx, const int *taps, int n_taps,
-                            int cout_pad, int cin_pad, uint16_t *dst, uint16_t *dst_lo) {
+                            int cout_pad, int cin_pad, uint16_t *dst, uint16_t *dst_lo, int et, float scale) {
   const int nchunks = round_up(cin_pad, 64) / 64;
   memset(dst, 0, tdnn_weight_frag_elems(cout_pad, cin_pad, n_taps) * 2);
   if (dst_lo) memset(dst_lo, 0, tdnn_weight_frag_elems(cout_pad, cin_pad, n_taps) * 2);
@@ -77,12 +71,23 @@ void pack_tdnn_weight_frags(const float *w, int out_ch, int in_ch, int tot_ctx, 
       for (int ci = 0; ci < in_ch; ++ci) {
         const int c = ci / 64, kg = (ci % 64) / 16, lh = (ci % 16) / 8, e = ci % 8;
         const size_t idx = ((((size_t)nf * n_taps + t) * nchunks + c) * 4 + kg) * 512 + (size_t)(lh * 32 + lr) * 8 + e;
-        const float v = w[((size_t)co * in_ch + ci) * tot_ctx + k];
-        dst[idx] = f32_to_bf16_host(v);
-        if (dst_lo) dst_lo[idx] = f32_to_bf16_host(v - bf16_to_f32_host(dst[idx]));      // f32x mode: w = hi + lo
+        const float v = w[((size_t)co * in_ch + ci) * tot_ctx + k] * scale;
+        dst[idx] = f32_to_h16_host(v, et);
+        if (dst_lo) dst_lo[idx] = f32_to_h16_host(v - h16_to_f32_host(dst[idx], et), et);      // f32x mode: w = hi + lo
       }
     }
   }
+}
+
+// Power of two that lifts the largest weight of a layer to [2^13, 2^14) (the half-precision split of the f32x mode): every
+// weight down to 2^-15 of the largest keeps a normal lo half; the products grow by the same factor, far inside f32.
+static float x3_weight_scale(const float *w, size_t n) {
+  float mx = 0.0f;
+  for (size_t i = 0; i < n; ++i) mx = std::max(mx, std::fabs(w[i]));
+  if (!(mx > 0.0f) || !std::isfinite(mx)) return 1.0f;
+  int e = 0;
+  (void)std::frexp(mx, &e);                       // mx = m * 2^e, 0.5 <= m < 1
+  return std::ldexp(1.0f, 14 - e);
 }
 
 namespace {
@@ -121,6 +126,7 @@ struct Op {
   void *wlo = nullptr;           // pooled layers in bf16 precision mode: bf16 lo halves (kernels_utts.hip)
   float *bias = nullptr, *scale = nullptr, *shift = nullptr;
   int cin_pad = 0, cout_pad = 0, cout_store = 0;
+  float w_scale = 1.0f;          // f32x mode, half-precision split: the power of two the fragment weights were multiplied by
   bool utts = false;             // op runs in the utts domain (always f32)
   bool has_affine = false;
   int fused_pool = -1;           // TDNN op: index of the statistics-pooling op folded into its epilogue
@@ -177,11 +183,14 @@ struct asv_net {
   std::vector<Stamp> stamps;
   std::vector<hipEvent_t> event_pool;
 
-  bool frames_bf16() const { return precision == ASV_PREC_BF16; }
+  bool frames_h16() const { return precision == ASV_PREC_BF16 || precision == ASV_PREC_F16; }     // 16-bit frames-domain storage
+  int frames_et() const { return precision == ASV_PREC_BF16 ? ET_BF16 : (precision == ASV_PREC_F16 ? ET_F16 : ET_F32); }
+  int x3_et() const { return (flags & ASV_FLAG_X3_SPLIT_BF16) ? ET_BF16 : ET_F16; }                  // f32x: type of the operand halves
+  int x3_terms() const { return 1 | ((flags & ASV_FLAG_X3_NO_XLO) ? 0 : 2) | ((flags & ASV_FLAG_X3_NO_WLO) ? 0 : 4); }
   bool x3() const { return precision == ASV_PREC_F32X; }        // f32 storage, split-bf16 matrix products
   bool is_utts(int domain) const { return domains[domain].kind == ASV_DOMAIN_UTTS; }
-  bool dom_bf16(int domain) const { return !is_utts(domain) && frames_bf16(); }
-  size_t elem_size(int domain) const { return dom_bf16(domain) ? 2 : 4; }
+  int dom_et(int domain) const { return is_utts(domain) ? ET_F32 : frames_et(); }                    // element type of a domain's rows
+  size_t elem_size(int domain) const { return dom_et(domain) != ET_F32 ? 2 : 4; }
 };
 
 namespace {
@@ -358,7 +367,8 @@ int asv_device_count(int *count) {
 
 int asv_net_create(asv_net_t **out, int device, int precision, unsigned flags, int feat_dim) {
   ASV_REQUIRE(out != nullptr, "asv_net_create: null out pointer");
-  ASV_REQUIRE(precision == ASV_PREC_F32 || precision == ASV_PREC_BF16 || precision == ASV_PREC_F32X, "asv_net_create: unknown precision %d", precision);
+  ASV_REQUIRE(precision == ASV_PREC_F32 || precision == ASV_PREC_BF16 || precision == ASV_PREC_F32X || precision == ASV_PREC_F16, "asv_net_create: unknown precision %d", precision);
+  ASV_REQUIRE((flags & ASV_FLAG_X3_SPLIT_BF16) == 0 || (flags & ASV_FLAG_X3_SPLIT_F16) == 0, "asv_net_create: both split types requested");
   ASV_REQUIRE(feat_dim >= 1, "asv_net_create: feat_dim %d", feat_dim);
   int ndev = 0;
   ASV_HIP_CHECK(hipGetDeviceCount(&ndev));
@@ -464,7 +474,8 @@ int asv_net_add_tdnn(asv_net_t *net, const asv_tdnn_desc_t *d) {
   op.kind = OP_TDNN;
   op.tdnn = *d;
   op.utts = net->is_utts(dom);
-  const bool bf16 = net->dom_bf16(dom);
+  const int et = net->dom_et(dom);
+  const bool bf16 = et != ET_F32;                  // 16-bit rows and weights (bf16 or half)
   op.cin_pad = round_up(d->in_ch, kChanAlign);
   op.cout_pad = round_up(d->out_ch, kBigTileN);
   op.cout_store = round_up(d->out_ch, kChanAlign);
@@ -474,7 +485,7 @@ int asv_net_add_tdnn(asv_net_t *net, const asv_tdnn_desc_t *d) {
     const size_t n = (size_t)op.cout_pad * d->n_taps * op.cin_pad;
     std::vector<unsigned char> packed(n * (bf16 ? 2 : 4));
     pack_tdnn_weight(d->weight, d->out_ch, d->in_ch, d->w_tot_context, d->w_left_context, d->taps, d->n_taps, op.cout_pad,
-                     op.cin_pad, bf16, packed.data());
+                     op.cin_pad, et, packed.data());
     if ((rc = dev_upload(net, packed.data(), packed.size(), &op.w))) return rc;
     // the two fragment orders are mutually exclusive per layer: a 3x3 trunk convolution the conv2d kernels take never needs
     // the v3 order (grid_conv_* precede big3 in the dispatch and accept every such layer), and each family has its own pointer
@@ -482,13 +493,16 @@ int asv_net_add_tdnn(asv_net_t *net, const asv_tdnn_desc_t *d) {
                              d->in_ch == op.cin_pad && d->out_ch == d->in_ch;
     if (bf16 && !conv2d_pack && op.cout_store > 96 && op.cin_pad >= 64) {         // candidates of the 256- / 128-channel tiles (kernels_tdnn_v3.hip)
       std::vector<uint16_t> frags(tdnn_weight_frag_elems(op.cout_pad, op.cin_pad, d->n_taps));
-      pack_tdnn_weight_frags(d->weight, d->out_ch, d->in_ch, d->w_tot_context, d->w_left_context, d->taps, d->n_taps, op.cout_pad, op.cin_pad, frags.data());
+      pack_tdnn_weight_frags(d->weight, d->out_ch, d->in_ch, d->w_tot_context, d->w_left_context, d->taps, d->n_taps, op.cout_pad, op.cin_pad, frags.data(), nullptr, et);
       if ((rc = dev_upload(net, frags.data(), frags.size() * 2, &op.wfrag))) return rc;
     }
     if (net->x3() && !op.utts && net->domains[dom].kind == ASV_DOMAIN_FRAMES && op.cout_store >= 192 && op.cin_pad >= 32) {
-      // f32x mode: hi / lo bf16 halves of the weights in the same fragment order (kernels_tdnn_x3.hip)
+      // f32x mode: hi / lo halves of the weights in the same fragment order (kernels_tdnn_x3.hip); the half-precision split
+      // scales the layer's weights by a power of two first (see x3_weight_scale)
       std::vector<uint16_t> hi(tdnn_weight_frag_elems(op.cout_pad, op.cin_pad, d->n_taps)), lo(hi.size());
-      pack_tdnn_weight_frags(d->weight, d->out_ch, d->in_ch, d->w_tot_context, d->w_left_context, d->taps, d->n_taps, op.cout_pad, op.cin_pad, hi.data(), lo.data());
+      op.w_scale = net->x3_et() == ET_F16 ? x3_weight_scale(d->weight, (size_t)d->out_ch * d->in_ch * d->w_tot_context) : 1.0f;
+      pack_tdnn_weight_frags(d->weight, d->out_ch, d->in_ch, d->w_tot_context, d->w_left_context, d->taps, d->n_taps, op.cout_pad, op.cin_pad, hi.data(), lo.data(),
+                             net->x3_et(), op.w_scale);
       if ((rc = dev_upload(net, hi.data(), hi.size() * 2, &op.wfrag))) return rc;
       if ((rc = dev_upload(net, lo.data(), lo.size() * 2, &op.wlo))) return rc;
     }
@@ -503,12 +517,12 @@ int asv_net_add_tdnn(asv_net_t *net, const asv_tdnn_desc_t *d) {
           for (int ci = 0; ci < d->in_ch; ++ci) {
             const int kg = ci / 16, lh = (ci % 16) / 8, e = ci % 8, nf = co / 32, lr = co % 32;
             frags[((size_t)(t * kgs + kg) * nfs + nf) * 512 + (size_t)(lh * 32 + lr) * 8 + e] =
-                f32_to_bf16_host(d->weight[((size_t)co * d->in_ch + ci) * d->w_tot_context + k]);
+                f32_to_h16_host(d->weight[((size_t)co * d->in_ch + ci) * d->w_tot_context + k], et);
           }
       }
       if ((rc = dev_upload(net, frags.data(), frags.size() * 2, &op.wconv))) return rc;
     }
-    if (op.utts && (net->frames_bf16() || net->x3())) {
+    if (op.utts && (net->frames_h16() || net->x3())) {
       // pooled-domain layers keep f32 activations; their GEMM runs on the bf16 matrix cores with every
       // operand split into two bf16 halves, the weight halves in the fragment order kernels_utts.hip walks:
       // [32-channel fragment][32-k step][j][lane = (k half lh, channel lr)][8], k = 32 * step + 16 * lh + 8 * j + e
@@ -609,7 +623,7 @@ int asv_net_add_lde_pool(asv_net_t *net, const asv_lde_desc_t *d) {
 int asv_net_add_res2(asv_net_t *net, const asv_res2_desc_t *d) {
   ASV_REQUIRE(net && d && !net->finalized, "asv_net_add_res2: net is null or finalized");
   ASV_REQUIRE(d->struct_size == sizeof(asv_res2_desc_t), "asv_net_add_res2: struct_size mismatch");
-  ASV_REQUIRE(net->frames_bf16(), "res2: the one-kernel Res2NetBlock exists for the bf16 precision mode only");
+  ASV_REQUIRE(net->frames_h16(), "res2: the one-kernel Res2NetBlock exists for the 16-bit precision modes (bf16, f16) only");
   ASV_REQUIRE(d->branches >= 1 && d->branches <= 7 && d->dilation >= 1 && d->dilation <= kHalo, "res2: %d branches, dilation %d", d->branches, d->dilation);
   ASV_REQUIRE(d->weight && d->bias && d->scale && d->shift, "res2: weight / bias / scale / shift are required");
   const int ch = (d->branches + 1) * kRes2Width;
@@ -626,7 +640,7 @@ int asv_net_add_res2(asv_net_t *net, const asv_res2_desc_t *d) {
   const size_t per_branch = tdnn_weight_frag_elems(W, W, 3);
   std::vector<uint16_t> frags(per_branch * d->branches);
   for (int b = 0; b < d->branches; ++b)
-    pack_tdnn_weight_frags(d->weight + (size_t)b * W * W * tot, W, W, tot, -d->dilation, taps, 3, W, W, frags.data() + per_branch * b);
+    pack_tdnn_weight_frags(d->weight + (size_t)b * W * W * tot, W, W, tot, -d->dilation, taps, 3, W, W, frags.data() + per_branch * b, nullptr, net->frames_et());
   if ((rc = dev_upload(net, frags.data(), frags.size() * 2, &op.wfrag))) return rc;
   if ((rc = upload_padded(net, d->bias, d->branches * W, d->branches * W, 0.0f, &op.bias))) return rc;
   if ((rc = upload_padded(net, d->scale, d->branches * W, d->branches * W, 0.0f, &op.scale))) return rc;
@@ -655,7 +669,7 @@ int asv_net_add_eltwise(asv_net_t *net, const asv_eltwise_desc_t *d) {
                 net->bufs[d->seg_norm_buf].channels >= 2 * d->channels && d->seg_norm_mode >= 1 && d->seg_norm_mode <= 3,
                 "eltwise: bad per-segment normalisation buffer / mode");
   ASV_REQUIRE(d->act >= ASV_ACT_NONE && d->act <= ASV_ACT_SIGMOID, "eltwise: unknown activation %d", d->act);
-  const int vec = net->dom_bf16(dom) ? 8 : 4;
+  const int vec = net->dom_et(dom) != ET_F32 ? 8 : 4;
   ASV_REQUIRE(d->out_ch_off + round_up(d->channels, vec) <= net->bufs[d->out_buf].ld, "eltwise: padded view exceeds pitch");
   ASV_REQUIRE((d->out2_buf >= 0) == (d->d_buf >= 0), "eltwise: the second output and its addend come together");
   if (d->out2_buf >= 0) {
@@ -715,7 +729,7 @@ int asv_net_finalize(asv_net_t *net, int out_buf, int embed_dim) {
   ASV_REQUIRE(!net->ops.empty(), "asv_net_finalize: empty program");
   // fuse "layer -> StatisticsPooling" when the layer's output has no other reader: the 157 MB tensor
   // (C2: 52k frames x 1500 channels) is then never written to or re-read from HBM
-  if ((net->flags & ASV_FLAG_NO_FUSE) == 0 && net->frames_bf16()) {
+  if ((net->flags & ASV_FLAG_NO_FUSE) == 0 && net->frames_h16()) {
     for (size_t i = 0; i + 1 < net->ops.size(); ++i) {
       Op &a = net->ops[i], &b = net->ops[i + 1];
       if (a.kind != OP_TDNN || b.kind != OP_POOL || a.utts || a.wfrag == nullptr) continue;
@@ -741,7 +755,7 @@ int asv_net_finalize(asv_net_t *net, int out_buf, int embed_dim) {
   }
   // chains "layer -> 512, [1-tap 512 -> 512]*, 1-tap + fused pooling" whose intermediate tensors nobody else reads run as
   // ONE kernel with the 128 x 512 tiles resident in LDS (x-vector: tdnn3 -> tdnn4 -> tdnn5 -> pooling)
-  if ((net->flags & (ASV_FLAG_NO_FUSE | ASV_FLAG_NO_CHAIN)) == 0 && net->frames_bf16()) {
+  if ((net->flags & (ASV_FLAG_NO_FUSE | ASV_FLAG_NO_CHAIN)) == 0 && net->frames_h16()) {
     auto plain = [&](const Op &o) {
       const auto &d = o.tdnn;
       return o.kind == OP_TDNN && !o.utts && o.wfrag != nullptr && net->bufs[d.in_buf].domain == ASV_DOMAIN_FRAMES && d.in2_buf < 0 && d.seg_bias_buf < 0 &&
@@ -805,7 +819,7 @@ int asv_net_describe(const asv_net_t *net, char *buf, size_t cap) {
   std::string s;
   char line[512];
   snprintf(line, sizeof(line), "asv_net precision=%s flags=%u feat_dim=%d buffers=%zu ops=%zu out=%d embed_dim=%d\n",
-           net->precision == ASV_PREC_BF16 ? "bf16" : (net->precision == ASV_PREC_F32X ? "f32x" : "f32"), net->flags, net->feat_dim, net->bufs.size(), net->ops.size(), net->out_buf, net->embed_dim);
+           net->precision == ASV_PREC_BF16 ? "bf16" : (net->precision == ASV_PREC_F16 ? "f16" : (net->precision == ASV_PREC_F32X ? "f32x" : "f32")), net->flags, net->feat_dim, net->bufs.size(), net->ops.size(), net->out_buf, net->embed_dim);
   s += line;
   for (size_t i = 0; i < net->bufs.size(); ++i) {
     const Domain &dm = net->domains[net->bufs[i].domain];
@@ -1023,9 +1037,11 @@ int run_ops(RunCtx &c, size_t n_ops) {
         const auto &d = op.tdnn;
         const int domid = net->bufs[d.in_buf].domain;
         const DomainRun &dr = c.dom[domid];
-        const bool bf16 = net->dom_bf16(domid);
+        const int et = net->dom_et(domid);
+        const bool bf16 = et != ET_F32;              // 16-bit rows (bf16 or half)
         TdnnKernelParams p;
         memset(&p, 0, sizeof(p));
+        p.et = et; p.x3_et = net->x3_et(); p.x3_terms = net->x3_terms(); p.w_unscale = 1.0f / op.w_scale;
         p.x = view(c, d.in_buf, d.in_ch_off); p.ldx = net->bufs[d.in_buf].ld;
         if (d.in2_buf >= 0) { p.x2 = view(c, d.in2_buf, d.in2_ch_off); p.ldx2 = net->bufs[d.in2_buf].ld; }
         p.w = op.w; p.bias = op.bias; p.scale = op.scale; p.shift = op.shift;
@@ -1061,7 +1077,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
             cp.n_mid = (int)(l - i - 1);
             for (size_t k = i + 1; k < l; ++k) cp.mid[k - i - 1] = layer_of(net->ops[k]);
             cp.last = layer_of(lo);
-            cp.pool_slots = slots; cp.ld_partial = lo.cout_pad; cp.row_seg = dr.row_seg;
+            cp.pool_slots = slots; cp.ld_partial = lo.cout_pad; cp.row_seg = dr.row_seg; cp.et = et;
             if ((rc = ensure(net->poolpart_dev, (size_t)(p.rows / 128) * slots * 2 * 3 * cp.ld_partial * 4, c.s, false))) return rc;
             cp.pool_partial = reinterpret_cast<float *>(net->poolpart_dev.ptr);
             double fl = 0.0;
@@ -1136,12 +1152,12 @@ int run_ops(RunCtx &c, size_t n_ops) {
           pool_slots = worst;
           if (pool_slots > 16) pool_slots = 0;               // many tiny utterances: use the separate pooling kernel
         }
-        const bool big3 = !use_ref && narrow && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && tdnn_big3_supported(p, bf16, !bf16);
+        const bool big3 = !use_ref && narrow && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && tdnn_big3_supported(p, et, !bf16);
         const bool utts_kernel = !use_ref && op.utts;
         const bool x3 = !use_ref && !op.utts && net->x3() && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && tdnn_x3_supported(p);
-        const bool c1_conv = !use_ref && net->domains[domid].kind == 2 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && grid_conv_c1_supported(p, bf16, d.in_ch);
-        const bool narrow_conv = !use_ref && net->domains[domid].kind == 2 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && grid_conv_narrow_supported(p, bf16);
-        const bool wide_conv = !use_ref && net->domains[domid].kind == 2 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && grid_conv_wide_supported(p, bf16);
+        const bool c1_conv = !use_ref && net->domains[domid].kind == 2 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && grid_conv_c1_supported(p, et, d.in_ch);
+        const bool narrow_conv = !use_ref && net->domains[domid].kind == 2 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && grid_conv_narrow_supported(p, et);
+        const bool wide_conv = !use_ref && net->domains[domid].kind == 2 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && grid_conv_wide_supported(p, et);
         if (!use_ref && !big3 && op.utts && !utts_kernel) {
           // pooled-domain layers have one row per utterance (M is tiny, K is large): slice K over more
           // workgroups.  The slice count depends on K only, never on the batch, so an utterance's
@@ -1169,7 +1185,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
           if ((rc = ensure(net->poolpart_dev, (size_t)(p.rows / 128) * pool_slots * 3 * p.ld_partial * 4, c.s, false))) return rc;
           p.pool_partial = reinterpret_cast<float *>(net->poolpart_dev.ptr);
         }
-        if (use_ref) rc = launch_tdnn_ref(p, bf16, !bf16, c.s);
+        if (use_ref) rc = launch_tdnn_ref(p, et, !bf16, c.s);
         else if (utts_kernel) {
           // last layer, every utterance a single chunk: the kernel also produces the caller's [utterance][embed_dim] result
           if (c.final_out != nullptr && i + 1 == net->ops.size() && d.out_buf == net->out_buf && d.out_ch_off == 0 && d.out_ch == net->embed_dim &&
@@ -1177,7 +1193,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
             p.final_out = c.final_out; p.final_ld = net->embed_dim; p.final_len = c.seg_frames;
             c.final_written = true;
           }
-          rc = launch_utts_gemm(p, bp.segments, net->frames_bf16() || net->x3(), c.s);
+          rc = launch_utts_gemm(p, bp.segments, net->frames_h16() || net->x3(), c.s);
         }
         else if (narrow_conv) rc = launch_grid_conv_narrow(p, c.s);
         else if (wide_conv) rc = launch_grid_conv_wide(p, c.s);
@@ -1185,8 +1201,8 @@ int run_ops(RunCtx &c, size_t n_ops) {
         else if (x3) rc = launch_tdnn_x3(p, c.s);
         else if (big3) rc = launch_tdnn_big3(p, c.s);
         else {
-          rc = launch_tdnn_mfma(p, bf16, !bf16, c.s);
-          if (!rc && p.ksplit > 1) rc = launch_splitk_epilogue(p, bf16, !bf16, c.s);
+          rc = launch_tdnn_mfma(p, et, !bf16, c.s);
+          if (!rc && p.ksplit > 1) rc = launch_splitk_epilogue(p, et, !bf16, c.s);
         }
         if (rc) return rc;
         if ((rc = prof.end())) return rc;
@@ -1221,7 +1237,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         p.row_stride = d.per_bin ? dm.pitch : 1;
         p.groups = d.per_bin ? dm.width : 1;
         if ((rc = prof.begin(K_POOL, 0, (int)i))) return rc;
-        if ((rc = launch_stats_pool(p, bp.segments, net->dom_bf16(domid), c.s))) return rc;
+        if ((rc = launch_stats_pool(p, bp.segments, net->dom_et(domid), c.s))) return rc;
         if ((rc = prof.end())) return rc;
         break;
       }
@@ -1232,7 +1248,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         const int group = d.logit_group > 1 ? d.logit_group : (d.shared_logits ? d.channels : 1);
         rc = launch_attentive_pool(view(c, d.x_buf, d.x_ch_off), net->bufs[d.x_buf].ld, view(c, d.logit_buf, d.logit_ch_off), net->bufs[d.logit_buf].ld,
                                    d.channels, dr.seg_row0, dr.seg_len, bp.segments, d.eps,
-                                   reinterpret_cast<float *>(net->arena[d.out_buf].ptr) + d.out_ch_off, net->bufs[d.out_buf].ld, net->frames_bf16(), group, d.logit_softplus2 != 0, op.scale, op.shift, c.s);
+                                   reinterpret_cast<float *>(net->arena[d.out_buf].ptr) + d.out_ch_off, net->bufs[d.out_buf].ld, net->frames_et(), group, d.logit_softplus2 != 0, op.scale, op.shift, c.s);
         if (rc) return rc;
         if ((rc = prof.end())) return rc;
         break;
@@ -1244,7 +1260,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         if ((rc = prof.begin(K_ATT, 0, (int)i))) return rc;
         rc = launch_lde_pool(view(c, d.x_buf, d.x_ch_off), net->bufs[d.x_buf].ld, d.channels, dr.rows_pad, op.scale, op.shift, d.n_centres,
                              reinterpret_cast<float *>(net->lde_dev.ptr), dr.seg_row0, dr.seg_len, bp.segments,
-                             reinterpret_cast<float *>(net->arena[d.out_buf].ptr) + d.out_ch_off, net->bufs[d.out_buf].ld, net->frames_bf16(), c.s);
+                             reinterpret_cast<float *>(net->arena[d.out_buf].ptr) + d.out_ch_off, net->bufs[d.out_buf].ld, net->frames_et(), c.s);
         if (rc) return rc;
         if ((rc = prof.end())) return rc;
         break;
@@ -1270,7 +1286,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         if (op.utts) { p.rows = bp.segments; }
         else { p.rows = c.dom[domid].rows_pad; p.row_seg = c.dom[domid].row_seg; p.row_valid = c.dom[domid].row_valid; }
         if ((rc = prof.begin(K_ELT, 0, (int)i))) return rc;
-        if ((rc = launch_eltwise(p, net->dom_bf16(domid), c.s))) return rc;
+        if ((rc = launch_eltwise(p, net->dom_et(domid), c.s))) return rc;
         if ((rc = prof.end())) return rc;
         break;
       }
@@ -1282,7 +1298,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         p.x = view(c, d.in_buf, d.in_ch_off); p.ldx = net->bufs[d.in_buf].ld;
         p.y = view(c, d.out_buf, d.out_ch_off); p.ldy = net->bufs[d.out_buf].ld;
         p.rows = dr.rows_pad; p.wfrag = op.wfrag; p.bias = op.bias; p.scale = op.scale; p.shift = op.shift; p.row_valid = dr.row_valid;
-        p.branches = d.branches; p.dilation = d.dilation;
+        p.branches = d.branches; p.dilation = d.dilation; p.et = net->frames_et();
         if ((rc = prof.begin(K_TDNN, 2.0 * (double)bp.frames * kRes2Width * kRes2Width * 3 * d.branches, (int)i))) return rc;
         static const bool res2_dbg = getenv("ASV_AMD_RES2_DBG") != nullptr;          // developer aid: phase durations to stderr
         DevMem dbg;
@@ -1318,7 +1334,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         const DomainRun &dg = c.dom[domid];
         if ((rc = prof.begin(K_GATHER, 0, (int)i))) return rc;
         rc = launch_grid_from_frames(net->arena[op.gin.in_buf].ptr, net->bufs[op.gin.in_buf].ld, net->feat_dim, c.dom[ASV_DOMAIN_FRAMES].seg_row0, dg.seg_row0, dg.row_seg, dg.row_valid,
-                                     dg.rows_pad, net->domains[domid].pitch, net->arena[op.gin.out_buf].ptr, net->bufs[op.gin.out_buf].ld, net->frames_bf16(), c.s);
+                                     dg.rows_pad, net->domains[domid].pitch, net->arena[op.gin.out_buf].ptr, net->bufs[op.gin.out_buf].ld, net->frames_et(), c.s);
         if (rc) return rc;
         if ((rc = prof.end())) return rc;
         break;
@@ -1337,7 +1353,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         p.in_pitch = net->domains[din].pitch; p.in_width = net->domains[din].width;
         p.out_pitch = net->domains[dout].pitch; p.out_rows = c.dom[dout].rows_pad;
         if ((rc = prof.begin(K_GATHER, 0, (int)i))) return rc;
-        if ((rc = launch_im2col(p, net->frames_bf16(), c.s))) return rc;
+        if ((rc = launch_im2col(p, net->frames_et(), c.s))) return rc;
         if ((rc = prof.end())) return rc;
         break;
       }
@@ -1352,7 +1368,7 @@ int pack_features(RunCtx &c, const float *feats) {
   const DomainRun &dr = c.dom[ASV_DOMAIN_FRAMES];
   if ((rc = prof.begin(K_PACK, 0))) return rc;
   if ((rc = launch_pack_input(feats, c.net->feat_dim, c.seg_src0, dr.seg_row0, dr.row_seg, dr.rows_pad, c.net->arena[0].ptr, c.net->bufs[0].ld,
-                              c.net->frames_bf16(), c.s))) return rc;
+                              c.net->frames_et(), c.s))) return rc;
   return prof.end();
 }
 
@@ -1400,7 +1416,7 @@ int asv_tdnn_forward(const asv_tdnn_desc_t *d, int precision, unsigned flags, co
   if ((rc = pack_features(c, x))) return rc;
   if ((rc = run_ops(c, 1))) return rc;
   const DomainRun &dr = c.dom[ASV_DOMAIN_FRAMES];
-  if ((rc = launch_unpack_rows(net->arena[ob].ptr, net->bufs[ob].ld, d->out_ch, c.seg_src0, dr.seg_row0, dr.row_seg, dr.rows_pad, y, net->frames_bf16(), c.s))) return rc;
+  if ((rc = launch_unpack_rows(net->arena[ob].ptr, net->bufs[ob].ld, d->out_ch, c.seg_src0, dr.seg_row0, dr.row_seg, dr.rows_pad, y, net->frames_et(), c.s))) return rc;
   ASV_HIP_CHECK(hipStreamSynchronize(c.s));
   return ASV_OK;
 }

@@ -5,6 +5,7 @@
 #include <vector>
 #include <algorithm>
 #include "../asv_internal.h"
+#include "../host_convert.h"
 
 using namespace asv;
 

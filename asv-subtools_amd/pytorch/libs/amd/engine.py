@@ -17,14 +17,36 @@ from . import ir as _ir
 
 PRECISIONS = {"f32": capi.PREC_F32, "fp32": capi.PREC_F32, "float32": capi.PREC_F32,
               "bf16": capi.PREC_BF16, "bfloat16": capi.PREC_BF16,
-              "f32x": capi.PREC_F32X, "bf16x3": capi.PREC_F32X}
+              "f16": capi.PREC_F16, "fp16": capi.PREC_F16, "half": capi.PREC_F16, "float16": capi.PREC_F16,
+              "f32x": capi.PREC_F32X, "bf16x3": capi.PREC_F32X, "f16x3": capi.PREC_F32X}
+H16_MODES = ("bf16", "bfloat16", "f16", "fp16", "half", "float16")       # 16-bit frames-domain storage
+
+# options of the f32x mode, appended with '-' (e.g. "f32x-bf16"): the 16-bit type the operands are split into, and the
+# reduced-product MEASUREMENT variants ("why not two matrix instructions per product", DESIGN.md "Precision modes")
+X3_OPTIONS = {"bf16": capi.FLAG_X3_SPLIT_BF16, "f16": capi.FLAG_X3_SPLIT_F16, "half": capi.FLAG_X3_SPLIT_F16,
+              "noxlo": capi.FLAG_X3_NO_XLO, "nowlo": capi.FLAG_X3_NO_WLO}
+
+
+def parse_precision(name):
+    """'f32x-bf16-noxlo' -> ('f32x', capi.PREC_F32X, flag bits).  'bf16x3' / 'f16x3' name the split type themselves."""
+    parts = name.lower().split("-")
+    base = parts[0]
+    if base not in PRECISIONS:
+        raise ValueError("unknown precision %r (have %s)" % (name, sorted(set(PRECISIONS))))
+    bits = {"bf16x3": capi.FLAG_X3_SPLIT_BF16, "f16x3": capi.FLAG_X3_SPLIT_F16}.get(base, 0)
+    for opt in parts[1:]:
+        if PRECISIONS[base] != capi.PREC_F32X or opt not in X3_OPTIONS:
+            raise ValueError("precision %r: option %r (only the f32x mode has options: %s)" % (name, opt, sorted(X3_OPTIONS)))
+        bits |= X3_OPTIONS[opt]
+    return base, PRECISIONS[base], bits
 
 
 def default_precision():
-    """'f32x' (the default): f32 storage, matrix products on the bf16 cores with both operands split into bf16 hi + lo
-    halves - within the reference's 1e-4 embedding gate and the 0.01 % EER gate at ~3x the rate of 'f32' (exact f32-input
-    MFMA, the bit-for-bit fma chain); 'bf16' is the throughput mode (bf16 storage and products, f32 accumulate, f32 pooled
-    tail; measured EER delta 0.024 % on the 50 000-trial gate, tests/test_gpu_eer_gate.py)."""
+    """'f32x' (the default): f32 storage, matrix products on the 16-bit cores with both operands split into hi + lo halves
+    (IEEE half since round 3: 22 significant bits per operand) - within the reference's 1e-4 embedding gate and the 0.01 % EER
+    gate at ~3x the rate of 'f32' (exact f32-input MFMA, the bit-for-bit fma chain); 'bf16' / 'f16' are the throughput modes
+    (16-bit storage and products, f32 accumulate, f32 pooled tail; 'f16' rounds 8x finer at the same rate, operands within
+    +-65504; their measured distance from the gates: tests/test_gpu_eer_gate.py, DESIGN.md "Precision modes")."""
     return os.environ.get("ASV_AMD_PRECISION", "f32x").lower()
 
 
@@ -53,14 +75,12 @@ class Engine(object):
         self.graph = graph
         self.device_index = int(device_index)
         self.precision = (precision or default_precision()).lower()
-        if self.precision not in PRECISIONS:
-            raise ValueError("unknown precision %r (have %s)" % (precision, sorted(set(PRECISIONS))))
-        self.flags = default_flags() if flags is None else int(flags)
+        self.precision_base, prec_id, prec_bits = parse_precision(self.precision)
+        self.flags = (default_flags() if flags is None else int(flags)) | prec_bits
         self.embed_dim = graph.output.channels
         self.feat_dim = graph.feat_dim
         self._net = C.c_void_p()
-        capi.check(self.lib.asv_net_create(C.byref(self._net), self.device_index, PRECISIONS[self.precision],
-                                           self.flags, graph.feat_dim), "asv_net_create")
+        capi.check(self.lib.asv_net_create(C.byref(self._net), self.device_index, prec_id, self.flags, graph.feat_dim), "asv_net_create")
         try:
             self._build()
         except Exception:
@@ -76,8 +96,8 @@ class Engine(object):
             if spec[0] == "grid":
                 dom_of[i] = capi.check(L.asv_net_define_grid(self._net, spec[1], spec[2], spec[3]), "asv_net_define_grid")
         # one device buffer per IR tensor that something writes as a whole or in slices
-        # bf16 engines run every Res2NetBlock as one kernel (kernels_res2.hip); the parity modes keep one layer per branch
-        fuse = self.precision in ("bf16", "bfloat16") and (self.flags & (capi.FLAG_REF_KERNELS | capi.FLAG_NO_FUSE | capi.FLAG_SMALL_TILES)) == 0
+        # 16-bit engines run every Res2NetBlock as one kernel (kernels_res2.hip); the parity modes keep one layer per branch
+        fuse = self.precision_base in H16_MODES and (self.flags & (capi.FLAG_REF_KERNELS | capi.FLAG_NO_FUSE | capi.FLAG_SMALL_TILES)) == 0
         ops = g.fused_res2_ops() if fuse else g.ops
         if (self.flags & (capi.FLAG_REF_KERNELS | capi.FLAG_NO_FUSE)) == 0:
             ops = g.fused_add_ops(ops)               # exact in every precision mode (see its docstring)

@@ -56,12 +56,24 @@ int         asv_device_count(int *count);
 #define ASV_PREC_F32X  2   /* f32 activations; the wide frame layers and the pooled layers run on the bf16 matrix cores with both
                             * operands split into bf16 hi + lo halves (hi*hi + hi*lo + lo*hi, f32 accumulate): f32-grade results
                             * (<= 1e-4 of the reference) at ~1/3 of the bf16 rate instead of the 1/16 of the f32-input MFMA */
+#define ASV_PREC_F16   3   /* IEEE-half activations/weights, v_mfma_f32_32x32x16_f16, f32 accumulate: the rate and footprint of
+                            * ASV_PREC_BF16 with an 11-bit significand (8x less operand rounding).  Range +-65504: activations
+                            * behind eval BatchNorm and mean-normalised features are O(1..100); a value beyond it becomes
+                            * inf and the embedding NaN - loud, never silently saturated                                   */
 /* flags for asv_net_create */
 #define ASV_FLAG_REF_KERNELS 1u  /* run the plain-VALU self-check kernels instead of MFMA ones */
 #define ASV_FLAG_NO_FUSE     2u  /* disable epilogue fusions (stats pooling into the producer)  */
 #define ASV_FLAG_SMALL_TILES 4u  /* never pick the 256x256 kernels (A/B testing)                    */
 #define ASV_FLAG_BIG_V2      8u  /* reserved, ignored: the 256x256 both-operands-through-LDS kernel it selected was removed in round 2 */
 #define ASV_FLAG_NO_CHAIN   16u  /* one launch per layer: do not run tdnn -> 1-tap tdnn -> ... -> pooling chains in one kernel */
+/* ASV_PREC_F32X only: the 16-bit type both operands are split into (neither bit: the library default, half) ... */
+#define ASV_FLAG_X3_SPLIT_BF16 32u /* bf16 hi + bf16 lo: 16 significant bits per operand, the full f32 exponent range              */
+#define ASV_FLAG_X3_SPLIT_F16  64u /* half hi + half lo: 22 significant bits per operand (weights pre-scaled by a power of two per
+                                    * layer so that both halves are normal numbers), operands within +-65504                      */
+/* ... and measurement variants that drop one of the three products hi*hi + w_hi*x_lo + w_lo*x_hi (NOT f32-grade: they exist so
+ * that "two matrix instructions per product are not enough" is a measured statement, DESIGN.md "Precision modes") */
+#define ASV_FLAG_X3_NO_XLO   128u  /* activations rounded to one 16-bit value (no w_hi*x_lo product) */
+#define ASV_FLAG_X3_NO_WLO   256u  /* weights rounded to one 16-bit value (no w_lo*x_hi product)     */
 
 #define ASV_ACT_NONE    0
 #define ASV_ACT_RELU    1

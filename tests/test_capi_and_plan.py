@@ -270,3 +270,30 @@ def test_free_statistics_pooling_and_weight_normalised_affine_trace_like_their_p
         y = torch.nn.functional.conv1d(xin, w, m.a.bias)
         want = torch.cat([y.mean(2), y.std(2, unbiased=True)], dim=1)[0].numpy()
     assert rel_err(got, want) < 1e-5
+
+
+def test_host_half_and_bf16_conversions_match_numpy(tmp_path):
+    """The weight packer's f32 -> IEEE half / bf16 conversions (csrc/host_convert.h, plain C++: compiled here with g++) against
+    numpy's float16 (round-to-nearest-even, subnormals, overflow to infinity) and a bit-level bf16 reference, on random values
+    of every magnitude plus the edge cases around the half range."""
+    import subprocess
+    src = tmp_path / "conv.cc"
+    src.write_text('#include <stdio.h>\n#include "host_convert.h"\nint main() { float f; while (fread(&f, 4, 1, stdin) == 1) { unsigned short h = asv::f32_to_f16_host(f), '
+                   'b = asv::f32_to_bf16_host(f); float back = asv::f16_to_f32_host(h); fwrite(&h, 2, 1, stdout); fwrite(&b, 2, 1, stdout); fwrite(&back, 4, 1, stdout); } return 0; }\n')
+    exe = tmp_path / "conv"
+    subprocess.check_call(["g++", "-O1", "-I", os.path.join(helpers.REPO, "asv-subtools_amd", "csrc"), str(src), "-o", str(exe)])
+    r = np.random.RandomState(0)
+    vals = np.concatenate([
+        (r.randn(20000) * np.exp2(r.randint(-30, 18, 20000))).astype(np.float32),
+        np.array([0.0, -0.0, 65504.0, 65519.9, 65520.0, 65536.0, -65520.0, 1e9, 2.0 ** -14, 2.0 ** -24, 2.0 ** -25, 2.0 ** -25 * 1.0000001, 2.0 ** -26, 3 * 2.0 ** -25,
+                  6.1e-5, 5.96e-8, np.inf, -np.inf, 1.0 + 2.0 ** -11, 1.0 + 3 * 2.0 ** -11, 1.0 + 2.0 ** -11 + 2.0 ** -20], dtype=np.float32),
+        np.float16(r.randn(2000) * np.exp2(r.randint(-24, 15, 2000))).astype(np.float32)])      # exactly representable halves round-trip
+    out = subprocess.run([str(exe)], input=vals.tobytes(), capture_output=True, check=True).stdout
+    rec = np.frombuffer(out, dtype=np.dtype([("h", "<u2"), ("b", "<u2"), ("back", "<f4")]))
+    with np.errstate(over="ignore"):
+        want_h = vals.astype(np.float16)
+    assert np.array_equal(rec["h"], want_h.view(np.uint16)), np.flatnonzero(rec["h"] != want_h.view(np.uint16))[:5]
+    assert np.array_equal(rec["back"].view(np.uint32), want_h.astype(np.float32).view(np.uint32))
+    u = vals.view(np.uint32).astype(np.uint64)
+    want_b = ((u + 0x7fff + ((u >> 16) & 1)) >> 16).astype(np.uint16)                                # RNE on the upper 16 bits (no NaN in the set)
+    assert np.array_equal(rec["b"], want_b)

@@ -72,9 +72,25 @@ CASES = [
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "%dx%d_ctx%s" % (c[0], c[1], "_".join(map(str, c[2]))))
-@pytest.mark.parametrize("mode", ["f32_mfma", "f32_ref", "bf16_mfma", "bf16_ref", "f32x_mfma"])
-def test_tdnn_layer_vs_oracle(case, mode):
+def _mode_args(mode):
+    """test mode name -> (precision id, flags) of the C ABI"""
     from libs.amd import capi
+    base, _, opt = mode.partition("_")
+    prec = {"f32": capi.PREC_F32, "bf16": capi.PREC_BF16, "f16": capi.PREC_F16, "f32x": capi.PREC_F32X, "f32xb": capi.PREC_F32X}[base]
+    flags = capi.FLAG_REF_KERNELS if opt == "ref" else 0
+    if base == "f32xb":
+        flags |= capi.FLAG_X3_SPLIT_BF16
+    return prec, flags
+
+
+# bf16: 8-bit significand operands and outputs; f16: 11 bits (8x finer); f32xb: bf16 hi + lo operand halves (16 bits, the
+# lo * lo term dropped); f32x: IEEE-half hi + lo halves (22 bits): what is left is the f32 accumulation itself
+MODE_TOL = {"bf16": 2e-2, "f16": 2.5e-3, "f32xb": 2e-5, "f32x": 3e-6, "f32": 2e-5}
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "%dx%d_ctx%s" % (c[0], c[1], "_".join(map(str, c[2]))))
+@pytest.mark.parametrize("mode", ["f32_mfma", "f32_ref", "bf16_mfma", "bf16_ref", "f16_mfma", "f16_ref", "f32x_mfma", "f32xb_mfma"])
+def test_tdnn_layer_vs_oracle(case, mode):
     cin, cout, ctx, lens = case
     r = np.random.RandomState(cin * 7 + cout)
     offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
@@ -84,14 +100,39 @@ def test_tdnn_layer_vs_oracle(case, mode):
     b = (0.1 * r.randn(cout)).astype(np.float32)
     scale = r.uniform(0.5, 1.5, cout).astype(np.float32)
     shift = (0.2 * r.randn(cout)).astype(np.float32)
-    prec = capi.PREC_F32X if mode.startswith("f32x") else (capi.PREC_F32 if mode.startswith("f32") else capi.PREC_BF16)
-    flags = capi.FLAG_REF_KERNELS if mode.endswith("ref") else 0
+    prec, flags = _mode_args(mode)
     got = _tdnn_forward(x, offsets, w, b, ctx, "relu", scale, shift, False, prec, flags)
     want = _oracle_layer(x, offsets, w, b, ctx, "relu", scale, shift, False)
     err = rel_err(got, want)
-    # bf16: 8-bit mantissa operands and outputs; f32x: bf16 hi + lo operand halves (16 mantissa bits, the lo * lo term dropped)
-    tol = 2e-2 if mode.startswith("bf16") else 2e-5
+    wide = cout >= 192 and cin >= 32                # only the wide layers run on the split kernel; the others are exact f32 in the f32x modes
+    tol = MODE_TOL[mode.split("_")[0]] if (wide or not mode.startswith("f32x")) else 2e-5
     assert err < tol, "%s: rel err %g" % (mode, err)
+
+
+def test_half_split_keeps_small_operands_and_two_products_are_not_enough():
+    """The f32x mode's IEEE-half split (kernels_tdnn_x3.hip): (1) activations of magnitude 1e-2 .. 1e-3 have a SUBNORMAL lo half
+    - the matrix cores must not flush it (they would leave 2^-12 relative error, the one-rounding level); weights of any
+    magnitude are lifted into the normal range by the host's per-layer power of two.  (2) the measurement variants that drop
+    one of the three products land at the one-rounding level of the dropped operand, three orders above the full split."""
+    from libs.amd import capi
+    r = np.random.RandomState(33)
+    lens = [200, 131, 64]
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    errs = {}
+    for xs, ws in ((1.0, 1.0), (3e-3, 1.0), (1.0, 1e-4), (40.0, 30.0)):
+        x = (xs * r.randn(int(offsets[-1]), 512)).astype(np.float32)
+        w = (ws * r.randn(512, 512, 5) / 40).astype(np.float32)
+        want = _oracle_layer(x, offsets, w, None, [-2, 0, 2], None, None, None, False)
+        for name, flags in (("f16x3", 0), ("bf16x3", capi.FLAG_X3_SPLIT_BF16), ("f16 no x_lo", capi.FLAG_X3_NO_XLO), ("f16 no w_lo", capi.FLAG_X3_NO_WLO),
+                            ("f16 one product", capi.FLAG_X3_NO_XLO | capi.FLAG_X3_NO_WLO)):
+            got = _tdnn_forward(x, offsets, w, None, [-2, 0, 2], None, None, None, False, capi.PREC_F32X, flags)
+            errs[(xs, ws, name)] = rel_err(got, want)
+    print("\n[x3 split] " + "; ".join("x*%g w*%g %s: %.2e" % (k + (v,)) for k, v in errs.items()))
+    for xs, ws in ((1.0, 1.0), (3e-3, 1.0), (1.0, 1e-4), (40.0, 30.0)):
+        assert errs[(xs, ws, "f16x3")] < 3e-6, (xs, ws, errs[(xs, ws, "f16x3")])
+        assert errs[(xs, ws, "bf16x3")] < 2e-5
+        for two in ("f16 no x_lo", "f16 no w_lo"):
+            assert 2e-5 < errs[(xs, ws, two)] < 2e-3, (two, errs[(xs, ws, two)])
 
 
 def test_bf16_mfma_matches_bf16_ref_closely():
