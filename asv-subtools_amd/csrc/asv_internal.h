@@ -173,7 +173,8 @@ struct TdnnChainParams {
   const void *x; int ldx, rows, cin_pad, n_taps; int taps[ASV_MAX_TAPS];     // input of the first layer (bf16 rows)
   TdnnChainLayer first; int n_mid; TdnnChainLayer mid[2]; TdnnChainLayer last;
   float *pool_partial; int pool_slots, ld_partial; const int32_t *row_seg;    // as in TdnnKernelParams
-  unsigned long long *dbg;      // developer aid (ASV_AMD_CHAIN_DBG=1): [workgroup][wave][16] s_memtime stamps at the phase boundaries, or nullptr
+  unsigned long long *dbg;      // developer aid (ASV_AMD_CHAIN_DBG=1): [workgroup][wave][32] s_memtime stamps at the phase boundaries, or nullptr
+  int dbg_fine;                 // ASV_AMD_CHAIN_DBG >= 3: also stamps inside the first pooling epilogue of every wave
   int et;                       // ET_BF16 / ET_F16: element type of the rows and of every layer's weight fragments
 };
 int launch_tdnn_chain(const TdnnChainParams &p, hipStream_t s);

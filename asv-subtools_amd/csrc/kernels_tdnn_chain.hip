@@ -87,7 +87,10 @@ __device__ __forceinline__ void chain_glds16_s(const void *sbase, uint32_t voff,
 // POOLV: pooling epilogue of the last layer.  0 = first version (per-lane segment tracking, register-by-register seams);
 //        1 = run-based (default): every utterance inside a 32-frame fragment is one masked run over all 16 registers,
 //            packed f32 arithmetic (v_pk_add_f32 / v_pk_fma_f32).  ASV_AMD_CHAIN_POOLV selects at launch (A/B aid).
-template <int POOLV, int ET = ET_BF16>
+// ABL (developer aid, ASV_AMD_CHAIN_ABL with ASV_AMD_LIVE_TUNE=1; results are garbage): 1 = the last layer without its pooling
+//        epilogue (what do the K loops cost on their own), 2 = the epilogue's arithmetic without its global loads / stores;
+//        3 (ASV_AMD_CHAIN_DBG >= 3; results valid) = the production kernel + stamps inside every wave's first pooling epilogue.
+template <int POOLV, int ET = ET_BF16, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[CHAIN_LDS];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -97,13 +100,19 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
   const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(chain_lds_byte *)lds);
   float *par = reinterpret_cast<float *>(lds + SCR_OFF);            // bias[512] | scale[512] | shift[512] of the layer in flight
 
+  // developer aid: [workgroup][wave][32] s_memtime stamps; 0..12 phase boundaries, 14 / 15 s_memrealtime at start / end,
+  // 16..23 (dbg_fine) inside the pooling epilogue of the wave's first unit: before the fragments, after each of the four, after
+  // the final publish
   int n_stamp = 0;
   auto stamp = [&]() {
-    if (p.dbg != nullptr && lane == 0 && n_stamp < 16) p.dbg[((size_t)blockIdx.x * 8 + wave) * 16 + n_stamp] = __builtin_amdgcn_s_memtime();
+    if (p.dbg != nullptr && lane == 0 && n_stamp < 14) p.dbg[((size_t)blockIdx.x * 8 + wave) * 32 + n_stamp] = __builtin_amdgcn_s_memtime();
     ++n_stamp;
   };
+  auto fine = [&](int k) {
+    if constexpr (ABL == 3) if (p.dbg != nullptr && lane == 0) p.dbg[((size_t)blockIdx.x * 8 + wave) * 32 + 16 + k] = __builtin_amdgcn_s_memtime();
+  };
   stamp();                                                       // 0: start
-  if (p.dbg != nullptr && lane == 0) p.dbg[((size_t)blockIdx.x * 8 + wave) * 16 + 14] = __builtin_amdgcn_s_memrealtime();
+  if (p.dbg != nullptr && lane == 0) p.dbg[((size_t)blockIdx.x * 8 + wave) * 32 + 14] = __builtin_amdgcn_s_memrealtime();
   auto stage_params = [&](const TdnnChainLayer &L) {
     if (tid < 384) {
       const int which = tid >> 7, idx = (tid & 127) * 4;
@@ -245,12 +254,33 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
     }
   }
 
-  // epilogue of a 512-wide layer: [ReLU], folded BN, bf16 -> Y (row-major, 16-byte slots XOR-swizzled by row & 15); the bias
-  // is in the accumulators already
-  auto store_Y = [&](int relu) {
+  // epilogue of a 512-wide layer: [ReLU], folded BN, 16-bit -> Y (row-major, 16-byte slots XOR-swizzled by row & 15); the bias
+  // is in the accumulators already.  `affine` = false: the layer's eval BatchNorm was folded into the NEXT layer's weights and
+  // bias on the host (exact for a 1-tap consumer: W (s u + t) + b = (W diag s) u + (W t + b); runtime.hip asv_net_finalize) -
+  // what is stored is ReLU(acc) alone: one conversion per pair and the ReLU as ONE integer maximum on the packed pair
+  // (relu_h16x2) instead of a maximum and a multiply-add per value: 6 instead of 10 VALU operations per four values, in a
+  // phase in which no wave of the workgroup has matrix work to hide them behind.
+  auto store_Y = [&](int relu, bool affine) {
     const float act_lo = relu ? 0.0f : -INFINITY;
     unsigned char *yrow = lds + lr * YROWB + lh * 8;
     const int rx = lr & 15;
+    if (!affine) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          unsigned char *dst = yrow + (((wave * 8 + j * 4 + q) ^ rx) << 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            uint2 pk;
+            pk.x = pack_h16x2<ET>(acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1]);
+            pk.y = pack_h16x2<ET>(acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
+            if (relu) { pk.x = relu_h16x2(pk.x); pk.y = relu_h16x2(pk.y); }
+            *reinterpret_cast<uint2 *>(dst + i * 32 * YROWB) = pk;
+          }
+        }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -325,7 +355,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
   __builtin_amdgcn_s_barrier();            // every wave is done with the ring: Y may be written
   asm volatile("" ::: "memory");
   stamp();                                 // 3
-  store_Y(p.first.relu);
+  store_Y(p.first.relu, p.first.scale != nullptr);
   __builtin_amdgcn_s_barrier();            // Y complete; the constants of layer A are dead
   asm volatile("" ::: "memory");
   stamp();                                 // 4: Y of layer A complete
@@ -342,7 +372,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();          // nobody reads the old Y any more (and the staged constants are visible)
     asm volatile("" ::: "memory");
-    store_Y(L.relu);
+    store_Y(L.relu, L.scale != nullptr);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     stamp();                               // 6: Y of the middle layer complete
@@ -371,7 +401,13 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
       // which pool_finish_kernel merges (Chan et al.), knowing how many frames each half holds.  The BN scale multiplies the
       // three moments at publication (u = scale * act(acc): moments about a pivot are linear / quadratic in it); the BN
       // shift is added to the mean by pool_finish.
-      const float sc[2] = {L.scale != nullptr ? L.scale[cb + lr] : 1.0f, L.scale != nullptr ? L.scale[cb + 32 + lr] : 1.0f};
+      if constexpr (ABL == 1) {                // no pooling epilogue at all: the accumulators only have to stay alive up to here
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(acc[i][0]), "v"(acc[i][1]));
+        stamp();
+        continue;
+      }
+      const float sc[2] = {(ABL != 2 && L.scale != nullptr) ? L.scale[cb + lr] : 1.0f, (ABL != 2 && L.scale != nullptr) ? L.scale[cb + 32 + lr] : 1.0f};
       if constexpr (POOLV == 0) {
         float ps[2] = {0.f, 0.f}, pq[2] = {0.f, 0.f}, pv[2] = {0.f, 0.f};
         int cur_seg = -1;                    // per lane: the halves cross an utterance seam at different registers
@@ -450,9 +486,12 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
         publish(true);
       } else {
         float ps[2] = {0.f, 0.f}, pq[2] = {0.f, 0.f}, pv[2] = {0.f, 0.f};
+        const bool first_unit = ABL == 3 && cb < 512;
+        if (first_unit) fine(0);
         int cur_seg = -1;                    // uniform: all lanes walk the utterances of the tile together
         auto publish = [&]() {
           const int slot = cur_seg - first_seg;
+          if constexpr (ABL == 2) { asm volatile("" ::"v"(ps[0]), "v"(ps[1]), "v"(pq[0]), "v"(pq[1]), "v"(pv[0]), "v"(pv[1])); return; }
           if (cur_seg >= 0 && slot >= 0 && slot < p.pool_slots) {
             float *dst = p.pool_partial + ((size_t)((half * p.pool_slots + slot) * 2 + lh) * 3) * p.ld_partial + cb + lr;
   #pragma unroll
@@ -536,12 +575,14 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
               ps[1] += s2[1].x + s2[1].y; pq[1] += q2[1].x + q2[1].y;
             }
           }
+          if (first_unit) fine(1 + i);
         }
         publish();
+        if (first_unit) fine(5);
       }
       stamp();                             // 8, 10, 12: pooling epilogue of the unit done
     }
-    if (p.dbg != nullptr && lane == 0) p.dbg[((size_t)blockIdx.x * 8 + wave) * 16 + 15] = __builtin_amdgcn_s_memrealtime();
+    if (p.dbg != nullptr && lane == 0) p.dbg[((size_t)blockIdx.x * 8 + wave) * 32 + 15] = __builtin_amdgcn_s_memrealtime();
   }
 }
 
@@ -554,10 +595,19 @@ int launch_tdnn_chain(const TdnnChainParams &p, hipStream_t s) {
   ASV_REQUIRE(p.first.wfrag && p.last.wfrag && p.last.bias && p.n_mid >= 0 && p.n_mid <= 2 && p.last.cout_pad % 64 == 0, "tdnn(chain): incomplete layer description");
   ASV_REQUIRE(p.pool_partial && p.row_seg && p.pool_slots >= 1, "tdnn(chain): the last layer feeds the fused pooling (partials / row map missing)");
   for (int t = 0; t < p.n_taps; ++t) ASV_REQUIRE(p.taps[t] >= -kHalo && p.taps[t] <= kHalo, "tdnn(chain): tap offset %d exceeds the %d-frame halo", p.taps[t], kHalo);
-  const char *pv = getenv("ASV_AMD_CHAIN_POOLV");                // read at every launch: in-process A/B (tools/chain_ab.py)
-  if (p.et == ET_F16) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_F16>), dim3(p.rows / CM), dim3(512), 0, s, p);
-  else if (pv != nullptr && pv[0] == '0') hipLaunchKernelGGL(tdnn_chain_kernel<0>, dim3(p.rows / CM), dim3(512), 0, s, p);
-  else hipLaunchKernelGGL(tdnn_chain_kernel<1>, dim3(p.rows / CM), dim3(512), 0, s, p);
+  // Developer switches are read ONCE per process; with ASV_AMD_LIVE_TUNE=1 (tools/chain_ab.py: in-process interleaved A/B) at
+  // every launch.
+  static const bool live = getenv("ASV_AMD_LIVE_TUNE") != nullptr;
+  auto read_int = [](const char *name) { const char *v = getenv(name); return v != nullptr ? atoi(v) : -1; };
+  static const int poolv0 = read_int("ASV_AMD_CHAIN_POOLV"), abl0 = read_int("ASV_AMD_CHAIN_ABL");
+  const int poolv = live ? read_int("ASV_AMD_CHAIN_POOLV") : poolv0, abl = live ? read_int("ASV_AMD_CHAIN_ABL") : abl0;
+  const dim3 grid(p.rows / CM), block(512);
+  if (p.et == ET_F16) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_F16>), grid, block, 0, s, p);
+  else if (p.dbg != nullptr && p.dbg_fine) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_BF16, 3>), grid, block, 0, s, p);
+  else if (abl == 1) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_BF16, 1>), grid, block, 0, s, p);
+  else if (abl == 2) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_BF16, 2>), grid, block, 0, s, p);
+  else if (poolv == 0) hipLaunchKernelGGL(tdnn_chain_kernel<0>, grid, block, 0, s, p);
+  else hipLaunchKernelGGL(tdnn_chain_kernel<1>, grid, block, 0, s, p);
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }

@@ -690,7 +690,10 @@ int tdnn_big3_pick_geometry(const TdnnKernelParams &p) {
 // lost, and the result is 4-6 us slower on every C2 layer (89 vs 85 us on the 3-tap 512 -> 512 layer).  The row-range
 // parameters (row_begin / row_count) stay for tools/gemm_ablate.
 int launch_tdnn_big3(const TdnnKernelParams &p, hipStream_t s) {
-  const char *tune = getenv("ASV_AMD_BIG3_TUNE");            // developer aid, read at every launch: in-process A/B (tools/chain_ab.py)
+  // developer aid (in-process A/B, tools/chain_ab.py): read once per process; at every launch only with ASV_AMD_LIVE_TUNE=1
+  static const bool live = getenv("ASV_AMD_LIVE_TUNE") != nullptr;
+  static const char *tune0 = getenv("ASV_AMD_BIG3_TUNE");
+  const char *tune = live ? getenv("ASV_AMD_BIG3_TUNE") : tune0;
   if (tune != nullptr && p.tune == 0) {
     TdnnKernelParams q = p;
     q.tune = atoi(tune);

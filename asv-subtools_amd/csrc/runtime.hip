@@ -126,6 +126,11 @@ struct Op {
   void *wlo = nullptr;           // pooled layers in bf16 precision mode: bf16 lo halves (kernels_utts.hip)
   float *bias = nullptr, *scale = nullptr, *shift = nullptr;
   int cin_pad = 0, cout_pad = 0, cout_store = 0;
+  // chain candidates (16-bit modes, 1-tap layers reading a 512-channel buffer): host copies kept until asv_net_finalize, which
+  // folds the eval BatchNorm of the PREVIOUS chain layer into this layer's weights and bias (see the chain pass there)
+  std::vector<float> host_w, host_bias, host_scale, host_shift;
+  void *wfrag_fold = nullptr;    // fragment-ordered W diag(s_prev) ...
+  float *bias_fold = nullptr;    // ... and b + W t_prev
   float w_scale = 1.0f;          // f32x mode, half-precision split: the power of two the fragment weights were multiplied by
   bool utts = false;             // op runs in the utts domain (always f32)
   bool has_affine = false;
@@ -548,6 +553,17 @@ int asv_net_add_tdnn(asv_net_t *net, const asv_tdnn_desc_t *d) {
     if ((rc = upload_padded(net, d->scale, d->out_ch, op.cout_pad, 0.0f, &op.scale))) return rc;
     if ((rc = upload_padded(net, d->shift, d->out_ch, op.cout_pad, 0.0f, &op.shift))) return rc;
   }
+  if (bf16 && !op.utts && net->domains[dom].kind == ASV_DOMAIN_FRAMES && op.wfrag != nullptr && (net->flags & (ASV_FLAG_NO_FUSE | ASV_FLAG_NO_CHAIN)) == 0) {
+    // possible member of a layer chain: its BatchNorm may be folded into the next member, or the previous member's into it
+    if (d->scale) { op.host_scale.assign(d->scale, d->scale + d->out_ch); op.host_shift.assign(d->shift, d->shift + d->out_ch); }
+    if (d->n_taps == 1 && d->taps[0] == 0 && d->in_ch == kChainWidth) {
+      const size_t tot = (size_t)d->w_tot_context, k = (size_t)(0 - d->w_left_context);
+      op.host_w.resize((size_t)d->out_ch * d->in_ch);
+      for (size_t i = 0; i < op.host_w.size(); ++i) op.host_w[i] = d->weight[i * tot + k];           // the one active tap, [out][in]
+      op.host_bias.assign((size_t)d->out_ch, 0.0f);
+      if (d->bias) op.host_bias.assign(d->bias, d->bias + d->out_ch);
+    }
+  }
   op.tdnn.weight = nullptr; op.tdnn.bias = nullptr; op.tdnn.scale = nullptr; op.tdnn.shift = nullptr;
   net->ops.push_back(op);
   return ASV_OK;
@@ -798,7 +814,42 @@ int asv_net_finalize(asv_net_t *net, int out_buf, int embed_dim) {
       for (size_t k = head + 1; k < l; ++k) mids_ok &= from_resident(net->ops[k]);
       if (!mids_ok) continue;
       net->ops[head].chain_last = (int)l;
+      // Fold the eval BatchNorm y = s u + t of every chain layer but the last into its (1-tap) consumer:
+      //   W (s u + t) + b = (W diag s) u + (W t + b)          - exact in real arithmetic; the products W s are rounded to the
+      // 16-bit element type once, here, instead of s u + t being rounded per value in the kernel.  The producing layer's
+      // epilogue inside the chain kernel is then ReLU + conversion alone (kernels_tdnn_chain.hip store_Y).  The per-layer
+      // path (ASV_FLAG_NO_CHAIN, batches the chain cannot take) keeps the unfolded weights: both are uploaded.
+      static const bool no_fold = getenv("ASV_AMD_CHAIN_FOLD") != nullptr && atoi(getenv("ASV_AMD_CHAIN_FOLD")) == 0;
+      for (size_t k = head + 1; k <= l && !no_fold; ++k) {
+        Op &cur = net->ops[k];
+        const Op &prev = net->ops[k - 1];
+        if (!prev.has_affine || prev.host_scale.empty() || cur.host_w.empty()) continue;
+        const int out_ch = cur.tdnn.out_ch, in_ch = cur.tdnn.in_ch;
+        std::vector<float> wf((size_t)out_ch * in_ch), bf((size_t)cur.cout_pad, 0.0f);
+        for (int co = 0; co < out_ch; ++co) {
+          double acc = cur.host_bias[co];
+          for (int ci = 0; ci < in_ch; ++ci) {
+            const float w = cur.host_w[(size_t)co * in_ch + ci];
+            wf[(size_t)co * in_ch + ci] = w * prev.host_scale[ci];
+            acc += (double)w * (double)prev.host_shift[ci];
+          }
+          bf[co] = (float)acc;
+        }
+        const int tap0 = 0;
+        std::vector<uint16_t> frags(tdnn_weight_frag_elems(cur.cout_pad, cur.cin_pad, 1));
+        pack_tdnn_weight_frags(wf.data(), out_ch, in_ch, 1, 0, &tap0, 1, cur.cout_pad, cur.cin_pad, frags.data(), nullptr, net->frames_et());
+        ASV_ON_DEVICE(net->device);
+        int rc;
+        if ((rc = dev_upload(net, frags.data(), frags.size() * 2, &cur.wfrag_fold))) return rc;
+        void *bdev = nullptr;
+        if ((rc = dev_upload(net, bf.data(), bf.size() * sizeof(float), &bdev))) return rc;
+        cur.bias_fold = reinterpret_cast<float *>(bdev);
+      }
     }
+  }
+  for (Op &o : net->ops) {                       // the host copies have served their purpose
+    std::vector<float>().swap(o.host_w); std::vector<float>().swap(o.host_bias);
+    std::vector<float>().swap(o.host_scale); std::vector<float>().swap(o.host_shift);
   }
   net->out_buf = out_buf; net->embed_dim = embed_dim; net->finalized = true;
   net->arena.resize(net->bufs.size());
@@ -1071,54 +1122,73 @@ int run_ops(RunCtx &c, size_t n_ops) {
             memset(&cp, 0, sizeof(cp));
             cp.x = p.x; cp.ldx = p.ldx; cp.rows = p.rows; cp.cin_pad = p.cin_pad; cp.n_taps = p.n_taps;
             for (int t = 0; t < p.n_taps; ++t) cp.taps[t] = p.taps[t];
-            auto layer_of = [&](const Op &o) { TdnnChainLayer L; L.wfrag = o.wfrag; L.bias = o.bias; L.scale = o.scale; L.shift = o.shift;
-                                               L.relu = o.tdnn.act1 == ASV_ACT_RELU; L.cout_pad = o.cout_pad; return L; };
-            cp.first = layer_of(op);
+            // a layer whose consumer holds folded weights (wfrag_fold) stores ReLU(acc) only: its scale / shift are not passed
+            auto layer_of = [&](size_t k) {
+              const Op &o = net->ops[k];
+              const bool folded_in = o.wfrag_fold != nullptr;                                  // the previous layer's BN sits in these weights
+              const bool folded_out = k < l && net->ops[k + 1].wfrag_fold != nullptr;          // this layer's BN sits in the next layer's
+              TdnnChainLayer L;
+              L.wfrag = folded_in ? o.wfrag_fold : o.wfrag; L.bias = folded_in ? o.bias_fold : o.bias;
+              L.scale = folded_out ? nullptr : o.scale; L.shift = folded_out ? nullptr : o.shift;
+              L.relu = o.tdnn.act1 == ASV_ACT_RELU; L.cout_pad = o.cout_pad;
+              return L;
+            };
+            cp.first = layer_of(i);
             cp.n_mid = (int)(l - i - 1);
-            for (size_t k = i + 1; k < l; ++k) cp.mid[k - i - 1] = layer_of(net->ops[k]);
-            cp.last = layer_of(lo);
+            for (size_t k = i + 1; k < l; ++k) cp.mid[k - i - 1] = layer_of(k);
+            cp.last = layer_of(l);
             cp.pool_slots = slots; cp.ld_partial = lo.cout_pad; cp.row_seg = dr.row_seg; cp.et = et;
             if ((rc = ensure(net->poolpart_dev, (size_t)(p.rows / 128) * slots * 2 * 3 * cp.ld_partial * 4, c.s, false))) return rc;
             cp.pool_partial = reinterpret_cast<float *>(net->poolpart_dev.ptr);
             double fl = 0.0;
             for (size_t k = i; k <= l; ++k) fl += 2.0 * (double)bp.frames * net->ops[k].tdnn.in_ch * net->ops[k].tdnn.out_ch * net->ops[k].tdnn.n_taps;
             if ((rc = prof.begin(K_TDNN, fl, (int)i))) return rc;
-            static const bool chain_dbg = getenv("ASV_AMD_CHAIN_DBG") != nullptr;        // developer aid: phase durations to stderr
+            static const int chain_dbg = getenv("ASV_AMD_CHAIN_DBG") != nullptr ? std::max(1, atoi(getenv("ASV_AMD_CHAIN_DBG"))) : 0;   // developer aid: phase durations to stderr
             DevMem dbg;
             if (chain_dbg) {
-              if ((rc = ensure(dbg, (size_t)(p.rows / 128) * 8 * 16 * 8, c.s, true))) return rc;
+              if ((rc = ensure(dbg, (size_t)(p.rows / 128) * 8 * 32 * 8, c.s, true))) return rc;
               cp.dbg = reinterpret_cast<unsigned long long *>(dbg.ptr);
+              cp.dbg_fine = chain_dbg >= 3;
             }
             if ((rc = launch_tdnn_chain(cp, c.s))) return rc;
             if ((rc = prof.end())) return rc;
             if (chain_dbg) {
               const size_t nwg = (size_t)(p.rows / 128);
-              std::vector<unsigned long long> h(nwg * 8 * 16);
+              std::vector<unsigned long long> h(nwg * 8 * 32);
               ASV_HIP_CHECK(hipStreamSynchronize(c.s));
               ASV_HIP_CHECK(hipMemcpy(h.data(), dbg.ptr, h.size() * 8, hipMemcpyDeviceToHost));
               ASV_HIP_CHECK(hipFree(dbg.ptr));
-              double sum[16] = {0}; size_t cnt = 0; double cyc = 0, rt = 0;
+              double sum[32] = {0}; size_t cnt = 0; double cyc = 0, rt = 0;
               for (size_t w = 0; w < nwg * 8; ++w) {
-                const unsigned long long *t = &h[w * 16];
+                const unsigned long long *t = &h[w * 32];
                 if (t[0] == 0) continue;
                 for (int k = 1; k < 13; ++k) if (t[k] > t[k - 1]) sum[k] += (double)(t[k] - t[k - 1]);
+                if (chain_dbg >= 3) {
+                  if (t[16] > t[7]) sum[16] += (double)(t[16] - t[7]);                                   // unit's K loop end -> epilogue body
+                  for (int k = 17; k < 22; ++k) if (t[k] > t[k - 1]) sum[k] += (double)(t[k] - t[k - 1]);
+                }
                 if (t[12] > t[0] && t[15] > t[14]) { cyc += (double)(t[12] - t[0]); rt += (double)(t[15] - t[14]); }
                 ++cnt;
               }
               fprintf(stderr, "[chain dbg] %zu waves, mean cycles per phase:", cnt);
               fprintf(stderr, " [shader clock %.0f MHz, %.1f us per workgroup]", rt > 0 ? 100.0 * cyc / rt : 0.0, cnt ? rt / 100.0 / (double)cnt : 0.0);
               for (int k = 1; k < 13; ++k) fprintf(stderr, " %d:%.0f", k, sum[k] / (double)std::max<size_t>(cnt, 1));
+              if (chain_dbg >= 3) {
+                fprintf(stderr, " | first epilogue: entry %.0f, fragments", sum[16] / (double)std::max<size_t>(cnt, 1));
+                for (int k = 17; k < 21; ++k) fprintf(stderr, " %.0f", sum[k] / (double)std::max<size_t>(cnt, 1));
+                fprintf(stderr, ", publish %.0f", sum[21] / (double)std::max<size_t>(cnt, 1));
+              }
               fprintf(stderr, "\n");
-              static const int chain_dbg_level = atoi(getenv("ASV_AMD_CHAIN_DBG"));
-              if (chain_dbg_level >= 2) {                 // raw timelines of two workgroups: waves w and w + 4 share a SIMD
+              if (chain_dbg == 2 || chain_dbg >= 4) {                 // raw timelines of two workgroups: waves w and w + 4 share a SIMD
                 const size_t picks[2] = {nwg / 4, nwg / 2 + 1};
                 for (size_t wg : picks) {
                   if (wg >= nwg) continue;
                   unsigned long long t0 = ~0ull;
-                  for (int w = 0; w < 8; ++w) if (h[(wg * 8 + w) * 16] != 0) t0 = std::min(t0, h[(wg * 8 + w) * 16]);
+                  for (int w = 0; w < 8; ++w) if (h[(wg * 8 + w) * 32] != 0) t0 = std::min(t0, h[(wg * 8 + w) * 32]);
                   for (int w = 0; w < 8; ++w) {
                     fprintf(stderr, "[chain dbg] workgroup %zu wave %d stamps (cycles since the first wave's stamp 0):", wg, w);
-                    for (int k = 0; k < 13; ++k) fprintf(stderr, " %lld", (long long)(h[(wg * 8 + w) * 16 + k] - t0));
+                    for (int k = 0; k < 13; ++k) fprintf(stderr, " %lld", (long long)(h[(wg * 8 + w) * 32 + k] - t0));
+                    if (chain_dbg >= 4) { fprintf(stderr, " |"); for (int k = 16; k < 22; ++k) fprintf(stderr, " %lld", (long long)(h[(wg * 8 + w) * 32 + k] - t0)); }
                     fprintf(stderr, "\n");
                   }
                 }

@@ -9,6 +9,8 @@ for p in (REPO, PKG, os.path.dirname(os.path.abspath(__file__))):
     if p not in sys.path:
         sys.path.insert(0, p)
 os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+# the library reads its developer switches (kernel variants for A/B) once per process; the tests flip them between launches
+os.environ.setdefault("ASV_AMD_LIVE_TUNE", "1")
 
 
 def pytest_configure(config):
