@@ -115,3 +115,18 @@ def synth_trials(labels, n_trials, seed, target_frac=0.5):
                 b = r.randint(n)
         enroll[t], test[t], tgt[t] = a, b, int(labels[a] == labels[b])
     return enroll, test, tgt
+
+
+def synth_planted_utts(n_spk, per_spk, dim, t_lo, t_hi, noise, seed=3):
+    """Planted-speaker feature matrices for the EER gates (tests/test_gpu_eer_gate.py, bench.py's `parity.eer` leg): speaker s owns a
+    fixed random feature track, an utterance is its first T ~ randint[t_lo, t_hi] frames plus white noise.  Returns
+    (list of [T, dim] float32 matrices, int labels)."""
+    r = np.random.RandomState(int(seed))
+    mats, labels = [], []
+    for s in range(int(n_spk)):
+        base = synth_feats(t_hi, dim, 500_000 + s)
+        for _ in range(int(per_spk)):
+            T = int(r.randint(t_lo, t_hi + 1))
+            mats.append((base[:T] + noise * r.standard_normal((T, dim)).astype(np.float32)).astype(np.float32))
+            labels.append(s)
+    return mats, np.asarray(labels)

@@ -14,9 +14,15 @@ step (the path's only exchange).
 Prints ONE JSON line on rank 0 (contract in the task statement): `value` from the MEDIAN of `repeats` back-to-back
 timed regions of exactly K steps each (one region is ~16 ms: the regions are repeated until >= 1 s has been measured),
 `roofline` (frame-level GEMM launches, hipEvent-timed inside libasv_amd.so on the extract stream during timed steps),
-`parity` (utterances of the timed batch against the CPU port of the reference), `cpu_baseline` (N = 1 only) and, at
-N = 1, `supplementary` records: the same workload in the f32x / f32 precision modes and the configs[2] / configs[4]
-extractors (ECAPA-TDNN C = 1024, ResNet34-SE).
+`parity` (utterances of the timed batch against the CPU port of the reference + the north star's two gates: embeddings
+within 1e-4, EER delta < 0.01 % on a 50 000-trial planted-speaker set against the exact-f32 extraction), `cpu_baseline`
+(N = 1 only) and, at N = 1, `supplementary` records: the same workload in the f16 / f32x / f32 precision modes (each with
+its gates; `value_parity_grade` = the fastest mode that passes both) and the configs[2] / configs[4] extractors
+(ECAPA-TDNN C = 1024; ResNet34-SE on fixed 200-frame and on variable 200..1000-frame utterances).
+
+`--backend gloo --dry-run` runs the same control flow - self-launch, barriers, MAX over ranks, the double-buffered
+asynchronous all-gather, rank 0's JSON line - on CPU ranks with a stand-in extractor (no device, no library): the N > 1
+path exercised end to end where no multi-GPU box is available (tests/test_bench_selflaunch_gloo.py).
 """
 
 import argparse
@@ -35,7 +41,8 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [os.path.join(REPO, "asv-subtools_amd", "pytorch"), REPO]
 
 # dense MFMA peaks, MI355X_MICROARCH.md.  f32x issues 3 bf16 matrix instructions per product: its roofline is the bf16 one / 3.
-PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "f32x": 2500.0 / 3.0}
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3, "f32x": 2500.0 / 3.0}
+GATE_REL, GATE_EER = 1e-4, 0.01          # BASELINE.json north_star: embeddings within 1e-4 relative, EER delta < 0.01 % absolute
 
 MODELS = {
     "xvector": ("xvector.py", "Xvector(%d,10,training=False)", "BASELINE configs[1]: standard TDNN x-vector"),
@@ -54,7 +61,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32", "f32x"])
+    ap.add_argument("--precision", default="bf16", help="bf16 (default, BASELINE configs[1]) | f16 | f32x[-bf16|-f16] | f32")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL on the GPUs (default); gloo needs --dry-run")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU ranks, stand-in extractor: exercises self-launch, barriers, the double-buffered all-gather and the JSON line without a device")
+    ap.add_argument("--eer-trials", type=int, default=50000, help="trials of the EER gate leg (0 = skip)")
+    ap.add_argument("--lengths", default=None, help="'lo:hi' = utterance lengths ~ U[lo, hi] (seeded) instead of --frames")
     ap.add_argument("--batch", type=int, default=None,
                     help="utterances per GPU per step (default: 640 for the x-vector - 640 x 204 padded rows = 1020 row tiles of 128, two "
                          "column tiles each, fill the 512 workgroup slots of the device in whole rounds, +15 %% over 256; 256 for the others)")
@@ -92,7 +104,7 @@ def self_launch(args):
 class Workload(object):
     """One model in one precision mode on this rank's device, with a device-resident synthetic batch."""
 
-    def __init__(self, args, kind, precision, batch, frames, rank, dev):
+    def __init__(self, args, kind, precision, batch, frames, rank, dev, lengths=None):
         import numpy as np
         import torch
         import libs.support.utils as utils
@@ -108,10 +120,52 @@ class Workload(object):
         model.cuda()
         model.amd_precision = precision
         self.model, self.eng = model, model._amd_engine()
-        self.mats = [synth.synth_feats(frames, self.D, 10_000 * rank + i) for i in range(batch)]
+        # fixed length (the BASELINE configs[1..2] shapes) or seeded U[lo, hi] lengths (configs[4]: 200..1000 frames), packed ragged
+        self.lengths = np.full(batch, frames, dtype=np.int64) if lengths is None else synth.synth_lengths(batch, lengths[0], lengths[1], 77 + rank)
+        self.mats = [synth.synth_feats(int(t), self.D, 10_000 * rank + i) for i, t in enumerate(self.lengths)]
         self.feats = torch.from_numpy(np.concatenate(self.mats, axis=0)).to(dev)
-        self.offsets = (np.arange(batch + 1) * frames).astype(np.int32)
+        self.offsets = np.concatenate([[0], np.cumsum(self.lengths)]).astype(np.int32)
+        self.frames_total = int(self.lengths.sum())
         self.dev = dev
+
+    def extract(self, out):
+        self.eng.extract_device(self.feats, self.offsets, out=out)
+
+
+class DryRunEngine(object):
+    """Stand-in for libs.amd.engine.Engine in --dry-run: the same call surface on CPU tensors, trivially cheap arithmetic."""
+    embed_dim = 32
+
+    def extract_device(self, feats, offsets, out=None, **kw):
+        import torch
+        idx = torch.repeat_interleave(torch.arange(len(offsets) - 1), torch.as_tensor(offsets[1:] - offsets[:-1]).long())
+        acc = torch.zeros((len(offsets) - 1, feats.shape[1]), dtype=torch.float32).index_add_(0, idx, feats)
+        res = acc[:, :self.embed_dim]
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
+
+    def set_profiling(self, enable):
+        pass
+
+    def get_profile(self):
+        return []
+
+
+class DryRunWorkload(object):
+    def __init__(self, args, batch, frames, rank):
+        import numpy as np
+        import torch
+        self.kind, self.precision, self.B, self.T, self.D = "xvector", "dry-run", batch, frames, args.feat_dim
+        self.title, self.creation = "dry run (stand-in extractor on CPU ranks, no device)", "none"
+        self.eng = DryRunEngine()
+        r = np.random.RandomState(1000 + rank)
+        self.feats = torch.from_numpy(r.randn(batch * frames, max(self.D, DryRunEngine.embed_dim)).astype(np.float32))
+        self.offsets = (np.arange(batch + 1) * frames).astype(np.int32)
+        self.lengths = np.full(batch, frames, dtype=np.int64)
+        self.frames_total = batch * frames
+        self.mats, self.sd = None, None
 
     def extract(self, out):
         self.eng.extract_device(self.feats, self.offsets, out=out)
@@ -131,12 +185,25 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    assert torch.cuda.is_available(), "bench.py needs a ROCm device"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+    dry = args.dry_run
+    if args.backend == "gloo" and not dry:
+        sys.exit("bench.py: --backend gloo is the CPU dry run of the multi-rank control flow: pass --dry-run")
+    if dry:
+        dev = torch.device("cpu")
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="gloo")
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a ROCm device"
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+
+    def dev_sync():
+        if not dry:
+            torch.cuda.synchronize(dev)
 
     if args.frames is None:
         args.frames = 300 if args.model == "ecapa" else 200
@@ -180,10 +247,10 @@ def main():
                 if pending[k] is not None:
                     pending[k].wait()
                     pending[k] = None
-            torch.cuda.synchronize(dev)
+            dev_sync()
             if world > 1:
                 dist.barrier()
-                torch.cuda.synchronize(dev)
+                dev_sync()
 
         def timed(n, sample_events=0):
             """sample_events = k > 0: per-GEMM hipEvents are recorded on every k-th step of the timed region
@@ -206,7 +273,7 @@ def main():
         while time.perf_counter() - t_settle < args.settle_seconds:       # untimed: bring the device to its steady clock
             for _ in range(50):
                 extract_once(outs[0])                                    # local work only: the count differs between ranks,
-            torch.cuda.synchronize(dev)                                   # so no collective may be issued here
+            dev_sync()                                   # so no collective may be issued here
         for _ in range(warmup):
             step()
         barrier()
@@ -231,11 +298,20 @@ def main():
             if sampled:
                 rows.extend(eng.get_profile())
         eng.set_profiling(False)
+        gather_ok = None
+        if dry and collective:
+            # the dry run also checks WHAT the double-buffered gather delivered: every rank's block of the last two steps
+            # against that rank's stand-in result, recomputed here from its seed
+            barrier()
+            want = torch.cat([DryRunWorkload(args, B, wl.T, r).eng.extract_device(DryRunWorkload(args, B, wl.T, r).feats, wl.offsets) for r in range(world)])
+            gather_ok = all(bool(torch.equal(g, want)) for g in gathered)
         allr = sorted(dts + dts_sampled)
         med = allr[len(allr) // 2]
         rec = {"value": round(world * B * steps / med, 1), "ms_per_step": round(1e3 * med / steps, 4), "repeats": len(allr),
                "timed_seconds": round(sum(allr), 3),
                "ms_per_step_min_max": [round(1e3 * allr[0] / steps, 4), round(1e3 * allr[-1] / steps, 4)]}
+        if gather_ok is not None:
+            rec["gather_verified"] = gather_ok
         if dts and dts_sampled:
             rec["value_without_event_recording"] = round(world * B * steps / sorted(dts)[len(dts) // 2], 1)
         gemm_ms = sum(r["total_ms"] for r in rows if r["name"] == "tdnn_gemm")
@@ -243,20 +319,20 @@ def main():
         gemm_n = sum(r["launches"] for r in rows if r["name"] == "tdnn_gemm")
         if gemm_ms > 0:
             achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12
-            peak = PEAK_TFLOPS[wl.precision]
+            peak = PEAK_TFLOPS[wl.precision.split("-")[0]]
             per_frame, per_utt = eng.graph.flops_per_frame()
             sampled_steps = len(dts_sampled) * ((steps + stride - 1) // stride)
             rec["roofline"] = {"bound": "mfma", "kernel": KERNEL_NAMES[wl.kind], "achieved": round(achieved, 2), "peak": round(peak, 1),
                                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
                                "launches": gemm_n, "avg_launch_us": round(1e3 * gemm_ms / gemm_n, 2),
-                               "algorithmic_gflop_per_utt": round((per_frame * wl.T + per_utt) / 1e9, 4), "sampled_steps": sampled_steps,
+                               "algorithmic_gflop_per_utt": round((per_frame * wl.frames_total / wl.B + per_utt) / 1e9, 4), "sampled_steps": sampled_steps,
                                "gemm_ms_per_step": round(gemm_ms / sampled_steps, 4)}
         if profile and rank == 0 and "roofline" in rec:
             # every frame-level GEMM launch on its own (one hipEvent pair per launch: a few untimed steps after the timed regions)
             eng.set_profiling(2)
             for _ in range(8):
                 step()
-            torch.cuda.synchronize(dev)
+            dev_sync()
             ops = getattr(eng, "ops", eng.graph.ops)
             per = []
             for r in sorted(eng.get_profile(), key=lambda r: r["op_index"]):
@@ -265,7 +341,7 @@ def main():
                 i = r["op_index"]
                 what = "op %d" % i
                 if 0 <= i < len(ops) and ops[i].kind == "tdnn":
-                    own = 2.0 * wl.B * wl.T * ops[i].inp.channels * ops[i].out.channels * len(ops[i].taps)      # this layer alone, per launch
+                    own = 2.0 * wl.frames_total * ops[i].inp.channels * ops[i].out.channels * len(ops[i].taps)      # this layer alone, per launch
                     chained = r["flops"] / max(r["launches"], 1) > 1.5 * own
                     what = "%d->%d taps=%d%s" % (ops[i].inp.channels, ops[i].out.channels, len(ops[i].taps), " + the layers chained behind it (tdnn_chain_kernel)" if chained else "")
                 elif 0 <= i < len(ops) and ops[i].kind == "res2":
@@ -280,7 +356,7 @@ def main():
             eng.set_profiling(2)
             for _ in range(steps):
                 step()
-            torch.cuda.synchronize(dev)
+            dev_sync()
             ops = getattr(eng, "ops", eng.graph.ops)
             for r in sorted(eng.get_profile(), key=lambda r: r["op_index"]):
                 i = r["op_index"]
@@ -298,7 +374,7 @@ def main():
 
     def parity_of(wl, n=4):
         """A few utterances of the timed batch against the CPU port of the reference's call sequence (checker leg only;
-        x-vector only - the port restates model/xvector.py)."""
+        x-vector only - the port restates model/xvector.py).  `gate_1e-4`: the north star's embedding gate on that sample."""
         from oracle import torch_cpu_port as P
         ex = P.XvectorCpu(wl.sd, "far")
         pos = [0, 1, wl.B // 2, wl.B - 1][:n]
@@ -306,12 +382,72 @@ def main():
         want = np.stack([ex.extract_embedding(wl.mats[i]).numpy() for i in pos])
         rel = float(np.abs(got - want).max() / np.abs(want).max())
         cos = float(((got * want).sum(1) / np.linalg.norm(got, axis=1) / np.linalg.norm(want, axis=1)).min())
-        return {"max_rel_err": float("%.3g" % rel), "min_cosine": round(cos, 6), "n": len(pos), "against": "oracle/torch_cpu_port.py (the reference's torch CPU call "
+        return {"max_rel_err": float("%.3g" % rel), "min_cosine": round(cos, 6), "n": len(pos), "gate_1e-4": bool(rel < GATE_REL),
+                "against": "oracle/torch_cpu_port.py (the reference's torch CPU call "
                 "sequence, pinned to the reference's own outputs by tests/test_oracle_golden.py)", "metric": "max|a-b| / max|b| over the sampled embeddings"}
 
+    eer_state = {}
+
+    def eer_gate_of(wl):
+        """The north star's second gate for this workload's precision mode: |EER(mode) - EER(exact-f32 extraction)| on the
+        planted-speaker set of tests/test_gpu_eer_gate.py (4 708 utterances of 200..500 frames, args.eer_trials trials, cosine
+        scoring: sub-mean, length-norm, dot products).  The f32 extraction is the reference-equivalent one (tied to the oracle
+        by the -m gpu tests).  Checker leg: not timed."""
+        from libs.amd import scoring
+        if "mats" not in eer_state:
+            mats, labels = synth.synth_planted_utts(1177, 4, wl.D, 200, 500, 0.8)
+            eer_state["mats"] = mats
+            eer_state["trials"] = synth.synth_trials(labels, args.eer_trials, seed=41)
+            order = np.argsort([-m.shape[0] for m in mats], kind="stable")
+            batches, i = [], 0
+            while i < len(order):
+                j, frames = i, 0
+                while j < len(order) and (j == i or frames + mats[order[j]].shape[0] <= 130_000):
+                    frames += mats[order[j]].shape[0]
+                    j += 1
+                idx = order[i:j]
+                offs = np.concatenate([[0], np.cumsum([mats[k].shape[0] for k in idx])]).astype(np.int32)
+                batches.append((idx, torch.from_numpy(np.concatenate([mats[k] for k in idx], axis=0)).to(dev), offs))
+                i = j
+            eer_state["batches"] = batches
+
+        def extract_all(eng):
+            out = torch.empty((len(eer_state["mats"]), eng.embed_dim), dtype=torch.float32, device=dev)
+            for idx, feats, offs in eer_state["batches"]:
+                out[torch.as_tensor(idx, device=dev)] = eng.extract_device(feats, offs)
+            return out
+
+        def eer_of(emb):
+            ei, ti, tgt = eer_state["trials"]
+            e = scoring.length_normalize(emb, scoring.mean_vector(emb))
+            sc = scoring.score_trials(e, e, ei, ti)
+            return scoring.eer(sc, tgt)[0], sc
+
+        if "ref" not in eer_state:
+            wl.model.amd_precision = "f32"
+            eer_state["ref"] = eer_of(extract_all(wl.model._amd_engine()))
+            wl.model.amd_precision = wl.precision
+        eer_ref, sc_ref = eer_state["ref"]
+        eer_new, sc_new = eer_of(extract_all(wl.eng))
+        delta = float(eer_new - eer_ref)
+        return {"eer_percent": round(float(eer_new), 4), "eer_f32_percent": round(float(eer_ref), 4), "eer_delta_percent": round(delta, 4),
+                "max_abs_score_delta": float("%.3g" % float((sc_new - sc_ref).abs().max().item())), "trials": int(args.eer_trials),
+                "utterances": len(eer_state["mats"]), "gate_0.01": bool(abs(delta) < GATE_EER)}
+
+    def gates_of(wl):
+        rec = parity_of(wl)
+        if args.eer_trials > 0:
+            rec["eer"] = eer_gate_of(wl)
+            rec["eer_gate"] = rec["eer"]["gate_0.01"]
+        return rec
+
     # ---- the headline workload ------------------------------------------------------------------
-    wl = Workload(args, args.model, args.precision, args.batch, args.frames, rank, dev)
-    head = measure(wl, args.steps, args.warmup, args.min_seconds, not args.no_profile, world > 1, per_op=args.per_op, from_wav=args.from_wav)
+    if dry:
+        wl = DryRunWorkload(args, args.batch, args.frames, rank)
+    else:
+        lengths = tuple(int(v) for v in args.lengths.split(":")) if args.lengths else None
+        wl = Workload(args, args.model, args.precision, args.batch, args.frames, rank, dev, lengths=lengths)
+    head = measure(wl, args.steps, args.warmup, args.min_seconds, not args.no_profile and not dry, world > 1, per_op=args.per_op, from_wav=args.from_wav)
     res = {
         "metric": "utterances/sec (200-frame) embedding extraction + EER, 1/2/4/8 MI355X",
         "value": head["value"], "unit": "utterances/s",
@@ -319,15 +455,24 @@ def main():
         "ms_per_step": head["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.precision, "data": "synthetic",
-        "config": {"workload": "%s: %s, %d-dim fbank, %d utterances x %d frames per GPU per step, "
-                               "%s resident in HBM, f32 embeddings out%s" % (wl.title, wl.creation, wl.D, wl.B, wl.T,
+        "config": {"workload": "%s: %s, %d-dim fbank, %d utterances x %s frames per GPU per step, "
+                               "%s resident in HBM, f32 embeddings out%s" % (wl.title, wl.creation, wl.D, wl.B, ("%d" % wl.T) if not args.lengths else "U[%s]" % args.lengths,
                                                                              "16-bit PCM (fbank + CMN computed on the device in every step)" if args.from_wav else "features",
                                                                              ", + RCCL all-gather of embeddings" if world > 1 else ""),
-                   "global_batch_utts": world * wl.B, "frames_per_utt": wl.T, "parallelism": "utterance shards x%d" % world},
+                   "global_batch_utts": world * wl.B, "frames_per_utt": wl.T if not args.lengths else round(wl.frames_total / wl.B, 1),
+                   "parallelism": "utterance shards x%d" % world},
         "timing": {"regions": head["repeats"], "steps_per_region": args.steps, "timed_seconds": head["timed_seconds"], "value_from": "median region",
                    "ms_per_step_min_max": head["ms_per_step_min_max"]},
         "settle_seconds": args.settle_seconds,
     }
+    if dry:
+        res["dry_run"] = True
+        if "gather_verified" in head:
+            res["gather_verified"] = head["gather_verified"]
+        res["dtype"] = "none"
+        res["backend"] = args.backend
+        res["config"]["workload"] = "DRY RUN of the control flow on %d CPU rank(s), backend %s: stand-in extractor, %d x %d rows per step%s - not a measurement" % (
+            world, args.backend if world > 1 else "none", wl.B, wl.T, ", + all-gather of embeddings" if world > 1 else "")
     if "value_without_event_recording" in head:
         res["value_without_event_recording"] = head["value_without_event_recording"]
     if "roofline" in head:
@@ -341,11 +486,14 @@ def main():
             with open(pmc) as f:
                 info = json.load(f)
             res["roofline"]["traffic"] = info.get("traffic_bytes_per_launch")
-            res["roofline"]["traffic_source"] = "static: profiles/pmc_summary.json (" + str(info.get("source")) + "); not re-measured by bench.py"
+            res["roofline"]["traffic_algorithmic_bytes"] = info.get("algorithmic_bytes_per_launch")
+            res["roofline"]["traffic_source"] = "static: profiles/pmc_summary.json (" + str(info.get("source")) + "; library build " + str(info.get("library_sha256_16")) + "); not re-measured by bench.py"
 
-    if rank == 0 and args.model == "xvector":
-        res["parity"] = parity_of(wl)
-    if rank == 0 and world == 1 and not args.no_supplementary and args.model == "xvector" and not args.from_wav:
+    modes = {}
+    if rank == 0 and args.model == "xvector" and not dry and not args.lengths:
+        res["parity"] = gates_of(wl) if (world == 1 and not args.from_wav) else parity_of(wl)
+        modes[args.precision] = {"value": head["value"], "gate_1e-4": res["parity"]["gate_1e-4"], "eer_gate": res["parity"].get("eer_gate")}
+    if rank == 0 and world == 1 and not args.no_supplementary and args.model == "xvector" and not args.from_wav and not dry and not args.lengths:
         # ---- supplementary records, same harness (shorter: 0.4 s of timed regions each) --------------
         sup = {}
         w256 = Workload(args, "xvector", args.precision, 256, args.frames, rank, dev)
@@ -356,23 +504,28 @@ def main():
             res["roofline_at_b256"] = {k: r["roofline"][k] for k in ("achieved", "peak", "unit", "frac", "avg_launch_us")}
         res["config"]["configs1_batch_note"] = "BASELINE configs[1] names batch=256: value_at_b256 / roofline_at_b256 are that figure; `value` uses 640 utterances per step"
         del w256
-        for prec in ("f32x", "f32"):
+        for prec in ("f16", "f32x", "f32"):
             if prec == args.precision:
                 continue
             w = Workload(args, "xvector", prec, args.batch, args.frames, rank, dev)
             r = measure(w, args.steps, 2, 0.4, not args.no_profile, False)
-            rec = {"value": r["value"], "unit": "utterances/s", "ms_per_step": r["ms_per_step"], "parity": parity_of(w)}
+            rec = {"value": r["value"], "unit": "utterances/s", "ms_per_step": r["ms_per_step"], "parity": gates_of(w)}
             if "roofline" in r:
                 rec["gemm_tflops"] = r["roofline"]["achieved"]
                 rec["frac_of_mode_peak"] = r["roofline"]["frac"]
                 rec["mode_peak_tflops"] = r["roofline"]["peak"]
             sup["xvector_" + prec] = rec
+            modes[prec] = {"value": r["value"], "gate_1e-4": rec["parity"]["gate_1e-4"], "eer_gate": rec["parity"].get("eer_gate")}
             del w
-        for kind, key, frames in (("ecapa", "ecapa_c3", 300), ("resnet", "resnet_c5", 200)):
+        for kind, key, frames, prec, lens in (("ecapa", "ecapa_c3", 300, args.precision, None), ("ecapa", "ecapa_c3_f32x", 300, "f32x", None),
+                                              ("resnet", "resnet_c5_t200", 200, args.precision, None), ("resnet", "resnet_c5", 600, args.precision, (200, 1000)),
+                                              ("resnet", "resnet_c5_f32x", 600, "f32x", (200, 1000))):
             try:
-                w = Workload(args, kind, args.precision, 256, frames, rank, dev)
+                w = Workload(args, kind, prec, 256, frames, rank, dev, lengths=lens)
                 r = measure(w, max(4, args.steps // 4), 2, 0.4, not args.no_profile, False)
-                rec = {"value": r["value"], "unit": "utterances/s", "ms_per_step": r["ms_per_step"], "workload": "%s: %s, 256 utterances x %d frames, %s" % (w.title, w.creation, frames, args.precision)}
+                shape = "%d frames" % frames if lens is None else "U[%d, %d] frames (packed ragged, %d frames in all)" % (lens[0], lens[1], w.frames_total)
+                rec = {"value": r["value"], "unit": "utterances/s", "ms_per_step": r["ms_per_step"], "frames_per_s": round(r["value"] * w.frames_total / w.B, 0),
+                       "workload": "%s: %s, 256 utterances x %s, %s" % (w.title, w.creation, shape, prec)}
                 if "roofline" in r:
                     rec["gemm_tflops"] = r["roofline"]["achieved"]
                     rec["frac"] = r["roofline"]["frac"]
@@ -383,8 +536,14 @@ def main():
             except Exception as e:                                        # a supplementary record must never take the headline down
                 sup[key] = {"error": "%s: %s" % (type(e).__name__, e)}
         res["supplementary"] = sup
+    if modes and all(m["eer_gate"] is not None for m in modes.values()):
+        passing = {k: m for k, m in modes.items() if m["gate_1e-4"] and m["eer_gate"]}
+        best = max(passing, key=lambda k: passing[k]["value"]) if passing else None
+        res["value_parity_grade"] = {"mode": best, "value": passing[best]["value"] if best else None, "unit": "utterances/s",
+                                     "rule": "the fastest precision mode of this workload that passes BOTH north-star gates (parity.gate_1e-4 and parity.eer_gate)",
+                                     "modes": modes}
 
-    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+    if rank == 0 and world == 1 and args.cpu_seconds > 0 and not dry and not args.lengths:
         from oracle import torch_cpu_port as P                        # cpu_baseline leg only
         # torch's default (one thread per core) collapses on many-core hosts for these small
         # convolutions: probe a few thread counts briefly and time the sample with the best one

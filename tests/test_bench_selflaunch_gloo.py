@@ -1,0 +1,45 @@
+"""bench.py's N > 1 control flow on CPU: `python bench.py --gpus 2 --backend gloo --dry-run` re-executes
+itself under torch.distributed.run on 127.0.0.1, runs settle / warm-up / the timed regions with barriers and the MAX over
+ranks, the double-buffered asynchronous all_gather_into_tensor, and prints ONE JSON line on rank 0 - with a stand-in
+extractor on CPU tensors, so that the path the driver launches on an 8-GPU node has been executed end to end before it gets
+there.  What the gather delivered is checked inside the run (`gather_verified`)."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config")
+
+
+def _run(gpus, launcher):
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(gpus), "--backend", "gloo", "--dry-run", "--steps", "6", "--warmup", "2",
+           "--batch", "48", "--frames", "50", "--min-seconds", "0.05", "--settle-seconds", "0.02"]
+    if launcher:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1", "--master-port", "29731"] + cmd[1:]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stdout + res.stderr
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout                         # exactly one JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("gpus,launcher", [(1, False), (2, False), (2, True), (3, False)])
+def test_bench_dry_run_control_flow(gpus, launcher):
+    rec = _run(gpus, launcher)
+    for k in REQUIRED:
+        assert k in rec, k
+    assert rec["n_gpus"] == gpus and rec["steps"] == 6 and rec["warmup"] == 2 and rec["dry_run"] is True and rec["scaling"] == "weak"
+    assert rec["config"]["global_batch_utts"] == gpus * 48 and rec["value"] > 0 and rec["ms_per_step"] > 0
+    assert abs(rec["value"] - gpus * 48 / (rec["ms_per_step"] * 1e-3)) / rec["value"] < 0.01        # value = whole-job units / time
+    if gpus > 1:
+        assert rec["gather_verified"] is True and rec["backend"] == "gloo"
+
+
+def test_bench_refuses_gloo_without_dry_run():
+    res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--backend", "gloo"], capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0 and "--dry-run" in (res.stdout + res.stderr)

@@ -27,15 +27,7 @@ BF16_BOUND = 0.05
 
 def _planted(dim, t_lo, t_hi, noise, seed=3):
     from libs.amd import synth
-    r = np.random.RandomState(seed)
-    mats, labels = [], []
-    for s in range(N_SPK):
-        base = synth.synth_feats(t_hi, dim, 500_000 + s)
-        for _ in range(PER_SPK):
-            T = int(r.randint(t_lo, t_hi + 1))
-            mats.append((base[:T] + noise * r.standard_normal((T, dim)).astype(np.float32)).astype(np.float32))
-            labels.append(s)
-    return mats, np.asarray(labels)
+    return synth.synth_planted_utts(N_SPK, PER_SPK, dim, t_lo, t_hi, noise, seed)
 
 
 def _extract(model, mats, max_frames=130_000):
