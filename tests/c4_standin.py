@@ -32,7 +32,7 @@ def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--model", default="ecapa", choices=["ecapa", "xvector"])
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32x", "f32"])
+    ap.add_argument("--precision", default="bf16", help="bf16 | f16 | f32x[-bf16|-f16] | f32")
     ap.add_argument("--utts", type=int, default=4708)
     ap.add_argument("--per-spk", type=int, default=4)
     ap.add_argument("--t-lo", type=int, default=400)

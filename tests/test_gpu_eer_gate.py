@@ -67,7 +67,11 @@ def test_eer_gate_c4_standin_all_precision_modes(capsys):
     assert len(mats) == 4708
     ei, ti, tgt = synth.synth_trials(labels, N_TRIALS, seed=41)
     emb, eer, scores = {}, {}, {}
-    for prec in ("f32", "f32x", "bf16"):
+    # f32x = the default of the drop-in API (IEEE-half hi + lo halves); f32x-bf16 = the round-2 form (bf16 halves); f16 / bf16 = the
+    # 16-bit throughput modes; the "-noxlo" / "-nowlo" variants run TWO matrix instructions per product (activations or weights
+    # rounded to one half): the measured answer to "is there a mode between one and three instructions that passes the gates"
+    modes = ("f32", "f32x", "f32x-bf16", "f16", "bf16", "f32x-f16-noxlo", "f32x-f16-nowlo", "f32x-bf16-noxlo", "f32x-bf16-nowlo")
+    for prec in modes:
         model.amd_precision = prec
         emb[prec] = _extract(model, mats)
         eer[prec], scores[prec] = _eer(emb[prec], ei, ti, tgt)
@@ -76,11 +80,19 @@ def test_eer_gate_c4_standin_all_precision_modes(capsys):
     want = np.stack([O.extract_embedding(lambda c: O.xvector_embed(c, sd, "far"), mats[i]) for i in pos])
     assert rel_err(emb["f32"][pos], want) < 1e-4
     assert rel_err(emb["f32x"][pos], want) < 1e-4
+    assert rel_err(emb["f32x-bf16"][pos], want) < 1e-4
     with capsys.disabled():
-        print("\n[eer gate] %d utterances, %d trials: EER f32 %.4f %%, f32x %.4f %% (delta %+.4f), bf16 %.4f %% (delta %+.4f); "
-              "max |score - f32 score|: f32x %.2e, bf16 %.2e" % (len(mats), N_TRIALS, eer["f32"], eer["f32x"], eer["f32x"] - eer["f32"], eer["bf16"],
-                                                                eer["bf16"] - eer["f32"], np.abs(scores["f32x"] - scores["f32"]).max(),
-                                                                np.abs(scores["bf16"] - scores["f32"]).max()))
+        print("\n[eer gate] %d utterances, %d trials, EER f32 %.4f %%" % (len(mats), N_TRIALS, eer["f32"]))
+        for prec in modes[1:]:
+            print("[eer gate]   %-16s EER delta %+.4f %%   max |score - f32 score| %.2e   embeddings vs f32: max rel %.2e" % (
+                prec, eer[prec] - eer["f32"], np.abs(scores[prec] - scores["f32"]).max(), rel_err(emb[prec], emb["f32"])))
     assert 0.5 < eer["f32"] < 30.0, "the planted set should give a non-trivial EER, got %.3f" % eer["f32"]
     assert abs(eer["f32x"] - eer["f32"]) < GATE, (eer["f32x"], eer["f32"])
+    assert abs(eer["f32x-bf16"] - eer["f32"]) < GATE, (eer["f32x-bf16"], eer["f32"])
+    assert np.abs(scores["f32x"] - scores["f32"]).max() < 2e-5            # the half split is f32-grade: an order below the bf16 split's 4e-5
     assert abs(eer["bf16"] - eer["f32"]) < BF16_BOUND, (eer["bf16"], eer["f32"])
+    assert abs(eer["f16"] - eer["f32"]) < BF16_BOUND / 2, (eer["f16"], eer["f32"])
+    assert rel_err(emb["f16"], emb["f32"]) < 0.25 * rel_err(emb["bf16"], emb["f32"])        # 3 more significand bits: ~8x closer
+    # two matrix instructions per product: the embeddings stay at the one-rounding level of the operand that was not split
+    for two in ("f32x-f16-noxlo", "f32x-f16-nowlo"):
+        assert rel_err(emb[two], emb["f32"]) > 10 * rel_err(emb["f32x"], emb["f32"]), two

@@ -9,6 +9,7 @@ outputs by tests/test_oracle_golden.py) in every precision mode:
     f32, f32x : max |a - b| / max |b| <= 1e-4               (north_star: "within 1e-4 relative fp32")
     bf16      : the same metric <= 2e-2 and cosine >= 0.9995   (bf16 operands: 8 mantissa bits; the EER gate of the
                                                                 throughput mode is tests/test_gpu_eer_gate.py)
+    f16       : <= 2.5e-3 and cosine >= 0.99999                (IEEE-half operands: 11 bits)
 """
 
 import numpy as np
@@ -21,6 +22,7 @@ pytestmark = pytest.mark.gpu
 
 TOL_F32 = 1e-4
 TOL_BF16_REL, TOL_BF16_COS = 2e-2, 0.9995
+TOL_F16_REL, TOL_F16_COS = 2.5e-3, 0.99999
 
 
 def _sample_positions(n, k=8):
@@ -32,15 +34,16 @@ def _sample_positions(n, k=8):
 def _check(got, want, precision, what):
     for g, w, tag in zip(got, want, what):
         err = rel_err(g, w)
-        if precision == "bf16":
+        if precision in ("bf16", "f16"):
             cos = float((g * w).sum() / np.linalg.norm(g) / np.linalg.norm(w))
-            assert err < TOL_BF16_REL and cos > TOL_BF16_COS, "%s bf16: rel err %.3g cos %.6f" % (tag, err, cos)
+            tol_rel, tol_cos = (TOL_BF16_REL, TOL_BF16_COS) if precision == "bf16" else (TOL_F16_REL, TOL_F16_COS)
+            assert err < tol_rel and cos > tol_cos, "%s %s: rel err %.3g cos %.7f" % (tag, precision, err, cos)
         else:
             assert err < TOL_F32, "%s %s: rel err %.3g" % (tag, precision, err)
 
 
 @pytest.mark.parametrize("batch", [256, 640])
-@pytest.mark.parametrize("precision", ["f32", "f32x", "bf16"])
+@pytest.mark.parametrize("precision", ["f32", "f32x", "f32x-bf16", "bf16", "f16"])
 def test_c2_xvector_full_batch_vs_oracle(batch, precision):
     """BASELINE configs[1]: Xvector(80, ...) on batch x [200, 80]; 640 is the bench's batch."""
     from libs.amd import synth
@@ -60,7 +63,7 @@ def test_c2_xvector_full_batch_vs_oracle(batch, precision):
     _check([got[i] for i in pos], want, precision, ["utt %d of %d" % (i, batch) for i in pos])
 
 
-@pytest.mark.parametrize("precision", ["f32", "f32x", "bf16"])
+@pytest.mark.parametrize("precision", ["f32", "f32x", "bf16", "f16"])
 def test_c3_ecapa_full_batch_vs_oracle(precision):
     """BASELINE configs[2]: ECAPA_TDNN(80, ...) C = 1024 on 256 x [300, 80]."""
     from libs.amd import synth
@@ -78,6 +81,31 @@ def test_c3_ecapa_full_batch_vs_oracle(precision):
     pos = _sample_positions(256, k=6)
     want = [O.extract_embedding(lambda c: O.ecapa_embed(c, sd, "near"), mats[i]) for i in pos]
     _check([got[i] for i in pos], want, precision, ["utt %d of 256" % i for i in pos])
+
+
+@pytest.mark.parametrize("precision", ["f32", "f32x", "bf16", "f16"])
+def test_c5_resnet_variable_length_full_batch_vs_oracle(precision):
+    """BASELINE configs[4] extractor at the bench's batch: ResNet34-SE on 256 utterances of mixed 200..1000 frames packed ragged in
+    ONE batch (every stride-2 stage: L_out = floor((L - 1) / 2) + 1 per utterance; per-bin pooling over true lengths -
+    model/resnet_xvector.py:183-208 does batch = 1).  Sampled utterances, incl. the shortest and the longest, vs the numpy oracle."""
+    from libs.amd import synth
+    from oracle import np_oracle as O
+    import torch
+    creation = ("ResNetXvector(80,10,training=False,resnet_params={'use_se':True,'se_ratio':4,'full_pre_activation':False},"
+                "fc2_params={'nonlinearity':'','bn_params':{'momentum':0.5,'affine':False,'track_running_stats':True}})")
+    model = helpers.build_model("resnet_xvector.py", creation)
+    sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 0)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model.cuda()
+    model.amd_precision = precision
+    lengths = synth.synth_lengths(256, 200, 1000, 77)                       # the bench's lengths on rank 0 (bench.py Workload)
+    lengths[3], lengths[200] = 200, 1000                                    # both ends of the range are in the batch
+    mats = [synth.synth_feats(int(t), 80, i) for i, t in enumerate(lengths)]
+    got = model.extract_embedding_batch(mats).numpy()
+    assert got.shape == (256, 256) and np.isfinite(got).all()
+    pos = sorted({0, 3, 127, 128, 200, 255, int(np.argmin(lengths)), int(np.argmax(lengths))})
+    want = [O.extract_embedding(lambda c: O.resnet_embed(c, sd, "near", ""), mats[i]) for i in pos]
+    _check([got[i] for i in pos], want, precision, ["utt %d (%d frames)" % (i, lengths[i]) for i in pos])
 
 
 @pytest.mark.parametrize("name", ["xvector_c1", "xvector_near_ragged", "xvector_chunked", "ecapa_c3", "ecapa_launcher", "ecapa_c512_fc1_far",

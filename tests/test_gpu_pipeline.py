@@ -150,21 +150,50 @@ def test_c4_standin_full_size_single_gpu():
         return rec
 
     # With 18 860 target trials one trial that changes side moves the EER by 0.0053 %: a single stand-in set resolves the
-    # 0.01 % gate to one trial, and at the 11-17 % EER of planted speakers behind random weights ~75 trials sit within the
-    # f32x score error (<= 2e-3 after mean subtraction) of the threshold - one draw is a coin flip around the gate (measured
-    # r2b/r2c: 0.0000 / 0.0053 / 0.0000 / 0.0212 % at noise 0.05 / 0.1 / 0.2 / 0.3).  Three independent sets (noise levels)
-    # are extracted and the gate is held on their mean, each one bounded on its own.
-    f32x = [run("f32x", nz, 2 if i == 0 else 0) for i, nz in enumerate((0.05, 0.1, 0.2))]
+    # 0.01 % gate to one trial.  Round 2's f32x mode (bf16 hi + lo halves, ~6e-6 relative on the embeddings) sat AT that gate
+    # here: at the 11-17 % EER of planted speakers behind random weights ~75 trials lie within its score error (<= 2e-3 after
+    # the mean subtraction, which removes the large common component of these embeddings) of the threshold - measured 0.0000 /
+    # 0.0053 / 0.0000 / 0.0212 % over four sets, so the gate was held on the mean of three.  With IEEE-half halves (22
+    # significant bits per operand: f32-grade products) the mode is inside the gate on EVERY set, with score deltas an order
+    # smaller; the bf16 split is still measured on one set for the record.
+    f32x = [run("f32x", nz, 2 if i == 0 else 0) for i, nz in enumerate((0.05, 0.1, 0.3))]
     assert f32x[0]["oracle_max_rel_err_f32"] < 1e-4
     for rec in f32x:
         assert 0.5 < rec["eer_reference_equivalent_percent"] < 40.0
-        assert abs(rec["eer_delta_percent"]) < 0.03, rec
-        assert rec["max_abs_score_delta"] < 5e-3, rec
-    mean_delta = sum(abs(r["eer_delta_percent"]) for r in f32x) / len(f32x)
-    assert mean_delta < 0.01, [r["eer_delta_percent"] for r in f32x]
-    # bf16 ECAPA embeddings sit at cosine 0.9999 / 1.5-2 % relative error from the f32 ones whatever the length (tools/
+        assert abs(rec["eer_delta_percent"]) < 0.01, rec
+        assert rec["max_abs_score_delta"] < 5e-4, rec
+    old_split = run("f32x-bf16", 0.3, 0)
+    assert abs(old_split["eer_delta_percent"]) < 0.03 and old_split["max_abs_score_delta"] < 5e-3, old_split
+    # 16-bit ECAPA embeddings sit at 1.5-2 % (bf16) / ~0.2 % (f16) relative error from the f32 ones whatever the length (tools/
     # ecapa_precision_probe.py).  With synthetic weights the embeddings share a large common component that the scoring chain
     # subtracts (sub-mean), so that error is a large share of what is left: cosine scores move by up to 0.3 and the EER by
-    # 0.1-0.5 % abs on this stand-in (0.39 % at noise 0.1).  Reported by the script; bounded here only against gross regressions.
+    # 0.1-0.5 % abs in bf16 on this stand-in (0.39 % at noise 0.1).  Reported by the script; bounded here only against gross regressions.
     bf16 = run("bf16", 0.1, 0)
     assert abs(bf16["eer_delta_percent"]) < 1.0, bf16
+    f16 = run("f16", 0.1, 0)
+    assert abs(f16["eer_delta_percent"]) < 0.25 and f16["max_abs_score_delta"] < 0.25 * bf16["max_abs_score_delta"] + 1e-3, (f16, bf16)
+
+def test_c5_standin_stated_shape_single_gpu():
+    """BASELINE configs[4] at its stated shape on one GPU (the 8-GPU run is the same script under torch.distributed.run):
+    ResNet34-SE on 2 000 packed-ragged utterances of 200..1000 frames, PLDA trained with 10 EM iterations ON the extracted
+    embeddings (plda_base.py:248-300), LLR scoring, EER.  The parity-grade f32x mode meets the north-star gates against the
+    reference-equivalent chain (exact-f32 extraction, oracle-checked incl. the longest utterance); the 16-bit throughput
+    modes are reported and bounded."""
+    import json
+    script = os.path.join(helpers.REPO, "tests", "c5_standin.py")
+
+    def run(prec, checks):
+        res = subprocess.run([sys.executable, script, "--precision", prec, "--oracle-checks", str(checks)], capture_output=True, text=True, timeout=1500)
+        assert res.returncode == 0, res.stdout + res.stderr
+        rec = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+        print(rec)
+        return rec
+
+    r = run("f32x", 3)
+    assert r["frames"] > 1_000_000 and 0.5 < r["eer_reference_equivalent_percent"] < 45.0, r
+    assert r["oracle_max_rel_err_f32"] < 1e-4 and r["oracle_max_abs_llr_err_200_trials"] < 2e-3, r
+    assert r["embedding_max_rel_err_vs_f32"] < 1e-4, r
+    assert abs(r["eer_delta_percent"]) < 0.01, r
+    for prec, bound in (("f16", 0.5), ("bf16", 2.0)):
+        h = run(prec, 0)
+        assert abs(h["eer_delta_percent"]) < bound, h

@@ -111,3 +111,21 @@ def test_c4_standin_control_flow_under_gloo_world2():
     assert r1["n_gpus"] == 1 and r2["n_gpus"] == 2
     assert r1["eer_percent"] == r2["eer_percent"] and 0.0 < r1["eer_percent"] < 50.0
     assert r2["eer_delta_percent"] == 0.0
+
+
+def test_c5_standin_control_flow_under_gloo_world2():
+    """tests/c5_standin.py (BASELINE configs[4]: variable-length extraction, one all-gather, PLDA EM + LLR + EER on rank 0) with the
+    numpy stand-ins on two gloo ranks: the sharded run equals the single-process run."""
+    script = os.path.join(helpers.REPO, "tests", "c5_standin.py")
+    base = [sys.executable, script, "--fake-extractor", "--utts", "120", "--per-spk", "4", "--t-lo", "20", "--t-hi", "100", "--trials", "1500", "--noise", "1.5",
+            "--plda-iters", "3"]
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    one = subprocess.run(base, capture_output=True, text=True, env=env, timeout=600)
+    assert one.returncode == 0, one.stdout + one.stderr
+    two = subprocess.run(base + ["--gpus", "2"], capture_output=True, text=True, env=env, timeout=600)
+    assert two.returncode == 0, two.stdout + two.stderr
+    r1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    r2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert r1["n_gpus"] == 1 and r2["n_gpus"] == 2 and r1["frames"] == r2["frames"]
+    assert r1["eer_percent"] == r2["eer_percent"] and 0.0 <= r1["eer_percent"] < 50.0
+    assert r2["eer_delta_percent"] == 0.0 and r2["max_abs_llr_delta"] == 0.0
