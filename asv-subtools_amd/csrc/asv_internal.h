@@ -194,6 +194,7 @@ void pack_tdnn_weight_frags(const float *w, int out_ch, int in_ch, int tot_ctx, 
                             int cout_pad, int cin_pad, uint16_t *dst, uint16_t *dst_lo = nullptr, int et = ET_BF16, float scale = 1.0f);
 // f32-grade split-bf16 kernel of the f32x precision mode (kernels_tdnn_x3.hip): f32 activations, hi / lo weight fragments
 bool tdnn_x3_supported(const TdnnKernelParams &p);
+bool tdnn_x3_pool_supported(const TdnnKernelParams &p);      // fused statistics pooling (128-row tiles, plain epilogue)
 int launch_tdnn_x3(const TdnnKernelParams &p, hipStream_t s);
 size_t tdnn_weight_frag_elems(int cout_pad, int cin_pad, int n_taps);
 int launch_stats_pool(const PoolKernelParams &p, int segments, int et, hipStream_t s);

@@ -24,23 +24,34 @@
 // kernel is not bound by the split but by what it streams: 4 KiB of weight fragments per 12 MFMAs and wave (64-row waves,
 // hi + lo halves: 341 B per MFMA against 256 B in the bf16 kernel with 128-row waves) and f32 windows / outputs (the 1-tap
 // 512 -> 1500 layer moves 1.05 GB per launch).  The next step for this mode is the 128-row wave tile of kernels_tdnn_v3.hip.
+#include <cstdlib>
+
 #include "device_utils.h"
 
 namespace asv {
 namespace {
 
 constexpr int XBN = 256;            // channels per workgroup
-constexpr int XBM = 64;             // frames per workgroup
 constexpr int XBK = 32;             // channels per chunk (128-byte f32 rows in LDS)
 constexpr int XROWB = 128;
 constexpr int XSTAGES = 4;
-constexpr int XWIN = XBM + 2 * kHalo;          // 72 window rows
-constexpr int XGROUPS = XWIN / 8;              // 9 eight-row DMA pieces
-constexpr int XPIECES = (XGROUPS + 3) / 4;     // 3 per wave
-constexpr int XSTAGE = XWIN * XROWB;           // 9216 B
-constexpr int XRING = XSTAGES * XSTAGE;        // 36864 B
 constexpr int XSPITCH = 68;                    // floats per epilogue scratch row
-static_assert(4 * 32 * XSPITCH * 4 <= XRING, "epilogue scratch must fit in the ring");
+// MF = 32-frame accumulator fragments per wave:
+//   MF = 2:  64 frames per workgroup, <= 168 VGPRs, 39 KiB of LDS: three workgroups per CU (round 2's geometry; kept for batches
+//            whose 128-row tiles would not fill the chip);
+//   MF = 4: 128 frames per workgroup (round 3), 72 KiB of LDS, two workgroups per CU: every weight fragment pair (hi, lo) a wave
+//            fetches from L2 feeds 12 instead of 6 matrix instructions (171 instead of 341 bytes per instruction - the 64-row
+//            kernel sat at the L1 fill rate), and the wave's 128 rows x 64 channels are what the fused statistics pooling
+//            epilogue (POOL; the layout of kernels_tdnn_v3.hip's) works on.
+template <int MF> struct X3Geom {
+  static constexpr int BM = MF * 32;                  // frames per workgroup
+  static constexpr int WIN = BM + 2 * kHalo;          // 72 | 136 window rows
+  static constexpr int GROUPS = WIN / 8;              // 9 | 17 eight-row DMA pieces
+  static constexpr int PIECES = (GROUPS + 3) / 4;     // 3 | 5 per wave
+  static constexpr int STAGE = WIN * XROWB;           // 9216 | 17408 B
+  static constexpr int RING = XSTAGES * STAGE;        // 36864 | 69632 B
+  static_assert(4 * 32 * XSPITCH * 4 <= RING, "epilogue scratch must fit in the ring");
+};
 static_assert(XBN == kBigTileN, "weight padding must match the N tile");
 
 typedef __attribute__((address_space(3))) unsigned char x3_lds_byte;
@@ -89,8 +100,11 @@ __device__ __forceinline__ X3Frag x3_split(const uint4 a, const uint4 b) {
 }
 
 // ET: the 16-bit type of the operand halves; TERMS: bit 0 = w_hi x_hi, bit 1 = w_hi x_lo, bit 2 = w_lo x_hi
-template <bool GENERIC, int ET, int TERMS>
-__global__ __launch_bounds__(256, 3) void tdnn_gemm_x3_kernel(const TdnnKernelParams p, int m_tiles, int n_tiles) {
+template <bool GENERIC, int ET, int TERMS, int MF = 2, bool POOL = false>
+__global__ __launch_bounds__(256, MF == 2 ? 3 : 2) void tdnn_gemm_x3_kernel(const TdnnKernelParams p, int m_tiles, int n_tiles) {
+  using Geo = X3Geom<MF>;
+  constexpr int XBM = Geo::BM, XGROUPS = Geo::GROUPS, XPIECES = Geo::PIECES, XSTAGE = Geo::STAGE, XRING = Geo::RING;
+  static_assert(!POOL || (MF == 4 && !GENERIC), "the fused pooling epilogue works on 128-row tiles with the plain epilogue");
   __shared__ __attribute__((aligned(16))) unsigned char lds[XRING + 3 * 256 * 4];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -147,7 +161,7 @@ __global__ __launch_bounds__(256, 3) void tdnn_gemm_x3_kernel(const TdnnKernelPa
   const unsigned char *wl_base = reinterpret_cast<const unsigned char *>(p.wlo) + wf_off0;
 
   struct WFrags { uint4 h[2], l[2]; };
-  struct XFrags { X3Frag f[2]; };
+  struct XFrags { X3Frag f[MF]; };
   // k-group index g runs over (chunk, tap, half): g = (c * n_taps + t) * 2 + kg
   auto load_w = [&](int c, int t, int kg, WFrags &w) {
     const size_t off = ((size_t)t * nkg + (size_t)c * 2 + kg) * 1024;
@@ -162,7 +176,7 @@ __global__ __launch_bounds__(256, 3) void tdnn_gemm_x3_kernel(const TdnnKernelPa
     const unsigned char *Ab = lds + (c % XSTAGES) * XSTAGE;
     const int s0 = kg * 4 + lh * 2;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MF; ++i) {
       const int w = i * 32 + lr + kHalo + d;
       const uint4 a = *reinterpret_cast<const uint4 *>(Ab + w * XROWB + xswz(w, s0) * 16);
       const uint4 b = *reinterpret_cast<const uint4 *>(Ab + w * XROWB + xswz(w, s0 + 1) * 16);
@@ -170,9 +184,9 @@ __global__ __launch_bounds__(256, 3) void tdnn_gemm_x3_kernel(const TdnnKernelPa
     }
   };
 
-  f32x16_t acc[2][2];
+  f32x16_t acc[MF][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MF; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -186,7 +200,7 @@ __global__ __launch_bounds__(256, 3) void tdnn_gemm_x3_kernel(const TdnnKernelPa
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MF; ++i) {
           const uint4 a = (term == 2) ? w.l[j] : w.h[j];
           const uint4 b = (term == 1) ? x.f[i].lo : x.f[i].hi;
           acc[i][j] = mfma16<ET>(a, b, acc[i][j]);
@@ -248,9 +262,88 @@ __global__ __launch_bounds__(256, 3) void tdnn_gemm_x3_kernel(const TdnnKernelPa
   float *scr = reinterpret_cast<float *>(lds) + wn * (32 * XSPITCH);
   const float act_lo = (p.act1 == ASV_ACT_RELU) ? 0.0f : -INFINITY;
   const float unscale = p.w_unscale;           // 1 / the power of two the host multiplied the weights by (exact; 1 for the bf16 split)
+  if constexpr (POOL) {
+    // Fused statistics pooling (pooling.py:58-67 folded into the producing layer; the f32 form of kernels_tdnn_v3.hip's POOL
+    // epilogue, same partial layout): the layer's output - 783 MB per C2 step for tdnn5 in f32, written and read back by the
+    // pooling kernel - never reaches HBM.  Per 32-frame fragment the wave writes u = max(acc + b, lo) * scale (the output
+    // minus the BN shift) to its scratch tile, then lane = channel sums the rows per utterance about a pivot (the utterance's
+    // first value in this tile): sum (u - pv), sum (u - pv)^2, pv -> P[tile of 128 rows][segment slot][3][channel];
+    // pool_finish_kernel merges a segment's tiles in row order (Chan et al.) and adds the shift to the mean.
+    const int half = m0 >> 7;
+    int first_seg = -1;
+#pragma unroll
+    for (int k = 0; k < kHalo + 1; ++k)
+      if (first_seg < 0 && m0 + k < p.rows) first_seg = p.row_seg[m0 + k];
+    const int ch_l = n0 + wn * 64 + lane;
+    const int rowseg_lo = p.row_seg[m0 + lane], rowseg_hi = p.row_seg[m0 + 64 + lane];
+    float ps = 0.0f, pq = 0.0f, pv = 0.0f;
+    int cur_seg = -1;
+    auto flush = [&]() {
+      const int slot = cur_seg - first_seg;
+      if (slot >= 0 && slot < p.pool_slots && ch_l < p.ld_partial) {
+        float *dst = p.pool_partial + ((size_t)(half * p.pool_slots + slot) * 3) * p.ld_partial + ch_l;
+        dst[0] = ps;
+        dst[p.ld_partial] = pq;
+        dst[2 * p.ld_partial] = pv;
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+      const bool valid = (p.row_valid[(m0 + i * 32) >> 5] >> lr) & 1u;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int chl = wn * 64 + j * 32 + 8 * q + 4 * lh;
+          const float4 b4 = *reinterpret_cast<const float4 *>(lds_par + chl);
+          const float4 sc4 = *reinterpret_cast<const float4 *>(lds_par + 256 + chl);
+          float4 u;
+          u.x = valid ? fmaxf(fmaf(acc[i][j][q * 4 + 0], unscale, b4.x), act_lo) * sc4.x : 0.0f;
+          u.y = valid ? fmaxf(fmaf(acc[i][j][q * 4 + 1], unscale, b4.y), act_lo) * sc4.y : 0.0f;
+          u.z = valid ? fmaxf(fmaf(acc[i][j][q * 4 + 2], unscale, b4.z), act_lo) * sc4.z : 0.0f;
+          u.w = valid ? fmaxf(fmaf(acc[i][j][q * 4 + 3], unscale, b4.w), act_lo) * sc4.w : 0.0f;
+          *reinterpret_cast<float4 *>(scr + lr * XSPITCH + j * 32 + 8 * q + 4 * lh) = u;
+        }
+      // rows are consumed in order, segments are contiguous in rows; rowseg_lo / hi hold row_seg of the tile's 128 rows
+      const int rs_vec = (i < 2) ? rowseg_lo : rowseg_hi;
+      const unsigned long long in_frag = 0xffffffffull << ((i & 1) * 32);
+      const unsigned long long m_valid = __builtin_amdgcn_ballot_w64(rs_vec >= 0) & in_frag;
+      if (m_valid == 0) continue;                                                  // gap rows only
+      const int sg0 = __builtin_amdgcn_readlane(rs_vec, __builtin_ctzll(m_valid));
+      const unsigned long long m_same = __builtin_amdgcn_ballot_w64(rs_vec == sg0) & in_frag;
+      if (m_same == in_frag) {                                                     // one utterance, no gap row: branch-free
+        if (sg0 != cur_seg) {
+          if (cur_seg >= 0) flush();
+          cur_seg = sg0; ps = 0.0f; pq = 0.0f; pv = scr[lane];
+        }
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+          const float d = scr[r * XSPITCH + lane] - pv;
+          ps += d;
+          pq = fmaf(d, d, pq);
+        }
+      } else {
+#pragma unroll 1
+        for (int r = 0; r < 32; ++r) {
+          const int sg = __builtin_amdgcn_readlane(rs_vec, (i & 1) * 32 + r);          // wave-uniform
+          if (sg < 0) continue;                                                          // gap row
+          const float v = scr[r * XSPITCH + lane];
+          if (sg != cur_seg) {
+            if (cur_seg >= 0) flush();
+            cur_seg = sg; ps = 0.0f; pq = 0.0f; pv = v;
+          }
+          const float d = v - pv;
+          ps += d;
+          pq = fmaf(d, d, pq);
+        }
+      }
+    }
+    if (cur_seg >= 0) flush();
+    return;
+  }
   float *yg = reinterpret_cast<float *>(p.y);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < MF; ++i) {
     const bool valid = (p.row_valid[(m0 + i * 32) >> 5] >> lr) & 1u;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -290,28 +383,52 @@ __global__ __launch_bounds__(256, 3) void tdnn_gemm_x3_kernel(const TdnnKernelPa
 
 }  // namespace
 
+// tile rows the launcher will use for this layer: 128 unless the batch is too small to fill the chip with 128-row tiles
+// (ASV_AMD_X3_TILE = 64 | 128 overrides: A/B)
+static int x3_tile_rows(const TdnnKernelParams &p) {
+  static const int forced = getenv("ASV_AMD_X3_TILE") != nullptr ? atoi(getenv("ASV_AMD_X3_TILE")) : 0;
+  static const bool live = getenv("ASV_AMD_LIVE_TUNE") != nullptr;
+  const int f = live ? (getenv("ASV_AMD_X3_TILE") != nullptr ? atoi(getenv("ASV_AMD_X3_TILE")) : 0) : forced;
+  if (f == 64 || f == 128) return (f == 128 && p.rows % 128 != 0) ? 64 : f;
+  const long long t128 = (long long)(p.rows / 128) * (round_up(p.cout_store, XBN) / XBN);
+  return (p.rows % 128 == 0 && t128 >= 384) ? 128 : 64;
+}
+
 bool tdnn_x3_supported(const TdnnKernelParams &p) {
   const bool fits32 = (unsigned long long)p.rows * (unsigned long long)p.ldx * 4ull < (1ull << 40);
   return p.wfrag != nullptr && p.wlo != nullptr && p.x2 == nullptr && p.seg_bias == nullptr && p.seg_scale == nullptr && p.res == nullptr &&
-         p.pool_partial == nullptr && p.zero16 != nullptr && p.rows % XBM == 0 && p.cout_store % 4 == 0 && p.cout_store >= 192 && p.cin_pad >= 32 &&
+         p.zero16 != nullptr && p.rows % 64 == 0 && p.cout_store % 4 == 0 && p.cout_store >= 192 && p.cin_pad >= 32 &&
          p.halo <= kHalo && p.ksplit <= 1 && fits32;
 }
 
+// the fused statistics pooling needs the 128-row geometry and the plain epilogue
+bool tdnn_x3_pool_supported(const TdnnKernelParams &p) {
+  const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first;
+  return tdnn_x3_supported(p) && fast && p.rows % 128 == 0 && (p.x3_terms & 7) == 7;
+}
+
 int launch_tdnn_x3(const TdnnKernelParams &p, hipStream_t s) {
-  ASV_REQUIRE(p.rows % XBM == 0, "tdnn(x3): rows %d not a multiple of %d", p.rows, XBM);
+  ASV_REQUIRE(p.rows % 64 == 0, "tdnn(x3): rows %d not a multiple of 64", p.rows);
   ASV_REQUIRE(p.wfrag != nullptr && p.wlo != nullptr, "tdnn(x3): split fragment-packed weights missing");
   for (int t = 0; t < p.n_taps; ++t)
     ASV_REQUIRE(p.taps[t] >= -kHalo && p.taps[t] <= kHalo, "tdnn(x3): tap offset %d exceeds the %d-frame halo", p.taps[t], kHalo);
-  const int m_tiles = p.rows / XBM, n_tiles = round_up(p.cout_store, XBN) / XBN;
+  const bool pool = p.pool_partial != nullptr;
+  const int terms = (p.x3_terms & 7) | 1;
+  const int bm = pool ? 128 : (terms != 7 ? 64 : x3_tile_rows(p));        // the reduced-product variants: 64-row geometry only
+  const int m_tiles = p.rows / bm, n_tiles = round_up(p.cout_store, XBN) / XBN;
   const dim3 grid(m_tiles * n_tiles), block(256);
   const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first;
-  const int terms = (p.x3_terms & 7) | 1;
   ASV_REQUIRE(p.x3_et == ET_BF16 || p.x3_et == ET_F16, "tdnn(x3): split type %d", p.x3_et);
   ASV_REQUIRE(p.w_unscale > 0.0f, "tdnn(x3): weight scale missing");
-#define ASV_X3(GENV, ETV, TV) hipLaunchKernelGGL((tdnn_gemm_x3_kernel<GENV, ETV, TV>), grid, block, 0, s, p, m_tiles, n_tiles)
-  // the reduced-product measurement variants exist for the plain epilogue only (a layer with another one runs all three products)
-#define ASV_X3_ET(ETV) do { if (!fast) ASV_X3(true, ETV, 7); else if (terms == 7) ASV_X3(false, ETV, 7); else if (terms == 3) ASV_X3(false, ETV, 3); \
-                            else if (terms == 5) ASV_X3(false, ETV, 5); else ASV_X3(false, ETV, 1); } while (0)
+  ASV_REQUIRE(!pool || (tdnn_x3_pool_supported(p) && p.row_seg != nullptr && p.pool_slots >= 1), "tdnn(x3): fused pooling needs the plain epilogue, all three products, 128-row tiles and a row map");
+#define ASV_X3(GENV, ETV, TV, MFV, POOLV) hipLaunchKernelGGL((tdnn_gemm_x3_kernel<GENV, ETV, TV, MFV, POOLV>), grid, block, 0, s, p, m_tiles, n_tiles)
+  // the reduced-product measurement variants exist for the plain epilogue and the 64-row geometry only (a layer with another
+  // epilogue runs all three products)
+#define ASV_X3_ET(ETV) do { if (pool) ASV_X3(false, ETV, 7, 4, true); \
+                            else if (!fast) { if (bm == 128) ASV_X3(true, ETV, 7, 4, false); else ASV_X3(true, ETV, 7, 2, false); } \
+                            else if (terms == 7) { if (bm == 128) ASV_X3(false, ETV, 7, 4, false); else ASV_X3(false, ETV, 7, 2, false); } \
+                            else if (terms == 3) ASV_X3(false, ETV, 3, 2, false); \
+                            else if (terms == 5) ASV_X3(false, ETV, 5, 2, false); else ASV_X3(false, ETV, 1, 2, false); } while (0)
   if (p.x3_et == ET_F16) ASV_X3_ET(ET_F16);
   else ASV_X3_ET(ET_BF16);
 #undef ASV_X3_ET

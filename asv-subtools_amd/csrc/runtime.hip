@@ -527,7 +527,7 @@ int asv_net_add_tdnn(asv_net_t *net, const asv_tdnn_desc_t *d) {
       }
       if ((rc = dev_upload(net, frags.data(), frags.size() * 2, &op.wconv))) return rc;
     }
-    if (op.utts && (net->frames_h16() || net->x3())) {
+    if (op.utts && net->frames_h16()) {
       // pooled-domain layers keep f32 activations; their GEMM runs on the bf16 matrix cores with every
       // operand split into two bf16 halves, the weight halves in the fragment order kernels_utts.hip walks:
       // [32-channel fragment][32-k step][j][lane = (k half lh, channel lr)][8], k = 32 * step + 16 * lh + 8 * j + e
@@ -745,7 +745,7 @@ int asv_net_finalize(asv_net_t *net, int out_buf, int embed_dim) {
   ASV_REQUIRE(!net->ops.empty(), "asv_net_finalize: empty program");
   // fuse "layer -> StatisticsPooling" when the layer's output has no other reader: the 157 MB tensor
   // (C2: 52k frames x 1500 channels) is then never written to or re-read from HBM
-  if ((net->flags & ASV_FLAG_NO_FUSE) == 0 && net->frames_h16()) {
+  if ((net->flags & ASV_FLAG_NO_FUSE) == 0 && (net->frames_h16() || net->x3())) {
     for (size_t i = 0; i + 1 < net->ops.size(); ++i) {
       Op &a = net->ops[i], &b = net->ops[i + 1];
       if (a.kind != OP_TDNN || b.kind != OP_POOL || a.utts || a.wfrag == nullptr) continue;
@@ -1248,7 +1248,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
           for (int32_t len : bp.dom[domid].seg_len) valid_rows += (double)(len / net->domains[domid].pitch) * net->domains[domid].width;
         }
         if ((rc = prof.begin(op.utts ? K_UTTS : K_TDNN, 2.0 * valid_rows * d.in_ch * d.out_ch * d.n_taps * (d.alg_fraction > 0.0f ? (double)d.alg_fraction : 1.0), (int)i))) return rc;
-        const bool fuse = big3 && pool_slots > 0;
+        const bool fuse = pool_slots > 0 && (big3 || (x3 && tdnn_x3_pool_supported(p)));
         if (fuse) {
           p.pool_slots = pool_slots;
           p.ld_partial = op.cout_pad;
@@ -1263,7 +1263,10 @@ int run_ops(RunCtx &c, size_t n_ops) {
             p.final_out = c.final_out; p.final_ld = net->embed_dim; p.final_len = c.seg_frames;
             c.final_written = true;
           }
-          rc = launch_utts_gemm(p, bp.segments, net->frames_h16() || net->x3(), c.s);
+          // pooled-domain layers: split-bf16 products (f32-grade to ~2^-17, twice the rate of the f32-input MFMA) in the 16-bit
+          // throughput modes; the exact f32-input MFMA in the parity modes - with IEEE-half operand halves in the frame layers
+          // the bf16 split here would be the largest error left in the f32x mode (< 0.3 % of the FLOPs: +1 % of an f32x step)
+          rc = launch_utts_gemm(p, bp.segments, net->frames_h16(), c.s);
         }
         else if (narrow_conv) rc = launch_grid_conv_narrow(p, c.s);
         else if (wide_conv) rc = launch_grid_conv_wide(p, c.s);

@@ -65,9 +65,11 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL on the GPUs (default); gloo needs --dry-run")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU ranks, stand-in extractor: exercises self-launch, barriers, the double-buffered all-gather and the JSON line without a device")
-    ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
+    ap.add_argument("--streams", type=int, default=None, choices=[1, 2],
                     help="2 = consecutive steps alternate between two engines (same weights, own activation arenas) on two HIP streams: the small "
-                         "launches at the end of step i (pooling merge, pooled affine) overlap the wide GEMMs at the start of step i + 1")
+                         "launches at the end of step i (pooling merge, pooled affine) overlap the wide GEMMs at the start of step i + 1 "
+                         "(default for the x-vector workload: +4.7 %% measured, profiles/r3a_*; the roofline object and `value_single_stream` "
+                         "come from a single-stream pass of the same workload)")
     ap.add_argument("--eer-trials", type=int, default=50000, help="trials of the EER gate leg (0 = skip)")
     ap.add_argument("--lengths", default=None, help="'lo:hi' = utterance lengths ~ U[lo, hi] (seeded) instead of --frames")
     ap.add_argument("--batch", type=int, default=None,
@@ -240,16 +242,19 @@ def main():
         def step():
             k = counter[0] & 1
             counter[0] += 1
-            if pending[k] is not None:                                  # buffer pair k is free once its gather has finished
-                pending[k].wait()                                       # (stream-side wait, the host does not block)
-                pending[k] = None
             if side is not None:
                 # two engines, two streams: step i + 1 starts while the tail of step i is still running
                 with torch.cuda.stream(side[k]):
+                    if pending[k] is not None:                          # THIS stream waits until the gather that reads outs[k] has finished
+                        pending[k].wait()
+                        pending[k] = None
                     (wl if k == 0 else wl2).extract(outs[k])
                     if collective:
                         pending[k] = dist.all_gather_into_tensor(gathered[k], outs[k], async_op=True)
                 return
+            if pending[k] is not None:                                  # buffer pair k is free once its gather has finished
+                pending[k].wait()                                       # (stream-side wait, the host does not block)
+                pending[k] = None
             extract_once(outs[k])
             if collective:
                 pending[k] = dist.all_gather_into_tensor(gathered[k], outs[k], async_op=True)
@@ -459,8 +464,16 @@ def main():
     else:
         lengths = tuple(int(v) for v in args.lengths.split(":")) if args.lengths else None
         wl = Workload(args, args.model, args.precision, args.batch, args.frames, rank, dev, lengths=lengths)
+    if args.streams is None:
+        args.streams = 2 if (args.model == "xvector" and not dry and not args.from_wav and not args.per_op) else 1
     wl2 = Workload(args, args.model, args.precision, args.batch, args.frames, rank, dev, lengths=lengths) if (args.streams == 2 and not dry) else None
     head = measure(wl, args.steps, args.warmup, args.min_seconds, not args.no_profile and not dry and wl2 is None, world > 1, per_op=args.per_op, from_wav=args.from_wav, wl2=wl2)
+    single = None
+    if wl2 is not None:
+        # the kernel-level figures (roofline: hipEvents around the GEMM launches of ONE stream) come from a single-stream pass
+        single = measure(wl, args.steps, 2, min(args.min_seconds, 0.6), not args.no_profile, world > 1)
+        if "roofline" in single:
+            head["roofline"] = single["roofline"]
     res = {
         "metric": "utterances/sec (200-frame) embedding extraction + EER, 1/2/4/8 MI355X",
         "value": head["value"], "unit": "utterances/s",
@@ -478,6 +491,9 @@ def main():
                    "ms_per_step_min_max": head["ms_per_step_min_max"]},
         "settle_seconds": args.settle_seconds,
     }
+    if single is not None:
+        res["value_single_stream"] = single["value"]
+        res["ms_per_step_single_stream"] = single["ms_per_step"]
     if wl2 is not None:
         res["config"]["streams"] = "2 engines x 2 HIP streams, consecutive steps alternate (software pipelining across batches; every step is a full pass)"
     if dry:
