@@ -88,9 +88,19 @@ __device__ __forceinline__ X3Frag x3_split(const uint4 a, const uint4 b) {
     h[k] = pack_h16x2<ET>(v[2 * k], v[2 * k + 1]);
     l[k] = 0u;
     if constexpr (WITH_LO) {
-      float h0, h1;
-      unpack_h16x2<ET>(h[k], h0, h1);
-      l[k] = pack_h16x2<ET>(v[2 * k] - h0, v[2 * k + 1] - h1);
+      float r0, r1;
+      if constexpr (ET == ET_F16) {
+        // x - hi in ONE mixed-precision fma per value, straight from the packed halves (v_fma_mix_f32: hi is read as half, -1 and x
+        // as f32): the unpacking conversions (two v_cvt_f32_f16 per pair) were a third of this loop's VALU work, and the VALU work -
+        // ~4 operations per matrix instruction - is what this kernel's K loop is bound by
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h[k]), "v"(v[2 * k]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h[k]), "v"(v[2 * k + 1]));
+      } else {
+        float h0, h1;
+        unpack_h16x2<ET>(h[k], h0, h1);
+        r0 = v[2 * k] - h0; r1 = v[2 * k + 1] - h1;
+      }
+      l[k] = pack_h16x2<ET>(r0, r1);
     }
   }
   X3Frag f;

@@ -131,7 +131,9 @@ def test_half_split_keeps_small_operands_and_two_products_are_not_enough():
             errs[(xs, ws, name)] = rel_err(got, want)
     print("\n[x3 split] " + "; ".join("x*%g w*%g %s: %.2e" % (k + (v,)) for k, v in errs.items()))
     for xs, ws in ((1.0, 1.0), (3e-3, 1.0), (1.0, 1e-4), (40.0, 30.0)):
-        assert errs[(xs, ws, "f16x3")] < 3e-6, (xs, ws, errs[(xs, ws, "f16x3")])
+        # activations of magnitude 3e-3: hi keeps 11 bits, lo is a subnormal half with the absolute precision 2^-25 = 1e-5 of such a
+        # value (kept, not flushed: a flush would leave 2^-12 = 2.4e-4) - the level of the bf16 split; O(1) activations: f32-grade
+        assert errs[(xs, ws, "f16x3")] < (1e-5 if xs < 0.1 else 3e-6), (xs, ws, errs[(xs, ws, "f16x3")])
         assert errs[(xs, ws, "bf16x3")] < 2e-5
         for two in ("f16 no x_lo", "f16 no w_lo"):
             assert 2e-5 < errs[(xs, ws, two)] < 2e-3, (two, errs[(xs, ws, two)])

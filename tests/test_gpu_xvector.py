@@ -220,8 +220,13 @@ def test_layer_chain_kernel_matches_per_layer_kernels(monkeypatch):
     monkeypatch.setenv("ASV_AMD_NO_CHAIN", "1")
     plain = model.extract_embedding_batch(mats).numpy()
     assert np.isfinite(chain).all()
-    assert rel_err(chain, plain) < 2e-3, rel_err(chain, plain)
+    # Since round 3 the chain folds the eval BatchNorm of its inner layers into the consumers' weights (W diag(s) rounded to bf16
+    # once, instead of s u + t rounded per value): the two paths are two bf16 evaluations of the same f32 function with
+    # independent roundings - they differ by ~sqrt(2) x the bf16 noise of either (2.3e-3), and neither is further from the reference
+    assert rel_err(chain, plain) < 6e-3, rel_err(chain, plain)
     assert not np.array_equal(chain, plain)                      # two different code paths
+    e_chain, e_plain = rel_err(chain[:70], g["embeddings"][:70]), rel_err(plain[:70], g["embeddings"][:70])
+    assert e_chain < 1.3 * e_plain + 1e-4, (e_chain, e_plain)
     assert rel_err(chain[:70], g["embeddings"][:70]) < 3e-2
     cos = (chain[:70] * g["embeddings"][:70]).sum(1) / np.linalg.norm(chain[:70], axis=1) / np.linalg.norm(g["embeddings"][:70], axis=1)
     assert cos.min() > 0.9995
@@ -232,7 +237,7 @@ def test_layer_chain_kernel_matches_per_layer_kernels(monkeypatch):
     a = model2.extract_embedding_batch(mats2).numpy()
     monkeypatch.setenv("ASV_AMD_NO_CHAIN", "1")
     b = model2.extract_embedding_batch(mats2).numpy()
-    assert rel_err(a, b) < 2e-3, rel_err(a, b)
+    assert rel_err(a, b) < 6e-3, rel_err(a, b)
     # many utterances per 32-frame fragment (several masked runs per fragment, lane halves without frames, single-frame
     # utterances), both pooling epilogues of the chain kernel (ASV_AMD_CHAIN_POOLV is read at every launch)
     lens = [1, 2, 3, 5, 4, 7, 1, 9, 13, 21, 2, 34, 6, 55, 3, 89, 11, 144, 1, 1, 8, 233, 17, 2, 40, 31, 32, 33, 64, 63, 65, 12] * 6
@@ -244,7 +249,7 @@ def test_layer_chain_kernel_matches_per_layer_kernels(monkeypatch):
         monkeypatch.setenv("ASV_AMD_CHAIN_POOLV", v)
         outs[v] = model2.extract_embedding_batch(mats3).numpy()
         assert np.isfinite(outs[v]).all()
-        assert rel_err(outs[v], ref) < 2e-3, (v, rel_err(outs[v], ref))
+        assert rel_err(outs[v], ref) < 6e-3, (v, rel_err(outs[v], ref))
         a200 = model2.extract_embedding_batch(mats2).numpy()
-        assert rel_err(a200, b) < 2e-3, (v, rel_err(a200, b))
+        assert rel_err(a200, b) < 6e-3, (v, rel_err(a200, b))
     assert rel_err(outs["0"], outs["1"]) < 1e-4, rel_err(outs["0"], outs["1"])   # same moments, other summation order
