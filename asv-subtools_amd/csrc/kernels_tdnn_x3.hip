@@ -110,11 +110,20 @@ __device__ __forceinline__ X3Frag x3_split(const uint4 a, const uint4 b) {
 }
 
 // ET: the 16-bit type of the operand halves; TERMS: bit 0 = w_hi x_hi, bit 1 = w_hi x_lo, bit 2 = w_lo x_hi
-template <bool GENERIC, int ET, int TERMS, int MF = 2, bool POOL = false>
+// SHARED (round 3, 128-row geometry): the f32 window of a chunk is split into its [hi | lo] image ONCE per workgroup - every
+//   thread converts two or three 8-value pieces - instead of by every wave for every tap inside the K loop (the four waves of a
+//   workgroup multiply the SAME 128 rows by their own 64 channels: 4 waves x n_taps redundant splits, ~4 VALU operations per
+//   matrix instruction - the K loop was VALU-bound at ~50 % matrix-pipe utilisation).  LDS: two f32 stages (LDS-DMA targets) +
+//   two image buffers = the four stages of the other form; per chunk c, behind its one barrier: LDS-DMA of window c + 2 into
+//   the stage window c has just been converted out of, conversion of window c + 1, K loop on image c (8 ds_read_b128 + 4 weight
+//   fetches per 24 matrix instructions, no VALU).  Round 2 tried this on the 64-row geometry, whose K loop was bound by its
+//   weight-fragment traffic instead, and saw nothing (profiles/r2p_*).
+template <bool GENERIC, int ET, int TERMS, int MF = 2, bool POOL = false, bool SHARED = false>
 __global__ __launch_bounds__(256, MF == 2 ? 3 : 2) void tdnn_gemm_x3_kernel(const TdnnKernelParams p, int m_tiles, int n_tiles) {
   using Geo = X3Geom<MF>;
   constexpr int XBM = Geo::BM, XGROUPS = Geo::GROUPS, XPIECES = Geo::PIECES, XSTAGE = Geo::STAGE, XRING = Geo::RING;
   static_assert(!POOL || (MF == 4 && !GENERIC), "the fused pooling epilogue works on 128-row tiles with the plain epilogue");
+  static_assert(!SHARED || (MF == 4 && TERMS == 7), "the shared split exists for the 128-row geometry with all three products");
   __shared__ __attribute__((aligned(16))) unsigned char lds[XRING + 3 * 256 * 4];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -182,7 +191,35 @@ __global__ __launch_bounds__(256, MF == 2 ? 3 : 2) void tdnn_gemm_x3_kernel(cons
       else w.l[j] = make_uint4(0, 0, 0, 0);
     }
   };
+  // SHARED: window c -> image buffer c & 1: row w = [hi of channels 0..31 (4 slots) | lo (4 slots)], slots swizzled like the window's
+  auto convert = [&](int c) {
+    const unsigned char *src = lds + (c & 1) * XSTAGE;
+    unsigned char *dst = lds + (2 + (c & 1)) * XSTAGE;
+#pragma unroll
+    for (int it = 0; it < (Geo::WIN * 4 + 255) / 256; ++it) {
+      const int item = it * 256 + tid;
+      if (item < Geo::WIN * 4) {
+        const int w = item >> 2, q = item & 3;
+        const uint4 a = *reinterpret_cast<const uint4 *>(src + w * XROWB + xswz(w, 2 * q) * 16);
+        const uint4 b = *reinterpret_cast<const uint4 *>(src + w * XROWB + xswz(w, 2 * q + 1) * 16);
+        const X3Frag f = x3_split<ET, true>(a, b);
+        *reinterpret_cast<uint4 *>(dst + w * XROWB + xswz(w, q) * 16) = f.hi;
+        *reinterpret_cast<uint4 *>(dst + w * XROWB + xswz(w, 4 + q) * 16) = f.lo;
+      }
+    }
+  };
   auto load_x = [&](int c, int d, int kg, XFrags &x) {
+    if constexpr (SHARED) {
+      const unsigned char *Ib = lds + (2 + (c & 1)) * XSTAGE;
+      const int sh = kg * 2 + lh;
+#pragma unroll
+      for (int i = 0; i < MF; ++i) {
+        const int w = i * 32 + lr + kHalo + d;
+        x.f[i].hi = *reinterpret_cast<const uint4 *>(Ib + w * XROWB + xswz(w, sh) * 16);
+        x.f[i].lo = *reinterpret_cast<const uint4 *>(Ib + w * XROWB + xswz(w, 4 + sh) * 16);
+      }
+      return;
+    }
     const unsigned char *Ab = lds + (c % XSTAGES) * XSTAGE;
     const int s0 = kg * 4 + lh * 2;
 #pragma unroll
@@ -225,11 +262,25 @@ __global__ __launch_bounds__(256, MF == 2 ? 3 : 2) void tdnn_gemm_x3_kernel(cons
   XFrags x0, x1;
   load_w(0, 0, 0, w0);
   if (nchunks > 1) issue_A(1, 1);
-  if (nchunks > 2) issue_A(2, 2);
-  if (nchunks > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * XPIECES) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
+  if constexpr (SHARED) {
+    // window 0 landed -> image 0; its stage then takes window 2.  Window 1 is converted at the top of chunk 0 (below).
+    if (nchunks > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XPIECES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    convert(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // window 1 (this wave's pieces) landed, image 0 written
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (nchunks > 2) issue_A(2, 0);
+    if (nchunks > 1) convert(1);
+  } else {
+    if (nchunks > 2) issue_A(2, 2);
+    if (nchunks > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * XPIECES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
   load_x(0, __builtin_amdgcn_readlane(v_taps, 0), 0, x0);
 
   // ---- main loop over k-groups, two per trip (register sets 0 / 1 alternate: static indices only)
@@ -243,13 +294,25 @@ __global__ __launch_bounds__(256, MF == 2 ? 3 : 2) void tdnn_gemm_x3_kernel(cons
     if (kg2 == 2) { kg2 = 0; t2 = t + 1; if (t2 == n_taps) { t2 = 0; c2 = c + 1; } }
     if (g + 1 < G) {
       if (c2 != c) {
-        // VMEM retires in order: everything but the youngest 4 operations (the fragments of k-group g, fetched one
-        // k-group ago) has landed, in particular this wave's pieces of window c+1 (>= 7 operations old: the pieces of
-        // window c+2 and at least one group of fragments were issued behind them)
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (c + 3 < nchunks) issue_A(c + 3, (c + 3) % XSTAGES);       // nobody reads window c-1 any more
+        if constexpr (SHARED) {
+          // entering chunk c + 1: its image was written at the top of chunk c (by every wave: lgkmcnt), window c + 2 was
+          // issued there too and is older than the youngest 4 operations (the fragments of k-group g).  Behind the barrier
+          // nobody reads image c any more and window c + 1's stage is free: it takes window c + 3; window c + 2 becomes
+          // image (c + 2) & 1 = c & 1.
+          asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          if (c + 3 < nchunks) issue_A(c + 3, (c + 1) & 1);
+          if (c + 2 < nchunks) convert(c + 2);
+        } else {
+          // VMEM retires in order: everything but the youngest 4 operations (the fragments of k-group g, fetched one
+          // k-group ago) has landed, in particular this wave's pieces of window c+1 (>= 7 operations old: the pieces of
+          // window c+2 and at least one group of fragments were issued behind them)
+          asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          if (c + 3 < nchunks) issue_A(c + 3, (c + 3) % XSTAGES);       // nobody reads window c-1 any more
+        }
       }
       load_w(c2, t2, kg2, wn_);
       load_x(c2, __builtin_amdgcn_readlane(v_taps, t2), kg2, xn);
@@ -431,17 +494,23 @@ int launch_tdnn_x3(const TdnnKernelParams &p, hipStream_t s) {
   ASV_REQUIRE(p.x3_et == ET_BF16 || p.x3_et == ET_F16, "tdnn(x3): split type %d", p.x3_et);
   ASV_REQUIRE(p.w_unscale > 0.0f, "tdnn(x3): weight scale missing");
   ASV_REQUIRE(!pool || (tdnn_x3_pool_supported(p) && p.row_seg != nullptr && p.pool_slots >= 1), "tdnn(x3): fused pooling needs the plain epilogue, all three products, 128-row tiles and a row map");
-#define ASV_X3(GENV, ETV, TV, MFV, POOLV) hipLaunchKernelGGL((tdnn_gemm_x3_kernel<GENV, ETV, TV, MFV, POOLV>), grid, block, 0, s, p, m_tiles, n_tiles)
+  // ASV_AMD_X3_SHARED=0: the per-wave split inside the K loop on the 128-row geometry too (A/B; read once, or per launch with LIVE_TUNE)
+  static const bool live = getenv("ASV_AMD_LIVE_TUNE") != nullptr;
+  static const int shared0 = getenv("ASV_AMD_X3_SHARED") != nullptr ? atoi(getenv("ASV_AMD_X3_SHARED")) : 1;
+  const bool shared = (live ? (getenv("ASV_AMD_X3_SHARED") != nullptr ? atoi(getenv("ASV_AMD_X3_SHARED")) : 1) : shared0) != 0;
+#define ASV_X3(GENV, ETV, TV, MFV, POOLV, SHV) hipLaunchKernelGGL((tdnn_gemm_x3_kernel<GENV, ETV, TV, MFV, POOLV, SHV>), grid, block, 0, s, p, m_tiles, n_tiles)
+#define ASV_X3_128(GENV, ETV, POOLV) do { if (shared) ASV_X3(GENV, ETV, 7, 4, POOLV, true); else ASV_X3(GENV, ETV, 7, 4, POOLV, false); } while (0)
   // the reduced-product measurement variants exist for the plain epilogue and the 64-row geometry only (a layer with another
   // epilogue runs all three products)
-#define ASV_X3_ET(ETV) do { if (pool) ASV_X3(false, ETV, 7, 4, true); \
-                            else if (!fast) { if (bm == 128) ASV_X3(true, ETV, 7, 4, false); else ASV_X3(true, ETV, 7, 2, false); } \
-                            else if (terms == 7) { if (bm == 128) ASV_X3(false, ETV, 7, 4, false); else ASV_X3(false, ETV, 7, 2, false); } \
-                            else if (terms == 3) ASV_X3(false, ETV, 3, 2, false); \
-                            else if (terms == 5) ASV_X3(false, ETV, 5, 2, false); else ASV_X3(false, ETV, 1, 2, false); } while (0)
+#define ASV_X3_ET(ETV) do { if (pool) ASV_X3_128(false, ETV, true); \
+                            else if (!fast) { if (bm == 128) ASV_X3_128(true, ETV, false); else ASV_X3(true, ETV, 7, 2, false, false); } \
+                            else if (terms == 7) { if (bm == 128) ASV_X3_128(false, ETV, false); else ASV_X3(false, ETV, 7, 2, false, false); } \
+                            else if (terms == 3) ASV_X3(false, ETV, 3, 2, false, false); \
+                            else if (terms == 5) ASV_X3(false, ETV, 5, 2, false, false); else ASV_X3(false, ETV, 1, 2, false, false); } while (0)
   if (p.x3_et == ET_F16) ASV_X3_ET(ET_F16);
   else ASV_X3_ET(ET_BF16);
 #undef ASV_X3_ET
+#undef ASV_X3_128
 #undef ASV_X3
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
