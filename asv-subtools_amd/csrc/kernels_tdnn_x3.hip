@@ -319,12 +319,58 @@ __global__ __launch_bounds__(256, MF == 2 ? 3 : 2) void tdnn_gemm_x3_kernel(cons
     }
     c = c2; t = t2;
   };
-  for (int g = 0; g < G; g += 2) {
-    advance(g, x1, w1);
-    mma(x0, w0);
-    if (g + 1 < G) {
-      advance(g + 1, x0, w0);
-      mma(x1, w1);
+  if constexpr (SHARED) {
+    // Pinned schedule: the 12 fetches of k-group g + 1 (4 weight fragments from L2, 8 image fragments from LDS) are threaded one in
+    // front of every pair of the 24 matrix instructions of k-group g (sched_barrier after each pair, as kernels_tdnn_v3.hip does):
+    // left to itself hipcc puts a group's fetches and their waits in front of its matrix instructions, and with two waves per SIMD
+    // both then sit in the same wait (measured: the unpinned SHARED form was 10 % SLOWER than the per-wave split, r3c).
+    auto step = [&](const XFrags &xc, const WFrags &wc, XFrags &xn, WFrags &wnx, int g) {
+      const int kg = g & 1;
+      int c2 = c, t2 = t, kg2 = kg + 1;
+      if (kg2 == 2) { kg2 = 0; t2 = t + 1; if (t2 == n_taps) { t2 = 0; c2 = c + 1; } }
+      const bool more = g + 1 < G;
+      if (!more) { c2 = c; t2 = t; kg2 = kg; }                     // the last k-group re-fetches itself (valid memory, never used)
+      if (more && c2 != c) {
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (c + 3 < nchunks) issue_A(c + 3, (c + 1) & 1);
+        if (c + 2 < nchunks) convert(c + 2);
+      }
+      const size_t woff = ((size_t)t2 * nkg + (size_t)c2 * 2 + kg2) * 1024;
+      const int wrow = lr + kHalo + __builtin_amdgcn_readlane(v_taps, t2);
+      const int sw = (wrow >> 1) & 7;                               // the swizzle term is blind to + 32 rows: one address per half image
+      const unsigned char *ib = lds + (2 + (c2 & 1)) * XSTAGE + wrow * XROWB;
+      const unsigned char *ih = ib + (((kg2 * 2 + lh) ^ sw) << 4), *il = ib + (((4 + kg2 * 2 + lh) ^ sw) << 4);
+#pragma unroll
+      for (int pr = 0; pr < 12; ++pr) {
+        if (pr < 2) wnx.h[pr] = *reinterpret_cast<const uint4 *>(wh_base + pr * frag_stride + woff);
+        else if (pr < 4) wnx.l[pr - 2] = *reinterpret_cast<const uint4 *>(wl_base + (pr - 2) * frag_stride + woff);
+        else if (((pr - 4) & 1) == 0) xn.f[(pr - 4) >> 1].hi = *reinterpret_cast<const uint4 *>(ih + ((pr - 4) >> 1) * 32 * XROWB);
+        else xn.f[(pr - 4) >> 1].lo = *reinterpret_cast<const uint4 *>(il + ((pr - 4) >> 1) * 32 * XROWB);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int idx = 2 * pr + e, term = idx >> 3, j = (idx >> 2) & 1, i = idx & 3;     // term-major: an accumulator recurs every 8th instruction
+          const uint4 a = (term == 2) ? wc.l[j] : wc.h[j];
+          const uint4 b = (term == 1) ? xc.f[i].lo : xc.f[i].hi;
+          acc[i][j] = mfma16<ET>(a, b, acc[i][j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      c = c2; t = t2;
+    };
+    for (int g = 0; g < G; g += 2) {
+      step(x0, w0, x1, w1, g);
+      if (g + 1 < G) step(x1, w1, x0, w0, g + 1);
+    }
+  } else {
+    for (int g = 0; g < G; g += 2) {
+      advance(g, x1, w1);
+      mma(x0, w0);
+      if (g + 1 < G) {
+        advance(g + 1, x0, w0);
+        mma(x1, w1);
+      }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
