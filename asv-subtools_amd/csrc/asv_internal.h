@@ -168,6 +168,7 @@ constexpr int kChainWidth = 512;
 struct TdnnChainLayer {
   const void *wfrag; const float *bias, *scale, *shift;   // scale / shift may be nullptr (1, 0)
   int relu, cout_pad;
+  const void *wlo; float w_scale;                          // f32x chain (kernels_tdnn_chainx.hip): lo halves, and the power of two both halves carry
 };
 struct TdnnChainParams {
   const void *x; int ldx, rows, cin_pad, n_taps; int taps[ASV_MAX_TAPS];     // input of the first layer (bf16 rows)
@@ -178,6 +179,8 @@ struct TdnnChainParams {
   int et;                       // ET_BF16 / ET_F16: element type of the rows and of every layer's weight fragments
 };
 int launch_tdnn_chain(const TdnnChainParams &p, hipStream_t s);
+// the same chain with f32-grade split products and the tiles resident as hi / lo half images; 64-row tiles (kernels_tdnn_chainx.hip)
+int launch_tdnn_chainx(const TdnnChainParams &p, hipStream_t s);
 // ECAPA Res2NetBlock as one kernel (kernels_res2.hip)
 constexpr int kRes2Width = 128;
 struct Res2KernelParams {
@@ -203,6 +206,7 @@ int launch_stats_pool(const PoolKernelParams &p, int segments, int et, hipStream
 struct PoolFinishParams {
   const float *partial; int ld_partial, pool_slots;
   int lh_split;                  // partials of the chain kernel: [tile][slot][lh][3][ld], lh = bit 2 of the row index of the frames summed
+  int tile_shift;                // log2 of the rows one partial covers: 7 (128-row tiles; 0 means 7) or 6 (the f32x chain's 64-row tiles)
   const int32_t *row_seg; int rows;
   const int32_t *seg_row0, *seg_len;
   const float *shift;            // per-channel BN shift that the producer left out (or nullptr)

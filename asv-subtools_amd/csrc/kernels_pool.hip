@@ -217,12 +217,13 @@ __global__ __launch_bounds__(64) void pool_finish_kernel(const PoolFinishParams 
   // and one difference of nearby means - well conditioned in f32; the float64 version of this loop was 20 of the x-vector
   // step's 700 us, most of it double-precision divisions); every partial holds sum (u - pv), sum (u - pv)^2 about its own pivot pv
   float n_acc = 0.0f, mean = 0.0f, m2 = 0.0f;
-  for (int h = row0 >> 7; h <= (row0 + len - 1) >> 7; ++h) {
+  const int ts = p.tile_shift ? p.tile_shift : 7;       // rows per partial: 128, or 64 (f32x chain)
+  for (int h = row0 >> ts; h <= (row0 + len - 1) >> ts; ++h) {
     int first = -1;
     for (int k = 0; k < kHalo + 1 && first < 0; ++k)
-      if (h * 128 + k < p.rows) first = p.row_seg[h * 128 + k];
+      if ((h << ts) + k < p.rows) first = p.row_seg[(h << ts) + k];
     const int slot = seg - first;                       // segments are consecutive in row order
-    const int a = max(row0, h * 128), b = min(row0 + len, (h + 1) * 128);
+    const int a = max(row0, h << ts), b = min(row0 + len, (h + 1) << ts);
     const int parts = p.lh_split ? 2 : 1;
     for (int part = 0; part < parts; ++part) {
       int cnt = b - a;

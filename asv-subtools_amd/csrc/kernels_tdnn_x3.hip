@@ -330,12 +330,14 @@ __global__ __launch_bounds__(256, MF == 2 ? 3 : 2) void tdnn_gemm_x3_kernel(cons
       if (kg2 == 2) { kg2 = 0; t2 = t + 1; if (t2 == n_taps) { t2 = 0; c2 = c + 1; } }
       const bool more = g + 1 < G;
       if (!more) { c2 = c; t2 = t; kg2 = kg; }                     // the last k-group re-fetches itself (valid memory, never used)
-      if (more && c2 != c) {
+      const bool enter = more && c2 != c;
+      if (enter) {
         asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (c + 3 < nchunks) issue_A(c + 3, (c + 1) & 1);
         if (c + 2 < nchunks) convert(c + 2);
+        // window c + 3 is issued BEHIND this step's weight fetches (below): the vector-memory counter retires in order, a fetch
+        // issued behind the DMA could not be consumed before the window has landed
       }
       const size_t woff = ((size_t)t2 * nkg + (size_t)c2 * 2 + kg2) * 1024;
       const int wrow = lr + kHalo + __builtin_amdgcn_readlane(v_taps, t2);
@@ -344,6 +346,7 @@ __global__ __launch_bounds__(256, MF == 2 ? 3 : 2) void tdnn_gemm_x3_kernel(cons
       const unsigned char *ih = ib + (((kg2 * 2 + lh) ^ sw) << 4), *il = ib + (((4 + kg2 * 2 + lh) ^ sw) << 4);
 #pragma unroll
       for (int pr = 0; pr < 12; ++pr) {
+        if (pr == 4 && enter && c + 3 < nchunks) issue_A(c + 3, (c + 1) & 1);
         if (pr < 2) wnx.h[pr] = *reinterpret_cast<const uint4 *>(wh_base + pr * frag_stride + woff);
         else if (pr < 4) wnx.l[pr - 2] = *reinterpret_cast<const uint4 *>(wl_base + (pr - 2) * frag_stride + woff);
         else if (((pr - 4) & 1) == 0) xn.f[(pr - 4) >> 1].hi = *reinterpret_cast<const uint4 *>(ih + ((pr - 4) >> 1) * 32 * XROWB);

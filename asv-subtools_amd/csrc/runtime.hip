@@ -129,7 +129,9 @@ struct Op {
   // chain candidates (16-bit modes, 1-tap layers reading a 512-channel buffer): host copies kept until asv_net_finalize, which
   // folds the eval BatchNorm of the PREVIOUS chain layer into this layer's weights and bias (see the chain pass there)
   std::vector<float> host_w, host_bias, host_scale, host_shift;
-  void *wfrag_fold = nullptr;    // fragment-ordered W diag(s_prev) ...
+  void *wfrag_fold = nullptr;    // fragment-ordered W diag(s_prev) ... (f32x: its hi halves, wlo_fold the lo halves, w_scale_fold their power of two)
+  void *wlo_fold = nullptr;
+  float w_scale_fold = 1.0f;
   float *bias_fold = nullptr;    // ... and b + W t_prev
   float w_scale = 1.0f;          // f32x mode, half-precision split: the power of two the fragment weights were multiplied by
   bool utts = false;             // op runs in the utts domain (always f32)
@@ -553,7 +555,7 @@ int asv_net_add_tdnn(asv_net_t *net, const asv_tdnn_desc_t *d) {
     if ((rc = upload_padded(net, d->scale, d->out_ch, op.cout_pad, 0.0f, &op.scale))) return rc;
     if ((rc = upload_padded(net, d->shift, d->out_ch, op.cout_pad, 0.0f, &op.shift))) return rc;
   }
-  if (bf16 && !op.utts && net->domains[dom].kind == ASV_DOMAIN_FRAMES && op.wfrag != nullptr && (net->flags & (ASV_FLAG_NO_FUSE | ASV_FLAG_NO_CHAIN)) == 0) {
+  if ((bf16 || net->x3()) && !op.utts && net->domains[dom].kind == ASV_DOMAIN_FRAMES && op.wfrag != nullptr && (net->flags & (ASV_FLAG_NO_FUSE | ASV_FLAG_NO_CHAIN)) == 0) {
     // possible member of a layer chain: its BatchNorm may be folded into the next member, or the previous member's into it
     if (d->scale) { op.host_scale.assign(d->scale, d->scale + d->out_ch); op.host_shift.assign(d->shift, d->shift + d->out_ch); }
     if (d->n_taps == 1 && d->taps[0] == 0 && d->in_ch == kChainWidth) {
@@ -771,10 +773,10 @@ int asv_net_finalize(asv_net_t *net, int out_buf, int embed_dim) {
   }
   // chains "layer -> 512, [1-tap 512 -> 512]*, 1-tap + fused pooling" whose intermediate tensors nobody else reads run as
   // ONE kernel with the 128 x 512 tiles resident in LDS (x-vector: tdnn3 -> tdnn4 -> tdnn5 -> pooling)
-  if ((net->flags & (ASV_FLAG_NO_FUSE | ASV_FLAG_NO_CHAIN)) == 0 && net->frames_h16()) {
+  if ((net->flags & (ASV_FLAG_NO_FUSE | ASV_FLAG_NO_CHAIN)) == 0 && (net->frames_h16() || (net->x3() && net->x3_terms() == 7))) {
     auto plain = [&](const Op &o) {
       const auto &d = o.tdnn;
-      return o.kind == OP_TDNN && !o.utts && o.wfrag != nullptr && net->bufs[d.in_buf].domain == ASV_DOMAIN_FRAMES && d.in2_buf < 0 && d.seg_bias_buf < 0 &&
+      return o.kind == OP_TDNN && !o.utts && o.wfrag != nullptr && (!net->x3() || o.wlo != nullptr) && net->bufs[d.in_buf].domain == ASV_DOMAIN_FRAMES && d.in2_buf < 0 && d.seg_bias_buf < 0 &&
              d.seg_scale_buf < 0 && d.res_buf < 0 && !d.affine_first && d.act2 == ASV_ACT_NONE && (d.act1 == ASV_ACT_NONE || d.act1 == ASV_ACT_RELU);
     };
     auto from_resident = [&](const Op &o) {            // 1-tap layer that consumes a whole 512-channel buffer
@@ -836,10 +838,17 @@ int asv_net_finalize(asv_net_t *net, int out_buf, int embed_dim) {
           bf[co] = (float)acc;
         }
         const int tap0 = 0;
-        std::vector<uint16_t> frags(tdnn_weight_frag_elems(cur.cout_pad, cur.cin_pad, 1));
-        pack_tdnn_weight_frags(wf.data(), out_ch, in_ch, 1, 0, &tap0, 1, cur.cout_pad, cur.cin_pad, frags.data(), nullptr, net->frames_et());
+        std::vector<uint16_t> frags(tdnn_weight_frag_elems(cur.cout_pad, cur.cin_pad, 1)), frags_lo;
         ASV_ON_DEVICE(net->device);
         int rc;
+        if (net->x3()) {
+          frags_lo.resize(frags.size());
+          cur.w_scale_fold = net->x3_et() == ET_F16 ? x3_weight_scale(wf.data(), wf.size()) : 1.0f;
+          pack_tdnn_weight_frags(wf.data(), out_ch, in_ch, 1, 0, &tap0, 1, cur.cout_pad, cur.cin_pad, frags.data(), frags_lo.data(), net->x3_et(), cur.w_scale_fold);
+          if ((rc = dev_upload(net, frags_lo.data(), frags_lo.size() * 2, &cur.wlo_fold))) return rc;
+        } else {
+          pack_tdnn_weight_frags(wf.data(), out_ch, in_ch, 1, 0, &tap0, 1, cur.cout_pad, cur.cin_pad, frags.data(), nullptr, net->frames_et());
+        }
         if ((rc = dev_upload(net, frags.data(), frags.size() * 2, &cur.wfrag_fold))) return rc;
         void *bdev = nullptr;
         if ((rc = dev_upload(net, bf.data(), bf.size() * sizeof(float), &bdev))) return rc;
@@ -1107,14 +1116,16 @@ int run_ops(RunCtx &c, size_t n_ops) {
         p.act1 = d.act1; p.act2 = d.act2; p.affine_first = d.affine_first;
         p.zero16 = net->zero_page;
         p.wfrag = op.wfrag; p.wlo = op.wlo; p.wconv = op.wconv;
-        if (op.chain_last >= 0 && !use_ref && bf16 && p.halo <= kHalo && (net->flags & ASV_FLAG_SMALL_TILES) == 0 &&
-            (unsigned long long)p.rows * (unsigned long long)p.ldx * 2ull < (1ull << 32)) {
+        const bool chain_x3 = net->x3();             // f32x: the split-product chain on 64-row tiles (kernels_tdnn_chainx.hip)
+        if (op.chain_last >= 0 && !use_ref && (bf16 || chain_x3) && p.halo <= kHalo && (net->flags & ASV_FLAG_SMALL_TILES) == 0 &&
+            (chain_x3 || (unsigned long long)p.rows * (unsigned long long)p.ldx * 2ull < (1ull << 32))) {
           // tdnn -> [1-tap]* -> 1-tap + pooling in one kernel, if the batch allows the fused pooling (no crowd of tiny utterances)
           const DomainPlan &fp = bp.dom[ASV_DOMAIN_FRAMES];
-          std::vector<int> per_half((size_t)fp.rows_pad / 128 + 1, 0);
+          const int tshift = chain_x3 ? 6 : 7;         // rows per pooling partial: the kernel's tile
+          std::vector<int> per_half(((size_t)fp.rows_pad >> tshift) + 1, 0);
           int slots = 1;
           for (size_t sidx = 0; sidx < fp.seg_row0.size(); ++sidx)
-            for (int h = fp.seg_row0[sidx] >> 7; h <= (fp.seg_row0[sidx] + fp.seg_len[sidx] - 1) >> 7; ++h) slots = std::max(slots, ++per_half[h]);
+            for (int h = fp.seg_row0[sidx] >> tshift; h <= (fp.seg_row0[sidx] + fp.seg_len[sidx] - 1) >> tshift; ++h) slots = std::max(slots, ++per_half[h]);
           if (slots <= 16) {
             const size_t l = (size_t)op.chain_last;
             Op &lo = net->ops[l];
@@ -1129,6 +1140,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
               const bool folded_out = k < l && net->ops[k + 1].wfrag_fold != nullptr;          // this layer's BN sits in the next layer's
               TdnnChainLayer L;
               L.wfrag = folded_in ? o.wfrag_fold : o.wfrag; L.bias = folded_in ? o.bias_fold : o.bias;
+              L.wlo = folded_in ? o.wlo_fold : o.wlo; L.w_scale = folded_in ? o.w_scale_fold : o.w_scale;
               L.scale = folded_out ? nullptr : o.scale; L.shift = folded_out ? nullptr : o.shift;
               L.relu = o.tdnn.act1 == ASV_ACT_RELU; L.cout_pad = o.cout_pad;
               return L;
@@ -1137,22 +1149,23 @@ int run_ops(RunCtx &c, size_t n_ops) {
             cp.n_mid = (int)(l - i - 1);
             for (size_t k = i + 1; k < l; ++k) cp.mid[k - i - 1] = layer_of(k);
             cp.last = layer_of(l);
-            cp.pool_slots = slots; cp.ld_partial = lo.cout_pad; cp.row_seg = dr.row_seg; cp.et = et;
-            if ((rc = ensure(net->poolpart_dev, (size_t)(p.rows / 128) * slots * 2 * 3 * cp.ld_partial * 4, c.s, false))) return rc;
+            cp.pool_slots = slots; cp.ld_partial = lo.cout_pad; cp.row_seg = dr.row_seg;
+            cp.et = chain_x3 ? net->x3_et() : et;
+            if ((rc = ensure(net->poolpart_dev, (size_t)(p.rows >> tshift) * slots * 2 * 3 * cp.ld_partial * 4, c.s, false))) return rc;
             cp.pool_partial = reinterpret_cast<float *>(net->poolpart_dev.ptr);
             double fl = 0.0;
             for (size_t k = i; k <= l; ++k) fl += 2.0 * (double)bp.frames * net->ops[k].tdnn.in_ch * net->ops[k].tdnn.out_ch * net->ops[k].tdnn.n_taps;
             if ((rc = prof.begin(K_TDNN, fl, (int)i))) return rc;
             static const int chain_dbg = getenv("ASV_AMD_CHAIN_DBG") != nullptr ? std::max(1, atoi(getenv("ASV_AMD_CHAIN_DBG"))) : 0;   // developer aid: phase durations to stderr
             DevMem dbg;
-            if (chain_dbg) {
+            if (chain_dbg && !chain_x3) {
               if ((rc = ensure(dbg, (size_t)(p.rows / 128) * 8 * 32 * 8, c.s, true))) return rc;
               cp.dbg = reinterpret_cast<unsigned long long *>(dbg.ptr);
               cp.dbg_fine = chain_dbg >= 3;
             }
-            if ((rc = launch_tdnn_chain(cp, c.s))) return rc;
+            if ((rc = chain_x3 ? launch_tdnn_chainx(cp, c.s) : launch_tdnn_chain(cp, c.s))) return rc;
             if ((rc = prof.end())) return rc;
-            if (chain_dbg) {
+            if (chain_dbg && !chain_x3) {
               const size_t nwg = (size_t)(p.rows / 128);
               std::vector<unsigned long long> h(nwg * 8 * 32);
               ASV_HIP_CHECK(hipStreamSynchronize(c.s));
@@ -1198,7 +1211,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
             po.skipped = true;
             const auto &q = po.pool;
             PoolFinishParams f;
-            f.partial = cp.pool_partial; f.ld_partial = cp.ld_partial; f.pool_slots = slots; f.lh_split = 1;
+            f.partial = cp.pool_partial; f.ld_partial = cp.ld_partial; f.pool_slots = slots; f.lh_split = 1; f.tile_shift = tshift;
             f.row_seg = dr.row_seg; f.rows = dr.rows_pad; f.seg_row0 = dr.seg_row0; f.seg_len = dr.seg_len;
             f.shift = lo.shift;
             f.out = reinterpret_cast<float *>(net->arena[q.out_buf].ptr) + q.out_ch_off; f.ld_out = net->bufs[q.out_buf].ld; f.channels = q.channels;
@@ -1285,7 +1298,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
           if (fuse) {
             const auto &q = po.pool;
             PoolFinishParams f;
-            f.partial = p.pool_partial; f.ld_partial = p.ld_partial; f.pool_slots = pool_slots; f.lh_split = 0;
+            f.partial = p.pool_partial; f.ld_partial = p.ld_partial; f.pool_slots = pool_slots; f.lh_split = 0; f.tile_shift = 7;
             f.row_seg = dr.row_seg; f.rows = dr.rows_pad; f.seg_row0 = dr.seg_row0; f.seg_len = dr.seg_len;
             f.shift = op.shift;
             f.out = reinterpret_cast<float *>(net->arena[q.out_buf].ptr) + q.out_ch_off; f.ld_out = net->bufs[q.out_buf].ld; f.channels = q.channels;
