@@ -89,7 +89,10 @@ __device__ __forceinline__ void chain_glds16_s(const void *sbase, uint32_t voff,
 //            packed f32 arithmetic (v_pk_add_f32 / v_pk_fma_f32).  ASV_AMD_CHAIN_POOLV selects at launch (A/B aid).
 // ABL (developer aid, ASV_AMD_CHAIN_ABL with ASV_AMD_LIVE_TUNE=1; results are garbage): 1 = the last layer without its pooling
 //        epilogue (what do the K loops cost on their own), 2 = the epilogue's arithmetic without its global loads / stores;
-//        3 (ASV_AMD_CHAIN_DBG >= 3; results valid) = the production kernel + stamps inside every wave's first pooling epilogue.
+//        3 (ASV_AMD_CHAIN_DBG >= 3; results valid) = the production kernel + stamps inside every wave's first pooling epilogue;
+//        4 (results valid) = the last layer in lockstep: a workgroup barrier behind every unit's K loop and behind every pooling
+//        epilogue, so that the two waves of a SIMD run their loops together (sharing the matrix pipe at its full rate) and their
+//        epilogues together (no matrix stream beside the packed f32 arithmetic, which otherwise only issues in its gaps).
 template <int POOLV, int ET = ET_BF16, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[CHAIN_LDS];
@@ -393,6 +396,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
     for (int cb = wave * 64; cb < L.cout_pad; cb += 512) {
       const unsigned char *wb = reinterpret_cast<const unsigned char *>(L.wfrag) + (size_t)(cb / 32) * frag_stride;
       yloop(wb, wb + frag_stride, L.bias + cb, TrYes{});
+      if constexpr (ABL == 4) __builtin_amdgcn_s_barrier();
       stamp();                             // 7, 9, 11: main loop of a unit done
       // Pooling epilogue, registers only.  acc[i][j][r] = channel cb + j*32 + lr, frame i*32 + 8 (r >> 2) + 4 lh + (r & 3): a
       // lane sums its own frames (those with bit 2 of the row index == lh) per utterance, about the pivot of its first
@@ -580,6 +584,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
         publish();
         if (first_unit) fine(5);
       }
+      if constexpr (ABL == 4) __builtin_amdgcn_s_barrier();
       stamp();                             // 8, 10, 12: pooling epilogue of the unit done
     }
     if (p.dbg != nullptr && lane == 0) p.dbg[((size_t)blockIdx.x * 8 + wave) * 32 + 15] = __builtin_amdgcn_s_memrealtime();
@@ -606,6 +611,7 @@ int launch_tdnn_chain(const TdnnChainParams &p, hipStream_t s) {
   else if (p.dbg != nullptr && p.dbg_fine) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_BF16, 3>), grid, block, 0, s, p);
   else if (abl == 1) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_BF16, 1>), grid, block, 0, s, p);
   else if (abl == 2) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_BF16, 2>), grid, block, 0, s, p);
+  else if (abl == 4 && p.last.cout_pad % 512 == 0) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_BF16, 4>), grid, block, 0, s, p);   // every wave runs the same number of units
   else if (poolv == 0) hipLaunchKernelGGL(tdnn_chain_kernel<0>, grid, block, 0, s, p);
   else hipLaunchKernelGGL(tdnn_chain_kernel<1>, grid, block, 0, s, p);
   ASV_HIP_CHECK(hipGetLastError());

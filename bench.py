@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL on the GPUs (default); gloo needs --dry-run")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU ranks, stand-in extractor: exercises self-launch, barriers, the double-buffered all-gather and the JSON line without a device")
-    ap.add_argument("--streams", type=int, default=None, choices=[1, 2],
+    ap.add_argument("--streams", type=int, default=None, choices=[1, 2, 3, 4],
                     help="2 = consecutive steps alternate between two engines (same weights, own activation arenas) on two HIP streams: the small "
                          "launches at the end of step i (pooling merge, pooled affine) overlap the wide GEMMs at the start of step i + 1 "
                          "(default for the x-vector workload: +4.7 %% measured, profiles/r3a_*; the roofline object and `value_single_stream` "
@@ -216,13 +216,17 @@ def main():
         args.batch = 640 if args.model == "xvector" else 256
 
     def measure(wl, steps, warmup, min_seconds, profile, collective, per_op=False, from_wav=False, wl2=None):
+        """wl2: None, or a list of further Workloads (same model, own engines): consecutive steps rotate over [wl] + wl2 on one HIP
+        stream each."""
         """settle -> warmup -> `repeats` timed regions of exactly `steps` steps (barrier + synchronize on both sides, MAX over
         ranks); returns the record of the median region."""
         eng, B = wl.eng, wl.B
-        # two output / gather buffer pairs: the all-gather of step i runs on RCCL's stream while step i+1 computes
-        outs = [torch.empty((B, eng.embed_dim), dtype=torch.float32, device=dev) for _ in range(2)]
-        gathered = [torch.empty((world * B, eng.embed_dim), dtype=torch.float32, device=dev) for _ in range(2)] if collective else None
-        pending, counter = [None, None], [0]
+        # two (or one per engine) output / gather buffer pairs: the all-gather of step i runs on RCCL's stream while step i+1 computes
+        engines = [wl] + list(wl2 or [])
+        nbuf = max(2, len(engines))
+        outs = [torch.empty((B, eng.embed_dim), dtype=torch.float32, device=dev) for _ in range(nbuf)]
+        gathered = [torch.empty((world * B, eng.embed_dim), dtype=torch.float32, device=dev) for _ in range(nbuf)] if collective else None
+        pending, counter = [None] * nbuf, [0]
         if from_wav:
             from libs.amd import frontend
             n_samp = 400 + (wl.T - 1) * 160                             # 25 ms windows, 10 ms shift at 16 kHz: exactly T frames
@@ -237,18 +241,18 @@ def main():
             else:
                 wl.extract(out)
 
-        side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)] if wl2 is not None else None
+        side = [torch.cuda.Stream(device=dev) for _ in engines] if wl2 else None
 
         def step():
-            k = counter[0] & 1
+            k = counter[0] % nbuf
             counter[0] += 1
             if side is not None:
-                # two engines, two streams: step i + 1 starts while the tail of step i is still running
+                # one engine per stream: step i + 1 starts while the tail of step i is still running
                 with torch.cuda.stream(side[k]):
                     if pending[k] is not None:                          # THIS stream waits until the gather that reads outs[k] has finished
                         pending[k].wait()
                         pending[k] = None
-                    (wl if k == 0 else wl2).extract(outs[k])
+                    engines[k].extract(outs[k])
                     if collective:
                         pending[k] = dist.all_gather_into_tensor(gathered[k], outs[k], async_op=True)
                 return
@@ -260,7 +264,7 @@ def main():
                 pending[k] = dist.all_gather_into_tensor(gathered[k], outs[k], async_op=True)
 
         def barrier():
-            for k in range(2):
+            for k in range(nbuf):
                 if pending[k] is not None:
                     pending[k].wait()
                     pending[k] = None
@@ -465,8 +469,8 @@ def main():
         lengths = tuple(int(v) for v in args.lengths.split(":")) if args.lengths else None
         wl = Workload(args, args.model, args.precision, args.batch, args.frames, rank, dev, lengths=lengths)
     if args.streams is None:
-        args.streams = 2 if (args.model == "xvector" and not dry and not args.from_wav and not args.per_op) else 1
-    wl2 = Workload(args, args.model, args.precision, args.batch, args.frames, rank, dev, lengths=lengths) if (args.streams == 2 and not dry) else None
+        args.streams = 2 if (not dry and not args.from_wav and not args.per_op and args.precision.split("-")[0] not in ("f32x", "f32")) else 1
+    wl2 = [Workload(args, args.model, args.precision, args.batch, args.frames, rank, dev, lengths=lengths) for _ in range(args.streams - 1)] if (args.streams >= 2 and not dry) else None
     head = measure(wl, args.steps, args.warmup, args.min_seconds, not args.no_profile and not dry and wl2 is None, world > 1, per_op=args.per_op, from_wav=args.from_wav, wl2=wl2)
     single = None
     if wl2 is not None:
@@ -495,7 +499,7 @@ def main():
         res["value_single_stream"] = single["value"]
         res["ms_per_step_single_stream"] = single["ms_per_step"]
     if wl2 is not None:
-        res["config"]["streams"] = "2 engines x 2 HIP streams, consecutive steps alternate (software pipelining across batches; every step is a full pass)"
+        res["config"]["streams"] = "%d engines on %d HIP streams, consecutive steps rotate over them (software pipelining across batches; every step is a full pass)" % (args.streams, args.streams)
     if dry:
         res["dry_run"] = True
         if "gather_verified" in head:
@@ -527,41 +531,58 @@ def main():
     if rank == 0 and world == 1 and not args.no_supplementary and args.model == "xvector" and not args.from_wav and not dry and not args.lengths:
         # ---- supplementary records, same harness (shorter: 0.4 s of timed regions each) --------------
         sup = {}
-        w256 = Workload(args, "xvector", args.precision, 256, args.frames, rank, dev)
-        r = measure(w256, args.steps, 2, 0.4, not args.no_profile, False)
-        res["value_at_b256"] = r["value"]
-        if "roofline" in r:
-            r["roofline"].pop("gemm_ms_per_step", None)
-            res["roofline_at_b256"] = {k: r["roofline"][k] for k in ("achieved", "peak", "unit", "frac", "avg_launch_us")}
-        res["config"]["configs1_batch_note"] = "BASELINE configs[1] names batch=256: value_at_b256 / roofline_at_b256 are that figure; `value` uses 640 utterances per step"
+        two = args.streams >= 2
+
+        def record(kind, prec, batch, frames, lens=None, steps=None, min_s=0.4, f32x_single=True):
+            """One sub-record: `value` as the headline is measured (two engines on two streams unless --streams 1; the f32x / f32
+            modes gain nothing from it - their steps are one long matrix-bound launch sequence - and run on one), the kernel
+            figures from a single-stream pass."""
+            steps = steps or args.steps
+            use_two = two and not (f32x_single and prec.split("-")[0] in ("f32x", "f32"))
+            w = Workload(args, kind, prec, batch, frames, rank, dev, lengths=lens)
+            w2 = [Workload(args, kind, prec, batch, frames, rank, dev, lengths=lens)] if use_two else None
+            r1 = measure(w, steps, 2, min_s, not args.no_profile, False)
+            r = measure(w, steps, 2, min_s, False, False, wl2=w2) if use_two else r1
+            rec = {"value": r["value"], "unit": "utterances/s", "ms_per_step": r["ms_per_step"], "streams": 2 if use_two else 1}
+            if use_two:
+                rec["value_single_stream"] = r1["value"]
+            if "roofline" in r1:
+                rec["gemm_tflops"] = r1["roofline"]["achieved"]
+                rec["frac"] = r1["roofline"]["frac"]
+                rec["mode_peak_tflops"] = r1["roofline"]["peak"]
+                rec["avg_launch_us"] = r1["roofline"]["avg_launch_us"]
+                rec["algorithmic_gflop_per_utt"] = r1["roofline"]["algorithmic_gflop_per_utt"]
+                rec["whole_step_tflops"] = round(rec["algorithmic_gflop_per_utt"] * r["value"] / 1e3, 1)
+            return rec, w
+
+        rec, w256 = record("xvector", args.precision, 256, args.frames)
+        res["value_at_b256"] = rec["value"]
+        if "value_single_stream" in rec:
+            res["value_at_b256_single_stream"] = rec["value_single_stream"]
+        if "frac" in rec:
+            res["roofline_at_b256"] = {"achieved": rec["gemm_tflops"], "peak": rec["mode_peak_tflops"], "unit": "TFLOP/s", "frac": rec["frac"], "avg_launch_us": rec["avg_launch_us"],
+                                       "whole_step_frac": round(rec["whole_step_tflops"] / rec["mode_peak_tflops"], 4)}
+        res["config"]["configs1_batch_note"] = ("BASELINE configs[1] names batch=256: value_at_b256 is that configuration (same harness; two streams fill the CUs the second, "
+                                                "59 %-full round of 128-row tiles leaves idle: +20 % over one stream); `value` uses 640 utterances per step - whole rounds of "
+                                                "workgroups - so that the kernel-level roofline is not a statement about tile quantisation")
         del w256
         for prec in ("f16", "f32x", "f32"):
             if prec == args.precision:
                 continue
-            w = Workload(args, "xvector", prec, args.batch, args.frames, rank, dev)
-            r = measure(w, args.steps, 2, 0.4, not args.no_profile, False)
-            rec = {"value": r["value"], "unit": "utterances/s", "ms_per_step": r["ms_per_step"], "parity": gates_of(w)}
-            if "roofline" in r:
-                rec["gemm_tflops"] = r["roofline"]["achieved"]
-                rec["frac_of_mode_peak"] = r["roofline"]["frac"]
-                rec["mode_peak_tflops"] = r["roofline"]["peak"]
+            rec, w = record("xvector", prec, args.batch, args.frames)
+            rec["parity"] = gates_of(w)
+            rec["frac_of_mode_peak"] = rec.get("frac")
             sup["xvector_" + prec] = rec
-            modes[prec] = {"value": r["value"], "gate_1e-4": rec["parity"]["gate_1e-4"], "eer_gate": rec["parity"].get("eer_gate")}
+            modes[prec] = {"value": rec["value"], "gate_1e-4": rec["parity"]["gate_1e-4"], "eer_gate": rec["parity"].get("eer_gate")}
             del w
         for kind, key, frames, prec, lens in (("ecapa", "ecapa_c3", 300, args.precision, None), ("ecapa", "ecapa_c3_f32x", 300, "f32x", None),
                                               ("resnet", "resnet_c5_t200", 200, args.precision, None), ("resnet", "resnet_c5", 600, args.precision, (200, 1000)),
                                               ("resnet", "resnet_c5_f32x", 600, "f32x", (200, 1000))):
             try:
-                w = Workload(args, kind, prec, 256, frames, rank, dev, lengths=lens)
-                r = measure(w, max(4, args.steps // 4), 2, 0.4, not args.no_profile, False)
+                rec, w = record(kind, prec, 256, frames, lens, steps=max(4, args.steps // 4), f32x_single=(kind == "resnet"))
                 shape = "%d frames" % frames if lens is None else "U[%d, %d] frames (packed ragged, %d frames in all)" % (lens[0], lens[1], w.frames_total)
-                rec = {"value": r["value"], "unit": "utterances/s", "ms_per_step": r["ms_per_step"], "frames_per_s": round(r["value"] * w.frames_total / w.B, 0),
-                       "workload": "%s: %s, 256 utterances x %s, %s" % (w.title, w.creation, shape, prec)}
-                if "roofline" in r:
-                    rec["gemm_tflops"] = r["roofline"]["achieved"]
-                    rec["frac"] = r["roofline"]["frac"]
-                    rec["algorithmic_gflop_per_utt"] = r["roofline"]["algorithmic_gflop_per_utt"]
-                    rec["whole_step_tflops"] = round(rec["algorithmic_gflop_per_utt"] * r["value"] / 1e3, 1)
+                rec["frames_per_s"] = round(rec["value"] * w.frames_total / w.B, 0)
+                rec["workload"] = "%s: %s, 256 utterances x %s, %s" % (w.title, w.creation, shape, prec)
                 sup[key] = rec
                 del w
             except Exception as e:                                        # a supplementary record must never take the headline down
