@@ -220,14 +220,7 @@ int launch_attentive_pool(const void *x, int ldx, const void *logits, int ldl, i
                           hipStream_t s);
 // row r of a segment is valid iff (r - row0) % pitch < width (frames domain: pitch = width = 1)
 int launch_rowmap(const int32_t *seg_row0, const int32_t *seg_len, int segments, int rows, int pitch, int width,
-                  int32_t *row_seg, uint32_t *row_valid, const int32_t *seg_src0, int32_t *row_src, hipStream_t s);   // row_src: frames domain only, or nullptr
-// the input layer straight from the caller's feature matrix (kernels_tdnn_in.hip)
-struct TdnnInputSource {
-  const float *feats; int feat_dim;      // [sum T][feat_dim] f32, as handed to asv_net_extract
-  const int32_t *row_src;                // [rows] row of `feats` behind every padded row, -1 = gap row
-};
-bool tdnn_input_supported(const TdnnKernelParams &p, int et);
-int launch_tdnn_input(const TdnnKernelParams &p, const TdnnInputSource &src, hipStream_t s);
+                  int32_t *row_seg, uint32_t *row_valid, hipStream_t s);
 // frames-domain feature rows [t][f] -> grid rows (t*pitch + f) with one channel (pitch of `out` = ldo)
 int launch_grid_from_frames(const void *x, int ldx, int feat_dim, const int32_t *fr_row0, const int32_t *g_row0, const int32_t *g_row_seg,
                             const uint32_t *g_row_valid, int g_rows, int pitch, void *out, int ldo, int et, hipStream_t s);

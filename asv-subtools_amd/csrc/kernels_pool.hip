@@ -10,8 +10,7 @@ namespace {
 // ---------------------------------------------------------------------------------------
 // row map: for every padded row, which segment it belongs to (-1: gap) + a validity bitmask
 __global__ __launch_bounds__(256) void rowmap_kernel(const int32_t *seg_row0, const int32_t *seg_len, int segments,
-                                                     int rows, int pitch, int width, int32_t *row_seg, uint32_t *row_valid,
-                                                     const int32_t *seg_src0, int32_t *row_src) {
+                                                     int rows, int pitch, int width, int32_t *row_seg, uint32_t *row_valid) {
   const int row = blockIdx.x * 256 + threadIdx.x;      // rows is a multiple of 128; grid covers it in 64-row waves
   int seg = -1;
   if (row < rows) {
@@ -22,9 +21,6 @@ __global__ __launch_bounds__(256) void rowmap_kernel(const int32_t *seg_row0, co
     }
     if (segments > 0 && seg_row0[lo] <= row && row < seg_row0[lo] + seg_len[lo] && (row - seg_row0[lo]) % pitch < width) seg = lo;
     row_seg[row] = seg;
-    // frames domain: the row of the caller's packed feature matrix this row holds (-1: gap row) - what the input-layer kernel
-    // (kernels_tdnn_in.hip) gathers through instead of reading a packed copy
-    if (row_src != nullptr) row_src[row] = seg >= 0 ? seg_src0[seg] + (row - seg_row0[seg]) : -1;
   }
   const unsigned long long b = __ballot(seg >= 0);
   if ((threadIdx.x & 63) == 0 && row < rows) {
@@ -685,8 +681,8 @@ int launch_im2col(const Im2colParams &p, int et, hipStream_t s) {
 }
 
 int launch_rowmap(const int32_t *seg_row0, const int32_t *seg_len, int segments, int rows, int pitch, int width, int32_t *row_seg,
-                  uint32_t *row_valid, const int32_t *seg_src0, int32_t *row_src, hipStream_t s) {
-  hipLaunchKernelGGL(rowmap_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, seg_row0, seg_len, segments, rows, pitch, width, row_seg, row_valid, seg_src0, row_src);
+                  uint32_t *row_valid, hipStream_t s) {
+  hipLaunchKernelGGL(rowmap_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, seg_row0, seg_len, segments, rows, pitch, width, row_seg, row_valid);
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }

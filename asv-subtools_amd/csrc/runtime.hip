@@ -158,7 +158,6 @@ struct asv_net {
   int device = 0, precision = 0, feat_dim = 0;
   unsigned flags = 0;
   bool finalized = false;
-  bool input_direct = false;       // every reader of buffer 0 is an input layer kernels_tdnn_in.hip takes: the packing pass is skipped
   int out_buf = -1, embed_dim = 0;
   std::vector<Buffer> bufs;
   std::vector<Domain> domains;
@@ -499,7 +498,7 @@ int asv_net_add_tdnn(asv_net_t *net, const asv_tdnn_desc_t *d) {
     // the v3 order (grid_conv_* precede big3 in the dispatch and accept every such layer), and each family has its own pointer
     const bool conv2d_pack = bf16 && net->domains[dom].kind == 2 && d->n_taps == 9 && (op.cin_pad == 32 || op.cin_pad == 64 || op.cin_pad == 128 || op.cin_pad == 256) &&
                              d->in_ch == op.cin_pad && d->out_ch == d->in_ch;
-    if (bf16 && !conv2d_pack && op.cout_store > 96 && (op.cin_pad >= 64 || (d->in_buf == 0 && op.cin_pad >= 32))) {         // candidates of the 256- / 128-channel tiles (kernels_tdnn_v3.hip)
+    if (bf16 && !conv2d_pack && op.cout_store > 96 && op.cin_pad >= 64) {         // candidates of the 256- / 128-channel tiles (kernels_tdnn_v3.hip)
       std::vector<uint16_t> frags(tdnn_weight_frag_elems(op.cout_pad, op.cin_pad, d->n_taps));
       pack_tdnn_weight_frags(d->weight, d->out_ch, d->in_ch, d->w_tot_context, d->w_left_context, d->taps, d->n_taps, op.cout_pad, op.cin_pad, frags.data(), nullptr, et);
       if ((rc = dev_upload(net, frags.data(), frags.size() * 2, &op.wfrag))) return rc;
@@ -861,29 +860,6 @@ int asv_net_finalize(asv_net_t *net, int out_buf, int embed_dim) {
     std::vector<float>().swap(o.host_w); std::vector<float>().swap(o.host_bias);
     std::vector<float>().swap(o.host_scale); std::vector<float>().swap(o.host_shift);
   }
-  {
-    // Does anything but input-layer TDNN ops (kernels_tdnn_in.hip: 16-bit modes, <= 96 input channels, plain epilogue) read the raw
-    // feature buffer?  If not, asv_net_extract skips the packing pass: those layers gather from the caller's matrix themselves.
-    bool any = false, all = net->frames_h16() && (net->flags & (ASV_FLAG_REF_KERNELS | ASV_FLAG_SMALL_TILES)) == 0;
-    for (const Op &o : net->ops) {
-      const int reads[] = {o.kind == OP_TDNN ? o.tdnn.in_buf : -1, o.kind == OP_TDNN ? o.tdnn.in2_buf : -1, o.kind == OP_TDNN ? o.tdnn.res_buf : -1,
-                           o.kind == OP_POOL ? o.pool.in_buf : -1, o.kind == OP_ATTPOOL ? o.att.x_buf : -1, o.kind == OP_ATTPOOL ? o.att.logit_buf : -1,
-                           o.kind == OP_ELTWISE ? o.elt.a_buf : -1, o.kind == OP_ELTWISE ? o.elt.b_buf : -1, o.kind == OP_ELTWISE ? o.elt.c_buf : -1,
-                           o.kind == OP_ELTWISE ? o.elt.d_buf : -1, o.kind == OP_IM2COL ? o.i2c.in_buf : -1, o.kind == OP_LDE ? o.lde.x_buf : -1,
-                           o.kind == OP_GRID_INPUT ? o.gin.in_buf : -1, o.kind == OP_RES2 ? o.res2.in_buf : -1};
-      bool reads0 = false;
-      for (int rb : reads) reads0 |= (rb == 0);
-      if (!reads0) continue;
-      any = true;
-      const auto &d = o.tdnn;
-      bool ok = o.kind == OP_TDNN && d.in_buf == 0 && d.in_ch_off == 0 && d.in2_buf != 0 && d.res_buf != 0 && !o.utts && o.wfrag != nullptr && o.cin_pad >= 32 &&
-                o.cin_pad <= 96 && o.cout_store >= 192 && d.in2_buf < 0 && d.seg_bias_buf < 0 && d.seg_scale_buf < 0 && d.res_buf < 0 && !d.affine_first &&
-                d.act2 == ASV_ACT_NONE && (d.act1 == ASV_ACT_NONE || d.act1 == ASV_ACT_RELU) && o.fused_pool < 0 && o.chain_last < 0;
-      for (int t = 0; ok && t < d.n_taps; ++t) ok = std::abs(d.taps[t]) <= kHalo;
-      all = all && ok;
-    }
-    net->input_direct = any && all;
-  }
   net->out_buf = out_buf; net->embed_dim = embed_dim; net->finalized = true;
   net->arena.resize(net->bufs.size());
   return ASV_OK;
@@ -1007,13 +983,11 @@ struct DomainRun {
   int rows_pad = 0;
   int32_t *seg_row0 = nullptr, *seg_len = nullptr, *row_seg = nullptr;
   uint32_t *row_valid = nullptr;
-  int32_t *row_src = nullptr;              // frames domain: source row in the caller's feature matrix per padded row (-1: gap)
 };
 
 struct RunCtx {
   asv_net *net; hipStream_t s; BatchPlan bp;
   float *final_out = nullptr;      // asv_net_extract: the caller's result matrix (lets the last layer write it directly)
-  const float *raw_feats = nullptr; // the caller's packed feature matrix (the input-layer kernel gathers from it directly)
   bool final_written = false;
   int32_t *seg_src0, *seg_frames, *utt_seg0, *utt_nseg;     // device metadata
   std::vector<DomainRun> dom;
@@ -1073,7 +1047,7 @@ int prepare(RunCtx &c, const int32_t *offsets, int n_utts, int max_chunk) {
     put(bp.dom[i].seg_row0, &c.dom[i].seg_row0);
     put(bp.dom[i].seg_len, &c.dom[i].seg_len);
     c.dom[i].rows_pad = bp.dom[i].rows_pad;
-    rm_words += (size_t)bp.dom[i].rows_pad + bp.dom[i].rows_pad / 32 + (net->domains[i].kind == ASV_DOMAIN_FRAMES ? (size_t)bp.dom[i].rows_pad : 0);
+    rm_words += (size_t)bp.dom[i].rows_pad + bp.dom[i].rows_pad / 32;
   }
   ASV_HIP_CHECK(hipMemcpyAsync(d, h, meta_bytes, hipMemcpyHostToDevice, c.s));
   ASV_HIP_CHECK(hipEventRecord(net->meta_copied, c.s));
@@ -1087,11 +1061,9 @@ int prepare(RunCtx &c, const int32_t *offsets, int n_utts, int max_chunk) {
     const Domain &dm = net->domains[i];
     c.dom[i].row_seg = r; r += c.dom[i].rows_pad;
     c.dom[i].row_valid = reinterpret_cast<uint32_t *>(r); r += c.dom[i].rows_pad / 32;
-    c.dom[i].row_src = nullptr;
-    if (dm.kind == ASV_DOMAIN_FRAMES) { c.dom[i].row_src = r; r += c.dom[i].rows_pad; }
     const int nseg = (int)bp.dom[i].seg_row0.size();
     if ((rc = launch_rowmap(c.dom[i].seg_row0, c.dom[i].seg_len, nseg, c.dom[i].rows_pad, dm.kind == 2 ? dm.pitch : 1, dm.kind == 2 ? dm.width : 1,
-                            c.dom[i].row_seg, c.dom[i].row_valid, c.seg_src0, c.dom[i].row_src, c.s))) return rc;
+                            c.dom[i].row_seg, c.dom[i].row_valid, c.s))) return rc;
   }
   if ((rc = prof.end())) return rc;
   // ---- activation arena
@@ -1263,8 +1235,6 @@ int run_ops(RunCtx &c, size_t n_ops) {
           pool_slots = worst;
           if (pool_slots > 16) pool_slots = 0;               // many tiny utterances: use the separate pooling kernel
         }
-        const bool in_kernel = !use_ref && narrow && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && d.in_buf == 0 && d.in_ch_off == 0 && domid == ASV_DOMAIN_FRAMES &&
-                               c.raw_feats != nullptr && op.fused_pool < 0 && tdnn_input_supported(p, et);
         const bool big3 = !use_ref && narrow && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && tdnn_big3_supported(p, et, !bf16);
         const bool utts_kernel = !use_ref && op.utts;
         const bool x3 = !use_ref && !op.utts && net->x3() && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && tdnn_x3_supported(p);
@@ -1310,10 +1280,6 @@ int run_ops(RunCtx &c, size_t n_ops) {
           // throughput modes; the exact f32-input MFMA in the parity modes - with IEEE-half operand halves in the frame layers
           // the bf16 split here would be the largest error left in the f32x mode (< 0.3 % of the FLOPs: +1 % of an f32x step)
           rc = launch_utts_gemm(p, bp.segments, net->frames_h16(), c.s);
-        }
-        else if (in_kernel) {
-          TdnnInputSource src{c.raw_feats, net->feat_dim, dr.row_src};
-          rc = launch_tdnn_input(p, src, c.s);
         }
         else if (narrow_conv) rc = launch_grid_conv_narrow(p, c.s);
         else if (wide_conv) rc = launch_grid_conv_wide(p, c.s);
@@ -1485,9 +1451,6 @@ int run_ops(RunCtx &c, size_t n_ops) {
 int pack_features(RunCtx &c, const float *feats) {
   Prof prof{c.net, c.s};
   int rc;
-  c.raw_feats = feats;
-  static const bool no_in = getenv("ASV_AMD_NO_INPUT_KERNEL") != nullptr && atoi(getenv("ASV_AMD_NO_INPUT_KERNEL")) != 0;
-  if (c.net->input_direct && !no_in) return ASV_OK;      // every reader of the feature buffer gathers from `feats` itself (kernels_tdnn_in.hip)
   const DomainRun &dr = c.dom[ASV_DOMAIN_FRAMES];
   if ((rc = prof.begin(K_PACK, 0))) return rc;
   if ((rc = launch_pack_input(feats, c.net->feat_dim, c.seg_src0, dr.seg_row0, dr.row_seg, dr.rows_pad, c.net->arena[0].ptr, c.net->bufs[0].ld,
