@@ -177,8 +177,12 @@ struct TdnnChainParams {
   unsigned long long *dbg;      // developer aid (ASV_AMD_CHAIN_DBG=1): [workgroup][wave][32] s_memtime stamps at the phase boundaries, or nullptr
   int dbg_fine;                 // ASV_AMD_CHAIN_DBG >= 3: also stamps inside the first pooling epilogue of every wave
   int et;                       // ET_BF16 / ET_F16: element type of the rows and of every layer's weight fragments
+  int min_seg_len;              // shortest utterance of the batch in frames (the 4-wave kernel needs >= 32: at most one seam per 32-frame fragment)
 };
 int launch_tdnn_chain(const TdnnChainParams &p, hipStream_t s);
+// the same chain as four waves of 512 registers, pooling arithmetic inside the next unit's K loop (kernels_tdnn_chain4.hip)
+bool tdnn_chain4_supported(const TdnnChainParams &p);
+int launch_tdnn_chain4(const TdnnChainParams &p, hipStream_t s);
 // the same chain with f32-grade split products and the tiles resident as hi / lo half images; 64-row tiles (kernels_tdnn_chainx.hip)
 int launch_tdnn_chainx(const TdnnChainParams &p, hipStream_t s);
 // ECAPA Res2NetBlock as one kernel (kernels_res2.hip)

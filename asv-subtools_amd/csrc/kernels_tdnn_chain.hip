@@ -606,6 +606,11 @@ int launch_tdnn_chain(const TdnnChainParams &p, hipStream_t s) {
   auto read_int = [](const char *name) { const char *v = getenv(name); return v != nullptr ? atoi(v) : -1; };
   static const int poolv0 = read_int("ASV_AMD_CHAIN_POOLV"), abl0 = read_int("ASV_AMD_CHAIN_ABL");
   const int poolv = live ? read_int("ASV_AMD_CHAIN_POOLV") : poolv0, abl = live ? read_int("ASV_AMD_CHAIN_ABL") : abl0;
+  // ASV_AMD_CHAIN_WAVES=4: the 4-wave form (kernels_tdnn_chain4.hip) where it applies.  Measured 0 - 1 % SLOWER than this kernel
+  // (profiles/r3k_*): kept as the reproducible A/B of that design, not used by default.
+  static const int waves0 = read_int("ASV_AMD_CHAIN_WAVES");
+  const int waves = live ? read_int("ASV_AMD_CHAIN_WAVES") : waves0;
+  if (waves == 4 && abl <= 0 && poolv != 0 && !(p.dbg != nullptr && p.dbg_fine) && tdnn_chain4_supported(p)) return launch_tdnn_chain4(p, s);
   const dim3 grid(p.rows / CM), block(512);
   if (p.et == ET_F16) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_F16>), grid, block, 0, s, p);
   else if (p.dbg != nullptr && p.dbg_fine) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_BF16, 3>), grid, block, 0, s, p);

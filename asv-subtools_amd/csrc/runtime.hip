@@ -1123,7 +1123,8 @@ int run_ops(RunCtx &c, size_t n_ops) {
           const DomainPlan &fp = bp.dom[ASV_DOMAIN_FRAMES];
           const int tshift = chain_x3 ? 6 : 7;         // rows per pooling partial: the kernel's tile
           std::vector<int> per_half(((size_t)fp.rows_pad >> tshift) + 1, 0);
-          int slots = 1;
+          int slots = 1, min_len = 1 << 30;
+          for (size_t sidx = 0; sidx < fp.seg_len.size(); ++sidx) min_len = std::min(min_len, (int)fp.seg_len[sidx]);
           for (size_t sidx = 0; sidx < fp.seg_row0.size(); ++sidx)
             for (int h = fp.seg_row0[sidx] >> tshift; h <= (fp.seg_row0[sidx] + fp.seg_len[sidx] - 1) >> tshift; ++h) slots = std::max(slots, ++per_half[h]);
           if (slots <= 16) {
@@ -1151,6 +1152,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
             cp.last = layer_of(l);
             cp.pool_slots = slots; cp.ld_partial = lo.cout_pad; cp.row_seg = dr.row_seg;
             cp.et = chain_x3 ? net->x3_et() : et;
+            cp.min_seg_len = min_len;
             if ((rc = ensure(net->poolpart_dev, (size_t)(p.rows >> tshift) * slots * 2 * 3 * cp.ld_partial * 4, c.s, false))) return rc;
             cp.pool_partial = reinterpret_cast<float *>(net->poolpart_dev.ptr);
             double fl = 0.0;
@@ -1175,23 +1177,38 @@ int run_ops(RunCtx &c, size_t n_ops) {
               for (size_t w = 0; w < nwg * 8; ++w) {
                 const unsigned long long *t = &h[w * 32];
                 if (t[0] == 0) continue;
-                for (int k = 1; k < 13; ++k) if (t[k] > t[k - 1]) sum[k] += (double)(t[k] - t[k - 1]);
+                for (int k = 1; k < 14; ++k) if (t[k] > t[k - 1]) sum[k] += (double)(t[k] - t[k - 1]);      // 13: the 4-wave kernel's drain
                 if (chain_dbg >= 3) {
                   if (t[16] > t[7]) sum[16] += (double)(t[16] - t[7]);                                   // unit's K loop end -> epilogue body
                   for (int k = 17; k < 22; ++k) if (t[k] > t[k - 1]) sum[k] += (double)(t[k] - t[k - 1]);
                 }
-                if (t[12] > t[0] && t[15] > t[14]) { cyc += (double)(t[12] - t[0]); rt += (double)(t[15] - t[14]); }
+                const unsigned long long t_end = t[13] > t[12] ? t[13] : t[12];
+                if (t_end > t[0] && t[15] > t[14]) { cyc += (double)(t_end - t[0]); rt += (double)(t[15] - t[14]); }
                 ++cnt;
               }
               fprintf(stderr, "[chain dbg] %zu waves, mean cycles per phase:", cnt);
               fprintf(stderr, " [shader clock %.0f MHz, %.1f us per workgroup]", rt > 0 ? 100.0 * cyc / rt : 0.0, cnt ? rt / 100.0 / (double)cnt : 0.0);
-              for (int k = 1; k < 13; ++k) fprintf(stderr, " %d:%.0f", k, sum[k] / (double)std::max<size_t>(cnt, 1));
+              for (int k = 1; k < 14; ++k) if (k < 13 || sum[k] > 0) fprintf(stderr, " %d:%.0f", k, sum[k] / (double)std::max<size_t>(cnt, 1));
               if (chain_dbg >= 3) {
                 fprintf(stderr, " | first epilogue: entry %.0f, fragments", sum[16] / (double)std::max<size_t>(cnt, 1));
                 for (int k = 17; k < 21; ++k) fprintf(stderr, " %.0f", sum[k] / (double)std::max<size_t>(cnt, 1));
                 fprintf(stderr, ", publish %.0f", sum[21] / (double)std::max<size_t>(cnt, 1));
               }
               fprintf(stderr, "\n");
+              {                                                       // 4-wave kernel, ablation 8: fine stamps of wave 0's third unit (slots of wave 4..7)
+                double fs[25] = {0}; size_t fc = 0;
+                for (size_t wg = 0; wg < nwg; ++wg) {
+                  const unsigned long long *t = &h[(wg * 8 + 4) * 32];
+                  if (t[0] == 0 || t[24] <= t[0]) continue;
+                  for (int k = 1; k < 25; ++k) fs[k] += (double)(t[k] - t[k - 1]);
+                  ++fc;
+                }
+                if (fc) {
+                  fprintf(stderr, "[chain dbg] third unit of wave 0, %zu workgroups, per chunk: pre | 32 matrix instructions | post:", fc);
+                  for (int c = 0; c < 8; ++c) fprintf(stderr, "  %.0f | %.0f | %.0f", fs[3 * c + 1] / fc, fs[3 * c + 2] / fc, fs[3 * c + 3] / fc);
+                  fprintf(stderr, "\n");
+                }
+              }
               if (chain_dbg == 2 || chain_dbg >= 4) {                 // raw timelines of two workgroups: waves w and w + 4 share a SIMD
                 const size_t picks[2] = {nwg / 4, nwg / 2 + 1};
                 for (size_t wg : picks) {

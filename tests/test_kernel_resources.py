@@ -1,0 +1,45 @@
+"""Build-time properties of the hand-allocated kernel (no GPU needed: hipcc cross-compiles gfx950).
+
+kernels_tdnn_chain4.hip keeps its 256 accumulator registers in AGPRs that the COMPILER does not know about (every access is inline
+assembly naming the registers).  That is only sound while hipcc itself puts nothing there: no spills (it parks spilled VGPRs in
+free AGPRs first) and no AGPR operand outside the assembly blocks."""
+import os
+import re
+import subprocess
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(REPO, "asv-subtools_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_chain4_kernel_has_no_spills_and_no_compiler_owned_agprs(tmp_path):
+    out = tmp_path / "chain4.s"
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(REPO, "include"), "-I" + CSRC, "-Xclang", "-target-feature", "-Xclang",
+           "-packed-fp32-ops", "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o", str(out), os.path.join(CSRC, "kernels_tdnn_chain4.hip")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    kernels = re.findall(r"Function Name: (\S+)", r.stderr)
+    spills = [int(x) for x in re.findall(r"VGPRs Spill: (\d+)", r.stderr)]
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
+    agprs = [int(x) for x in re.findall(r"AGPRs: (\d+)", r.stderr)]
+    assert len(kernels) >= 2 and len(spills) == len(kernels)
+    assert all(s == 0 for s in spills) and all(s == 0 for s in scratch), (spills, scratch)
+    assert all(a == 256 for a in agprs), agprs                   # the kernel descriptor covers the whole accumulator file
+    in_asm, bad, n_mfma = False, [], 0
+    for line in out.read_text().splitlines():
+        if "#ASMSTART" in line:
+            in_asm = True
+            continue
+        if "#ASMEND" in line:
+            in_asm = False
+            continue
+        code = line.split(";")[0]
+        if "v_mfma" in code:
+            n_mfma += 1
+        if not in_asm and re.search(r"\ba\[?\d", code) and re.match(r"\s+[a-z]", code):
+            bad.append(line.strip())
+    assert n_mfma > 1000
+    assert not bad, bad[:5]

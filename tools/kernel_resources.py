@@ -5,7 +5,7 @@ import re, subprocess, sys, os
 csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "asv-subtools_amd", "csrc")
 unit = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
-extra = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"] if unit in ("kernels_tdnn_x3",) else []
+extra = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"] if unit in ("kernels_tdnn_x3", "kernels_tdnn_chainx", "kernels_tdnn_chain4") else []
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(csrc, "..", "..", "include"), "-I" + csrc] + extra + \
       ["-c", os.path.join(csrc, unit + ".hip"), "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
