@@ -149,7 +149,9 @@ int launch_tdnn_ref(const TdnnKernelParams &p, int et, bool out_f32, hipStream_t
 int launch_utts_gemm(const TdnnKernelParams &p, int rows_valid, bool split, hipStream_t s);
 // kernels_conv2d.hip: 3x3 grid convolutions with 32 / 64 channels (weights in p.wfrag, [tap][k-group][n-frag][lane][8])
 bool grid_conv_narrow_supported(const TdnnKernelParams &p, int et);
-size_t grid_conv_frag_elems(int cin_pad, int cout_pad32);
+size_t grid_conv_frag_elems(int cin_pad, int cout_pad32, int n_taps = 9);
+bool grid_conv_s2d_supported(const TdnnKernelParams &p, int et);      // 128 (4 phases x 32) -> 64 channels, 4 backward taps
+int launch_grid_conv_s2d(const TdnnKernelParams &p, hipStream_t s);
 int launch_grid_conv_narrow(const TdnnKernelParams &p, hipStream_t s);
 bool grid_conv_wide_supported(const TdnnKernelParams &p, int et);      // the C = 128 / 256 stages (same fragment order)
 int launch_grid_conv_wide(const TdnnKernelParams &p, hipStream_t s);

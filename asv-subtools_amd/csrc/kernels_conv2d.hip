@@ -309,6 +309,116 @@ __global__ __launch_bounds__(256, 2) void grid_conv_wide_kernel(const TdnnKernel
     }
 }
 
+// The stride-2 3x3 convolution that opens the C = 64 stage (32 -> 64 channels, resnet.py:352-368 through BasicBlock's conv1) in its
+// "space to depth" form (pytorch/libs/nnet/resnet.py emit_conv_bn): the four phases of the input grid side by side = 128 input
+// channels on the OUTPUT grid, 4 taps {-(pitch' + 1), -pitch', -1, 0}, 64 output channels.  (As im2col + 1-tap GEMM this layer cost
+// 342 + 231 us of a 6.6 ms step; on the generic 128 x 128 tile its 4-tap form ran at 87 TFLOP/s.)  The wide kernel's scheme with
+// the geometry this layer needs: all taps look BACK, so the 304-row window is 48 rows of halo + 256 output rows; a wave owns 64
+// rows x all 64 channels (2 x 2 accumulators).  Weights [tap][k-group][2 n-fragments][lane][8]; K order = chunk outermost, taps
+// inside, as the generic tile: bit-identical to it.
+constexpr int S2D_HLO = 48, S2D_BM = 256, S2D_WIN = S2D_BM + S2D_HLO, S2D_ROWB = 256, S2D_KG = 8, S2D_NT = 4;
+template <bool GENERIC, int ET = ET_BF16>
+__global__ __launch_bounds__(256, 2) void grid_conv_s2d_kernel(const TdnnKernelParams p) {
+  constexpr int SLOTS = S2D_ROWB / 16, RPP = 1024 / S2D_ROWB, PIECES = S2D_WIN / RPP, STEPS = S2D_NT * S2D_KG / 4;
+  static_assert(S2D_WIN % RPP == 0 && S2D_WIN * S2D_ROWB <= 81920, "s2d grid conv geometry");
+  __shared__ __attribute__((aligned(16))) unsigned char win[S2D_WIN * S2D_ROWB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+  const int m0 = xcd_swizzle(blockIdx.x, gridDim.x) * S2D_BM;
+
+  const unsigned char *xg = reinterpret_cast<const unsigned char *>(p.x);
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_byte_t *)win);
+  for (int piece = wave; piece < PIECES; piece += 4) {
+    const int w = piece * RPP + lane / SLOTS;
+    const int row = min(max(m0 - S2D_HLO + w, 0), p.rows - 1);
+    const int src_slot = (lane % SLOTS) ^ (w & 15);
+    conv_glds16(xg + (size_t)row * ((size_t)p.ldx * 2) + src_slot * 16, __builtin_amdgcn_readfirstlane(lds_base + piece * 1024));
+  }
+  const int v_taps = p.taps[lane < S2D_NT ? lane : 0];
+  const unsigned char *wbase = reinterpret_cast<const unsigned char *>(p.wconv) + (size_t)lane * 16;
+  auto frag_ptr = [&](int t, int kg, int j) { return wbase + ((size_t)(t * S2D_KG + kg) * 2 + j) * 1024; };
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  struct XF { uint4 x[2]; };
+  auto read_x1 = [&](int d, int kg_abs, int i, XF &f) {
+    const int w = S2D_HLO + wave * 64 + i * 32 + lr + d;
+    f.x[i] = *reinterpret_cast<const uint4 *>(win + w * S2D_ROWB + (((kg_abs * 2 + lh) ^ (w & 15)) << 4));
+  };
+  uint4 wf[4][2];
+#pragma unroll
+  for (int kg = 0; kg < 4; ++kg) {
+    wf[kg][0] = *reinterpret_cast<const uint4 *>(frag_ptr(0, kg, 0));
+    wf[kg][1] = *reinterpret_cast<const uint4 *>(frag_ptr(0, kg, 1));
+  }
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");              // the window pieces are older than the 8 fragment loads
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  XF x0, x1;
+  {
+    const int d0 = __builtin_amdgcn_readlane(v_taps, 0);
+    read_x1(d0, 0, 0, x0);
+    read_x1(d0, 0, 1, x0);
+  }
+#pragma unroll 1
+  for (int st = 0; st < STEPS; ++st) {
+    const int c4 = st / S2D_NT, t = st % S2D_NT;
+    const int stn = st + 1 < STEPS ? st + 1 : st;                  // the last step re-fetches its own fragments (never used)
+    const int c4n = stn / S2D_NT, tn = stn % S2D_NT;
+    const int d = __builtin_amdgcn_readlane(v_taps, t), dn = __builtin_amdgcn_readlane(v_taps, tn);
+    auto group = [&](const XF &xc, int kg, XF &xn, int d_next, int kg_abs_next) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        read_x1(d_next, kg_abs_next, j, xn);
+        acc[0][j] = mfma16<ET>(wf[kg][j], xc.x[0], acc[0][j]);
+        acc[1][j] = mfma16<ET>(wf[kg][j], xc.x[1], acc[1][j]);
+        wf[kg][j] = *reinterpret_cast<const uint4 *>(frag_ptr(tn, c4n * 4 + kg, j));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    group(x0, 0, x1, d, c4 * 4 + 1);
+    group(x1, 1, x0, d, c4 * 4 + 2);
+    group(x0, 2, x1, d, c4 * 4 + 3);
+    group(x1, 3, x0, dn, c4n * 4);
+  }
+
+  // ---- epilogue: acc[i][j][r] = row m0 + wave*64 + i*32 + lr, channel j*32 + 8*(r>>2) + 4*lh + (r&3): 8-byte stores
+  const float act_lo = (p.act1 == ASV_ACT_RELU) ? 0.0f : -INFINITY;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ch = j * 32 + 8 * q + 4 * lh;
+      const float4 b4 = *reinterpret_cast<const float4 *>(p.bias + ch);
+      const float4 sc4 = p.scale ? *reinterpret_cast<const float4 *>(p.scale + ch) : make_float4(1.f, 1.f, 1.f, 1.f);
+      const float4 sh4 = p.shift ? *reinterpret_cast<const float4 *>(p.shift + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float b[4] = {b4.x, b4.y, b4.z, b4.w}, sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = m0 + wave * 64 + i * 32 + lr;
+        const bool valid = (p.row_valid[row >> 5] >> (row & 31)) & 1u;
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if constexpr (GENERIC) y[e] = tdnn_epilogue<true>(p, acc[i][j][q * 4 + e], row, ch + e, b[e], sc[e], sh[e], valid);
+          else y[e] = tdnn_epilogue_fast(acc[i][j][q * 4 + e], b[e], act_lo, sc[e], sh[e], valid);
+        }
+        uint2 pk;
+        pk.x = pack_h16x2<ET>(y[0], y[1]);
+        pk.y = pack_h16x2<ET>(y[2], y[3]);
+        *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(p.y) + (size_t)row * p.ldy + ch) = pk;
+      }
+    }
+}
+
 // The first convolution of the trunk: ONE input channel (the fbank map itself), 3x3, 32 output channels
 // (resnet.py:96-99).  9 multiply-adds per output - nothing for a matrix core: f32 fma in tap order (bit-identical to the
 // MFMA path, whose other 15 k-lanes are zeros).  A workgroup owns C1_SPAN consecutive rows: their inputs (the span plus
@@ -405,7 +515,7 @@ bool grid_conv_narrow_supported(const TdnnKernelParams &p, int et) {
 }
 
 // elements of the fragment-ordered weight copy for this kernel
-size_t grid_conv_frag_elems(int cin_pad, int cout_pad32) { return (size_t)9 * (cin_pad / 16) * (cout_pad32 / 32) * 512; }
+size_t grid_conv_frag_elems(int cin_pad, int cout_pad32, int n_taps) { return (size_t)n_taps * (cin_pad / 16) * (cout_pad32 / 32) * 512; }
 
 int launch_grid_conv_narrow(const TdnnKernelParams &p, hipStream_t s) {
   ASV_REQUIRE(grid_conv_narrow_supported(p, true), "grid conv (narrow): unsupported layer");
@@ -446,6 +556,26 @@ int launch_grid_conv_wide(const TdnnKernelParams &p, hipStream_t s) {
     if (fast) ASV_CONV_ET(grid_conv_wide_kernel<256, false);
     else ASV_CONV_ET(grid_conv_wide_kernel<256, true);
   }
+  ASV_HIP_CHECK(hipGetLastError());
+  return ASV_OK;
+}
+
+// the 32 -> 64 stride-2 convolution in space-to-depth form: 128 input channels, 4 backward taps, 64 output channels
+bool grid_conv_s2d_supported(const TdnnKernelParams &p, int et) {
+  if (et == ET_F32 || p.n_taps != S2D_NT || p.x2 != nullptr || p.wconv == nullptr) return false;
+  if (p.cin_pad != 128 || p.cout_store != 64) return false;
+  for (int t = 0; t < p.n_taps; ++t) if (p.taps[t] > 0 || p.taps[t] < -S2D_HLO) return false;
+  if (p.rows % S2D_BM != 0 || p.ldx % 8 != 0 || p.ldy % 4 != 0) return false;
+  return true;
+}
+
+int launch_grid_conv_s2d(const TdnnKernelParams &p, hipStream_t s) {
+  ASV_REQUIRE(grid_conv_s2d_supported(p, true), "grid conv (space to depth): unsupported layer");
+  const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first && p.seg_bias == nullptr &&
+                    p.seg_scale == nullptr && p.res == nullptr;
+  const dim3 grid(p.rows / S2D_BM), block(256);
+  if (fast) ASV_CONV_ET(grid_conv_s2d_kernel<false);
+  else ASV_CONV_ET(grid_conv_s2d_kernel<true);
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }

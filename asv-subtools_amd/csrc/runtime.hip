@@ -496,8 +496,10 @@ int asv_net_add_tdnn(asv_net_t *net, const asv_tdnn_desc_t *d) {
     if ((rc = dev_upload(net, packed.data(), packed.size(), &op.w))) return rc;
     // the two fragment orders are mutually exclusive per layer: a 3x3 trunk convolution the conv2d kernels take never needs
     // the v3 order (grid_conv_* precede big3 in the dispatch and accept every such layer), and each family has its own pointer
-    const bool conv2d_pack = bf16 && net->domains[dom].kind == 2 && d->n_taps == 9 && (op.cin_pad == 32 || op.cin_pad == 64 || op.cin_pad == 128 || op.cin_pad == 256) &&
-                             d->in_ch == op.cin_pad && d->out_ch == d->in_ch;
+    // (+ the 32 -> 64 stride-2 convolution in space-to-depth form: 4 x 32 input channels, 4 taps, 64 output channels)
+    const bool s2d_pack = bf16 && net->domains[dom].kind == 2 && d->n_taps == 4 && op.cin_pad == 128 && d->in_ch == 128 && d->out_ch == 64;
+    const bool conv2d_pack = s2d_pack || (bf16 && net->domains[dom].kind == 2 && d->n_taps == 9 && (op.cin_pad == 32 || op.cin_pad == 64 || op.cin_pad == 128 || op.cin_pad == 256) &&
+                             d->in_ch == op.cin_pad && d->out_ch == d->in_ch);
     if (bf16 && !conv2d_pack && op.cout_store > 96 && op.cin_pad >= 64) {         // candidates of the 256- / 128-channel tiles (kernels_tdnn_v3.hip)
       std::vector<uint16_t> frags(tdnn_weight_frag_elems(op.cout_pad, op.cin_pad, d->n_taps));
       pack_tdnn_weight_frags(d->weight, d->out_ch, d->in_ch, d->w_tot_context, d->w_left_context, d->taps, d->n_taps, op.cout_pad, op.cin_pad, frags.data(), nullptr, et);
@@ -516,9 +518,9 @@ int asv_net_add_tdnn(asv_net_t *net, const asv_tdnn_desc_t *d) {
     if (conv2d_pack) {
       // 3x3 trunk convolutions with 32 / 64 channels: fragment order of kernels_conv2d.hip,
       // [tap][k-group][n-fragment][lane = (k half lh, channel lr)][8], k = kg * 16 + lh * 8 + e
-      const int kgs = op.cin_pad / 16, nfs = op.cin_pad / 32;
-      std::vector<uint16_t> frags(grid_conv_frag_elems(op.cin_pad, op.cin_pad), 0);
-      for (int t = 0; t < 9; ++t) {
+      const int kgs = op.cin_pad / 16, nfs = (d->out_ch + 31) / 32;
+      std::vector<uint16_t> frags(grid_conv_frag_elems(op.cin_pad, nfs * 32, d->n_taps), 0);
+      for (int t = 0; t < d->n_taps; ++t) {
         const int k = d->taps[t] - d->w_left_context;
         for (int co = 0; co < d->out_ch; ++co)
           for (int ci = 0; ci < d->in_ch; ++ci) {
@@ -1258,6 +1260,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         const bool c1_conv = !use_ref && net->domains[domid].kind == 2 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && grid_conv_c1_supported(p, et, d.in_ch);
         const bool narrow_conv = !use_ref && net->domains[domid].kind == 2 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && grid_conv_narrow_supported(p, et);
         const bool wide_conv = !use_ref && net->domains[domid].kind == 2 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && grid_conv_wide_supported(p, et);
+        const bool s2d_conv = !use_ref && net->domains[domid].kind == 2 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && grid_conv_s2d_supported(p, et);
         if (!use_ref && !big3 && op.utts && !utts_kernel) {
           // pooled-domain layers have one row per utterance (M is tiny, K is large): slice K over more
           // workgroups.  The slice count depends on K only, never on the batch, so an utterance's
@@ -1300,6 +1303,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         }
         else if (narrow_conv) rc = launch_grid_conv_narrow(p, c.s);
         else if (wide_conv) rc = launch_grid_conv_wide(p, c.s);
+        else if (s2d_conv) rc = launch_grid_conv_s2d(p, c.s);
         else if (c1_conv) rc = launch_grid_conv_c1(p, c.s);
         else if (x3) rc = launch_tdnn_x3(p, c.s);
         else if (big3) rc = launch_tdnn_big3(p, c.s);

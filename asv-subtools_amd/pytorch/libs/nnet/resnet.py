@@ -44,9 +44,10 @@ def _folded_bn(bn):
 # Stride-2 convolutions with this many input channels are lowered as space-to-depth gather + 2 x 2 convolution on the output
 # grid (see emit_conv_bn).  Measured on the ResNet34 trunk (r2n, 256 x 200 frames): 64 -> 128: gather 181 + 22 -> 84 us, convolution
 # 97 -> 123 us (its 256 -> 128 4-tap form runs on the generic 128 x 128 tile): -93 us; 32 -> 64: gather 344 + 46 -> 157 us but
-# the 128 -> 64 4-tap form falls to 87 TFLOP/s on that tile (233 -> 436 us): not taken; 128 -> 256: the 512-channel form would
-# not beat im2col + the 256-channel tiles: not taken.
-S2D_CIN = (64,)
+# the 128 -> 64 4-tap form falls to 87 TFLOP/s on that tile (233 -> 436 us): taken since round 3, with a kernel of its own for that
+# form (kernels_conv2d.hip grid_conv_s2d_kernel; profiles/r3l_*); 128 -> 256: the 512-channel form would not beat im2col + the
+# 256-channel tiles: not taken.
+S2D_CIN = (32, 64)
 
 
 def s2d_kernel(w, pitch_out):

@@ -146,10 +146,10 @@ def test_resnet_traced_program_reproduces_reference_on_cpu(name, idx):
     from libs.amd import ir
     g, sd, model = helpers.golden_model(name)
     graph = ir.trace(model, type(model).extract_embedding.__wrapped_body__, int(g["dim"]))
-    # the 64 -> 128 transition: one space-to-depth gather feeds the strided 3x3 and the strided 1x1 shortcut; the other two: im2col
-    # of all taps + 1x1 gather (the pre-activation block feeds its two strided convolutions from different tensors: no sharing)
+    # the 32 -> 64 and 64 -> 128 transitions: one space-to-depth gather feeds the strided 3x3 and the strided 1x1 shortcut; 128 -> 256:
+    # im2col of all taps + 1x1 gather (the pre-activation block feeds its two strided convolutions from different tensors: no sharing)
     if "bottleneck" not in name:
-        assert sum(1 for op in graph.ops if op.kind == "im2col") == (6 if "preact" in name else 5)
+        assert sum(1 for op in graph.ops if op.kind == "im2col") == (6 if "preact" in name else 4)
     if name == "resnet34_cmvn":
         assert [op.kind for op in graph.ops[:3]] == ["pool", "eltwise", "grid_input"]   # InputSequenceNormalization
     per_frame, _ = graph.flops_per_frame()
