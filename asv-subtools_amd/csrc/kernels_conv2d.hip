@@ -15,6 +15,8 @@
 // LDS rows are C * 2 bytes; 16-byte slot s of window row w sits at s ^ ((w >> 2) & 3) (64-byte rows) or
 // s ^ ((w >> 1) & 7) (128-byte rows): conflict-free ds_read_b128 for any tap shift; the DMA applies the same
 // permutation on the source side.
+#include <cstdlib>
+
 #include "device_utils.h"
 
 namespace asv {
@@ -68,6 +70,9 @@ __global__ __launch_bounds__(256, CIN == 32 ? 3 : 2) void grid_conv_narrow_kerne
   }
   const int v_taps = p.taps[lane < 9 ? lane : 0];
   const uint4 *wf = reinterpret_cast<const uint4 *>(p.wconv) + lane;            // fragment f at wf[f * 64]
+  // developer aid (ASV_AMD_CONV_ABL with ASV_AMD_LIVE_TUNE=1; results are garbage): bit 0 = no output stores, bit 1 = one tap
+  // instead of nine (the window is still fetched whole)
+  const int abl = p.tune;
 
   f32x16_t acc[2][NF];
 #pragma unroll
@@ -95,6 +100,7 @@ __global__ __launch_bounds__(256, CIN == 32 ? 3 : 2) void grid_conv_narrow_kerne
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
+      if ((abl & 2) && t > 0) break;
       const int d = __builtin_amdgcn_readlane(v_taps, t);
 #pragma unroll
       for (int kg = 0; kg < KG; ++kg)
@@ -165,7 +171,7 @@ __global__ __launch_bounds__(256, CIN == 32 ? 3 : 2) void grid_conv_narrow_kerne
         uint2 pk;
         pk.x = pack_h16x2<ET>(y[0], y[1]);
         pk.y = pack_h16x2<ET>(y[2], y[3]);
-        *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(p.y) + (size_t)row * p.ldy + ch) = pk;
+        if (!(abl & 1) || pk.x == 0x12345678u) *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(p.y) + (size_t)row * p.ldy + ch) = pk;
       }
   }
 }
@@ -517,7 +523,10 @@ bool grid_conv_narrow_supported(const TdnnKernelParams &p, int et) {
 // elements of the fragment-ordered weight copy for this kernel
 size_t grid_conv_frag_elems(int cin_pad, int cout_pad32, int n_taps) { return (size_t)n_taps * (cin_pad / 16) * (cout_pad32 / 32) * 512; }
 
-int launch_grid_conv_narrow(const TdnnKernelParams &p, hipStream_t s) {
+int launch_grid_conv_narrow(const TdnnKernelParams &p0, hipStream_t s) {
+  TdnnKernelParams p = p0;
+  static const bool live = getenv("ASV_AMD_LIVE_TUNE") != nullptr;
+  p.tune = live && getenv("ASV_AMD_CONV_ABL") != nullptr ? atoi(getenv("ASV_AMD_CONV_ABL")) : 0;
   ASV_REQUIRE(grid_conv_narrow_supported(p, true), "grid conv (narrow): unsupported layer");
   const dim3 grid(p.rows / CBM), block(256);
   const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first && p.seg_bias == nullptr &&

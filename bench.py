@@ -215,6 +215,8 @@ def main():
     if args.batch is None:
         args.batch = 640 if args.model == "xvector" else 256
 
+    SIDE_STREAMS = []
+
     def measure(wl, steps, warmup, min_seconds, profile, collective, per_op=False, from_wav=False, wl2=None):
         """wl2: None, or a list of further Workloads (same model, own engines): consecutive steps rotate over [wl] + wl2 on one HIP
         stream each."""
@@ -241,7 +243,16 @@ def main():
             else:
                 wl.extract(out)
 
-        side = [torch.cuda.Stream(device=dev) for _ in engines] if wl2 else None
+        # One set of side streams per process, reused by every two-stream measurement.  Measured (profiles/r3q_b256_streams.txt): the
+        # first pair of torch pool streams a process uses runs its kernels side by side; a SECOND pair taken later (what every
+        # supplementary record did until round 3's last build) does not - 750 k instead of 931 k utt/s for the 256-utterance
+        # record, below its own single-stream figure.  BENCH_NEW_STREAMS=1 restores a fresh pair per measurement (A/B aid).
+        if wl2:
+            while len(SIDE_STREAMS) < len(engines) or os.environ.get("BENCH_NEW_STREAMS"):
+                SIDE_STREAMS.append(torch.cuda.Stream(device=dev))
+                if len(SIDE_STREAMS) >= 64:
+                    break
+        side = (SIDE_STREAMS[-len(engines):] if os.environ.get("BENCH_NEW_STREAMS") else SIDE_STREAMS[:len(engines)]) if wl2 else None
 
         def step():
             k = counter[0] % nbuf
