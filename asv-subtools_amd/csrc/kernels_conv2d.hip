@@ -15,6 +15,7 @@
 // LDS rows are C * 2 bytes; 16-byte slot s of window row w sits at s ^ ((w >> 2) & 3) (64-byte rows) or
 // s ^ ((w >> 1) & 7) (128-byte rows): conflict-free ds_read_b128 for any tap shift; the DMA applies the same
 // permutation on the source side.
+#include <algorithm>
 #include <cstdlib>
 
 #include "device_utils.h"
@@ -173,6 +174,158 @@ __global__ __launch_bounds__(256, CIN == 32 ? 3 : 2) void grid_conv_narrow_kerne
         pk.y = pack_h16x2<ET>(y[2], y[3]);
         if (!(abl & 1) || pk.x == 0x12345678u) *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(p.y) + (size_t)row * p.ldy + ch) = pk;
       }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same convolution as a PERSISTENT kernel with a sliding window (round 3).  Ablations of the kernel above on the C = 32 layers
+// (profiles/r3o_conv_abl.txt: 168 - 184 us as is, 112 - 121 without its stores, 159 - 176 with one tap instead of nine, 102 - 110
+// with neither) say the matrix work is ~free and the load and store phases simply add up: a workgroup fetches its whole window,
+// waits, computes, stores, ends - with three workgroups per CU on average ONE is fetching, 27 KiB in flight per CU against a
+// ~2.5 us round trip, and every tile re-fetches 176 halo rows its neighbour already had (1.69 x read amplification).  Here a
+// workgroup walks a contiguous run of tiles: the window lives in an LDS ring addressed by the global row index, the rows tile
+// k + 1 adds (BM of them: amplification 1.0) are fetched while tile k is computed and stored, and the stores of tile k stay in
+// flight across the barrier (the vector-memory counter retires in order: waiting for the older fetches leaves the younger stores
+// outstanding).  Two tiles are fetched ahead; two workgroups per CU: C = 32: 256-row tiles, 960-row ring (60 KiB); C = 64: 128-row
+// tiles, 576-row ring (72 KiB).
+// Same (tap, k-group) accumulation order: bit-identical to the kernel above and to the generic tile.
+template <int CIN> struct NarrowPers {
+  static constexpr int WN = CIN / 32;                      // waves along the output channels (32 each): 1 | 2
+  static constexpr int WM = 4 / WN;                        // waves along the rows (64 each): 4 | 2
+  static constexpr int BM = WM * 64;                       // rows per tile: 256 | 128
+  static constexpr int ROWB = CIN * 2, SLOTS = ROWB / 16, RPP = 1024 / ROWB;       // 16 | 8 rows per 1 KiB piece
+  static constexpr int HALO = CIN == 32 ? 96 : 88;         // >= pitch + 1 (<= 84), a multiple of RPP
+  static constexpr int WIN = BM + 2 * HALO;                // 448 | 304
+  static constexpr int PF = 2;                             // tiles fetched ahead: what is in flight per CU is what bounds this kernel
+  static constexpr int RING = WIN + PF * BM;               // 960 | 560 -> 576 rows
+  static constexpr int RING_ROWS = (RING + RPP * 4 - 1) / (RPP * 4) * (RPP * 4);
+  static constexpr int STAGE = 32 * 64;                    // per wave: 32 rows x 32 channels of output on their way to 16-byte stores
+  static constexpr int LDS = RING_ROWS * ROWB + 4 * STAGE; // 69632 | 81920: two workgroups per CU
+  static_assert(HALO % RPP == 0 && BM % RPP == 0 && RING_ROWS % RPP == 0 && (BM / RPP) % 4 == 0 && 2 * LDS <= 163840, "sliding-window geometry");
+};
+
+// A wave = 64 rows x 32 output channels with the layer's weights for those channels in registers for the whole run (C = 32: 18
+// fragments, C = 64: 36 - the one-tile kernel streams the C = 64 layer's 72 KiB from L2 per wave and tile).  Epilogue: the 8-byte
+// (row, 4 channels) pieces the accumulator layout yields go through a per-wave LDS tile and leave as 16-byte stores, 16 whole
+// 64-byte row pieces per instruction (the direct 8-byte stores touch 32 rows with 16 bytes each: four times the address work).
+template <int CIN, bool GENERIC, int ET = ET_BF16>
+__global__ __launch_bounds__(256, 2) void grid_conv_narrow_pers_kernel(const TdnnKernelParams p, const int tiles_per_wg) {
+  using G = NarrowPers<CIN>;
+  constexpr int KG = CIN / 16, NF = CIN / 32;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS];
+  unsigned char *ring = lds;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / G::WN, wn = wave % G::WN;
+  unsigned char *stage = lds + G::RING_ROWS * G::ROWB + wave * G::STAGE;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int n_tiles = p.rows / G::BM;
+  const int t_begin = blockIdx.x * tiles_per_wg, t_end = min(t_begin + tiles_per_wg, n_tiles);
+  if (t_begin >= t_end) return;
+
+  const unsigned char *xg = reinterpret_cast<const unsigned char *>(p.x);
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_byte_t *)ring);
+  // `count` 1 KiB pieces of window rows starting at virtual row v0 (virtual row v = matrix row v - HALO, clamped onto the matrix:
+  // its first / last rows are gaps); a piece's ring position is its virtual row modulo the ring
+  auto fetch = [&](int v0, int count) {
+    for (int j = wave; j < count; j += 4) {
+      const int v = v0 + j * G::RPP;                             // first virtual row of the piece (wave-uniform)
+      const int rbase = v % G::RING_ROWS;
+      const int rrow = rbase + lane / G::SLOTS;                  // ring row of this lane's 16 bytes
+      const int row = min(max(v - G::HALO + lane / G::SLOTS, 0), p.rows - 1);
+      const int src_slot = cswz<CIN>(rrow, lane % G::SLOTS);
+      conv_glds16(xg + (size_t)row * ((size_t)p.ldx * 2) + src_slot * 16, __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)rbase * G::ROWB));
+    }
+  };
+  fetch(t_begin * G::BM, (G::WIN + (min(t_end - t_begin, G::PF) - 1) * G::BM) / G::RPP);          // the first window + the rows of the next PF - 1 tiles
+
+  const int v_taps = p.taps[lane < 9 ? lane : 0];
+  const uint4 *wf = reinterpret_cast<const uint4 *>(p.wconv) + lane;            // fragment f at wf[f * 64]
+  uint4 wr[9][KG];                                                              // this wave's 32 output channels, all taps
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int kg = 0; kg < KG; ++kg) wr[t][kg] = wf[((t * KG + kg) * NF + wn) * 64];
+  // the epilogue's constants for this lane's 16 channels (wn * 32 + 8 q + 4 lh + e)
+  float cb[16], cs[16], ct[16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int ch = wn * 32 + 8 * q + 4 * lh;
+    const float4 b4 = *reinterpret_cast<const float4 *>(p.bias + ch);
+    const float4 sc4 = p.scale ? *reinterpret_cast<const float4 *>(p.scale + ch) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 sh4 = p.shift ? *reinterpret_cast<const float4 *>(p.shift + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+    cb[q * 4] = b4.x; cb[q * 4 + 1] = b4.y; cb[q * 4 + 2] = b4.z; cb[q * 4 + 3] = b4.w;
+    cs[q * 4] = sc4.x; cs[q * 4 + 1] = sc4.y; cs[q * 4 + 2] = sc4.z; cs[q * 4 + 3] = sc4.w;
+    ct[q * 4] = sh4.x; ct[q * 4 + 1] = sh4.y; ct[q * 4 + 2] = sh4.z; ct[q * 4 + 3] = sh4.w;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  const float act_lo = (p.act1 == ASV_ACT_RELU) ? 0.0f : -INFINITY;
+#pragma unroll 1
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int m0 = tile * G::BM;
+    const int wbase = __builtin_amdgcn_readfirstlane(m0 % G::RING_ROWS);       // ring row of the window's first row (virtual row m0)
+    const bool ahead = tile + G::PF < t_end;
+    if (ahead) fetch(m0 + G::WIN + (G::PF - 1) * G::BM, G::BM / G::RPP);        // the rows tile + PF adds
+
+    f32x16_t acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int d = __builtin_amdgcn_readlane(v_taps, t);
+#pragma unroll
+      for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          int w = wbase + G::HALO + wm * 64 + i * 32 + lr + d;
+          w = w >= G::RING_ROWS ? w - G::RING_ROWS : w;
+          const uint4 x = *reinterpret_cast<const uint4 *>(ring + w * G::ROWB + cswz<CIN>(w, kg * 2 + lh) * 16);
+          acc[i] = mfma16<ET>(wr[t][kg], x, acc[i]);
+        }
+    }
+
+    // ---- epilogue: acc[i][r] = row m0 + wm*64 + i*32 + lr, channel wn*32 + 8*(r>>2) + 4*lh + (r&3)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = m0 + wm * 64 + i * 32 + lr;
+      const bool valid = (p.row_valid[row >> 5] >> (row & 31)) & 1u;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if constexpr (GENERIC) y[e] = tdnn_epilogue<true>(p, acc[i][q * 4 + e], row, wn * 32 + 8 * q + 4 * lh + e, cb[q * 4 + e], cs[q * 4 + e], ct[q * 4 + e], valid);
+          else y[e] = tdnn_epilogue_fast(acc[i][q * 4 + e], cb[q * 4 + e], act_lo, cs[q * 4 + e], ct[q * 4 + e], valid);
+        }
+        uint2 pk;
+        pk.x = pack_h16x2<ET>(y[0], y[1]);
+        pk.y = pack_h16x2<ET>(y[2], y[3]);
+        // staging tile: row lr, 16-byte slot q ^ ((lr >> 2) & 3), half lh
+        *reinterpret_cast<uint2 *>(stage + lr * 64 + ((q ^ ((lr >> 2) & 3)) << 4) + lh * 8) = pk;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // the wave's own writes (no other wave touches this tile)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int srow = h * 16 + (lane >> 2), slot = lane & 3;
+        const uint4 v = *reinterpret_cast<const uint4 *>(stage + srow * 64 + ((slot ^ ((srow >> 2) & 3)) << 4));
+        const int orow = m0 + wm * 64 + i * 32 + srow;
+        *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(p.y) + (size_t)orow * p.ldy + wn * 32 + slot * 8) = v;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // reads done before the next fragment overwrites the tile
+    }
+    // every wave is through with window `tile` and the NEXT tile's rows have landed.  Younger than that fetch and free to stay in
+    // flight (the counter retires in order): per further tile ahead a fetch (BM / RPP / 4 pieces per wave) and a tile's 4 stores,
+    // and this tile's 4 stores.  Near the end of the run nothing was fetched in this iteration: only the own stores may remain.
+    constexpr int kYounger = (G::PF - 1) * (G::BM / G::RPP / 4 + 4) + 4;
+    if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kYounger) : "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
   }
 }
 
@@ -531,6 +684,23 @@ int launch_grid_conv_narrow(const TdnnKernelParams &p0, hipStream_t s) {
   const dim3 grid(p.rows / CBM), block(256);
   const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first && p.seg_bias == nullptr &&
                     p.seg_scale == nullptr && p.res == nullptr;
+  static const int pers0 = getenv("ASV_AMD_CONV_PERS") != nullptr ? atoi(getenv("ASV_AMD_CONV_PERS")) : 1;
+  const int pers = live && getenv("ASV_AMD_CONV_PERS") != nullptr ? atoi(getenv("ASV_AMD_CONV_PERS")) : pers0;
+  if (pers && p.tune == 0 && p.ldy % 8 == 0) {                 // (its 16-byte stores)
+    // persistent sliding-window form: every workgroup a contiguous run of tiles; as many workgroups as the chip holds at once
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int bm = p.cin_pad == 32 ? NarrowPers<32>::BM : NarrowPers<64>::BM, per_cu = 2;
+    const int n_tiles = p.rows / bm, wgs = std::min(n_tiles, cus * per_cu), per_wg = (n_tiles + wgs - 1) / wgs;
+    const dim3 pgrid((n_tiles + per_wg - 1) / per_wg);
+#define ASV_CONV_PERS(...) do { if (p.et == ET_F16) hipLaunchKernelGGL((__VA_ARGS__, ET_F16>), pgrid, block, 0, s, p, per_wg); \
+                                else hipLaunchKernelGGL((__VA_ARGS__, ET_BF16>), pgrid, block, 0, s, p, per_wg); } while (0)
+    if (p.cin_pad == 32) { if (fast) ASV_CONV_PERS(grid_conv_narrow_pers_kernel<32, false); else ASV_CONV_PERS(grid_conv_narrow_pers_kernel<32, true); }
+    else { if (fast) ASV_CONV_PERS(grid_conv_narrow_pers_kernel<64, false); else ASV_CONV_PERS(grid_conv_narrow_pers_kernel<64, true); }
+#undef ASV_CONV_PERS
+    ASV_HIP_CHECK(hipGetLastError());
+    return ASV_OK;
+  }
   if (p.cin_pad == 32) {
     if (fast) ASV_CONV_ET(grid_conv_narrow_kernel<32, 1, false);
     else ASV_CONV_ET(grid_conv_narrow_kernel<32, 1, true);
