@@ -373,12 +373,28 @@ __global__ __launch_bounds__(256, 2) void grid_conv_wide_kernel(const TdnnKernel
   const unsigned char *xg = reinterpret_cast<const unsigned char *>(p.x);
   const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_byte_t *)win);
   for (int piece = wave; piece < G::PIECES; piece += 4) {
+    if (p.tune & 4) break;                                            // developer aid (ASV_AMD_CONV_ABL bit 2): no window fetch
     const int w = piece * G::RPP + lane / G::SLOTS;
     const int row = min(max(m0 - G::HALO + w, 0), p.rows - 1);
     const int src_slot = (lane % G::SLOTS) ^ (w & 15);
     conv_glds16(xg + (size_t)row * ((size_t)p.ldx * 2) + src_slot * 16, __builtin_amdgcn_readfirstlane(lds_base + piece * 1024));
   }
   const int v_taps = p.taps[lane < 9 ? lane : 0];
+  // The epilogue's per-channel constants, fetched NOW, one to three floats per thread (bias | scale | shift, CIN each): behind the K
+  // loop they go through LDS to the lanes that need them.  (Until round 3 every (j, q) step of the epilogue fetched its three
+  // float4 and waited: eight L2 round trips in a row per tile - with fetch, K loop and stores ablated the kernel still took 85 of
+  // its 103 us, profiles/r3v_wide_abl.txt.)
+  constexpr int NCST = 3 * CIN / 256 + (3 * CIN % 256 != 0);
+  float cpre[NCST];
+#pragma unroll
+  for (int k = 0; k < NCST; ++k) {
+    const int e = tid + 256 * k, which = e / CIN, c = e % CIN;
+    cpre[k] = which == 0 ? 0.0f : (which == 1 ? 1.0f : 0.0f);
+    if (e < 3 * CIN) {
+      const float *src = which == 0 ? p.bias : (which == 1 ? p.scale : p.shift);
+      if (src != nullptr) cpre[k] = src[c];
+    }
+  }
   // weights: [tap][k-group][n-fragment][lane][8]; this wave's two fragments are n-fragments wn * 2 and wn * 2 + 1
   const unsigned char *wbase = reinterpret_cast<const unsigned char *>(p.wconv) + (size_t)(wn * 2) * 1024 + (size_t)lane * 16;
   auto frag_ptr = [&](int t, int kg, int j) { return wbase + ((size_t)(t * G::KG + kg) * G::NFR + j) * 1024; };
@@ -414,6 +430,7 @@ __global__ __launch_bounds__(256, 2) void grid_conv_wide_kernel(const TdnnKernel
   }
 #pragma unroll 1
   for (int st = 0; st < G::STEPS; ++st) {
+    if ((p.tune & 2) && st >= 2) break;                               // developer aid (ASV_AMD_CONV_ABL bit 1): two K steps instead of all
     // 64-channel chunk outermost, taps inside it: the K order of the generic tile (kernels_tdnn.hip), hence the same bits
     const int c4 = st / 9, t = st % 9;
     const int stn = st + 1 < G::STEPS ? st + 1 : st;               // the last step re-fetches its own fragments (never used)
@@ -439,21 +456,33 @@ __global__ __launch_bounds__(256, 2) void grid_conv_wide_kernel(const TdnnKernel
     group(x1, 3, x0, dn, c4n * 4);
   }
 
-  // ---- epilogue: acc[i][j][r] = row m0 + wm*128 + i*32 + lr, channel wn*64 + j*32 + 8*(r>>2) + 4*lh + (r&3): 8-byte stores
+  // ---- epilogue: acc[i][j][r] = row m0 + wm*128 + i*32 + lr, channel wn*64 + j*32 + 8*(r>>2) + 4*lh + (r&3).
+  // The window is dead: its first 16 KiB become four per-wave tiles (32 rows x 64 channels) through which the 8-byte pieces of the
+  // accumulator layout turn into 16-byte stores of whole 128-byte row pieces, the 3 x CIN constants sit behind them.
   const float act_lo = (p.act1 == ASV_ACT_RELU) ? 0.0f : -INFINITY;
+  __builtin_amdgcn_s_barrier();                                       // every wave is through with the window
+  asm volatile("" ::: "memory");
+  float *cst = reinterpret_cast<float *>(win + 16384);
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int k = 0; k < NCST; ++k)
+    if (tid + 256 * k < 3 * CIN) cst[tid + 256 * k] = cpre[k];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  unsigned char *stage = win + wave * 4096;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int ch = wn * 64 + j * 32 + 8 * q + 4 * lh;
-      const float4 b4 = *reinterpret_cast<const float4 *>(p.bias + ch);
-      const float4 sc4 = p.scale ? *reinterpret_cast<const float4 *>(p.scale + ch) : make_float4(1.f, 1.f, 1.f, 1.f);
-      const float4 sh4 = p.shift ? *reinterpret_cast<const float4 *>(p.shift + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
-      const float b[4] = {b4.x, b4.y, b4.z, b4.w}, sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+  for (int i = 0; i < 4; ++i) {
+    const int row = m0 + wm * 128 + i * 32 + lr;
+    const bool valid = (p.row_valid[row >> 5] >> (row & 31)) & 1u;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = m0 + wm * 128 + i * 32 + lr;
-        const bool valid = (p.row_valid[row >> 5] >> (row & 31)) & 1u;
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ch = wn * 64 + j * 32 + 8 * q + 4 * lh;
+        const float4 b4 = *reinterpret_cast<const float4 *>(cst + ch);
+        const float4 sc4 = *reinterpret_cast<const float4 *>(cst + CIN + ch);
+        const float4 sh4 = *reinterpret_cast<const float4 *>(cst + 2 * CIN + ch);
+        const float b[4] = {b4.x, b4.y, b4.z, b4.w}, sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
         float y[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -463,9 +492,19 @@ __global__ __launch_bounds__(256, 2) void grid_conv_wide_kernel(const TdnnKernel
         uint2 pk;
         pk.x = pack_h16x2<ET>(y[0], y[1]);
         pk.y = pack_h16x2<ET>(y[2], y[3]);
-        *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(p.y) + (size_t)row * p.ldy + ch) = pk;
+        // tile row lr (128 bytes), 16-byte slot (j * 4 + q) ^ (lr & 7), half lh
+        *reinterpret_cast<uint2 *>(stage + lr * 128 + (((j * 4 + q) ^ (lr & 7)) << 4) + lh * 8) = pk;
       }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // the wave's own writes (no other wave touches this tile)
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const int srow = h * 8 + (lane >> 3), slot = lane & 7;
+      const uint4 v = *reinterpret_cast<const uint4 *>(stage + srow * 128 + ((slot ^ (srow & 7)) << 4));
+      const int orow = m0 + wm * 128 + i * 32 + srow;
+      *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(p.y) + (size_t)orow * p.ldy + wn * 64 + slot * 8) = v;
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // reads done before the next fragment overwrites the tile
+  }
 }
 
 // The stride-2 3x3 convolution that opens the C = 64 stage (32 -> 64 channels, resnet.py:352-368 through BasicBlock's conv1) in its
@@ -495,6 +534,12 @@ __global__ __launch_bounds__(256, 2) void grid_conv_s2d_kernel(const TdnnKernelP
     conv_glds16(xg + (size_t)row * ((size_t)p.ldx * 2) + src_slot * 16, __builtin_amdgcn_readfirstlane(lds_base + piece * 1024));
   }
   const int v_taps = p.taps[lane < S2D_NT ? lane : 0];
+  // bias | scale | shift of the 64 output channels: fetched now by the first 192 threads, handed out through LDS behind the K loop
+  float cpre = tid < 128 ? (tid < 64 ? 0.0f : 1.0f) : 0.0f;
+  if (tid < 192) {
+    const float *src = tid < 64 ? p.bias : (tid < 128 ? p.scale : p.shift);
+    if (src != nullptr) cpre = src[tid & 63];
+  }
   const unsigned char *wbase = reinterpret_cast<const unsigned char *>(p.wconv) + (size_t)lane * 16;
   auto frag_ptr = [&](int t, int kg, int j) { return wbase + ((size_t)(t * S2D_KG + kg) * 2 + j) * 1024; };
 
@@ -549,21 +594,30 @@ __global__ __launch_bounds__(256, 2) void grid_conv_s2d_kernel(const TdnnKernelP
     group(x1, 3, x0, dn, c4n * 4);
   }
 
-  // ---- epilogue: acc[i][j][r] = row m0 + wave*64 + i*32 + lr, channel j*32 + 8*(r>>2) + 4*lh + (r&3): 8-byte stores
+  // ---- epilogue: acc[i][j][r] = row m0 + wave*64 + i*32 + lr, channel j*32 + 8*(r>>2) + 4*lh + (r&3); through per-wave LDS tiles
+  // in the dead window to 16-byte stores of whole 128-byte rows (see grid_conv_wide_kernel)
   const float act_lo = (p.act1 == ASV_ACT_RELU) ? 0.0f : -INFINITY;
+  __builtin_amdgcn_s_barrier();                                       // every wave is through with the window
+  asm volatile("" ::: "memory");
+  float *cst = reinterpret_cast<float *>(win + 16384);
+  if (tid < 192) cst[tid] = cpre;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  unsigned char *stage = win + wave * 4096;
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int i = 0; i < 2; ++i) {
+    const int row = m0 + wave * 64 + i * 32 + lr;
+    const bool valid = (p.row_valid[row >> 5] >> (row & 31)) & 1u;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int ch = j * 32 + 8 * q + 4 * lh;
-      const float4 b4 = *reinterpret_cast<const float4 *>(p.bias + ch);
-      const float4 sc4 = p.scale ? *reinterpret_cast<const float4 *>(p.scale + ch) : make_float4(1.f, 1.f, 1.f, 1.f);
-      const float4 sh4 = p.shift ? *reinterpret_cast<const float4 *>(p.shift + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
-      const float b[4] = {b4.x, b4.y, b4.z, b4.w}, sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = m0 + wave * 64 + i * 32 + lr;
-        const bool valid = (p.row_valid[row >> 5] >> (row & 31)) & 1u;
+      for (int q = 0; q < 4; ++q) {
+        const int ch = j * 32 + 8 * q + 4 * lh;
+        const float4 b4 = *reinterpret_cast<const float4 *>(cst + ch);
+        const float4 sc4 = *reinterpret_cast<const float4 *>(cst + 64 + ch);
+        const float4 sh4 = *reinterpret_cast<const float4 *>(cst + 128 + ch);
+        const float b[4] = {b4.x, b4.y, b4.z, b4.w}, sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
         float y[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -573,9 +627,18 @@ __global__ __launch_bounds__(256, 2) void grid_conv_s2d_kernel(const TdnnKernelP
         uint2 pk;
         pk.x = pack_h16x2<ET>(y[0], y[1]);
         pk.y = pack_h16x2<ET>(y[2], y[3]);
-        *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(p.y) + (size_t)row * p.ldy + ch) = pk;
+        *reinterpret_cast<uint2 *>(stage + lr * 128 + (((j * 4 + q) ^ (lr & 7)) << 4) + lh * 8) = pk;
       }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const int srow = h * 8 + (lane >> 3), slot = lane & 7;
+      const uint4 v = *reinterpret_cast<const uint4 *>(stage + srow * 128 + ((slot ^ (srow & 7)) << 4));
+      const int orow = m0 + wave * 64 + i * 32 + srow;
+      *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(p.y) + (size_t)orow * p.ldy + slot * 8) = v;
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
 }
 
 // The first convolution of the trunk: ONE input channel (the fbank map itself), 3x3, 32 output channels
@@ -718,11 +781,14 @@ bool grid_conv_wide_supported(const TdnnKernelParams &p, int et) {
   if (p.cout_store != p.cin_pad) return false;                 // the trunk's 3x3 convolutions keep the channel count
   const int halo_max = p.cin_pad == 128 ? WideGeom<128>::HALO : WideGeom<256>::HALO;
   const int bm = p.cin_pad == 128 ? WideGeom<128>::BM : WideGeom<256>::BM;
-  if (p.halo > halo_max || p.rows % bm != 0 || p.ldx % 8 != 0 || p.ldy % 4 != 0) return false;
+  if (p.halo > halo_max || p.rows % bm != 0 || p.ldx % 8 != 0 || p.ldy % 8 != 0) return false;      // (16-byte stores)
   return true;
 }
 
-int launch_grid_conv_wide(const TdnnKernelParams &p, hipStream_t s) {
+int launch_grid_conv_wide(const TdnnKernelParams &p0, hipStream_t s) {
+  TdnnKernelParams p = p0;
+  static const bool live = getenv("ASV_AMD_LIVE_TUNE") != nullptr;
+  p.tune = live && getenv("ASV_AMD_CONV_ABL") != nullptr ? atoi(getenv("ASV_AMD_CONV_ABL")) : 0;
   ASV_REQUIRE(grid_conv_wide_supported(p, true), "grid conv (wide): unsupported layer");
   const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first && p.seg_bias == nullptr &&
                     p.seg_scale == nullptr && p.res == nullptr;
@@ -744,7 +810,7 @@ bool grid_conv_s2d_supported(const TdnnKernelParams &p, int et) {
   if (et == ET_F32 || p.n_taps != S2D_NT || p.x2 != nullptr || p.wconv == nullptr) return false;
   if (p.cin_pad != 128 || p.cout_store != 64) return false;
   for (int t = 0; t < p.n_taps; ++t) if (p.taps[t] > 0 || p.taps[t] < -S2D_HLO) return false;
-  if (p.rows % S2D_BM != 0 || p.ldx % 8 != 0 || p.ldy % 4 != 0) return false;
+  if (p.rows % S2D_BM != 0 || p.ldx % 8 != 0 || p.ldy % 8 != 0) return false;
   return true;
 }
 
