@@ -700,7 +700,13 @@ int launch_tdnn_big3(const TdnnKernelParams &p, hipStream_t s) {
     const int geom = tdnn_big3_pick_geometry(q);
     return launch_tdnn_big3_variant(q, geom * 100 + ((q.tune & 0x20000) && geom == 0 && q.pool_partial == nullptr ? 3 : 0), s);
   }
-  return launch_tdnn_big3_variant(p, tdnn_big3_pick_geometry(p) * 100, s);
+  // ASV_AMD_BIG3_GEOM=1|2 (A/B aid): 256 x 256 tiles, one workgroup per CU / 64 x 256, three per CU, for the layers the default
+  // 128 x 256 geometry would take
+  static const char *geom0 = getenv("ASV_AMD_BIG3_GEOM");
+  const char *geom_s = live ? getenv("ASV_AMD_BIG3_GEOM") : geom0;
+  int geom = tdnn_big3_pick_geometry(p);
+  if (geom_s != nullptr && geom == 0 && p.pool_partial == nullptr && (atoi(geom_s) == 1 || atoi(geom_s) == 2)) geom = atoi(geom_s);
+  return launch_tdnn_big3_variant(p, geom * 100, s);
 }
 
 }  // namespace asv
