@@ -25,8 +25,9 @@ done
 if [ "${2:-}" = "pmc" ]; then
   short="--steps 4 --warmup 2 --no-profile --min-seconds 0.05 $one"
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/${tag}_pmc_$c -- python $root/bench.py $short > /dev/null 2>&1
-    cp $out/${tag}_pmc_$c/*/*counter_collection.csv $out/${tag}_pmc_${c}.csv 2>/dev/null
+    timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/${tag}_pmc_$c -- python $root/bench.py $short > $out/${tag}_pmc_$c.log 2>&1
+    echo "pmc $c rc=$?"
+    cp $out/${tag}_pmc_$c/*/*counter_collection.csv $out/${tag}_pmc_${c}.csv 2>/dev/null || echo "pmc $c: no counter file (see ${tag}_pmc_$c.log; the passes also run from a call of their own: the last lines of this script)"
     rm -rf $out/${tag}_pmc_$c
   done
   timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/${tag}_pmc_sq -- python $root/bench.py $short > /dev/null 2>&1
