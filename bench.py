@@ -53,7 +53,7 @@ MODELS = {
 KERNEL_NAMES = {"xvector": "the 3 frame-level GEMM launches of a step: tdnn_chain_kernel (tdnn3 -> tdnn4 -> tdnn5 -> statistics pooling in one launch, the dominant "
                            "kernel: 65 % of the FLOPs) and tdnn_gemm_big3_kernel (tdnn1, tdnn2); `per_launch` lists each one",
                 "ecapa": "frame-level GEMM launches (tdnn_gemm_big3_kernel for the wide layers, res2_chain / tdnn_gemm_kernel for the 128-channel ones)",
-                "resnet": "frame-level GEMM launches (grid_conv_narrow_kernel / tdnn_gemm_kernel)"}
+                "resnet": "frame-level GEMM launches (grid_conv_narrow_pers_kernel / grid_conv_wide_kernel / grid_conv_s2d_kernel / tdnn_gemm_kernel)"}
 
 
 def parse():
