@@ -137,7 +137,11 @@ struct PoolKernelParams {
   // grid (2-D) inputs: `groups` frequency bins are pooled separately over time; bin g reads rows
   // row0 + g + k*row_stride (k < len/row_stride) and writes columns [g*C*(1+stddev), ...) of the row
   int row_stride, groups;
+  // mean-only pooling of long segments (the SE squeeze over a 2-D map) in two steps: every kPoolChunkRows rows of a segment
+  // one workgroup, sums to chunk_partial[(segment * chunks + chunk)][ld_chunk], then a finish kernel.  chunks = 0: one pass.
+  float *chunk_partial; int chunks, ld_chunk;
 };
+constexpr int kPoolChunkRows = 2048;     // a property of the kernel, never of the batch: an utterance's mean does not depend on its neighbours
 
 // Element type of frames-domain storage and of the matrix operands: the launchers' `et` argument (a former `bool bf16`
 // converts to the first two values).

@@ -208,6 +208,66 @@ __global__ __launch_bounds__(256) void stats_pool_kernel(const PoolKernelParams 
   }
 }
 
+// Mean over the rows of a LONG segment (the SE squeeze of the 2-D trunk: 16 k rows x 32 channels per utterance) in two steps.  One
+// workgroup per (segment, 64 channels) - stats_pool_kernel - leaves a 256-utterance batch with 256 workgroups of four waves: 4.1 TB/s.
+// Here every kPoolChunkRows rows of a segment get a workgroup (grid.z), chunked from the SEGMENT'S first row: which rows are summed
+// together, and in which order, depends on the utterance alone - bit-for-bit batch invariance holds (the round-2 attempt split by a
+// batch-dependent count and met through a ticket behind a device-scope fence: slower and not invariant).  Plain sums: the pivot of
+// the one-pass variance is not needed for a mean.
+template <int ET, bool NARROW>
+__global__ __launch_bounds__(256) void sum_chunk_kernel(const PoolKernelParams p) {
+  constexpr int VEC = (ET != ET_F32) ? 8 : 4;
+  constexpr int CG = NARROW ? 4 : 64 / VEC;
+  constexpr int RS = 64 / CG;
+  __shared__ float sm[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cg = lane % CG, rs = lane / CG;
+  const int seg = blockIdx.y, chunk = blockIdx.z, ch = blockIdx.x * (CG * VEC) + cg * VEC;
+  const int len = p.seg_len[seg];
+  const int r_begin = chunk * kPoolChunkRows, r_end = min(len, r_begin + kPoolChunkRows);
+  if (r_begin >= len) return;                                   // (uniform for the workgroup; no partial is read for it)
+  const size_t base = (size_t)p.seg_row0[seg] * p.ldx + ch;
+  const bool active = ch < round_up_dev(p.channels, kChanAlign);
+  float s[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s[i] = 0.0f;
+  if (active) {
+    int r = r_begin + wave * RS + rs;
+    for (; r + 3 * 4 * RS < r_end; r += 4 * 4 * RS) {           // 4 independent row streams per lane
+      float v0[VEC], v1[VEC], v2[VEC], v3[VEC];
+      load_vec<ET, VEC>(p.x, base + (size_t)r * p.ldx, v0);
+      load_vec<ET, VEC>(p.x, base + (size_t)(r + 4 * RS) * p.ldx, v1);
+      load_vec<ET, VEC>(p.x, base + (size_t)(r + 8 * RS) * p.ldx, v2);
+      load_vec<ET, VEC>(p.x, base + (size_t)(r + 12 * RS) * p.ldx, v3);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) s[i] += (v0[i] + v1[i]) + (v2[i] + v3[i]);
+    }
+    for (; r < r_end; r += 4 * RS) {
+      float v[VEC];
+      load_vec<ET, VEC>(p.x, base + (size_t)r * p.ldx, v);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) s[i] += v[i];
+    }
+  }
+  block_reduce_rows<VEC, CG>(s, sm, wave, cg, rs);
+  if (wave == 0 && rs == 0 && active) {
+    float *dst = p.chunk_partial + ((size_t)seg * p.chunks + chunk) * p.ld_chunk + ch;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i)
+      if (ch + i < p.channels) dst[i] = s[i];
+  }
+}
+
+__global__ __launch_bounds__(64) void sum_chunk_finish_kernel(const PoolKernelParams p) {
+  const int seg = blockIdx.y, ch = blockIdx.x * 64 + threadIdx.x;
+  if (ch >= p.channels) return;
+  const int len = p.seg_len[seg];
+  const int n = (len + kPoolChunkRows - 1) / kPoolChunkRows;
+  float s = 0.0f;
+  for (int k = 0; k < n; ++k) s += p.chunk_partial[((size_t)seg * p.chunks + k) * p.ld_chunk + ch];
+  p.out[(size_t)seg * p.ld_out + ch] = s / (float)len;
+}
+
 // Fused-pooling finish (see the POOL epilogue of kernels_tdnn_v3.hip): one wave per (segment, 64 channels).
 __global__ __launch_bounds__(64) void pool_finish_kernel(const PoolFinishParams p) {
   const int seg = blockIdx.y, ch = blockIdx.x * 64 + threadIdx.x;
@@ -712,6 +772,19 @@ int launch_unpack_rows(const void *y, int ldy, int channels, const int32_t *seg_
 
 int launch_stats_pool(const PoolKernelParams &p, int segments, int et, hipStream_t s) {
   if (segments <= 0) return ASV_OK;
+  if (p.chunks > 0) {
+    ASV_REQUIRE(!p.stddev && p.groups == 1 && p.row_stride == 1 && p.chunk_partial != nullptr && p.ld_chunk >= p.channels, "stats_pool: the chunked form is mean-only over contiguous rows");
+    const bool narrow = et != ET_F32 && p.channels <= 32;
+    const dim3 cgrid(narrow ? 1 : (p.channels + 63) / 64, segments, p.chunks), block(256);
+    if (et == ET_BF16 && narrow) hipLaunchKernelGGL((sum_chunk_kernel<ET_BF16, true>), cgrid, block, 0, s, p);
+    else if (et == ET_F16 && narrow) hipLaunchKernelGGL((sum_chunk_kernel<ET_F16, true>), cgrid, block, 0, s, p);
+    else if (et == ET_BF16) hipLaunchKernelGGL((sum_chunk_kernel<ET_BF16, false>), cgrid, block, 0, s, p);
+    else if (et == ET_F16) hipLaunchKernelGGL((sum_chunk_kernel<ET_F16, false>), cgrid, block, 0, s, p);
+    else hipLaunchKernelGGL((sum_chunk_kernel<ET_F32, false>), cgrid, block, 0, s, p);
+    hipLaunchKernelGGL(sum_chunk_finish_kernel, dim3((p.channels + 63) / 64, segments), dim3(64), 0, s, p);
+    ASV_HIP_CHECK(hipGetLastError());
+    return ASV_OK;
+  }
   const dim3 grid((p.channels + 63) / 64, segments * p.groups), block(256);
   if (et == ET_BF16 && p.channels <= 32) hipLaunchKernelGGL((stats_pool_kernel<ET_BF16, true>), dim3(1, segments * p.groups), block, 0, s, p);
   else if (et == ET_F16 && p.channels <= 32) hipLaunchKernelGGL((stats_pool_kernel<ET_F16, true>), dim3(1, segments * p.groups), block, 0, s, p);

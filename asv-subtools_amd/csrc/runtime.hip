@@ -1343,6 +1343,18 @@ int run_ops(RunCtx &c, size_t n_ops) {
         p.stddev = d.stddev; p.unbiased = d.unbiased; p.var_mode = d.var_mode; p.eps = d.eps;
         p.row_stride = d.per_bin ? dm.pitch : 1;
         p.groups = d.per_bin ? dm.width : 1;
+        p.chunk_partial = nullptr; p.chunks = 0; p.ld_chunk = 0;
+        if (!d.stddev && !d.per_bin && dm.kind == 2 && dm.pitch >= 32 && (net->flags & ASV_FLAG_NO_FUSE) == 0) {      // (narrow maps: the second launch costs more than it saves)
+          // mean over a 2-D map (SE squeeze): long segments, few of them - kPoolChunkRows rows per workgroup + a finish kernel
+          int max_len = 0;
+          for (int32_t len : bp.dom[domid].seg_len) max_len = std::max(max_len, (int)len);
+          const int chunks = (max_len + kPoolChunkRows - 1) / kPoolChunkRows;
+          if (chunks >= 1) {                                       // always this form for these ops: the arithmetic must not depend on the batch
+            p.chunks = chunks; p.ld_chunk = round_up(d.channels, 64);
+            if ((rc = ensure(net->poolpart_dev, (size_t)bp.segments * chunks * p.ld_chunk * 4, c.s, false))) return rc;
+            p.chunk_partial = reinterpret_cast<float *>(net->poolpart_dev.ptr);
+          }
+        }
         if ((rc = prof.begin(K_POOL, 0, (int)i))) return rc;
         if ((rc = launch_stats_pool(p, bp.segments, net->dom_et(domid), c.s))) return rc;
         if ((rc = prof.end())) return rc;
