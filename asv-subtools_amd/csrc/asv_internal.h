@@ -124,6 +124,7 @@ struct TdnnKernelParams {
   int x3_et, x3_terms;  // f32x kernel (kernels_tdnn_x3.hip): 16-bit type of the operand halves (ET_BF16 / ET_F16) and which products run -
                         // bit 0: w_hi x_hi, bit 1: w_hi x_lo, bit 2: w_lo x_hi (7 = the f32-grade mode; the others are the measured
                         // "why not two matrix instructions" variants)
+  int x3_tile;          // f32x kernel: 0 = pick the tile rows from the batch size, 128 = ASV_FLAG_X3_TILE128
   float w_unscale;      // f32x kernel: the accumulators are multiplied by this (1 / the power of two the host scaled the weights by)
   int et;               // ET_*: element type of x / x2 / res / y rows and of the packed weights (the launchers without an `et` argument read it)
 };
@@ -161,6 +162,14 @@ bool grid_conv_wide_supported(const TdnnKernelParams &p, int et);      // the C 
 int launch_grid_conv_wide(const TdnnKernelParams &p, hipStream_t s);
 bool grid_conv_c1_supported(const TdnnKernelParams &p, int et, int in_ch);
 int launch_grid_conv_c1(const TdnnKernelParams &p, hipStream_t s);
+// kernels_conv2d_x3.hip: the grid-domain layers of the f32x precision mode (f32 rows, three 16-bit matrix instructions per product);
+// weights in p.wconv as [chunk32][tap][k-group][n-fragment][hi | lo][lane][8], scaled by 1 / p.w_unscale
+bool grid_conv_x3_shape_ok(int cin_pad, int cout_store);
+size_t grid_conv_x3_frag_elems(int cin_pad, int cout_store, int n_taps);
+void pack_grid_conv_x3_frags(const float *w, int out_ch, int in_ch, int tot_ctx, int left_ctx, const int *taps, int n_taps, int cin_pad, int cout_store,
+                             int et, float scale, uint16_t *dst);
+bool grid_conv_x3_supported(const TdnnKernelParams &p);
+int launch_grid_conv_x3(const TdnnKernelParams &p, hipStream_t s);
 int launch_splitk_epilogue(const TdnnKernelParams &p, int et, bool out_f32, hipStream_t s);
 // 256-channel tiles of the bf16 frame-layer kernel (kernels_tdnn_v3.hip): weights are padded to kBigTileN output channels
 constexpr int kBigTileN = 256;
@@ -186,9 +195,12 @@ struct TdnnChainParams {
   int min_seg_len;              // shortest utterance of the batch in frames (the 4-wave kernel needs >= 32: at most one seam per 32-frame fragment)
 };
 int launch_tdnn_chain(const TdnnChainParams &p, hipStream_t s);
-// the same chain as four waves of 512 registers, pooling arithmetic inside the next unit's K loop (kernels_tdnn_chain4.hip)
+#ifdef ASV_WITH_ABLATION
+// the same chain as four waves of 512 registers, pooling arithmetic inside the next unit's K loop (tools/kernels_tdnn_chain4.hip:
+// measured 0 - 1 % slower; part of the developer build libasv_amd_dev.so only, `make dev`)
 bool tdnn_chain4_supported(const TdnnChainParams &p);
 int launch_tdnn_chain4(const TdnnChainParams &p, hipStream_t s);
+#endif
 // the same chain with f32-grade split products and the tiles resident as hi / lo half images; 64-row tiles (kernels_tdnn_chainx.hip)
 int launch_tdnn_chainx(const TdnnChainParams &p, hipStream_t s);
 // ECAPA Res2NetBlock as one kernel (kernels_res2.hip)

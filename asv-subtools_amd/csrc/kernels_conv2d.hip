@@ -27,6 +27,14 @@ constexpr int CBM = 256;              // output rows per workgroup
 constexpr int CHALO = 88;             // window halo: >= pitch + 1 (<= 84), a multiple of 8
 constexpr int CWIN = CBM + 2 * CHALO;  // 432 window rows
 
+// Ablation bits (ASV_AMD_CONV_ABL; results are garbage) exist in the developer build only (libasv_amd_dev.so, `make dev`): in the
+// product library this is the constant 0 and the ablated paths are not in the code.
+#ifdef ASV_WITH_ABLATION
+__device__ __forceinline__ int conv_abl(const TdnnKernelParams &p) { return p.tune; }
+#else
+__device__ __forceinline__ constexpr int conv_abl(const TdnnKernelParams &) { return 0; }
+#endif
+
 typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
 
 template <int CIN> __device__ __forceinline__ int cswz(int row, int slot) {
@@ -73,7 +81,7 @@ __global__ __launch_bounds__(256, CIN == 32 ? 3 : 2) void grid_conv_narrow_kerne
   const uint4 *wf = reinterpret_cast<const uint4 *>(p.wconv) + lane;            // fragment f at wf[f * 64]
   // developer aid (ASV_AMD_CONV_ABL with ASV_AMD_LIVE_TUNE=1; results are garbage): bit 0 = no output stores, bit 1 = one tap
   // instead of nine (the window is still fetched whole)
-  const int abl = p.tune;
+  const int abl = conv_abl(p);
 
   f32x16_t acc[2][NF];
 #pragma unroll
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(256, CIN == 32 ? 3 : 2) void grid_conv_narrow_kerne
         float y[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          if constexpr (GENERIC) y[e] = tdnn_epilogue<true>(p, acc[i][n][q * 4 + e], row, ch + e, b[e], sc[e], sh[e], valid);
+          if constexpr (GENERIC) y[e] = tdnn_epilogue<ET>(p, acc[i][n][q * 4 + e], row, ch + e, b[e], sc[e], sh[e], valid);
           else y[e] = tdnn_epilogue_fast(acc[i][n][q * 4 + e], b[e], act_lo, sc[e], sh[e], valid);
         }
         uint2 pk;
@@ -299,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void grid_conv_narrow_pers_kernel(const Tdn
         float y[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          if constexpr (GENERIC) y[e] = tdnn_epilogue<true>(p, acc[i][q * 4 + e], row, wn * 32 + 8 * q + 4 * lh + e, cb[q * 4 + e], cs[q * 4 + e], ct[q * 4 + e], valid);
+          if constexpr (GENERIC) y[e] = tdnn_epilogue<ET>(p, acc[i][q * 4 + e], row, wn * 32 + 8 * q + 4 * lh + e, cb[q * 4 + e], cs[q * 4 + e], ct[q * 4 + e], valid);
           else y[e] = tdnn_epilogue_fast(acc[i][q * 4 + e], cb[q * 4 + e], act_lo, cs[q * 4 + e], ct[q * 4 + e], valid);
         }
         uint2 pk;
@@ -373,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void grid_conv_wide_kernel(const TdnnKernel
   const unsigned char *xg = reinterpret_cast<const unsigned char *>(p.x);
   const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_byte_t *)win);
   for (int piece = wave; piece < G::PIECES; piece += 4) {
-    if (p.tune & 4) break;                                            // developer aid (ASV_AMD_CONV_ABL bit 2): no window fetch
+    if (conv_abl(p) & 4) break;                                            // developer aid (ASV_AMD_CONV_ABL bit 2): no window fetch
     const int w = piece * G::RPP + lane / G::SLOTS;
     const int row = min(max(m0 - G::HALO + w, 0), p.rows - 1);
     const int src_slot = (lane % G::SLOTS) ^ (w & 15);
@@ -430,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void grid_conv_wide_kernel(const TdnnKernel
   }
 #pragma unroll 1
   for (int st = 0; st < G::STEPS; ++st) {
-    if ((p.tune & 2) && st >= 2) break;                               // developer aid (ASV_AMD_CONV_ABL bit 1): two K steps instead of all
+    if ((conv_abl(p) & 2) && st >= 2) break;                               // developer aid (ASV_AMD_CONV_ABL bit 1): two K steps instead of all
     // 64-channel chunk outermost, taps inside it: the K order of the generic tile (kernels_tdnn.hip), hence the same bits
     const int c4 = st / 9, t = st % 9;
     const int stn = st + 1 < G::STEPS ? st + 1 : st;               // the last step re-fetches its own fragments (never used)
@@ -486,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void grid_conv_wide_kernel(const TdnnKernel
         float y[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          if constexpr (GENERIC) y[e] = tdnn_epilogue<true>(p, acc[i][j][q * 4 + e], row, ch + e, b[e], sc[e], sh[e], valid);
+          if constexpr (GENERIC) y[e] = tdnn_epilogue<ET>(p, acc[i][j][q * 4 + e], row, ch + e, b[e], sc[e], sh[e], valid);
           else y[e] = tdnn_epilogue_fast(acc[i][j][q * 4 + e], b[e], act_lo, sc[e], sh[e], valid);
         }
         uint2 pk;
@@ -621,7 +629,7 @@ __global__ __launch_bounds__(256, 2) void grid_conv_s2d_kernel(const TdnnKernelP
         float y[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          if constexpr (GENERIC) y[e] = tdnn_epilogue<true>(p, acc[i][j][q * 4 + e], row, ch + e, b[e], sc[e], sh[e], valid);
+          if constexpr (GENERIC) y[e] = tdnn_epilogue<ET>(p, acc[i][j][q * 4 + e], row, ch + e, b[e], sc[e], sh[e], valid);
           else y[e] = tdnn_epilogue_fast(acc[i][j][q * 4 + e], b[e], act_lo, sc[e], sh[e], valid);
         }
         uint2 pk;
@@ -714,7 +722,7 @@ __global__ __launch_bounds__(256) void grid_conv_c1_kernel(const TdnnKernelParam
     float y[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      if constexpr (GENERIC) y[e] = tdnn_epilogue<true>(p, acc[e], row, ch + e, cb[e], cs[e], ct[e], valid);
+      if constexpr (GENERIC) y[e] = tdnn_epilogue<ET>(p, acc[e], row, ch + e, cb[e], cs[e], ct[e], valid);
       else y[e] = tdnn_epilogue_fast(acc[e], cb[e], act_lo, cs[e], ct[e], valid);
     }
     uint4 o;
@@ -742,7 +750,10 @@ size_t grid_conv_frag_elems(int cin_pad, int cout_pad32, int n_taps) { return (s
 int launch_grid_conv_narrow(const TdnnKernelParams &p0, hipStream_t s) {
   TdnnKernelParams p = p0;
   static const bool live = getenv("ASV_AMD_LIVE_TUNE") != nullptr;
+  p.tune = 0;
+#ifdef ASV_WITH_ABLATION
   p.tune = live && getenv("ASV_AMD_CONV_ABL") != nullptr ? atoi(getenv("ASV_AMD_CONV_ABL")) : 0;
+#endif
   ASV_REQUIRE(grid_conv_narrow_supported(p, true), "grid conv (narrow): unsupported layer");
   const dim3 grid(p.rows / CBM), block(256);
   const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first && p.seg_bias == nullptr &&
@@ -787,8 +798,11 @@ bool grid_conv_wide_supported(const TdnnKernelParams &p, int et) {
 
 int launch_grid_conv_wide(const TdnnKernelParams &p0, hipStream_t s) {
   TdnnKernelParams p = p0;
+  p.tune = 0;
+#ifdef ASV_WITH_ABLATION
   static const bool live = getenv("ASV_AMD_LIVE_TUNE") != nullptr;
   p.tune = live && getenv("ASV_AMD_CONV_ABL") != nullptr ? atoi(getenv("ASV_AMD_CONV_ABL")) : 0;
+#endif
   ASV_REQUIRE(grid_conv_wide_supported(p, true), "grid conv (wide): unsupported layer");
   const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first && p.seg_bias == nullptr &&
                     p.seg_scale == nullptr && p.res == nullptr;

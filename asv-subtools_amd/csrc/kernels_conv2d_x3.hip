@@ -1,0 +1,348 @@
+// The 2-D ResNet trunk's convolutions in the f32x precision mode: f32 rows in HBM, every product as THREE 16-bit matrix
+// instructions on hi / lo operand halves (w_hi x_hi + w_hi x_lo + w_lo x_hi, f32 accumulate) - the scheme of kernels_tdnn_x3.hip
+// for the grid domain.  Replaces conv3x3 / conv1x1 + eval BatchNorm (+ ReLU) of libs/nnet/resnet.py:12-20, 23-110, 352-368 in
+// the parity-grade mode, where until round 4 every grid-domain layer ran on the exact f32-input matrix instruction
+// (157 TFLOP/s peak: ResNet34-SE at 1.7 k utterances/s against 18 k in bf16).
+//
+// A [B, C, F, T] map is a [rows][C] matrix, rows = (time, frequency) positions, frequency fastest (runtime.hip): a
+// stride-1 3 x 3 convolution is nine row-offset taps dt * pitch + df, the stride-2 ones arrive as 4 backward taps over a
+// space-to-depth tensor or as 1-tap layers over an im2col tensor.  One kernel template serves all of them:
+//   * workgroup = BM output rows x BN output channels (BN = the layer's whole width up to 256), 4 waves as WM x WN, a wave owns
+//     MF x NFW accumulator fragments of 32 x 32;
+//   * K walks 32-channel chunks; per chunk the window (HLO + BM + HHI rows, all taps read it shifted) sits in LDS as ONE image
+//     [row][hi: 32 halves | lo: 32 halves] = 128 bytes per row, 16-byte slots XOR-swizzled by (row >> 1) & 7 (conflict-free
+//     ds_read_b128 for any tap shift).  The f32 rows come from HBM into registers, are split there (v_cvt_pk_f16_f32,
+//     v_fma_mix_f32: x - hi exactly, v_cvt_pk_f16_f32 again) and written to the image once per workgroup: nine taps share one
+//     split.  Two images: the loads of chunk c + 1 are issued at the top of chunk c's K loop - BEHIND the first weight prefetch,
+//     the vector-memory counter retires in order - and converted behind it; one barrier per chunk;
+//   * weights: hi / lo halves in fragment order [chunk][tap][k-group][n-fragment][hi | lo][lane][8], scaled by a power of two
+//     per layer on the host (runtime.hip x3_weight_scale), 1 KiB wave loads from L2 one (tap, k-group) step ahead;
+//   * a unit = one (NFW = 2) or two (NFW = 1) row fragments: 2 or 4 ds_read_b128 feed 6 matrix instructions; the next unit's
+//     reads are issued in front of them;
+//   * epilogue: acc / scale + bias -> [ReLU] -> folded BN, through a per-wave LDS tile to 16-byte stores of whole row pieces.
+// Every output row is a fixed-order sum over its own window: bit-identical whatever batch the utterance is extracted in.
+#include <algorithm>
+#include <cstdlib>
+
+#include "device_utils.h"
+#include "host_convert.h"
+
+namespace asv {
+namespace {
+
+constexpr int QROWB = 128;          // image row: 32 channels as [hi 64 B | lo 64 B]
+constexpr int QCH = 32;             // channels per chunk
+
+__device__ __forceinline__ int qswz(int row, int slot) { return slot ^ ((row >> 1) & 7); }
+
+template <int WM_, int WN_, int MF_, int NFW_, int HLO_, int HHI_, int NBUF_>
+struct QGeom {
+  static constexpr int WM = WM_, WN = WN_, MF = MF_, NFW = NFW_, HLO = HLO_, HHI = HHI_, NBUF = NBUF_;
+  static constexpr int BM = WM * MF * 32, BN = WN * NFW * 32;
+  static constexpr int WIN = HLO + BM + HHI;
+  static constexpr int IMG = WIN * QROWB;
+  static constexpr int NP = (WIN * 4 + 255) / 256;          // 8-channel pieces per thread and chunk
+  static constexpr int SPITCH = NFW * 32 + 4;               // floats per row of the epilogue's per-wave tile
+  static constexpr int SCR = 4 * 32 * SPITCH * 4;
+  static constexpr int MAIN = NBUF * IMG > SCR ? NBUF * IMG : SCR;
+  static constexpr int LDS = MAIN + 3 * BN * 4;
+  static constexpr int UI = NFW == 1 ? 2 : 1;               // row fragments per unit (6 matrix instructions either way)
+  static constexpr int NU = MF / UI;                        // units per (tap, k-group) step
+  static_assert(WM * WN == 4 && MF % UI == 0 && 2 * LDS <= 163840, "grid conv (f32x) geometry");
+};
+
+template <typename G, int ET>
+__global__ __launch_bounds__(256, 2) void grid_conv_x3_kernel(const TdnnKernelParams p, const int n_tiles, const int nft) {
+  constexpr int WN = G::WN, MF = G::MF, NFW = G::NFW, HLO = G::HLO, BM = G::BM, BN = G::BN, WIN = G::WIN, NP = G::NP, UI = G::UI, NU = G::NU;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int m0 = (tile / n_tiles) * BM, n0 = (tile % n_tiles) * BN;
+  const int n_taps = p.n_taps;
+  const int nchunks = (p.cin_pad + QCH - 1) / QCH;
+
+  // the epilogue's per-channel constants (bias | scale | shift of this tile's BN channels) -> LDS now, read behind the K loops
+  float *lds_par = reinterpret_cast<float *>(lds + G::MAIN);
+  for (int e = tid; e < 3 * BN; e += 256) {
+    const int which = e / BN, c = e % BN;
+    const float *src = which == 0 ? p.bias : (which == 1 ? p.scale : p.shift);
+    lds_par[e] = src != nullptr ? src[n0 + c] : (which == 1 ? 1.0f : 0.0f);
+  }
+
+  // ---- staging: f32 rows -> registers -> [hi | lo] image
+  const float *xg = reinterpret_cast<const float *>(p.x);
+  uint4 ra[NP], rb[NP];
+  auto gload = [&](int c) {
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+      const int item = it * 256 + tid, w = item >> 2, q = item & 3;
+      const int row = m0 - HLO + w, ch = c * QCH + q * 8;
+      uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
+      if (item < WIN * 4 && row >= 0 && row < p.rows && ch < p.cin_pad) {
+        const float *src = xg + (size_t)row * p.ldx + ch;
+        a = *reinterpret_cast<const uint4 *>(src);
+        b = *reinterpret_cast<const uint4 *>(src + 4);
+      }
+      ra[it] = a; rb[it] = b;
+    }
+  };
+  auto sstore = [&](int buf) {
+    unsigned char *img = lds + buf * G::IMG;
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+      const int item = it * 256 + tid, w = item >> 2, q = item & 3;
+      if (item < WIN * 4) {
+        const X3Frag f = x3_split<ET, true>(ra[it], rb[it]);
+        *reinterpret_cast<uint4 *>(img + w * QROWB + qswz(w, q) * 16) = f.hi;
+        *reinterpret_cast<uint4 *>(img + w * QROWB + qswz(w, 4 + q) * 16) = f.lo;
+      }
+    }
+  };
+
+  // ---- operands
+  struct WF { uint4 h[NFW], l[NFW]; };
+  struct XF { uint4 h[UI], l[UI]; };
+  const unsigned char *wq = reinterpret_cast<const unsigned char *>(p.wconv) + (size_t)(n0 / 32 + wn * NFW) * 2048 + (size_t)lane * 16;
+  const size_t step_stride = (size_t)nft * 2048;               // bytes per (chunk, tap, k-group) step: nft fragments x (hi, lo)
+  auto load_w = [&](int step, WF &w) {                         // step = (c * n_taps + t) * 2 + kg
+    const unsigned char *b = wq + (size_t)step * step_stride;
+#pragma unroll
+    for (int j = 0; j < NFW; ++j) {
+      w.h[j] = *reinterpret_cast<const uint4 *>(b + j * 2048);
+      w.l[j] = *reinterpret_cast<const uint4 *>(b + j * 2048 + 1024);
+    }
+  };
+  const int wrow0 = HLO + wm * (MF * 32) + lr;                 // window row of this lane in row fragment 0 at tap offset 0
+  auto load_x = [&](const unsigned char *img, int d, int kg, int u, XF &x) {
+#pragma unroll
+    for (int k = 0; k < UI; ++k) {
+      const int w = wrow0 + (u * UI + k) * 32 + d;
+      x.h[k] = *reinterpret_cast<const uint4 *>(img + w * QROWB + qswz(w, kg * 2 + lh) * 16);
+      x.l[k] = *reinterpret_cast<const uint4 *>(img + w * QROWB + qswz(w, 4 + kg * 2 + lh) * 16);
+    }
+  };
+
+  f32x16_t acc[MF][NFW];
+#pragma unroll
+  for (int i = 0; i < MF; ++i)
+#pragma unroll
+    for (int j = 0; j < NFW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  auto mma = [&](const WF &w, const XF &x, int u) {
+    // product-major: an accumulator recurs every UI * NFW = 2 instructions
+#pragma unroll
+    for (int term = 0; term < 3; ++term)
+#pragma unroll
+      for (int k = 0; k < UI; ++k)
+#pragma unroll
+        for (int j = 0; j < NFW; ++j) {
+          const uint4 a = term == 2 ? w.l[j] : w.h[j];
+          const uint4 b = term == 1 ? x.l[k] : x.h[k];
+          acc[u * UI + k][j] = mfma16<ET>(a, b, acc[u * UI + k][j]);
+        }
+  };
+
+  // ---- prologue: window of chunk 0 -> image 0, weights of step 0
+  const int v_taps = p.taps[lane < ASV_MAX_TAPS ? lane : 0];
+  WF wa, wb;
+  gload(0);
+  load_w(0, wa);
+  sstore(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+#pragma unroll 1
+  for (int c = 0; c < nchunks; ++c) {
+    const unsigned char *img = lds + (G::NBUF == 2 ? (c & 1) : 0) * G::IMG;
+    const bool more_chunks = c + 1 < nchunks;
+    XF xa, xb;
+    load_x(img, __builtin_amdgcn_readlane(v_taps, 0), 0, 0, xa);
+#pragma unroll 1
+    for (int t = 0; t < n_taps; ++t) {
+      const int step = (c * n_taps + t) * 2;
+      const int d = __builtin_amdgcn_readlane(v_taps, t);
+      const bool last_tap = t + 1 == n_taps;
+      const int dn = __builtin_amdgcn_readlane(v_taps, last_tap ? t : t + 1);
+      // k-group 0 on wa; k-group 1's fragments -> wb; at the chunk's first tap the next chunk's rows follow them into flight
+      load_w(step + 1, wb);
+      if constexpr (G::NBUF == 2) {
+        if (t == 0 && more_chunks) gload(c + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        XF &xc = (u & 1) ? xb : xa;
+        XF &xn = (u & 1) ? xa : xb;
+        if (u + 1 < NU) load_x(img, d, 0, u + 1, xn);
+        else load_x(img, d, 1, 0, xn);
+        mma(wa, xc, u);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // k-group 1 on wb; the next step's fragments (next tap, or the next chunk's first step; the very last step re-fetches
+      // itself: valid memory, never used) -> wa
+      {
+        const int next = (last_tap && !more_chunks) ? step + 1 : step + 2;
+        load_w(next, wa);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        // units alternate the two fragment sets; NU units per k-group: the set in use at the start of k-group 1 is (NU & 1)
+        XF &xc = ((NU + u) & 1) ? xb : xa;
+        XF &xn = ((NU + u) & 1) ? xa : xb;
+        if (u + 1 < NU) load_x(img, d, 1, u + 1, xn);
+        else if (!last_tap) load_x(img, dn, 0, 0, xn);          // (2 NU units per tap: the next tap starts on xa again)
+        mma(wb, xc, u);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if constexpr (G::NBUF == 2) {
+      if (more_chunks) {
+        sstore((c + 1) & 1);                                     // nobody reads that image: it was chunk c - 1's
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+    }
+  }
+
+  // ---- epilogue: acc[i][j][r] = row m0 + wm*MF*32 + i*32 + lr, channel n0 + (wn*NFW + j)*32 + 8*(r>>2) + 4*lh + (r&3)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                                   // every wave is through with the images: they become scratch
+  asm volatile("" ::: "memory");
+  float *scr = reinterpret_cast<float *>(lds) + wave * (32 * G::SPITCH);
+  const float act_lo = (p.act1 == ASV_ACT_RELU) ? 0.0f : -INFINITY;
+  const float unscale = p.w_unscale;
+  float *yg = reinterpret_cast<float *>(p.y);
+#pragma unroll
+  for (int i = 0; i < MF; ++i) {
+    const int rbase = m0 + wm * (MF * 32) + i * 32;
+    const bool valid = (p.row_valid[rbase >> 5] >> lr) & 1u;
+#pragma unroll
+    for (int j = 0; j < NFW; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int chl = (wn * NFW + j) * 32 + 8 * q + 4 * lh;
+        const float4 b4 = *reinterpret_cast<const float4 *>(lds_par + chl);
+        const float4 sc4 = *reinterpret_cast<const float4 *>(lds_par + BN + chl);
+        const float4 sh4 = *reinterpret_cast<const float4 *>(lds_par + 2 * BN + chl);
+        const float b[4] = {b4.x, b4.y, b4.z, b4.w}, sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float z = fmaxf(fmaf(acc[i][j][q * 4 + e], unscale, b[e]), act_lo) * sc[e] + sh[e];      // = tdnn_epilogue_fast for unscale = 1
+          y[e] = valid ? z : 0.0f;
+        }
+        *reinterpret_cast<float4 *>(scr + lr * G::SPITCH + j * 32 + 8 * q + 4 * lh) = make_float4(y[0], y[1], y[2], y[3]);
+      }
+    // the tile is wave-private: LDS operations of one wave complete in order
+    constexpr int SLOTS = NFW * 8;                                // float4 per row of the tile
+    constexpr int RPI = 64 / SLOTS;                               // rows per store instruction: 8 | 4
+#pragma unroll
+    for (int it = 0; it < 32 / RPI; ++it) {
+      const int frow = it * RPI + lane / SLOTS, slot = lane % SLOTS;
+      const float4 v = *reinterpret_cast<const float4 *>(scr + frow * G::SPITCH + slot * 4);
+      *reinterpret_cast<float4 *>(yg + (size_t)(rbase + frow) * p.ldy + n0 + wn * (NFW * 32) + slot * 4) = v;
+    }
+  }
+}
+
+// the nine-tap geometries (halo >= pitch + 1 of the stage's grid) and the halo-free ones (1-tap layers over im2col / space-to-depth
+// tensors); two image buffers unless the layer is a single chunk
+using Q32 = QGeom<4, 1, 2, 1, 82, 82, 1>;      // 32 -> 32, grids of <= 80 bins (halo = pitch + 1 <= 82): 256 rows, one chunk, 52.9 KiB: three workgroups per CU
+using Q64 = QGeom<2, 2, 2, 1, 48, 48, 2>;      // 64 channels out, 40-bin grid: 128 rows, 2 x 28 KiB
+using Q64P = QGeom<2, 2, 2, 1, 0, 0, 2>;
+using Q128 = QGeom<2, 2, 4, 2, 24, 24, 2>;     // 128 out, 20-bin grid: 256 rows, 2 x 38 KiB
+using Q128P = QGeom<2, 2, 4, 2, 0, 0, 2>;
+using Q256 = QGeom<1, 4, 4, 2, 16, 16, 2>;     // 256 out (per n tile), 10-bin grid: 128 rows, 2 x 20 KiB
+using Q256P = QGeom<1, 4, 4, 2, 0, 0, 2>;
+
+struct QPick { int bm, bn, hlo, hhi, id; };
+QPick pick_geom(const TdnnKernelParams &p) {
+  int lo = 0, hi = 0;
+  for (int t = 0; t < p.n_taps; ++t) { lo = std::max(lo, -p.taps[t]); hi = std::max(hi, p.taps[t]); }
+  const bool plain = lo == 0 && hi == 0;
+  if (p.cout_store == 32) return p.cin_pad == 32 ? QPick{Q32::BM, 32, Q32::HLO, Q32::HHI, 0} : QPick{0, 0, 0, 0, -1};
+  if (p.cout_store == 64) return plain ? QPick{Q64P::BM, 64, 0, 0, 2} : QPick{Q64::BM, 64, Q64::HLO, Q64::HHI, 1};
+  if (p.cout_store == 128) return plain ? QPick{Q128P::BM, 128, 0, 0, 4} : QPick{Q128::BM, 128, Q128::HLO, Q128::HHI, 3};
+  if (p.cout_store % 256 == 0) return plain ? QPick{Q256P::BM, 256, 0, 0, 6} : QPick{Q256::BM, 256, Q256::HLO, Q256::HHI, 5};
+  return QPick{0, 0, 0, 0, -1};
+}
+
+}  // namespace
+
+// can the layer be packed for / run by the f32x grid kernel?  (shape only: the weights come in p.wconv)
+bool grid_conv_x3_shape_ok(int cin_pad, int cout_store) {
+  if (cin_pad % QCH != 0 || cin_pad < QCH) return false;
+  if (cout_store == 32) return cin_pad == 32;
+  return cout_store == 64 || cout_store == 128 || (cout_store > 0 && cout_store % 256 == 0);
+}
+
+size_t grid_conv_x3_frag_elems(int cin_pad, int cout_store, int n_taps) {
+  return (size_t)(cin_pad / QCH) * n_taps * 2 * (cout_store / 32) * 2 * 512;
+}
+
+// [chunk][tap][k-group][n-fragment][hi | lo][lane = (k half lh, channel lr)][8]: channel nf * 32 + lr, k = chunk * 32 + kg * 16 + lh * 8 + e;
+// every weight multiplied by `scale` (a power of two) first; lo = w * scale - hi
+void pack_grid_conv_x3_frags(const float *w, int out_ch, int in_ch, int tot_ctx, int left_ctx, const int *taps, int n_taps, int cin_pad, int cout_store,
+                             int et, float scale, uint16_t *dst) {
+  const int nft = cout_store / 32;
+  const size_t n = grid_conv_x3_frag_elems(cin_pad, cout_store, n_taps);
+  for (size_t i = 0; i < n; ++i) dst[i] = 0;
+  for (int co = 0; co < out_ch; ++co)
+    for (int t = 0; t < n_taps; ++t) {
+      const int k = taps[t] - left_ctx;
+      for (int ci = 0; ci < in_ch; ++ci) {
+        const int c = ci / QCH, kg = (ci % QCH) / 16, lh = (ci % 16) / 8, e = ci % 8, nf = co / 32, lr = co % 32;
+        const size_t frag = ((((size_t)c * n_taps + t) * 2 + kg) * nft + nf) * 2;
+        const size_t at = (size_t)(lh * 32 + lr) * 8 + e;
+        const float v = w[((size_t)co * in_ch + ci) * tot_ctx + k] * scale;
+        const uint16_t h = et == ET_F16 ? f32_to_f16_host(v) : f32_to_bf16_host(v);
+        const float hv = et == ET_F16 ? f16_to_f32_host(h) : bf16_to_f32_host(h);
+        dst[frag * 512 + at] = h;
+        dst[(frag + 1) * 512 + at] = et == ET_F16 ? f32_to_f16_host(v - hv) : f32_to_bf16_host(v - hv);
+      }
+    }
+}
+
+bool grid_conv_x3_supported(const TdnnKernelParams &p) {
+  if (p.wconv == nullptr || p.x2 != nullptr || p.ksplit > 1 || !grid_conv_x3_shape_ok(p.cin_pad, p.cout_store)) return false;
+  const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first && p.seg_bias == nullptr &&
+                    p.seg_scale == nullptr && p.res == nullptr;
+  if (!fast || (p.x3_terms & 7) != 7 || !(p.w_unscale > 0.0f)) return false;
+  const QPick g = pick_geom(p);
+  if (g.id < 0 || p.rows % g.bm != 0 || p.ldx % 4 != 0 || p.ldy % 4 != 0) return false;
+  for (int t = 0; t < p.n_taps; ++t)
+    if (-p.taps[t] > g.hlo || p.taps[t] > g.hhi) return false;
+  if (g.id == 0 && p.cin_pad != QCH) return false;                 // the one-image geometry holds one chunk
+  return true;
+}
+
+int launch_grid_conv_x3(const TdnnKernelParams &p, hipStream_t s) {
+  ASV_REQUIRE(grid_conv_x3_supported(p), "grid conv (f32x): unsupported layer");
+  ASV_REQUIRE(p.x3_et == ET_BF16 || p.x3_et == ET_F16, "grid conv (f32x): split type %d", p.x3_et);
+  const QPick g = pick_geom(p);
+  const int m_tiles = p.rows / g.bm, n_tiles = p.cout_store / g.bn, nft = p.cout_store / 32;
+  const dim3 grid(m_tiles * n_tiles), block(256);
+#define ASV_QCONV(GEO) do { if (p.x3_et == ET_F16) hipLaunchKernelGGL((grid_conv_x3_kernel<GEO, ET_F16>), grid, block, 0, s, p, n_tiles, nft); \
+                            else hipLaunchKernelGGL((grid_conv_x3_kernel<GEO, ET_BF16>), grid, block, 0, s, p, n_tiles, nft); } while (0)
+  switch (g.id) {
+    case 0: ASV_QCONV(Q32); break;
+    case 1: ASV_QCONV(Q64); break;
+    case 2: ASV_QCONV(Q64P); break;
+    case 3: ASV_QCONV(Q128); break;
+    case 4: ASV_QCONV(Q128P); break;
+    case 5: ASV_QCONV(Q256); break;
+    default: ASV_QCONV(Q256P); break;
+  }
+#undef ASV_QCONV
+  ASV_HIP_CHECK(hipGetLastError());
+  return ASV_OK;
+}
+
+}  // namespace asv

@@ -87,7 +87,7 @@ __device__ __forceinline__ void chain_glds16_s(const void *sbase, uint32_t voff,
 // POOLV: pooling epilogue of the last layer.  0 = first version (per-lane segment tracking, register-by-register seams);
 //        1 = run-based (default): every utterance inside a 32-frame fragment is one masked run over all 16 registers,
 //            packed f32 arithmetic (v_pk_add_f32 / v_pk_fma_f32).  ASV_AMD_CHAIN_POOLV selects at launch (A/B aid).
-// ABL (developer aid, ASV_AMD_CHAIN_ABL with ASV_AMD_LIVE_TUNE=1; results are garbage): 1 = the last layer without its pooling
+// ABL (developer aid: instantiated in the developer build libasv_amd_dev.so only, ASV_AMD_CHAIN_ABL; results are garbage): 1 = the last layer without its pooling
 //        epilogue (what do the K loops cost on their own), 2 = the epilogue's arithmetic without its global loads / stores;
 //        3 (ASV_AMD_CHAIN_DBG >= 3; results valid) = the production kernel + stamps inside every wave's first pooling epilogue;
 //        4 (results valid) = the last layer in lockstep: a workgroup barrier behind every unit's K loop and behind every pooling
@@ -600,24 +600,31 @@ int launch_tdnn_chain(const TdnnChainParams &p, hipStream_t s) {
   ASV_REQUIRE(p.first.wfrag && p.last.wfrag && p.last.bias && p.n_mid >= 0 && p.n_mid <= 2 && p.last.cout_pad % 64 == 0, "tdnn(chain): incomplete layer description");
   ASV_REQUIRE(p.pool_partial && p.row_seg && p.pool_slots >= 1, "tdnn(chain): the last layer feeds the fused pooling (partials / row map missing)");
   for (int t = 0; t < p.n_taps; ++t) ASV_REQUIRE(p.taps[t] >= -kHalo && p.taps[t] <= kHalo, "tdnn(chain): tap offset %d exceeds the %d-frame halo", p.taps[t], kHalo);
-  // Developer switches are read ONCE per process; with ASV_AMD_LIVE_TUNE=1 (tools/chain_ab.py: in-process interleaved A/B) at
-  // every launch.
+  const dim3 grid(p.rows / CM), block(512);
+#ifdef ASV_WITH_ABLATION
+  // Developer build only (libasv_amd_dev.so, `make dev`): the ablation instantiations (results are garbage), the first pooling
+  // epilogue and the four-wave kernel.  The switches are read ONCE per process; with ASV_AMD_LIVE_TUNE=1 (tools/chain_ab.py:
+  // in-process interleaved A/B) at every launch.  The product library has none of this code: no environment variable reaches it.
   static const bool live = getenv("ASV_AMD_LIVE_TUNE") != nullptr;
   auto read_int = [](const char *name) { const char *v = getenv(name); return v != nullptr ? atoi(v) : -1; };
   static const int poolv0 = read_int("ASV_AMD_CHAIN_POOLV"), abl0 = read_int("ASV_AMD_CHAIN_ABL");
   const int poolv = live ? read_int("ASV_AMD_CHAIN_POOLV") : poolv0, abl = live ? read_int("ASV_AMD_CHAIN_ABL") : abl0;
-  // ASV_AMD_CHAIN_WAVES=4: the 4-wave form (kernels_tdnn_chain4.hip) where it applies.  Measured 0 - 1 % SLOWER than this kernel
-  // (profiles/r3k_*): kept as the reproducible A/B of that design, not used by default.
+  // ASV_AMD_CHAIN_WAVES=4: the 4-wave form (tools/kernels_tdnn_chain4.hip) where it applies.  Measured 0 - 1 % SLOWER than this
+  // kernel (profiles/r3k_*): kept as the reproducible A/B of that design.
   static const int waves0 = read_int("ASV_AMD_CHAIN_WAVES");
   const int waves = live ? read_int("ASV_AMD_CHAIN_WAVES") : waves0;
   if (waves == 4 && abl <= 0 && poolv != 0 && !(p.dbg != nullptr && p.dbg_fine) && tdnn_chain4_supported(p)) return launch_tdnn_chain4(p, s);
-  const dim3 grid(p.rows / CM), block(512);
+  if (p.et == ET_BF16 && !(p.dbg != nullptr && p.dbg_fine) && (abl == 1 || abl == 2 || (abl == 4 && p.last.cout_pad % 512 == 0) || poolv == 0)) {
+    if (abl == 1) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_BF16, 1>), grid, block, 0, s, p);
+    else if (abl == 2) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_BF16, 2>), grid, block, 0, s, p);
+    else if (abl == 4) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_BF16, 4>), grid, block, 0, s, p);   // every wave runs the same number of units
+    else hipLaunchKernelGGL(tdnn_chain_kernel<0>, grid, block, 0, s, p);
+    ASV_HIP_CHECK(hipGetLastError());
+    return ASV_OK;
+  }
+#endif
   if (p.et == ET_F16) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_F16>), grid, block, 0, s, p);
-  else if (p.dbg != nullptr && p.dbg_fine) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_BF16, 3>), grid, block, 0, s, p);
-  else if (abl == 1) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_BF16, 1>), grid, block, 0, s, p);
-  else if (abl == 2) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_BF16, 2>), grid, block, 0, s, p);
-  else if (abl == 4 && p.last.cout_pad % 512 == 0) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_BF16, 4>), grid, block, 0, s, p);   // every wave runs the same number of units
-  else if (poolv == 0) hipLaunchKernelGGL(tdnn_chain_kernel<0>, grid, block, 0, s, p);
+  else if (p.dbg != nullptr && p.dbg_fine) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_BF16, 3>), grid, block, 0, s, p);   // stamps only: results valid
   else hipLaunchKernelGGL(tdnn_chain_kernel<1>, grid, block, 0, s, p);
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;

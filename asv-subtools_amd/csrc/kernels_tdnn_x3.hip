@@ -71,43 +71,7 @@ __device__ __forceinline__ void x3_glds16(const void *gsrc, uint32_t lds_dst) {
       : "memory");
 }
 
-struct X3Frag { uint4 hi, lo; };     // 8 k values of one lane: the two 16-bit halves
-
-// 8 f32 -> hi + lo in the 16-bit type ET (x - hi is exact in f32: hi keeps the leading 8 / 11 significand bits of x).
-// ET_BF16: 16 significant bits together, the whole f32 exponent range.  ET_F16: 22 bits together for |x| >= 2^-2 (lo is a
-// normal half there), an absolute error <= 2^-25 below (lo a subnormal half; the matrix cores keep subnormal inputs - checked
-// on the device by tests/test_gpu_kernels.py), |x| <= 65504.  WITH_LO = false: one rounding, no second half (the measured
-// two-instruction variants).
-template <int ET, bool WITH_LO>
-__device__ __forceinline__ X3Frag x3_split(const uint4 a, const uint4 b) {
-  const float v[8] = {__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w),
-                      __uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w)};
-  uint32_t h[4], l[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    h[k] = pack_h16x2<ET>(v[2 * k], v[2 * k + 1]);
-    l[k] = 0u;
-    if constexpr (WITH_LO) {
-      float r0, r1;
-      if constexpr (ET == ET_F16) {
-        // x - hi in ONE mixed-precision fma per value, straight from the packed halves (v_fma_mix_f32: hi is read as half, -1 and x
-        // as f32): the unpacking conversions (two v_cvt_f32_f16 per pair) were a third of this loop's VALU work, and the VALU work -
-        // ~4 operations per matrix instruction - is what this kernel's K loop is bound by
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h[k]), "v"(v[2 * k]));
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h[k]), "v"(v[2 * k + 1]));
-      } else {
-        float h0, h1;
-        unpack_h16x2<ET>(h[k], h0, h1);
-        r0 = v[2 * k] - h0; r1 = v[2 * k + 1] - h1;
-      }
-      l[k] = pack_h16x2<ET>(r0, r1);
-    }
-  }
-  X3Frag f;
-  f.hi = make_uint4(h[0], h[1], h[2], h[3]);
-  f.lo = make_uint4(l[0], l[1], l[2], l[3]);
-  return f;
-}
+// X3Frag / x3_split (8 f32 -> the hi and lo halves in the 16-bit type): device_utils.h, shared with kernels_conv2d_x3.hip
 
 // ET: the 16-bit type of the operand halves; TERMS: bit 0 = w_hi x_hi, bit 1 = w_hi x_lo, bit 2 = w_lo x_hi
 // SHARED (round 3, 128-row geometry): the f32 window of a chunk is split into its [hi | lo] image ONCE per workgroup - every
@@ -512,6 +476,7 @@ static int x3_tile_rows(const TdnnKernelParams &p) {
   static const bool live = getenv("ASV_AMD_LIVE_TUNE") != nullptr;
   const int f = live ? (getenv("ASV_AMD_X3_TILE") != nullptr ? atoi(getenv("ASV_AMD_X3_TILE")) : 0) : forced;
   if (f == 64 || f == 128) return (f == 128 && p.rows % 128 != 0) ? 64 : f;
+  if (p.x3_tile == 128 && p.rows % 128 == 0) return 128;
   const long long t128 = (long long)(p.rows / 128) * (round_up(p.cout_store, XBN) / XBN);
   return (p.rows % 128 == 0 && t128 >= 384) ? 128 : 64;
 }

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(UW * 64) void utts_gemm_kernel(const TdnnKernelPara
     if (ch < p.cout_store) {
       const bool valid = (p.row_valid[row >> 5] >> (row & 31)) & 1u;
       const float scale = p.scale ? p.scale[ch] : 1.0f, shift = p.shift ? p.shift[ch] : 0.0f;
-      const float e = tdnn_epilogue<false>(p, s, row, ch, p.bias[ch], scale, shift, valid);
+      const float e = tdnn_epilogue<ET_F32>(p, s, row, ch, p.bias[ch], scale, shift, valid);
       reinterpret_cast<float *>(p.y)[(size_t)row * p.ldy + ch] = e;
       if (p.final_out != nullptr && valid && ch < p.final_ld) {
         // for_extract_embedding's weighted mean over ONE chunk (framework.py:44-52), bit for bit what combine_kernel does

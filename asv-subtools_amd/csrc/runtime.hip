@@ -515,6 +515,15 @@ int asv_net_add_tdnn(asv_net_t *net, const asv_tdnn_desc_t *d) {
       if ((rc = dev_upload(net, hi.data(), hi.size() * 2, &op.wfrag))) return rc;
       if ((rc = dev_upload(net, lo.data(), lo.size() * 2, &op.wlo))) return rc;
     }
+    if (net->x3() && !op.utts && net->domains[dom].kind == 2 && grid_conv_x3_shape_ok(op.cin_pad, op.cout_store) && (net->flags & ASV_FLAG_SMALL_TILES) == 0) {
+      // f32x mode, grid domain (the 2-D ResNet trunk): hi / lo halves in the fragment order of kernels_conv2d_x3.hip, scaled
+      // by the layer's power of two for the half-precision split
+      std::vector<uint16_t> frags(grid_conv_x3_frag_elems(op.cin_pad, op.cout_store, d->n_taps));
+      op.w_scale = net->x3_et() == ET_F16 ? x3_weight_scale(d->weight, (size_t)d->out_ch * d->in_ch * d->w_tot_context) : 1.0f;
+      pack_grid_conv_x3_frags(d->weight, d->out_ch, d->in_ch, d->w_tot_context, d->w_left_context, d->taps, d->n_taps, op.cin_pad, op.cout_store, net->x3_et(),
+                              op.w_scale, frags.data());
+      if ((rc = dev_upload(net, frags.data(), frags.size() * 2, &op.wconv))) return rc;
+    }
     if (conv2d_pack) {
       // 3x3 trunk convolutions with 32 / 64 channels: fragment order of kernels_conv2d.hip,
       // [tap][k-group][n-fragment][lane = (k half lh, channel lr)][8], k = kg * 16 + lh * 8 + e
@@ -1104,6 +1113,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         TdnnKernelParams p;
         memset(&p, 0, sizeof(p));
         p.et = et; p.x3_et = net->x3_et(); p.x3_terms = net->x3_terms(); p.w_unscale = 1.0f / op.w_scale;
+        p.x3_tile = (net->flags & ASV_FLAG_X3_TILE128) ? 128 : 0;
         p.x = view(c, d.in_buf, d.in_ch_off); p.ldx = net->bufs[d.in_buf].ld;
         if (d.in2_buf >= 0) { p.x2 = view(c, d.in2_buf, d.in2_ch_off); p.ldx2 = net->bufs[d.in2_buf].ld; }
         p.w = op.w; p.bias = op.bias; p.scale = op.scale; p.shift = op.shift;
@@ -1261,6 +1271,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         const bool narrow_conv = !use_ref && net->domains[domid].kind == 2 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && grid_conv_narrow_supported(p, et);
         const bool wide_conv = !use_ref && net->domains[domid].kind == 2 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && grid_conv_wide_supported(p, et);
         const bool s2d_conv = !use_ref && net->domains[domid].kind == 2 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && grid_conv_s2d_supported(p, et);
+        const bool x3_conv = !use_ref && net->x3() && net->domains[domid].kind == 2 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && grid_conv_x3_supported(p);
         if (!use_ref && !big3 && op.utts && !utts_kernel) {
           // pooled-domain layers have one row per utterance (M is tiny, K is large): slice K over more
           // workgroups.  The slice count depends on K only, never on the batch, so an utterance's
@@ -1301,6 +1312,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
           // the bf16 split here would be the largest error left in the f32x mode (< 0.3 % of the FLOPs: +1 % of an f32x step)
           rc = launch_utts_gemm(p, bp.segments, net->frames_h16(), c.s);
         }
+        else if (x3_conv) rc = launch_grid_conv_x3(p, c.s);
         else if (narrow_conv) rc = launch_grid_conv_narrow(p, c.s);
         else if (wide_conv) rc = launch_grid_conv_wide(p, c.s);
         else if (s2d_conv) rc = launch_grid_conv_s2d(p, c.s);

@@ -13,7 +13,7 @@ import os
 ASV_OK = 0
 PREC_F32, PREC_BF16, PREC_F32X, PREC_F16 = 0, 1, 2, 3
 FLAG_REF_KERNELS, FLAG_NO_FUSE, FLAG_SMALL_TILES, FLAG_BIG_V2, FLAG_NO_CHAIN = 1, 2, 4, 8, 16
-FLAG_X3_SPLIT_BF16, FLAG_X3_SPLIT_F16, FLAG_X3_NO_XLO, FLAG_X3_NO_WLO = 32, 64, 128, 256
+FLAG_X3_SPLIT_BF16, FLAG_X3_SPLIT_F16, FLAG_X3_NO_XLO, FLAG_X3_NO_WLO, FLAG_X3_TILE128 = 32, 64, 128, 256, 512
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
 DOMAIN_FRAMES, DOMAIN_UTTS = 0, 1
 MAX_TAPS = 9

@@ -55,10 +55,12 @@ def gather_embeddings(local, local_indices, shards, group=None):
     Returns [n_total, E] in original utterance order on every rank."""
     import torch
     import torch.distributed as dist
-    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    inited = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if inited else 1
     n_total = int(sum(len(s) for s in shards))
     E = local.shape[1]
-    if world == 1:
+    if not inited:                       # no process group: a plain single-process run.  With one, the collective runs at any world
+                                         # size, 1 included (the one-GPU check that RCCL loads and delivers: tests/test_gpu_rccl.py)
         out = torch.empty((n_total, E), dtype=local.dtype, device=local.device)
         out[torch.as_tensor(np.asarray(local_indices), device=local.device)] = local
         return out
@@ -82,7 +84,7 @@ def _agree_or_raise(err, embed_dim, device, group, rank, world):
     import torch
     import torch.distributed as dist
     flag = torch.tensor([1 if err is not None else 0, int(embed_dim)], dtype=torch.int64, device=device if device is not None else "cpu")
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
     failed, width = (int(v) for v in flag.cpu().tolist())
     if err is not None:

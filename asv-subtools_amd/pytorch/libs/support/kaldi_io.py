@@ -303,8 +303,21 @@ def read_vec_int(file_or_fd):
 # ------------------------------------------------------------------------------ matrices
 
 def _read_compressed_mat(fd, fmt, chunk=None):
-    """Kaldi CompressedMatrix 'CM ' (per-column 4-point piecewise-linear uint8 quantiser)."""
-    assert fmt == "CM ", "The formats CM2, CM3 are not supported..."
+    """Kaldi CompressedMatrix: 'CM ' (per-column 4-point piecewise-linear uint8 quantiser - the one format the reference's
+    reader decodes, kaldi_io.py:527-569), and the two header-only formats of Kaldi's compressed-matrix.cc, which the reference
+    refuses: 'CM2' (kTwoByte: row-major uint16, value = min + range * u / 65535) and 'CM3' (kOneByte: row-major uint8,
+    value = min + range * u / 255).  All three share the 16-byte GlobalHeader behind the token."""
+    if fmt in ("CM2", "CM3"):
+        assert _read_exact(fd, 1) == b" "                 # the space that ends the 3-letter token
+        gmin, grange, rows, cols = struct.unpack("<ffii", _read_exact(fd, 16))
+        width, dt, top = (2, np.uint16, 65535.0) if fmt == "CM2" else (1, np.uint8, 255.0)
+        q = np.frombuffer(_read_exact(fd, rows * cols * width), dtype=dt).reshape(rows, cols).astype(np.float32)
+        mat = np.float32(gmin) + q * np.float32(np.float64(np.float32(grange)) * (1.0 / top))    # compressed-matrix.cc: float increment = range * (1.0 / 65535.0)
+        if chunk is not None:
+            mat = mat[int(chunk[0]):int(chunk[1]) + 1]
+        return mat
+    if fmt != "CM ":
+        raise UnknownMatrixHeader("The header contained '%s'" % fmt)
     gmin, grange, rows, cols = struct.unpack("<ffii", _read_exact(fd, 16))
     pct = np.frombuffer(_read_exact(fd, cols * 8), dtype=np.uint16).reshape(cols, 4).astype(np.float32)
     pct = pct * np.float32(grange) * np.float32(1.52590218966964e-05) + np.float32(gmin)

@@ -253,7 +253,13 @@ def run_sharded(args, model, max_chunk, verbose):
     w = kaldi_io.open_or_fd(args.vectors_wspecifier, "wb") if rank == 0 else None
     try:
         with torch.cuda.device(dev):
-            return extract_sharded_scp(extract_batch, entries, lengths, w, args.batch_frames, args.batch_utts, verbose, device=dev)
+            n = extract_sharded_scp(extract_batch, entries, lengths, w, args.batch_frames, args.batch_utts, verbose, device=dev)
+        if rank == 0 and dist.is_initialized():
+            with open("/proc/self/maps") as f:
+                rccl = "librccl" in f.read()
+            print("Sharded over {0} rank(s); embeddings collected by all_gather_into_tensor, backend {1} (librccl mapped: {2}).".format(
+                dist.get_world_size(), dist.get_backend(), rccl))
+        return n
     finally:
         if w is not None:
             w.close()
@@ -281,8 +287,16 @@ def main(argv=None):
             if args.gpu_id == "":
                 args.gpu_id = str(local_rank)                               # one process per GPU
             torch.cuda.set_device(int(args.gpu_id))
-            if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", int(args.gpu_id)))   # "nccl" is RCCL on ROCm
+            # the process group exists at every world size, 1 included (under torch.distributed.run --nproc-per-node 1 or without
+            # a launcher): the collection step is then always RCCL's all-gather - one code path, exercised on a single GPU too
+            if "RANK" not in os.environ or "WORLD_SIZE" not in os.environ:
+                os.environ["RANK"], os.environ["WORLD_SIZE"] = "0", "1"
+            if "MASTER_PORT" not in os.environ:
+                import socket
+                with socket.socket() as sock:
+                    sock.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", int(args.gpu_id)))   # "nccl" is RCCL on ROCm
 
         model = utils.create_model_from_py(model_blueprint, model_creation)
         model.load_state_dict(torch.load(args.model_path, map_location="cpu"), strict=False)

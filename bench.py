@@ -191,19 +191,24 @@ def main():
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dry = args.dry_run
+    # Under a launcher (torch.distributed.run sets RANK / WORLD_SIZE / MASTER_PORT) the process group is initialised and the
+    # all-gather runs at ANY world size, 1 included: `python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` is the
+    # one-GPU proof that RCCL loads and moves the embeddings (tests/test_gpu_rccl.py).  Plain `python bench.py` stays collective-free.
+    dist_on = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
     if args.backend == "gloo" and not dry:
         sys.exit("bench.py: --backend gloo is the CPU dry run of the multi-rank control flow: pass --dry-run")
     if dry:
         dev = torch.device("cpu")
-        if world > 1:
+        if dist_on:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group(backend="gloo")
     else:
         assert torch.cuda.is_available(), "bench.py needs a ROCm device"
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
-        if world > 1:
+        if dist_on:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC for RCCL on these hosts
             dist.init_process_group(backend="nccl", device_id=dev)      # "nccl" is RCCL on ROCm
 
     def dev_sync():
@@ -280,7 +285,7 @@ def main():
                     pending[k].wait()
                     pending[k] = None
             dev_sync()
-            if world > 1:
+            if dist_on:
                 dist.barrier()
                 dev_sync()
 
@@ -295,7 +300,7 @@ def main():
                 step()
             barrier()
             dt = time.perf_counter() - t0
-            if world > 1:
+            if dist_on:
                 t = torch.tensor([dt], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt = float(t.item())
@@ -337,6 +342,10 @@ def main():
             barrier()
             want = torch.cat([DryRunWorkload(args, B, wl.T, r).eng.extract_device(DryRunWorkload(args, B, wl.T, r).feats, wl.offsets) for r in range(world)])
             gather_ok = all(bool(torch.equal(g, want)) for g in gathered)
+        elif collective:
+            # on the device: this rank's block of what the last all-gathers delivered equals its own embeddings, bit for bit
+            barrier()
+            gather_ok = all(bool(torch.equal(gathered[k][rank * B:(rank + 1) * B], outs[k])) for k in range(nbuf) if counter[0] > k)
         allr = sorted(dts + dts_sampled)
         med = allr[len(allr) // 2]
         rec = {"value": round(world * B * steps / med, 1), "ms_per_step": round(1e3 * med / steps, 4), "repeats": len(allr),
@@ -482,11 +491,11 @@ def main():
     if args.streams is None:
         args.streams = 2 if (not dry and not args.from_wav and not args.per_op and args.precision.split("-")[0] not in ("f32x", "f32")) else 1
     wl2 = [Workload(args, args.model, args.precision, args.batch, args.frames, rank, dev, lengths=lengths) for _ in range(args.streams - 1)] if (args.streams >= 2 and not dry) else None
-    head = measure(wl, args.steps, args.warmup, args.min_seconds, not args.no_profile and not dry and wl2 is None, world > 1, per_op=args.per_op, from_wav=args.from_wav, wl2=wl2)
+    head = measure(wl, args.steps, args.warmup, args.min_seconds, not args.no_profile and not dry and wl2 is None, dist_on, per_op=args.per_op, from_wav=args.from_wav, wl2=wl2)
     single = None
     if wl2 is not None:
         # the kernel-level figures (roofline: hipEvents around the GEMM launches of ONE stream) come from a single-stream pass
-        single = measure(wl, args.steps, 2, min(args.min_seconds, 0.6), not args.no_profile, world > 1)
+        single = measure(wl, args.steps, 2, min(args.min_seconds, 0.6), not args.no_profile, dist_on)
         if "roofline" in single:
             head["roofline"] = single["roofline"]
     res = {
@@ -499,7 +508,7 @@ def main():
         "config": {"workload": "%s: %s, %d-dim fbank, %d utterances x %s frames per GPU per step, "
                                "%s resident in HBM, f32 embeddings out%s" % (wl.title, wl.creation, wl.D, wl.B, ("%d" % wl.T) if not args.lengths else "U[%s]" % args.lengths,
                                                                              "16-bit PCM (fbank + CMN computed on the device in every step)" if args.from_wav else "features",
-                                                                             ", + RCCL all-gather of embeddings" if world > 1 else ""),
+                                                                             ", + RCCL all-gather of embeddings" if dist_on else ""),
                    "global_batch_utts": world * wl.B, "frames_per_utt": wl.T if not args.lengths else round(wl.frames_total / wl.B, 1),
                    "parallelism": "utterance shards x%d" % world},
         "timing": {"regions": head["repeats"], "steps_per_region": args.steps, "timed_seconds": head["timed_seconds"], "value_from": "median region",
@@ -511,6 +520,8 @@ def main():
         res["ms_per_step_single_stream"] = single["ms_per_step"]
     if wl2 is not None:
         res["config"]["streams"] = "%d engines on %d HIP streams, consecutive steps rotate over them (software pipelining across batches; every step is a full pass)" % (args.streams, args.streams)
+    if dist_on and not dry:
+        res["collective"] = {"op": "all_gather_into_tensor", "backend": dist.get_backend(), "world": world, "verified": head.get("gather_verified")}
     if dry:
         res["dry_run"] = True
         if "gather_verified" in head:
@@ -629,7 +640,7 @@ def main():
                                            "calls (dense masked conv1d, in-place ReLU, eval batch_norm, two-pass pooling) and is pinned to the reference's outputs"}
     if rank == 0:
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

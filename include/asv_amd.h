@@ -74,6 +74,8 @@ int         asv_device_count(int *count);
  * that "two matrix instructions per product are not enough" is a measured statement, DESIGN.md "Precision modes") */
 #define ASV_FLAG_X3_NO_XLO   128u  /* activations rounded to one 16-bit value (no w_hi*x_lo product) */
 #define ASV_FLAG_X3_NO_WLO   256u  /* weights rounded to one 16-bit value (no w_lo*x_hi product)     */
+#define ASV_FLAG_X3_TILE128  512u  /* ASV_PREC_F32X: the split kernel's 128-row tiles whatever the batch size (by default batches too small to
+                                    * fill the chip with them take its 64-row tiles); same results to the last bit of the f32 sums' order */
 
 #define ASV_ACT_NONE    0
 #define ASV_ACT_RELU    1

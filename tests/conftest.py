@@ -9,8 +9,9 @@ for p in (REPO, PKG, os.path.dirname(os.path.abspath(__file__))):
     if p not in sys.path:
         sys.path.insert(0, p)
 os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
-# the library reads its developer switches (kernel variants for A/B) once per process; the tests flip them between launches
-os.environ.setdefault("ASV_AMD_LIVE_TUNE", "1")
+# ASV_AMD_LIVE_TUNE is NOT set here: the suite exercises the library as production runs it (developer switches read once per
+# process; the product library has no ablation code at all).  The kernel variants of the developer build are tested by
+# tests/test_gpu_devlib.py in a subprocess of its own.
 
 
 def pytest_configure(config):

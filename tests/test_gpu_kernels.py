@@ -71,7 +71,6 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", CASES, ids=lambda c: "%dx%d_ctx%s" % (c[0], c[1], "_".join(map(str, c[2]))))
 def _mode_args(mode):
     """test mode name -> (precision id, flags) of the C ABI"""
     from libs.amd import capi
@@ -80,6 +79,8 @@ def _mode_args(mode):
     flags = capi.FLAG_REF_KERNELS if opt == "ref" else 0
     if base == "f32xb":
         flags |= capi.FLAG_X3_SPLIT_BF16
+    if base == "f32x128":
+        flags |= capi.FLAG_X3_TILE128            # small batches take the 64-row geometry of the split kernel by themselves
     return prec, flags
 
 
@@ -90,10 +91,8 @@ MODE_TOL = {"bf16": 2e-2, "f16": 2.5e-3, "f32xb": 2e-5, "f32x": 3e-6, "f32x128":
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "%dx%d_ctx%s" % (c[0], c[1], "_".join(map(str, c[2]))))
 @pytest.mark.parametrize("mode", ["f32_mfma", "f32_ref", "bf16_mfma", "bf16_ref", "f16_mfma", "f16_ref", "f32x_mfma", "f32xb_mfma", "f32x128_mfma"])
-def test_tdnn_layer_vs_oracle(case, mode, monkeypatch):
+def test_tdnn_layer_vs_oracle(case, mode):
     cin, cout, ctx, lens = case
-    # small batches take the 64-row geometry of the split kernel by themselves; f32x128 forces its 128-row one
-    monkeypatch.setenv("ASV_AMD_X3_TILE", "128" if mode.startswith("f32x128") else "0")
     r = np.random.RandomState(cin * 7 + cout)
     offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
     x = r.randn(int(offsets[-1]), cin).astype(np.float32)

@@ -345,3 +345,27 @@ def test_matrix_rows_reads_compressed_headers_and_scp_ranges(tmp_path):
             f.write(b"\0B" + tag + struct.pack("<ffii", 0.0, 1.0, 11, 4))
         assert X.matrix_rows("%s:%d" % (p, off)) == 11
         assert X.matrix_rows("%s:%d[3:9]" % (p, off)) == 7
+
+
+def test_read_mat_decodes_the_header_only_compressed_formats(tmp_path):
+    """matrix_rows accepted CM2 / CM3 entries that read_mat then refused on one rank during the load.  Both are decoded
+    now (Kaldi compressed-matrix.cc: kTwoByte / kOneByte - row-major integers behind the GlobalHeader, value = min + range * u / top);
+    the reference's reader stops at an assert for them (kaldi_io.py:531)."""
+    import struct
+    from libs.support import kaldi_io as K
+    r = np.random.RandomState(5)
+    for tag, dt, top in ((b"CM2 ", np.uint16, 65535.0), (b"CM3 ", np.uint8, 255.0)):
+        q = r.randint(0, int(top) + 1, size=(6, 5)).astype(dt)
+        gmin, grange = np.float32(-3.25), np.float32(7.5)
+        p = tmp_path / ("m_%s.ark" % tag.decode().strip())
+        with open(p, "wb") as f:
+            f.write(b"utt ")
+            off = f.tell()
+            f.write(b"\0B" + tag + struct.pack("<ffii", gmin, grange, 6, 5) + q.tobytes())
+        want = (gmin + q.astype(np.float32) * np.float32(np.float64(grange) / top)).astype(np.float32)
+        got = K.read_mat("%s:%d" % (p, off))
+        assert got.dtype == np.float32 and got.shape == (6, 5)
+        assert np.allclose(got, want, rtol=0, atol=1e-6)
+        assert got.min() >= gmin - 1e-6 and got.max() <= gmin + grange + 1e-6
+        ((key, m),) = list(K.read_mat_ark(str(p)))
+        assert key == "utt" and np.array_equal(m, got)

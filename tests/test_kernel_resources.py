@@ -1,6 +1,6 @@
 """Build-time properties of the hand-allocated kernel (no GPU needed: hipcc cross-compiles gfx950).
 
-kernels_tdnn_chain4.hip keeps its 256 accumulator registers in AGPRs that the COMPILER does not know about (every access is inline
+csrc/tools/kernels_tdnn_chain4.hip (developer build only) keeps its 256 accumulator registers in AGPRs that the COMPILER does not know about (every access is inline
 assembly naming the registers).  That is only sound while hipcc itself puts nothing there: no spills (it parks spilled VGPRs in
 free AGPRs first) and no AGPR operand outside the assembly blocks."""
 import os
@@ -18,7 +18,7 @@ HIPCC = "/opt/rocm/bin/hipcc"
 def test_chain4_kernel_has_no_spills_and_no_compiler_owned_agprs(tmp_path):
     out = tmp_path / "chain4.s"
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(REPO, "include"), "-I" + CSRC, "-Xclang", "-target-feature", "-Xclang",
-           "-packed-fp32-ops", "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o", str(out), os.path.join(CSRC, "kernels_tdnn_chain4.hip")]
+           "-packed-fp32-ops", "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o", str(out), "-DASV_WITH_ABLATION", os.path.join(CSRC, "tools", "kernels_tdnn_chain4.hip")]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     kernels = re.findall(r"Function Name: (\S+)", r.stderr)

@@ -7,7 +7,8 @@ unit = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 extra = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"] if unit in ("kernels_tdnn_x3", "kernels_tdnn_chainx", "kernels_tdnn_chain4") else []
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(csrc, "..", "..", "include"), "-I" + csrc] + extra + \
-      ["-c", os.path.join(csrc, unit + ".hip"), "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
+      ["-c", os.path.join(csrc, unit + ".hip") if os.path.exists(os.path.join(csrc, unit + ".hip")) else os.path.join(csrc, "tools", unit + ".hip"),
+       "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"] + (["-DASV_WITH_ABLATION"] if unit == "kernels_tdnn_chain4" else [])
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur = None
 rows = {}
