@@ -669,10 +669,10 @@ __global__ __launch_bounds__(256) void grid_conv_c1_kernel(const TdnnKernelParam
   const int rows_per_step = 256 / chunks, span = rows_per_step * C1_ROWS;
   const long long base = (long long)blockIdx.x * span;
   {
-    const uint16_t *w = reinterpret_cast<const uint16_t *>(p.w);               // [cout_pad][n_taps][cin_pad] bf16
+    // weights [cout_pad][n_taps][cin_pad] in the rows' element type (f32 in the parity modes: the same exact fma chain)
     for (int i = threadIdx.x; i < 9 * 64; i += 256) {
       const int t = i / 64, c = i % 64;
-      w_s[i] = (t < p.n_taps && c < p.cout_store) ? h16_bits_to_f32<ET>(w[((size_t)c * p.n_taps + t) * p.cin_pad]) : 0.0f;
+      w_s[i] = (t < p.n_taps && c < p.cout_store) ? load_elem<ET>(p.w, ((size_t)c * p.n_taps + t) * p.cin_pad) : 0.0f;
     }
     for (int c = threadIdx.x; c < 64; c += 256) {
       const bool ok = c < p.cout_store;
@@ -680,10 +680,9 @@ __global__ __launch_bounds__(256) void grid_conv_c1_kernel(const TdnnKernelParam
       c_s[64 + c] = (ok && p.scale) ? p.scale[c] : 1.0f;
       c_s[128 + c] = (ok && p.shift) ? p.shift[c] : 0.0f;
     }
-    const uint16_t *x = reinterpret_cast<const uint16_t *>(p.x);
     for (int i = threadIdx.x; i < span + 2 * C1_HALO; i += 256) {
       const long long r = base - C1_HALO + i;
-      x_s[i] = (r >= 0 && r < p.rows) ? h16_bits_to_f32<ET>(x[(size_t)r * p.ldx]) : 0.0f;
+      x_s[i] = (r >= 0 && r < p.rows) ? load_elem<ET>(p.x, (size_t)r * p.ldx) : 0.0f;
     }
   }
   __syncthreads();
@@ -725,9 +724,15 @@ __global__ __launch_bounds__(256) void grid_conv_c1_kernel(const TdnnKernelParam
       if constexpr (GENERIC) y[e] = tdnn_epilogue<ET>(p, acc[e], row, ch + e, cb[e], cs[e], ct[e], valid);
       else y[e] = tdnn_epilogue_fast(acc[e], cb[e], act_lo, cs[e], ct[e], valid);
     }
-    uint4 o;
-    o.x = pack_h16x2<ET>(y[0], y[1]); o.y = pack_h16x2<ET>(y[2], y[3]); o.z = pack_h16x2<ET>(y[4], y[5]); o.w = pack_h16x2<ET>(y[6], y[7]);
-    *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(p.y) + (size_t)row * p.ldy + ch) = o;
+    if constexpr (ET == ET_F32) {
+      float *yo = reinterpret_cast<float *>(p.y) + (size_t)row * p.ldy + ch;
+      *reinterpret_cast<float4 *>(yo) = make_float4(y[0], y[1], y[2], y[3]);
+      *reinterpret_cast<float4 *>(yo + 4) = make_float4(y[4], y[5], y[6], y[7]);
+    } else {
+      uint4 o;
+      o.x = pack_h16x2<ET>(y[0], y[1]); o.y = pack_h16x2<ET>(y[2], y[3]); o.z = pack_h16x2<ET>(y[4], y[5]); o.w = pack_h16x2<ET>(y[6], y[7]);
+      *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(p.y) + (size_t)row * p.ldy + ch) = o;
+    }
   }
 }
 
@@ -840,7 +845,7 @@ int launch_grid_conv_s2d(const TdnnKernelParams &p, hipStream_t s) {
 }
 
 bool grid_conv_c1_supported(const TdnnKernelParams &p, int et, int in_ch) {
-  return et != ET_F32 && in_ch == 1 && p.x2 == nullptr && p.w != nullptr && p.cout_store % 8 == 0 && p.cout_store >= 32 && p.cout_store <= 64 && p.ldy % 8 == 0 &&
+  return in_ch == 1 && p.x2 == nullptr && p.w != nullptr && p.cout_store % 8 == 0 && p.cout_store >= 32 && p.cout_store <= 64 && p.ldy % 8 == 0 &&
          p.n_taps <= 9 && p.halo <= C1_HALO;
 }
 
@@ -849,7 +854,10 @@ int launch_grid_conv_c1(const TdnnKernelParams &p, hipStream_t s) {
   const dim3 grid((unsigned)((p.rows + rows_per_wg - 1) / rows_per_wg)), block(256);
   const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first && p.seg_bias == nullptr &&
                     p.seg_scale == nullptr && p.res == nullptr;
-  if (fast) ASV_CONV_ET(grid_conv_c1_kernel<false);
+  if (p.et == ET_F32) {                              // the parity modes (f32 / f32x): f32 rows and weights, the same fma chain
+    if (fast) hipLaunchKernelGGL((grid_conv_c1_kernel<false, ET_F32>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((grid_conv_c1_kernel<true, ET_F32>), grid, block, 0, s, p);
+  } else if (fast) ASV_CONV_ET(grid_conv_c1_kernel<false);
   else ASV_CONV_ET(grid_conv_c1_kernel<true);
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;

@@ -51,7 +51,7 @@ struct QGeom {
   static_assert(WM * WN == 4 && MF % UI == 0 && 2 * LDS <= 163840, "grid conv (f32x) geometry");
 };
 
-template <typename G, int ET>
+template <typename G, int ET, bool GENERIC = false>
 __global__ __launch_bounds__(256, 2) void grid_conv_x3_kernel(const TdnnKernelParams p, const int n_tiles, const int nft) {
   constexpr int WN = G::WN, MF = G::MF, NFW = G::NFW, HLO = G::HLO, BM = G::BM, BN = G::BN, WIN = G::WIN, NP = G::NP, UI = G::UI, NU = G::NU;
   __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS];
@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256, 2) void grid_conv_x3_kernel(const TdnnKernelPa
 
   // ---- staging: f32 rows -> registers -> [hi | lo] image
   const float *xg = reinterpret_cast<const float *>(p.x);
+  const float *x2g = reinterpret_cast<const float *>(p.x2);       // optional second input, added while the rows are staged (Res2Net's sp + x_i)
   uint4 ra[NP], rb[NP];
   auto gload = [&](int c) {
 #pragma unroll
@@ -85,6 +86,13 @@ __global__ __launch_bounds__(256, 2) void grid_conv_x3_kernel(const TdnnKernelPa
         const float *src = xg + (size_t)row * p.ldx + ch;
         a = *reinterpret_cast<const uint4 *>(src);
         b = *reinterpret_cast<const uint4 *>(src + 4);
+        if constexpr (GENERIC) {
+          if (x2g != nullptr) {
+            const float *src2 = x2g + (size_t)row * p.ldx2 + ch;
+            a = add_f32x4(a, *reinterpret_cast<const uint4 *>(src2));
+            b = add_f32x4(b, *reinterpret_cast<const uint4 *>(src2 + 4));
+          }
+        }
       }
       ra[it] = a; rb[it] = b;
     }
@@ -235,8 +243,13 @@ __global__ __launch_bounds__(256, 2) void grid_conv_x3_kernel(const TdnnKernelPa
         float y[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float z = fmaxf(fmaf(acc[i][j][q * 4 + e], unscale, b[e]), act_lo) * sc[e] + sh[e];      // = tdnn_epilogue_fast for unscale = 1
-          y[e] = valid ? z : 0.0f;
+          if constexpr (GENERIC) {
+            // tanh / sigmoid / "bn-relu" order / per-segment bias and scale / residual: the shared epilogue of device_utils.h
+            y[e] = tdnn_epilogue<ET_F32>(p, acc[i][j][q * 4 + e] * unscale, rbase + lr, n0 + chl + e, b[e], sc[e], sh[e], valid);
+          } else {
+            const float z = fmaxf(fmaf(acc[i][j][q * 4 + e], unscale, b[e]), act_lo) * sc[e] + sh[e];      // = tdnn_epilogue_fast for unscale = 1
+            y[e] = valid ? z : 0.0f;
+          }
         }
         *reinterpret_cast<float4 *>(scr + lr * G::SPITCH + j * 32 + 8 * q + 4 * lh) = make_float4(y[0], y[1], y[2], y[3]);
       }
@@ -261,17 +274,39 @@ using Q128 = QGeom<2, 2, 4, 2, 24, 24, 2>;     // 128 out, 20-bin grid: 256 rows
 using Q128P = QGeom<2, 2, 4, 2, 0, 0, 2>;
 using Q256 = QGeom<1, 4, 4, 2, 16, 16, 2>;     // 256 out (per n tile), 10-bin grid: 128 rows, 2 x 20 KiB
 using Q256P = QGeom<1, 4, 4, 2, 0, 0, 2>;
+// frames-domain layers the wide f32x kernel (kernels_tdnn_x3.hip: >= 192 output channels, no second input, plain epilogue) does not
+// take: ECAPA's Res2Net branches (128 -> 128, 3 dilated taps, sp + x_i as second input) and attention bottleneck (1536 -> 128 + tanh
+// + per-utterance bias); halo = kHalo rounded up to 8
+using Q64F = QGeom<2, 2, 2, 1, 8, 8, 2>;
+using Q128F = QGeom<2, 2, 4, 2, 8, 8, 2>;
+using Q256F = QGeom<1, 4, 4, 2, 8, 8, 2>;
+// the 128-channel geometries with the long epilogue / a second input: 128-row tiles (64 accumulator registers instead of 128: the
+// 256-row forms spill ~20 registers there)
+using Q128g = QGeom<2, 2, 2, 2, 24, 24, 2>;
+using Q128Fg = QGeom<2, 2, 2, 2, 8, 8, 2>;
 
 struct QPick { int bm, bn, hlo, hhi, id; };
+template <typename G> QPick qpick(int id) { return QPick{G::BM, G::BN, G::HLO, G::HHI, id}; }
+// the geometry with the smallest window that holds the layer's taps
+bool plain_epilogue(const TdnnKernelParams &p) {
+  return (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first && p.seg_bias == nullptr && p.seg_scale == nullptr &&
+         p.res == nullptr && p.x2 == nullptr;
+}
 QPick pick_geom(const TdnnKernelParams &p) {
+  const bool fast = plain_epilogue(p);
   int lo = 0, hi = 0;
   for (int t = 0; t < p.n_taps; ++t) { lo = std::max(lo, -p.taps[t]); hi = std::max(hi, p.taps[t]); }
-  const bool plain = lo == 0 && hi == 0;
-  if (p.cout_store == 32) return p.cin_pad == 32 ? QPick{Q32::BM, 32, Q32::HLO, Q32::HHI, 0} : QPick{0, 0, 0, 0, -1};
-  if (p.cout_store == 64) return plain ? QPick{Q64P::BM, 64, 0, 0, 2} : QPick{Q64::BM, 64, Q64::HLO, Q64::HHI, 1};
-  if (p.cout_store == 128) return plain ? QPick{Q128P::BM, 128, 0, 0, 4} : QPick{Q128::BM, 128, Q128::HLO, Q128::HHI, 3};
-  if (p.cout_store % 256 == 0) return plain ? QPick{Q256P::BM, 256, 0, 0, 6} : QPick{Q256::BM, 256, Q256::HLO, Q256::HHI, 5};
-  return QPick{0, 0, 0, 0, -1};
+  const int halo = std::max(lo, hi);
+  const QPick none{0, 0, 0, 0, -1};
+  if (p.cout_store == 32) return (p.cin_pad == 32 && halo <= Q32::HLO) ? qpick<Q32>(0) : none;
+  if (p.cout_store == 64) return halo == 0 ? qpick<Q64P>(2) : (halo <= 8 ? qpick<Q64F>(7) : (halo <= Q64::HLO ? qpick<Q64>(1) : none));
+  if (p.cout_store == 128) {
+    if (halo == 0) return qpick<Q128P>(4);
+    if (halo <= 8) return fast ? qpick<Q128F>(8) : qpick<Q128Fg>(11);
+    return halo <= Q128::HLO ? (fast ? qpick<Q128>(3) : qpick<Q128g>(10)) : none;
+  }
+  if (p.cout_store % 256 == 0) return halo == 0 ? qpick<Q256P>(6) : (halo <= 8 ? qpick<Q256F>(9) : (halo <= Q256::HLO ? qpick<Q256>(5) : none));
+  return none;
 }
 
 }  // namespace
@@ -311,14 +346,10 @@ void pack_grid_conv_x3_frags(const float *w, int out_ch, int in_ch, int tot_ctx,
 }
 
 bool grid_conv_x3_supported(const TdnnKernelParams &p) {
-  if (p.wconv == nullptr || p.x2 != nullptr || p.ksplit > 1 || !grid_conv_x3_shape_ok(p.cin_pad, p.cout_store)) return false;
-  const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first && p.seg_bias == nullptr &&
-                    p.seg_scale == nullptr && p.res == nullptr;
-  if (!fast || (p.x3_terms & 7) != 7 || !(p.w_unscale > 0.0f)) return false;
+  if (p.wconv == nullptr || p.ksplit > 1 || !grid_conv_x3_shape_ok(p.cin_pad, p.cout_store)) return false;
+  if ((p.x3_terms & 7) != 7 || !(p.w_unscale > 0.0f)) return false;
   const QPick g = pick_geom(p);
-  if (g.id < 0 || p.rows % g.bm != 0 || p.ldx % 4 != 0 || p.ldy % 4 != 0) return false;
-  for (int t = 0; t < p.n_taps; ++t)
-    if (-p.taps[t] > g.hlo || p.taps[t] > g.hhi) return false;
+  if (g.id < 0 || p.rows % g.bm != 0 || p.ldx % 4 != 0 || p.ldy % 4 != 0 || (p.x2 != nullptr && p.ldx2 % 4 != 0)) return false;
   if (g.id == 0 && p.cin_pad != QCH) return false;                 // the one-image geometry holds one chunk
   return true;
 }
@@ -329,8 +360,12 @@ int launch_grid_conv_x3(const TdnnKernelParams &p, hipStream_t s) {
   const QPick g = pick_geom(p);
   const int m_tiles = p.rows / g.bm, n_tiles = p.cout_store / g.bn, nft = p.cout_store / 32;
   const dim3 grid(m_tiles * n_tiles), block(256);
-#define ASV_QCONV(GEO) do { if (p.x3_et == ET_F16) hipLaunchKernelGGL((grid_conv_x3_kernel<GEO, ET_F16>), grid, block, 0, s, p, n_tiles, nft); \
-                            else hipLaunchKernelGGL((grid_conv_x3_kernel<GEO, ET_BF16>), grid, block, 0, s, p, n_tiles, nft); } while (0)
+  // the hot instantiations carry the short epilogue only; tanh / sigmoid / per-segment terms / residual / "bn-relu" order / a second
+  // input go to the GENERIC ones
+  const bool fast = plain_epilogue(p);
+#define ASV_QCONV2(GEO, ETV) do { if (fast) hipLaunchKernelGGL((grid_conv_x3_kernel<GEO, ETV, false>), grid, block, 0, s, p, n_tiles, nft); \
+                                  else hipLaunchKernelGGL((grid_conv_x3_kernel<GEO, ETV, true>), grid, block, 0, s, p, n_tiles, nft); } while (0)
+#define ASV_QCONV(GEO) do { if (p.x3_et == ET_F16) ASV_QCONV2(GEO, ET_F16); else ASV_QCONV2(GEO, ET_BF16); } while (0)
   switch (g.id) {
     case 0: ASV_QCONV(Q32); break;
     case 1: ASV_QCONV(Q64); break;
@@ -338,9 +373,15 @@ int launch_grid_conv_x3(const TdnnKernelParams &p, hipStream_t s) {
     case 3: ASV_QCONV(Q128); break;
     case 4: ASV_QCONV(Q128P); break;
     case 5: ASV_QCONV(Q256); break;
-    default: ASV_QCONV(Q256P); break;
+    case 6: ASV_QCONV(Q256P); break;
+    case 7: ASV_QCONV(Q64F); break;
+    case 8: ASV_QCONV(Q128F); break;
+    case 10: ASV_QCONV(Q128g); break;
+    case 11: ASV_QCONV(Q128Fg); break;
+    default: ASV_QCONV(Q256F); break;
   }
 #undef ASV_QCONV
+#undef ASV_QCONV2
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }

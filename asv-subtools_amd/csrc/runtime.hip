@@ -515,9 +515,12 @@ int asv_net_add_tdnn(asv_net_t *net, const asv_tdnn_desc_t *d) {
       if ((rc = dev_upload(net, hi.data(), hi.size() * 2, &op.wfrag))) return rc;
       if ((rc = dev_upload(net, lo.data(), lo.size() * 2, &op.wlo))) return rc;
     }
-    if (net->x3() && !op.utts && net->domains[dom].kind == 2 && grid_conv_x3_shape_ok(op.cin_pad, op.cout_store) && (net->flags & ASV_FLAG_SMALL_TILES) == 0) {
-      // f32x mode, grid domain (the 2-D ResNet trunk): hi / lo halves in the fragment order of kernels_conv2d_x3.hip, scaled
-      // by the layer's power of two for the half-precision split
+    const bool x3_wide_frames = net->x3() && !op.utts && net->domains[dom].kind == ASV_DOMAIN_FRAMES && op.cout_store >= 192 && op.cin_pad >= 32 && d->in2_buf < 0;
+    if (net->x3() && !op.utts && (net->domains[dom].kind == 2 || !x3_wide_frames) && grid_conv_x3_shape_ok(op.cin_pad, op.cout_store) &&
+        (net->flags & ASV_FLAG_SMALL_TILES) == 0) {
+      // f32x mode, grid domain (the 2-D ResNet trunk) and the frames-domain layers the wide split kernel does not take (fewer than
+      // 192 output channels, or a second input): hi / lo halves in the fragment order of kernels_conv2d_x3.hip, scaled by the
+      // layer's power of two for the half-precision split
       std::vector<uint16_t> frags(grid_conv_x3_frag_elems(op.cin_pad, op.cout_store, d->n_taps));
       op.w_scale = net->x3_et() == ET_F16 ? x3_weight_scale(d->weight, (size_t)d->out_ch * d->in_ch * d->w_tot_context) : 1.0f;
       pack_grid_conv_x3_frags(d->weight, d->out_ch, d->in_ch, d->w_tot_context, d->w_left_context, d->taps, d->n_taps, op.cin_pad, op.cout_store, net->x3_et(),
@@ -1271,7 +1274,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         const bool narrow_conv = !use_ref && net->domains[domid].kind == 2 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && grid_conv_narrow_supported(p, et);
         const bool wide_conv = !use_ref && net->domains[domid].kind == 2 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && grid_conv_wide_supported(p, et);
         const bool s2d_conv = !use_ref && net->domains[domid].kind == 2 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && grid_conv_s2d_supported(p, et);
-        const bool x3_conv = !use_ref && net->x3() && net->domains[domid].kind == 2 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && grid_conv_x3_supported(p);
+        const bool x3_conv = !use_ref && !op.utts && net->x3() && !x3 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && grid_conv_x3_supported(p);
         if (!use_ref && !big3 && op.utts && !utts_kernel) {
           // pooled-domain layers have one row per utterance (M is tiny, K is large): slice K over more
           // workgroups.  The slice count depends on K only, never on the batch, so an utterance's
@@ -1312,12 +1315,12 @@ int run_ops(RunCtx &c, size_t n_ops) {
           // the bf16 split here would be the largest error left in the f32x mode (< 0.3 % of the FLOPs: +1 % of an f32x step)
           rc = launch_utts_gemm(p, bp.segments, net->frames_h16(), c.s);
         }
-        else if (x3_conv) rc = launch_grid_conv_x3(p, c.s);
         else if (narrow_conv) rc = launch_grid_conv_narrow(p, c.s);
         else if (wide_conv) rc = launch_grid_conv_wide(p, c.s);
         else if (s2d_conv) rc = launch_grid_conv_s2d(p, c.s);
         else if (c1_conv) rc = launch_grid_conv_c1(p, c.s);
         else if (x3) rc = launch_tdnn_x3(p, c.s);
+        else if (x3_conv) rc = launch_grid_conv_x3(p, c.s);
         else if (big3) rc = launch_tdnn_big3(p, c.s);
         else {
           rc = launch_tdnn_mfma(p, et, !bf16, c.s);

@@ -219,6 +219,10 @@ class Engine(object):
         capi.check(L.asv_net_finalize(self._net, buf_of[g.output.tid], g.output.channels), "asv_net_finalize")
 
     def close(self):
+        twin = getattr(self, "_wide_range_twin", None)
+        if twin is not None:
+            self._wide_range_twin = None
+            twin.close()
         if getattr(self, "_net", None) is not None and self._net.value:
             self.lib.asv_net_destroy(self._net)
             self._net = C.c_void_p()
@@ -259,7 +263,33 @@ class Engine(object):
 
     def extract_batch(self, mats, max_chunk=10000):
         """mats: list of [T_i, D] array-likes (host), or of CUDA tensors (e.g. libs.amd.frontend.fbank output - packed on
-        the device, no host round trip).  Returns a CPU float32 tensor [B, E]."""
+        the device, no host round trip).  Returns a CPU float32 tensor [B, E].
+
+        Range guard of the default mode: 'f32x' splits every operand into IEEE-half halves, so an activation beyond +-65504
+        (un-normalised features of huge magnitude, a checkpoint whose BatchNorm lets a layer blow up) becomes inf and the
+        embedding NaN - the f32 reference has no such limit.  A batch that comes back non-finite is therefore re-run ONCE on a
+        lazily compiled twin of this engine with bf16 halves ('f32x-bf16': 16 significant bits per operand, the whole f32
+        exponent range; ~6e-6 relative, still inside the 1e-4 gate), with a warning.  If that is non-finite too, the input
+        itself is (NaN / inf features): returned as is, like the reference would.  extract_device() (device tensor out, no
+        host synchronisation) does not check."""
+        import torch
+        out = self._extract_batch(mats, max_chunk)
+        if self._range_fallback_applies() and out.numel() and not bool(torch.isfinite(out).all()):
+            import warnings
+            warnings.warn("asv-subtools_amd: non-finite embeddings in the f32x mode (an activation beyond the IEEE-half range of its operand split?): "
+                          "re-running the batch with bf16 operand halves (precision 'f32x-bf16')", RuntimeWarning)
+            if getattr(self, "_wide_range_twin", None) is None:
+                self._wide_range_twin = Engine(self.graph, device_index=self.device_index, precision="f32x-bf16",
+                                               flags=self.flags & ~(capi.FLAG_X3_SPLIT_F16 | capi.FLAG_X3_SPLIT_BF16))
+            again = self._wide_range_twin._extract_batch(mats, max_chunk)
+            bad = ~torch.isfinite(out).all(dim=1)
+            out[bad] = again[bad]                        # utterances that were fine keep their f32-grade result (batch invariance)
+        return out
+
+    def _range_fallback_applies(self):
+        return self.precision_base in ("f32x", "f16x3") and (self.flags & (capi.FLAG_X3_SPLIT_BF16 | capi.FLAG_REF_KERNELS)) == 0
+
+    def _extract_batch(self, mats, max_chunk=10000):
         import torch
         mats = list(mats)
         if not mats:                                  # an empty feature archive is not an error in the reference's loop either

@@ -96,3 +96,33 @@ def test_eer_gate_c4_standin_all_precision_modes(capsys):
     # two matrix instructions per product: the embeddings stay at the one-rounding level of the operand that was not split
     for two in ("f32x-f16-noxlo", "f32x-f16-nowlo"):
         assert rel_err(emb[two], emb["f32"]) > 10 * rel_err(emb["f32x"], emb["f32"]), two
+
+
+@pytest.mark.parametrize("model", ["xvector", "ecapa", "resnet"])
+def test_gates_as_statistics_per_model(model, capsys):
+    """one draw (one weight seed, one trial list) cannot settle a 0.01 % gate that is two flipped trials wide.
+    tests/gate_table.py: 3 weight seeds x 3 trial lists + one 500 000-trial list per seed, per model, with the model's own scoring
+    chain (cosine for the x-vector / ECAPA, PLDA trained on each mode's embeddings for the ResNet).  The parity-grade mode (f32x,
+    the default of the drop-in API) must be inside BOTH gates on every draw of every model; the 16-bit throughput modes are
+    measured and recorded (gpurun_out/eer_gate_table_<model>.json -> profiles/): they are NOT asserted to pass - the table is
+    the answer to "is f16 an EER-grade mode"."""
+    import json
+    import os
+    import gate_table
+    g = gate_table.Gates(model)
+    tab = g.table(["f32x", "f16", "bf16"], weight_seeds=(0, 1, 2))
+    out_dir = os.path.join(helpers.REPO, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "eer_gate_table_%s.json" % model), "w") as f:
+        json.dump(tab, f, indent=1)
+    with capsys.disabled():
+        print("\n[gate table] %s: EER(f32) %s %%" % (model, tab["eer_f32_percent"]))
+        for p, m in tab["modes"].items():
+            print("[gate table]   %-5s embeddings %.2e (gate %s)   dEER %s | 500k: %s   every draw: %s" % (
+                p, m["embedding_max_rel_err"], m["gate_1e-4"], m["eer_delta_percent"], m["eer_delta_percent_500k"], m["eer_gate_every_draw"]))
+    x = tab["modes"]["f32x"]
+    assert x["gate_1e-4"] and x["eer_gate_every_draw"], x
+    assert all(0.3 < e < 45.0 for e in tab["eer_f32_percent"]), tab["eer_f32_percent"]          # non-trivial error rates on every seed
+    # the throughput modes: bounded against gross regressions only (measured: DESIGN.md "Precision modes")
+    assert tab["modes"]["f16"]["embedding_max_rel_err"] < 0.5 * tab["modes"]["bf16"]["embedding_max_rel_err"]
+    assert tab["modes"]["bf16"]["worst_abs_eer_delta_percent"] < 3.0

@@ -249,3 +249,38 @@ def test_layer_chain_kernel_matches_per_layer_kernels(monkeypatch):
     assert rel_err(out, ref) < 6e-3, rel_err(out, ref)
     a200 = model2.extract_embedding_batch(mats2).numpy()
     assert rel_err(a200, b) < 6e-3, rel_err(a200, b)
+
+
+def test_f32x_range_guard_and_small_features():
+    """the default mode splits operands into IEEE-half halves - an activation beyond +-65504 becomes inf and the
+    embedding NaN, where the f32 reference has no limit.  extract_batch() re-runs a batch that comes back non-finite with bf16
+    halves (full f32 exponent range, still inside the 1e-4 gate) and warns; utterances that were fine keep their result.
+    Small features (3e-3: the lo halves are subnormal halves, absolute precision 2^-25) stay inside the gate too."""
+    import warnings
+    g, sd, model = _gpu_model("xvector_near_ragged", "f32")
+    mats = helpers.golden_feats(g)[:6]
+    huge = [m.copy() for m in mats]
+    huge[2] = (huge[2] * 3.0e5).astype(np.float32)               # un-normalised features of absurd magnitude in ONE utterance
+    want = model.extract_embedding_batch(huge).numpy()           # exact f32
+    assert np.isfinite(want).all()
+    model.amd_precision = "f32x"
+    clean = model.extract_embedding_batch(mats).numpy()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got = model.extract_embedding_batch(huge).numpy()
+    assert any("f32x-bf16" in str(x.message) for x in w), [str(x.message) for x in w]
+    assert np.isfinite(got).all()
+    for i in range(len(huge)):
+        assert rel_err(got[i], want[i]) < 1e-4, i
+    for i in (0, 1, 3, 4, 5):
+        assert np.array_equal(got[i], clean[i]), i               # untouched utterances: bit-identical to the run without the outlier
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        model.extract_embedding_batch(mats)
+    assert not w                                                 # no fallback on ordinary input
+    small = [(m * 3.0e-3).astype(np.float32) for m in mats]
+    model.amd_precision = "f32"
+    want_s = model.extract_embedding_batch(small).numpy()
+    model.amd_precision = "f32x"
+    got_s = model.extract_embedding_batch(small).numpy()
+    assert rel_err(got_s, want_s) < 1e-4, rel_err(got_s, want_s)
