@@ -127,6 +127,7 @@ struct TdnnKernelParams {
   int x3_tile;          // f32x kernel: 0 = pick the tile rows from the batch size, 128 = ASV_FLAG_X3_TILE128
   float w_unscale;      // f32x kernel: the accumulators are multiplied by this (1 / the power of two the host scaled the weights by)
   int et;               // ET_*: element type of x / x2 / res / y rows and of the packed weights (the launchers without an `et` argument read it)
+  uint32_t *status;     // f32x kernels: device word, bit ASV_STATUS_HALF_RANGE is OR-ed in when an operand's half split overflowed (or nullptr)
 };
 
 struct PoolKernelParams {
@@ -193,6 +194,7 @@ struct TdnnChainParams {
   int dbg_fine;                 // ASV_AMD_CHAIN_DBG >= 3: also stamps inside the first pooling epilogue of every wave
   int et;                       // ET_BF16 / ET_F16: element type of the rows and of every layer's weight fragments
   int min_seg_len;              // shortest utterance of the batch in frames (the 4-wave kernel needs >= 32: at most one seam per 32-frame fragment)
+  uint32_t *status;             // f32x chain: as TdnnKernelParams::status
 };
 int launch_tdnn_chain(const TdnnChainParams &p, hipStream_t s);
 #ifdef ASV_WITH_ABLATION

@@ -115,6 +115,15 @@ __device__ __forceinline__ uint4 add_f32x4(uint4 a, uint4 b) {
 // ---- the operand split of the f32x precision mode (kernels_tdnn_x3.hip, kernels_tdnn_chainx.hip, kernels_conv2d_x3.hip)
 struct X3Frag { uint4 hi, lo; };     // 8 k values of one lane: the two 16-bit halves
 
+// Range watch of the IEEE-half split: a packed pair of hi halves -> a word whose bits 15 / 31 are set iff the low / high half is
+// inf or NaN (0x7c00 + 0x0400 carries into bit 15; the largest finite half, 0x7bff, does not).  Callers OR these words together
+// (3 VALU operations per pair) and publish once per wave with x3_publish_range: an activation beyond +-65504 would otherwise turn
+// into a NaN product that the next ReLU (fmaxf) silently maps to 0 - wrong embeddings without a trace.
+__device__ __forceinline__ uint32_t h16_range_bits(uint32_t packed_hi) { return (packed_hi & 0x7fff7fffu) + 0x04000400u; }
+__device__ __forceinline__ void x3_publish_range(uint32_t acc_bits, uint32_t *status) {
+  if (status != nullptr && __builtin_amdgcn_ballot_w64((acc_bits & 0x80008000u) != 0u) != 0ull && (threadIdx.x & 63) == 0) atomicOr(status, ASV_STATUS_HALF_RANGE);
+}
+
 // 8 f32 -> hi + lo in the 16-bit type ET (x - hi is exact in f32: hi keeps the leading 8 / 11 significand bits of x).
 // ET_BF16: 16 significant bits together, the whole f32 exponent range.  ET_F16: 22 bits together for |x| >= 2^-2 (lo is a
 // normal half there), an absolute error <= 2^-25 below (lo a subnormal half; the matrix cores keep subnormal inputs - checked
@@ -148,6 +157,14 @@ __device__ __forceinline__ X3Frag x3_split(const uint4 a, const uint4 b) {
   X3Frag f;
   f.hi = make_uint4(h[0], h[1], h[2], h[3]);
   f.lo = make_uint4(l[0], l[1], l[2], l[3]);
+  return f;
+}
+// the same, watching the range of the half split: `range` collects h16_range_bits of the hi halves (ET_F16 only; bf16 halves
+// share the f32 exponent range)
+template <int ET, bool WITH_LO>
+__device__ __forceinline__ X3Frag x3_split(const uint4 a, const uint4 b, uint32_t &range) {
+  const X3Frag f = x3_split<ET, WITH_LO>(a, b);
+  if constexpr (ET == ET_F16) range |= h16_range_bits(f.hi.x) | h16_range_bits(f.hi.y) | h16_range_bits(f.hi.z) | h16_range_bits(f.hi.w);
   return f;
 }
 

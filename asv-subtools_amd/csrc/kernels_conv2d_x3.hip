@@ -48,6 +48,10 @@ struct QGeom {
   static constexpr int LDS = MAIN + 3 * BN * 4;
   static constexpr int UI = NFW == 1 ? 2 : 1;               // row fragments per unit (6 matrix instructions either way)
   static constexpr int NU = MF / UI;                        // units per (tap, k-group) step
+  // Halo-free geometries serve 1-tap layers: a chunk's K loop is 2 steps (~0.4 - 0.8 us) - shorter than the round trip of the next
+  // chunk's rows - so they keep TWO register stages and fetch chunk c + 2 at the top of chunk c (measured with one stage: the
+  // 1536 -> 128 layer of ECAPA's attention at 284 us, the 1152 -> 256 im2col GEMM of the ResNet at 166 us)
+  static constexpr bool PF2 = HLO == 0 && HHI == 0 && NBUF == 2;
   static_assert(WM * WN == 4 && MF % UI == 0 && 2 * LDS <= 163840, "grid conv (f32x) geometry");
 };
 
@@ -75,8 +79,9 @@ __global__ __launch_bounds__(256, 2) void grid_conv_x3_kernel(const TdnnKernelPa
   // ---- staging: f32 rows -> registers -> [hi | lo] image
   const float *xg = reinterpret_cast<const float *>(p.x);
   const float *x2g = reinterpret_cast<const float *>(p.x2);       // optional second input, added while the rows are staged (Res2Net's sp + x_i)
-  uint4 ra[NP], rb[NP];
-  auto gload = [&](int c) {
+  struct Stage { uint4 a[NP], b[NP], a2[GENERIC ? NP : 1], b2[GENERIC ? NP : 1]; };
+  uint32_t range = 0u;                                           // range watch of the half split (device_utils.h)
+  auto gload = [&](int c, Stage &st) {
 #pragma unroll
     for (int it = 0; it < NP; ++it) {
       const int item = it * 256 + tid, w = item >> 2, q = item & 3;
@@ -87,23 +92,30 @@ __global__ __launch_bounds__(256, 2) void grid_conv_x3_kernel(const TdnnKernelPa
         a = *reinterpret_cast<const uint4 *>(src);
         b = *reinterpret_cast<const uint4 *>(src + 4);
         if constexpr (GENERIC) {
+          // the second input stays in registers of its own until the rows are converted: adding here would wait for both loads
+          // in front of the K loop they are meant to hide behind (measured: 95 instead of 43 us for a Res2Net branch)
           if (x2g != nullptr) {
             const float *src2 = x2g + (size_t)row * p.ldx2 + ch;
-            a = add_f32x4(a, *reinterpret_cast<const uint4 *>(src2));
-            b = add_f32x4(b, *reinterpret_cast<const uint4 *>(src2 + 4));
+            st.a2[it] = *reinterpret_cast<const uint4 *>(src2);
+            st.b2[it] = *reinterpret_cast<const uint4 *>(src2 + 4);
           }
         }
+      } else if constexpr (GENERIC) {
+        st.a2[it] = make_uint4(0, 0, 0, 0); st.b2[it] = make_uint4(0, 0, 0, 0);
       }
-      ra[it] = a; rb[it] = b;
+      st.a[it] = a; st.b[it] = b;
     }
   };
-  auto sstore = [&](int buf) {
+  auto sstore = [&](int buf, Stage &st) {
     unsigned char *img = lds + buf * G::IMG;
 #pragma unroll
     for (int it = 0; it < NP; ++it) {
       const int item = it * 256 + tid, w = item >> 2, q = item & 3;
       if (item < WIN * 4) {
-        const X3Frag f = x3_split<ET, true>(ra[it], rb[it]);
+        if constexpr (GENERIC) {
+          if (x2g != nullptr) { st.a[it] = add_f32x4(st.a[it], st.a2[it]); st.b[it] = add_f32x4(st.b[it], st.b2[it]); }
+        }
+        const X3Frag f = x3_split<ET, true>(st.a[it], st.b[it], range);
         *reinterpret_cast<uint4 *>(img + w * QROWB + qswz(w, q) * 16) = f.hi;
         *reinterpret_cast<uint4 *>(img + w * QROWB + qswz(w, 4 + q) * 16) = f.lo;
       }
@@ -157,15 +169,21 @@ __global__ __launch_bounds__(256, 2) void grid_conv_x3_kernel(const TdnnKernelPa
   // ---- prologue: window of chunk 0 -> image 0, weights of step 0
   const int v_taps = p.taps[lane < ASV_MAX_TAPS ? lane : 0];
   WF wa, wb;
-  gload(0);
+  Stage s0;
+  Stage s1;                                                        // (PF2 only; dead otherwise)
+  gload(0, s0);
   load_w(0, wa);
-  sstore(0);
+  sstore(0, s0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  if constexpr (G::PF2) {
+    if (nchunks > 1) gload(1, s1);
+  }
 
-#pragma unroll 1
-  for (int c = 0; c < nchunks; ++c) {
+  // one chunk: its K loop on image c & 1; the rows of chunk `c_ld` go into flight (-> `ld`) behind the first weight prefetch, the
+  // rows in `st` (chunk c + 1, landed by now) are converted into the other image behind the loop
+  auto chunk = [&](const int c, Stage &ld, const int c_ld, Stage &st) {
     const unsigned char *img = lds + (G::NBUF == 2 ? (c & 1) : 0) * G::IMG;
     const bool more_chunks = c + 1 < nchunks;
     XF xa, xb;
@@ -176,10 +194,11 @@ __global__ __launch_bounds__(256, 2) void grid_conv_x3_kernel(const TdnnKernelPa
       const int d = __builtin_amdgcn_readlane(v_taps, t);
       const bool last_tap = t + 1 == n_taps;
       const int dn = __builtin_amdgcn_readlane(v_taps, last_tap ? t : t + 1);
-      // k-group 0 on wa; k-group 1's fragments -> wb; at the chunk's first tap the next chunk's rows follow them into flight
+      // k-group 0 on wa; k-group 1's fragments -> wb; at the chunk's first tap the next rows follow them into flight (the
+      // vector-memory counter retires in order: a fragment fetch issued BEHIND the rows could not be consumed before they land)
       load_w(step + 1, wb);
       if constexpr (G::NBUF == 2) {
-        if (t == 0 && more_chunks) gload(c + 1);
+        if (t == 0 && c_ld < nchunks) gload(c_ld, ld);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -211,17 +230,29 @@ __global__ __launch_bounds__(256, 2) void grid_conv_x3_kernel(const TdnnKernelPa
     }
     if constexpr (G::NBUF == 2) {
       if (more_chunks) {
-        sstore((c + 1) & 1);                                     // nobody reads that image: it was chunk c - 1's
+        sstore((c + 1) & 1, st);                                 // nobody reads that image: it was chunk c - 1's
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
       }
     }
+  };
+  if constexpr (G::PF2) {
+    // even chunks: chunk c + 2 -> s0 (chunk c left it at the end of chunk c - 1), chunk c + 1 waits in s1; odd chunks: the other way
+#pragma unroll 1
+    for (int c = 0; c < nchunks; c += 2) {
+      chunk(c, s0, c + 2, s1);
+      if (c + 1 < nchunks) chunk(c + 1, s1, c + 3, s0);
+    }
+  } else {
+#pragma unroll 1
+    for (int c = 0; c < nchunks; ++c) chunk(c, s0, c + 1, s0);
   }
 
   // ---- epilogue: acc[i][j][r] = row m0 + wm*MF*32 + i*32 + lr, channel n0 + (wn*NFW + j)*32 + 8*(r>>2) + 4*lh + (r&3)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                                   // every wave is through with the images: they become scratch
+  x3_publish_range(range, p.status);
   asm volatile("" ::: "memory");
   float *scr = reinterpret_cast<float *>(lds) + wave * (32 * G::SPITCH);
   const float act_lo = (p.act1 == ASV_ACT_RELU) ? 0.0f : -INFINITY;
@@ -271,7 +302,7 @@ using Q32 = QGeom<4, 1, 2, 1, 82, 82, 1>;      // 32 -> 32, grids of <= 80 bins 
 using Q64 = QGeom<2, 2, 2, 1, 48, 48, 2>;      // 64 channels out, 40-bin grid: 128 rows, 2 x 28 KiB
 using Q64P = QGeom<2, 2, 2, 1, 0, 0, 2>;
 using Q128 = QGeom<2, 2, 4, 2, 24, 24, 2>;     // 128 out, 20-bin grid: 256 rows, 2 x 38 KiB
-using Q128P = QGeom<2, 2, 4, 2, 0, 0, 2>;
+using Q128P = QGeom<2, 2, 2, 2, 0, 0, 2>;     // (128-row tiles: two register stages of rows, see QGeom::PF2)
 using Q256 = QGeom<1, 4, 4, 2, 16, 16, 2>;     // 256 out (per n tile), 10-bin grid: 128 rows, 2 x 20 KiB
 using Q256P = QGeom<1, 4, 4, 2, 0, 0, 2>;
 // frames-domain layers the wide f32x kernel (kernels_tdnn_x3.hip: >= 192 output channels, no second input, plain epilogue) does not
@@ -284,6 +315,10 @@ using Q256F = QGeom<1, 4, 4, 2, 8, 8, 2>;
 // 256-row forms spill ~20 registers there)
 using Q128g = QGeom<2, 2, 2, 2, 24, 24, 2>;
 using Q128Fg = QGeom<2, 2, 2, 2, 8, 8, 2>;
+using Q128Pg = QGeom<2, 2, 2, 2, 0, 0, 2>;
+using Q256g = QGeom<1, 4, 2, 2, 16, 16, 2>;     // (64-row tiles)
+using Q256Fg = QGeom<1, 4, 2, 2, 8, 8, 2>;
+using Q256Pg = QGeom<1, 4, 2, 2, 0, 0, 2>;
 
 struct QPick { int bm, bn, hlo, hhi, id; };
 template <typename G> QPick qpick(int id) { return QPick{G::BM, G::BN, G::HLO, G::HHI, id}; }
@@ -301,11 +336,15 @@ QPick pick_geom(const TdnnKernelParams &p) {
   if (p.cout_store == 32) return (p.cin_pad == 32 && halo <= Q32::HLO) ? qpick<Q32>(0) : none;
   if (p.cout_store == 64) return halo == 0 ? qpick<Q64P>(2) : (halo <= 8 ? qpick<Q64F>(7) : (halo <= Q64::HLO ? qpick<Q64>(1) : none));
   if (p.cout_store == 128) {
-    if (halo == 0) return qpick<Q128P>(4);
+    if (halo == 0) return fast ? qpick<Q128P>(4) : qpick<Q128Pg>(12);
     if (halo <= 8) return fast ? qpick<Q128F>(8) : qpick<Q128Fg>(11);
     return halo <= Q128::HLO ? (fast ? qpick<Q128>(3) : qpick<Q128g>(10)) : none;
   }
-  if (p.cout_store % 256 == 0) return halo == 0 ? qpick<Q256P>(6) : (halo <= 8 ? qpick<Q256F>(9) : (halo <= Q256::HLO ? qpick<Q256>(5) : none));
+  if (p.cout_store % 256 == 0) {
+    if (halo == 0) return fast ? qpick<Q256P>(6) : qpick<Q256Pg>(15);
+    if (halo <= 8) return fast ? qpick<Q256F>(9) : qpick<Q256Fg>(14);
+    return halo <= Q256::HLO ? (fast ? qpick<Q256>(5) : qpick<Q256g>(13)) : none;
+  }
   return none;
 }
 
@@ -363,25 +402,30 @@ int launch_grid_conv_x3(const TdnnKernelParams &p, hipStream_t s) {
   // the hot instantiations carry the short epilogue only; tanh / sigmoid / per-segment terms / residual / "bn-relu" order / a second
   // input go to the GENERIC ones
   const bool fast = plain_epilogue(p);
-#define ASV_QCONV2(GEO, ETV) do { if (fast) hipLaunchKernelGGL((grid_conv_x3_kernel<GEO, ETV, false>), grid, block, 0, s, p, n_tiles, nft); \
-                                  else hipLaunchKernelGGL((grid_conv_x3_kernel<GEO, ETV, true>), grid, block, 0, s, p, n_tiles, nft); } while (0)
-#define ASV_QCONV(GEO) do { if (p.x3_et == ET_F16) ASV_QCONV2(GEO, ET_F16); else ASV_QCONV2(GEO, ET_BF16); } while (0)
+#define ASV_QCONV(GEO, GENV) do { if (p.x3_et == ET_F16) hipLaunchKernelGGL((grid_conv_x3_kernel<GEO, ET_F16, GENV>), grid, block, 0, s, p, n_tiles, nft); \
+                                  else hipLaunchKernelGGL((grid_conv_x3_kernel<GEO, ET_BF16, GENV>), grid, block, 0, s, p, n_tiles, nft); } while (0)
+  // the small-tile geometries (ids 0 - 2, 7) carry both epilogues; the 128- / 256-channel ones have a geometry per epilogue (the long one
+  // and the second input's registers do not fit beside 128 accumulator registers)
+  (void)fast;
   switch (g.id) {
-    case 0: ASV_QCONV(Q32); break;
-    case 1: ASV_QCONV(Q64); break;
-    case 2: ASV_QCONV(Q64P); break;
-    case 3: ASV_QCONV(Q128); break;
-    case 4: ASV_QCONV(Q128P); break;
-    case 5: ASV_QCONV(Q256); break;
-    case 6: ASV_QCONV(Q256P); break;
-    case 7: ASV_QCONV(Q64F); break;
-    case 8: ASV_QCONV(Q128F); break;
-    case 10: ASV_QCONV(Q128g); break;
-    case 11: ASV_QCONV(Q128Fg); break;
-    default: ASV_QCONV(Q256F); break;
+    case 0: if (fast) ASV_QCONV(Q32, false); else ASV_QCONV(Q32, true); break;
+    case 1: if (fast) ASV_QCONV(Q64, false); else ASV_QCONV(Q64, true); break;
+    case 2: if (fast) ASV_QCONV(Q64P, false); else ASV_QCONV(Q64P, true); break;
+    case 7: if (fast) ASV_QCONV(Q64F, false); else ASV_QCONV(Q64F, true); break;
+    case 3: ASV_QCONV(Q128, false); break;
+    case 4: ASV_QCONV(Q128P, false); break;
+    case 8: ASV_QCONV(Q128F, false); break;
+    case 5: ASV_QCONV(Q256, false); break;
+    case 6: ASV_QCONV(Q256P, false); break;
+    case 9: ASV_QCONV(Q256F, false); break;
+    case 10: ASV_QCONV(Q128g, true); break;
+    case 11: ASV_QCONV(Q128Fg, true); break;
+    case 12: ASV_QCONV(Q128Pg, true); break;
+    case 13: ASV_QCONV(Q256g, true); break;
+    case 14: ASV_QCONV(Q256Fg, true); break;
+    default: ASV_QCONV(Q256Pg, true); break;
   }
 #undef ASV_QCONV
-#undef ASV_QCONV2
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }

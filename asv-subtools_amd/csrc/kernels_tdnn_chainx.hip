@@ -56,8 +56,9 @@ __device__ __forceinline__ void chainx_glds16(const void *gsrc, uint32_t lds_dst
 
 // two f32 -> hi pair + lo pair of the 16-bit type (kernels_tdnn_x3.hip x3_split)
 template <int ET>
-__device__ __forceinline__ void split2(float v0, float v1, uint32_t &hi, uint32_t &lo) {
+__device__ __forceinline__ void split2(float v0, float v1, uint32_t &hi, uint32_t &lo, uint32_t &range) {
   hi = pack_h16x2<ET>(v0, v1);
+  if constexpr (ET == ET_F16) range |= h16_range_bits(hi);         // range watch of the half split (device_utils.h)
   float r0, r1;
   if constexpr (ET == ET_F16) {
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(v0));
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainx_kernel(const TdnnChainPara
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
   const int m0 = blockIdx.x * XM;
+  uint32_t range = 0u;                      // range watch of the half split (device_utils.h): layer A's window and the resident tiles
   const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(chainx_lds_byte *)lds);
   float *par = reinterpret_cast<float *>(lds + XPAR);
   const uint32_t lane16 = (uint32_t)lane * 16u;
@@ -157,10 +159,10 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainx_kernel(const TdnnChainPara
         const uint4 a = *reinterpret_cast<const uint4 *>(src + wswz(w, 2 * q) * 16);
         const uint4 b = *reinterpret_cast<const uint4 *>(src + wswz(w, 2 * q + 1) * 16);
         uint4 hi, lo;
-        split2<ET>(__uint_as_float(a.x), __uint_as_float(a.y), hi.x, lo.x);
-        split2<ET>(__uint_as_float(a.z), __uint_as_float(a.w), hi.y, lo.y);
-        split2<ET>(__uint_as_float(b.x), __uint_as_float(b.y), hi.z, lo.z);
-        split2<ET>(__uint_as_float(b.z), __uint_as_float(b.w), hi.w, lo.w);
+        split2<ET>(__uint_as_float(a.x), __uint_as_float(a.y), hi.x, lo.x, range);
+        split2<ET>(__uint_as_float(a.z), __uint_as_float(a.w), hi.y, lo.y, range);
+        split2<ET>(__uint_as_float(b.x), __uint_as_float(b.y), hi.z, lo.z, range);
+        split2<ET>(__uint_as_float(b.z), __uint_as_float(b.w), hi.w, lo.w, range);
         unsigned char *dst = lds + (2 + (c & 1)) * XSTG + w * XROW;
         *reinterpret_cast<uint4 *>(dst + wswz(w, q) * 16) = hi;
         *reinterpret_cast<uint4 *>(dst + wswz(w, 4 + q) * 16) = lo;
@@ -278,8 +280,8 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainx_kernel(const TdnnChainPara
             y[e] = affine ? fmaf(v, sc[e], sh[e]) : v;
           }
           uint2 hi, lo;
-          split2<ET>(y[0], y[1], hi.x, lo.x);
-          split2<ET>(y[2], y[3], hi.y, lo.y);
+          split2<ET>(y[0], y[1], hi.x, lo.x, range);
+          split2<ET>(y[2], y[3], hi.y, lo.y, range);
           unsigned char *dst = lds + (i * 32 + lr) * YROW + slot_off;
           *reinterpret_cast<uint2 *>(dst) = hi;
           *reinterpret_cast<uint2 *>(dst + YIMG) = lo;
@@ -440,6 +442,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainx_kernel(const TdnnChainPara
       publish();
     }
   }
+  x3_publish_range(range, p.status);
 }
 
 }  // namespace

@@ -143,6 +143,7 @@ __global__ __launch_bounds__(256, MF == 2 ? 3 : 2) void tdnn_gemm_x3_kernel(cons
   const unsigned char *wh_base = reinterpret_cast<const unsigned char *>(p.wfrag) + wf_off0;
   const unsigned char *wl_base = reinterpret_cast<const unsigned char *>(p.wlo) + wf_off0;
 
+  uint32_t range = 0u;                       // range watch of the half split (device_utils.h)
   struct WFrags { uint4 h[2], l[2]; };
   struct XFrags { X3Frag f[MF]; };
   // k-group index g runs over (chunk, tap, half): g = (c * n_taps + t) * 2 + kg
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256, MF == 2 ? 3 : 2) void tdnn_gemm_x3_kernel(cons
         const int w = item >> 2, q = item & 3;
         const uint4 a = *reinterpret_cast<const uint4 *>(src + w * XROWB + xswz(w, 2 * q) * 16);
         const uint4 b = *reinterpret_cast<const uint4 *>(src + w * XROWB + xswz(w, 2 * q + 1) * 16);
-        const X3Frag f = x3_split<ET, true>(a, b);
+        const X3Frag f = x3_split<ET, true>(a, b, range);
         *reinterpret_cast<uint4 *>(dst + w * XROWB + xswz(w, q) * 16) = f.hi;
         *reinterpret_cast<uint4 *>(dst + w * XROWB + xswz(w, 4 + q) * 16) = f.lo;
       }
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(256, MF == 2 ? 3 : 2) void tdnn_gemm_x3_kernel(cons
       const int w = i * 32 + lr + kHalo + d;
       const uint4 a = *reinterpret_cast<const uint4 *>(Ab + w * XROWB + xswz(w, s0) * 16);
       const uint4 b = *reinterpret_cast<const uint4 *>(Ab + w * XROWB + xswz(w, s0 + 1) * 16);
-      x.f[i] = x3_split<ET, (TERMS & 2) != 0>(a, b);
+      x.f[i] = x3_split<ET, (TERMS & 2) != 0>(a, b, range);
     }
   };
 
@@ -342,6 +343,7 @@ __global__ __launch_bounds__(256, MF == 2 ? 3 : 2) void tdnn_gemm_x3_kernel(cons
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();            // the ring becomes epilogue scratch
+  x3_publish_range(range, p.status);
   asm volatile("" ::: "memory");
 
   // ---- epilogue: acc[i][j][r]: frame = m0 + i*32 + lr, channel = n0 + wn*64 + j*32 + 8*(r>>2) + 4*lh + (r&3)

@@ -171,7 +171,7 @@ struct asv_net {
   DevMem splitk_dev;                     // split-K partial accumulators
   DevMem poolpart_dev;                   // fused-pooling partial moments
   DevMem lde_dev;                        // LDE pooling: per-row centre weights [rows][64]
-  void *zero_page = nullptr;             // 256 zero bytes (masked direct-to-LDS loads)
+  void *zero_page = nullptr;             // 256 zero bytes (masked direct-to-LDS loads); bytes 128..131: the status word (asv_net_status)
   void *meta_host = nullptr;             // pinned staging
   size_t meta_host_cap = 0;
   hipEvent_t meta_copied = nullptr;      // H2D of meta_host finished
@@ -201,6 +201,9 @@ struct asv_net {
 };
 
 namespace {
+
+// the range-status word of the f32x kernels lives behind the zero page's zeros (own 64-byte line; kernels only ever OR into it)
+uint32_t *status_word(asv_net *net) { return reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(net->zero_page) + 128); }
 
 int dev_upload(asv_net *net, const void *host, size_t bytes, void **out) {
   void *d = nullptr;
@@ -881,6 +884,18 @@ int asv_net_finalize(asv_net_t *net, int out_buf, int embed_dim) {
 
 int asv_net_embed_dim(const asv_net_t *net) { return net ? net->embed_dim : ASV_EINVAL; }
 
+int asv_net_status(asv_net_t *net, unsigned *status, void *stream) {
+  ASV_REQUIRE(net != nullptr && status != nullptr, "asv_net_status: null argument");
+  ASV_ON_DEVICE(net->device);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  uint32_t word = 0;
+  ASV_HIP_CHECK(hipMemcpyAsync(&word, status_word(net), sizeof(word), hipMemcpyDeviceToHost, s));
+  ASV_HIP_CHECK(hipMemsetAsync(status_word(net), 0, sizeof(word), s));
+  ASV_HIP_CHECK(hipStreamSynchronize(s));
+  *status = word;
+  return ASV_OK;
+}
+
 size_t asv_net_device_bytes(const asv_net_t *net) {
   if (!net) return 0;
   size_t n = net->weight_bytes + net->meta_dev.cap + net->rowmeta_dev.cap;
@@ -1117,6 +1132,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         memset(&p, 0, sizeof(p));
         p.et = et; p.x3_et = net->x3_et(); p.x3_terms = net->x3_terms(); p.w_unscale = 1.0f / op.w_scale;
         p.x3_tile = (net->flags & ASV_FLAG_X3_TILE128) ? 128 : 0;
+        p.status = status_word(net);
         p.x = view(c, d.in_buf, d.in_ch_off); p.ldx = net->bufs[d.in_buf].ld;
         if (d.in2_buf >= 0) { p.x2 = view(c, d.in2_buf, d.in2_ch_off); p.ldx2 = net->bufs[d.in2_buf].ld; }
         p.w = op.w; p.bias = op.bias; p.scale = op.scale; p.shift = op.shift;
@@ -1168,6 +1184,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
             cp.pool_slots = slots; cp.ld_partial = lo.cout_pad; cp.row_seg = dr.row_seg;
             cp.et = chain_x3 ? net->x3_et() : et;
             cp.min_seg_len = min_len;
+            cp.status = status_word(net);
             if ((rc = ensure(net->poolpart_dev, (size_t)(p.rows >> tshift) * slots * 2 * 3 * cp.ld_partial * 4, c.s, false))) return rc;
             cp.pool_partial = reinterpret_cast<float *>(net->poolpart_dev.ptr);
             double fl = 0.0;

@@ -266,25 +266,35 @@ class Engine(object):
         the device, no host round trip).  Returns a CPU float32 tensor [B, E].
 
         Range guard of the default mode: 'f32x' splits every operand into IEEE-half halves, so an activation beyond +-65504
-        (un-normalised features of huge magnitude, a checkpoint whose BatchNorm lets a layer blow up) becomes inf and the
-        embedding NaN - the f32 reference has no such limit.  A batch that comes back non-finite is therefore re-run ONCE on a
-        lazily compiled twin of this engine with bf16 halves ('f32x-bf16': 16 significant bits per operand, the whole f32
-        exponent range; ~6e-6 relative, still inside the 1e-4 gate), with a warning.  If that is non-finite too, the input
-        itself is (NaN / inf features): returned as is, like the reference would.  extract_device() (device tensor out, no
-        host synchronisation) does not check."""
+        (un-normalised features of huge magnitude, a checkpoint whose BatchNorm lets a layer blow up) cannot be represented -
+        the f32 reference has no such limit - and the NaN products it causes are mapped to 0 by the next ReLU: wrong embeddings
+        without a trace.  The split kernels therefore watch the range of every hi half they produce and raise a status bit
+        (asv_net_status); a batch that raised it is re-run ONCE on a lazily compiled twin of this engine with bf16 halves
+        ('f32x-bf16': 16 significant bits per operand, the whole f32 exponent range; ~6e-6 relative, still inside the 1e-4
+        gate), with a warning.  extract_device() (device tensor out, no host synchronisation) does not check: call status()."""
         import torch
+        watch = self._range_fallback_applies()
+        if watch:
+            self.status()                                 # clear what earlier asynchronous calls may have left
         out = self._extract_batch(mats, max_chunk)
-        if self._range_fallback_applies() and out.numel() and not bool(torch.isfinite(out).all()):
+        if watch and out.numel() and (self.status() & capi.STATUS_HALF_RANGE):
             import warnings
-            warnings.warn("asv-subtools_amd: non-finite embeddings in the f32x mode (an activation beyond the IEEE-half range of its operand split?): "
+            warnings.warn("asv-subtools_amd: an activation left the IEEE-half range of the f32x mode's operand split (|x| > 65504 or NaN): "
                           "re-running the batch with bf16 operand halves (precision 'f32x-bf16')", RuntimeWarning)
             if getattr(self, "_wide_range_twin", None) is None:
                 self._wide_range_twin = Engine(self.graph, device_index=self.device_index, precision="f32x-bf16",
                                                flags=self.flags & ~(capi.FLAG_X3_SPLIT_F16 | capi.FLAG_X3_SPLIT_BF16))
-            again = self._wide_range_twin._extract_batch(mats, max_chunk)
-            bad = ~torch.isfinite(out).all(dim=1)
-            out[bad] = again[bad]                        # utterances that were fine keep their f32-grade result (batch invariance)
+            out = self._wide_range_twin._extract_batch(mats, max_chunk)
         return out
+
+    def status(self, stream=None):
+        """Range status bits since the last call (capi.STATUS_HALF_RANGE); synchronises on `stream` (default: the current one)."""
+        import torch
+        if stream is None:
+            stream = torch.cuda.current_stream(torch.device("cuda", self.device_index)).cuda_stream
+        word = C.c_uint(0)
+        capi.check(self.lib.asv_net_status(self._net, C.byref(word), C.c_void_p(stream)), "asv_net_status")
+        return int(word.value)
 
     def _range_fallback_applies(self):
         return self.precision_base in ("f32x", "f16x3") and (self.flags & (capi.FLAG_X3_SPLIT_BF16 | capi.FLAG_REF_KERNELS)) == 0

@@ -252,6 +252,13 @@ int asv_net_describe(const asv_net_t *net, char *buf, size_t cap);
 int asv_net_extract(asv_net_t *net, const float *feats, const int32_t *offsets, int n_utts,
                     float *out, int max_chunk, void *stream);
 
+/* Range status of the extractions since the last call (ASV_PREC_F32X with IEEE-half operand halves, the default split): bit
+ * ASV_STATUS_HALF_RANGE is set when an activation beyond +-65504 (or a NaN) met the operand split - the affected embeddings are then
+ * wrong (the f32 reference has no such limit) and the batch should be re-extracted on a net created with ASV_FLAG_X3_SPLIT_BF16
+ * (bf16 halves: the whole f32 exponent range, ~6e-6 relative).  Waits for `stream`, returns the bits in *status and clears them. */
+#define ASV_STATUS_HALF_RANGE 1u
+int asv_net_status(asv_net_t *net, unsigned *status, void *stream);
+
 /* Bytes of device memory currently held by the net (weights + activation arena). */
 size_t asv_net_device_bytes(const asv_net_t *net);
 

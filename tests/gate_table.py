@@ -4,8 +4,9 @@
     embedding gate   max |e(mode) - e(f32)| / max |e(f32)| < 1e-4 over a planted-speaker set, and
     EER gate         |EER(mode) - EER(f32)| < 0.01 % absolute on the same trials,
 
-on >= 3 weight seeds x >= 3 trial lists of the set's own size class (50 000 / 37 720 / 20 000 trials: one flipped trial moves
-an error rate by 0.004 - 0.01 %) plus one list of 500 000 trials per weight seed.  A mode "passes the EER gate" only if it
+on >= 3 weight seeds x >= 3 trial lists (50 000 / 37 720 / 50 000 trials with 50 % targets: one flipped trial moves an error rate
+by 0.004 - 0.005 %, so every list resolves the gate - a 20 000-trial list, where ONE trial is exactly 0.01 %, cannot: the first
+version of the ResNet table showed one such draw) plus one list of 500 000 trials per weight seed.  A mode "passes the EER gate" only if it
 passes on EVERY draw.  The exact-f32 extraction is the reference-equivalent one (pinned to the reference's own outputs by the
 golden fixtures and to the numpy oracle on utterances of these very sets by tests/test_gpu_eer_gate.py, c4_standin.py,
 c5_standin.py).  Scoring chains: cosine (sub-mean, length-norm, dot products: score/process.sh:177-203, score/score.sh:82-97)
@@ -36,7 +37,7 @@ MODELS = {
     # name: (blueprint, creation, scoring chain, planted set (speakers, per speaker, t_lo, t_hi, noise), trials per list)
     "xvector": ("xvector.py", "Xvector(%d,10,training=False)", "cosine", (1177, 4, 200, 500, 0.8), 50_000),
     "ecapa": ("ecapa_tdnn_xvector.py", "ECAPA_TDNN(%d,10,training=False)", "cosine", (1177, 4, 200, 500, 0.1), 37_720),
-    "resnet": ("resnet_xvector.py", RESNET_CREATION, "plda", (500, 4, 200, 1000, 0.8), 20_000),
+    "resnet": ("resnet_xvector.py", RESNET_CREATION, "plda", (500, 8, 200, 1000, 0.8), 50_000),
 }
 
 
@@ -97,7 +98,7 @@ class Gates(object):
             i = j
         self.planted = dict(speakers=n_spk, per_speaker=per_spk, frames_lo=t_lo, frames_hi=t_hi, noise=noise, utterances=self.n_utts, frames=self.frames)
         if self.chain == "plda":
-            self.train_mask = self.labels < int(round(0.6 * n_spk))
+            self.train_mask = self.labels < int(round(0.5 * n_spk))     # half of the speakers train the PLDA, the others are scored
             self.eval_labels = self.labels[~self.train_mask]
         else:
             self.train_mask, self.eval_labels = None, self.labels
