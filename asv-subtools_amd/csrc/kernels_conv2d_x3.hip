@@ -55,8 +55,14 @@ struct QGeom {
   static_assert(WM * WN == 4 && MF % UI == 0 && 2 * LDS <= 163840, "grid conv (f32x) geometry");
 };
 
-template <typename G, int ET, bool GENERIC = false>
+// MODE 0: one input, the plain epilogue (bias -> [ReLU] -> folded BN); 1: + a second input added while the rows are staged (Res2Net's
+// sp + x_i), plain epilogue; 2: the long epilogue of device_utils.h tdnn_epilogue (tanh / sigmoid / "bn-relu" order / per-segment bias
+// and scale / residual), with or without a second input - kept ROLLED (one copy of its code per kernel, applied to the rows on their
+// way out of the per-wave tile): unrolled over the 64 accumulator pieces it was measured 2.3 x slower than the whole K loop
+template <typename G, int ET, int MODE = 0>
 __global__ __launch_bounds__(256, 2) void grid_conv_x3_kernel(const TdnnKernelParams p, const int n_tiles, const int nft) {
+  constexpr bool GENERIC = MODE != 0;         // (registers for a second input)
+  constexpr bool LONG_EPI = MODE == 2;
   constexpr int WN = G::WN, MF = G::MF, NFW = G::NFW, HLO = G::HLO, BM = G::BM, BN = G::BN, WIN = G::WIN, NP = G::NP, UI = G::UI, NU = G::NU;
   __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -261,23 +267,24 @@ __global__ __launch_bounds__(256, 2) void grid_conv_x3_kernel(const TdnnKernelPa
 #pragma unroll
   for (int i = 0; i < MF; ++i) {
     const int rbase = m0 + wm * (MF * 32) + i * 32;
-    const bool valid = (p.row_valid[rbase >> 5] >> lr) & 1u;
+    const uint32_t vbits = p.row_valid[rbase >> 5];
+    const bool valid = (vbits >> lr) & 1u;
 #pragma unroll
     for (int j = 0; j < NFW; ++j)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int chl = (wn * NFW + j) * 32 + 8 * q + 4 * lh;
-        const float4 b4 = *reinterpret_cast<const float4 *>(lds_par + chl);
-        const float4 sc4 = *reinterpret_cast<const float4 *>(lds_par + BN + chl);
-        const float4 sh4 = *reinterpret_cast<const float4 *>(lds_par + 2 * BN + chl);
-        const float b[4] = {b4.x, b4.y, b4.z, b4.w}, sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
         float y[4];
+        if constexpr (LONG_EPI) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if constexpr (GENERIC) {
-            // tanh / sigmoid / "bn-relu" order / per-segment bias and scale / residual: the shared epilogue of device_utils.h
-            y[e] = tdnn_epilogue<ET_F32>(p, acc[i][j][q * 4 + e] * unscale, rbase + lr, n0 + chl + e, b[e], sc[e], sh[e], valid);
-          } else {
+          for (int e = 0; e < 4; ++e) y[e] = acc[i][j][q * 4 + e] * unscale;          // the epilogue itself: on the way out, below
+        } else {
+          const float4 b4 = *reinterpret_cast<const float4 *>(lds_par + chl);
+          const float4 sc4 = *reinterpret_cast<const float4 *>(lds_par + BN + chl);
+          const float4 sh4 = *reinterpret_cast<const float4 *>(lds_par + 2 * BN + chl);
+          const float b[4] = {b4.x, b4.y, b4.z, b4.w}, sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
             const float z = fmaxf(fmaf(acc[i][j][q * 4 + e], unscale, b[e]), act_lo) * sc[e] + sh[e];      // = tdnn_epilogue_fast for unscale = 1
             y[e] = valid ? z : 0.0f;
           }
@@ -287,11 +294,27 @@ __global__ __launch_bounds__(256, 2) void grid_conv_x3_kernel(const TdnnKernelPa
     // the tile is wave-private: LDS operations of one wave complete in order
     constexpr int SLOTS = NFW * 8;                                // float4 per row of the tile
     constexpr int RPI = 64 / SLOTS;                               // rows per store instruction: 8 | 4
+    if constexpr (LONG_EPI) {
+#pragma unroll 1
+      for (int it = 0; it < 32 / RPI; ++it) {
+        const int frow = it * RPI + lane / SLOTS, slot = lane % SLOTS;
+        const float4 v = *reinterpret_cast<const float4 *>(scr + frow * G::SPITCH + slot * 4);
+        const int chl = wn * (NFW * 32) + slot * 4;
+        const bool ok = (vbits >> frow) & 1u;
+        const float a[4] = {v.x, v.y, v.z, v.w};
+        float y[4];
+#pragma unroll 1
+        for (int e = 0; e < 4; ++e)
+          y[e] = tdnn_epilogue<ET_F32>(p, a[e], rbase + frow, n0 + chl + e, lds_par[chl + e], lds_par[BN + chl + e], lds_par[2 * BN + chl + e], ok);
+        *reinterpret_cast<float4 *>(yg + (size_t)(rbase + frow) * p.ldy + n0 + chl) = make_float4(y[0], y[1], y[2], y[3]);
+      }
+    } else {
 #pragma unroll
-    for (int it = 0; it < 32 / RPI; ++it) {
-      const int frow = it * RPI + lane / SLOTS, slot = lane % SLOTS;
-      const float4 v = *reinterpret_cast<const float4 *>(scr + frow * G::SPITCH + slot * 4);
-      *reinterpret_cast<float4 *>(yg + (size_t)(rbase + frow) * p.ldy + n0 + wn * (NFW * 32) + slot * 4) = v;
+      for (int it = 0; it < 32 / RPI; ++it) {
+        const int frow = it * RPI + lane / SLOTS, slot = lane % SLOTS;
+        const float4 v = *reinterpret_cast<const float4 *>(scr + frow * G::SPITCH + slot * 4);
+        *reinterpret_cast<float4 *>(yg + (size_t)(rbase + frow) * p.ldy + n0 + wn * (NFW * 32) + slot * 4) = v;
+      }
     }
   }
 }
@@ -402,30 +425,37 @@ int launch_grid_conv_x3(const TdnnKernelParams &p, hipStream_t s) {
   // the hot instantiations carry the short epilogue only; tanh / sigmoid / per-segment terms / residual / "bn-relu" order / a second
   // input go to the GENERIC ones
   const bool fast = plain_epilogue(p);
-#define ASV_QCONV(GEO, GENV) do { if (p.x3_et == ET_F16) hipLaunchKernelGGL((grid_conv_x3_kernel<GEO, ET_F16, GENV>), grid, block, 0, s, p, n_tiles, nft); \
-                                  else hipLaunchKernelGGL((grid_conv_x3_kernel<GEO, ET_BF16, GENV>), grid, block, 0, s, p, n_tiles, nft); } while (0)
+  const bool long_epi = !((p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first && p.seg_bias == nullptr &&
+                          p.seg_scale == nullptr && p.res == nullptr);
+#define ASV_QCONV1(GEO, MODEV) do { if (p.x3_et == ET_F16) hipLaunchKernelGGL((grid_conv_x3_kernel<GEO, ET_F16, MODEV>), grid, block, 0, s, p, n_tiles, nft); \
+                                    else hipLaunchKernelGGL((grid_conv_x3_kernel<GEO, ET_BF16, MODEV>), grid, block, 0, s, p, n_tiles, nft); } while (0)
+  // FAST: MODE 0; GEN: MODE 1 (second input, plain epilogue) or 2 (the long epilogue)
+#define ASV_QCONV_FAST(GEO) ASV_QCONV1(GEO, 0)
+#define ASV_QCONV_GEN(GEO) do { if (long_epi) ASV_QCONV1(GEO, 2); else ASV_QCONV1(GEO, 1); } while (0)
   // the small-tile geometries (ids 0 - 2, 7) carry both epilogues; the 128- / 256-channel ones have a geometry per epilogue (the long one
   // and the second input's registers do not fit beside 128 accumulator registers)
   (void)fast;
   switch (g.id) {
-    case 0: if (fast) ASV_QCONV(Q32, false); else ASV_QCONV(Q32, true); break;
-    case 1: if (fast) ASV_QCONV(Q64, false); else ASV_QCONV(Q64, true); break;
-    case 2: if (fast) ASV_QCONV(Q64P, false); else ASV_QCONV(Q64P, true); break;
-    case 7: if (fast) ASV_QCONV(Q64F, false); else ASV_QCONV(Q64F, true); break;
-    case 3: ASV_QCONV(Q128, false); break;
-    case 4: ASV_QCONV(Q128P, false); break;
-    case 8: ASV_QCONV(Q128F, false); break;
-    case 5: ASV_QCONV(Q256, false); break;
-    case 6: ASV_QCONV(Q256P, false); break;
-    case 9: ASV_QCONV(Q256F, false); break;
-    case 10: ASV_QCONV(Q128g, true); break;
-    case 11: ASV_QCONV(Q128Fg, true); break;
-    case 12: ASV_QCONV(Q128Pg, true); break;
-    case 13: ASV_QCONV(Q256g, true); break;
-    case 14: ASV_QCONV(Q256Fg, true); break;
-    default: ASV_QCONV(Q256Pg, true); break;
+    case 0: if (fast) ASV_QCONV_FAST(Q32); else ASV_QCONV_GEN(Q32); break;
+    case 1: if (fast) ASV_QCONV_FAST(Q64); else ASV_QCONV_GEN(Q64); break;
+    case 2: if (fast) ASV_QCONV_FAST(Q64P); else ASV_QCONV_GEN(Q64P); break;
+    case 7: if (fast) ASV_QCONV_FAST(Q64F); else ASV_QCONV_GEN(Q64F); break;
+    case 3: ASV_QCONV_FAST(Q128); break;
+    case 4: ASV_QCONV_FAST(Q128P); break;
+    case 8: ASV_QCONV_FAST(Q128F); break;
+    case 5: ASV_QCONV_FAST(Q256); break;
+    case 6: ASV_QCONV_FAST(Q256P); break;
+    case 9: ASV_QCONV_FAST(Q256F); break;
+    case 10: ASV_QCONV_GEN(Q128g); break;
+    case 11: ASV_QCONV_GEN(Q128Fg); break;
+    case 12: ASV_QCONV_GEN(Q128Pg); break;
+    case 13: ASV_QCONV_GEN(Q256g); break;
+    case 14: ASV_QCONV_GEN(Q256Fg); break;
+    default: ASV_QCONV_GEN(Q256Pg); break;
   }
-#undef ASV_QCONV
+#undef ASV_QCONV_FAST
+#undef ASV_QCONV_GEN
+#undef ASV_QCONV1
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }
