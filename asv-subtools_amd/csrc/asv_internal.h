@@ -195,7 +195,22 @@ struct TdnnChainParams {
   int et;                       // ET_BF16 / ET_F16: element type of the rows and of every layer's weight fragments
   int min_seg_len;              // shortest utterance of the batch in frames (the 4-wave kernel needs >= 32: at most one seam per 32-frame fragment)
   uint32_t *status;             // f32x chain: as TdnnKernelParams::status
+  int n128, n96;                // 16-bit chain: the launch's tile plan (chain_tile_plan): n128 tiles of 128 frames, then n96 of 96
+  int row_base, tile_base;      // set by the launcher per kernel launch: first row / first partial-moment block of that launch
 };
+// How the 16-bit chain kernel cuts `rows` (a multiple of 128) into tiles: whole rounds of the chip's workgroup slots in 128-frame
+// tiles; the last, partly filled round - R tiles left for `cus` CUs - as ceil(R * 128 / 96) tiles of 96 frames when they fit one
+// round (R <= 3/4 cus): the same rows on more CUs, each for 3/4 of the time.  Partial-moment block t covers rows
+// [row0(t), row0(t) + rows_of(t)); rows beyond `rows` (the last 96-frame tile may overhang) are gap rows.
+struct ChainTilePlan {
+  int n128 = 0, n96 = 0;
+  int rows128() const { return n128 * 128; }
+  int tiles() const { return n128 + n96; }
+  int tile_of(int row) const { return row < rows128() ? row >> 7 : n128 + (row - rows128()) / 96; }
+  int row0(int t) const { return t < n128 ? t * 128 : rows128() + (t - n128) * 96; }
+  int rows_of(int t) const { return t < n128 ? 128 : 96; }
+};
+ChainTilePlan chain_tile_plan(int rows, bool allow_tail);
 int launch_tdnn_chain(const TdnnChainParams &p, hipStream_t s);
 #ifdef ASV_WITH_ABLATION
 // the same chain as four waves of 512 registers, pooling arithmetic inside the next unit's K loop (tools/kernels_tdnn_chain4.hip:
@@ -231,6 +246,7 @@ struct PoolFinishParams {
   const float *partial; int ld_partial, pool_slots;
   int lh_split;                  // partials of the chain kernel: [tile][slot][lh][3][ld], lh = bit 2 of the row index of the frames summed
   int tile_shift;                // log2 of the rows one partial covers: 7 (128-row tiles; 0 means 7) or 6 (the f32x chain's 64-row tiles)
+  int rows_shift, tail_rows, n_shift;   // tiles behind row `rows_shift` (0 = none): blocks n_shift + k cover `tail_rows` rows each (ChainTilePlan: 96)
   const int32_t *row_seg; int rows;
   const int32_t *seg_row0, *seg_len;
   const float *shift;            // per-channel BN shift that the producer left out (or nullptr)

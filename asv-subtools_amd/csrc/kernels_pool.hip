@@ -278,12 +278,19 @@ __global__ __launch_bounds__(64) void pool_finish_kernel(const PoolFinishParams 
   // step's 700 us, most of it double-precision divisions); every partial holds sum (u - pv), sum (u - pv)^2 about its own pivot pv
   float n_acc = 0.0f, mean = 0.0f, m2 = 0.0f;
   const int ts = p.tile_shift ? p.tile_shift : 7;       // rows per partial: 128, or 64 (f32x chain)
-  for (int h = row0 >> ts; h <= (row0 + len - 1) >> ts; ++h) {
+  // blocks of 2^ts rows up to row `rows_shift`, blocks of `tail_rows` rows behind it (the 16-bit chain's 96-frame tiles for the last
+  // round of workgroups, ChainTilePlan; rows_shift = 0: uniform blocks)
+  const int r_shift = p.rows_shift > 0 ? p.rows_shift : 0x7fffffff;
+  auto block_of = [&](int row) { return row < r_shift ? row >> ts : p.n_shift + (row - r_shift) / p.tail_rows; };
+  auto block_row0 = [&](int h) { return (p.rows_shift > 0 && h >= p.n_shift) ? r_shift + (h - p.n_shift) * p.tail_rows : h << ts; };
+  auto block_rows = [&](int h) { return (p.rows_shift > 0 && h >= p.n_shift) ? p.tail_rows : 1 << ts; };
+  for (int h = block_of(row0); h <= block_of(row0 + len - 1); ++h) {
+    const int h0 = block_row0(h);
     int first = -1;
     for (int k = 0; k < kHalo + 1 && first < 0; ++k)
-      if ((h << ts) + k < p.rows) first = p.row_seg[(h << ts) + k];
+      if (h0 + k < p.rows) first = p.row_seg[h0 + k];
     const int slot = seg - first;                       // segments are consecutive in row order
-    const int a = max(row0, h << ts), b = min(row0 + len, (h + 1) << ts);
+    const int a = max(row0, h0), b = min(row0 + len, h0 + block_rows(h));
     const int parts = p.lh_split ? 2 : 1;
     for (int part = 0; part < parts; ++part) {
       int cnt = b - a;

@@ -48,21 +48,26 @@
 namespace asv {
 namespace {
 
-constexpr int CM = 128;                   // frames per workgroup
 constexpr int CN = kChainWidth;           // channels of the resident tile (512)
 constexpr int CBK = 64;
 constexpr int CROWB = 128;                // window row: 64 bf16
 constexpr int CSTAGES = 4;
-constexpr int CWIN = CM + 2 * kHalo;      // 136
-constexpr int CSTAGE = CWIN * CROWB;      // 17408 B
-constexpr int CGROUPS = CWIN / 8;         // 17 eight-row DMA pieces
-constexpr int CPIECES = (CGROUPS + 7) / 8;   // 3 per wave
 constexpr int YROWB = CN * 2;             // 1024 B per Y row
-constexpr int Y_BYTES = CM * YROWB;       // 131072
-constexpr int SCR_OFF = Y_BYTES;          // 32 KiB: epilogue constants (phases 1, 2) | 8 x 4 KiB pooling scratch (last phase)
-constexpr int CHAIN_LDS = Y_BYTES + 32768;
-static_assert(CSTAGES * CSTAGE <= Y_BYTES, "the window ring lives inside the Y region");
-static_assert(CHAIN_LDS <= 163840, "160 KiB of LDS per CU");
+// MF = 32-frame fragments per tile: 4 (128 frames, the default) or 3 (96 frames: the instantiation for the LAST, partly filled round of
+// workgroups - 152 tiles of 128 frames left over for 256 CUs become 203 tiles of 96, a round that takes 3/4 of the time; see
+// launch_tdnn_chain)
+template <int MF> struct ChainGeom {
+  static constexpr int CM = MF * 32;                  // frames per workgroup
+  static constexpr int CWIN = CM + 2 * kHalo;         // 136 | 104
+  static constexpr int CSTAGE = CWIN * CROWB;         // 17408 | 13312 B
+  static constexpr int CGROUPS = CWIN / 8;            // 17 | 13 eight-row DMA pieces
+  static constexpr int CPIECES = (CGROUPS + 7) / 8;   // 3 | 2 per wave
+  static constexpr int Y_BYTES = CM * YROWB;          // 131072 | 98304
+  static constexpr int SCR_OFF = Y_BYTES;             // 32 KiB: epilogue constants (phases 1, 2) | 8 x 4 KiB pooling scratch (last phase)
+  static constexpr int LDS = Y_BYTES + 32768;
+  static_assert(CSTAGES * CSTAGE <= Y_BYTES, "the window ring lives inside the Y region");
+  static_assert(LDS <= 163840, "160 KiB of LDS per CU");
+};
 
 typedef __attribute__((address_space(3))) unsigned char chain_lds_byte;
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -93,13 +98,15 @@ __device__ __forceinline__ void chain_glds16_s(const void *sbase, uint32_t voff,
 //        4 (results valid) = the last layer in lockstep: a workgroup barrier behind every unit's K loop and behind every pooling
 //        epilogue, so that the two waves of a SIMD run their loops together (sharing the matrix pipe at its full rate) and their
 //        epilogues together (no matrix stream beside the packed f32 arithmetic, which otherwise only issues in its gaps).
-template <int POOLV, int ET = ET_BF16, int ABL = 0>
+template <int POOLV, int ET = ET_BF16, int ABL = 0, int MF = 4>
 __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParams p) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[CHAIN_LDS];
+  using Geo = ChainGeom<MF>;
+  constexpr int CM = Geo::CM, CSTAGE = Geo::CSTAGE, CGROUPS = Geo::CGROUPS, CPIECES = Geo::CPIECES, SCR_OFF = Geo::SCR_OFF;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[Geo::LDS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // 0..7: channel slice of phases 1-2, unit index of the last
   const int lr = lane & 31, lh = lane >> 5;
-  const int m0 = blockIdx.x * CM;
+  const int m0 = p.row_base + blockIdx.x * CM;                      // (row_base / tile_base: the launch's first row and tile, launch_tdnn_chain)
   const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(chain_lds_byte *)lds);
   float *par = reinterpret_cast<float *>(lds + SCR_OFF);            // bias[512] | scale[512] | shift[512] of the layer in flight
 
@@ -127,8 +134,8 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
   };
 
   uint4 wf[4][2];
-  f32x16_t acc[4][2];
-  struct XFrags { uint4 x[4]; };
+  f32x16_t acc[MF][2];
+  struct XFrags { uint4 x[MF]; };
   // the accumulators start from the bias (one v_mov per register either way; saves the add in every epilogue):
   // acc[i][j][4 q + e] belongs to channel j * 32 + 8 q + 4 lh + e of the wave's 64-channel slice, for every frame fragment i
   auto init_acc = [&](const float *bias64) {
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
       for (int q = 0; q < 4; ++q) {
         const float4 b4 = *reinterpret_cast<const float4 *>(bias64 + j * 32 + 8 * q + 4 * lh);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MF; ++i) {
           acc[i][j][q * 4 + 0] = b4.x; acc[i][j][q * 4 + 1] = b4.y; acc[i][j][q * 4 + 2] = b4.z; acc[i][j][q * 4 + 3] = b4.w;
         }
       }
@@ -149,7 +156,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
   //              fragment i - the pooling epilogue then sums over frames inside a lane, without any transposition.
   auto mma2 = [&](const XFrags &f, int kg, int j, int i0, auto tr) {
 #pragma unroll
-    for (int i = i0; i < i0 + 2; ++i) {
+    for (int i = i0; i < i0 + 2 && i < MF; ++i) {
       if constexpr (decltype(tr)::value) acc[i][j] = mfma16<ET>(f.x[i], wf[kg][j], acc[i][j]);
       else acc[i][j] = mfma16<ET>(wf[kg][j], f.x[i], acc[i][j]);
     }
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
     XFrags x0, x1;
     uint32_t xb = x_base(0, d_first);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) load_x4(xb, 0, i, x0);
+    for (int i = 0; i < MF; ++i) load_x4(xb, 0, i, x0);
 #pragma unroll 1
     for (int c = 0; c < nchunks; ++c) {
       for (int t = 0; t < n_taps; ++t) {
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
         auto group = [&](const XFrags &xc, int kg, XFrags &xn, uint32_t xbn, int kgn) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            load_x4(xbn, kgn, q, xn);
+            if (q < MF) load_x4(xbn, kgn, q, xn);
             mma2(xc, kg, q / 2, (q % 2) * 2, TrNo{});
             if (q == 1) wf[kg][0] = *reinterpret_cast<const uint4 *>(wA0 + wnext + (size_t)kg * 1024 + lane16);
             if (q == 3) wf[kg][1] = *reinterpret_cast<const uint4 *>(wA1 + wnext + (size_t)kg * 1024 + lane16);
@@ -274,7 +281,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
         for (int q = 0; q < 4; ++q) {
           unsigned char *dst = yrow + (((wave * 8 + j * 4 + q) ^ rx) << 4);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
+          for (int i = 0; i < MF; ++i) {
             uint2 pk;
             pk.x = pack_h16x2<ET>(acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1]);
             pk.y = pack_h16x2<ET>(acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
         const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
         unsigned char *dst = yrow + (((wave * 8 + j * 4 + q) ^ rx) << 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MF; ++i) {
           float y[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) y[e] = fmaf(max_lo(acc[i][j][q * 4 + e], act_lo), sc[e], sh[e]);
@@ -323,7 +330,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
     if constexpr (decltype(tr)::value) {                        // lane = channel: one bias per lane and channel fragment
       const float b0 = bias64[lr], b1 = bias64[32 + lr];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MF; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[i][0][r] = b0; acc[i][1][r] = b1; }
     } else {
@@ -331,7 +338,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
     }
     XFrags x0, x1;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) load_y4(0, 0, i, x0);
+    for (int i = 0; i < MF; ++i) load_y4(0, 0, i, x0);
 #pragma unroll 1
     for (int c = 0; c < CN / CBK; ++c) {
       const int cn = min(c + 1, CN / CBK - 1);
@@ -339,7 +346,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
       auto group = [&](const XFrags &xc, int kg, XFrags &xn, int c2, int kgn) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          load_y4(c2, kgn, q, xn);
+          if (q < MF) load_y4(c2, kgn, q, xn);
           mma2(xc, kg, q / 2, (q % 2) * 2, tr);
           if (q == 1) wf[kg][0] = *reinterpret_cast<const uint4 *>(wb0 + wnext + (size_t)kg * 1024 + lane16);
           if (q == 3) wf[kg][1] = *reinterpret_cast<const uint4 *>(wb1 + wnext + (size_t)kg * 1024 + lane16);
@@ -385,12 +392,14 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
   {
     const TdnnChainLayer &L = p.last;
     const float act_lo = L.relu ? 0.0f : -INFINITY;
-    const int half = m0 >> 7;
+    const int half = p.tile_base + (int)blockIdx.x;      // index of this tile's partial-moment block
     int first_seg = -1;
 #pragma unroll
     for (int k = 0; k < kHalo + 1; ++k)
       if (first_seg < 0 && m0 + k < p.rows) first_seg = p.row_seg[m0 + k];
-    const int rowseg_lo = p.row_seg[m0 + lane], rowseg_hi = p.row_seg[m0 + 64 + lane];
+    // row -> utterance of the tile's rows (-1: gap row; rows beyond the tile - the 96-frame form - or beyond the matrix count as gaps)
+    const int rowseg_lo = (m0 + lane < p.rows) ? p.row_seg[m0 + lane] : -1;
+    const int rowseg_hi = (64 + lane < CM && m0 + 64 + lane < p.rows) ? p.row_seg[m0 + 64 + lane] : -1;
     const size_t frag_stride = (size_t)(CN / CBK) * 4096;
 #pragma unroll 1
     for (int cb = wave * 64; cb < L.cout_pad; cb += 512) {
@@ -407,7 +416,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
       // shift is added to the mean by pool_finish.
       if constexpr (ABL == 1) {                // no pooling epilogue at all: the accumulators only have to stay alive up to here
 #pragma unroll
-        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(acc[i][0]), "v"(acc[i][1]));
+        for (int i = 0; i < MF; ++i) asm volatile("" ::"v"(acc[i][0]), "v"(acc[i][1]));
         stamp();
         continue;
       }
@@ -429,7 +438,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
           }
         };
   #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MF; ++i) {
           const int rs_vec = (i < 2) ? rowseg_lo : rowseg_hi;
           const unsigned long long in_frag = 0xffffffffull << ((i & 1) * 32);
           const unsigned long long m_valid = __builtin_amdgcn_ballot_w64(rs_vec >= 0) & in_frag;
@@ -508,7 +517,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
           }
         };
   #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MF; ++i) {
           const int rs_vec = (i < 2) ? rowseg_lo : rowseg_hi;
           const int shift = (i & 1) * 32;
           uint32_t rem = (uint32_t)(__builtin_amdgcn_ballot_w64(rs_vec >= 0) >> shift);       // rows of the fragment that belong to an utterance
@@ -593,14 +602,33 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
 
 }  // namespace
 
-int launch_tdnn_chain(const TdnnChainParams &p, hipStream_t s) {
+ChainTilePlan chain_tile_plan(int rows, bool allow_tail) {
+  ChainTilePlan plan;
+  const int n = rows / 128;
+  plan.n128 = n;
+  static const bool off = getenv("ASV_AMD_CHAIN_TAIL") != nullptr && atoi(getenv("ASV_AMD_CHAIN_TAIL")) == 0;      // A/B aid, read once: results equal either way
+  if (!allow_tail || off) return plan;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const int tail = n % cus;                          // tiles of the last round (one workgroup per CU: 160 KiB of LDS)
+  const int as96 = (tail * 128 + 95) / 96;
+  if (tail > 0 && as96 <= cus) { plan.n128 = n - tail; plan.n96 = as96; }
+  return plan;
+}
+
+int launch_tdnn_chain(const TdnnChainParams &p0, hipStream_t s) {
+  TdnnChainParams p = p0;
+  constexpr int CM = 128;
   ASV_REQUIRE(p.rows % CM == 0 && p.rows >= CM, "tdnn(chain): rows %d not a multiple of %d", p.rows, CM);
   ASV_REQUIRE(p.cin_pad % CBK == 0 && p.cin_pad >= CBK && p.n_taps >= 1 && p.n_taps <= ASV_MAX_TAPS, "tdnn(chain): first layer with %d channels / %d taps", p.cin_pad, p.n_taps);
   ASV_REQUIRE((unsigned long long)p.rows * (unsigned long long)p.ldx * 2ull < (1ull << 32), "tdnn(chain): input matrix beyond 32-bit offsets");
   ASV_REQUIRE(p.first.wfrag && p.last.wfrag && p.last.bias && p.n_mid >= 0 && p.n_mid <= 2 && p.last.cout_pad % 64 == 0, "tdnn(chain): incomplete layer description");
   ASV_REQUIRE(p.pool_partial && p.row_seg && p.pool_slots >= 1, "tdnn(chain): the last layer feeds the fused pooling (partials / row map missing)");
   for (int t = 0; t < p.n_taps; ++t) ASV_REQUIRE(p.taps[t] >= -kHalo && p.taps[t] <= kHalo, "tdnn(chain): tap offset %d exceeds the %d-frame halo", p.taps[t], kHalo);
-  const dim3 grid(p.rows / CM), block(512);
+  if (p.n128 == 0 && p.n96 == 0) p.n128 = p.rows / CM;              // callers without a plan: 128-frame tiles throughout
+  ASV_REQUIRE(p.n128 * 128 + p.n96 * 96 >= p.rows && p.n128 * 128 <= p.rows, "tdnn(chain): tile plan %d x 128 + %d x 96 does not cover %d rows", p.n128, p.n96, p.rows);
+  const dim3 block(512);
+  p.row_base = 0; p.tile_base = 0;
 #ifdef ASV_WITH_ABLATION
   // Developer build only (libasv_amd_dev.so, `make dev`): the ablation instantiations (results are garbage), the first pooling
   // epilogue and the four-wave kernel.  The switches are read ONCE per process; with ASV_AMD_LIVE_TUNE=1 (tools/chain_ab.py:
@@ -613,19 +641,33 @@ int launch_tdnn_chain(const TdnnChainParams &p, hipStream_t s) {
   // kernel (profiles/r3k_*): kept as the reproducible A/B of that design.
   static const int waves0 = read_int("ASV_AMD_CHAIN_WAVES");
   const int waves = live ? read_int("ASV_AMD_CHAIN_WAVES") : waves0;
-  if (waves == 4 && abl <= 0 && poolv != 0 && !(p.dbg != nullptr && p.dbg_fine) && tdnn_chain4_supported(p)) return launch_tdnn_chain4(p, s);
-  if (p.et == ET_BF16 && !(p.dbg != nullptr && p.dbg_fine) && (abl == 1 || abl == 2 || (abl == 4 && p.last.cout_pad % 512 == 0) || poolv == 0)) {
-    if (abl == 1) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_BF16, 1>), grid, block, 0, s, p);
-    else if (abl == 2) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_BF16, 2>), grid, block, 0, s, p);
-    else if (abl == 4) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_BF16, 4>), grid, block, 0, s, p);   // every wave runs the same number of units
-    else hipLaunchKernelGGL(tdnn_chain_kernel<0>, grid, block, 0, s, p);
-    ASV_HIP_CHECK(hipGetLastError());
-    return ASV_OK;
+  if (p.n96 == 0) {
+    const dim3 grid(p.n128);
+    if (waves == 4 && abl <= 0 && poolv != 0 && !(p.dbg != nullptr && p.dbg_fine) && tdnn_chain4_supported(p)) return launch_tdnn_chain4(p, s);
+    if (p.et == ET_BF16 && !(p.dbg != nullptr && p.dbg_fine) && (abl == 1 || abl == 2 || (abl == 4 && p.last.cout_pad % 512 == 0) || poolv == 0)) {
+      if (abl == 1) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_BF16, 1>), grid, block, 0, s, p);
+      else if (abl == 2) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_BF16, 2>), grid, block, 0, s, p);
+      else if (abl == 4) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_BF16, 4>), grid, block, 0, s, p);   // every wave runs the same number of units
+      else hipLaunchKernelGGL(tdnn_chain_kernel<0>, grid, block, 0, s, p);
+      ASV_HIP_CHECK(hipGetLastError());
+      return ASV_OK;
+    }
   }
 #endif
-  if (p.et == ET_F16) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_F16>), grid, block, 0, s, p);
-  else if (p.dbg != nullptr && p.dbg_fine) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_BF16, 3>), grid, block, 0, s, p);   // stamps only: results valid
-  else hipLaunchKernelGGL(tdnn_chain_kernel<1>, grid, block, 0, s, p);
+  if (p.n128 > 0) {
+    const dim3 grid(p.n128);
+    if (p.et == ET_F16) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_F16>), grid, block, 0, s, p);
+    else if (p.dbg != nullptr && p.dbg_fine) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_BF16, 3>), grid, block, 0, s, p);   // stamps only: results valid
+    else hipLaunchKernelGGL(tdnn_chain_kernel<1>, grid, block, 0, s, p);
+  }
+  if (p.n96 > 0) {
+    // the last round of workgroups as 96-frame tiles (chain_tile_plan): behind the full rounds on the same stream
+    p.row_base = p.n128 * 128; p.tile_base = p.n128;
+    p.dbg = nullptr;                                   // (the stamp buffer is laid out for the 128-frame launch)
+    const dim3 grid(p.n96);
+    if (p.et == ET_F16) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_F16, 0, 3>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_BF16, 0, 3>), grid, block, 0, s, p);
+  }
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }

@@ -1153,11 +1153,18 @@ int run_ops(RunCtx &c, size_t n_ops) {
           // tdnn -> [1-tap]* -> 1-tap + pooling in one kernel, if the batch allows the fused pooling (no crowd of tiny utterances)
           const DomainPlan &fp = bp.dom[ASV_DOMAIN_FRAMES];
           const int tshift = chain_x3 ? 6 : 7;         // rows per pooling partial: the kernel's tile
-          std::vector<int> per_half(((size_t)fp.rows_pad >> tshift) + 1, 0);
+          // the 16-bit chain cuts the last, partly filled round of workgroups into 96-frame tiles (ChainTilePlan); developer runs
+          // with phase stamps keep 128-frame tiles throughout
+          static const bool chain_dbg_on = getenv("ASV_AMD_CHAIN_DBG") != nullptr;
+          ChainTilePlan plan;
+          if (!chain_x3) plan = chain_tile_plan(p.rows, !chain_dbg_on);
+          auto block_of = [&](int row) { return chain_x3 ? row >> tshift : plan.tile_of(row); };
+          const int n_blocks = chain_x3 ? (p.rows >> tshift) : plan.tiles();
+          std::vector<int> per_half((size_t)n_blocks + 1, 0);
           int slots = 1, min_len = 1 << 30;
           for (size_t sidx = 0; sidx < fp.seg_len.size(); ++sidx) min_len = std::min(min_len, (int)fp.seg_len[sidx]);
           for (size_t sidx = 0; sidx < fp.seg_row0.size(); ++sidx)
-            for (int h = fp.seg_row0[sidx] >> tshift; h <= (fp.seg_row0[sidx] + fp.seg_len[sidx] - 1) >> tshift; ++h) slots = std::max(slots, ++per_half[h]);
+            for (int h = block_of(fp.seg_row0[sidx]); h <= block_of(fp.seg_row0[sidx] + fp.seg_len[sidx] - 1); ++h) slots = std::max(slots, ++per_half[h]);
           if (slots <= 16) {
             const size_t l = (size_t)op.chain_last;
             Op &lo = net->ops[l];
@@ -1185,7 +1192,8 @@ int run_ops(RunCtx &c, size_t n_ops) {
             cp.et = chain_x3 ? net->x3_et() : et;
             cp.min_seg_len = min_len;
             cp.status = status_word(net);
-            if ((rc = ensure(net->poolpart_dev, (size_t)(p.rows >> tshift) * slots * 2 * 3 * cp.ld_partial * 4, c.s, false))) return rc;
+            cp.n128 = plan.n128; cp.n96 = plan.n96;
+            if ((rc = ensure(net->poolpart_dev, (size_t)n_blocks * slots * 2 * 3 * cp.ld_partial * 4, c.s, false))) return rc;
             cp.pool_partial = reinterpret_cast<float *>(net->poolpart_dev.ptr);
             double fl = 0.0;
             for (size_t k = i; k <= l; ++k) fl += 2.0 * (double)bp.frames * net->ops[k].tdnn.in_ch * net->ops[k].tdnn.out_ch * net->ops[k].tdnn.n_taps;
@@ -1261,6 +1269,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
             const auto &q = po.pool;
             PoolFinishParams f;
             f.partial = cp.pool_partial; f.ld_partial = cp.ld_partial; f.pool_slots = slots; f.lh_split = 1; f.tile_shift = tshift;
+            f.rows_shift = plan.n96 > 0 ? plan.rows128() : 0; f.tail_rows = 96; f.n_shift = plan.n128;
             f.row_seg = dr.row_seg; f.rows = dr.rows_pad; f.seg_row0 = dr.seg_row0; f.seg_len = dr.seg_len;
             f.shift = lo.shift;
             f.out = reinterpret_cast<float *>(net->arena[q.out_buf].ptr) + q.out_ch_off; f.ld_out = net->bufs[q.out_buf].ld; f.channels = q.channels;
@@ -1352,6 +1361,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
             const auto &q = po.pool;
             PoolFinishParams f;
             f.partial = p.pool_partial; f.ld_partial = p.ld_partial; f.pool_slots = pool_slots; f.lh_split = 0; f.tile_shift = 7;
+            f.rows_shift = 0; f.tail_rows = 0; f.n_shift = 0;
             f.row_seg = dr.row_seg; f.rows = dr.rows_pad; f.seg_row0 = dr.seg_row0; f.seg_len = dr.seg_len;
             f.shift = op.shift;
             f.out = reinterpret_cast<float *>(net->arena[q.out_buf].ptr) + q.out_ch_off; f.ld_out = net->bufs[q.out_buf].ld; f.channels = q.channels;

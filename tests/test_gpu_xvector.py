@@ -293,3 +293,45 @@ def test_f32x_range_guard_and_small_features():
     model.amd_precision = "f32x"
     got_s = model.extract_embedding_batch(small).numpy()
     assert rel_err(got_s, want_s) < 1e-4, rel_err(got_s, want_s)
+
+
+def test_chain_kernel_tail_round_in_96_frame_tiles(tmp_path):
+    """Round 4: the chain kernel runs the last, partly filled round of workgroups as 96-frame tiles (256 utterances of 200 frames =
+    408 tiles of 128 frames on 256 CUs: one full round + 152 tiles -> + 203 tiles of 96 frames, 3/4 of the time).  Every row's
+    products are the same whatever the tile; only the f32 merge of the pooled moments changes with the tile boundaries.  Against
+    the same extraction with ASV_AMD_CHAIN_TAIL=0 (read once per process: a subprocess), on the configs[1] batch (both tile
+    forms in one launch pair), on a ragged batch that fits one round (96-frame tiles only, seams and gap rows inside), and on a
+    batch whose last tile overhangs the matrix."""
+    import subprocess
+    import sys
+    from libs.amd import synth
+    code = r'''
+import sys, numpy as np
+sys.path[:0] = [%r, %r, %r]
+import helpers
+from libs.amd import synth
+g, sd, model = helpers.golden_model("xvector_near_ragged")
+model.cuda()
+out = {}
+for prec in ("bf16", "f16"):
+    model.amd_precision = prec
+    for name, lens in (("c2", [200] * 256), ("ragged", [int(x) for x in np.random.RandomState(5).randint(1, 420, size=120)]), ("overhang", [200] * 36 + [37])):
+        mats = [synth.synth_feats(t, 80, 4000 + i) for i, t in enumerate(lens)]
+        out[prec + "_" + name] = model.extract_embedding_batch(mats).numpy()
+np.savez(sys.argv[1], **out)
+''' % (helpers.REPO, helpers.PKG if hasattr(helpers, "PKG") else __import__("os").path.join(helpers.REPO, "asv-subtools_amd", "pytorch"), __import__("os").path.join(helpers.REPO, "tests"))
+    import os
+    res = {}
+    for tail in ("1", "0"):
+        path = str(tmp_path / ("tail%s.npz" % tail))
+        env = dict(os.environ, ASV_AMD_CHAIN_TAIL=tail)
+        r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        res[tail] = dict(np.load(path))
+    differ = 0
+    for k in res["1"]:
+        a, b = res["1"][k], res["0"][k]
+        assert np.isfinite(a).all() and a.shape == b.shape
+        assert rel_err(a, b) < 2e-5, (k, rel_err(a, b))
+        differ += int(not np.array_equal(a, b))
+    assert differ >= 1, "the 96-frame tail tiles did not run (identical bits everywhere)"
