@@ -246,7 +246,7 @@ struct PoolFinishParams {
   const float *partial; int ld_partial, pool_slots;
   int lh_split;                  // partials of the chain kernel: [tile][slot][lh][3][ld], lh = bit 2 of the row index of the frames summed
   int tile_shift;                // log2 of the rows one partial covers: 7 (128-row tiles; 0 means 7) or 6 (the f32x chain's 64-row tiles)
-  int rows_shift, tail_rows, n_shift;   // tiles behind row `rows_shift` (0 = none): blocks n_shift + k cover `tail_rows` rows each (ChainTilePlan: 96)
+  int rows_shift, tail_rows, n_shift;   // tail_rows > 0: behind row `rows_shift` the blocks n_shift + k cover `tail_rows` rows each (ChainTilePlan: 96)
   const int32_t *row_seg; int rows;
   const int32_t *seg_row0, *seg_len;
   const float *shift;            // per-channel BN shift that the producer left out (or nullptr)

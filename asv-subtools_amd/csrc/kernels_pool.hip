@@ -279,11 +279,12 @@ __global__ __launch_bounds__(64) void pool_finish_kernel(const PoolFinishParams 
   float n_acc = 0.0f, mean = 0.0f, m2 = 0.0f;
   const int ts = p.tile_shift ? p.tile_shift : 7;       // rows per partial: 128, or 64 (f32x chain)
   // blocks of 2^ts rows up to row `rows_shift`, blocks of `tail_rows` rows behind it (the 16-bit chain's 96-frame tiles for the last
-  // round of workgroups, ChainTilePlan; rows_shift = 0: uniform blocks)
-  const int r_shift = p.rows_shift > 0 ? p.rows_shift : 0x7fffffff;
+  // round of workgroups, ChainTilePlan; tail_rows = 0: uniform blocks.  rows_shift may be 0: a batch of less than one round)
+  const bool mixed = p.tail_rows > 0;
+  const int r_shift = mixed ? p.rows_shift : 0x7fffffff;
   auto block_of = [&](int row) { return row < r_shift ? row >> ts : p.n_shift + (row - r_shift) / p.tail_rows; };
-  auto block_row0 = [&](int h) { return (p.rows_shift > 0 && h >= p.n_shift) ? r_shift + (h - p.n_shift) * p.tail_rows : h << ts; };
-  auto block_rows = [&](int h) { return (p.rows_shift > 0 && h >= p.n_shift) ? p.tail_rows : 1 << ts; };
+  auto block_row0 = [&](int h) { return (mixed && h >= p.n_shift) ? r_shift + (h - p.n_shift) * p.tail_rows : h << ts; };
+  auto block_rows = [&](int h) { return (mixed && h >= p.n_shift) ? p.tail_rows : 1 << ts; };
   for (int h = block_of(row0); h <= block_of(row0 + len - 1); ++h) {
     const int h0 = block_row0(h);
     int first = -1;

@@ -1269,7 +1269,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
             const auto &q = po.pool;
             PoolFinishParams f;
             f.partial = cp.pool_partial; f.ld_partial = cp.ld_partial; f.pool_slots = slots; f.lh_split = 1; f.tile_shift = tshift;
-            f.rows_shift = plan.n96 > 0 ? plan.rows128() : 0; f.tail_rows = 96; f.n_shift = plan.n128;
+            f.rows_shift = plan.rows128(); f.tail_rows = plan.n96 > 0 ? 96 : 0; f.n_shift = plan.n128;
             f.row_seg = dr.row_seg; f.rows = dr.rows_pad; f.seg_row0 = dr.seg_row0; f.seg_len = dr.seg_len;
             f.shift = lo.shift;
             f.out = reinterpret_cast<float *>(net->arena[q.out_buf].ptr) + q.out_ch_off; f.ld_out = net->bufs[q.out_buf].ld; f.channels = q.channels;

@@ -492,7 +492,10 @@ def main():
         lengths = tuple(int(v) for v in args.lengths.split(":")) if args.lengths else None
         wl = Workload(args, args.model, args.precision, args.batch, args.frames, rank, dev, lengths=lengths)
     if args.streams is None:
-        args.streams = 2 if (not dry and not args.from_wav and not args.per_op and args.precision.split("-")[0] not in ("f32x", "f32")) else 1
+        # two engines on two streams fill the CUs a partly filled last round of tiles leaves idle: +12 % for the f32x mode at 256
+        # utterances per step too (288 k -> 321 k, profiles/r4e_f32x_streams.txt); at 640 (whole rounds) it costs that mode 3 %
+        one_only = ("f32",) if args.batch <= 320 else ("f32x", "f32")
+        args.streams = 2 if (not dry and not args.from_wav and not args.per_op and args.precision.split("-")[0] not in one_only) else 1
     wl2 = [Workload(args, args.model, args.precision, args.batch, args.frames, rank, dev, lengths=lengths) for _ in range(args.streams - 1)] if (args.streams >= 2 and not dry) else None
     head = measure(wl, args.steps, args.warmup, args.min_seconds, not args.no_profile and not dry and wl2 is None, dist_on, per_op=args.per_op, from_wav=args.from_wav, wl2=wl2)
     single = None
@@ -563,7 +566,7 @@ def main():
             modes gain nothing from it - their steps are one long matrix-bound launch sequence - and run on one), the kernel
             figures from a single-stream pass."""
             steps = steps or args.steps
-            use_two = two and not (f32x_single and prec.split("-")[0] in ("f32x", "f32"))
+            use_two = two and not (f32x_single and prec.split("-")[0] in (("f32",) if (kind == "xvector" and batch <= 320) else ("f32x", "f32")))
             w = Workload(args, kind, prec, batch, frames, rank, dev, lengths=lens)
             w2 = [Workload(args, kind, prec, batch, frames, rank, dev, lengths=lens)] if use_two else None
             r1 = measure(w, steps, 2, min_s, not args.no_profile, False)

@@ -31,14 +31,20 @@ def _sample_positions(n, k=8):
     return pos[:k]
 
 
-def _check(got, want, precision, what, depth=1.0):
+MEASURED = {}          # (test label, precision) -> worst (rel err, cosine) seen: written to gpurun_out/ by the last test of the module
+
+
+def _check(got, want, precision, what, depth=1.0, label=None):
     """depth: how much deeper than the 5-layer x-vector the model is - the operand rounding of a 16-bit mode accumulates over the
     layers (ECAPA: ~25 frame-level layers on a path, measured 2.6e-3 in f16; ResNet34: 36 convolutions, 3.0e-2 in bf16 / 4.0e-3 in
     f16); the parity-grade modes are held to 1e-4 whatever the depth."""
     for g, w, tag in zip(got, want, what):
         err = rel_err(g, w)
+        cos = float((g * w).sum() / np.linalg.norm(g) / np.linalg.norm(w))
+        key = "%s | %s" % (label or tag.split(" of ")[-1], precision)
+        prev = MEASURED.get(key, (0.0, 1.0))
+        MEASURED[key] = (max(prev[0], err), min(prev[1], cos))
         if precision in ("bf16", "f16"):
-            cos = float((g * w).sum() / np.linalg.norm(g) / np.linalg.norm(w))
             tol_rel, tol_cos = (TOL_BF16_REL, TOL_BF16_COS) if precision == "bf16" else (TOL_F16_REL, TOL_F16_COS)
             tol_rel, tol_cos = tol_rel * depth, 1.0 - (1.0 - tol_cos) * depth * depth
             assert err < tol_rel and cos > tol_cos, "%s %s: rel err %.3g cos %.7f" % (tag, precision, err, cos)
@@ -64,7 +70,7 @@ def test_c2_xvector_full_batch_vs_oracle(batch, precision):
     assert got.shape == (batch, 512) and np.isfinite(got).all()
     pos = _sample_positions(batch)
     want = [O.extract_embedding(lambda c: O.xvector_embed(c, sd, "far"), mats[i]) for i in pos]
-    _check([got[i] for i in pos], want, precision, ["utt %d of %d" % (i, batch) for i in pos])
+    _check([got[i] for i in pos], want, precision, ["utt %d of %d" % (i, batch) for i in pos], label="c2 xvector b%d" % batch)
 
 
 @pytest.mark.parametrize("precision", ["f32", "f32x", "bf16", "f16"])
@@ -84,7 +90,7 @@ def test_c3_ecapa_full_batch_vs_oracle(precision):
     assert got.shape == (256, 192) and np.isfinite(got).all()
     pos = _sample_positions(256, k=6)
     want = [O.extract_embedding(lambda c: O.ecapa_embed(c, sd, "near"), mats[i]) for i in pos]
-    _check([got[i] for i in pos], want, precision, ["utt %d of 256" % i for i in pos], depth=2.0)
+    _check([got[i] for i in pos], want, precision, ["utt %d of 256" % i for i in pos], depth=2.0, label="c3 ecapa b256")
 
 
 @pytest.mark.parametrize("precision", ["f32", "f32x", "bf16", "f16"])
@@ -109,7 +115,7 @@ def test_c5_resnet_variable_length_full_batch_vs_oracle(precision):
     assert got.shape == (256, 256) and np.isfinite(got).all()
     pos = sorted({0, 3, 127, 128, 200, 255, int(np.argmin(lengths)), int(np.argmax(lengths))})
     want = [O.extract_embedding(lambda c: O.resnet_embed(c, sd, "near", ""), mats[i]) for i in pos]
-    _check([got[i] for i in pos], want, precision, ["utt %d (%d frames)" % (i, lengths[i]) for i in pos], depth=2.5)
+    _check([got[i] for i in pos], want, precision, ["utt %d (%d frames)" % (i, lengths[i]) for i in pos], depth=2.5, label="c5 resnet ragged b256")
 
 
 @pytest.mark.parametrize("name", ["xvector_c1", "xvector_near_ragged", "xvector_chunked", "ecapa_c3", "ecapa_launcher", "ecapa_c512_fc1_far",
@@ -166,3 +172,14 @@ def test_low_variance_channels_and_long_utterances_in_the_fused_pooling():
         cos_plain = float((plain[i] * want[i]).sum() / np.linalg.norm(plain[i]) / np.linalg.norm(want[i]))
         assert cos > TOL_BF16_COS, "fused pooling, %d frames: cos %.6f (separate pooling: %.6f)" % (mats[i].shape[0], cos, cos_plain)
         assert rel_err(fused[i], want[i]) < TOL_BF16_REL
+
+
+def test_zz_record_measured_errors():
+    """Not a check: dumps the worst error / cosine every case of this module measured (gpurun_out/full_size_parity_measured.json),
+    the numbers the 16-bit tolerances above are set from."""
+    import json
+    import os
+    out = os.path.join(helpers.REPO, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "full_size_parity_measured.json"), "w") as f:
+        json.dump({k: {"max_rel_err": float("%.3g" % v[0]), "min_cosine": round(v[1], 7)} for k, v in sorted(MEASURED.items())}, f, indent=1)
