@@ -195,20 +195,24 @@ struct TdnnChainParams {
   int et;                       // ET_BF16 / ET_F16: element type of the rows and of every layer's weight fragments
   int min_seg_len;              // shortest utterance of the batch in frames (the 4-wave kernel needs >= 32: at most one seam per 32-frame fragment)
   uint32_t *status;             // f32x chain: as TdnnKernelParams::status
-  int n128, n96;                // 16-bit chain: the launch's tile plan (chain_tile_plan): n128 tiles of 128 frames, then n96 of 96
+  int n128, n_tail, tail_rows;  // 16-bit chain: the launch's tile plan (chain_tile_plan): n128 tiles of 128 frames, then n_tail of tail_rows (96 | 64)
   int row_base, tile_base;      // set by the launcher per kernel launch: first row / first partial-moment block of that launch
 };
-// How the 16-bit chain kernel cuts `rows` (a multiple of 128) into tiles: whole rounds of the chip's workgroup slots in 128-frame
-// tiles; the last, partly filled round - R tiles left for `cus` CUs - as ceil(R * 128 / 96) tiles of 96 frames when they fit one
-// round (R <= 3/4 cus): the same rows on more CUs, each for 3/4 of the time.  Partial-moment block t covers rows
-// [row0(t), row0(t) + rows_of(t)); rows beyond `rows` (the last 96-frame tile may overhang) are gap rows.
+// How the 16-bit chain kernel cuts `rows` (a multiple of 128) into tiles.  One workgroup per CU (160 KiB of LDS), so:
+//   * a batch that does not fill ONE round of the chip's CUs in 128-frame tiles runs in the smallest tile - 64 or 96 frames -
+//     that still fits one round: the same rows on more CUs, each for 1/2 or 3/4 of the time (a single utterance: 2 tiles -> 4);
+//   * larger batches run in 128-frame tiles throughout.  Cutting only their last, partly filled round into 96-frame tiles (a second
+//     launch) was measured at configs[1]'s 256 utterances - 408 tiles on 256 CUs -: +2 % on one stream, -2 % with two engines on two
+//     streams (the other stream's workgroups fill the idle CUs anyway, the extra launch is pure cost): opt-in, ASV_AMD_CHAIN_TAIL=2
+//     (profiles/r4f_chain_tail_ab.txt).
+// Partial-moment block t covers rows [row0(t), row0(t) + rows_of(t)); rows beyond `rows` (the last tile may overhang) count as gaps.
 struct ChainTilePlan {
-  int n128 = 0, n96 = 0;
+  int n128 = 0, n_tail = 0, tail_rows = 0;
   int rows128() const { return n128 * 128; }
-  int tiles() const { return n128 + n96; }
-  int tile_of(int row) const { return row < rows128() ? row >> 7 : n128 + (row - rows128()) / 96; }
-  int row0(int t) const { return t < n128 ? t * 128 : rows128() + (t - n128) * 96; }
-  int rows_of(int t) const { return t < n128 ? 128 : 96; }
+  int tiles() const { return n128 + n_tail; }
+  int tile_of(int row) const { return row < rows128() ? row >> 7 : n128 + (row - rows128()) / tail_rows; }
+  int row0(int t) const { return t < n128 ? t * 128 : rows128() + (t - n128) * tail_rows; }
+  int rows_of(int t) const { return t < n128 ? 128 : tail_rows; }
 };
 ChainTilePlan chain_tile_plan(int rows, bool allow_tail);
 int launch_tdnn_chain(const TdnnChainParams &p, hipStream_t s);

@@ -53,12 +53,11 @@ constexpr int CBK = 64;
 constexpr int CROWB = 128;                // window row: 64 bf16
 constexpr int CSTAGES = 4;
 constexpr int YROWB = CN * 2;             // 1024 B per Y row
-// MF = 32-frame fragments per tile: 4 (128 frames, the default) or 3 (96 frames: the instantiation for the LAST, partly filled round of
-// workgroups - 152 tiles of 128 frames left over for 256 CUs become 203 tiles of 96, a round that takes 3/4 of the time; see
-// launch_tdnn_chain)
+// MF = 32-frame fragments per tile: 4 (128 frames, the default), 3 or 2 (96 / 64 frames: batches that do not fill one round of the
+// chip's CUs run in the smallest tile that still fits one round - more CUs, each for 3/4 or 1/2 of the time; chain_tile_plan)
 template <int MF> struct ChainGeom {
   static constexpr int CM = MF * 32;                  // frames per workgroup
-  static constexpr int CWIN = CM + 2 * kHalo;         // 136 | 104
+  static constexpr int CWIN = CM + 2 * kHalo;         // 136 | 104 | 72
   static constexpr int CSTAGE = CWIN * CROWB;         // 17408 | 13312 B
   static constexpr int CGROUPS = CWIN / 8;            // 17 | 13 eight-row DMA pieces
   static constexpr int CPIECES = (CGROUPS + 7) / 8;   // 3 | 2 per wave
@@ -415,8 +414,10 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
       // three moments at publication (u = scale * act(acc): moments about a pivot are linear / quadratic in it); the BN
       // shift is added to the mean by pool_finish.
       if constexpr (ABL == 1) {                // no pooling epilogue at all: the accumulators only have to stay alive up to here
+#if defined(__HIP_DEVICE_COMPILE__)      // (a "v" constraint means nothing to the host pass: with a template-dependent bound it drops the kernel's host stub)
 #pragma unroll
         for (int i = 0; i < MF; ++i) asm volatile("" ::"v"(acc[i][0]), "v"(acc[i][1]));
+#endif
         stamp();
         continue;
       }
@@ -606,13 +607,23 @@ ChainTilePlan chain_tile_plan(int rows, bool allow_tail) {
   ChainTilePlan plan;
   const int n = rows / 128;
   plan.n128 = n;
-  static const bool off = getenv("ASV_AMD_CHAIN_TAIL") != nullptr && atoi(getenv("ASV_AMD_CHAIN_TAIL")) == 0;      // A/B aid, read once: results equal either way
-  if (!allow_tail || off) return plan;
+  // ASV_AMD_CHAIN_TAIL (read once; results agree to the order of the f32 sums of the pooled moments): 0 = 128-frame tiles always,
+  // 2 = also cut the last round of a multi-round batch into 96-frame tiles (measured: see asv_internal.h)
+  static const int mode = getenv("ASV_AMD_CHAIN_TAIL") != nullptr ? atoi(getenv("ASV_AMD_CHAIN_TAIL")) : 1;
+  if (!allow_tail || mode == 0) return plan;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  const int tail = n % cus;                          // tiles of the last round (one workgroup per CU: 160 KiB of LDS)
-  const int as96 = (tail * 128 + 95) / 96;
-  if (tail > 0 && as96 <= cus) { plan.n128 = n - tail; plan.n96 = as96; }
+  if (n < cus) {                                     // less than one round: the smallest tile that still fits one round
+    for (int r : {64, 96}) {
+      const int t = (rows + r - 1) / r;
+      if (t <= cus) { plan.n128 = 0; plan.n_tail = t; plan.tail_rows = r; return plan; }
+    }
+    return plan;
+  }
+  if (mode == 2) {
+    const int tail = n % cus, as96 = (tail * 128 + 95) / 96;
+    if (tail > 0 && as96 <= cus) { plan.n128 = n - tail; plan.n_tail = as96; plan.tail_rows = 96; }
+  }
   return plan;
 }
 
@@ -625,8 +636,10 @@ int launch_tdnn_chain(const TdnnChainParams &p0, hipStream_t s) {
   ASV_REQUIRE(p.first.wfrag && p.last.wfrag && p.last.bias && p.n_mid >= 0 && p.n_mid <= 2 && p.last.cout_pad % 64 == 0, "tdnn(chain): incomplete layer description");
   ASV_REQUIRE(p.pool_partial && p.row_seg && p.pool_slots >= 1, "tdnn(chain): the last layer feeds the fused pooling (partials / row map missing)");
   for (int t = 0; t < p.n_taps; ++t) ASV_REQUIRE(p.taps[t] >= -kHalo && p.taps[t] <= kHalo, "tdnn(chain): tap offset %d exceeds the %d-frame halo", p.taps[t], kHalo);
-  if (p.n128 == 0 && p.n96 == 0) p.n128 = p.rows / CM;              // callers without a plan: 128-frame tiles throughout
-  ASV_REQUIRE(p.n128 * 128 + p.n96 * 96 >= p.rows && p.n128 * 128 <= p.rows, "tdnn(chain): tile plan %d x 128 + %d x 96 does not cover %d rows", p.n128, p.n96, p.rows);
+  if (p.n128 == 0 && p.n_tail == 0) p.n128 = p.rows / CM;           // callers without a plan: 128-frame tiles throughout
+  ASV_REQUIRE(p.n_tail == 0 || p.tail_rows == 96 || p.tail_rows == 64, "tdnn(chain): tail tiles of %d frames", p.tail_rows);
+  ASV_REQUIRE(p.n128 * 128 + p.n_tail * p.tail_rows >= p.rows && p.n128 * 128 <= p.rows, "tdnn(chain): tile plan %d x 128 + %d x %d does not cover %d rows", p.n128, p.n_tail,
+              p.tail_rows, p.rows);
   const dim3 block(512);
   p.row_base = 0; p.tile_base = 0;
 #ifdef ASV_WITH_ABLATION
@@ -641,7 +654,7 @@ int launch_tdnn_chain(const TdnnChainParams &p0, hipStream_t s) {
   // kernel (profiles/r3k_*): kept as the reproducible A/B of that design.
   static const int waves0 = read_int("ASV_AMD_CHAIN_WAVES");
   const int waves = live ? read_int("ASV_AMD_CHAIN_WAVES") : waves0;
-  if (p.n96 == 0) {
+  if (p.n_tail == 0) {
     const dim3 grid(p.n128);
     if (waves == 4 && abl <= 0 && poolv != 0 && !(p.dbg != nullptr && p.dbg_fine) && tdnn_chain4_supported(p)) return launch_tdnn_chain4(p, s);
     if (p.et == ET_BF16 && !(p.dbg != nullptr && p.dbg_fine) && (abl == 1 || abl == 2 || (abl == 4 && p.last.cout_pad % 512 == 0) || poolv == 0)) {
@@ -660,13 +673,18 @@ int launch_tdnn_chain(const TdnnChainParams &p0, hipStream_t s) {
     else if (p.dbg != nullptr && p.dbg_fine) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_BF16, 3>), grid, block, 0, s, p);   // stamps only: results valid
     else hipLaunchKernelGGL(tdnn_chain_kernel<1>, grid, block, 0, s, p);
   }
-  if (p.n96 > 0) {
-    // the last round of workgroups as 96-frame tiles (chain_tile_plan): behind the full rounds on the same stream
+  if (p.n_tail > 0) {
+    // the smaller tiles (chain_tile_plan): behind the full rounds, if any, on the same stream
     p.row_base = p.n128 * 128; p.tile_base = p.n128;
     p.dbg = nullptr;                                   // (the stamp buffer is laid out for the 128-frame launch)
-    const dim3 grid(p.n96);
-    if (p.et == ET_F16) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_F16, 0, 3>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_BF16, 0, 3>), grid, block, 0, s, p);
+    const dim3 grid(p.n_tail);
+    if (p.tail_rows == 96) {
+      if (p.et == ET_F16) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_F16, 0, 3>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_BF16, 0, 3>), grid, block, 0, s, p);
+    } else {
+      if (p.et == ET_F16) hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_F16, 0, 2>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((tdnn_chain_kernel<1, ET_BF16, 0, 2>), grid, block, 0, s, p);
+    }
   }
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;

@@ -1153,8 +1153,8 @@ int run_ops(RunCtx &c, size_t n_ops) {
           // tdnn -> [1-tap]* -> 1-tap + pooling in one kernel, if the batch allows the fused pooling (no crowd of tiny utterances)
           const DomainPlan &fp = bp.dom[ASV_DOMAIN_FRAMES];
           const int tshift = chain_x3 ? 6 : 7;         // rows per pooling partial: the kernel's tile
-          // the 16-bit chain cuts the last, partly filled round of workgroups into 96-frame tiles (ChainTilePlan); developer runs
-          // with phase stamps keep 128-frame tiles throughout
+          // the 16-bit chain runs batches of less than one round of workgroups in 96- / 64-frame tiles (ChainTilePlan); developer
+          // runs with phase stamps keep 128-frame tiles throughout
           static const bool chain_dbg_on = getenv("ASV_AMD_CHAIN_DBG") != nullptr;
           ChainTilePlan plan;
           if (!chain_x3) plan = chain_tile_plan(p.rows, !chain_dbg_on);
@@ -1192,7 +1192,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
             cp.et = chain_x3 ? net->x3_et() : et;
             cp.min_seg_len = min_len;
             cp.status = status_word(net);
-            cp.n128 = plan.n128; cp.n96 = plan.n96;
+            cp.n128 = plan.n128; cp.n_tail = plan.n_tail; cp.tail_rows = plan.tail_rows;
             if ((rc = ensure(net->poolpart_dev, (size_t)n_blocks * slots * 2 * 3 * cp.ld_partial * 4, c.s, false))) return rc;
             cp.pool_partial = reinterpret_cast<float *>(net->poolpart_dev.ptr);
             double fl = 0.0;
@@ -1269,7 +1269,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
             const auto &q = po.pool;
             PoolFinishParams f;
             f.partial = cp.pool_partial; f.ld_partial = cp.ld_partial; f.pool_slots = slots; f.lh_split = 1; f.tile_shift = tshift;
-            f.rows_shift = plan.rows128(); f.tail_rows = plan.n96 > 0 ? 96 : 0; f.n_shift = plan.n128;
+            f.rows_shift = plan.rows128(); f.tail_rows = plan.n_tail > 0 ? plan.tail_rows : 0; f.n_shift = plan.n128;
             f.row_seg = dr.row_seg; f.rows = dr.rows_pad; f.seg_row0 = dr.seg_row0; f.seg_len = dr.seg_len;
             f.shift = lo.shift;
             f.out = reinterpret_cast<float *>(net->arena[q.out_buf].ptr) + q.out_ch_off; f.ld_out = net->bufs[q.out_buf].ld; f.channels = q.channels;

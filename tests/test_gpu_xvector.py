@@ -295,16 +295,17 @@ def test_f32x_range_guard_and_small_features():
     assert rel_err(got_s, want_s) < 1e-4, rel_err(got_s, want_s)
 
 
-def test_chain_kernel_tail_round_in_96_frame_tiles(tmp_path):
-    """Round 4: the chain kernel runs the last, partly filled round of workgroups as 96-frame tiles (256 utterances of 200 frames =
-    408 tiles of 128 frames on 256 CUs: one full round + 152 tiles -> + 203 tiles of 96 frames, 3/4 of the time).  Every row's
-    products are the same whatever the tile; only the f32 merge of the pooled moments changes with the tile boundaries.  Against
-    the same extraction with ASV_AMD_CHAIN_TAIL=0 (read once per process: a subprocess), on the configs[1] batch (both tile
-    forms in one launch pair), on a ragged batch that fits one round (96-frame tiles only, seams and gap rows inside), and on a
-    batch whose last tile overhangs the matrix."""
+def test_chain_kernel_small_tile_forms(tmp_path):
+    """Round 4: the chain kernel has 96- and 64-frame tile forms.  A batch that does not fill one round of the chip's CUs in 128-frame
+    tiles runs in the smallest tile that still fits one round (default); ASV_AMD_CHAIN_TAIL=2 also cuts the last, partly filled
+    round of a larger batch into 96-frame tiles (a second launch: measured, not the default); =0 keeps 128-frame tiles.  Every
+    row's products are the same whatever the tile; only the f32 merge of the pooled moments changes with the tile boundaries.
+    The switch is read once per process: one subprocess per setting.  Cases: 60 ragged utterances (64-frame tiles, seams and gap
+    rows inside), 100 x 200 frames (96-frame tiles, the last one overhanging the matrix), a single utterance, and configs[1]'s
+    256 x 200 frames (both tile forms in one launch pair under =2)."""
+    import os
     import subprocess
     import sys
-    from libs.amd import synth
     code = r'''
 import sys, numpy as np
 sys.path[:0] = [%r, %r, %r]
@@ -315,23 +316,25 @@ model.cuda()
 out = {}
 for prec in ("bf16", "f16"):
     model.amd_precision = prec
-    for name, lens in (("c2", [200] * 256), ("ragged", [int(x) for x in np.random.RandomState(5).randint(1, 420, size=120)]), ("overhang", [200] * 36 + [37])):
+    for name, lens in (("c2", [200] * 256), ("ragged64", [int(x) for x in np.random.RandomState(5).randint(1, 420, size=60)]), ("mid96", [200] * 100), ("one", [200])):
         mats = [synth.synth_feats(t, 80, 4000 + i) for i, t in enumerate(lens)]
         out[prec + "_" + name] = model.extract_embedding_batch(mats).numpy()
 np.savez(sys.argv[1], **out)
-''' % (helpers.REPO, helpers.PKG if hasattr(helpers, "PKG") else __import__("os").path.join(helpers.REPO, "asv-subtools_amd", "pytorch"), __import__("os").path.join(helpers.REPO, "tests"))
-    import os
+''' % (helpers.REPO, os.path.join(helpers.REPO, "asv-subtools_amd", "pytorch"), os.path.join(helpers.REPO, "tests"))
     res = {}
-    for tail in ("1", "0"):
-        path = str(tmp_path / ("tail%s.npz" % tail))
-        env = dict(os.environ, ASV_AMD_CHAIN_TAIL=tail)
+    for mode in ("0", "1", "2"):
+        path = str(tmp_path / ("tail%s.npz" % mode))
+        env = dict(os.environ, ASV_AMD_CHAIN_TAIL=mode)
         r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-        res[tail] = dict(np.load(path))
-    differ = 0
-    for k in res["1"]:
-        a, b = res["1"][k], res["0"][k]
-        assert np.isfinite(a).all() and a.shape == b.shape
-        assert rel_err(a, b) < 2e-5, (k, rel_err(a, b))
-        differ += int(not np.array_equal(a, b))
-    assert differ >= 1, "the 96-frame tail tiles did not run (identical bits everywhere)"
+        res[mode] = dict(np.load(path))
+    for mode in ("1", "2"):
+        for k in res[mode]:
+            a, b = res[mode][k], res["0"][k]
+            assert np.isfinite(a).all() and a.shape == b.shape
+            assert rel_err(a, b) < 2e-5, (mode, k, rel_err(a, b))
+    for prec in ("bf16", "f16"):
+        for k in ("ragged64", "mid96", "one"):
+            assert not np.array_equal(res["1"][prec + "_" + k], res["0"][prec + "_" + k]), "the small-tile form did not run for %s %s" % (prec, k)
+        assert np.array_equal(res["1"][prec + "_c2"], res["0"][prec + "_c2"])               # a multi-round batch: 128-frame tiles by default
+        assert not np.array_equal(res["2"][prec + "_c2"], res["0"][prec + "_c2"]), "the 96-frame tail launch did not run"
