@@ -352,12 +352,10 @@ __global__ __launch_bounds__(256, 2) void grid_conv_narrow_pers_kernel(const Tdn
 //   as their MFMAs have issued (8 fragments = 32 VGPRs in flight), rows are read one k-group ahead.  Same (tap, k-group)
 //   accumulation order as the generic tile: bit-identical outputs (tests/test_gpu_resnet.py).
 //   16-byte slot s of window row w sits at s ^ (w & 15): conflict-free ds_read_b128 for any tap shift.
-// MF = 32-row fragments per wave: 4 (the tile above) or 2 (round 4: the half-height tile the LAST, thinly filled round of workgroups
-// runs in - launch_grid_conv_wide)
-template <int CIN, int MF = 4> struct WideGeom {
+template <int CIN> struct WideGeom {
   static constexpr int HALO = CIN == 128 ? 24 : 16;
-  static constexpr int WMS = CIN == 128 ? 2 : 1, WNS = 4 / WMS;    // waves along rows / along channels
-  static constexpr int BM = WMS * MF * 32;                         // 256 | 128 (half height: 128 | 64)
+  static constexpr int BM = CIN == 128 ? 256 : 128;
+  static constexpr int WMS = BM / 128, WNS = 4 / WMS;             // waves along rows / along channels
   static constexpr int WIN = BM + 2 * HALO;                        // 304 | 160 rows
   static constexpr int ROWB = CIN * 2;                             // 256 | 512 bytes
   static constexpr int SLOTS = ROWB / 16;                          // 16 | 32
@@ -366,18 +364,18 @@ template <int CIN, int MF = 4> struct WideGeom {
   static constexpr int KG = CIN / 16;                              // k-groups per tap: 8 | 16
   static constexpr int NFR = CIN / 32;                             // 32-channel output fragments of the layer: 4 | 8
   static constexpr int STEPS = 9 * KG / 4;                         // 18 | 36 steps of 4 k-groups
-  static_assert(WNS * 64 == CIN && WIN % RPP == 0 && WIN * ROWB <= 81920 && WIN * ROWB >= 16384 + 3 * CIN * 4, "wide grid conv geometry");
+  static_assert(WNS * 64 == CIN && WIN % RPP == 0 && WIN * ROWB <= 81920, "wide grid conv geometry");
 };
 
-template <int CIN, bool GENERIC, int MF, int ET = ET_BF16>
+template <int CIN, bool GENERIC, int ET = ET_BF16>
 __global__ __launch_bounds__(256, 2) void grid_conv_wide_kernel(const TdnnKernelParams p) {
-  using G = WideGeom<CIN, MF>;
+  using G = WideGeom<CIN>;
   __shared__ __attribute__((aligned(16))) unsigned char win[G::WIN * G::ROWB];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / G::WNS, wn = wave % G::WNS;
   const int lr = lane & 31, lh = lane >> 5;
-  const int m0 = p.row_begin + xcd_swizzle(blockIdx.x, gridDim.x) * G::BM;       // (row_begin: the launch's first row)
+  const int m0 = xcd_swizzle(blockIdx.x, gridDim.x) * G::BM;
 
   // ---- window: one LDS-DMA instruction per 1 KiB piece, rows clamped onto the matrix (its first / last rows are gaps)
   const unsigned char *xg = reinterpret_cast<const unsigned char *>(p.x);
@@ -409,17 +407,17 @@ __global__ __launch_bounds__(256, 2) void grid_conv_wide_kernel(const TdnnKernel
   const unsigned char *wbase = reinterpret_cast<const unsigned char *>(p.wconv) + (size_t)(wn * 2) * 1024 + (size_t)lane * 16;
   auto frag_ptr = [&](int t, int kg, int j) { return wbase + ((size_t)(t * G::KG + kg) * G::NFR + j) * 1024; };
 
-  f32x16_t acc[MF][2];
+  f32x16_t acc[4][2];
 #pragma unroll
-  for (int i = 0; i < MF; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  struct XF { uint4 x[MF]; };
+  struct XF { uint4 x[4]; };
   auto read_x1 = [&](int d, int kg_abs, int i, XF &f) {           // kg_abs: k-group within the tap (0 .. KG-1)
-    const int w = G::HALO + wm * (MF * 32) + i * 32 + lr + d;
+    const int w = G::HALO + wm * 128 + i * 32 + lr + d;
     f.x[i] = *reinterpret_cast<const uint4 *>(win + w * G::ROWB + (((kg_abs * 2 + lh) ^ (w & 15)) << 4));
   };
   uint4 wf[4][2];
@@ -436,7 +434,7 @@ __global__ __launch_bounds__(256, 2) void grid_conv_wide_kernel(const TdnnKernel
   {
     const int d0 = __builtin_amdgcn_readlane(v_taps, 0);
 #pragma unroll
-    for (int i = 0; i < MF; ++i) read_x1(d0, 0, i, x0);
+    for (int i = 0; i < 4; ++i) read_x1(d0, 0, i, x0);
   }
 #pragma unroll 1
   for (int st = 0; st < G::STEPS; ++st) {
@@ -451,9 +449,9 @@ __global__ __launch_bounds__(256, 2) void grid_conv_wide_kernel(const TdnnKernel
       for (int q = 0; q < 4; ++q) {
         // pair q: channel fragment j = q / 2 against row fragments 2 (q % 2) and + 1; one row read of the next k-group in
         // front of every pair, the fragment of the next step behind its last pair (the order of kernels_tdnn_v3.hip)
-        if (q < MF) read_x1(d_next, kg_abs_next, q, xn);
+        read_x1(d_next, kg_abs_next, q, xn);
 #pragma unroll
-        for (int i = (q % 2) * 2; i < (q % 2) * 2 + 2 && i < MF; ++i)
+        for (int i = (q % 2) * 2; i < (q % 2) * 2 + 2; ++i)
           acc[i][q / 2] = mfma16<ET>(wf[kg][q / 2], xc.x[i], acc[i][q / 2]);
         if (q == 1) wf[kg][0] = *reinterpret_cast<const uint4 *>(frag_ptr(tn, c4n * 4 + kg, 0));
         if (q == 3) wf[kg][1] = *reinterpret_cast<const uint4 *>(frag_ptr(tn, c4n * 4 + kg, 1));
@@ -481,8 +479,8 @@ __global__ __launch_bounds__(256, 2) void grid_conv_wide_kernel(const TdnnKernel
   asm volatile("" ::: "memory");
   unsigned char *stage = win + wave * 4096;
 #pragma unroll
-  for (int i = 0; i < MF; ++i) {
-    const int row = m0 + wm * (MF * 32) + i * 32 + lr;
+  for (int i = 0; i < 4; ++i) {
+    const int row = m0 + wm * 128 + i * 32 + lr;
     const bool valid = (p.row_valid[row >> 5] >> (row & 31)) & 1u;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -510,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void grid_conv_wide_kernel(const TdnnKernel
     for (int h = 0; h < 4; ++h) {
       const int srow = h * 8 + (lane >> 3), slot = lane & 7;
       const uint4 v = *reinterpret_cast<const uint4 *>(stage + srow * 128 + ((slot ^ (srow & 7)) << 4));
-      const int orow = m0 + wm * (MF * 32) + i * 32 + srow;
+      const int orow = m0 + wm * 128 + i * 32 + srow;
       *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(p.y) + (size_t)orow * p.ldy + wn * 64 + slot * 8) = v;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // reads done before the next fragment overwrites the tile
@@ -813,28 +811,15 @@ int launch_grid_conv_wide(const TdnnKernelParams &p0, hipStream_t s) {
   ASV_REQUIRE(grid_conv_wide_supported(p, true), "grid conv (wide): unsupported layer");
   const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first && p.seg_bias == nullptr &&
                     p.seg_scale == nullptr && p.res == nullptr;
-  // Tile quantisation (round 4): the tiles come in rounds of the chip's workgroup slots (two per CU) and a last round with few tiles
-  // costs a whole one - ResNet34 at 256 x 200 frames: 1050 tiles of the 128-channel stage on 512 slots = 2.05 -> 3 rounds, 550 of
-  // the 256-channel stage = 1.07 -> 2.  When the remainder fits HALF a round, those rows run as
-  // half-height tiles (MF = 2) in a second launch: the same rows on twice the CUs for about half the time.  Every output row is
-  // the same (tap, k-group)-ordered sum whatever the tile: bit-identical (tests/test_gpu_resnet.py).
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  static const bool no_tail = getenv("ASV_AMD_CONV_TAIL") != nullptr && atoi(getenv("ASV_AMD_CONV_TAIL")) == 0;      // A/B aid, read once; same bits
-  const int bm = p.cin_pad == 128 ? WideGeom<128>::BM : WideGeom<256>::BM;
-  const int slots = 2 * cus, m_tiles = p.rows / bm, tail = m_tiles % slots;
-  const bool split = !no_tail && p.tune == 0 && tail > 0 && 2 * tail <= slots && m_tiles > tail;
-  const int rows_full = split ? (m_tiles - tail) * bm : p.rows;
-  const dim3 block(256);
-#define ASV_WIDE(CINV, MFV, ROWS) do { const dim3 grid((ROWS) / WideGeom<CINV, MFV>::BM); \
-    if (fast) ASV_CONV_ET(grid_conv_wide_kernel<CINV, false, MFV); else ASV_CONV_ET(grid_conv_wide_kernel<CINV, true, MFV); } while (0)
-  p.row_begin = 0;
-  if (p.cin_pad == 128) ASV_WIDE(128, 4, rows_full); else ASV_WIDE(256, 4, rows_full);
-  if (split) {
-    p.row_begin = rows_full;
-    if (p.cin_pad == 128) ASV_WIDE(128, 2, p.rows - rows_full); else ASV_WIDE(256, 2, p.rows - rows_full);
+  if (p.cin_pad == 128) {
+    const dim3 grid(p.rows / WideGeom<128>::BM), block(256);
+    if (fast) ASV_CONV_ET(grid_conv_wide_kernel<128, false);
+    else ASV_CONV_ET(grid_conv_wide_kernel<128, true);
+  } else {
+    const dim3 grid(p.rows / WideGeom<256>::BM), block(256);
+    if (fast) ASV_CONV_ET(grid_conv_wide_kernel<256, false);
+    else ASV_CONV_ET(grid_conv_wide_kernel<256, true);
   }
-#undef ASV_WIDE
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }

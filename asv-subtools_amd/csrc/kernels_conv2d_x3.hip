@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256, 2) void grid_conv_x3_kernel(const TdnnKernelPa
   const int wm = wave / WN, wn = wave % WN;
   const int lr = lane & 31, lh = lane >> 5;
   const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int m0 = p.row_begin + (tile / n_tiles) * BM, n0 = (tile % n_tiles) * BN;      // (row_begin: the launch's first row, launch_grid_conv_x3)
+  const int m0 = (tile / n_tiles) * BM, n0 = (tile % n_tiles) * BN;
   const int n_taps = p.n_taps;
   const int nchunks = (p.cin_pad + QCH - 1) / QCH;
 
@@ -416,11 +416,11 @@ bool grid_conv_x3_supported(const TdnnKernelParams &p) {
   return true;
 }
 
-namespace {
-// one launch of geometry `id` over rows [p.row_begin, p.row_begin + p.row_count)
-int launch_geom(const TdnnKernelParams &p, int id, int bm, int bn, hipStream_t s) {
-  const int m_tiles = p.row_count / bm, n_tiles = p.cout_store / bn, nft = p.cout_store / 32;
-  if (m_tiles <= 0) return ASV_OK;
+int launch_grid_conv_x3(const TdnnKernelParams &p, hipStream_t s) {
+  ASV_REQUIRE(grid_conv_x3_supported(p), "grid conv (f32x): unsupported layer");
+  ASV_REQUIRE(p.x3_et == ET_BF16 || p.x3_et == ET_F16, "grid conv (f32x): split type %d", p.x3_et);
+  const QPick g = pick_geom(p);
+  const int m_tiles = p.rows / g.bm, n_tiles = p.cout_store / g.bn, nft = p.cout_store / 32;
   const dim3 grid(m_tiles * n_tiles), block(256);
   // the hot instantiations carry the short epilogue only; tanh / sigmoid / per-segment terms / residual / "bn-relu" order / a second
   // input go to the GENERIC ones
@@ -429,76 +429,35 @@ int launch_geom(const TdnnKernelParams &p, int id, int bm, int bn, hipStream_t s
                           p.seg_scale == nullptr && p.res == nullptr);
 #define ASV_QCONV1(GEO, MODEV) do { if (p.x3_et == ET_F16) hipLaunchKernelGGL((grid_conv_x3_kernel<GEO, ET_F16, MODEV>), grid, block, 0, s, p, n_tiles, nft); \
                                     else hipLaunchKernelGGL((grid_conv_x3_kernel<GEO, ET_BF16, MODEV>), grid, block, 0, s, p, n_tiles, nft); } while (0)
-  // FAST: MODE 0; GEN: MODE 1 (second input, plain epilogue) or 2 (the long epilogue); BOTH: whichever the layer needs
+  // FAST: MODE 0; GEN: MODE 1 (second input, plain epilogue) or 2 (the long epilogue)
 #define ASV_QCONV_FAST(GEO) ASV_QCONV1(GEO, 0)
 #define ASV_QCONV_GEN(GEO) do { if (long_epi) ASV_QCONV1(GEO, 2); else ASV_QCONV1(GEO, 1); } while (0)
-#define ASV_QCONV_BOTH(GEO) do { if (fast) ASV_QCONV_FAST(GEO); else ASV_QCONV_GEN(GEO); } while (0)
-  // the small-tile geometries carry both epilogues; the 256-row 128-channel and 128-row 256-channel ones the plain epilogue only
-  // (the long one and the second input's registers do not fit beside 128 accumulator registers)
-  switch (id) {
-    case 0: ASV_QCONV_BOTH(Q32); break;
-    case 1: ASV_QCONV_BOTH(Q64); break;
-    case 2: ASV_QCONV_BOTH(Q64P); break;
-    case 7: ASV_QCONV_BOTH(Q64F); break;
+  // the small-tile geometries (ids 0 - 2, 7) carry both epilogues; the 128- / 256-channel ones have a geometry per epilogue (the long one
+  // and the second input's registers do not fit beside 128 accumulator registers)
+  (void)fast;
+  switch (g.id) {
+    case 0: if (fast) ASV_QCONV_FAST(Q32); else ASV_QCONV_GEN(Q32); break;
+    case 1: if (fast) ASV_QCONV_FAST(Q64); else ASV_QCONV_GEN(Q64); break;
+    case 2: if (fast) ASV_QCONV_FAST(Q64P); else ASV_QCONV_GEN(Q64P); break;
+    case 7: if (fast) ASV_QCONV_FAST(Q64F); else ASV_QCONV_GEN(Q64F); break;
     case 3: ASV_QCONV_FAST(Q128); break;
     case 4: ASV_QCONV_FAST(Q128P); break;
     case 8: ASV_QCONV_FAST(Q128F); break;
     case 5: ASV_QCONV_FAST(Q256); break;
     case 6: ASV_QCONV_FAST(Q256P); break;
     case 9: ASV_QCONV_FAST(Q256F); break;
-    case 10: ASV_QCONV_BOTH(Q128g); break;
-    case 11: ASV_QCONV_BOTH(Q128Fg); break;
+    case 10: ASV_QCONV_GEN(Q128g); break;
+    case 11: ASV_QCONV_GEN(Q128Fg); break;
     case 12: ASV_QCONV_GEN(Q128Pg); break;
-    case 13: ASV_QCONV_BOTH(Q256g); break;
-    case 14: ASV_QCONV_BOTH(Q256Fg); break;
+    case 13: ASV_QCONV_GEN(Q256g); break;
+    case 14: ASV_QCONV_GEN(Q256Fg); break;
     default: ASV_QCONV_GEN(Q256Pg); break;
   }
-#undef ASV_QCONV_BOTH
 #undef ASV_QCONV_FAST
 #undef ASV_QCONV_GEN
 #undef ASV_QCONV1
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
-}
-
-// the half-height twin of a full-height geometry (same window halo, half the rows per wave), or -1
-int half_height_of(int id, int *bm) {
-  switch (id) {
-    case 3: *bm = Q128g::BM; return 10;
-    case 8: *bm = Q128Fg::BM; return 11;
-    case 5: *bm = Q256g::BM; return 13;
-    case 9: *bm = Q256Fg::BM; return 14;
-    default: return -1;
-  }
-}
-}  // namespace
-
-int launch_grid_conv_x3(const TdnnKernelParams &p0, hipStream_t s) {
-  ASV_REQUIRE(grid_conv_x3_supported(p0), "grid conv (f32x): unsupported layer");
-  ASV_REQUIRE(p0.x3_et == ET_BF16 || p0.x3_et == ET_F16, "grid conv (f32x): split type %d", p0.x3_et);
-  TdnnKernelParams p = p0;
-  const QPick g = pick_geom(p);
-  // Tile quantisation: the full-height tiles come in rounds of the chip's workgroup slots (two per CU); a last round with few tiles
-  // costs a whole round (ResNet34 at 256 x 200 frames: 1050 tiles of the 128-channel stage on 512 slots = 2.05 -> 3 rounds, 550 of
-  // the 256-channel stage = 1.07 -> 2).  When the remainder fits HALF a round, those rows run as half-height tiles of the twin
-  // geometry in a second launch: the same rows on twice the CUs for about half the time.  Per-row results do not depend on the tile.
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  static const bool no_tail = getenv("ASV_AMD_CONV_TAIL") != nullptr && atoi(getenv("ASV_AMD_CONV_TAIL")) == 0;      // A/B aid, read once; same results
-  const int slots = 2 * cus, n_tiles = p.cout_store / g.bn, m_tiles = p.rows / g.bm;
-  const int per_round = std::max(1, slots / n_tiles);               // row tiles per round
-  const int tail = m_tiles % per_round;
-  int half_bm = 0;
-  const int half_id = half_height_of(g.id, &half_bm);
-  int rc;
-  if (!no_tail && half_id >= 0 && tail > 0 && 2 * tail <= per_round && m_tiles > tail) {
-    p.row_begin = 0; p.row_count = (m_tiles - tail) * g.bm;
-    if ((rc = launch_geom(p, g.id, g.bm, g.bn, s))) return rc;
-    p.row_begin = p.row_count; p.row_count = p.rows - p.row_begin;
-    return launch_geom(p, half_id, half_bm, g.bn, s);
-  }
-  p.row_begin = 0; p.row_count = p.rows;
-  return launch_geom(p, g.id, g.bm, g.bn, s);
 }
 
 }  // namespace asv

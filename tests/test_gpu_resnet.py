@@ -66,36 +66,3 @@ def test_resnet_preactivation_bf16_is_close():
     ref = g["embeddings"]
     cos = (got * ref).sum(1) / np.linalg.norm(got, axis=1) / np.linalg.norm(ref, axis=1)
     assert cos.min() > 0.998, cos
-
-
-def test_half_height_tail_tiles_are_bit_identical(tmp_path):
-    """Round 4: the 128- / 256-channel convolution kernels (bf16 / f16: grid_conv_wide_kernel; f32x: grid_conv_x3_kernel) run the last,
-    thinly filled round of workgroups as half-height tiles in a second launch (256 x 200 frames: 1050 tiles on 512 slots = 2.05 ->
-    3 rounds without it).  Every output row is the same (tap, k-group)-ordered sum whatever the tile, so the embeddings are
-    bit-identical to a run with ASV_AMD_CONV_TAIL=0 (read once per process: subprocesses)."""
-    import os
-    import subprocess
-    import sys
-    code = r'''
-import sys, numpy as np
-sys.path[:0] = [%r, %r, %r]
-import helpers
-from libs.amd import synth
-g, sd, model = helpers.golden_model("resnet34se_c5")
-model.cuda()
-mats = [synth.synth_feats(200, 80, 6000 + i) for i in range(256)]
-out = {}
-for prec in ("bf16", "f32x"):
-    model.amd_precision = prec
-    out[prec] = model.extract_embedding_batch(mats).numpy()
-np.savez(sys.argv[1], **out)
-''' % (helpers.REPO, os.path.join(helpers.REPO, "asv-subtools_amd", "pytorch"), os.path.join(helpers.REPO, "tests"))
-    res = {}
-    for mode in ("1", "0"):
-        path = str(tmp_path / ("tail%s.npz" % mode))
-        r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, ASV_AMD_CONV_TAIL=mode), capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-        res[mode] = dict(np.load(path))
-    for prec in ("bf16", "f32x"):
-        assert np.isfinite(res["1"][prec]).all()
-        assert np.array_equal(res["1"][prec], res["0"][prec]), prec
