@@ -74,6 +74,7 @@ def parse():
                          "come from a single-stream pass of the same workload)")
     ap.add_argument("--eer-trials", type=int, default=50000, help="trials of the EER gate leg (0 = skip)")
     ap.add_argument("--gate-seeds", type=int, default=3, help="weight seeds of the per-model gate table (parity_grade; 0 = skip)")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes that measure roofline.traffic (N = 1, default workload)")
     ap.add_argument("--lengths", default=None, help="'lo:hi' = utterance lengths ~ U[lo, hi] (seeded) instead of --frames")
     ap.add_argument("--batch", type=int, default=None,
                     help="utterances per GPU per step (default: 640 for the x-vector - 640 x 204 padded rows = 1020 row tiles of 128, two "
@@ -96,6 +97,45 @@ def parse():
                     help="xvector = BASELINE configs[1] (the default, the contract's workload); ecapa = configs[2] (C=1024, 300 frames); "
                          "resnet = the configs[4] extractor (ResNet34-SE)")
     return ap.parse_args()
+
+
+def measure_traffic(kernel_sub="tdnn_chain_kernel", timeout_s=150):
+    """HBM traffic of the dominant kernel, measured in THIS run: two short passes of this same script under rocprofv3, one counter
+    each (FETCH_SIZE and WRITE_SIZE do not share a pass on gfx950), collected and corrected as MI355X_MICROARCH.md prescribes - KiB per
+    dispatch, the read side doubled (gfx950 reports half the bytes of wide streaming reads), the write side as is - and averaged over
+    the kernel's dispatches.  Returns (bytes per launch, detail dict) or (None, {"error": ...}); never raises."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, {"error": "rocprofv3 not found"}
+    got = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="asv_pmc_", dir="/tmp")
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "4", "--warmup", "2", "--no-profile", "--min-seconds", "0.05", "--settle-seconds", "0.2", "--streams", "1", "--cpu-seconds", "0",
+                   "--no-supplementary", "--eer-trials", "0", "--no-traffic"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+            vals = []
+            for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        if row.get("Counter_Name") == counter and kernel_sub in row.get("Kernel_Name", ""):
+                            vals.append(float(row["Counter_Value"]))
+            shutil.rmtree(d, ignore_errors=True)
+            if not vals:
+                return None, {"error": "%s pass: no dispatches of %s in the counter file (rc %d): %s" % (counter, kernel_sub, r.returncode, r.stderr.decode(errors="replace")[-300:])}
+            got[counter] = (1024.0 * sum(vals) / len(vals), len(vals))
+    except Exception as e:                                        # a counter pass must never take the bench line down
+        return None, {"error": "%s: %s" % (type(e).__name__, e)}
+    fetch_b, write_b = 2.0 * got["FETCH_SIZE"][0], got["WRITE_SIZE"][0]
+    return fetch_b + write_b, {"fetch_bytes_per_launch_corrected": round(fetch_b), "write_bytes_per_launch": round(write_b), "dispatches": got["FETCH_SIZE"][1],
+                               "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes of this script, 4 steps each), "
+                                         "FETCH_SIZE x 2 (gfx950), averaged over the dispatches of " + kernel_sub}
 
 
 def self_launch(args):
@@ -541,16 +581,28 @@ def main():
     if "roofline" in head:
         res["roofline"] = head["roofline"]
         res["gemm_ms_per_step"] = head["roofline"].pop("gemm_ms_per_step")
-        pmc = os.path.join(REPO, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc) and args.model == "xvector" and args.precision == "bf16":
-            # NOT measured in this run: HBM traffic of the dominant kernel from the committed rocprofv3 --pmc passes of this
-            # same command (tools/collect_profiles.sh -> tools/pmc_summary.py; FETCH_SIZE doubled as MI355X_MICROARCH.md
-            # prescribes for gfx950)
-            with open(pmc) as f:
-                info = json.load(f)
-            res["roofline"]["traffic"] = info.get("traffic_bytes_per_launch")
-            res["roofline"]["traffic_algorithmic_bytes"] = info.get("algorithmic_bytes_per_launch")
-            res["roofline"]["traffic_source"] = "static: profiles/pmc_summary.json (" + str(info.get("source")) + "; library build " + str(info.get("library_sha256_16")) + "); not re-measured by bench.py"
+        if args.model == "xvector" and args.precision == "bf16":
+            # strictly algorithmic bytes of one chain-kernel launch: the 512-channel 16-bit input rows once, the three layers' weights
+            # once, the pooled statistics out
+            rows = wl.B * (wl.T + 4) + 4
+            alg = rows * 512 * 2 + (3 * 512 * 512 + 512 * 512 + 512 * 1536) * 2 + wl.B * 2 * 1500 * 4
+            res["roofline"]["traffic_algorithmic_bytes"] = alg
+            traffic, detail = (None, {"error": "skipped (--no-traffic)"})
+            if world == 1 and not args.no_traffic and not args.lengths and not args.from_wav:
+                traffic, detail = measure_traffic()
+            if traffic is not None:
+                res["roofline"]["traffic"] = round(traffic)
+                res["roofline"]["traffic_over_algorithmic"] = round(traffic / alg, 3)
+                res["roofline"]["traffic_source"] = detail
+            else:
+                # fall back to the committed passes of the same command (tools/collect_profiles.sh -> tools/pmc_summary.py)
+                pmc = os.path.join(REPO, "profiles", "pmc_summary.json")
+                if os.path.exists(pmc):
+                    with open(pmc) as f:
+                        info = json.load(f)
+                    res["roofline"]["traffic"] = info.get("traffic_bytes_per_launch")
+                    res["roofline"]["traffic_source"] = {"static": "profiles/pmc_summary.json (" + str(info.get("source")) + "; library build " + str(info.get("library_sha256_16")) +
+                                                         ", batch of that collection: " + str(info.get("batch", 640)) + ")", "live_pass": detail}
 
     modes = {}
     if rank == 0 and args.model == "xvector" and not dry and not args.lengths:

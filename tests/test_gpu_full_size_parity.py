@@ -7,9 +7,9 @@ from INSIDE those full batches are compared with the numpy oracle (oracle/np_ora
 outputs by tests/test_oracle_golden.py) in every precision mode:
 
     f32, f32x : max |a - b| / max |b| <= 1e-4               (north_star: "within 1e-4 relative fp32")
-    bf16      : the same metric <= 2e-2 and cosine >= 0.9995   (bf16 operands: 8 mantissa bits; the EER gate of the
-                                                                throughput mode is tests/test_gpu_eer_gate.py)
-    f16       : <= 2.5e-3 and cosine >= 0.99999                (IEEE-half operands: 11 bits)
+    bf16, f16 : the 16-bit throughput modes are held to about TWICE what they measure per model (TOL_16 below; the measured
+                values: profiles/r4_full_size_parity_measured.json, written by the last test of this module) - tight enough to
+                show drift, not only breakage.  Their gates are another matter: tests/test_gpu_eer_gate.py.
 """
 
 import numpy as np
@@ -21,8 +21,11 @@ from helpers import rel_err
 pytestmark = pytest.mark.gpu
 
 TOL_F32 = 1e-4
-TOL_BF16_REL, TOL_BF16_COS = 2e-2, 0.9995
-TOL_F16_REL, TOL_F16_COS = 2.5e-3, 0.99999
+# (model, precision) -> (max rel err, min cosine).  Measured in round 4 (rel err / 1 - cosine): x-vector bf16 2.3e-3 / 1.8e-6, f16
+# 2.6e-4 / 1e-7; ECAPA bf16 1.9e-2 / 1.5e-4, f16 2.6e-3 / 2.4e-6; ResNet34-SE (ragged) bf16 3.5e-2 / 7.6e-4, f16 4.4e-3 / 7.6e-6
+TOL_16 = {("xvector", "bf16"): (5e-3, 1 - 1e-5), ("xvector", "f16"): (6e-4, 1 - 1e-6),
+          ("ecapa", "bf16"): (4e-2, 1 - 5e-4), ("ecapa", "f16"): (6e-3, 1 - 1e-5),
+          ("resnet", "bf16"): (7e-2, 1 - 2.5e-3), ("resnet", "f16"): (1e-2, 1 - 3e-5)}
 
 
 def _sample_positions(n, k=8):
@@ -34,10 +37,7 @@ def _sample_positions(n, k=8):
 MEASURED = {}          # (test label, precision) -> worst (rel err, cosine) seen: written to gpurun_out/ by the last test of the module
 
 
-def _check(got, want, precision, what, depth=1.0, label=None):
-    """depth: how much deeper than the 5-layer x-vector the model is - the operand rounding of a 16-bit mode accumulates over the
-    layers (ECAPA: ~25 frame-level layers on a path, measured 2.6e-3 in f16; ResNet34: 36 convolutions, 3.0e-2 in bf16 / 4.0e-3 in
-    f16); the parity-grade modes are held to 1e-4 whatever the depth."""
+def _check(got, want, precision, what, model, label=None):
     for g, w, tag in zip(got, want, what):
         err = rel_err(g, w)
         cos = float((g * w).sum() / np.linalg.norm(g) / np.linalg.norm(w))
@@ -45,8 +45,7 @@ def _check(got, want, precision, what, depth=1.0, label=None):
         prev = MEASURED.get(key, (0.0, 1.0))
         MEASURED[key] = (max(prev[0], err), min(prev[1], cos))
         if precision in ("bf16", "f16"):
-            tol_rel, tol_cos = (TOL_BF16_REL, TOL_BF16_COS) if precision == "bf16" else (TOL_F16_REL, TOL_F16_COS)
-            tol_rel, tol_cos = tol_rel * depth, 1.0 - (1.0 - tol_cos) * depth * depth
+            tol_rel, tol_cos = TOL_16[(model, precision)]
             assert err < tol_rel and cos > tol_cos, "%s %s: rel err %.3g cos %.7f" % (tag, precision, err, cos)
         else:
             assert err < TOL_F32, "%s %s: rel err %.3g" % (tag, precision, err)
@@ -70,7 +69,7 @@ def test_c2_xvector_full_batch_vs_oracle(batch, precision):
     assert got.shape == (batch, 512) and np.isfinite(got).all()
     pos = _sample_positions(batch)
     want = [O.extract_embedding(lambda c: O.xvector_embed(c, sd, "far"), mats[i]) for i in pos]
-    _check([got[i] for i in pos], want, precision, ["utt %d of %d" % (i, batch) for i in pos], label="c2 xvector b%d" % batch)
+    _check([got[i] for i in pos], want, precision, ["utt %d of %d" % (i, batch) for i in pos], "xvector", label="c2 xvector b%d" % batch)
 
 
 @pytest.mark.parametrize("precision", ["f32", "f32x", "bf16", "f16"])
@@ -90,7 +89,7 @@ def test_c3_ecapa_full_batch_vs_oracle(precision):
     assert got.shape == (256, 192) and np.isfinite(got).all()
     pos = _sample_positions(256, k=6)
     want = [O.extract_embedding(lambda c: O.ecapa_embed(c, sd, "near"), mats[i]) for i in pos]
-    _check([got[i] for i in pos], want, precision, ["utt %d of 256" % i for i in pos], depth=2.0, label="c3 ecapa b256")
+    _check([got[i] for i in pos], want, precision, ["utt %d of 256" % i for i in pos], "ecapa", label="c3 ecapa b256")
 
 
 @pytest.mark.parametrize("precision", ["f32", "f32x", "bf16", "f16"])
@@ -115,7 +114,7 @@ def test_c5_resnet_variable_length_full_batch_vs_oracle(precision):
     assert got.shape == (256, 256) and np.isfinite(got).all()
     pos = sorted({0, 3, 127, 128, 200, 255, int(np.argmin(lengths)), int(np.argmax(lengths))})
     want = [O.extract_embedding(lambda c: O.resnet_embed(c, sd, "near", ""), mats[i]) for i in pos]
-    _check([got[i] for i in pos], want, precision, ["utt %d (%d frames)" % (i, lengths[i]) for i in pos], depth=2.5, label="c5 resnet ragged b256")
+    _check([got[i] for i in pos], want, precision, ["utt %d (%d frames)" % (i, lengths[i]) for i in pos], "resnet", label="c5 resnet ragged b256")
 
 
 @pytest.mark.parametrize("name", ["xvector_c1", "xvector_near_ragged", "xvector_chunked", "ecapa_c3", "ecapa_launcher", "ecapa_c512_fc1_far",
