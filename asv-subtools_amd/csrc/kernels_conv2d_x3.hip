@@ -85,32 +85,34 @@ __global__ __launch_bounds__(256, 2) void grid_conv_x3_kernel(const TdnnKernelPa
   // ---- staging: f32 rows -> registers -> [hi | lo] image
   const float *xg = reinterpret_cast<const float *>(p.x);
   const float *x2g = reinterpret_cast<const float *>(p.x2);       // optional second input, added while the rows are staged (Res2Net's sp + x_i)
-  struct Stage { uint4 a[NP], b[NP], a2[GENERIC ? NP : 1], b2[GENERIC ? NP : 1]; };
+  // The loads are issued UNCONDITIONALLY (rows / channels outside the matrix: a valid address, the value zeroed at conversion, `ok`
+  // bit per piece): behind per-lane branches hipcc cannot count them and waits with vmcnt(0) in front of the conversion - for the
+  // loads issued a chunk ago AND the ones just issued (the two-stage prefetch of the 1-tap geometries then hides nothing).
+  struct Stage { uint4 a[NP], b[NP], a2[GENERIC ? NP : 1], b2[GENERIC ? NP : 1]; uint32_t ok; };
   uint32_t range = 0u;                                           // range watch of the half split (device_utils.h)
   auto gload = [&](int c, Stage &st) {
+    uint32_t okbits = 0u;
 #pragma unroll
     for (int it = 0; it < NP; ++it) {
       const int item = it * 256 + tid, w = item >> 2, q = item & 3;
       const int row = m0 - HLO + w, ch = c * QCH + q * 8;
-      uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
-      if (item < WIN * 4 && row >= 0 && row < p.rows && ch < p.cin_pad) {
-        const float *src = xg + (size_t)row * p.ldx + ch;
-        a = *reinterpret_cast<const uint4 *>(src);
-        b = *reinterpret_cast<const uint4 *>(src + 4);
-        if constexpr (GENERIC) {
-          // the second input stays in registers of its own until the rows are converted: adding here would wait for both loads
-          // in front of the K loop they are meant to hide behind (measured: 95 instead of 43 us for a Res2Net branch)
-          if (x2g != nullptr) {
-            const float *src2 = x2g + (size_t)row * p.ldx2 + ch;
-            st.a2[it] = *reinterpret_cast<const uint4 *>(src2);
-            st.b2[it] = *reinterpret_cast<const uint4 *>(src2 + 4);
-          }
+      const bool ok = item < WIN * 4 && row >= 0 && row < p.rows && ch < p.cin_pad;
+      okbits |= ok ? (1u << it) : 0u;
+      const size_t off = ok ? (size_t)row * p.ldx + ch : 0;
+      const float *src = xg + off;
+      st.a[it] = *reinterpret_cast<const uint4 *>(src);
+      st.b[it] = *reinterpret_cast<const uint4 *>(src + 4);
+      if constexpr (GENERIC) {
+        // the second input stays in registers of its own until the rows are converted: adding here would wait for both loads
+        // in front of the K loop they are meant to hide behind (measured: 95 instead of 43 us for a Res2Net branch)
+        if (x2g != nullptr) {                                     // (wave-uniform)
+          const float *src2 = x2g + (ok ? (size_t)row * p.ldx2 + ch : 0);
+          st.a2[it] = *reinterpret_cast<const uint4 *>(src2);
+          st.b2[it] = *reinterpret_cast<const uint4 *>(src2 + 4);
         }
-      } else if constexpr (GENERIC) {
-        st.a2[it] = make_uint4(0, 0, 0, 0); st.b2[it] = make_uint4(0, 0, 0, 0);
       }
-      st.a[it] = a; st.b[it] = b;
     }
+    st.ok = okbits;
   };
   auto sstore = [&](int buf, Stage &st) {
     unsigned char *img = lds + buf * G::IMG;
@@ -121,7 +123,9 @@ __global__ __launch_bounds__(256, 2) void grid_conv_x3_kernel(const TdnnKernelPa
         if constexpr (GENERIC) {
           if (x2g != nullptr) { st.a[it] = add_f32x4(st.a[it], st.a2[it]); st.b[it] = add_f32x4(st.b[it], st.b2[it]); }
         }
-        const X3Frag f = x3_split<ET, true>(st.a[it], st.b[it], range);
+        const bool ok = (st.ok >> it) & 1u;
+        const uint4 zero = make_uint4(0, 0, 0, 0);
+        const X3Frag f = x3_split<ET, true>(ok ? st.a[it] : zero, ok ? st.b[it] : zero, range);
         *reinterpret_cast<uint4 *>(img + w * QROWB + qswz(w, q) * 16) = f.hi;
         *reinterpret_cast<uint4 *>(img + w * QROWB + qswz(w, 4 + q) * 16) = f.lo;
       }
@@ -194,19 +198,21 @@ __global__ __launch_bounds__(256, 2) void grid_conv_x3_kernel(const TdnnKernelPa
     const bool more_chunks = c + 1 < nchunks;
     XF xa, xb;
     load_x(img, __builtin_amdgcn_readlane(v_taps, 0), 0, 0, xa);
-#pragma unroll 1
-    for (int t = 0; t < n_taps; ++t) {
-      const int step = (c * n_taps + t) * 2;
+    // k-group 1's fragments of the first tap -> wb, then the next rows go into flight BEHIND them (the vector-memory counter retires
+    // in order: a fragment fetch issued behind the rows could not be consumed before they land).  Both sit in front of the tap loop,
+    // which runs at least once (do-while): hipcc can then count the fragment fetches that are younger than the rows and waits for
+    // the rows alone in front of their conversion (with a for loop it had to assume zero trips: vmcnt(0), every chunk).
+    int step = c * n_taps * 2;
+    load_w(step + 1, wb);
+    if constexpr (G::NBUF == 2) {
+      if (c_ld < nchunks) gload(c_ld, ld);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // one tap: k-group 0 on wa, k-group 1 on wb, the fragments of the next two k-groups fetched one k-group ahead
+    auto tap = [&](const int t) {
       const int d = __builtin_amdgcn_readlane(v_taps, t);
       const bool last_tap = t + 1 == n_taps;
       const int dn = __builtin_amdgcn_readlane(v_taps, last_tap ? t : t + 1);
-      // k-group 0 on wa; k-group 1's fragments -> wb; at the chunk's first tap the next rows follow them into flight (the
-      // vector-memory counter retires in order: a fragment fetch issued BEHIND the rows could not be consumed before they land)
-      load_w(step + 1, wb);
-      if constexpr (G::NBUF == 2) {
-        if (t == 0 && c_ld < nchunks) gload(c_ld, ld);
-      }
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
         XF &xc = (u & 1) ? xb : xa;
@@ -216,8 +222,8 @@ __global__ __launch_bounds__(256, 2) void grid_conv_x3_kernel(const TdnnKernelPa
         mma(wa, xc, u);
         __builtin_amdgcn_sched_barrier(0);
       }
-      // k-group 1 on wb; the next step's fragments (next tap, or the next chunk's first step; the very last step re-fetches
-      // itself: valid memory, never used) -> wa
+      // the next step's fragments (next tap, or the next chunk's first step; the very last step re-fetches itself: valid memory,
+      // never used) -> wa
       {
         const int next = (last_tap && !more_chunks) ? step + 1 : step + 2;
         load_w(next, wa);
@@ -233,6 +239,17 @@ __global__ __launch_bounds__(256, 2) void grid_conv_x3_kernel(const TdnnKernelPa
         mma(wb, xc, u);
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (!last_tap) load_w(step + 3, wb);                       // k-group 1 of the next tap
+      __builtin_amdgcn_sched_barrier(0);
+      step += 2;
+    };
+    // The FIRST tap stands outside the loop: its waits for wa / wb are then counted against what this chunk has issued so far -
+    // inside the loop hipcc merges them with the back edge's (only 4 younger fetches) and the chunk would start by waiting for the
+    // rows it has just requested.  (Halo-free geometries have exactly one tap: taps ascend strictly and |tap| <= 0.)
+    tap(0);
+    if constexpr (!G::PF2) {
+#pragma unroll 1
+      for (int t = 1; t < n_taps; ++t) tap(t);
     }
     if constexpr (G::NBUF == 2) {
       if (more_chunks) {

@@ -8,6 +8,7 @@
 #   gpurun_out/<tag>_pmc_*.csv                 (with "pmc") FETCH_SIZE / WRITE_SIZE / SQ passes, each its own run
 set -u
 tag=${1:-r4}
+do_pmc=${2:-}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out
 mkdir -p $out
@@ -26,7 +27,7 @@ for m in "xvector bf16" "xvector f32x" "ecapa bf16" "ecapa f32x" "resnet bf16" "
   cp $out/${tag}_kt_$name/*/*kernel_stats.csv $out/${tag}_${name}_kernel_stats.csv 2>/dev/null
   rm -rf $out/${tag}_kt_$name
 done
-if [ "${2:-}" = "pmc" ]; then
+if [ "$do_pmc" = "pmc" ]; then
   short="--steps 4 --warmup 2 --no-profile --min-seconds 0.05 $one"
   for cfg in "xvector bf16" "resnet f32x"; do
     set -- $cfg; model=$1; prec=$2
