@@ -274,6 +274,8 @@ struct Im2colParams {
   int dt[ASV_MAX_TAPS], df[ASV_MAX_TAPS];
   const int32_t *in_row0, *in_len, *out_row0, *out_row_seg; const uint32_t *out_row_valid;
   int in_pitch, in_width, out_pitch, out_rows;
+  // optional elementwise prologue: value = act(in * seg_scale[segment] + b), rounded to the element type (the arithmetic of eltwise_kernel)
+  const void *b; int ldb; const float *seg_scale; int ld_segscale; int act;
 };
 int launch_im2col(const Im2colParams &p, int et, hipStream_t s);
 int launch_pack_input(const float *feats, int feat_dim, const int32_t *seg_src0, const int32_t *seg_row0,

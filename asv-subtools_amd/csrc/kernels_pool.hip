@@ -599,12 +599,12 @@ __global__ __launch_bounds__(256) void eltwise_kernel(const EltwiseKernelParams 
       float ss[VEC];
       table(p.seg_scale + (size_t)seg * p.ld_segscale, ss);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) o[i] *= ss[i];
-    }
+      for (int i = 0; i < VEC; ++i) o[i] = __fmul_rn(o[i], ss[i]);          // (separately rounded, like the reference's x * s + residual:
+    }                                                                         //  never contracted into one fma - im2col_kernel's prologue repeats it)
     if (p.b != nullptr) {
       load_vec<ET, VEC>(p.b, (size_t)row * p.ldb + ch, tb);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) o[i] += tb[i];
+      for (int i = 0; i < VEC; ++i) o[i] = __fadd_rn(o[i], tb[i]);
     }
     if (p.c != nullptr) {
       float t[VEC];
@@ -715,9 +715,32 @@ __global__ __launch_bounds__(256) void im2col_kernel(const Im2colParams p) {
     const int t = (rel / p.out_pitch) * p.stride + p.dt[k], f = (rel % p.out_pitch) * p.stride + p.df[k];
     const int in_frames = p.in_len[seg] / p.in_pitch;
     if (t >= 0 && t < in_frames && f >= 0 && f < p.in_width) {
-      const size_t src = (size_t)(p.in_row0[seg] + t * p.in_pitch + f) * p.ldi + (size_t)piece * VEC;
+      const size_t srow = (size_t)(p.in_row0[seg] + t * p.in_pitch + f);
+      const size_t src = srow * p.ldi + (size_t)piece * VEC;
       if constexpr (ET != ET_F32) v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(p.in) + src);
       else v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const float *>(p.in) + src);
+      if (p.b != nullptr || p.seg_scale != nullptr || p.act != ASV_ACT_NONE) {
+        // elementwise prologue: exactly eltwise_kernel's operations on this piece (separately rounded multiply and add, then the
+        // activation, then the rounding to the element type), so that fusing the pass changes no bit
+        float o[VEC];
+        if constexpr (ET != ET_F32) unpack_h16x8<ET>(v, o);
+        else { o[0] = __uint_as_float(v.x); o[1] = __uint_as_float(v.y); o[2] = __uint_as_float(v.z); o[3] = __uint_as_float(v.w); }
+        if (p.seg_scale != nullptr) {
+          const float *ss = p.seg_scale + (size_t)seg * p.ld_segscale + (size_t)piece * VEC;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) o[i] = __fmul_rn(o[i], ss[i]);
+        }
+        if (p.b != nullptr) {
+          float tb[VEC];
+          load_vec<ET, VEC>(p.b, srow * p.ldb + (size_t)piece * VEC, tb);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) o[i] = __fadd_rn(o[i], tb[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) o[i] = apply_act(o[i], p.act);
+        if constexpr (ET != ET_F32) v = pack_h16x8<ET>(o);
+        else v = make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3]));
+      }
     }
   }
   const size_t dst = (size_t)row * p.ldo + (size_t)k * p.channels + (size_t)piece * VEC;

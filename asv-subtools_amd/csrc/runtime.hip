@@ -751,6 +751,15 @@ int asv_net_add_im2col(asv_net_t *net, const asv_im2col_desc_t *d) {
   ASV_REQUIRE(di.kind == 2 && dq.kind == 2 && d->out_buf != d->in_buf && d->out_buf != 0, "im2col: grid -> grid");
   ASV_REQUIRE(dq.shift == di.shift + (d->stride == 2 ? 1 : 0) && dq.width == (di.width + d->stride - 1) / d->stride,
               "im2col: output grid (T/%d x %d) does not match stride %d over input grid (T/%d x %d)", 1 << dq.shift, dq.width, d->stride, 1 << di.shift, di.width);
+  ASV_REQUIRE(d->act == ASV_ACT_NONE || d->act == ASV_ACT_RELU, "im2col: the elementwise prologue takes no activation or ReLU (got %d)", d->act);
+  if (d->b_buf >= 0) {
+    if ((rc = check_view(net, d->b_buf, 0, d->channels, "im2col addend"))) return rc;
+    ASV_REQUIRE(net->bufs[d->b_buf].domain == net->bufs[d->in_buf].domain && net->bufs[d->b_buf].channels == d->channels && d->b_buf != d->out_buf,
+                "im2col: the addend must be a whole buffer of the input's grid and width");
+  }
+  if (d->seg_scale_buf >= 0)
+    ASV_REQUIRE(d->seg_scale_buf < (int)net->bufs.size() && net->is_utts(net->bufs[d->seg_scale_buf].domain) && net->bufs[d->seg_scale_buf].channels >= d->channels,
+                "im2col: bad per-segment scale buffer");
   Op op; op.kind = OP_IM2COL; op.i2c = *d;
   net->ops.push_back(op);
   return ASV_OK;
@@ -780,7 +789,7 @@ int asv_net_finalize(asv_net_t *net, int out_buf, int embed_dim) {
                              o.kind == OP_POOL ? o.pool.in_buf : -1, o.kind == OP_ATTPOOL ? o.att.x_buf : -1, o.kind == OP_ATTPOOL ? o.att.logit_buf : -1,
                              o.kind == OP_ELTWISE ? o.elt.a_buf : -1, o.kind == OP_ELTWISE ? o.elt.b_buf : -1, o.kind == OP_ELTWISE ? o.elt.c_buf : -1,
                              o.kind == OP_ELTWISE ? o.elt.d_buf : -1,
-                             o.kind == OP_IM2COL ? o.i2c.in_buf : -1, o.kind == OP_LDE ? o.lde.x_buf : -1, o.kind == OP_RES2 ? o.res2.in_buf : -1};
+                             o.kind == OP_IM2COL ? o.i2c.in_buf : -1, o.kind == OP_IM2COL ? o.i2c.b_buf : -1, o.kind == OP_LDE ? o.lde.x_buf : -1, o.kind == OP_RES2 ? o.res2.in_buf : -1};
         for (int rbuf : reads) other_reader |= (rbuf == d.out_buf);
       }
       if (other_reader || d.out_buf == out_buf) continue;
@@ -810,7 +819,7 @@ int asv_net_finalize(asv_net_t *net, int out_buf, int embed_dim) {
                              o.kind == OP_POOL ? o.pool.in_buf : -1, o.kind == OP_ATTPOOL ? o.att.x_buf : -1, o.kind == OP_ATTPOOL ? o.att.logit_buf : -1,
                              o.kind == OP_ELTWISE ? o.elt.a_buf : -1, o.kind == OP_ELTWISE ? o.elt.b_buf : -1, o.kind == OP_ELTWISE ? o.elt.c_buf : -1,
                              o.kind == OP_ELTWISE ? o.elt.seg_scale_buf : -1, o.kind == OP_ELTWISE ? o.elt.seg_norm_buf : -1, o.kind == OP_ELTWISE ? o.elt.d_buf : -1,
-                             o.kind == OP_IM2COL ? o.i2c.in_buf : -1, o.kind == OP_LDE ? o.lde.x_buf : -1, o.kind == OP_GRID_INPUT ? o.gin.in_buf : -1,
+                             o.kind == OP_IM2COL ? o.i2c.in_buf : -1, o.kind == OP_IM2COL ? o.i2c.b_buf : -1, o.kind == OP_IM2COL ? o.i2c.seg_scale_buf : -1, o.kind == OP_LDE ? o.lde.x_buf : -1, o.kind == OP_GRID_INPUT ? o.gin.in_buf : -1,
                              o.kind == OP_RES2 ? o.res2.in_buf : -1};
         for (int rbuf : reads) if (rbuf == buf) return false;
       }
@@ -1513,6 +1522,9 @@ int run_ops(RunCtx &c, size_t n_ops) {
         p.out_row0 = c.dom[dout].seg_row0; p.out_row_seg = c.dom[dout].row_seg; p.out_row_valid = c.dom[dout].row_valid;
         p.in_pitch = net->domains[din].pitch; p.in_width = net->domains[din].width;
         p.out_pitch = net->domains[dout].pitch; p.out_rows = c.dom[dout].rows_pad;
+        if (d.b_buf >= 0) { p.b = net->arena[d.b_buf].ptr; p.ldb = net->bufs[d.b_buf].ld; }
+        if (d.seg_scale_buf >= 0) { p.seg_scale = reinterpret_cast<const float *>(net->arena[d.seg_scale_buf].ptr); p.ld_segscale = net->bufs[d.seg_scale_buf].ld; }
+        p.act = d.act;
         if ((rc = prof.begin(K_GATHER, 0, (int)i))) return rc;
         if ((rc = launch_im2col(p, net->frames_et(), c.s))) return rc;
         if ((rc = prof.end())) return rc;

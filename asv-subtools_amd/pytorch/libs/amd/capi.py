@@ -116,6 +116,7 @@ class Im2colDesc(C.Structure):
         ("struct_size", C.c_uint32),
         ("in_buf", C.c_int32), ("out_buf", C.c_int32), ("channels", C.c_int32), ("n_taps", C.c_int32), ("stride", C.c_int32),
         ("dt", C.c_int32 * MAX_TAPS), ("df", C.c_int32 * MAX_TAPS),
+        ("b_buf", C.c_int32), ("seg_scale_buf", C.c_int32), ("act", C.c_int32),
     ]
 
 

@@ -67,6 +67,12 @@ def _view_args(v):
     return (-1, 0) if v is None else (v.tid, v.ch_off)
 
 
+def gather_fuse_on():
+    """ASV_AMD_NO_GATHER_FUSE=1 keeps the stage-closing elementwise pass of a ResNet and the strided gathers behind it as two passes
+    (A/B switch; the fused form gives the same bits - tests/test_gpu_resnet.py)."""
+    return os.environ.get("ASV_AMD_NO_GATHER_FUSE", "0") in ("0", "", "false")
+
+
 class Engine(object):
     """One compiled model on one device."""
 
@@ -101,6 +107,8 @@ class Engine(object):
         ops = g.fused_res2_ops() if fuse else g.ops
         if (self.flags & (capi.FLAG_REF_KERNELS | capi.FLAG_NO_FUSE)) == 0:
             ops = g.fused_add_ops(ops)               # exact in every precision mode (see its docstring)
+            if gather_fuse_on():
+                ops = g.fused_gather_ops(ops)        # likewise: the stage-closing elementwise pass as the prologue of the strided gathers
         self.ops = ops                               # the program as uploaded (op indices of the profiling rows refer to it)
         written = sorted({op.out.tid for op in ops} | {op.out2.tid for op in ops if getattr(op, "out2", None) is not None})
         for tid in written:
@@ -211,6 +219,9 @@ class Engine(object):
                 d.channels, d.n_taps, d.stride = op.inp.channels, len(op.taps), op.stride
                 for i, (dt, df) in enumerate(op.taps):
                     d.dt[i], d.df[i] = dt, df
+                d.b_buf = bv(getattr(op, "b", None))[0]
+                d.seg_scale_buf = bv(getattr(op, "seg_scale", None))[0]
+                d.act = capi.ACT_BY_NAME[getattr(op, "act", None)]
                 capi.check(L.asv_net_add_im2col(self._net, C.byref(d)), "asv_net_add_im2col")
             else:
                 raise _ir.TraceError("op kind %r survived graph optimisation" % op.kind)

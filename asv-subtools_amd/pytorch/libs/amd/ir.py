@@ -66,7 +66,9 @@ class Op(object):
             names = ("x",)
         elif self.kind == "eltwise":
             names = ("a", "b", "c", "seg_scale", "seg_norm", "d")
-        elif self.kind in ("grid_input", "im2col", "res2"):
+        elif self.kind == "im2col":
+            names = ("inp", "b", "seg_scale")
+        elif self.kind in ("grid_input", "res2"):
             names = ("inp",)
         else:
             return list(self.parts)
@@ -75,7 +77,7 @@ class Op(object):
     def input_names(self):
         return {"tdnn": ("inp", "inp2", "seg_bias", "seg_scale", "res"), "pool": ("inp",),
                 "attpool": ("x", "logits"), "lde": ("x",), "eltwise": ("a", "b", "c", "seg_scale", "seg_norm", "d"), "cat": (), "grid_input": ("inp",),
-                "im2col": ("inp",), "res2": ("inp",)}[self.kind]
+                "im2col": ("inp", "b", "seg_scale"), "res2": ("inp",)}[self.kind]
 
 
 class Graph(object):
@@ -412,6 +414,60 @@ class Graph(object):
                     skip.add(idx + 1)
                     continue
             out.append(op)
+        return out
+
+    def fused_gather_ops(self, ops=None):
+        """The op list with every elementwise pass `o = act(a * seg_scale + b)` that only im2col gathers read folded into those
+        gathers as their prologue: the output of the last block of a ResNet stage (resnet.py:70-85: relu(se(y) + identity)) feeds
+        nothing but the stride-2 convolutions of the next stage (their gather, and the 1x1 downsample's), so the tensor is never
+        needed in its own layout.  One pass less over the widest maps of the stage; the prologue performs the elementwise kernel's
+        operations in its order with its roundings (kernels_pool.hip), so every bit of the gathered tensor stays what the two
+        passes produce."""
+        ops = list(self.ops if ops is None else ops)
+        readers = {}
+        for idx, op in enumerate(ops):
+            for v in op.inputs():
+                readers.setdefault(v.tid, []).append(idx)
+        fold = {}                                            # index of a gather -> the eltwise op folded into it
+        drop = set()
+        for idx, op in enumerate(ops):
+            if op.kind != "eltwise" or op.a is None or op.act not in (None, "relu"):
+                continue
+            if any(getattr(op, n, None) is not None for n in ("c", "scale", "shift", "seg_norm", "d", "out2")):
+                continue
+            if getattr(op, "b", None) is None and getattr(op, "seg_scale", None) is None and op.act is None:
+                continue
+            whole = lambda v: v is None or (v.ch_off == 0 and v.channels == self.tensors[v.tid][1])
+            if not (whole(op.out) and whole(op.a) and whole(getattr(op, "b", None))):
+                continue
+            if self.output is not None and self.output.tid == op.out.tid:
+                continue
+            rd = readers.get(op.out.tid, [])
+            if not rd or any(ops[r].kind != "im2col" or ops[r].inp.tid != op.out.tid or getattr(ops[r], "b", None) is not None
+                             or getattr(ops[r], "seg_scale", None) is not None or getattr(ops[r], "act", None) is not None for r in rd):
+                continue
+            if any(o.out.tid == op.out.tid for j, o in enumerate(ops) if j != idx):      # written in slices by somebody else
+                continue
+            # the operands must still hold their values where the gathers run: nothing between rewrites them (buffers are
+            # written once per pass in this IR, so a later writer of the same tensor id is the only hazard)
+            last = max(rd)
+            srcs = {v.tid for v in op.inputs()}
+            if any(o.out.tid in srcs for o in ops[idx + 1:last + 1]):
+                continue
+            drop.add(idx)
+            for r in rd:
+                fold[r] = op
+        out = []
+        for idx, op in enumerate(ops):
+            if idx in drop:
+                continue
+            if idx in fold:
+                e = fold[idx]
+                g = Op("im2col", op.out, **{k: v for k, v in op.__dict__.items() if k not in ("kind", "out")})
+                g.inp, g.b, g.seg_scale, g.act = e.a, getattr(e, "b", None), getattr(e, "seg_scale", None), e.act
+                out.append(g)
+            else:
+                out.append(op)
         return out
 
     def describe(self):

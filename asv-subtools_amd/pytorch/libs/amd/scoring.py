@@ -180,7 +180,9 @@ def score_normalize(scores, enroll_cohort, test_cohort, enroll_idx, test_idx, to
     ei, ti = _trial_indices(enroll_idx, ec.shape[0], test_idx, tc.shape[0], s.device, "score_normalize")
     assert ei.shape[0] == s.shape[0] == ti.shape[0]
     # two full passes + two blocking read-backs: debug switch only (ASV_AMD_DEBUG_CHECKS=1); cohort scores are dot products of
-    # finite, length-normalised vectors in every caller of this module
+    # finite, length-normalised vectors in every caller of this module.  (Without the check a NaN cohort score is SKIPPED by the
+    # device selection - which is also what the reference's pandas groupby().mean() / .std() / sort_values().head() do with it:
+    # skipna, NaN sorted last.)
     if _debug_checks() and (bool(torch.isnan(ec).any().item()) or bool(torch.isnan(tc).any().item())):
         raise ValueError("score_normalize: NaN in the cohort scores (pandas would propagate it into every statistic; the device "
                          "selection orders keys and would silently skip it)")

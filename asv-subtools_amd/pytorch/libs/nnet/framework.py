@@ -97,14 +97,16 @@ class TopVirtualNnet(torch.nn.Module):
         self._invalidate_engines()              # .cuda() / .cpu() / .to(): recompile for the new device
         return super(TopVirtualNnet, self)._apply(fn, *args, **kwargs)
 
-    def _amd_engine(self, function=None):
-        """Compiles (once per device / precision / body) and returns the libasv_amd engine."""
+    def _amd_engine(self, function=None, replica=0):
+        """Compiles (once per device / precision / body / replica) and returns the libasv_amd engine.  `replica` > 0: further engines
+        of the same program (own activation arena, own HIP stream in the caller's hands): what the extraction script and bench.py
+        rotate consecutive batches over; cached here like the first one, dropped with it by load_state_dict() / .to()."""
         from libs.amd import engine as _engine
         if function is None:
             function = getattr(type(self).extract_embedding, "__wrapped_body__", None)
         precision = getattr(self, "amd_precision", None) or _engine.default_precision()
         p = next(self.parameters())
-        key = (function, str(p.device), precision, _engine.default_flags(), getattr(self, "extracted_embedding", None))
+        key = (function, str(p.device), precision, _engine.default_flags(), _engine.gather_fuse_on(), getattr(self, "extracted_embedding", None), int(replica))
         eng = self._amd_engines.get(key)
         if eng is None:
             eng = _engine.compile_model(self, function=function, precision=precision)

@@ -86,9 +86,8 @@ def extract_stream(model, r, w, batch_frames, batch_utts, max_chunk, verbose=Fal
     engines = [engine] * n_sets
     streams = [torch.cuda.current_stream(dev)] * n_sets
     if os.environ.get("ASV_AMD_PIPELINE_ENGINES", "2") != "1":
-        from libs.amd import engine as _engine
-        engines = [engine] + [_engine.compile_model(model, function=getattr(method, "__wrapped_body__", None), precision=engine.precision, flags=engine.flags)
-                              for _ in range(n_sets - 1)]
+        # (cached on the model like the first engine: a second call of extract_stream compiles nothing - ADVICE r3)
+        engines = [engine] + [model._amd_engine(replica=k) for k in range(1, n_sets)]
         streams = [torch.cuda.Stream(device=dev) for _ in range(n_sets)]
     host_in = [torch.empty((batch_frames, dim), dtype=torch.float32).pin_memory() for _ in range(n_sets)]
     host_np = [t.numpy() for t in host_in]

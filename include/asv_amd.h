@@ -227,11 +227,17 @@ typedef struct asv_grid_input_desc {
 int asv_net_add_grid_input(asv_net_t *net, const asv_grid_input_desc_t *d);
 
 /* im2col gather between grids for strided convolutions (resnet.py stride-2 conv3x3 / conv1x1
- * downsample): out[(t', f')][k*C + c] = in[(stride*t' + dt[k], stride*f' + df[k])][c], zero outside. */
+ * downsample): out[(t', f')][k*C + c] = v[(stride*t' + dt[k], stride*f' + df[k])][c], zero outside, where v = in - or, with the
+ * optional elementwise prologue (round 4), v = act(in * seg_scale[segment] + b) rounded to the buffers' element type: the block
+ * output `relu(y * s + identity)` (resnet.py:70-85) of the block in front of a stride-2 stage is then never written in its own layout
+ * (nothing but the gather reads it): one pass instead of two.  Same arithmetic, same rounding as asv_net_add_eltwise + a plain gather. */
 typedef struct asv_im2col_desc {
   uint32_t struct_size;
   int32_t in_buf, out_buf, channels, n_taps, stride;
   int32_t dt[ASV_MAX_TAPS], df[ASV_MAX_TAPS];
+  int32_t b_buf;                 /* optional addend, a whole buffer of in_buf's grid and width; -1 = none */
+  int32_t seg_scale_buf;         /* optional per-(segment, channel) scale: utts-domain buffer; -1 = none  */
+  int32_t act;                   /* ASV_ACT_NONE | ASV_ACT_RELU, applied last                              */
 } asv_im2col_desc_t;
 int asv_net_add_im2col(asv_net_t *net, const asv_im2col_desc_t *d);
 

@@ -76,6 +76,11 @@ def run_graph(graph, feats, dtype=np.float32, ops=None):
             put(op.out, g)
         elif op.kind == "im2col":
             x = get(op.inp)
+            if getattr(op, "seg_scale", None) is not None:        # the elementwise prologue of Graph.fused_gather_ops
+                x = x * get(op.seg_scale)
+            if getattr(op, "b", None) is not None:
+                x = x + get(op.b)
+            x = _act(x, getattr(op, "act", None)).astype(dtype)
             fi, wi, pi = grid_dims(op.inp.tid)
             fo, wo, po = grid_dims(op.out.tid)
             C = op.inp.channels

@@ -138,6 +138,28 @@ def test_ecapa_late_fusion_passes_preserve_the_program(name):
     assert rel_err(ir_interp.extract(graph, x, ops=fused), plain) < 1e-6
 
 
+@pytest.mark.parametrize("name", ["resnet34se_c5", "resnet34_plain", "resnet34_preact", "resnet_bottleneck_se"])
+def test_resnet_gather_fusion_pass_preserves_the_program(name):
+    """Graph.fused_gather_ops: the elementwise pass that closes a ResNet stage (relu(se(y) + identity)) becomes the prologue of the
+    stride-2 gathers that are its only readers.  A rewrite of the op list only: same operations in the same order, so the
+    interpreted embedding is the unfused one bit for bit; every folded pass disappears from the list."""
+    from libs.amd import ir
+    g, sd, model = helpers.golden_model(name)
+    graph = ir.trace(model, type(model).extract_embedding.__wrapped_body__, int(g["dim"]))
+    fused = graph.fused_gather_ops()
+    folded = [op for op in fused if op.kind == "im2col" and (getattr(op, "b", None) is not None or getattr(op, "act", None) is not None)]
+    assert len(fused) < len(graph.ops) or not folded
+    if name == "resnet34se_c5":
+        assert len(graph.ops) - len(fused) == 3 and len(folded) == 4           # three stage transitions; the last one feeds two gathers
+        assert all(op.seg_scale is not None and op.b is not None and op.act == "relu" for op in folded)
+    written = {op.out.tid for op in fused}
+    for op in fused:
+        for v in op.inputs():
+            assert v.tid == 0 or v.tid in written, "an input of %s lost its producer" % op.kind
+    x = helpers.golden_feats(g)[0]
+    assert np.array_equal(ir_interp.extract(graph, x, ops=fused), ir_interp.extract(graph, x))
+
+
 @pytest.mark.parametrize("name,idx", [("resnet34se_c5", 2), ("resnet34se_c5", 3), ("resnet34_plain", 1), ("resnet34_cmvn", 1), ("resnet34_preact", 2),
                                       ("resnet34se_preact", 1), ("resnet_bottleneck_se", 0), ("resnet_bottleneck_se", 1), ("resnet_bottleneck_preact", 0)])
 def test_resnet_traced_program_reproduces_reference_on_cpu(name, idx):

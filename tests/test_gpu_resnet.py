@@ -66,3 +66,24 @@ def test_resnet_preactivation_bf16_is_close():
     ref = g["embeddings"]
     cos = (got * ref).sum(1) / np.linalg.norm(got, axis=1) / np.linalg.norm(ref, axis=1)
     assert cos.min() > 0.998, cos
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f32x", "f32"])
+def test_gather_with_elementwise_prologue_changes_no_bit(precision, monkeypatch):
+    """Round 4: the pass that closes a ResNet stage - relu(y * se + identity), resnet.py:70-85 - is folded into the stride-2 gathers
+    that are its only readers (Graph.fused_gather_ops -> asv_im2col_desc_t.b_buf / seg_scale_buf / act).  The prologue repeats the
+    elementwise kernel's operations and roundings, so with ASV_AMD_NO_GATHER_FUSE=1 (two passes) every bit of the embeddings is the
+    same, in every precision mode; ragged batch, SE and plain blocks."""
+    from libs.amd import synth
+    for name in ("resnet34se_c5", "resnet34_plain"):
+        g, sd, model = helpers.golden_model(name)
+        model.cuda()
+        model.amd_precision = precision
+        mats = [synth.synth_feats(T, int(g["dim"]), 4100 + i) for i, T in enumerate([200, 333, 517, 201])]
+        monkeypatch.delenv("ASV_AMD_NO_GATHER_FUSE", raising=False)
+        fused = model.extract_embedding_batch(mats).numpy()
+        n_fused = len(model._amd_engine().ops)
+        monkeypatch.setenv("ASV_AMD_NO_GATHER_FUSE", "1")
+        two = model.extract_embedding_batch(mats).numpy()
+        assert len(model._amd_engine().ops) > n_fused or name == "resnet34_plain"
+        assert np.isfinite(fused).all() and np.array_equal(fused, two), (name, precision, float(np.abs(fused - two).max()))
