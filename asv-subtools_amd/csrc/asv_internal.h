@@ -278,6 +278,9 @@ struct Im2colParams {
   const void *b; int ldb; const float *seg_scale; int ld_segscale; int act;
 };
 int launch_im2col(const Im2colParams &p, int et, hipStream_t s);
+// [rows (t', f)][C] on a grid -> [rows t'][c*F + f] on the sequence domain of the same time shift
+int launch_grid_flatten(const void *in, int ldi, int channels, int width, int in_pitch, const int32_t *in_row0, const int32_t *out_row0,
+                        const int32_t *out_row_seg, const uint32_t *out_row_valid, int out_rows, void *out, int ldo, int et, hipStream_t s);
 int launch_pack_input(const float *feats, int feat_dim, const int32_t *seg_src0, const int32_t *seg_row0,
                       const int32_t *row_seg, int rows, void *x, int ldx, int et, hipStream_t s);
 int launch_unpack_rows(const void *y, int ldy, int channels, const int32_t *seg_src0, const int32_t *seg_row0,

@@ -748,7 +748,50 @@ __global__ __launch_bounds__(256) void im2col_kernel(const Im2colParams p) {
   else *reinterpret_cast<uint4 *>(reinterpret_cast<float *>(p.out) + dst) = v;
 }
 
+// ResNetXvector's [B, C, F', T'] -> [B, C*F', T'] reshape for the frame-weighting poolings: one thread per (output row, 16-byte
+// piece) gathers its 8 (4) elements c*F + f from the F consecutive grid rows of the frame - a [F][C] block of a few KiB that the
+// other threads of the row read too (L1 / L2 hits).  Once per batch on the smallest map of the trunk: not a hot kernel.
+template <int ET>
+__global__ __launch_bounds__(256) void grid_flatten_kernel(const void *in, int ldi, int channels, int width, int in_pitch, const int32_t *in_row0,
+                                                           const int32_t *out_row0, const int32_t *out_row_seg, const uint32_t *out_row_valid,
+                                                           int out_rows, void *out, int ldo) {
+  constexpr int VEC = (ET != ET_F32) ? 8 : 4;
+  const int pieces = ldo / VEC;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long long)out_rows * pieces) return;
+  const int row = (int)(gid / pieces), j0 = (int)(gid % pieces) * VEC;
+  float v[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) v[i] = 0.0f;
+  if ((out_row_valid[row >> 5] >> (row & 31)) & 1u) {
+    const int seg = out_row_seg[row];
+    const size_t base = (size_t)(in_row0[seg] + (row - out_row0[seg]) * in_pitch);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const int j = j0 + i;
+      if (j < channels * width) v[i] = load_elem<ET>(in, (base + j % width) * ldi + j / width);
+    }
+  }
+  if constexpr (ET != ET_F32) {
+    *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(out) + (size_t)row * ldo + j0) = pack_h16x8<ET>(v);
+  } else {
+    *reinterpret_cast<float4 *>(reinterpret_cast<float *>(out) + (size_t)row * ldo + j0) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
 }  // namespace
+
+int launch_grid_flatten(const void *in, int ldi, int channels, int width, int in_pitch, const int32_t *in_row0, const int32_t *out_row0,
+                        const int32_t *out_row_seg, const uint32_t *out_row_valid, int out_rows, void *out, int ldo, int et, hipStream_t s) {
+  const int vec = et != ET_F32 ? 8 : 4;
+  const long long n = (long long)out_rows * (ldo / vec);
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (et == ET_BF16) hipLaunchKernelGGL(grid_flatten_kernel<ET_BF16>, grid, block, 0, s, in, ldi, channels, width, in_pitch, in_row0, out_row0, out_row_seg, out_row_valid, out_rows, out, ldo);
+  else if (et == ET_F16) hipLaunchKernelGGL(grid_flatten_kernel<ET_F16>, grid, block, 0, s, in, ldi, channels, width, in_pitch, in_row0, out_row0, out_row_seg, out_row_valid, out_rows, out, ldo);
+  else hipLaunchKernelGGL(grid_flatten_kernel<ET_F32>, grid, block, 0, s, in, ldi, channels, width, in_pitch, in_row0, out_row0, out_row_seg, out_row_valid, out_rows, out, ldo);
+  ASV_HIP_CHECK(hipGetLastError());
+  return ASV_OK;
+}
 
 int launch_grid_from_frames(const void *x, int ldx, int feat_dim, const int32_t *fr_row0, const int32_t *g_row0, const int32_t *g_row_seg,
                             const uint32_t *g_row_valid, int g_rows, int pitch, void *out, int ldo, int et, hipStream_t s) {

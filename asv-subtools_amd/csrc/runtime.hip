@@ -106,7 +106,7 @@ struct Domain {
   int gap() const { return kind == ASV_DOMAIN_FRAMES ? kHalo : pitch + 2; }
 };
 
-enum OpKind { OP_TDNN = 0, OP_POOL = 1, OP_ATTPOOL = 2, OP_ELTWISE = 3, OP_GRID_INPUT = 4, OP_IM2COL = 5, OP_LDE = 6, OP_RES2 = 7 };
+enum OpKind { OP_TDNN = 0, OP_POOL = 1, OP_ATTPOOL = 2, OP_ELTWISE = 3, OP_GRID_INPUT = 4, OP_IM2COL = 5, OP_LDE = 6, OP_RES2 = 7, OP_FLATTEN = 8 };
 
 struct Op {
   OpKind kind;
@@ -117,6 +117,7 @@ struct Op {
   asv_eltwise_desc_t elt;
   asv_grid_input_desc_t gin;
   asv_im2col_desc_t i2c;
+  asv_grid_flatten_desc_t flat;
   asv_lde_desc_t lde;            // mu / beta live in `scale` / `shift` on the device
   asv_res2_desc_t res2;          // fragments in `wfrag`, per-branch constants in bias / scale / shift
   // device parameters
@@ -196,6 +197,8 @@ struct asv_net {
   int x3_terms() const { return 1 | ((flags & ASV_FLAG_X3_NO_XLO) ? 0 : 2) | ((flags & ASV_FLAG_X3_NO_WLO) ? 0 : 4); }
   bool x3() const { return precision == ASV_PREC_F32X; }        // f32 storage, split-bf16 matrix products
   bool is_utts(int domain) const { return domains[domain].kind == ASV_DOMAIN_UTTS; }
+  // one row per frame: the frames domain, or a width-1 / pitch-1 grid (the 2-D trunk's output flattened, asv_net_add_grid_flatten)
+  bool is_sequence(int domain) const { return domains[domain].kind == ASV_DOMAIN_FRAMES || (domains[domain].kind == 2 && domains[domain].width == 1 && domains[domain].pitch == 1); }
   int dom_et(int domain) const { return is_utts(domain) ? ET_F32 : frames_et(); }                    // element type of a domain's rows
   size_t elem_size(int domain) const { return dom_et(domain) != ET_F32 ? 2 : 4; }
 };
@@ -421,7 +424,8 @@ void asv_net_destroy(asv_net_t *net) {
 int asv_net_define_grid(asv_net_t *net, int time_shift, int width, int pitch) {
   ASV_REQUIRE(net && !net->finalized, "asv_net_define_grid: net is null or finalized");
   ASV_REQUIRE(time_shift >= 0 && time_shift <= 8, "asv_net_define_grid: time_shift %d", time_shift);
-  ASV_REQUIRE(width >= 1 && pitch >= width + 1 && pitch + 1 <= 84, "asv_net_define_grid: need 1 <= width < pitch <= 83 (got %d, %d)", width, pitch);
+  // (width 1, pitch 1: a sequence at the grid's frame rate - no frequency neighbours, so no zero column between frames; asv_net_add_grid_flatten)
+  ASV_REQUIRE(width >= 1 && (pitch >= width + 1 || (width == 1 && pitch == 1)) && pitch + 1 <= 84, "asv_net_define_grid: need 1 <= width < pitch <= 83, or width = pitch = 1 (got %d, %d)", width, pitch);
   Domain d{2};
   d.shift = time_shift; d.width = width; d.pitch = pitch;
   net->domains.push_back(d);
@@ -621,8 +625,8 @@ int asv_net_add_attentive_pool(asv_net_t *net, const asv_attpool_desc_t *d) {
   } else if ((rc = check_view(net, d->logit_buf, d->logit_ch_off, d->channels, "attentive pool logits"))) return rc;
   ASV_REQUIRE(d->out_buf > 0 && d->out_buf < (int)net->bufs.size(), "attentive pool: output buffer id %d", d->out_buf);
   ASV_REQUIRE(d->out_ch_off >= 0 && d->out_ch_off + 2 * d->channels <= net->bufs[d->out_buf].channels, "attentive pool: output view exceeds buffer");
-  ASV_REQUIRE(net->bufs[d->x_buf].domain == ASV_DOMAIN_FRAMES && net->bufs[d->logit_buf].domain == ASV_DOMAIN_FRAMES &&
-              net->is_utts(net->bufs[d->out_buf].domain), "attentive pool: frames -> utts");
+  ASV_REQUIRE(net->is_sequence(net->bufs[d->x_buf].domain) && net->bufs[d->logit_buf].domain == net->bufs[d->x_buf].domain &&
+              net->is_utts(net->bufs[d->out_buf].domain), "attentive pool: frames (or a sequence domain) -> utts");
   ASV_REQUIRE((d->prior_logit == nullptr) == (d->prior_value == nullptr), "attentive pool: prior logits and values come together");
   ASV_REQUIRE(!(d->logit_softplus2 || d->prior_logit) || group == 1, "attentive pool: the xi-vector options need per-channel logits");
   Op op; op.kind = OP_ATTPOOL; op.att = *d;
@@ -644,7 +648,7 @@ int asv_net_add_lde_pool(asv_net_t *net, const asv_lde_desc_t *d) {
   if ((rc = check_view(net, d->x_buf, d->x_ch_off, d->channels, "lde pool x"))) return rc;
   ASV_REQUIRE(d->out_buf > 0 && d->out_buf < (int)net->bufs.size(), "lde pool: output buffer id %d", d->out_buf);
   ASV_REQUIRE(d->out_ch_off >= 0 && d->out_ch_off + d->channels * d->n_centres <= net->bufs[d->out_buf].channels, "lde pool: output view exceeds buffer");
-  ASV_REQUIRE(net->bufs[d->x_buf].domain == ASV_DOMAIN_FRAMES && net->is_utts(net->bufs[d->out_buf].domain), "lde pool: frames -> utts");
+  ASV_REQUIRE(net->is_sequence(net->bufs[d->x_buf].domain) && net->is_utts(net->bufs[d->out_buf].domain), "lde pool: frames (or a sequence domain) -> utts");
   Op op; op.kind = OP_LDE; op.lde = *d;
   ASV_ON_DEVICE(net->device);
   const int n = d->channels * d->n_centres;
@@ -765,6 +769,21 @@ int asv_net_add_im2col(asv_net_t *net, const asv_im2col_desc_t *d) {
   return ASV_OK;
 }
 
+int asv_net_add_grid_flatten(asv_net_t *net, const asv_grid_flatten_desc_t *d) {
+  ASV_REQUIRE(net && d && !net->finalized, "asv_net_add_grid_flatten: net is null or finalized");
+  ASV_REQUIRE(d->struct_size == sizeof(asv_grid_flatten_desc_t), "asv_net_add_grid_flatten: struct_size mismatch");
+  ASV_REQUIRE(d->in_buf > 0 && d->in_buf < (int)net->bufs.size() && d->out_buf > 0 && d->out_buf < (int)net->bufs.size() && d->in_buf != d->out_buf,
+              "grid_flatten: buffer ids %d -> %d", d->in_buf, d->out_buf);
+  const Domain &di = net->domains[net->bufs[d->in_buf].domain], &dq = net->domains[net->bufs[d->out_buf].domain];
+  ASV_REQUIRE(di.kind == 2 && dq.kind == 2 && dq.width == 1 && dq.pitch == 1 && dq.shift == di.shift,
+              "grid_flatten: the output must live on the sequence domain (width 1, pitch 1) of the input grid's time shift");
+  ASV_REQUIRE(net->bufs[d->out_buf].channels == net->bufs[d->in_buf].channels * di.width, "grid_flatten: %d channels x %d bins do not give %d output channels",
+              net->bufs[d->in_buf].channels, di.width, net->bufs[d->out_buf].channels);
+  Op op; op.kind = OP_FLATTEN; op.flat = *d;
+  net->ops.push_back(op);
+  return ASV_OK;
+}
+
 int asv_net_finalize(asv_net_t *net, int out_buf, int embed_dim) {
   ASV_REQUIRE(net && !net->finalized, "asv_net_finalize: net is null or already finalized");
   ASV_REQUIRE(out_buf > 0 && out_buf < (int)net->bufs.size() && net->is_utts(net->bufs[out_buf].domain),
@@ -789,7 +808,7 @@ int asv_net_finalize(asv_net_t *net, int out_buf, int embed_dim) {
                              o.kind == OP_POOL ? o.pool.in_buf : -1, o.kind == OP_ATTPOOL ? o.att.x_buf : -1, o.kind == OP_ATTPOOL ? o.att.logit_buf : -1,
                              o.kind == OP_ELTWISE ? o.elt.a_buf : -1, o.kind == OP_ELTWISE ? o.elt.b_buf : -1, o.kind == OP_ELTWISE ? o.elt.c_buf : -1,
                              o.kind == OP_ELTWISE ? o.elt.d_buf : -1,
-                             o.kind == OP_IM2COL ? o.i2c.in_buf : -1, o.kind == OP_IM2COL ? o.i2c.b_buf : -1, o.kind == OP_LDE ? o.lde.x_buf : -1, o.kind == OP_RES2 ? o.res2.in_buf : -1};
+                             o.kind == OP_IM2COL ? o.i2c.in_buf : -1, o.kind == OP_IM2COL ? o.i2c.b_buf : -1, o.kind == OP_LDE ? o.lde.x_buf : -1, o.kind == OP_RES2 ? o.res2.in_buf : -1, o.kind == OP_FLATTEN ? o.flat.in_buf : -1};
         for (int rbuf : reads) other_reader |= (rbuf == d.out_buf);
       }
       if (other_reader || d.out_buf == out_buf) continue;
@@ -820,7 +839,7 @@ int asv_net_finalize(asv_net_t *net, int out_buf, int embed_dim) {
                              o.kind == OP_ELTWISE ? o.elt.a_buf : -1, o.kind == OP_ELTWISE ? o.elt.b_buf : -1, o.kind == OP_ELTWISE ? o.elt.c_buf : -1,
                              o.kind == OP_ELTWISE ? o.elt.seg_scale_buf : -1, o.kind == OP_ELTWISE ? o.elt.seg_norm_buf : -1, o.kind == OP_ELTWISE ? o.elt.d_buf : -1,
                              o.kind == OP_IM2COL ? o.i2c.in_buf : -1, o.kind == OP_IM2COL ? o.i2c.b_buf : -1, o.kind == OP_IM2COL ? o.i2c.seg_scale_buf : -1, o.kind == OP_LDE ? o.lde.x_buf : -1, o.kind == OP_GRID_INPUT ? o.gin.in_buf : -1,
-                             o.kind == OP_RES2 ? o.res2.in_buf : -1};
+                             o.kind == OP_RES2 ? o.res2.in_buf : -1, o.kind == OP_FLATTEN ? o.flat.in_buf : -1};
         for (int rbuf : reads) if (rbuf == buf) return false;
       }
       return true;
@@ -957,6 +976,9 @@ int asv_net_describe(const asv_net_t *net, char *buf, size_t cap) {
         break;
       case OP_GRID_INPUT:
         snprintf(line, sizeof(line), "  op %zu: grid_input %d -> %d\n", i, op.gin.in_buf, op.gin.out_buf);
+        break;
+      case OP_FLATTEN:
+        snprintf(line, sizeof(line), "  op %zu: grid_flatten %d -> %d\n", i, op.flat.in_buf, op.flat.out_buf);
         break;
       case OP_IM2COL:
         snprintf(line, sizeof(line), "  op %zu: im2col %d -> %d taps=%d stride=%d channels=%d\n", i, op.i2c.in_buf, op.i2c.out_buf, op.i2c.n_taps, op.i2c.stride, op.i2c.channels);
@@ -1413,7 +1435,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
       }
       case OP_ATTPOOL: {
         const auto &d = op.att;
-        const DomainRun &dr = c.dom[ASV_DOMAIN_FRAMES];
+        const DomainRun &dr = c.dom[net->bufs[d.x_buf].domain];          // the frames domain, or a sequence domain behind the 2-D trunk
         if ((rc = prof.begin(K_ATT, 0, (int)i))) return rc;
         const int group = d.logit_group > 1 ? d.logit_group : (d.shared_logits ? d.channels : 1);
         rc = launch_attentive_pool(view(c, d.x_buf, d.x_ch_off), net->bufs[d.x_buf].ld, view(c, d.logit_buf, d.logit_ch_off), net->bufs[d.logit_buf].ld,
@@ -1425,7 +1447,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
       }
       case OP_LDE: {
         const auto &d = op.lde;
-        const DomainRun &dr = c.dom[ASV_DOMAIN_FRAMES];
+        const DomainRun &dr = c.dom[net->bufs[d.x_buf].domain];
         if ((rc = ensure(net->lde_dev, (size_t)dr.rows_pad * 64 * 4, c.s, false))) return rc;
         if ((rc = prof.begin(K_ATT, 0, (int)i))) return rc;
         rc = launch_lde_pool(view(c, d.x_buf, d.x_ch_off), net->bufs[d.x_buf].ld, d.channels, dr.rows_pad, op.scale, op.shift, d.n_centres,
@@ -1505,6 +1527,17 @@ int run_ops(RunCtx &c, size_t n_ops) {
         if ((rc = prof.begin(K_GATHER, 0, (int)i))) return rc;
         rc = launch_grid_from_frames(net->arena[op.gin.in_buf].ptr, net->bufs[op.gin.in_buf].ld, net->feat_dim, c.dom[ASV_DOMAIN_FRAMES].seg_row0, dg.seg_row0, dg.row_seg, dg.row_valid,
                                      dg.rows_pad, net->domains[domid].pitch, net->arena[op.gin.out_buf].ptr, net->bufs[op.gin.out_buf].ld, net->frames_et(), c.s);
+        if (rc) return rc;
+        if ((rc = prof.end())) return rc;
+        break;
+      }
+      case OP_FLATTEN: {
+        const auto &d = op.flat;
+        const int din = net->bufs[d.in_buf].domain, dout = net->bufs[d.out_buf].domain;
+        if ((rc = prof.begin(K_GATHER, 0, (int)i))) return rc;
+        rc = launch_grid_flatten(net->arena[d.in_buf].ptr, net->bufs[d.in_buf].ld, net->bufs[d.in_buf].channels, net->domains[din].width, net->domains[din].pitch,
+                                 c.dom[din].seg_row0, c.dom[dout].seg_row0, c.dom[dout].row_seg, c.dom[dout].row_valid, c.dom[dout].rows_pad,
+                                 net->arena[d.out_buf].ptr, net->bufs[d.out_buf].ld, net->frames_et(), c.s);
         if (rc) return rc;
         if ((rc = prof.end())) return rc;
         break;

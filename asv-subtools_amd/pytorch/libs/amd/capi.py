@@ -111,6 +111,10 @@ class GridInputDesc(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("out_buf", C.c_int32), ("in_buf", C.c_int32)]
 
 
+class GridFlattenDesc(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("in_buf", C.c_int32), ("out_buf", C.c_int32)]
+
+
 class Im2colDesc(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32),
@@ -150,7 +154,7 @@ _LIB = None
 SYMBOLS = [
     "asv_version", "asv_last_error", "asv_device_count",
     "asv_net_create", "asv_net_destroy", "asv_net_define_grid", "asv_net_new_buffer", "asv_net_add_tdnn",
-    "asv_net_add_grid_input", "asv_net_add_im2col",
+    "asv_net_add_grid_input", "asv_net_add_im2col", "asv_net_add_grid_flatten",
     "asv_net_add_stats_pool", "asv_net_add_attentive_pool", "asv_net_add_lde_pool", "asv_net_add_eltwise", "asv_net_add_res2",
     "asv_net_finalize", "asv_net_embed_dim", "asv_net_describe", "asv_net_extract",
     "asv_net_device_bytes", "asv_net_set_profiling", "asv_net_get_profile", "asv_net_status",
@@ -194,6 +198,7 @@ def lib():
     L.asv_net_define_grid.argtypes = [vp, ci, ci, ci]
     L.asv_net_add_grid_input.argtypes = [vp, C.POINTER(GridInputDesc)]
     L.asv_net_add_im2col.argtypes = [vp, C.POINTER(Im2colDesc)]
+    L.asv_net_add_grid_flatten.argtypes = [vp, C.POINTER(GridFlattenDesc)]
     L.asv_net_add_tdnn.argtypes = [vp, C.POINTER(TdnnDesc)]
     L.asv_net_add_stats_pool.argtypes = [vp, C.POINTER(PoolDesc)]
     L.asv_net_add_attentive_pool.argtypes = [vp, C.POINTER(AttPoolDesc)]

@@ -101,6 +101,8 @@ class Engine(object):
         for i, spec in enumerate(g.domains):
             if spec[0] == "grid":
                 dom_of[i] = capi.check(L.asv_net_define_grid(self._net, spec[1], spec[2], spec[3]), "asv_net_define_grid")
+            elif spec[0] == "seq":                   # one row per frame at the grid's rate = a grid of width 1, pitch 1
+                dom_of[i] = capi.check(L.asv_net_define_grid(self._net, spec[1], 1, 1), "asv_net_define_grid")
         # one device buffer per IR tensor that something writes as a whole or in slices
         # 16-bit engines run every Res2NetBlock as one kernel (kernels_res2.hip); the parity modes keep one layer per branch
         fuse = self.precision_base in H16_MODES and (self.flags & (capi.FLAG_REF_KERNELS | capi.FLAG_NO_FUSE | capi.FLAG_SMALL_TILES)) == 0
@@ -212,6 +214,11 @@ class Engine(object):
                 d.out_buf = buf_of[op.out.tid]
                 d.in_buf = buf_of[op.inp.tid]
                 capi.check(L.asv_net_add_grid_input(self._net, C.byref(d)), "asv_net_add_grid_input")
+            elif op.kind == "flatten":
+                d = capi.GridFlattenDesc()
+                d.struct_size = C.sizeof(capi.GridFlattenDesc)
+                d.in_buf, d.out_buf = buf_of[op.inp.tid], buf_of[op.out.tid]
+                capi.check(L.asv_net_add_grid_flatten(self._net, C.byref(d)), "asv_net_add_grid_flatten")
             elif op.kind == "im2col":
                 d = capi.Im2colDesc()
                 d.struct_size = C.sizeof(capi.Im2colDesc)

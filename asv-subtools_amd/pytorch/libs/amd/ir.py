@@ -68,7 +68,7 @@ class Op(object):
             names = ("a", "b", "c", "seg_scale", "seg_norm", "d")
         elif self.kind == "im2col":
             names = ("inp", "b", "seg_scale")
-        elif self.kind in ("grid_input", "res2"):
+        elif self.kind in ("grid_input", "res2", "flatten"):
             names = ("inp",)
         else:
             return list(self.parts)
@@ -77,7 +77,7 @@ class Op(object):
     def input_names(self):
         return {"tdnn": ("inp", "inp2", "seg_bias", "seg_scale", "res"), "pool": ("inp",),
                 "attpool": ("x", "logits"), "lde": ("x",), "eltwise": ("a", "b", "c", "seg_scale", "seg_norm", "d"), "cat": (), "grid_input": ("inp",),
-                "im2col": ("inp", "b", "seg_scale"), "res2": ("inp",)}[self.kind]
+                "im2col": ("inp", "b", "seg_scale"), "res2": ("inp",), "flatten": ("inp",)}[self.kind]
 
 
 class Graph(object):
@@ -85,7 +85,8 @@ class Graph(object):
         self.tensors = []          # [(domain, channels)]
         self.ops = []
         self.feat_dim = int(feat_dim)
-        # row domains: 0 frames, 1 utts, >= 2 (time, frequency) grids ("grid", time_shift, width, pitch)
+        # row domains: 0 frames, 1 utts, >= 2 (time, frequency) grids ("grid", time_shift, width, pitch) and the sequences
+        # ("seq", time_shift) their flattened [B, C*F, T'] views live on (one row per frame of the subsampled time axis)
         self.domains = [("frames",), ("utts",)]
         self.new_tensor(DOMAIN_FRAMES, feat_dim)        # tensor 0 = input features
         self.output = None                                # View (utts domain)
@@ -108,6 +109,16 @@ class Graph(object):
             self.domains.append(spec)
         return self.domains.index(spec)
 
+    def seq_domain(self, shift):
+        spec = ("seq", int(shift))
+        if spec not in self.domains:
+            self.domains.append(spec)
+        return self.domains.index(spec)
+
+    def seq_spec(self, tid):
+        d = self.domains[self.domain(tid)]
+        return d if d[0] == "seq" else None
+
     def is_utts(self, tid):
         return self.domains[self.domain(tid)][0] == "utts"
 
@@ -122,7 +133,7 @@ class Graph(object):
         assert weight.ndim == 3 and weight.shape[1] == inp.channels, (weight.shape, inp)
         taps = [int(t) for t in taps]
         dom = self.domain(inp.tid)
-        halo = MAX_HALO if dom == DOMAIN_FRAMES else (self.domains[dom][3] + 1 if self.domains[dom][0] == "grid" else 0)
+        halo = MAX_HALO if dom == DOMAIN_FRAMES else (self.domains[dom][3] + 1 if self.domains[dom][0] == "grid" else (2 if self.domains[dom][0] == "seq" else 0))
         if max(abs(t) for t in taps) > halo and dom != DOMAIN_UTTS:
             raise TraceError("TDNN context %s reaches beyond the +-%d row halo of the MI355X row layout" % (taps, halo))
         if dom == DOMAIN_UTTS and taps != [0]:
@@ -160,6 +171,15 @@ class Graph(object):
         dom = self.grid_domain(g[1] + (1 if stride == 2 else 0), (g[2] + stride - 1) // stride)
         out = self.full_view(self.new_tensor(dom, inp.channels * len(taps)))
         self.ops.append(Op("im2col", out, inp=inp, taps=[(int(a), int(b)) for a, b in taps], stride=int(stride)))
+        return out
+
+    def flatten_grid(self, inp):
+        """[B, C, F', T'] -> [B, C*F', T'] with the reference's channel index c*F' + f (resnet_xvector.py:193), as a tensor on the
+        sequence domain of the grid's time shift: what the frame-weighting poolings and frame-level layers behind the 2-D trunk read."""
+        g = self.grid_spec(inp.tid)
+        assert g is not None and inp.ch_off == 0 and inp.channels == self.tensors[inp.tid][1]
+        out = self.full_view(self.new_tensor(self.seq_domain(g[1]), inp.channels * g[2]))
+        self.ops.append(Op("flatten", out, inp=inp))
         return out
 
     def attpool(self, x, logits, eps=1e-5, shared=False, group=0, softplus2=False, prior_logit=None, prior_value=None):
@@ -485,6 +505,8 @@ class Graph(object):
                 ins, extra = repr(op.inp), ""
             elif op.kind == "im2col":
                 ins, extra = repr(op.inp), "taps=%d stride=%d" % (len(op.taps), op.stride)
+            elif op.kind == "flatten":
+                ins, extra = repr(op.inp), ""
             elif op.kind == "attpool":
                 ins, extra = "x=%r logits=%r" % (op.x, op.logits), "eps=%g" % op.eps
             elif op.kind == "lde":
@@ -510,6 +532,8 @@ class Graph(object):
                 per_frame += f
             elif g is not None:
                 per_frame += f * g[2] / float(1 << g[1])       # width positions per frame, every 2^shift-th frame
+            elif self.seq_spec(op.inp.tid) is not None:
+                per_frame += f / float(1 << self.seq_spec(op.inp.tid)[1])
             else:
                 per_utt += f
         return per_frame, per_utt
@@ -526,6 +550,14 @@ class Sym(object):
     def __init__(self, graph, view, rank=3, flat_grid=False, col_order=None):
         self.graph, self.view, self.rank = graph, view, rank
         self.flat_grid, self.col_order = flat_grid, col_order
+
+    def as_sequence(self):
+        """self, or - for the [1, C*F, T] reshape of a grid tensor - the materialised [T'][c*F + f] tensor (once per Sym)."""
+        if not self.flat_grid:
+            return self
+        if getattr(self, "_flat", None) is None:
+            self._flat = Sym(self.graph, self.graph.flatten_grid(self.view), 3)
+        return self._flat
 
     # -- what blueprint code inspects
     @property

@@ -70,6 +70,7 @@ class TdnnAffine(torch.nn.Module):
         heads of pooling.py:279-296) becomes the block-diagonal dense matrix it is; `row_scale` multiplies output rows
         (weights and bias) by constants."""
         self._check_supported()
+        x = x.as_sequence()                    # behind the 2-D trunk: the [B, C*F', T'] reshape, materialised once
         order = getattr(x, "col_order", None)
         have = x.view.channels if order is None else int((order >= 0).sum())
         if have != self.input_dim:

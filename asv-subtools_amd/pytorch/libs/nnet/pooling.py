@@ -136,10 +136,14 @@ class AttentionAlphaComponent(torch.nn.Module):
 
 
 def _attentive_stats(inputs, want_dim, what):
+    """The traced input of a frame-weighting pooling.  Behind the 2-D trunk (ResNetXvector, resnet_xvector.py:104-111,193) it is
+    the [B, C*F', T'] reshape of a grid tensor: materialised here in the reference's channel order (Graph.flatten_grid)."""
     if not isinstance(inputs, _ir.Sym):
         raise NotImplementedError("%s.forward() on a torch tensor: eager forward is not part of asv-subtools_amd" % what)
+    inputs = inputs.as_sequence()
     if inputs.view.channels != want_dim:
         raise _ir.TraceError("%s expects %d channels, got %d" % (what, want_dim, inputs.view.channels))
+    return inputs
 
 
 class AttentiveStatisticsPooling(torch.nn.Module):
@@ -156,7 +160,7 @@ class AttentiveStatisticsPooling(torch.nn.Module):
         self.attention = AttentionAlphaComponent(input_dim, num_head=1, share=True, affine_layers=affine_layers, hidden_size=hidden_size, context=context)
 
     def forward(self, inputs):
-        _attentive_stats(inputs, self.input_dim, "AttentiveStatisticsPooling")
+        inputs = _attentive_stats(inputs, self.input_dim, "AttentiveStatisticsPooling")
         g = inputs.graph
         logits = self.attention.logits(inputs)
         both = g.attpool(inputs.view, logits.view, eps=self.eps, shared=True)        # [mean(C) | std(C)]
@@ -186,7 +190,7 @@ class MultiHeadAttentionPooling(torch.nn.Module):
                                                  affine_layers=affine_layers, bias=False, **options)
 
     def forward(self, inputs):
-        _attentive_stats(inputs, self.input_dim, "MultiHeadAttentionPooling")
+        inputs = _attentive_stats(inputs, self.input_dim, "MultiHeadAttentionPooling")
         g = inputs.graph
         logits = self.attention.logits(inputs)
         if self.share and self.num_head > 1:
@@ -227,7 +231,7 @@ class GlobalMultiHeadAttentionPooling(torch.nn.Module):
 
     def forward(self, inputs):
         import numpy as np
-        _attentive_stats(inputs, self.input_dim, type(self).__name__)
+        inputs = _attentive_stats(inputs, self.input_dim, type(self).__name__)
         g = inputs.graph
         C, H = self.input_dim, self.num_head
         per_head = 1 if self.share else C
@@ -278,7 +282,7 @@ class xivec_stdinit_softplus2_prec_pooling(torch.nn.Module):
         self.softplus2 = torch.nn.Softplus(beta=1, threshold=20)
 
     def forward(self, inputs):
-        _attentive_stats(inputs, self.input_dim, "xivec_stdinit_softplus2_prec_pooling")
+        inputs = _attentive_stats(inputs, self.input_dim, "xivec_stdinit_softplus2_prec_pooling")
         g = inputs.graph
         prec = self.lin2(self.lin1_relu_bn(inputs))
         both = g.attpool(inputs.view, prec.view, eps=1.0e-10, softplus2=True,
@@ -303,7 +307,7 @@ class LDEPooling(torch.nn.Module):
         self.softmax_for_w = torch.nn.Softmax(dim=3)
 
     def forward(self, inputs):
-        _attentive_stats(inputs, self.input_dim, "LDEPooling")
+        inputs = _attentive_stats(inputs, self.input_dim, "LDEPooling")
         s = self.s.detach().cpu().numpy().astype("float32")
         out = inputs.graph.lde(inputs.view, self.mu.detach().cpu().numpy(), s * s + self.eps)
         return _ir.Sym(inputs.graph, out, 3)

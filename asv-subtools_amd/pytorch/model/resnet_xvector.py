@@ -3,8 +3,9 @@
 
 Public surface of the reference blueprint (/root/reference/pytorch/model/resnet_xvector.py:15-208):
 class name, `init` arguments, sub-module names (state_dict keys `resnet.*`, `fc1.*`, `fc2.*`) and the
-`extract_embedding` positions.  Statistics pooling only (the other pooling options of the reference
-raise), `cmvn=False` only.
+`extract_embedding` positions, with every pooling the reference's constructor selects (resnet_xvector.py:104-111): statistics
+(pooled per frequency bin straight from the grid), and - over the [B, C*F', T'] reshape materialised once on the device -
+attentive, multi-head, multi-resolution and LDE.
 """
 
 import sys
@@ -35,8 +36,6 @@ class ResNetXvector(TopVirtualNnet):
         fc1_params = utils.assign_params_dict(fc_defaults, fc1_params)
         fc2_params = utils.assign_params_dict(fc_defaults, fc2_params)
         cmvn_params = utils.assign_params_dict({"mean_norm": True, "std_norm": False}, cmvn_params)
-        if pooling not in ("statistics", "stats", None, ""):
-            raise NotImplementedError("pooling='%s' is outside the MI355X extraction path (SURVEY.md section 2, row 3)" % pooling)
 
         self.extracted_embedding = extracted_embedding
         self.inputs_dim = inputs_dim
@@ -45,7 +44,17 @@ class ResNetXvector(TopVirtualNnet):
         self.resnet = ResNet(1 if self.convXd == 2 else inputs_dim, **resnet_params)
         mult = self.resnet.get_downsample_multiple()
         trunk_dim = (inputs_dim + mult - 1) // mult * self.resnet.get_output_planes()
-        self.stats = StatisticsPooling(trunk_dim, stddev=pooling_params["stddev"])
+        stddev = pooling_params.pop("stddev")                            # the reference's selection, resnet_xvector.py:103-115
+        if pooling == "lde":
+            self.stats = LDEPooling(trunk_dim, c_num=pooling_params["num_head"])
+        elif pooling == "attentive":
+            self.stats = AttentiveStatisticsPooling(trunk_dim, hidden_size=pooling_params["hidden_size"], context=pooling_params["context"], stddev=stddev)
+        elif pooling == "multi-head":
+            self.stats = MultiHeadAttentionPooling(trunk_dim, stddev=stddev, **pooling_params)
+        elif pooling == "multi-resolution":
+            self.stats = MultiResolutionMultiHeadAttentionPooling(trunk_dim, **pooling_params)
+        else:
+            self.stats = StatisticsPooling(trunk_dim, stddev=stddev)
         embd = resnet_params["planes"][3]
         self.fc1 = ReluBatchNormTdnnLayer(self.stats.get_output_dim(), embd, **fc1_params) if fc1 else None
         self.fc2 = ReluBatchNormTdnnLayer(embd if fc1 else self.stats.get_output_dim(), embd, **fc2_params)

@@ -241,6 +241,17 @@ typedef struct asv_im2col_desc {
 } asv_im2col_desc_t;
 int asv_net_add_im2col(asv_net_t *net, const asv_im2col_desc_t *d);
 
+/* ResNetXvector's `x.reshape(B, C*F', T')` (resnet_xvector.py:193) in front of a pooling that weights FRAMES (attentive /
+ * multi-head / multi-resolution / LDE, resnet_xvector.py:104-111; plain statistics pooling needs no copy - asv_pool_desc_t.per_bin):
+ * out[t'][c*F' + f] = in[(t', f)][c], the reference's channel order.  `out_buf` lives on a SEQUENCE domain: a grid of width 1 and
+ * pitch 1 at the input grid's time shift (asv_net_define_grid(net, shift, 1, 1)), on which frame-level layers (context within +-2
+ * frames) and every pooling run as they do on the frames domain. */
+typedef struct asv_grid_flatten_desc {
+  uint32_t struct_size;
+  int32_t in_buf, out_buf;       /* whole buffers: C channels on a (shift, F', pitch) grid -> C*F' channels on the (shift, 1, 1) grid */
+} asv_grid_flatten_desc_t;
+int asv_net_add_grid_flatten(asv_net_t *net, const asv_grid_flatten_desc_t *d);
+
 /* Freezes the program; `out_buf` must be an utts-domain buffer: its first `embed_dim`
  * channels are the embedding. */
 int asv_net_finalize(asv_net_t *net, int out_buf, int embed_dim);

@@ -162,6 +162,24 @@ CASES = {
     "resnet_bottleneck_preact": dict(blueprint="resnet_xvector.py",
                                      creation="ResNetXvector(33,10,training=False,resnet_params={'block':'Bottleneck','layers':[1,1,1,1],'planes':[16,32,64,128]})",
                                      dim=33, utts=[(70, 5600), (21, 5601)], wseed=12),
+    # the frame-weighting poolings behind the 2-D trunk (resnet_xvector.py:104-111, over the [B, C*F', T'] reshape of :193); small trunks
+    "resnet_attentive": dict(blueprint="resnet_xvector.py",
+                             creation="ResNetXvector(40,10,training=False,pooling='attentive',pooling_params={'hidden_size':32,'context':[-1,0,1]},"
+                                      "resnet_params={'layers':[1,1,1,1],'planes':[16,32,64,128],'use_se':True,'full_pre_activation':False})",
+                             dim=40, utts=[(150, 5700), (64, 5701), (9, 5702)], wseed=16),
+    "resnet_multihead": dict(blueprint="resnet_xvector.py",
+                             creation="ResNetXvector(33,10,training=False,pooling='multi-head',pooling_params={'num_head':4,'share':True,'affine_layers':1},"
+                                      "resnet_params={'layers':[1,1,1,1],'planes':[16,32,64,128]})",
+                             dim=33, utts=[(120, 5800), (41, 5801)], wseed=17),
+    "resnet_multires": dict(blueprint="resnet_xvector.py",
+                            creation="ResNetXvector(40,10,training=False,fc1=True,extracted_embedding='far',pooling='multi-resolution',"
+                                     "pooling_params={'num_head':4,'share':True,'affine_layers':2,'hidden_size':32,'temperature':True},"
+                                     "resnet_params={'layers':[1,1,1,1],'planes':[16,32,64,128],'full_pre_activation':False})",
+                            dim=40, utts=[(130, 5900), (57, 5901)], wseed=18),
+    "resnet_lde": dict(blueprint="resnet_xvector.py",
+                       creation="ResNetXvector(40,10,training=False,pooling='lde',pooling_params={'num_head':8},"
+                                "resnet_params={'layers':[1,1,1,1],'planes':[16,32,64,128],'full_pre_activation':False})",
+                       dim=40, utts=[(140, 6000), (33, 6001)], wseed=19),
     "resnet34_plain": dict(blueprint="resnet_xvector.py",
                            creation="ResNetXvector(61,10,training=False,resnet_params={'full_pre_activation':False})",
                            dim=61, utts=[(150, 5100), (77, 5101)], wseed=7),

@@ -29,10 +29,18 @@ def run_graph(graph, feats, dtype=np.float32, ops=None):
             fr = (fr + 1) // 2
         return fr, g[2], g[3]                     # frames, width, pitch
 
+    def seq_frames(tid):
+        fr = T
+        for _ in range(graph.seq_spec(tid)[1]):
+            fr = (fr + 1) // 2
+        return fr
+
     def rows(tid):
         if graph.grid_spec(tid) is not None:
             fr, _, pitch = grid_dims(tid)
             return fr * pitch
+        if graph.seq_spec(tid) is not None:
+            return seq_frames(tid)
         return T if graph.domain(tid) == 0 else 1
 
     def valid_mask(tid):
@@ -74,6 +82,14 @@ def run_graph(graph, feats, dtype=np.float32, ops=None):
             for t in range(fr):
                 g[t * pitch:t * pitch + width, 0] = src[t, :width]
             put(op.out, g)
+        elif op.kind == "flatten":
+            x = get(op.inp)
+            fr, width, pitch = grid_dims(op.inp.tid)
+            C = op.inp.channels
+            out = np.zeros((fr, C * width), dtype=dtype)
+            for f in range(width):
+                out[:, f::width] = x[f::pitch][:fr]               # column c*F + f
+            put(op.out, out)
         elif op.kind == "im2col":
             x = get(op.inp)
             if getattr(op, "seg_scale", None) is not None:        # the elementwise prologue of Graph.fused_gather_ops

@@ -181,6 +181,25 @@ def test_resnet_traced_program_reproduces_reference_on_cpu(name, idx):
     assert rel_err(ir_interp.extract(graph, x), g["embeddings"][idx]) < 2e-5
 
 
+@pytest.mark.parametrize("name,kinds", [("resnet_attentive", ["flatten", "attpool"]), ("resnet_multihead", ["flatten", "attpool"]),
+                                        ("resnet_multires", ["flatten"] + ["attpool"] * 4), ("resnet_lde", ["flatten", "lde"])])
+def test_resnet_frame_weighting_poolings_reproduce_reference_on_cpu(name, kinds):
+    """ResNetXvector with the reference's other pooling options (resnet_xvector.py:104-111): the [B, C*F', T'] reshape (:193) is
+    materialised ONCE, in the reference's channel order c*F' + f, on a sequence domain at the trunk's frame rate (T / 8); the
+    attention layers (time context included) and the pooling kernels then run on it like on the frames domain.  Golden vectors:
+    the reference's own outputs (oracle/gen_golden.py), every utterance incl. the 9-frame one (two trunk frames)."""
+    from libs.amd import ir
+    g, sd, model = helpers.golden_model(name)
+    graph = ir.trace(model, type(model).extract_embedding.__wrapped_body__, int(g["dim"]))
+    tail = [op.kind for op in graph.ops if op.kind in ("flatten", "attpool", "lde", "pool")]
+    assert tail[-len(kinds):] == kinds
+    assert ("seq", 3) in graph.domains
+    flat = [op for op in graph.ops if op.kind == "flatten"][0]
+    assert flat.out.channels == model.stats.input_dim == flat.inp.channels * graph.grid_spec(flat.inp.tid)[2]
+    for x, ref in zip(helpers.golden_feats(g), g["embeddings"]):
+        assert rel_err(ir_interp.extract(graph, x), ref) < 3e-5, (name, len(x))
+
+
 REF_MODEL_DIR = "/root/reference/pytorch/model"
 
 
@@ -188,6 +207,8 @@ REF_MODEL_DIR = "/root/reference/pytorch/model"
 @pytest.mark.parametrize("blueprint,creation,golden", [("xvector.py", "Xvector(30,10,training=False)", "xvector_c1"),
                                                        ("ecapa_tdnn_xvector.py", "ECAPA_TDNN(80,10,training=False)", "ecapa_c3"),
                                                        ("resnet_xvector.py", "ResNetXvector(61,10,training=False,resnet_params={'full_pre_activation':False})", "resnet34_plain"),
+                                                       ("resnet_xvector.py", "ResNetXvector(40,10,training=False,pooling='attentive',pooling_params={'hidden_size':32,'context':[-1,0,1]},"
+                                                        "resnet_params={'layers':[1,1,1,1],'planes':[16,32,64,128],'use_se':True,'full_pre_activation':False})", "resnet_attentive"),
                                                        ("extended_xvector.py", "ExtendedXvector(40,10,training=False)", "extended_far"),
                                                        ("snowdar_xvector.py", "Xvector(40,10,training=False,extend=True,skip_connection=True,SE=True,extracted_embedding='near')",
                                                         "snowdar_full_near"),

@@ -87,3 +87,34 @@ def test_gather_with_elementwise_prologue_changes_no_bit(precision, monkeypatch)
         two = model.extract_embedding_batch(mats).numpy()
         assert len(model._amd_engine().ops) > n_fused or name == "resnet34_plain"
         assert np.isfinite(fused).all() and np.array_equal(fused, two), (name, precision, float(np.abs(fused - two).max()))
+
+
+@pytest.mark.parametrize("precision", ["f32", "f32x"])
+@pytest.mark.parametrize("name", ["resnet_attentive", "resnet_multihead", "resnet_multires", "resnet_lde"])
+def test_resnet_with_frame_weighting_poolings_vs_reference_golden(name, precision):
+    """Round 4: ResNetXvector(pooling='attentive' | 'multi-head' | 'multi-resolution' | 'lde') - resnet_xvector.py:104-111 - on the
+    device: asv_net_add_grid_flatten writes the trunk's output as [T'][c*F' + f] rows on a sequence domain (a width-1 grid at T / 8),
+    the attention layers and attentive_pool / lde_pool kernels run there.  Reference outputs, 1e-4, in the exact and the default mode."""
+    g, sd, model = helpers.golden_model(name)
+    model.cuda()
+    model.amd_precision = precision
+    got = model.extract_embedding_batch(helpers.golden_feats(g)).numpy()
+    assert got.shape == g["embeddings"].shape
+    for i, (T, _) in enumerate(g["utts"]):
+        assert rel_err(got[i], g["embeddings"][i]) < 1e-4, "%s: utterance of %d frames" % (name, T)
+    assert any(op.kind == "flatten" for op in model._amd_engine().ops)
+
+
+def test_resnet_attentive_pooling_16bit_modes_are_close_and_batch_invariant():
+    from libs.amd import synth
+    g, sd, model = helpers.golden_model("resnet_attentive")
+    model.cuda()
+    ref = g["embeddings"]
+    for precision, floor in (("bf16", 0.995), ("f16", 0.9995)):
+        model.amd_precision = precision
+        got = model.extract_embedding_batch(helpers.golden_feats(g)).numpy()
+        cos = (got * ref).sum(1) / np.linalg.norm(got, axis=1) / np.linalg.norm(ref, axis=1)
+        assert cos.min() > floor, (precision, cos)
+        mats = [synth.synth_feats(T, 40, 9100 + i) for i, T in enumerate([200, 77, 333])]
+        full = model.extract_embedding_batch(mats).numpy()
+        assert np.array_equal(model.extract_embedding(mats[1]).numpy(), full[1])
