@@ -336,6 +336,184 @@ __global__ __launch_bounds__(256, 2) void grid_conv_x3_kernel(const TdnnKernelPa
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The 32 -> 32 convolutions of the trunk's first stage (6 of 32 layers, the widest maps: 17 % of a ResNet34-SE f32x step) as a
+// PERSISTENT kernel with a sliding window - the f32x form of kernels_conv2d.hip grid_conv_narrow_pers_kernel.  The one-tile kernel
+// above fetches and splits 420 window rows for 256 output rows (halo = pitch + 1 = 82 rows on either side: 1.64 x the reads and the
+// conversion work), one phase after the other - SQ counters (profiles/r4_mfma_util_resnet_f32x.json): matrix pipe 0.29 busy, waves
+// parked at a wait 0.44 of their time.  Here a workgroup walks a contiguous run of 128-row tiles:
+//   * the window lives in an LDS ring of [hi | lo] image rows addressed by the matrix row modulo the ring; a tile adds its 128 new
+//     rows only (read and split once: amplification 1.0);
+//   * those rows are fetched into registers TWO tiles ahead (top of the tile's K loop), split and written to the ring one tile
+//     ahead, behind the tile's stores - into ring rows nobody reads any more (ring = window + one tile, 448 rows): one barrier per tile;
+//   * a wave = 32 rows x the 32 output channels with ALL weight fragments (9 taps x 2 k-groups x hi / lo = 36 x 16 bytes per lane)
+//     in registers for the whole run: the K loop is LDS reads and matrix instructions only;
+//   * the same (tap, k-group, term) accumulation order as the one-tile kernel: bit-identical outputs (tests/test_gpu_grid_conv_x3.py).
+struct QPers32 {
+  static constexpr int BM = 128, HALO = 84;                 // >= pitch + 1 of an 80-bin grid (82), a multiple of 4
+  static constexpr int WIN = BM + 2 * HALO;                 // 296
+  static constexpr int RING = 448;                          // >= WIN + BM = 424, a multiple of 16 (the slot swizzle continues across the wrap)
+  static constexpr int SPITCH = 36;
+  static constexpr int SCR_OFF = RING * QROWB;              // 57344
+  static constexpr int PAR_OFF = SCR_OFF + 4 * 32 * SPITCH * 4;
+  static constexpr int LDS = PAR_OFF + 3 * 32 * 4;          // 76160: two workgroups per CU
+  static_assert(RING >= WIN + BM && RING % 16 == 0 && 2 * LDS <= 163840, "sliding-window geometry (f32x, 32 channels)");
+};
+
+template <int ET>
+__global__ __launch_bounds__(256, 2) void grid_conv_x3_pers32_kernel(const TdnnKernelParams p, const int tiles_per_wg) {
+  using G = QPers32;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+  const int n_tiles = p.rows / G::BM;
+  const int t_begin = blockIdx.x * tiles_per_wg, t_end = min(t_begin + tiles_per_wg, n_tiles);
+  if (t_begin >= t_end) return;
+
+  float *lds_par = reinterpret_cast<float *>(lds + G::PAR_OFF);
+  if (tid < 96) {
+    const int which = tid / 32, c = tid % 32;
+    const float *src = which == 0 ? p.bias : (which == 1 ? p.scale : p.shift);
+    lds_par[tid] = src != nullptr ? src[c] : (which == 1 ? 1.0f : 0.0f);
+  }
+
+  // ---- rows -> registers -> ring.  A stage = the 128 new rows of one tile: 2 pieces (row, 8 channels) per thread
+  const float *xg = reinterpret_cast<const float *>(p.x);
+  struct Stage { uint4 a[2], b[2]; uint32_t ok; };
+  uint32_t range = 0u;
+  const int q = tid & 3;                                      // this thread's 8-channel group, in every piece
+  auto gload = [&](int row0, Stage &st) {                     // matrix rows row0 .. row0 + 127 (unconditional loads, see the kernel above)
+    uint32_t okbits = 0u;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int row = row0 + it * 64 + (tid >> 2);
+      const bool ok = row >= 0 && row < p.rows;
+      okbits |= ok ? (1u << it) : 0u;
+      const float *src = xg + (ok ? (size_t)row * p.ldx + q * 8 : 0);
+      st.a[it] = *reinterpret_cast<const uint4 *>(src);
+      st.b[it] = *reinterpret_cast<const uint4 *>(src + 4);
+    }
+    st.ok = okbits;
+  };
+  auto sstore = [&](int row0, const Stage &st) {              // (row0 + HALO >= 0: virtual rows)
+    const int v0 = (row0 + G::HALO) % G::RING;                // wave-uniform
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      int rr = v0 + it * 64 + (tid >> 2);
+      rr = rr >= G::RING ? rr - G::RING : rr;
+      const bool ok = (st.ok >> it) & 1u;
+      const uint4 zero = make_uint4(0, 0, 0, 0);
+      const X3Frag f = x3_split<ET, true>(ok ? st.a[it] : zero, ok ? st.b[it] : zero, range);
+      *reinterpret_cast<uint4 *>(lds + rr * QROWB + qswz(rr, q) * 16) = f.hi;
+      *reinterpret_cast<uint4 *>(lds + rr * QROWB + qswz(rr, 4 + q) * 16) = f.lo;
+    }
+  };
+
+  // ---- weights: every fragment of the layer, for the whole run
+  uint4 wh[9][2], wl[9][2];
+  {
+    const unsigned char *wq = reinterpret_cast<const unsigned char *>(p.wconv) + (size_t)lane * 16;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg) {
+        wh[t][kg] = *reinterpret_cast<const uint4 *>(wq + (size_t)(t * 2 + kg) * 2048);
+        wl[t][kg] = *reinterpret_cast<const uint4 *>(wq + (size_t)(t * 2 + kg) * 2048 + 1024);
+      }
+  }
+  const int v_taps = p.taps[lane < 9 ? lane : 0];
+
+  // ---- the first window (rows m - HALO .. m + BM + HALO of the first tile), then the next tile's rows into registers
+  {
+    const int first = t_begin * G::BM - G::HALO;
+    Stage st;
+#pragma unroll 1
+    for (int r0 = 0; r0 < G::WIN; r0 += 128) {              // 3 x 128 rows (the last 88 beyond the window belong to the next tile: rewritten below, harmless)
+      gload(first + r0, st);
+      sstore(first + r0, st);
+    }
+  }
+  Stage sa, sb;                                               // sa: tile + 1's rows (landed), sb: tile + 2's rows (in flight)
+  gload((t_begin + 1) * G::BM + G::HALO, sa);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  const float act_lo = (p.act1 == ASV_ACT_RELU) ? 0.0f : -INFINITY;
+  const float unscale = p.w_unscale;
+  float *yg = reinterpret_cast<float *>(p.y);
+  float *scr = reinterpret_cast<float *>(lds + G::SCR_OFF) + wave * (32 * G::SPITCH);
+
+  // Every vector-memory operation of the loop is UNCONDITIONAL (past the end of the run: rows that are fetched / split and never
+  // read) and the validity bits travel one tile ahead: hipcc then counts what is younger than the value it needs and waits for
+  // that value alone - behind a branch, or consumed in the tile that fetched them, each wait became vmcnt(0): the row fetch of the
+  // next tiles and the previous tile's stores drained in front of every K loop.
+  const int last_word = (p.rows >> 5) - 1;
+  auto one_tile = [&](const int tile, Stage &next, Stage &next2, const uint32_t vbits, uint32_t &vbits_next) {
+    const int m0 = tile * G::BM;
+    vbits_next = p.row_valid[min((m0 + G::BM + wave * 32) >> 5, last_word)];
+    // the rows tile + 2 adds -> next2 (nobody holds it: its previous content went to the ring at the end of the previous tile)
+    gload((tile + 2) * G::BM + G::HALO, next2);
+    const int wb = __builtin_amdgcn_readfirstlane((m0 + G::HALO + wave * 32) % G::RING);      // ring row of this wave's first output row
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int d = __builtin_amdgcn_readlane(v_taps, t);
+      int rr = wb + lr + d;
+      rr = rr < 0 ? rr + G::RING : (rr >= G::RING ? rr - G::RING : rr);
+      const unsigned char *rowp = lds + rr * QROWB;
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg) {
+        const uint4 xh = *reinterpret_cast<const uint4 *>(rowp + qswz(rr, kg * 2 + lh) * 16);
+        const uint4 xl = *reinterpret_cast<const uint4 *>(rowp + qswz(rr, 4 + kg * 2 + lh) * 16);
+        acc = mfma16<ET>(wh[t][kg], xh, acc);
+        acc = mfma16<ET>(wh[t][kg], xl, acc);
+        acc = mfma16<ET>(wl[t][kg], xh, acc);
+      }
+    }
+    // ---- epilogue: acc[r] = row m0 + wave*32 + lr, channel 8*(r>>2) + 4*lh + (r&3)
+    const int rbase = m0 + wave * 32;
+    const bool valid = (vbits >> lr) & 1u;
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const int chl = 8 * qq + 4 * lh;
+      const float4 b4 = *reinterpret_cast<const float4 *>(lds_par + chl);
+      const float4 sc4 = *reinterpret_cast<const float4 *>(lds_par + 32 + chl);
+      const float4 sh4 = *reinterpret_cast<const float4 *>(lds_par + 64 + chl);
+      const float b[4] = {b4.x, b4.y, b4.z, b4.w}, sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+      float y[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float z = fmaxf(fmaf(acc[qq * 4 + e], unscale, b[e]), act_lo) * sc[e] + sh[e];
+        y[e] = valid ? z : 0.0f;
+      }
+      *reinterpret_cast<float4 *>(scr + lr * G::SPITCH + chl) = make_float4(y[0], y[1], y[2], y[3]);
+    }
+    // the tile is wave-private: the LDS operations of one wave complete in order
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int frow = it * 8 + (lane >> 3), slot = lane & 7;
+      const float4 v = *reinterpret_cast<const float4 *>(scr + frow * G::SPITCH + slot * 4);
+      *reinterpret_cast<float4 *>(yg + (size_t)(rbase + frow) * p.ldy + slot * 4) = v;
+    }
+    // tile + 1's rows: split and into the ring rows behind the window (nobody reads them during this tile)
+    sstore((tile + 1) * G::BM + G::HALO, next);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  uint32_t va = p.row_valid[min((t_begin * G::BM + wave * 32) >> 5, last_word)], vb = 0u;
+#pragma unroll 1
+  for (int tile = t_begin; tile < t_end; tile += 2) {
+    one_tile(tile, sa, sb, va, vb);
+    if (tile + 1 < t_end) one_tile(tile + 1, sb, sa, vb, va);
+  }
+  x3_publish_range(range, p.status);
+}
+
 // the nine-tap geometries (halo >= pitch + 1 of the stage's grid) and the halo-free ones (1-tap layers over im2col / space-to-depth
 // tensors); two image buffers unless the layer is a single chunk
 using Q32 = QGeom<4, 1, 2, 1, 82, 82, 1>;      // 32 -> 32, grids of <= 80 bins (halo = pitch + 1 <= 82): 256 rows, one chunk, 52.9 KiB: three workgroups per CU
@@ -437,6 +615,25 @@ int launch_grid_conv_x3(const TdnnKernelParams &p, hipStream_t s) {
   ASV_REQUIRE(grid_conv_x3_supported(p), "grid conv (f32x): unsupported layer");
   ASV_REQUIRE(p.x3_et == ET_BF16 || p.x3_et == ET_F16, "grid conv (f32x): split type %d", p.x3_et);
   const QPick g = pick_geom(p);
+  {
+    // the 32 -> 32 nine-tap layers: persistent sliding-window form (ASV_AMD_X3_PERS=0: the one-tile kernel; same bits)
+    static const bool live = getenv("ASV_AMD_LIVE_TUNE") != nullptr;
+    static const int pers0 = getenv("ASV_AMD_X3_PERS") != nullptr ? atoi(getenv("ASV_AMD_X3_PERS")) : 1;
+    const int pers = live && getenv("ASV_AMD_X3_PERS") != nullptr ? atoi(getenv("ASV_AMD_X3_PERS")) : pers0;
+    int halo = 0;
+    for (int t = 0; t < p.n_taps; ++t) halo = std::max(halo, std::abs(p.taps[t]));
+    if (pers && g.id == 0 && plain_epilogue(p) && p.n_taps == 9 && p.cin_pad == 32 && p.cout_store == 32 && halo <= QPers32::HALO && p.rows % QPers32::BM == 0 &&
+        p.rows >= QPers32::RING) {
+      int dev = 0, cus = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      const int n_tiles = p.rows / QPers32::BM, wgs = std::min(n_tiles, cus * 2), per_wg = (n_tiles + wgs - 1) / wgs;
+      const dim3 pgrid((n_tiles + per_wg - 1) / per_wg), pblock(256);
+      if (p.x3_et == ET_F16) hipLaunchKernelGGL((grid_conv_x3_pers32_kernel<ET_F16>), pgrid, pblock, 0, s, p, per_wg);
+      else hipLaunchKernelGGL((grid_conv_x3_pers32_kernel<ET_BF16>), pgrid, pblock, 0, s, p, per_wg);
+      ASV_HIP_CHECK(hipGetLastError());
+      return ASV_OK;
+    }
+  }
   const int m_tiles = p.rows / g.bm, n_tiles = p.cout_store / g.bn, nft = p.cout_store / 32;
   const dim3 grid(m_tiles * n_tiles), block(256);
   // the hot instantiations carry the short epilogue only; tanh / sigmoid / per-segment terms / residual / "bn-relu" order / a second

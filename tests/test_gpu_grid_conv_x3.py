@@ -125,3 +125,44 @@ def test_f32x_grid_convolution_vs_numpy_oracle(name):
     assert np.array_equal(alone[0], got[0])
     for e in (eng, slow, engb):
         e.close()
+
+
+def test_persistent_32_channel_kernel_equals_the_one_tile_kernel(tmp_path):
+    """Round 4: the 32 -> 32 convolutions of the first ResNet stage run as a persistent sliding-window kernel in the f32x mode
+    (grid_conv_x3_pers32_kernel: the window in an LDS ring, each row fetched and split once, all weight fragments in registers).
+    Same (tap, k-group, term) accumulation order as the one-tile kernel: with ASV_AMD_X3_PERS=0 (read once per process: one
+    subprocess per setting) every bit of the embeddings is the same - small ragged batch (runs of a few tiles, utterance seams, a
+    9-frame utterance) and 24 x 600 frames (18 tiles per workgroup, the ring wraps many times), IEEE-half and bf16 halves."""
+    import os
+    import subprocess
+    import sys
+    import helpers
+    code = r'''
+import sys, numpy as np
+sys.path[:0] = [%r, %r, %r]
+import helpers
+from libs.amd import synth
+g, sd, model = helpers.golden_model("resnet34se_c5")
+model.cuda()
+out = {}
+for prec in ("f32x", "f32x-bf16"):
+    model.amd_precision = prec
+    for name, lens in (("ragged", [200, 333, 517, 201, 9]), ("big", [600] * 24)):
+        mats = [synth.synth_feats(t, 80, 8800 + i) for i, t in enumerate(lens)]
+        out[prec + "_" + name] = model.extract_embedding_batch(mats).numpy()
+out["golden"] = model.extract_embedding_batch(helpers.golden_feats(g)).numpy()
+np.savez(sys.argv[1], **out)
+''' % (helpers.REPO, os.path.join(helpers.REPO, "asv-subtools_amd", "pytorch"), os.path.join(helpers.REPO, "tests"))
+    res = {}
+    for mode in ("0", "1"):
+        path = str(tmp_path / ("pers%s.npz" % mode))
+        env = dict(os.environ, ASV_AMD_X3_PERS=mode)
+        env.pop("ASV_AMD_LIVE_TUNE", None)
+        r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        res[mode] = dict(np.load(path))
+    g, sd = helpers.golden_state_dict("resnet34se_c5")
+    for i in range(len(g["utts"])):
+        assert helpers.rel_err(res["1"]["golden"][i], g["embeddings"][i]) < 1e-4
+    for k in res["1"]:
+        assert np.isfinite(res["1"][k]).all() and np.array_equal(res["1"][k], res["0"][k]), (k, float(np.abs(res["1"][k] - res["0"][k]).max()))
