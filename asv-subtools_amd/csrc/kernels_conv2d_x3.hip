@@ -514,6 +514,182 @@ __global__ __launch_bounds__(256, 2) void grid_conv_x3_pers32_kernel(const TdnnK
   x3_publish_range(range, p.status);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The 64 -> 64 convolutions of the second stage (7 layers; one-tile kernel: 282 us against ~100 us of matrix work or HBM time - every
+// 128-row tile streams the layer's 147 KiB of hi / lo weight fragments from L2 once per wave column, re-fetches 96 halo rows and
+// converts 1.75 x its rows) in the same persistent form.  The weights of a 64-channel layer do not fit one wave's registers, so K is
+// split over TWO waves: workgroup = 512 threads = 8 waves = 2 row fragments x 2 output fragments x 2 INPUT halves; a wave keeps the
+// 36 fragments of (its 32 output channels, its 32 input channels, 9 taps) for the whole run and reads only its half of the ring rows;
+// the two partial accumulators meet in LDS once per tile - each wave of the pair finishes HALF of the 32 channels (partner's part +
+// its own: one f32 addition, the same whichever wave performs it) and runs that half's epilogue and stores.  64-row tiles, ring of 224
+// rows x 256 B ([chunk][hi | lo], 16-byte slots XOR-swizzled by row & 15), one workgroup per CU.
+// Not the accumulation order of the one-tile kernel (there: chunk 0's taps, then chunk 1's, in one accumulator; here the two chunk
+// sums are added at the end): equal to f32 rounding (~1e-7), not bit for bit; every row still has ONE fixed order whatever the batch.
+struct QPers64 {
+  static constexpr int BM = 64, HALO = 44;                  // >= pitch + 1 of a 40-bin grid (42), a multiple of 4
+  static constexpr int WIN = BM + 2 * HALO;                 // 152
+  static constexpr int RING = 224;                          // >= WIN + BM = 216, a multiple of 16
+  static constexpr int ROWB = 256;
+  static constexpr int RED_OFF = RING * ROWB;               // 57344: partial accumulators, [parity][pair][half][2][lane] float4
+  static constexpr int SCR_OFF = RED_OFF + 2 * 4 * 4096;    // per wave: 32 rows x 16 channels (+4) on their way to 16-byte stores
+  static constexpr int SPITCH = 20;
+  static constexpr int PAR_OFF = SCR_OFF + 8 * 32 * SPITCH * 4;
+  static constexpr int LDS = PAR_OFF + 3 * 64 * 4;          // 111360: one workgroup (8 waves) per CU
+  static_assert(RING >= WIN + BM && RING % 16 == 0 && LDS <= 163840, "sliding-window geometry (f32x, 64 channels)");
+};
+
+template <int ET>
+__global__ __launch_bounds__(512, 1) void grid_conv_x3_pers64_kernel(const TdnnKernelParams p, const int tiles_per_wg) {
+  using G = QPers64;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = (wave >> 1) & 1, kh = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int n_tiles = p.rows / G::BM;
+  const int t_begin = blockIdx.x * tiles_per_wg, t_end = min(t_begin + tiles_per_wg, n_tiles);
+  if (t_begin >= t_end) return;
+
+  float *lds_par = reinterpret_cast<float *>(lds + G::PAR_OFF);
+  if (tid < 192) {
+    const int which = tid / 64, c = tid % 64;
+    const float *src = which == 0 ? p.bias : (which == 1 ? p.scale : p.shift);
+    lds_par[tid] = src != nullptr ? src[c] : (which == 1 ? 1.0f : 0.0f);
+  }
+
+  // ---- rows -> registers -> ring.  A stage = the 64 new rows of one tile: ONE piece (row, 8 channels) per thread
+  const float *xg = reinterpret_cast<const float *>(p.x);
+  struct Stage { uint4 a, b; uint32_t ok; };
+  uint32_t range = 0u;
+  const int q8 = tid & 7, srow = tid >> 3;                    // this thread's 8-channel group (chunk q8 >> 2, piece q8 & 3) and row of a stage
+  auto gload = [&](int row0, Stage &st) {
+    const int row = row0 + srow;
+    const bool ok = row >= 0 && row < p.rows;
+    const float *src = xg + (ok ? (size_t)row * p.ldx + q8 * 8 : 0);
+    st.a = *reinterpret_cast<const uint4 *>(src);
+    st.b = *reinterpret_cast<const uint4 *>(src + 4);
+    st.ok = ok ? 1u : 0u;
+  };
+  auto sstore = [&](int row0, const Stage &st) {
+    int rr = (row0 + G::HALO) % G::RING + srow;
+    rr = rr >= G::RING ? rr - G::RING : rr;
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+    const X3Frag f = x3_split<ET, true>(st.ok ? st.a : zero, st.ok ? st.b : zero, range);
+    const int s0 = (q8 >> 2) * 8 + (q8 & 3);
+    *reinterpret_cast<uint4 *>(lds + rr * G::ROWB + ((s0 ^ (rr & 15)) << 4)) = f.hi;
+    *reinterpret_cast<uint4 *>(lds + rr * G::ROWB + (((s0 + 4) ^ (rr & 15)) << 4)) = f.lo;
+  };
+
+  // ---- weights: the fragments of (output fragment wn, input chunk kh), for the whole run
+  uint4 wh[9][2], wl[9][2];
+  {
+    const unsigned char *wq = reinterpret_cast<const unsigned char *>(p.wconv) + (size_t)lane * 16;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg) {
+        const size_t frag = ((((size_t)kh * 9 + t) * 2 + kg) * 2 + wn) * 2;
+        wh[t][kg] = *reinterpret_cast<const uint4 *>(wq + frag * 1024);
+        wl[t][kg] = *reinterpret_cast<const uint4 *>(wq + frag * 1024 + 1024);
+      }
+  }
+  const int v_taps = p.taps[lane < 9 ? lane : 0];
+
+  {
+    const int first = t_begin * G::BM - G::HALO;
+    Stage st;
+#pragma unroll 1
+    for (int r0 = 0; r0 < G::WIN; r0 += 64) {                // 3 x 64 rows (the last 40 belong to the next tile: rewritten below, harmless)
+      gload(first + r0, st);
+      sstore(first + r0, st);
+    }
+  }
+  Stage sa, sb;
+  gload((t_begin + 1) * G::BM + G::HALO, sa);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  const float act_lo = (p.act1 == ASV_ACT_RELU) ? 0.0f : -INFINITY;
+  const float unscale = p.w_unscale;
+  float *yg = reinterpret_cast<float *>(p.y);
+  float *scr = reinterpret_cast<float *>(lds + G::SCR_OFF) + wave * (32 * G::SPITCH);
+  const int last_word = (p.rows >> 5) - 1;
+  const int cbase = wn * 32 + kh * 16;                        // the 16 output channels this wave finishes
+
+  auto one_tile = [&](const int tile, Stage &next, Stage &next2, const uint32_t vbits, uint32_t &vbits_next) {
+    const int m0 = tile * G::BM;
+    vbits_next = p.row_valid[min((m0 + G::BM + wm * 32) >> 5, last_word)];
+    gload((tile + 2) * G::BM + G::HALO, next2);
+    const int wb = __builtin_amdgcn_readfirstlane((m0 + G::HALO + wm * 32) % G::RING);
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int d = __builtin_amdgcn_readlane(v_taps, t);
+      int rr = wb + lr + d;
+      rr = rr < 0 ? rr + G::RING : (rr >= G::RING ? rr - G::RING : rr);
+      const unsigned char *rowp = lds + rr * G::ROWB;
+      const int sw = rr & 15;
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg) {
+        const uint4 xh = *reinterpret_cast<const uint4 *>(rowp + (((kh * 8 + kg * 2 + lh) ^ sw) << 4));
+        const uint4 xl = *reinterpret_cast<const uint4 *>(rowp + (((kh * 8 + 4 + kg * 2 + lh) ^ sw) << 4));
+        acc = mfma16<ET>(wh[t][kg], xh, acc);
+        acc = mfma16<ET>(wh[t][kg], xl, acc);
+        acc = mfma16<ET>(wl[t][kg], xh, acc);
+      }
+    }
+    // ---- the pair's accumulators meet: this wave hands over the half the partner finishes (registers 8 (1 - kh) .. + 8)
+    float4 *red = reinterpret_cast<float4 *>(lds + G::RED_OFF) + ((tile & 1) * 4 + (wave >> 1)) * 256;
+    {
+      const int o = (1 - kh) * 8;
+      red[((1 - kh) * 2 + 0) * 64 + lane] = make_float4(acc[o + 0], acc[o + 1], acc[o + 2], acc[o + 3]);
+      red[((1 - kh) * 2 + 1) * 64 + lane] = make_float4(acc[o + 4], acc[o + 5], acc[o + 6], acc[o + 7]);
+    }
+    // tile + 1's rows: split and into the ring rows behind the window (nobody reads them during this tile)
+    sstore((tile + 1) * G::BM + G::HALO, next);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // ---- epilogue of this wave's 16 channels: rows m0 + wm*32 + lr, channels cbase + 8*j + 4*lh + e (accumulator register 8*kh + 4*j + e)
+    const int rbase = m0 + wm * 32;
+    const bool valid = (vbits >> lr) & 1u;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float4 o4 = red[(kh * 2 + j) * 64 + lane];
+      const float other[4] = {o4.x, o4.y, o4.z, o4.w};
+      const int chl = cbase + 8 * j + 4 * lh;
+      const float4 b4 = *reinterpret_cast<const float4 *>(lds_par + chl);
+      const float4 sc4 = *reinterpret_cast<const float4 *>(lds_par + 64 + chl);
+      const float4 sh4 = *reinterpret_cast<const float4 *>(lds_par + 128 + chl);
+      const float b[4] = {b4.x, b4.y, b4.z, b4.w}, sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+      float y[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float sum = __fadd_rn(acc[kh * 8 + j * 4 + e], other[e]);          // chunk 0's part + chunk 1's part (commutative: the same in either wave)
+        const float z = fmaxf(fmaf(sum, unscale, b[e]), act_lo) * sc[e] + sh[e];
+        y[e] = valid ? z : 0.0f;
+      }
+      *reinterpret_cast<float4 *>(scr + lr * G::SPITCH + 8 * j + 4 * lh) = make_float4(y[0], y[1], y[2], y[3]);
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int frow = it * 16 + (lane >> 2), slot = lane & 3;
+      const float4 v = *reinterpret_cast<const float4 *>(scr + frow * G::SPITCH + slot * 4);
+      *reinterpret_cast<float4 *>(yg + (size_t)(rbase + frow) * p.ldy + cbase + slot * 4) = v;
+    }
+  };
+  uint32_t va = p.row_valid[min((t_begin * G::BM + wm * 32) >> 5, last_word)], vb = 0u;
+#pragma unroll 1
+  for (int tile = t_begin; tile < t_end; tile += 2) {
+    one_tile(tile, sa, sb, va, vb);
+    if (tile + 1 < t_end) one_tile(tile + 1, sb, sa, vb, va);
+  }
+  x3_publish_range(range, p.status);
+}
+
 // the nine-tap geometries (halo >= pitch + 1 of the stage's grid) and the halo-free ones (1-tap layers over im2col / space-to-depth
 // tensors); two image buffers unless the layer is a single chunk
 using Q32 = QGeom<4, 1, 2, 1, 82, 82, 1>;      // 32 -> 32, grids of <= 80 bins (halo = pitch + 1 <= 82): 256 rows, one chunk, 52.9 KiB: three workgroups per CU
@@ -616,7 +792,8 @@ int launch_grid_conv_x3(const TdnnKernelParams &p, hipStream_t s) {
   ASV_REQUIRE(p.x3_et == ET_BF16 || p.x3_et == ET_F16, "grid conv (f32x): split type %d", p.x3_et);
   const QPick g = pick_geom(p);
   {
-    // the 32 -> 32 nine-tap layers: persistent sliding-window form (ASV_AMD_X3_PERS=0: the one-tile kernel; same bits)
+    // the 32 -> 32 and 64 -> 64 nine-tap layers: persistent sliding-window forms (ASV_AMD_X3_PERS=0: the one-tile kernels; =3: the 32-channel
+    // form only - it gives the one-tile kernel's bits, the 64-channel form its values to f32 rounding)
     static const bool live = getenv("ASV_AMD_LIVE_TUNE") != nullptr;
     static const int pers0 = getenv("ASV_AMD_X3_PERS") != nullptr ? atoi(getenv("ASV_AMD_X3_PERS")) : 1;
     const int pers = live && getenv("ASV_AMD_X3_PERS") != nullptr ? atoi(getenv("ASV_AMD_X3_PERS")) : pers0;
@@ -630,6 +807,17 @@ int launch_grid_conv_x3(const TdnnKernelParams &p, hipStream_t s) {
       const dim3 pgrid((n_tiles + per_wg - 1) / per_wg), pblock(256);
       if (p.x3_et == ET_F16) hipLaunchKernelGGL((grid_conv_x3_pers32_kernel<ET_F16>), pgrid, pblock, 0, s, p, per_wg);
       else hipLaunchKernelGGL((grid_conv_x3_pers32_kernel<ET_BF16>), pgrid, pblock, 0, s, p, per_wg);
+      ASV_HIP_CHECK(hipGetLastError());
+      return ASV_OK;
+    }
+    if (pers && g.id == 1 && plain_epilogue(p) && p.n_taps == 9 && p.cin_pad == 64 && p.cout_store == 64 && halo <= QPers64::HALO && p.rows % QPers64::BM == 0 &&
+        p.rows >= QPers64::RING && (pers & 2) == 0) {
+      int dev = 0, cus = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      const int n_tiles = p.rows / QPers64::BM, wgs = std::min(n_tiles, cus), per_wg = (n_tiles + wgs - 1) / wgs;
+      const dim3 pgrid((n_tiles + per_wg - 1) / per_wg), pblock(512);
+      if (p.x3_et == ET_F16) hipLaunchKernelGGL((grid_conv_x3_pers64_kernel<ET_F16>), pgrid, pblock, 0, s, p, per_wg);
+      else hipLaunchKernelGGL((grid_conv_x3_pers64_kernel<ET_BF16>), pgrid, pblock, 0, s, p, per_wg);
       ASV_HIP_CHECK(hipGetLastError());
       return ASV_OK;
     }
