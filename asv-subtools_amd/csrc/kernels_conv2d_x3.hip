@@ -459,20 +459,27 @@ __global__ __launch_bounds__(256, 2) void grid_conv_x3_pers32_kernel(const TdnnK
     f32x16_t acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
+    // the operands of step (t, kg) + 1 are read in front of step (t, kg)'s three matrix instructions (two waves per SIMD: without
+    // this the ~100+ cycles of every ds_read round trip stand between two 96-cycle instruction groups of a wave)
+    uint4 xh[2], xl[2];
+    auto read_x = [&](const int t, const int kg, uint4 &h, uint4 &l) {
       const int d = __builtin_amdgcn_readlane(v_taps, t);
       int rr = wb + lr + d;
       rr = rr < 0 ? rr + G::RING : (rr >= G::RING ? rr - G::RING : rr);
       const unsigned char *rowp = lds + rr * QROWB;
+      h = *reinterpret_cast<const uint4 *>(rowp + qswz(rr, kg * 2 + lh) * 16);
+      l = *reinterpret_cast<const uint4 *>(rowp + qswz(rr, 4 + kg * 2 + lh) * 16);
+    };
+    read_x(0, 0, xh[0], xl[0]);
 #pragma unroll
-      for (int kg = 0; kg < 2; ++kg) {
-        const uint4 xh = *reinterpret_cast<const uint4 *>(rowp + qswz(rr, kg * 2 + lh) * 16);
-        const uint4 xl = *reinterpret_cast<const uint4 *>(rowp + qswz(rr, 4 + kg * 2 + lh) * 16);
-        acc = mfma16<ET>(wh[t][kg], xh, acc);
-        acc = mfma16<ET>(wh[t][kg], xl, acc);
-        acc = mfma16<ET>(wl[t][kg], xh, acc);
-      }
+    for (int st = 0; st < 18; ++st) {
+      const int t = st >> 1, kg = st & 1;
+      if (st + 1 < 18) read_x((st + 1) >> 1, (st + 1) & 1, xh[(st + 1) & 1], xl[(st + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);                       // (hipcc otherwise sinks the reads behind the step's second instruction)
+      acc = mfma16<ET>(wh[t][kg], xh[st & 1], acc);
+      acc = mfma16<ET>(wh[t][kg], xl[st & 1], acc);
+      acc = mfma16<ET>(wl[t][kg], xh[st & 1], acc);
+      __builtin_amdgcn_sched_barrier(0);
     }
     // ---- epilogue: acc[r] = row m0 + wave*32 + lr, channel 8*(r>>2) + 4*lh + (r&3)
     const int rbase = m0 + wave * 32;
@@ -523,28 +530,45 @@ __global__ __launch_bounds__(256, 2) void grid_conv_x3_pers32_kernel(const TdnnK
 // the two partial accumulators meet in LDS once per tile - each wave of the pair finishes HALF of the 32 channels (partner's part +
 // its own: one f32 addition, the same whichever wave performs it) and runs that half's epilogue and stores.  64-row tiles, ring of 224
 // rows x 256 B ([chunk][hi | lo], 16-byte slots XOR-swizzled by row & 15), one workgroup per CU.
-// Not the accumulation order of the one-tile kernel (there: chunk 0's taps, then chunk 1's, in one accumulator; here the two chunk
-// sums are added at the end): equal to f32 rounding (~1e-7), not bit for bit; every row still has ONE fixed order whatever the batch.
-struct QPers64 {
-  static constexpr int BM = 64, HALO = 44;                  // >= pitch + 1 of a 40-bin grid (42), a multiple of 4
-  static constexpr int WIN = BM + 2 * HALO;                 // 152
-  static constexpr int RING = 224;                          // >= WIN + BM = 216, a multiple of 16
+// Measured (profiles/r4m_x3_pers64_ab.txt, r4n_pers64_abl.txt, r4o_pers_skew.txt): 282 -> 214 us per layer.  Ablations of the developer
+// build: 230 us as is on that box, 121 without the K loop, 200 without exchange + epilogue, 220 without row fetch / split, 70 without
+// K loop and fetch, 33 with nothing but the loop skeleton - the K loop costs its full 109 us (= the matrix pipe's time for the layer at
+// the clock it runs at) ON TOP of the other phases: the two waves a SIMD holds run the same phase at the same time.  Tried without
+// effect on that sum: 64-row tiles / one 8-wave workgroup per CU (=5), LDS operands one step ahead, two accumulators per wave (kept:
+// they cost nothing), starting the odd workgroup of a CU one K loop late.  What is left is interleaving tile i's epilogue and tile
+// i + 1's row split INTO tile i + 1's K loop by hand (next round).
+// Not the accumulation order of the one-tile kernel (there: chunk 0's taps, then chunk 1's, in one accumulator; here four partial
+// sums - (chunk, k-group) - are added at the end): equal to f32 rounding (~1e-7), not bit for bit; every row still has ONE fixed
+// order whatever the batch.
+// WM = row fragments per tile: 1 -> 32-row tiles, 4 waves, 67 KiB: TWO workgroups per CU (the default: one workgroup's barrier,
+// exchange and epilogue phases run under the other's K loop); 2 -> 64-row tiles, 8 waves, 109 KiB: one workgroup per CU (measured
+// first: 282 -> 214 us per layer).
+template <int WM_> struct QPers64 {
+  static constexpr int WM = WM_, NT = WM * 256, PAIRS = WM * 2;
+  static constexpr int BM = WM * 32, HALO = 44;             // >= pitch + 1 of a 40-bin grid (42), a multiple of 4
+  static constexpr int WIN = BM + 2 * HALO;                 // 120 | 152
+  static constexpr int RING = WM == 1 ? 160 : 224;          // >= WIN + BM = 152 | 216, a multiple of 16
   static constexpr int ROWB = 256;
-  static constexpr int RED_OFF = RING * ROWB;               // 57344: partial accumulators, [parity][pair][half][2][lane] float4
-  static constexpr int SCR_OFF = RED_OFF + 2 * 4 * 4096;    // per wave: 32 rows x 16 channels (+4) on their way to 16-byte stores
+  static constexpr int RED_OFF = RING * ROWB;               // partial accumulators, [parity][pair][half][2][lane] float4
+  static constexpr int SCR_OFF = RED_OFF + 2 * PAIRS * 4096;    // per wave: 32 rows x 16 channels (+4) on their way to 16-byte stores
   static constexpr int SPITCH = 20;
-  static constexpr int PAR_OFF = SCR_OFF + 8 * 32 * SPITCH * 4;
-  static constexpr int LDS = PAR_OFF + 3 * 64 * 4;          // 111360: one workgroup (8 waves) per CU
-  static_assert(RING >= WIN + BM && RING % 16 == 0 && LDS <= 163840, "sliding-window geometry (f32x, 64 channels)");
+  static constexpr int PAR_OFF = SCR_OFF + 4 * WM * 32 * SPITCH * 4;
+  static constexpr int LDS = PAR_OFF + 3 * 64 * 4;          // 68352 | 111360
+  static_assert(RING >= WIN + BM && RING % 16 == 0 && (3 - WM) * LDS <= 163840, "sliding-window geometry (f32x, 64 channels)");
 };
 
-template <int ET>
-__global__ __launch_bounds__(512, 1) void grid_conv_x3_pers64_kernel(const TdnnKernelParams p, const int tiles_per_wg) {
-  using G = QPers64;
+template <int ET, int WM>
+__global__ __launch_bounds__(WM * 256, 3 - WM) void grid_conv_x3_pers64_kernel(const TdnnKernelParams p, const int tiles_per_wg) {
+  using G = QPers64<WM>;
+#ifdef ASV_WITH_ABLATION
+  const int abl = p.tune;           // developer build only (results are garbage): 1 no output stores, 2 no row fetch / split, 4 no K loop, 8 no exchange + epilogue
+#else
+  constexpr int abl = 0;
+#endif
   __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = (wave >> 1) & 1, kh = wave & 1;
+  const int wm = WM == 1 ? 0 : (wave >> 2), wn = (wave >> 1) & 1, kh = wave & 1;
   const int lr = lane & 31, lh = lane >> 5;
   const int n_tiles = p.rows / G::BM;
   const int t_begin = blockIdx.x * tiles_per_wg, t_end = min(t_begin + tiles_per_wg, n_tiles);
@@ -557,7 +581,7 @@ __global__ __launch_bounds__(512, 1) void grid_conv_x3_pers64_kernel(const TdnnK
     lds_par[tid] = src != nullptr ? src[c] : (which == 1 ? 1.0f : 0.0f);
   }
 
-  // ---- rows -> registers -> ring.  A stage = the 64 new rows of one tile: ONE piece (row, 8 channels) per thread
+  // ---- rows -> registers -> ring.  A stage = the BM new rows of one tile: ONE piece (row, 8 channels) per thread
   const float *xg = reinterpret_cast<const float *>(p.x);
   struct Stage { uint4 a, b; uint32_t ok; };
   uint32_t range = 0u;
@@ -599,7 +623,7 @@ __global__ __launch_bounds__(512, 1) void grid_conv_x3_pers64_kernel(const TdnnK
     const int first = t_begin * G::BM - G::HALO;
     Stage st;
 #pragma unroll 1
-    for (int r0 = 0; r0 < G::WIN; r0 += 64) {                // 3 x 64 rows (the last 40 belong to the next tile: rewritten below, harmless)
+    for (int r0 = 0; r0 < G::WIN; r0 += G::BM) {             // whole stages (the rows past the window belong to the next tile: rewritten below, harmless)
       gload(first + r0, st);
       sstore(first + r0, st);
     }
@@ -620,39 +644,59 @@ __global__ __launch_bounds__(512, 1) void grid_conv_x3_pers64_kernel(const TdnnK
   auto one_tile = [&](const int tile, Stage &next, Stage &next2, const uint32_t vbits, uint32_t &vbits_next) {
     const int m0 = tile * G::BM;
     vbits_next = p.row_valid[min((m0 + G::BM + wm * 32) >> 5, last_word)];
-    gload((tile + 2) * G::BM + G::HALO, next2);
+    if (!(abl & 2)) gload((tile + 2) * G::BM + G::HALO, next2);
     const int wb = __builtin_amdgcn_readfirstlane((m0 + G::HALO + wm * 32) % G::RING);
-    f32x16_t acc;
+    // TWO accumulators, k-group 0's steps in one and k-group 1's in the other: a step's three matrix instructions stand back to
+    // back on one accumulator (nothing between them: the lo half is read FIRST, so the wait in front of the first instruction
+    // covers both operands), the reads of the next step follow, and the next step's instructions use the OTHER accumulator.  With one
+    // accumulator every ds_read / s_waitcnt between two dependent matrix instructions cost the ~43-cycle same-accumulator penalty
+    // (MI355X_MICROARCH.md, instruction table): the pipe sat at 0.42 of its peak whatever the tile shape or the read-ahead.
+    f32x16_t acc, acc2;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; acc2[r] = 0.0f; }
+    uint4 xh[2], xl[2];
+    auto read_x = [&](const int t, const int kg, uint4 &h, uint4 &l) {
       const int d = __builtin_amdgcn_readlane(v_taps, t);
       int rr = wb + lr + d;
       rr = rr < 0 ? rr + G::RING : (rr >= G::RING ? rr - G::RING : rr);
       const unsigned char *rowp = lds + rr * G::ROWB;
       const int sw = rr & 15;
+      l = *reinterpret_cast<const uint4 *>(rowp + (((kh * 8 + 4 + kg * 2 + lh) ^ sw) << 4));
+      h = *reinterpret_cast<const uint4 *>(rowp + (((kh * 8 + kg * 2 + lh) ^ sw) << 4));
+    };
+    read_x(0, 0, xh[0], xl[0]);
 #pragma unroll
-      for (int kg = 0; kg < 2; ++kg) {
-        const uint4 xh = *reinterpret_cast<const uint4 *>(rowp + (((kh * 8 + kg * 2 + lh) ^ sw) << 4));
-        const uint4 xl = *reinterpret_cast<const uint4 *>(rowp + (((kh * 8 + 4 + kg * 2 + lh) ^ sw) << 4));
-        acc = mfma16<ET>(wh[t][kg], xh, acc);
-        acc = mfma16<ET>(wh[t][kg], xl, acc);
-        acc = mfma16<ET>(wl[t][kg], xh, acc);
+    for (int st = 0; st < 18; ++st) {
+      if (abl & 4) break;
+      const int t = st >> 1, kg = st & 1;
+      if (st + 1 < 18) read_x((st + 1) >> 1, (st + 1) & 1, xh[(st + 1) & 1], xl[(st + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);                       // (hipcc otherwise sinks the reads behind the step's second instruction)
+      if (kg == 0) {
+        acc = mfma16<ET>(wh[t][kg], xh[st & 1], acc);
+        acc = mfma16<ET>(wh[t][kg], xl[st & 1], acc);
+        acc = mfma16<ET>(wl[t][kg], xh[st & 1], acc);
+      } else {
+        acc2 = mfma16<ET>(wh[t][kg], xh[st & 1], acc2);
+        acc2 = mfma16<ET>(wh[t][kg], xl[st & 1], acc2);
+        acc2 = mfma16<ET>(wl[t][kg], xh[st & 1], acc2);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = __fadd_rn(acc[r], acc2[r]);       // this wave's part: k-group 0's sum + k-group 1's
     // ---- the pair's accumulators meet: this wave hands over the half the partner finishes (registers 8 (1 - kh) .. + 8)
-    float4 *red = reinterpret_cast<float4 *>(lds + G::RED_OFF) + ((tile & 1) * 4 + (wave >> 1)) * 256;
-    {
+    float4 *red = reinterpret_cast<float4 *>(lds + G::RED_OFF) + ((tile & 1) * G::PAIRS + (wave >> 1)) * 256;
+    if (!(abl & 8)) {
       const int o = (1 - kh) * 8;
       red[((1 - kh) * 2 + 0) * 64 + lane] = make_float4(acc[o + 0], acc[o + 1], acc[o + 2], acc[o + 3]);
       red[((1 - kh) * 2 + 1) * 64 + lane] = make_float4(acc[o + 4], acc[o + 5], acc[o + 6], acc[o + 7]);
     }
     // tile + 1's rows: split and into the ring rows behind the window (nobody reads them during this tile)
-    sstore((tile + 1) * G::BM + G::HALO, next);
+    if (!(abl & 2)) sstore((tile + 1) * G::BM + G::HALO, next);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if (abl & 8) return;
     // ---- epilogue of this wave's 16 channels: rows m0 + wm*32 + lr, channels cbase + 8*j + 4*lh + e (accumulator register 8*kh + 4*j + e)
     const int rbase = m0 + wm * 32;
     const bool valid = (vbits >> lr) & 1u;
@@ -678,7 +722,7 @@ __global__ __launch_bounds__(512, 1) void grid_conv_x3_pers64_kernel(const TdnnK
     for (int it = 0; it < 2; ++it) {
       const int frow = it * 16 + (lane >> 2), slot = lane & 3;
       const float4 v = *reinterpret_cast<const float4 *>(scr + frow * G::SPITCH + slot * 4);
-      *reinterpret_cast<float4 *>(yg + (size_t)(rbase + frow) * p.ldy + cbase + slot * 4) = v;
+      if (!(abl & 1)) *reinterpret_cast<float4 *>(yg + (size_t)(rbase + frow) * p.ldy + cbase + slot * 4) = v;
     }
   };
   uint32_t va = p.row_valid[min((t_begin * G::BM + wm * 32) >> 5, last_word)], vb = 0u;
@@ -800,7 +844,7 @@ int launch_grid_conv_x3(const TdnnKernelParams &p, hipStream_t s) {
     int halo = 0;
     for (int t = 0; t < p.n_taps; ++t) halo = std::max(halo, std::abs(p.taps[t]));
     if (pers && g.id == 0 && plain_epilogue(p) && p.n_taps == 9 && p.cin_pad == 32 && p.cout_store == 32 && halo <= QPers32::HALO && p.rows % QPers32::BM == 0 &&
-        p.rows >= QPers32::RING) {
+        p.rows >= QPers32::RING && (pers & 8) == 0) {
       int dev = 0, cus = 256;
       if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
       const int n_tiles = p.rows / QPers32::BM, wgs = std::min(n_tiles, cus * 2), per_wg = (n_tiles + wgs - 1) / wgs;
@@ -810,14 +854,25 @@ int launch_grid_conv_x3(const TdnnKernelParams &p, hipStream_t s) {
       ASV_HIP_CHECK(hipGetLastError());
       return ASV_OK;
     }
-    if (pers && g.id == 1 && plain_epilogue(p) && p.n_taps == 9 && p.cin_pad == 64 && p.cout_store == 64 && halo <= QPers64::HALO && p.rows % QPers64::BM == 0 &&
-        p.rows >= QPers64::RING && (pers & 2) == 0) {
+    if (pers && g.id == 1 && plain_epilogue(p) && p.n_taps == 9 && p.cin_pad == 64 && p.cout_store == 64 && halo <= QPers64<1>::HALO && p.rows % 64 == 0 &&
+        p.rows >= QPers64<2>::RING && (pers & 2) == 0) {
       int dev = 0, cus = 256;
       if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      const int n_tiles = p.rows / QPers64::BM, wgs = std::min(n_tiles, cus), per_wg = (n_tiles + wgs - 1) / wgs;
-      const dim3 pgrid((n_tiles + per_wg - 1) / per_wg), pblock(512);
-      if (p.x3_et == ET_F16) hipLaunchKernelGGL((grid_conv_x3_pers64_kernel<ET_F16>), pgrid, pblock, 0, s, p, per_wg);
-      else hipLaunchKernelGGL((grid_conv_x3_pers64_kernel<ET_BF16>), pgrid, pblock, 0, s, p, per_wg);
+      const int wm = (pers & 4) ? 2 : 1;                               // ASV_AMD_X3_PERS=5: the 64-row / 8-wave form
+#ifdef ASV_WITH_ABLATION
+      TdnnKernelParams pa = p;
+      pa.tune = live && getenv("ASV_AMD_X3_PERS_ABL") != nullptr ? atoi(getenv("ASV_AMD_X3_PERS_ABL")) : 0;
+      const TdnnKernelParams &p = pa;
+#endif
+      const int n_tiles = p.rows / (32 * wm), wgs = std::min(n_tiles, cus * (3 - wm)), per_wg = (n_tiles + wgs - 1) / wgs;
+      const dim3 pgrid((n_tiles + per_wg - 1) / per_wg), pblock(256 * wm);
+      if (wm == 1) {
+        if (p.x3_et == ET_F16) hipLaunchKernelGGL((grid_conv_x3_pers64_kernel<ET_F16, 1>), pgrid, pblock, 0, s, p, per_wg);
+        else hipLaunchKernelGGL((grid_conv_x3_pers64_kernel<ET_BF16, 1>), pgrid, pblock, 0, s, p, per_wg);
+      } else {
+        if (p.x3_et == ET_F16) hipLaunchKernelGGL((grid_conv_x3_pers64_kernel<ET_F16, 2>), pgrid, pblock, 0, s, p, per_wg);
+        else hipLaunchKernelGGL((grid_conv_x3_pers64_kernel<ET_BF16, 2>), pgrid, pblock, 0, s, p, per_wg);
+      }
       ASV_HIP_CHECK(hipGetLastError());
       return ASV_OK;
     }
