@@ -100,7 +100,9 @@ void asv_net_destroy(asv_net_t *net);
  * ceil(T / 2^time_shift) frames x `pitch` rows ((time, frequency) positions, frequency fastest),
  * of which the first `width` rows of every frame are real and the rest zero padding.  A 3x3
  * convolution (resnet.py:12-15) over such a buffer is a 9-tap layer with row offsets dt*pitch + df.
- * Returns the domain id (>= 2). */
+ * 1 <= width < pitch <= 83; or width = pitch = 1: a SEQUENCE domain - one row per frame of the subsampled time axis, two
+ * zero rows between utterances - on which frame-level layers (|tap| <= 2) and every pooling run as on the frames domain
+ * (asv_net_add_grid_flatten writes the 2-D trunk's [B, C*F', T'] reshape there).  Returns the domain id (>= 2). */
 int  asv_net_define_grid(asv_net_t *net, int time_shift, int width, int pitch);
 
 /* Declares an activation buffer; returns its id (>= 1) or a negative error. */
