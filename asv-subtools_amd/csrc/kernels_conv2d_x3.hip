@@ -535,8 +535,8 @@ __global__ __launch_bounds__(256, 2) void grid_conv_x3_pers32_kernel(const TdnnK
 // K loop and fetch, 33 with nothing but the loop skeleton - the K loop costs its full 109 us (= the matrix pipe's time for the layer at
 // the clock it runs at) ON TOP of the other phases: the two waves a SIMD holds run the same phase at the same time.  Tried without
 // effect on that sum: 64-row tiles / one 8-wave workgroup per CU (=5), LDS operands one step ahead, two accumulators per wave (kept:
-// they cost nothing), starting the odd workgroup of a CU one K loop late.  What is left is interleaving tile i's epilogue and tile
-// i + 1's row split INTO tile i + 1's K loop by hand (next round).
+// they cost nothing), starting the odd workgroup of a CU one K loop late; and (template parameter PIPE, the default) tile i's exchange read + epilogue + stores and the row split placed BETWEEN the steps of tile i + 1's K loop: 220 -> 217 us (profiles/r4p_pers64_pipe_ab.txt) - correct, kept, not the answer either.
+// Open: what the two waves of a SIMD wait for while neither the matrix pipe (0.48), nor LDS (0.32 of its bandwidth), nor HBM (2.4 TB/s) is busy - next: an SQ-counter pass of this kernel (none was left in the round's GPU budget).
 // Not the accumulation order of the one-tile kernel (there: chunk 0's taps, then chunk 1's, in one accumulator; here four partial
 // sums - (chunk, k-group) - are added at the end): equal to f32 rounding (~1e-7), not bit for bit; every row still has ONE fixed
 // order whatever the batch.
@@ -557,7 +557,7 @@ template <int WM_> struct QPers64 {
   static_assert(RING >= WIN + BM && RING % 16 == 0 && (3 - WM) * LDS <= 163840, "sliding-window geometry (f32x, 64 channels)");
 };
 
-template <int ET, int WM>
+template <int ET, int WM, bool PIPE = false>
 __global__ __launch_bounds__(WM * 256, 3 - WM) void grid_conv_x3_pers64_kernel(const TdnnKernelParams p, const int tiles_per_wg) {
   using G = QPers64<WM>;
 #ifdef ASV_WITH_ABLATION
@@ -726,10 +726,105 @@ __global__ __launch_bounds__(WM * 256, 3 - WM) void grid_conv_x3_pers64_kernel(c
     }
   };
   uint32_t va = p.row_valid[min((t_begin * G::BM + wm * 32) >> 5, last_word)], vb = 0u;
+  if constexpr (!PIPE) {
 #pragma unroll 1
-  for (int tile = t_begin; tile < t_end; tile += 2) {
-    one_tile(tile, sa, sb, va, vb);
-    if (tile + 1 < t_end) one_tile(tile + 1, sb, sa, vb, va);
+    for (int tile = t_begin; tile < t_end; tile += 2) {
+      one_tile(tile, sa, sb, va, vb);
+      if (tile + 1 < t_end) one_tile(tile + 1, sb, sa, vb, va);
+    }
+  } else {
+    // PIPE: the phases of a tile that are not matrix work - the exchange's second half + epilogue + stores of tile i, the split of tile
+    // i + 2's rows... of tile i + 1's rows - are placed INSIDE tile i + 1's K loop (between its steps): the two waves a SIMD holds walk
+    // the same phases at the same time (ablations above), so what a wave issues between its matrix instructions runs while the other
+    // wave's matrix instructions occupy the pipe, and the stretch outside the K loop shrinks to the exchange write and the barrier.
+    // The first pass of the loop finishes a tile of zeros onto the first tile's own rows (no branch: every vector-memory operation
+    // of the loop stays unconditional); the real values follow from the same wave, one tile later.
+    struct Pend { float mine[8]; uint32_t vbits; int m0, par; };
+    auto epi_a = [&](const Pend &pd) {
+      const float4 *red = reinterpret_cast<const float4 *>(lds + G::RED_OFF) + (pd.par * G::PAIRS + (wave >> 1)) * 256;
+      const bool valid = (pd.vbits >> lr) & 1u;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float4 o4 = red[(kh * 2 + j) * 64 + lane];
+        const float other[4] = {o4.x, o4.y, o4.z, o4.w};
+        const int chl = cbase + 8 * j + 4 * lh;
+        const float4 b4 = *reinterpret_cast<const float4 *>(lds_par + chl);
+        const float4 sc4 = *reinterpret_cast<const float4 *>(lds_par + 64 + chl);
+        const float4 sh4 = *reinterpret_cast<const float4 *>(lds_par + 128 + chl);
+        const float b[4] = {b4.x, b4.y, b4.z, b4.w}, sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float sum = __fadd_rn(pd.mine[j * 4 + e], other[e]);
+          const float z = fmaxf(fmaf(sum, unscale, b[e]), act_lo) * sc[e] + sh[e];
+          y[e] = valid ? z : 0.0f;
+        }
+        *reinterpret_cast<float4 *>(scr + lr * G::SPITCH + 8 * j + 4 * lh) = make_float4(y[0], y[1], y[2], y[3]);
+      }
+    };
+    auto epi_b = [&](const Pend &pd) {
+      const int rbase = pd.m0 + wm * 32;
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int frow = it * 16 + (lane >> 2), slot = lane & 3;
+        const float4 v = *reinterpret_cast<const float4 *>(scr + frow * G::SPITCH + slot * 4);
+        *reinterpret_cast<float4 *>(yg + (size_t)(rbase + frow) * p.ldy + cbase + slot * 4) = v;
+      }
+    };
+    Pend pd;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pd.mine[j] = 0.0f;
+    pd.vbits = 0u; pd.m0 = t_begin * G::BM; pd.par = 0;
+    auto tile_pipe = [&](const int tile, Stage &next, Stage &next2, const uint32_t vbits, uint32_t &vbits_next) {
+      const int m0 = tile * G::BM;
+      vbits_next = p.row_valid[min((m0 + G::BM + wm * 32) >> 5, last_word)];
+      gload((tile + 2) * G::BM + G::HALO, next2);
+      const int wb = __builtin_amdgcn_readfirstlane((m0 + G::HALO + wm * 32) % G::RING);
+      f32x16_t acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+      uint4 xh[2], xl[2];
+      auto read_x = [&](const int t, const int kg, uint4 &h, uint4 &l) {
+        const int d = __builtin_amdgcn_readlane(v_taps, t);
+        int rr = wb + lr + d;
+        rr = rr < 0 ? rr + G::RING : (rr >= G::RING ? rr - G::RING : rr);
+        const unsigned char *rowp = lds + rr * G::ROWB;
+        const int sw = rr & 15;
+        l = *reinterpret_cast<const uint4 *>(rowp + (((kh * 8 + 4 + kg * 2 + lh) ^ sw) << 4));
+        h = *reinterpret_cast<const uint4 *>(rowp + (((kh * 8 + kg * 2 + lh) ^ sw) << 4));
+      };
+      read_x(0, 0, xh[0], xl[0]);
+#pragma unroll
+      for (int st = 0; st < 18; ++st) {
+        const int t = st >> 1, kg = st & 1;
+        if (st + 1 < 18) read_x((st + 1) >> 1, (st + 1) & 1, xh[(st + 1) & 1], xl[(st + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        acc = mfma16<ET>(wh[t][kg], xh[st & 1], acc);
+        acc = mfma16<ET>(wh[t][kg], xl[st & 1], acc);
+        acc = mfma16<ET>(wl[t][kg], xh[st & 1], acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (st == 2) { epi_a(pd); __builtin_amdgcn_sched_barrier(0); }             // the previous tile: partner's part + own, epilogue -> the wave's LDS tile
+        if (st == 7) { epi_b(pd); __builtin_amdgcn_sched_barrier(0); }             // ... -> 16-byte stores
+        if (st == 12) { sstore((tile + 1) * G::BM + G::HALO, next); __builtin_amdgcn_sched_barrier(0); }      // the next tile's rows -> ring
+      }
+      float4 *red = reinterpret_cast<float4 *>(lds + G::RED_OFF) + ((tile & 1) * G::PAIRS + (wave >> 1)) * 256;
+      const int o = (1 - kh) * 8;
+      red[((1 - kh) * 2 + 0) * 64 + lane] = make_float4(acc[o + 0], acc[o + 1], acc[o + 2], acc[o + 3]);
+      red[((1 - kh) * 2 + 1) * 64 + lane] = make_float4(acc[o + 4], acc[o + 5], acc[o + 6], acc[o + 7]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pd.mine[j] = acc[kh * 8 + j];
+      pd.vbits = vbits; pd.m0 = m0; pd.par = tile & 1;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    };
+#pragma unroll 1
+    for (int tile = t_begin; tile < t_end; tile += 2) {
+      tile_pipe(tile, sa, sb, va, vb);
+      if (tile + 1 < t_end) tile_pipe(tile + 1, sb, sa, vb, va);
+    }
+    epi_a(pd);
+    epi_b(pd);
   }
   x3_publish_range(range, p.status);
 }
@@ -866,7 +961,10 @@ int launch_grid_conv_x3(const TdnnKernelParams &p, hipStream_t s) {
 #endif
       const int n_tiles = p.rows / (32 * wm), wgs = std::min(n_tiles, cus * (3 - wm)), per_wg = (n_tiles + wgs - 1) / wgs;
       const dim3 pgrid((n_tiles + per_wg - 1) / per_wg), pblock(256 * wm);
-      if (wm == 1) {
+      if (wm == 1 && (pers & 16) == 0) {                               // (default) the tile loop with the non-matrix phases inside the K loop
+        if (p.x3_et == ET_F16) hipLaunchKernelGGL((grid_conv_x3_pers64_kernel<ET_F16, 1, true>), pgrid, pblock, 0, s, p, per_wg);
+        else hipLaunchKernelGGL((grid_conv_x3_pers64_kernel<ET_BF16, 1, true>), pgrid, pblock, 0, s, p, per_wg);
+      } else if (wm == 1) {                                            // ASV_AMD_X3_PERS=17: phase after phase
         if (p.x3_et == ET_F16) hipLaunchKernelGGL((grid_conv_x3_pers64_kernel<ET_F16, 1>), pgrid, pblock, 0, s, p, per_wg);
         else hipLaunchKernelGGL((grid_conv_x3_pers64_kernel<ET_BF16, 1>), pgrid, pblock, 0, s, p, per_wg);
       } else {
