@@ -38,6 +38,9 @@ int main(void) {
   printf("%zu %zu %zu %zu %zu\n", sizeof(asv_tdnn_desc_t), sizeof(asv_pool_desc_t), sizeof(asv_attpool_desc_t), sizeof(asv_eltwise_desc_t), sizeof(asv_kernel_time_t));
   printf("%zu %zu %zu %zu\n", offsetof(asv_tdnn_desc_t, weight), offsetof(asv_tdnn_desc_t, scale), offsetof(asv_tdnn_desc_t, res_ch_off), offsetof(asv_eltwise_desc_t, scale));
   printf("%zu %zu\n", offsetof(asv_kernel_time_t, total_ms), offsetof(asv_kernel_time_t, flops));
+  printf("%zu %zu %zu %zu %zu %zu\n", sizeof(asv_lde_desc_t), sizeof(asv_res2_desc_t), sizeof(asv_grid_input_desc_t), sizeof(asv_grid_flatten_desc_t),
+         sizeof(asv_im2col_desc_t), sizeof(asv_fbank_opts_t));
+  printf("%zu %zu %zu %zu\n", offsetof(asv_im2col_desc_t, df), offsetof(asv_im2col_desc_t, b_buf), offsetof(asv_im2col_desc_t, act), offsetof(asv_grid_flatten_desc_t, out_buf));
   return 0;
 }''')
     exe = tmp_path / "sizes"
@@ -48,6 +51,10 @@ int main(void) {
     offs = [int(v) for v in lines[1].split()]
     assert offs == [capi.TdnnDesc.weight.offset, capi.TdnnDesc.scale.offset, capi.TdnnDesc.res_ch_off.offset, capi.EltwiseDesc.scale.offset]
     assert [int(v) for v in lines[2].split()] == [capi.KernelTime.total_ms.offset, capi.KernelTime.flops.offset]
+    # every other struct of the header, incl. the ones round 4 touched (the strided gather's elementwise prologue, grid_flatten)
+    assert [int(v) for v in lines[3].split()] == [C.sizeof(capi.LdeDesc), C.sizeof(capi.Res2Desc), C.sizeof(capi.GridInputDesc), C.sizeof(capi.GridFlattenDesc),
+                                                  C.sizeof(capi.Im2colDesc), C.sizeof(capi.FbankOpts)]
+    assert [int(v) for v in lines[4].split()] == [capi.Im2colDesc.df.offset, capi.Im2colDesc.b_buf.offset, capi.Im2colDesc.act.offset, capi.GridFlattenDesc.out_buf.offset]
 
 
 def test_no_gpu_calls_fail_loudly_not_silently():
