@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256, 2) void grid_conv_x3_pers32_kernel(const TdnnK
 // the clock it runs at) ON TOP of the other phases: the two waves a SIMD holds run the same phase at the same time.  Tried without
 // effect on that sum: 64-row tiles / one 8-wave workgroup per CU (=5), LDS operands one step ahead, two accumulators per wave (kept:
 // they cost nothing), starting the odd workgroup of a CU one K loop late; and (template parameter PIPE, the default) tile i's exchange read + epilogue + stores and the row split placed BETWEEN the steps of tile i + 1's K loop: 220 -> 217 us (profiles/r4p_pers64_pipe_ab.txt) - correct, kept, not the answer either.
-// Open: what the two waves of a SIMD wait for while neither the matrix pipe (0.48), nor LDS (0.32 of its bandwidth), nor HBM (2.4 TB/s) is busy - next: an SQ-counter pass of this kernel (none was left in the round's GPU budget).
+// Working explanation (instruction count of the loop body, tools/r5_pers64_sq.sh is the check): a wave issues ~660 instructions per 32-row tile - 54 matrix (one dependent chain), ~300 VALU (ring / swizzle addresses of 36 reads, split, epilogue), ~80 SALU, 30 s_nop - IN ORDER, two waves per SIMD: ~11 cycles each = the 7.2 k cycles per tile measured; the pipe is idle half the time because the wave is busy elsewhere, not because it waits for data.
 // Not the accumulation order of the one-tile kernel (there: chunk 0's taps, then chunk 1's, in one accumulator; here four partial
 // sums - (chunk, k-group) - are added at the end): equal to f32 rounding (~1e-7), not bit for bit; every row still has ONE fixed
 // order whatever the batch.
