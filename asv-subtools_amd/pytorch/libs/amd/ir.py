@@ -686,6 +686,13 @@ def sym_batch_norm(x, running_mean, running_var, weight=None, bias=None, trainin
     if training or running_mean is None:
         raise TraceError("batch_norm in training mode / without running stats cannot be traced")
     scale, shift = fold_batchnorm(_np(running_mean), _np(running_var), _np(weight), _np(bias), eps)
+    order = getattr(x, "col_order", None)
+    if order is not None:          # a pooled tensor whose columns are a permutation (with gaps) of the reference's: permute the constants with it
+        if int((order >= 0).sum()) != scale.shape[0]:
+            raise TraceError("batch_norm over %d channels applied to a tensor of %d" % (scale.shape[0], int((order >= 0).sum())))
+        sc, sh = np.ones(order.shape[0], dtype=scale.dtype), np.zeros(order.shape[0], dtype=shift.dtype)
+        sc[order >= 0], sh[order >= 0] = scale[order[order >= 0]], shift[order[order >= 0]]
+        return Sym(x.graph, x.graph.eltwise(x.view, scale=sc, shift=sh), x.rank, col_order=order)
     return Sym(x.graph, x.graph.eltwise(x.view, scale=scale, shift=shift), x.rank)
 
 

@@ -6,8 +6,10 @@ sub-module names (hence state_dict keys), `extract_embedding` positions and
 `extract_embedding_whole` / `embedding_dim` (reference
 /root/reference/pytorch/model/ecapa_tdnn_xvector.py: Res2NetBlock 17-75, SE_Connect 97-111,
 SE_Res2Block 118-149, AttentiveStatsPool 156-188, ECAPA_TDNN 200-482) - so reference
-`nnet.config` / `*.params` files work unchanged.  Only the default "ecpa-attentive" pooling
-and plain statistics pooling are on the hot path; the other pooling options raise.
+`nnet.config` / `*.params` files work unchanged.  Poolings: the default "ecpa-attentive", "attentive"
+(AttentiveStatisticsPooling, reference :275-281) and plain statistics pooling.  "multi-head", "global-multi"
+and "multi-resolution" cannot be constructed in the reference either (its pooling defaults hand
+`time_attention` to AttentionAlphaComponent: TypeError) and "mqmha" is out of scope: they raise.
 
 All modules are parameter holders whose forward() records fused ops for libasv_amd.so.
 """
@@ -127,9 +129,15 @@ class ECAPA_TDNN(TopVirtualNnet):
         if pooling == "ecpa-attentive":
             self.stats = AttentiveStatsPool(mfa_dim, pooling_params["hidden_size"], pooling_params["time_attention"])
             self.bn_stats = nn.BatchNorm1d(mfa_dim * 2, **ecapa_params["bn_params"])
-        elif pooling in ("attentive", "mqmha", "multi-head", "global-multi", "multi-resolution"):
-            raise NotImplementedError("pooling='%s' is a selectable option of the reference that the MI355X path does not implement "
-                                      "(SURVEY.md section 2, row 3)" % pooling)
+        elif pooling == "attentive":                                   # reference :275-281 (needs pooling_params["context"], like there)
+            self.stats = AttentiveStatisticsPooling(mfa_dim, hidden_size=pooling_params["hidden_size"], context=pooling_params["context"], stddev=stddev)
+            self.bn_stats = nn.BatchNorm1d(mfa_dim * 2, **ecapa_params["bn_params"])
+        elif pooling in ("multi-head", "global-multi", "multi-resolution"):
+            raise TypeError("pooling='%s': the reference's ECAPA_TDNN cannot build this option either - its pooling defaults pass "
+                            "`time_attention` on to AttentionAlphaComponent, which does not take it (ecapa_tdnn_xvector.py:213-217, 296-316)" % pooling)
+        elif pooling == "mqmha":
+            raise NotImplementedError("pooling='mqmha' (MQMHASP) is a selectable option of the reference outside the MI355X extraction path "
+                                      "(SURVEY.md section 2, row 3)")
         else:
             self.stats = StatisticsPooling(mfa_dim, stddev=stddev)
             self.bn_stats = nn.BatchNorm1d(mfa_dim * 2)

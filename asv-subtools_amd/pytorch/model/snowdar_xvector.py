@@ -5,8 +5,8 @@ connection, optional tdnn6) for the MI355X extraction path - SURVEY.md section 8
 Constructor signature, sub-module names (=> state_dict keys) and the three `extract_embedding` positions follow the
 reference blueprint (/root/reference/pytorch/model/snowdar_xvector.py:13-278); that file also traces unmodified against
 this package's `libs.nnet`.  What is an extraction-time no-op there (mixup, SpecAugment, dropouts, margin / step
-parameters) is accepted and ignored; what would change the extraction graph in a way that is not built yet (the
-multi-head / LDE / xi-vector poolings) raises at construction.
+parameters) is accepted and ignored.  Every pooling the reference's constructor selects is built: statistics, attentive,
+multi-head, multi-resolution, LDE and the two xi-vector poolings (libs/nnet/pooling.py).
 """
 
 import sys

@@ -180,6 +180,11 @@ CASES = {
                        creation="ResNetXvector(40,10,training=False,pooling='lde',pooling_params={'num_head':8},"
                                 "resnet_params={'layers':[1,1,1,1],'planes':[16,32,64,128],'full_pre_activation':False})",
                        dim=40, utts=[(140, 6000), (33, 6001)], wseed=19),
+    # ECAPA with the reference's other constructible pooling: AttentiveStatisticsPooling with time context (ecapa_tdnn_xvector.py:275-281)
+    "ecapa_attentive": dict(blueprint="ecapa_tdnn_xvector.py",
+                            creation="ECAPA_TDNN(40,10,training=False,pooling='attentive',pooling_params={'hidden_size':64,'context':[-1,0,1]},"
+                                     "ecapa_params={'channels':512,'embd_dim':128,'mfa_conv':768})",
+                            dim=40, utts=[(150, 6100), (37, 6101)], wseed=20),
     "resnet34_plain": dict(blueprint="resnet_xvector.py",
                            creation="ResNetXvector(61,10,training=False,resnet_params={'full_pre_activation':False})",
                            dim=61, utts=[(150, 5100), (77, 5101)], wseed=7),

@@ -207,6 +207,63 @@ def test_resnet_frame_weighting_poolings_reproduce_reference_on_cpu(name, kinds)
         assert rel_err(ir_interp.extract(graph, x), ref) < 3e-5, (name, len(x))
 
 
+def test_ecapa_with_attentive_statistics_pooling_reproduces_reference_on_cpu():
+    """ECAPA_TDNN(pooling='attentive') - the one further pooling option the reference's ECAPA constructor can build
+    (ecapa_tdnn_xvector.py:275-281; 'multi-head' / 'global-multi' / 'multi-resolution' die there with a TypeError and raise the same
+    here): AttentiveStatisticsPooling with time context behind the MFA layer, eval BatchNorm over the pooled statistics.  Golden
+    vectors: the reference's outputs (oracle/gen_golden.py ecapa_attentive)."""
+    from libs.amd import ir
+    g, sd, model = helpers.golden_model("ecapa_attentive")
+    graph = ir.trace(model, type(model).extract_embedding.__wrapped_body__, int(g["dim"]))
+    assert [op.kind for op in graph.ops if op.kind in ("attpool", "pool")][-1] == "attpool"
+    for x, ref in zip(helpers.golden_feats(g), g["embeddings"]):
+        assert rel_err(ir_interp.extract(graph, x), ref) < 2e-5
+
+
+def test_batch_norm_over_a_pooled_tensor_in_device_column_order():
+    """F.batch_norm applied to a pooled tensor whose device columns are a permutation (with alignment gaps) of the reference's -
+    the global multi-head poolings' [mean_h | std_h] blocks - permutes its constants with the columns and keeps the gaps at zero:
+    pooling -> BatchNorm1d -> affine traced in one graph equals the same affine applied to the hand-normalised pooled statistics."""
+    import torch
+    from libs.amd import ir
+    from libs.nnet import GlobalMultiHeadAttentionPooling, TdnnAffine
+    from libs.amd import synth
+    C, H = 24, 3
+
+    class Probe(torch.nn.Module):
+        def __init__(self, with_bn):
+            super().__init__()
+            self.pool = GlobalMultiHeadAttentionPooling(C, num_head=H, share=True, affine_layers=1)
+            self.bn = torch.nn.BatchNorm1d(2 * C * H) if with_bn else None
+            self.out = TdnnAffine(2 * C * H, 8)
+
+        def body(self, x):
+            y = self.pool(x)
+            if self.bn is not None:
+                y = self.bn(y)
+            return self.out(y)
+
+    rs = np.random.RandomState(3)
+    with_bn, plain = Probe(True), Probe(False)
+    sd = {k: torch.from_numpy(rs.randn(*v.shape).astype(np.float32) * 0.3) for k, v in with_bn.state_dict().items() if "num_batches" not in k}
+    sd["bn.running_var"] = sd["bn.running_var"].abs() + 0.5
+    with_bn.load_state_dict(sd, strict=False)
+    plain.load_state_dict({k: v for k, v in sd.items() if not k.startswith("bn.")}, strict=False)
+    x = synth.synth_feats(57, C, 77)
+    got = ir_interp.extract(ir.trace(with_bn, Probe.body, C), x)
+    # the same by hand: pooled statistics in the REFERENCE's column order = what an identity affine reads
+    eye = Probe(False)
+    eye.load_state_dict({k: v for k, v in sd.items() if k.startswith("pool.")}, strict=False)
+    eye.out = TdnnAffine(2 * C * H, 2 * C * H)
+    with torch.no_grad():
+        eye.out.weight.copy_(torch.eye(2 * C * H)[:, :, None]); eye.out.bias.zero_()
+    stats = ir_interp.extract(ir.trace(eye, Probe.body, C), x).astype(np.float64)
+    bn = {k[3:]: v.numpy().astype(np.float64) for k, v in sd.items() if k.startswith("bn.")}
+    normed = (stats - bn["running_mean"]) / np.sqrt(bn["running_var"] + 1e-5) * bn["weight"] + bn["bias"]
+    want = sd["out.weight"].numpy()[:, :, 0].astype(np.float64) @ normed + sd["out.bias"].numpy().reshape(-1)
+    assert rel_err(got, want) < 1e-5
+
+
 REF_MODEL_DIR = "/root/reference/pytorch/model"
 
 
@@ -216,6 +273,8 @@ REF_MODEL_DIR = "/root/reference/pytorch/model"
                                                        ("resnet_xvector.py", "ResNetXvector(61,10,training=False,resnet_params={'full_pre_activation':False})", "resnet34_plain"),
                                                        ("resnet_xvector.py", "ResNetXvector(40,10,training=False,pooling='attentive',pooling_params={'hidden_size':32,'context':[-1,0,1]},"
                                                         "resnet_params={'layers':[1,1,1,1],'planes':[16,32,64,128],'use_se':True,'full_pre_activation':False})", "resnet_attentive"),
+                                                       ("ecapa_tdnn_xvector.py", "ECAPA_TDNN(40,10,training=False,pooling='attentive',pooling_params={'hidden_size':64,'context':[-1,0,1]},"
+                                                        "ecapa_params={'channels':512,'embd_dim':128,'mfa_conv':768})", "ecapa_attentive"),
                                                        ("extended_xvector.py", "ExtendedXvector(40,10,training=False)", "extended_far"),
                                                        ("snowdar_xvector.py", "Xvector(40,10,training=False,extend=True,skip_connection=True,SE=True,extracted_embedding='near')",
                                                         "snowdar_full_near"),
