@@ -184,8 +184,8 @@ def score_normalize(scores, enroll_cohort, test_cohort, enroll_idx, test_idx, to
     # device selection - which is also what the reference's pandas groupby().mean() / .std() / sort_values().head() do with it:
     # skipna, NaN sorted last.)
     if _debug_checks() and (bool(torch.isnan(ec).any().item()) or bool(torch.isnan(tc).any().item())):
-        raise ValueError("score_normalize: NaN in the cohort scores (pandas would propagate it into every statistic; the device "
-                         "selection orders keys and would silently skip it)")
+        raise ValueError("score_normalize: NaN in the cohort scores (the device selection orders keys and skips it, as the reference's "
+                         "pandas groupby().mean() / .std() / sort_values().head() do - silently in both; ASV_AMD_DEBUG_CHECKS=1 makes it loud)")
     out = torch.empty_like(s)
     capi.check(capi.lib().asv_score_norm(_ptr(ec), ec.shape[0], _ptr(tc), tc.shape[0], ec.shape[1], _ptr(ei), _ptr(ti), _ptr(s), s.shape[0],
                                          int(top_n), int(bool(cross_select)), _ptr(out), _stream(s)), "asv_score_norm")

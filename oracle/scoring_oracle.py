@@ -174,7 +174,8 @@ def score_norm(enroll_cohort, test_cohort, ei, ti, scores, top_n=0, cross_select
     """S-norm (top_n <= 0) / AS-norm of score/ScoreNormalization.py:70-179 on dense score matrices
     enroll_cohort [E, C], test_cohort [T, C] (the reference works on <key, key, score> text rows; the recipe
     scores every enrol / test vector against every cohort vector, gather_results_from_epochs.sh:103-183).
-    pandas semantics: mean and *sample* std (ddof = 1) of the selected cohort scores, float64;
+    pandas semantics: mean and *sample* std (ddof = 1) of the selected cohort scores, float64 (FINITE scores: pandas skips a NaN
+    cohort score - and so does the device selection -, numpy's mean here would propagate it; no caller produces one);
     normed = 0.5 * ((s - mu_e) / sd_e + (s - mu_t) / sd_t)                       (lines 104-105, 171-175).
     AS-norm: the top_n largest cohort scores per row (124-126, 150-151); cross_select: the enrol-side statistics
     of trial (e, t) use the cohort vectors that are top_n for t and vice versa (139-148)."""
