@@ -108,3 +108,15 @@ def test_score_norm_oracle_edge_cases():
     mu_t, sd_t = (0.8 + 0.6) / 2, np.std([np.float32(0.8), np.float32(0.6)], ddof=1)
     assert abs(out[0] - 0.5 * ((0.7 - mu_e) / sd_e + (0.7 - mu_t) / sd_t)) < 1e-6
     assert np.isnan(S.score_norm(ec, tc, [0], [0], [0.7], top_n=1)[0])   # one score: sample std undefined, NaN like pandas
+
+
+def test_pandas_skips_a_nan_cohort_score_like_the_device_selection():
+    """ADVICE r3 (score_normalize's NaN check is a debug switch): what the reference's pandas calls (ScoreNormalization.py:88-105,
+    124-151: groupby().mean() / .std(), sort_values(ascending=False).head(N)) do with a NaN cohort score - they SKIP it (skipna, NaN
+    sorted last), which is also what the device's key-ordered selection does; nothing propagates in either."""
+    import pandas as pd
+    df = pd.DataFrame({"enroll": ["a", "a", "a", "b", "b", "b"], "score": [1.0, np.nan, 3.0, 2.0, 4.0, 6.0]})
+    grp = df.groupby("enroll")["score"]
+    assert grp.mean().to_dict() == {"a": 2.0, "b": 4.0}
+    assert abs(grp.std()["a"] - np.std([1.0, 3.0], ddof=1)) < 1e-15
+    assert df[df.enroll == "a"].sort_values(by="score", ascending=False).head(2)["score"].tolist() == [3.0, 1.0]
