@@ -43,3 +43,30 @@ def test_chain4_kernel_has_no_spills_and_no_compiler_owned_agprs(tmp_path):
             bad.append(line.strip())
     assert n_mfma > 1000
     assert not bad, bad[:5]
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_persistent_f32x_convolution_kernels_keep_their_weights_in_registers(tmp_path):
+    """grid_conv_x3_pers32_kernel / _pers64_kernel (kernels_conv2d_x3.hip) hold all 36 hi / lo weight fragments of their layer (144
+    registers) for a whole run of tiles and are launched two workgroups per CU: that design stands only while the compiler keeps the
+    kernels inside 256 registers WITHOUT spilling into scratch (a spilled fragment would be re-read from memory inside the K loop)
+    and the LDS rings leave room for two workgroups (the 64-row / 8-wave form: one)."""
+    out = tmp_path / "x3.s"
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(REPO, "include"), "-I" + CSRC, "-Xclang", "-target-feature", "-Xclang",
+           "-packed-fp32-ops", "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o", str(out), os.path.join(CSRC, "kernels_conv2d_x3.hip")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    blocks = re.split(r"remark: [^\n]*Function Name: ", r.stderr)[1:]
+    seen = 0
+    for b in blocks:
+        name = b.split()[0]
+        if "pers32_kernel" not in name and "pers64_kernel" not in name:
+            continue
+        seen += 1
+        vgprs = int(re.search(r"VGPRs: (\d+)", b).group(1))
+        scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+        lds = int(re.search(r"LDS Size \[bytes/block\]: (\d+)", b).group(1))
+        assert vgprs <= 256 and scratch == 0, (name, vgprs, scratch)
+        one_per_cu = "pers64_kernelILi1ELi2E" in name or "pers64_kernelILi2ELi2E" in name          # WM = 2: 8 waves, one workgroup per CU
+        assert lds * (1 if one_per_cu else 2) <= 163840, (name, lds)
+    assert seen >= 8, seen            # pers32 x 2 split types, pers64 x 2 split types x {32-row, 32-row pipelined, 64-row}
