@@ -461,7 +461,7 @@ def main():
         x-vector only - the port restates model/xvector.py).  `gate_1e-4`: the north star's embedding gate on that sample."""
         from oracle import torch_cpu_port as P
         ex = P.XvectorCpu(wl.sd, "far")
-        pos = [0, 1, wl.B // 2, wl.B - 1][:n]
+        pos = sorted({min(q, wl.B - 1) for q in (0, 1, wl.B // 2, wl.B - 1)})[:n]         # (a batch of one or two utterances: fewer positions)
         got = wl.eng.extract_device(wl.feats, wl.offsets).cpu().numpy()[pos]
         want = np.stack([ex.extract_embedding(wl.mats[i]).numpy() for i in pos])
         rel = float(np.abs(got - want).max() / np.abs(want).max())
