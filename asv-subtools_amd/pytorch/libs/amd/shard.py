@@ -109,11 +109,24 @@ def extract_sharded(extract_batch, lengths, load_utt, max_frames=65536, max_utts
     shards = balance_by_length(lengths, world)
     mine = shards[rank]
     outs, err = [], None
+    # batch k + 1 is read on a worker thread while batch k is extracted (file reads release the GIL).  A loader with a
+    # `load_batch(indices)` method (pipeline/onestep/extract_embeddings.py ScpBatchLoader) hands over the whole batch packed in one
+    # buffer; a plain callable is asked utterance by utterance.
+    from concurrent.futures import ThreadPoolExecutor
+    whole = getattr(load_utt, "load_batch", None)
+    fetch = (lambda b: whole(b)) if whole is not None else (lambda b: [load_utt(i) for i in b])
+    pool = ThreadPoolExecutor(1)
     try:
-        for batch in plan_batches(lengths, mine, max_frames, max_utts):
-            outs.append(extract_batch([load_utt(i) for i in batch]))
+        batches = list(plan_batches(lengths, mine, max_frames, max_utts))
+        ahead = pool.submit(fetch, batches[0]) if batches else None
+        for k in range(len(batches)):
+            mats = ahead.result()
+            ahead = pool.submit(fetch, batches[k + 1]) if k + 1 < len(batches) else None
+            outs.append(extract_batch(mats))
     except Exception as e:                            # reported to every rank below, then re-raised here
         err = e
+    finally:
+        pool.shutdown(wait=True)
     local = torch.cat(outs, dim=0) if (outs and err is None) else None
     width = _agree_or_raise(err, local.shape[1] if local is not None else 0, device, group, rank, world)
     if local is None:

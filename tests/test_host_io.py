@@ -369,3 +369,56 @@ def test_read_mat_decodes_the_header_only_compressed_formats(tmp_path):
         assert got.min() >= gmin - 1e-6 and got.max() <= gmin + grange + 1e-6
         ((key, m),) = list(K.read_mat_ark(str(p)))
         assert key == "utt" and np.array_equal(m, got)
+
+
+def test_scp_batch_loader_packs_a_batch_like_read_mat(tmp_path):
+    """pipeline/onestep/extract_embeddings.py ScpBatchLoader (round 4): the host side of the sharded path reads the utterances of
+    a batch straight into one packed buffer - plain float32 entries by header pread + payload preadv on worker threads, every other
+    kind of entry (float64, compressed, range specifiers) through read_matrix.  Byte for byte the matrices read_matrix returns, in
+    batch order, across two ark files; consecutive batches use alternating buffers (batch k stays intact while k + 1 is loaded)."""
+    import importlib.util
+    from libs.support import kaldi_io
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("extract_embeddings_mod", os.path.join(repo, "asv-subtools_amd", "pytorch", "pipeline", "onestep",
+                                                                                         "extract_embeddings.py"))
+    ee = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ee)
+    rs = np.random.RandomState(4)
+    entries = []
+    for a in range(2):
+        path = tmp_path / ("feats%d.ark" % a)
+        with open(path, "wb") as f:
+            for i in range(40):
+                key = "a%d_u%03d" % (a, i)
+                m = rs.randn(int(rs.randint(1, 60)), 24)
+                f.write((key + " ").encode())
+                pos = f.tell()
+                if i % 11 == 5:
+                    kaldi_io.write_mat(f, m.astype(np.float64))                   # 'DM '
+                else:
+                    kaldi_io.write_mat(f, m.astype(np.float32))
+                entries.append((key, "%s:%d" % (path, pos)))
+    big = [i for i, (k, rx) in enumerate(entries) if ee.matrix_rows(rx) >= 12][:3]
+    for i in big:
+        entries[i] = (entries[i][0], entries[i][1] + "[2:9]")                    # Kaldi range specifier: rows 2..9
+    want = [ee.read_matrix(rx) for _, rx in entries]
+    order = list(rs.permutation(len(entries)))
+    for threads in (1, 4):
+        ld = ee.ScpBatchLoader(entries, threads=threads)
+        try:
+            first = ld.load_batch(order[:37])
+            keep = [m.copy() for m in first]
+            second = ld.load_batch(order[37:])
+            for got, idx in ((first, order[:37]), (second, order[37:])):
+                assert got.packed.flags["C_CONTIGUOUS"] and got.packed.dtype == np.float32
+                assert list(got.offsets) == list(np.concatenate([[0], np.cumsum([want[i].shape[0] for i in idx])]))
+                for m, i in zip(got, idx):
+                    assert m.shape == want[i].shape and np.array_equal(m, want[i])
+            assert all(np.array_equal(a, b) for a, b in zip(first, keep))          # the first batch survived the second load
+            assert np.array_equal(ld(order[0]), want[order[0]])
+            assert len(ld._fds) == 2                                                # one descriptor per ark file
+        finally:
+            ld.close()
+    with pytest.raises(Exception):
+        bad = ee.ScpBatchLoader([("x", "%s:%d" % (tmp_path / "feats0.ark", os.path.getsize(tmp_path / "feats0.ark") - 20))])
+        bad.load_batch([0])
