@@ -1,0 +1,75 @@
+/* libasv_io.so: batched positioned reads on native threads (include/asv_io.h).  Plain C, no HIP: the GPU library is not
+ * touched by it. */
+#define _GNU_SOURCE
+#include <errno.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <unistd.h>
+
+#include "asv_io.h"
+
+static __thread int tls_errno = 0;
+static int last_errno = 0;
+
+int asv_io_version(void) { return ASV_IO_VERSION; }
+int asv_io_last_errno(void) { return last_errno; }
+
+typedef struct {
+  int lo, hi;
+  const int32_t *fd;
+  const int64_t *off, *nbytes;
+  void *const *dst;
+  int failed;          /* index + 1 of the first failing read of this range, 0 = none */
+  int err;
+} range_t;
+
+static void *run_range(void *arg) {
+  range_t *r = (range_t *)arg;
+  for (int i = r->lo; i < r->hi; ++i) {
+    int64_t got = 0;
+    char *p = (char *)r->dst[i];
+    while (got < r->nbytes[i]) {
+      const ssize_t k = pread(r->fd[i], p + got, (size_t)(r->nbytes[i] - got), (off_t)(r->off[i] + got));
+      if (k < 0 && errno == EINTR) continue;
+      if (k <= 0) {                                   /* error, or the file ends inside the matrix */
+        r->failed = i + 1;
+        r->err = k < 0 ? errno : 0;
+        return NULL;
+      }
+      got += k;
+    }
+  }
+  return NULL;
+}
+
+int asv_io_pread_batch(int n, const int32_t *fd, const int64_t *off, const int64_t *nbytes, void *const *dst, int threads) {
+  (void)tls_errno;
+  if (n <= 0) return 0;
+  if (threads < 1) threads = 1;
+  if (threads > 64) threads = 64;
+  if (threads > n) threads = n;
+  range_t r[64];
+  pthread_t th[64];
+  const int step = (n + threads - 1) / threads;
+  int used = 0;
+  for (int t = 0; t < threads; ++t) {
+    const int lo = t * step, hi = lo + step < n ? lo + step : n;
+    if (lo >= hi) break;
+    r[used] = (range_t){lo, hi, fd, off, nbytes, dst, 0, 0};
+    ++used;
+  }
+  int started = 0;
+  for (int t = 1; t < used; ++t) {                    /* range 0 runs on the calling thread */
+    if (pthread_create(&th[t], NULL, run_range, &r[t]) != 0) break;
+    started = t;
+  }
+  run_range(&r[0]);
+  for (int t = started + 1; t < used; ++t) run_range(&r[t]);      /* threads that could not be created: do their work here */
+  for (int t = 1; t <= started; ++t) pthread_join(th[t], NULL);
+  for (int t = 0; t < used; ++t)
+    if (r[t].failed) {
+      last_errno = r[t].err;
+      return -r[t].failed;
+    }
+  return 0;
+}

@@ -223,18 +223,20 @@ class ScpBatchLoader(object):
     matrices, range specifiers, pipes - goes through read_matrix and is copied in.  Two buffers alternate:
     libs.amd.shard.extract_sharded fetches batch k + 1 while batch k is on the device.  `loader(i)` (one utterance) stays
     available: it is what the function takes as `load_utt`.
-    Measured on the build host (20 000 x [200, 80] float32 from the page cache): 66 k utterances/s = 4.2 GB/s on one thread
-    (the kernel's copy rate); `threads` > 1 splits a batch over worker threads, which LOSES here (2: 64 k, 4: 43 k, 8: 26 k - a
-    64 KiB read is ~12 us, the Python around it ~3 us under the GIL, and the hand-over between threads costs more than it buys):
-    the default is 1; a native reader loop is what would scale."""
+    The payload reads of a batch are ONE call into libasv_io.so (csrc/host_io.c: positioned reads on `threads` native threads,
+    the GIL released for the whole call); without that library (not built) the same reads are issued from Python, one per
+    utterance.  Measured on the build host (20 000 x [200, 80] float32 from the page cache; DESIGN.md row "a16, e (host side)"):
+    203 k utterances/s = 13 GB/s on 4 native threads (1: 92 k, 8: 213 k); the Python reads: 66 k on one thread and LESS when
+    split over Python threads (4: 43 k - a 64 KiB read is ~12 us, the Python around it ~3 us under the GIL, the hand-over
+    between threads costs more than it buys); the round-3 path (read_mat per utterance + concatenate): 10 k."""
 
-    def __init__(self, entries, threads=1):
+    def __init__(self, entries, threads=4):
         self.entries = entries
         self.threads = max(1, int(threads))
         self._fds = {}
+        self._heads = {}
         self._bufs = [None, None]
         self._turn = 0
-        self._pool = None
         import threading
         self._lock = threading.Lock()
 
@@ -244,10 +246,7 @@ class ScpBatchLoader(object):
     def close(self):
         for fd in self._fds.values():
             os.close(fd)
-        self._fds = {}
-        if self._pool is not None:
-            self._pool.shutdown(wait=True)
-            self._pool = None
+        self._fds, self._heads = {}, {}
 
     def _fd(self, path):
         with self._lock:
@@ -256,31 +255,34 @@ class ScpBatchLoader(object):
                 fd = self._fds[path] = os.open(path, os.O_RDONLY)
             return fd
 
-    def _direct(self, rxfile):
-        """(fd, payload offset, rows, cols) of a plain float32 'file:offset' entry, else None."""
+    def _direct(self, i):
+        """(fd, payload offset, rows, cols) of entry i if it is a plain float32 'file:offset' entry, else None (parsed once)."""
+        h = self._heads.get(i, 0)
+        if h != 0:
+            return h
         import struct
-        if rxfile.endswith("]") or rxfile.endswith("|") or ":" not in rxfile:
-            return None
-        path, _, off = rxfile.rpartition(":")
-        if not off.isdigit() or not os.path.isfile(path):
-            return None
-        fd, off = self._fd(path), int(off)
-        head = os.pread(fd, 15, off)
-        if len(head) != 15 or head[:5] != b"\0BFM " or head[5] != 4 or head[10] != 4:
-            return None
-        rows, cols = struct.unpack_from("<i", head, 6)[0], struct.unpack_from("<i", head, 11)[0]
-        return fd, off + 15, rows, cols
+        rxfile = self.entries[i][1]
+        h = None
+        if not (rxfile.endswith("]") or rxfile.endswith("|") or ":" not in rxfile):
+            path, _, off = rxfile.rpartition(":")
+            if off.isdigit() and (path in self._fds or os.path.isfile(path)):
+                fd, off = self._fd(path), int(off)
+                head = os.pread(fd, 15, off)
+                if len(head) == 15 and head[:5] == b"\0BFM " and head[5] == 4 and head[10] == 4:
+                    h = (fd, off + 15, struct.unpack_from("<i", head, 6)[0], struct.unpack_from("<i", head, 11)[0])
+        self._heads[i] = h
+        return h
 
     def lengths(self):
         """Frames of every entry, from the headers (what the length-balanced sharding needs when no utt2num_frames is given)."""
         out = np.empty(len(self.entries), dtype=np.int64)
         for i, (_, rx) in enumerate(self.entries):
-            h = self._direct(rx)
+            h = self._direct(i)
             out[i] = h[2] if h is not None else matrix_rows(rx)
         return out
 
     def load_batch(self, indices):
-        heads = [self._direct(self.entries[i][1]) for i in indices]
+        heads = [self._direct(i) for i in indices]
         slow = {k: self(i) for k, (i, h) in enumerate(zip(indices, heads)) if h is None}
         rows = [slow[k].shape[0] if h is None else h[2] for k, h in enumerate(heads)]
         dims = {slow[k].shape[1] if h is None else h[3] for k, h in enumerate(heads)}
@@ -312,13 +314,18 @@ class ScpBatchLoader(object):
                     got += n
 
         n = len(indices)
-        if self.threads > 1 and n >= 2 * self.threads:
-            if self._pool is None:
-                from concurrent.futures import ThreadPoolExecutor
-                self._pool = ThreadPoolExecutor(self.threads)
-            step = -(-n // self.threads)
-            for f in [self._pool.submit(fill, lo, min(lo + step, n)) for lo in range(0, n, step)]:
-                f.result()
+        from libs.support import native_io
+        if native_io.lib() is not None:
+            ks = [k for k in range(n) if heads[k] is not None]
+            if ks:
+                try:
+                    native_io.pread_batch([heads[k][0] for k in ks], [heads[k][1] for k in ks], [(int(offs[k + 1]) - int(offs[k])) * dim * 4 for k in ks],
+                                          packed.ctypes.data, [int(offs[k]) * dim * 4 for k in ks], threads=self.threads)
+                except OSError as e:
+                    k = ks[e.args[2]] if len(e.args) > 2 else ks[0]
+                    raise kaldi_io.BadInputFormat("scp entry %r: %s" % (self.entries[indices[k]][1], e.args[1]))
+            for k in slow:
+                packed[int(offs[k]):int(offs[k + 1])] = slow[k]
         else:
             fill(0, n)
         out = PackedBatch(packed[int(offs[k]):int(offs[k + 1])] for k in range(n))
@@ -326,7 +333,7 @@ class ScpBatchLoader(object):
         return out
 
 
-def extract_sharded_scp(extract_batch, entries, lengths, w, batch_frames, batch_utts, verbose=False, device=None):
+def extract_sharded_scp(extract_batch, entries, lengths, w, batch_frames, batch_utts, verbose=False, device=None, loader=None):
     """Sharded extraction of scp entries (one call per rank, torch.distributed initialised or not):
         extract_batch(list of [T, D] float32 matrices) -> [b, E] tensor
     Every rank extracts its length-balanced shard; one all-gather; rank 0 writes the ark entries to `w` in scp order.
@@ -334,11 +341,12 @@ def extract_sharded_scp(extract_batch, entries, lengths, w, batch_frames, batch_
     import torch.distributed as dist
     from libs.amd import shard
     rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
-    load = ScpBatchLoader(entries, threads=int(os.environ.get("ASV_AMD_READER_THREADS", "1")))
+    load = loader if loader is not None else ScpBatchLoader(entries, threads=int(os.environ.get("ASV_AMD_READER_THREADS", "4")))
     try:
         emb = shard.extract_sharded(extract_batch, lengths, load, max_frames=batch_frames, max_utts=batch_utts, device=device)
     finally:
-        load.close()
+        if loader is None:
+            load.close()
     if rank == 0:
         keys = [k for k, _ in entries]
         if verbose:
@@ -354,15 +362,12 @@ def run_sharded(args, model, max_chunk, verbose):
         raise ValueError("--sharded needs random access to the features: pass 'scp:feats.scp' (the reference shards feats.scp too, "
                          "splitDataByLength.sh:44-80), not %r" % args.feats_rspecifier)
     entries = read_scp(args.feats_rspecifier)
+    loader = ScpBatchLoader(entries, threads=int(os.environ.get("ASV_AMD_READER_THREADS", "4")))
     if args.utt2num_frames:
         table = dict(line.split() for line in open(args.utt2num_frames) if line.strip())
         lengths = np.array([int(table[k]) for k, _ in entries], dtype=np.int64)
     else:
-        probe = ScpBatchLoader(entries)                # one 15-byte pread per plain float32 entry (a descriptor per ark file, not per entry)
-        try:
-            lengths = probe.lengths()
-        finally:
-            probe.close()
+        lengths = loader.lengths()                     # one 15-byte pread per plain float32 entry (a descriptor per ark file, not per entry)
     engine = model._amd_engine()
     dev = torch.device("cuda", engine.device_index)
     if max_chunk is None:
@@ -381,7 +386,7 @@ def run_sharded(args, model, max_chunk, verbose):
     w = kaldi_io.open_or_fd(args.vectors_wspecifier, "wb") if rank == 0 else None
     try:
         with torch.cuda.device(dev):
-            n = extract_sharded_scp(extract_batch, entries, lengths, w, args.batch_frames, args.batch_utts, verbose, device=dev)
+            n = extract_sharded_scp(extract_batch, entries, lengths, w, args.batch_frames, args.batch_utts, verbose, device=dev, loader=loader)
         if rank == 0 and dist.is_initialized():
             with open("/proc/self/maps") as f:
                 rccl = "librccl" in f.read()
@@ -389,6 +394,7 @@ def run_sharded(args, model, max_chunk, verbose):
                 dist.get_world_size(), dist.get_backend(), rccl))
         return n
     finally:
+        loader.close()
         if w is not None:
             w.close()
 

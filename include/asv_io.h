@@ -1,0 +1,29 @@
+/* libasv_io.so - host-side I/O helper of asv-subtools_amd (no HIP in it; built by gcc next to libasv_amd.so).
+ *
+ * Replaces, on the sharded extraction path, the per-utterance read loop of the reference's extractor
+ * (/root/reference/pytorch/pipeline/onestep/extract_embeddings.py:73-83: `for key, feats in kaldi_io.read_mat_scp(...)`,
+ * one Python-level read + array per utterance): the payloads of a whole batch of scp entries are read straight into
+ * their rows of one packed (pinned or pageable) batch buffer by a few native threads. */
+#ifndef ASV_IO_H_
+#define ASV_IO_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASV_IO_VERSION 1
+int asv_io_version(void);
+
+/* n positioned reads: nbytes[i] bytes of descriptor fd[i] from file offset off[i] into dst[i], split over `threads` worker
+ * threads (contiguous index ranges; <= 1: the calling thread).  Every read is completed (short reads are continued).
+ * Returns 0, or -(i + 1) for the first read that failed or hit the end of its file early (errno-style detail in
+ * asv_io_last_errno()). */
+int asv_io_pread_batch(int n, const int32_t *fd, const int64_t *off, const int64_t *nbytes, void *const *dst, int threads);
+int asv_io_last_errno(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -371,7 +371,7 @@ def test_read_mat_decodes_the_header_only_compressed_formats(tmp_path):
         assert key == "utt" and np.array_equal(m, got)
 
 
-def test_scp_batch_loader_packs_a_batch_like_read_mat(tmp_path):
+def test_scp_batch_loader_packs_a_batch_like_read_mat(tmp_path, monkeypatch):
     """pipeline/onestep/extract_embeddings.py ScpBatchLoader (round 4): the host side of the sharded path reads the utterances of
     a batch straight into one packed buffer - plain float32 entries by header pread + payload preadv on worker threads, every other
     kind of entry (float64, compressed, range specifiers) through read_matrix.  Byte for byte the matrices read_matrix returns, in
@@ -403,7 +403,10 @@ def test_scp_batch_loader_packs_a_batch_like_read_mat(tmp_path):
         entries[i] = (entries[i][0], entries[i][1] + "[2:9]")                    # Kaldi range specifier: rows 2..9
     want = [ee.read_matrix(rx) for _, rx in entries]
     order = list(rs.permutation(len(entries)))
-    for threads in (1, 4):
+    from libs.support import native_io
+    assert native_io.lib() is not None and native_io.lib().asv_io_version() == 1, "libasv_io.so is built by `make -C asv-subtools_amd/csrc` (build())"
+    for threads, native in ((1, True), (4, True), (1, False)):             # native reads (libasv_io.so) / the Python fallback: the same bytes
+        monkeypatch.setattr(native_io, "_LIB", None if native else False)
         ld = ee.ScpBatchLoader(entries, threads=threads)
         try:
             first = ld.load_batch(order[:37])
@@ -419,6 +422,27 @@ def test_scp_batch_loader_packs_a_batch_like_read_mat(tmp_path):
             assert len(ld._fds) == 2                                                # one descriptor per ark file
         finally:
             ld.close()
-    with pytest.raises(Exception):
-        bad = ee.ScpBatchLoader([("x", "%s:%d" % (tmp_path / "feats0.ark", os.path.getsize(tmp_path / "feats0.ark") - 20))])
-        bad.load_batch([0])
+    # an entry whose matrix runs past the end of its archive: loud in both paths
+    with open(tmp_path / "cut.ark", "wb") as f:
+        f.write(b"k ")
+        pos = f.tell()
+        kaldi_io.write_mat(f, rs.randn(30, 24).astype(np.float32))
+        f.truncate(f.tell() - 100)
+    for native in (True, False):
+        monkeypatch.setattr(native_io, "_LIB", None if native else False)
+        bad = ee.ScpBatchLoader([("k", "%s:%d" % (tmp_path / "cut.ark", pos))])
+        with pytest.raises(kaldi_io.BadInputFormat):
+            bad.load_batch([0])
+        bad.close()
+
+
+def test_libasv_io_exports_what_its_header_declares():
+    import ctypes, re
+    from libs.support import native_io
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(repo, "include", "asv_io.h")).read()
+    names = sorted(set(re.findall(r"\b(asv_io_[a-z_]+)\s*\(", header)))
+    assert names == ["asv_io_last_errno", "asv_io_pread_batch", "asv_io_version"]
+    L = ctypes.CDLL(native_io.library_path())
+    for n in names:
+        assert hasattr(L, n), n
