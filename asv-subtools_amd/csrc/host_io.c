@@ -73,3 +73,47 @@ int asv_io_pread_batch(int n, const int32_t *fd, const int64_t *off, const int64
     }
   return 0;
 }
+
+int64_t asv_io_scan_ark(int fd, int64_t start, int64_t cap, int64_t *payload_off, int32_t *rows, int32_t *cols, char *keys, int64_t keys_cap,
+                        int64_t *next, int32_t *stopped) {
+  enum { CHUNK = 512 };
+  unsigned char buf[CHUNK];
+  int64_t pos = start, n = 0, kused = 0;
+  *stopped = 0;
+  while (n < cap) {
+    ssize_t got;
+    do { got = pread(fd, buf, CHUNK, (off_t)pos); } while (got < 0 && errno == EINTR);
+    if (got < 0) { last_errno = errno; *stopped = 4; break; }
+    /* skip what Kaldi allows between entries: nothing in binary archives, but tolerate trailing whitespace at the end of the file */
+    ssize_t b = 0;
+    while (b < got && (buf[b] == '\n' || buf[b] == ' ' || buf[b] == '\t' || buf[b] == '\r')) ++b;
+    if (b == got) {
+      if (got < CHUNK) break;                          /* end of file */
+      pos += b;
+      continue;
+    }
+    ssize_t sp = b;
+    while (sp < got && buf[sp] != ' ') ++sp;
+    if (sp >= got || sp == b) { *stopped = 3; pos += b; break; }       /* no key terminator within the chunk (keys are short) / empty key */
+    const ssize_t klen = sp - b;
+    if (sp + 1 + 15 > got) { *stopped = (sp + 1 + 2 <= got && !(buf[sp + 1] == 0 && buf[sp + 2] == 'B')) ? 2 : 3; pos += b; break; }
+    const unsigned char *h = buf + sp + 1;
+    if (!(h[0] == 0 && h[1] == 'B' && h[2] == 'F' && h[3] == 'M' && h[4] == ' ' && h[5] == 4 && h[10] == 4)) { *stopped = 2; pos += b; break; }
+    int32_t r, c;
+    __builtin_memcpy(&r, h + 6, 4);
+    __builtin_memcpy(&c, h + 11, 4);
+    if (r < 0 || c < 0) { *stopped = 3; pos += b; break; }
+    if (kused + klen + 1 > keys_cap) { *stopped = 1; pos += b; break; }
+    __builtin_memcpy(keys + kused, buf + b, (size_t)klen);
+    keys[kused + klen] = '\n';
+    kused += klen + 1;
+    payload_off[n] = pos + sp + 1 + 15;
+    rows[n] = r;
+    cols[n] = c;
+    pos = payload_off[n] + (int64_t)r * c * 4;
+    ++n;
+    if (n == cap) { *stopped = 1; break; }
+  }
+  *next = pos;
+  return n;
+}

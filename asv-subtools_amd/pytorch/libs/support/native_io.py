@@ -31,6 +31,9 @@ def lib():
             L.asv_io_last_errno.restype = C.c_int
             L.asv_io_pread_batch.restype = C.c_int
             L.asv_io_pread_batch.argtypes = [C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.c_int]
+            L.asv_io_scan_ark.restype = C.c_int64
+            L.asv_io_scan_ark.argtypes = [C.c_int, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_char_p, C.c_int64,
+                                          C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
             _LIB = L
     return _LIB or None
 
@@ -50,3 +53,24 @@ def pread_batch(fds, offsets, nbytes, base_address, dst_offsets, threads=4):
     if rc != 0:
         err = L.asv_io_last_errno()
         raise OSError(err, "read %d of the batch failed (%s)" % (-rc - 1, os.strerror(err) if err else "the file ends inside the matrix"), -rc - 1)
+
+
+def scan_ark(fd, start, cap=8192, keys_cap=None):
+    """Index of up to `cap` plain float32 entries of the ark file behind descriptor `fd` from byte `start` (asv_io_scan_ark):
+    (keys, payload offsets int64, rows int32, cols int32, next offset, stopped) - stopped: 0 end of file, 1 cap reached, 2 an entry
+    of another kind at `next`, 3 malformed entry at `next`; a read error raises OSError."""
+    import numpy as np
+    L = lib()
+    keys_cap = int(keys_cap or cap * 48)
+    off = np.empty(cap, dtype=np.int64)
+    rows = np.empty(cap, dtype=np.int32)
+    cols = np.empty(cap, dtype=np.int32)
+    keys = C.create_string_buffer(keys_cap)
+    nxt, stopped = C.c_int64(0), C.c_int32(0)
+    n = int(L.asv_io_scan_ark(int(fd), int(start), int(cap), off.ctypes.data_as(C.POINTER(C.c_int64)), rows.ctypes.data_as(C.POINTER(C.c_int32)),
+                              cols.ctypes.data_as(C.POINTER(C.c_int32)), keys, keys_cap, C.byref(nxt), C.byref(stopped)))
+    if stopped.value == 4:
+        err = L.asv_io_last_errno()
+        raise OSError(err, os.strerror(err))
+    names = [k.decode("latin1") for k in keys.raw.split(b"\n", n)[:n]]
+    return names, off[:n], rows[:n], cols[:n], int(nxt.value), int(stopped.value)

@@ -23,6 +23,15 @@ int asv_io_version(void);
 int asv_io_pread_batch(int n, const int32_t *fd, const int64_t *off, const int64_t *nbytes, void *const *dst, int threads);
 int asv_io_last_errno(void);
 
+/* Index of a Kaldi ark file of uncompressed float32 matrices - entries `key SP \0 B F M SP \4 <int32 rows> \4 <int32 cols> <payload>`,
+ * what copy-feats / the reference's feature scripts write - scanned from byte `start` with small positioned reads (the payloads
+ * are skipped).  Fills at most `cap` entries: payload_off[i], rows[i], cols[i], and the keys one after the other, '\n'-terminated,
+ * into keys[0 .. keys_cap).  Returns the number of entries scanned; *next = file offset of the first entry NOT scanned;
+ * *stopped = 0 end of file, 1 `cap` or `keys_cap` reached, 2 the entry at *next is of another kind (text, float64, compressed:
+ * the caller falls back to its generic decoder), 3 malformed / truncated entry at *next, 4 read error (asv_io_last_errno()). */
+int64_t asv_io_scan_ark(int fd, int64_t start, int64_t cap, int64_t *payload_off, int32_t *rows, int32_t *cols, char *keys, int64_t keys_cap,
+                        int64_t *next, int32_t *stopped);
+
 #ifdef __cplusplus
 }
 #endif

@@ -442,7 +442,115 @@ def test_libasv_io_exports_what_its_header_declares():
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     header = open(os.path.join(repo, "include", "asv_io.h")).read()
     names = sorted(set(re.findall(r"\b(asv_io_[a-z_]+)\s*\(", header)))
-    assert names == ["asv_io_last_errno", "asv_io_pread_batch", "asv_io_version"]
+    assert names == ["asv_io_last_errno", "asv_io_pread_batch", "asv_io_scan_ark", "asv_io_version"]
     L = ctypes.CDLL(native_io.library_path())
     for n in names:
         assert hasattr(L, n), n
+
+
+def _drain(reader, cap_rows, dim, max_utts):
+    """Everything a packed reader yields: [(keys, offsets, frames, data copy)]."""
+    out = []
+    buf = np.empty((cap_rows, dim), dtype=np.float32)
+    while True:
+        keys, offs, frames = reader.read_group(buf, max_utts)
+        if not keys:
+            return out
+        data = frames.copy() if isinstance(frames, np.ndarray) else buf[:frames].copy()
+        out.append((list(keys), [int(o) for o in offs], data))
+
+
+def test_indexed_ark_reader_yields_what_the_sequential_reader_yields(tmp_path):
+    """kaldi_io.IndexedArkReader (round 4: native header scan + one batched positioned read per group, libasv_io.so) against
+    PackedArkReader on the same files: same groups, same offsets, same bytes - ragged lengths, groups cut by capacity and by
+    max_utts, an utterance longer than the buffer (returned alone), entries of other kinds in the middle of the file (float64,
+    compressed: the generic reader takes over at that byte), a file opened at an offset, an empty file; a wrong-width entry and a
+    truncated archive are loud."""
+    rs = np.random.RandomState(11)
+    dim = 20
+
+    def write(path, kinds, rows_of):
+        with open(path, "wb") as f:
+            for i, kind in enumerate(kinds):
+                m = rs.randn(rows_of(i), dim)
+                f.write(("utt_%04d " % i).encode())
+                if kind == "f8":
+                    kaldi_io.write_mat(f, m.astype(np.float64))
+                elif kind == "cm":
+                    kaldi_io.write_mat(f, m.astype(np.float32), compressed=True) if "compressed" in kaldi_io.write_mat.__code__.co_varnames else kaldi_io.write_mat(f, m.astype(np.float64))
+                else:
+                    kaldi_io.write_mat(f, m.astype(np.float32))
+
+    plain = tmp_path / "plain.ark"
+    write(plain, ["f4"] * 300, lambda i: 1 + (i * 37) % 90)
+    mixed = tmp_path / "mixed.ark"
+    write(mixed, ["f4"] * 40 + ["f8"] + ["f4"] * 25 + ["cm"] + ["f4"] * 10, lambda i: 5 + (i * 13) % 60)
+    big = tmp_path / "big.ark"
+    write(big, ["f4"] * 12, lambda i: 700 if i in (0, 5) else 30)
+    for path in (plain, mixed, big):
+        for cap, mx in ((400, 1024), (256, 7), (90, 3)):
+            with open(path, "rb") as a, open(path, "rb") as b:
+                fast = kaldi_io.IndexedArkReader.open(a)
+                assert fast is not None
+                slow = kaldi_io.PackedArkReader(b)
+                assert fast.peek_dim() == slow.peek_dim() == dim
+                got, want = _drain(fast, cap, dim, mx), _drain(slow, cap, dim, mx)
+            assert sum(len(g[0]) for g in got) == {plain: 300, mixed: 77, big: 12}[path]
+            if path != mixed:
+                assert len(got) == len(want)
+                for g, w in zip(got, want):
+                    assert g[0] == w[0] and g[1] == w[1] and np.array_equal(g[2], w[2])
+            else:          # a group ends where the generic reader takes over: same utterances in the same order, cut into groups differently
+                flat = lambda gs: [(k, g[2][g[1][j]:g[1][j + 1]]) for g in gs for j, k in enumerate(g[0])]
+                for (ka, ma), (kb, mb) in zip(flat(got), flat(want)):
+                    assert ka == kb and np.array_equal(ma, mb)
+    # opened behind the first entries (an 'ark:file:offset' rspecifier)
+    with open(plain, "rb") as a, open(plain, "rb") as b:
+        first = kaldi_io.PackedArkReader(open(plain, "rb"))
+        first.read_group(np.empty((64, dim), dtype=np.float32), 1)
+        skip = len(b"utt_0000 ") + 15 + 1 * dim * 4
+        a.seek(skip); b.seek(skip)
+        got, want = _drain(kaldi_io.IndexedArkReader.open(a), 300, dim, 64), _drain(kaldi_io.PackedArkReader(b), 300, dim, 64)
+        assert got[0][0][0] == "utt_0001" and [g[0] for g in got] == [w[0] for w in want]
+    empty = tmp_path / "empty.ark"
+    empty.write_bytes(b"")
+    with open(empty, "rb") as a:
+        rd = kaldi_io.IndexedArkReader.open(a)
+        assert rd is not None and rd.peek_dim() is None and rd.read_group(np.empty((8, dim), dtype=np.float32), 4)[0] == []
+    # a text archive / a pipe: not this reader's business
+    text = tmp_path / "text.ark"
+    with open(text, "wb") as f:
+        f.write(b"k  [\n 1 2\n 3 4 ]\n")
+    with open(text, "rb") as a:
+        assert kaldi_io.IndexedArkReader.open(a) is None
+    assert kaldi_io.IndexedArkReader.open(io.BytesIO(plain.read_bytes())) is None
+    # loud failures: a later entry of another width; the archive cut inside its last matrix
+    wide = tmp_path / "wide.ark"
+    with open(wide, "wb") as f:
+        for i, d in enumerate((dim, dim, dim + 4)):
+            f.write(("w%d " % i).encode())
+            kaldi_io.write_mat(f, rs.randn(9, d).astype(np.float32))
+    with open(wide, "rb") as a:
+        rd = kaldi_io.IndexedArkReader.open(a)
+        buf = np.empty((100, dim), dtype=np.float32)
+        assert rd.read_group(buf, 8)[0] == ["w0", "w1"]
+        with pytest.raises(kaldi_io.BadInputFormat):
+            rd.read_group(buf, 8)
+    cut = tmp_path / "cut2.ark"
+    cut.write_bytes(plain.read_bytes()[:-50])
+    with open(cut, "rb") as a:
+        rd = kaldi_io.IndexedArkReader.open(a)
+        with pytest.raises(kaldi_io.BadInputFormat):
+            _drain(rd, 4000, dim, 1024)
+
+
+def test_indexed_reader_is_not_offered_for_gzip_archives(tmp_path):
+    import gzip
+    p = tmp_path / "f.ark.gz"
+    with gzip.open(p, "wb") as f:
+        f.write(b"k ")
+        kaldi_io.write_mat(f, np.ones((3, 4), dtype=np.float32))
+    with kaldi_io.open_or_fd(str(p), "rb") as f:
+        assert kaldi_io.IndexedArkReader.open(f) is None
+        rd = kaldi_io.PackedArkReader(f)
+        assert rd.peek_dim() == 4
