@@ -451,6 +451,10 @@ def main(argv=None):
             if dist.is_initialized():
                 dist.barrier()
                 dist.destroy_process_group()
+        elif args.feats_rspecifier.startswith("scp:"):
+            # random-access input without --sharded (the reference's script reads `scp:` through read_mat_scp): the sharded loop as a
+            # single shard, no process group - length-sorted batches, the packed scp loader, vectors written in scp order
+            n_done = run_sharded(args, model, max_chunk, verbose)
         else:
             with kaldi_io.open_or_fd(args.feats_rspecifier, "rb") as r, kaldi_io.open_or_fd(args.vectors_wspecifier, "wb") as w:
                 n_done = extract_stream(model, r, w, args.batch_frames, args.batch_utts, max_chunk, verbose)
