@@ -25,12 +25,15 @@ def balance_by_length(lengths, n_shards):
     if n_shards < 1:
         raise ValueError("n_shards must be >= 1")
     order = np.argsort(-lengths, kind="stable")
-    loads = np.zeros(n_shards, dtype=np.int64)
+    if n_shards == 1:
+        return [order.astype(np.int64)]
+    import heapq
+    heap = [(0, s) for s in range(n_shards)]                # (frames so far, shard id): the smallest pair = fewest frames, lower id on ties
     shards = [[] for _ in range(n_shards)]
-    for idx in order:
-        s = int(np.argmin(loads))
-        shards[s].append(int(idx))
-        loads[s] += lengths[idx]
+    for idx, n in zip(order.tolist(), lengths[order].tolist()):
+        load, s = heap[0]
+        shards[s].append(idx)
+        heapq.heapreplace(heap, (load + n, s))
     return [np.asarray(s, dtype=np.int64) for s in shards]
 
 
