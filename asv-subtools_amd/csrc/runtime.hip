@@ -924,6 +924,15 @@ int asv_net_status(asv_net_t *net, unsigned *status, void *stream) {
   return ASV_OK;
 }
 
+int asv_net_status_async(asv_net_t *net, unsigned *host_status, void *stream) {
+  ASV_REQUIRE(net != nullptr && host_status != nullptr, "asv_net_status_async: null argument");
+  ASV_ON_DEVICE(net->device);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  ASV_HIP_CHECK(hipMemcpyAsync(host_status, status_word(net), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  ASV_HIP_CHECK(hipMemsetAsync(status_word(net), 0, sizeof(uint32_t), s));
+  return ASV_OK;
+}
+
 size_t asv_net_device_bytes(const asv_net_t *net) {
   if (!net) return 0;
   size_t n = net->weight_bytes + net->meta_dev.cap + net->rowmeta_dev.cap;

@@ -278,6 +278,12 @@ int asv_net_extract(asv_net_t *net, const float *feats, const int32_t *offsets, 
 #define ASV_STATUS_HALF_RANGE 1u
 int asv_net_status(asv_net_t *net, unsigned *status, void *stream);
 
+/* The same without the wait, for pipelined callers (the extraction scripts): enqueues on `stream` the copy of the status bits into
+ * *host_status (the caller's word, page-locked for the copy to be asynchronous; valid once work enqueued behind it on `stream` is
+ * known to have finished - e.g. the event the caller records behind its own result copy) and the clearing of the device word.
+ * One status word per net: keep one batch per net in flight between two such calls. */
+int asv_net_status_async(asv_net_t *net, unsigned *host_status, void *stream);
+
 /* Bytes of device memory currently held by the net (weights + activation arena). */
 size_t asv_net_device_bytes(const asv_net_t *net);
 

@@ -164,3 +164,23 @@ def test_np_oracle_resnet_matches_reference(name, preact, fc2_act, idx):
     x = helpers.golden_feats(g)[idx]
     got = O.extract_embedding(lambda c: O.resnet_embed(c, sd, "near", fc2_act, preact=preact), x)
     assert rel_err(got, g["embeddings"][idx]) < 2e-5, name
+
+
+@pytest.mark.parametrize("name,position,fc2_act,idx", [("ecapa_c3", "near", "relu", (2, 3, 4)), ("ecapa_launcher", "near", "", (2,)),
+                                                       ("ecapa_c512_near_affine", "near_affine", "relu", (1,)), ("ecapa_c512_fc1_far", "far", "relu", (0,))])
+def test_np_oracle_ecapa_matches_reference(name, position, fc2_act, idx):
+    """The numpy ECAPA restatement (np_oracle.ecapa_embed: ecapa_tdnn_xvector.py:403-426, SE-Res2Blocks 61-75 / 97-111 / 139-149, attentive
+    statistics 173-188) against the embeddings the reference's own ECAPA_TDNN produced (oracle/gen_golden.py) - the direct CPU pin of the
+    function the GPU parity tests of configs[2] / [3] compare against.  Short utterances (2, 9, 123 frames) keep
+    the 16 M-parameter numpy forward in seconds; T = 2 and 9 are also the zero-padding edge cases of the 5-tap input layer."""
+    g, sd = helpers.golden_state_dict(name)
+    sd64 = O.cast_state_dict(sd, np.float64)
+    mats = helpers.golden_feats(g)
+    for i in idx:
+        # the float64 evaluation of the restatement brackets the reference's f32 rounding ...
+        e64 = O.extract_embedding(lambda c: O.ecapa_embed(c, sd64, position, fc2_act), mats[i], dtype=np.float64)
+        assert rel_err(g["embeddings"][i], e64) < 5e-6, (name, i)
+        # ... and its f32 evaluation is the reference to f32 rounding (T = 2: the attentive std = sqrt(sum a x^2 - mean^2) of two frames
+        # cancels in f32, 8.5e-6 measured; every other case <= 1.1e-6)
+        got = O.extract_embedding(lambda c: O.ecapa_embed(c, sd, position, fc2_act), mats[i])
+        assert rel_err(got, g["embeddings"][i]) < (2e-5 if mats[i].shape[0] < 4 else 5e-6), (name, i)
