@@ -8,8 +8,9 @@
 
 #include "asv_io.h"
 
-static __thread int tls_errno = 0;
-static int last_errno = 0;
+/* per calling thread: two loaders reading on two threads do not overwrite each other's detail.  The worker threads
+ * of a batch hand their errno back through their range_t; it is published here by the thread that made the call. */
+static __thread int last_errno = 0;
 
 int asv_io_version(void) { return ASV_IO_VERSION; }
 int asv_io_last_errno(void) { return last_errno; }
@@ -43,7 +44,6 @@ static void *run_range(void *arg) {
 }
 
 int asv_io_pread_batch(int n, const int32_t *fd, const int64_t *off, const int64_t *nbytes, void *const *dst, int threads) {
-  (void)tls_errno;
   if (n <= 0) return 0;
   if (threads < 1) threads = 1;
   if (threads > 64) threads = 64;

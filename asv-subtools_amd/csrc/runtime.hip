@@ -756,6 +756,13 @@ int asv_net_add_im2col(asv_net_t *net, const asv_im2col_desc_t *d) {
   ASV_REQUIRE(dq.shift == di.shift + (d->stride == 2 ? 1 : 0) && dq.width == (di.width + d->stride - 1) / d->stride,
               "im2col: output grid (T/%d x %d) does not match stride %d over input grid (T/%d x %d)", 1 << dq.shift, dq.width, d->stride, 1 << di.shift, di.width);
   ASV_REQUIRE(d->act == ASV_ACT_NONE || d->act == ASV_ACT_RELU, "im2col: the elementwise prologue takes no activation or ReLU (got %d)", d->act);
+  // optional buffers: -1 = none, and so is 0 - buffer 0 is the feature matrix (frames domain), which can be neither a grid addend nor a
+  // per-segment scale, so a caller that zero-initialises the descriptor (memset + struct_size, the usual C pattern) gets what the
+  // descriptor meant before these fields existed
+  asv_im2col_desc_t norm = *d;
+  if (norm.b_buf <= 0) norm.b_buf = -1;
+  if (norm.seg_scale_buf <= 0) norm.seg_scale_buf = -1;
+  d = &norm;
   if (d->b_buf >= 0) {
     if ((rc = check_view(net, d->b_buf, 0, d->channels, "im2col addend"))) return rc;
     ASV_REQUIRE(net->bufs[d->b_buf].domain == net->bufs[d->in_buf].domain && net->bufs[d->b_buf].channels == d->channels && d->b_buf != d->out_buf,

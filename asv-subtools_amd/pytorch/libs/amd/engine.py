@@ -279,6 +279,21 @@ class Engine(object):
                                             C.c_void_p(out.data_ptr()), int(max_chunk), C.c_void_p(stream)), "asv_net_extract")
         return out
 
+    def extract_device_guarded(self, feats, offsets, max_chunk=10000, out=None):
+        """extract_device() + the range guard of extract_batch(), for synchronous callers that hold their batch on the device
+        (extract_embeddings_online.py): waits for the batch, and re-runs it on the bf16-halves twin with a RuntimeWarning if an
+        activation left the range of the f32x mode's operand split."""
+        watch = self._range_fallback_applies()
+        if watch:
+            self.status()                                 # clear what earlier asynchronous calls may have left
+        out = self.extract_device(feats, offsets, max_chunk=max_chunk, out=out)
+        if watch and out.numel() and (self.status() & capi.STATUS_HALF_RANGE):
+            import warnings
+            warnings.warn("asv-subtools_amd: an activation left the IEEE-half range of the f32x mode's operand split (|x| > 65504 or NaN): "
+                          "re-running the batch with bf16 operand halves (precision 'f32x-bf16')", RuntimeWarning)
+            out = self.wide_range_twin().extract_device(feats, offsets, max_chunk=max_chunk, out=out)
+        return out
+
     def extract_batch(self, mats, max_chunk=10000):
         """mats: list of [T_i, D] array-likes (host), or of CUDA tensors (e.g. libs.amd.frontend.fbank output - packed on
         the device, no host round trip).  Returns a CPU float32 tensor [B, E].
@@ -289,7 +304,8 @@ class Engine(object):
         without a trace.  The split kernels therefore watch the range of every hi half they produce and raise a status bit
         (asv_net_status); a batch that raised it is re-run ONCE on a lazily compiled twin of this engine with bf16 halves
         ('f32x-bf16': 16 significant bits per operand, the whole f32 exponent range; ~6e-6 relative, still inside the 1e-4
-        gate), with a warning.  extract_device() (device tensor out, no host synchronisation) does not check: call status()."""
+        gate), with a warning.  extract_device() (device tensor out, no host synchronisation) does not check: call status(), or
+        status_async() behind it - libs.amd.pipeline.DeviceSets, the path of the extraction scripts, does that for every batch."""
         import torch
         watch = self._range_fallback_applies()
         if watch:
@@ -299,11 +315,16 @@ class Engine(object):
             import warnings
             warnings.warn("asv-subtools_amd: an activation left the IEEE-half range of the f32x mode's operand split (|x| > 65504 or NaN): "
                           "re-running the batch with bf16 operand halves (precision 'f32x-bf16')", RuntimeWarning)
-            if getattr(self, "_wide_range_twin", None) is None:
-                self._wide_range_twin = Engine(self.graph, device_index=self.device_index, precision="f32x-bf16",
-                                               flags=self.flags & ~(capi.FLAG_X3_SPLIT_F16 | capi.FLAG_X3_SPLIT_BF16))
-            out = self._wide_range_twin._extract_batch(mats, max_chunk)
+            out = self.wide_range_twin()._extract_batch(mats, max_chunk)
         return out
+
+    def wide_range_twin(self):
+        """The lazily compiled twin of an f32x engine with bf16 operand halves ('f32x-bf16'): what a batch that raised
+        STATUS_HALF_RANGE is re-run on (here and in libs.amd.pipeline.DeviceSets, the scripts' path)."""
+        if getattr(self, "_wide_range_twin", None) is None:
+            self._wide_range_twin = Engine(self.graph, device_index=self.device_index, precision="f32x-bf16",
+                                           flags=self.flags & ~(capi.FLAG_X3_SPLIT_F16 | capi.FLAG_X3_SPLIT_BF16))
+        return self._wide_range_twin
 
     def status(self, stream=None):
         """Range status bits since the last call (capi.STATUS_HALF_RANGE); synchronises on `stream` (default: the current one)."""
@@ -313,6 +334,16 @@ class Engine(object):
         word = C.c_uint(0)
         capi.check(self.lib.asv_net_status(self._net, C.byref(word), C.c_void_p(stream)), "asv_net_status")
         return int(word.value)
+
+    def status_async(self, host_word, stream=None):
+        """Enqueues the copy of the range status bits into `host_word` (a page-locked int32 / uint32 tensor of one element) behind
+        the work already on `stream` (default: the current one) and clears them on the device - no wait: the word is valid once
+        an event recorded behind this call has completed.  One batch per engine between two calls."""
+        import torch
+        assert host_word.is_pinned() and host_word.numel() == 1 and host_word.element_size() == 4
+        if stream is None:
+            stream = torch.cuda.current_stream(torch.device("cuda", self.device_index)).cuda_stream
+        capi.check(self.lib.asv_net_status_async(self._net, C.c_void_p(host_word.data_ptr()), C.c_void_p(stream)), "asv_net_status_async")
 
     def _range_fallback_applies(self):
         return self.precision_base in ("f32x", "f16x3") and (self.flags & (capi.FLAG_X3_SPLIT_BF16 | capi.FLAG_REF_KERNELS)) == 0

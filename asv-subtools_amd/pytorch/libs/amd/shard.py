@@ -130,6 +130,12 @@ def extract_sharded(extract_batch, lengths, load_utt, max_frames=65536, max_utts
         err = e
     finally:
         pool.shutdown(wait=True)
+    flush = getattr(extract_batch, "flush", None)         # a pipelined extract_batch (libs.amd.pipeline.DeviceSets) returns tensors whose
+    if flush is not None and err is None:                  # work is still in flight: finished (and range-checked) here, before they are read
+        try:
+            flush()
+        except Exception as e:
+            err = e
     local = torch.cat(outs, dim=0) if (outs and err is None) else None
     width = _agree_or_raise(err, local.shape[1] if local is not None else 0, device, group, rank, world)
     if local is None:

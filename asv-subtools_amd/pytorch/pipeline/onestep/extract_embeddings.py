@@ -27,6 +27,7 @@ import argparse
 import os
 import re
 import sys
+import time
 import traceback
 
 sys.path.insert(0, "subtools/pytorch")
@@ -59,56 +60,41 @@ def get_args(argv=None):
     return parser.parse_args(argv)
 
 
-def extract_stream(model, r, w, batch_frames, batch_utts, max_chunk, verbose=False):
+def extract_stream(model, r, w, batch_frames, batch_utts, max_chunk, verbose=False, reader=None):
     """feature ark stream -> embedding ark stream, pipelined in three stages over two buffer sets:
       reader thread   next packed batch -> pinned host buffer   (kaldi_io.IndexedArkReader for ark files - native index + batched reads -,
-                      kaldi_io.PackedArkReader for pipes: block reads, no per-utterance arrays)
-      device          async H2D, asv_net_extract, async D2H into a pinned result buffer   (one stream, in order)
+                      kaldi_io.PackedArkReader for pipes: block reads, no per-utterance arrays; ScpGroupReader for `scp:` input)
+      device          async H2D, asv_net_extract, async D2H into a pinned result buffer + the range status word   (libs.amd.pipeline.DeviceSets:
+                      each buffer set has its own engine - same weights, own activation arena - on its own HIP stream)
       writer          previous batch's vectors -> one write() of the assembled ark bytes
     so reading batch i+1 and writing batch i-1 overlap the device work of batch i.  Output order = input order.
-    Each buffer set has its own engine (same weights, own activation arena) and its own HIP stream: consecutive batches overlap
-    on the device - the small launches at the end of one (pooling merge, pooled layers, attention tail) run beside the wide
-    GEMMs at the start of the next (device-resident rate: +5 % x-vector, +9 % ECAPA, +19 % ResNet34-SE, profiles/r3h_streams.txt;
-    ASV_AMD_PIPELINE_ENGINES=1 keeps one engine on one stream)."""
+    A batch whose activations left the range of the default mode's operand split is re-run with bf16 halves before it is written
+    (DeviceSets.finish; the reference's f32 forward has no such limit)."""
     import queue
     import threading
-    engine = model._amd_engine()
+    from libs.amd.pipeline import DeviceSets
     method = type(model).extract_embedding
     if max_chunk is None:
         max_chunk = getattr(method, "max_chunk", 10000)
-    # an ark FILE of plain float32 matrices: native header index + one batched positioned read per group (libasv_io.so: 240 k
-    # utterances/s from the page cache against 58 k for the sequential parser); pipes, stdin, other matrix kinds: the sequential reader
-    reader = kaldi_io.IndexedArkReader.open(r) if os.environ.get("ASV_AMD_INDEXED_READER", "1") != "0" else None
     if reader is None:
-        reader = kaldi_io.PackedArkReader(r)
+        # an ark FILE of plain float32 matrices: native header index + one batched positioned read per group (libasv_io.so: 240 k
+        # utterances/s from the page cache against 58 k for the sequential parser); pipes, stdin, other matrix kinds: the sequential reader
+        reader = kaldi_io.IndexedArkReader.open(r) if os.environ.get("ASV_AMD_INDEXED_READER", "1") != "0" else None
+        if reader is None:
+            reader = kaldi_io.PackedArkReader(r)
     dim = reader.peek_dim()
     if dim is None:
         return 0
-    if dim != engine.feat_dim:
-        raise ValueError("the archive holds %d-dimensional features, the model expects %d" % (dim, engine.feat_dim))
-    dev = torch.device("cuda", engine.device_index)
-    n_sets = 2
-    engines = [engine] * n_sets
-    streams = [torch.cuda.current_stream(dev)] * n_sets
-    if os.environ.get("ASV_AMD_PIPELINE_ENGINES", "2") != "1":
-        # (cached on the model like the first engine: a second call of extract_stream compiles nothing - ADVICE r3)
-        engines = [engine] + [model._amd_engine(replica=k) for k in range(1, n_sets)]
-        streams = [torch.cuda.Stream(device=dev) for _ in range(n_sets)]
-    host_in = [torch.empty((batch_frames, dim), dtype=torch.float32).pin_memory() for _ in range(n_sets)]
-    host_np = [t.numpy() for t in host_in]
-    dev_in = [torch.empty((batch_frames, dim), dtype=torch.float32, device=dev) for _ in range(n_sets)]
-    dev_out = [torch.empty((batch_utts, engine.embed_dim), dtype=torch.float32, device=dev) for _ in range(n_sets)]
-    host_out = [torch.empty((batch_utts, engine.embed_dim), dtype=torch.float32).pin_memory() for _ in range(n_sets)]
-    done = [torch.cuda.Event() for _ in range(n_sets)]
+    sets = DeviceSets(model, batch_frames, batch_utts, dim, max_chunk, n_sets=2, results="host")
     free_sets, batches = queue.Queue(), queue.Queue()
-    for k in range(n_sets):
+    for k in range(sets.n_sets):
         free_sets.put(k)
 
     def produce():
         try:
             while True:
                 k = free_sets.get()
-                keys, offsets, frames = reader.read_group(host_np[k], batch_utts)
+                keys, offsets, frames = reader.read_group(sets.host_buffer(k), batch_utts)
                 batches.put((k, keys, offsets, frames))
                 if not keys:
                     return
@@ -120,47 +106,59 @@ def extract_stream(model, r, w, batch_frames, batch_utts, max_chunk, verbose=Fal
     n_done, in_flight = 0, None
 
     def finish(item):
-        k, keys, n = item
-        done[k].synchronize()
+        k, keys = item
+        vectors = sets.finish(k)                      # waits for the batch; range guard (re-run on the bf16-halves twin if flagged)
         if verbose:
             for key in keys:
                 print("Process utterance for key {0}".format(key))
-        w.write(kaldi_io.vec_flt_ark_bytes(keys, host_out[k][:n].numpy()))
+        w.write(kaldi_io.vec_flt_ark_bytes(keys, vectors))
         free_sets.put(k)
-        return n
+        return len(keys)
 
-    with torch.cuda.device(dev):
-        while True:
-            item = batches.get()
-            if isinstance(item, BaseException):
-                raise item
-            k, keys, offsets, frames = item
-            if not keys:
-                break
-            n = len(keys)
-            with torch.cuda.stream(streams[k]):
-                if isinstance(frames, np.ndarray):        # one utterance longer than a whole batch buffer
-                    feats = torch.from_numpy(frames).to(dev)
-                else:
-                    feats = dev_in[k][:frames]
-                    feats.copy_(host_in[k][:frames], non_blocking=True)
-                out = engines[k].extract_device(feats, offsets, max_chunk=max_chunk, out=dev_out[k][:n])
-                host_out[k][:n].copy_(out, non_blocking=True)
-                done[k].record()
-            if in_flight is not None:
-                n_done += finish(in_flight)
-            in_flight = (k, keys, n)
+    t0 = time.perf_counter()
+    while True:
+        item = batches.get()
+        if isinstance(item, BaseException):
+            raise item
+        k, keys, offsets, frames = item
+        if not keys:
+            break
+        sets.submit(k, offsets, frames)
         if in_flight is not None:
             n_done += finish(in_flight)
+        in_flight = (k, keys)
+    if in_flight is not None:
+        n_done += finish(in_flight)
     t.join()
+    _report_loop("stream", n_done, time.perf_counter() - t0, sets)
     return n_done
 
 
+def _report_loop(path, n, seconds, sets):
+    """ASV_AMD_REPORT_TIMING=1: one line with the rate of the read -> device -> write loop alone (model load, engine compilation and
+    process start excluded; tools/bench_pipeline.py and bench.py's supplementary.ark_to_ark read it)."""
+    if os.environ.get("ASV_AMD_REPORT_TIMING", "0") not in ("0", "", "false"):
+        print("Loop[{0}]: {1} utterances in {2:.4f} s = {3:.1f} utterances/s (reader -> device -> writer; range re-runs: {4})".format(
+            path, n, seconds, n / max(seconds, 1e-9), sets.range_reruns))
+
+
+_SCP_PREFIX = re.compile(r"^scp(,[a-z_,]*)?:")
+
+
 def read_scp(path):
-    """[(key, rxfile)] of a Kaldi scp ('scp:' prefix optional)."""
-    name = path.split(":", 1)[1] if path.startswith("scp:") else path
-    with open(name) as f:
-        return [tuple(line.strip().split(None, 1)) for line in f if line.strip()]
+    """[(key, rxfile)] of a Kaldi scp rspecifier: 'scp:feats.scp', with options ('scp,p:', 'scp,s,cs:' - accepted and ignored, like
+    the reference's read_mat_scp), 'scp:-' (stdin), 'scp:cmd |' (a pipe), .gz; the prefix is optional."""
+    m = _SCP_PREFIX.match(path)
+    name = path[m.end():] if m else path
+    if name.strip() == "-":
+        lines = sys.stdin.read().splitlines()
+    else:
+        fd = kaldi_io.open_or_fd(name.strip(), "rb")
+        try:
+            lines = fd.read().decode("latin1").splitlines()
+        finally:
+            fd.close()
+    return [tuple(line.strip().split(None, 1)) for line in lines if line.strip()]
 
 
 _RANGE = re.compile(r"\[([0-9]*):?([0-9]*)(?:,([0-9]*):?([0-9]*))?\]$")
@@ -213,55 +211,76 @@ def matrix_rows(rxfile):
 
 
 class PackedBatch(list):
-    """The matrices of one batch as row slices of ONE buffer: `packed` [frames, D] float32, `offsets` int32 [n + 1]."""
+    """The matrices of one batch as row slices of ONE buffer: `packed` [frames, D] float32, `offsets` int32 [n + 1]; `turn`: which of
+    the loader's buffers it lies in (None: an array of its own)."""
     packed = None
     offsets = None
+    turn = None
 
 
 class ScpBatchLoader(object):
-    """Loads the utterances of a batch from scp entries into one packed buffer - the host side of the sharded path.
+    """Loads the utterances of a batch from scp entries into one packed buffer - the host side of the sharded path and of `scp:` input.
 
     Until round 4 a rank read its shard one `read_mat` at a time (open, parse, array) and concatenated the batch: 10 k utterances/s
     (0.65 GB/s) per rank against 56 k for the sequential stream reader and ~950 k the device extracts.  Here an uncompressed float32
-    entry 'file.ark:offset' (what copy-feats / the reference's make_features write) costs one 15-byte header pread and one preadv of its
-    payload straight into its rows of the batch buffer, one descriptor per ark file; everything else - float64, compressed, text
-    matrices, range specifiers, pipes - goes through read_matrix and is copied in.  Two buffers alternate:
-    libs.amd.shard.extract_sharded fetches batch k + 1 while batch k is on the device.  `loader(i)` (one utterance) stays
-    available: it is what the function takes as `load_utt`.
+    entry 'file.ark:offset' (what copy-feats / the reference's make_features write) costs one 15-byte header pread and one read of its
+    payload straight into its rows of the batch buffer; everything else - float64, compressed, text matrices, range specifiers,
+    pipes - goes through read_matrix and is copied in.  Two buffers alternate: libs.amd.shard.extract_sharded fetches batch k + 1
+    while batch k is on the device.  The buffers are the loader's own arrays, or the CALLER's (`buffers`: e.g. the page-locked
+    input buffers of libs.amd.pipeline.DeviceSets, so that the H2D copy starts from where the file was read to; `before_fill(turn)`
+    is then called before buffer `turn` is overwritten - the caller waits for its copy out of it there).  `loader(i)` (one
+    utterance) stays available: it is what extract_sharded takes as `load_utt`.
     The payload reads of a batch are ONE call into libasv_io.so (csrc/host_io.c: positioned reads on `threads` native threads,
     the GIL released for the whole call); without that library (not built) the same reads are issued from Python, one per
     utterance.  Measured on the build host (20 000 x [200, 80] float32 from the page cache; DESIGN.md row "a16, e (host side)"):
     203 k utterances/s = 13 GB/s on 4 native threads (1: 92 k, 8: 213 k); the Python reads: 66 k on one thread and LESS when
     split over Python threads (4: 43 k - a 64 KiB read is ~12 us, the Python around it ~3 us under the GIL, the hand-over
-    between threads costs more than it buys); the round-3 path (read_mat per utterance + concatenate): 10 k."""
+    between threads costs more than it buys); the round-3 path (read_mat per utterance + concatenate): 10 k.
+    Descriptors: one per ark file, kept in an LRU of `max_open` (a feats.scp of an augmented / nj-split feature directory names
+    more files than the soft RLIMIT_NOFILE allows open at once - ADVICE r4); the files of the batch being read are never evicted."""
 
-    def __init__(self, entries, threads=4):
+    def __init__(self, entries, threads=4, buffers=None, before_fill=None, max_open=256):
+        import collections
+        import threading
         self.entries = entries
         self.threads = max(1, int(threads))
-        self._fds = {}
+        self.max_open = max(1, int(max_open))
+        self._fds = collections.OrderedDict()            # path -> descriptor, least recently used first
         self._heads = {}
-        self._bufs = [None, None]
+        self._bufs = list(buffers) if buffers is not None else [None, None]
+        self._own = buffers is None
+        self._before_fill = before_fill
         self._turn = 0
-        import threading
         self._lock = threading.Lock()
 
     def __call__(self, i):
         return read_matrix(self.entries[i][1])
 
     def close(self):
-        for fd in self._fds.values():
-            os.close(fd)
-        self._fds, self._heads = {}, {}
+        with self._lock:
+            for fd in self._fds.values():
+                os.close(fd)
+            self._fds.clear()
 
-    def _fd(self, path):
+    def _fd(self, path, keep=()):
+        """Descriptor of `path` (opened on demand, most recently used last); beyond max_open the least recently used one that the
+        current batch (`keep`) does not need is closed."""
         with self._lock:
             fd = self._fds.get(path)
-            if fd is None:
-                fd = self._fds[path] = os.open(path, os.O_RDONLY)
+            if fd is not None:
+                self._fds.move_to_end(path)
+                return fd
+            if len(self._fds) >= self.max_open:
+                for old in list(self._fds):
+                    if len(self._fds) < self.max_open:
+                        break
+                    if old not in keep:
+                        os.close(self._fds.pop(old))
+            fd = self._fds[path] = os.open(path, os.O_RDONLY)
             return fd
 
     def _direct(self, i):
-        """(fd, payload offset, rows, cols) of entry i if it is a plain float32 'file:offset' entry, else None (parsed once)."""
+        """(path, payload offset, rows, cols) of entry i if it is a plain float32 'file:offset' entry, else None (parsed once)."""
         h = self._heads.get(i, 0)
         if h != 0:
             return h
@@ -271,10 +290,10 @@ class ScpBatchLoader(object):
         if not (rxfile.endswith("]") or rxfile.endswith("|") or ":" not in rxfile):
             path, _, off = rxfile.rpartition(":")
             if off.isdigit() and (path in self._fds or os.path.isfile(path)):
-                fd, off = self._fd(path), int(off)
-                head = os.pread(fd, 15, off)
+                off = int(off)
+                head = os.pread(self._fd(path), 15, off)
                 if len(head) == 15 and head[:5] == b"\0BFM " and head[5] == 4 and head[10] == 4:
-                    h = (fd, off + 15, struct.unpack_from("<i", head, 6)[0], struct.unpack_from("<i", head, 11)[0])
+                    h = (path, off + 15, struct.unpack_from("<i", head, 6)[0], struct.unpack_from("<i", head, 11)[0])
         self._heads[i] = h
         return h
 
@@ -286,56 +305,132 @@ class ScpBatchLoader(object):
             out[i] = h[2] if h is not None else matrix_rows(rx)
         return out
 
-    def load_batch(self, indices):
+    def shape(self, i, slow=None):
+        """(rows, cols) of entry i: from its header if it is a plain float32 entry, else by decoding it (the matrix is kept in
+        `slow[i]` for the fill that follows)."""
+        h = self._direct(i)
+        if h is not None:
+            return h[2], h[3]
+        m = slow.get(i) if slow is not None else None
+        if m is None:
+            m = self(i)
+            if slow is not None:
+                slow[i] = m
+        return m.shape
+
+    def fill(self, indices, packed, offs, slow=None):
+        """Reads the matrices of `indices` into packed[offs[k]:offs[k + 1]] (C-contiguous [frames, dim] float32); `slow`: already
+        decoded matrices of non-plain entries by entry index."""
         heads = [self._direct(i) for i in indices]
-        slow = {k: self(i) for k, (i, h) in enumerate(zip(indices, heads)) if h is None}
-        rows = [slow[k].shape[0] if h is None else h[2] for k, h in enumerate(heads)]
-        dims = {slow[k].shape[1] if h is None else h[3] for k, h in enumerate(heads)}
+        dim = packed.shape[1]
+        n = len(indices)
+        slow = slow if slow is not None else {}
+        ks = [k for k in range(n) if heads[k] is not None]
+        paths = {heads[k][0] for k in ks}
+        fds = {path: self._fd(path, keep=paths) for path in paths}
+        for k in range(n):
+            if heads[k] is None:
+                i = indices[k]
+                m = slow[i] if i in slow else self(i)
+                packed[int(offs[k]):int(offs[k + 1])] = m
+        if not ks:
+            return
+        from libs.support import native_io
+        if native_io.lib() is not None:
+            try:
+                native_io.pread_batch([fds[heads[k][0]] for k in ks], [heads[k][1] for k in ks], [(int(offs[k + 1]) - int(offs[k])) * dim * 4 for k in ks],
+                                      packed.ctypes.data, [int(offs[k]) * dim * 4 for k in ks], threads=self.threads)
+            except OSError as e:
+                k = ks[e.args[2]] if len(e.args) > 2 else ks[0]
+                raise kaldi_io.BadInputFormat("scp entry %r: %s" % (self.entries[indices[k]][1], e.args[1]))
+            return
+        raw = memoryview(packed.reshape(-1).view(np.uint8))
+        for k in ks:
+            h, a, b = heads[k], int(offs[k]), int(offs[k + 1])
+            fd, pos, want = fds[h[0]], h[1], (b - a) * dim * 4
+            got, view = 0, raw[a * dim * 4:b * dim * 4]
+            while got < want:
+                r = os.preadv(fd, [view[got:]], pos + got)
+                if r <= 0:
+                    raise kaldi_io.BadInputFormat("scp entry %r: the archive ends inside the matrix" % (self.entries[indices[k]][1],))
+                got += r
+
+    def load_batch(self, indices):
+        slow = {}
+        shapes = [self.shape(i, slow) for i in indices]
+        dims = {c for _, c in shapes}
         if len(dims) != 1:
             raise ValueError("feature matrices of different widths in one batch: %s" % sorted(dims))
         dim = dims.pop()
         offs = np.zeros(len(indices) + 1, dtype=np.int32)
-        np.cumsum(rows, out=offs[1:])
+        np.cumsum([r for r, _ in shapes], out=offs[1:])
         total = int(offs[-1])
         turn, self._turn = self._turn, self._turn ^ 1
+        if self._before_fill is not None:
+            self._before_fill(turn)
         buf = self._bufs[turn]
-        if buf is None or buf.size < total * dim:
-            buf = self._bufs[turn] = np.empty(max(total * dim, 1), dtype=np.float32)
-        packed = buf[:total * dim].reshape(total, dim)
-        raw = memoryview(packed.reshape(-1).view(np.uint8))
-
-        def fill(lo, hi):
-            for k in range(lo, hi):
-                h, a, b = heads[k], int(offs[k]), int(offs[k + 1])
-                if h is None:
-                    packed[a:b] = slow[k]
-                    continue
-                fd, pos, want = h[0], h[1], (b - a) * dim * 4
-                got, view = 0, raw[a * dim * 4:b * dim * 4]
-                while got < want:
-                    n = os.preadv(fd, [view[got:]], pos + got)
-                    if n <= 0:
-                        raise kaldi_io.BadInputFormat("scp entry %r: the archive ends inside the matrix" % (self.entries[indices[k]][1],))
-                    got += n
-
-        n = len(indices)
-        from libs.support import native_io
-        if native_io.lib() is not None:
-            ks = [k for k in range(n) if heads[k] is not None]
-            if ks:
-                try:
-                    native_io.pread_batch([heads[k][0] for k in ks], [heads[k][1] for k in ks], [(int(offs[k + 1]) - int(offs[k])) * dim * 4 for k in ks],
-                                          packed.ctypes.data, [int(offs[k]) * dim * 4 for k in ks], threads=self.threads)
-                except OSError as e:
-                    k = ks[e.args[2]] if len(e.args) > 2 else ks[0]
-                    raise kaldi_io.BadInputFormat("scp entry %r: %s" % (self.entries[indices[k]][1], e.args[1]))
-            for k in slow:
-                packed[int(offs[k]):int(offs[k + 1])] = slow[k]
-        else:
-            fill(0, n)
-        out = PackedBatch(packed[int(offs[k]):int(offs[k + 1])] for k in range(n))
-        out.packed, out.offsets = packed, offs
+        if self._own:
+            if buf is None or buf.size < total * dim:
+                buf = self._bufs[turn] = np.empty(max(total * dim, 1), dtype=np.float32)
+            packed = buf[:total * dim].reshape(total, dim)
+        elif buf.ndim == 2 and buf.shape[1] == dim and buf.shape[0] >= total:
+            packed = buf[:total]
+        else:                                          # does not fit the caller's buffer (one utterance longer than a whole batch): its own array
+            packed, turn = np.empty((total, dim), dtype=np.float32), None
+        self.fill(indices, packed, offs, slow)
+        out = PackedBatch(packed[int(offs[k]):int(offs[k + 1])] for k in range(len(indices)))
+        out.packed, out.offsets, out.turn = packed, offs, turn
         return out
+
+
+class ScpGroupReader(object):
+    """kaldi_io.PackedArkReader's interface (peek_dim / read_group) over scp entries IN SCP ORDER: what extract_stream reads `scp:`
+    input through when the run is not sharded - batches are written as they finish, memory is one batch, the keys print as they go
+    (the reference's loop over read_mat_scp does the same one utterance at a time, extract_embeddings.py:70-83).  Packed ragged
+    batches have no padding, so nothing is gained by sorting a single process's utterances by length."""
+
+    def __init__(self, entries, threads=4):
+        self.entries = entries
+        self.loader = ScpBatchLoader(entries, threads=threads)
+        self._at = 0
+        self._slow = {}
+
+    def close(self):
+        self.loader.close()
+
+    def peek_dim(self):
+        if self._at >= len(self.entries):
+            return None
+        return int(self.loader.shape(self._at, self._slow)[1])
+
+    def read_group(self, feats, max_utts=1024):
+        cap, dim = feats.shape
+        idx, offs, used = [], [0], 0
+        while len(idx) < max_utts and self._at < len(self.entries):
+            i = self._at
+            rows, cols = self.loader.shape(i, self._slow)
+            if cols != dim:
+                raise kaldi_io.BadInputFormat("scp entry '%s' has %d columns, the table started with %d" % (self.entries[i][0], cols, dim))
+            if rows > cap:
+                if idx:
+                    break                                  # flush what we have first
+                self._at += 1
+                big = np.empty((rows, dim), dtype=np.float32)
+                self.loader.fill([i], big, np.array([0, rows], dtype=np.int32), self._slow)
+                self._slow.pop(i, None)
+                return [self.entries[i][0]], np.array([0, rows], dtype=np.int32), big
+            if used + rows > cap:
+                break
+            idx.append(i)
+            used += rows
+            offs.append(used)
+            self._at += 1
+        offs = np.asarray(offs, dtype=np.int32)
+        if idx:
+            self.loader.fill(idx, feats[:used], offs, self._slow)
+            for i in idx:
+                self._slow.pop(i, None)
+        return [self.entries[i][0] for i in idx], offs, used
 
 
 def extract_sharded_scp(extract_batch, entries, lengths, w, batch_frames, batch_utts, verbose=False, device=None, loader=None):
@@ -363,35 +458,46 @@ def extract_sharded_scp(extract_batch, entries, lengths, w, batch_frames, batch_
 
 def run_sharded(args, model, max_chunk, verbose):
     import torch.distributed as dist
-    if not args.feats_rspecifier.startswith("scp:"):
+    from libs.amd.pipeline import DeviceSets
+    if not _SCP_PREFIX.match(args.feats_rspecifier):
         raise ValueError("--sharded needs random access to the features: pass 'scp:feats.scp' (the reference shards feats.scp too, "
                          "splitDataByLength.sh:44-80), not %r" % args.feats_rspecifier)
     entries = read_scp(args.feats_rspecifier)
-    loader = ScpBatchLoader(entries, threads=int(os.environ.get("ASV_AMD_READER_THREADS", "4")))
+    engine = model._amd_engine()
+    dev = torch.device("cuda", engine.device_index)
+    if max_chunk is None:
+        max_chunk = getattr(type(model).extract_embedding, "max_chunk", 10000)
+    # the device side is the stream path's: page-locked input buffers the loader reads the files INTO, asynchronous H2D, two engines
+    # on two HIP streams, the range status word behind every batch (libs.amd.pipeline.DeviceSets) - until round 5 this path copied a
+    # pageable batch synchronously into ONE engine and never looked at the status word
+    sets = DeviceSets(model, args.batch_frames, args.batch_utts, engine.feat_dim, max_chunk, n_sets=2, results="device")
+    loader = ScpBatchLoader(entries, threads=int(os.environ.get("ASV_AMD_READER_THREADS", "4")),
+                            buffers=[sets.host_buffer(0), sets.host_buffer(1)], before_fill=sets.input_consumed)
     if args.utt2num_frames:
         table = dict(line.split() for line in open(args.utt2num_frames) if line.strip())
         lengths = np.array([int(table[k]) for k, _ in entries], dtype=np.int64)
     else:
         lengths = loader.lengths()                     # one 15-byte pread per plain float32 entry (a descriptor per ark file, not per entry)
-    engine = model._amd_engine()
-    dev = torch.device("cuda", engine.device_index)
-    if max_chunk is None:
-        max_chunk = getattr(type(model).extract_embedding, "max_chunk", 10000)
 
     def extract_batch(mats):
-        if getattr(mats, "packed", None) is not None:        # ScpBatchLoader: the batch already lies packed in one buffer
-            feats, offs = torch.from_numpy(mats.packed).to(dev), mats.offsets
-        else:
-            offs = np.zeros(len(mats) + 1, dtype=np.int32)
-            np.cumsum([m.shape[0] for m in mats], out=offs[1:])
-            feats = torch.from_numpy(np.concatenate(mats, axis=0)).to(dev)
-        return engine.extract_device(feats, offs, max_chunk=max_chunk)
+        if getattr(mats, "packed", None) is not None:        # ScpBatchLoader: the batch already lies packed in one (page-locked) buffer
+            k = mats.turn if mats.turn is not None else 0
+            sets.finish(k)                                   # the batch before last (same set): done by now; range guard
+            return sets.submit(k, mats.offsets, int(mats.offsets[-1]) if mats.turn is not None else mats.packed)
+        offs = np.zeros(len(mats) + 1, dtype=np.int32)
+        np.cumsum([m.shape[0] for m in mats], out=offs[1:])
+        sets.finish(0)
+        return sets.submit(0, offs, np.concatenate(mats, axis=0))
 
+    extract_batch.flush = sets.flush                       # extract_sharded calls it before it reads the results
     rank = dist.get_rank() if dist.is_initialized() else 0
     w = kaldi_io.open_or_fd(args.vectors_wspecifier, "wb") if rank == 0 else None
     try:
+        t0 = time.perf_counter()
         with torch.cuda.device(dev):
             n = extract_sharded_scp(extract_batch, entries, lengths, w, args.batch_frames, args.batch_utts, verbose, device=dev, loader=loader)
+        if rank == 0:
+            _report_loop("sharded", n, time.perf_counter() - t0, sets)
         if rank == 0 and dist.is_initialized():
             with open("/proc/self/maps") as f:
                 rccl = "librccl" in f.read()
@@ -431,6 +537,11 @@ def main(argv=None):
             if "RANK" not in os.environ or "WORLD_SIZE" not in os.environ:
                 os.environ["RANK"], os.environ["WORLD_SIZE"] = "0", "1"
             if "MASTER_PORT" not in os.environ:
+                # a free local port only for the launcher-less single-rank run: ranks of a real job that each picked their own
+                # port would wait for one another until the rendezvous times out
+                if int(os.environ["WORLD_SIZE"]) != 1:
+                    raise RuntimeError("--sharded with WORLD_SIZE=%s needs MASTER_PORT (and MASTER_ADDR) in the environment: launch with "
+                                       "`python -m torch.distributed.run --nproc-per-node N ...` or export them" % os.environ["WORLD_SIZE"])
                 import socket
                 with socket.socket() as sock:
                     sock.bind(("127.0.0.1", 0))
@@ -451,10 +562,15 @@ def main(argv=None):
             if dist.is_initialized():
                 dist.barrier()
                 dist.destroy_process_group()
-        elif args.feats_rspecifier.startswith("scp:"):
-            # random-access input without --sharded (the reference's script reads `scp:` through read_mat_scp): the sharded loop as a
-            # single shard, no process group - length-sorted batches, the packed scp loader, vectors written in scp order
-            n_done = run_sharded(args, model, max_chunk, verbose)
+        elif _SCP_PREFIX.match(args.feats_rspecifier):
+            # random-access input without --sharded (the reference's script reads `scp:` through read_mat_scp): the stream loop over
+            # a reader that fills its batches from the scp entries in order - vectors are written batch by batch, in scp order
+            reader = ScpGroupReader(read_scp(args.feats_rspecifier), threads=int(os.environ.get("ASV_AMD_READER_THREADS", "4")))
+            try:
+                with kaldi_io.open_or_fd(args.vectors_wspecifier, "wb") as w:
+                    n_done = extract_stream(model, None, w, args.batch_frames, args.batch_utts, max_chunk, verbose, reader=reader)
+            finally:
+                reader.close()
         else:
             with kaldi_io.open_or_fd(args.feats_rspecifier, "rb") as r, kaldi_io.open_or_fd(args.vectors_wspecifier, "wb") as w:
                 n_done = extract_stream(model, r, w, args.batch_frames, args.batch_utts, max_chunk, verbose)

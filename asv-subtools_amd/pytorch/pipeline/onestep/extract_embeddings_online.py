@@ -166,7 +166,7 @@ def _extract_subset(engine, feats, frame_off, keep, max_chunk):
     lens = [int(frame_off[i + 1] - frame_off[i]) for i in keep]
     offs = np.zeros(len(keep) + 1, dtype=np.int32)
     np.cumsum(lens, out=offs[1:])
-    return engine.extract_device(feats, offs, max_chunk=max_chunk)
+    return engine.extract_device_guarded(feats, offs, max_chunk=max_chunk)       # (synchronous loop: the range guard's wait costs nothing here)
 
 
 def main(argv=None):

@@ -77,14 +77,17 @@ def parse():
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes that measure roofline.traffic (N = 1, default workload)")
     ap.add_argument("--lengths", default=None, help="'lo:hi' = utterance lengths ~ U[lo, hi] (seeded) instead of --frames")
     ap.add_argument("--batch", type=int, default=None,
-                    help="utterances per GPU per step (default: 640 for the x-vector - 640 x 204 padded rows = 1020 row tiles of 128, two "
-                         "column tiles each, fill the 512 workgroup slots of the device in whole rounds, +15 %% over 256; 256 for the others)")
+                    help="utterances per GPU per step (default: 256, what BASELINE configs[1] / [2] / [4] state; the same harness at 640 - whole "
+                         "rounds of workgroups - is reported beside it as value_at_b640 / roofline_at_b640)")
     ap.add_argument("--frames", type=int, default=None, help="frames per utterance (default: 200; 300 for --model ecapa, BASELINE configs[2])")
     ap.add_argument("--feat-dim", type=int, default=80)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="the K-step timed region is repeated until this much time has been measured")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel hipEvents in the timed region")
-    ap.add_argument("--no-supplementary", action="store_true", help="skip the b256 / f32x / f32 / ECAPA / ResNet sub-records")
+    ap.add_argument("--no-supplementary", action="store_true", help="skip the b640 / f32x / f32 / ECAPA / ResNet / ark->ark sub-records")
+    ap.add_argument("--ark-utts", type=int, default=30000,
+                    help="utterances of the supplementary ark -> ark record (the extraction SCRIPT on a synthetic archive read from the page cache: "
+                         "stream and --sharded paths, f32x and the headline mode; 0 = skip; tools/bench_pipeline.py runs the same at 50 000)")
     ap.add_argument("--event-stride", type=int, default=8, help="record the per-GEMM hipEvents on every k-th timed step")
     ap.add_argument("--per-op", action="store_true", help="also print a per-op timing table to stderr")
     ap.add_argument("--settle-seconds", type=float, default=0.5,
@@ -434,6 +437,14 @@ def main():
                 per.append({"layer": what, "us": round(us, 1), "tflops": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 1)})
             if len(per) <= 12:
                 rec["roofline"]["per_launch"] = per
+            if per:
+                # the dominant kernel as FLAT scalars (a list does not survive the driver's parse of this line - VERDICT r4 item 6):
+                # the launch with the most algorithmic FLOPs, its own hipEvent-timed duration and its own fraction of the peak
+                dom = max(per, key=lambda q: q["us"] * q["tflops"])
+                rec["roofline"].update({"dominant_kernel": dom["layer"], "dominant_us": dom["us"], "dominant_tflops": dom["tflops"],
+                                        "dominant_frac": round(dom["tflops"] / peak, 4),
+                                        "dominant_flop_per_launch": round(dom["us"] * 1e-6 * dom["tflops"] * 1e12),
+                                        "dominant_share_of_gemm_time": round(dom["us"] / max(sum(q["us"] for q in per), 1e-9), 4)})
             eng.set_profiling(False)
             barrier()
         if per_op and rank == 0:
@@ -633,6 +644,9 @@ def main():
                 rec["avg_launch_us"] = r1["roofline"]["avg_launch_us"]
                 rec["algorithmic_gflop_per_utt"] = r1["roofline"]["algorithmic_gflop_per_utt"]
                 rec["whole_step_tflops"] = round(rec["algorithmic_gflop_per_utt"] * r["value"] / 1e3, 1)
+                for k in ("dominant_kernel", "dominant_us", "dominant_tflops", "dominant_frac", "dominant_flop_per_launch", "dominant_share_of_gemm_time"):
+                    if k in r1["roofline"]:
+                        rec[k] = r1["roofline"][k]
             return rec, w
 
         if wl.B != 640:
@@ -667,6 +681,16 @@ def main():
                 del w
             except Exception as e:                                        # a supplementary record must never take the headline down
                 sup[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if args.ark_utts > 0:
+            # SURVEY 8(d) "then also ark->ark": the drop-in script itself (subprocesses of its own: reader thread / native loaders,
+            # page-locked buffers, H2D, two engines, D2H, ark writer), not timed inside the headline region
+            try:
+                sys.path.insert(0, os.path.join(REPO, "tools"))
+                import bench_pipeline
+                sup["ark_to_ark"] = bench_pipeline.measure(args.ark_utts, 200, tuple(dict.fromkeys(("f32x", args.precision))), ("stream", "sharded"),
+                                                           directory=os.path.join("/tmp", "asv_pipe_%d" % os.getpid()))
+            except Exception as e:                                        # a supplementary record must never take the headline down
+                sup["ark_to_ark"] = {"error": "%s: %s" % (type(e).__name__, e)}
         res["supplementary"] = sup
     if modes and args.gate_seeds > 0 and "supplementary" in res:
         # The gates as statistics (tests/gate_table.py: checker leg, not timed): per model, every mode on `gate_seeds` weight seeds x 3

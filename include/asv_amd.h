@@ -237,8 +237,8 @@ typedef struct asv_im2col_desc {
   uint32_t struct_size;
   int32_t in_buf, out_buf, channels, n_taps, stride;
   int32_t dt[ASV_MAX_TAPS], df[ASV_MAX_TAPS];
-  int32_t b_buf;                 /* optional addend, a whole buffer of in_buf's grid and width; -1 = none */
-  int32_t seg_scale_buf;         /* optional per-(segment, channel) scale: utts-domain buffer; -1 = none  */
+  int32_t b_buf;                 /* optional addend, a whole buffer of in_buf's grid and width; -1 (or 0) = none */
+  int32_t seg_scale_buf;         /* optional per-(segment, channel) scale: utts-domain buffer; -1 (or 0: a zero-initialised descriptor) = none */
   int32_t act;                   /* ASV_ACT_NONE | ASV_ACT_RELU, applied last                              */
 } asv_im2col_desc_t;
 int asv_net_add_im2col(asv_net_t *net, const asv_im2col_desc_t *d);

@@ -19,7 +19,7 @@ int asv_io_version(void);
 /* n positioned reads: nbytes[i] bytes of descriptor fd[i] from file offset off[i] into dst[i], split over `threads` worker
  * threads (contiguous index ranges; <= 1: the calling thread).  Every read is completed (short reads are continued).
  * Returns 0, or -(i + 1) for the first read that failed or hit the end of its file early (errno-style detail in
- * asv_io_last_errno()). */
+ * asv_io_last_errno(): the value of the CALLING thread's last failing call - thread-local, so concurrent callers do not race). */
 int asv_io_pread_batch(int n, const int32_t *fd, const int64_t *off, const int64_t *nbytes, void *const *dst, int threads);
 int asv_io_last_errno(void);
 

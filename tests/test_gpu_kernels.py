@@ -266,3 +266,30 @@ def test_f32x_split_kernel_is_f32_grade_on_hard_inputs():
         # 256 products of unit-scale operands, each carrying the 2^-17 representation error of a bf16 pair: ~3e-5 at the
         # worst of 160 000 outputs (the embedding-level 1e-4 gate is tests/test_gpu_full_size_parity.py)
         assert rel_err(got, want) < 5e-5, (act, first)
+
+
+def test_im2col_descriptor_zero_initialised_means_no_optional_buffers():
+    """asv_im2col_desc_t gained b_buf / seg_scale_buf in round 4 (-1 = none).  A C caller that zero-initialises the
+    descriptor (memset + struct_size) passes 0 in both - buffer 0 is the feature matrix, never a grid addend or a per-segment scale -
+    and must get the plain gather it got before the fields existed, not 'the addend must be a whole buffer...'."""
+    from libs.amd import capi
+    lib = capi.lib()
+    net = C.c_void_p()
+    capi.check(lib.asv_net_create(C.byref(net), 0, capi.PREC_BF16, 0, 80), "asv_net_create")
+    try:
+        g0 = capi.check(lib.asv_net_define_grid(net, 0, 80, 83), "asv_net_define_grid")
+        g1 = capi.check(lib.asv_net_define_grid(net, 1, 40, 43), "asv_net_define_grid")
+        a = capi.check(lib.asv_net_new_buffer(net, g0, 32), "asv_net_new_buffer")
+        b = capi.check(lib.asv_net_new_buffer(net, g1, 32 * 4), "asv_net_new_buffer")
+        d = capi.Im2colDesc()                                    # ctypes structures start zeroed: b_buf = seg_scale_buf = 0
+        d.struct_size = C.sizeof(capi.Im2colDesc)
+        d.in_buf, d.out_buf, d.channels, d.n_taps, d.stride = a, b, 32, 4, 2
+        for i, (dt, df) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+            d.dt[i], d.df[i] = dt, df
+        assert d.b_buf == 0 and d.seg_scale_buf == 0
+        capi.check(lib.asv_net_add_im2col(net, C.byref(d)), "asv_net_add_im2col (zero-initialised optional buffers)")
+        d.b_buf = -1
+        d.seg_scale_buf = -1
+        capi.check(lib.asv_net_add_im2col(net, C.byref(d)), "asv_net_add_im2col (-1)")
+    finally:
+        lib.asv_net_destroy(net)

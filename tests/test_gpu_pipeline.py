@@ -135,6 +135,102 @@ def test_extract_embeddings_script_sharded_mode_matches_stream_mode(tmp_path):
         assert rel_err(v, ref) < 1e-4, k
 
 
+@pytest.mark.parametrize("mode", ["ark", "scp", "sharded"])
+def test_script_range_guard_huge_features(tmp_path, mode):
+    """VERDICT r4 / ADVICE r4: the range guard of the default (f32x) mode through the SCRIPT.  Features scaled by 1e5 in some
+    utterances drive activations past the IEEE-half range of the operand split; the reference's f32 forward
+    (/root/reference/pytorch/pipeline/onestep/extract_embeddings.py:70-83) has no such limit.  Every entry point - the ark stream, the
+    `scp:` stream and `--sharded true` - must notice (status word behind every batch, libs.amd.pipeline.DeviceSets), re-run the flagged
+    batch with bf16 halves and write embeddings within 1e-4 of the numpy oracle, with the RuntimeWarning in the log."""
+    import torch
+    from libs.support import kaldi_io
+    import libs.support.utils as utils
+    from oracle import np_oracle as O
+    g, sd = helpers.golden_state_dict("xvector_near_ragged")
+    mats = [m.copy() for m in helpers.golden_feats(g)]
+    for i in (1, 4, len(mats) - 1):                                  # in different batches (--batch-frames 700)
+        mats[i] = (mats[i] * 1.0e5).astype(np.float32)
+    want = np.stack([O.extract_embedding(lambda c: O.xvector_embed(c, sd, "near"), m) for m in mats])
+    assert np.isfinite(want).all()
+    keys = ["utt%03d" % i for i in range(len(mats))]
+    feats_ark, feats_scp = tmp_path / "feats.ark", tmp_path / "feats.scp"
+    with open(feats_ark, "wb") as f, open(feats_scp, "w") as sc:
+        for k, m in zip(keys, mats):
+            f.write((k + " ").encode())
+            sc.write("%s %s:%d\n" % (k, feats_ark, f.tell()))
+            kaldi_io.write_mat(f, m)
+    params = tmp_path / "final.params"
+    torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, str(params))
+    cfg = tmp_path / "nnet.config"
+    utils.write_nnet_config(os.path.join(helpers.MODEL_DIR, "xvector.py"), str(g["creation"]), str(cfg))
+    out_ark = tmp_path / "xvector.ark"
+    script = os.path.join(helpers.REPO, "asv-subtools_amd", "pytorch", "pipeline", "onestep", "extract_embeddings.py")
+    extra = ["--sharded", "true"] if mode == "sharded" else []
+    rspec = "ark:%s" % feats_ark if mode == "ark" else "scp:%s" % feats_scp
+    env = {k: v for k, v in os.environ.items() if k != "ASV_AMD_PRECISION"}          # the default mode: f32x
+    res = subprocess.run([sys.executable, "-W", "always", script, "--nnet-config", str(cfg), "--use-gpu", "true", "--gpu-id", "0", "--batch-frames", "700"] + extra +
+                         [str(params), rspec, "ark:%s" % out_ark], capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "RuntimeWarning" in res.stderr and "f32x-bf16" in res.stderr, res.stderr[-2000:]
+    got = list(kaldi_io.read_vec_flt_ark(str(out_ark)))
+    assert [k for k, _ in got] == keys
+    for (k, v), ref in zip(got, want):
+        assert np.isfinite(v).all() and rel_err(v, ref) < 1e-4, (mode, k, rel_err(v, ref))
+
+
+def test_device_sets_guard_and_plain_batches():
+    """libs.amd.pipeline.DeviceSets directly: results on the host and on the device, a clean batch (no warning, no re-run) next to a
+    flagged one (re-run on the twin, in place), the oversize-utterance path, and Engine.extract_device_guarded (the online script's
+    call)."""
+    import warnings
+    import torch
+    from libs.amd.pipeline import DeviceSets
+    from oracle import np_oracle as O
+    g, sd, model = helpers.golden_model("xvector_near_ragged")
+    model.cuda()
+    model.amd_precision = "f32x"
+    mats = [m.copy() for m in helpers.golden_feats(g)][:6]
+    huge = [m.copy() for m in mats]
+    huge[3] = (huge[3] * 1.0e5).astype(np.float32)
+    want_clean = np.stack([O.extract_embedding(lambda c: O.xvector_embed(c, sd, "near"), m) for m in mats])
+    want_huge = np.stack([O.extract_embedding(lambda c: O.xvector_embed(c, sd, "near"), m) for m in huge])
+    dim = mats[0].shape[1]
+    rows = sum(m.shape[0] for m in mats)
+    offs = np.concatenate([[0], np.cumsum([m.shape[0] for m in mats])]).astype(np.int32)
+    for results in ("host", "device"):
+        sets = DeviceSets(model, rows + 8, 16, dim, 10000, n_sets=2, results=results)
+        assert sets.watch
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            sets.host_buffer(0)[:rows] = np.concatenate(mats)
+            sets.submit(0, offs, rows)
+            sets.host_buffer(1)[:rows] = np.concatenate(huge)
+            sets.submit(1, offs, rows)
+            sets.input_consumed(0)
+            a = sets.finish(0)
+            a = a.copy() if results == "host" else a.cpu().numpy()
+            assert not w and sets.range_reruns == 0
+            b = sets.finish(1)
+            b = b.copy() if results == "host" else b.cpu().numpy()
+            assert sets.range_reruns == 1 and any("f32x-bf16" in str(x.message) for x in w)
+            big = np.concatenate(mats)                               # an "utterance longer than the buffer": the ndarray path
+            sets.submit(0, offs, big)
+            c = sets.finish(0)
+            c = c.copy() if results == "host" else c.cpu().numpy()
+            sets.flush()
+        assert rel_err(a, want_clean) < 1e-4 and rel_err(c, want_clean) < 1e-4
+        for i in range(len(huge)):
+            assert rel_err(b[i], want_huge[i]) < 1e-4, (results, i)
+    eng = model._amd_engine()
+    dev = torch.device("cuda", eng.device_index)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = eng.extract_device_guarded(torch.from_numpy(np.concatenate(huge)).to(dev), offs).cpu().numpy()
+    assert any("f32x-bf16" in str(x.message) for x in w)
+    for i in range(len(huge)):
+        assert rel_err(out[i], want_huge[i]) < 1e-4, i
+
+
 def test_c4_standin_full_size_single_gpu():
     """BASELINE configs[3] at SURVEY 8(d) size on one GPU (the 8-GPU run is the same script under torch.distributed.run):
     4 708 ECAPA-TDNN utterances of 400..1500 frames, 37 720 trials; the parity-grade f32x mode meets the north-star EER gate

@@ -3,6 +3,7 @@
 import io
 import os
 import struct
+import sys
 
 import numpy as np
 import pytest
@@ -434,6 +435,158 @@ def test_scp_batch_loader_packs_a_batch_like_read_mat(tmp_path, monkeypatch):
         with pytest.raises(kaldi_io.BadInputFormat):
             bad.load_batch([0])
         bad.close()
+
+
+def _load_extract_script():
+    import importlib.util
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("extract_embeddings_mod", os.path.join(repo, "asv-subtools_amd", "pytorch", "pipeline", "onestep",
+                                                                                         "extract_embeddings.py"))
+    ee = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ee)
+    return ee
+
+
+def _write_many_arks(tmp_path, n_files, per_file, dim=8, seed=7):
+    from libs.support import kaldi_io
+    rs = np.random.RandomState(seed)
+    entries, want = [], []
+    for a in range(n_files):
+        path = tmp_path / ("f%03d.ark" % a)
+        with open(path, "wb") as f:
+            for i in range(per_file):
+                key = "f%03d_u%02d" % (a, i)
+                m = rs.randn(int(rs.randint(1, 20)), dim).astype(np.float64 if (a + i) % 9 == 4 else np.float32)
+                f.write((key + " ").encode())
+                pos = f.tell()
+                kaldi_io.write_mat(f, m)
+                entries.append((key, "%s:%d" % (path, pos)))
+                want.append(m.astype(np.float32))
+    return entries, want
+
+
+def test_scp_batch_loader_bounds_its_open_descriptors(tmp_path):
+    """a feats.scp over more ark files than descriptors may stay open (augmented / nj-split feature directories against
+    the soft RLIMIT_NOFILE): the loader keeps an LRU of `max_open` descriptors, never evicts a file of the batch it is reading,
+    and lengths() + every batch still return the right bytes."""
+    ee = _load_extract_script()
+    entries, want = _write_many_arks(tmp_path, n_files=40, per_file=2)
+    ld = ee.ScpBatchLoader(entries, threads=2, max_open=5)
+    try:
+        assert list(ld.lengths()) == [m.shape[0] for m in want]
+        assert len(ld._fds) <= 5
+        order = list(np.random.RandomState(1).permutation(len(entries)))
+        for lo in range(0, len(order), 24):                  # 24 utterances from up to 24 files per batch: more than max_open at once
+            idx = order[lo:lo + 24]
+            got = ld.load_batch(idx)
+            for m, i in zip(got, idx):
+                assert np.array_equal(m, want[i])
+            assert len(ld._fds) <= max(5, len({entries[i][1].rsplit(":", 1)[0] for i in idx}))
+        one = ld.load_batch([3])
+        assert np.array_equal(one[0], want[3]) and len(ld._fds) <= 5 + 1
+    finally:
+        ld.close()
+    assert len(ld._fds) == 0
+
+
+def test_scp_batch_loader_fills_the_callers_buffers(tmp_path):
+    """The sharded path hands the loader the page-locked input buffers of the device pipeline (libs.amd.pipeline.DeviceSets): batches
+    land in them alternately, `before_fill(turn)` is called before a buffer is overwritten, and a batch that does not fit gets an
+    array of its own (turn None)."""
+    ee = _load_extract_script()
+    entries, want = _write_many_arks(tmp_path, n_files=3, per_file=12)
+    bufs = [np.full((80, 8), np.nan, dtype=np.float32) for _ in range(2)]
+    calls = []
+    ld = ee.ScpBatchLoader(entries, threads=2, buffers=bufs, before_fill=calls.append)
+    try:
+        a = ld.load_batch([0, 1, 2])
+        b = ld.load_batch([5, 4])
+        assert (a.turn, b.turn) == (0, 1) and calls == [0, 1]
+        assert a.packed.base is bufs[0] or a.packed.ctypes.data == bufs[0].ctypes.data
+        assert b.packed.ctypes.data == bufs[1].ctypes.data
+        for got, idx in ((a, [0, 1, 2]), (b, [5, 4])):
+            for m, i in zip(got, idx):
+                assert np.array_equal(m, want[i])
+        everything = list(range(len(entries)))                # > 80 rows: cannot fit a buffer
+        assert sum(m.shape[0] for m in want) > 80
+        c = ld.load_batch(everything)
+        assert c.turn is None and all(np.array_equal(m, want[i]) for m, i in zip(c, everything))
+    finally:
+        ld.close()
+
+
+def test_scp_group_reader_streams_the_table_in_order(tmp_path):
+    """`scp:` input without --sharded goes through extract_stream over ScpGroupReader (PackedArkReader's interface): groups in scp
+    order bounded by the buffer and by max_utts, an utterance longer than the buffer alone in its own array, float64 entries
+    converted - every matrix exactly once, byte for byte what read_matrix returns."""
+    ee = _load_extract_script()
+    from libs.support import kaldi_io
+    entries, want = _write_many_arks(tmp_path, n_files=4, per_file=9)
+    with open(tmp_path / "long.ark", "wb") as f:              # one utterance longer than the whole buffer, in the middle of the table
+        f.write(b"long ")
+        pos = f.tell()
+        big = np.random.RandomState(2).randn(70, 8).astype(np.float32)
+        kaldi_io.write_mat(f, big)
+    entries.insert(17, ("long", "%s:%d" % (tmp_path / "long.ark", pos)))
+    want.insert(17, big)
+    rd = ee.ScpGroupReader(entries, threads=2)
+    try:
+        assert rd.peek_dim() == 8
+        buf = np.empty((50, 8), dtype=np.float32)
+        seen = []
+        while True:
+            keys, offs, frames = rd.read_group(buf, max_utts=7)
+            if not keys:
+                break
+            assert len(keys) <= 7 and len(offs) == len(keys) + 1
+            data = frames if isinstance(frames, np.ndarray) else buf[:frames]
+            for j, k in enumerate(keys):
+                seen.append((k, data[offs[j]:offs[j + 1]].copy()))
+        assert [k for k, _ in seen] == [k for k, _ in entries]
+        assert all(np.array_equal(m, w) for (_, m), w in zip(seen, want))
+        assert rd.peek_dim() is None
+    finally:
+        rd.close()
+    # a width change inside the table is an error that names the entry
+    with open(tmp_path / "wide.ark", "wb") as f:
+        f.write(b"wide ")
+        pos = f.tell()
+        kaldi_io.write_mat(f, np.zeros((3, 9), dtype=np.float32))
+    rd = ee.ScpGroupReader(entries[:2] + [("wide", "%s:%d" % (tmp_path / "wide.ark", pos))])
+    with pytest.raises(kaldi_io.BadInputFormat, match="wide"):
+        while rd.read_group(np.empty((500, 8), dtype=np.float32), 64)[0]:
+            pass
+    rd.close()
+
+
+def test_read_scp_accepts_the_rspecifier_forms_of_the_reference(tmp_path, monkeypatch):
+    """'scp:file', 'scp,p:file' / 'scp,s,cs:file' (options accepted and ignored, like read_mat_scp's open_or_fd), no
+    prefix, 'scp:cmd |' and 'scp:-'."""
+    import io
+    ee = _load_extract_script()
+    scp = tmp_path / "feats.scp"
+    scp.write_text("utt1 /data/a.ark:12\nutt2 /data/a.ark:3456[0:9]\n\nutt3 gunzip -c /data/b.ark.gz |\n")
+    want = [("utt1", "/data/a.ark:12"), ("utt2", "/data/a.ark:3456[0:9]"), ("utt3", "gunzip -c /data/b.ark.gz |")]
+    for spec in ("scp:%s", "scp,p:%s", "scp,s,cs:%s", "%s", "scp:cat %s |"):
+        assert ee.read_scp(spec % scp) == want, spec
+    monkeypatch.setattr(sys, "stdin", io.StringIO(scp.read_text()))
+    assert ee.read_scp("scp:-") == want
+    assert ee._SCP_PREFIX.match("scp,p:x") and not ee._SCP_PREFIX.match("ark:x")
+
+
+def test_sharded_mode_wants_a_master_port_from_a_real_launcher(tmp_path, monkeypatch, capsys):
+    """a free local port is picked only for the launcher-less single-rank run; WORLD_SIZE > 1 without MASTER_PORT is an
+    immediate error (each rank picking its own port would hang until the rendezvous times out).  Reaches no device: the check
+    sits in front of init_process_group."""
+    ee = _load_extract_script()
+    import torch
+    monkeypatch.setenv("RANK", "1")
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.delenv("MASTER_PORT", raising=False)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda *_: None)
+    with pytest.raises(SystemExit):
+        ee.main(["--model-blueprint", "x.py", "--model-creation", "X()", "--sharded", "true", "--gpu-id", "0", "m.params", "scp:" + str(tmp_path / "f.scp"), "ark:/dev/null"])
+    assert "needs MASTER_PORT" in capsys.readouterr().err
 
 
 def test_libasv_io_exports_what_its_header_declares():
