@@ -4,6 +4,7 @@
 #include <errno.h>
 #include <pthread.h>
 #include <stdint.h>
+#include <string.h>
 #include <unistd.h>
 
 #include "asv_io.h"
@@ -116,4 +117,27 @@ int64_t asv_io_scan_ark(int fd, int64_t start, int64_t cap, int64_t *payload_off
   }
   *next = pos;
   return n;
+}
+
+int64_t asv_io_pack_vec_ark(int n, int dim, const char *keys, const float *vectors, int64_t ld, char *out, int64_t out_cap) {
+  /* key SP \0 B F V SP \4 <int32 dim> <dim x f32> per vector: the bytes kaldi_io.write_vec_flt writes one entry at a time */
+  const char *k = keys;
+  int64_t used = 0;
+  for (int i = 0; i < n; ++i) {
+    const char *e = k;
+    while (*e != '\n' && *e != 0) ++e;
+    const int64_t klen = e - k, need = klen + 1 + 10 + (int64_t)dim * 4;
+    if (used + need > out_cap) return -1;
+    memcpy(out + used, k, (size_t)klen);
+    used += klen;
+    out[used++] = ' ';
+    out[used++] = 0; out[used++] = 'B'; out[used++] = 'F'; out[used++] = 'V'; out[used++] = ' '; out[used++] = 4;
+    const int32_t d = dim;
+    memcpy(out + used, &d, 4);
+    used += 4;
+    memcpy(out + used, vectors + (int64_t)i * ld, (size_t)dim * 4);
+    used += (int64_t)dim * 4;
+    k = (*e == '\n') ? e + 1 : e;
+  }
+  return used;
 }

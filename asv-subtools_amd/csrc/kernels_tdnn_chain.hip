@@ -503,6 +503,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
         const bool first_unit = ABL == 3 && cb < 512;
         if (first_unit) fine(0);
         int cur_seg = -1;                    // uniform: all lanes walk the utterances of the tile together
+        bool have = false;                   // per lane: pv is a frame of cur_seg (the lane has had a frame of it in this tile)
         auto publish = [&]() {
           const int slot = cur_seg - first_seg;
           if constexpr (ABL == 2) { asm volatile("" ::"v"(ps[0]), "v"(ps[1]), "v"(pq[0]), "v"(pq[1]), "v"(pv[0]), "v"(pv[1])); return; }
@@ -538,14 +539,18 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
             if (fresh) {
               publish();
               cur_seg = sg;
+              have = false;
   #pragma unroll
               for (int j = 0; j < 2; ++j) { ps[j] = 0.0f; pq[j] = 0.0f; }
             }
             if (bits == 0xffffffffu) {
               // the whole fragment is one utterance (84 % of the fragments at 200 frames): 2.5 VALU operations per value
+              // (every lane has frames here: one without a pivot of this utterance yet - see the seam path - takes its first)
+              const bool need = !have;
+              have = true;
   #pragma unroll
               for (int j = 0; j < 2; ++j) {
-                if (fresh) pv[j] = u[j][0];
+                pv[j] = need ? u[j][0] : pv[j];
                 const f32x2_t pv2 = {pv[j], pv[j]};
                 f32x2_t s2[2] = {{0.f, 0.f}, {0.f, 0.f}}, q2[2] = {{0.f, 0.f}, {0.f, 0.f}};
   #pragma unroll
@@ -563,16 +568,21 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
               // a seam or gap rows: register r of this lane holds frame 8 (r >> 2) + 4 lh + (r & 3) -> bit r of the lane's mask
               const uint32_t x = bits >> (4 * lh);
               const uint32_t lm = (x & 0xfu) | ((x >> 4) & 0xf0u) | ((x >> 8) & 0xf00u) | ((x >> 12) & 0xf000u);
-              if (fresh) {
-                // pivot = the lane's first frame of the utterance (a lane half without frames keeps a stale pivot; pool_finish
-                // skips parts without frames)
-                const int rsel = lm != 0 ? __builtin_ctz(lm) : 16;
+              // pivot = the lane's FIRST frame of the utterance, in whichever fragment of the tile that frame lies.  (Until round 5
+              // it was only taken in the utterance's first fragment: a lane half without a frame there - an utterance that starts in
+              // the last rows of a fragment - kept the PREVIOUS utterance's pivot for the rest of the tile.  Harmless between
+              // utterances of like scale; next to one whose activations are 1e5 x larger the sums about that pivot cancelled and the
+              // embedding depended on its batch neighbour: tests/test_gpu_xvector.py::test_pooled_moments_ignore_the_neighbour.)
+              const bool need = !have && lm != 0;
+              if (__builtin_amdgcn_ballot_w64(need) != 0) {
+                const int rsel = need ? __builtin_ctz(lm) : 16;
   #pragma unroll
                 for (int r = 15; r >= 0; --r) {
                   const bool hit = rsel == r;
                   pv[0] = hit ? u[0][r] : pv[0];
                   pv[1] = hit ? u[1][r] : pv[1];
                 }
+                have = have || need;
               }
               f32x2_t s2[2] = {{0.f, 0.f}, {0.f, 0.f}}, q2[2] = {{0.f, 0.f}, {0.f, 0.f}};
               const f32x2_t pva = {pv[0], pv[0]}, pvb = {pv[1], pv[1]};

@@ -382,6 +382,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainx_kernel(const TdnnChainPara
       const float sc[2] = {L.scale != nullptr ? L.scale[cb + lr] : 1.0f, L.scale != nullptr ? L.scale[cb + 32 + lr] : 1.0f};
       float ps[2] = {0.f, 0.f}, pq[2] = {0.f, 0.f}, pv[2] = {0.f, 0.f};
       int cur_seg = -1;                      // uniform: all lanes walk the utterances of the tile together
+      bool have = false;                     // per lane: pv is a frame of cur_seg (the lane has had a frame of it in this tile)
       auto publish = [&]() {
         const int slot = cur_seg - first_seg;
         if (cur_seg >= 0 && slot >= 0 && slot < p.pool_slots) {
@@ -413,22 +414,28 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainx_kernel(const TdnnChainPara
           if (fresh) {
             publish();
             cur_seg = sg;
+            have = false;
 #pragma unroll
             for (int j = 0; j < 2; ++j) { ps[j] = 0.0f; pq[j] = 0.0f; }
           }
           // register r of this lane holds frame 8 (r >> 2) + 4 lh + (r & 3) -> bit r of the lane's mask
           const uint32_t x = bits >> (4 * lh);
           const uint32_t lm = (x & 0xfu) | ((x >> 4) & 0xf0u) | ((x >> 8) & 0xf00u) | ((x >> 12) & 0xf000u);
-          if (fresh) {
-            // pivot = the lane's first frame of the utterance (a lane half without frames keeps a stale pivot; pool_finish skips
-            // parts without frames)
-            const int rsel = lm != 0 ? __builtin_ctz(lm) : 16;
+          // pivot = the lane's FIRST frame of the utterance, in whichever fragment of the tile that frame lies.  (Until round 5 the
+          // pivot was only taken in the utterance's first fragment: a lane half without a frame there - an utterance starting in
+          // the last rows of a fragment - kept the previous utterance's pivot for the rest of the tile.  Harmless between
+          // utterances of like scale, but next to one whose activations are 1e5 x larger the sums about that pivot cancelled:
+          // an embedding that depended on its batch neighbour, tests/test_gpu_xvector.py::test_pooled_moments_ignore_the_neighbour.)
+          const bool need = !have && lm != 0;
+          if (__builtin_amdgcn_ballot_w64(need) != 0) {
+            const int rsel = need ? __builtin_ctz(lm) : 16;
 #pragma unroll
             for (int r = 15; r >= 0; --r) {
               const bool hit = rsel == r;
               pv[0] = hit ? u[0][r] : pv[0];
               pv[1] = hit ? u[1][r] : pv[1];
             }
+            have = have || need;
           }
 #pragma unroll
           for (int r = 0; r < 16; ++r) {

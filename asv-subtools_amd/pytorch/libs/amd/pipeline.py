@@ -22,7 +22,7 @@ from . import capi
 
 
 class DeviceSets(object):
-    """`n_sets` buffer sets for batches of at most `batch_frames` frames / `batch_utts` utterances.
+    """`n_sets` buffer sets (and `n_engines` engines, each on its own HIP stream) for batches of at most `batch_frames` frames / `batch_utts` utterances.
 
         sets = DeviceSets(model, batch_frames, batch_utts, dim, max_chunk)
         buf = sets.host_buffer(k)                      # [batch_frames, dim] float32 numpy view of page-locked memory: the reader fills it
@@ -35,7 +35,7 @@ class DeviceSets(object):
     ASV_AMD_PIPELINE_ENGINES=1 keeps one engine on one stream (device-resident rate of two: +5 % x-vector, +9 % ECAPA, +19 %
     ResNet34-SE, profiles/r3h_streams.txt)."""
 
-    def __init__(self, model, batch_frames, batch_utts, dim, max_chunk, n_sets=2, results="host"):
+    def __init__(self, model, batch_frames, batch_utts, dim, max_chunk, n_sets=3, results="host", n_engines=2):
         import torch
         assert results in ("host", "device")
         self.torch = torch
@@ -46,12 +46,19 @@ class DeviceSets(object):
             raise ValueError("the input holds %d-dimensional features, the model expects %d" % (dim, engine.feat_dim))
         self.dev = dev = torch.device("cuda", engine.device_index)
         self.n_sets = n_sets
-        self.engines = [engine] * n_sets
-        self.streams = [torch.cuda.current_stream(dev)] * n_sets
-        if os.environ.get("ASV_AMD_PIPELINE_ENGINES", "2") != "1":
+        # engines / streams are fewer than buffer sets: a third set lets the reader fill batch i + 2 while batch i + 1 waits behind
+        # batch i on the device and batch i - 1 is being written (with two sets the read of batch i + 1 only started once batch
+        # i - 1 had been written: 173 k instead of 240 k utterances/s through the f32x stream path, profiles/r5a_ark_to_ark.json)
+        if os.environ.get("ASV_AMD_PIPELINE_ENGINES", "2") == "1":
+            n_engines = 1
+        if n_engines <= 1:
+            self.engines = [engine]
+            self.streams = [torch.cuda.current_stream(dev)]
+        else:
             # (cached on the model like the first engine: a second loop over the same model compiles nothing)
-            self.engines = [engine] + [model._amd_engine(replica=k) for k in range(1, n_sets)]
-            self.streams = [torch.cuda.Stream(device=dev) for _ in range(n_sets)]
+            self.engines = [engine] + [model._amd_engine(replica=k) for k in range(1, n_engines)]
+            self.streams = [torch.cuda.Stream(device=dev) for _ in range(n_engines)]
+        self._next_engine = 0
         self.embed_dim = engine.embed_dim
         self.watch = engine._range_fallback_applies()
         self.host_in = [torch.empty((batch_frames, dim), dtype=torch.float32).pin_memory() for _ in range(n_sets)]
@@ -63,7 +70,7 @@ class DeviceSets(object):
             self.host_out = [torch.empty((batch_utts, self.embed_dim), dtype=torch.float32).pin_memory() for _ in range(n_sets)]
         self.h2d = [torch.cuda.Event() for _ in range(n_sets)]
         self.done = [torch.cuda.Event() for _ in range(n_sets)]
-        self.pending = [None] * n_sets                   # (feats tensor, offsets, out tensor, n) of the batch in flight on a set
+        self.pending = [None] * n_sets                   # (feats tensor, offsets, out tensor, n, engine index) of the batch in flight on a set
         self.range_reruns = 0
 
     def host_buffer(self, k):
@@ -73,10 +80,12 @@ class DeviceSets(object):
         torch = self.torch
         assert self.pending[k] is None, "set %d still holds a batch: finish() it first" % k
         n = len(offsets) - 1
+        e = self._next_engine                            # consecutive batches alternate between the engines (each on its own stream: in
+        self._next_engine = (e + 1) % len(self.engines)  # order, so the status word copied behind a batch is that batch's alone)
         out = None
         if self.results == "device":
             out = torch.empty((n, self.embed_dim), dtype=torch.float32, device=self.dev)     # (allocated on the caller's stream: it outlives this one)
-        with torch.cuda.device(self.dev), torch.cuda.stream(self.streams[k]):
+        with torch.cuda.device(self.dev), torch.cuda.stream(self.streams[e]):
             if isinstance(frames, np.ndarray):           # one utterance longer than a whole batch buffer: a pageable copy of its own
                 feats = torch.from_numpy(np.ascontiguousarray(frames, dtype=np.float32)).to(self.dev)
             else:
@@ -85,13 +94,13 @@ class DeviceSets(object):
             self.h2d[k].record()
             if self.results == "host":
                 out = self.dev_out[k][:n]
-            self.engines[k].extract_device(feats, offsets, max_chunk=self.max_chunk, out=out)
+            self.engines[e].extract_device(feats, offsets, max_chunk=self.max_chunk, out=out)
             if self.results == "host":
                 self.host_out[k][:n].copy_(out, non_blocking=True)
             if self.watch:
-                self.engines[k].status_async(self.status_host[k])
+                self.engines[e].status_async(self.status_host[k])
             self.done[k].record()
-        self.pending[k] = (feats, np.array(offsets, dtype=np.int32), out, n)
+        self.pending[k] = (feats, np.array(offsets, dtype=np.int32), out, n, e)
         return out
 
     def input_consumed(self, k):
@@ -102,18 +111,18 @@ class DeviceSets(object):
         p = self.pending[k]
         if p is None:
             return None
-        feats, offsets, out, n = p
+        feats, offsets, out, n, e = p
         self.done[k].synchronize()
         if self.watch and (int(self.status_host[k][0]) & capi.STATUS_HALF_RANGE):
             torch = self.torch
             warnings.warn("asv-subtools_amd: an activation left the IEEE-half range of the f32x mode's operand split (|x| > 65504 or NaN): "
                           "re-running the batch with bf16 operand halves (precision 'f32x-bf16')", RuntimeWarning)
-            twin = self.engines[k].wide_range_twin()
-            with torch.cuda.device(self.dev), torch.cuda.stream(self.streams[k]):
+            twin = self.engines[e].wide_range_twin()
+            with torch.cuda.device(self.dev), torch.cuda.stream(self.streams[e]):
                 twin.extract_device(feats, offsets, max_chunk=self.max_chunk, out=out)
                 if self.results == "host":
                     self.host_out[k][:n].copy_(out, non_blocking=True)
-                self.streams[k].synchronize()
+                self.streams[e].synchronize()
             self.status_host[k].zero_()
             self.range_reruns += 1
         self.pending[k] = None

@@ -34,8 +34,27 @@ def lib():
             L.asv_io_scan_ark.restype = C.c_int64
             L.asv_io_scan_ark.argtypes = [C.c_int, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_char_p, C.c_int64,
                                           C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+            if L.asv_io_version() >= 2:
+                L.asv_io_pack_vec_ark.restype = C.c_int64
+                L.asv_io_pack_vec_ark.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
             _LIB = L
     return _LIB or None
+
+
+def pack_vec_ark(keys, vectors):
+    """bytes of the binary ark entries of float32 row vectors [n, dim] (asv_io_pack_vec_ark; kaldi_io.vec_flt_ark_bytes uses it when
+    the library is there - 0.05 ms instead of 0.4 ms of Python per batch of 327 vectors)."""
+    import numpy as np
+    L = lib()
+    v = np.ascontiguousarray(vectors, dtype=np.float32)
+    n, dim = v.shape
+    blob = "\n".join(keys).encode("latin1")
+    cap = len(blob) - max(n - 1, 0) + n * (11 + 4 * dim)
+    out = np.empty(cap, dtype=np.uint8)
+    used = L.asv_io_pack_vec_ark(n, dim, blob, v.ctypes.data, dim, out.ctypes.data, cap)
+    if used != cap:
+        raise ValueError("asv_io_pack_vec_ark wrote %d of %d bytes (a key with a newline?)" % (used, cap))
+    return out.tobytes()
 
 
 def pread_batch(fds, offsets, nbytes, base_address, dst_offsets, threads=4):

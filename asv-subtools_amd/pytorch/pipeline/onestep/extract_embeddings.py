@@ -79,13 +79,13 @@ def extract_stream(model, r, w, batch_frames, batch_utts, max_chunk, verbose=Fal
     if reader is None:
         # an ark FILE of plain float32 matrices: native header index + one batched positioned read per group (libasv_io.so: 240 k
         # utterances/s from the page cache against 58 k for the sequential parser); pipes, stdin, other matrix kinds: the sequential reader
-        reader = kaldi_io.IndexedArkReader.open(r) if os.environ.get("ASV_AMD_INDEXED_READER", "1") != "0" else None
+        reader = kaldi_io.IndexedArkReader.open(r, threads=_reader_threads()) if os.environ.get("ASV_AMD_INDEXED_READER", "1") != "0" else None
         if reader is None:
             reader = kaldi_io.PackedArkReader(r)
     dim = reader.peek_dim()
     if dim is None:
         return 0
-    sets = DeviceSets(model, batch_frames, batch_utts, dim, max_chunk, n_sets=2, results="host")
+    sets = DeviceSets(model, batch_frames, batch_utts, dim, max_chunk, n_sets=3, results="host")
     free_sets, batches = queue.Queue(), queue.Queue()
     for k in range(sets.n_sets):
         free_sets.put(k)
@@ -105,41 +105,64 @@ def extract_stream(model, r, w, batch_frames, batch_utts, max_chunk, verbose=Fal
     t.start()
     n_done, in_flight = 0, None
 
+    clock = time.perf_counter
+    spent = {"reader": 0.0, "submit": 0.0, "device": 0.0, "write": 0.0}       # where the consumer thread's time goes (ASV_AMD_REPORT_TIMING)
+
     def finish(item):
         k, keys = item
+        a = clock()
         vectors = sets.finish(k)                      # waits for the batch; range guard (re-run on the bf16-halves twin if flagged)
+        b = clock()
         if verbose:
             for key in keys:
                 print("Process utterance for key {0}".format(key))
         w.write(kaldi_io.vec_flt_ark_bytes(keys, vectors))
         free_sets.put(k)
+        spent["device"] += b - a
+        spent["write"] += clock() - b
         return len(keys)
 
-    t0 = time.perf_counter()
+    t0 = clock()
     while True:
+        a = clock()
         item = batches.get()
+        b = clock()
+        spent["reader"] += b - a
         if isinstance(item, BaseException):
             raise item
         k, keys, offsets, frames = item
         if not keys:
             break
         sets.submit(k, offsets, frames)
+        spent["submit"] += clock() - b
         if in_flight is not None:
             n_done += finish(in_flight)
         in_flight = (k, keys)
     if in_flight is not None:
         n_done += finish(in_flight)
     t.join()
-    _report_loop("stream", n_done, time.perf_counter() - t0, sets)
+    _report_loop("stream", n_done, clock() - t0, sets, spent)
     return n_done
 
 
-def _report_loop(path, n, seconds, sets):
+def _reader_threads():
+    """Native reader threads per process (ASV_AMD_READER_THREADS; default 8, at most the cores this process may run on): positioned
+    reads from the page cache scale to ~8 threads (203 k / 213 k utterances/s on 4 / 8 on the build host, row "a16, e (host side)")."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores = os.cpu_count() or 1
+    return max(1, min(int(os.environ.get("ASV_AMD_READER_THREADS", "8")), cores))
+
+
+def _report_loop(path, n, seconds, sets, spent=None):
     """ASV_AMD_REPORT_TIMING=1: one line with the rate of the read -> device -> write loop alone (model load, engine compilation and
     process start excluded; tools/bench_pipeline.py and bench.py's supplementary.ark_to_ark read it)."""
     if os.environ.get("ASV_AMD_REPORT_TIMING", "0") not in ("0", "", "false"):
         print("Loop[{0}]: {1} utterances in {2:.4f} s = {3:.1f} utterances/s (reader -> device -> writer; range re-runs: {4})".format(
             path, n, seconds, n / max(seconds, 1e-9), sets.range_reruns))
+        if spent:
+            print("Loop[{0}] consumer thread: ".format(path) + ", ".join("{0} {1:.4f} s".format(k, v) for k, v in spent.items()))
 
 
 _SCP_PREFIX = re.compile(r"^scp(,[a-z_,]*)?:")
@@ -365,7 +388,7 @@ class ScpBatchLoader(object):
         offs = np.zeros(len(indices) + 1, dtype=np.int32)
         np.cumsum([r for r, _ in shapes], out=offs[1:])
         total = int(offs[-1])
-        turn, self._turn = self._turn, self._turn ^ 1
+        turn, self._turn = self._turn, (self._turn + 1) % len(self._bufs)
         if self._before_fill is not None:
             self._before_fill(turn)
         buf = self._bufs[turn]
@@ -441,7 +464,7 @@ def extract_sharded_scp(extract_batch, entries, lengths, w, batch_frames, batch_
     import torch.distributed as dist
     from libs.amd import shard
     rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
-    load = loader if loader is not None else ScpBatchLoader(entries, threads=int(os.environ.get("ASV_AMD_READER_THREADS", "4")))
+    load = loader if loader is not None else ScpBatchLoader(entries, threads=_reader_threads())
     try:
         emb = shard.extract_sharded(extract_batch, lengths, load, max_frames=batch_frames, max_utts=batch_utts, device=device)
     finally:
@@ -470,9 +493,9 @@ def run_sharded(args, model, max_chunk, verbose):
     # the device side is the stream path's: page-locked input buffers the loader reads the files INTO, asynchronous H2D, two engines
     # on two HIP streams, the range status word behind every batch (libs.amd.pipeline.DeviceSets) - until round 5 this path copied a
     # pageable batch synchronously into ONE engine and never looked at the status word
-    sets = DeviceSets(model, args.batch_frames, args.batch_utts, engine.feat_dim, max_chunk, n_sets=2, results="device")
-    loader = ScpBatchLoader(entries, threads=int(os.environ.get("ASV_AMD_READER_THREADS", "4")),
-                            buffers=[sets.host_buffer(0), sets.host_buffer(1)], before_fill=sets.input_consumed)
+    sets = DeviceSets(model, args.batch_frames, args.batch_utts, engine.feat_dim, max_chunk, n_sets=3, results="device")
+    loader = ScpBatchLoader(entries, threads=_reader_threads(),
+                            buffers=[sets.host_buffer(k) for k in range(sets.n_sets)], before_fill=sets.input_consumed)
     if args.utt2num_frames:
         table = dict(line.split() for line in open(args.utt2num_frames) if line.strip())
         lengths = np.array([int(table[k]) for k, _ in entries], dtype=np.int64)
@@ -547,6 +570,11 @@ def main(argv=None):
                     sock.bind(("127.0.0.1", 0))
                     os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", int(args.gpu_id)))   # "nccl" is RCCL on ROCm
+            # RCCL builds its communicator inside the first collective (0.1 - 0.2 s): here, with the model still to be loaded, not
+            # inside the extraction loop in front of the all-gather
+            warm = torch.zeros(1, device=torch.device("cuda", int(args.gpu_id)))
+            dist.all_reduce(warm)
+            del warm
 
         model = utils.create_model_from_py(model_blueprint, model_creation)
         model.load_state_dict(torch.load(args.model_path, map_location="cpu"), strict=False)
@@ -565,7 +593,7 @@ def main(argv=None):
         elif _SCP_PREFIX.match(args.feats_rspecifier):
             # random-access input without --sharded (the reference's script reads `scp:` through read_mat_scp): the stream loop over
             # a reader that fills its batches from the scp entries in order - vectors are written batch by batch, in scp order
-            reader = ScpGroupReader(read_scp(args.feats_rspecifier), threads=int(os.environ.get("ASV_AMD_READER_THREADS", "4")))
+            reader = ScpGroupReader(read_scp(args.feats_rspecifier), threads=_reader_threads())
             try:
                 with kaldi_io.open_or_fd(args.vectors_wspecifier, "wb") as w:
                     n_done = extract_stream(model, None, w, args.batch_frames, args.batch_utts, max_chunk, verbose, reader=reader)

@@ -13,7 +13,7 @@
 extern "C" {
 #endif
 
-#define ASV_IO_VERSION 1
+#define ASV_IO_VERSION 2
 int asv_io_version(void);
 
 /* n positioned reads: nbytes[i] bytes of descriptor fd[i] from file offset off[i] into dst[i], split over `threads` worker
@@ -31,6 +31,13 @@ int asv_io_last_errno(void);
  * the caller falls back to its generic decoder), 3 malformed / truncated entry at *next, 4 read error (asv_io_last_errno()). */
 int64_t asv_io_scan_ark(int fd, int64_t start, int64_t cap, int64_t *payload_off, int32_t *rows, int32_t *cols, char *keys, int64_t keys_cap,
                         int64_t *next, int32_t *stopped);
+
+/* The binary ark entries `key SP \0 B F V SP \4 <int32 dim> <dim x float32>` of n row vectors (vectors[i * ld .. + dim)) in one buffer -
+ * what the reference's extractor writes one kaldi_io.write_vec_flt() call at a time
+ * (/root/reference/pytorch/pipeline/onestep/extract_embeddings.py:83, kaldi_io.py:367-399).  keys: the n keys, '\n'-separated (no
+ * trailing separator needed, NUL-terminated).  Returns the bytes written, or -1 when out_cap is too small
+ * (exact size: sum of key lengths + n * (11 + 4 * dim)). */
+int64_t asv_io_pack_vec_ark(int n, int dim, const char *keys, const float *vectors, int64_t ld, char *out, int64_t out_cap);
 
 #ifdef __cplusplus
 }

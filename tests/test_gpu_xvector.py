@@ -295,6 +295,30 @@ def test_f32x_range_guard_and_small_features():
     assert rel_err(got_s, want_s) < 1e-4, rel_err(got_s, want_s)
 
 
+@pytest.mark.parametrize("prec,tol", [("f32", 1e-5), ("f32x-bf16", 1e-4), ("bf16", 2e-2)])
+def test_pooled_moments_ignore_the_neighbour(prec, tol):
+    """Round 5 (found by the script-level range-guard test): an utterance's embedding must not depend on the batch it is extracted in
+    (the reference extracts every utterance alone, framework.py:33-45).  Order [201 frames | 200 frames x 1e5 | 37 frames | ...]: the
+    37-frame utterance starts in the last three rows of a 32-frame fragment, so one lane half has no frame of it there - the fused
+    pooling epilogue of the chain kernels then kept the HUGE neighbour's pivot for that half and the sums about it cancelled
+    (relative error 9.8 in the bf16-halves mode, 7.3 in bf16).  Every utterance against the oracle, and the small ones against
+    their own extraction alone."""
+    from oracle import np_oracle as O
+    g, sd, model = _gpu_model("xvector_near_ragged", prec)
+    mats = [m.copy() for m in helpers.golden_feats(g)][:6]
+    mats[4] = (mats[4] * 1.0e5).astype(np.float32)
+    mats[1] = (mats[1] * 1.0e5).astype(np.float32)
+    want = np.stack([O.extract_embedding(lambda c: O.xvector_embed(c, sd, "near"), m) for m in mats])
+    eng = model._amd_engine()
+    for order in ([5, 4, 3, 2, 1, 0], [0, 1, 2, 3, 4, 5], [4, 3, 5], [2, 4, 3, 1, 0]):
+        got = eng._extract_batch([mats[i] for i in order]).numpy()
+        for j, i in enumerate(order):
+            assert rel_err(got[j], want[i]) < tol, (prec, order, i, rel_err(got[j], want[i]))
+    alone = eng._extract_batch([mats[3]]).numpy()[0]
+    beside = eng._extract_batch([mats[5], mats[4], mats[3]]).numpy()[2]
+    assert rel_err(beside, alone) < tol
+
+
 def test_chain_kernel_small_tile_forms(tmp_path):
     """Round 4: the chain kernel has 96- and 64-frame tile forms.  A batch that does not fill one round of the chip's CUs in 128-frame
     tiles runs in the smallest tile that still fits one round (default); ASV_AMD_CHAIN_TAIL=2 also cuts the last, partly filled

@@ -405,7 +405,7 @@ def test_scp_batch_loader_packs_a_batch_like_read_mat(tmp_path, monkeypatch):
     want = [ee.read_matrix(rx) for _, rx in entries]
     order = list(rs.permutation(len(entries)))
     from libs.support import native_io
-    assert native_io.lib() is not None and native_io.lib().asv_io_version() == 1, "libasv_io.so is built by `make -C asv-subtools_amd/csrc` (build())"
+    assert native_io.lib() is not None and native_io.lib().asv_io_version() >= 2, "libasv_io.so is built by `make -C asv-subtools_amd/csrc` (build())"
     for threads, native in ((1, True), (4, True), (1, False)):             # native reads (libasv_io.so) / the Python fallback: the same bytes
         monkeypatch.setattr(native_io, "_LIB", None if native else False)
         ld = ee.ScpBatchLoader(entries, threads=threads)
@@ -595,7 +595,7 @@ def test_libasv_io_exports_what_its_header_declares():
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     header = open(os.path.join(repo, "include", "asv_io.h")).read()
     names = sorted(set(re.findall(r"\b(asv_io_[a-z_]+)\s*\(", header)))
-    assert names == ["asv_io_last_errno", "asv_io_pread_batch", "asv_io_scan_ark", "asv_io_version"]
+    assert names == ["asv_io_last_errno", "asv_io_pack_vec_ark", "asv_io_pread_batch", "asv_io_scan_ark", "asv_io_version"]
     L = ctypes.CDLL(native_io.library_path())
     for n in names:
         assert hasattr(L, n), n
@@ -707,3 +707,26 @@ def test_indexed_reader_is_not_offered_for_gzip_archives(tmp_path):
         assert kaldi_io.IndexedArkReader.open(f) is None
         rd = kaldi_io.PackedArkReader(f)
         assert rd.peek_dim() == 4
+
+
+def test_native_vector_ark_packing_equals_write_vec_flt(tmp_path):
+    """asv_io_pack_vec_ark (round 5: the writer side of the extraction loop) produces, for a whole batch in one call, the bytes
+    kaldi_io.write_vec_flt writes entry by entry - keys of different lengths, batches below the native threshold through the Python
+    path, a key containing a newline refused by the native path (falls back)."""
+    from libs.support import native_io
+    rs = np.random.RandomState(5)
+    for n in (1, 15, 16, 327):
+        keys = ["spk%d-utt%0*d" % (i % 7, 1 + i % 5, i) for i in range(n)]
+        v = rs.randn(n, 192).astype(np.float32)
+        ref = io.BytesIO()
+        ref.mode = "wb"
+        for k, row in zip(keys, v):
+            kaldi_io.write_vec_flt(ref, row, key=k)
+        got = kaldi_io.vec_flt_ark_bytes(keys, v)
+        assert isinstance(got, bytes) and got == ref.getvalue(), n
+        assert native_io.pack_vec_ark(keys, v) == ref.getvalue()
+    odd = ["a\nb"] + ["k%d" % i for i in range(20)]
+    v = rs.randn(21, 8).astype(np.float32)
+    back = list(kaldi_io.read_vec_flt_ark(io.BytesIO(kaldi_io.vec_flt_ark_bytes(odd[1:], v[1:]))))
+    assert [k for k, _ in back] == odd[1:]
+    assert kaldi_io.vec_flt_ark_bytes(odd, v).startswith(b"a\nb \0BFV ")

@@ -81,6 +81,9 @@ def run_once(files, path, precision, utts, out_dir, timeout=900):
     if m:
         rec["loop_seconds"] = float(m.group(3))
         rec["loop_utts_per_s"] = float(m.group(4))
+    m = re.search(r"consumer thread: (.*)", res.stdout)
+    if m:
+        rec["consumer_thread_seconds"] = {k: float(v) for k, v in re.findall(r"(\w+) ([0-9.]+) s", m.group(1))}
     return rec
 
 
