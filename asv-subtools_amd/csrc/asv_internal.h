@@ -178,6 +178,10 @@ constexpr int kBigTileN = 256;
 bool tdnn_big3_supported(const TdnnKernelParams &p, int et, bool out_f32);
 int launch_tdnn_big3(const TdnnKernelParams &p, hipStream_t s);
 int launch_tdnn_big3_variant(const TdnnKernelParams &p, int variant, hipStream_t s);
+// 256 x 256 tiles, both operands through LDS-DMA, four phases per K-tile with counted waits (kernels_tdnn_p8.hip); weights in p.w
+bool tdnn_p8_supported(const TdnnKernelParams &p, int et, bool out_f32);
+int launch_tdnn_p8(const TdnnKernelParams &p, hipStream_t s);
+int launch_tdnn_p8_variant(const TdnnKernelParams &p, int variant, hipStream_t s);
 // tdnn -> [1-tap 512 -> 512]* -> 1-tap + fused statistics pooling in one kernel, the 128 x 512 intermediate tiles resident in
 // LDS (kernels_tdnn_chain.hip).  Weight fragments as for the variant-3 kernel.
 constexpr int kChainWidth = 512;

@@ -1,0 +1,355 @@
+// 16-bit TDNN / 1x1-conv implicit GEMM, 256 x 256 tiles, BOTH operands through LDS-DMA, four phases per K-tile with counted
+// waits - the structure of the 8-phase GEMM template of /opt/skills/guides/cdna_hip_programming.md (":612-700", T2 - T5), built for
+// this library's layer shapes (round 5).  It replaces, for the layers it takes, kernels_tdnn_v3.hip's 128 x 256
+// tile (feature window through LDS, weight fragments straight from L2, two self-synchronising workgroups per CU).
+//
+//   * One workgroup of 8 waves (2 along the frames x 4 along the channels) per CU, a wave owns 128 frames x 64 channels = 4 x 2
+//     accumulators of v_mfma_f32_32x32x16 (D = W . X^T: lane = frame, registers = channels - the operand order and the epilogue of
+//     kernels_tdnn_v3.hip, so the outputs are bit-identical to that kernel's: same products, same k order).
+//   * K walks (64-channel chunk) x (tap): a K-tile is 256 frames x 64 channels of X, read at row offset d_tap (a tap is nothing but
+//     a shifted row window; rows beyond the matrix ends are clamped onto its zero gap rows), and 256 channels x 64 of the weights in
+//     their plain [cout][tap][cin] order.  Each operand tile is staged as TWO half-tiles of 128 rows x 128 bytes (16 KiB, 2 LDS-DMA
+//     instructions per wave): HB0 | HA0 | HB1 | HA1.  The rows of a half-tile are not contiguous in the matrix: half-tile HA0 holds,
+//     for each of the two wave rows, the FIRST 64 of its 128 frames, HA1 the second 64; HB0 the first 32 of every wave column's 64
+//     channels, HB1 the second 32.  A wave therefore needs HB0 + HA0 for its first accumulator quadrant, HB1 for the second, HA1
+//     for the third, and the half-tiles become free in that order.
+//   * LDS: 2 buffers x 4 half-tiles = 128 KiB (+ 3 KiB epilogue constants).  16-byte slots XOR-swizzled by (row >> 1) & 7 on the
+//     DMA SOURCE address and on the ds_read_b128 address (the LDS image of a DMA is lane-linear).
+//   * A K-tile is four phases, each {fragment reads | one half-tile staged | barrier | wait | 8 MFMAs at priority 1 | barrier}:
+//         P1: read HB0 (4) + HA0 (8), stage HA1 of K-tile kt+1, lgkmcnt(8) - the HB0 reads have returned - , barrier, lgkmcnt(0), Q(A0,B0)
+//         P2: read HB1 (4),           stage HB0 of K-tile kt+2,                                              barrier, lgkmcnt(0), Q(A0,B1)
+//         P3: read HA1 (8),           stage HA0 of K-tile kt+2,                                              barrier, lgkmcnt(0), Q(A1,B1)
+//         P4:                         stage HB1 of K-tile kt+2, vmcnt(6) - K-tile kt+1 has landed -,          barrier,             Q(A1,B0)
+//     One counted vmcnt per K-tile, never 0 in the loop: three half-tiles stay in flight across every barrier.  The two wave rows
+//     run staggered by one barrier (the second row executes one extra barrier in front of the loop, the first one behind it): on
+//     every SIMD one wave is inside its MFMA cluster while its partner issues reads and DMA.
+//     Why this is race free (the rules of the guide, ":660-669"):
+//       RAW  a staged half-tile is read one phase after the wait that retires it: the P4 wait stands in front of P4's first barrier,
+//            the reads of K-tile kt+1 start in the next phase; with the stagger, the lagging row has executed ITS P4 wait before the
+//            leading row passes P4's second barrier.
+//       WAR  a half-tile is restaged two phases after its last read (HA0: read P1, staged P3; HB1: P2 -> P4; HA1: P3 -> P1 of the
+//            next K-tile) - the reads retire at the lgkmcnt(0) behind the reading phase's first barrier, which every wave of BOTH rows
+//            has executed once the staging wave has passed two more barriers - or one phase after where the reads retire in front of
+//            the reading phase's first barrier (HB0: read first in P1, retired by lgkmcnt(8), staged in P2).
+//   * Epilogue: kernels_tdnn_v3.hip's (bias -> ReLU -> folded BN, packed 16-bit, wave-private LDS transpose, 16-byte row stores).
+#include <cstdlib>
+#include <type_traits>
+
+#include "device_utils.h"
+
+namespace asv {
+namespace {
+
+constexpr int P8_HALF = 128 * 128;                  // bytes of a half-tile
+constexpr int P8_OFF_B0 = 0, P8_OFF_A0 = P8_HALF, P8_OFF_B1 = 2 * P8_HALF, P8_OFF_A1 = 3 * P8_HALF;
+constexpr int P8_BUF = 4 * P8_HALF;                 // 64 KiB per K-tile buffer
+constexpr int P8_PARAM_OFF = 2 * P8_BUF;
+constexpr int P8_LDS_BYTES = 2 * P8_BUF + 3 * 256 * 4;
+constexpr int P8_ROWB = 128;
+
+typedef __attribute__((address_space(3))) unsigned char p8_lds_byte;
+
+// one LDS-DMA instruction: 64 lanes x 16 bytes from (scalar base + per-lane 32-bit byte offset) to LDS [M0 .. M0 + 1024)
+__device__ __forceinline__ void p8_glds(const void *sbase, uint32_t voff, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_dst)
+      : "memory");
+}
+
+// VAR (measurement variants of the developer build; 0 = the production kernel):
+//   1 no stagger between the wave rows    2 no s_setprio around the MFMA clusters    3 neither
+//   4 MFMA + barriers only (no reads, no DMA in the loop: the skeleton's ceiling; results are garbage)
+template <int ET, int VAR>
+__global__ __launch_bounds__(512, 2) void tdnn_gemm_p8_kernel(const TdnnKernelParams p, int m_tiles, int n_tiles) {
+  constexpr bool STAGGER = !(VAR == 1 || VAR == 3), PRIO = !(VAR == 2 || VAR == 3), SKELETON = VAR == 4;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[P8_LDS_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  const int tile = xcd_swizzle(blockIdx.x, m_tiles * n_tiles);
+  const int m0 = (tile / n_tiles) * 256;
+  const int n0 = (tile % n_tiles) * 256;
+
+  const unsigned char *xg = reinterpret_cast<const unsigned char *>(p.x);
+  const unsigned char *wg = reinterpret_cast<const unsigned char *>(p.w);
+  const uint32_t x_pitch = (uint32_t)p.ldx * 2u;
+  const uint32_t w_pitch = (uint32_t)p.n_taps * (uint32_t)p.cin_pad * 2u;
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(p8_lds_byte *)lds);
+  const int nchunks = p.cin_pad / 64;
+  const int n_taps = p.n_taps;
+  const int nkt = nchunks * n_taps;
+
+  // per-channel epilogue constants -> LDS (kernels_tdnn_v3.hip)
+  float *lds_par = reinterpret_cast<float *>(lds + P8_PARAM_OFF);
+  if (tid < 192) {
+    const int which = tid >> 6, idx = (tid & 63) * 4;
+    float4 v = (which == 1) ? make_float4(1.f, 1.f, 1.f, 1.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float *src = (which == 0) ? p.bias : (which == 1 ? p.scale : p.shift);
+    if (src != nullptr) v = *reinterpret_cast<const float4 *>(src + n0 + idx);
+    *reinterpret_cast<float4 *>(lds_par + which * 256 + idx) = v;
+  }
+
+  // ---- LDS-DMA pieces: a half-tile = 16 pieces of 8 rows x 128 B; this wave issues pieces 2 wave and 2 wave + 1 of every half-tile.
+  // Half-tile row r <-> matrix row:  A: frame m0 + (r >> 6) * 128 + (r & 63) (+ 64 in HA1);  B: channel n0 + (r >> 5) * 64 + (r & 31) (+ 32 in HB1)
+  const int g_row = lane >> 3, g_slot = lane & 7;
+  int a_row[2];                 // matrix row of this lane's row in HA0 (tap offset and + 64 for HA1 are added per piece, then clamped)
+  uint32_t a_slot[2];           // byte offset of the 16-byte slot this lane fetches (the swizzle lives on the source side)
+  uint32_t b_off[2];            // byte offset into the weights of this lane's 16 bytes in HB0 (+ 32 rows for HB1, + (tap, chunk) per K-tile)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (wave * 2 + i) * 8 + g_row;
+    const uint32_t slot16 = (uint32_t)(g_slot ^ ((r >> 1) & 7)) * 16u;
+    a_row[i] = m0 + (r >> 6) * 128 + (r & 63);
+    a_slot[i] = slot16;
+    b_off[i] = (uint32_t)(n0 + (r >> 5) * 64 + (r & 31)) * w_pitch + slot16;
+  }
+  // tap t in lane t (v_readlane in the loop: no s_load + lgkmcnt(0) there); built from the scalar kernel arguments - indexing the
+  // argument array by the lane is a GLOBAL load, and the compiler's vmcnt(0) in front of its first use drained the first DMA pieces
+  int v_taps = p.taps[0];
+#pragma unroll
+  for (int t = 1; t < ASV_MAX_TAPS; ++t) v_taps = (lane == t) ? p.taps[t] : v_taps;
+  const int last_row = p.rows - 1;
+
+  // stage half-tile `which` (0 HB0, 1 HA0, 2 HB1, 3 HA1) of K-tile (chunk c, tap t) into buffer b
+  auto stage = [&](int which, int c, int t, int b) {
+    if (SKELETON) return;
+    const uint32_t dst0 = lds_base + (uint32_t)b * P8_BUF + (uint32_t)which * P8_HALF + (uint32_t)wave * 2048u;
+    if (which & 1) {                                 // an A half-tile
+      const int d = __builtin_amdgcn_readlane(v_taps, t) + (which == 3 ? 64 : 0);
+      const unsigned char *base = xg + (size_t)c * 128;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = min(max(a_row[i] + d, 0), last_row);
+        p8_glds(base, (uint32_t)row * x_pitch + a_slot[i], __builtin_amdgcn_readfirstlane(dst0 + i * 1024u));
+      }
+    } else {
+      const unsigned char *base = wg + ((size_t)t * p.cin_pad + (size_t)c * 64) * 2 + (which == 2 ? (size_t)32 * w_pitch : 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) p8_glds(base, b_off[i], __builtin_amdgcn_readfirstlane(dst0 + i * 1024u));
+    }
+  };
+
+  // ---- fragment reads: 16 bytes of row (lr), k-slot (2 kg + lh) ^ swizzle
+  const uint32_t sw = (uint32_t)((lr >> 1) & 7);
+  const uint32_t a_base = (uint32_t)(wm * 64 + lr) * P8_ROWB, b_base = (uint32_t)(wn * 32 + lr) * P8_ROWB;
+  uint32_t a_addr[4], b_addr[4];          // per k-group; bit 16 toggles between the two K-tile buffers
+#pragma unroll
+  for (int kg = 0; kg < 4; ++kg) {
+    const uint32_t s16 = (((uint32_t)(kg * 2 + lh)) ^ sw) * 16u;
+    a_addr[kg] = a_base + s16;
+    b_addr[kg] = b_base + s16;
+  }
+
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  // ---- prologue: K-tile 0 complete + the first three half-tiles of K-tile 1 in flight
+  {
+    int c1 = 0, t1 = 1;
+    if (t1 == n_taps) { t1 = 0; c1 = 1; }
+    stage(0, 0, 0, 0); stage(1, 0, 0, 0); stage(2, 0, 0, 0); stage(3, 0, 0, 0);
+    if (nkt > 1) {
+      stage(0, c1, t1, 1); stage(1, c1, t1, 1); stage(2, c1, t1, 1);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (STAGGER && wm == 1) __builtin_amdgcn_s_barrier();        // this wave row runs one barrier behind the other from here on
+
+  uint4 wb0[4], wb1[4], xa[2][4];          // weight fragments of HB0 / HB1, frame fragments of the A half-tile in use
+  if (SKELETON) {
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) { wb0[kg] = make_uint4(lane, 1, 2, 3); wb1[kg] = make_uint4(3, lane, 1, 0); xa[0][kg] = make_uint4(1, 1, lane, 1); xa[1][kg] = make_uint4(2, 2, 2, lane); }
+  }
+  auto mma_q = [&](const uint4 (&wfr)[4], int j, int i0) {
+    if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg)
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2) acc[i0 + i2][j] = mfma16<ET>(wfr[kg], xa[i2][kg], acc[i0 + i2][j]);
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
+  };
+  auto barrier = [&]() {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  // K-tile kt in buffer kt & 1.  TAIL 0: K-tiles kt + 1 and kt + 2 exist; 1: kt + 1 is the last; 2: kt is the last.
+  int cs = 0, ts = 0;                       // (chunk, tap) of K-tile kt + 1, then of kt + 2 (the staging cursor runs ahead)
+  auto advance = [&]() { if (++ts == n_taps) { ts = 0; ++cs; } };
+  advance();                                // K-tile 1
+  auto ktile = [&](int kt, auto tail_c) {
+    constexpr int TAIL = decltype(tail_c)::value;
+    const uint32_t bsel = (uint32_t)(kt & 1) * P8_BUF;
+    const unsigned char *L = lds + bsel;
+    // ---- P1
+    if (!SKELETON) {
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg) wb0[kg] = *reinterpret_cast<const uint4 *>(L + P8_OFF_B0 + b_addr[kg]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg)
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) xa[i2][kg] = *reinterpret_cast<const uint4 *>(L + P8_OFF_A0 + i2 * (32 * P8_ROWB) + a_addr[kg]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (TAIL <= 1) stage(3, cs, ts, (kt + 1) & 1);               // HA1 of K-tile kt + 1
+    if (TAIL == 0) advance();                                    // the cursor moves on to K-tile kt + 2
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");           // the four HB0 reads (issued first) have returned: HB0 may be restaged in P2
+    barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    mma_q(wb0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    barrier();
+    // ---- P2
+    if (!SKELETON) {
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg) wb1[kg] = *reinterpret_cast<const uint4 *>(L + P8_OFF_B1 + b_addr[kg]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (TAIL == 0) stage(0, cs, ts, kt & 1);                     // HB0 of K-tile kt + 2
+    barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    mma_q(wb1, 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    barrier();
+    // ---- P3
+    if (!SKELETON) {
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg)
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) xa[i2][kg] = *reinterpret_cast<const uint4 *>(L + P8_OFF_A1 + i2 * (32 * P8_ROWB) + a_addr[kg]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (TAIL == 0) stage(1, cs, ts, kt & 1);                     // HA0 of K-tile kt + 2
+    barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    mma_q(wb1, 1, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    barrier();
+    // ---- P4
+    if (TAIL == 0) {
+      stage(2, cs, ts, kt & 1);                                  // HB1 of K-tile kt + 2
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");           // everything but the last three half-tiles: K-tile kt + 1 is in LDS
+    } else if (TAIL == 1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    mma_q(wb0, 0, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    barrier();
+  };
+  int kt = 0;
+  for (; kt + 2 < nkt; ++kt) ktile(kt, std::integral_constant<int, 0>{});
+  if (kt + 1 < nkt) { ktile(kt, std::integral_constant<int, 1>{}); ++kt; }
+  ktile(kt, std::integral_constant<int, 2>{});
+  if (STAGGER && wm == 0) __builtin_amdgcn_s_barrier();        // the rows meet again: every wave is done with the buffers
+  asm volatile("" ::: "memory");
+
+  // ---- epilogue (kernels_tdnn_v3.hip) ---------------------------------------------------------
+  // acc[i][j][r]: frame = m0 + wm*128 + i*32 + lr, channel = n0 + wn*64 + j*32 + 8*(r>>2) + 4*lh + (r&3)
+  unsigned char *scr = lds + wave * (128 * P8_ROWB);     // [128 frames][64 channels] 16-bit, 128-B rows, swizzled slots
+  const float act_lo = (p.act1 == ASV_ACT_RELU) ? 0.0f : -INFINITY;
+  uint32_t vmask = 0;                                     // bit i: this lane's frame of m-fragment i is a real frame
+#pragma unroll
+  for (int i = 0; i < 4; ++i) vmask |= ((p.row_valid[(m0 + wm * 128 + i * 32) >> 5] >> lr) & 1u) << i;
+  auto swz = [](int row, int slot) { return slot ^ ((row >> 1) & 7); };
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int chl = wn * 64 + j * 32 + 8 * q + 4 * lh;                 // channel inside the tile
+      const float4 b4 = *reinterpret_cast<const float4 *>(lds_par + chl);
+      const float4 sc4 = *reinterpret_cast<const float4 *>(lds_par + 256 + chl);
+      const float4 sh4 = *reinterpret_cast<const float4 *>(lds_par + 512 + chl);
+      const float b[4] = {b4.x, b4.y, b4.z, b4.w}, sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+      const int slot = j * 4 + q;                // channel offset j*32 + 8*q + 4*lh -> 16-B slot, 8-B half lh
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool valid = (vmask >> i) & 1u;
+        const int frow = i * 32 + lr;            // row inside the wave's scratch tile
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = tdnn_epilogue_fast(acc[i][j][q * 4 + e], b[e], act_lo, sc[e], sh[e], true);
+        uint2 pk;
+        pk.x = pack_h16x2<ET>(y[0], y[1]);
+        pk.y = pack_h16x2<ET>(y[2], y[3]);
+        pk.x = valid ? pk.x : 0u;                  // gap rows are zeros: on the packed pairs, 2 selects per 4 values
+        pk.y = valid ? pk.y : 0u;
+        // odd rows keep their two 8-byte halves swapped so rows r, r+1 (same slot) hit different banks
+        *reinterpret_cast<uint2 *>(scr + frow * P8_ROWB + swz(frow, slot) * 16 + ((lh ^ (frow & 1)) * 8)) = pk;
+      }
+    }
+  }
+  // the scratch tile belongs to this wave only: LDS ops of one wave complete in order
+  {
+    unsigned char *yg = reinterpret_cast<unsigned char *>(p.y);
+    const size_t y_pitch = (size_t)p.ldy * 2;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int piece = it * 64 + lane, frow = piece >> 3, slot = piece & 7;
+      uint4 v = *reinterpret_cast<const uint4 *>(scr + frow * P8_ROWB + swz(frow, slot) * 16);
+      if (frow & 1) v = make_uint4(v.z, v.w, v.x, v.y);
+      const int ch = n0 + wn * 64 + slot * 8;
+      const int row = m0 + wm * 128 + frow;
+      if (ch < p.cout_store) *reinterpret_cast<uint4 *>(yg + (size_t)row * y_pitch + (size_t)ch * 2) = v;
+    }
+  }
+}
+
+}  // namespace
+
+// Layers the 8-phase kernel takes: 16-bit rows, the plain epilogue (affine -> [ReLU] -> folded BN), whole 64-channel chunks.
+bool tdnn_p8_supported(const TdnnKernelParams &p, int et, bool out_f32) {
+  const bool fits32 = (unsigned long long)p.rows * (unsigned long long)p.ldx * 2ull < (1ull << 32) &&
+                      (unsigned long long)round_up(p.cout_store, 256) * (unsigned long long)p.n_taps * (unsigned long long)p.cin_pad * 2ull < (1ull << 32);
+  const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first;
+  return p.w != nullptr && et != ET_F32 && !out_f32 && fits32 && fast && p.x2 == nullptr && p.seg_bias == nullptr && p.seg_scale == nullptr && p.res == nullptr &&
+         p.pool_partial == nullptr && p.rows % 256 == 0 && p.rows >= 256 && p.cin_pad % 64 == 0 && p.cin_pad >= 64 && p.cout_store % 8 == 0 && p.cout_store >= 192 &&
+         p.n_taps >= 1 && p.n_taps <= ASV_MAX_TAPS && p.row_valid != nullptr;
+}
+
+int launch_tdnn_p8_variant(const TdnnKernelParams &p, int variant, hipStream_t s) {
+  ASV_REQUIRE(tdnn_p8_supported(p, p.et, false), "tdnn(p8): layer shape not supported (rows %d cin %d cout %d taps %d)", p.rows, p.cin_pad, p.cout_store, p.n_taps);
+  const int m_tiles = p.rows / 256, n_tiles = round_up(p.cout_store, 256) / 256;
+  const dim3 grid(m_tiles * n_tiles), block(512);
+  const bool f16 = p.et == ET_F16;
+  switch (variant) {
+#ifdef ASV_WITH_ABLATION
+    case 1: hipLaunchKernelGGL((tdnn_gemm_p8_kernel<ET_BF16, 1>), grid, block, 0, s, p, m_tiles, n_tiles); break;
+    case 2: hipLaunchKernelGGL((tdnn_gemm_p8_kernel<ET_BF16, 2>), grid, block, 0, s, p, m_tiles, n_tiles); break;
+    case 3: hipLaunchKernelGGL((tdnn_gemm_p8_kernel<ET_BF16, 3>), grid, block, 0, s, p, m_tiles, n_tiles); break;
+    case 4: hipLaunchKernelGGL((tdnn_gemm_p8_kernel<ET_BF16, 4>), grid, block, 0, s, p, m_tiles, n_tiles); break;
+#endif
+    default:
+      if (f16) hipLaunchKernelGGL((tdnn_gemm_p8_kernel<ET_F16, 0>), grid, block, 0, s, p, m_tiles, n_tiles);
+      else hipLaunchKernelGGL((tdnn_gemm_p8_kernel<ET_BF16, 0>), grid, block, 0, s, p, m_tiles, n_tiles);
+  }
+  ASV_HIP_CHECK(hipGetLastError());
+  return ASV_OK;
+}
+
+int launch_tdnn_p8(const TdnnKernelParams &p, hipStream_t s) { return launch_tdnn_p8_variant(p, 0, s); }
+
+}  // namespace asv
