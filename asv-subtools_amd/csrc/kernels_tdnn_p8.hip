@@ -15,12 +15,15 @@
 //     for the third, and the half-tiles become free in that order.
 //   * LDS: 2 buffers x 4 half-tiles = 128 KiB (+ 3 KiB epilogue constants).  16-byte slots XOR-swizzled by (row >> 1) & 7 on the
 //     DMA SOURCE address and on the ds_read_b128 address (the LDS image of a DMA is lane-linear).
-//   * A K-tile is four phases, each {fragment reads | one half-tile staged | barrier | wait | 8 MFMAs at priority 1 | barrier}:
-//         P1: read HB0 (4) + HA0 (8), stage HA1 of K-tile kt+1, lgkmcnt(8) - the HB0 reads have returned - , barrier, lgkmcnt(0), Q(A0,B0)
-//         P2: read HB1 (4),           stage HB0 of K-tile kt+2,                                              barrier, lgkmcnt(0), Q(A0,B1)
-//         P3: read HA1 (8),           stage HA0 of K-tile kt+2,                                              barrier, lgkmcnt(0), Q(A1,B1)
-//         P4:                         stage HB1 of K-tile kt+2, vmcnt(6) - K-tile kt+1 has landed -,          barrier,             Q(A1,B0)
-//     One counted vmcnt per K-tile, never 0 in the loop: three half-tiles stay in flight across every barrier.  The two wave rows
+//   * A K-tile is four phases, each {fragment reads | one half-tile staged | [wait] | barrier | lgkmcnt(0) | 8 MFMAs | barrier}:
+//         P1: read HA0 (8),               stage HA1 of K-tile kt+1,                                                  Q(A0,B0)
+//         P2: read HB1 (4),               stage HB0 of K-tile kt+2,                                                  Q(A0,B1)
+//         P3: read HA1 (8),               stage HA0 of K-tile kt+2, vmcnt(10) - HB0 of K-tile kt+1 has landed -,      Q(A1,B1)
+//         P4: read HB0 of K-tile kt+1 (4) stage HB1 of K-tile kt+2, vmcnt(6)  - all of K-tile kt+1 has landed -,      Q(A1,B0)
+//     (the HB0 fragments live in two register sets: P4's MFMAs use this K-tile's while the next one's arrive; first version:
+//     HB0 + HA0 = 12 reads in P1 and none in P4 - the phase with the reads of a wave is the one its partner's MFMA cluster has to
+//     cover, 8 / 4 / 8 / 4 instead of 12 / 4 / 8 / 0 brought ... see DESIGN.md)
+//     Counted vmcnt, never 0 in the loop: three half-tiles stay in flight across every barrier.  The two wave rows
 //     run staggered by one barrier (the second row executes one extra barrier in front of the loop, the first one behind it): on
 //     every SIMD one wave is inside its MFMA cluster while its partner issues reads and DMA.
 //     Why this is race free (the rules of the guide, ":660-669"):
@@ -30,7 +33,8 @@
 //       WAR  a half-tile is restaged two phases after its last read (HA0: read P1, staged P3; HB1: P2 -> P4; HA1: P3 -> P1 of the
 //            next K-tile) - the reads retire at the lgkmcnt(0) behind the reading phase's first barrier, which every wave of BOTH rows
 //            has executed once the staging wave has passed two more barriers - or one phase after where the reads retire in front of
-//            the reading phase's first barrier (HB0: read first in P1, retired by lgkmcnt(8), staged in P2).
+//            the reading phase's first barrier (first version only: HB0 read first in P1, retired by lgkmcnt(8), staged in P2; now
+//            HB0 is read in P4 of the previous K-tile and restaged in P2: two phases).
 //   * Epilogue: kernels_tdnn_v3.hip's (bias -> ReLU -> folded BN, packed 16-bit, wave-private LDS transpose, 16-byte row stores).
 #include <cstdlib>
 #include <type_traits>
@@ -49,26 +53,27 @@ constexpr int P8_ROWB = 128;
 
 typedef __attribute__((address_space(3))) unsigned char p8_lds_byte;
 
-// one LDS-DMA instruction: 64 lanes x 16 bytes from (scalar base + per-lane 32-bit byte offset) to LDS [M0 .. M0 + 1024)
+// one LDS-DMA instruction: 64 lanes x 16 bytes from (scalar base + per-lane 32-bit byte offset) to LDS [M0 .. M0 + 1024).
+// M0 is declared clobbered instead of saved and restored (nothing else in this kernel reads it: two SALU operations less per piece).
 __device__ __forceinline__ void p8_glds(const void *sbase, uint32_t voff, uint32_t lds_dst) {
-  uint32_t keep;
   asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %3\n\t"
+      "s_mov_b32 m0, %2\n\t"
       "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %2\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
+      "global_load_lds_dwordx4 %0, %1"
+      :
       : "v"(voff), "s"(sbase), "s"(lds_dst)
-      : "memory");
+      : "memory", "m0");
 }
 
 // VAR (measurement variants of the developer build; 0 = the production kernel):
 //   1 no stagger between the wave rows    2 no s_setprio around the MFMA clusters    3 neither
 //   4 MFMA + barriers only (no reads, no DMA in the loop: the skeleton's ceiling; results are garbage)
-template <int ET, int VAR>
+//   5 no DMA in the loop (fragment reads of stale LDS; garbage)    6 no fragment reads in the loop (garbage)
+// ONE_TAP: a 1-tap layer (row offset 0): the DMA source offsets of the feature rows are loop constants
+template <int ET, int VAR, bool ONE_TAP>
 __global__ __launch_bounds__(512, 2) void tdnn_gemm_p8_kernel(const TdnnKernelParams p, int m_tiles, int n_tiles) {
-  constexpr bool STAGGER = !(VAR == 1 || VAR == 3), PRIO = !(VAR == 2 || VAR == 3), SKELETON = VAR == 4;
+  constexpr bool STAGGER = !(VAR == 1 || VAR == 3), PRIO = (VAR == 2 || VAR == 3), SKELETON = VAR == 4;
+  constexpr bool NO_DMA = SKELETON || VAR == 5, NO_READS = SKELETON || VAR == 6;
   __shared__ __attribute__((aligned(16))) unsigned char lds[P8_LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -82,11 +87,11 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_p8_kernel(const TdnnKernelPa
   const unsigned char *xg = reinterpret_cast<const unsigned char *>(p.x);
   const unsigned char *wg = reinterpret_cast<const unsigned char *>(p.w);
   const uint32_t x_pitch = (uint32_t)p.ldx * 2u;
-  const uint32_t w_pitch = (uint32_t)p.n_taps * (uint32_t)p.cin_pad * 2u;
+  const int cin_pad = p.cin_pad;
+  const int n_taps = ONE_TAP ? 1 : p.n_taps;
+  const uint32_t w_pitch = (uint32_t)n_taps * (uint32_t)cin_pad * 2u;
   const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(p8_lds_byte *)lds);
-  const int nchunks = p.cin_pad / 64;
-  const int n_taps = p.n_taps;
-  const int nkt = nchunks * n_taps;
+  const int nkt = (cin_pad / 64) * n_taps;
 
   // per-channel epilogue constants -> LDS (kernels_tdnn_v3.hip)
   float *lds_par = reinterpret_cast<float *>(lds + P8_PARAM_OFF);
@@ -103,36 +108,46 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_p8_kernel(const TdnnKernelPa
   const int g_row = lane >> 3, g_slot = lane & 7;
   int a_row[2];                 // matrix row of this lane's row in HA0 (tap offset and + 64 for HA1 are added per piece, then clamped)
   uint32_t a_slot[2];           // byte offset of the 16-byte slot this lane fetches (the swizzle lives on the source side)
+  uint32_t a_voff[2][2];        // ONE_TAP: the whole per-lane source offset of HA0 / HA1
   uint32_t b_off[2];            // byte offset into the weights of this lane's 16 bytes in HB0 (+ 32 rows for HB1, + (tap, chunk) per K-tile)
+  const int last_row = p.rows - 1;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int r = (wave * 2 + i) * 8 + g_row;
     const uint32_t slot16 = (uint32_t)(g_slot ^ ((r >> 1) & 7)) * 16u;
     a_row[i] = m0 + (r >> 6) * 128 + (r & 63);
     a_slot[i] = slot16;
+    a_voff[0][i] = (uint32_t)a_row[i] * x_pitch + slot16;
+    a_voff[1][i] = (uint32_t)min(a_row[i] + 64, last_row) * x_pitch + slot16;
     b_off[i] = (uint32_t)(n0 + (r >> 5) * 64 + (r & 31)) * w_pitch + slot16;
   }
   // tap t in lane t (v_readlane in the loop: no s_load + lgkmcnt(0) there); built from the scalar kernel arguments - indexing the
   // argument array by the lane is a GLOBAL load, and the compiler's vmcnt(0) in front of its first use drained the first DMA pieces
   int v_taps = p.taps[0];
+  if (!ONE_TAP) {
 #pragma unroll
-  for (int t = 1; t < ASV_MAX_TAPS; ++t) v_taps = (lane == t) ? p.taps[t] : v_taps;
-  const int last_row = p.rows - 1;
+    for (int t = 1; t < ASV_MAX_TAPS; ++t) v_taps = (lane == t) ? p.taps[t] : v_taps;
+  }
 
   // stage half-tile `which` (0 HB0, 1 HA0, 2 HB1, 3 HA1) of K-tile (chunk c, tap t) into buffer b
-  auto stage = [&](int which, int c, int t, int b) {
-    if (SKELETON) return;
+  auto stage = [&](int which, int c, int t, int b, bool in_loop) {
+    if (NO_DMA && in_loop) return;
     const uint32_t dst0 = lds_base + (uint32_t)b * P8_BUF + (uint32_t)which * P8_HALF + (uint32_t)wave * 2048u;
     if (which & 1) {                                 // an A half-tile
-      const int d = __builtin_amdgcn_readlane(v_taps, t) + (which == 3 ? 64 : 0);
       const unsigned char *base = xg + (size_t)c * 128;
+      if (ONE_TAP) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = min(max(a_row[i] + d, 0), last_row);
-        p8_glds(base, (uint32_t)row * x_pitch + a_slot[i], __builtin_amdgcn_readfirstlane(dst0 + i * 1024u));
+        for (int i = 0; i < 2; ++i) p8_glds(base, a_voff[which == 3][i], __builtin_amdgcn_readfirstlane(dst0 + i * 1024u));
+      } else {
+        const int d = __builtin_amdgcn_readlane(v_taps, t) + (which == 3 ? 64 : 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int row = min(max(a_row[i] + d, 0), last_row);
+          p8_glds(base, (uint32_t)row * x_pitch + a_slot[i], __builtin_amdgcn_readfirstlane(dst0 + i * 1024u));
+        }
       }
     } else {
-      const unsigned char *base = wg + ((size_t)t * p.cin_pad + (size_t)c * 64) * 2 + (which == 2 ? (size_t)32 * w_pitch : 0);
+      const unsigned char *base = wg + ((size_t)t * cin_pad + (size_t)c * 64) * 2 + (which == 2 ? (size_t)32 * w_pitch : 0);
 #pragma unroll
       for (int i = 0; i < 2; ++i) p8_glds(base, b_off[i], __builtin_amdgcn_readfirstlane(dst0 + i * 1024u));
     }
@@ -141,7 +156,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_p8_kernel(const TdnnKernelPa
   // ---- fragment reads: 16 bytes of row (lr), k-slot (2 kg + lh) ^ swizzle
   const uint32_t sw = (uint32_t)((lr >> 1) & 7);
   const uint32_t a_base = (uint32_t)(wm * 64 + lr) * P8_ROWB, b_base = (uint32_t)(wn * 32 + lr) * P8_ROWB;
-  uint32_t a_addr[4], b_addr[4];          // per k-group; bit 16 toggles between the two K-tile buffers
+  uint32_t a_addr[4], b_addr[4];          // per k-group; the K-tile buffer (bit 16) is added per K-tile
 #pragma unroll
   for (int kg = 0; kg < 4; ++kg) {
     const uint32_t s16 = (((uint32_t)(kg * 2 + lh)) ^ sw) * 16u;
@@ -161,9 +176,9 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_p8_kernel(const TdnnKernelPa
   {
     int c1 = 0, t1 = 1;
     if (t1 == n_taps) { t1 = 0; c1 = 1; }
-    stage(0, 0, 0, 0); stage(1, 0, 0, 0); stage(2, 0, 0, 0); stage(3, 0, 0, 0);
+    stage(0, 0, 0, 0, false); stage(1, 0, 0, 0, false); stage(2, 0, 0, 0, false); stage(3, 0, 0, 0, false);
     if (nkt > 1) {
-      stage(0, c1, t1, 1); stage(1, c1, t1, 1); stage(2, c1, t1, 1);
+      stage(0, c1, t1, 1, false); stage(1, c1, t1, 1, false); stage(2, c1, t1, 1, false);
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -171,13 +186,22 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_p8_kernel(const TdnnKernelPa
   }
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+
+  // weight fragments of HB0 (two sets: the next K-tile's are read in P4, while the current ones feed P4's MFMAs) and HB1, frame
+  // fragments of the A half-tile in use
+  uint4 wb0[2][4], wb1[4], xa[2][4];
+  if (NO_READS) {
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+      wb0[0][kg] = make_uint4(lane, 1, 2, 3); wb0[1][kg] = make_uint4(lane, 5, 2, 3); wb1[kg] = make_uint4(3, lane, 1, 0);
+      xa[0][kg] = make_uint4(1, 1, lane, 1); xa[1][kg] = make_uint4(2, 2, 2, lane);
+    }
+  } else {
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) wb0[0][kg] = *reinterpret_cast<const uint4 *>(lds + P8_OFF_B0 + b_addr[kg]);     // HB0 of K-tile 0
+  }
   if (STAGGER && wm == 1) __builtin_amdgcn_s_barrier();        // this wave row runs one barrier behind the other from here on
 
-  uint4 wb0[4], wb1[4], xa[2][4];          // weight fragments of HB0 / HB1, frame fragments of the A half-tile in use
-  if (SKELETON) {
-#pragma unroll
-    for (int kg = 0; kg < 4; ++kg) { wb0[kg] = make_uint4(lane, 1, 2, 3); wb1[kg] = make_uint4(3, lane, 1, 0); xa[0][kg] = make_uint4(1, 1, lane, 1); xa[1][kg] = make_uint4(2, 2, 2, lane); }
-  }
   auto mma_q = [&](const uint4 (&wfr)[4], int j, int i0) {
     if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -191,79 +215,89 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_p8_kernel(const TdnnKernelPa
     asm volatile("" ::: "memory");
   };
 
-  // K-tile kt in buffer kt & 1.  TAIL 0: K-tiles kt + 1 and kt + 2 exist; 1: kt + 1 is the last; 2: kt is the last.
+  // K-tile kt in buffer kt & 1 (= PAR, also the register set of its HB0 fragments).
+  // TAIL 0: K-tiles kt + 1 and kt + 2 exist; 1: kt + 1 is the last; 2: kt is the last.
   int cs = 0, ts = 0;                       // (chunk, tap) of K-tile kt + 1, then of kt + 2 (the staging cursor runs ahead)
   auto advance = [&]() { if (++ts == n_taps) { ts = 0; ++cs; } };
   advance();                                // K-tile 1
-  auto ktile = [&](int kt, auto tail_c) {
-    constexpr int TAIL = decltype(tail_c)::value;
-    const uint32_t bsel = (uint32_t)(kt & 1) * P8_BUF;
-    const unsigned char *L = lds + bsel;
-    // ---- P1
-    if (!SKELETON) {
-#pragma unroll
-      for (int kg = 0; kg < 4; ++kg) wb0[kg] = *reinterpret_cast<const uint4 *>(L + P8_OFF_B0 + b_addr[kg]);
-      __builtin_amdgcn_sched_barrier(0);
+  auto ktile = [&](auto tail_c, auto par_c) {
+    constexpr int TAIL = decltype(tail_c)::value, PAR = decltype(par_c)::value;
+    const unsigned char *L = lds + PAR * P8_BUF, *Ln = lds + (PAR ^ 1) * P8_BUF;
+    // ---- P1: read HA0 (8), stage HA1 of K-tile kt + 1
+    if (!NO_READS) {
 #pragma unroll
       for (int kg = 0; kg < 4; ++kg)
 #pragma unroll
         for (int i2 = 0; i2 < 2; ++i2) xa[i2][kg] = *reinterpret_cast<const uint4 *>(L + P8_OFF_A0 + i2 * (32 * P8_ROWB) + a_addr[kg]);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (TAIL <= 1) stage(3, cs, ts, (kt + 1) & 1);               // HA1 of K-tile kt + 1
+    if (TAIL <= 1) stage(3, cs, ts, PAR ^ 1, true);
     if (TAIL == 0) advance();                                    // the cursor moves on to K-tile kt + 2
-    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");           // the four HB0 reads (issued first) have returned: HB0 may be restaged in P2
     barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    mma_q(wb0, 0, 0);
+    mma_q(wb0[PAR], 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     barrier();
-    // ---- P2
-    if (!SKELETON) {
+    // ---- P2: read HB1 (4), stage HB0 of K-tile kt + 2 (HB0 of this K-tile was read in P4 of the previous one)
+    if (!NO_READS) {
 #pragma unroll
       for (int kg = 0; kg < 4; ++kg) wb1[kg] = *reinterpret_cast<const uint4 *>(L + P8_OFF_B1 + b_addr[kg]);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (TAIL == 0) stage(0, cs, ts, kt & 1);                     // HB0 of K-tile kt + 2
+    if (TAIL == 0) stage(0, cs, ts, PAR, true);
     barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     mma_q(wb1, 1, 0);
     __builtin_amdgcn_sched_barrier(0);
     barrier();
-    // ---- P3
-    if (!SKELETON) {
+    // ---- P3: read HA1 (8), stage HA0 of K-tile kt + 2; HB0 of K-tile kt + 1 (staged 5 | 3 half-tiles ago) has landed behind this wait
+    if (!NO_READS) {
 #pragma unroll
       for (int kg = 0; kg < 4; ++kg)
 #pragma unroll
         for (int i2 = 0; i2 < 2; ++i2) xa[i2][kg] = *reinterpret_cast<const uint4 *>(L + P8_OFF_A1 + i2 * (32 * P8_ROWB) + a_addr[kg]);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (TAIL == 0) stage(1, cs, ts, kt & 1);                     // HA0 of K-tile kt + 2
+    if (TAIL == 0) {
+      stage(1, cs, ts, PAR, true);
+      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    } else if (TAIL == 1) {
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    }
     barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     mma_q(wb1, 1, 2);
     __builtin_amdgcn_sched_barrier(0);
     barrier();
-    // ---- P4
+    // ---- P4: read HB0 of K-tile kt + 1 (4) into the other register set, stage HB1 of K-tile kt + 2; K-tile kt + 1 has landed behind this wait
+    if (!NO_READS && TAIL <= 1) {
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg) wb0[PAR ^ 1][kg] = *reinterpret_cast<const uint4 *>(Ln + P8_OFF_B0 + b_addr[kg]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if (TAIL == 0) {
-      stage(2, cs, ts, kt & 1);                                  // HB1 of K-tile kt + 2
+      stage(2, cs, ts, PAR, true);
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");           // everything but the last three half-tiles: K-tile kt + 1 is in LDS
     } else if (TAIL == 1) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the HB0 reads retire here: two phases before that half-tile is restaged
     __builtin_amdgcn_sched_barrier(0);
-    mma_q(wb0, 0, 2);
+    mma_q(wb0[PAR], 0, 2);
     __builtin_amdgcn_sched_barrier(0);
     barrier();
   };
-  int kt = 0;
-  for (; kt + 2 < nkt; ++kt) ktile(kt, std::integral_constant<int, 0>{});
-  if (kt + 1 < nkt) { ktile(kt, std::integral_constant<int, 1>{}); ++kt; }
-  ktile(kt, std::integral_constant<int, 2>{});
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+  // nkt is even (tdnn_p8_supported): pairs of K-tiles, one per register set of the HB0 fragments, then the two closing ones.  (One
+  // straight line of code on purpose: with the three possible remainders of an odd / even count as if - else alternatives the
+  // register allocator kept a copy of the 128 accumulator registers per alternative - 560 spilled registers.)
+  for (int kt = 0; kt + 2 < nkt; kt += 2) { ktile(I0{}, I0{}); ktile(I0{}, I1{}); }
+  ktile(I1{}, I0{});
+  ktile(I2{}, I1{});
   if (STAGGER && wm == 0) __builtin_amdgcn_s_barrier();        // the rows meet again: every wave is done with the buffers
   asm volatile("" ::: "memory");
 
@@ -327,7 +361,7 @@ bool tdnn_p8_supported(const TdnnKernelParams &p, int et, bool out_f32) {
   const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first;
   return p.w != nullptr && et != ET_F32 && !out_f32 && fits32 && fast && p.x2 == nullptr && p.seg_bias == nullptr && p.seg_scale == nullptr && p.res == nullptr &&
          p.pool_partial == nullptr && p.rows % 256 == 0 && p.rows >= 256 && p.cin_pad % 64 == 0 && p.cin_pad >= 64 && p.cout_store % 8 == 0 && p.cout_store >= 192 &&
-         p.n_taps >= 1 && p.n_taps <= ASV_MAX_TAPS && p.row_valid != nullptr;
+         p.n_taps >= 1 && p.n_taps <= ASV_MAX_TAPS && p.row_valid != nullptr && ((p.cin_pad / 64) * p.n_taps) % 2 == 0;       // an even number of K-tiles
 }
 
 int launch_tdnn_p8_variant(const TdnnKernelParams &p, int variant, hipStream_t s) {
@@ -335,17 +369,22 @@ int launch_tdnn_p8_variant(const TdnnKernelParams &p, int variant, hipStream_t s
   const int m_tiles = p.rows / 256, n_tiles = round_up(p.cout_store, 256) / 256;
   const dim3 grid(m_tiles * n_tiles), block(512);
   const bool f16 = p.et == ET_F16;
+  const bool one = p.n_taps == 1 && p.taps[0] == 0;
+#define ASV_P8(ETV, VARV) do { if (one) hipLaunchKernelGGL((tdnn_gemm_p8_kernel<ETV, VARV, true>), grid, block, 0, s, p, m_tiles, n_tiles); \
+                               else hipLaunchKernelGGL((tdnn_gemm_p8_kernel<ETV, VARV, false>), grid, block, 0, s, p, m_tiles, n_tiles); } while (0)
   switch (variant) {
 #ifdef ASV_WITH_ABLATION
-    case 1: hipLaunchKernelGGL((tdnn_gemm_p8_kernel<ET_BF16, 1>), grid, block, 0, s, p, m_tiles, n_tiles); break;
-    case 2: hipLaunchKernelGGL((tdnn_gemm_p8_kernel<ET_BF16, 2>), grid, block, 0, s, p, m_tiles, n_tiles); break;
-    case 3: hipLaunchKernelGGL((tdnn_gemm_p8_kernel<ET_BF16, 3>), grid, block, 0, s, p, m_tiles, n_tiles); break;
-    case 4: hipLaunchKernelGGL((tdnn_gemm_p8_kernel<ET_BF16, 4>), grid, block, 0, s, p, m_tiles, n_tiles); break;
+    case 1: ASV_P8(ET_BF16, 1); break;
+    case 2: ASV_P8(ET_BF16, 2); break;
+    case 4: ASV_P8(ET_BF16, 4); break;
+    case 5: ASV_P8(ET_BF16, 5); break;
+    case 6: ASV_P8(ET_BF16, 6); break;
 #endif
     default:
-      if (f16) hipLaunchKernelGGL((tdnn_gemm_p8_kernel<ET_F16, 0>), grid, block, 0, s, p, m_tiles, n_tiles);
-      else hipLaunchKernelGGL((tdnn_gemm_p8_kernel<ET_BF16, 0>), grid, block, 0, s, p, m_tiles, n_tiles);
+      if (f16) ASV_P8(ET_F16, 0);
+      else ASV_P8(ET_BF16, 0);
   }
+#undef ASV_P8
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }

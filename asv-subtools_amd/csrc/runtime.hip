@@ -1375,6 +1375,13 @@ int run_ops(RunCtx &c, size_t n_ops) {
           if ((rc = ensure(net->poolpart_dev, (size_t)(p.rows / 128) * pool_slots * 3 * p.ld_partial * 4, c.s, false))) return rc;
           p.pool_partial = reinterpret_cast<float *>(net->poolpart_dev.ptr);
         }
+        // Round 5: the layers of the variant-3 kernel with the plain epilogue, whole 64-channel chunks and at least one round of 256 x 256
+        // tiles on the chip's CUs go to the 8-phase kernel (kernels_tdnn_p8.hip: both operands through LDS-DMA, staggered wave rows;
+        // bit-identical outputs, 1.03 - 1.15 x the rate: profiles/r5e_p8_shapes.txt).  ASV_AMD_P8=0: the variant-3 kernel everywhere.
+        static const int p8_env = getenv("ASV_AMD_P8") ? atoi(getenv("ASV_AMD_P8")) : 1;
+        const int p8_on = getenv("ASV_AMD_LIVE_TUNE") != nullptr ? (getenv("ASV_AMD_P8") ? atoi(getenv("ASV_AMD_P8")) : 1) : p8_env;
+        const bool p8 = big3 && !fuse && p8_on != 0 && tdnn_p8_supported(p, et, !bf16) &&
+                        (long long)(p.rows / 256) * (round_up(p.cout_store, 256) / 256) >= (p8_on > 1 ? p8_on : 256);
         if (use_ref) rc = launch_tdnn_ref(p, et, !bf16, c.s);
         else if (utts_kernel) {
           // last layer, every utterance a single chunk: the kernel also produces the caller's [utterance][embed_dim] result
@@ -1394,6 +1401,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         else if (c1_conv) rc = launch_grid_conv_c1(p, c.s);
         else if (x3) rc = launch_tdnn_x3(p, c.s);
         else if (x3_conv) rc = launch_grid_conv_x3(p, c.s);
+        else if (p8) rc = launch_tdnn_p8(p, c.s);
         else if (big3) rc = launch_tdnn_big3(p, c.s);
         else {
           rc = launch_tdnn_mfma(p, et, !bf16, c.s);

@@ -96,7 +96,7 @@ int main(int argc, char **argv) {
   printf("p8 vs big3 over 6 more launches: %zu differing values\n", race);
   // ---- timing: interleaved rounds
   struct Var { const char *name; int kind, variant; };
-  const Var vars[] = {{"big3 128x256 (2 WG/CU)", 0, 0}, {"big3 256x256 (1 WG/CU)", 0, 100}, {"p8", 1, 0}, {"p8 no stagger", 1, 1}, {"p8 no setprio", 1, 2}, {"p8 no stagger, no setprio", 1, 3},
+  const Var vars[] = {{"big3 128x256 (2 WG/CU)", 0, 0}, {"p8", 1, 0}, {"p8 no stagger", 1, 1}, {"p8 with setprio", 1, 2}, {"p8 no DMA in the loop", 1, 5}, {"p8 no fragment reads in the loop", 1, 6},
                       {"p8 skeleton (MFMA + barriers)", 1, 4}};
   const int nv = sizeof(vars) / sizeof(vars[0]);
   std::vector<std::vector<float>> us(nv);

@@ -37,13 +37,15 @@ def balance_by_length(lengths, n_shards):
     return [np.asarray(s, dtype=np.int64) for s in shards]
 
 
-def plan_batches(lengths, indices, max_frames=65536, max_utts=1024):
+def plan_batches(lengths, indices, max_frames=65536, max_utts=1024, row_pad=0):
     """Groups a shard's utterances (already length-sorted) into batches bounded by total frames
-    and count; neighbours have similar length, so the packed ragged batch wastes no padding."""
+    and count; neighbours have similar length, so the packed ragged batch wastes no padding.
+    row_pad: rows the device layout adds per utterance (its 4 gap rows): frames + row_pad * (utterances + 1) <= max_frames as well,
+    so that a batch fills whole tiles of the device's row count (see pipeline/onestep/extract_embeddings.py extract_stream)."""
     batches, cur, frames = [], [], 0
     for i in indices:
         n = int(lengths[i])
-        if cur and (frames + n > max_frames or len(cur) >= max_utts):
+        if cur and (frames + n + row_pad * (len(cur) + 2) > max_frames or len(cur) >= max_utts):
             batches.append(cur)
             cur, frames = [], 0
         cur.append(int(i))
@@ -97,7 +99,7 @@ def _agree_or_raise(err, embed_dim, device, group, rank, world):
     return width
 
 
-def extract_sharded(extract_batch, lengths, load_utt, max_frames=65536, max_utts=1024, group=None, device=None):
+def extract_sharded(extract_batch, lengths, load_utt, max_frames=65536, max_utts=1024, group=None, device=None, row_pad=0):
     """Full sharded extraction.
         extract_batch(list_of_mats) -> [b, E] tensor on `device`     (e.g. Engine.extract_device wrapper)
         load_utt(i) -> [T_i, D] float32 matrix of utterance i          (only called for this rank's shard)
@@ -120,7 +122,7 @@ def extract_sharded(extract_batch, lengths, load_utt, max_frames=65536, max_utts
     fetch = (lambda b: whole(b)) if whole is not None else (lambda b: [load_utt(i) for i in b])
     pool = ThreadPoolExecutor(1)
     try:
-        batches = list(plan_batches(lengths, mine, max_frames, max_utts))
+        batches = list(plan_batches(lengths, mine, max_frames, max_utts, row_pad))
         ahead = pool.submit(fetch, batches[0]) if batches else None
         for k in range(len(batches)):
             mats = ahead.result()

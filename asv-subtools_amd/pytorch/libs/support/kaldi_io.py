@@ -449,6 +449,8 @@ class PackedArkReader(object):
         self.pos = 0
         self.eof = False
         self._pending = None                                  # (key, rows, cols, kind) parsed but not consumed yet
+        self.row_pad = 0                                      # rows the consumer adds per utterance (the device layout's gap rows): a group is
+                                                              # cut so that frames + row_pad * (utterances + 1) fits the buffer's row count too
 
     # -- byte supply ---------------------------------------------------------------------------------
     def _avail(self):
@@ -579,7 +581,7 @@ class PackedArkReader(object):
                     self._payload_into(big.reshape(-1).view(np.uint8), big.nbytes)
                     big = big.astype(np.float32, copy=False)
                 return [key], np.array([0, rows], dtype=np.int32), big
-            if used + rows > cap:
+            if used + rows > cap or (keys and used + rows + self.row_pad * (len(keys) + 2) > cap):
                 break
             self._pending = None
             if isinstance(kind, np.ndarray):
@@ -629,6 +631,7 @@ class IndexedArkReader(object):
         self._at = self._n = 0
         self._stopped = 1
         self._tail = None                                    # PackedArkReader for the rest of the file once another kind of entry shows up
+        self.row_pad = 0                                     # as PackedArkReader.row_pad
         self._more()
 
     def _more(self):
@@ -647,6 +650,7 @@ class IndexedArkReader(object):
         if self._tail is None and self._stopped in (2, 3):
             self.f.seek(self._next)
             self._tail = PackedArkReader(self.f)
+            self._tail.row_pad = self.row_pad
         return self._tail
 
     def peek_dim(self):
@@ -672,6 +676,10 @@ class IndexedArkReader(object):
             rows = self._rows[a:a + m].astype(np.int64)
             ends = np.cumsum(rows)
             take = int(np.searchsorted(ends, cap - used, side="right"))         # how many of them still fit
+            if self.row_pad and take:
+                # ... with the consumer's gap rows counted in: frames + row_pad * (utterances + 1) <= cap (at least one utterance per group)
+                padded = ends + self.row_pad * (np.arange(1, len(ends) + 1) + len(keys) + 1)
+                take = min(take, max(int(np.searchsorted(padded, cap - used, side="right")), 0 if keys else 1))
             if take == 0:
                 if rows[0] > cap and not keys:                # an utterance longer than the whole buffer: alone, in an array of its own
                     self._at += 1

@@ -85,6 +85,10 @@ def extract_stream(model, r, w, batch_frames, batch_utts, max_chunk, verbose=Fal
     dim = reader.peek_dim()
     if dim is None:
         return 0
+    # the device lays a batch out with kHalo = 4 zero rows in front of, between and behind the utterances and works in tiles of 64 /
+    # 128 / 256 rows: a group is cut so that its ROWS fit --batch-frames (65 536 = 256 tiles of 256 rows: 321 utterances of 200 frames
+    # fill whole rounds of tiles on the 256 CUs; 327 - the frames alone - were 2.04 rounds of 128-row tiles, i.e. three)
+    reader.row_pad = 4
     sets = DeviceSets(model, batch_frames, batch_utts, dim, max_chunk, n_sets=3, results="host")
     free_sets, batches = queue.Queue(), queue.Queue()
     for k in range(sets.n_sets):
@@ -417,6 +421,7 @@ class ScpGroupReader(object):
         self.loader = ScpBatchLoader(entries, threads=threads)
         self._at = 0
         self._slow = {}
+        self.row_pad = 0                                   # as kaldi_io.PackedArkReader.row_pad
 
     def close(self):
         self.loader.close()
@@ -442,7 +447,7 @@ class ScpGroupReader(object):
                 self.loader.fill([i], big, np.array([0, rows], dtype=np.int32), self._slow)
                 self._slow.pop(i, None)
                 return [self.entries[i][0]], np.array([0, rows], dtype=np.int32), big
-            if used + rows > cap:
+            if used + rows > cap or (idx and used + rows + self.row_pad * (len(idx) + 2) > cap):
                 break
             idx.append(i)
             used += rows
@@ -456,7 +461,7 @@ class ScpGroupReader(object):
         return [self.entries[i][0] for i in idx], offs, used
 
 
-def extract_sharded_scp(extract_batch, entries, lengths, w, batch_frames, batch_utts, verbose=False, device=None, loader=None):
+def extract_sharded_scp(extract_batch, entries, lengths, w, batch_frames, batch_utts, verbose=False, device=None, loader=None, row_pad=0):
     """Sharded extraction of scp entries (one call per rank, torch.distributed initialised or not):
         extract_batch(list of [T, D] float32 matrices) -> [b, E] tensor
     Every rank extracts its length-balanced shard; one all-gather; rank 0 writes the ark entries to `w` in scp order.
@@ -466,7 +471,7 @@ def extract_sharded_scp(extract_batch, entries, lengths, w, batch_frames, batch_
     rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
     load = loader if loader is not None else ScpBatchLoader(entries, threads=_reader_threads())
     try:
-        emb = shard.extract_sharded(extract_batch, lengths, load, max_frames=batch_frames, max_utts=batch_utts, device=device)
+        emb = shard.extract_sharded(extract_batch, lengths, load, max_frames=batch_frames, max_utts=batch_utts, device=device, row_pad=row_pad)
     finally:
         if loader is None:
             load.close()
@@ -518,7 +523,7 @@ def run_sharded(args, model, max_chunk, verbose):
     try:
         t0 = time.perf_counter()
         with torch.cuda.device(dev):
-            n = extract_sharded_scp(extract_batch, entries, lengths, w, args.batch_frames, args.batch_utts, verbose, device=dev, loader=loader)
+            n = extract_sharded_scp(extract_batch, entries, lengths, w, args.batch_frames, args.batch_utts, verbose, device=dev, loader=loader, row_pad=4)
         if rank == 0:
             _report_loop("sharded", n, time.perf_counter() - t0, sets)
         if rank == 0 and dist.is_initialized():
