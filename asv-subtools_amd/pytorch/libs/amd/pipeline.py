@@ -72,6 +72,7 @@ class DeviceSets(object):
         self.done = [torch.cuda.Event() for _ in range(n_sets)]
         self.pending = [None] * n_sets                   # (feats tensor, offsets, out tensor, n, engine index) of the batch in flight on a set
         self.range_reruns = 0
+        self.submit_seconds = {}                         # host time inside submit() by piece (ASV_AMD_REPORT_TIMING)
 
     def host_buffer(self, k):
         return self.host_np[k]
@@ -85,6 +86,8 @@ class DeviceSets(object):
         out = None
         if self.results == "device":
             out = torch.empty((n, self.embed_dim), dtype=torch.float32, device=self.dev)     # (allocated on the caller's stream: it outlives this one)
+        import time
+        t = [time.perf_counter()]
         with torch.cuda.device(self.dev), torch.cuda.stream(self.streams[e]):
             if isinstance(frames, np.ndarray):           # one utterance longer than a whole batch buffer: a pageable copy of its own
                 feats = torch.from_numpy(np.ascontiguousarray(frames, dtype=np.float32)).to(self.dev)
@@ -92,14 +95,19 @@ class DeviceSets(object):
                 feats = self.dev_in[k][:frames]
                 feats.copy_(self.host_in[k][:frames], non_blocking=True)
             self.h2d[k].record()
+            t.append(time.perf_counter())
             if self.results == "host":
                 out = self.dev_out[k][:n]
             self.engines[e].extract_device(feats, offsets, max_chunk=self.max_chunk, out=out)
+            t.append(time.perf_counter())
             if self.results == "host":
                 self.host_out[k][:n].copy_(out, non_blocking=True)
             if self.watch:
                 self.engines[e].status_async(self.status_host[k])
             self.done[k].record()
+            t.append(time.perf_counter())
+        for i, name in enumerate(("h2d", "extract", "d2h")):
+            self.submit_seconds[name] = self.submit_seconds.get(name, 0.0) + t[i + 1] - t[i]
         self.pending[k] = (feats, np.array(offsets, dtype=np.int32), out, n, e)
         return out
 

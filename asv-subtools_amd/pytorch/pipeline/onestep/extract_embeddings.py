@@ -167,6 +167,7 @@ def _report_loop(path, n, seconds, sets, spent=None):
             path, n, seconds, n / max(seconds, 1e-9), sets.range_reruns))
         if spent:
             print("Loop[{0}] consumer thread: ".format(path) + ", ".join("{0} {1:.4f} s".format(k, v) for k, v in spent.items()))
+        print("Loop[{0}] submit pieces: ".format(path) + ", ".join("{0} {1:.4f} s".format(k, v) for k, v in sets.submit_seconds.items()))
 
 
 _SCP_PREFIX = re.compile(r"^scp(,[a-z_,]*)?:")
