@@ -14,6 +14,7 @@
 #include <memory>
 #include <vector>
 
+#include <atomic>
 #include "asv_internal.h"
 #include "host_convert.h"
 
@@ -204,6 +205,8 @@ struct asv_net {
 };
 
 namespace {
+
+std::atomic<unsigned long long> g_kernel_launches[4];       // asv_kernel_launch_count
 
 // the range-status word of the f32x kernels lives behind the zero page's zeros (own 64-byte line; kernels only ever OR into it)
 uint32_t *status_word(asv_net *net) { return reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(net->zero_page) + 128); }
@@ -940,6 +943,10 @@ int asv_net_status_async(asv_net_t *net, unsigned *host_status, void *stream) {
   return ASV_OK;
 }
 
+unsigned long long asv_kernel_launch_count(int which) {
+  return (which == ASV_KERNEL_TDNN_P8 || which == ASV_KERNEL_TDNN_BIG3) ? g_kernel_launches[which].load() : 0ull;
+}
+
 size_t asv_net_device_bytes(const asv_net_t *net) {
   if (!net) return 0;
   size_t n = net->weight_bytes + net->meta_dev.cap + net->rowmeta_dev.cap;
@@ -1401,8 +1408,8 @@ int run_ops(RunCtx &c, size_t n_ops) {
         else if (c1_conv) rc = launch_grid_conv_c1(p, c.s);
         else if (x3) rc = launch_tdnn_x3(p, c.s);
         else if (x3_conv) rc = launch_grid_conv_x3(p, c.s);
-        else if (p8) rc = launch_tdnn_p8(p, c.s);
-        else if (big3) rc = launch_tdnn_big3(p, c.s);
+        else if (p8) { rc = launch_tdnn_p8(p, c.s); ++g_kernel_launches[ASV_KERNEL_TDNN_P8]; }
+        else if (big3) { rc = launch_tdnn_big3(p, c.s); ++g_kernel_launches[ASV_KERNEL_TDNN_BIG3]; }
         else {
           rc = launch_tdnn_mfma(p, et, !bf16, c.s);
           if (!rc && p.ksplit > 1) rc = launch_splitk_epilogue(p, et, !bf16, c.s);

@@ -20,6 +20,7 @@ MAX_TAPS = 9
 POOL_VAR_CLAMP, POOL_VAR_ADD = 0, 1
 PLDA_NORM_NONE, PLDA_NORM_SIMPLE, PLDA_NORM_PSI = 0, 1, 2
 STATUS_HALF_RANGE = 1
+KERNEL_TDNN_P8, KERNEL_TDNN_BIG3 = 1, 2
 
 ACT_BY_NAME = {None: ACT_NONE, "": ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "tanh": ACT_TANH,
                "sigmoid": ACT_SIGMOID}
@@ -157,7 +158,7 @@ SYMBOLS = [
     "asv_net_add_grid_input", "asv_net_add_im2col", "asv_net_add_grid_flatten",
     "asv_net_add_stats_pool", "asv_net_add_attentive_pool", "asv_net_add_lde_pool", "asv_net_add_eltwise", "asv_net_add_res2",
     "asv_net_finalize", "asv_net_embed_dim", "asv_net_describe", "asv_net_extract",
-    "asv_net_device_bytes", "asv_net_set_profiling", "asv_net_get_profile", "asv_net_status", "asv_net_status_async",
+    "asv_net_device_bytes", "asv_net_set_profiling", "asv_net_get_profile", "asv_net_status", "asv_net_status_async", "asv_kernel_launch_count",
     "asv_tdnn_forward", "asv_stats_pool_forward",
     "asv_length_norm", "asv_mean_vec", "asv_dot_score_matrix", "asv_dot_score_trials",
     "asv_plda_transform", "asv_plda_llr_trials", "asv_eer", "asv_score_norm", "asv_group_mean", "asv_two_cov_trials",
@@ -212,6 +213,7 @@ def lib():
     L.asv_net_device_bytes.argtypes = [vp]; L.asv_net_device_bytes.restype = C.c_size_t
     L.asv_net_status.argtypes = [vp, C.POINTER(C.c_uint), vp]
     L.asv_net_status_async.argtypes = [vp, vp, vp]
+    L.asv_kernel_launch_count.argtypes = [ci]; L.asv_kernel_launch_count.restype = C.c_ulonglong
     L.asv_net_set_profiling.argtypes = [vp, ci]
     L.asv_net_get_profile.argtypes = [vp, C.POINTER(KernelTime), ci, C.POINTER(ci)]
     L.asv_tdnn_forward.argtypes = [C.POINTER(TdnnDesc), ci, cu, vp, c_int32_p, ci, vp, vp]

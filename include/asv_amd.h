@@ -284,6 +284,12 @@ int asv_net_status(asv_net_t *net, unsigned *status, void *stream);
  * One status word per net: keep one batch per net in flight between two such calls. */
 int asv_net_status_async(asv_net_t *net, unsigned *host_status, void *stream);
 
+/* Diagnostic: launches of a kernel family by this process since the library was loaded (tests assert with it that the kernel they
+ * mean to exercise is the one that ran - no silent fall-back onto another tile).  which: ASV_KERNEL_* below; unknown ids return 0. */
+#define ASV_KERNEL_TDNN_P8 1     /* kernels_tdnn_p8.hip: 256 x 256 tiles, both operands through LDS-DMA */
+#define ASV_KERNEL_TDNN_BIG3 2   /* kernels_tdnn_v3.hip: 128 x 256 tiles, window through LDS, weight fragments from L2 */
+unsigned long long asv_kernel_launch_count(int which);
+
 /* Bytes of device memory currently held by the net (weights + activation arena). */
 size_t asv_net_device_bytes(const asv_net_t *net);
 

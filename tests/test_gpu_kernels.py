@@ -293,3 +293,75 @@ def test_im2col_descriptor_zero_initialised_means_no_optional_buffers():
         capi.check(lib.asv_net_add_im2col(net, C.byref(d)), "asv_net_add_im2col (-1)")
     finally:
         lib.asv_net_destroy(net)
+
+
+P8_CASES = [
+    # layers the 8-phase kernel takes (whole 64-channel chunks, an even number of K-tiles, >= 192 output channels, plain epilogue)
+    (512, 512, [-2, 0, 2], [200, 200, 64, 300]),
+    (512, 512, [-3, 0, 3], [129, 1, 2, 3, 4, 5, 6, 7, 250]),
+    (512, 1500, [0], [200, 100]),
+    (128, 256, [0], [300, 9, 8]),                  # two K-tiles: prologue + the two closing K-tiles only
+    (192, 320, [-1, 1], [77, 256, 1, 255]),        # 3 chunks x 2 taps, a partly filled last channel tile
+    (1024, 1024, [0], [300, 200]),
+    (64, 200, [-4, 4], [5, 600]),                  # one chunk x two taps at the halo's edge, 200 of 256 channels
+    (256, 512, [-2, -1, 0, 1, 2], [1, 511, 3]),    # wait: 4 chunks x 5 taps = 20 K-tiles
+]
+
+
+@pytest.mark.parametrize("case", P8_CASES, ids=lambda c: "%dx%d_ctx%s" % (c[0], c[1], "_".join(map(str, c[2]))))
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+@pytest.mark.parametrize("act", ["relu", None])
+def test_p8_kernel_vs_oracle_and_big3(case, mode, act, monkeypatch):
+    """Round 5: kernels_tdnn_p8.hip (256 x 256 tiles, both operands through LDS-DMA, four phases per K-tile, staggered wave rows)
+    through the C ABI, forced onto small batches (ASV_AMD_P8=2: from two tiles on; production: from one round of the chip's CUs):
+    against the f64 numpy oracle of TdnnAffine + ReLU + eval BN (components.py:107-149, 418-431) AND bit for bit against the
+    variant-3 kernel (same products in the same order) - ragged utterances, gap rows, taps up to the halo, partly filled channel
+    tiles.  The launch counters prove which kernel ran."""
+    from libs.amd import capi
+    L = capi.lib()
+    cin, cout, ctx, lens = case
+    r = np.random.RandomState(cin * 11 + cout)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    x = r.randn(int(offsets[-1]), cin).astype(np.float32)
+    left, right = min(0, ctx[0]), max(0, ctx[-1])
+    w = (r.randn(cout, cin, right - left + 1) / np.sqrt(cin * len(ctx))).astype(np.float32)
+    b = (0.1 * r.randn(cout)).astype(np.float32)
+    scale = r.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = (0.2 * r.randn(cout)).astype(np.float32)
+    prec, flags = _mode_args(mode + "_mfma")
+    monkeypatch.setenv("ASV_AMD_LIVE_TUNE", "1")
+    monkeypatch.setenv("ASV_AMD_P8", "2")
+    n0 = L.asv_kernel_launch_count(capi.KERNEL_TDNN_P8)
+    got = _tdnn_forward(x, offsets, w, b, ctx, act, scale, shift, False, prec, flags)
+    assert L.asv_kernel_launch_count(capi.KERNEL_TDNN_P8) == n0 + 1, "the 8-phase kernel did not take this layer"
+    monkeypatch.setenv("ASV_AMD_P8", "0")
+    m0 = L.asv_kernel_launch_count(capi.KERNEL_TDNN_BIG3)
+    ref = _tdnn_forward(x, offsets, w, b, ctx, act, scale, shift, False, prec, flags)
+    assert L.asv_kernel_launch_count(capi.KERNEL_TDNN_BIG3) == m0 + 1 and L.asv_kernel_launch_count(capi.KERNEL_TDNN_P8) == n0 + 1
+    assert np.array_equal(got, ref), "8-phase kernel and variant-3 kernel differ in %d values" % int((got != ref).sum())
+    want = _oracle_layer(x, offsets, w, b, ctx, act, scale, shift, False)
+    assert rel_err(got, want) < MODE_TOL[mode]
+
+
+def test_p8_kernel_is_the_one_the_wide_layers_run_on(monkeypatch):
+    """Production dispatch: from one round of 256 x 256 tiles (256 of them) a plain wide layer goes to the 8-phase kernel, smaller
+    batches and the layers it does not take (cin = 80, an odd number of K-tiles) stay on the variant-3 kernel."""
+    from libs.amd import capi
+    monkeypatch.setenv("ASV_AMD_LIVE_TUNE", "1")     # (the library reads ASV_AMD_P8 once per process otherwise: an earlier test's value would stick)
+    monkeypatch.setenv("ASV_AMD_P8", "1")            # 1 = the production rule
+    L = capi.lib()
+    r = np.random.RandomState(3)
+    prec, flags = _mode_args("bf16_mfma")
+
+    def run(cin, cout, ctx, lens):
+        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        x = r.randn(int(offsets[-1]), cin).astype(np.float32)
+        w = (r.randn(cout, cin, max(0, ctx[-1]) - min(0, ctx[0]) + 1) / np.sqrt(cin * len(ctx))).astype(np.float32)
+        a, b = L.asv_kernel_launch_count(capi.KERNEL_TDNN_P8), L.asv_kernel_launch_count(capi.KERNEL_TDNN_BIG3)
+        _tdnn_forward(x, offsets, w, None, ctx, "relu", None, None, False, prec, flags)
+        return L.asv_kernel_launch_count(capi.KERNEL_TDNN_P8) - a, L.asv_kernel_launch_count(capi.KERNEL_TDNN_BIG3) - b
+
+    assert run(512, 512, [-2, 0, 2], [200] * 256) == (1, 0)          # configs[1]'s tdnn2: 408 tiles
+    assert run(512, 512, [-2, 0, 2], [200] * 64) == (0, 1)           # 102 tiles: less than a round
+    assert run(80, 512, [-2, -1, 0, 1, 2], [200] * 256) == (0, 1)    # cin = 80: no whole chunks
+    assert run(192, 512, [0], [200] * 256) == (0, 1)                 # 3 K-tiles: odd
