@@ -85,7 +85,7 @@ def parse():
     ap.add_argument("--min-seconds", type=float, default=1.0, help="the K-step timed region is repeated until this much time has been measured")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel hipEvents in the timed region")
     ap.add_argument("--no-supplementary", action="store_true", help="skip the b640 / f32x / f32 / ECAPA / ResNet / ark->ark sub-records")
-    ap.add_argument("--ark-utts", type=int, default=30000,
+    ap.add_argument("--ark-utts", type=int, default=50000,
                     help="utterances of the supplementary ark -> ark record (the extraction SCRIPT on a synthetic archive read from the page cache: "
                          "stream and --sharded paths, f32x and the headline mode; 0 = skip; tools/bench_pipeline.py runs the same at 50 000)")
     ap.add_argument("--event-stride", type=int, default=8, help="record the per-GEMM hipEvents on every k-th timed step")
@@ -429,7 +429,7 @@ def main():
                 what = "op %d" % i
                 if 0 <= i < len(ops) and ops[i].kind == "tdnn":
                     own = 2.0 * wl.frames_total * ops[i].inp.channels * ops[i].out.channels * len(ops[i].taps)      # this layer alone, per launch
-                    chained = r["flops"] / max(r["launches"], 1) > 1.5 * own
+                    chained = wl.kind == "xvector" and r["flops"] / max(r["launches"], 1) > 1.5 * own
                     what = "%d->%d taps=%d%s" % (ops[i].inp.channels, ops[i].out.channels, len(ops[i].taps), " + the layers chained behind it (tdnn_chain_kernel)" if chained else "")
                 elif 0 <= i < len(ops) and ops[i].kind == "res2":
                     what = "res2 %d x 128->128" % ops[i].branches
