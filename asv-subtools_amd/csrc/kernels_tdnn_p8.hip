@@ -15,26 +15,26 @@
 //     for the third, and the half-tiles become free in that order.
 //   * LDS: 2 buffers x 4 half-tiles = 128 KiB (+ 3 KiB epilogue constants).  16-byte slots XOR-swizzled by (row >> 1) & 7 on the
 //     DMA SOURCE address and on the ds_read_b128 address (the LDS image of a DMA is lane-linear).
-//   * A K-tile is four phases, each {fragment reads | one half-tile staged | [wait] | barrier | lgkmcnt(0) | 8 MFMAs | barrier}:
-//         P1: read HA0 (8),               stage HA1 of K-tile kt+1,                                                  Q(A0,B0)
-//         P2: read HB1 (4),               stage HB0 of K-tile kt+2,                                                  Q(A0,B1)
-//         P3: read HA1 (8),               stage HA0 of K-tile kt+2, vmcnt(10) - HB0 of K-tile kt+1 has landed -,      Q(A1,B1)
-//         P4: read HB0 of K-tile kt+1 (4) stage HB1 of K-tile kt+2, vmcnt(6)  - all of K-tile kt+1 has landed -,      Q(A1,B0)
-//     (the HB0 fragments live in two register sets: P4's MFMAs use this K-tile's while the next one's arrive; first version:
-//     HB0 + HA0 = 12 reads in P1 and none in P4 - the phase with the reads of a wave is the one its partner's MFMA cluster has to
-//     cover, 8 / 4 / 8 / 4 instead of 12 / 4 / 8 / 0 brought ... see DESIGN.md)
-//     Counted vmcnt, never 0 in the loop: three half-tiles stay in flight across every barrier.  The two wave rows
-//     run staggered by one barrier (the second row executes one extra barrier in front of the loop, the first one behind it): on
-//     every SIMD one wave is inside its MFMA cluster while its partner issues reads and DMA.
+//   * Production schedule: TWO phases per K-tile, each {fragment reads | two half-tiles staged | lgkmcnt(0) + counted vmcnt | barrier |
+//     16 MFMAs at priority 1 | barrier}:
+//         PA: read HB0 (4) + HA0 (8) + HB1 (4), stage HB1 + HA1 of K-tile kt+1, vmcnt(8) - HA1 of this K-tile has landed -, Q(A0,B0) Q(A0,B1)
+//         PB: read HA1 (8),                      stage HB0 + HA0 of K-tile kt+2, vmcnt(6) - HB0, HA0, HB1 of K-tile kt+1 -,  Q(A1,B1) Q(A1,B0)
+//     Counted vmcnt, never 0 in the loop: two or three half-tiles stay in flight across every barrier.  The two wave rows run
+//     STAGGERED by one barrier (the second row executes one extra barrier in front of the loop, the first one behind it): on every
+//     SIMD one wave is inside its MFMA cluster while its partner issues reads and DMA - worth 15 - 19 % (tools/p8_probe).
 //     Why this is race free (the rules of the guide, ":660-669"):
-//       RAW  a staged half-tile is read one phase after the wait that retires it: the P4 wait stands in front of P4's first barrier,
-//            the reads of K-tile kt+1 start in the next phase; with the stagger, the lagging row has executed ITS P4 wait before the
-//            leading row passes P4's second barrier.
-//       WAR  a half-tile is restaged two phases after its last read (HA0: read P1, staged P3; HB1: P2 -> P4; HA1: P3 -> P1 of the
-//            next K-tile) - the reads retire at the lgkmcnt(0) behind the reading phase's first barrier, which every wave of BOTH rows
-//            has executed once the staging wave has passed two more barriers - or one phase after where the reads retire in front of
-//            the reading phase's first barrier (first version only: HB0 read first in P1, retired by lgkmcnt(8), staged in P2; now
-//            HB0 is read in P4 of the previous K-tile and restaged in P2: two phases).
+//       RAW  a staged half-tile is read one phase after the wait that retires it: the wait stands in front of the phase's first
+//            barrier, the reads it covers start in the next phase; with the stagger, the lagging row has executed ITS wait before the
+//            leading row passes that phase's second barrier.
+//       WAR  the reads of a phase are retired (lgkmcnt(0)) IN FRONT OF the phase's first barrier, so a half-tile may be restaged one
+//            phase after it was read: HB0 / HA0 read in PA -> restaged in PB; HA1 read in PB -> restaged in the next PA (HB1 read in
+//            PA -> restaged in the next PA: two phases).  A staging wave has passed the reading phase's second barrier, hence every
+//            wave of BOTH rows has passed its first one, hence executed the lgkmcnt(0) in front of it.
+//     The first two versions ran FOUR phases per K-tile (8 MFMAs between barriers, one half-tile staged per phase, vmcnt(6) once per
+//     K-tile - the guide's template as it stands; reads per phase 12 / 4 / 8 / 0, then 8 / 4 / 8 / 4 with the next K-tile's HB0 read
+//     in the last phase into a second register set).  It stays in the developer build (variants 40 / 41 / 44): the same rate to
+//     +-4 % on every shape (profiles/r5l_p8_shapes.txt) - its MFMA + barrier skeleton and this one's are equally fast: the number of
+//     barriers is not what the loop's ~20 % of non-MFMA cycles are - on 254 registers and an even number of K-tiles only.
 //   * Epilogue: kernels_tdnn_v3.hip's (bias -> ReLU -> folded BN, packed 16-bit, wave-private LDS transpose, 16-byte row stores).
 #include <cstdlib>
 #include <type_traits>
@@ -66,13 +66,14 @@ __device__ __forceinline__ void p8_glds(const void *sbase, uint32_t voff, uint32
 }
 
 // VAR (measurement variants of the developer build; 0 = the production kernel):
-//   1 no stagger between the wave rows    2 no s_setprio around the MFMA clusters    3 neither
+//   1 no stagger between the wave rows    2 no s_setprio around the MFMA clusters (+0 ... +5 % with it)    3 neither
 //   4 MFMA + barriers only (no reads, no DMA in the loop: the skeleton's ceiling; results are garbage)
 //   5 no DMA in the loop (fragment reads of stale LDS; garbage)    6 no fragment reads in the loop (garbage)
 // ONE_TAP: a 1-tap layer (row offset 0): the DMA source offsets of the feature rows are loop constants
-template <int ET, int VAR, bool ONE_TAP>
+template <int ET, int VAR, bool ONE_TAP, int PH>
 __global__ __launch_bounds__(512, 2) void tdnn_gemm_p8_kernel(const TdnnKernelParams p, int m_tiles, int n_tiles) {
-  constexpr bool STAGGER = !(VAR == 1 || VAR == 3), PRIO = (VAR == 2 || VAR == 3), SKELETON = VAR == 4;
+  static_assert(PH == 2 || PH == 4, "phases per K-tile");
+  constexpr bool STAGGER = !(VAR == 1 || VAR == 3), PRIO = !(VAR == 2 || VAR == 3), SKELETON = VAR == 4;
   constexpr bool NO_DMA = SKELETON || VAR == 5, NO_READS = SKELETON || VAR == 6;
   __shared__ __attribute__((aligned(16))) unsigned char lds[P8_LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -172,6 +173,107 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_p8_kernel(const TdnnKernelPa
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+  if constexpr (PH == 2) {
+    // ================= two phases per K-tile (16 MFMAs between barriers) =================
+    //     PA: read HB0 (4) + HA0 (8) + HB1 (4), stage HB1 + HA1 of K-tile kt+1, lgkmcnt(0), vmcnt(8) - HA1 of THIS K-tile has landed -, barrier, Q(A0,B0) Q(A0,B1), barrier
+    //     PB: read HA1 (8),                      stage HB0 + HA0 of K-tile kt+2, lgkmcnt(0), vmcnt(6) - HB0 HA0 HB1 of K-tile kt+1 have landed -, barrier, Q(A1,B1) Q(A1,B0), barrier
+    // Half the barriers per MFMA of the four-phase form (SQ counters of that form: its MFMA + barriers skeleton keeps the matrix pipe
+    // busy 0.56 - 0.61 of the cycles - ~110 cycles go by around every barrier beside 256 of MFMA).  The reads of a phase are retired
+    // (lgkmcnt(0)) IN FRONT OF the phase's first barrier, so a half-tile may be restaged one phase after it was read (the guide's
+    // WAR rule, second form): HB0 / HA0 read in PA -> restaged in PB; HA1 read in PB -> restaged in the next PA; HB1 read in PA ->
+    // restaged in the next PA.  RAW as before: a wait stands in front of a phase's first barrier, the reads it covers come a phase
+    // later.  Prefetch distance: two phases (~1.2 k cycles) for the feature half-tiles, one for HB1 (weights: L2-resident).
+    stage(0, 0, 0, 0, false); stage(1, 0, 0, 0, false); stage(2, 0, 0, 0, false); stage(3, 0, 0, 0, false);
+    {
+      int c1 = 0, t1 = 1;
+      if (t1 == n_taps) { t1 = 0; c1 = 1; }
+      if (nkt > 1) {
+        stage(0, c1, t1, 1, false); stage(1, c1, t1, 1, false);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    uint4 wb0[4], wb1[4], xa[2][4];
+    if (NO_READS) {
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg) {
+        wb0[kg] = make_uint4(lane, 1, 2, 3); wb1[kg] = make_uint4(3, lane, 1, 0);
+        xa[0][kg] = make_uint4(1, 1, lane, 1); xa[1][kg] = make_uint4(2, 2, 2, lane);
+      }
+    }
+    if (STAGGER && wm == 1) __builtin_amdgcn_s_barrier();      // this wave row runs one barrier behind the other from here on
+    auto mma_q = [&](const uint4 (&wfr)[4], int j, int i0) {
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg)
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) acc[i0 + i2][j] = mfma16<ET>(wfr[kg], xa[i2][kg], acc[i0 + i2][j]);
+    };
+    auto barrier = [&]() {
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    };
+    int c1 = 0, t1 = 0, c2 = 0, t2 = 0;     // (chunk, tap) of K-tile kt + 1 and of K-tile kt + 2
+    auto adv = [&](int &c, int &t) { if (++t == n_taps) { t = 0; ++c; } };
+    adv(c1, t1); adv(c2, t2); adv(c2, t2);
+    // TAIL 0: K-tiles kt + 1 and kt + 2 exist; 1: kt + 1 is the last; 2: kt is the last
+    auto ktile2 = [&](int kt, auto tail_c) {
+      constexpr int TAIL = decltype(tail_c)::value;
+      const int b = kt & 1;
+      const unsigned char *L = lds + (uint32_t)b * P8_BUF;
+      // ---- PA
+      if (!NO_READS) {
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) wb0[kg] = *reinterpret_cast<const uint4 *>(L + P8_OFF_B0 + b_addr[kg]);
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg)
+#pragma unroll
+          for (int i2 = 0; i2 < 2; ++i2) xa[i2][kg] = *reinterpret_cast<const uint4 *>(L + P8_OFF_A0 + i2 * (32 * P8_ROWB) + a_addr[kg]);
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) wb1[kg] = *reinterpret_cast<const uint4 *>(L + P8_OFF_B1 + b_addr[kg]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (TAIL <= 1) { stage(2, c1, t1, b ^ 1, true); stage(3, c1, t1, b ^ 1, true); }      // HB1, HA1 of K-tile kt + 1
+      if (TAIL <= 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");            // HA1 of this K-tile has landed; this phase's reads are back
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (PRIO) __builtin_amdgcn_s_setprio(1);
+      mma_q(wb0, 0, 0);
+      mma_q(wb1, 1, 0);
+      if (PRIO) __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      barrier();
+      // ---- PB
+      if (!NO_READS) {
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg)
+#pragma unroll
+          for (int i2 = 0; i2 < 2; ++i2) xa[i2][kg] = *reinterpret_cast<const uint4 *>(L + P8_OFF_A1 + i2 * (32 * P8_ROWB) + a_addr[kg]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (TAIL == 0) { stage(0, c2, t2, b, true); stage(1, c2, t2, b, true); }                // HB0, HA0 of K-tile kt + 2
+      if (TAIL == 0) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");            // HB0, HA0, HB1 of K-tile kt + 1 have landed
+      else if (TAIL == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (PRIO) __builtin_amdgcn_s_setprio(1);
+      mma_q(wb1, 1, 2);
+      mma_q(wb0, 0, 2);
+      if (PRIO) __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      barrier();
+      adv(c1, t1); adv(c2, t2);
+    };
+    using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>; using J2 = std::integral_constant<int, 2>;
+    int kt = 0;
+    for (; kt + 2 < nkt; ++kt) ktile2(kt, J0{});
+    if (kt + 1 < nkt) { ktile2(kt, J1{}); ++kt; }
+    ktile2(kt, J2{});
+  } else {
   // ---- prologue: K-tile 0 complete + the first three half-tiles of K-tile 1 in flight
   {
     int c1 = 0, t1 = 1;
@@ -298,6 +400,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_p8_kernel(const TdnnKernelPa
   for (int kt = 0; kt + 2 < nkt; kt += 2) { ktile(I0{}, I0{}); ktile(I0{}, I1{}); }
   ktile(I1{}, I0{});
   ktile(I2{}, I1{});
+  }
   if (STAGGER && wm == 0) __builtin_amdgcn_s_barrier();        // the rows meet again: every wave is done with the buffers
   asm volatile("" ::: "memory");
 
@@ -361,7 +464,7 @@ bool tdnn_p8_supported(const TdnnKernelParams &p, int et, bool out_f32) {
   const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first;
   return p.w != nullptr && et != ET_F32 && !out_f32 && fits32 && fast && p.x2 == nullptr && p.seg_bias == nullptr && p.seg_scale == nullptr && p.res == nullptr &&
          p.pool_partial == nullptr && p.rows % 256 == 0 && p.rows >= 256 && p.cin_pad % 64 == 0 && p.cin_pad >= 64 && p.cout_store % 8 == 0 && p.cout_store >= 192 &&
-         p.n_taps >= 1 && p.n_taps <= ASV_MAX_TAPS && p.row_valid != nullptr && ((p.cin_pad / 64) * p.n_taps) % 2 == 0;       // an even number of K-tiles
+         p.n_taps >= 1 && p.n_taps <= ASV_MAX_TAPS && p.row_valid != nullptr;
 }
 
 int launch_tdnn_p8_variant(const TdnnKernelParams &p, int variant, hipStream_t s) {
@@ -370,8 +473,9 @@ int launch_tdnn_p8_variant(const TdnnKernelParams &p, int variant, hipStream_t s
   const dim3 grid(m_tiles * n_tiles), block(512);
   const bool f16 = p.et == ET_F16;
   const bool one = p.n_taps == 1 && p.taps[0] == 0;
-#define ASV_P8(ETV, VARV) do { if (one) hipLaunchKernelGGL((tdnn_gemm_p8_kernel<ETV, VARV, true>), grid, block, 0, s, p, m_tiles, n_tiles); \
-                               else hipLaunchKernelGGL((tdnn_gemm_p8_kernel<ETV, VARV, false>), grid, block, 0, s, p, m_tiles, n_tiles); } while (0)
+#define ASV_P8(ETV, VARV) ASV_P8P(ETV, VARV, 2)
+#define ASV_P8P(ETV, VARV, PHV) do { if (one) hipLaunchKernelGGL((tdnn_gemm_p8_kernel<ETV, VARV, true, PHV>), grid, block, 0, s, p, m_tiles, n_tiles); \
+                               else hipLaunchKernelGGL((tdnn_gemm_p8_kernel<ETV, VARV, false, PHV>), grid, block, 0, s, p, m_tiles, n_tiles); } while (0)
   switch (variant) {
 #ifdef ASV_WITH_ABLATION
     case 1: ASV_P8(ET_BF16, 1); break;
@@ -379,12 +483,17 @@ int launch_tdnn_p8_variant(const TdnnKernelParams &p, int variant, hipStream_t s
     case 4: ASV_P8(ET_BF16, 4); break;
     case 5: ASV_P8(ET_BF16, 5); break;
     case 6: ASV_P8(ET_BF16, 6); break;
+    case 40: case 41: case 44:                       // the four-phase form (round 5, second version) and its variants: an even number of K-tiles
+      ASV_REQUIRE(((p.cin_pad / 64) * p.n_taps) % 2 == 0, "tdnn(p8): the four-phase form takes an even number of K-tiles");
+      if (variant == 40) ASV_P8P(ET_BF16, 0, 4); else if (variant == 41) ASV_P8P(ET_BF16, 1, 4); else ASV_P8P(ET_BF16, 4, 4);
+      break;
 #endif
     default:
       if (f16) ASV_P8(ET_F16, 0);
       else ASV_P8(ET_BF16, 0);
   }
 #undef ASV_P8
+#undef ASV_P8P
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }

@@ -94,16 +94,27 @@ int main(int argc, char **argv) {
     for (int r = 0; r < rows; ++r) for (int c = 0; c < p.cout_store; ++c) { const size_t i = (size_t)r * cout_pad + c; race += h0[i] != h1[i]; }
   }
   printf("p8 vs big3 over 6 more launches: %zu differing values\n", race);
+  {
+    CK(hipMemset(y1, 0x33, (size_t)rows * cout_pad * 2));
+    p.y = y1;
+    if (tdnn_p8_supported(p, ET_BF16, false) && ((cin / 64) * ntaps) % 2 == 0 && launch_tdnn_p8_variant(p, 40, 0) == 0) {
+      CK(hipMemcpy(h1.data(), y1, h1.size() * 2, hipMemcpyDeviceToHost));
+      size_t d4 = 0;
+      for (int r = 0; r < rows; ++r) for (int c = 0; c < p.cout_store; ++c) { const size_t i = (size_t)r * cout_pad + c; d4 += h0[i] != h1[i]; }
+      printf("p8 four-phase form vs big3: %zu differing values\n", d4);
+    }
+  }
   // ---- timing: interleaved rounds
   struct Var { const char *name; int kind, variant; };
-  const Var vars[] = {{"big3 128x256 (2 WG/CU)", 0, 0}, {"p8", 1, 0}, {"p8 no stagger", 1, 1}, {"p8 with setprio", 1, 2}, {"p8 no DMA in the loop", 1, 5}, {"p8 no fragment reads in the loop", 1, 6},
-                      {"p8 skeleton (MFMA + barriers)", 1, 4}};
+  const Var vars[] = {{"big3 128x256 (2 WG/CU)", 0, 0}, {"p8 two-phase", 1, 0}, {"p8 four-phase", 1, 40}, {"p8 two-phase no stagger", 1, 1}, {"p8 two-phase without setprio", 1, 2},
+                      {"p8 two-phase no DMA in the loop", 1, 5}, {"p8 two-phase no fragment reads", 1, 6}, {"p8 two-phase skeleton", 1, 4}, {"p8 four-phase skeleton", 1, 44}};
   const int nv = sizeof(vars) / sizeof(vars[0]);
   std::vector<std::vector<float>> us(nv);
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   p.y = y0;
   for (int r = 0; r < rounds + 1; ++r)
     for (int v = 0; v < nv; ++v) {
+      if (vars[v].variant >= 40 && ((cin / 64) * ntaps) % 2 != 0) { if (r > 0) us[v].push_back(0.0f); continue; }
       CK(hipEventRecord(a, 0));
       for (int i = 0; i < iters; ++i) {
         const int rc = vars[v].kind == 0 ? launch_tdnn_big3_variant(p, vars[v].variant, 0) : launch_tdnn_p8_variant(p, vars[v].variant, 0);

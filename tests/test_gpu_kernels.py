@@ -304,7 +304,10 @@ P8_CASES = [
     (192, 320, [-1, 1], [77, 256, 1, 255]),        # 3 chunks x 2 taps, a partly filled last channel tile
     (1024, 1024, [0], [300, 200]),
     (64, 200, [-4, 4], [5, 600]),                  # one chunk x two taps at the halo's edge, 200 of 256 channels
-    (256, 512, [-2, -1, 0, 1, 2], [1, 511, 3]),    # wait: 4 chunks x 5 taps = 20 K-tiles
+    (256, 512, [-2, -1, 0, 1, 2], [1, 511, 3]),    # 4 chunks x 5 taps = 20 K-tiles
+    (192, 512, [0], [130, 200]),                   # three K-tiles: an odd count (prologue + one closing pair + the last)
+    (64, 256, [0], [300]),                         # ONE K-tile
+    (320, 384, [-1, 0, 1], [40, 41, 300]),         # 5 chunks x 3 taps = 15
 ]
 
 
@@ -345,7 +348,7 @@ def test_p8_kernel_vs_oracle_and_big3(case, mode, act, monkeypatch):
 
 def test_p8_kernel_is_the_one_the_wide_layers_run_on(monkeypatch):
     """Production dispatch: from one round of 256 x 256 tiles (256 of them) a plain wide layer goes to the 8-phase kernel, smaller
-    batches and the layers it does not take (cin = 80, an odd number of K-tiles) stay on the variant-3 kernel."""
+    batches and the layers it does not take (cin = 80: no whole 64-channel chunks) stay on the variant-3 kernel."""
     from libs.amd import capi
     monkeypatch.setenv("ASV_AMD_LIVE_TUNE", "1")     # (the library reads ASV_AMD_P8 once per process otherwise: an earlier test's value would stick)
     monkeypatch.setenv("ASV_AMD_P8", "1")            # 1 = the production rule
@@ -364,4 +367,4 @@ def test_p8_kernel_is_the_one_the_wide_layers_run_on(monkeypatch):
     assert run(512, 512, [-2, 0, 2], [200] * 256) == (1, 0)          # configs[1]'s tdnn2: 408 tiles
     assert run(512, 512, [-2, 0, 2], [200] * 64) == (0, 1)           # 102 tiles: less than a round
     assert run(80, 512, [-2, -1, 0, 1, 2], [200] * 256) == (0, 1)    # cin = 80: no whole chunks
-    assert run(192, 512, [0], [200] * 256) == (0, 1)                 # 3 K-tiles: odd
+    assert run(192, 512, [0], [200] * 256) == (1, 0)                 # 3 K-tiles: an odd count is fine
