@@ -578,9 +578,14 @@ def main(argv=None):
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", int(args.gpu_id)))   # "nccl" is RCCL on ROCm
             # RCCL builds its communicator inside the first collective (0.1 - 0.2 s): here, with the model still to be loaded, not
             # inside the extraction loop in front of the all-gather
-            warm = torch.zeros(1, device=torch.device("cuda", int(args.gpu_id)))
-            dist.all_reduce(warm)
-            del warm
+            wdev = torch.device("cuda", int(args.gpu_id))
+            warm = torch.zeros(2, dtype=torch.int64, device=wdev)
+            dist.all_reduce(warm, op=dist.ReduceOp.MAX)                       # (the two collectives of libs/amd/shard.py, each once)
+            wsrc = torch.zeros((8, 8), dtype=torch.float32, device=wdev)
+            wdst = torch.empty((8 * dist.get_world_size(), 8), dtype=torch.float32, device=wdev)
+            dist.all_gather_into_tensor(wdst, wsrc)
+            torch.cuda.synchronize(wdev)
+            del warm, wsrc, wdst
 
         model = utils.create_model_from_py(model_blueprint, model_creation)
         model.load_state_dict(torch.load(args.model_path, map_location="cpu"), strict=False)
