@@ -94,15 +94,22 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_p8_kernel(const TdnnKernelPa
   const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(p8_lds_byte *)lds);
   const int nkt = (cin_pad / 64) * n_taps;
 
-  // per-channel epilogue constants -> LDS (kernels_tdnn_v3.hip)
+  // per-channel epilogue constants (bias | scale | shift of the tile's 256 channels) -> LDS by LDS-DMA, one 1 KiB piece each, issued by
+  // waves 0 - 2 in front of the prologue's pieces (they are then older than everything the prologue's counted wait leaves in flight).
+  // As compiler-visible loads they cost a memory round trip of their own in front of the first DMA piece - hipcc waits vmcnt(0) around
+  // every load it knows of when untracked (inline-asm) pieces are in flight.
   float *lds_par = reinterpret_cast<float *>(lds + P8_PARAM_OFF);
-  if (tid < 192) {
-    const int which = tid >> 6, idx = (tid & 63) * 4;
-    float4 v = (which == 1) ? make_float4(1.f, 1.f, 1.f, 1.f) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float *src = (which == 0) ? p.bias : (which == 1 ? p.scale : p.shift);
-    if (src != nullptr) v = *reinterpret_cast<const float4 *>(src + n0 + idx);
-    *reinterpret_cast<float4 *>(lds_par + which * 256 + idx) = v;
-  }
+  auto stage_params = [&]() {
+    if (wave < 3) {
+      const float *src = (wave == 0) ? p.bias : (wave == 1 ? p.scale : p.shift);
+      if (src != nullptr) {
+        p8_glds(src + n0, (uint32_t)lane * 16u, __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)P8_PARAM_OFF + (uint32_t)wave * 1024u));
+      } else {
+        const float dflt = (wave == 1) ? 1.0f : 0.0f;
+        *reinterpret_cast<float4 *>(lds_par + wave * 256 + lane * 4) = make_float4(dflt, dflt, dflt, dflt);
+      }
+    }
+  };
 
   // ---- LDS-DMA pieces: a half-tile = 16 pieces of 8 rows x 128 B; this wave issues pieces 2 wave and 2 wave + 1 of every half-tile.
   // Half-tile row r <-> matrix row:  A: frame m0 + (r >> 6) * 128 + (r & 63) (+ 64 in HA1);  B: channel n0 + (r >> 5) * 64 + (r & 31) (+ 32 in HB1)
@@ -183,6 +190,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_p8_kernel(const TdnnKernelPa
     // WAR rule, second form): HB0 / HA0 read in PA -> restaged in PB; HA1 read in PB -> restaged in the next PA; HB1 read in PA ->
     // restaged in the next PA.  RAW as before: a wait stands in front of a phase's first barrier, the reads it covers come a phase
     // later.  Prefetch distance: two phases (~1.2 k cycles) for the feature half-tiles, one for HB1 (weights: L2-resident).
+    stage_params();
     stage(0, 0, 0, 0, false); stage(1, 0, 0, 0, false); stage(2, 0, 0, 0, false); stage(3, 0, 0, 0, false);
     {
       int c1 = 0, t1 = 1;
@@ -278,6 +286,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_p8_kernel(const TdnnKernelPa
   {
     int c1 = 0, t1 = 1;
     if (t1 == n_taps) { t1 = 0; c1 = 1; }
+    stage_params();
     stage(0, 0, 0, 0, false); stage(1, 0, 0, 0, false); stage(2, 0, 0, 0, false); stage(3, 0, 0, 0, false);
     if (nkt > 1) {
       stage(0, c1, t1, 1, false); stage(1, c1, t1, 1, false); stage(2, c1, t1, 1, false);
