@@ -92,6 +92,25 @@ def measure(utts=50000, frames=200, precisions=("f32x", "bf16"), paths=("stream"
     out = {"workload": "%d utterances x %d x 80 f32 Kaldi ark (%.2f GB, page cache) -> x-vector ark through pipeline/onestep/extract_embeddings.py, one GPU" % (
                utts, frames, files["bytes"] / 1e9),
            "ark_write_seconds_synthetic": round(files["write_seconds"], 2), "host_cores": os.cpu_count(), "runs": {}}
+    # One short untimed run per path first: a fresh box reads the code it has never run - RCCL's collective kernels, torch's cat / index
+    # kernels of the gather, the script's own modules - from a cold file cache (the first --sharded run of a container measured 0.1 s
+    # more loop time than the second, whatever the precision); the feature archive itself is read from the page cache either way.
+    warm = dict(files)
+    warm["ark"] = os.path.join(directory, "warm.ark")
+    warm["scp"] = os.path.join(directory, "warm.scp")
+    n_warm = min(2000, utts)
+    with open(files["scp"]) as f, open(warm["scp"], "w") as g:
+        for i, line in enumerate(f):
+            if i >= n_warm:
+                break
+            g.write(line)
+    with open(files["ark"], "rb") as f, open(warm["ark"], "wb") as g:
+        g.write(f.read(n_warm * (files["bytes"] // utts)))
+    for path in paths:
+        run_once(warm, path, precisions[0], n_warm, directory)
+    for k in ("ark", "scp"):
+        os.remove(warm[k])
+    out["warm_up"] = "one untimed run of %d utterances per path (cold code pages of a fresh box)" % n_warm
     for prec in precisions:
         for path in paths:
             out["runs"]["%s_%s" % (path, prec)] = run_once(files, path, prec, utts, directory)
