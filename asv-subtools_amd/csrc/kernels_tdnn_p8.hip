@@ -36,6 +36,7 @@
 //     +-4 % on every shape (profiles/r5l_p8_shapes.txt) - its MFMA + barrier skeleton and this one's are equally fast: the number of
 //     barriers is not what the loop's ~20 % of non-MFMA cycles are - on 254 registers and an even number of K-tiles only.
 //   * Epilogue: kernels_tdnn_v3.hip's (bias -> ReLU -> folded BN, packed 16-bit, wave-private LDS transpose, 16-byte row stores).
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -75,6 +76,13 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_p8_kernel(const TdnnKernelPa
   static_assert(PH == 2 || PH == 4, "phases per K-tile");
   constexpr bool STAGGER = !(VAR == 1 || VAR == 3), PRIO = !(VAR == 2 || VAR == 3), SKELETON = VAR == 4;
   constexpr bool NO_DMA = SKELETON || VAR == 5, NO_READS = SKELETON || VAR == 6;
+  // VAR 7 (results valid): s_memtime stamps of wave 0 into p.partial[workgroup][8]: 0 start, 1 first K-tile in LDS, 2 K loop done, 3 end
+  auto stamp = [&](int k) {
+    if constexpr (VAR == 7) {
+      if (threadIdx.x == 0) reinterpret_cast<unsigned long long *>(p.partial)[(size_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime();
+    }
+  };
+  stamp(0);
   __shared__ __attribute__((aligned(16))) unsigned char lds[P8_LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -212,6 +220,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_p8_kernel(const TdnnKernelPa
         xa[0][kg] = make_uint4(1, 1, lane, 1); xa[1][kg] = make_uint4(2, 2, 2, lane);
       }
     }
+    stamp(1);
     if (STAGGER && wm == 1) __builtin_amdgcn_s_barrier();      // this wave row runs one barrier behind the other from here on
     auto mma_q = [&](const uint4 (&wfr)[4], int j, int i0) {
 #pragma unroll
@@ -412,6 +421,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_p8_kernel(const TdnnKernelPa
   }
   if (STAGGER && wm == 0) __builtin_amdgcn_s_barrier();        // the rows meet again: every wave is done with the buffers
   asm volatile("" ::: "memory");
+  stamp(2);
 
   // ---- epilogue (kernels_tdnn_v3.hip) ---------------------------------------------------------
   // acc[i][j][r]: frame = m0 + wm*128 + i*32 + lr, channel = n0 + wn*64 + j*32 + 8*(r>>2) + 4*lh + (r&3)
@@ -462,6 +472,281 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_p8_kernel(const TdnnKernelPa
       if (ch < p.cout_store) *reinterpret_cast<uint4 *>(yg + (size_t)row * y_pitch + (size_t)ch * 2) = v;
     }
   }
+  if constexpr (VAR == 7) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(3);
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// PERSISTENT form of the kernel above (two-phase schedule): as many workgroups as the chip has CUs, each walks its tiles (it,
+// it + grid, ...).  Per-tile stamps of the one-tile form (tools/p8_probe, ECAPA's 1024 -> 1024 layer): prologue 7.8 k cycles
+// (parameters + the first K-tile from HBM with nothing to overlap), K loop 38.8 k (2.4 k per K-tile of 2.05 k of MFMA issue),
+// epilogue + store drain 7.4 k, and ~8 k between the workgroups of a CU: 28 % of a tile outside its K loop.  Here
+//   * the NEXT tile's first K-tile (4 half-tiles -> buffer 0) and its parameters are requested BEFORE the epilogue of this tile; the
+//     epilogue's LDS transposition runs in two passes of 64 rows per wave inside buffer 1 (64 KiB), so the two do not meet;
+//   * the epilogue constants AND the tile's row-validity words arrive by LDS-DMA into one of two parameter slots: the kernel has
+//     no compiler-visible load at all (a visible load next to untracked DMA pieces costs a vmcnt(0));
+//   * the stores of a tile drain under the next tile's K loop; the wait in front of that loop is vmcnt(4) (everything but the two
+//     half-tiles of its second K-tile, requested behind the stores).
+constexpr int P8P_PAR_SLOT = 4096;                  // bias | scale | shift (3 x 1 KiB) | row-validity words (1 KiB piece, 32 B used)
+constexpr int P8P_LDS_BYTES = 2 * P8_BUF + 2 * P8P_PAR_SLOT;
+
+template <int ET, bool ONE_TAP>
+__global__ __launch_bounds__(512, 2) void tdnn_gemm_p8p_kernel(const TdnnKernelParams p, int m_tiles, int n_tiles) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[P8P_LDS_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int total = m_tiles * n_tiles;
+  const int grid = gridDim.x;
+
+  const unsigned char *xg = reinterpret_cast<const unsigned char *>(p.x);
+  const unsigned char *wg = reinterpret_cast<const unsigned char *>(p.w);
+  const uint32_t x_pitch = (uint32_t)p.ldx * 2u;
+  const int cin_pad = p.cin_pad;
+  const int n_taps = ONE_TAP ? 1 : p.n_taps;
+  const uint32_t w_pitch = (uint32_t)n_taps * (uint32_t)cin_pad * 2u;
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(p8_lds_byte *)lds);
+  const int nkt = (cin_pad / 64) * n_taps;
+  const int last_row = p.rows - 1;
+  const int g_row = lane >> 3, g_slot = lane & 7;
+
+  // per-tile, per-lane DMA source offsets (see the one-tile kernel)
+  struct TileAddr { int m0, n0; int a_row[2]; uint32_t a_slot[2], a_voff[2][2], b_off[2]; };
+  auto tile_addr = [&](int it) {
+    TileAddr t;
+    const int tile = xcd_swizzle(it, total);
+    t.m0 = (tile / n_tiles) * 256;
+    t.n0 = (tile % n_tiles) * 256;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (wave * 2 + i) * 8 + g_row;
+      const uint32_t slot16 = (uint32_t)(g_slot ^ ((r >> 1) & 7)) * 16u;
+      t.a_row[i] = t.m0 + (r >> 6) * 128 + (r & 63);
+      t.a_slot[i] = slot16;
+      t.a_voff[0][i] = (uint32_t)t.a_row[i] * x_pitch + slot16;
+      t.a_voff[1][i] = (uint32_t)min(t.a_row[i] + 64, last_row) * x_pitch + slot16;
+      t.b_off[i] = (uint32_t)(t.n0 + (r >> 5) * 64 + (r & 31)) * w_pitch + slot16;
+    }
+    return t;
+  };
+  int v_taps = p.taps[0];
+  if (!ONE_TAP) {
+#pragma unroll
+    for (int t = 1; t < ASV_MAX_TAPS; ++t) v_taps = (lane == t) ? p.taps[t] : v_taps;
+  }
+  auto stage = [&](const TileAddr &T, int which, int c, int t, int b) {
+    const uint32_t dst0 = lds_base + (uint32_t)b * P8_BUF + (uint32_t)which * P8_HALF + (uint32_t)wave * 2048u;
+    if (which & 1) {
+      const unsigned char *base = xg + (size_t)c * 128;
+      if (ONE_TAP) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) p8_glds(base, T.a_voff[which == 3][i], __builtin_amdgcn_readfirstlane(dst0 + i * 1024u));
+      } else {
+        const int d = __builtin_amdgcn_readlane(v_taps, t) + (which == 3 ? 64 : 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int row = min(max(T.a_row[i] + d, 0), last_row);
+          p8_glds(base, (uint32_t)row * x_pitch + T.a_slot[i], __builtin_amdgcn_readfirstlane(dst0 + i * 1024u));
+        }
+      }
+    } else {
+      const unsigned char *base = wg + ((size_t)t * cin_pad + (size_t)c * 64) * 2 + (which == 2 ? (size_t)32 * w_pitch : 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) p8_glds(base, T.b_off[i], __builtin_amdgcn_readfirstlane(dst0 + i * 1024u));
+    }
+  };
+  // bias | scale | shift of the tile's 256 channels and the validity words of its 256 rows -> parameter slot `slot`: one piece each
+  // from waves 0 .. 3 (the defaults of an absent scale / shift are written by the wave itself)
+  auto stage_tile_params = [&](const TileAddr &T, int slot) {
+    const uint32_t dst = lds_base + 2u * P8_BUF + (uint32_t)slot * P8P_PAR_SLOT + (uint32_t)wave * 1024u;
+    if (wave < 3) {
+      const float *src = (wave == 0) ? p.bias : (wave == 1 ? p.scale : p.shift);
+      if (src != nullptr) {
+        p8_glds(src + T.n0, (uint32_t)lane * 16u, __builtin_amdgcn_readfirstlane(dst));
+      } else {
+        const float dflt = (wave == 1) ? 1.0f : 0.0f;
+        *reinterpret_cast<float4 *>(lds + 2 * P8_BUF + slot * P8P_PAR_SLOT + wave * 1024 + lane * 16) = make_float4(dflt, dflt, dflt, dflt);
+      }
+    } else if (wave == 3) {
+      // 8 words = 32 bytes: lanes 0 and 1 fetch them, the others re-read the first 16 bytes (valid memory; their LDS bytes are never used)
+      p8_glds(p.row_valid + (T.m0 >> 5), lane < 2 ? (uint32_t)lane * 16u : 0u, __builtin_amdgcn_readfirstlane(dst));
+    }
+  };
+
+  const uint32_t sw = (uint32_t)((lr >> 1) & 7);
+  const uint32_t a_base = (uint32_t)(wm * 64 + lr) * P8_ROWB, b_base = (uint32_t)(wn * 32 + lr) * P8_ROWB;
+  uint32_t a_addr[4], b_addr[4];
+#pragma unroll
+  for (int kg = 0; kg < 4; ++kg) {
+    const uint32_t s16 = (((uint32_t)(kg * 2 + lh)) ^ sw) * 16u;
+    a_addr[kg] = a_base + s16;
+    b_addr[kg] = b_base + s16;
+  }
+  auto barrier = [&]() {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  auto kt_ct = [&](int kt, int &c, int &t) { c = kt / n_taps; t = kt - c * n_taps; };
+  auto swz = [](int row, int slot) { return slot ^ ((row >> 1) & 7); };
+  const float act_lo = (p.act1 == ASV_ACT_RELU) ? 0.0f : -INFINITY;
+  unsigned char *yg = reinterpret_cast<unsigned char *>(p.y);
+  const size_t y_pitch = (size_t)p.ldy * 2;
+
+  int it = blockIdx.x;
+  int slot = 0;
+  TileAddr cur = tile_addr(it);
+  // ---- request the first tile: parameters, K-tile 0 -> buffer 0, the first two half-tiles of K-tile 1 -> buffer 1
+  stage_tile_params(cur, 0);
+  stage(cur, 0, 0, 0, 0); stage(cur, 1, 0, 0, 0); stage(cur, 2, 0, 0, 0); stage(cur, 3, 0, 0, 0);
+  if (nkt > 1) {
+    int c1, t1;
+    kt_ct(1, c1, t1);
+    stage(cur, 0, c1, t1, 1); stage(cur, 1, c1, t1, 1);
+  }
+#pragma unroll 1
+  while (true) {
+    if (nkt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    barrier();
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    uint4 wb0[4], wb1[4], xa[2][4];
+    if (wm == 1) __builtin_amdgcn_s_barrier();                 // this wave row runs one barrier behind the other inside the K loop
+    auto mma_q = [&](const uint4 (&wfr)[4], int j, int i0) {
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg)
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) acc[i0 + i2][j] = mfma16<ET>(wfr[kg], xa[i2][kg], acc[i0 + i2][j]);
+    };
+    int c1 = 0, t1 = 0, c2 = 0, t2 = 0;
+    auto adv = [&](int &c, int &t) { if (++t == n_taps) { t = 0; ++c; } };
+    adv(c1, t1); adv(c2, t2); adv(c2, t2);
+    auto ktile2 = [&](int kt, auto tail_c) {
+      constexpr int TAIL = decltype(tail_c)::value;
+      const int b = kt & 1;
+      const unsigned char *L = lds + (uint32_t)b * P8_BUF;
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg) wb0[kg] = *reinterpret_cast<const uint4 *>(L + P8_OFF_B0 + b_addr[kg]);
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg)
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) xa[i2][kg] = *reinterpret_cast<const uint4 *>(L + P8_OFF_A0 + i2 * (32 * P8_ROWB) + a_addr[kg]);
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg) wb1[kg] = *reinterpret_cast<const uint4 *>(L + P8_OFF_B1 + b_addr[kg]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (TAIL <= 1) { stage(cur, 2, c1, t1, b ^ 1); stage(cur, 3, c1, t1, b ^ 1); }
+      if (TAIL <= 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      mma_q(wb0, 0, 0);
+      mma_q(wb1, 1, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      barrier();
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg)
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) xa[i2][kg] = *reinterpret_cast<const uint4 *>(L + P8_OFF_A1 + i2 * (32 * P8_ROWB) + a_addr[kg]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (TAIL == 0) { stage(cur, 0, c2, t2, b); stage(cur, 1, c2, t2, b); }
+      if (TAIL == 0) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+      else if (TAIL == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      mma_q(wb1, 1, 2);
+      mma_q(wb0, 0, 2);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      barrier();
+      adv(c1, t1); adv(c2, t2);
+    };
+    using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>; using J2 = std::integral_constant<int, 2>;
+    int kt = 0;
+    for (; kt + 2 < nkt; ++kt) ktile2(kt, J0{});
+    if (kt + 1 < nkt) { ktile2(kt, J1{}); ++kt; }
+    ktile2(kt, J2{});
+    if (wm == 0) __builtin_amdgcn_s_barrier();                 // the rows meet again: nobody reads the buffers any more, no DMA in flight
+    asm volatile("" ::: "memory");
+
+    // ---- the next tile's parameters and first K-tile, requested in front of this tile's epilogue
+    const bool has_next = it + grid < total;
+    TileAddr nxt = cur;
+    if (has_next) {
+      nxt = tile_addr(it + grid);
+      stage_tile_params(nxt, slot ^ 1);
+      stage(nxt, 0, 0, 0, 0); stage(nxt, 1, 0, 0, 0); stage(nxt, 2, 0, 0, 0); stage(nxt, 3, 0, 0, 0);
+    }
+    // ---- epilogue of `cur` (kernels_tdnn_v3.hip's), two passes of 64 rows per wave through buffer 1
+    {
+      const float *par = reinterpret_cast<const float *>(lds + 2 * P8_BUF + slot * P8P_PAR_SLOT);
+      const uint32_t *vw = reinterpret_cast<const uint32_t *>(lds + 2 * P8_BUF + slot * P8P_PAR_SLOT + 3072);
+      unsigned char *scr = lds + P8_BUF + wave * (64 * P8_ROWB);        // [64 frames][64 channels] 16-bit, 128-B rows, swizzled slots
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        uint32_t vmask = 0;
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) vmask |= ((vw[wm * 4 + h * 2 + i2] >> lr) & 1u) << i2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int chl = wn * 64 + j * 32 + 8 * q + 4 * lh;
+            const float4 b4 = *reinterpret_cast<const float4 *>(par + chl);
+            const float4 sc4 = *reinterpret_cast<const float4 *>(par + 256 + chl);
+            const float4 sh4 = *reinterpret_cast<const float4 *>(par + 512 + chl);
+            const float b[4] = {b4.x, b4.y, b4.z, b4.w}, sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+            const int sl = j * 4 + q;
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2) {
+              const bool valid = (vmask >> i2) & 1u;
+              const int frow = i2 * 32 + lr;
+              float y[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) y[e] = tdnn_epilogue_fast(acc[h * 2 + i2][j][q * 4 + e], b[e], act_lo, sc[e], sh[e], true);
+              uint2 pk;
+              pk.x = pack_h16x2<ET>(y[0], y[1]);
+              pk.y = pack_h16x2<ET>(y[2], y[3]);
+              pk.x = valid ? pk.x : 0u;
+              pk.y = valid ? pk.y : 0u;
+              *reinterpret_cast<uint2 *>(scr + frow * P8_ROWB + swz(frow, sl) * 16 + ((lh ^ (frow & 1)) * 8)) = pk;
+            }
+          }
+        }
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) {
+          const int piece = s8 * 64 + lane, frow = piece >> 3, sl = piece & 7;
+          uint4 v = *reinterpret_cast<const uint4 *>(scr + frow * P8_ROWB + swz(frow, sl) * 16);
+          if (frow & 1) v = make_uint4(v.z, v.w, v.x, v.y);
+          const int ch = cur.n0 + wn * 64 + sl * 8;
+          const int row = cur.m0 + wm * 128 + h * 64 + frow;
+          if (ch < p.cout_store) *reinterpret_cast<uint4 *>(yg + (size_t)row * y_pitch + (size_t)ch * 2) = v;
+        }
+      }
+    }
+    if (!has_next) break;
+    barrier();                                                  // every wave is done with its scratch in buffer 1
+    if (nkt > 1) {
+      int c1n, t1n;
+      kt_ct(1, c1n, t1n);
+      stage(nxt, 0, c1n, t1n, 1); stage(nxt, 1, c1n, t1n, 1);
+    }
+    cur = nxt;
+    slot ^= 1;
+    it += grid;
+  }
 }
 
 }  // namespace
@@ -492,14 +777,30 @@ int launch_tdnn_p8_variant(const TdnnKernelParams &p, int variant, hipStream_t s
     case 4: ASV_P8(ET_BF16, 4); break;
     case 5: ASV_P8(ET_BF16, 5); break;
     case 6: ASV_P8(ET_BF16, 6); break;
+    case 7: ASV_P8(ET_BF16, 7); break;
     case 40: case 41: case 44:                       // the four-phase form (round 5, second version) and its variants: an even number of K-tiles
       ASV_REQUIRE(((p.cin_pad / 64) * p.n_taps) % 2 == 0, "tdnn(p8): the four-phase form takes an even number of K-tiles");
       if (variant == 40) ASV_P8P(ET_BF16, 0, 4); else if (variant == 41) ASV_P8P(ET_BF16, 1, 4); else ASV_P8P(ET_BF16, 4, 4);
       break;
 #endif
-    default:
+    case 50:                                         // the one-tile two-phase form (A/B)
       if (f16) ASV_P8(ET_F16, 0);
       else ASV_P8(ET_BF16, 0);
+      break;
+    default: {
+      // persistent form: one workgroup per CU
+      static int cus = 0;
+      if (cus == 0) {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        cus = n > 0 ? n : 256;
+      }
+      const dim3 pgrid(std::min(m_tiles * n_tiles, cus));
+      if (one) { if (f16) hipLaunchKernelGGL((tdnn_gemm_p8p_kernel<ET_F16, true>), pgrid, block, 0, s, p, m_tiles, n_tiles);
+                 else hipLaunchKernelGGL((tdnn_gemm_p8p_kernel<ET_BF16, true>), pgrid, block, 0, s, p, m_tiles, n_tiles); }
+      else { if (f16) hipLaunchKernelGGL((tdnn_gemm_p8p_kernel<ET_F16, false>), pgrid, block, 0, s, p, m_tiles, n_tiles);
+             else hipLaunchKernelGGL((tdnn_gemm_p8p_kernel<ET_BF16, false>), pgrid, block, 0, s, p, m_tiles, n_tiles); }
+    }
   }
 #undef ASV_P8
 #undef ASV_P8P

@@ -95,6 +95,16 @@ int main(int argc, char **argv) {
   }
   printf("p8 vs big3 over 6 more launches: %zu differing values\n", race);
   {
+    CK(hipMemset(y1, 0x55, (size_t)rows * cout_pad * 2));
+    p.y = y1;
+    if (launch_tdnn_p8_variant(p, 50, 0) == 0) {
+      CK(hipMemcpy(h1.data(), y1, h1.size() * 2, hipMemcpyDeviceToHost));
+      size_t d1 = 0;
+      for (int r = 0; r < rows; ++r) for (int c = 0; c < p.cout_store; ++c) { const size_t i = (size_t)r * cout_pad + c; d1 += h0[i] != h1[i]; }
+      printf("p8 one-tile form vs big3: %zu differing values\n", d1);
+    }
+  }
+  {
     CK(hipMemset(y1, 0x33, (size_t)rows * cout_pad * 2));
     p.y = y1;
     if (tdnn_p8_supported(p, ET_BF16, false) && ((cin / 64) * ntaps) % 2 == 0 && launch_tdnn_p8_variant(p, 40, 0) == 0) {
@@ -104,10 +114,26 @@ int main(int argc, char **argv) {
       printf("p8 four-phase form vs big3: %zu differing values\n", d4);
     }
   }
+  // ---- phase stamps of the production kernel (variant 7): prologue | K loop | epilogue, cycles of wave 0, mean over the workgroups
+  {
+    const int n_wg = (rows / 256) * (cout_pad / 256);
+    unsigned long long *dbg; CK(hipMalloc(&dbg, (size_t)n_wg * 64)); CK(hipMemset(dbg, 0, (size_t)n_wg * 64));
+    p.partial = reinterpret_cast<float *>(dbg); p.y = y1;
+    for (int i = 0; i < 3; ++i) if (launch_tdnn_p8_variant(p, 7, 0)) { printf("stamp launch failed: %s\n", asv_last_error()); return 1; }
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> h((size_t)n_wg * 8);
+    CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+    double a = 0, b = 0, c = 0;
+    for (int w = 0; w < n_wg; ++w) { a += (double)(h[w * 8 + 1] - h[w * 8]); b += (double)(h[w * 8 + 2] - h[w * 8 + 1]); c += (double)(h[w * 8 + 3] - h[w * 8 + 2]); }
+    printf("p8 phase stamps (s_memtime cycles of wave 0, mean over %d workgroups): prologue %.0f | K loop %.0f (%.0f per K-tile) | epilogue + store drain %.0f\n", n_wg, a / n_wg, b / n_wg,
+           b / n_wg / ((cin / 64) * ntaps), c / n_wg);
+    p.partial = nullptr;
+    CK(hipFree(dbg));
+  }
   // ---- timing: interleaved rounds
   struct Var { const char *name; int kind, variant; };
-  const Var vars[] = {{"big3 128x256 (2 WG/CU)", 0, 0}, {"p8 two-phase", 1, 0}, {"p8 four-phase", 1, 40}, {"p8 two-phase no stagger", 1, 1}, {"p8 two-phase without setprio", 1, 2},
-                      {"p8 two-phase no DMA in the loop", 1, 5}, {"p8 two-phase no fragment reads", 1, 6}, {"p8 two-phase skeleton", 1, 4}, {"p8 four-phase skeleton", 1, 44}};
+  const Var vars[] = {{"big3 128x256 (2 WG/CU)", 0, 0}, {"p8 persistent (production)", 1, 0}, {"p8 one tile per workgroup", 1, 50}, {"p8 four-phase, one tile", 1, 40},
+                      {"p8 one tile, no stagger", 1, 1}, {"p8 one tile, without setprio", 1, 2}, {"p8 one tile, skeleton", 1, 4}};
   const int nv = sizeof(vars) / sizeof(vars[0]);
   std::vector<std::vector<float>> us(nv);
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
