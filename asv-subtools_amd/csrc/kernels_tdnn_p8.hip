@@ -35,6 +35,8 @@
 //     in the last phase into a second register set).  It stays in the developer build (variants 40 / 41 / 44): the same rate to
 //     +-4 % on every shape (profiles/r5l_p8_shapes.txt) - its MFMA + barrier skeleton and this one's are equally fast: the number of
 //     barriers is not what the loop's ~20 % of non-MFMA cycles are - on 254 registers and an even number of K-tiles only.
+//   * Production = tdnn_gemm_p8p_kernel further down: this schedule inside a persistent tile loop (the next tile's first K-tile is
+//     requested in front of the epilogue).  The one-tile kernel here stays for A/B (variant 50) and carries the measurement variants.
 //   * Epilogue: kernels_tdnn_v3.hip's (bias -> ReLU -> folded BN, packed 16-bit, wave-private LDS transpose, 16-byte row stores).
 #include <algorithm>
 #include <cstdlib>
