@@ -102,6 +102,7 @@ struct TdnnKernelParams {
   const void *wconv;    // 3x3 grid convolutions (kernels_conv2d.hip): bf16 weights in THAT kernel family's fragment order [tap][k-group][n-frag][lane][8]
                         // - its own pointer, so that neither family can ever be handed the other's layout - or nullptr
   const void *wlo;      // pooled-domain layers and the f32x frame kernel: the bf16 'lo' halves (w - hi), same layout as wfrag, or nullptr
+  const void *wx3p;     // f32x 8-phase kernel (kernels_tdnn_p8x.hip): [cout_pad][tap][chunk32][hi 32 | lo 32] 16-bit halves of w * 2^s, or nullptr
   // split-K (small-M layers: the pooled domain): blockIdx.y walks `ksplit` slices of the channel
   // chunks, raw f32 accumulators go to partial[slice][rows][ld_partial]; a second kernel sums
   // the slices in order and applies the epilogue (deterministic, no atomics)
@@ -182,6 +183,11 @@ int launch_tdnn_big3_variant(const TdnnKernelParams &p, int variant, hipStream_t
 bool tdnn_p8_supported(const TdnnKernelParams &p, int et, bool out_f32);
 int launch_tdnn_p8(const TdnnKernelParams &p, hipStream_t s);
 int launch_tdnn_p8_variant(const TdnnKernelParams &p, int variant, hipStream_t s);
+// the same structure for the f32x mode: f32 rows split in registers, three matrix instructions per product (kernels_tdnn_p8x.hip); weights in p.wx3p
+bool tdnn_p8x_supported(const TdnnKernelParams &p);
+int launch_tdnn_p8x(const TdnnKernelParams &p, hipStream_t s);
+void pack_tdnn_weight_x3p(const float *w, int out_ch, int in_ch, int tot_ctx, int left_ctx, const int *taps, int n_taps, int cout_pad, int cin_pad,
+                          int et, float scale, uint16_t *dst);
 // tdnn -> [1-tap 512 -> 512]* -> 1-tap + fused statistics pooling in one kernel, the 128 x 512 intermediate tiles resident in
 // LDS (kernels_tdnn_chain.hip).  Weight fragments as for the variant-3 kernel.
 constexpr int kChainWidth = 512;

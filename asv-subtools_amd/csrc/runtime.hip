@@ -80,6 +80,24 @@ void pack_tdnn_weight_frags(const float *w, int out_ch, int in_ch, int tot_ctx, 
   }
 }
 
+// Plain order for kernels_tdnn_p8x.hip (the weight half-tiles arrive by LDS-DMA, 128-byte rows): [cout_pad][tap][chunk32][hi 32 | lo 32],
+// the same halves of w * scale as pack_tdnn_weight_frags writes (the two kernels give the same bits)
+void pack_tdnn_weight_x3p(const float *w, int out_ch, int in_ch, int tot_ctx, int left_ctx, const int *taps, int n_taps, int cout_pad, int cin_pad,
+                          int et, float scale, uint16_t *dst) {
+  const int nchunks = cin_pad / 32;
+  memset(dst, 0, (size_t)cout_pad * n_taps * nchunks * 64 * 2);
+  for (int co = 0; co < out_ch; ++co)
+    for (int t = 0; t < n_taps; ++t) {
+      const int k = taps[t] - left_ctx;
+      for (int ci = 0; ci < in_ch; ++ci) {
+        const size_t idx = (((size_t)co * n_taps + t) * nchunks + ci / 32) * 64 + ci % 32;
+        const float v = w[((size_t)co * in_ch + ci) * tot_ctx + k] * scale;
+        dst[idx] = f32_to_h16_host(v, et);
+        dst[idx + 32] = f32_to_h16_host(v - h16_to_f32_host(dst[idx], et), et);
+      }
+    }
+}
+
 // Power of two that lifts the largest weight of a layer to [2^13, 2^14) (the half-precision split of the f32x mode): every
 // weight down to 2^-15 of the largest keeps a normal lo half; the products grow by the same factor, far inside f32.
 static float x3_weight_scale(const float *w, size_t n) {
@@ -126,6 +144,7 @@ struct Op {
   void *wfrag = nullptr;         // fragment-ordered copy for the variant-3 kernel (bf16 frame layers); pooled layers: bf16 hi halves
   void *wconv = nullptr;         // 3x3 trunk convolutions with 32 / 64 / 128 / 256 channels: fragment order of kernels_conv2d.hip
   void *wlo = nullptr;           // pooled layers in bf16 precision mode: bf16 lo halves (kernels_utts.hip)
+  void *wx3p = nullptr;          // f32x mode, wide frame layers with the plain epilogue: [hi | lo] rows for kernels_tdnn_p8x.hip
   float *bias = nullptr, *scale = nullptr, *shift = nullptr;
   int cin_pad = 0, cout_pad = 0, cout_store = 0;
   // chain candidates (16-bit modes, 1-tap layers reading a 512-channel buffer): host copies kept until asv_net_finalize, which
@@ -524,6 +543,14 @@ int asv_net_add_tdnn(asv_net_t *net, const asv_tdnn_desc_t *d) {
                              net->x3_et(), op.w_scale);
       if ((rc = dev_upload(net, hi.data(), hi.size() * 2, &op.wfrag))) return rc;
       if ((rc = dev_upload(net, lo.data(), lo.size() * 2, &op.wlo))) return rc;
+      // the candidates of the 8-phase form (256 x 256 tiles; the dispatch decides per batch): the plain epilogue, whole 32-channel chunks
+      const bool plain = (d->act1 == ASV_ACT_NONE || d->act1 == ASV_ACT_RELU) && d->act2 == ASV_ACT_NONE && !d->affine_first;
+      if (plain && op.cin_pad % 32 == 0 && d->in2_buf < 0 && d->seg_bias_buf < 0 && d->seg_scale_buf < 0 && d->res_buf < 0 && (long long)op.cin_pad * d->n_taps >= 512) {
+        std::vector<uint16_t> rows((size_t)op.cout_pad * d->n_taps * (op.cin_pad / 32) * 64);
+        pack_tdnn_weight_x3p(d->weight, d->out_ch, d->in_ch, d->w_tot_context, d->w_left_context, d->taps, d->n_taps, op.cout_pad, op.cin_pad, net->x3_et(), op.w_scale,
+                             rows.data());
+        if ((rc = dev_upload(net, rows.data(), rows.size() * 2, &op.wx3p))) return rc;
+      }
     }
     const bool x3_wide_frames = net->x3() && !op.utts && net->domains[dom].kind == ASV_DOMAIN_FRAMES && op.cout_store >= 192 && op.cin_pad >= 32 && d->in2_buf < 0;
     if (net->x3() && !op.utts && (net->domains[dom].kind == 2 || !x3_wide_frames) && grid_conv_x3_shape_ok(op.cin_pad, op.cout_store) &&
@@ -944,7 +971,7 @@ int asv_net_status_async(asv_net_t *net, unsigned *host_status, void *stream) {
 }
 
 unsigned long long asv_kernel_launch_count(int which) {
-  return (which == ASV_KERNEL_TDNN_P8 || which == ASV_KERNEL_TDNN_BIG3) ? g_kernel_launches[which].load() : 0ull;
+  return (which >= ASV_KERNEL_TDNN_P8 && which <= ASV_KERNEL_TDNN_P8X) ? g_kernel_launches[which].load() : 0ull;
 }
 
 size_t asv_net_device_bytes(const asv_net_t *net) {
@@ -1200,7 +1227,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         for (int t = 0; t < d.n_taps; ++t) { p.taps[t] = d.taps[t]; p.halo = std::max(p.halo, std::abs(d.taps[t])); }
         p.act1 = d.act1; p.act2 = d.act2; p.affine_first = d.affine_first;
         p.zero16 = net->zero_page;
-        p.wfrag = op.wfrag; p.wlo = op.wlo; p.wconv = op.wconv;
+        p.wfrag = op.wfrag; p.wlo = op.wlo; p.wconv = op.wconv; p.wx3p = op.wx3p;
         const bool chain_x3 = net->x3();             // f32x: the split-product chain on 64-row tiles (kernels_tdnn_chainx.hip)
         if (op.chain_last >= 0 && !use_ref && (bf16 || chain_x3) && p.halo <= kHalo && (net->flags & ASV_FLAG_SMALL_TILES) == 0 &&
             (chain_x3 || (unsigned long long)p.rows * (unsigned long long)p.ldx * 2ull < (1ull << 32))) {
@@ -1389,6 +1416,15 @@ int run_ops(RunCtx &c, size_t n_ops) {
         const int p8_on = getenv("ASV_AMD_LIVE_TUNE") != nullptr ? (getenv("ASV_AMD_P8") ? atoi(getenv("ASV_AMD_P8")) : 1) : p8_env;
         const bool p8 = big3 && !fuse && p8_on != 0 && tdnn_p8_supported(p, et, !bf16) &&
                         (long long)(p.rows / 256) * (round_up(p.cout_store, 256) / 256) >= (p8_on > 1 ? p8_on : 256);
+        // ... and the same structure for the f32x mode's wide plain layers (kernels_tdnn_p8x.hip; the bits of tdnn_gemm_x3_kernel).  ASV_AMD_P8X=0: off
+        static const int p8x_env = getenv("ASV_AMD_P8X") ? atoi(getenv("ASV_AMD_P8X")) : 1;
+        const int p8x_on = getenv("ASV_AMD_LIVE_TUNE") != nullptr ? (getenv("ASV_AMD_P8X") ? atoi(getenv("ASV_AMD_P8X")) : 1) : p8x_env;
+        // (production rule: at least one round of tiles AND a last round that is >= 85 % full - the x-vector's tdnn2 at 256 utterances is
+        //  408 tiles = 1.6 rounds, where the finer 128-row tiles of tdnn_gemm_x3_kernel are as fast and leave CUs to the other stream:
+        //  -0.9 % on two streams, profiles/r5s_p8x_model_ab.txt; ECAPA's layers are 4.75 and 7.1 rounds)
+        const long long p8x_tiles = (long long)(p.rows / 256) * (round_up(p.cout_store, 256) / 256);
+        const bool p8x_fill = p8x_on > 1 ? p8x_tiles >= p8x_on : (p8x_tiles >= 256 && p8x_tiles * 100 >= ((p8x_tiles + 255) / 256) * 256 * 85);
+        const bool p8x = x3 && !fuse && p8x_on != 0 && tdnn_p8x_supported(p) && p8x_fill;
         if (use_ref) rc = launch_tdnn_ref(p, et, !bf16, c.s);
         else if (utts_kernel) {
           // last layer, every utterance a single chunk: the kernel also produces the caller's [utterance][embed_dim] result
@@ -1406,6 +1442,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         else if (wide_conv) rc = launch_grid_conv_wide(p, c.s);
         else if (s2d_conv) rc = launch_grid_conv_s2d(p, c.s);
         else if (c1_conv) rc = launch_grid_conv_c1(p, c.s);
+        else if (p8x) { rc = launch_tdnn_p8x(p, c.s); ++g_kernel_launches[ASV_KERNEL_TDNN_P8X]; }
         else if (x3) rc = launch_tdnn_x3(p, c.s);
         else if (x3_conv) rc = launch_grid_conv_x3(p, c.s);
         else if (p8) { rc = launch_tdnn_p8(p, c.s); ++g_kernel_launches[ASV_KERNEL_TDNN_P8]; }

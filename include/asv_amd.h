@@ -287,6 +287,7 @@ int asv_net_status_async(asv_net_t *net, unsigned *host_status, void *stream);
 /* Diagnostic: launches of a kernel family by this process since the library was loaded (tests assert with it that the kernel they
  * mean to exercise is the one that ran - no silent fall-back onto another tile).  which: ASV_KERNEL_* below; unknown ids return 0. */
 #define ASV_KERNEL_TDNN_P8 1     /* kernels_tdnn_p8.hip: 256 x 256 tiles, both operands through LDS-DMA */
+#define ASV_KERNEL_TDNN_P8X 3    /* kernels_tdnn_p8x.hip: the same structure for the f32x mode (f32 rows split in registers) */
 #define ASV_KERNEL_TDNN_BIG3 2   /* kernels_tdnn_v3.hip: 128 x 256 tiles, window through LDS, weight fragments from L2 */
 unsigned long long asv_kernel_launch_count(int which);
 

@@ -61,6 +61,47 @@ def test_ecapa_batch_composition_invariance():
         assert np.array_equal(model.extract_embedding(mats[i]).numpy(), full[i])
 
 
+def test_ecapa_f32x_8phase_kernel_same_bits_and_range_status(monkeypatch):
+    """Round 5: the f32x mode's wide plain layers (ECAPA's 1-tap C -> C layers, the 3C -> 1536 layer) go to kernels_tdnn_p8x.hip from
+    one round of 256 x 256 tiles on; forced onto this small batch (ASV_AMD_P8X=2) the embeddings must be the bits tdnn_gemm_x3_kernel
+    gives (the dispatch depends on the batch size: an utterance's embedding may not), inside the f32 gate against the reference's own
+    outputs, and the range watch of the IEEE-half split - on the accumulators in this kernel - must raise the status word the
+    scripts' guard reads."""
+    import torch
+    from libs.amd import capi, synth
+    L = capi.lib()
+    g, sd, model = helpers.golden_model("ecapa_c512_near_affine")
+    model.cuda()
+    model.amd_precision = "f32x"
+    feats = helpers.golden_feats(g)
+    mats = [synth.synth_feats(T, 80, 7100 + i) for i, T in enumerate([300, 211, 300, 64, 500, 300, 2, 129])]
+    monkeypatch.setenv("ASV_AMD_LIVE_TUNE", "1")
+    monkeypatch.setenv("ASV_AMD_P8X", "0")
+    n0 = L.asv_kernel_launch_count(capi.KERNEL_TDNN_P8X)
+    ref_g = model.extract_embedding_batch(feats).numpy()
+    ref = model.extract_embedding_batch(mats).numpy()
+    assert L.asv_kernel_launch_count(capi.KERNEL_TDNN_P8X) == n0
+    monkeypatch.setenv("ASV_AMD_P8X", "2")
+    got_g = model.extract_embedding_batch(feats).numpy()
+    got = model.extract_embedding_batch(mats).numpy()
+    assert L.asv_kernel_launch_count(capi.KERNEL_TDNN_P8X) > n0, "no layer went to the f32x 8-phase kernel"
+    assert np.array_equal(got, ref) and np.array_equal(got_g, ref_g)
+    for i, (T, _) in enumerate(g["utts"]):
+        assert rel_err(got_g[i], g["embeddings"][i]) < TOL_F32
+    eng = model._amd_engine()
+    assert eng.status() == 0
+    huge = [m.copy() for m in mats]
+    huge[4] = (huge[4] * 3.0e5).astype(np.float32)
+    dev = torch.device("cuda", eng.device_index)
+    offs = np.concatenate([[0], np.cumsum([m.shape[0] for m in huge])]).astype(np.int32)
+    for p8x in ("2", "0"):
+        monkeypatch.setenv("ASV_AMD_P8X", p8x)
+        eng.extract_device(torch.from_numpy(np.concatenate(huge)).to(dev), offs)
+        assert eng.status() & capi.STATUS_HALF_RANGE, p8x
+        eng.extract_device(torch.from_numpy(np.concatenate(mats)).to(dev), offs)
+        assert eng.status() == 0, p8x
+
+
 def test_res2_block_kernel_matches_per_branch_layers(monkeypatch):
     """bf16 mode runs every Res2NetBlock (ecapa_tdnn_xvector.py:61-75) as one kernel with the running tensor in LDS
     (kernels_res2.hip); ASV_AMD_NO_FUSE=1 keeps one launch per branch.  Same bf16 operands and the same bf16 rounding of every

@@ -346,6 +346,54 @@ def test_p8_kernel_vs_oracle_and_big3(case, mode, act, monkeypatch):
     assert rel_err(got, want) < MODE_TOL[mode]
 
 
+P8X_CASES = [
+    # layers the f32x 8-phase kernel takes (whole 32-channel chunks, cin x taps >= 512, >= 192 output channels, plain epilogue)
+    (512, 512, [-2, 0, 2], [200, 200, 64, 300]),
+    (512, 1500, [0], [200, 100]),
+    (1024, 1024, [0], [300, 200]),
+    (256, 512, [-2, -1, 0, 1, 2], [1, 511, 3]),    # 8 chunks x 5 taps = 40 K-tiles
+    (96, 200, [-4, -3, 0, 1, 3, 4], [5, 600]),     # 3 chunks x 6 taps = 18, taps up to the halo's edge, 200 of 256 channels
+    (512, 320, [0], [77, 256, 1, 255]),            # a partly filled second channel tile
+    (544, 256, [0], [300]),                        # 17 K-tiles: an odd count
+    (160, 384, [-1, 0, 1, 2], [40, 41, 300]),      # 5 chunks x 4 taps
+]
+
+
+@pytest.mark.parametrize("case", P8X_CASES, ids=lambda c: "%dx%d_ctx%s" % (c[0], c[1], "_".join(map(str, c[2]))))
+@pytest.mark.parametrize("mode", ["f32x", "f32xb"])
+@pytest.mark.parametrize("act", ["relu", None])
+def test_p8x_kernel_vs_oracle_and_x3(case, mode, act, monkeypatch):
+    """Round 5: kernels_tdnn_p8x.hip (the persistent 8-phase structure for the f32x mode: f32 rows and [hi | lo] weight rows through
+    LDS-DMA, the split in registers, three matrix instructions per product) through the C ABI, forced onto small batches
+    (ASV_AMD_P8X=2): against the f64 numpy oracle of TdnnAffine + ReLU + eval BN (components.py:107-149, 418-431) at the mode's
+    tolerance AND bit for bit against tdnn_gemm_x3_kernel (the same products into each accumulator in the same order, the same
+    epilogue expression) - so an utterance's embedding does not depend on which of the two its batch was sent to."""
+    from libs.amd import capi
+    L = capi.lib()
+    cin, cout, ctx, lens = case
+    r = np.random.RandomState(cin * 13 + cout)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    x = r.randn(int(offsets[-1]), cin).astype(np.float32)
+    left, right = min(0, ctx[0]), max(0, ctx[-1])
+    w = (r.randn(cout, cin, right - left + 1) / np.sqrt(cin * len(ctx))).astype(np.float32)
+    b = (0.1 * r.randn(cout)).astype(np.float32)
+    scale = r.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = (0.2 * r.randn(cout)).astype(np.float32)
+    prec, flags = _mode_args(mode + "_mfma")
+    monkeypatch.setenv("ASV_AMD_LIVE_TUNE", "1")
+    monkeypatch.setenv("ASV_AMD_P8X", "2")
+    n0 = L.asv_kernel_launch_count(capi.KERNEL_TDNN_P8X)
+    got = _tdnn_forward(x, offsets, w, b, ctx, act, scale, shift, False, prec, flags)
+    assert L.asv_kernel_launch_count(capi.KERNEL_TDNN_P8X) == n0 + 1, "the f32x 8-phase kernel did not take this layer"
+    monkeypatch.setenv("ASV_AMD_P8X", "0")
+    ref = _tdnn_forward(x, offsets, w, b, ctx, act, scale, shift, False, prec, flags)
+    assert L.asv_kernel_launch_count(capi.KERNEL_TDNN_P8X) == n0 + 1
+    assert np.array_equal(got, ref), "f32x 8-phase kernel and tdnn_gemm_x3_kernel differ in %d values (max %g)" % (
+        int((got != ref).sum()), float(np.abs(got - ref).max()))
+    want = _oracle_layer(x, offsets, w, b, ctx, act, scale, shift, False)
+    assert rel_err(got, want) < MODE_TOL[mode]
+
+
 def test_p8_kernel_is_the_one_the_wide_layers_run_on(monkeypatch):
     """Production dispatch: from one round of 256 x 256 tiles (256 of them) a plain wide layer goes to the 8-phase kernel, smaller
     batches and the layers it does not take (cin = 80: no whole 64-channel chunks) stay on the variant-3 kernel."""

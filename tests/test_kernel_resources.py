@@ -70,3 +70,46 @@ def test_persistent_f32x_convolution_kernels_keep_their_weights_in_registers(tmp
         one_per_cu = "pers64_kernelILi1ELi2E" in name or "pers64_kernelILi2ELi2E" in name          # WM = 2: 8 waves, one workgroup per CU
         assert lds * (1 if one_per_cu else 2) <= 163840, (name, lds)
     assert seen >= 8, seen            # pers32 x 2 split types, pers64 x 2 split types x {32-row, 32-row pipelined, 64-row}
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+@pytest.mark.parametrize("src,extra", [("kernels_tdnn_p8.hip", []), ("kernels_tdnn_p8x.hip", ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"])])
+def test_8phase_kernels_have_no_spills_and_no_compiler_visible_vector_loads(tmp_path, src, extra):
+    """The 8-phase kernels (kernels_tdnn_p8.hip, kernels_tdnn_p8x.hip) issue every vector-memory read as LDS-DMA from inline assembly
+    and wait with counted `s_waitcnt vmcnt(N)`: hipcc counts only the vector-memory operations it knows of, so ONE load of its own in
+    the tile loop - or one spilled register (scratch is vector memory) - turns into waits that, in hardware terms, drain the DMA pieces
+    in flight (the first p8x build spilled 30 registers across the K loop and got a `vmcnt(0)` at the top of every tile).  Build-time
+    check: no spills, no scratch, 2 waves per SIMD, and no global / scratch / buffer load instruction of the compiler's behind a kernel's first DMA."""
+    out = tmp_path / "k.s"
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(REPO, "include"), "-I" + CSRC, "-Wno-inline-asm"] + extra + [
+        "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o", str(out), os.path.join(CSRC, src)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    blocks = re.split(r"remark: [^\n]*Function Name: ", r.stderr)[1:]
+    assert len(blocks) >= 4
+    for b in blocks:
+        name = b.split()[0]
+        assert int(re.search(r"VGPRs Spill: (\d+)", b).group(1)) == 0, name
+        assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1)) == 0, name
+        assert int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1)) == 2, name
+    in_asm, bad, n_dma, dma_seen, checked = False, [], 0, False, False
+    for line in out.read_text().splitlines():
+        if re.match(r"_Z\w+:", line):                          # a kernel begins (the persistent production forms are the ones checked:
+            dma_seen = False                                   #  the one-tile development forms of kernels_tdnn_p8.hip keep plain loads)
+            checked = "p8p_kernel" in line or "p8x_kernel" in line
+        if "#ASMSTART" in line:
+            in_asm = True
+            continue
+        if "#ASMEND" in line:
+            in_asm = False
+            continue
+        code = line.split(";")[0].strip()
+        if in_asm and code.startswith("global_load_lds_dwordx4"):
+            n_dma += 1
+            dma_seen = True
+        # (in front of a kernel's first DMA a load of hipcc's own is harmless: the tap table, which it fetches from the kernarg segment
+        #  with a vector load when the kernel selects an entry by lane)
+        if not in_asm and dma_seen and checked and re.match(r"(global_load|scratch_load|scratch_store|buffer_load|flat_load)", code):
+            bad.append(code)
+    assert n_dma >= 40
+    assert not bad, bad[:5]
