@@ -126,6 +126,33 @@ def test_res2_block_kernel_matches_per_branch_layers(monkeypatch):
     assert cos_ref.min() > 0.999, cos_ref
 
 
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+def test_res2_block_kernel_window_forms_give_the_same_bits(precision, monkeypatch):
+    """Round 5: res2_chain_kernel has two window sizes (6 / 7 row fragments: 128 / 160 output rows per workgroup, 4 + 3 fragments on
+    the two row halves of the larger one, images B and X in one buffer); the launcher picks by the batch's tile count.  Every output row
+    is computed from the same operands in the same order in both, so the embeddings must be bit-identical - on ragged batches whose
+    row counts leave the last 160-row tile overhanging the matrix by different amounts (its loads clamp onto the last gap row, its
+    stores write that row's zeros), at all three dilations of the model."""
+    from libs.amd import synth
+    g, sd, model = helpers.golden_model("ecapa_launcher")
+    model.cuda()
+    model.amd_precision = precision
+    monkeypatch.setenv("ASV_AMD_LIVE_TUNE", "1")
+    lens_sets = [[300, 211, 300, 64, 500, 300, 2, 129], [1, 2, 7, 33], [200] * 9, [517, 640, 3, 300, 300, 300, 41], [160], [161, 159, 160, 1]]
+    for k, lens in enumerate(lens_sets):
+        mats = [synth.synth_feats(T, 80, 7300 + 17 * k + i) for i, T in enumerate(lens)]
+        monkeypatch.setenv("ASV_AMD_RES2_FR", "6")
+        a = model.extract_embedding_batch(mats).numpy()
+        monkeypatch.setenv("ASV_AMD_RES2_FR", "7")
+        b = model.extract_embedding_batch(mats).numpy()
+        assert "res2" in model._amd_engine().describe()
+        assert np.isfinite(a).all()
+        assert np.array_equal(a, b), (precision, lens, int((a != b).sum()))
+    monkeypatch.delenv("ASV_AMD_RES2_FR")
+    c = model.extract_embedding_batch(mats).numpy()              # the launcher's own choice
+    assert np.array_equal(a, c)
+
+
 @pytest.mark.parametrize("precision", ["f32", "f32x"])
 def test_ecapa_with_attentive_statistics_pooling_vs_reference_golden(precision):
     """Round 4: ECAPA_TDNN(pooling='attentive') - AttentiveStatisticsPooling with time context behind the MFA layer
