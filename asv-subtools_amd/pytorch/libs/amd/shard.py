@@ -99,51 +99,78 @@ def _agree_or_raise(err, embed_dim, device, group, rank, world):
     return width
 
 
-def extract_sharded(extract_batch, lengths, load_utt, max_frames=65536, max_utts=1024, group=None, device=None, row_pad=0):
-    """Full sharded extraction.
-        extract_batch(list_of_mats) -> [b, E] tensor on `device`     (e.g. Engine.extract_device wrapper)
-        load_utt(i) -> [T_i, D] float32 matrix of utterance i          (only called for this rank's shard)
-    Returns [n_total, E] (original order) on every rank.  A rank with an empty shard (more ranks than utterances) contributes
-    zero rows; a rank whose read / extraction raises makes EVERY rank raise before the all-gather (no rank is left waiting in a
-    collective)."""
+def extract_sharded_segments(extract_batch, lengths, load_utt, on_segment, segment_utts=None, max_frames=65536, max_utts=1024, group=None,
+                             device=None, row_pad=0):
+    """Sharded extraction in SEGMENTS of the utterance list, one collective pair per segment (round 5).
+        extract_batch(list_of_mats) -> [b, E] tensor on `device`     (e.g. a libs.amd.pipeline.DeviceSets wrapper)
+        load_utt(i) -> [T_i, D] float32 matrix of utterance i          (only called for this rank's share; `.load_batch(indices)` if it has one)
+        on_segment(a, b, emb)                                          emb = [b - a, E] embeddings of utterances a .. b - 1 in their order,
+                                                                       called on EVERY rank as soon as the segment has been gathered
+    Utterances [a, b) of a segment (`segment_utts` per rank; None = everything in one segment) are balanced by length over the ranks
+    and batched like the whole list used to be; the reader runs one batch ahead ACROSS segment ends; at a segment's end the rank's
+    pipeline is flushed, the ranks agree that nobody failed (one tiny all-reduce) and all-gather the segment.  What this buys: rank 0
+    can copy out and write segment s while segment s + 1 is being extracted - with one gather at the very end the 102 MB of 50 000
+    x-vectors (device -> host, ark packing, write) were a serial tail of 0.14 s behind a 0.2 s extraction loop
+    (profiles/r5z_bench.json: --sharded 150 k utterances/s against 251 k through the stream path).  The payload per collective stays
+    latency-sized (8192 x 512 x 4 B = 16 MB), their number small (50 000 utterances on one rank: 7).
+    A rank with nothing in a segment contributes zero rows; a rank whose read / extraction raises makes EVERY rank raise at that
+    segment's agreement (no rank is left waiting in a collective).  Returns the number of utterances."""
     import torch
     import torch.distributed as dist
     inited = dist.is_available() and dist.is_initialized()
     rank = dist.get_rank(group) if inited else 0
     world = dist.get_world_size(group) if inited else 1
-    shards = balance_by_length(lengths, world)
-    mine = shards[rank]
-    outs, err = [], None
-    # batch k + 1 is read on a worker thread while batch k is extracted (file reads release the GIL).  A loader with a
-    # `load_batch(indices)` method (pipeline/onestep/extract_embeddings.py ScpBatchLoader) hands over the whole batch packed in one
-    # buffer; a plain callable is asked utterance by utterance.
+    lengths = np.asarray(lengths, dtype=np.int64)
+    n = int(lengths.shape[0])
+    step = n if not segment_utts else max(1, int(segment_utts)) * world
+    plan = []                                             # per segment: (a, b, shards relative to a, this rank's batches in global indices)
+    for a in range(0, max(n, 1), max(step, 1)):
+        b = min(n, a + step)
+        shards = balance_by_length(lengths[a:b], world)
+        plan.append((a, b, shards, plan_batches(lengths, (shards[rank] + a).tolist(), max_frames, max_utts, row_pad)))
+    flat = [batch for _, _, _, batches in plan for batch in batches]
     from concurrent.futures import ThreadPoolExecutor
     whole = getattr(load_utt, "load_batch", None)
-    fetch = (lambda b: whole(b)) if whole is not None else (lambda b: [load_utt(i) for i in b])
+    fetch = (lambda batch: whole(batch)) if whole is not None else (lambda batch: [load_utt(i) for i in batch])
+    flush = getattr(extract_batch, "flush", None)          # a pipelined extract_batch returns tensors whose work is still in flight
     pool = ThreadPoolExecutor(1)
+    err, k = None, 0
     try:
-        batches = list(plan_batches(lengths, mine, max_frames, max_utts, row_pad))
-        ahead = pool.submit(fetch, batches[0]) if batches else None
-        for k in range(len(batches)):
-            mats = ahead.result()
-            ahead = pool.submit(fetch, batches[k + 1]) if k + 1 < len(batches) else None
-            outs.append(extract_batch(mats))
-    except Exception as e:                            # reported to every rank below, then re-raised here
-        err = e
+        ahead = pool.submit(fetch, flat[0]) if flat else None
+        for a, b, shards, batches in plan:
+            outs = []
+            if err is None:
+                try:
+                    for _ in batches:
+                        mats = ahead.result()
+                        k += 1
+                        ahead = pool.submit(fetch, flat[k]) if k < len(flat) else None
+                        outs.append(extract_batch(mats))
+                    if flush is not None:                   # finished (and range-checked) before the results are read
+                        flush()
+                except Exception as e:                      # reported to every rank below, then re-raised here
+                    err = e
+            local = torch.cat(outs, dim=0) if (outs and err is None) else None
+            width = _agree_or_raise(err, local.shape[1] if local is not None else 0, device, group, rank, world)
+            if local is None:
+                if width == 0:
+                    raise ValueError("sharded extraction: no utterances at all")
+                local = torch.zeros((0, width), dtype=torch.float32)
+            if device is not None:
+                local = local.to(device)
+            on_segment(a, b, gather_embeddings(local, shards[rank], shards, group=group))
     finally:
         pool.shutdown(wait=True)
-    flush = getattr(extract_batch, "flush", None)         # a pipelined extract_batch (libs.amd.pipeline.DeviceSets) returns tensors whose
-    if flush is not None and err is None:                  # work is still in flight: finished (and range-checked) here, before they are read
-        try:
-            flush()
-        except Exception as e:
-            err = e
-    local = torch.cat(outs, dim=0) if (outs and err is None) else None
-    width = _agree_or_raise(err, local.shape[1] if local is not None else 0, device, group, rank, world)
-    if local is None:
-        if width == 0:
-            raise ValueError("sharded extraction: no utterances at all")
-        local = torch.zeros((0, width), dtype=torch.float32)
-    if device is not None:
-        local = local.to(device)
-    return gather_embeddings(local, mine, shards, group=group)
+    return n
+
+
+def extract_sharded(extract_batch, lengths, load_utt, max_frames=65536, max_utts=1024, group=None, device=None, row_pad=0):
+    """Full sharded extraction with ONE gather at the end (extract_sharded_segments with a single segment).
+        extract_batch(list_of_mats) -> [b, E] tensor on `device`     (e.g. Engine.extract_device wrapper)
+        load_utt(i) -> [T_i, D] float32 matrix of utterance i          (only called for this rank's shard)
+    Returns [n_total, E] (original order) on every rank.  A rank with an empty shard (more ranks than utterances) contributes
+    zero rows; a rank whose read / extraction raises makes EVERY rank raise before the all-gather (no rank is left waiting in a
+    collective)."""
+    got = []
+    extract_sharded_segments(extract_batch, lengths, load_utt, lambda a, b, emb: got.append(emb), None, max_frames, max_utts, group, device, row_pad)
+    return got[0]

@@ -715,15 +715,16 @@ class IndexedArkReader(object):
             raise BadInputFormat("ark entry '%s': %s" % (keys[k], e.args[1]))
 
 
-def vec_flt_ark_bytes(keys, vectors):
+def vec_flt_ark_bytes(keys, vectors, as_buffer=False):
     """One bytes object holding the binary ark entries `key SP \\0B FV \\4 dim data` of float32 row vectors [n, dim]
-    (write_vec_flt's format, assembled per batch instead of written per key)."""
+    (write_vec_flt's format, assembled per batch instead of written per key).  as_buffer: any bytes-like object will do (a file's
+    write() takes it): the native packer's own array is handed over without the copy into a bytes object."""
     vectors = np.ascontiguousarray(vectors, dtype=np.float32)
     if len(keys) >= 16:
         from . import native_io
         L = native_io.lib()
         if L is not None and L.asv_io_version() >= 2 and not any("\n" in k for k in keys):
-            return native_io.pack_vec_ark(keys, vectors)
+            return native_io.pack_vec_ark(keys, vectors, as_array=as_buffer)
     head = b"\0BFV \4" + struct.pack("<I", vectors.shape[1])
     rows = vectors.view(np.uint8).reshape(vectors.shape[0], -1)
     return b"".join([(k + " ").encode("latin1") + head + rows[i].tobytes() for i, k in enumerate(keys)])

@@ -238,12 +238,28 @@ def matrix_rows(rxfile):
     return len(range(*rows.indices(n)))
 
 
-class PackedBatch(list):
+class PackedBatch(object):
     """The matrices of one batch as row slices of ONE buffer: `packed` [frames, D] float32, `offsets` int32 [n + 1]; `turn`: which of
-    the loader's buffers it lies in (None: an array of its own)."""
-    packed = None
-    offsets = None
-    turn = None
+    the loader's buffers it lies in (None: an array of its own).  A sequence of the [T_k, D] views, made when asked for (the device
+    path takes `packed` and `offsets` as they are: 321 views per batch were 50 000 slicing calls per run that nobody looked at)."""
+
+    def __init__(self, packed, offsets, turn):
+        self.packed, self.offsets, self.turn = packed, offsets, turn
+
+    def __len__(self):
+        return len(self.offsets) - 1
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return [self[j] for j in range(*k.indices(len(self)))]
+        if k < 0:
+            k += len(self)
+        if not 0 <= k < len(self):
+            raise IndexError(k)
+        return self.packed[int(self.offsets[k]):int(self.offsets[k + 1])]
+
+    def __iter__(self):
+        return (self[k] for k in range(len(self)))
 
 
 class ScpBatchLoader(object):
@@ -275,6 +291,7 @@ class ScpBatchLoader(object):
         self.max_open = max(1, int(max_open))
         self._fds = collections.OrderedDict()            # path -> descriptor, least recently used first
         self._heads = {}
+        self._table = None                               # index_all(): (plain, file id, payload offset, rows, cols) arrays + the file list
         self._bufs = list(buffers) if buffers is not None else [None, None]
         self._own = buffers is None
         self._before_fill = before_fill
@@ -312,6 +329,9 @@ class ScpBatchLoader(object):
         h = self._heads.get(i, 0)
         if h != 0:
             return h
+        if self._table:
+            plain, fid, pos, rows, cols, files = self._table
+            return (files[fid[i]], int(pos[i]), int(rows[i]), int(cols[i])) if plain[i] else None
         import struct
         rxfile = self.entries[i][1]
         h = None
@@ -325,8 +345,66 @@ class ScpBatchLoader(object):
         self._heads[i] = h
         return h
 
+    def index_all(self):
+        """Headers of ALL plain float32 'file:offset' entries in one native call (15 bytes each, libasv_io.so asv_io_pread_batch) and a
+        vectorised parse: arrays (plain, file id, payload offset, rows, cols) that load_batch() indexes with a batch's entry numbers -
+        per batch a handful of numpy operations instead of ~10 Python operations per utterance (50 000 utterances: 0.15 s of
+        interpreter time on the reader thread, under the GIL the submitting thread needs too; the header pass itself 0.2 s -> 0.03 s).
+        Without the native library, with more files than `max_open`, or if any header read fails, the per-entry path stays in charge
+        (returns False)."""
+        if self._table is not None:
+            return self._table is not False
+        self._table = False
+        from libs.support import native_io
+        if native_io.lib() is None:
+            return False
+        n = len(self.entries)
+        files, ids, cand, c_fid, c_off = [], {}, [], [], []
+        for i, (_, rx) in enumerate(self.entries):
+            path, sep, o = rx.rpartition(":")
+            if not sep or not o.isdigit():                # (range specifiers end in ']', pipes in '|': neither is all digits)
+                continue
+            j = ids.get(path)
+            if j is None:
+                j = ids[path] = len(files) if os.path.isfile(path) else -1
+                if j >= 0:
+                    files.append(path)
+            if j >= 0:
+                cand.append(i)
+                c_fid.append(j)
+                c_off.append(int(o))
+        fid, off = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int64)
+        fid[cand], off[cand] = c_fid, c_off
+        if not cand or len(files) > self.max_open:
+            return False
+        cand = np.asarray(cand, dtype=np.int64)
+        keep = set(files)
+        lut = np.asarray([self._fd(path, keep=keep) for path in files], dtype=np.int32)
+        heads = np.zeros((len(cand), 16), dtype=np.uint8)
+        try:
+            native_io.pread_batch(lut[fid[cand]], off[cand], np.full(len(cand), 15, dtype=np.int64), heads.ctypes.data,
+                                  np.arange(len(cand), dtype=np.int64) * 16, threads=self.threads)
+        except OSError:
+            return False                                  # (an offset at the very end of a file: the per-entry path names the entry)
+        ok = (heads[:, 0] == 0) & (heads[:, 1] == ord("B")) & (heads[:, 2] == ord("F")) & (heads[:, 3] == ord("M")) & (heads[:, 4] == ord(" ")) & \
+             (heads[:, 5] == 4) & (heads[:, 10] == 4)
+        rows_c = np.ascontiguousarray(heads[:, 6:10]).view("<i4").ravel()
+        cols_c = np.ascontiguousarray(heads[:, 11:15]).view("<i4").ravel()
+        plain = np.zeros(n, dtype=bool)
+        rows, cols = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64)
+        good = cand[ok]
+        plain[good], rows[good], cols[good] = True, rows_c[ok], cols_c[ok]
+        self._table = (plain, fid, off + 15, rows, cols, files)
+        return True
+
     def lengths(self):
         """Frames of every entry, from the headers (what the length-balanced sharding needs when no utt2num_frames is given)."""
+        if self.index_all():
+            plain, _, _, rows, _, _ = self._table
+            out = rows.copy()
+            for i in np.nonzero(~plain)[0]:
+                out[i] = matrix_rows(self.entries[i][1])
+            return out
         out = np.empty(len(self.entries), dtype=np.int64)
         for i, (_, rx) in enumerate(self.entries):
             h = self._direct(i)
@@ -385,13 +463,24 @@ class ScpBatchLoader(object):
 
     def load_batch(self, indices):
         slow = {}
-        shapes = [self.shape(i, slow) for i in indices]
-        dims = {c for _, c in shapes}
-        if len(dims) != 1:
-            raise ValueError("feature matrices of different widths in one batch: %s" % sorted(dims))
-        dim = dims.pop()
-        offs = np.zeros(len(indices) + 1, dtype=np.int32)
-        np.cumsum([r for r, _ in shapes], out=offs[1:])
+        idx = np.asarray(indices, dtype=np.int64)
+        fast = bool(self._table) and len(idx) > 0 and bool(self._table[0][idx].all())     # every entry of the batch is in the header table
+        if fast:
+            _, _, _, t_rows, t_cols, _ = self._table
+            cols = t_cols[idx]
+            dim = int(cols[0])
+            if (cols != dim).any():
+                raise ValueError("feature matrices of different widths in one batch: %s" % sorted(set(cols.tolist())))
+            offs = np.zeros(len(idx) + 1, dtype=np.int32)
+            np.cumsum(t_rows[idx], out=offs[1:])
+        else:
+            shapes = [self.shape(i, slow) for i in indices]
+            dims = {c for _, c in shapes}
+            if len(dims) != 1:
+                raise ValueError("feature matrices of different widths in one batch: %s" % sorted(dims))
+            dim = dims.pop()
+            offs = np.zeros(len(indices) + 1, dtype=np.int32)
+            np.cumsum([r for r, _ in shapes], out=offs[1:])
         total = int(offs[-1])
         turn, self._turn = self._turn, (self._turn + 1) % len(self._bufs)
         if self._before_fill is not None:
@@ -405,10 +494,28 @@ class ScpBatchLoader(object):
             packed = buf[:total]
         else:                                          # does not fit the caller's buffer (one utterance longer than a whole batch): its own array
             packed, turn = np.empty((total, dim), dtype=np.float32), None
-        self.fill(indices, packed, offs, slow)
-        out = PackedBatch(packed[int(offs[k]):int(offs[k + 1])] for k in range(len(indices)))
-        out.packed, out.offsets, out.turn = packed, offs, turn
-        return out
+        if fast:
+            self._fill_table(idx, packed, offs, dim)
+        else:
+            self.fill(indices, packed, offs, slow)
+        return PackedBatch(packed, offs, turn)
+
+    def _fill_table(self, idx, packed, offs, dim):
+        """fill() for a batch whose entries are all in the header table: the arguments of the one native read call by array indexing."""
+        from libs.support import native_io
+        _, t_fid, t_pos, _, _, files = self._table
+        fid = t_fid[idx]
+        used = np.unique(fid)
+        keep = {files[j] for j in used.tolist()}
+        lut = np.zeros(len(files), dtype=np.int32)
+        for j in used.tolist():
+            lut[j] = self._fd(files[j], keep=keep)
+        o64 = offs.astype(np.int64)
+        try:
+            native_io.pread_batch(lut[fid], t_pos[idx], (o64[1:] - o64[:-1]) * (dim * 4), packed.ctypes.data, o64[:-1] * (dim * 4), threads=self.threads)
+        except OSError as e:
+            k = e.args[2] if len(e.args) > 2 else 0
+            raise kaldi_io.BadInputFormat("scp entry %r: %s" % (self.entries[int(idx[k])][1], e.args[1]))
 
 
 class ScpGroupReader(object):
@@ -462,27 +569,60 @@ class ScpGroupReader(object):
         return [self.entries[i][0] for i in idx], offs, used
 
 
-def extract_sharded_scp(extract_batch, entries, lengths, w, batch_frames, batch_utts, verbose=False, device=None, loader=None, row_pad=0):
+def _shard_segment_utts():
+    """Utterances per rank between two gathers of the sharded path (ASV_AMD_SHARD_SEGMENT; 0 = one gather at the very end)."""
+    return max(0, int(os.environ.get("ASV_AMD_SHARD_SEGMENT", "8192")))
+
+
+def extract_sharded_scp(extract_batch, entries, lengths, w, batch_frames, batch_utts, verbose=False, device=None, loader=None, row_pad=0,
+                        segment_utts=None):
     """Sharded extraction of scp entries (one call per rank, torch.distributed initialised or not):
         extract_batch(list of [T, D] float32 matrices) -> [b, E] tensor
-    Every rank extracts its length-balanced shard; one all-gather; rank 0 writes the ark entries to `w` in scp order.
+    The scp is walked in segments of `segment_utts` utterances per rank (default: ASV_AMD_SHARD_SEGMENT = 8192): every rank extracts
+    its length-balanced share of a segment, one all-gather per segment, and rank 0 writes the segment's ark entries to `w` - in scp
+    order - on a writer thread while the next segment is being extracted (libs.amd.shard.extract_sharded_segments).
     Returns the number of embeddings (on every rank)."""
+    import queue
+    import threading
     import torch.distributed as dist
     from libs.amd import shard
     rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
     load = loader if loader is not None else ScpBatchLoader(entries, threads=_reader_threads())
+    keys = [k for k, _ in entries]
+    todo, failed = queue.Queue(), []
+
+    def write_segments():
+        while True:
+            item = todo.get()
+            if item is None:
+                return
+            a, b, emb = item
+            if failed:
+                continue
+            try:
+                if verbose:
+                    for key in keys[a:b]:
+                        print("Process utterance for key {0}".format(key))
+                w.write(kaldi_io.vec_flt_ark_bytes(keys[a:b], emb.cpu().numpy(), as_buffer=True))
+            except Exception as e:                       # re-raised on the caller's thread below
+                failed.append(e)
+
+    writer = threading.Thread(target=write_segments, name="asv-shard-writer", daemon=True) if rank == 0 else None
+    if writer is not None:
+        writer.start()
     try:
-        emb = shard.extract_sharded(extract_batch, lengths, load, max_frames=batch_frames, max_utts=batch_utts, device=device, row_pad=row_pad)
+        n = shard.extract_sharded_segments(extract_batch, lengths, load, (lambda a, b, emb: todo.put((a, b, emb))) if rank == 0 else (lambda a, b, emb: None),
+                                           _shard_segment_utts() if segment_utts is None else segment_utts,
+                                           max_frames=batch_frames, max_utts=batch_utts, device=device, row_pad=row_pad)
     finally:
+        if writer is not None:
+            todo.put(None)
+            writer.join()
         if loader is None:
             load.close()
-    if rank == 0:
-        keys = [k for k, _ in entries]
-        if verbose:
-            for key in keys:
-                print("Process utterance for key {0}".format(key))
-        w.write(kaldi_io.vec_flt_ark_bytes(keys, emb.cpu().numpy()))
-    return int(emb.shape[0])
+    if failed:
+        raise failed[0]
+    return n
 
 
 def run_sharded(args, model, max_chunk, verbose):
@@ -502,6 +642,7 @@ def run_sharded(args, model, max_chunk, verbose):
     sets = DeviceSets(model, args.batch_frames, args.batch_utts, engine.feat_dim, max_chunk, n_sets=3, results="device")
     loader = ScpBatchLoader(entries, threads=_reader_threads(),
                             buffers=[sets.host_buffer(k) for k in range(sets.n_sets)], before_fill=sets.input_consumed)
+    loader.index_all()                                 # all headers in one native call (also what lengths() below reads)
     if args.utt2num_frames:
         table = dict(line.split() for line in open(args.utt2num_frames) if line.strip())
         lengths = np.array([int(table[k]) for k, _ in entries], dtype=np.int64)

@@ -489,6 +489,77 @@ def test_scp_batch_loader_bounds_its_open_descriptors(tmp_path):
     assert len(ld._fds) == 0
 
 
+def test_scp_batch_loader_header_table_equals_the_per_entry_path(tmp_path):
+    """Round 5: index_all() reads every plain entry's 15-byte header in ONE native call and load_batch() then builds a batch's read
+    list by array indexing (no per-utterance Python).  Same lengths, same bytes as the per-entry path - on a table with float64
+    entries and a range specifier in between (not in the table: a batch that holds one goes the per-entry way), with a batch of
+    different widths refused, and not at all (False, per-entry path) when the files outnumber `max_open` or an offset points at the
+    end of its file."""
+    from libs.support import kaldi_io
+    ee = _load_extract_script()
+    rs = np.random.RandomState(9)
+    entries, want = [], []
+    for a in range(3):
+        path = tmp_path / ("t%d.ark" % a)
+        with open(path, "wb") as f:
+            for i in range(30):
+                key = "t%d_u%02d" % (a, i)
+                m = rs.randn(int(rs.randint(1, 50)), 16).astype(np.float32)
+                f.write((key + " ").encode())
+                pos = f.tell()
+                kaldi_io.write_mat(f, m.astype(np.float64) if i % 13 == 4 else m)
+                entries.append((key, "%s:%d" % (path, pos)))
+                want.append(m)
+    entries[7] = (entries[7][0], entries[7][1] + "[0:0]")
+    want[7] = want[7][0:1]
+    fast, slow = ee.ScpBatchLoader(entries, threads=3), ee.ScpBatchLoader(entries, threads=3)
+    slow._table = False
+    try:
+        assert fast.index_all() is True and slow.index_all() is False
+        plain = fast._table[0]
+        assert [i for i in range(len(entries)) if not plain[i]] == sorted({7} | {i for i in range(len(entries)) if i % 30 % 13 == 4})      # the range entry, the float64 ones
+        assert list(fast.lengths()) == list(slow.lengths()) == [m.shape[0] for m in want]
+        order = list(rs.permutation(len(entries)))
+        all_plain = [i for i in order if plain[i]]
+        for idx in (order[:25], order[25:60], all_plain[:40], all_plain[40:], [all_plain[0]]):
+            a, b = fast.load_batch(idx), slow.load_batch(idx)
+            assert len(a) == len(b) == len(idx) and list(a.offsets) == list(b.offsets)
+            assert np.array_equal(a.packed, b.packed)
+            for k, i in enumerate(idx):
+                assert np.array_equal(a[k], want[i]) and np.array_equal(a[k - len(idx)], want[i])
+            assert [m.shape for m in a] == [want[i].shape for i in idx] and len(a[1:3]) == len(idx[1:3])
+        with pytest.raises(IndexError):
+            a[len(idx)]
+    finally:
+        fast.close()
+        slow.close()
+    # another width in the table: a batch mixing the two is refused, by either path
+    path = tmp_path / "wide.ark"
+    with open(path, "wb") as f:
+        f.write(b"w ")
+        pos = f.tell()
+        kaldi_io.write_mat(f, rs.randn(5, 20).astype(np.float32))
+    mixed = entries + [("w", "%s:%d" % (path, pos))]
+    ld = ee.ScpBatchLoader(mixed, threads=2)
+    try:
+        assert ld.index_all()
+        with pytest.raises(ValueError, match="different widths"):
+            ld.load_batch([0, len(mixed) - 1])
+    finally:
+        ld.close()
+    few = ee.ScpBatchLoader(entries, threads=2, max_open=2)             # 3 files > 2 descriptors: per-entry path
+    try:
+        assert few.index_all() is False and list(few.lengths()) == [m.shape[0] for m in want]
+    finally:
+        few.close()
+    size = os.path.getsize(tmp_path / "t0.ark")
+    at_end = ee.ScpBatchLoader(entries + [("bad", "%s:%d" % (tmp_path / "t0.ark", size - 3))], threads=2)
+    try:
+        assert at_end.index_all() is False                                 # (the per-entry path reports which entry it is)
+    finally:
+        at_end.close()
+
+
 def test_scp_batch_loader_fills_the_callers_buffers(tmp_path):
     """The sharded path hands the loader the page-locked input buffers of the device pipeline (libs.amd.pipeline.DeviceSets): batches
     land in them alternately, `before_fill(turn)` is called before a buffer is overwritten, and a batch that does not fit gets an

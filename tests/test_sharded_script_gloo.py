@@ -39,7 +39,7 @@ def _fake_embedding(mat):
     return v
 
 
-def _worker(rank, world, port, scp, out_ark, use_table):
+def _worker(rank, world, port, scp, out_ark, use_table, segment=None):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -54,7 +54,7 @@ def _worker(rank, world, port, scp, out_ark, use_table):
             lengths = np.array([m.matrix_rows(rx) for _, rx in entries])
         extract = lambda mats: torch.from_numpy(np.stack([_fake_embedding(x) for x in mats]))
         w = open(out_ark, "wb") if rank == 0 else None
-        n = m.extract_sharded_scp(extract, entries, lengths, w, batch_frames=900, batch_utts=5)
+        n = m.extract_sharded_scp(extract, entries, lengths, w, batch_frames=900, batch_utts=5, segment_utts=segment)
         if w is not None:
             w.close()
         assert n == len(entries)
@@ -83,6 +83,32 @@ def test_sharded_script_writes_all_vectors_in_scp_order(tmp_path, use_table):
                 kaldi_io.write_mat(f, mats[key])
     out = str(tmp_path / "xvector.ark")
     mp.spawn(_worker, args=(2, _free_port(), scp, out, use_table), nprocs=2, join=True)
+    got = list(kaldi_io.read_vec_flt_ark(out))
+    assert [k for k, _ in got] == ["utt%02d" % i for i in range(len(lens))]
+    for k, v in got:
+        assert np.array_equal(v, _fake_embedding(mats[k])), k
+
+
+@pytest.mark.parametrize("world,segment", [(2, 3), (1, 4), (3, 1), (2, 0)])
+def test_sharded_script_in_segments_writes_the_same_ark(tmp_path, world, segment):
+    """Round 5: the sharded path gathers and writes in segments of `segment` utterances per rank (the writer thread of rank 0 works
+    on segment s while segment s + 1 is extracted); whatever the segment size - 1 per rank, a size that leaves a ragged last segment,
+    0 = one gather at the end - the ark holds every vector once, in scp order."""
+    import torch.multiprocessing as mp
+    from libs.support import kaldi_io
+    from libs.amd import synth
+    lens = np.random.RandomState(11).randint(10, 300, size=29)
+    ark, scp = str(tmp_path / "feats.ark"), str(tmp_path / "feats.scp")
+    mats = {}
+    with open(ark, "wb") as f, open(scp, "w") as s:
+        for i, n in enumerate(lens):
+            key = "utt%02d" % i
+            mats[key] = synth.synth_feats(int(n), 8, 900 + i)
+            f.write((key + " ").encode())
+            s.write("%s %s:%d\n" % (key, ark, f.tell()))
+            kaldi_io.write_mat(f, mats[key])
+    out = str(tmp_path / "xvector.ark")
+    mp.spawn(_worker, args=(world, _free_port(), scp, out, False, segment), nprocs=world, join=True)
     got = list(kaldi_io.read_vec_flt_ark(out))
     assert [k for k, _ in got] == ["utt%02d" % i for i in range(len(lens))]
     for k, v in got:
