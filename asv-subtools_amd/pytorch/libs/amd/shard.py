@@ -41,7 +41,25 @@ def plan_batches(lengths, indices, max_frames=65536, max_utts=1024, row_pad=0):
     """Groups a shard's utterances (already length-sorted) into batches bounded by total frames
     and count; neighbours have similar length, so the packed ragged batch wastes no padding.
     row_pad: rows the device layout adds per utterance (its 4 gap rows): frames + row_pad * (utterances + 1) <= max_frames as well,
-    so that a batch fills whole tiles of the device's row count (see pipeline/onestep/extract_embeddings.py extract_stream)."""
+    so that a batch fills whole tiles of the device's row count (see pipeline/onestep/extract_embeddings.py extract_stream).
+    One searchsorted per BATCH on the running sum of (frames + row_pad) - the per-utterance Python loop this replaces was 20 ms per
+    50 000 utterances in front of the first read (same batches: tests/test_shard_gloo.py compares the two)."""
+    idx = np.asarray(indices, dtype=np.int64)
+    if idx.size == 0:
+        return []
+    run = np.concatenate([[0], np.cumsum(np.asarray(lengths, dtype=np.int64)[idx] + row_pad)])      # run[j] = frames + pads of the first j utterances
+    batches, i, n = [], 0, int(idx.size)
+    while i < n:
+        # the largest m >= 1 with frames(i .. i + m) + row_pad * (m + 1) <= max_frames and m <= max_utts (an over-long utterance still gets a batch)
+        m = int(np.searchsorted(run, run[i] + max_frames - row_pad, side="right")) - 1 - i
+        m = max(1, min(m, max_utts, n - i))
+        batches.append(idx[i:i + m].tolist())
+        i += m
+    return batches
+
+
+def _plan_batches_loop(lengths, indices, max_frames=65536, max_utts=1024, row_pad=0):
+    """The per-utterance statement of plan_batches' rule (what the tests hold the vectorised form against)."""
     batches, cur, frames = [], [], 0
     for i in indices:
         n = int(lengths[i])
@@ -93,9 +111,9 @@ def _agree_or_raise(err, embed_dim, device, group, rank, world):
         dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
     failed, width = (int(v) for v in flag.cpu().tolist())
     if err is not None:
-        raise err
+        raise _Agreed(err)
     if failed:
-        raise RuntimeError("sharded extraction: another rank failed (this is rank %d of %d); see its log" % (rank, world))
+        raise _Agreed(RuntimeError("sharded extraction: another rank failed (this is rank %d of %d); see its log" % (rank, world)))
     return width
 
 
@@ -107,14 +125,20 @@ def extract_sharded_segments(extract_batch, lengths, load_utt, on_segment, segme
         on_segment(a, b, emb)                                          emb = [b - a, E] embeddings of utterances a .. b - 1 in their order,
                                                                        called on EVERY rank as soon as the segment has been gathered
     Utterances [a, b) of a segment (`segment_utts` per rank; None = everything in one segment) are balanced by length over the ranks
-    and batched like the whole list used to be; the reader runs one batch ahead ACROSS segment ends; at a segment's end the rank's
-    pipeline is flushed, the ranks agree that nobody failed (one tiny all-reduce) and all-gather the segment.  What this buys: rank 0
-    can copy out and write segment s while segment s + 1 is being extracted - with one gather at the very end the 102 MB of 50 000
-    x-vectors (device -> host, ark packing, write) were a serial tail of 0.14 s behind a 0.2 s extraction loop
+    and batched like the whole list used to be.  ONE pipeline runs through all segments: the reader stays one batch ahead across
+    segment ends, and a segment is gathered when its results are final, not when its last batch has been submitted - a pipelined
+    extract_batch says how many later submissions that takes (`extract_batch.depth`: libs.amd.pipeline.DeviceSets finishes a buffer
+    set's batch before it reuses the set; absent = results are final on return), so nothing is flushed before the very end and the
+    device never drains at a segment end.  Per segment the ranks agree that nobody failed (one tiny all-reduce) and all-gather it.
+    What this buys: rank 0 can copy out and write segment s while later segments are extracted - with one gather at the very end
+    the 102 MB of 50 000 x-vectors (device -> host, ark packing, write) were a serial tail of 0.14 s behind a 0.2 s extraction loop
     (profiles/r5z_bench.json: --sharded 150 k utterances/s against 251 k through the stream path).  The payload per collective stays
-    latency-sized (8192 x 512 x 4 B = 16 MB), their number small (50 000 utterances on one rank: 7).
-    A rank with nothing in a segment contributes zero rows; a rank whose read / extraction raises makes EVERY rank raise at that
-    segment's agreement (no rank is left waiting in a collective).  Returns the number of utterances."""
+    latency-sized (4096 x 512 x 4 B = 8 MB), their number small.  Segments are planned one ahead of their first batch (the plan of
+    50 000 utterances in one go stood in front of the first read).
+    A rank with nothing in a segment contributes zero rows; a rank whose read / extraction raises makes EVERY rank raise at the next
+    agreement (no rank is left waiting in a collective; all ranks run the same sequence of collectives).  Returns the number of
+    utterances."""
+    import collections
     import torch
     import torch.distributed as dist
     inited = dist.is_available() and dist.is_initialized()
@@ -122,46 +146,83 @@ def extract_sharded_segments(extract_batch, lengths, load_utt, on_segment, segme
     world = dist.get_world_size(group) if inited else 1
     lengths = np.asarray(lengths, dtype=np.int64)
     n = int(lengths.shape[0])
-    step = n if not segment_utts else max(1, int(segment_utts)) * world
-    plan = []                                             # per segment: (a, b, shards relative to a, this rank's batches in global indices)
-    for a in range(0, max(n, 1), max(step, 1)):
-        b = min(n, a + step)
+    step = max(n, 1) if not segment_utts else max(1, int(segment_utts)) * world
+    bounds = [(a, min(n, a + step)) for a in range(0, max(n, 1), step)]
+
+    def plan(s):
+        a, b = bounds[s]
         shards = balance_by_length(lengths[a:b], world)
-        plan.append((a, b, shards, plan_batches(lengths, (shards[rank] + a).tolist(), max_frames, max_utts, row_pad)))
-    flat = [batch for _, _, _, batches in plan for batch in batches]
+        return a, b, shards, plan_batches(lengths, shards[rank] + a, max_frames, max_utts, row_pad)
+
     from concurrent.futures import ThreadPoolExecutor
     whole = getattr(load_utt, "load_batch", None)
     fetch = (lambda batch: whole(batch)) if whole is not None else (lambda batch: [load_utt(i) for i in batch])
     flush = getattr(extract_batch, "flush", None)          # a pipelined extract_batch returns tensors whose work is still in flight
+    depth = int(getattr(extract_batch, "depth", 0)) if flush is not None else 0
     pool = ThreadPoolExecutor(1)
-    err, k = None, 0
+    done = collections.deque()                              # submitted segments not gathered yet: (a, b, shards, outs, index of the last submission)
+    err, submitted = None, 0
+
+    def gather(entry):
+        a, b, shards, outs, _ = entry
+        local = torch.cat(outs, dim=0) if (outs and err is None) else None
+        width = _agree_or_raise(err, local.shape[1] if local is not None else 0, device, group, rank, world)
+        if local is None:
+            if width == 0:
+                raise ValueError("sharded extraction: no utterances at all")
+            local = torch.zeros((0, width), dtype=torch.float32)
+        if device is not None:
+            local = local.to(device)
+        on_segment(a, b, gather_embeddings(local, shards[rank], shards, group=group))
+
     try:
-        ahead = pool.submit(fetch, flat[0]) if flat else None
-        for a, b, shards, batches in plan:
-            outs = []
-            if err is None:
-                try:
-                    for _ in batches:
-                        mats = ahead.result()
-                        k += 1
-                        ahead = pool.submit(fetch, flat[k]) if k < len(flat) else None
-                        outs.append(extract_batch(mats))
-                    if flush is not None:                   # finished (and range-checked) before the results are read
+        try:
+            nxt = plan(0)
+            queue = collections.deque(nxt[3])                # batches planned but not handed to the reader yet
+            ahead = pool.submit(fetch, queue.popleft()) if queue else None
+            for s in range(len(bounds)):
+                a, b, shards, batches = nxt
+                nxt = plan(s + 1) if s + 1 < len(bounds) else None
+                if nxt is not None:
+                    queue.extend(nxt[3])
+                    if ahead is None and queue:
+                        ahead = pool.submit(fetch, queue.popleft())
+                outs = []
+                for _ in batches:
+                    mats = ahead.result()
+                    ahead = pool.submit(fetch, queue.popleft()) if queue else None
+                    outs.append(extract_batch(mats))
+                    submitted += 1
+                    while done and done[0][4] + depth <= submitted:     # (its last batch has been finished by the pipeline itself)
+                        gather(done.popleft())
+                done.append((a, b, shards, outs, submitted))
+                if depth == 0:
+                    if flush is not None:
                         flush()
-                except Exception as e:                      # reported to every rank below, then re-raised here
-                    err = e
-            local = torch.cat(outs, dim=0) if (outs and err is None) else None
-            width = _agree_or_raise(err, local.shape[1] if local is not None else 0, device, group, rank, world)
-            if local is None:
-                if width == 0:
-                    raise ValueError("sharded extraction: no utterances at all")
-                local = torch.zeros((0, width), dtype=torch.float32)
-            if device is not None:
-                local = local.to(device)
-            on_segment(a, b, gather_embeddings(local, shards[rank], shards, group=group))
+                    gather(done.popleft())
+            if flush is not None:                           # finished (and range-checked) before the last results are read
+                flush()
+        except Exception as e:                              # reported to every rank at the next agreement, then re-raised here
+            if err is None and not isinstance(e, _Agreed):
+                err = e
+            else:
+                raise
+        while done:
+            gather(done.popleft())
+        if err is not None:                                 # (failed with nothing left to agree on)
+            gather((0, 0, [np.zeros(0, dtype=np.int64)] * world, [], 0))
+    except _Agreed as e:
+        raise e.error
     finally:
         pool.shutdown(wait=True)
     return n
+
+
+class _Agreed(Exception):
+    """An error every rank has been told about (carried out of the pipeline loop as it is)."""
+    def __init__(self, error):
+        Exception.__init__(self, str(error))
+        self.error = error
 
 
 def extract_sharded(extract_batch, lengths, load_utt, max_frames=65536, max_utts=1024, group=None, device=None, row_pad=0):

@@ -571,14 +571,14 @@ class ScpGroupReader(object):
 
 def _shard_segment_utts():
     """Utterances per rank between two gathers of the sharded path (ASV_AMD_SHARD_SEGMENT; 0 = one gather at the very end)."""
-    return max(0, int(os.environ.get("ASV_AMD_SHARD_SEGMENT", "8192")))
+    return max(0, int(os.environ.get("ASV_AMD_SHARD_SEGMENT", "4096")))
 
 
 def extract_sharded_scp(extract_batch, entries, lengths, w, batch_frames, batch_utts, verbose=False, device=None, loader=None, row_pad=0,
                         segment_utts=None):
     """Sharded extraction of scp entries (one call per rank, torch.distributed initialised or not):
         extract_batch(list of [T, D] float32 matrices) -> [b, E] tensor
-    The scp is walked in segments of `segment_utts` utterances per rank (default: ASV_AMD_SHARD_SEGMENT = 8192): every rank extracts
+    The scp is walked in segments of `segment_utts` utterances per rank (default: ASV_AMD_SHARD_SEGMENT = 4096): every rank extracts
     its length-balanced share of a segment, one all-gather per segment, and rank 0 writes the segment's ark entries to `w` - in scp
     order - on a writer thread while the next segment is being extracted (libs.amd.shard.extract_sharded_segments).
     Returns the number of embeddings (on every rank)."""
@@ -659,7 +659,8 @@ def run_sharded(args, model, max_chunk, verbose):
         sets.finish(0)
         return sets.submit(0, offs, np.concatenate(mats, axis=0))
 
-    extract_batch.flush = sets.flush                       # extract_sharded calls it before it reads the results
+    extract_batch.flush = sets.flush                       # extract_sharded_segments calls it before it reads the last results ...
+    extract_batch.depth = sets.n_sets                      # ... and reads a segment's results once this many later batches were submitted
     rank = dist.get_rank() if dist.is_initialized() else 0
     w = kaldi_io.open_or_fd(args.vectors_wspecifier, "wb") if rank == 0 else None
     try:

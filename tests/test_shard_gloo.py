@@ -30,6 +30,68 @@ def test_plan_batches_respects_limits():
     assert shard.plan_batches(lengths, [0], max_frames=10, max_utts=1) == [[0]]     # an over-long utterance still gets a batch
 
 
+def test_plan_batches_vectorised_form_equals_the_per_utterance_rule():
+    """Round 5: plan_batches is one searchsorted per batch; the per-utterance statement of its rule stays as _plan_batches_loop."""
+    rs = np.random.RandomState(0)
+    for trial in range(200):
+        n = int(rs.randint(1, 200))
+        lengths = rs.randint(1, 400, size=n)
+        if trial % 5 == 0:
+            lengths[:] = 200
+        idx = rs.permutation(n) if trial % 7 == 0 else np.argsort(-lengths, kind="stable")
+        mf, mu, rp = int(rs.choice([10, 300, 900, 2000, 65536])), int(rs.choice([1, 3, 5, 1024])), int(rs.choice([0, 4]))
+        assert shard.plan_batches(lengths, idx, mf, mu, rp) == shard._plan_batches_loop(lengths, idx, mf, mu, rp), (trial, mf, mu, rp)
+    assert shard.plan_batches([], [], 100, 4) == []
+
+
+class _LatePipeline(object):
+    """Stand-in for libs.amd.pipeline.DeviceSets behind extract_batch: the tensor a call returns is filled in only when `depth`
+    later calls have been made (or on flush) - reading it earlier yields NaN."""
+
+    def __init__(self, depth):
+        self.depth, self.pending, self.calls, self.flushes = depth, [], 0, 0
+
+    def __call__(self, mats):
+        import torch
+        out = torch.full((len(mats), 16), float("nan"))
+        self.pending.append((self.calls, out, np.stack([_fake_embedding(m) for m in mats])))
+        self.calls += 1
+        while self.pending and self.pending[0][0] + self.depth <= self.calls:
+            _, t, v = self.pending.pop(0)
+            t.copy_(torch.from_numpy(v))
+        return out
+
+    def flush(self):
+        import torch
+        self.flushes += 1
+        for _, t, v in self.pending:
+            t.copy_(torch.from_numpy(v))
+        self.pending = []
+
+
+@pytest.mark.parametrize("depth,segment", [(3, 4), (3, 1), (1, 7), (2, None), (5, 3)])
+def test_segments_are_gathered_only_when_their_results_are_final(depth, segment):
+    """extract_sharded_segments runs ONE pipeline through all segments: a segment is gathered once `extract_batch.depth` later batches
+    have been submitted (or after the final flush), never by flushing at a segment's end - and never before its tensors are final."""
+    from libs.amd import synth
+    lengths = np.random.RandomState(8).randint(20, 300, size=41)
+    load = lambda i: synth.synth_feats(int(lengths[i]), 8, 100 + i)
+    pipe = _LatePipeline(depth)
+    got = {}
+
+    def on_segment(a, b, emb):
+        assert not np.isnan(emb.numpy()).any(), "segment [%d, %d) was read before its results were final" % (a, b)
+        got[(a, b)] = emb.numpy().copy()
+    n = shard.extract_sharded_segments(pipe, lengths, load, on_segment, segment, max_frames=700, max_utts=4)
+    assert n == len(lengths) and pipe.flushes == 1
+    want = np.stack([_fake_embedding(load(i)) for i in range(len(lengths))])
+    spans = sorted(got)
+    assert spans[0][0] == 0 and spans[-1][1] == len(lengths) and all(spans[k][1] == spans[k + 1][0] for k in range(len(spans) - 1))
+    if segment:
+        assert all(b - a <= segment for a, b in spans)
+    assert np.array_equal(np.concatenate([got[k] for k in spans]), want)
+
+
 def _fake_embedding(mat, dim=16):
     # deterministic, length- and content-dependent stand-in for the extractor
     v = np.zeros(dim, dtype=np.float32)
@@ -126,3 +188,40 @@ def test_a_failing_rank_makes_every_rank_raise_before_the_gather(tmp_path):
     mp.spawn(_worker_edge, args=(2, _free_port(), lengths, str(tmp_path), 1), nprocs=2, join=True)
     e0, e1 = (tmp_path / "rank0.err").read_text(), (tmp_path / "rank1.err").read_text()
     assert e1.startswith("OSError: rank 1 cannot read") and "another rank failed" in e0, (e0, e1)
+
+
+def _worker_late_failure(rank, world, port, lengths, out_dir):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from libs.amd import synth
+
+        def load(i):
+            if rank == 1 and i >= 12:
+                raise IOError("rank 1 cannot read utterance %d" % i)
+            return synth.synth_feats(int(lengths[i]), 8, 100 + i)
+        pipe = _LatePipeline(3)
+        seen = []
+        try:
+            shard.extract_sharded_segments(pipe, lengths, load, lambda a, b, emb: seen.append((a, b)), 3, max_frames=600, max_utts=2)
+            seen.append("finished")
+        except Exception as e:
+            seen.append("%s: %s" % (type(e).__name__, e))
+        with open(os.path.join(out_dir, "rank%d.txt" % rank), "w") as f:
+            f.write(repr(seen))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_rank_failing_in_a_later_segment_stops_every_rank_at_the_same_agreement(tmp_path):
+    """The failure reaches both ranks at ONE agreement (the same segments delivered on both before it - none behind the failing
+    utterances; segments still waiting for their results when the read failed are given up, not flushed), nobody hangs."""
+    import torch.multiprocessing as mp
+    lengths = np.random.RandomState(6).randint(20, 100, size=30)
+    mp.spawn(_worker_late_failure, args=(2, _free_port(), lengths, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = eval((tmp_path / "rank0.txt").read_text()), eval((tmp_path / "rank1.txt").read_text())
+    assert r1[-1].startswith("OSError: rank 1 cannot read") and "another rank failed" in r0[-1], (r0, r1)
+    assert r0[:-1] == r1[:-1] and all(b <= 12 for a, b in r0[:-1]), (r0, r1)
