@@ -102,7 +102,6 @@ struct TdnnKernelParams {
   const void *wconv;    // 3x3 grid convolutions (kernels_conv2d.hip): bf16 weights in THAT kernel family's fragment order [tap][k-group][n-frag][lane][8]
                         // - its own pointer, so that neither family can ever be handed the other's layout - or nullptr
   const void *wlo;      // pooled-domain layers and the f32x frame kernel: the bf16 'lo' halves (w - hi), same layout as wfrag, or nullptr
-  const void *wtail;    // 8-phase kernel, cin = 64 q + 16 | 32 with taps: the remainder's weights packed [cout_pad][K-tile][64] (4 / 2 taps per K-tile), or nullptr
   const void *wx3p;     // f32x 8-phase kernel (kernels_tdnn_p8x.hip): [cout_pad][tap][chunk32][hi 32 | lo 32] 16-bit halves of w * 2^s, or nullptr
   // split-K (small-M layers: the pooled domain): blockIdx.y walks `ksplit` slices of the channel
   // chunks, raw f32 accumulators go to partial[slice][rows][ld_partial]; a second kernel sums
@@ -182,8 +181,6 @@ int launch_tdnn_big3(const TdnnKernelParams &p, hipStream_t s);
 int launch_tdnn_big3_variant(const TdnnKernelParams &p, int variant, hipStream_t s);
 // 256 x 256 tiles, both operands through LDS-DMA, four phases per K-tile with counted waits (kernels_tdnn_p8.hip); weights in p.w
 bool tdnn_p8_supported(const TdnnKernelParams &p, int et, bool out_f32);
-size_t tdnn_p8_tail_elems(int cout_pad, int cin_pad, int n_taps);        // 0: no packed remainder for this shape
-void pack_tdnn_p8_tail(const uint16_t *w_plain, int cout_pad, int cin_pad, int n_taps, uint16_t *dst);   // from the plain [cout_pad][tap][cin_pad] 16-bit weights
 int launch_tdnn_p8(const TdnnKernelParams &p, hipStream_t s);
 int launch_tdnn_p8_variant(const TdnnKernelParams &p, int variant, hipStream_t s);
 // the same structure for the f32x mode: f32 rows split in registers, three matrix instructions per product (kernels_tdnn_p8x.hip); weights in p.wx3p

@@ -495,15 +495,8 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_p8_kernel(const TdnnKernelPa
 constexpr int P8P_PAR_SLOT = 4096;                  // bias | scale | shift (3 x 1 KiB) | row-validity words (1 KiB piece, 32 B used)
 constexpr int P8P_LDS_BYTES = 2 * P8_BUF + 2 * P8P_PAR_SLOT;
 
-// TAILK (round 5, third step): layers whose channel count is 64 q + 16 or + 32 (the first layer: 80 features x 5 taps).  The whole chunks
-// run as above; the remaining 16 / 32 channels of ALL taps are packed into K-tiles of their own - 4 / 2 taps per K-tile (a 16-byte slot
-// = 8 channels of one tap: a lane of the DMA picks its tap's row offset by its slot, ds_bpermute on the tap table), the weights of those
-// K-tiles pre-packed on the host in the same slot order (p.wtail, zeros behind the last tap) - instead of one K-tile per tap that is 3/4 or
-// 1/2 zeros: 80 x 5 taps = 7 K-tiles instead of 10.  The k-groups reach every accumulator in the order of the variant-3 kernel's
-// short-tail form (whole chunks: chunk, tap, group; then tap, group of the remainder): the same bits.
-template <int ET, bool ONE_TAP, bool TAILK = false>
+template <int ET, bool ONE_TAP>
 __global__ __launch_bounds__(512, 2) void tdnn_gemm_p8p_kernel(const TdnnKernelParams p, int m_tiles, int n_tiles) {
-  static_assert(!(ONE_TAP && TAILK), "the packed remainder exists for layers with taps");
   __shared__ __attribute__((aligned(16))) unsigned char lds[P8P_LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -519,17 +512,12 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_p8p_kernel(const TdnnKernelP
   const int n_taps = ONE_TAP ? 1 : p.n_taps;
   const uint32_t w_pitch = (uint32_t)n_taps * (uint32_t)cin_pad * 2u;
   const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(p8_lds_byte *)lds);
-  const int full = cin_pad / 64;                                             // whole 64-channel chunks
-  const int rs_log = TAILK ? ((cin_pad % 64) == 32 ? 2 : 1) : 0;             // log2(16-byte slots of the remainder per tap): 16 channels = 2, 32 = 4
-  const int n_tail = TAILK ? ((n_taps << rs_log) + 7) / 8 : 0;               // K-tiles of the packed remainder
-  const int nkt = full * n_taps + n_tail;
-  const unsigned char *wtail = reinterpret_cast<const unsigned char *>(p.wtail);
-  const uint32_t wt_pitch = (uint32_t)n_tail * 128u;
+  const int nkt = (cin_pad / 64) * n_taps;
   const int last_row = p.rows - 1;
   const int g_row = lane >> 3, g_slot = lane & 7;
 
   // per-tile, per-lane DMA source offsets (see the one-tile kernel)
-  struct TileAddr { int m0, n0; int a_row[2]; uint32_t a_slot[2], a_voff[2][2], b_off[2], bt_off[2]; };
+  struct TileAddr { int m0, n0; int a_row[2]; uint32_t a_slot[2], a_voff[2][2], b_off[2]; };
   auto tile_addr = [&](int it) {
     TileAddr t;
     const int tile = xcd_swizzle(it, total);
@@ -544,7 +532,6 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_p8p_kernel(const TdnnKernelP
       t.a_voff[0][i] = (uint32_t)t.a_row[i] * x_pitch + slot16;
       t.a_voff[1][i] = (uint32_t)min(t.a_row[i] + 64, last_row) * x_pitch + slot16;
       t.b_off[i] = (uint32_t)(t.n0 + (r >> 5) * 64 + (r & 31)) * w_pitch + slot16;
-      t.bt_off[i] = TAILK ? (uint32_t)(t.n0 + (r >> 5) * 64 + (r & 31)) * wt_pitch + slot16 : 0u;
     }
     return t;
   };
@@ -553,30 +540,8 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_p8p_kernel(const TdnnKernelP
 #pragma unroll
     for (int t = 1; t < ASV_MAX_TAPS; ++t) v_taps = (lane == t) ? p.taps[t] : v_taps;
   }
-  // K-tile (c, t): c < full: chunk c at tap t; c == full (TAILK): K-tile t of the packed remainder
   auto stage = [&](const TileAddr &T, int which, int c, int t, int b) {
     const uint32_t dst0 = lds_base + (uint32_t)b * P8_BUF + (uint32_t)which * P8_HALF + (uint32_t)wave * 2048u;
-    if (TAILK && c == full) {
-      if (which & 1) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          // this lane's 16 bytes are logical slot L of the K-tile = slot (q mod rs) of the remainder at tap q >> rs_log, q = 8 t + L;
-          // behind the last tap: any finite bytes (the row's first slot at tap 0) - their weights are zeros
-          const int q = t * 8 + (int)(T.a_slot[i] >> 4);
-          const int tap = q >> rs_log;
-          const bool pad = tap >= n_taps;
-          const int d = __builtin_amdgcn_ds_bpermute((pad ? 0 : tap) << 2, v_taps) + (which == 3 ? 64 : 0);
-          const uint32_t cs = pad ? 0u : (uint32_t)(full * 8 + (q & ((1 << rs_log) - 1))) * 16u;
-          const int row = min(max(T.a_row[i] + d, 0), last_row);
-          p8_glds(xg, (uint32_t)row * x_pitch + cs, __builtin_amdgcn_readfirstlane(dst0 + i * 1024u));
-        }
-      } else {
-        const unsigned char *base = wtail + (size_t)t * 128 + (which == 2 ? (size_t)32 * wt_pitch : 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) p8_glds(base, T.bt_off[i], __builtin_amdgcn_readfirstlane(dst0 + i * 1024u));
-      }
-      return;
-    }
     if (which & 1) {
       const unsigned char *base = xg + (size_t)c * 128;
       if (ONE_TAP) {
@@ -627,10 +592,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_p8p_kernel(const TdnnKernelP
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
-  auto kt_ct = [&](int kt, int &c, int &t) {
-    if (TAILK && kt >= full * n_taps) { c = full; t = kt - full * n_taps; }
-    else { c = kt / n_taps; t = kt - c * n_taps; }
-  };
+  auto kt_ct = [&](int kt, int &c, int &t) { c = kt / n_taps; t = kt - c * n_taps; };
   auto swz = [](int row, int slot) { return slot ^ ((row >> 1) & 7); };
   const float act_lo = (p.act1 == ASV_ACT_RELU) ? 0.0f : -INFINITY;
   unsigned char *yg = reinterpret_cast<unsigned char *>(p.y);
@@ -668,7 +630,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_p8p_kernel(const TdnnKernelP
         for (int i2 = 0; i2 < 2; ++i2) acc[i0 + i2][j] = mfma16<ET>(wfr[kg], xa[i2][kg], acc[i0 + i2][j]);
     };
     int c1 = 0, t1 = 0, c2 = 0, t2 = 0;
-    auto adv = [&](int &c, int &t) { ++t; if ((!TAILK || c < full) && t == n_taps) { t = 0; ++c; } };      // (the K-tiles of the packed remainder: c stays = full)
+    auto adv = [&](int &c, int &t) { if (++t == n_taps) { t = 0; ++c; } };
     adv(c1, t1); adv(c2, t2); adv(c2, t2);
     auto ktile2 = [&](int kt, auto tail_c) {
       constexpr int TAIL = decltype(tail_c)::value;
@@ -731,9 +693,6 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_p8p_kernel(const TdnnKernelP
     }
     // ---- epilogue of `cur` (kernels_tdnn_v3.hip's), two passes of 64 rows per wave through buffer 1
     {
-      // (lane-derived values re-materialised per tile: visible as loop invariants, hipcc keeps the epilogue's addresses live across the K loop)
-      int lr_e = lr, lh_e = lh, lane_e = lane;
-      asm volatile("" : "+v"(lr_e), "+v"(lh_e), "+v"(lane_e));
       const float *par = reinterpret_cast<const float *>(lds + 2 * P8_BUF + slot * P8P_PAR_SLOT);
       const uint32_t *vw = reinterpret_cast<const uint32_t *>(lds + 2 * P8_BUF + slot * P8P_PAR_SLOT + 3072);
       unsigned char *scr = lds + P8_BUF + wave * (64 * P8_ROWB);        // [64 frames][64 channels] 16-bit, 128-B rows, swizzled slots
@@ -741,12 +700,12 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_p8p_kernel(const TdnnKernelP
       for (int h = 0; h < 2; ++h) {
         uint32_t vmask = 0;
 #pragma unroll
-        for (int i2 = 0; i2 < 2; ++i2) vmask |= ((vw[wm * 4 + h * 2 + i2] >> lr_e) & 1u) << i2;
+        for (int i2 = 0; i2 < 2; ++i2) vmask |= ((vw[wm * 4 + h * 2 + i2] >> lr) & 1u) << i2;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const int chl = wn * 64 + j * 32 + 8 * q + 4 * lh_e;
+            const int chl = wn * 64 + j * 32 + 8 * q + 4 * lh;
             const float4 b4 = *reinterpret_cast<const float4 *>(par + chl);
             const float4 sc4 = *reinterpret_cast<const float4 *>(par + 256 + chl);
             const float4 sh4 = *reinterpret_cast<const float4 *>(par + 512 + chl);
@@ -755,7 +714,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_p8p_kernel(const TdnnKernelP
 #pragma unroll
             for (int i2 = 0; i2 < 2; ++i2) {
               const bool valid = (vmask >> i2) & 1u;
-              const int frow = i2 * 32 + lr_e;
+              const int frow = i2 * 32 + lr;
               float y[4];
 #pragma unroll
               for (int e = 0; e < 4; ++e) y[e] = tdnn_epilogue_fast(acc[h * 2 + i2][j][q * 4 + e], b[e], act_lo, sc[e], sh[e], true);
@@ -764,13 +723,13 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_p8p_kernel(const TdnnKernelP
               pk.y = pack_h16x2<ET>(y[2], y[3]);
               pk.x = valid ? pk.x : 0u;
               pk.y = valid ? pk.y : 0u;
-              *reinterpret_cast<uint2 *>(scr + frow * P8_ROWB + swz(frow, sl) * 16 + ((lh_e ^ (frow & 1)) * 8)) = pk;
+              *reinterpret_cast<uint2 *>(scr + frow * P8_ROWB + swz(frow, sl) * 16 + ((lh ^ (frow & 1)) * 8)) = pk;
             }
           }
         }
 #pragma unroll
         for (int s8 = 0; s8 < 8; ++s8) {
-          const int piece = s8 * 64 + lane_e, frow = piece >> 3, sl = piece & 7;
+          const int piece = s8 * 64 + lane, frow = piece >> 3, sl = piece & 7;
           uint4 v = *reinterpret_cast<const uint4 *>(scr + frow * P8_ROWB + swz(frow, sl) * 16);
           if (frow & 1) v = make_uint4(v.z, v.w, v.x, v.y);
           const int ch = cur.n0 + wn * 64 + sl * 8;
@@ -794,24 +753,18 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_p8p_kernel(const TdnnKernelP
 
 }  // namespace
 
-// Layers the 8-phase kernel takes: 16-bit rows, the plain epilogue (affine -> [ReLU] -> folded BN), whole 64-channel chunks - or whole
-// chunks + 16 / 32 channels with taps and the remainder's weights packed (p.wtail: the persistent form only).
-static bool p8_tail_form(const TdnnKernelParams &p) {
-  const int rem = p.cin_pad % 64;
-  return (rem == 16 || rem == 32) && p.wtail != nullptr && p.n_taps >= 2 && p.ldx % 8 == 0;
-}
+// Layers the 8-phase kernel takes: 16-bit rows, the plain epilogue (affine -> [ReLU] -> folded BN), whole 64-channel chunks.
 bool tdnn_p8_supported(const TdnnKernelParams &p, int et, bool out_f32) {
   const bool fits32 = (unsigned long long)p.rows * (unsigned long long)p.ldx * 2ull < (1ull << 32) &&
-                      (unsigned long long)round_up(p.cout_store, 256) * (unsigned long long)p.n_taps * (unsigned long long)round_up(p.cin_pad, 64) * 2ull < (1ull << 32);
+                      (unsigned long long)round_up(p.cout_store, 256) * (unsigned long long)p.n_taps * (unsigned long long)p.cin_pad * 2ull < (1ull << 32);
   const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first;
   return p.w != nullptr && et != ET_F32 && !out_f32 && fits32 && fast && p.x2 == nullptr && p.seg_bias == nullptr && p.seg_scale == nullptr && p.res == nullptr &&
-         p.pool_partial == nullptr && p.rows % 256 == 0 && p.rows >= 256 && (p.cin_pad % 64 == 0 || p8_tail_form(p)) && p.cin_pad >= 64 && p.cout_store % 8 == 0 &&
-         p.cout_store >= 192 && p.n_taps >= 1 && p.n_taps <= ASV_MAX_TAPS && p.row_valid != nullptr;
+         p.pool_partial == nullptr && p.rows % 256 == 0 && p.rows >= 256 && p.cin_pad % 64 == 0 && p.cin_pad >= 64 && p.cout_store % 8 == 0 && p.cout_store >= 192 &&
+         p.n_taps >= 1 && p.n_taps <= ASV_MAX_TAPS && p.row_valid != nullptr;
 }
 
 int launch_tdnn_p8_variant(const TdnnKernelParams &p, int variant, hipStream_t s) {
   ASV_REQUIRE(tdnn_p8_supported(p, p.et, false), "tdnn(p8): layer shape not supported (rows %d cin %d cout %d taps %d)", p.rows, p.cin_pad, p.cout_store, p.n_taps);
-  ASV_REQUIRE(p.cin_pad % 64 == 0 || variant == 0, "tdnn(p8): a channel remainder runs on the persistent form only");
   const int m_tiles = p.rows / 256, n_tiles = round_up(p.cout_store, 256) / 256;
   const dim3 grid(m_tiles * n_tiles), block(512);
   const bool f16 = p.et == ET_F16;
@@ -845,10 +798,7 @@ int launch_tdnn_p8_variant(const TdnnKernelParams &p, int variant, hipStream_t s
         cus = n > 0 ? n : 256;
       }
       const dim3 pgrid(std::min(m_tiles * n_tiles, cus));
-      if (p.cin_pad % 64 != 0) {
-        if (f16) hipLaunchKernelGGL((tdnn_gemm_p8p_kernel<ET_F16, false, true>), pgrid, block, 0, s, p, m_tiles, n_tiles);
-        else hipLaunchKernelGGL((tdnn_gemm_p8p_kernel<ET_BF16, false, true>), pgrid, block, 0, s, p, m_tiles, n_tiles);
-      } else if (one) { if (f16) hipLaunchKernelGGL((tdnn_gemm_p8p_kernel<ET_F16, true>), pgrid, block, 0, s, p, m_tiles, n_tiles);
+      if (one) { if (f16) hipLaunchKernelGGL((tdnn_gemm_p8p_kernel<ET_F16, true>), pgrid, block, 0, s, p, m_tiles, n_tiles);
                  else hipLaunchKernelGGL((tdnn_gemm_p8p_kernel<ET_BF16, true>), pgrid, block, 0, s, p, m_tiles, n_tiles); }
       else { if (f16) hipLaunchKernelGGL((tdnn_gemm_p8p_kernel<ET_F16, false>), pgrid, block, 0, s, p, m_tiles, n_tiles);
              else hipLaunchKernelGGL((tdnn_gemm_p8p_kernel<ET_BF16, false>), pgrid, block, 0, s, p, m_tiles, n_tiles); }

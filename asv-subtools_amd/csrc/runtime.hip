@@ -98,24 +98,6 @@ void pack_tdnn_weight_x3p(const float *w, int out_ch, int in_ch, int tot_ctx, in
     }
 }
 
-// The packed remainder of kernels_tdnn_p8.hip (TAILK): cin_pad = 64 q + 16 | 32.  K-tile j of the remainder = 8 slots of 8 channels; slot s holds
-// channels 64 q + 8 (g mod rs) .. + 8 of tap g / rs, g = 8 j + s, rs = slots of the remainder per tap (2 | 4); zeros behind the last tap.
-size_t tdnn_p8_tail_elems(int cout_pad, int cin_pad, int n_taps) {
-  const int rem = cin_pad % 64;
-  if ((rem != 16 && rem != 32) || n_taps < 2 || cin_pad < 64) return 0;
-  const int rs = rem / 8, n_tail = (n_taps * rs + 7) / 8;
-  return (size_t)cout_pad * n_tail * 64;
-}
-void pack_tdnn_p8_tail(const uint16_t *w_plain, int cout_pad, int cin_pad, int n_taps, uint16_t *dst) {
-  const int rem = cin_pad % 64, rs = rem / 8, n_tail = (n_taps * rs + 7) / 8, base = cin_pad - rem;
-  memset(dst, 0, tdnn_p8_tail_elems(cout_pad, cin_pad, n_taps) * 2);
-  for (int co = 0; co < cout_pad; ++co)
-    for (int g = 0; g < n_taps * rs; ++g) {
-      const int tap = g / rs, ch = base + (g % rs) * 8;
-      memcpy(dst + ((size_t)co * n_tail + g / 8) * 64 + (g % 8) * 8, w_plain + ((size_t)co * n_taps + tap) * cin_pad + ch, 16);
-    }
-}
-
 // Power of two that lifts the largest weight of a layer to [2^13, 2^14) (the half-precision split of the f32x mode): every
 // weight down to 2^-15 of the largest keeps a normal lo half; the products grow by the same factor, far inside f32.
 static float x3_weight_scale(const float *w, size_t n) {
@@ -162,7 +144,6 @@ struct Op {
   void *wfrag = nullptr;         // fragment-ordered copy for the variant-3 kernel (bf16 frame layers); pooled layers: bf16 hi halves
   void *wconv = nullptr;         // 3x3 trunk convolutions with 32 / 64 / 128 / 256 channels: fragment order of kernels_conv2d.hip
   void *wlo = nullptr;           // pooled layers in bf16 precision mode: bf16 lo halves (kernels_utts.hip)
-  void *wtail = nullptr;         // 16-bit modes, cin = 64 q + 16 | 32 with taps: the remainder's weights packed for kernels_tdnn_p8.hip
   void *wx3p = nullptr;          // f32x mode, wide frame layers with the plain epilogue: [hi | lo] rows for kernels_tdnn_p8x.hip
   float *bias = nullptr, *scale = nullptr, *shift = nullptr;
   int cin_pad = 0, cout_pad = 0, cout_store = 0;
@@ -542,11 +523,6 @@ int asv_net_add_tdnn(asv_net_t *net, const asv_tdnn_desc_t *d) {
     pack_tdnn_weight(d->weight, d->out_ch, d->in_ch, d->w_tot_context, d->w_left_context, d->taps, d->n_taps, op.cout_pad,
                      op.cin_pad, et, packed.data());
     if ((rc = dev_upload(net, packed.data(), packed.size(), &op.w))) return rc;
-    if (bf16 && !op.utts && net->domains[dom].kind == ASV_DOMAIN_FRAMES && op.cout_store >= 192 && tdnn_p8_tail_elems(op.cout_pad, op.cin_pad, d->n_taps) != 0) {
-      std::vector<uint16_t> tail(tdnn_p8_tail_elems(op.cout_pad, op.cin_pad, d->n_taps));
-      pack_tdnn_p8_tail(reinterpret_cast<const uint16_t *>(packed.data()), op.cout_pad, op.cin_pad, d->n_taps, tail.data());
-      if ((rc = dev_upload(net, tail.data(), tail.size() * 2, &op.wtail))) return rc;
-    }
     // the two fragment orders are mutually exclusive per layer: a 3x3 trunk convolution the conv2d kernels take never needs
     // the v3 order (grid_conv_* precede big3 in the dispatch and accept every such layer), and each family has its own pointer
     // (+ the 32 -> 64 stride-2 convolution in space-to-depth form: 4 x 32 input channels, 4 taps, 64 output channels)
@@ -1252,12 +1228,6 @@ int run_ops(RunCtx &c, size_t n_ops) {
         p.act1 = d.act1; p.act2 = d.act2; p.affine_first = d.affine_first;
         p.zero16 = net->zero_page;
         p.wfrag = op.wfrag; p.wlo = op.wlo; p.wconv = op.wconv; p.wx3p = op.wx3p;
-        {
-          // ASV_AMD_P8_TAIL=0: layers with a channel remainder (the first layer: 80 features x 5 taps) stay on the variant-3 kernel (A/B; same bits)
-          static const bool tail_env = getenv("ASV_AMD_P8_TAIL") == nullptr || atoi(getenv("ASV_AMD_P8_TAIL")) != 0;
-          const bool tail_on = getenv("ASV_AMD_LIVE_TUNE") != nullptr ? (getenv("ASV_AMD_P8_TAIL") == nullptr || atoi(getenv("ASV_AMD_P8_TAIL")) != 0) : tail_env;
-          p.wtail = tail_on ? op.wtail : nullptr;
-        }
         const bool chain_x3 = net->x3();             // f32x: the split-product chain on 64-row tiles (kernels_tdnn_chainx.hip)
         if (op.chain_last >= 0 && !use_ref && (bf16 || chain_x3) && p.halo <= kHalo && (net->flags & ASV_FLAG_SMALL_TILES) == 0 &&
             (chain_x3 || (unsigned long long)p.rows * (unsigned long long)p.ldx * 2ull < (1ull << 32))) {

@@ -569,9 +569,18 @@ class ScpGroupReader(object):
         return [self.entries[i][0] for i in idx], offs, used
 
 
-def _shard_segment_utts():
-    """Utterances per rank between two gathers of the sharded path (ASV_AMD_SHARD_SEGMENT; 0 = one gather at the very end)."""
-    return max(0, int(os.environ.get("ASV_AMD_SHARD_SEGMENT", "4096")))
+def _shard_segment_utts(lengths=None, batch_frames=0, batch_utts=0, row_pad=0):
+    """Utterances per rank between two gathers of the sharded path (ASV_AMD_SHARD_SEGMENT, default 4096; 0 = one gather at the very
+    end), rounded to whole batches of the mean utterance: a segment's last batch is a partial one, and on a device-bound run (f32x)
+    a 245-utterance batch costs what a 321-utterance batch costs - 13 segments of 4096 x 200-frame utterances were 169 batches
+    instead of 156 (profiles/r5x_ark_*.json: --sharded 195 k utterances/s in f32x against 250 k through the stream path, while the
+    host-bound bf16 run was already level)."""
+    want = max(0, int(os.environ.get("ASV_AMD_SHARD_SEGMENT", "4096")))
+    if want == 0 or lengths is None or len(lengths) == 0 or batch_frames <= 0:
+        return want
+    mean = float(np.mean(lengths))
+    per_batch = int(max(1, min(batch_utts if batch_utts > 0 else 1 << 30, (batch_frames - row_pad) // max(1.0, mean + row_pad))))
+    return max(per_batch, int(round(want / float(per_batch))) * per_batch)
 
 
 def extract_sharded_scp(extract_batch, entries, lengths, w, batch_frames, batch_utts, verbose=False, device=None, loader=None, row_pad=0,
@@ -612,7 +621,7 @@ def extract_sharded_scp(extract_batch, entries, lengths, w, batch_frames, batch_
         writer.start()
     try:
         n = shard.extract_sharded_segments(extract_batch, lengths, load, (lambda a, b, emb: todo.put((a, b, emb))) if rank == 0 else (lambda a, b, emb: None),
-                                           _shard_segment_utts() if segment_utts is None else segment_utts,
+                                           _shard_segment_utts(lengths, batch_frames, batch_utts, row_pad) if segment_utts is None else segment_utts,
                                            max_frames=batch_frames, max_utts=batch_utts, device=device, row_pad=row_pad)
     finally:
         if writer is not None:

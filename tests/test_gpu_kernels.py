@@ -308,13 +308,6 @@ P8_CASES = [
     (192, 512, [0], [130, 200]),                   # three K-tiles: an odd count (prologue + one closing pair + the last)
     (64, 256, [0], [300]),                         # ONE K-tile
     (320, 384, [-1, 0, 1], [40, 41, 300]),         # 5 chunks x 3 taps = 15
-    # a channel remainder of 16 / 32 behind the whole chunks, packed 4 / 2 taps per K-tile (TAILK; the variant-3 kernel's short-tail order)
-    (80, 512, [-2, -1, 0, 1, 2], [200, 3, 1, 57, 200, 131]),       # the first layer: 5 + 2 K-tiles, the last one with three empty tap slots
-    (96, 256, [-1, 0, 1], [300, 9, 8]),            # 1 chunk x 3 taps + 32 channels x 3 taps = 2 K-tiles (one tap slot empty)
-    (144, 320, [-4, 0, 4], [77, 256, 1, 255]),     # 2 chunks + 16: 6 + 1 K-tiles, taps at the halo's edge
-    (80, 200, [-3, -2, -1, 0, 1, 2, 3, 4], [5, 600]),             # 8 taps: 8 + 2 whole K-tiles of remainder
-    (160, 256, [0, 2], [130, 200]),                # 2 chunks + 32, two taps: exactly one K-tile of remainder
-    (80, 256, [-1, 1], [300]),                     # 2 + 1 = 3 K-tiles
 ]
 
 
@@ -403,8 +396,7 @@ def test_p8x_kernel_vs_oracle_and_x3(case, mode, act, monkeypatch):
 
 def test_p8_kernel_is_the_one_the_wide_layers_run_on(monkeypatch):
     """Production dispatch: from one round of 256 x 256 tiles (256 of them) a plain wide layer goes to the 8-phase kernel, smaller
-    batches and the layers it does not take (cin = 112: a channel remainder that is neither 16 nor 32) stay on the
-    variant-3 kernel."""
+    batches and the layers it does not take (cin = 80: no whole 64-channel chunks) stay on the variant-3 kernel."""
     from libs.amd import capi
     monkeypatch.setenv("ASV_AMD_LIVE_TUNE", "1")     # (the library reads ASV_AMD_P8 once per process otherwise: an earlier test's value would stick)
     monkeypatch.setenv("ASV_AMD_P8", "1")            # 1 = the production rule
@@ -422,6 +414,5 @@ def test_p8_kernel_is_the_one_the_wide_layers_run_on(monkeypatch):
 
     assert run(512, 512, [-2, 0, 2], [200] * 256) == (1, 0)          # configs[1]'s tdnn2: 408 tiles
     assert run(512, 512, [-2, 0, 2], [200] * 64) == (0, 1)           # 102 tiles: less than a round
-    assert run(80, 512, [-2, -1, 0, 1, 2], [200] * 256) == (1, 0)    # cin = 80: one chunk + a packed remainder of 16 channels x 5 taps
-    assert run(112, 512, [-2, -1, 0, 1, 2], [200] * 256) == (0, 1)   # cin = 112: a remainder of 48 channels - neither 16 nor 32
+    assert run(80, 512, [-2, -1, 0, 1, 2], [200] * 256) == (0, 1)    # cin = 80: no whole chunks
     assert run(192, 512, [0], [200] * 256) == (1, 0)                 # 3 K-tiles: an odd count is fine

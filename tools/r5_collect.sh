@@ -41,7 +41,7 @@ if [ "$do_pmc" = "pmc" ]; then
       rm -rf $out/${tag}_pmc_${model}_$c $out/${tag}_pmc_${model}_$c.log
     done
   done
-  for cfg in "xvector bf16" "xvector f32x" "ecapa bf16" "resnet f32x"; do
+  for cfg in "xvector bf16" "xvector f32x" "ecapa bf16" "ecapa f32x" "resnet f32x"; do
     set -- $cfg; model=$1; prec=$2
     timeout 300 rocprofv3 --pmc $sq --kernel-trace --output-format csv -d $out/${tag}_pmc_sq_${model}_$prec -- python $root/bench.py --model $model --precision $prec $short > /dev/null 2>&1
     cp $out/${tag}_pmc_sq_${model}_$prec/*/*counter_collection.csv $out/${tag}_sq_${model}_$prec.csv 2>/dev/null
