@@ -118,7 +118,7 @@ def _agree_or_raise(err, embed_dim, device, group, rank, world):
 
 
 def extract_sharded_segments(extract_batch, lengths, load_utt, on_segment, segment_utts=None, max_frames=65536, max_utts=1024, group=None,
-                             device=None, row_pad=0):
+                             device=None, row_pad=0, timing=None):
     """Sharded extraction in SEGMENTS of the utterance list, one collective pair per segment (round 5).
         extract_batch(list_of_mats) -> [b, E] tensor on `device`     (e.g. a libs.amd.pipeline.DeviceSets wrapper)
         load_utt(i) -> [T_i, D] float32 matrix of utterance i          (only called for this rank's share; `.load_batch(indices)` if it has one)
@@ -137,8 +137,10 @@ def extract_sharded_segments(extract_batch, lengths, load_utt, on_segment, segme
     50 000 utterances in one go stood in front of the first read).
     A rank with nothing in a segment contributes zero rows; a rank whose read / extraction raises makes EVERY rank raise at the next
     agreement (no rank is left waiting in a collective; all ranks run the same sequence of collectives).  Returns the number of
-    utterances."""
+    utterances.  timing: a dict that receives where the submitting thread's time went (seconds: plan, reader = waiting for the batch
+    being read, extract = inside extract_batch, join = waiting for the collector at the end) and the collector thread's own total."""
     import collections
+    import time
     import torch
     import torch.distributed as dist
     inited = dist.is_available() and dist.is_initialized()
@@ -149,10 +151,17 @@ def extract_sharded_segments(extract_batch, lengths, load_utt, on_segment, segme
     step = max(n, 1) if not segment_utts else max(1, int(segment_utts)) * world
     bounds = [(a, min(n, a + step)) for a in range(0, max(n, 1), step)]
 
+    spent = timing if timing is not None else {}
+    for key in ("plan", "reader", "extract", "join", "collector"):
+        spent.setdefault(key, 0.0)
+
     def plan(s):
+        t0 = time.perf_counter()
         a, b = bounds[s]
         shards = balance_by_length(lengths[a:b], world)
-        return a, b, shards, plan_batches(lengths, shards[rank] + a, max_frames, max_utts, row_pad)
+        out = a, b, shards, plan_batches(lengths, shards[rank] + a, max_frames, max_utts, row_pad)
+        spent["plan"] += time.perf_counter() - t0
+        return out
 
     from concurrent.futures import ThreadPoolExecutor
     import queue
@@ -190,10 +199,12 @@ def extract_sharded_segments(extract_batch, lengths, load_utt, on_segment, segme
             if item is None:
                 return
             if state["err"] is None:
+                t0 = time.perf_counter()
                 try:
                     gather(*item)
                 except BaseException as e:                  # (an agreed failure, or anything else: the submitting thread stops at its next batch)
                     state["err"] = e
+                spent["collector"] += time.perf_counter() - t0
 
     collector = threading.Thread(target=collect, name="asv-shard-collector", daemon=True)
     collector.start()
@@ -213,9 +224,13 @@ def extract_sharded_segments(extract_batch, lengths, load_utt, on_segment, segme
                 for _ in batches:
                     if state["err"] is not None:
                         raise _Stop()
+                    t0 = time.perf_counter()
                     mats = ahead.result()
                     ahead = pool.submit(fetch, pending.popleft()) if pending else None
+                    t1 = time.perf_counter()
                     outs.append(extract_batch(mats))
+                    spent["reader"] += t1 - t0
+                    spent["extract"] += time.perf_counter() - t1
                     submitted += 1
                     while done and done[0][4] + depth <= submitted:     # (its last batch has been finished by the pipeline itself)
                         todo.put((done.popleft(), None))
@@ -233,9 +248,11 @@ def extract_sharded_segments(extract_batch, lengths, load_utt, on_segment, segme
         except Exception as e:                              # a failure of THIS rank: told to every rank at the collector's next agreement
             todo.put(((0, 0, [np.zeros(0, dtype=np.int64)] * world, [], 0), e))
     finally:
+        t0 = time.perf_counter()
         todo.put(None)
         collector.join()
         pool.shutdown(wait=True)
+        spent["join"] += time.perf_counter() - t0
     if state["err"] is not None:
         raise state["err"].error if isinstance(state["err"], _Agreed) else state["err"]
     return n

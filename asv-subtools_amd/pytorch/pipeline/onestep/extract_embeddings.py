@@ -584,7 +584,7 @@ def _shard_segment_utts(lengths=None, batch_frames=0, batch_utts=0, row_pad=0):
 
 
 def extract_sharded_scp(extract_batch, entries, lengths, w, batch_frames, batch_utts, verbose=False, device=None, loader=None, row_pad=0,
-                        segment_utts=None):
+                        segment_utts=None, timing=None):
     """Sharded extraction of scp entries (one call per rank, torch.distributed initialised or not):
         extract_batch(list of [T, D] float32 matrices) -> [b, E] tensor
     The scp is walked in segments of `segment_utts` utterances per rank (default: ASV_AMD_SHARD_SEGMENT = 4096): every rank extracts
@@ -622,11 +622,14 @@ def extract_sharded_scp(extract_batch, entries, lengths, w, batch_frames, batch_
     try:
         n = shard.extract_sharded_segments(extract_batch, lengths, load, (lambda a, b, emb: todo.put((a, b, emb))) if rank == 0 else (lambda a, b, emb: None),
                                            _shard_segment_utts(lengths, batch_frames, batch_utts, row_pad) if segment_utts is None else segment_utts,
-                                           max_frames=batch_frames, max_utts=batch_utts, device=device, row_pad=row_pad)
+                                           max_frames=batch_frames, max_utts=batch_utts, device=device, row_pad=row_pad, timing=timing)
     finally:
+        t0 = time.perf_counter()
         if writer is not None:
             todo.put(None)
             writer.join()
+        if timing is not None:
+            timing["writer_join"] = timing.get("writer_join", 0.0) + time.perf_counter() - t0
         if loader is None:
             load.close()
     if failed:
@@ -658,10 +661,14 @@ def run_sharded(args, model, max_chunk, verbose):
     else:
         lengths = loader.lengths()                     # one 15-byte pread per plain float32 entry (a descriptor per ark file, not per entry)
 
+    spent = {"finish": 0.0}
+
     def extract_batch(mats):
         if getattr(mats, "packed", None) is not None:        # ScpBatchLoader: the batch already lies packed in one (page-locked) buffer
             k = mats.turn if mats.turn is not None else 0
+            t0 = time.perf_counter()
             sets.finish(k)                                   # the batch before last (same set): done by now; range guard
+            spent["finish"] += time.perf_counter() - t0
             return sets.submit(k, mats.offsets, int(mats.offsets[-1]) if mats.turn is not None else mats.packed)
         offs = np.zeros(len(mats) + 1, dtype=np.int32)
         np.cumsum([m.shape[0] for m in mats], out=offs[1:])
@@ -675,9 +682,10 @@ def run_sharded(args, model, max_chunk, verbose):
     try:
         t0 = time.perf_counter()
         with torch.cuda.device(dev):
-            n = extract_sharded_scp(extract_batch, entries, lengths, w, args.batch_frames, args.batch_utts, verbose, device=dev, loader=loader, row_pad=4)
+            n = extract_sharded_scp(extract_batch, entries, lengths, w, args.batch_frames, args.batch_utts, verbose, device=dev, loader=loader, row_pad=4,
+                                    timing=spent)
         if rank == 0:
-            _report_loop("sharded", n, time.perf_counter() - t0, sets)
+            _report_loop("sharded", n, time.perf_counter() - t0, sets, spent)
         if rank == 0 and dist.is_initialized():
             with open("/proc/self/maps") as f:
                 rccl = "librccl" in f.read()
