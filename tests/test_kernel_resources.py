@@ -113,3 +113,25 @@ def test_8phase_kernels_have_no_spills_and_no_compiler_visible_vector_loads(tmp_
             bad.append(code)
     assert n_dma >= 40
     assert not bad, bad[:5]
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_res2_chain_kernel_forms_fit_their_lds_and_registers(tmp_path):
+    """res2_chain_kernel<ET, 6 | 7> (kernels_res2.hip): the weight fragments of a branch (96 registers) + 3 / 4 accumulators live in
+    registers and the fragment loads are inline assembly with counted waits - a spill would put compiler-tracked vector memory next to
+    them (the first FR = 7 build spilled the 7 DMA source addresses of a lane: scratch reloads between the window pieces).  The images
+    B and X share one buffer: 111 104 / 127 488 bytes of LDS (an array of registers in the streaming step was once promoted to LDS by
+    hipcc: + 32 KiB, silently)."""
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(REPO, "include"), "-I" + CSRC, "-c",
+                        "-Rpass-analysis=kernel-resource-usage", "-o", str(tmp_path / "res2.o"), os.path.join(CSRC, "kernels_res2.hip")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    blocks = re.split(r"remark: [^\n]*Function Name: ", r.stderr)[1:]
+    assert len(blocks) == 4
+    for b in blocks:
+        name = b.split()[0]
+        fr = 7 if "ELi7E" in name else 6
+        assert ("ELi%dE" % fr) in name
+        assert int(re.search(r"VGPRs Spill: (\d+)", b).group(1)) == 0, name
+        assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1)) == 0, name
+        assert int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1)) == 2, name
+        assert int(re.search(r"LDS Size \[bytes/block\]: (\d+)", b).group(1)) == {6: 111104, 7: 127488}[fr], name
