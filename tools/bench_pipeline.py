@@ -29,8 +29,9 @@ sys.path.insert(0, os.path.join(REPO, "asv-subtools_amd", "pytorch"))
 SCRIPT = os.path.join(REPO, "asv-subtools_amd", "pytorch", "pipeline", "onestep", "extract_embeddings.py")
 
 
-def prepare(directory, utts, frames=200, dim=80):
-    """feats.ark + feats.scp + final.params + nnet.config in `directory`; returns their paths and the seconds spent writing."""
+def prepare(directory, utts, frames=200, dim=80, lengths=None):
+    """feats.ark + feats.scp + final.params + nnet.config in `directory`; returns their paths and the seconds spent writing.
+    lengths = (lo, hi): utterance i has one of 64 lengths drawn from U[lo, hi] (a ragged table) instead of `frames` everywhere."""
     import numpy as np
     import torch
     from libs.support import kaldi_io
@@ -46,9 +47,9 @@ def prepare(directory, utts, frames=200, dim=80):
     cfg = os.path.join(directory, "nnet.config")
     utils.write_nnet_config(blueprint, creation, cfg)
     feats, scp = os.path.join(directory, "feats.ark"), os.path.join(directory, "feats.scp")
-    base = [synth.synth_feats(frames, dim, 50_000 + i) for i in range(64)]
-    head = b"\0BFM \4" + np.int32(frames).tobytes() + b"\4" + np.int32(dim).tobytes()
-    payload = [head + m.tobytes() for m in base]
+    lens = [frames] * 64 if lengths is None else [int(v) for v in np.random.RandomState(7).randint(lengths[0], lengths[1] + 1, size=64)]
+    base = [synth.synth_feats(lens[i], dim, 50_000 + i) for i in range(64)]
+    payload = [b"\0BFM \4" + np.int32(m.shape[0]).tobytes() + b"\4" + np.int32(dim).tobytes() + m.tobytes() for m in base]
     t0 = time.perf_counter()
     with open(feats, "wb") as f, open(scp, "w") as s:
         pos = 0
@@ -57,9 +58,11 @@ def prepare(directory, utts, frames=200, dim=80):
             f.write(key)
             pos += len(key)
             s.write("utt%07d %s:%d\n" % (i, feats, pos))
-            f.write(payload[i % 64])
-            pos += len(payload[i % 64])
-    return {"params": params, "cfg": cfg, "ark": feats, "scp": scp, "write_seconds": time.perf_counter() - t0, "bytes": os.path.getsize(feats)}
+            j = (i * 37) % 64 if lengths is not None else i % 64          # (ragged: neighbours in the table differ in length)
+            f.write(payload[j])
+            pos += len(payload[j])
+    return {"params": params, "cfg": cfg, "ark": feats, "scp": scp, "write_seconds": time.perf_counter() - t0, "bytes": os.path.getsize(feats),
+            "mean_frames": float(np.mean([lens[(i * 37) % 64 if lengths is not None else i % 64] for i in range(min(utts, 6400))]))}
 
 
 def run_once(files, path, precision, utts, out_dir, timeout=900):
@@ -88,10 +91,11 @@ def run_once(files, path, precision, utts, out_dir, timeout=900):
 
 
 def measure(utts=50000, frames=200, precisions=("f32x", "bf16"), paths=("stream", "scp", "sharded"), directory="/tmp/asv_pipe", keep=False,
-            repeats_in_both_orders=True):
-    files = prepare(directory, utts, frames)
-    out = {"workload": "%d utterances x %d x 80 f32 Kaldi ark (%.2f GB, page cache) -> x-vector ark through pipeline/onestep/extract_embeddings.py, one GPU" % (
-               utts, frames, files["bytes"] / 1e9),
+            repeats_in_both_orders=True, lengths=None):
+    files = prepare(directory, utts, frames, lengths=lengths)
+    shape = "%d" % frames if lengths is None else "U[%d, %d] (mean %.0f)" % (lengths[0], lengths[1], files["mean_frames"])
+    out = {"workload": "%d utterances x %s x 80 f32 Kaldi ark (%.2f GB, page cache) -> x-vector ark through pipeline/onestep/extract_embeddings.py, one GPU" % (
+               utts, shape, files["bytes"] / 1e9),
            "ark_write_seconds_synthetic": round(files["write_seconds"], 2), "host_cores": os.cpu_count(), "runs": {}}
     # One short untimed run per path first: a fresh box reads the code it has never run - RCCL's collective kernels, torch's cat / index
     # kernels of the gather, the script's own modules - from a cold file cache (the first --sharded run of a container measured 0.1 s
@@ -105,8 +109,11 @@ def measure(utts=50000, frames=200, precisions=("f32x", "bf16"), paths=("stream"
             if i >= n_warm:
                 break
             g.write(line)
+    with open(files["scp"]) as f:
+        entries = [line.split()[1] for line in f]
+    warm_bytes = files["bytes"] if n_warm >= utts else int(entries[n_warm].rsplit(":", 1)[1]) - len("utt%07d " % n_warm)      # up to the key of entry n_warm
     with open(files["ark"], "rb") as f, open(warm["ark"], "wb") as g:
-        g.write(f.read(n_warm * (files["bytes"] // utts)))
+        g.write(f.read(warm_bytes))
     for path in paths:
         run_once(warm, path, precisions[0], n_warm, directory)
     for k in ("ark", "scp"):
@@ -142,8 +149,12 @@ def main():
     ap.add_argument("--precisions", default="f32x,bf16")
     ap.add_argument("--paths", default="stream,scp,sharded")
     ap.add_argument("--dir", default="/tmp/asv_pipe")
+    ap.add_argument("--lengths", default="", help="lo,hi: a ragged table (64 lengths drawn from U[lo, hi]) instead of --frames everywhere")
+    ap.add_argument("--once", action="store_true", help="one run per (path, precision) instead of both positions of the sequence")
     args = ap.parse_args()
-    print(json.dumps(measure(args.utts, args.frames, tuple(args.precisions.split(",")), tuple(args.paths.split(",")), args.dir)))
+    lengths = tuple(int(v) for v in args.lengths.split(",")) if args.lengths else None
+    print(json.dumps(measure(args.utts, args.frames, tuple(args.precisions.split(",")), tuple(args.paths.split(",")), args.dir, repeats_in_both_orders=not args.once,
+                             lengths=lengths)))
 
 
 if __name__ == "__main__":
