@@ -181,7 +181,8 @@ def _read_exact(fd, n):
 
 def read_key(fd):
     """Next utterance key of an ark stream, or None at end of file."""
-    assert "b" in getattr(fd, "mode", "rb"), "Error: 'fd' was opened in text mode (in python3 use sys.stdin.buffer)"
+    mode = getattr(fd, "mode", "rb")                    # (gzip.GzipFile.mode is an int: always binary - the reference's `'b' in fd.mode` raises TypeError on a .gz ark)
+    assert not isinstance(mode, str) or "b" in mode, "Error: 'fd' was opened in text mode (in python3 use sys.stdin.buffer)"
     chars = []
     while True:
         ch = fd.read(1)

@@ -801,3 +801,22 @@ def test_native_vector_ark_packing_equals_write_vec_flt(tmp_path):
     back = list(kaldi_io.read_vec_flt_ark(io.BytesIO(kaldi_io.vec_flt_ark_bytes(odd[1:], v[1:]))))
     assert [k for k, _ in back] == odd[1:]
     assert kaldi_io.vec_flt_ark_bytes(odd, v).startswith(b"a\nb \0BFV ")
+
+
+def test_vector_ark_buffer_goes_through_files_gzip_and_pipes(tmp_path):
+    """The sharded path's writer hands a segment's packed entries to `w.write()` as the native packer's own uint8 array
+    (vec_flt_ark_bytes(as_buffer=True): one copy fewer); whatever open_or_fd returned for the wspecifier - a file, a .gz file, a
+    '| cmd' pipe (the reference pipes into copy-vector) - must take it, and the entries must read back (a .gz ark through
+    read_vec_flt_ark too: GzipFile.mode is an int, which the reference's read_key trips over)."""
+    from libs.support import kaldi_io
+    keys = ["k%03d" % i for i in range(40)]
+    v = np.random.RandomState(2).randn(40, 16).astype(np.float32)
+    blob = kaldi_io.vec_flt_ark_bytes(keys, v, as_buffer=True)
+    assert bytes(blob) == kaldi_io.vec_flt_ark_bytes(keys, v)
+    targets = {str(tmp_path / "a.ark"): str(tmp_path / "a.ark"), str(tmp_path / "b.ark.gz"): str(tmp_path / "b.ark.gz"),
+               "| cat > %s" % (tmp_path / "c.ark"): str(tmp_path / "c.ark")}
+    for spec, path in targets.items():
+        with kaldi_io.open_or_fd(spec, "wb") as w:
+            w.write(blob)
+        got = list(kaldi_io.read_vec_flt_ark(path))
+        assert [k for k, _ in got] == keys and np.array_equal(np.stack([x for _, x in got]), v), spec
