@@ -1,5 +1,5 @@
 #!/bin/bash
-# 8-phase kernel with a packed channel remainder (the first layer) + the sharded path without flushes at segment ends
+# 8-phase kernel with a packed channel remainder (the first layer; the kernel code measured here is commit 1065696 - taken out afterwards: slower) + the sharded path without flushes at segment ends
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out
 tag=${1:-r5v}
