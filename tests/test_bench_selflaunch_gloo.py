@@ -25,6 +25,9 @@ def _run(gpus, launcher):
     assert res.returncode == 0, res.stdout + res.stderr
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout                         # exactly one JSON line, from rank 0
+    assert res.stdout.rstrip("\n").splitlines()[-1] == lines[0]            # ... and it is the LAST stdout line (what the driver parses)
+    assert len(lines[0]) <= 4096, len(lines[0])                # a 19 KB line was not held by the driver
+    assert "bench.py full record: {" in res.stderr              # the long record goes to stderr and gpurun_out/bench_full.json
     return json.loads(lines[0])
 
 
@@ -43,3 +46,25 @@ def test_bench_dry_run_control_flow(gpus, launcher):
 def test_bench_refuses_gloo_without_dry_run():
     res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--backend", "gloo"], capture_output=True, text=True, timeout=300)
     assert res.returncode != 0 and "--dry-run" in (res.stdout + res.stderr)
+
+
+def test_compact_line_of_a_full_device_record_stays_small():
+    """The compact line built from a FULL single-GPU record (every supplementary model / mode, the gate tables, the ark -> ark runs:
+    profiles/r5y_bench.json is the 19.4 KB line the round-5 driver could not hold) keeps the contract's keys, the dominant kernel's
+    roofline, the CPU baseline and one scalar per supplementary record inside 4 KB."""
+    sys.path.insert(0, REPO)
+    import bench
+    with open(os.path.join(REPO, "profiles", "r5y_bench.json")) as f:
+        full = json.loads(f.read())
+    rec = bench.compact_record(full)
+    line = json.dumps(rec, separators=(",", ":"))
+    assert len(line) <= bench.LINE_TARGET, len(line)
+    for k in REQUIRED + ("roofline", "cpu_baseline", "value_parity_grade", "value_single_stream", "supplementary"):
+        assert k in rec, k
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "dominant_us", "dominant_frac", "dominant_flop_per_launch", "traffic_over_algorithmic"):
+        assert k in rec["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in rec["cpu_baseline"], k
+    for k in ("ecapa_c3", "ecapa_c3_f32x", "resnet_c5", "resnet_c5_f32x", "xvector_f32x", "ark_stream_f32x", "ark_sharded_f32x"):
+        assert k in rec["supplementary"], k
+    assert all(not isinstance(v, list) or len(v) <= 2 for sub in rec["supplementary"].values() for v in sub.values())

@@ -93,6 +93,26 @@ def run_once(files, path, precision, utts, out_dir, timeout=900):
 def measure(utts=50000, frames=200, precisions=("f32x", "bf16"), paths=("stream", "scp", "sharded"), directory="/tmp/asv_pipe", keep=False,
             repeats_in_both_orders=True, lengths=None):
     files = prepare(directory, utts, frames, lengths=lengths)
+    try:
+        return _measure(files, utts, frames, precisions, paths, directory, repeats_in_both_orders, lengths)
+    finally:
+        # a failing or timed-out run must not leave gigabytes in /tmp
+        if not keep:
+            for name in ("feats.ark", "feats.scp", "final.params", "nnet.config", "warm.ark", "warm.scp"):
+                try:
+                    os.remove(os.path.join(directory, name))
+                except OSError:
+                    pass
+            for name in os.listdir(directory) if os.path.isdir(directory) else []:
+                if name.startswith("xvector_") and name.endswith(".ark"):
+                    os.remove(os.path.join(directory, name))
+            try:
+                os.rmdir(directory)
+            except OSError:
+                pass
+
+
+def _measure(files, utts, frames, precisions, paths, directory, repeats_in_both_orders, lengths):
     shape = "%d" % frames if lengths is None else "U[%d, %d] (mean %.0f)" % (lengths[0], lengths[1], files["mean_frames"])
     out = {"workload": "%d utterances x %s x 80 f32 Kaldi ark (%.2f GB, page cache) -> x-vector ark through pipeline/onestep/extract_embeddings.py, one GPU" % (
                utts, shape, files["bytes"] / 1e9),
@@ -133,12 +153,6 @@ def measure(utts=50000, frames=200, precisions=("f32x", "bf16"), paths=("stream"
             best = out["runs"].get(name)
             if best is None or "error" in best or rec.get("loop_utts_per_s", 0.0) > best.get("loop_utts_per_s", 0.0):
                 out["runs"][name] = rec
-    if not keep:
-        for k in ("ark", "scp", "params", "cfg"):
-            try:
-                os.remove(files[k])
-            except OSError:
-                pass
     return out
 
 
