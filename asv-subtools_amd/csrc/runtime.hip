@@ -1412,18 +1412,25 @@ int run_ops(RunCtx &c, size_t n_ops) {
         // Round 5: the layers of the variant-3 kernel with the plain epilogue, whole 64-channel chunks and at least one round of 256 x 256
         // tiles on the chip's CUs go to the 8-phase kernel (kernels_tdnn_p8.hip: both operands through LDS-DMA, staggered wave rows;
         // bit-identical outputs, 1.03 - 1.15 x the rate: profiles/r5e_p8_shapes.txt).  ASV_AMD_P8=0: the variant-3 kernel everywhere.
+        static const bool live_tune = getenv("ASV_AMD_LIVE_TUNE") != nullptr;     // (read once: this is the launch path of every TDNN op)
         static const int p8_env = getenv("ASV_AMD_P8") ? atoi(getenv("ASV_AMD_P8")) : 1;
-        const int p8_on = getenv("ASV_AMD_LIVE_TUNE") != nullptr ? (getenv("ASV_AMD_P8") ? atoi(getenv("ASV_AMD_P8")) : 1) : p8_env;
+        const int p8_on = live_tune ? (getenv("ASV_AMD_P8") ? atoi(getenv("ASV_AMD_P8")) : 1) : p8_env;
+        // "one round of tiles" = one 256 x 256 tile per CU of THIS device (the kernels size their persistent grids from the same count)
+        static const long long cus = [] {
+          int dev = 0, n = 256;
+          if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+          return (long long)(n > 0 ? n : 256);
+        }();
         const bool p8 = big3 && !fuse && p8_on != 0 && tdnn_p8_supported(p, et, !bf16) &&
-                        (long long)(p.rows / 256) * (round_up(p.cout_store, 256) / 256) >= (p8_on > 1 ? p8_on : 256);
+                        (long long)(p.rows / 256) * (round_up(p.cout_store, 256) / 256) >= (p8_on > 1 ? p8_on : cus);
         // ... and the same structure for the f32x mode's wide plain layers (kernels_tdnn_p8x.hip; the bits of tdnn_gemm_x3_kernel).  ASV_AMD_P8X=0: off
         static const int p8x_env = getenv("ASV_AMD_P8X") ? atoi(getenv("ASV_AMD_P8X")) : 1;
-        const int p8x_on = getenv("ASV_AMD_LIVE_TUNE") != nullptr ? (getenv("ASV_AMD_P8X") ? atoi(getenv("ASV_AMD_P8X")) : 1) : p8x_env;
+        const int p8x_on = live_tune ? (getenv("ASV_AMD_P8X") ? atoi(getenv("ASV_AMD_P8X")) : 1) : p8x_env;
         // (production rule: at least one round of tiles AND a last round that is >= 85 % full - the x-vector's tdnn2 at 256 utterances is
         //  408 tiles = 1.6 rounds, where the finer 128-row tiles of tdnn_gemm_x3_kernel are as fast and leave CUs to the other stream:
         //  -0.9 % on two streams, profiles/r5s_p8x_model_ab.txt; ECAPA's layers are 4.75 and 7.1 rounds)
         const long long p8x_tiles = (long long)(p.rows / 256) * (round_up(p.cout_store, 256) / 256);
-        const bool p8x_fill = p8x_on > 1 ? p8x_tiles >= p8x_on : (p8x_tiles >= 256 && p8x_tiles * 100 >= ((p8x_tiles + 255) / 256) * 256 * 85);
+        const bool p8x_fill = p8x_on > 1 ? p8x_tiles >= p8x_on : (p8x_tiles >= cus && p8x_tiles * 100 >= ((p8x_tiles + cus - 1) / cus) * cus * 85);
         const bool p8x = x3 && !fuse && p8x_on != 0 && tdnn_p8x_supported(p) && p8x_fill;
         if (use_ref) rc = launch_tdnn_ref(p, et, !bf16, c.s);
         else if (utts_kernel) {

@@ -70,7 +70,8 @@ class DeviceSets(object):
             self.host_out = [torch.empty((batch_utts, self.embed_dim), dtype=torch.float32).pin_memory() for _ in range(n_sets)]
         self.h2d = [torch.cuda.Event() for _ in range(n_sets)]
         self.done = [torch.cuda.Event() for _ in range(n_sets)]
-        self.pending = [None] * n_sets                   # (feats tensor, offsets, out tensor, n, engine index) of the batch in flight on a set
+        self.pending = [None] * n_sets                   # (feats tensor, offsets, out tensor, n, engine index, submission number) of the batch in flight on a set
+        self.submitted = 0                               # submit() calls so far
         if warm:
             # one full-size batch of zeros through every engine now: the activation arenas (grown on demand by the first extraction:
             # a few hundred MB of hipMalloc per engine) and the segment tables exist before the first real batch arrives
@@ -100,7 +101,14 @@ class DeviceSets(object):
         self._next_engine = (e + 1) % len(self.engines)  # order, so the status word copied behind a batch is that batch's alone)
         out = None
         if self.results == "device":
-            out = torch.empty((n, self.embed_dim), dtype=torch.float32, device=self.dev)     # (allocated on the caller's stream: it outlives this one)
+            # a block of the ENGINE stream's pool (the stream that writes it), marked as used by the consumer's stream too: the caching
+            # allocator then hands it out again only after both streams have passed its last use (allocated on the caller's
+            # stream, a block the collector thread had just freed there could be overwritten under a still-pending cat / index kernel)
+            consumer = torch.cuda.current_stream(self.dev)
+            with torch.cuda.stream(self.streams[e]):
+                out = torch.empty((n, self.embed_dim), dtype=torch.float32, device=self.dev)
+            if consumer != self.streams[e]:
+                out.record_stream(consumer)
         import time
         t = [time.perf_counter()]
         with torch.cuda.device(self.dev), torch.cuda.stream(self.streams[e]):
@@ -123,8 +131,16 @@ class DeviceSets(object):
             t.append(time.perf_counter())
         for i, name in enumerate(("h2d", "extract", "d2h")):
             self.submit_seconds[name] = self.submit_seconds.get(name, 0.0) + t[i + 1] - t[i]
-        self.pending[k] = (feats, np.array(offsets, dtype=np.int32), out, n, e)
+        self.submitted += 1
+        self.pending[k] = (feats, np.array(offsets, dtype=np.int32), out, n, e, self.submitted)
         return out
+
+    def final_through(self):
+        """Every submission numbered <= this (1-based, in submit() order) has been finish()ed - synchronised, range-checked and, where
+        flagged, re-run: its result may be read from any stream.  Exact whatever set each batch used (the sharded path releases a
+        segment to the gather by it; a rule of "n_sets submissions later" only held while batches rotated over the sets)."""
+        live = [p[5] for p in self.pending if p is not None]
+        return (min(live) - 1) if live else self.submitted
 
     def input_consumed(self, k):
         if self.pending[k] is not None:
@@ -134,7 +150,7 @@ class DeviceSets(object):
         p = self.pending[k]
         if p is None:
             return None
-        feats, offsets, out, n, e = p
+        feats, offsets, out, n, e, _ = p
         self.done[k].synchronize()
         if self.watch and (int(self.status_host[k][0]) & capi.STATUS_HALF_RANGE):
             torch = self.torch

@@ -127,8 +127,8 @@ def extract_sharded_segments(extract_batch, lengths, load_utt, on_segment, segme
     Utterances [a, b) of a segment (`segment_utts` per rank; None = everything in one segment) are balanced by length over the ranks
     and batched like the whole list used to be.  ONE pipeline runs through all segments: the reader stays one batch ahead across
     segment ends, and a segment is gathered when its results are final, not when its last batch has been submitted - a pipelined
-    extract_batch says how many later submissions that takes (`extract_batch.depth`: libs.amd.pipeline.DeviceSets finishes a buffer
-    set's batch before it reuses the set; absent = results are final on return), so nothing is flushed before the very end and the
+    extract_batch says which submissions are final (`extract_batch.final_through()`: libs.amd.pipeline.DeviceSets counts the
+    batches it has finished and range-checked; or `extract_batch.depth` = that many later submissions; neither = final on return), so nothing is flushed before the very end and the
     device never drains at a segment end.  Per segment the ranks agree that nobody failed (one tiny all-reduce) and all-gather it.
     What this buys: rank 0 can copy out and write segment s while later segments are extracted - with one gather at the very end
     the 102 MB of 50 000 x-vectors (device -> host, ark packing, write) were a serial tail of 0.14 s behind a 0.2 s extraction loop
@@ -170,6 +170,9 @@ def extract_sharded_segments(extract_batch, lengths, load_utt, on_segment, segme
     fetch = (lambda batch: whole(batch)) if whole is not None else (lambda batch: [load_utt(i) for i in batch])
     flush = getattr(extract_batch, "flush", None)          # a pipelined extract_batch returns tensors whose work is still in flight
     depth = int(getattr(extract_batch, "depth", 0)) if flush is not None else 0
+    # the exact form of the same knowledge: how many of the submissions so far are final (libs.amd.pipeline.DeviceSets.final_through);
+    # preferred over `depth`, which presumes that batches rotate over the pipeline's buffer sets without exception
+    final_through = getattr(extract_batch, "final_through", None) if flush is not None else None
     pool = ThreadPoolExecutor(1)
     done = collections.deque()                              # submitted segments whose results are not final yet: (a, b, shards, outs, index of the last submission)
     submitted = 0
@@ -232,10 +235,11 @@ def extract_sharded_segments(extract_batch, lengths, load_utt, on_segment, segme
                     spent["reader"] += t1 - t0
                     spent["extract"] += time.perf_counter() - t1
                     submitted += 1
-                    while done and done[0][4] + depth <= submitted:     # (its last batch has been finished by the pipeline itself)
+                    limit = final_through() if final_through is not None else submitted - depth
+                    while done and done[0][4] <= limit:                 # (its last batch has been finished by the pipeline itself)
                         todo.put((done.popleft(), None))
                 done.append((a, b, shards, outs, submitted))
-                if depth == 0:
+                if depth == 0 and final_through is None:
                     if flush is not None:
                         flush()
                     todo.put((done.popleft(), None))
@@ -245,17 +249,37 @@ def extract_sharded_segments(extract_batch, lengths, load_utt, on_segment, segme
                 todo.put((done.popleft(), None))
         except _Stop:
             pass
-        except Exception as e:                              # a failure of THIS rank: told to every rank at the collector's next agreement
-            todo.put(((0, 0, [np.zeros(0, dtype=np.int64)] * world, [], 0), e))
+        except BaseException as e:                          # a failure of THIS rank (KeyboardInterrupt / SystemExit included): told to
+            todo.put(((0, 0, [np.zeros(0, dtype=np.int64)] * world, [], 0), e))      # every rank at the collector's next agreement
     finally:
         t0 = time.perf_counter()
         todo.put(None)
         collector.join()
         pool.shutdown(wait=True)
         spent["join"] += time.perf_counter() - t0
+        # the collector failed on THIS rank outside an agreement (on_segment raised, a collective failed locally; an agreed failure has
+        # reached every rank already): it has skipped its part of every later collective, and the other ranks would sit in the next
+        # segment's all-reduce until the collective times out - the process group is torn down instead
+        if world > 1 and state["err"] is not None and not isinstance(state["err"], _Agreed):
+            _abort_group(group, inited)
     if state["err"] is not None:
         raise state["err"].error if isinstance(state["err"], _Agreed) else state["err"]
     return n
+
+
+def _abort_group(group, inited):
+    """Ends this rank's part in the process group so that the other ranks' pending collectives fail instead of waiting for it."""
+    if not inited:
+        return
+    import torch.distributed as dist
+    try:
+        abort = getattr(dist.distributed_c10d, "_abort_process_group", None)
+        if abort is not None:
+            abort(group)
+        else:
+            dist.destroy_process_group(group)
+    except Exception:                                       # nothing more can be done from here: the original error is what the caller sees
+        pass
 
 
 class _Stop(Exception):

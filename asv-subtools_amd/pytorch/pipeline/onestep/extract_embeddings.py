@@ -239,12 +239,14 @@ def matrix_rows(rxfile):
 
 
 class PackedBatch(object):
-    """The matrices of one batch as row slices of ONE buffer: `packed` [frames, D] float32, `offsets` int32 [n + 1]; `turn`: which of
-    the loader's buffers it lies in (None: an array of its own).  A sequence of the [T_k, D] views, made when asked for (the device
-    path takes `packed` and `offsets` as they are: 321 views per batch were 50 000 slicing calls per run that nobody looked at)."""
+    """The matrices of one batch as row slices of ONE buffer: `packed` [frames, D] float32, `offsets` int32 [n + 1]; `turn`: the slot of
+    the loader's buffer rotation this batch consumed (always - the caller's pipeline rotates with it); `own_array`: the batch did not
+    fit that buffer (one utterance longer than a whole batch) and lies in an array of its own.  A sequence of the [T_k, D] views, made
+    when asked for (the device path takes `packed` and `offsets` as they are: 321 views per batch were 50 000 slicing calls per run
+    that nobody looked at)."""
 
-    def __init__(self, packed, offsets, turn):
-        self.packed, self.offsets, self.turn = packed, offsets, turn
+    def __init__(self, packed, offsets, turn, own_array=False):
+        self.packed, self.offsets, self.turn, self.own_array = packed, offsets, turn, own_array
 
     def __len__(self):
         return len(self.offsets) - 1
@@ -482,6 +484,7 @@ class ScpBatchLoader(object):
             offs = np.zeros(len(indices) + 1, dtype=np.int32)
             np.cumsum([r for r, _ in shapes], out=offs[1:])
         total = int(offs[-1])
+        own = False
         turn, self._turn = self._turn, (self._turn + 1) % len(self._bufs)
         if self._before_fill is not None:
             self._before_fill(turn)
@@ -493,12 +496,12 @@ class ScpBatchLoader(object):
         elif buf.ndim == 2 and buf.shape[1] == dim and buf.shape[0] >= total:
             packed = buf[:total]
         else:                                          # does not fit the caller's buffer (one utterance longer than a whole batch): its own array
-            packed, turn = np.empty((total, dim), dtype=np.float32), None
+            packed, own = np.empty((total, dim), dtype=np.float32), True       # (the slot of the rotation is consumed all the same)
         if fast:
             self._fill_table(idx, packed, offs, dim)
         else:
             self.fill(indices, packed, offs, slow)
-        return PackedBatch(packed, offs, turn)
+        return PackedBatch(packed, offs, turn, own)
 
     def _fill_table(self, idx, packed, offs, dim):
         """fill() for a batch whose entries are all in the header table: the arguments of the one native read call by array indexing."""
@@ -665,18 +668,19 @@ def run_sharded(args, model, max_chunk, verbose):
 
     def extract_batch(mats):
         if getattr(mats, "packed", None) is not None:        # ScpBatchLoader: the batch already lies packed in one (page-locked) buffer
-            k = mats.turn if mats.turn is not None else 0
+            k = mats.turn                                    # the slot the loader consumed: an over-long batch (own array) keeps the rotation too
             t0 = time.perf_counter()
             sets.finish(k)                                   # the batch before last (same set): done by now; range guard
             spent["finish"] += time.perf_counter() - t0
-            return sets.submit(k, mats.offsets, int(mats.offsets[-1]) if mats.turn is not None else mats.packed)
+            return sets.submit(k, mats.offsets, mats.packed if mats.own_array else int(mats.offsets[-1]))
         offs = np.zeros(len(mats) + 1, dtype=np.int32)
         np.cumsum([m.shape[0] for m in mats], out=offs[1:])
         sets.finish(0)
         return sets.submit(0, offs, np.concatenate(mats, axis=0))
 
     extract_batch.flush = sets.flush                       # extract_sharded_segments calls it before it reads the last results ...
-    extract_batch.depth = sets.n_sets                      # ... and reads a segment's results once this many later batches were submitted
+    base = sets.submitted
+    extract_batch.final_through = lambda: sets.final_through() - base      # ... and reads a segment's results once its last submission is final
     rank = dist.get_rank() if dist.is_initialized() else 0
     w = kaldi_io.open_or_fd(args.vectors_wspecifier, "wb") if rank == 0 else None
     try:

@@ -563,7 +563,7 @@ def test_scp_batch_loader_header_table_equals_the_per_entry_path(tmp_path):
 def test_scp_batch_loader_fills_the_callers_buffers(tmp_path):
     """The sharded path hands the loader the page-locked input buffers of the device pipeline (libs.amd.pipeline.DeviceSets): batches
     land in them alternately, `before_fill(turn)` is called before a buffer is overwritten, and a batch that does not fit gets an
-    array of its own (turn None)."""
+    array of its own (`own_array`; its slot of the rotation is consumed all the same)."""
     ee = _load_extract_script()
     entries, want = _write_many_arks(tmp_path, n_files=3, per_file=12)
     bufs = [np.full((80, 8), np.nan, dtype=np.float32) for _ in range(2)]
@@ -581,7 +581,10 @@ def test_scp_batch_loader_fills_the_callers_buffers(tmp_path):
         everything = list(range(len(entries)))                # > 80 rows: cannot fit a buffer
         assert sum(m.shape[0] for m in want) > 80
         c = ld.load_batch(everything)
-        assert c.turn is None and all(np.array_equal(m, want[i]) for m, i in zip(c, everything))
+        assert c.own_array and c.turn == 0 and calls == [0, 1, 0]        # the slot of the rotation is consumed all the same
+        assert all(np.array_equal(m, want[i]) for m, i in zip(c, everything))
+        d = ld.load_batch([7])
+        assert d.turn == 1 and not d.own_array and not a.own_array
     finally:
         ld.close()
 

@@ -92,6 +92,60 @@ def test_segments_are_gathered_only_when_their_results_are_final(depth, segment)
     assert np.array_equal(np.concatenate([got[k] for k in spans]), want)
 
 
+class _SetsPipeline(object):
+    """Stand-in with libs.amd.pipeline.DeviceSets' bookkeeping behind extract_batch: a batch's tensor is filled in when ITS buffer set is
+    finished (before the set's next submission, or on flush); `irregular` batches break the rotation - they run on set 0 whatever
+    set is due (what run_sharded did with an utterance longer than --batch-frames until round 6).  final_through() is exact."""
+
+    def __init__(self, n_sets, irregular):
+        self.n_sets, self.irregular, self.pending, self.submitted, self.flushes = n_sets, irregular, [None] * n_sets, 0, 0
+
+    def _finish(self, k):
+        import torch
+        if self.pending[k] is not None:
+            _, t, v = self.pending[k]
+            t.copy_(torch.from_numpy(v))
+            self.pending[k] = None
+
+    def __call__(self, mats):
+        import torch
+        k = 0 if self.submitted in self.irregular else self.submitted % self.n_sets
+        self._finish(k)
+        out = torch.full((len(mats), 16), float("nan"))
+        self.submitted += 1
+        self.pending[k] = (self.submitted, out, np.stack([_fake_embedding(m) for m in mats]))
+        return out
+
+    def final_through(self):
+        live = [p[0] for p in self.pending if p is not None]
+        return (min(live) - 1) if live else self.submitted
+
+    def flush(self):
+        self.flushes += 1
+        for k in range(self.n_sets):
+            self._finish(k)
+
+
+@pytest.mark.parametrize("segment", [1, 2, 3, 5])
+def test_segments_wait_for_final_results_when_the_rotation_is_broken(segment):
+    """with `depth = n_sets` a segment was released three submissions after its last batch - wrong as soon as one
+    batch leaves the rotation of the buffer sets (unfinished, unchecked results were gathered and written).  The release rule is now
+    the pipeline's own count of finished submissions."""
+    from libs.amd import synth
+    lengths = np.random.RandomState(9).randint(20, 300, size=67)
+    load = lambda i: synth.synth_feats(int(lengths[i]), 8, 100 + i)
+    pipe = _SetsPipeline(3, irregular={2, 3, 7, 11, 12, 13, 20})
+    seen = []
+
+    def on_segment(a, b, emb):
+        assert not np.isnan(emb.numpy()).any(), "segment [%d, %d) was read before its results were final" % (a, b)
+        seen.append((a, b, emb.numpy().copy()))
+    n = shard.extract_sharded_segments(pipe, lengths, load, on_segment, segment, max_frames=500, max_utts=3)
+    assert n == len(lengths) and pipe.flushes == 1
+    want = np.stack([_fake_embedding(load(i)) for i in range(len(lengths))])
+    assert np.array_equal(np.concatenate([e for _, _, e in sorted(seen, key=lambda t: t[0])]), want)
+
+
 def _fake_embedding(mat, dim=16):
     # deterministic, length- and content-dependent stand-in for the extractor
     v = np.zeros(dim, dtype=np.float32)
@@ -225,3 +279,53 @@ def test_a_rank_failing_in_a_later_segment_stops_every_rank_at_the_same_agreemen
     r0, r1 = eval((tmp_path / "rank0.txt").read_text()), eval((tmp_path / "rank1.txt").read_text())
     assert r1[-1].startswith("OSError: rank 1 cannot read") and "another rank failed" in r0[-1], (r0, r1)
     assert r0[:-1] == r1[:-1] and all(b <= 12 for a, b in r0[:-1]), (r0, r1)
+
+
+def _worker_one_sided(rank, world, port, lengths, out_dir, what):
+    import datetime
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=40))
+    from libs.amd import synth
+    import torch
+
+    def load(i):
+        if what == "interrupt" and rank == 1 and i >= 12:
+            raise KeyboardInterrupt()
+        return synth.synth_feats(int(lengths[i]), 8, 100 + i)
+
+    def on_segment(a, b, emb):
+        if what == "on_segment" and rank == 1 and a >= 6:
+            raise RuntimeError("rank 1 cannot write segment %d" % a)
+    extract = lambda mats: torch.from_numpy(np.stack([_fake_embedding(m) for m in mats]))
+    import time
+    t0 = time.time()
+    try:
+        shard.extract_sharded_segments(extract, lengths, load, on_segment, 3, max_frames=600, max_utts=2)
+        res = "finished"
+    except BaseException as e:
+        res = "%s: %s" % (type(e).__name__, e)
+    with open(os.path.join(out_dir, "rank%d.txt" % rank), "w") as f:
+        f.write("%.1f %s" % (time.time() - t0, res))
+    try:
+        dist.destroy_process_group()
+    except Exception:
+        pass
+
+
+@pytest.mark.parametrize("what", ["interrupt", "on_segment"])
+def test_a_one_sided_exit_does_not_leave_the_other_rank_in_a_collective(tmp_path, what):
+    """a KeyboardInterrupt / SystemExit on one rank's submitting loop is forwarded through the agreement like any other
+    failure; a failure of one rank's on_segment (outside any agreement) tears its process group down, so the other rank's next
+    collective fails at once instead of waiting for the collective's timeout (40 s here)."""
+    import torch.multiprocessing as mp
+    lengths = np.random.RandomState(6).randint(20, 100, size=30)
+    mp.spawn(_worker_one_sided, args=(2, _free_port(), lengths, str(tmp_path), what), nprocs=2, join=True)
+    r0, r1 = (tmp_path / "rank0.txt").read_text(), (tmp_path / "rank1.txt").read_text()
+    assert float(r0.split()[0]) < 30 and float(r1.split()[0]) < 30, (r0, r1)
+    assert "finished" not in r0 and "finished" not in r1, (r0, r1)
+    if what == "interrupt":
+        assert "KeyboardInterrupt" in r1 and "another rank failed" in r0, (r0, r1)
+    else:
+        assert "rank 1 cannot write" in r1, (r0, r1)
