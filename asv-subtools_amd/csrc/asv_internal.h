@@ -195,6 +195,7 @@ struct TdnnChainLayer {
   const void *wfrag; const float *bias, *scale, *shift;   // scale / shift may be nullptr (1, 0)
   int relu, cout_pad;
   const void *wlo; float w_scale;                          // f32x chain (kernels_tdnn_chainx.hip): lo halves, and the power of two both halves carry
+  const void *w8;                                          // f32m chain (kernels_tdnn_chainm.hip): 8-bit fragments [w_hi8 | w_lo8] (pack_tdnn_weight_mx8)
 };
 struct TdnnChainParams {
   const void *x; int ldx, rows, cin_pad, n_taps; int taps[ASV_MAX_TAPS];     // input of the first layer (bf16 rows)
@@ -234,6 +235,8 @@ int launch_tdnn_chain4(const TdnnChainParams &p, hipStream_t s);
 #endif
 // the same chain with f32-grade split products and the tiles resident as hi / lo half images; 64-row tiles (kernels_tdnn_chainx.hip)
 int launch_tdnn_chainx(const TdnnChainParams &p, hipStream_t s);
+// the same with the two correction products on the block-scaled 8-bit matrix instruction ("f32m", ASV_FLAG_X3_MX8; kernels_tdnn_chainm.hip)
+int launch_tdnn_chainm(const TdnnChainParams &p, hipStream_t s);
 // ECAPA Res2NetBlock as one kernel (kernels_res2.hip)
 constexpr int kRes2Width = 128;
 struct Res2KernelParams {

@@ -61,4 +61,39 @@ inline float f16_to_f32_host(uint16_t h) {
   return f;
 }
 
+// f32 -> OCP e4m3 (fn: no infinities, 0x7f / 0xff = NaN), round-to-nearest-even, saturating at +-448 (what the weights of the f32m
+// form are packed with: pack_tdnn_weight_mx8); and back
+inline uint8_t f32_to_e4m3_host(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  const uint8_t sign = (uint8_t)((u >> 24) & 0x80u);
+  const uint32_t a = u & 0x7fffffffu;
+  if (a > 0x7f800000u) return (uint8_t)(sign | 0x7fu);                        // NaN
+  float m;
+  memcpy(&m, &a, 4);                                                           // |f|
+  if (m >= 448.0f) return (uint8_t)(sign | 0x7eu);                            // saturate (incl. infinity)
+  if (m < 0.0009765625f) return sign;                                         // < 2^-10: half of the smallest subnormal 2^-9 ties to even = 0
+  const int e = (int)(a >> 23) - 127;                                         // unbiased exponent
+  const uint32_t man = (a & 0x7fffffu) | 0x800000u;                           // 24-bit significand
+  const int shift = (e < -6) ? (20 + (-6 - e)) : 20;                          // keep 3 fraction bits (subnormals: fewer)
+  uint32_t q = man >> shift;
+  const uint32_t rem = man & ((1u << shift) - 1u), mid = 1u << (shift - 1);
+  if (rem > mid || (rem == mid && (q & 1u))) ++q;
+  const uint32_t ebits = (e < -6) ? 0u : (uint32_t)(e + 7 - 1) << 3;           // the implicit bit of q bumps the exponent field by one
+  const uint32_t r = ebits + q;
+  return (uint8_t)(sign | (r > 0x7eu ? 0x7eu : r));
+}
+
+inline float e4m3_to_f32_host(uint8_t b) {
+  const int e = (b >> 3) & 15, m = b & 7;
+  float v;
+  if (e == 15 && m == 7) { const uint32_t n = 0x7fc00000u; memcpy(&v, &n, 4); return v; }
+  if (e == 0) v = (float)m * 0.001953125f;                                    // m * 2^-9
+  else {
+    const uint32_t u = ((uint32_t)(e - 7 + 127) << 23) | ((uint32_t)m << 20);
+    memcpy(&v, &u, 4);
+  }
+  return (b & 0x80u) ? -v : v;
+}
+
 }  // namespace asv

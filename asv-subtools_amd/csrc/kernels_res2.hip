@@ -298,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(const Res2KernelPara
 // overrides (A/B; read once per process unless ASV_AMD_LIVE_TUNE is set)
 static int res2_window_frags(int rows) {
   static const int forced = getenv("ASV_AMD_RES2_FR") != nullptr ? atoi(getenv("ASV_AMD_RES2_FR")) : 0;
-  static const bool live = getenv("ASV_AMD_LIVE_TUNE") != nullptr;
+  const bool live = getenv("ASV_AMD_LIVE_TUNE") != nullptr;          // (one lookup per launch; the A/B tests set it after the first launch)
   const int f = live ? (getenv("ASV_AMD_RES2_FR") != nullptr ? atoi(getenv("ASV_AMD_RES2_FR")) : 0) : forced;
   if (f == 6 || f == 7) return f;
   static int cus = 0;

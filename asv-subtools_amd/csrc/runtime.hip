@@ -98,6 +98,31 @@ void pack_tdnn_weight_x3p(const float *w, int out_ch, int in_ch, int tot_ctx, in
     }
 }
 
+// 8-bit fragments of the f32m form (kernels_tdnn_chainm.hip, the scaled 8-bit matrix instruction): for the halves hi = half(w * scale),
+// lo = w * scale - hi that pack_tdnn_weight_frags splits into, [32-channel output fragment][tap][32-channel input group][K block]
+// [lane = (input sixteen lh, output channel lr)][16]: block 0 = e4m3(hi 2^-6) (hi < 2^14 under x3_weight_scale), block 1 = e4m3(lo 2^6)
+// (|lo| <= 2^-11 |hi|); byte q = input channel 32 group + 16 lh + q.  The kernel's block scales undo the 2^-6 / 2^6.
+size_t tdnn_weight_mx8_bytes(int cout_pad, int cin_pad, int n_taps) { return (size_t)(cout_pad / 32) * n_taps * (cin_pad / 32) * 2048; }
+void pack_tdnn_weight_mx8(const float *w, int out_ch, int in_ch, int tot_ctx, int left_ctx, const int *taps, int n_taps, int cout_pad, int cin_pad,
+                          float scale, uint8_t *dst) {
+  const int ngroups = cin_pad / 32;
+  memset(dst, 0, tdnn_weight_mx8_bytes(cout_pad, cin_pad, n_taps));
+  for (int co = 0; co < out_ch; ++co) {
+    const int nf = co / 32, lr = co % 32;
+    for (int t = 0; t < n_taps; ++t) {
+      const int k = taps[t] - left_ctx;
+      for (int ci = 0; ci < in_ch; ++ci) {
+        const int g = ci / 32, lh = (ci % 32) / 16, q = ci % 16;
+        const float v = w[((size_t)co * in_ch + ci) * tot_ctx + k] * scale;
+        const float hi = f16_to_f32_host(f32_to_f16_host(v));
+        const size_t idx = (((size_t)nf * n_taps + t) * ngroups + g) * 2048 + (size_t)(lh * 32 + lr) * 16 + q;
+        dst[idx] = f32_to_e4m3_host(hi * 0.015625f);
+        dst[idx + 1024] = f32_to_e4m3_host((v - hi) * 64.0f);
+      }
+    }
+  }
+}
+
 // Power of two that lifts the largest weight of a layer to [2^13, 2^14) (the half-precision split of the f32x mode): every
 // weight down to 2^-15 of the largest keeps a normal lo half; the products grow by the same factor, far inside f32.
 static float x3_weight_scale(const float *w, size_t n) {
@@ -145,6 +170,7 @@ struct Op {
   void *wconv = nullptr;         // 3x3 trunk convolutions with 32 / 64 / 128 / 256 channels: fragment order of kernels_conv2d.hip
   void *wlo = nullptr;           // pooled layers in bf16 precision mode: bf16 lo halves (kernels_utts.hip)
   void *wx3p = nullptr;          // f32x mode, wide frame layers with the plain epilogue: [hi | lo] rows for kernels_tdnn_p8x.hip
+  void *w8 = nullptr, *w8_fold = nullptr;      // f32m form (ASV_FLAG_X3_MX8): 8-bit fragments of the layer / of its folded weights (pack_tdnn_weight_mx8)
   float *bias = nullptr, *scale = nullptr, *shift = nullptr;
   int cin_pad = 0, cout_pad = 0, cout_store = 0;
   // chain candidates (16-bit modes, 1-tap layers reading a 512-channel buffer): host copies kept until asv_net_finalize, which
@@ -216,6 +242,7 @@ struct asv_net {
   int x3_et() const { return (flags & ASV_FLAG_X3_SPLIT_BF16) ? ET_BF16 : ET_F16; }                  // f32x: type of the operand halves
   int x3_terms() const { return 1 | ((flags & ASV_FLAG_X3_NO_XLO) ? 0 : 2) | ((flags & ASV_FLAG_X3_NO_WLO) ? 0 : 4); }
   bool x3() const { return precision == ASV_PREC_F32X; }        // f32 storage, split-bf16 matrix products
+  bool x3_mx() const { return x3() && (flags & ASV_FLAG_X3_MX8) != 0 && x3_et() == ET_F16 && x3_terms() == 7; }      // "f32m": corrections on the scaled 8-bit instruction
   bool is_utts(int domain) const { return domains[domain].kind == ASV_DOMAIN_UTTS; }
   // one row per frame: the frames domain, or a width-1 / pitch-1 grid (the 2-D trunk's output flattened, asv_net_add_grid_flatten)
   bool is_sequence(int domain) const { return domains[domain].kind == ASV_DOMAIN_FRAMES || (domains[domain].kind == 2 && domains[domain].width == 1 && domains[domain].pitch == 1); }
@@ -225,7 +252,7 @@ struct asv_net {
 
 namespace {
 
-std::atomic<unsigned long long> g_kernel_launches[4];       // asv_kernel_launch_count
+std::atomic<unsigned long long> g_kernel_launches[6];       // asv_kernel_launch_count
 
 // the range-status word of the f32x kernels lives behind the zero page's zeros (own 64-byte line; kernels only ever OR into it)
 uint32_t *status_word(asv_net *net) { return reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(net->zero_page) + 128); }
@@ -543,6 +570,11 @@ int asv_net_add_tdnn(asv_net_t *net, const asv_tdnn_desc_t *d) {
                              net->x3_et(), op.w_scale);
       if ((rc = dev_upload(net, hi.data(), hi.size() * 2, &op.wfrag))) return rc;
       if ((rc = dev_upload(net, lo.data(), lo.size() * 2, &op.wlo))) return rc;
+      if (net->x3_mx() && op.cin_pad % 32 == 0 && op.cout_pad % 32 == 0) {
+        std::vector<uint8_t> w8(tdnn_weight_mx8_bytes(op.cout_pad, op.cin_pad, d->n_taps));
+        pack_tdnn_weight_mx8(d->weight, d->out_ch, d->in_ch, d->w_tot_context, d->w_left_context, d->taps, d->n_taps, op.cout_pad, op.cin_pad, op.w_scale, w8.data());
+        if ((rc = dev_upload(net, w8.data(), w8.size(), &op.w8))) return rc;
+      }
       // the candidates of the 8-phase form (256 x 256 tiles; the dispatch decides per batch): the plain epilogue, whole 32-channel chunks
       const bool plain = (d->act1 == ASV_ACT_NONE || d->act1 == ASV_ACT_RELU) && d->act2 == ASV_ACT_NONE && !d->affine_first;
       if (plain && op.cin_pad % 32 == 0 && d->in2_buf < 0 && d->seg_bias_buf < 0 && d->seg_scale_buf < 0 && d->res_buf < 0 && (long long)op.cin_pad * d->n_taps >= 512) {
@@ -928,6 +960,11 @@ int asv_net_finalize(asv_net_t *net, int out_buf, int embed_dim) {
           cur.w_scale_fold = net->x3_et() == ET_F16 ? x3_weight_scale(wf.data(), wf.size()) : 1.0f;
           pack_tdnn_weight_frags(wf.data(), out_ch, in_ch, 1, 0, &tap0, 1, cur.cout_pad, cur.cin_pad, frags.data(), frags_lo.data(), net->x3_et(), cur.w_scale_fold);
           if ((rc = dev_upload(net, frags_lo.data(), frags_lo.size() * 2, &cur.wlo_fold))) return rc;
+          if (net->x3_mx()) {
+            std::vector<uint8_t> w8(tdnn_weight_mx8_bytes(cur.cout_pad, cur.cin_pad, 1));
+            pack_tdnn_weight_mx8(wf.data(), out_ch, in_ch, 1, 0, &tap0, 1, cur.cout_pad, cur.cin_pad, cur.w_scale_fold, w8.data());
+            if ((rc = dev_upload(net, w8.data(), w8.size(), &cur.w8_fold))) return rc;
+          }
         } else {
           pack_tdnn_weight_frags(wf.data(), out_ch, in_ch, 1, 0, &tap0, 1, cur.cout_pad, cur.cin_pad, frags.data(), nullptr, net->frames_et());
         }
@@ -971,7 +1008,7 @@ int asv_net_status_async(asv_net_t *net, unsigned *host_status, void *stream) {
 }
 
 unsigned long long asv_kernel_launch_count(int which) {
-  return (which >= ASV_KERNEL_TDNN_P8 && which <= ASV_KERNEL_TDNN_P8X) ? g_kernel_launches[which].load() : 0ull;
+  return (which >= ASV_KERNEL_TDNN_P8 && which <= ASV_KERNEL_TDNN_X3M) ? g_kernel_launches[which].load() : 0ull;
 }
 
 size_t asv_net_device_bytes(const asv_net_t *net) {
@@ -1261,6 +1298,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
               TdnnChainLayer L;
               L.wfrag = folded_in ? o.wfrag_fold : o.wfrag; L.bias = folded_in ? o.bias_fold : o.bias;
               L.wlo = folded_in ? o.wlo_fold : o.wlo; L.w_scale = folded_in ? o.w_scale_fold : o.w_scale;
+              L.w8 = folded_in ? o.w8_fold : o.w8;
               L.scale = folded_out ? nullptr : o.scale; L.shift = folded_out ? nullptr : o.shift;
               L.relu = o.tdnn.act1 == ASV_ACT_RELU; L.cout_pad = o.cout_pad;
               return L;
@@ -1286,7 +1324,11 @@ int run_ops(RunCtx &c, size_t n_ops) {
               cp.dbg = reinterpret_cast<unsigned long long *>(dbg.ptr);
               cp.dbg_fine = chain_dbg >= 3;
             }
-            if ((rc = chain_x3 ? launch_tdnn_chainx(cp, c.s) : launch_tdnn_chain(cp, c.s))) return rc;
+            // f32m: the chain with its correction products on the scaled 8-bit instruction, when every layer of it has 8-bit fragments
+            bool chain_mx = chain_x3 && net->x3_mx() && cp.first.w8 != nullptr && cp.last.w8 != nullptr;
+            for (int m = 0; m < cp.n_mid; ++m) chain_mx = chain_mx && cp.mid[m].w8 != nullptr;
+            if (chain_mx) ++g_kernel_launches[ASV_KERNEL_TDNN_CHAINM];
+            if ((rc = chain_mx ? launch_tdnn_chainm(cp, c.s) : (chain_x3 ? launch_tdnn_chainx(cp, c.s) : launch_tdnn_chain(cp, c.s)))) return rc;
             if ((rc = prof.end())) return rc;
             if (chain_dbg && !chain_x3) {
               const size_t nwg = (size_t)(p.rows / 128);
@@ -1412,7 +1454,9 @@ int run_ops(RunCtx &c, size_t n_ops) {
         // Round 5: the layers of the variant-3 kernel with the plain epilogue, whole 64-channel chunks and at least one round of 256 x 256
         // tiles on the chip's CUs go to the 8-phase kernel (kernels_tdnn_p8.hip: both operands through LDS-DMA, staggered wave rows;
         // bit-identical outputs, 1.03 - 1.15 x the rate: profiles/r5e_p8_shapes.txt).  ASV_AMD_P8=0: the variant-3 kernel everywhere.
-        static const bool live_tune = getenv("ASV_AMD_LIVE_TUNE") != nullptr;     // (read once: this is the launch path of every TDNN op)
+        // (ONE environment lookup per TDNN op, ~50 ns: the in-process A/B tests switch ASV_AMD_LIVE_TUNE on after the library's first
+        //  launch, so this one cannot be cached; everything behind it is read once unless it is set)
+        const bool live_tune = getenv("ASV_AMD_LIVE_TUNE") != nullptr;
         static const int p8_env = getenv("ASV_AMD_P8") ? atoi(getenv("ASV_AMD_P8")) : 1;
         const int p8_on = live_tune ? (getenv("ASV_AMD_P8") ? atoi(getenv("ASV_AMD_P8")) : 1) : p8_env;
         // "one round of tiles" = one 256 x 256 tile per CU of THIS device (the kernels size their persistent grids from the same count)

@@ -13,14 +13,14 @@ import os
 ASV_OK = 0
 PREC_F32, PREC_BF16, PREC_F32X, PREC_F16 = 0, 1, 2, 3
 FLAG_REF_KERNELS, FLAG_NO_FUSE, FLAG_SMALL_TILES, FLAG_BIG_V2, FLAG_NO_CHAIN = 1, 2, 4, 8, 16
-FLAG_X3_SPLIT_BF16, FLAG_X3_SPLIT_F16, FLAG_X3_NO_XLO, FLAG_X3_NO_WLO, FLAG_X3_TILE128 = 32, 64, 128, 256, 512
+FLAG_X3_SPLIT_BF16, FLAG_X3_SPLIT_F16, FLAG_X3_NO_XLO, FLAG_X3_NO_WLO, FLAG_X3_TILE128, FLAG_X3_MX8 = 32, 64, 128, 256, 512, 1024
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
 DOMAIN_FRAMES, DOMAIN_UTTS = 0, 1
 MAX_TAPS = 9
 POOL_VAR_CLAMP, POOL_VAR_ADD = 0, 1
 PLDA_NORM_NONE, PLDA_NORM_SIMPLE, PLDA_NORM_PSI = 0, 1, 2
 STATUS_HALF_RANGE = 1
-KERNEL_TDNN_P8, KERNEL_TDNN_BIG3, KERNEL_TDNN_P8X = 1, 2, 3
+KERNEL_TDNN_P8, KERNEL_TDNN_BIG3, KERNEL_TDNN_P8X, KERNEL_TDNN_CHAINM, KERNEL_TDNN_X3M = 1, 2, 3, 4, 5
 
 ACT_BY_NAME = {None: ACT_NONE, "": ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "tanh": ACT_TANH,
                "sigmoid": ACT_SIGMOID}

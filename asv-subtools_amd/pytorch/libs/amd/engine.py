@@ -18,13 +18,13 @@ from . import ir as _ir
 PRECISIONS = {"f32": capi.PREC_F32, "fp32": capi.PREC_F32, "float32": capi.PREC_F32,
               "bf16": capi.PREC_BF16, "bfloat16": capi.PREC_BF16,
               "f16": capi.PREC_F16, "fp16": capi.PREC_F16, "half": capi.PREC_F16, "float16": capi.PREC_F16,
-              "f32x": capi.PREC_F32X, "bf16x3": capi.PREC_F32X, "f16x3": capi.PREC_F32X}
+              "f32x": capi.PREC_F32X, "bf16x3": capi.PREC_F32X, "f16x3": capi.PREC_F32X, "f32m": capi.PREC_F32X}
 H16_MODES = ("bf16", "bfloat16", "f16", "fp16", "half", "float16")       # 16-bit frames-domain storage
 
 # options of the f32x mode, appended with '-' (e.g. "f32x-bf16"): the 16-bit type the operands are split into, and the
 # reduced-product MEASUREMENT variants ("why not two matrix instructions per product", DESIGN.md "Precision modes")
 X3_OPTIONS = {"bf16": capi.FLAG_X3_SPLIT_BF16, "f16": capi.FLAG_X3_SPLIT_F16, "half": capi.FLAG_X3_SPLIT_F16,
-              "noxlo": capi.FLAG_X3_NO_XLO, "nowlo": capi.FLAG_X3_NO_WLO}
+              "noxlo": capi.FLAG_X3_NO_XLO, "nowlo": capi.FLAG_X3_NO_WLO, "mx": capi.FLAG_X3_MX8}
 
 
 def parse_precision(name):
@@ -33,7 +33,8 @@ def parse_precision(name):
     base = parts[0]
     if base not in PRECISIONS:
         raise ValueError("unknown precision %r (have %s)" % (name, sorted(set(PRECISIONS))))
-    bits = {"bf16x3": capi.FLAG_X3_SPLIT_BF16, "f16x3": capi.FLAG_X3_SPLIT_F16}.get(base, 0)
+    # 'f32m' = 'f32x-mx': the f32x mode with its two correction products on the block-scaled 8-bit matrix instruction (round 6)
+    bits = {"bf16x3": capi.FLAG_X3_SPLIT_BF16, "f16x3": capi.FLAG_X3_SPLIT_F16, "f32m": capi.FLAG_X3_MX8}.get(base, 0)
     for opt in parts[1:]:
         if PRECISIONS[base] != capi.PREC_F32X or opt not in X3_OPTIONS:
             raise ValueError("precision %r: option %r (only the f32x mode has options: %s)" % (name, opt, sorted(X3_OPTIONS)))
@@ -323,7 +324,7 @@ class Engine(object):
         STATUS_HALF_RANGE is re-run on (here and in libs.amd.pipeline.DeviceSets, the scripts' path)."""
         if getattr(self, "_wide_range_twin", None) is None:
             self._wide_range_twin = Engine(self.graph, device_index=self.device_index, precision="f32x-bf16",
-                                           flags=self.flags & ~(capi.FLAG_X3_SPLIT_F16 | capi.FLAG_X3_SPLIT_BF16))
+                                           flags=self.flags & ~(capi.FLAG_X3_SPLIT_F16 | capi.FLAG_X3_SPLIT_BF16 | capi.FLAG_X3_MX8))
         return self._wide_range_twin
 
     def status(self, stream=None):
@@ -346,7 +347,7 @@ class Engine(object):
         capi.check(self.lib.asv_net_status_async(self._net, C.c_void_p(host_word.data_ptr()), C.c_void_p(stream)), "asv_net_status_async")
 
     def _range_fallback_applies(self):
-        return self.precision_base in ("f32x", "f16x3") and (self.flags & (capi.FLAG_X3_SPLIT_BF16 | capi.FLAG_REF_KERNELS)) == 0
+        return self.precision_base in ("f32x", "f16x3", "f32m") and (self.flags & (capi.FLAG_X3_SPLIT_BF16 | capi.FLAG_REF_KERNELS)) == 0
 
     def _extract_batch(self, mats, max_chunk=10000):
         import torch

@@ -43,7 +43,9 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [os.path.join(REPO, "asv-subtools_amd", "pytorch"), REPO, os.path.join(REPO, "tests")]       # tests/: gate_table.py (checker leg)
 
 # dense MFMA peaks, MI355X_MICROARCH.md.  f32x issues 3 bf16 matrix instructions per product: its roofline is the bf16 one / 3.
-PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3, "f32x": 2500.0 / 3.0}
+# f32m: per product one 16-bit matrix instruction (2500) + both corrections in one block-scaled 8-bit instruction of twice the depth at twice
+# the rate (~5000 dense, MI355X_MICROARCH.md): 1 / (1 / 2500 + 2 / 5000) = 1250.
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3, "f32x": 2500.0 / 3.0, "f32m": 1250.0}
 GATE_REL, GATE_EER = 1e-4, 0.01          # BASELINE.json north_star: embeddings within 1e-4 relative, EER delta < 0.01 % absolute
 
 MODELS = {
@@ -641,7 +643,7 @@ def main():
     if args.streams is None:
         # two engines on two streams fill the CUs a partly filled last round of tiles leaves idle: +12 % for the f32x mode at 256
         # utterances per step too (288 k -> 321 k, profiles/r4e_f32x_streams.txt); at 640 (whole rounds) it costs that mode 3 %
-        one_only = ("f32",) if args.batch <= 320 else ("f32x", "f32")
+        one_only = ("f32",) if args.batch <= 320 else ("f32x", "f32m", "f32")
         args.streams = 2 if (not dry and not args.from_wav and not args.per_op and args.precision.split("-")[0] not in one_only) else 1
     wl2 = [Workload(args, args.model, args.precision, args.batch, args.frames, rank, dev, lengths=lengths) for _ in range(args.streams - 1)] if (args.streams >= 2 and not dry) else None
     head = measure(wl, args.steps, args.warmup, args.min_seconds, not args.no_profile and not dry and wl2 is None, dist_on, per_op=args.per_op, from_wav=args.from_wav, wl2=wl2)
@@ -725,7 +727,7 @@ def main():
             modes gain nothing from it - their steps are one long matrix-bound launch sequence - and run on one), the kernel
             figures from a single-stream pass."""
             steps = steps or args.steps
-            use_two = two and not (f32x_single and prec.split("-")[0] in (("f32",) if (kind == "xvector" and batch <= 320) else ("f32x", "f32")))
+            use_two = two and not (f32x_single and prec.split("-")[0] in (("f32",) if (kind == "xvector" and batch <= 320) else ("f32x", "f32m", "f32")))
             w = Workload(args, kind, prec, batch, frames, rank, dev, lengths=lens)
             w2 = [Workload(args, kind, prec, batch, frames, rank, dev, lengths=lens)] if use_two else None
             r1 = measure(w, steps, 2, min_s, not args.no_profile, False)
@@ -756,7 +758,7 @@ def main():
             res["config"]["batch_note"] = ("`value` is BASELINE configs[1] as stated: 256 utterances per step (408 row tiles of 128 frames on 256 CUs: 1.6 rounds of workgroups "
                                            "per launch); value_at_b640 / roofline_at_b640: the same harness at 640 utterances per step (whole rounds)")
             del w640
-        for prec in ("f16", "f32x", "f32"):
+        for prec in ("f16", "f32m", "f32x", "f32"):
             if prec == args.precision:
                 continue
             rec, w = record("xvector", prec, args.batch, args.frames)
@@ -795,7 +797,7 @@ def main():
         import gate_table
         sup = res["supplementary"]
         rate = {"xvector": {args.precision: res["value"]}, "ecapa": {}, "resnet": {}}
-        for prec in ("f16", "f32x", "f32"):
+        for prec in ("f16", "f32m", "f32x", "f32"):
             if "xvector_" + prec in sup and "value" in sup["xvector_" + prec]:
                 rate["xvector"][prec] = sup["xvector_" + prec]["value"]
         for model, stem in (("ecapa", "ecapa_c3"), ("resnet", "resnet_c5")):
@@ -807,7 +809,7 @@ def main():
             try:
                 t0 = time.perf_counter()
                 g = gate_table.Gates(model, feat_dim=args.feat_dim, device=dev)
-                tab = g.table([p for p in ("f32x", "f16", "bf16") if p in rate[model]], weight_seeds=tuple(range(args.gate_seeds)))
+                tab = g.table([p for p in ("f32x", "f32m", "f16", "bf16") if p in rate[model]], weight_seeds=tuple(range(args.gate_seeds)))
                 del g
                 torch.cuda.empty_cache()
                 m = tab["modes"]

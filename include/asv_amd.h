@@ -74,6 +74,10 @@ int         asv_device_count(int *count);
  * that "two matrix instructions per product are not enough" is a measured statement, DESIGN.md "Precision modes") */
 #define ASV_FLAG_X3_NO_XLO   128u  /* activations rounded to one 16-bit value (no w_hi*x_lo product) */
 #define ASV_FLAG_X3_NO_WLO   256u  /* weights rounded to one 16-bit value (no w_lo*x_hi product)     */
+#define ASV_FLAG_X3_MX8     1024u  /* ASV_PREC_F32X with half halves ("f32m"): the two correction products w_hi*x_lo + w_lo*x_hi run as ONE block-scaled
+                                    * 8-bit matrix instruction per 32 channels (e4m3 weights, e5m2 activations, power-of-two block scales) next to
+                                    * the exact half product w_hi*x_hi: ~1e-5 of the f32 forward instead of ~1e-7, 4 instead of 6 matrix-pipe time
+                                    * units per product.  Kernels without this form run the three half products as before. */
 #define ASV_FLAG_X3_TILE128  512u  /* ASV_PREC_F32X: the split kernel's 128-row tiles whatever the batch size (by default batches too small to
                                     * fill the chip with them take its 64-row tiles); same results to the last bit of the f32 sums' order */
 
@@ -289,6 +293,8 @@ int asv_net_status_async(asv_net_t *net, unsigned *host_status, void *stream);
 #define ASV_KERNEL_TDNN_P8 1     /* kernels_tdnn_p8.hip: 256 x 256 tiles, both operands through LDS-DMA */
 #define ASV_KERNEL_TDNN_P8X 3    /* kernels_tdnn_p8x.hip: the same structure for the f32x mode (f32 rows split in registers) */
 #define ASV_KERNEL_TDNN_BIG3 2   /* kernels_tdnn_v3.hip: 128 x 256 tiles, window through LDS, weight fragments from L2 */
+#define ASV_KERNEL_TDNN_CHAINM 4 /* kernels_tdnn_chainm.hip: the f32x layer chain with its correction products on the scaled 8-bit instruction */
+#define ASV_KERNEL_TDNN_X3M 5    /* kernels_tdnn_x3m.hip: the f32x wide-layer kernel in the same form */
 unsigned long long asv_kernel_launch_count(int which);
 
 /* Bytes of device memory currently held by the net (weights + activation arena). */

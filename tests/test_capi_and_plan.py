@@ -406,3 +406,30 @@ def test_host_half_and_bf16_conversions_match_numpy(tmp_path):
     u = vals.view(np.uint32).astype(np.uint64)
     want_b = ((u + 0x7fff + ((u >> 16) & 1)) >> 16).astype(np.uint16)                                # RNE on the upper 16 bits (no NaN in the set)
     assert np.array_equal(rec["b"], want_b)
+
+
+def test_host_e4m3_conversion_matches_torch(tmp_path):
+    """The f32m form's weight packer rounds the two weight corrections to OCP e4m3 on the host (csrc/host_convert.h f32_to_e4m3_host:
+    round-to-nearest-even, subnormals down to 2^-9, saturating at +-448) - against torch's float8_e4m3fn on values inside its range,
+    the saturation and every one of the 254 finite codes round-tripping."""
+    import subprocess
+    import torch
+    src = tmp_path / "conv8.cc"
+    src.write_text('#include <stdio.h>\n#include "host_convert.h"\nint main() { float f; while (fread(&f, 4, 1, stdin) == 1) { unsigned char b = asv::f32_to_e4m3_host(f); '
+                   'float back = asv::e4m3_to_f32_host(b); fwrite(&b, 1, 1, stdout); fwrite(&back, 4, 1, stdout); } return 0; }\n')
+    exe = tmp_path / "conv8"
+    subprocess.check_call(["g++", "-O1", "-I", os.path.join(helpers.REPO, "asv-subtools_amd", "csrc"), str(src), "-o", str(exe)])
+    r = np.random.RandomState(1)
+    codes = np.array([c for c in range(256) if (c & 0x7f) != 0x7f], dtype=np.uint8)
+    exact = torch.from_numpy(codes).view(torch.float8_e4m3fn).to(torch.float32).numpy()
+    vals = np.concatenate([
+        np.clip((r.randn(20000) * np.exp2(r.randint(-14, 9, 20000))), -447.9, 447.9).astype(np.float32),
+        np.array([0.0, -0.0, 448.0, 447.0, 464.0, 1e9, -1e9, np.inf, 2.0 ** -9, 2.0 ** -10, 2.0 ** -10 * 1.0001, 3 * 2.0 ** -10, 2.0 ** -6, 2.0 ** -6 - 2.0 ** -11,
+                  1.0625, 1.1875, 0.0019, 15.5, 17.0], dtype=np.float32),
+        exact])
+    out = subprocess.run([str(exe)], input=vals.tobytes(), capture_output=True, check=True).stdout
+    rec = np.frombuffer(out, dtype=np.dtype([("b", "u1"), ("back", "<f4")]))
+    want = torch.from_numpy(np.clip(vals, -448.0, 448.0)).to(torch.float8_e4m3fn)
+    assert np.array_equal(rec["b"], want.view(torch.uint8).numpy()), np.flatnonzero(rec["b"] != want.view(torch.uint8).numpy())[:8]
+    assert np.array_equal(rec["back"], want.to(torch.float32).numpy())
+    assert np.array_equal(rec["b"][-len(codes):] & 0x7f, codes & 0x7f) and np.array_equal(rec["back"][-len(codes):], exact)
