@@ -103,6 +103,7 @@ struct TdnnKernelParams {
                         // - its own pointer, so that neither family can ever be handed the other's layout - or nullptr
   const void *wlo;      // pooled-domain layers and the f32x frame kernel: the bf16 'lo' halves (w - hi), same layout as wfrag, or nullptr
   const void *wx3p;     // f32x 8-phase kernel (kernels_tdnn_p8x.hip): [cout_pad][tap][chunk32][hi 32 | lo 32] 16-bit halves of w * 2^s, or nullptr
+  const void *w8;       // f32m form (kernels_tdnn_x3m.hip): 8-bit fragments [w_hi8 | w_lo8] of w * 2^s (pack_tdnn_weight_mx8), or nullptr
   // split-K (small-M layers: the pooled domain): blockIdx.y walks `ksplit` slices of the channel
   // chunks, raw f32 accumulators go to partial[slice][rows][ld_partial]; a second kernel sums
   // the slices in order and applies the epilogue (deterministic, no atomics)
@@ -255,6 +256,9 @@ void pack_tdnn_weight_frags(const float *w, int out_ch, int in_ch, int tot_ctx, 
 bool tdnn_x3_supported(const TdnnKernelParams &p);
 bool tdnn_x3_pool_supported(const TdnnKernelParams &p);      // fused statistics pooling (128-row tiles, plain epilogue)
 int launch_tdnn_x3(const TdnnKernelParams &p, hipStream_t s);
+// the same layers with the correction products on the block-scaled 8-bit matrix instruction ("f32m"; kernels_tdnn_x3m.hip)
+bool tdnn_x3m_supported(const TdnnKernelParams &p);
+int launch_tdnn_x3m(const TdnnKernelParams &p, hipStream_t s);
 size_t tdnn_weight_frag_elems(int cout_pad, int cin_pad, int n_taps);
 int launch_stats_pool(const PoolKernelParams &p, int segments, int et, hipStream_t s);
 // second half of the fused pooling: adds each segment's half-tile partials in row order, adds the BN shift

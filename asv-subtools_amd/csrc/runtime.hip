@@ -102,10 +102,10 @@ void pack_tdnn_weight_x3p(const float *w, int out_ch, int in_ch, int tot_ctx, in
 // lo = w * scale - hi that pack_tdnn_weight_frags splits into, [32-channel output fragment][tap][32-channel input group][K block]
 // [lane = (input sixteen lh, output channel lr)][16]: block 0 = e4m3(hi 2^-6) (hi < 2^14 under x3_weight_scale), block 1 = e4m3(lo 2^6)
 // (|lo| <= 2^-11 |hi|); byte q = input channel 32 group + 16 lh + q.  The kernel's block scales undo the 2^-6 / 2^6.
-size_t tdnn_weight_mx8_bytes(int cout_pad, int cin_pad, int n_taps) { return (size_t)(cout_pad / 32) * n_taps * (cin_pad / 32) * 2048; }
+size_t tdnn_weight_mx8_bytes(int cout_pad, int cin_pad, int n_taps) { return (size_t)(cout_pad / 32) * n_taps * ((cin_pad + 31) / 32) * 2048; }
 void pack_tdnn_weight_mx8(const float *w, int out_ch, int in_ch, int tot_ctx, int left_ctx, const int *taps, int n_taps, int cout_pad, int cin_pad,
                           float scale, uint8_t *dst) {
-  const int ngroups = cin_pad / 32;
+  const int ngroups = (cin_pad + 31) / 32;                    // (a last, partial group is zero-padded: e4m3(0) = 0)
   memset(dst, 0, tdnn_weight_mx8_bytes(cout_pad, cin_pad, n_taps));
   for (int co = 0; co < out_ch; ++co) {
     const int nf = co / 32, lr = co % 32;
@@ -570,7 +570,7 @@ int asv_net_add_tdnn(asv_net_t *net, const asv_tdnn_desc_t *d) {
                              net->x3_et(), op.w_scale);
       if ((rc = dev_upload(net, hi.data(), hi.size() * 2, &op.wfrag))) return rc;
       if ((rc = dev_upload(net, lo.data(), lo.size() * 2, &op.wlo))) return rc;
-      if (net->x3_mx() && op.cin_pad % 32 == 0 && op.cout_pad % 32 == 0) {
+      if (net->x3_mx() && op.cout_pad % 32 == 0) {
         std::vector<uint8_t> w8(tdnn_weight_mx8_bytes(op.cout_pad, op.cin_pad, d->n_taps));
         pack_tdnn_weight_mx8(d->weight, d->out_ch, d->in_ch, d->w_tot_context, d->w_left_context, d->taps, d->n_taps, op.cout_pad, op.cin_pad, op.w_scale, w8.data());
         if ((rc = dev_upload(net, w8.data(), w8.size(), &op.w8))) return rc;
@@ -1264,7 +1264,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         for (int t = 0; t < d.n_taps; ++t) { p.taps[t] = d.taps[t]; p.halo = std::max(p.halo, std::abs(d.taps[t])); }
         p.act1 = d.act1; p.act2 = d.act2; p.affine_first = d.affine_first;
         p.zero16 = net->zero_page;
-        p.wfrag = op.wfrag; p.wlo = op.wlo; p.wconv = op.wconv; p.wx3p = op.wx3p;
+        p.wfrag = op.wfrag; p.wlo = op.wlo; p.wconv = op.wconv; p.wx3p = op.wx3p; p.w8 = op.w8;
         const bool chain_x3 = net->x3();             // f32x: the split-product chain on 64-row tiles (kernels_tdnn_chainx.hip)
         if (op.chain_last >= 0 && !use_ref && (bf16 || chain_x3) && p.halo <= kHalo && (net->flags & ASV_FLAG_SMALL_TILES) == 0 &&
             (chain_x3 || (unsigned long long)p.rows * (unsigned long long)p.ldx * 2ull < (1ull << 32))) {
@@ -1476,6 +1476,13 @@ int run_ops(RunCtx &c, size_t n_ops) {
         const long long p8x_tiles = (long long)(p.rows / 256) * (round_up(p.cout_store, 256) / 256);
         const bool p8x_fill = p8x_on > 1 ? p8x_tiles >= p8x_on : (p8x_tiles >= cus && p8x_tiles * 100 >= ((p8x_tiles + cus - 1) / cus) * cus * 85);
         const bool p8x = x3 && !fuse && p8x_on != 0 && tdnn_p8x_supported(p) && p8x_fill;
+        // f32m: the 128-row kernel with its correction products on the scaled 8-bit instruction, where the three-product kernel would take its
+        // 128-row tiles (ASV_AMD_X3M=0: off).  It also takes the layers of the f32x 8-phase kernel: 4 instead of 6 matrix-pipe time units per
+        // product outweigh that kernel's staging (tdnn2: 163 us here against 227 on either three-product kernel, profiles/r6f_*)
+        static const int x3m_env = getenv("ASV_AMD_X3M") ? atoi(getenv("ASV_AMD_X3M")) : 1;
+        const int x3m_on = live_tune ? (getenv("ASV_AMD_X3M") ? atoi(getenv("ASV_AMD_X3M")) : 1) : x3m_env;
+        const bool x3m = x3 && x3m_on != 0 && net->x3_mx() && tdnn_x3m_supported(p) &&
+                         (long long)(p.rows / 128) * (round_up(p.cout_store, 256) / 256) >= (x3m_on > 1 ? x3m_on : 384);      // (384: where the three-product kernel takes its 128-row tiles)
         if (use_ref) rc = launch_tdnn_ref(p, et, !bf16, c.s);
         else if (utts_kernel) {
           // last layer, every utterance a single chunk: the kernel also produces the caller's [utterance][embed_dim] result
@@ -1493,6 +1500,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         else if (wide_conv) rc = launch_grid_conv_wide(p, c.s);
         else if (s2d_conv) rc = launch_grid_conv_s2d(p, c.s);
         else if (c1_conv) rc = launch_grid_conv_c1(p, c.s);
+        else if (x3 && !fuse && x3m) { rc = launch_tdnn_x3m(p, c.s); ++g_kernel_launches[ASV_KERNEL_TDNN_X3M]; }
         else if (p8x) { rc = launch_tdnn_p8x(p, c.s); ++g_kernel_launches[ASV_KERNEL_TDNN_P8X]; }
         else if (x3) rc = launch_tdnn_x3(p, c.s);
         else if (x3_conv) rc = launch_grid_conv_x3(p, c.s);

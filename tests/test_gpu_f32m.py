@@ -59,7 +59,8 @@ def test_f32m_full_size_batch_against_exact_f32_and_f32x():
     eng = model._amd_engine()
     sub = eng._extract_batch([mats[i] for i in (7, 200, 31)]).numpy()
     for j, i in enumerate((7, 200, 31)):
-        assert rel_err(sub[j], out["f32m"][i]) < 2e-6, (i, rel_err(sub[j], out["f32m"][i]))
+        # (the rows' products are the same whatever the batch; the f32 merge of the per-tile pooled moments moves with the tile boundaries)
+        assert rel_err(sub[j], out["f32m"][i]) < 2e-5, (i, rel_err(sub[j], out["f32m"][i]))
 
 
 def test_f32m_range_watch_and_rerun():
@@ -100,3 +101,95 @@ def test_f32m_range_watch_and_rerun():
     assert eng.status() == 0
     for j, i in enumerate([0, 1, 3, 4, 5]):
         assert rel_err(got[j], want[i]) < 1e-4, i
+
+
+X3M_CASES = [
+    # (cin, cout, context, utterance lengths, activation, affine_first)
+    (512, 512, [-2, 0, 2], [200, 200, 64, 300], "relu", False),           # the x-vector's tdnn2
+    (80, 512, [-2, -1, 0, 1, 2], [200, 100, 7], "relu", False),           # tdnn1: 80 channels = two whole 32-channel groups + half of a third
+    (512, 1500, [0], [200, 100], "relu", False),                          # 1-tap: a new chunk every pair; 1500 of 1536 channels
+    (1024, 1024, [0], [300, 200], None, False),
+    (256, 512, [-2, -1, 0, 1, 2], [1, 511, 3], "relu", False),
+    (96, 200, [-4, -3, 0, 1, 3, 4], [5, 600], None, False),               # taps up to the halo's edge, 200 of 256 channels
+    (32, 256, [0], [129], "relu", False),                                 # ONE pair
+    (160, 384, [-1, 0, 1, 2], [40, 41, 300], "tanh", False),              # the generic epilogue
+    (192, 320, [-1, 0, 1], [300, 5], "relu", True),                       # bn-relu order
+]
+
+
+@pytest.mark.parametrize("case", X3M_CASES, ids=lambda c: "%dx%d_ctx%s_%s%s" % (c[0], c[1], "_".join(map(str, c[2])), c[4], "_bnfirst" if c[5] else ""))
+def test_x3m_kernel_vs_oracle(case, monkeypatch):
+    """kernels_tdnn_x3m.hip through the C ABI, forced onto small batches (ASV_AMD_X3M=2): TdnnAffine + activation + eval BN (components.py:107-149,
+    365-386, 418-431) against the f64 numpy oracle; the launch counter proves the 8-bit kernel took the layer, and the three-product kernel
+    (ASV_AMD_X3M=0) on the same layer is the yardstick: f32m within 3e-5 of the oracle (1e-4 behind a tanh)."""
+    import test_gpu_kernels as K
+    from libs.amd import capi
+    L = capi.lib()
+    cin, cout, ctx, lens, act, affine_first = case
+    r = np.random.RandomState(cin * 11 + cout)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    x = r.randn(int(offsets[-1]), cin).astype(np.float32)
+    left, right = min(0, ctx[0]), max(0, ctx[-1])
+    w = (r.randn(cout, cin, right - left + 1) / np.sqrt(cin * len(ctx))).astype(np.float32)
+    b = (0.1 * r.randn(cout)).astype(np.float32)
+    scale = r.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = (0.2 * r.randn(cout)).astype(np.float32)
+    monkeypatch.setenv("ASV_AMD_LIVE_TUNE", "1")
+    monkeypatch.setenv("ASV_AMD_P8X", "0")
+    monkeypatch.setenv("ASV_AMD_X3M", "2")
+    n0 = L.asv_kernel_launch_count(capi.KERNEL_TDNN_X3M)
+    got = K._tdnn_forward(x, offsets, w, b, ctx, act, scale, shift, affine_first, capi.PREC_F32X, capi.FLAG_X3_MX8)
+    assert L.asv_kernel_launch_count(capi.KERNEL_TDNN_X3M) == n0 + 1, "the 8-bit correction kernel did not take this layer"
+    monkeypatch.setenv("ASV_AMD_X3M", "0")
+    ref = K._tdnn_forward(x, offsets, w, b, ctx, act, scale, shift, affine_first, capi.PREC_F32X, capi.FLAG_X3_MX8)
+    assert L.asv_kernel_launch_count(capi.KERNEL_TDNN_X3M) == n0 + 1
+    want = K._oracle_layer(x, offsets, w, b, ctx, act, scale, shift, affine_first)
+    e_m, e_x = rel_err(got, want), rel_err(ref, want)
+    print("[x3m] %s: f32m %.3g, three half products %.3g of the oracle" % (case[:3], e_m, e_x))
+    # measured on the device: 1.5 - 1.9e-5 for every plain layer (0.5 - 0.9e-6 with three half products); tanh compresses max |y| to ~1.5 and
+    # keeps the pre-activation error near 0: 5.3e-5
+    assert np.isfinite(got).all() and e_m < (1e-4 if act == "tanh" else 3e-5) and e_x < 3e-6, (e_m, e_x)
+
+
+def test_x3m_is_the_kernel_of_the_xvector_wide_layers(monkeypatch):
+    """Production dispatch in the f32m form at configs[1]'s batch: tdnn1 and tdnn2 go to kernels_tdnn_x3m.hip, the chain to
+    kernels_tdnn_chainm.hip; in the plain f32x mode neither runs."""
+    import torch
+    from libs.amd import capi, synth
+    monkeypatch.setenv("ASV_AMD_LIVE_TUNE", "1")
+    monkeypatch.setenv("ASV_AMD_X3M", "1")
+    L = capi.lib()
+    model = helpers.build_model("xvector.py", "Xvector(80,10,training=False)")
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 0).items()})
+    model.cuda()
+    mats = [synth.synth_feats(200, 80, 3000 + i) for i in range(256)]
+    for prec, want in (("f32m", (2, 1)), ("f32x", (0, 0))):
+        model.amd_precision = prec
+        a, b = L.asv_kernel_launch_count(capi.KERNEL_TDNN_X3M), L.asv_kernel_launch_count(capi.KERNEL_TDNN_CHAINM)
+        model._amd_engine()._extract_batch(mats)
+        assert (L.asv_kernel_launch_count(capi.KERNEL_TDNN_X3M) - a, L.asv_kernel_launch_count(capi.KERNEL_TDNN_CHAINM) - b) == want, prec
+
+
+@pytest.mark.parametrize("name", ["ecapa_c3", "ecapa_launcher", "ecapa_c512_near_affine", "resnet34se_c5"])
+def test_other_models_in_the_f32m_form_vs_reference_golden(name):
+    """ECAPA-TDNN's wide layers (1-tap C -> C, 3C -> 1536, the 5-tap input layer) run on kernels_tdnn_x3m.hip in this form (from the production
+    tile count on: forced here onto the small golden batches with ASV_AMD_X3M=2), its 128-channel branches and the ResNet's 2-D convolutions stay on their three-product kernels: the mode must
+    be inside the gate on every model it can be selected for."""
+    import os
+    from libs.amd import capi
+    L = capi.lib()
+    os.environ["ASV_AMD_LIVE_TUNE"] = "1"
+    os.environ["ASV_AMD_X3M"] = "2"
+    try:
+        g, sd, model = _model(name)
+        n0 = L.asv_kernel_launch_count(capi.KERNEL_TDNN_X3M)
+        got = model.extract_embedding_batch(helpers.golden_feats(g)).numpy()
+        ran = L.asv_kernel_launch_count(capi.KERNEL_TDNN_X3M) - n0
+    finally:
+        os.environ.pop("ASV_AMD_X3M", None)
+        os.environ.pop("ASV_AMD_LIVE_TUNE", None)
+    worst = max(rel_err(got[i], g["embeddings"][i]) for i in range(len(got)))
+    print("[f32m] %s: worst embedding error vs the reference %.3g (%d launches of the 8-bit kernel)" % (name, worst, ran))
+    assert worst < 1e-4 and np.isfinite(got).all()
+    assert ran > 0 or name.startswith("resnet")

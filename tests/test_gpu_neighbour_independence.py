@@ -30,8 +30,13 @@ pytestmark = pytest.mark.gpu
 # by the f32 order in which per-tile partial sums are merged (tile boundaries move with the batch), never by the operands.
 TOL_ORACLE = {"f32": 1e-4, "f32x-bf16": 1e-4, "f32x": 1e-4, "bf16": 3e-2, "f16": 5e-3}
 TOL_ALONE = {"f32": 2e-5, "f32x-bf16": 2e-5, "f32x": 2e-5, "bf16": 2e-3, "f16": 5e-4}
-# a 1e5 x scaled utterance against the f64 oracle: its own f32 cancellations (sum a x^2 - mean^2 at 1e10) are the reference's too
-TOL_SCALED = {"f32": 2e-3, "f32x-bf16": 2e-3, "f32x": 2e-3, "bf16": 6e-2, "f16": None}
+# a 1e5 x scaled utterance against the f64 oracle: its own f32 cancellations (sum a x^2 - mean^2 at 1e10) are the reference's too.
+# None = not compared: the ResNet at that input scale is ill-conditioned for 8-bit significands whatever its neighbours are - the BatchNorm
+# shifts vanish beside 1e5-scale activations, nothing re-centres them and every convolution carries a large common component (measured
+# alone, profiles/r6b_resnet_scale_diag.txt: bf16 1.4e-2 at scale 1, 8e-2 at 10, 0.15 at 100, 0.44 from 1e3 on, bit-identical alone and
+# beside; f32 and f32x-bf16 stay at 1e-6 .. 1e-5).  Such an utterance must still be finite and the SAME alone and beside (checked below).
+TOL_SCALED = {"ecapa": {"f32": 2e-3, "f32x-bf16": 2e-3, "f32x": 2e-3, "bf16": 6e-2},
+              "resnet": {"f32": 2e-3, "f32x-bf16": 2e-3, "f32x": 2e-3, "bf16": None}}
 
 MODELS = {
     "ecapa": ("ecapa_c512_near_affine", lambda O, sd: (lambda c: O.ecapa_embed(c, sd, "near_affine", "relu"))),
@@ -70,9 +75,10 @@ def _setup(kind):
 def _check(kind, prec, got, order, want):
     for j, i in enumerate(order):
         scaled = BATCH[kind][i][2] != 1.0
-        tol = TOL_SCALED[prec] if scaled else TOL_ORACLE[prec]
+        tol = TOL_SCALED[kind][prec] if scaled else TOL_ORACLE[prec]
         assert np.isfinite(got[j]).all(), (kind, prec, order, i)
-        assert rel_err(got[j], want[i]) < tol, (kind, prec, order, i, "scaled" if scaled else "neighbour", rel_err(got[j], want[i]))
+        if tol is not None:
+            assert rel_err(got[j], want[i]) < tol, (kind, prec, order, i, "scaled" if scaled else "neighbour", rel_err(got[j], want[i]))
 
 
 @pytest.mark.parametrize("prec", ["f32", "f32x-bf16", "bf16"])
@@ -84,12 +90,12 @@ def test_every_utterance_matches_the_oracle_beside_huge_neighbours(kind, prec):
     for order in ORDERS[kind]:
         got = eng._extract_batch([mats[i] for i in order]).numpy()
         _check(kind, prec, got, order, want)
-    # alone against beside, for every unscaled utterance of the first order
+    # alone against beside, for every utterance of the first order (the scaled ones too: whatever their own conditioning, they may not
+    # depend on their neighbours either)
     full = eng._extract_batch(mats).numpy()
-    for i, (_, _, scale) in enumerate(BATCH[kind]):
-        if scale == 1.0:
-            alone = eng._extract_batch([mats[i]]).numpy()[0]
-            assert rel_err(full[i], alone) < TOL_ALONE[prec], (kind, prec, i, rel_err(full[i], alone))
+    for i in range(len(mats)):
+        alone = eng._extract_batch([mats[i]]).numpy()[0]
+        assert rel_err(full[i], alone) < TOL_ALONE[prec], (kind, prec, i, rel_err(full[i], alone))
 
 
 @pytest.mark.parametrize("prec", ["f32x-bf16", "bf16"])
