@@ -43,12 +43,15 @@ def parse_precision(name):
 
 
 def default_precision():
-    """'f32x' (the default): f32 storage, matrix products on the 16-bit cores with both operands split into hi + lo halves
-    (IEEE half since round 3: 22 significant bits per operand) - within the reference's 1e-4 embedding gate and the 0.01 % EER
-    gate at ~3x the rate of 'f32' (exact f32-input MFMA, the bit-for-bit fma chain); 'bf16' / 'f16' are the throughput modes
-    (16-bit storage and products, f32 accumulate, f32 pooled tail; 'f16' rounds 8x finer at the same rate, operands within
-    +-65504; their measured distance from the gates: tests/test_gpu_eer_gate.py, DESIGN.md "Precision modes")."""
-    return os.environ.get("ASV_AMD_PRECISION", "f32x").lower()
+    """'f32m' (the default since round 6): f32 storage, matrix products on the matrix cores from operands split into IEEE-half hi + lo halves
+    (22 significant bits per operand) - the main product w_hi x_hi on the 16-bit instruction, the two corrections w_hi x_lo + w_lo x_hi as ONE
+    block-scaled 8-bit instruction per 32 channels (kernels_tdnn_chainm.hip / kernels_tdnn_x3m.hip; kernels without that form run all three
+    products on the 16-bit instruction): ~1e-5 of the reference's embeddings, inside the 1e-4 gate and the 0.01 % EER gate on every draw of
+    tests/gate_table.py, at 1.35 x the rate of 'f32x' on the x-vector.  'f32x': all three products on the 16-bit instruction (~1e-7; ~3 x the
+    rate of 'f32', the exact f32-input MFMA and bit-for-bit fma chain).  'bf16' / 'f16' are the throughput modes (16-bit storage and products,
+    f32 accumulate, f32 pooled tail; 'f16' rounds 8x finer at the same rate, operands within +-65504; their measured distance from the
+    gates: tests/test_gpu_eer_gate.py, DESIGN.md "Precision modes")."""
+    return os.environ.get("ASV_AMD_PRECISION", "f32m").lower()
 
 
 def default_flags():

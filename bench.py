@@ -181,7 +181,7 @@ def parse():
     ap.add_argument("--no-supplementary", action="store_true", help="skip the b640 / f32x / f32 / ECAPA / ResNet / ark->ark sub-records")
     ap.add_argument("--ark-utts", type=int, default=50000,
                     help="utterances of the supplementary ark -> ark record (the extraction SCRIPT on a synthetic archive read from the page cache: "
-                         "stream and --sharded paths, f32x and the headline mode; 0 = skip; tools/bench_pipeline.py runs the same at 50 000)")
+                         "stream and --sharded paths, f32m (the scripts' default) and the headline mode; 0 = skip; tools/bench_pipeline.py runs the same at 50 000)")
     ap.add_argument("--event-stride", type=int, default=8, help="record the per-GEMM hipEvents on every k-th timed step")
     ap.add_argument("--per-op", action="store_true", help="also print a per-op timing table to stderr")
     ap.add_argument("--settle-seconds", type=float, default=0.5,
@@ -767,7 +767,7 @@ def main():
             sup["xvector_" + prec] = rec
             modes[prec] = {"value": rec["value"], "gate_1e-4": rec["parity"]["gate_1e-4"], "eer_gate": rec["parity"].get("eer_gate")}
             del w
-        for kind, key, frames, prec, lens in (("ecapa", "ecapa_c3", 300, args.precision, None), ("ecapa", "ecapa_c3_f16", 300, "f16", None), ("ecapa", "ecapa_c3_f32x", 300, "f32x", None),
+        for kind, key, frames, prec, lens in (("ecapa", "ecapa_c3", 300, args.precision, None), ("ecapa", "ecapa_c3_f16", 300, "f16", None), ("ecapa", "ecapa_c3_f32x", 300, "f32x", None), ("ecapa", "ecapa_c3_f32m", 300, "f32m", None),
                                               ("resnet", "resnet_c5_t200", 200, args.precision, None), ("resnet", "resnet_c5", 600, args.precision, (200, 1000)),
                                               ("resnet", "resnet_c5_f16", 600, "f16", (200, 1000)), ("resnet", "resnet_c5_f32x", 600, "f32x", (200, 1000))):
             try:
@@ -785,7 +785,7 @@ def main():
             try:
                 sys.path.insert(0, os.path.join(REPO, "tools"))
                 import bench_pipeline
-                sup["ark_to_ark"] = bench_pipeline.measure(args.ark_utts, 200, tuple(dict.fromkeys(("f32x", args.precision))), ("stream", "sharded"),
+                sup["ark_to_ark"] = bench_pipeline.measure(args.ark_utts, 200, tuple(dict.fromkeys(("f32m", args.precision))), ("stream", "sharded"),
                                                            directory=os.path.join("/tmp", "asv_pipe_%d" % os.getpid()))
             except Exception as e:                                        # a supplementary record must never take the headline down
                 sup["ark_to_ark"] = {"error": "%s: %s" % (type(e).__name__, e)}
@@ -801,7 +801,7 @@ def main():
             if "xvector_" + prec in sup and "value" in sup["xvector_" + prec]:
                 rate["xvector"][prec] = sup["xvector_" + prec]["value"]
         for model, stem in (("ecapa", "ecapa_c3"), ("resnet", "resnet_c5")):
-            for prec, key in ((args.precision, stem), ("f16", stem + "_f16"), ("f32x", stem + "_f32x")):
+            for prec, key in ((args.precision, stem), ("f16", stem + "_f16"), ("f32x", stem + "_f32x"), ("f32m", stem + "_f32m")):
                 if key in sup and "value" in sup[key]:
                     rate[model][prec] = sup[key]["value"]
         grade = {}

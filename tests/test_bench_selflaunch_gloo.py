@@ -65,6 +65,6 @@ def test_compact_line_of_a_full_device_record_stays_small():
         assert k in rec["roofline"], k
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in rec["cpu_baseline"], k
-    for k in ("ecapa_c3", "ecapa_c3_f32x", "resnet_c5", "resnet_c5_f32x", "xvector_f32x", "ark_stream_f32x", "ark_sharded_f32x"):
+    for k in ("ecapa_c3", "ecapa_c3_f32x", "resnet_c5", "resnet_c5_f32x", "xvector_f32x", "ark_stream_f32x", "ark_sharded_f32x"):        # (r5y: the record of the round before f32m)
         assert k in rec["supplementary"], k
     assert all(not isinstance(v, list) or len(v) <= 2 for sub in rec["supplementary"].values() for v in sub.values())

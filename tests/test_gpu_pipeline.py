@@ -167,7 +167,7 @@ def test_script_range_guard_huge_features(tmp_path, mode):
     script = os.path.join(helpers.REPO, "asv-subtools_amd", "pytorch", "pipeline", "onestep", "extract_embeddings.py")
     extra = ["--sharded", "true"] if mode == "sharded" else []
     rspec = "ark:%s" % feats_ark if mode == "ark" else "scp:%s" % feats_scp
-    env = {k: v for k, v in os.environ.items() if k != "ASV_AMD_PRECISION"}          # the default mode: f32x
+    env = {k: v for k, v in os.environ.items() if k != "ASV_AMD_PRECISION"}          # the default mode (f32m since round 6; the same range guard and twin as f32x)
     res = subprocess.run([sys.executable, "-W", "always", script, "--nnet-config", str(cfg), "--use-gpu", "true", "--gpu-id", "0", "--batch-frames", "700"] + extra +
                          [str(params), rspec, "ark:%s" % out_ark], capture_output=True, text=True, env=env, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
