@@ -141,3 +141,51 @@ int64_t asv_io_pack_vec_ark(int n, int dim, const char *keys, const float *vecto
   }
   return used;
 }
+
+int64_t asv_io_parse_scp(const char *buf, int64_t len, int64_t cap, int64_t *key_off, int32_t *key_len, int64_t *rx_off, int32_t *rx_len,
+                         int32_t *path_id, int64_t *offset, int32_t path_cap, int64_t *path_off, int32_t *path_len, int32_t *n_paths) {
+  int64_t n = 0, pos = 0;
+  int32_t np = 0, last = -1;
+  while (pos < len) {
+    int64_t eol = pos;
+    while (eol < len && buf[eol] != '\n') ++eol;
+    int64_t a = pos, b = eol;                            /* the line without surrounding white space */
+    while (a < b && (buf[a] == ' ' || buf[a] == '\t' || buf[a] == '\r')) ++a;
+    while (b > a && (buf[b - 1] == ' ' || buf[b - 1] == '\t' || buf[b - 1] == '\r')) --b;
+    pos = eol + 1;
+    if (a == b) continue;                                /* blank line */
+    if (n == cap) return -1;
+    int64_t ke = a;
+    while (ke < b && buf[ke] != ' ' && buf[ke] != '\t') ++ke;
+    int64_t rs = ke;
+    while (rs < b && (buf[rs] == ' ' || buf[rs] == '\t')) ++rs;
+    key_off[n] = a; key_len[n] = (int32_t)(ke - a);
+    rx_off[n] = rs; rx_len[n] = (int32_t)(b - rs);
+    path_id[n] = -1; offset[n] = 0;
+    /* plain form: path ':' digits (range specifiers end in ']', pipes in '|': neither ends in a digit run behind a colon) */
+    int64_t d = b;
+    while (d > rs && buf[d - 1] >= '0' && buf[d - 1] <= '9') --d;
+    if (d < b && d > rs + 1 && buf[d - 1] == ':' && b - d <= 18) {
+      int64_t v = 0;
+      for (int64_t q = d; q < b; ++q) v = v * 10 + (buf[q] - '0');
+      const int64_t po = rs;
+      const int32_t pl = (int32_t)(d - 1 - rs);
+      int32_t id = -1;
+      if (last >= 0 && path_len[last] == pl && memcmp(buf + path_off[last], buf + po, (size_t)pl) == 0) id = last;
+      else {
+        for (int32_t k = 0; k < np; ++k)
+          if (path_len[k] == pl && memcmp(buf + path_off[k], buf + po, (size_t)pl) == 0) { id = k; break; }
+        if (id < 0) {
+          if (np == path_cap) return -1;
+          path_off[np] = po; path_len[np] = pl;
+          id = np++;
+        }
+      }
+      last = id;
+      path_id[n] = id; offset[n] = v;
+    }
+    ++n;
+  }
+  *n_paths = np;
+  return n;
+}

@@ -37,8 +37,34 @@ def lib():
             if L.asv_io_version() >= 2:
                 L.asv_io_pack_vec_ark.restype = C.c_int64
                 L.asv_io_pack_vec_ark.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+            if L.asv_io_version() >= 3:
+                L.asv_io_parse_scp.restype = C.c_int64
+                L.asv_io_parse_scp.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
             _LIB = L
     return _LIB or None
+
+
+def parse_scp(data, path_cap=4096):
+    """One native pass over the bytes of a Kaldi scp table (asv_io_parse_scp): dict of arrays key_off / key_len / rx_off / rx_len (spans in
+    `data`), path_id (-1: not of the plain 'path:offset' form), offset, and `paths` (the distinct path strings); None when the library
+    is too old or a capacity is exceeded (the caller parses in Python)."""
+    import numpy as np
+    L = lib()
+    if L is None or L.asv_io_version() < 3:
+        return None
+    cap = data.count(b"\n") + 1
+    key_off, rx_off, offset = (np.empty(cap, dtype=np.int64) for _ in range(3))
+    key_len, rx_len, path_id = (np.empty(cap, dtype=np.int32) for _ in range(3))
+    path_off, path_len = np.empty(path_cap, dtype=np.int64), np.empty(path_cap, dtype=np.int32)
+    n_paths = C.c_int32(0)
+    n = int(L.asv_io_parse_scp(data, len(data), cap, key_off.ctypes.data, key_len.ctypes.data, rx_off.ctypes.data, rx_len.ctypes.data, path_id.ctypes.data,
+                               offset.ctypes.data, path_cap, path_off.ctypes.data, path_len.ctypes.data, C.byref(n_paths)))
+    if n < 0:
+        return None
+    paths = [data[int(path_off[k]):int(path_off[k]) + int(path_len[k])].decode("latin1") for k in range(n_paths.value)]
+    return {"n": n, "key_off": key_off[:n], "key_len": key_len[:n], "rx_off": rx_off[:n], "rx_len": rx_len[:n], "path_id": path_id[:n], "offset": offset[:n],
+            "paths": paths}
 
 
 def pack_vec_ark(keys, vectors, as_array=False):

@@ -150,13 +150,21 @@ def extract_stream(model, r, w, batch_frames, batch_utts, max_chunk, verbose=Fal
 
 
 def _reader_threads():
-    """Native reader threads per process (ASV_AMD_READER_THREADS; default 8, at most the cores this process may run on): positioned
-    reads from the page cache scale to ~8 threads (203 k / 213 k utterances/s on 4 / 8 on the build host, row "a16, e (host side)")."""
+    """Native reader threads per process: ASV_AMD_READER_THREADS, else 8 for one or two ranks on the host and 4 from three ranks on
+    (WORLD_SIZE / LOCAL_WORLD_SIZE), at most the cores this process may run on.  Positioned reads from the page cache scale to ~8 threads
+    for one process (186 k utterances/s of 200 x 80 f32 on 8 threads against 172 k on 4 and 92 k on one, on the GPU box's 256-core host);
+    with 4 - 8 ranks reading at once 4 threads per rank give the best aggregate and 8 lose 6 - 16 % (tools/bench_loaders.py,
+    profiles/r6*_loaders*.txt)."""
     try:
         cores = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         cores = os.cpu_count() or 1
-    return max(1, min(int(os.environ.get("ASV_AMD_READER_THREADS", "8")), cores))
+    try:
+        ranks = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    except ValueError:
+        ranks = 1
+    default = 8 if ranks <= 2 else 4
+    return max(1, min(int(os.environ.get("ASV_AMD_READER_THREADS", str(default))), cores))
 
 
 def _report_loop(path, n, seconds, sets, spent=None):
@@ -173,20 +181,74 @@ def _report_loop(path, n, seconds, sets, spent=None):
 _SCP_PREFIX = re.compile(r"^scp(,[a-z_,]*)?:")
 
 
+class ScpTable(object):
+    """The entries of a Kaldi scp table as a read-only sequence of (key, rxfile) tuples over ONE native parse of the file's bytes
+    (libasv_io.so asv_io_parse_scp): the tuples are made when asked for.  Every rank of a --sharded run walks the WHOLE table - it needs
+    every length to balance the shards - and as a Python list of tuples + a per-entry parse in ScpBatchLoader.index_all that was
+    0.12 - 0.18 s per 50 000 entries and rank: the part of the host work that did not scale with the ranks (tools/bench_loaders.py,
+    profiles/r6h_loaders_before.txt).  `plain_index()` hands the loader the parsed 'path:offset' arrays."""
+
+    def __init__(self, data, parsed):
+        self._data, self._p, self._n = data, parsed, int(parsed["n"])
+
+    def __len__(self):
+        return self._n
+
+    def _entry(self, i):
+        p, d = self._p, self._data
+        a, b = int(p["key_off"][i]), int(p["rx_off"][i])
+        return d[a:a + int(p["key_len"][i])].decode("latin1"), d[b:b + int(p["rx_len"][i])].decode("latin1")
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._entry(k) for k in range(*i.indices(self._n))]
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        return self._entry(i)
+
+    def __iter__(self):
+        return (self._entry(i) for i in range(self._n))
+
+    def __eq__(self, other):                               # (a sequence of tuples: equal to the list the Python parse returns)
+        try:
+            return len(other) == self._n and all(x == tuple(y) for x, y in zip(self, other))
+        except TypeError:
+            return NotImplemented
+
+    __hash__ = None
+
+    def keys(self, a=0, b=None):
+        """The keys of entries [a, b) (what rank 0 writes a segment's vectors under)."""
+        p, d = self._p, self._data
+        b = self._n if b is None else b
+        return [d[int(o):int(o) + int(l)].decode("latin1") for o, l in zip(p["key_off"][a:b], p["key_len"][a:b])]
+
+    def plain_index(self):
+        """(path id per entry or -1, byte offset per entry, the distinct paths) of the entries of the plain form 'path:offset'."""
+        return self._p["path_id"], self._p["offset"], self._p["paths"]
+
+
 def read_scp(path):
-    """[(key, rxfile)] of a Kaldi scp rspecifier: 'scp:feats.scp', with options ('scp,p:', 'scp,s,cs:' - accepted and ignored, like
-    the reference's read_mat_scp), 'scp:-' (stdin), 'scp:cmd |' (a pipe), .gz; the prefix is optional."""
+    """The (key, rxfile) entries of a Kaldi scp rspecifier: 'scp:feats.scp', with options ('scp,p:', 'scp,s,cs:' - accepted and ignored,
+    like the reference's read_mat_scp), 'scp:-' (stdin), 'scp:cmd |' (a pipe), .gz; the prefix is optional.  A ScpTable (one native
+    parse) when libasv_io.so is there, else a list of tuples - the same sequence either way."""
     m = _SCP_PREFIX.match(path)
     name = path[m.end():] if m else path
     if name.strip() == "-":
-        lines = sys.stdin.read().splitlines()
+        data = sys.stdin.buffer.read() if hasattr(sys.stdin, "buffer") else sys.stdin.read().encode("latin1")
     else:
         fd = kaldi_io.open_or_fd(name.strip(), "rb")
         try:
-            lines = fd.read().decode("latin1").splitlines()
+            data = fd.read()
         finally:
             fd.close()
-    return [tuple(line.strip().split(None, 1)) for line in lines if line.strip()]
+    from libs.support import native_io
+    parsed = native_io.parse_scp(data) if native_io.lib() is not None else None
+    if parsed is not None:
+        return ScpTable(data, parsed)
+    return [tuple(line.strip().split(None, 1)) for line in data.decode("latin1").splitlines() if line.strip()]
 
 
 _RANGE = re.compile(r"\[([0-9]*):?([0-9]*)(?:,([0-9]*):?([0-9]*))?\]$")
@@ -361,23 +423,37 @@ class ScpBatchLoader(object):
         if native_io.lib() is None:
             return False
         n = len(self.entries)
-        files, ids, cand, c_fid, c_off = [], {}, [], [], []
-        for i, (_, rx) in enumerate(self.entries):
-            path, sep, o = rx.rpartition(":")
-            if not sep or not o.isdigit():                # (range specifiers end in ']', pipes in '|': neither is all digits)
-                continue
-            j = ids.get(path)
-            if j is None:
-                j = ids[path] = len(files) if os.path.isfile(path) else -1
-                if j >= 0:
+        if hasattr(self.entries, "plain_index"):
+            # the table was parsed natively (ScpTable): path ids and offsets are arrays already - no per-entry Python
+            pid, poff, paths = self.entries.plain_index()
+            remap = np.full(len(paths) + 1, -1, dtype=np.int32)          # (slot -1 = "not plain": stays -1)
+            files = []
+            for k, path in enumerate(paths):
+                if os.path.isfile(path):
+                    remap[k] = len(files)
                     files.append(path)
-            if j >= 0:
-                cand.append(i)
-                c_fid.append(j)
-                c_off.append(int(o))
-        fid, off = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int64)
-        fid[cand], off[cand] = c_fid, c_off
-        if not cand or len(files) > self.max_open:
+            fid_all = remap[pid]                                          # pid = -1 indexes the last slot
+            cand = np.flatnonzero(fid_all >= 0).astype(np.int64)
+            fid, off = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int64)
+            fid[cand], off[cand] = fid_all[cand], poff[cand]
+        else:
+            files, ids, cand, c_fid, c_off = [], {}, [], [], []
+            for i, (_, rx) in enumerate(self.entries):
+                path, sep, o = rx.rpartition(":")
+                if not sep or not o.isdigit():                # (range specifiers end in ']', pipes in '|': neither is all digits)
+                    continue
+                j = ids.get(path)
+                if j is None:
+                    j = ids[path] = len(files) if os.path.isfile(path) else -1
+                    if j >= 0:
+                        files.append(path)
+                if j >= 0:
+                    cand.append(i)
+                    c_fid.append(j)
+                    c_off.append(int(o))
+            fid, off = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int64)
+            fid[cand], off[cand] = c_fid, c_off
+        if len(cand) == 0 or len(files) > self.max_open:
             return False
         cand = np.asarray(cand, dtype=np.int64)
         keep = set(files)
@@ -600,7 +676,9 @@ def extract_sharded_scp(extract_batch, entries, lengths, w, batch_frames, batch_
     from libs.amd import shard
     rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
     load = loader if loader is not None else ScpBatchLoader(entries, threads=_reader_threads())
-    keys = [k for k, _ in entries]
+    # (only rank 0 writes: the keys of a segment are made when it is written - 50 000 tuples up front on every rank were part of the
+    #  per-rank cost that does not shrink with the number of ranks)
+    keys_of = entries.keys if hasattr(entries, "keys") and not isinstance(entries, dict) else (lambda a, b: [k for k, _ in entries[a:b]])
     todo, failed = queue.Queue(), []
 
     def write_segments():
@@ -612,10 +690,11 @@ def extract_sharded_scp(extract_batch, entries, lengths, w, batch_frames, batch_
             if failed:
                 continue
             try:
+                seg_keys = keys_of(a, b)
                 if verbose:
-                    for key in keys[a:b]:
+                    for key in seg_keys:
                         print("Process utterance for key {0}".format(key))
-                w.write(kaldi_io.vec_flt_ark_bytes(keys[a:b], emb.cpu().numpy(), as_buffer=True))
+                w.write(kaldi_io.vec_flt_ark_bytes(seg_keys, emb.cpu().numpy(), as_buffer=True))
             except Exception as e:                       # re-raised on the caller's thread below
                 failed.append(e)
 

@@ -13,7 +13,7 @@
 extern "C" {
 #endif
 
-#define ASV_IO_VERSION 2
+#define ASV_IO_VERSION 3
 int asv_io_version(void);
 
 /* n positioned reads: nbytes[i] bytes of descriptor fd[i] from file offset off[i] into dst[i], split over `threads` worker
@@ -38,6 +38,16 @@ int64_t asv_io_scan_ark(int fd, int64_t start, int64_t cap, int64_t *payload_off
  * trailing separator needed, NUL-terminated).  Returns the bytes written, or -1 when out_cap is too small
  * (exact size: sum of key lengths + n * (11 + 4 * dim)). */
 int64_t asv_io_pack_vec_ark(int n, int dim, const char *keys, const float *vectors, int64_t ld, char *out, int64_t out_cap);
+
+/* (version 3) The text of a Kaldi scp table - one entry per non-blank line, `key WS rxfile`, what the reference reads one line at a time
+ * (/root/reference/pytorch/libs/support/kaldi_io.py read_mat_scp) - parsed in one pass: for entry i (at most `cap`) the spans of its key and
+ * rxfile in buf, and, when the rxfile has the plain form `path:digits`, path_id[i] = index of `path` among the distinct paths in order of first
+ * appearance (their spans: path_off / path_len, at most path_cap; *n_paths of them) and offset[i] = the number; otherwise path_id[i] = -1
+ * (range specifiers, pipes, bare files: the caller's generic reader).  Returns the number of entries, or -1 when cap / path_cap is too
+ * small.  Why: with N ranks on one host every rank walks the WHOLE table (it needs every length to balance the shards) - in Python that
+ * was 0.12 - 0.18 s per 50 000 entries and rank, the part of --sharded that did not scale (tools/bench_loaders.py). */
+int64_t asv_io_parse_scp(const char *buf, int64_t len, int64_t cap, int64_t *key_off, int32_t *key_len, int64_t *rx_off, int32_t *rx_len,
+                         int32_t *path_id, int64_t *offset, int32_t path_cap, int64_t *path_off, int32_t *path_len, int32_t *n_paths);
 
 #ifdef __cplusplus
 }

@@ -669,7 +669,7 @@ def test_libasv_io_exports_what_its_header_declares():
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     header = open(os.path.join(repo, "include", "asv_io.h")).read()
     names = sorted(set(re.findall(r"\b(asv_io_[a-z_]+)\s*\(", header)))
-    assert names == ["asv_io_last_errno", "asv_io_pack_vec_ark", "asv_io_pread_batch", "asv_io_scan_ark", "asv_io_version"]
+    assert names == ["asv_io_last_errno", "asv_io_pack_vec_ark", "asv_io_parse_scp", "asv_io_pread_batch", "asv_io_scan_ark", "asv_io_version"]
     L = ctypes.CDLL(native_io.library_path())
     for n in names:
         assert hasattr(L, n), n
@@ -823,3 +823,68 @@ def test_vector_ark_buffer_goes_through_files_gzip_and_pipes(tmp_path):
             w.write(blob)
         got = list(kaldi_io.read_vec_flt_ark(path))
         assert [k for k, _ in got] == keys and np.array_equal(np.stack([x for _, x in got]), v), spec
+
+
+def test_native_scp_parse_matches_the_python_parse(tmp_path):
+    """read_scp returns a ScpTable over ONE native parse (libasv_io.so asv_io_parse_scp): the same (key, rxfile) sequence as the per-line
+    Python parse for every form a Kaldi table holds - plain 'file:offset', range specifiers, pipes, bare files, tabs, CRLF, blank lines,
+    trailing white space, no final newline - and `plain_index()` names exactly the 'path:digits' entries."""
+    ee = _load_extract_script()
+    from libs.support import native_io
+    assert native_io.lib() is not None and native_io.lib().asv_io_version() >= 3
+    text = ("utt1 /data/a.ark:11\n"
+            "utt2\t/data/a.ark:6411  \r\n"
+            "\n"
+            "   \n"
+            "utt3 /data/b.ark:5[0:9]\n"
+            "utt4 gunzip -c /data/c.ark.gz |\n"
+            "utt5 /data/plain_matrix.txt\n"
+            "utt6 /data/b.ark:123456789012\n"
+            "utt7   /data/a.ark:0\n"
+            "utt8 /data/with:colon.ark:77\n"
+            "utt9 /data/a.ark:12x\n"
+            "utt10 C:44")
+    path = tmp_path / "t.scp"
+    path.write_bytes(text.encode("latin1"))
+    table = ee.read_scp("scp:" + str(path))
+    assert isinstance(table, ee.ScpTable)
+    want = [tuple(line.strip().split(None, 1)) for line in text.splitlines() if line.strip()]
+    assert len(table) == len(want) == 10
+    assert list(table) == want and [table[i] for i in range(len(want))] == want and table[2:5] == want[2:5] and table[-1] == want[-1]
+    assert table.keys() == [k for k, _ in want] and table.keys(3, 6) == [k for k, _ in want[3:6]]
+    pid, off, paths = table.plain_index()
+    plain = {"utt1": ("/data/a.ark", 11), "utt2": ("/data/a.ark", 6411), "utt6": ("/data/b.ark", 123456789012), "utt7": ("/data/a.ark", 0),
+             "utt8": ("/data/with:colon.ark", 77), "utt10": ("C", 44)}
+    for i, (k, _) in enumerate(want):
+        if k in plain:
+            assert pid[i] >= 0 and (paths[pid[i]], int(off[i])) == plain[k], k
+        else:
+            assert pid[i] == -1, k
+    assert paths == ["/data/a.ark", "/data/b.ark", "/data/with:colon.ark", "C"]
+    with pytest.raises(IndexError):
+        table[10]
+
+
+def test_loader_over_a_native_table_equals_the_list_path(tmp_path):
+    """ScpBatchLoader.index_all over a ScpTable (arrays from the native parse, no per-entry Python) gives the same header table, lengths
+    and batches as over a plain list of tuples - incl. entries that are not plain (a range specifier) and a path that does not exist."""
+    ee = _load_extract_script()
+    entries, want = _write_many_arks(tmp_path, n_files=3, per_file=9)
+    entries = list(entries)
+    entries.insert(4, ("ranged", entries[2][1] + "[1:3]"))
+    scp = tmp_path / "all.scp"
+    scp.write_text("".join("%s %s\n" % e for e in entries))
+    table = ee.read_scp(str(scp))
+    assert isinstance(table, ee.ScpTable) and list(table) == entries
+    a, b = ee.ScpBatchLoader(table, threads=2), ee.ScpBatchLoader(entries, threads=2)
+    try:
+        assert a.index_all() and b.index_all()
+        assert np.array_equal(a.lengths(), b.lengths())
+        for t, u in zip(a._table[:5], b._table[:5]):
+            assert np.array_equal(t, u)
+        idx = [0, 3, 4, 5, len(entries) - 1]
+        pa, pb = a.load_batch(idx), b.load_batch(idx)
+        assert np.array_equal(pa.offsets, pb.offsets) and np.array_equal(pa.packed, pb.packed)
+    finally:
+        a.close()
+        b.close()

@@ -78,7 +78,7 @@ def rank_main(rank, world, scp, threads, ready, go, out, batch_frames=65536, bat
     n = len(lengths)
     seg = ee._shard_segment_utts(lengths, batch_frames, batch_utts, 4) if segment else n
     step = max(1, seg) * world
-    keys = [k for k, _ in entries]
+    keys_of = entries.keys if hasattr(entries, "keys") else (lambda a, b: [k for k, _ in entries[a:b]])      # (as the script: made per segment, rank 0 only)
     mine, frames, nbytes = 0, 0, 0
     sink = open(os.devnull, "wb")
     for a in range(0, n, step):
@@ -96,7 +96,7 @@ def rank_main(rank, world, scp, threads, ready, go, out, batch_frames=65536, bat
         spent["read"] += time.perf_counter() - t0
         if rank == 0:                                    # rank 0 writes every rank's vectors of the segment
             t0 = time.perf_counter()
-            sink.write(kaldi_io.vec_flt_ark_bytes(keys[a:b], np.zeros((b - a, embed_dim), dtype=np.float32), as_buffer=True))
+            sink.write(kaldi_io.vec_flt_ark_bytes(keys_of(a, b), np.zeros((b - a, embed_dim), dtype=np.float32), as_buffer=True))
             spent["pack"] += time.perf_counter() - t0
     loader.close()
     total = time.perf_counter() - t_begin
