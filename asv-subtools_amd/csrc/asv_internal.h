@@ -209,6 +209,7 @@ struct TdnnChainParams {
   uint32_t *status;             // f32x chain: as TdnnKernelParams::status
   int n128, n_tail, tail_rows;  // 16-bit chain: the launch's tile plan (chain_tile_plan): n128 tiles of 128 frames, then n_tail of tail_rows (96 | 64)
   int row_base, tile_base;      // set by the launcher per kernel launch: first row / first partial-moment block of that launch
+  int abl;                      // f32m chain, developer aid with ASV_AMD_CHAIN_DBG (ASV_AMD_CHAINM_ABL; results are garbage): bit 0 no in-loop conversion, 1 no in-loop window DMA, 2 no chunk barrier (these three: garbage results), 3 no alternating issue priority (results unchanged)
 };
 // How the 16-bit chain kernel cuts `rows` (a multiple of 128) into tiles.  One workgroup per CU (160 KiB of LDS), so:
 //   * a batch that does not fill ONE round of the chip's CUs in 128-frame tiles runs in the smallest tile - 64 or 96 frames -

@@ -25,8 +25,21 @@
 // 512-channel tile (2 x 2 accumulators), the tile resident in LDS between the layers - as its half image Yh (64 KiB) and ONE 8-bit
 // image Y8 (64 KiB: per row and 32-channel group [x_lo8 16 | x_lo8 16 | x_hi8 16 | x_hi8 16]) where chainx keeps two half images -,
 // last layer in 64-channel units with swapped operands and the register-only pooling epilogue.  The K loop works in 32-channel pairs:
-// 8 half instructions (two k-groups) + 4 scaled ones; the main operands of a k-group are single-buffered and re-fetched two phases
-// ahead, the 8-bit operands double-buffered a whole pair ahead.  One workgroup (512 threads, 136 KiB of LDS) per CU.
+// 8 half instructions (two k-groups) + 4 scaled ones; ALL weight fragments of a pair are fetched a whole step ahead into the second of
+// two register sets, the rows from LDS two phases ahead.  The 8-bit weight block e4m3(w_hi) is made in registers from the half fragments
+// (v_cvt_scalef32_pk_fp8_f16): only w_hi (2 B) and e4m3(w_lo) (1 B) per weight come from memory.  One workgroup (512 threads, 136 KiB of
+// LDS) per CU.
+//
+// Where the time goes (round 6, s_memtime stamps: profiles/r6i_chainm_phase_stamps.txt, r6o_chainm_layerA_step_stamps.txt, r6p_*): per
+// 64-frame tile 114.7 k cycles of matrix work per SIMD, ~196 k measured.  A K step (one pair, 1024 matrix cycles for the two waves of a
+// SIMD) takes 1250 - 1350 cycles for the older wave of a SIMD and ~1900 for the younger when nothing synchronises them; layer A's chunk
+// barrier (every n_taps steps) then runs at the pace of the slower wave (~6000 cycles per 3-step chunk).  Not the cause: the window
+// conversion (in place and between the matrix instructions since; it was 450 cycles), the window DMA, the order of the fragment array
+// (a copy in step order changed nothing), the fetch distance of the half fragments (350 -> 1250 cycles: nothing).  What is left is the
+// weight stream itself: every CU streams the chain's whole weight set (3.7 MB of halves + 1.8 MB of 8-bit values, more than one XCD's
+// 4 MiB of L2) per 64 frames - 48 KiB per step and CU, 1.5 MB per step and XCD - and the three-product kernel has the same stream under
+// 1.5 x the matrix work.  Alternating the issue priority between the two waves of a SIMD step by step gives 3 % (r6p).  The lever that is
+// left is rows per workgroup (LDS: 96 frames fit if x_hi8 is made from the half rows in registers as w_hi8 is; registers: 96 accumulators).
 #include <cstdlib>
 
 #include "device_utils.h"
@@ -38,12 +51,12 @@ constexpr int MM = 64;                     // frames per workgroup
 constexpr int MN = kChainWidth;            // channels of the resident tile (512)
 constexpr int MROW = 128;                  // window row: 32 f32; image row: [hi16 64 B | lo8 32 B | hi8 32 B]
 constexpr int MWINR = MM + 2 * kHalo;      // 72 window rows
-constexpr int MSTG = MWINR * MROW;         // 9216 B per f32 stage / per image
+constexpr int MSTG = MWINR * MROW;         // 9216 B per window buffer (f32 stage, then image, in place)
 constexpr int MYROW = MN * 2;              // 1024 B per row of Yh and of Y8
 constexpr int MYIMG = MM * MYROW;          // 65536 B: Yh at 0, Y8 at MYIMG
 constexpr int MPAR = 2 * MYIMG;            // bias | scale | shift of the layer in flight (6 KiB)
 constexpr int CHAINM_LDS = 2 * MYIMG + 8192;
-static_assert(4 * MSTG <= MYIMG, "layer A's stages and images live inside the Y region");
+static_assert(3 * MSTG <= MYIMG, "layer A's window buffers live inside the Y region");
 static_assert(CHAINM_LDS <= 163840, "160 KiB of LDS per CU");
 
 // E8M0 block scales (2^(byte - 127)) that undo the host's / the epilogue's scaling of the 8-bit operands:
@@ -100,6 +113,14 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
   const uint32_t lane16 = (uint32_t)lane * 16u;
   const int scale_w = lh ? kScaleWlo : kScaleWhi, scale_x = lh ? kScaleXhi : kScaleXlo;
 
+  // developer aid (ASV_AMD_CHAIN_DBG=1): [workgroup][wave][32] s_memtime stamps at the phase boundaries; 14 / 15: s_memrealtime at start / end
+  int n_stamp = 0;
+  auto stamp = [&]() {
+    if (p.dbg != nullptr && lane == 0 && n_stamp < 14) p.dbg[((size_t)blockIdx.x * 8 + wave) * 32 + n_stamp] = __builtin_amdgcn_s_memtime();
+    ++n_stamp;
+  };
+  stamp();                                                       // 0: start
+  if (p.dbg != nullptr && lane == 0) p.dbg[((size_t)blockIdx.x * 8 + wave) * 32 + 14] = __builtin_amdgcn_s_memrealtime();
   auto stage_params = [&](const TdnnChainLayer &L) {
     if (tid < 384) {
       const int which = tid >> 7, idx = (tid & 127) * 4;
@@ -110,8 +131,14 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
     }
   };
 
-  struct MH { uint4 w[2], x[2]; };          // main operands of one 16-channel k-group: this wave's two weight fragments, the two frame fragments
-  struct ME { uint4 w[2][2], x[2][2]; };    // 8-bit operands of a 32-channel pair: w[j][K block], x[i][K block]
+  // Operands of a 32-channel pair.  Weights (from L2): this wave's two 32-channel fragments, as halves for the two k-groups and as K block 1
+  // (w_lo8) of the scaled instruction - TWO sets, fetched a whole step ahead (round 6: with the half fragments single-buffered and re-fetched
+  // ~350 matrix cycles ahead the K loops ran at 0.6 - 0.7 of the matrix rate, profiles/r6i_chainm_phase_stamps.txt).  Rows (from LDS): the
+  // two frame fragments per k-group, single-buffered two phases ahead, and their 8-bit K blocks x8[i][block], two sets.
+  struct MW { uint4 h0[2], h1[2], e[2]; };
+  struct MX8 { uint4 x[2][2]; };
+  uint4 h0x[2], h1x[2];
+  uint4 wq[2];                              // K block 0 of the pair's weights (w_hi8), made in registers from the two half fragments (whi8 below)
   f32x16_t acc[2][2];
   // the accumulators start from bias * w_scale (the weights carry the power of two w_scale; the epilogues multiply by 1 / w_scale):
   // TR = false: acc[i][j][4 q + e] = channel j * 32 + 8 q + 4 lh + e of the wave's slice; TR = true: lane = channel j * 32 + lr
@@ -137,14 +164,26 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
     }
   };
   // instruction q (0..3) of a phase: accumulator (i, j) = (q & 1, q >> 1); an accumulator recurs every 4th instruction
-  auto mma_main = [&](const MH &h, int q, auto tr) {
+  auto mma_main = [&](const uint4 (&w)[2], const uint4 (&x)[2], int q, auto tr) {
     const int i = q & 1, j = q >> 1;
-    if constexpr (decltype(tr)::value) acc[i][j] = mfma16<ET_F16>(h.x[i], h.w[j], acc[i][j]);
-    else acc[i][j] = mfma16<ET_F16>(h.w[j], h.x[i], acc[i][j]);
+    if constexpr (decltype(tr)::value) acc[i][j] = mfma16<ET_F16>(x[i], w[j], acc[i][j]);
+    else acc[i][j] = mfma16<ET_F16>(w[j], x[i], acc[i][j]);
   };
-  auto mma_mx = [&](const ME &e, int q, auto tr) {
+  // the 8 half values of a weight fragment -> e4m3(w_hi 2^-6) in two registers (RNE, the same bytes the host would pack): bytes 0-7 of K block
+  // 0 from the pair's first k-group, bytes 8-15 from its second
+  auto whi8 = [&](const uint4 &f, uint32_t &d0, uint32_t &d1) {
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+    s16x2 a = {0, 0}, b = {0, 0};
+    a = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(a, __builtin_bit_cast(h16x2, f.x), 64.0f, false);
+    a = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(a, __builtin_bit_cast(h16x2, f.y), 64.0f, true);
+    b = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(b, __builtin_bit_cast(h16x2, f.z), 64.0f, false);
+    b = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(b, __builtin_bit_cast(h16x2, f.w), 64.0f, true);
+    d0 = __builtin_bit_cast(uint32_t, a); d1 = __builtin_bit_cast(uint32_t, b);
+  };
+  auto mma_mx = [&](const MW &w, const MX8 &e, int q, auto tr) {
     const int i = q & 1, j = q >> 1;
-    const mx_v8i a = {(int)e.w[j][0].x, (int)e.w[j][0].y, (int)e.w[j][0].z, (int)e.w[j][0].w, (int)e.w[j][1].x, (int)e.w[j][1].y, (int)e.w[j][1].z, (int)e.w[j][1].w};
+    const mx_v8i a = {(int)wq[j].x, (int)wq[j].y, (int)wq[j].z, (int)wq[j].w, (int)w.e[j].x, (int)w.e[j].y, (int)w.e[j].z, (int)w.e[j].w};
     const mx_v8i b = {(int)e.x[i][0].x, (int)e.x[i][0].y, (int)e.x[i][0].z, (int)e.x[i][0].w, (int)e.x[i][1].x, (int)e.x[i][1].y, (int)e.x[i][1].z, (int)e.x[i][1].w};
     // operand formats: 0 = e4m3 (weights), 1 = e5m2 (activations)
     if constexpr (decltype(tr)::value) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b, a, acc[i][j], 1, 0, 0, scale_x, 0, scale_w);
@@ -160,149 +199,171 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
     const int nchunks = p.cin_pad / 32;
     const int n_taps = p.n_taps;
     const int nkg = (p.cin_pad / 64) * 4;                       // 16-channel k-groups per tap in the half fragment arrays
-    // window of chunk c -> f32 stage c & 1: piece w by wave w, the ninth piece by wave 0 (rows beyond the matrix ends are clamped
-    // onto zero gap rows)
+    // Window of chunk c -> buffer c % 3 (three buffers of 72 rows x 128 B inside the not yet written Y region): piece w by wave w, the ninth
+    // piece by wave 0 (rows beyond the matrix ends are clamped onto zero gap rows).  A buffer is f32 stage AND image: the conversion runs
+    // IN PLACE - the four threads of a row sit in one wave, their reads of the whole row retire before any of them writes - and, from
+    // chunk 2 on, interleaved with the matrix instructions of the step that follows the chunk barrier instead of in front of them (round
+    // 6: with the conversion between barrier and K loop every wave of the CU left the matrix pipe idle for it once per chunk - layer A's
+    // loop took 79 k cycles for 49 k of matrix work, profiles/r6i_chainm_phase_stamps.txt).
     auto piece_off = [&](int grp) -> size_t {
       const int w = grp * 8 + g_row;
       const int row = min(max(m0 - kHalo + w, 0), p.rows - 1);
       return (size_t)row * x_pitch + (size_t)mswz(w, g_slot) * 16u;
     };
     const size_t off_a = piece_off(wave), off_b = piece_off(8);
-    auto issue_A = [&](int c) {
+    auto issue_A = [&](int c, int buf) {
       const unsigned char *base = xg + (size_t)c * MROW;
-      chainm_glds16(base + off_a, __builtin_amdgcn_readfirstlane(lds_base + (c & 1) * MSTG + wave * 1024));
-      if (wave == 0) chainm_glds16(base + off_b, __builtin_amdgcn_readfirstlane(lds_base + (c & 1) * MSTG + 8 * 1024));
+      chainm_glds16(base + off_a, __builtin_amdgcn_readfirstlane(lds_base + buf * MSTG + wave * 1024));
+      if (wave == 0) chainm_glds16(base + off_b, __builtin_amdgcn_readfirstlane(lds_base + buf * MSTG + 8 * 1024));
     };
-    // f32 stage c & 1 -> image c & 1 (at 2 * MSTG): row = [hi halves of 32 channels (slots 0-3) | x_lo8 (slots 4, 5) | x_hi8 (slots 6, 7)];
-    // thread (w, q) converts channels 8 q .. 8 q + 7 of row w
-    auto convert = [&](int c) {
+    // f32 rows -> image rows [hi halves of 32 channels (slots 0-3) | x_lo8 (slots 4, 5 = lane halves 0, 1) | x_hi8 (slots 6, 7)], in place; thread (w, q)
+    // converts channels 8 q .. 8 q + 7 of row w: cv_load reads its 32 bytes, cv_store writes its 16 + 8 + 8
+    uint4 cva = make_uint4(0, 0, 0, 0), cvb = make_uint4(0, 0, 0, 0);
+    auto cv_load = [&](int buf) {
       if (tid < MWINR * 4) {
         const int w = tid >> 2, q = tid & 3;
-        const unsigned char *src = lds + (c & 1) * MSTG + w * MROW;
-        const uint4 a = *reinterpret_cast<const uint4 *>(src + mswz(w, 2 * q) * 16);
-        const uint4 b = *reinterpret_cast<const uint4 *>(src + mswz(w, 2 * q + 1) * 16);
-        uint4 hi;
-        int h8a = 0, l8a = 0, h8b = 0, l8b = 0;
-        split_mx<false>(__uint_as_float(a.x), __uint_as_float(a.y), hi.x, h8a, l8a, range);
-        split_mx<true>(__uint_as_float(a.z), __uint_as_float(a.w), hi.y, h8a, l8a, range);
-        split_mx<false>(__uint_as_float(b.x), __uint_as_float(b.y), hi.z, h8b, l8b, range);
-        split_mx<true>(__uint_as_float(b.z), __uint_as_float(b.w), hi.w, h8b, l8b, range);
-        unsigned char *dst = lds + (2 + (c & 1)) * MSTG + w * MROW;
-        *reinterpret_cast<uint4 *>(dst + mswz(w, q) * 16) = hi;
-        *reinterpret_cast<uint2 *>(dst + mswz(w, 4 + (q >> 1)) * 16 + (q & 1) * 8) = make_uint2((uint32_t)l8a, (uint32_t)l8b);
-        *reinterpret_cast<uint2 *>(dst + mswz(w, 6 + (q >> 1)) * 16 + (q & 1) * 8) = make_uint2((uint32_t)h8a, (uint32_t)h8b);
+        const unsigned char *src = lds + buf * MSTG + w * MROW;
+        cva = *reinterpret_cast<const uint4 *>(src + mswz(w, 2 * q) * 16);
+        cvb = *reinterpret_cast<const uint4 *>(src + mswz(w, 2 * q + 1) * 16);
       }
     };
+    auto cv_store = [&](int buf) {
+      if (tid < MWINR * 4) {
+        const int w = tid >> 2, q = tid & 3;
+        uint4 hi;
+        int h8a = 0, l8a = 0, h8b = 0, l8b = 0;
+        split_mx<false>(__uint_as_float(cva.x), __uint_as_float(cva.y), hi.x, h8a, l8a, range);
+        split_mx<true>(__uint_as_float(cva.z), __uint_as_float(cva.w), hi.y, h8a, l8a, range);
+        split_mx<false>(__uint_as_float(cvb.x), __uint_as_float(cvb.y), hi.z, h8b, l8b, range);
+        split_mx<true>(__uint_as_float(cvb.z), __uint_as_float(cvb.w), hi.w, h8b, l8b, range);
+        unsigned char *dst = lds + buf * MSTG + w * MROW;
+        *reinterpret_cast<uint4 *>(dst + mswz(w, q) * 16) = hi;
+        // byte b of an 8-bit slot of lane half lh = channel (b < 8 ? 8 lh + b : 16 + 8 lh + b - 8): the order of the lane's two half fragments
+        *reinterpret_cast<uint2 *>(dst + mswz(w, 4 + (q & 1)) * 16 + (q >> 1) * 8) = make_uint2((uint32_t)l8a, (uint32_t)l8b);
+        *reinterpret_cast<uint2 *>(dst + mswz(w, 6 + (q & 1)) * 16 + (q >> 1) * 8) = make_uint2((uint32_t)h8a, (uint32_t)h8b);
+      }
+    };
+    // fragment offsets of pair (c, t) in the tap-major arrays of pack_tdnn_weight_frags / _mx8.  (A copy in this loop's own order - consecutive
+    // steps fetching consecutive kilobytes instead of addresses 32 KiB apart - was measured without effect: profiles/r6o_*.)
+    auto off_h = [&](int c, int t) -> size_t { return ((size_t)t * nkg + (size_t)c * 2) * 1024; };
+    auto off_8 = [&](int c, int t) -> size_t { return ((size_t)t * nchunks + c) * 1024; };
     const size_t frag_stride = (size_t)n_taps * nkg * 1024;                    // half fragments: bytes per 32-channel output fragment
-    const size_t frag8_stride = (size_t)n_taps * nchunks * 2048;               // 8-bit fragments: [tap][32-channel group][K block][lane][16]
+    const size_t frag8_stride = (size_t)n_taps * nchunks * 1024;               // 8-bit fragments (w_lo8): [tap][32-channel group][lane][16]
     const unsigned char *wh = reinterpret_cast<const unsigned char *>(p.first.wfrag) + (size_t)(wave * 2) * frag_stride + lane16;
     const unsigned char *w8 = reinterpret_cast<const unsigned char *>(p.first.w8) + (size_t)(wave * 2) * frag8_stride + lane16;
     const int v_taps = p.taps[lane < 9 ? lane : 0];
-    // LDS byte address of this lane's row of image c & 1 for tap t, and its swizzle term (blind to + 32 rows)
-    auto x_row = [&](int c, int t, uint32_t &base, int &sw) {
+    // LDS byte address of this lane's row of the image in buffer `buf` for tap t, and its swizzle term (blind to + 32 rows)
+    auto x_row = [&](int buf, int t, uint32_t &base, int &sw) {
       const int wrow = lr + kHalo + __builtin_amdgcn_readlane(v_taps, t);
       sw = (wrow >> 1) & 7;
-      base = (uint32_t)((2 + (c & 1)) * MSTG + wrow * MROW);
+      base = (uint32_t)(buf * MSTG + wrow * MROW);
     };
-    auto ld_main = [&](int c, int t, int kg, MH &h) {
-      const size_t off = ((size_t)t * nkg + (size_t)c * 2 + kg) * 1024;
-      h.w[0] = *reinterpret_cast<const uint4 *>(wh + off); h.w[1] = *reinterpret_cast<const uint4 *>(wh + frag_stride + off);
-      uint32_t base; int sw;
-      x_row(c, t, base, sw);
-      const uint32_t a = base + (uint32_t)(((kg * 2 + lh) ^ sw) << 4);
-      h.x[0] = *reinterpret_cast<const uint4 *>(lds + a); h.x[1] = *reinterpret_cast<const uint4 *>(lds + a + 32 * MROW);
+    // the weights of pair (c, t): 6 fragment loads
+    auto ld_w = [&](int c, int t, MW &w) {
+      const size_t offh = off_h(c, t), off8 = off_8(c, t);
+      w.h0[0] = *reinterpret_cast<const uint4 *>(wh + offh); w.h0[1] = *reinterpret_cast<const uint4 *>(wh + frag_stride + offh);
+      w.h1[0] = *reinterpret_cast<const uint4 *>(wh + offh + 1024); w.h1[1] = *reinterpret_cast<const uint4 *>(wh + frag_stride + offh + 1024);
+      w.e[0] = *reinterpret_cast<const uint4 *>(w8 + off8); w.e[1] = *reinterpret_cast<const uint4 *>(w8 + frag8_stride + off8);
     };
-    auto ld_mx = [&](int c, int t, ME &e) {
-      const size_t off = ((size_t)t * nchunks + c) * 2048;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        e.w[j][0] = *reinterpret_cast<const uint4 *>(w8 + j * frag8_stride + off);
-        e.w[j][1] = *reinterpret_cast<const uint4 *>(w8 + j * frag8_stride + off + 1024);
-      }
+    // prologue: windows 0, 1, 2 in flight; 0 and 1 converted at once (the K loop's first barrier follows the first chunk)
+    issue_A(0, 0);
+    if (nchunks > 1) issue_A(1, 1);
+    if (nchunks > 2) issue_A(2, 2);
+    MW w0, w1;
+    MX8 e0, e1;
+    ld_w(0, 0, w0);
+    // windows 0 and 1 have landed: everything but the youngest 6 (the fragments) + this wave's pieces of window 2 ... kept simple: all of it
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    cv_load(0); cv_store(0);
+    if (nchunks > 1) { cv_load(1); cv_store(1); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    init_acc(p.first.bias + wave * 64, p.first.w_scale, MTrNo{});
+    {
       uint32_t base; int sw;
-      x_row(c, t, base, sw);
-      const uint32_t a0 = base + (uint32_t)(((4 + lh) ^ sw) << 4), a1 = base + (uint32_t)(((6 + lh) ^ sw) << 4);
+      x_row(0, 0, base, sw);
+      const uint32_t a0 = base + (uint32_t)((lh ^ sw) << 4), a1 = base + (uint32_t)(((2 + lh) ^ sw) << 4);
+      const uint32_t a4 = base + (uint32_t)(((4 + lh) ^ sw) << 4), a6 = base + (uint32_t)(((6 + lh) ^ sw) << 4);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        e.x[i][0] = *reinterpret_cast<const uint4 *>(lds + a0 + i * 32 * MROW);
-        e.x[i][1] = *reinterpret_cast<const uint4 *>(lds + a1 + i * 32 * MROW);
+        h0x[i] = *reinterpret_cast<const uint4 *>(lds + a0 + i * 32 * MROW);
+        h1x[i] = *reinterpret_cast<const uint4 *>(lds + a1 + i * 32 * MROW);
+        e0.x[i][0] = *reinterpret_cast<const uint4 *>(lds + a4 + i * 32 * MROW);
+        e0.x[i][1] = *reinterpret_cast<const uint4 *>(lds + a6 + i * 32 * MROW);
       }
-    };
-    issue_A(0);
-    if (nchunks > 1) issue_A(1);
-    // window 0 landed (everything but this wave's pieces of window 1) -> image 0; its stage then takes window 2
-    if (nchunks > 1) { if (wave == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); }
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    convert(0);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (nchunks > 2) issue_A(2);
-    if (nchunks > 1) convert(1);
-    init_acc(p.first.bias + wave * 64, p.first.w_scale, MTrNo{});
-    MH h0, h1;
-    ME e0, e1;
-    ld_mx(0, 0, e0);
-    ld_main(0, 0, 0, h0);
-    ld_main(0, 0, 1, h1);
+    }
     const int P = nchunks * n_taps;
-    int c = 0, t = 0;
+    int c = 0, t = 0, cb = 0;                                     // cb = c % 3: the buffer of chunk c's image
+    stamp();                                                     // 1: layer A's prologue (three windows, two conversions, first fetches)
     // pair n = (chunk c, tap t): 4 + 4 half instructions and 4 scaled ones; the fetches of pair n + 1 are pinned between them
-    auto step = [&](const ME &ec, ME &en, int n) {
+    auto step = [&](const MW &wc, MW &wn, const MX8 &ec, MX8 &en, int n) {
+      if (p.dbg != nullptr && p.dbg_fine && lane == 0 && n < 16) p.dbg[((size_t)blockIdx.x * 8 + wave) * 32 + 16 + n] = __builtin_amdgcn_s_memtime();
+      // The two waves of a SIMD (w and w + 4) take turns at the higher issue priority, step by step: left alone the older wave of a pair runs
+      // its steps in ~1280 cycles and the younger in ~1900 (profiles/r6o_chainm_layerA_step_stamps.txt, no barrier), and a chunk barrier
+      // then runs at the pace of the slower one.  ASV_AMD_CHAINM_ABL bit 3: off.
+      if ((p.abl & 8) == 0) { if (((n ^ (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
       int c2 = c, t2 = t + 1;
       if (t2 == n_taps) { t2 = 0; c2 = c + 1; }
       const bool more = n + 1 < P;
       if (!more) { c2 = c; t2 = t; }                               // the last pair re-fetches itself (valid memory, never used)
       const bool enter = more && c2 != c;
-      if (enter) {
-        // entering chunk c + 1 (the protocol of kernels_tdnn_chainx.hip): its image is complete, window c + 2 has landed - older than
-        // the youngest 4 vector-memory operations, the half fragments of pair n fetched in the previous step's phases 2 and 3 -;
-        // window c + 2 becomes image c & 1 now, its stage takes window c + 3, issued BEHIND this step's first weight fetches
-        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      const int cb1 = cb == 2 ? 0 : cb + 1, cb2 = cb == 0 ? 2 : cb - 1;        // (c + 1) % 3, (c + 2) % 3
+      const bool cv = enter && c + 2 < nchunks && (p.abl & 1) == 0;
+      if (enter && (p.abl & 4) == 0) {
+        // Entering chunk c + 1, at the start of the LAST step of chunk c (this step's operands were fetched in the previous one): image
+        // c + 1 is complete (converted during the step behind the previous chunk barrier: lgkmcnt), window c + 2 has landed (issued a
+        // chunk ago; the only vector-memory operations behind it that may still be in flight are this step's own weight fragments,
+        // needed now anyway), nobody reads image c any more.  Behind the barrier: window c + 3 goes into image c's buffer (issued
+        // behind this step's weight fetches), window c + 2 is converted in place between this step's matrix instructions.
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (c + 2 < nchunks) convert(c + 2);
       }
-      const size_t off8 = ((size_t)t2 * nchunks + c2) * 2048;
-      const size_t offh = ((size_t)t2 * nkg + (size_t)c2 * 2) * 1024;
+      const size_t off8 = off_8(c2, t2);
+      const size_t offh = off_h(c2, t2);
       uint32_t base; int sw;
-      x_row(c2, t2, base, sw);
+      x_row(c2 != c ? cb1 : cb, t2, base, sw);
       const uint32_t ax0 = base + (uint32_t)(((4 + lh) ^ sw) << 4), ax1 = base + (uint32_t)(((6 + lh) ^ sw) << 4);
       const uint32_t ah0 = base + (uint32_t)(((lh) ^ sw) << 4), ah1 = base + (uint32_t)(((2 + lh) ^ sw) << 4);
-      // phase 1: k-group 0 of the pair; the 8-bit operands of the next pair
+      // phase 1: k-group 0 of the pair; ALL weight fragments of the next pair, its 8-bit rows
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        if (q == 0) { en.w[0][0] = *reinterpret_cast<const uint4 *>(w8 + off8); en.w[0][1] = *reinterpret_cast<const uint4 *>(w8 + off8 + 1024); }
-        if (q == 1) { en.w[1][0] = *reinterpret_cast<const uint4 *>(w8 + frag8_stride + off8); en.w[1][1] = *reinterpret_cast<const uint4 *>(w8 + frag8_stride + off8 + 1024); }
-        if (q == 1 && enter && c + 3 < nchunks) issue_A(c + 3);
+        if (q == 0) { wn.h0[0] = *reinterpret_cast<const uint4 *>(wh + offh); wn.h0[1] = *reinterpret_cast<const uint4 *>(wh + frag_stride + offh); }
+        if (q == 0) { wn.h1[0] = *reinterpret_cast<const uint4 *>(wh + offh + 1024); wn.h1[1] = *reinterpret_cast<const uint4 *>(wh + frag_stride + offh + 1024); }
+        if (q == 1) { wn.e[0] = *reinterpret_cast<const uint4 *>(w8 + off8); wn.e[1] = *reinterpret_cast<const uint4 *>(w8 + frag8_stride + off8); }
+        if (q == 1 && enter && c + 3 < nchunks && (p.abl & 2) == 0) issue_A(c + 3, cb);
+        if (q == 1 && cv) cv_load(cb2);
         if (q == 2) { en.x[0][0] = *reinterpret_cast<const uint4 *>(lds + ax0); en.x[0][1] = *reinterpret_cast<const uint4 *>(lds + ax1); }
+        if (q == 2) { whi8(wc.h0[0], wq[0].x, wq[0].y); whi8(wc.h0[1], wq[1].x, wq[1].y); }
         if (q == 3) { en.x[1][0] = *reinterpret_cast<const uint4 *>(lds + ax0 + 32 * MROW); en.x[1][1] = *reinterpret_cast<const uint4 *>(lds + ax1 + 32 * MROW); }
-        mma_main(h0, q, MTrNo{});
+        mma_main(wc.h0, h0x, q, MTrNo{});
         __builtin_amdgcn_sched_barrier(0);
       }
-      // phase 2: k-group 1; k-group 0 of the next pair into the registers phase 1 has just read
+      // phase 2: k-group 1; the rows of the next pair's k-group 0 into the registers phase 1 has just read
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        mma_main(h1, q, MTrNo{});
-        if (q == 0) { h0.w[0] = *reinterpret_cast<const uint4 *>(wh + offh); h0.w[1] = *reinterpret_cast<const uint4 *>(wh + frag_stride + offh); }
-        if (q == 1) { h0.x[0] = *reinterpret_cast<const uint4 *>(lds + ah0); h0.x[1] = *reinterpret_cast<const uint4 *>(lds + ah0 + 32 * MROW); }
+        mma_main(wc.h1, h1x, q, MTrNo{});
+        if (q == 0) { h0x[0] = *reinterpret_cast<const uint4 *>(lds + ah0); h0x[1] = *reinterpret_cast<const uint4 *>(lds + ah0 + 32 * MROW); }
+        if (q == 1) { whi8(wc.h1[0], wq[0].z, wq[0].w); whi8(wc.h1[1], wq[1].z, wq[1].w); }
+        if (q == 2 && cv) cv_store(cb2);
         __builtin_amdgcn_sched_barrier(0);
       }
-      // phase 3: the corrections; k-group 1 of the next pair
+      // phase 3: the corrections; the rows of the next pair's k-group 1
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        mma_mx(ec, q, MTrNo{});
-        if (q == 0) { h1.w[0] = *reinterpret_cast<const uint4 *>(wh + offh + 1024); h1.w[1] = *reinterpret_cast<const uint4 *>(wh + frag_stride + offh + 1024); }
-        if (q == 1) { h1.x[0] = *reinterpret_cast<const uint4 *>(lds + ah1); h1.x[1] = *reinterpret_cast<const uint4 *>(lds + ah1 + 32 * MROW); }
+        mma_mx(wc, ec, q, MTrNo{});
+        if (q == 0) { h1x[0] = *reinterpret_cast<const uint4 *>(lds + ah1); h1x[1] = *reinterpret_cast<const uint4 *>(lds + ah1 + 32 * MROW); }
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (c2 != c) cb = cb1;
       c = c2; t = t2;
     };
     for (int n = 0; n < P; n += 2) {
-      step(e0, e1, n);
-      if (n + 1 < P) step(e1, e0, n + 1);
+      step(w0, w1, e0, e1, n);
+      if (n + 1 < P) step(w1, w0, e1, e0, n + 1);
     }
   }
 
@@ -325,10 +386,11 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
         }
         // Yh: 4 consecutive channels = 8 bytes inside the 16-byte slot (wave * 8 + j * 4 + q), half lh
         const uint32_t slot_off = (uint32_t)((((wave * 8 + j * 4 + q) ^ rx) << 4) + lh * 8);
-        // Y8: the 32-channel group (wave * 2 + j) owns slots 4 g .. 4 g + 3 = [lo8 ch 0-15 | lo8 ch 16-31 | hi8 ch 0-15 | hi8 ch 16-31];
-        // channels 8 q + 4 lh + e: sixteen-group q >> 1, bytes 8 (q & 1) + 4 lh + e
-        const int grp = (wave * 2 + j) * 4 + (q >> 1);
-        const uint32_t lo_off = (uint32_t)(((grp ^ rx) << 4) + (q & 1) * 8 + lh * 4), hi_off = (uint32_t)((((grp + 2) ^ rx) << 4) + (q & 1) * 8 + lh * 4);
+        // Y8: the 32-channel group (wave * 2 + j) owns slots 4 g .. 4 g + 3 = [lo8 of lane half 0 | lo8 of lane half 1 | hi8 of 0 | hi8 of 1], a
+        // half's 16 bytes = channels 8 lhK .. + 7 then 16 + 8 lhK .. + 7 (the order of the two half fragments); channels 8 q + 4 lh + e of
+        // this lane: lhK = q & 1, bytes 8 (q >> 1) + 4 lh + e
+        const int grp = (wave * 2 + j) * 4 + (q & 1);
+        const uint32_t lo_off = (uint32_t)(((grp ^ rx) << 4) + (q >> 1) * 8 + lh * 4), hi_off = (uint32_t)((((grp + 2) ^ rx) << 4) + (q >> 1) * 8 + lh * 4);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           float y[4];
@@ -352,78 +414,77 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
   // main loop of a layer whose input is Y: K = 512 = 16 pairs of 32 channels, no barrier.  wbh / wb8: wave-uniform bases of the half / 8-bit
   // fragment arrays of this wave's (or unit's) first 32-channel output fragment; the second follows at + 32 KiB in both.
   auto yloop = [&](const unsigned char *wbh, const unsigned char *wb8, const float *bias64, float w_scale, auto tr) {
-    constexpr size_t fs = (size_t)(MN / 16) * 1024, fs8 = (size_t)(MN / 32) * 2048;
+    constexpr size_t fs = (size_t)(MN / 16) * 1024, fs8 = (size_t)(MN / 32) * 1024;
     const uint32_t yb = (uint32_t)(lr * MYROW);
     const uint32_t sx = (uint32_t)(lh ^ (lr & 15));
-    MH h0, h1;
-    ME e0, e1;
-    auto ld_main = [&](int kg, MH &h) {
-      const size_t off = (size_t)kg * 1024 + lane16;
-      h.w[0] = *reinterpret_cast<const uint4 *>(wbh + off); h.w[1] = *reinterpret_cast<const uint4 *>(wbh + fs + off);
-      const uint32_t a = yb + ((((uint32_t)(kg * 2)) ^ sx) << 4);              // slot (2 kg + lh) ^ (lr & 15)
-      h.x[0] = *reinterpret_cast<const uint4 *>(lds + a); h.x[1] = *reinterpret_cast<const uint4 *>(lds + a + 32 * MYROW);
+    MW w0, w1;
+    MX8 e0, e1;
+    auto ld_w = [&](int n, MW &w) {
+      const size_t offh = (size_t)(n * 2) * 1024 + lane16, off8 = (size_t)n * 1024 + lane16;
+      w.h0[0] = *reinterpret_cast<const uint4 *>(wbh + offh); w.h0[1] = *reinterpret_cast<const uint4 *>(wbh + fs + offh);
+      w.h1[0] = *reinterpret_cast<const uint4 *>(wbh + offh + 1024); w.h1[1] = *reinterpret_cast<const uint4 *>(wbh + fs + offh + 1024);
+      w.e[0] = *reinterpret_cast<const uint4 *>(wb8 + off8); w.e[1] = *reinterpret_cast<const uint4 *>(wb8 + fs8 + off8);
     };
-    auto ld_mx = [&](int n, ME &e) {
-      const size_t off = (size_t)n * 2048 + lane16;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        e.w[j][0] = *reinterpret_cast<const uint4 *>(wb8 + j * fs8 + off);
-        e.w[j][1] = *reinterpret_cast<const uint4 *>(wb8 + j * fs8 + off + 1024);
-      }
-      const uint32_t a0 = MYIMG + yb + ((((uint32_t)(n * 4)) ^ sx) << 4), a1 = MYIMG + yb + ((((uint32_t)(n * 4 + 2)) ^ sx) << 4);
+    ld_w(0, w0);
+    {
+      const uint32_t a0 = yb + ((0u ^ sx) << 4), a1 = yb + ((2u ^ sx) << 4);                  // slots (2 kg + lh) ^ (lr & 15), kg = 0, 1
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        e.x[i][0] = *reinterpret_cast<const uint4 *>(lds + a0 + i * 32 * MYROW);
-        e.x[i][1] = *reinterpret_cast<const uint4 *>(lds + a1 + i * 32 * MYROW);
+        h0x[i] = *reinterpret_cast<const uint4 *>(lds + a0 + i * 32 * MYROW);
+        h1x[i] = *reinterpret_cast<const uint4 *>(lds + a1 + i * 32 * MYROW);
+        e0.x[i][0] = *reinterpret_cast<const uint4 *>(lds + MYIMG + a0 + i * 32 * MYROW);
+        e0.x[i][1] = *reinterpret_cast<const uint4 *>(lds + MYIMG + a1 + i * 32 * MYROW);
       }
-    };
-    ld_mx(0, e0);
-    ld_main(0, h0);
-    ld_main(1, h1);
+    }
     init_acc(bias64, w_scale, tr);
-    auto step = [&](const ME &ec, ME &en, int nn) {                // computes the pair in (h0, h1, ec); fetches pair nn
-      const size_t off8 = (size_t)nn * 2048 + lane16;
+    auto step = [&](const MW &wc, MW &wn, const MX8 &ec, MX8 &en, int nn) {      // computes the pair in (wc, h0x, h1x, ec); fetches pair nn
+      if ((p.abl & 8) == 0) { if (((nn ^ (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+      const size_t off8 = (size_t)nn * 1024 + lane16;
       const size_t offh = (size_t)(nn * 2) * 1024 + lane16;
       const uint32_t ax0 = MYIMG + yb + ((((uint32_t)(nn * 4)) ^ sx) << 4), ax1 = MYIMG + yb + ((((uint32_t)(nn * 4 + 2)) ^ sx) << 4);
       const uint32_t ah0 = yb + ((((uint32_t)(nn * 4)) ^ sx) << 4), ah1 = yb + ((((uint32_t)(nn * 4 + 2)) ^ sx) << 4);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        if (q == 0) { en.w[0][0] = *reinterpret_cast<const uint4 *>(wb8 + off8); en.w[0][1] = *reinterpret_cast<const uint4 *>(wb8 + off8 + 1024); }
-        if (q == 1) { en.w[1][0] = *reinterpret_cast<const uint4 *>(wb8 + fs8 + off8); en.w[1][1] = *reinterpret_cast<const uint4 *>(wb8 + fs8 + off8 + 1024); }
+        if (q == 0) { wn.h0[0] = *reinterpret_cast<const uint4 *>(wbh + offh); wn.h0[1] = *reinterpret_cast<const uint4 *>(wbh + fs + offh); }
+        if (q == 0) { wn.h1[0] = *reinterpret_cast<const uint4 *>(wbh + offh + 1024); wn.h1[1] = *reinterpret_cast<const uint4 *>(wbh + fs + offh + 1024); }
+        if (q == 1) { wn.e[0] = *reinterpret_cast<const uint4 *>(wb8 + off8); wn.e[1] = *reinterpret_cast<const uint4 *>(wb8 + fs8 + off8); }
         if (q == 2) { en.x[0][0] = *reinterpret_cast<const uint4 *>(lds + ax0); en.x[0][1] = *reinterpret_cast<const uint4 *>(lds + ax1); }
+        if (q == 2) { whi8(wc.h0[0], wq[0].x, wq[0].y); whi8(wc.h0[1], wq[1].x, wq[1].y); }
         if (q == 3) { en.x[1][0] = *reinterpret_cast<const uint4 *>(lds + ax0 + 32 * MYROW); en.x[1][1] = *reinterpret_cast<const uint4 *>(lds + ax1 + 32 * MYROW); }
-        mma_main(h0, q, tr);
+        mma_main(wc.h0, h0x, q, tr);
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        mma_main(h1, q, tr);
-        if (q == 0) { h0.w[0] = *reinterpret_cast<const uint4 *>(wbh + offh); h0.w[1] = *reinterpret_cast<const uint4 *>(wbh + fs + offh); }
-        if (q == 1) { h0.x[0] = *reinterpret_cast<const uint4 *>(lds + ah0); h0.x[1] = *reinterpret_cast<const uint4 *>(lds + ah0 + 32 * MYROW); }
+        mma_main(wc.h1, h1x, q, tr);
+        if (q == 0) { h0x[0] = *reinterpret_cast<const uint4 *>(lds + ah0); h0x[1] = *reinterpret_cast<const uint4 *>(lds + ah0 + 32 * MYROW); }
+        if (q == 1) { whi8(wc.h1[0], wq[0].z, wq[0].w); whi8(wc.h1[1], wq[1].z, wq[1].w); }
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        mma_mx(ec, q, tr);
-        if (q == 0) { h1.w[0] = *reinterpret_cast<const uint4 *>(wbh + offh + 1024); h1.w[1] = *reinterpret_cast<const uint4 *>(wbh + fs + offh + 1024); }
-        if (q == 1) { h1.x[0] = *reinterpret_cast<const uint4 *>(lds + ah1); h1.x[1] = *reinterpret_cast<const uint4 *>(lds + ah1 + 32 * MYROW); }
+        mma_mx(wc, ec, q, tr);
+        if (q == 0) { h1x[0] = *reinterpret_cast<const uint4 *>(lds + ah1); h1x[1] = *reinterpret_cast<const uint4 *>(lds + ah1 + 32 * MYROW); }
         __builtin_amdgcn_sched_barrier(0);
       }
     };
 #pragma unroll 1
     for (int n = 0; n < MN / 32; n += 2) {
-      step(e0, e1, n + 1);
-      step(e1, e0, min(n + 2, MN / 32 - 1));                       // the last pair re-fetches itself (never used)
+      step(w0, w1, e0, e1, n + 1);
+      step(w1, w0, e1, e0, min(n + 2, MN / 32 - 1));               // the last pair re-fetches itself (never used)
     }
   };
 
+  __builtin_amdgcn_s_setprio(0);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();            // every wave is done with layer A's stages and images: Y may be written
   asm volatile("" ::: "memory");
+  stamp();                                                       // 3: the wait for the slowest wave
   store_Y(p.first.relu, p.first.scale != nullptr, 1.0f / p.first.w_scale);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();            // Y complete; the constants of layer A are dead
   asm volatile("" ::: "memory");
+  stamp();                                                       // 4: layer A's epilogue (split, Yh / Y8) + barrier
 
   // ================================ middle layers: Y -> Y ================================
 #pragma unroll 1
@@ -431,8 +492,9 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
     const TdnnChainLayer &L = p.mid[m];
     stage_params(L);
     const unsigned char *wbh = reinterpret_cast<const unsigned char *>(L.wfrag) + (size_t)(wave * 2) * ((size_t)(MN / 16) * 1024);
-    const unsigned char *wb8 = reinterpret_cast<const unsigned char *>(L.w8) + (size_t)(wave * 2) * ((size_t)(MN / 32) * 2048);
+    const unsigned char *wb8 = reinterpret_cast<const unsigned char *>(L.w8) + (size_t)(wave * 2) * ((size_t)(MN / 32) * 1024);
     yloop(wbh, wb8, L.bias + wave * 64, L.w_scale, MTrNo{});
+    stamp();                                                     // 5: a middle layer's K loop
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();          // nobody reads the old Y any more (and the staged constants are visible)
     asm volatile("" ::: "memory");
@@ -440,6 +502,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    stamp();                                                     // 6: its barriers + epilogue
   }
 
   // ================================ last layer + fused statistics pooling ================================
@@ -456,8 +519,9 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
 #pragma unroll 1
     for (int cb = wave * 64; cb < L.cout_pad; cb += 512) {
       const unsigned char *wbh = reinterpret_cast<const unsigned char *>(L.wfrag) + (size_t)(cb / 32) * ((size_t)(MN / 16) * 1024);
-      const unsigned char *wb8 = reinterpret_cast<const unsigned char *>(L.w8) + (size_t)(cb / 32) * ((size_t)(MN / 32) * 2048);
+      const unsigned char *wb8 = reinterpret_cast<const unsigned char *>(L.w8) + (size_t)(cb / 32) * ((size_t)(MN / 32) * 1024);
       yloop(wbh, wb8, L.bias + cb, L.w_scale, MTrYes{});
+      stamp();                                                   // 7, 9, 11: a unit's K loop
       // Pooling epilogue, registers only (kernels_tdnn_chainx.hip, the same arithmetic): acc[i][j][r] = channel cb + j*32 + lr, frame
       // i*32 + 8 (r >> 2) + 4 lh + (r & 3); a lane sums its own frames per utterance about the pivot of its FIRST frame of that utterance,
       // the two lane halves publish P[tile of 64 rows][segment slot][lh][3 = sum (u - pv), sum (u - pv)^2, pv][channel] with the BN scale
@@ -525,8 +589,10 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
         }
       }
       publish();
+      stamp();                                                   // 8, 10, 12: its pooling epilogue
     }
   }
+  if (p.dbg != nullptr && lane == 0) p.dbg[((size_t)blockIdx.x * 8 + wave) * 32 + 15] = __builtin_amdgcn_s_memrealtime();
   x3_publish_range(range, p.status);
 }
 

@@ -142,21 +142,23 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_x3m_kernel(const TdnnKernelP
         q_split<false>(__uint_as_float(b.x), __uint_as_float(b.y), hi.z, h8b, l8b, range);
         q_split<true>(__uint_as_float(b.z), __uint_as_float(b.w), hi.w, h8b, l8b, range);
         *reinterpret_cast<uint4 *>(dst + w * QROWB + qswz(w, q) * 16) = hi;
-        *reinterpret_cast<uint2 *>(dst + w * QROWB + qswz(w, 4 + (q >> 1)) * 16 + (q & 1) * 8) = make_uint2((uint32_t)l8a, (uint32_t)l8b);
-        *reinterpret_cast<uint2 *>(dst + w * QROWB + qswz(w, 6 + (q >> 1)) * 16 + (q & 1) * 8) = make_uint2((uint32_t)h8a, (uint32_t)h8b);
+        // byte b of an 8-bit slot of lane half lh = channel (b < 8 ? 8 lh + b : 16 + 8 lh + b - 8): the order of the lane's two half fragments
+        *reinterpret_cast<uint2 *>(dst + w * QROWB + qswz(w, 4 + (q & 1)) * 16 + (q >> 1) * 8) = make_uint2((uint32_t)l8a, (uint32_t)l8b);
+        *reinterpret_cast<uint2 *>(dst + w * QROWB + qswz(w, 6 + (q & 1)) * 16 + (q >> 1) * 8) = make_uint2((uint32_t)h8a, (uint32_t)h8b);
       }
     }
   };
 
   const size_t frag_stride = (size_t)n_taps * nkg * 1024;                     // half fragments: bytes per 32-channel output fragment
-  const size_t frag8_stride = (size_t)n_taps * nchunks * 2048;                // 8-bit fragments: [tap][32-channel group][K block][lane][16]
+  const size_t frag8_stride = (size_t)n_taps * nchunks * 1024;                // 8-bit fragments (w_lo8): [tap][32-channel group][lane][16]
   const unsigned char *wh = reinterpret_cast<const unsigned char *>(p.wfrag) + (size_t)((n0 + wn * 64) / 32) * frag_stride + (size_t)lane * 16;
   const unsigned char *w8 = reinterpret_cast<const unsigned char *>(p.w8) + (size_t)((n0 + wn * 64) / 32) * frag8_stride + (size_t)lane * 16;
 
   // Operand registers (the accumulators take 128 of the 256): the weight fragments of the three phases each have their own registers and are
   // re-fetched from L2 right after their phase (two phases ahead of their next use); the LDS operands rotate through two sets of four,
   // fetched one phase ahead.
-  uint4 wh0[2], wh1[2], we[2][2];            // this wave's two 32-channel fragments: k-group 0, k-group 1 (halves), the pair's 8-bit K blocks
+  uint4 wh0[2], wh1[2], we[2];               // this wave's two 32-channel fragments: k-group 0, k-group 1 (halves), the pair's 8-bit K block 1 (w_lo8)
+  uint4 wq[2];                               // K block 0 (w_hi8): made in registers from wh0 (bytes 0-7) and wh1 (bytes 8-15), no memory traffic
   uint4 xa[4], xb[4];
   f32x16_t acc[4][2];
 #pragma unroll
@@ -170,9 +172,20 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_x3m_kernel(const TdnnKernelP
     const int i = q & 3, j = q >> 2;
     acc[i][j] = mfma16<ET_F16>(w[j], x[i], acc[i][j]);
   };
+  // the 8 half values of a weight fragment -> e4m3(w_hi 2^-6) in two registers (RNE: the bytes a host packer would write)
+  auto whi8 = [&](const uint4 &f, uint32_t &d0, uint32_t &d1) {
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+    s16x2 a = {0, 0}, b = {0, 0};
+    a = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(a, __builtin_bit_cast(h16x2, f.x), 64.0f, false);
+    a = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(a, __builtin_bit_cast(h16x2, f.y), 64.0f, true);
+    b = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(b, __builtin_bit_cast(h16x2, f.z), 64.0f, false);
+    b = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(b, __builtin_bit_cast(h16x2, f.w), 64.0f, true);
+    d0 = __builtin_bit_cast(uint32_t, a); d1 = __builtin_bit_cast(uint32_t, b);
+  };
   // corrections of accumulator (i, j): x0 / x1 = the frame fragment's K blocks 0 (x_lo8) / 1 (x_hi8)
   auto mma_mx = [&](int i, int j, const uint4 &x0, const uint4 &x1) {
-    const q_v8i a = {(int)we[j][0].x, (int)we[j][0].y, (int)we[j][0].z, (int)we[j][0].w, (int)we[j][1].x, (int)we[j][1].y, (int)we[j][1].z, (int)we[j][1].w};
+    const q_v8i a = {(int)wq[j].x, (int)wq[j].y, (int)wq[j].z, (int)wq[j].w, (int)we[j].x, (int)we[j].y, (int)we[j].z, (int)we[j].w};
     const q_v8i b = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
     acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc[i][j], 0, 1, 0, scale_w, 0, scale_x);      // e4m3 weights, e5m2 activations
   };
@@ -201,8 +214,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_x3m_kernel(const TdnnKernelP
   {
     wh0[0] = *reinterpret_cast<const uint4 *>(wh); wh0[1] = *reinterpret_cast<const uint4 *>(wh + frag_stride);
     wh1[0] = *reinterpret_cast<const uint4 *>(wh + 1024); wh1[1] = *reinterpret_cast<const uint4 *>(wh + frag_stride + 1024);
-    we[0][0] = *reinterpret_cast<const uint4 *>(w8); we[0][1] = *reinterpret_cast<const uint4 *>(w8 + 1024);
-    we[1][0] = *reinterpret_cast<const uint4 *>(w8 + frag8_stride); we[1][1] = *reinterpret_cast<const uint4 *>(w8 + frag8_stride + 1024);
+    we[0] = *reinterpret_cast<const uint4 *>(w8); we[1] = *reinterpret_cast<const uint4 *>(w8 + frag8_stride);
     uint32_t base; int sw;
     x_row(0, 0, base, sw);
 #pragma unroll
@@ -221,13 +233,14 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_x3m_kernel(const TdnnKernelP
     uint32_t base; int sw;
     x_row(c, t, base, sw);
     const size_t offh2 = ((size_t)t2 * nkg + (size_t)c2 * 2) * 1024;
-    const size_t off82 = ((size_t)t2 * nchunks + c2) * 2048;
+    const size_t off82 = ((size_t)t2 * nchunks + c2) * 1024;
     // phase 1: k-group 0 from (wh0, xa); the pair's 8-bit weights were requested one step ago - the NEXT pair's are requested behind phase 3
     {
       const uint32_t a = base + (uint32_t)(((2 + lh) ^ sw) << 4);                     // k-group 1 of this pair -> xb
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         if (q < 4) xb[q] = *reinterpret_cast<const uint4 *>(lds + a + q * 32 * QROWB);
+        if (q == 5) { whi8(wh0[0], wq[0].x, wq[0].y); whi8(wh0[1], wq[1].x, wq[1].y); }
         mma_main(wh0, xa, q);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -240,6 +253,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_x3m_kernel(const TdnnKernelP
         if (q == 0) { wh0[0] = *reinterpret_cast<const uint4 *>(wh + offh2); wh0[1] = *reinterpret_cast<const uint4 *>(wh + frag_stride + offh2); }
         if (q == 1) { xa[0] = *reinterpret_cast<const uint4 *>(lds + a0); xa[1] = *reinterpret_cast<const uint4 *>(lds + a1); }
         if (q == 2) { xa[2] = *reinterpret_cast<const uint4 *>(lds + a0 + 32 * QROWB); xa[3] = *reinterpret_cast<const uint4 *>(lds + a1 + 32 * QROWB); }
+        if (q == 5) { whi8(wh1[0], wq[0].z, wq[0].w); whi8(wh1[1], wq[1].z, wq[1].w); }
         mma_main(wh1, xb, q);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -278,8 +292,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_x3m_kernel(const TdnnKernelP
         mma_mx(2 + (q & 1), q >> 1, xb[2 * (q & 1)], xb[2 * (q & 1) + 1]);
         __builtin_amdgcn_sched_barrier(0);
       }
-      we[0][0] = *reinterpret_cast<const uint4 *>(w8 + off82); we[0][1] = *reinterpret_cast<const uint4 *>(w8 + off82 + 1024);
-      we[1][0] = *reinterpret_cast<const uint4 *>(w8 + frag8_stride + off82); we[1][1] = *reinterpret_cast<const uint4 *>(w8 + frag8_stride + off82 + 1024);
+      we[0] = *reinterpret_cast<const uint4 *>(w8 + off82); we[1] = *reinterpret_cast<const uint4 *>(w8 + frag8_stride + off82);
     }
     c = c2; t = t2;
   }

@@ -98,11 +98,14 @@ void pack_tdnn_weight_x3p(const float *w, int out_ch, int in_ch, int tot_ctx, in
     }
 }
 
-// 8-bit fragments of the f32m form (kernels_tdnn_chainm.hip, the scaled 8-bit matrix instruction): for the halves hi = half(w * scale),
-// lo = w * scale - hi that pack_tdnn_weight_frags splits into, [32-channel output fragment][tap][32-channel input group][K block]
-// [lane = (input sixteen lh, output channel lr)][16]: block 0 = e4m3(hi 2^-6) (hi < 2^14 under x3_weight_scale), block 1 = e4m3(lo 2^6)
-// (|lo| <= 2^-11 |hi|); byte q = input channel 32 group + 16 lh + q.  The kernel's block scales undo the 2^-6 / 2^6.
-size_t tdnn_weight_mx8_bytes(int cout_pad, int cin_pad, int n_taps) { return (size_t)(cout_pad / 32) * n_taps * ((cin_pad + 31) / 32) * 2048; }
+// 8-bit fragments of the f32m form (kernels_tdnn_chainm.hip / kernels_tdnn_x3m.hip, the scaled 8-bit matrix instruction): for the halves
+// hi = half(w * scale), lo = w * scale - hi that pack_tdnn_weight_frags splits into, e4m3(lo 2^6) (|lo| <= 2^-11 |hi|, hi < 2^14 under
+// x3_weight_scale) as [32-channel output fragment][tap][32-channel input group][lane = (lh, output channel lr)][16]; byte q of lane half lh =
+// input channel 32 group + (q < 8 ? 8 lh + q : 16 + 8 lh + q - 8) - the channels the lane's two half fragments of the group hold, in their
+// order: the kernels make the OTHER 8-bit weight block, e4m3(hi 2^-6), from those half fragments in registers (v_cvt_scalef32_pk_fp8_f16),
+// so it costs no memory traffic (the weight stream from L2 is what bounds these kernels: profiles/r6j_*).  The kernels' block scales undo
+// the 2^6 / 2^-6.
+size_t tdnn_weight_mx8_bytes(int cout_pad, int cin_pad, int n_taps) { return (size_t)(cout_pad / 32) * n_taps * ((cin_pad + 31) / 32) * 1024; }
 void pack_tdnn_weight_mx8(const float *w, int out_ch, int in_ch, int tot_ctx, int left_ctx, const int *taps, int n_taps, int cout_pad, int cin_pad,
                           float scale, uint8_t *dst) {
   const int ngroups = (cin_pad + 31) / 32;                    // (a last, partial group is zero-padded: e4m3(0) = 0)
@@ -112,12 +115,10 @@ void pack_tdnn_weight_mx8(const float *w, int out_ch, int in_ch, int tot_ctx, in
     for (int t = 0; t < n_taps; ++t) {
       const int k = taps[t] - left_ctx;
       for (int ci = 0; ci < in_ch; ++ci) {
-        const int g = ci / 32, lh = (ci % 32) / 16, q = ci % 16;
+        const int g = ci / 32, r = ci % 32, kg = r / 16, lh = (r % 16) / 8, q = kg * 8 + r % 8;
         const float v = w[((size_t)co * in_ch + ci) * tot_ctx + k] * scale;
         const float hi = f16_to_f32_host(f32_to_f16_host(v));
-        const size_t idx = (((size_t)nf * n_taps + t) * ngroups + g) * 2048 + (size_t)(lh * 32 + lr) * 16 + q;
-        dst[idx] = f32_to_e4m3_host(hi * 0.015625f);
-        dst[idx + 1024] = f32_to_e4m3_host((v - hi) * 64.0f);
+        dst[(((size_t)nf * n_taps + t) * ngroups + g) * 1024 + (size_t)(lh * 32 + lr) * 16 + q] = f32_to_e4m3_host((v - hi) * 64.0f);
       }
     }
   }
@@ -1311,6 +1312,8 @@ int run_ops(RunCtx &c, size_t n_ops) {
             cp.et = chain_x3 ? net->x3_et() : et;
             cp.min_seg_len = min_len;
             cp.status = status_word(net);
+            static const int chainm_abl = getenv("ASV_AMD_CHAINM_ABL") != nullptr ? atoi(getenv("ASV_AMD_CHAINM_ABL")) : 0;       // developer aid, read once
+            cp.abl = (chainm_abl & 7) != 0 && getenv("ASV_AMD_CHAIN_DBG") == nullptr ? (chainm_abl & 8) : chainm_abl;               // the garbage-result bits only under ASV_AMD_CHAIN_DBG
             cp.n128 = plan.n128; cp.n_tail = plan.n_tail; cp.tail_rows = plan.tail_rows;
             if ((rc = ensure(net->poolpart_dev, (size_t)n_blocks * slots * 2 * 3 * cp.ld_partial * 4, c.s, false))) return rc;
             cp.pool_partial = reinterpret_cast<float *>(net->poolpart_dev.ptr);
@@ -1319,19 +1322,21 @@ int run_ops(RunCtx &c, size_t n_ops) {
             if ((rc = prof.begin(K_TDNN, fl, (int)i))) return rc;
             static const int chain_dbg = getenv("ASV_AMD_CHAIN_DBG") != nullptr ? std::max(1, atoi(getenv("ASV_AMD_CHAIN_DBG"))) : 0;   // developer aid: phase durations to stderr
             DevMem dbg;
-            if (chain_dbg && !chain_x3) {
-              if ((rc = ensure(dbg, (size_t)(p.rows / 128) * 8 * 32 * 8, c.s, true))) return rc;
-              cp.dbg = reinterpret_cast<unsigned long long *>(dbg.ptr);
-              cp.dbg_fine = chain_dbg >= 3;
-            }
             // f32m: the chain with its correction products on the scaled 8-bit instruction, when every layer of it has 8-bit fragments
             bool chain_mx = chain_x3 && net->x3_mx() && cp.first.w8 != nullptr && cp.last.w8 != nullptr;
             for (int m = 0; m < cp.n_mid; ++m) chain_mx = chain_mx && cp.mid[m].w8 != nullptr;
+            const size_t dbg_wgs = chain_mx ? (size_t)(p.rows / 64) : (size_t)(p.rows / 128);
+            if (chain_dbg && (!chain_x3 || chain_mx)) {
+              if ((rc = ensure(dbg, dbg_wgs * 8 * 32 * 8, c.s, true))) return rc;
+              cp.dbg = reinterpret_cast<unsigned long long *>(dbg.ptr);
+              cp.dbg_fine = chain_dbg >= 3;
+
+            }
             if (chain_mx) ++g_kernel_launches[ASV_KERNEL_TDNN_CHAINM];
             if ((rc = chain_mx ? launch_tdnn_chainm(cp, c.s) : (chain_x3 ? launch_tdnn_chainx(cp, c.s) : launch_tdnn_chain(cp, c.s)))) return rc;
             if ((rc = prof.end())) return rc;
-            if (chain_dbg && !chain_x3) {
-              const size_t nwg = (size_t)(p.rows / 128);
+            if (chain_dbg && (!chain_x3 || chain_mx)) {
+              const size_t nwg = dbg_wgs;
               std::vector<unsigned long long> h(nwg * 8 * 32);
               ASV_HIP_CHECK(hipStreamSynchronize(c.s));
               ASV_HIP_CHECK(hipMemcpy(h.data(), dbg.ptr, h.size() * 8, hipMemcpyDeviceToHost));
@@ -1358,6 +1363,20 @@ int run_ops(RunCtx &c, size_t n_ops) {
                 fprintf(stderr, ", publish %.0f", sum[21] / (double)std::max<size_t>(cnt, 1));
               }
               fprintf(stderr, "\n");
+              if (chain_mx && chain_dbg >= 3) {                      // layer A, steps 0 .. 14: mean cycles per step, by wave
+                for (int wv = 0; wv < 8; ++wv) {
+                  double d[15] = {0}; size_t cn = 0;
+                  for (size_t wg = 0; wg < nwg; ++wg) {
+                    const unsigned long long *t = &h[(wg * 8 + wv) * 32];
+                    if (t[16] == 0 || t[31] <= t[16]) continue;
+                    for (int k = 0; k < 15; ++k) d[k] += (double)(t[17 + k] - t[16 + k]);
+                    ++cn;
+                  }
+                  fprintf(stderr, "[chainm dbg] wave %d, cycles of layer A's steps 0..14:", wv);
+                  for (int k = 0; k < 15; ++k) fprintf(stderr, " %.0f", d[k] / (double)std::max<size_t>(cn, 1));
+                  fprintf(stderr, "\n");
+                }
+              }
               {                                                       // 4-wave kernel, ablation 8: fine stamps of wave 0's third unit (slots of wave 4..7)
                 double fs[25] = {0}; size_t fc = 0;
                 for (size_t wg = 0; wg < nwg; ++wg) {

@@ -135,3 +135,27 @@ def test_res2_chain_kernel_forms_fit_their_lds_and_registers(tmp_path):
         assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1)) == 0, name
         assert int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1)) == 2, name
         assert int(re.search(r"LDS Size \[bytes/block\]: (\d+)", b).group(1)) == {6: 111104, 7: 127488}[fr], name
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_f32m_kernels_fit_their_registers_and_lds(tmp_path):
+    """The 8-bit correction kernels of the f32m form (round 6): tdnn_chainm_kernel - 64 accumulators, two sets of weight fragments, one
+    workgroup of 8 waves per CU = 256 registers per lane - must not spill at all (its K loops are bound by the weight stream: a spilled
+    fragment would add to it) and must fit one CU's LDS; tdnn_gemm_x3m_kernel<false> - 128 accumulators at two workgroups per CU - may park
+    a few lane-constant values outside its K loop (pinned here at <= 8 spilled registers), with LDS for two workgroups."""
+    seen = {}
+    for name in ("kernels_tdnn_chainm.hip", "kernels_tdnn_x3m.hip"):
+        out = tmp_path / (name + ".s")
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(REPO, "include"), "-I" + CSRC, "-Xclang", "-target-feature", "-Xclang",
+               "-packed-fp32-ops", "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o", str(out), os.path.join(CSRC, name)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        for block in re.split(r"remark: [^\n]*Function Name: ", r.stderr)[1:]:
+            fn = block.split()[0]
+            seen[fn] = {k: int(re.search(p, block).group(1)) for k, p in (("vgprs", r" VGPRs: (\d+)"), ("spill", r"VGPRs Spill: (\d+)"),
+                                                                         ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"), ("lds", r"LDS Size \[bytes/block\]: (\d+)"))}
+    chain = [v for k, v in seen.items() if "tdnn_chainm_kernel" in k]
+    x3m = [v for k, v in seen.items() if "tdnn_gemm_x3m_kernelILb0" in k]
+    assert len(chain) == 1 and len(x3m) == 1, sorted(seen)
+    assert chain[0]["spill"] == 0 and chain[0]["scratch"] == 0 and chain[0]["vgprs"] <= 256 and chain[0]["lds"] <= 160 * 1024, chain
+    assert x3m[0]["spill"] <= 8 and x3m[0]["vgprs"] <= 256 and 2 * x3m[0]["lds"] <= 160 * 1024, x3m
