@@ -125,7 +125,7 @@ struct TdnnKernelParams {
   int halo;             // max |tap offset| of this layer (selects the window size of the 128x128 kernel)
   int x3_et, x3_terms;  // f32x kernel (kernels_tdnn_x3.hip): 16-bit type of the operand halves (ET_BF16 / ET_F16) and which products run -
                         // bit 0: w_hi x_hi, bit 1: w_hi x_lo, bit 2: w_lo x_hi (7 = the f32-grade mode; the others are the measured
-                        // "why not two matrix instructions" variants)
+                        // "why not two matrix instructions" variants, LABLOG.md "Precision modes")
   int x3_tile;          // f32x kernel: 0 = pick the tile rows from the batch size, 128 = ASV_FLAG_X3_TILE128
   float w_unscale;      // f32x kernel: the accumulators are multiplied by this (1 / the power of two the host scaled the weights by)
   int et;               // ET_*: element type of x / x2 / res / y rows and of the packed weights (the launchers without an `et` argument read it)

@@ -30,7 +30,7 @@
 // profiles/r2r_coissue2.txt): the two waves of a SIMD do alternate loop / epilogue, a loop takes 10.3k cycles with or without a
 // computing partner, an epilogue 12 - 15k next to a partner's loop and 4.0k alone - the epilogue sets the period.  Its packed f32
 // operations only issue in the gaps of the partner's MFMA stream, plain ones would at ~8 cycles each (twice as many: no gain,
-// profiles/r2s_lib_ab_packed_fp32.txt); behind a wave's OWN MFMAs a plain VALU operation costs ~0.5 cycle.  Next step (DESIGN.md
+// profiles/r2s_lib_ab_packed_fp32.txt); behind a wave's OWN MFMAs a plain VALU operation costs ~0.5 cycle.  Next step (LABLOG.md
 // section 8): the pooling arithmetic of unit u interleaved into the MFMA loop of unit u + 1 of the same wave.
 // Tried and dropped at the end of round 2 (profiles/r2v_ab_chain_prefetch.txt): bias / BN scale of the NEXT unit loaded before a
 // unit's K loop and the next unit's first weight fragments fetched by the last K step (no memory round trip at the start of a

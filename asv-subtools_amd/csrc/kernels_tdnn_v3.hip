@@ -194,7 +194,7 @@ __global__ __launch_bounds__(Geom3<WM>::WAVES * 64, WM == 0 ? 3 : 2) void tdnn_g
 
   // Plain epilogue (ABL 3 = the first form, for in-process A/B): the gap-row mask is applied to the packed bf16 pairs (2 selects
   // per 4 values instead of 4) - a saturating MFMA stream leaves the SIMD's VALU no issue slot, so every VALU instruction of an
-  // epilogue is paid in full.  Starting the accumulators from the bias saves another 128 additions
+  // epilogue is paid in full (LABLOG.md, round 2 item 1).  Starting the accumulators from the bias saves another 128 additions
   // per wave tile (736 -> 449 VALU operations, +0.2 % / +0.6 % per x-vector / ECAPA step in the A/B of profiles/r2q_*) but moves
   // the bias to the front of the f32 sum: the outputs are then no longer bit-identical to the generic tile's, which layer
   // shapes beyond this kernel's 32-bit row offsets fall back to - an utterance's bits would depend on the batch it is in.

@@ -22,7 +22,7 @@ PRECISIONS = {"f32": capi.PREC_F32, "fp32": capi.PREC_F32, "float32": capi.PREC_
 H16_MODES = ("bf16", "bfloat16", "f16", "fp16", "half", "float16")       # 16-bit frames-domain storage
 
 # options of the f32x mode, appended with '-' (e.g. "f32x-bf16"): the 16-bit type the operands are split into, and the
-# reduced-product MEASUREMENT variants ("why not two matrix instructions per product", DESIGN.md "Precision modes")
+# reduced-product MEASUREMENT variants ("why not two matrix instructions per product", LABLOG.md "Precision modes")
 X3_OPTIONS = {"bf16": capi.FLAG_X3_SPLIT_BF16, "f16": capi.FLAG_X3_SPLIT_F16, "half": capi.FLAG_X3_SPLIT_F16,
               "noxlo": capi.FLAG_X3_NO_XLO, "nowlo": capi.FLAG_X3_NO_WLO, "mx": capi.FLAG_X3_MX8}
 
@@ -50,7 +50,7 @@ def default_precision():
     tests/gate_table.py, at 1.35 x the rate of 'f32x' on the x-vector.  'f32x': all three products on the 16-bit instruction (~1e-7; ~3 x the
     rate of 'f32', the exact f32-input MFMA and bit-for-bit fma chain).  'bf16' / 'f16' are the throughput modes (16-bit storage and products,
     f32 accumulate, f32 pooled tail; 'f16' rounds 8x finer at the same rate, operands within +-65504; their measured distance from the
-    gates: tests/test_gpu_eer_gate.py, DESIGN.md "Precision modes")."""
+    gates: tests/test_gpu_eer_gate.py)."""
     return os.environ.get("ASV_AMD_PRECISION", "f32m").lower()
 
 

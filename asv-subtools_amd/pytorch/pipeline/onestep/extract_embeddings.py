@@ -340,7 +340,7 @@ class ScpBatchLoader(object):
     utterance) stays available: it is what extract_sharded takes as `load_utt`.
     The payload reads of a batch are ONE call into libasv_io.so (csrc/host_io.c: positioned reads on `threads` native threads,
     the GIL released for the whole call); without that library (not built) the same reads are issued from Python, one per
-    utterance.  Measured on the build host (20 000 x [200, 80] float32 from the page cache; DESIGN.md row "a16, e (host side)"):
+    utterance.  Measured on the build host (20 000 x [200, 80] float32 from the page cache; LABLOG.md row "a16, e (host side)"):
     203 k utterances/s = 13 GB/s on 4 native threads (1: 92 k, 8: 213 k); the Python reads: 66 k on one thread and LESS when
     split over Python threads (4: 43 k - a 64 KiB read is ~12 us, the Python around it ~3 us under the GIL, the hand-over
     between threads costs more than it buys); the round-3 path (read_mat per utterance + concatenate): 10 k.

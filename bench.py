@@ -4,7 +4,7 @@
 One "step" = one pass of the hot path over one batch of synthetic input that is already resident in HBM:
 BASELINE.json configs[1] - standard TDNN x-vector, 80-dim fbank, 200-frame utterances, bf16 MFMA (f32 accumulate,
 f32 pooled tail) - 256 utterances per GPU per step, exactly as configs[1] states; the same harness at 640 utterances per step
-(whole rounds of workgroups) is reported in the same line (`value_at_b640`, `roofline_at_b640`).
+(whole rounds of workgroups, see LABLOG.md) is reported in the same line (`value_at_b640`, `roofline_at_b640`).
 Weak scaling: every rank extracts its own shard; with N > 1 the embeddings are collected with one RCCL all-gather per
 step (the path's only exchange).
 

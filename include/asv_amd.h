@@ -71,7 +71,7 @@ int         asv_device_count(int *count);
 #define ASV_FLAG_X3_SPLIT_F16  64u /* half hi + half lo: 22 significant bits per operand (weights pre-scaled by a power of two per
                                     * layer so that both halves are normal numbers), operands within +-65504                      */
 /* ... and measurement variants that drop one of the three products hi*hi + w_hi*x_lo + w_lo*x_hi (NOT f32-grade: they exist so
- * that "two matrix instructions per product are not enough" is a measured statement, DESIGN.md "Precision modes") */
+ * that "two matrix instructions per product are not enough" is a measured statement, LABLOG.md "Precision modes") */
 #define ASV_FLAG_X3_NO_XLO   128u  /* activations rounded to one 16-bit value (no w_hi*x_lo product) */
 #define ASV_FLAG_X3_NO_WLO   256u  /* weights rounded to one 16-bit value (no w_lo*x_hi product)     */
 #define ASV_FLAG_X3_MX8     1024u  /* ASV_PREC_F32X with half halves ("f32m"): the two correction products w_hi*x_lo + w_lo*x_hi run as ONE block-scaled

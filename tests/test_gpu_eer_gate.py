@@ -123,6 +123,6 @@ def test_gates_as_statistics_per_model(model, capsys):
     x = tab["modes"]["f32x"]
     assert x["gate_1e-4"] and x["eer_gate_every_draw"], x
     assert all(0.3 < e < 45.0 for e in tab["eer_f32_percent"]), tab["eer_f32_percent"]          # non-trivial error rates on every seed
-    # the throughput modes: bounded against gross regressions only (measured: DESIGN.md "Precision modes")
+    # the throughput modes: bounded against gross regressions only (measured: DESIGN.md section 5, LABLOG.md "Precision modes")
     assert tab["modes"]["f16"]["embedding_max_rel_err"] < 0.5 * tab["modes"]["bf16"]["embedding_max_rel_err"]
     assert tab["modes"]["bf16"]["worst_abs_eer_delta_percent"] < 3.0
