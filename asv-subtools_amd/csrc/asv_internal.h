@@ -103,7 +103,7 @@ struct TdnnKernelParams {
                         // - its own pointer, so that neither family can ever be handed the other's layout - or nullptr
   const void *wlo;      // pooled-domain layers and the f32x frame kernel: the bf16 'lo' halves (w - hi), same layout as wfrag, or nullptr
   const void *wx3p;     // f32x 8-phase kernel (kernels_tdnn_p8x.hip): [cout_pad][tap][chunk32][hi 32 | lo 32] 16-bit halves of w * 2^s, or nullptr
-  const void *w8;       // f32m form (kernels_tdnn_x3m.hip): 8-bit fragments [w_hi8 | w_lo8] of w * 2^s (pack_tdnn_weight_mx8), or nullptr
+  const void *w8;       // f32m form (kernels_tdnn_x3m.hip): 8-bit fragments of w * 2^s, planes [w_lo8][w_hi8] (pack_tdnn_weight_mx8), or nullptr
   // split-K (small-M layers: the pooled domain): blockIdx.y walks `ksplit` slices of the channel
   // chunks, raw f32 accumulators go to partial[slice][rows][ld_partial]; a second kernel sums
   // the slices in order and applies the epilogue (deterministic, no atomics)
@@ -196,7 +196,7 @@ struct TdnnChainLayer {
   const void *wfrag; const float *bias, *scale, *shift;   // scale / shift may be nullptr (1, 0)
   int relu, cout_pad;
   const void *wlo; float w_scale;                          // f32x chain (kernels_tdnn_chainx.hip): lo halves, and the power of two both halves carry
-  const void *w8;                                          // f32m chain (kernels_tdnn_chainm.hip): 8-bit fragments [w_hi8 | w_lo8] (pack_tdnn_weight_mx8)
+  const void *w8;                                          // f32m chain (kernels_tdnn_chainm.hip): 8-bit fragments, planes [w_lo8][w_hi8] (pack_tdnn_weight_mx8)
 };
 struct TdnnChainParams {
   const void *x; int ldx, rows, cin_pad, n_taps; int taps[ASV_MAX_TAPS];     // input of the first layer (bf16 rows)
@@ -239,6 +239,9 @@ int launch_tdnn_chain4(const TdnnChainParams &p, hipStream_t s);
 int launch_tdnn_chainx(const TdnnChainParams &p, hipStream_t s);
 // the same with the two correction products on the block-scaled 8-bit matrix instruction ("f32m", ASV_FLAG_X3_MX8; kernels_tdnn_chainm.hip)
 int launch_tdnn_chainm(const TdnnChainParams &p, hipStream_t s);
+// ... in 96-frame tiles (kernels_tdnn_chainm96.hip): 1.5 x the matrix work per byte of the weight stream that bounds the 64-frame kernel
+int chainm96_tiles(int rows);
+int launch_tdnn_chainm96(const TdnnChainParams &p, hipStream_t s);
 // ECAPA Res2NetBlock as one kernel (kernels_res2.hip)
 constexpr int kRes2Width = 128;
 struct Res2KernelParams {

@@ -44,6 +44,10 @@
 
 #include "device_utils.h"
 
+#ifndef CHAINM_WHI8_REG
+#define CHAINM_WHI8_REG 0      // 1: e4m3(w_hi) made in registers from the half fragments (24 conversions per step) instead of fetched (rounds 6i - 6r)
+#endif
+
 namespace asv {
 namespace {
 
@@ -135,10 +139,16 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
   // (w_lo8) of the scaled instruction - TWO sets, fetched a whole step ahead (round 6: with the half fragments single-buffered and re-fetched
   // ~350 matrix cycles ahead the K loops ran at 0.6 - 0.7 of the matrix rate, profiles/r6i_chainm_phase_stamps.txt).  Rows (from LDS): the
   // two frame fragments per k-group, single-buffered two phases ahead, and their 8-bit K blocks x8[i][block], two sets.
+#if CHAINM_WHI8_REG
   struct MW { uint4 h0[2], h1[2], e[2]; };
+#else
+  struct MW { uint4 h0[2], h1[2], e[2], q[2]; };      // q: K block 0 of the pair's 8-bit weights, e4m3(w_hi 2^-6), from the array's second plane
+#endif
   struct MX8 { uint4 x[2][2]; };
   uint4 h0x[2], h1x[2];
+#if CHAINM_WHI8_REG
   uint4 wq[2];                              // K block 0 of the pair's weights (w_hi8), made in registers from the two half fragments (whi8 below)
+#endif
   f32x16_t acc[2][2];
   // the accumulators start from bias * w_scale (the weights carry the power of two w_scale; the epilogues multiply by 1 / w_scale):
   // TR = false: acc[i][j][4 q + e] = channel j * 32 + 8 q + 4 lh + e of the wave's slice; TR = true: lane = channel j * 32 + lr
@@ -183,7 +193,11 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
   };
   auto mma_mx = [&](const MW &w, const MX8 &e, int q, auto tr) {
     const int i = q & 1, j = q >> 1;
+#if CHAINM_WHI8_REG
     const mx_v8i a = {(int)wq[j].x, (int)wq[j].y, (int)wq[j].z, (int)wq[j].w, (int)w.e[j].x, (int)w.e[j].y, (int)w.e[j].z, (int)w.e[j].w};
+#else
+    const mx_v8i a = {(int)w.q[j].x, (int)w.q[j].y, (int)w.q[j].z, (int)w.q[j].w, (int)w.e[j].x, (int)w.e[j].y, (int)w.e[j].z, (int)w.e[j].w};
+#endif
     const mx_v8i b = {(int)e.x[i][0].x, (int)e.x[i][0].y, (int)e.x[i][0].z, (int)e.x[i][0].w, (int)e.x[i][1].x, (int)e.x[i][1].y, (int)e.x[i][1].z, (int)e.x[i][1].w};
     // operand formats: 0 = e4m3 (weights), 1 = e5m2 (activations)
     if constexpr (decltype(tr)::value) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b, a, acc[i][j], 1, 0, 0, scale_x, 0, scale_w);
@@ -251,6 +265,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
     const size_t frag8_stride = (size_t)n_taps * nchunks * 1024;               // 8-bit fragments (w_lo8): [tap][32-channel group][lane][16]
     const unsigned char *wh = reinterpret_cast<const unsigned char *>(p.first.wfrag) + (size_t)(wave * 2) * frag_stride + lane16;
     const unsigned char *w8 = reinterpret_cast<const unsigned char *>(p.first.w8) + (size_t)(wave * 2) * frag8_stride + lane16;
+    const size_t plane8 = (size_t)(kChainWidth / 32) * frag8_stride;           // the w_hi8 plane follows the w_lo8 plane (pack_tdnn_weight_mx8)
     const int v_taps = p.taps[lane < 9 ? lane : 0];
     // LDS byte address of this lane's row of the image in buffer `buf` for tap t, and its swizzle term (blind to + 32 rows)
     auto x_row = [&](int buf, int t, uint32_t &base, int &sw) {
@@ -264,6 +279,9 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
       w.h0[0] = *reinterpret_cast<const uint4 *>(wh + offh); w.h0[1] = *reinterpret_cast<const uint4 *>(wh + frag_stride + offh);
       w.h1[0] = *reinterpret_cast<const uint4 *>(wh + offh + 1024); w.h1[1] = *reinterpret_cast<const uint4 *>(wh + frag_stride + offh + 1024);
       w.e[0] = *reinterpret_cast<const uint4 *>(w8 + off8); w.e[1] = *reinterpret_cast<const uint4 *>(w8 + frag8_stride + off8);
+#if !CHAINM_WHI8_REG
+      w.q[0] = *reinterpret_cast<const uint4 *>(w8 + plane8 + off8); w.q[1] = *reinterpret_cast<const uint4 *>(w8 + plane8 + frag8_stride + off8);
+#endif
     };
     // prologue: windows 0, 1, 2 in flight; 0 and 1 converted at once (the K loop's first barrier follows the first chunk)
     issue_A(0, 0);
@@ -334,10 +352,15 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
         if (q == 0) { wn.h0[0] = *reinterpret_cast<const uint4 *>(wh + offh); wn.h0[1] = *reinterpret_cast<const uint4 *>(wh + frag_stride + offh); }
         if (q == 0) { wn.h1[0] = *reinterpret_cast<const uint4 *>(wh + offh + 1024); wn.h1[1] = *reinterpret_cast<const uint4 *>(wh + frag_stride + offh + 1024); }
         if (q == 1) { wn.e[0] = *reinterpret_cast<const uint4 *>(w8 + off8); wn.e[1] = *reinterpret_cast<const uint4 *>(w8 + frag8_stride + off8); }
+#if !CHAINM_WHI8_REG
+        if (q == 1) { wn.q[0] = *reinterpret_cast<const uint4 *>(w8 + plane8 + off8); wn.q[1] = *reinterpret_cast<const uint4 *>(w8 + plane8 + frag8_stride + off8); }
+#endif
         if (q == 1 && enter && c + 3 < nchunks && (p.abl & 2) == 0) issue_A(c + 3, cb);
         if (q == 1 && cv) cv_load(cb2);
         if (q == 2) { en.x[0][0] = *reinterpret_cast<const uint4 *>(lds + ax0); en.x[0][1] = *reinterpret_cast<const uint4 *>(lds + ax1); }
+#if CHAINM_WHI8_REG
         if (q == 2) { whi8(wc.h0[0], wq[0].x, wq[0].y); whi8(wc.h0[1], wq[1].x, wq[1].y); }
+#endif
         if (q == 3) { en.x[1][0] = *reinterpret_cast<const uint4 *>(lds + ax0 + 32 * MROW); en.x[1][1] = *reinterpret_cast<const uint4 *>(lds + ax1 + 32 * MROW); }
         mma_main(wc.h0, h0x, q, MTrNo{});
         __builtin_amdgcn_sched_barrier(0);
@@ -347,7 +370,9 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
       for (int q = 0; q < 4; ++q) {
         mma_main(wc.h1, h1x, q, MTrNo{});
         if (q == 0) { h0x[0] = *reinterpret_cast<const uint4 *>(lds + ah0); h0x[1] = *reinterpret_cast<const uint4 *>(lds + ah0 + 32 * MROW); }
+#if CHAINM_WHI8_REG
         if (q == 1) { whi8(wc.h1[0], wq[0].z, wq[0].w); whi8(wc.h1[1], wq[1].z, wq[1].w); }
+#endif
         if (q == 2 && cv) cv_store(cb2);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -413,7 +438,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
 
   // main loop of a layer whose input is Y: K = 512 = 16 pairs of 32 channels, no barrier.  wbh / wb8: wave-uniform bases of the half / 8-bit
   // fragment arrays of this wave's (or unit's) first 32-channel output fragment; the second follows at + 32 KiB in both.
-  auto yloop = [&](const unsigned char *wbh, const unsigned char *wb8, const float *bias64, float w_scale, auto tr) {
+  auto yloop = [&](const unsigned char *wbh, const unsigned char *wb8, size_t plane8, const float *bias64, float w_scale, auto tr) {
     constexpr size_t fs = (size_t)(MN / 16) * 1024, fs8 = (size_t)(MN / 32) * 1024;
     const uint32_t yb = (uint32_t)(lr * MYROW);
     const uint32_t sx = (uint32_t)(lh ^ (lr & 15));
@@ -424,6 +449,9 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
       w.h0[0] = *reinterpret_cast<const uint4 *>(wbh + offh); w.h0[1] = *reinterpret_cast<const uint4 *>(wbh + fs + offh);
       w.h1[0] = *reinterpret_cast<const uint4 *>(wbh + offh + 1024); w.h1[1] = *reinterpret_cast<const uint4 *>(wbh + fs + offh + 1024);
       w.e[0] = *reinterpret_cast<const uint4 *>(wb8 + off8); w.e[1] = *reinterpret_cast<const uint4 *>(wb8 + fs8 + off8);
+#if !CHAINM_WHI8_REG
+      w.q[0] = *reinterpret_cast<const uint4 *>(wb8 + plane8 + off8); w.q[1] = *reinterpret_cast<const uint4 *>(wb8 + plane8 + fs8 + off8);
+#endif
     };
     ld_w(0, w0);
     {
@@ -448,8 +476,13 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
         if (q == 0) { wn.h0[0] = *reinterpret_cast<const uint4 *>(wbh + offh); wn.h0[1] = *reinterpret_cast<const uint4 *>(wbh + fs + offh); }
         if (q == 0) { wn.h1[0] = *reinterpret_cast<const uint4 *>(wbh + offh + 1024); wn.h1[1] = *reinterpret_cast<const uint4 *>(wbh + fs + offh + 1024); }
         if (q == 1) { wn.e[0] = *reinterpret_cast<const uint4 *>(wb8 + off8); wn.e[1] = *reinterpret_cast<const uint4 *>(wb8 + fs8 + off8); }
+#if !CHAINM_WHI8_REG
+        if (q == 1) { wn.q[0] = *reinterpret_cast<const uint4 *>(wb8 + plane8 + off8); wn.q[1] = *reinterpret_cast<const uint4 *>(wb8 + plane8 + fs8 + off8); }
+#endif
         if (q == 2) { en.x[0][0] = *reinterpret_cast<const uint4 *>(lds + ax0); en.x[0][1] = *reinterpret_cast<const uint4 *>(lds + ax1); }
+#if CHAINM_WHI8_REG
         if (q == 2) { whi8(wc.h0[0], wq[0].x, wq[0].y); whi8(wc.h0[1], wq[1].x, wq[1].y); }
+#endif
         if (q == 3) { en.x[1][0] = *reinterpret_cast<const uint4 *>(lds + ax0 + 32 * MYROW); en.x[1][1] = *reinterpret_cast<const uint4 *>(lds + ax1 + 32 * MYROW); }
         mma_main(wc.h0, h0x, q, tr);
         __builtin_amdgcn_sched_barrier(0);
@@ -458,7 +491,9 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
       for (int q = 0; q < 4; ++q) {
         mma_main(wc.h1, h1x, q, tr);
         if (q == 0) { h0x[0] = *reinterpret_cast<const uint4 *>(lds + ah0); h0x[1] = *reinterpret_cast<const uint4 *>(lds + ah0 + 32 * MYROW); }
+#if CHAINM_WHI8_REG
         if (q == 1) { whi8(wc.h1[0], wq[0].z, wq[0].w); whi8(wc.h1[1], wq[1].z, wq[1].w); }
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
@@ -476,6 +511,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
   };
 
   __builtin_amdgcn_s_setprio(0);
+  stamp();                                                       // 2: layer A's K loop
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();            // every wave is done with layer A's stages and images: Y may be written
   asm volatile("" ::: "memory");
@@ -493,7 +529,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
     stage_params(L);
     const unsigned char *wbh = reinterpret_cast<const unsigned char *>(L.wfrag) + (size_t)(wave * 2) * ((size_t)(MN / 16) * 1024);
     const unsigned char *wb8 = reinterpret_cast<const unsigned char *>(L.w8) + (size_t)(wave * 2) * ((size_t)(MN / 32) * 1024);
-    yloop(wbh, wb8, L.bias + wave * 64, L.w_scale, MTrNo{});
+    yloop(wbh, wb8, (size_t)(L.cout_pad / 32) * ((size_t)(MN / 32) * 1024), L.bias + wave * 64, L.w_scale, MTrNo{});
     stamp();                                                     // 5: a middle layer's K loop
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();          // nobody reads the old Y any more (and the staged constants are visible)
@@ -520,7 +556,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
     for (int cb = wave * 64; cb < L.cout_pad; cb += 512) {
       const unsigned char *wbh = reinterpret_cast<const unsigned char *>(L.wfrag) + (size_t)(cb / 32) * ((size_t)(MN / 16) * 1024);
       const unsigned char *wb8 = reinterpret_cast<const unsigned char *>(L.w8) + (size_t)(cb / 32) * ((size_t)(MN / 32) * 1024);
-      yloop(wbh, wb8, L.bias + cb, L.w_scale, MTrYes{});
+      yloop(wbh, wb8, (size_t)(L.cout_pad / 32) * ((size_t)(MN / 32) * 1024), L.bias + cb, L.w_scale, MTrYes{});
       stamp();                                                   // 7, 9, 11: a unit's K loop
       // Pooling epilogue, registers only (kernels_tdnn_chainx.hip, the same arithmetic): acc[i][j][r] = channel cb + j*32 + lr, frame
       // i*32 + 8 (r >> 2) + 4 lh + (r & 3); a lane sums its own frames per utterance about the pivot of its FIRST frame of that utterance,

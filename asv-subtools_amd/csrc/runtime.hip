@@ -99,17 +99,20 @@ void pack_tdnn_weight_x3p(const float *w, int out_ch, int in_ch, int tot_ctx, in
 }
 
 // 8-bit fragments of the f32m form (kernels_tdnn_chainm.hip / kernels_tdnn_x3m.hip, the scaled 8-bit matrix instruction): for the halves
-// hi = half(w * scale), lo = w * scale - hi that pack_tdnn_weight_frags splits into, e4m3(lo 2^6) (|lo| <= 2^-11 |hi|, hi < 2^14 under
-// x3_weight_scale) as [32-channel output fragment][tap][32-channel input group][lane = (lh, output channel lr)][16]; byte q of lane half lh =
-// input channel 32 group + (q < 8 ? 8 lh + q : 16 + 8 lh + q - 8) - the channels the lane's two half fragments of the group hold, in their
-// order: the kernels make the OTHER 8-bit weight block, e4m3(hi 2^-6), from those half fragments in registers (v_cvt_scalef32_pk_fp8_f16),
-// so it costs no memory traffic (the weight stream from L2 is what bounds these kernels: profiles/r6j_*).  The kernels' block scales undo
-// the 2^6 / 2^-6.
-size_t tdnn_weight_mx8_bytes(int cout_pad, int cin_pad, int n_taps) { return (size_t)(cout_pad / 32) * n_taps * ((cin_pad + 31) / 32) * 1024; }
+// hi = half(w * scale), lo = w * scale - hi that pack_tdnn_weight_frags splits into, two planes of
+// [32-channel output fragment][tap][32-channel input group][lane = (lh, output channel lr)][16]: plane 0 = e4m3(lo 2^6) (|lo| <= 2^-11 |hi|,
+// hi < 2^14 under x3_weight_scale), plane 1 = e4m3(hi 2^-6).  Byte q of lane half lh = input channel 32 group + (q < 8 ? 8 lh + q :
+// 16 + 8 lh + q - 8) - the channels the lane's two half fragments of the group hold, in their order, so that a kernel may also MAKE plane 1
+// from those half fragments in registers (v_cvt_scalef32_pk_fp8_f16: kernels_tdnn_x3m.hip and the 96-frame chain do; the 64-frame chain
+// fetches it - 24 conversions per K step cost its waves more issue time than two more 16-byte loads, profiles/r6s_*).  The kernels' block
+// scales undo the 2^6 / 2^-6.
+size_t tdnn_weight_mx8_plane_bytes(int cout_pad, int cin_pad, int n_taps) { return (size_t)(cout_pad / 32) * n_taps * ((cin_pad + 31) / 32) * 1024; }
+size_t tdnn_weight_mx8_bytes(int cout_pad, int cin_pad, int n_taps) { return 2 * tdnn_weight_mx8_plane_bytes(cout_pad, cin_pad, n_taps); }
 void pack_tdnn_weight_mx8(const float *w, int out_ch, int in_ch, int tot_ctx, int left_ctx, const int *taps, int n_taps, int cout_pad, int cin_pad,
                           float scale, uint8_t *dst) {
   const int ngroups = (cin_pad + 31) / 32;                    // (a last, partial group is zero-padded: e4m3(0) = 0)
   memset(dst, 0, tdnn_weight_mx8_bytes(cout_pad, cin_pad, n_taps));
+  const size_t plane = tdnn_weight_mx8_plane_bytes(cout_pad, cin_pad, n_taps);
   for (int co = 0; co < out_ch; ++co) {
     const int nf = co / 32, lr = co % 32;
     for (int t = 0; t < n_taps; ++t) {
@@ -118,7 +121,9 @@ void pack_tdnn_weight_mx8(const float *w, int out_ch, int in_ch, int tot_ctx, in
         const int g = ci / 32, r = ci % 32, kg = r / 16, lh = (r % 16) / 8, q = kg * 8 + r % 8;
         const float v = w[((size_t)co * in_ch + ci) * tot_ctx + k] * scale;
         const float hi = f16_to_f32_host(f32_to_f16_host(v));
-        dst[(((size_t)nf * n_taps + t) * ngroups + g) * 1024 + (size_t)(lh * 32 + lr) * 16 + q] = f32_to_e4m3_host((v - hi) * 64.0f);
+        const size_t at = (((size_t)nf * n_taps + t) * ngroups + g) * 1024 + (size_t)(lh * 32 + lr) * 16 + q;
+        dst[at] = f32_to_e4m3_host((v - hi) * 64.0f);
+        dst[plane + at] = f32_to_e4m3_host(hi * (1.0f / 64.0f));
       }
     }
   }
@@ -1277,8 +1282,16 @@ int run_ops(RunCtx &c, size_t n_ops) {
           static const bool chain_dbg_on = getenv("ASV_AMD_CHAIN_DBG") != nullptr;
           ChainTilePlan plan;
           if (!chain_x3) plan = chain_tile_plan(p.rows, !chain_dbg_on);
-          auto block_of = [&](int row) { return chain_x3 ? row >> tshift : plan.tile_of(row); };
-          const int n_blocks = chain_x3 ? (p.rows >> tshift) : plan.tiles();
+          // f32m: the chain with its correction products on the scaled 8-bit instruction, when every layer of it has 8-bit fragments - in
+          // 64-frame tiles (kernels_tdnn_chainm.hip).  ASV_AMD_CHAINM_ROWS=96 selects the 96-frame kernel (kernels_tdnn_chainm96.hip: the same
+          // results, measured 13 % SLOWER - 507.6 against 450.1 us on one box, profiles/r6r_*: kept as the measurement it is)
+          bool chain_mx = chain_x3 && net->x3_mx();
+          for (size_t k = i; k <= (size_t)op.chain_last && chain_mx; ++k)
+            chain_mx = (net->ops[k].wfrag_fold != nullptr ? net->ops[k].w8_fold : net->ops[k].w8) != nullptr;
+          static const int chainm_rows = getenv("ASV_AMD_CHAINM_ROWS") != nullptr ? atoi(getenv("ASV_AMD_CHAINM_ROWS")) : 64;
+          const bool mx96 = chain_mx && chainm_rows == 96 && p.rows >= 96;
+          auto block_of = [&](int row) { return mx96 ? row / 96 : (chain_x3 ? row >> tshift : plan.tile_of(row)); };
+          const int n_blocks = mx96 ? chainm96_tiles(p.rows) : (chain_x3 ? (p.rows >> tshift) : plan.tiles());
           std::vector<int> per_half((size_t)n_blocks + 1, 0);
           int slots = 1, min_len = 1 << 30;
           for (size_t sidx = 0; sidx < fp.seg_len.size(); ++sidx) min_len = std::min(min_len, (int)fp.seg_len[sidx]);
@@ -1322,10 +1335,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
             if ((rc = prof.begin(K_TDNN, fl, (int)i))) return rc;
             static const int chain_dbg = getenv("ASV_AMD_CHAIN_DBG") != nullptr ? std::max(1, atoi(getenv("ASV_AMD_CHAIN_DBG"))) : 0;   // developer aid: phase durations to stderr
             DevMem dbg;
-            // f32m: the chain with its correction products on the scaled 8-bit instruction, when every layer of it has 8-bit fragments
-            bool chain_mx = chain_x3 && net->x3_mx() && cp.first.w8 != nullptr && cp.last.w8 != nullptr;
-            for (int m = 0; m < cp.n_mid; ++m) chain_mx = chain_mx && cp.mid[m].w8 != nullptr;
-            const size_t dbg_wgs = chain_mx ? (size_t)(p.rows / 64) : (size_t)(p.rows / 128);
+            const size_t dbg_wgs = mx96 ? (size_t)n_blocks : (chain_mx ? (size_t)(p.rows / 64) : (size_t)(p.rows / 128));
             if (chain_dbg && (!chain_x3 || chain_mx)) {
               if ((rc = ensure(dbg, dbg_wgs * 8 * 32 * 8, c.s, true))) return rc;
               cp.dbg = reinterpret_cast<unsigned long long *>(dbg.ptr);
@@ -1333,7 +1343,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
 
             }
             if (chain_mx) ++g_kernel_launches[ASV_KERNEL_TDNN_CHAINM];
-            if ((rc = chain_mx ? launch_tdnn_chainm(cp, c.s) : (chain_x3 ? launch_tdnn_chainx(cp, c.s) : launch_tdnn_chain(cp, c.s)))) return rc;
+            if ((rc = mx96 ? launch_tdnn_chainm96(cp, c.s) : (chain_mx ? launch_tdnn_chainm(cp, c.s) : (chain_x3 ? launch_tdnn_chainx(cp, c.s) : launch_tdnn_chain(cp, c.s))))) return rc;
             if ((rc = prof.end())) return rc;
             if (chain_dbg && (!chain_x3 || chain_mx)) {
               const size_t nwg = dbg_wgs;
@@ -1412,6 +1422,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
             PoolFinishParams f;
             f.partial = cp.pool_partial; f.ld_partial = cp.ld_partial; f.pool_slots = slots; f.lh_split = 1; f.tile_shift = tshift;
             f.rows_shift = plan.rows128(); f.tail_rows = plan.n_tail > 0 ? plan.tail_rows : 0; f.n_shift = plan.n128;
+            if (mx96) { f.rows_shift = 0; f.tail_rows = 96; f.n_shift = 0; }       // uniform 96-row blocks (pool_finish_kernel's tail form from row 0 on)
             f.row_seg = dr.row_seg; f.rows = dr.rows_pad; f.seg_row0 = dr.seg_row0; f.seg_len = dr.seg_len;
             f.shift = lo.shift;
             f.out = reinterpret_cast<float *>(net->arena[q.out_buf].ptr) + q.out_ch_off; f.ld_out = net->bufs[q.out_buf].ld; f.channels = q.channels;
@@ -1496,11 +1507,13 @@ int run_ops(RunCtx &c, size_t n_ops) {
         const bool p8x_fill = p8x_on > 1 ? p8x_tiles >= p8x_on : (p8x_tiles >= cus && p8x_tiles * 100 >= ((p8x_tiles + cus - 1) / cus) * cus * 85);
         const bool p8x = x3 && !fuse && p8x_on != 0 && tdnn_p8x_supported(p) && p8x_fill;
         // f32m: the 128-row kernel with its correction products on the scaled 8-bit instruction, where the three-product kernel would take its
-        // 128-row tiles (ASV_AMD_X3M=0: off).  It also takes the layers of the f32x 8-phase kernel: 4 instead of 6 matrix-pipe time units per
-        // product outweigh that kernel's staging (tdnn2: 163 us here against 227 on either three-product kernel, profiles/r6f_*)
+        // 128-row tiles (ASV_AMD_X3M=0: off) and the 8-phase kernel does not (its fill rule: the x-vector's tdnn1 / tdnn2 - 163 us here against
+        // 227 on the three-product kernel, profiles/r6f_*).  ECAPA's wide 1-tap layers stay on the 8-phase kernel: a new window (barrier +
+        // conversion) per 32 channels makes this kernel only 4 - 12 % faster there on one stream and 8 % slower in the two-stream pipeline
+        // (35.1 k against 38.2 k utterances/s, profiles/r6q_bench_line.json)
         static const int x3m_env = getenv("ASV_AMD_X3M") ? atoi(getenv("ASV_AMD_X3M")) : 1;
         const int x3m_on = live_tune ? (getenv("ASV_AMD_X3M") ? atoi(getenv("ASV_AMD_X3M")) : 1) : x3m_env;
-        const bool x3m = x3 && x3m_on != 0 && net->x3_mx() && tdnn_x3m_supported(p) &&
+        const bool x3m = x3 && !p8x && x3m_on != 0 && net->x3_mx() && tdnn_x3m_supported(p) &&
                          (long long)(p.rows / 128) * (round_up(p.cout_store, 256) / 256) >= (x3m_on > 1 ? x3m_on : 384);      // (384: where the three-product kernel takes its 128-row tiles)
         if (use_ref) rc = launch_tdnn_ref(p, et, !bf16, c.s);
         else if (utts_kernel) {
