@@ -103,6 +103,8 @@ struct TdnnKernelParams {
                         // - its own pointer, so that neither family can ever be handed the other's layout - or nullptr
   const void *wlo;      // pooled-domain layers and the f32x frame kernel: the bf16 'lo' halves (w - hi), same layout as wfrag, or nullptr
   const void *wx3p;     // f32x 8-phase kernel (kernels_tdnn_p8x.hip): [cout_pad][tap][chunk32][hi 32 | lo 32] 16-bit halves of w * 2^s, or nullptr
+  int x_image, y_image; // f32m form: the input rows are / the output rows become IMAGES - per (row, 32-channel group) the 128 bytes [hi halves | x_lo8 | x_hi8]
+                        // the readers' window conversion would make of the f32 values (kernels_tdnn_x3m.hip's epilogue; run_ops decides per buffer and run)
   const void *w8;       // f32m form (kernels_tdnn_x3m.hip): 8-bit fragments of w * 2^s, planes [w_lo8][w_hi8] (pack_tdnn_weight_mx8), or nullptr
   // split-K (small-M layers: the pooled domain): blockIdx.y walks `ksplit` slices of the channel
   // chunks, raw f32 accumulators go to partial[slice][rows][ld_partial]; a second kernel sums
@@ -209,6 +211,7 @@ struct TdnnChainParams {
   uint32_t *status;             // f32x chain: as TdnnKernelParams::status
   int n128, n_tail, tail_rows;  // 16-bit chain: the launch's tile plan (chain_tile_plan): n128 tiles of 128 frames, then n_tail of tail_rows (96 | 64)
   int row_base, tile_base;      // set by the launcher per kernel launch: first row / first partial-moment block of that launch
+  int x_image;                  // f32m chain: the first layer's input rows are images (TdnnKernelParams::x_image): no window conversion
   int abl;                      // f32m chain, developer aid with ASV_AMD_CHAIN_DBG (ASV_AMD_CHAINM_ABL; results are garbage): bit 0 no in-loop conversion, 1 no in-loop window DMA, 2 no chunk barrier (these three: garbage results), 3 no alternating issue priority (results unchanged)
 };
 // How the 16-bit chain kernel cuts `rows` (a multiple of 128) into tiles.  One workgroup per CU (160 KiB of LDS), so:
@@ -263,6 +266,8 @@ int launch_tdnn_x3(const TdnnKernelParams &p, hipStream_t s);
 // the same layers with the correction products on the block-scaled 8-bit matrix instruction ("f32m"; kernels_tdnn_x3m.hip)
 bool tdnn_x3m_supported(const TdnnKernelParams &p);
 int launch_tdnn_x3m(const TdnnKernelParams &p, hipStream_t s);
+bool tdnn_x3m_image_in_supported(const TdnnKernelParams &p);
+bool tdnn_x3m_image_out_supported(const TdnnKernelParams &p);
 size_t tdnn_weight_frag_elems(int cout_pad, int cin_pad, int n_taps);
 int launch_stats_pool(const PoolKernelParams &p, int segments, int et, hipStream_t s);
 // second half of the fused pooling: adds each segment's half-tile partials in row order, adds the BN shift

@@ -179,6 +179,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
     if constexpr (decltype(tr)::value) acc[i][j] = mfma16<ET_F16>(x[i], w[j], acc[i][j]);
     else acc[i][j] = mfma16<ET_F16>(w[j], x[i], acc[i][j]);
   };
+#if CHAINM_WHI8_REG
   // the 8 half values of a weight fragment -> e4m3(w_hi 2^-6) in two registers (RNE, the same bytes the host would pack): bytes 0-7 of K block
   // 0 from the pair's first k-group, bytes 8-15 from its second
   auto whi8 = [&](const uint4 &f, uint32_t &d0, uint32_t &d1) {
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
     b = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(b, __builtin_bit_cast(h16x2, f.w), 64.0f, true);
     d0 = __builtin_bit_cast(uint32_t, a); d1 = __builtin_bit_cast(uint32_t, b);
   };
+#endif
   auto mma_mx = [&](const MW &w, const MX8 &e, int q, auto tr) {
     const int i = q & 1, j = q >> 1;
 #if CHAINM_WHI8_REG
@@ -294,8 +296,11 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    cv_load(0); cv_store(0);
-    if (nchunks > 1) { cv_load(1); cv_store(1); }
+    // (p.x_image: the rows are images already - the producing layer's epilogue made them, kernels_tdnn_x3m.hip - and every conversion is skipped)
+    if (!p.x_image) {
+      cv_load(0); cv_store(0);
+      if (nchunks > 1) { cv_load(1); cv_store(1); }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -329,7 +334,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
       if (!more) { c2 = c; t2 = t; }                               // the last pair re-fetches itself (valid memory, never used)
       const bool enter = more && c2 != c;
       const int cb1 = cb == 2 ? 0 : cb + 1, cb2 = cb == 0 ? 2 : cb - 1;        // (c + 1) % 3, (c + 2) % 3
-      const bool cv = enter && c + 2 < nchunks && (p.abl & 1) == 0;
+      const bool cv = enter && c + 2 < nchunks && (p.abl & 1) == 0 && !p.x_image;
       if (enter && (p.abl & 4) == 0) {
         // Entering chunk c + 1, at the start of the LAST step of chunk c (this step's operands were fetched in the previous one): image
         // c + 1 is complete (converted during the step behind the previous chunk barrier: lgkmcnt), window c + 2 has landed (issued a

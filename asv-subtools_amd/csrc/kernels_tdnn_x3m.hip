@@ -69,7 +69,9 @@ __device__ __forceinline__ void q_split(float v0, float v1, uint32_t &hi16, int 
   lo8 = __builtin_amdgcn_cvt_pk_bf8_f32(r0 * 2048.0f, r1 * 2048.0f, lo8, SEL);
 }
 
-template <bool GENERIC>
+// XIMG: the input rows are IMAGES already (p.x_image: written by this kernel's image epilogue, p.y_image, in the producing layer - see the
+// epilogue): the window of a chunk goes by LDS-DMA straight into one of FOUR image slots (ring), no conversion pass, no f32 stage.
+template <bool GENERIC, bool XIMG>
 __global__ __launch_bounds__(256, 2) void tdnn_gemm_x3m_kernel(const TdnnKernelParams p, int m_tiles, int n_tiles) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[QRING + 3 * 256 * 4];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_x3m_kernel(const TdnnKernelP
 #pragma unroll
     for (int i = 0; i < QPIECES; ++i) {
       const int grp = min(wn + i * 4, QGROUPS - 1);
-      const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (c & 1) * QSTAGE + grp * 1024);
+      const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (XIMG ? (c & 3) : (c & 1)) * QSTAGE + grp * 1024);
       const int w = grp * 8 + g_row;
       const bool ok = !tail || (c * QBK + qswz(w, g_slot) * 4 < p.cin_pad);
       x3m_glds16(ok ? base + a_off[i] : zero, dst);
@@ -195,22 +197,32 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_x3m_kernel(const TdnnKernelP
   auto x_row = [&](int c, int t, uint32_t &base, int &sw) {
     const int wrow = lr + kHalo + __builtin_amdgcn_readlane(v_taps, t);
     sw = (wrow >> 1) & 7;
-    base = (uint32_t)((2 + (c & 1)) * QSTAGE + wrow * QROWB);
+    base = (uint32_t)((XIMG ? (c & 3) : 2 + (c & 1)) * QSTAGE + wrow * QROWB);
   };
 
   // ---- prologue: windows 0 and 1 in flight; window 0 -> image 0; its stage takes window 2; window 1 -> image 1
   issue_A(0);
   if (nchunks > 1) issue_A(1);
-  if (nchunks > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QPIECES) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  convert(0);
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  if (nchunks > 2) issue_A(2);
-  if (nchunks > 1) convert(1);
+  if constexpr (XIMG) {
+    // images 0, 1, 2 in flight; image 0 has landed when all but the youngest 2 x QPIECES operations have
+    if (nchunks > 2) issue_A(2);
+    if (nchunks > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * QPIECES) : "memory");
+    else if (nchunks > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QPIECES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  } else {
+    if (nchunks > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QPIECES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    convert(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (nchunks > 2) issue_A(2);
+    if (nchunks > 1) convert(1);
+  }
   {
     wh0[0] = *reinterpret_cast<const uint4 *>(wh); wh0[1] = *reinterpret_cast<const uint4 *>(wh + frag_stride);
     wh1[0] = *reinterpret_cast<const uint4 *>(wh + 1024); wh1[1] = *reinterpret_cast<const uint4 *>(wh + frag_stride + 1024);
@@ -278,7 +290,8 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_x3m_kernel(const TdnnKernelP
       asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (c + 2 < nchunks) convert(c + 2);
+      // (XIMG: window c + 1 - issued three chunks ago - has landed for the same reason; window c + 3 goes into the slot of image c - 1)
+      if constexpr (!XIMG) { if (c + 2 < nchunks) convert(c + 2); }
       if (c + 3 < nchunks) issue_A(c + 3);
     }
     // phase 3, second half: fragments 2, 3 from (we, xb); xa <- k-group 0 of the next pair; then we <- the next pair's 8-bit weights
@@ -298,7 +311,6 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_x3m_kernel(const TdnnKernelP
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();            // the ring becomes epilogue scratch
-  x3_publish_range(range, p.status);
   asm volatile("" ::: "memory");
 
   // ---- epilogue (kernels_tdnn_x3.hip): acc[i][j][r]: frame = m0 + i*32 + lr, channel = n0 + wn*64 + j*32 + 8*(r>>2) + 4*lh + (r&3)
@@ -331,7 +343,21 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_x3m_kernel(const TdnnKernelP
             y[e2] = valid ? z : 0.0f;
           }
         }
-        *reinterpret_cast<float4 *>(scr + lr * QSPITCH + j * 32 + 8 * q + 4 * lh) = make_float4(y[0], y[1], y[2], y[3]);
+        if (p.y_image) {
+          // image output (the reader is an f32m kernel that takes images: the split it would do per workgroup is done here, once): the 128
+          // bytes of (row, 32-channel group) = [hi halves 64 B | x_lo8 32 B | x_hi8 32 B], bytes as q_split / the readers' conversion
+          // pass would write them - the reader's results are bit-identical to those from the f32 row
+          uint2 hi;
+          int h8 = 0, l8 = 0;
+          q_split<false>(y[0], y[1], hi.x, h8, l8, range);
+          q_split<true>(y[2], y[3], hi.y, h8, l8, range);
+          unsigned char *rowb = reinterpret_cast<unsigned char *>(scr + lr * QSPITCH) + j * 128;
+          *reinterpret_cast<uint2 *>(rowb + q * 16 + lh * 8) = hi;
+          *reinterpret_cast<uint32_t *>(rowb + 64 + (q & 1) * 16 + (q >> 1) * 8 + lh * 4) = (uint32_t)l8;
+          *reinterpret_cast<uint32_t *>(rowb + 96 + (q & 1) * 16 + (q >> 1) * 8 + lh * 4) = (uint32_t)h8;
+        } else {
+          *reinterpret_cast<float4 *>(scr + lr * QSPITCH + j * 32 + 8 * q + 4 * lh) = make_float4(y[0], y[1], y[2], y[3]);
+        }
       }
     // the scratch tile is wave-private: LDS operations of one wave complete in order
 #pragma unroll
@@ -343,6 +369,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_x3m_kernel(const TdnnKernelP
       if (ch < p.cout_store) *reinterpret_cast<float4 *>(yg + (size_t)row * p.ldy + ch) = v;
     }
   }
+  x3_publish_range(range, p.status);       // the window conversions' watch and, with image output, the epilogue's
 }
 
 }  // namespace
@@ -351,6 +378,9 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_x3m_kernel(const TdnnKernelP
 bool tdnn_x3m_supported(const TdnnKernelParams &p) {
   return tdnn_x3_supported(p) && p.w8 != nullptr && p.x3_et == ET_F16 && (p.x3_terms & 7) == 7 && p.rows % 128 == 0 && p.pool_partial == nullptr && p.w_unscale > 0.0f;
 }
+// image rows in / out: whole 32-channel groups on both sides
+bool tdnn_x3m_image_in_supported(const TdnnKernelParams &p) { return p.cin_pad % 32 == 0 && p.x2 == nullptr; }
+bool tdnn_x3m_image_out_supported(const TdnnKernelParams &p) { return p.cout_store % 32 == 0 && p.res == nullptr; }
 
 int launch_tdnn_x3m(const TdnnKernelParams &p, hipStream_t s) {
   ASV_REQUIRE(tdnn_x3m_supported(p), "tdnn(x3m): layer not supported");
@@ -359,8 +389,15 @@ int launch_tdnn_x3m(const TdnnKernelParams &p, hipStream_t s) {
   const int m_tiles = p.rows / QBM, n_tiles = round_up(p.cout_store, QBN) / QBN;
   const dim3 grid(m_tiles * n_tiles), block(256);
   const bool fast = (p.act1 == ASV_ACT_NONE || p.act1 == ASV_ACT_RELU) && p.act2 == ASV_ACT_NONE && !p.affine_first;
-  if (fast) hipLaunchKernelGGL((tdnn_gemm_x3m_kernel<false>), grid, block, 0, s, p, m_tiles, n_tiles);
-  else hipLaunchKernelGGL((tdnn_gemm_x3m_kernel<true>), grid, block, 0, s, p, m_tiles, n_tiles);
+  ASV_REQUIRE(!p.x_image || tdnn_x3m_image_in_supported(p), "tdnn(x3m): image input needs whole 32-channel groups");
+  ASV_REQUIRE(!p.y_image || tdnn_x3m_image_out_supported(p), "tdnn(x3m): image output needs whole 32-channel groups");
+  if (p.x_image) {
+    if (fast) hipLaunchKernelGGL((tdnn_gemm_x3m_kernel<false, true>), grid, block, 0, s, p, m_tiles, n_tiles);
+    else hipLaunchKernelGGL((tdnn_gemm_x3m_kernel<true, true>), grid, block, 0, s, p, m_tiles, n_tiles);
+  } else {
+    if (fast) hipLaunchKernelGGL((tdnn_gemm_x3m_kernel<false, false>), grid, block, 0, s, p, m_tiles, n_tiles);
+    else hipLaunchKernelGGL((tdnn_gemm_x3m_kernel<true, false>), grid, block, 0, s, p, m_tiles, n_tiles);
+  }
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }

@@ -191,6 +191,8 @@ struct Op {
   bool has_affine = false;
   int fused_pool = -1;           // TDNN op: index of the statistics-pooling op folded into its epilogue
   int chain_last = -1;           // TDNN op heading a chain (kernels_tdnn_chain.hip): index of the chain's last layer
+  int image_reader = -1;         // f32m: the ONE op that reads this TDNN op's whole output buffer, as its input rows - the buffer may hold images
+                                 // (TdnnKernelParams::y_image) in a run where both ops go to image-capable kernels (run_ops)
   bool skipped = false;          // pool op executed by its producer
 };
 
@@ -258,7 +260,7 @@ struct asv_net {
 
 namespace {
 
-std::atomic<unsigned long long> g_kernel_launches[6];       // asv_kernel_launch_count
+std::atomic<unsigned long long> g_kernel_launches[7];       // asv_kernel_launch_count
 
 // the range-status word of the f32x kernels lives behind the zero page's zeros (own 64-byte line; kernels only ever OR into it)
 uint32_t *status_word(asv_net *net) { return reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(net->zero_page) + 128); }
@@ -891,6 +893,22 @@ int asv_net_finalize(asv_net_t *net, int out_buf, int embed_dim) {
       b.skipped = true;
     }
   }
+  auto sole_reader = [&](int buf, size_t reader) {
+    if (buf == out_buf) return false;
+    for (size_t k = 0; k < net->ops.size(); ++k) {
+      if (k == reader) continue;
+      const Op &o = net->ops[k];
+      const int reads[] = {o.kind == OP_TDNN ? o.tdnn.in_buf : -1, o.kind == OP_TDNN ? o.tdnn.in2_buf : -1, o.kind == OP_TDNN ? o.tdnn.res_buf : -1,
+                           o.kind == OP_TDNN ? o.tdnn.seg_bias_buf : -1, o.kind == OP_TDNN ? o.tdnn.seg_scale_buf : -1,
+                           o.kind == OP_POOL ? o.pool.in_buf : -1, o.kind == OP_ATTPOOL ? o.att.x_buf : -1, o.kind == OP_ATTPOOL ? o.att.logit_buf : -1,
+                           o.kind == OP_ELTWISE ? o.elt.a_buf : -1, o.kind == OP_ELTWISE ? o.elt.b_buf : -1, o.kind == OP_ELTWISE ? o.elt.c_buf : -1,
+                           o.kind == OP_ELTWISE ? o.elt.seg_scale_buf : -1, o.kind == OP_ELTWISE ? o.elt.seg_norm_buf : -1, o.kind == OP_ELTWISE ? o.elt.d_buf : -1,
+                           o.kind == OP_IM2COL ? o.i2c.in_buf : -1, o.kind == OP_IM2COL ? o.i2c.b_buf : -1, o.kind == OP_IM2COL ? o.i2c.seg_scale_buf : -1, o.kind == OP_LDE ? o.lde.x_buf : -1, o.kind == OP_GRID_INPUT ? o.gin.in_buf : -1,
+                           o.kind == OP_RES2 ? o.res2.in_buf : -1, o.kind == OP_FLATTEN ? o.flat.in_buf : -1};
+      for (int rbuf : reads) if (rbuf == buf) return false;
+    }
+    return true;
+  };
   // chains "layer -> 512, [1-tap 512 -> 512]*, 1-tap + fused pooling" whose intermediate tensors nobody else reads run as
   // ONE kernel with the 128 x 512 tiles resident in LDS (x-vector: tdnn3 -> tdnn4 -> tdnn5 -> pooling)
   if ((net->flags & (ASV_FLAG_NO_FUSE | ASV_FLAG_NO_CHAIN)) == 0 && (net->frames_h16() || (net->x3() && net->x3_terms() == 7))) {
@@ -902,22 +920,6 @@ int asv_net_finalize(asv_net_t *net, int out_buf, int embed_dim) {
     auto from_resident = [&](const Op &o) {            // 1-tap layer that consumes a whole 512-channel buffer
       const auto &d = o.tdnn;
       return d.n_taps == 1 && d.taps[0] == 0 && d.in_ch == kChainWidth && d.in_ch_off == 0 && net->bufs[d.in_buf].channels == kChainWidth;
-    };
-    auto sole_reader = [&](int buf, size_t reader) {
-      if (buf == out_buf) return false;
-      for (size_t k = 0; k < net->ops.size(); ++k) {
-        if (k == reader) continue;
-        const Op &o = net->ops[k];
-        const int reads[] = {o.kind == OP_TDNN ? o.tdnn.in_buf : -1, o.kind == OP_TDNN ? o.tdnn.in2_buf : -1, o.kind == OP_TDNN ? o.tdnn.res_buf : -1,
-                             o.kind == OP_TDNN ? o.tdnn.seg_bias_buf : -1, o.kind == OP_TDNN ? o.tdnn.seg_scale_buf : -1,
-                             o.kind == OP_POOL ? o.pool.in_buf : -1, o.kind == OP_ATTPOOL ? o.att.x_buf : -1, o.kind == OP_ATTPOOL ? o.att.logit_buf : -1,
-                             o.kind == OP_ELTWISE ? o.elt.a_buf : -1, o.kind == OP_ELTWISE ? o.elt.b_buf : -1, o.kind == OP_ELTWISE ? o.elt.c_buf : -1,
-                             o.kind == OP_ELTWISE ? o.elt.seg_scale_buf : -1, o.kind == OP_ELTWISE ? o.elt.seg_norm_buf : -1, o.kind == OP_ELTWISE ? o.elt.d_buf : -1,
-                             o.kind == OP_IM2COL ? o.i2c.in_buf : -1, o.kind == OP_IM2COL ? o.i2c.b_buf : -1, o.kind == OP_IM2COL ? o.i2c.seg_scale_buf : -1, o.kind == OP_LDE ? o.lde.x_buf : -1, o.kind == OP_GRID_INPUT ? o.gin.in_buf : -1,
-                             o.kind == OP_RES2 ? o.res2.in_buf : -1, o.kind == OP_FLATTEN ? o.flat.in_buf : -1};
-        for (int rbuf : reads) if (rbuf == buf) return false;
-      }
-      return true;
     };
     for (size_t l = 1; l < net->ops.size(); ++l) {
       Op &last = net->ops[l];
@@ -981,6 +983,30 @@ int asv_net_finalize(asv_net_t *net, int out_buf, int embed_dim) {
       }
     }
   }
+  // f32m: a frame-level TDNN layer whose whole output buffer is read by exactly one other TDNN layer, as its input rows, may hand it over
+  // as IMAGES (the split [hi halves | x_lo8 | x_hi8] the reader would otherwise make of the f32 rows per workgroup and chunk): recorded
+  // here, decided per run (run_ops: both kernels must be the image-capable ones for that batch)
+  if (net->x3_mx()) {
+    for (size_t i = 0; i + 1 < net->ops.size(); ++i) {
+      Op &o = net->ops[i];
+      if (o.kind != OP_TDNN || o.utts || o.w8 == nullptr || o.fused_pool >= 0 || o.chain_last >= 0) continue;
+      const auto &d = o.tdnn;
+      const Buffer &b = net->bufs[d.out_buf];
+      if (b.domain != ASV_DOMAIN_FRAMES || d.out_ch_off != 0 || d.out_ch != b.channels || b.channels % 32 != 0 || d.res_buf >= 0) continue;
+      bool inside_chain = false;
+      for (size_t h = 0; h < i; ++h) inside_chain |= net->ops[h].chain_last >= (int)i;
+      if (inside_chain) continue;
+      for (size_t j = i + 1; j < net->ops.size(); ++j) {
+        const Op &r = net->ops[j];
+        if (r.kind != OP_TDNN || r.tdnn.in_buf != d.out_buf) continue;
+        const auto &rd = r.tdnn;
+        const bool clean = rd.in_ch_off == 0 && rd.in_ch == b.channels && rd.in2_buf < 0 && rd.res_buf != d.out_buf && rd.seg_bias_buf != d.out_buf &&
+                           rd.seg_scale_buf != d.out_buf && !r.utts && (r.chain_last >= 0 || (r.w8 != nullptr && r.fused_pool < 0));
+        if (clean && sole_reader(d.out_buf, j)) o.image_reader = (int)j;
+        break;
+      }
+    }
+  }
   for (Op &o : net->ops) {                       // the host copies have served their purpose
     std::vector<float>().swap(o.host_w); std::vector<float>().swap(o.host_bias);
     std::vector<float>().swap(o.host_scale); std::vector<float>().swap(o.host_shift);
@@ -1014,7 +1040,7 @@ int asv_net_status_async(asv_net_t *net, unsigned *host_status, void *stream) {
 }
 
 unsigned long long asv_kernel_launch_count(int which) {
-  return (which >= ASV_KERNEL_TDNN_P8 && which <= ASV_KERNEL_TDNN_X3M) ? g_kernel_launches[which].load() : 0ull;
+  return (which >= ASV_KERNEL_TDNN_P8 && which <= ASV_KERNEL_TDNN_X3M_IMAGE) ? g_kernel_launches[which].load() : 0ull;
 }
 
 size_t asv_net_device_bytes(const asv_net_t *net) {
@@ -1144,6 +1170,7 @@ struct RunCtx {
   bool final_written = false;
   int32_t *seg_src0, *seg_frames, *utt_seg0, *utt_nseg;     // device metadata
   std::vector<DomainRun> dom;
+  std::vector<char> buf_image;     // per run: buffer holds images (TdnnKernelParams::y_image of its producer)
 };
 
 // what prepare() leaves behind for the next call with identical offsets
@@ -1243,6 +1270,105 @@ int run_ops(RunCtx &c, size_t n_ops) {
   Prof prof{net, c.s};
   int rc;
   const bool use_ref = (net->flags & ASV_FLAG_REF_KERNELS) != 0;
+  c.buf_image.assign(net->bufs.size(), 0);
+  // Kernel-selection switches (developer A/B aids; read once unless ASV_AMD_LIVE_TUNE is set - the in-process A/B tests switch that on
+  // after the library's first launch, so THAT lookup cannot be cached: one getenv per run)
+  const bool live_tune = getenv("ASV_AMD_LIVE_TUNE") != nullptr;
+  auto tune = [&](const char *name, int dflt, int cached) { return live_tune ? (getenv(name) ? atoi(getenv(name)) : dflt) : cached; };
+  static const int p8_env = getenv("ASV_AMD_P8") ? atoi(getenv("ASV_AMD_P8")) : 1;
+  static const int p8x_env = getenv("ASV_AMD_P8X") ? atoi(getenv("ASV_AMD_P8X")) : 1;
+  static const int x3m_env = getenv("ASV_AMD_X3M") ? atoi(getenv("ASV_AMD_X3M")) : 1;
+  static const int img_env = getenv("ASV_AMD_X3M_IMAGE") ? atoi(getenv("ASV_AMD_X3M_IMAGE")) : 1;
+  static const int chainm_rows_env = getenv("ASV_AMD_CHAINM_ROWS") != nullptr ? atoi(getenv("ASV_AMD_CHAINM_ROWS")) : 64;
+  const int p8_on = tune("ASV_AMD_P8", 1, p8_env), p8x_on = tune("ASV_AMD_P8X", 1, p8x_env), x3m_on = tune("ASV_AMD_X3M", 1, x3m_env);
+  const int img_on = tune("ASV_AMD_X3M_IMAGE", 1, img_env), chainm_rows = tune("ASV_AMD_CHAINM_ROWS", 64, chainm_rows_env);
+  // "one round of tiles" = one 256 x 256 tile per CU of THIS device (the kernels size their persistent grids from the same count)
+  static const long long cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return (long long)(n > 0 ? n : 256);
+  }();
+  // the kernel parameters of TDNN op k (views, weights, taps)
+  auto fill_tdnn_params = [&](size_t k, TdnnKernelParams &p) {
+    const Op &op = net->ops[k];
+    const auto &d = op.tdnn;
+    const int domid = net->bufs[d.in_buf].domain;
+    const DomainRun &dr = c.dom[domid];
+    const int et = net->dom_et(domid);
+    memset(&p, 0, sizeof(p));
+    p.et = et; p.x3_et = net->x3_et(); p.x3_terms = net->x3_terms(); p.w_unscale = 1.0f / op.w_scale;
+    p.x3_tile = (net->flags & ASV_FLAG_X3_TILE128) ? 128 : 0;
+    p.status = status_word(net);
+    p.x = view(c, d.in_buf, d.in_ch_off); p.ldx = net->bufs[d.in_buf].ld;
+    if (d.in2_buf >= 0) { p.x2 = view(c, d.in2_buf, d.in2_ch_off); p.ldx2 = net->bufs[d.in2_buf].ld; }
+    p.w = op.w; p.bias = op.bias; p.scale = op.scale; p.shift = op.shift;
+    if (d.seg_bias_buf >= 0) { p.seg_bias = reinterpret_cast<const float *>(net->arena[d.seg_bias_buf].ptr); p.ld_segbias = net->bufs[d.seg_bias_buf].ld; }
+    if (d.seg_scale_buf >= 0) { p.seg_scale = reinterpret_cast<const float *>(net->arena[d.seg_scale_buf].ptr); p.ld_segscale = net->bufs[d.seg_scale_buf].ld; }
+    if (d.res_buf >= 0) { p.res = view(c, d.res_buf, d.res_ch_off); p.ldres = net->bufs[d.res_buf].ld; }
+    p.y = view(c, d.out_buf, d.out_ch_off); p.ldy = net->bufs[d.out_buf].ld;
+    p.row_seg = dr.row_seg; p.row_valid = dr.row_valid; p.rows = dr.rows_pad;
+    p.cin_pad = op.cin_pad; p.cout_store = op.cout_store;
+    p.n_taps = d.n_taps;
+    for (int t = 0; t < d.n_taps; ++t) { p.taps[t] = d.taps[t]; p.halo = std::max(p.halo, std::abs(d.taps[t])); }
+    p.act1 = d.act1; p.act2 = d.act2; p.affine_first = d.affine_first;
+    p.zero16 = net->zero_page;
+    p.wfrag = op.wfrag; p.wlo = op.wlo; p.wconv = op.wconv; p.wx3p = op.wx3p; p.w8 = op.w8;
+  };
+  // f32x: the 8-phase three-product kernel takes the wide plain layers that fill whole rounds of 256 x 256 tiles (kernels_tdnn_p8x.hip; the
+  // bits of tdnn_gemm_x3_kernel; ASV_AMD_P8X=0: off).  Production rule: at least one round of tiles AND a last round that is >= 85 % full -
+  // the x-vector's tdnn2 at 256 utterances is 408 tiles = 1.6 rounds, where the finer 128-row tiles of tdnn_gemm_x3_kernel are as fast and
+  // leave CUs to the other stream: -0.9 % on two streams, profiles/r5s_p8x_model_ab.txt; ECAPA's layers are 4.75 and 7.1 rounds
+  auto p8x_rule = [&](const TdnnKernelParams &q, bool x3q, bool fuseq) {
+    const long long tiles = (long long)(q.rows / 256) * (round_up(q.cout_store, 256) / 256);
+    const bool fill = p8x_on > 1 ? tiles >= p8x_on : (tiles >= cus && tiles * 100 >= ((tiles + cus - 1) / cus) * cus * 85);
+    return x3q && !fuseq && p8x_on != 0 && tdnn_p8x_supported(q) && fill;
+  };
+  // f32m: the 128-row kernel with its correction products on the scaled 8-bit instruction, where the three-product kernel would take its
+  // 128-row tiles (ASV_AMD_X3M=0: off) and the 8-phase kernel does not (its fill rule: the x-vector's tdnn1 / tdnn2 - 163 us here against
+  // 227 on the three-product kernel, profiles/r6f_*).  ECAPA's wide 1-tap layers stay on the 8-phase kernel: a new window (barrier +
+  // conversion) per 32 channels makes this kernel only 4 - 12 % faster there on one stream and 8 % slower in the two-stream pipeline
+  // (35.1 k against 38.2 k utterances/s, profiles/r6q_bench_line.json)
+  auto x3m_rule = [&](const TdnnKernelParams &q, bool x3q, bool fuseq) {
+    return x3q && !fuseq && !p8x_rule(q, x3q, fuseq) && x3m_on != 0 && net->x3_mx() && tdnn_x3m_supported(q) &&
+           (long long)(q.rows / 128) * (round_up(q.cout_store, 256) / 256) >= (x3m_on > 1 ? x3m_on : 384);      // (384: where the three-product kernel takes its 128-row tiles)
+  };
+  auto x3_rule = [&](const Op &o, const TdnnKernelParams &q) {
+    return !use_ref && !o.utts && net->x3() && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && tdnn_x3_supported(q);
+  };
+  // the chain kernels' fused pooling: utterances per block of `block_rows` rows, worst block (a crowd of tiny utterances -> per-layer path)
+  auto chain_slots_uniform = [&](int block_rows, int n_blocks, int *min_len) {
+    const DomainPlan &fp = bp.dom[ASV_DOMAIN_FRAMES];
+    std::vector<int> per_block((size_t)n_blocks + 1, 0);
+    int slots = 1, ml = 1 << 30;
+    for (size_t sidx = 0; sidx < fp.seg_len.size(); ++sidx) ml = std::min(ml, (int)fp.seg_len[sidx]);
+    for (size_t sidx = 0; sidx < fp.seg_row0.size(); ++sidx)
+      for (int h = fp.seg_row0[sidx] / block_rows; h <= (fp.seg_row0[sidx] + fp.seg_len[sidx] - 1) / block_rows; ++h) slots = std::max(slots, ++per_block[h]);
+    if (min_len != nullptr) *min_len = ml;
+    return slots;
+  };
+  auto chain_is_mx = [&](size_t head) {
+    bool mx = net->x3() && net->x3_mx();
+    for (size_t k = head; k <= (size_t)net->ops[head].chain_last && mx; ++k)
+      mx = (net->ops[k].wfrag_fold != nullptr ? net->ops[k].w8_fold : net->ops[k].w8) != nullptr;
+    return mx;
+  };
+  auto chain_branch = [&](const Op &o, const TdnnKernelParams &q, bool rows16) {      // the condition under which op o runs as the head of a chain kernel
+    return o.chain_last >= 0 && !use_ref && (rows16 || net->x3()) && q.halo <= kHalo && (net->flags & ASV_FLAG_SMALL_TILES) == 0 &&
+           (net->x3() || (unsigned long long)q.rows * (unsigned long long)q.ldx * 2ull < (1ull << 32));
+  };
+  // f32m, op j reads ONE buffer as its input rows (Op::image_reader of the producer): will it, in THIS run, go to a kernel that reads
+  // images?  Follows the selection below step by step - the chain branch first, then the per-layer rules - and the launches check it.
+  auto reader_takes_image = [&](size_t j) {
+    const Op &o = net->ops[j];
+    TdnnKernelParams q;
+    fill_tdnn_params(j, q);
+    if (chain_branch(o, q, false)) {
+      const bool mx = chain_is_mx(j), mx96 = mx && chainm_rows == 96 && q.rows >= 96;
+      const int slots = mx96 ? chain_slots_uniform(96, chainm96_tiles(q.rows), nullptr) : chain_slots_uniform(64, q.rows >> 6, nullptr);
+      if (slots <= 16) return mx && !mx96 && q.cin_pad % 32 == 0;
+    }
+    return o.fused_pool < 0 && x3m_rule(q, x3_rule(o, q), false) && tdnn_x3m_image_in_supported(q);
+  };
   for (size_t i = 0; i < n_ops; ++i) {
     Op &op = net->ops[i];
     switch (op.kind) {
@@ -1253,27 +1379,10 @@ int run_ops(RunCtx &c, size_t n_ops) {
         const int et = net->dom_et(domid);
         const bool bf16 = et != ET_F32;              // 16-bit rows (bf16 or half)
         TdnnKernelParams p;
-        memset(&p, 0, sizeof(p));
-        p.et = et; p.x3_et = net->x3_et(); p.x3_terms = net->x3_terms(); p.w_unscale = 1.0f / op.w_scale;
-        p.x3_tile = (net->flags & ASV_FLAG_X3_TILE128) ? 128 : 0;
-        p.status = status_word(net);
-        p.x = view(c, d.in_buf, d.in_ch_off); p.ldx = net->bufs[d.in_buf].ld;
-        if (d.in2_buf >= 0) { p.x2 = view(c, d.in2_buf, d.in2_ch_off); p.ldx2 = net->bufs[d.in2_buf].ld; }
-        p.w = op.w; p.bias = op.bias; p.scale = op.scale; p.shift = op.shift;
-        if (d.seg_bias_buf >= 0) { p.seg_bias = reinterpret_cast<const float *>(net->arena[d.seg_bias_buf].ptr); p.ld_segbias = net->bufs[d.seg_bias_buf].ld; }
-        if (d.seg_scale_buf >= 0) { p.seg_scale = reinterpret_cast<const float *>(net->arena[d.seg_scale_buf].ptr); p.ld_segscale = net->bufs[d.seg_scale_buf].ld; }
-        if (d.res_buf >= 0) { p.res = view(c, d.res_buf, d.res_ch_off); p.ldres = net->bufs[d.res_buf].ld; }
-        p.y = view(c, d.out_buf, d.out_ch_off); p.ldy = net->bufs[d.out_buf].ld;
-        p.row_seg = dr.row_seg; p.row_valid = dr.row_valid; p.rows = dr.rows_pad;
-        p.cin_pad = op.cin_pad; p.cout_store = op.cout_store;
-        p.n_taps = d.n_taps;
-        for (int t = 0; t < d.n_taps; ++t) { p.taps[t] = d.taps[t]; p.halo = std::max(p.halo, std::abs(d.taps[t])); }
-        p.act1 = d.act1; p.act2 = d.act2; p.affine_first = d.affine_first;
-        p.zero16 = net->zero_page;
-        p.wfrag = op.wfrag; p.wlo = op.wlo; p.wconv = op.wconv; p.wx3p = op.wx3p; p.w8 = op.w8;
+        fill_tdnn_params(i, p);
+        p.x_image = c.buf_image[d.in_buf];
         const bool chain_x3 = net->x3();             // f32x: the split-product chain on 64-row tiles (kernels_tdnn_chainx.hip)
-        if (op.chain_last >= 0 && !use_ref && (bf16 || chain_x3) && p.halo <= kHalo && (net->flags & ASV_FLAG_SMALL_TILES) == 0 &&
-            (chain_x3 || (unsigned long long)p.rows * (unsigned long long)p.ldx * 2ull < (1ull << 32))) {
+        if (chain_branch(op, p, bf16)) {
           // tdnn -> [1-tap]* -> 1-tap + pooling in one kernel, if the batch allows the fused pooling (no crowd of tiny utterances)
           const DomainPlan &fp = bp.dom[ASV_DOMAIN_FRAMES];
           const int tshift = chain_x3 ? 6 : 7;         // rows per pooling partial: the kernel's tile
@@ -1285,19 +1394,20 @@ int run_ops(RunCtx &c, size_t n_ops) {
           // f32m: the chain with its correction products on the scaled 8-bit instruction, when every layer of it has 8-bit fragments - in
           // 64-frame tiles (kernels_tdnn_chainm.hip).  ASV_AMD_CHAINM_ROWS=96 selects the 96-frame kernel (kernels_tdnn_chainm96.hip: the same
           // results, measured 13 % SLOWER - 507.6 against 450.1 us on one box, profiles/r6r_*: kept as the measurement it is)
-          bool chain_mx = chain_x3 && net->x3_mx();
-          for (size_t k = i; k <= (size_t)op.chain_last && chain_mx; ++k)
-            chain_mx = (net->ops[k].wfrag_fold != nullptr ? net->ops[k].w8_fold : net->ops[k].w8) != nullptr;
-          static const int chainm_rows = getenv("ASV_AMD_CHAINM_ROWS") != nullptr ? atoi(getenv("ASV_AMD_CHAINM_ROWS")) : 64;
+          const bool chain_mx = chain_x3 && chain_is_mx(i);
           const bool mx96 = chain_mx && chainm_rows == 96 && p.rows >= 96;
-          auto block_of = [&](int row) { return mx96 ? row / 96 : (chain_x3 ? row >> tshift : plan.tile_of(row)); };
           const int n_blocks = mx96 ? chainm96_tiles(p.rows) : (chain_x3 ? (p.rows >> tshift) : plan.tiles());
-          std::vector<int> per_half((size_t)n_blocks + 1, 0);
           int slots = 1, min_len = 1 << 30;
-          for (size_t sidx = 0; sidx < fp.seg_len.size(); ++sidx) min_len = std::min(min_len, (int)fp.seg_len[sidx]);
-          for (size_t sidx = 0; sidx < fp.seg_row0.size(); ++sidx)
-            for (int h = block_of(fp.seg_row0[sidx]); h <= block_of(fp.seg_row0[sidx] + fp.seg_len[sidx] - 1); ++h) slots = std::max(slots, ++per_half[h]);
+          if (chain_x3) {
+            slots = chain_slots_uniform(mx96 ? 96 : 64, n_blocks, &min_len);
+          } else {
+            std::vector<int> per_half((size_t)n_blocks + 1, 0);
+            for (size_t sidx = 0; sidx < fp.seg_len.size(); ++sidx) min_len = std::min(min_len, (int)fp.seg_len[sidx]);
+            for (size_t sidx = 0; sidx < fp.seg_row0.size(); ++sidx)
+              for (int h = plan.tile_of(fp.seg_row0[sidx]); h <= plan.tile_of(fp.seg_row0[sidx] + fp.seg_len[sidx] - 1); ++h) slots = std::max(slots, ++per_half[h]);
+          }
           if (slots <= 16) {
+            ASV_REQUIRE(!p.x_image || (chain_mx && !mx96), "tdnn(chain): image rows reached a chain kernel that cannot read them (internal)");
             const size_t l = (size_t)op.chain_last;
             Op &lo = net->ops[l];
             TdnnChainParams cp;
@@ -1325,6 +1435,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
             cp.et = chain_x3 ? net->x3_et() : et;
             cp.min_seg_len = min_len;
             cp.status = status_word(net);
+            cp.x_image = p.x_image;
             static const int chainm_abl = getenv("ASV_AMD_CHAINM_ABL") != nullptr ? atoi(getenv("ASV_AMD_CHAINM_ABL")) : 0;       // developer aid, read once
             cp.abl = (chainm_abl & 7) != 0 && getenv("ASV_AMD_CHAIN_DBG") == nullptr ? (chainm_abl & 8) : chainm_abl;               // the garbage-result bits only under ASV_AMD_CHAIN_DBG
             cp.n128 = plan.n128; cp.n_tail = plan.n_tail; cp.tail_rows = plan.tail_rows;
@@ -1448,7 +1559,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         }
         const bool big3 = !use_ref && narrow && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && tdnn_big3_supported(p, et, !bf16);
         const bool utts_kernel = !use_ref && op.utts;
-        const bool x3 = !use_ref && !op.utts && net->x3() && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && tdnn_x3_supported(p);
+        const bool x3 = x3_rule(op, p);
         const bool c1_conv = !use_ref && net->domains[domid].kind == 2 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && grid_conv_c1_supported(p, et, d.in_ch);
         const bool narrow_conv = !use_ref && net->domains[domid].kind == 2 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && grid_conv_narrow_supported(p, et);
         const bool wide_conv = !use_ref && net->domains[domid].kind == 2 && (net->flags & ASV_FLAG_SMALL_TILES) == 0 && grid_conv_wide_supported(p, et);
@@ -1484,37 +1595,19 @@ int run_ops(RunCtx &c, size_t n_ops) {
         // Round 5: the layers of the variant-3 kernel with the plain epilogue, whole 64-channel chunks and at least one round of 256 x 256
         // tiles on the chip's CUs go to the 8-phase kernel (kernels_tdnn_p8.hip: both operands through LDS-DMA, staggered wave rows;
         // bit-identical outputs, 1.03 - 1.15 x the rate: profiles/r5e_p8_shapes.txt).  ASV_AMD_P8=0: the variant-3 kernel everywhere.
-        // (ONE environment lookup per TDNN op, ~50 ns: the in-process A/B tests switch ASV_AMD_LIVE_TUNE on after the library's first
-        //  launch, so this one cannot be cached; everything behind it is read once unless it is set)
-        const bool live_tune = getenv("ASV_AMD_LIVE_TUNE") != nullptr;
-        static const int p8_env = getenv("ASV_AMD_P8") ? atoi(getenv("ASV_AMD_P8")) : 1;
-        const int p8_on = live_tune ? (getenv("ASV_AMD_P8") ? atoi(getenv("ASV_AMD_P8")) : 1) : p8_env;
-        // "one round of tiles" = one 256 x 256 tile per CU of THIS device (the kernels size their persistent grids from the same count)
-        static const long long cus = [] {
-          int dev = 0, n = 256;
-          if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-          return (long long)(n > 0 ? n : 256);
-        }();
         const bool p8 = big3 && !fuse && p8_on != 0 && tdnn_p8_supported(p, et, !bf16) &&
                         (long long)(p.rows / 256) * (round_up(p.cout_store, 256) / 256) >= (p8_on > 1 ? p8_on : cus);
-        // ... and the same structure for the f32x mode's wide plain layers (kernels_tdnn_p8x.hip; the bits of tdnn_gemm_x3_kernel).  ASV_AMD_P8X=0: off
-        static const int p8x_env = getenv("ASV_AMD_P8X") ? atoi(getenv("ASV_AMD_P8X")) : 1;
-        const int p8x_on = live_tune ? (getenv("ASV_AMD_P8X") ? atoi(getenv("ASV_AMD_P8X")) : 1) : p8x_env;
-        // (production rule: at least one round of tiles AND a last round that is >= 85 % full - the x-vector's tdnn2 at 256 utterances is
-        //  408 tiles = 1.6 rounds, where the finer 128-row tiles of tdnn_gemm_x3_kernel are as fast and leave CUs to the other stream:
-        //  -0.9 % on two streams, profiles/r5s_p8x_model_ab.txt; ECAPA's layers are 4.75 and 7.1 rounds)
-        const long long p8x_tiles = (long long)(p.rows / 256) * (round_up(p.cout_store, 256) / 256);
-        const bool p8x_fill = p8x_on > 1 ? p8x_tiles >= p8x_on : (p8x_tiles >= cus && p8x_tiles * 100 >= ((p8x_tiles + cus - 1) / cus) * cus * 85);
-        const bool p8x = x3 && !fuse && p8x_on != 0 && tdnn_p8x_supported(p) && p8x_fill;
-        // f32m: the 128-row kernel with its correction products on the scaled 8-bit instruction, where the three-product kernel would take its
-        // 128-row tiles (ASV_AMD_X3M=0: off) and the 8-phase kernel does not (its fill rule: the x-vector's tdnn1 / tdnn2 - 163 us here against
-        // 227 on the three-product kernel, profiles/r6f_*).  ECAPA's wide 1-tap layers stay on the 8-phase kernel: a new window (barrier +
-        // conversion) per 32 channels makes this kernel only 4 - 12 % faster there on one stream and 8 % slower in the two-stream pipeline
-        // (35.1 k against 38.2 k utterances/s, profiles/r6q_bench_line.json)
-        static const int x3m_env = getenv("ASV_AMD_X3M") ? atoi(getenv("ASV_AMD_X3M")) : 1;
-        const int x3m_on = live_tune ? (getenv("ASV_AMD_X3M") ? atoi(getenv("ASV_AMD_X3M")) : 1) : x3m_env;
-        const bool x3m = x3 && !p8x && x3m_on != 0 && net->x3_mx() && tdnn_x3m_supported(p) &&
-                         (long long)(p.rows / 128) * (round_up(p.cout_store, 256) / 256) >= (x3m_on > 1 ? x3m_on : 384);      // (384: where the three-product kernel takes its 128-row tiles)
+        // ... and the f32x / f32m forms (the rules: p8x_rule, x3m_rule above)
+        const bool p8x = p8x_rule(p, x3, fuse);
+        const bool x3m = x3m_rule(p, x3, fuse);
+        ASV_REQUIRE(!p.x_image || (x3m && tdnn_x3m_image_in_supported(p)), "tdnn: image rows reached a kernel that cannot read them (internal)");
+        // f32m: the output rows as images, when their one reader will take them as such in this run (Op::image_reader; ASV_AMD_X3M_IMAGE=0: off)
+        if (x3m && img_on != 0 && op.image_reader >= 0 && (size_t)op.image_reader < n_ops && tdnn_x3m_image_out_supported(p) &&
+            reader_takes_image((size_t)op.image_reader)) {
+          p.y_image = 1;
+          c.buf_image[d.out_buf] = 1;
+          ++g_kernel_launches[ASV_KERNEL_TDNN_X3M_IMAGE];
+        }
         if (use_ref) rc = launch_tdnn_ref(p, et, !bf16, c.s);
         else if (utts_kernel) {
           // last layer, every utterance a single chunk: the kernel also produces the caller's [utterance][embed_dim] result
@@ -1532,7 +1625,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
         else if (wide_conv) rc = launch_grid_conv_wide(p, c.s);
         else if (s2d_conv) rc = launch_grid_conv_s2d(p, c.s);
         else if (c1_conv) rc = launch_grid_conv_c1(p, c.s);
-        else if (x3 && !fuse && x3m) { rc = launch_tdnn_x3m(p, c.s); ++g_kernel_launches[ASV_KERNEL_TDNN_X3M]; }
+        else if (x3m) { rc = launch_tdnn_x3m(p, c.s); ++g_kernel_launches[ASV_KERNEL_TDNN_X3M]; }
         else if (p8x) { rc = launch_tdnn_p8x(p, c.s); ++g_kernel_launches[ASV_KERNEL_TDNN_P8X]; }
         else if (x3) rc = launch_tdnn_x3(p, c.s);
         else if (x3_conv) rc = launch_grid_conv_x3(p, c.s);

@@ -20,7 +20,7 @@ MAX_TAPS = 9
 POOL_VAR_CLAMP, POOL_VAR_ADD = 0, 1
 PLDA_NORM_NONE, PLDA_NORM_SIMPLE, PLDA_NORM_PSI = 0, 1, 2
 STATUS_HALF_RANGE = 1
-KERNEL_TDNN_P8, KERNEL_TDNN_BIG3, KERNEL_TDNN_P8X, KERNEL_TDNN_CHAINM, KERNEL_TDNN_X3M = 1, 2, 3, 4, 5
+KERNEL_TDNN_P8, KERNEL_TDNN_BIG3, KERNEL_TDNN_P8X, KERNEL_TDNN_CHAINM, KERNEL_TDNN_X3M, KERNEL_TDNN_X3M_IMAGE = 1, 2, 3, 4, 5, 6
 
 ACT_BY_NAME = {None: ACT_NONE, "": ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "tanh": ACT_TANH,
                "sigmoid": ACT_SIGMOID}

@@ -295,6 +295,7 @@ int asv_net_status_async(asv_net_t *net, unsigned *host_status, void *stream);
 #define ASV_KERNEL_TDNN_BIG3 2   /* kernels_tdnn_v3.hip: 128 x 256 tiles, window through LDS, weight fragments from L2 */
 #define ASV_KERNEL_TDNN_CHAINM 4 /* kernels_tdnn_chainm.hip: the f32x layer chain with its correction products on the scaled 8-bit instruction */
 #define ASV_KERNEL_TDNN_X3M 5    /* kernels_tdnn_x3m.hip: the f32x wide-layer kernel in the same form */
+#define ASV_KERNEL_TDNN_X3M_IMAGE 6 /* launches of that kernel that wrote their output rows as images for an f32m reader (counted in 5 as well) */
 unsigned long long asv_kernel_launch_count(int which);
 
 /* Bytes of device memory currently held by the net (weights + activation arena). */

@@ -171,6 +171,66 @@ def test_x3m_is_the_kernel_of_the_xvector_wide_layers(monkeypatch):
         assert (L.asv_kernel_launch_count(capi.KERNEL_TDNN_X3M) - a, L.asv_kernel_launch_count(capi.KERNEL_TDNN_CHAINM) - b) == want, prec
 
 
+def _synth_xvector():
+    import torch
+    from libs.amd import synth
+    model = helpers.build_model("xvector.py", "Xvector(80,10,training=False)")
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 0).items()})
+    model.cuda()
+    model.amd_precision = "f32m"
+    return model
+
+
+@pytest.mark.parametrize("lens", [[200] * 256, [200] * 255 + [37], list(range(60, 316))], ids=["256x200", "short_last", "ragged_60_315"])
+def test_image_rows_between_f32m_layers_change_no_bit(lens, monkeypatch):
+    """The hand-over of activations as IMAGES (the [hi halves | x_lo8 | x_hi8] split made once in the producing layer's epilogue instead of
+    per workgroup and chunk in the readers: kernels_tdnn_x3m.hip, TdnnKernelParams::y_image / x_image, run_ops' reader_takes_image) is the
+    same arithmetic in another place: tdnn1 -> tdnn2 -> chain of configs[1]'s x-vector with it (two image launches per pass, counted) and
+    without it (ASV_AMD_X3M_IMAGE=0) must agree to the last bit, on whole and ragged batches."""
+    from libs.amd import capi, synth
+    monkeypatch.setenv("ASV_AMD_LIVE_TUNE", "1")
+    L = capi.lib()
+    model = _synth_xvector()
+    mats = [synth.synth_feats(T, 80, 5000 + i) for i, T in enumerate(lens)]
+    eng = model._amd_engine()
+    monkeypatch.setenv("ASV_AMD_X3M_IMAGE", "1")
+    n0, m0 = L.asv_kernel_launch_count(capi.KERNEL_TDNN_X3M_IMAGE), L.asv_kernel_launch_count(capi.KERNEL_TDNN_X3M)
+    with_images = eng._extract_batch(mats).numpy()
+    assert (L.asv_kernel_launch_count(capi.KERNEL_TDNN_X3M_IMAGE) - n0, L.asv_kernel_launch_count(capi.KERNEL_TDNN_X3M) - m0) == (2, 2)
+    monkeypatch.setenv("ASV_AMD_X3M_IMAGE", "0")
+    n1 = L.asv_kernel_launch_count(capi.KERNEL_TDNN_X3M_IMAGE)
+    without = eng._extract_batch(mats).numpy()
+    assert L.asv_kernel_launch_count(capi.KERNEL_TDNN_X3M_IMAGE) == n1
+    assert np.isfinite(with_images).all() and np.array_equal(with_images, without), float(np.abs(with_images - without).max())
+
+
+def test_image_rows_on_the_small_goldens_and_tiny_utterances(monkeypatch):
+    """Forced onto the golden batches (ASV_AMD_X3M=2: the 8-bit kernel from two tiles on): the x-vector goldens inside the gate with image
+    rows between its layers; and small batches - one of them a crowd of 5-frame utterances beside long ones - with and without images:
+    equal bits."""
+    from libs.amd import capi, synth
+    monkeypatch.setenv("ASV_AMD_LIVE_TUNE", "1")
+    monkeypatch.setenv("ASV_AMD_X3M", "2")
+    L = capi.lib()
+    for name in ("xvector_c1", "xvector_near_ragged"):
+        g, sd, model = _model(name)
+        n0 = L.asv_kernel_launch_count(capi.KERNEL_TDNN_X3M_IMAGE)
+        got = model.extract_embedding_batch(helpers.golden_feats(g)).numpy()
+        assert L.asv_kernel_launch_count(capi.KERNEL_TDNN_X3M_IMAGE) > n0, name
+        for i, (T, _) in enumerate(g["utts"]):
+            assert rel_err(got[i], g["embeddings"][i]) < 1e-4, (name, T)
+    model = _synth_xvector()
+    eng = model._amd_engine()
+    for lens in ([200] * 8, [5] * 40 + [200] * 4):
+        mats = [synth.synth_feats(T, 80, 7000 + i) for i, T in enumerate(lens)]
+        res = {}
+        for img in ("1", "0"):
+            monkeypatch.setenv("ASV_AMD_X3M_IMAGE", img)
+            res[img] = eng._extract_batch(mats).numpy()
+        assert np.isfinite(res["1"]).all() and np.array_equal(res["1"], res["0"]), (lens[:2], float(np.abs(res["1"] - res["0"]).max()))
+
+
 @pytest.mark.parametrize("name", ["ecapa_c3", "ecapa_launcher", "ecapa_c512_near_affine", "resnet34se_c5"])
 def test_other_models_in_the_f32m_form_vs_reference_golden(name):
     """ECAPA-TDNN's wide layers (1-tap C -> C, 3C -> 1536, the 5-tap input layer) run on kernels_tdnn_x3m.hip in this form (from the production
