@@ -60,7 +60,8 @@ constexpr int MYROW = MN * 2;              // 1024 B per row of Yh and of Y8
 constexpr int MYIMG = MM * MYROW;          // 65536 B: Yh at 0, Y8 at MYIMG
 constexpr int MPAR = 2 * MYIMG;            // bias | scale | shift of the layer in flight (6 KiB)
 constexpr int CHAINM_LDS = 2 * MYIMG + 8192;
-static_assert(3 * MSTG <= MYIMG, "layer A's window buffers live inside the Y region");
+constexpr int MRING = 10;                  // image rows in (p.x_image): window buffers of the ring, see layer A
+static_assert(MRING * MSTG <= 2 * MYIMG, "layer A's window buffers live inside the Y region (Yh + Y8)");
 static_assert(CHAINM_LDS <= 163840, "160 KiB of LDS per CU");
 
 // E8M0 block scales (2^(byte - 127)) that undo the host's / the epilogue's scaling of the 8-bit operands:
@@ -285,25 +286,40 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
       w.q[0] = *reinterpret_cast<const uint4 *>(w8 + plane8 + off8); w.q[1] = *reinterpret_cast<const uint4 *>(w8 + plane8 + frag8_stride + off8);
 #endif
     };
-    // prologue: windows 0, 1, 2 in flight; 0 and 1 converted at once (the K loop's first barrier follows the first chunk)
-    issue_A(0, 0);
-    if (nchunks > 1) issue_A(1, 1);
-    if (nchunks > 2) issue_A(2, 2);
+    // f32 rows: windows 0, 1, 2 in flight; 0 and 1 converted at once (the K loop's first barrier follows the first chunk); a ring of 3 buffers,
+    // a workgroup barrier per chunk (the conversion of window c + 2 and the DMA of window c + 3 hang on it).
+    // Image rows (p.x_image: the producing layer's epilogue made them, kernels_tdnn_x3m.hip): nothing to convert - a ring of MRING buffers
+    // filled SIX chunks ahead, and a barrier only in front of chunks 1, 4, 8, 12, ...: at the barrier in front of chunk g every wave has
+    // waited for its own pieces of the windows up to g + 3 (the youngest of them issued three steps before), so the group's windows are
+    // complete; the window issued behind it, c + 6, takes the buffer of chunk c - 4, which lies in front of the group barrier every wave
+    // has passed.  4 barriers in layer A instead of 16.
+    const bool grouped = p.x_image == 1;          // (x_image == 2, a measuring aid: image rows under the per-chunk protocol of the f32 rows)
+    const int ring = grouped ? MRING : 3;
     MW w0, w1;
     MX8 e0, e1;
-    ld_w(0, 0, w0);
-    // windows 0 and 1 have landed: everything but the youngest 6 (the fragments) + this wave's pieces of window 2 ... kept simple: all of it
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    // (p.x_image: the rows are images already - the producing layer's epilogue made them, kernels_tdnn_x3m.hip - and every conversion is skipped)
-    if (!p.x_image) {
-      cv_load(0); cv_store(0);
-      if (nchunks > 1) { cv_load(1); cv_store(1); }
+    issue_A(0, 0);
+    if (grouped) {
+      ld_w(0, 0, w0);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CHAINM_WHI8_REG ? 6 : 8) : "memory");      // window 0 is older than the fragment loads
+      for (int k = 1; k < 6; ++k) if (k < nchunks) issue_A(k, k);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    } else {
+      if (nchunks > 1) issue_A(1, 1);
+      if (nchunks > 2) issue_A(2, 2);
+      ld_w(0, 0, w0);
+      // windows 0 and 1 have landed: everything but the youngest 6 (the fragments) + this wave's pieces of window 2 ... kept simple: all of it
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (!p.x_image) {
+        cv_load(0); cv_store(0);
+        if (nchunks > 1) { cv_load(1); cv_store(1); }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
     init_acc(p.first.bias + wave * 64, p.first.w_scale, MTrNo{});
     {
       uint32_t base; int sw;
@@ -319,7 +335,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
       }
     }
     const int P = nchunks * n_taps;
-    int c = 0, t = 0, cb = 0;                                     // cb = c % 3: the buffer of chunk c's image
+    int c = 0, t = 0, cb = 0;                                     // cb = c % ring: the buffer of chunk c's image
     stamp();                                                     // 1: layer A's prologue (three windows, two conversions, first fetches)
     // pair n = (chunk c, tap t): 4 + 4 half instructions and 4 scaled ones; the fetches of pair n + 1 are pinned between them
     auto step = [&](const MW &wc, MW &wn, const MX8 &ec, MX8 &en, int n) {
@@ -333,9 +349,10 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
       const bool more = n + 1 < P;
       if (!more) { c2 = c; t2 = t; }                               // the last pair re-fetches itself (valid memory, never used)
       const bool enter = more && c2 != c;
-      const int cb1 = cb == 2 ? 0 : cb + 1, cb2 = cb == 0 ? 2 : cb - 1;        // (c + 1) % 3, (c + 2) % 3
+      const int cb1 = cb + 1 == ring ? 0 : cb + 1, cb2 = cb == 0 ? 2 : cb - 1;        // (c + 1) % ring; f32 rows: (c + 2) % 3
       const bool cv = enter && c + 2 < nchunks && (p.abl & 1) == 0 && !p.x_image;
-      if (enter && (p.abl & 4) == 0) {
+      const int ahead = grouped ? 6 : 3;                          // the window issued behind this step's fetches: c + ahead
+      if (enter && (p.abl & 4) == 0 && (!grouped || c == 0 || ((c + 1) & 3) == 0)) {
         // Entering chunk c + 1, at the start of the LAST step of chunk c (this step's operands were fetched in the previous one): image
         // c + 1 is complete (converted during the step behind the previous chunk barrier: lgkmcnt), window c + 2 has landed (issued a
         // chunk ago; the only vector-memory operations behind it that may still be in flight are this step's own weight fragments,
@@ -360,7 +377,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
 #if !CHAINM_WHI8_REG
         if (q == 1) { wn.q[0] = *reinterpret_cast<const uint4 *>(w8 + plane8 + off8); wn.q[1] = *reinterpret_cast<const uint4 *>(w8 + plane8 + frag8_stride + off8); }
 #endif
-        if (q == 1 && enter && c + 3 < nchunks && (p.abl & 2) == 0) issue_A(c + 3, cb);
+        if (q == 1 && enter && c + ahead < nchunks && (p.abl & 2) == 0) issue_A(c + ahead, grouped ? (cb + 6 >= MRING ? cb + 6 - MRING : cb + 6) : cb);
         if (q == 1 && cv) cv_load(cb2);
         if (q == 2) { en.x[0][0] = *reinterpret_cast<const uint4 *>(lds + ax0); en.x[0][1] = *reinterpret_cast<const uint4 *>(lds + ax1); }
 #if CHAINM_WHI8_REG
