@@ -106,6 +106,10 @@ __device__ __forceinline__ void split_mx(float v0, float v1, uint32_t &hi16, int
   lo8 = __builtin_amdgcn_cvt_pk_bf8_f32(r0 * 2048.0f, r1 * 2048.0f, lo8, SEL);
 }
 
+// IMG: the first layer's input rows are images (p.x_image).  DEV: the instantiation with the developer aids compiled in (per-step stamps,
+// ASV_AMD_CHAINM_ABL, the x_image == 2 protocol); the production instantiations carry none of their tests in the K loops (layer A's loop
+// was 269 scalar + 143 vector instructions per 24 matrix instructions with all of them in, round 6).
+template <bool IMG, bool DEV>
 __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[CHAINM_LDS];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -119,6 +123,8 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
   const int scale_w = lh ? kScaleWlo : kScaleWhi, scale_x = lh ? kScaleXhi : kScaleXlo;
 
   // developer aid (ASV_AMD_CHAIN_DBG=1): [workgroup][wave][32] s_memtime stamps at the phase boundaries; 14 / 15: s_memrealtime at start / end
+  const int abl = DEV ? p.abl : 0;
+  const bool fine = DEV && p.dbg != nullptr && p.dbg_fine;
   int n_stamp = 0;
   auto stamp = [&]() {
     if (p.dbg != nullptr && lane == 0 && n_stamp < 14) p.dbg[((size_t)blockIdx.x * 8 + wave) * 32 + n_stamp] = __builtin_amdgcn_s_memtime();
@@ -293,7 +299,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
     // waited for its own pieces of the windows up to g + 3 (the youngest of them issued three steps before), so the group's windows are
     // complete; the window issued behind it, c + 6, takes the buffer of chunk c - 4, which lies in front of the group barrier every wave
     // has passed.  4 barriers in layer A instead of 16.
-    const bool grouped = p.x_image == 1;          // (x_image == 2, a measuring aid: image rows under the per-chunk protocol of the f32 rows)
+    const bool grouped = IMG && (!DEV || p.x_image == 1);          // (x_image == 2, developer build of the kernel: image rows under the per-chunk protocol of the f32 rows)
     const int ring = grouped ? MRING : 3;
     MW w0, w1;
     MX8 e0, e1;
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (!p.x_image) {
+      if constexpr (!IMG) {
         cv_load(0); cv_store(0);
         if (nchunks > 1) { cv_load(1); cv_store(1); }
       }
@@ -339,20 +345,20 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
     stamp();                                                     // 1: layer A's prologue (three windows, two conversions, first fetches)
     // pair n = (chunk c, tap t): 4 + 4 half instructions and 4 scaled ones; the fetches of pair n + 1 are pinned between them
     auto step = [&](const MW &wc, MW &wn, const MX8 &ec, MX8 &en, int n) {
-      if (p.dbg != nullptr && p.dbg_fine && lane == 0 && n < 16) p.dbg[((size_t)blockIdx.x * 8 + wave) * 32 + 16 + n] = __builtin_amdgcn_s_memtime();
+      if (fine && lane == 0 && n < 16) p.dbg[((size_t)blockIdx.x * 8 + wave) * 32 + 16 + n] = __builtin_amdgcn_s_memtime();
       // The two waves of a SIMD (w and w + 4) take turns at the higher issue priority, step by step: left alone the older wave of a pair runs
       // its steps in ~1280 cycles and the younger in ~1900 (profiles/r6o_chainm_layerA_step_stamps.txt, no barrier), and a chunk barrier
       // then runs at the pace of the slower one.  ASV_AMD_CHAINM_ABL bit 3: off.
-      if ((p.abl & 8) == 0) { if (((n ^ (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+      if ((abl & 8) == 0) { if (((n ^ (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
       int c2 = c, t2 = t + 1;
       if (t2 == n_taps) { t2 = 0; c2 = c + 1; }
       const bool more = n + 1 < P;
       if (!more) { c2 = c; t2 = t; }                               // the last pair re-fetches itself (valid memory, never used)
       const bool enter = more && c2 != c;
       const int cb1 = cb + 1 == ring ? 0 : cb + 1, cb2 = cb == 0 ? 2 : cb - 1;        // (c + 1) % ring; f32 rows: (c + 2) % 3
-      const bool cv = enter && c + 2 < nchunks && (p.abl & 1) == 0 && !p.x_image;
+      const bool cv = !IMG && enter && c + 2 < nchunks && (abl & 1) == 0;
       const int ahead = grouped ? 6 : 3;                          // the window issued behind this step's fetches: c + ahead
-      if (enter && (p.abl & 4) == 0 && (!grouped || c == 0 || ((c + 1) & 3) == 0)) {
+      if (enter && (abl & 4) == 0 && (!grouped || c == 0 || ((c + 1) & 3) == 0)) {
         // Entering chunk c + 1, at the start of the LAST step of chunk c (this step's operands were fetched in the previous one): image
         // c + 1 is complete (converted during the step behind the previous chunk barrier: lgkmcnt), window c + 2 has landed (issued a
         // chunk ago; the only vector-memory operations behind it that may still be in flight are this step's own weight fragments,
@@ -377,8 +383,8 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
 #if !CHAINM_WHI8_REG
         if (q == 1) { wn.q[0] = *reinterpret_cast<const uint4 *>(w8 + plane8 + off8); wn.q[1] = *reinterpret_cast<const uint4 *>(w8 + plane8 + frag8_stride + off8); }
 #endif
-        if (q == 1 && enter && c + ahead < nchunks && (p.abl & 2) == 0) issue_A(c + ahead, grouped ? (cb + 6 >= MRING ? cb + 6 - MRING : cb + 6) : cb);
-        if (q == 1 && cv) cv_load(cb2);
+        if (q == 1 && enter && c + ahead < nchunks && (abl & 2) == 0) issue_A(c + ahead, grouped ? (cb + 6 >= MRING ? cb + 6 - MRING : cb + 6) : cb);
+        if constexpr (!IMG) { if (q == 1 && cv) cv_load(cb2); }
         if (q == 2) { en.x[0][0] = *reinterpret_cast<const uint4 *>(lds + ax0); en.x[0][1] = *reinterpret_cast<const uint4 *>(lds + ax1); }
 #if CHAINM_WHI8_REG
         if (q == 2) { whi8(wc.h0[0], wq[0].x, wq[0].y); whi8(wc.h0[1], wq[1].x, wq[1].y); }
@@ -395,7 +401,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
 #if CHAINM_WHI8_REG
         if (q == 1) { whi8(wc.h1[0], wq[0].z, wq[0].w); whi8(wc.h1[1], wq[1].z, wq[1].w); }
 #endif
-        if (q == 2 && cv) cv_store(cb2);
+        if constexpr (!IMG) { if (q == 2 && cv) cv_store(cb2); }
         __builtin_amdgcn_sched_barrier(0);
       }
       // phase 3: the corrections; the rows of the next pair's k-group 1
@@ -488,7 +494,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
     }
     init_acc(bias64, w_scale, tr);
     auto step = [&](const MW &wc, MW &wn, const MX8 &ec, MX8 &en, int nn) {      // computes the pair in (wc, h0x, h1x, ec); fetches pair nn
-      if ((p.abl & 8) == 0) { if (((nn ^ (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+      if ((abl & 8) == 0) { if (((nn ^ (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
       const size_t off8 = (size_t)nn * 1024 + lane16;
       const size_t offh = (size_t)(nn * 2) * 1024 + lane16;
       const uint32_t ax0 = MYIMG + yb + ((((uint32_t)(nn * 4)) ^ sx) << 4), ax1 = MYIMG + yb + ((((uint32_t)(nn * 4 + 2)) ^ sx) << 4);
@@ -666,7 +672,14 @@ int launch_tdnn_chainm(const TdnnChainParams &p, hipStream_t s) {
   ASV_REQUIRE(p.pool_partial && p.row_seg && p.pool_slots >= 1, "tdnn(chainm): the last layer feeds the fused pooling (partials / row map missing)");
   for (int t = 0; t < p.n_taps; ++t) ASV_REQUIRE(p.taps[t] >= -kHalo && p.taps[t] <= kHalo, "tdnn(chainm): tap offset %d exceeds the %d-frame halo", p.taps[t], kHalo);
   const dim3 grid(p.rows / MM), block(512);
-  hipLaunchKernelGGL(tdnn_chainm_kernel, grid, block, 0, s, p);
+  const bool dev = p.dbg != nullptr || p.abl != 0 || p.x_image == 2;
+  if (p.x_image) {
+    if (dev) hipLaunchKernelGGL((tdnn_chainm_kernel<true, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((tdnn_chainm_kernel<true, false>), grid, block, 0, s, p);
+  } else {
+    if (dev) hipLaunchKernelGGL((tdnn_chainm_kernel<false, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((tdnn_chainm_kernel<false, false>), grid, block, 0, s, p);
+  }
   ASV_HIP_CHECK(hipGetLastError());
   return ASV_OK;
 }

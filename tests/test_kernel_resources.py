@@ -154,8 +154,13 @@ def test_f32m_kernels_fit_their_registers_and_lds(tmp_path):
             fn = block.split()[0]
             seen[fn] = {k: int(re.search(p, block).group(1)) for k, p in (("vgprs", r" VGPRs: (\d+)"), ("spill", r"VGPRs Spill: (\d+)"),
                                                                          ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"), ("lds", r"LDS Size \[bytes/block\]: (\d+)"))}
-    chain = [v for k, v in seen.items() if "tdnn_chainm_kernel" in k]
-    x3m = [v for k, v in seen.items() if "tdnn_gemm_x3m_kernelILb0" in k]
-    assert len(chain) == 1 and len(x3m) == 1, sorted(seen)
-    assert chain[0]["spill"] == 0 and chain[0]["scratch"] == 0 and chain[0]["vgprs"] <= 256 and chain[0]["lds"] <= 160 * 1024, chain
-    assert x3m[0]["spill"] <= 8 and x3m[0]["vgprs"] <= 256 and 2 * x3m[0]["lds"] <= 160 * 1024, x3m
+    chain = [v for k, v in seen.items() if "tdnn_chainm_kernel" in k]                 # <IMG, DEV>: f32 / image rows in, production / developer aids
+    x3m = [v for k, v in seen.items() if "tdnn_gemm_x3m_kernel" in k]                 # <GENERIC, XIMG>
+    x3m_img = [v for k, v in seen.items() if "tdnn_gemm_x3m_kernelILb0ELb1" in k or "tdnn_gemm_x3m_kernelILb1ELb1" in k]
+    assert len(chain) == 4 and len(x3m) == 4 and len(x3m_img) == 2, sorted(seen)
+    for c in chain:
+        assert c["spill"] == 0 and c["scratch"] == 0 and c["vgprs"] <= 256 and c["lds"] <= 160 * 1024, chain
+    for v in x3m_img:                                                                 # image rows in: no conversion pass, nothing parked
+        assert v["spill"] == 0, x3m_img
+    for v in x3m:
+        assert v["spill"] <= 8 and v["vgprs"] <= 256 and 2 * v["lds"] <= 160 * 1024, x3m
