@@ -26,24 +26,28 @@
 // image Y8 (64 KiB: per row and 32-channel group [x_lo8 16 | x_lo8 16 | x_hi8 16 | x_hi8 16]) where chainx keeps two half images -,
 // last layer in 64-channel units with swapped operands and the register-only pooling epilogue.  The K loop works in 32-channel pairs:
 // 8 half instructions (two k-groups) + 4 scaled ones; ALL weight fragments of a pair are fetched a whole step ahead into the second of
-// two register sets, the rows from LDS two phases ahead.  The 8-bit weight block e4m3(w_hi) is made in registers from the half fragments
-// (v_cvt_scalef32_pk_fp8_f16): only w_hi (2 B) and e4m3(w_lo) (1 B) per weight come from memory.  One workgroup (512 threads, 136 KiB of
-// LDS) per CU.
+// two register sets, the rows from LDS two phases ahead: halves (2 B), e4m3(w_lo) (1 B) and e4m3(w_hi) (1 B, the second plane of
+// pack_tdnn_weight_mx8; CHAINM_WHI8_REG = 1 makes it in registers instead: 24 conversions per step, 2.5 % slower).  One workgroup (512
+// threads, 136 KiB of LDS) per CU.  Layer A's rows come as f32 (converted in place, a ring of 3 windows, a barrier per chunk) or as IMAGES from
+// the producing layer's epilogue (kernels_tdnn_x3m.hip: a ring of 10 windows, a barrier per four chunks) - see there.
 //
-// Where the time goes (round 6, s_memtime stamps: profiles/r6i_chainm_phase_stamps.txt, r6o_chainm_layerA_step_stamps.txt, r6p_*): per
-// 64-frame tile 114.7 k cycles of matrix work per SIMD, ~196 k measured.  A K step (one pair, 1024 matrix cycles for the two waves of a
-// SIMD) takes 1250 - 1350 cycles for the older wave of a SIMD and ~1900 for the younger when nothing synchronises them; layer A's chunk
-// barrier (every n_taps steps) then runs at the pace of the slower wave (~6000 cycles per 3-step chunk).  Not the cause: the window
-// conversion (in place and between the matrix instructions since; it was 450 cycles), the window DMA, the order of the fragment array
-// (a copy in step order changed nothing), the fetch distance of the half fragments (350 -> 1250 cycles: nothing).  What is left is the
-// weight stream itself: every CU streams the chain's whole weight set (3.7 MB of halves + 1.8 MB of 8-bit values, more than one XCD's
-// 4 MiB of L2) per 64 frames - 48 KiB per step and CU, 1.5 MB per step and XCD - and the three-product kernel has the same stream under
-// 1.5 x the matrix work.  Alternating the issue priority between the two waves of a SIMD step by step gives 3 % (r6p).  The lever that is
-// left is rows per workgroup (LDS: 96 frames fit if x_hi8 is made from the half rows in registers as w_hi8 is; registers: 96 accumulators).
+// Where the time goes (round 6, s_memtime stamps: profiles/r6i, r6o, r6p, r6r, r6s, r6u, r6x): per 64-frame tile 114.7 k cycles of matrix work per
+// SIMD, 206 k measured at first, 192 k now.  A K step (one pair, 1024 matrix cycles for the two waves of a SIMD) takes ~1350 cycles in the
+// barrier-free Y loops and ~1450 in layer A with image rows (1900 with f32 rows and a barrier per chunk).  Not the cause: the window
+// conversion, the window DMA, the order of the fragment array (a copy in step order changed nothing), the fetch distance of the fragments
+// (350 -> 1250 cycles: nothing), the stream from L2 as such (every step fetching the SAME fragments: -5 %), the LDS reads (0 %).  The
+// cause, by experiment builds (-DCHAINM_EXP, r6x): the NUMBER of fragment bytes a CU ingests per step - 8 x 1 KiB per wave = 64 KiB per
+// step and CU through the vector memory path; with half of those loads the loop's cycles drop 9 % and the shader clock RISES 8 % (power),
+// together -13 % per workgroup.  4 bytes per weight is what this form costs; more frames per fetched byte is the lever and LDS capacity
+// (2 KiB per resident frame) stops it - the 96-frame kernel (x_hi8 made in registers to fit) paid more in conversions than it gained.
+// Alternating the issue priority between the two waves of a SIMD step by step gives 3 % (r6p).
 #include <cstdlib>
 
 #include "device_utils.h"
 
+#ifndef CHAINM_EXP
+#define CHAINM_EXP 0
+#endif
 #ifndef CHAINM_WHI8_REG
 #define CHAINM_WHI8_REG 0      // 1: e4m3(w_hi) made in registers from the half fragments (24 conversions per step) instead of fetched (rounds 6i - 6r)
 #endif
@@ -495,17 +499,21 @@ __global__ __launch_bounds__(512, 2) void tdnn_chainm_kernel(const TdnnChainPara
     init_acc(bias64, w_scale, tr);
     auto step = [&](const MW &wc, MW &wn, const MX8 &ec, MX8 &en, int nn) {      // computes the pair in (wc, h0x, h1x, ec); fetches pair nn
       if ((abl & 8) == 0) { if (((nn ^ (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-      const size_t off8 = (size_t)nn * 1024 + lane16;
-      const size_t offh = (size_t)(nn * 2) * 1024 + lane16;
-      const uint32_t ax0 = MYIMG + yb + ((((uint32_t)(nn * 4)) ^ sx) << 4), ax1 = MYIMG + yb + ((((uint32_t)(nn * 4 + 2)) ^ sx) << 4);
-      const uint32_t ah0 = yb + ((((uint32_t)(nn * 4)) ^ sx) << 4), ah1 = yb + ((((uint32_t)(nn * 4 + 2)) ^ sx) << 4);
+      // (developer instantiation, results garbage: abl bit 4 = every step fetches the SAME weight fragments - the loads stay, the stream from
+      //  L2 goes; bit 5 = every step reads the same rows of Y)
+      // (CHAINM_EXP, experiment builds only - never the product: bit 0 = no fetch of the two 8-bit weight blocks in the Y loops, bit 1 = none of k-group 1's halves)
+      const int nw = (abl & 16) ? 0 : nn, nx = (abl & 32) ? 0 : nn;
+      const size_t off8 = (size_t)nw * 1024 + lane16;
+      const size_t offh = (size_t)(nw * 2) * 1024 + lane16;
+      const uint32_t ax0 = MYIMG + yb + ((((uint32_t)(nx * 4)) ^ sx) << 4), ax1 = MYIMG + yb + ((((uint32_t)(nx * 4 + 2)) ^ sx) << 4);
+      const uint32_t ah0 = yb + ((((uint32_t)(nx * 4)) ^ sx) << 4), ah1 = yb + ((((uint32_t)(nx * 4 + 2)) ^ sx) << 4);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         if (q == 0) { wn.h0[0] = *reinterpret_cast<const uint4 *>(wbh + offh); wn.h0[1] = *reinterpret_cast<const uint4 *>(wbh + fs + offh); }
-        if (q == 0) { wn.h1[0] = *reinterpret_cast<const uint4 *>(wbh + offh + 1024); wn.h1[1] = *reinterpret_cast<const uint4 *>(wbh + fs + offh + 1024); }
-        if (q == 1) { wn.e[0] = *reinterpret_cast<const uint4 *>(wb8 + off8); wn.e[1] = *reinterpret_cast<const uint4 *>(wb8 + fs8 + off8); }
+        if (q == 0 && !(CHAINM_EXP & 2)) { wn.h1[0] = *reinterpret_cast<const uint4 *>(wbh + offh + 1024); wn.h1[1] = *reinterpret_cast<const uint4 *>(wbh + fs + offh + 1024); }
+        if (q == 1 && !(CHAINM_EXP & 1)) { wn.e[0] = *reinterpret_cast<const uint4 *>(wb8 + off8); wn.e[1] = *reinterpret_cast<const uint4 *>(wb8 + fs8 + off8); }
 #if !CHAINM_WHI8_REG
-        if (q == 1) { wn.q[0] = *reinterpret_cast<const uint4 *>(wb8 + plane8 + off8); wn.q[1] = *reinterpret_cast<const uint4 *>(wb8 + plane8 + fs8 + off8); }
+        if (q == 1 && !(CHAINM_EXP & 1)) { wn.q[0] = *reinterpret_cast<const uint4 *>(wb8 + plane8 + off8); wn.q[1] = *reinterpret_cast<const uint4 *>(wb8 + plane8 + fs8 + off8); }
 #endif
         if (q == 2) { en.x[0][0] = *reinterpret_cast<const uint4 *>(lds + ax0); en.x[0][1] = *reinterpret_cast<const uint4 *>(lds + ax1); }
 #if CHAINM_WHI8_REG

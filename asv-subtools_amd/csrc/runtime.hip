@@ -1438,7 +1438,7 @@ int run_ops(RunCtx &c, size_t n_ops) {
             static const bool chainm_group_off = getenv("ASV_AMD_CHAINM_GROUP") != nullptr && atoi(getenv("ASV_AMD_CHAINM_GROUP")) == 0;      // measuring aid (same results)
             cp.x_image = p.x_image ? (chainm_group_off ? 2 : 1) : 0;
             static const int chainm_abl = getenv("ASV_AMD_CHAINM_ABL") != nullptr ? atoi(getenv("ASV_AMD_CHAINM_ABL")) : 0;       // developer aid, read once
-            cp.abl = (chainm_abl & 7) != 0 && getenv("ASV_AMD_CHAIN_DBG") == nullptr ? (chainm_abl & 8) : chainm_abl;               // the garbage-result bits only under ASV_AMD_CHAIN_DBG
+            cp.abl = (chainm_abl & ~8) != 0 && getenv("ASV_AMD_CHAIN_DBG") == nullptr ? (chainm_abl & 8) : chainm_abl;               // the garbage-result bits only under ASV_AMD_CHAIN_DBG
             cp.n128 = plan.n128; cp.n_tail = plan.n_tail; cp.tail_rows = plan.tail_rows;
             if ((rc = ensure(net->poolpart_dev, (size_t)n_blocks * slots * 2 * 3 * cp.ld_partial * 4, c.s, false))) return rc;
             cp.pool_partial = reinterpret_cast<float *>(net->poolpart_dev.ptr);
