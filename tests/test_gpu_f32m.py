@@ -205,6 +205,28 @@ def test_image_rows_between_f32m_layers_change_no_bit(lens, monkeypatch):
     assert np.isfinite(with_images).all() and np.array_equal(with_images, without), float(np.abs(with_images - without).max())
 
 
+def test_image_rows_through_the_unchained_layers(monkeypatch):
+    """With the chain kernel off (ASV_AMD_NO_CHAIN=1: one launch per layer) tdnn1 .. tdnn4 run on the 8-bit wide-layer kernel at configs[1]'s
+    batch (tdnn5, with the pooling fused into its epilogue, stays on the three-product kernel and reads f32 rows): three hand-overs as
+    images, and the embeddings equal those without them bit for bit and the chained extraction to the f32 order of the pooled moments."""
+    from libs.amd import capi, synth
+    monkeypatch.setenv("ASV_AMD_LIVE_TUNE", "1")
+    L = capi.lib()
+    mats = [synth.synth_feats(200, 80, 9000 + i) for i in range(256)]
+    chained = _synth_xvector()._amd_engine()._extract_batch(mats).numpy()
+    monkeypatch.setenv("ASV_AMD_NO_CHAIN", "1")
+    eng = _synth_xvector()._amd_engine()
+    res = {}
+    for img in ("1", "0"):
+        monkeypatch.setenv("ASV_AMD_X3M_IMAGE", img)
+        n0, m0, c0 = (L.asv_kernel_launch_count(k) for k in (capi.KERNEL_TDNN_X3M_IMAGE, capi.KERNEL_TDNN_X3M, capi.KERNEL_TDNN_CHAINM))
+        res[img] = eng._extract_batch(mats).numpy()
+        got = tuple(L.asv_kernel_launch_count(k) - b for k, b in ((capi.KERNEL_TDNN_X3M_IMAGE, n0), (capi.KERNEL_TDNN_X3M, m0), (capi.KERNEL_TDNN_CHAINM, c0)))
+        assert got == ((3, 4, 0) if img == "1" else (0, 4, 0)), (img, got)
+    assert np.isfinite(res["1"]).all() and np.array_equal(res["1"], res["0"])
+    assert rel_err(res["1"], chained) < 2e-5, rel_err(res["1"], chained)
+
+
 def test_image_rows_on_the_small_goldens_and_tiny_utterances(monkeypatch):
     """Forced onto the golden batches (ASV_AMD_X3M=2: the 8-bit kernel from two tiles on): the x-vector goldens inside the gate with image
     rows between its layers; and small batches - one of them a crowd of 5-frame utterances beside long ones - with and without images:
