@@ -40,10 +40,19 @@
 // first use is vmcnt(2) where the steady state needs vmcnt(7) - every K step waits for fragments fetched 8 MFMAs earlier.  With the
 // entry loads pinned to the loop's order all waits become vmcnt(7): bit-identical, 705.8 -> 708.4 us per step (L2 hits return
 // within those 256 cycles) - dropped.
+// What bounds the K loops (round 6, experiment builds -DCHAIN_EXP below, profiles/r6z_chain_fetch_experiments.txt): every layer's loop runs at
+// 79 % of the matrix rate (20.6 k cycles per 16 steps against 16.4 k).  With one of the two weight-fragment loads per k-group taken away the
+// same loop runs at 16.6 - 16.8 k - the matrix rate; with all loads but from one address (L1 hits) at 20.1 k.  It is the CU's vector-memory
+// path: 32 x 1 KiB per 1024-cycle step = 32 B/clk whatever level serves it, and at 128 frames per tile a fetched weight byte is worth 128
+// FLOP - 4096 FLOP/clk, the matrix rate: co-bound by construction.  More frames per resident tile is the only lever (128 x 512 x 16 bit IS the LDS).
 // One workgroup (512 threads, 160 KiB LDS) per CU.
 #include <cstdlib>
 
 #include "device_utils.h"
+
+#ifndef CHAIN_EXP
+#define CHAIN_EXP 0      // experiment builds: bit 0 / 1 = the Y loops fetch only one / none of the two weight fragments per k-group, bit 2 = every chunk fetches the SAME fragments (results garbage)
+#endif
 
 namespace asv {
 namespace {
@@ -341,14 +350,14 @@ __global__ __launch_bounds__(512, 2) void tdnn_chain_kernel(const TdnnChainParam
 #pragma unroll 1
     for (int c = 0; c < CN / CBK; ++c) {
       const int cn = min(c + 1, CN / CBK - 1);
-      const size_t wnext = (size_t)cn * 4096;
+      const size_t wnext = (CHAIN_EXP & 4) ? 0 : (size_t)cn * 4096;
       auto group = [&](const XFrags &xc, int kg, XFrags &xn, int c2, int kgn) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           if (q < MF) load_y4(c2, kgn, q, xn);
           mma2(xc, kg, q / 2, (q % 2) * 2, tr);
-          if (q == 1) wf[kg][0] = *reinterpret_cast<const uint4 *>(wb0 + wnext + (size_t)kg * 1024 + lane16);
-          if (q == 3) wf[kg][1] = *reinterpret_cast<const uint4 *>(wb1 + wnext + (size_t)kg * 1024 + lane16);
+          if (q == 1 && !(CHAIN_EXP & 2)) wf[kg][0] = *reinterpret_cast<const uint4 *>(wb0 + wnext + (size_t)kg * 1024 + lane16);
+          if (q == 3 && !(CHAIN_EXP & 1)) wf[kg][1] = *reinterpret_cast<const uint4 *>(wb1 + wnext + (size_t)kg * 1024 + lane16);      // (CHAIN_EXP: experiment builds only, never the product - profiles/r6z_*)
           __builtin_amdgcn_sched_barrier(0);
         }
       };
