@@ -227,6 +227,35 @@ def test_image_rows_through_the_unchained_layers(monkeypatch):
     assert rel_err(res["1"], chained) < 2e-5, rel_err(res["1"], chained)
 
 
+def test_range_watch_through_the_image_epilogue_at_full_size():
+    """configs[1]'s batch with ONE utterance scaled by 1e5: with image rows the half-range watch of tdnn2's and the chain's inputs sits in the
+    producing layers' epilogues (kernels_tdnn_x3m.hip).  The raw pass must raise ASV_STATUS_HALF_RANGE (and has handed rows over as images),
+    the guarded extraction re-runs on the bf16-halves twin, and the 255 ordinary utterances equal their extraction without the scaled
+    neighbour to the f32 order of the pooled moments."""
+    from libs.amd import capi, synth
+    L = capi.lib()
+    model = _synth_xvector()
+    eng = model._amd_engine()
+    mats = [synth.synth_feats(200, 80, 11000 + i) for i in range(256)]
+    clean = eng.extract_batch(mats).numpy()
+    assert eng.status() == 0
+    big = list(mats)
+    big[100] = (mats[100] * 1.0e5).astype(np.float32)
+    eng.status()
+    n0 = L.asv_kernel_launch_count(capi.KERNEL_TDNN_X3M_IMAGE)
+    eng._extract_batch(big)
+    assert L.asv_kernel_launch_count(capi.KERNEL_TDNN_X3M_IMAGE) == n0 + 2
+    assert eng.status() & capi.STATUS_HALF_RANGE
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got = eng.extract_batch(big).numpy()
+    assert any("f32x-bf16" in str(x.message) for x in w)
+    assert np.isfinite(got).all()
+    others = [i for i in range(256) if i != 100]
+    # (the twin's products are three bf16-halves terms: 1e-5-grade against the f32m pass, far inside the gate)
+    assert rel_err(got[others], clean[others]) < 5e-5, rel_err(got[others], clean[others])
+
+
 def test_image_rows_on_the_small_goldens_and_tiny_utterances(monkeypatch):
     """Forced onto the golden batches (ASV_AMD_X3M=2: the 8-bit kernel from two tiles on): the x-vector goldens inside the gate with image
     rows between its layers; and small batches - one of them a crowd of 5-frame utterances beside long ones - with and without images:
