@@ -256,6 +256,50 @@ def test_range_watch_through_the_image_epilogue_at_full_size():
     assert rel_err(got[others], clean[others]) < 5e-5, rel_err(got[others], clean[others])
 
 
+def test_image_handover_decisions_over_random_batches(monkeypatch):
+    """The producer decides the hand-over by PREDICTING its reader's kernel (run_ops: reader_takes_image); a reader that finds images it cannot
+    read fails the call.  40 seeded batches across the sizes where the selection rules flip (the 8-bit kernel from 384 tiles of 128 x 256 on,
+    the 8-phase kernel's whole-rounds rule, short / long / tiny utterances, chained and un-chained): no call may fail, and with and without the
+    hand-over the embeddings are the same bits."""
+    from libs.amd import capi, synth
+    monkeypatch.setenv("ASV_AMD_LIVE_TUNE", "1")
+    L = capi.lib()
+    rng = np.random.default_rng(20260930)
+    engines = {"chained": _synth_xvector()._amd_engine()}
+    monkeypatch.setenv("ASV_AMD_NO_CHAIN", "1")
+    engines["unchained"] = _synth_xvector()._amd_engine()
+    monkeypatch.delenv("ASV_AMD_NO_CHAIN")
+    pool = {}
+    handed = 0
+    for trial in range(40):
+        n = int(rng.choice([40, 90, 120, 150, 200, 256, 300, 400, 520]))
+        kind = trial % 4
+        if kind == 0:
+            lens = [200] * n
+        elif kind == 1:
+            lens = [int(v) for v in rng.integers(100, 400, n)]
+        elif kind == 2:
+            lens = [int(v) for v in rng.integers(1, 60, n // 2)] + [int(v) for v in rng.integers(300, 900, n // 4)]
+        else:
+            lens = [int(v) for v in rng.integers(150, 260, n)]
+        mats = []
+        for T in lens:
+            if T not in pool:
+                pool[T] = synth.synth_feats(T, 80, 13000 + T)
+            mats.append(pool[T])
+        eng = engines["unchained" if trial % 5 == 4 else "chained"]
+        res = {}
+        for img in ("1", "0"):
+            monkeypatch.setenv("ASV_AMD_X3M_IMAGE", img)
+            n0 = L.asv_kernel_launch_count(capi.KERNEL_TDNN_X3M_IMAGE)
+            res[img] = eng._extract_batch(mats).numpy()
+            if img == "1":
+                handed += L.asv_kernel_launch_count(capi.KERNEL_TDNN_X3M_IMAGE) - n0
+        assert np.isfinite(res["1"]).all() and np.array_equal(res["1"], res["0"]), (trial, n, kind)
+    assert handed >= 20, handed          # the sweep did reach the hand-over (most batches from ~190 utterances on)
+    print("[f32m] 40 random batches: %d hand-overs as images, equal bits with and without" % handed)
+
+
 def test_image_rows_on_the_small_goldens_and_tiny_utterances(monkeypatch):
     """Forced onto the golden batches (ASV_AMD_X3M=2: the 8-bit kernel from two tiles on): the x-vector goldens inside the gate with image
     rows between its layers; and small batches - one of them a crowd of 5-frame utterances beside long ones - with and without images:
