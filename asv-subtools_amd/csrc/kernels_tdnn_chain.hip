@@ -40,11 +40,12 @@
 // first use is vmcnt(2) where the steady state needs vmcnt(7) - every K step waits for fragments fetched 8 MFMAs earlier.  With the
 // entry loads pinned to the loop's order all waits become vmcnt(7): bit-identical, 705.8 -> 708.4 us per step (L2 hits return
 // within those 256 cycles) - dropped.
-// What bounds the K loops (round 6, experiment builds -DCHAIN_EXP below, profiles/r6z_chain_fetch_experiments.txt): every layer's loop runs at
-// 79 % of the matrix rate (20.6 k cycles per 16 steps against 16.4 k).  With one of the two weight-fragment loads per k-group taken away the
-// same loop runs at 16.6 - 16.8 k - the matrix rate; with all loads but from one address (L1 hits) at 20.1 k.  It is the CU's vector-memory
-// path: 32 x 1 KiB per 1024-cycle step = 32 B/clk whatever level serves it, and at 128 frames per tile a fetched weight byte is worth 128
-// FLOP - 4096 FLOP/clk, the matrix rate: co-bound by construction.  More frames per resident tile is the only lever (128 x 512 x 16 bit IS the LDS).
+// What bounds the K loops (round 6, experiment builds -DCHAIN_EXP below, profiles/r6z_chain_fetch_experiments.txt; csrc/tools/vmem_probe.hip,
+// profiles/r6z_vmem_probe.txt): every layer's loop runs at 79 % (20.6 k ticks per 16 steps against 16.4 k at 32 per matrix instruction).  With
+// one of the two weight-fragment loads per k-group taken away the same loop runs at 16.6 - 16.8 k; with all loads but from one address (L1
+// hits) at 20.1 k.  It is what a 1 KiB vector load costs the SIMD that issues it (~60 matrix-issue clocks, whatever level serves it): a bare
+// probe with this kernel's 4 loads per 16 matrix instructions reaches 61 - 65 % of the datasheet rate, with 1 load 92 %.  The load count is
+// the tile's weight bytes / 1 KiB: more frames per resident tile is the only lever (128 x 512 x 16 bit IS the LDS).
 // One workgroup (512 threads, 160 KiB LDS) per CU.
 #include <cstdlib>
 
