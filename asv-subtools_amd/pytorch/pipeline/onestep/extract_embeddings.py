@@ -409,8 +409,15 @@ class ScpBatchLoader(object):
         self._heads[i] = h
         return h
 
-    def index_all(self):
-        """Headers of ALL plain float32 'file:offset' entries in one native call (15 bytes each, libasv_io.so asv_io_pread_batch) and a
+    def index_all(self, ranks=None):
+        """`ranks` = (rank, world, gather) under --sharded with more than one rank: the header pass is SHARED - every rank reads the
+        headers of one contiguous 1 / world of the entries and `gather(local uint8 array) -> [world, ...] array` (an all-gather)
+        completes the table on every rank (round 6: the per-rank pass over the WHOLE table was what did not scale on one host - 0.10 s
+        per 50 000 entries on every rank, 64 % of a rank's host work at 8 ranks, tools/bench_loaders.py).  Every rank must hold the same
+        table; the ranks first compare (entries, plain candidates, a checksum of their offsets) and fall back to the whole pass, each on
+        its own, if they differ; a failed header read on any rank sends all of them to the per-entry path together.
+
+        Headers of ALL plain float32 'file:offset' entries in one native call (15 bytes each, libasv_io.so asv_io_pread_batch) and a
         vectorised parse: arrays (plain, file id, payload offset, rows, cols) that load_batch() indexes with a batch's entry numbers -
         per batch a handful of numpy operations instead of ~10 Python operations per utterance (50 000 utterances: 0.15 s of
         interpreter time on the reader thread, under the GIL the submitting thread needs too; the header pass itself 0.2 s -> 0.03 s).
@@ -458,12 +465,36 @@ class ScpBatchLoader(object):
         cand = np.asarray(cand, dtype=np.int64)
         keep = set(files)
         lut = np.asarray([self._fd(path, keep=keep) for path in files], dtype=np.int32)
-        heads = np.zeros((len(cand), 16), dtype=np.uint8)
-        try:
-            native_io.pread_batch(lut[fid[cand]], off[cand], np.full(len(cand), 15, dtype=np.int64), heads.ctypes.data,
-                                  np.arange(len(cand), dtype=np.int64) * 16, threads=self.threads)
-        except OSError:
-            return False                                  # (an offset at the very end of a file: the per-entry path names the entry)
+        nc = len(cand)
+        shared = False
+        if ranks is not None and ranks[1] > 1:
+            rank, world, gather = ranks
+            mine = np.zeros((1, 16), dtype=np.uint8)
+            mine.view("<i8")[0, 0], mine.view("<i8")[0, 1] = nc * 1000003 + n, int(np.bitwise_xor.reduce(off[cand] * 31 + fid[cand]))
+            seen = gather(mine)
+            shared = bool((seen == mine[None]).all())          # the same table on every rank (else: every rank for itself, no further collective)
+        if shared:
+            per = -(-nc // world)
+            lo, hi = min(rank * per, nc), min((rank + 1) * per, nc)
+            local = np.zeros((per + 1, 16), dtype=np.uint8)      # last row: this rank's reads succeeded
+            try:
+                if hi > lo:
+                    native_io.pread_batch(lut[fid[cand[lo:hi]]], off[cand[lo:hi]], np.full(hi - lo, 15, dtype=np.int64), local.ctypes.data,
+                                          np.arange(hi - lo, dtype=np.int64) * 16, threads=self.threads)
+                local[per, 0] = 1
+            except OSError:
+                pass
+            full = gather(local)
+            if not (full[:, per, 0] == 1).all():
+                return False                              # every rank sees the same flags: all of them take the per-entry path
+            heads = np.ascontiguousarray(full[:, :per].reshape(-1, 16)[:nc])
+        else:
+            heads = np.zeros((nc, 16), dtype=np.uint8)
+            try:
+                native_io.pread_batch(lut[fid[cand]], off[cand], np.full(nc, 15, dtype=np.int64), heads.ctypes.data,
+                                      np.arange(nc, dtype=np.int64) * 16, threads=self.threads)
+            except OSError:
+                return False                              # (an offset at the very end of a file: the per-entry path names the entry)
         ok = (heads[:, 0] == 0) & (heads[:, 1] == ord("B")) & (heads[:, 2] == ord("F")) & (heads[:, 3] == ord("M")) & (heads[:, 4] == ord(" ")) & \
              (heads[:, 5] == 4) & (heads[:, 10] == 4)
         rows_c = np.ascontiguousarray(heads[:, 6:10]).view("<i4").ravel()
@@ -719,6 +750,24 @@ def extract_sharded_scp(extract_batch, entries, lengths, w, batch_frames, batch_
     return n
 
 
+def index_ranks(device=None):
+    """(rank, world, gather) for ScpBatchLoader.index_all under an initialised process group of more than one rank, else None.  `gather`
+    all-gathers a uint8 array - through device memory under NCCL / RCCL (`device`), host memory under gloo."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() < 2 or os.environ.get("ASV_AMD_SHARD_INDEX", "1") == "0":
+        return None
+    world = dist.get_world_size()
+    where = device if (device is not None and dist.get_backend() == "nccl") else torch.device("cpu")
+
+    def gather(local):
+        t = torch.from_numpy(np.ascontiguousarray(local)).to(where)
+        out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=torch.uint8, device=where)      # (the concatenated form: gloo takes no other)
+        dist.all_gather_into_tensor(out, t)
+        return out.cpu().numpy().reshape((world,) + tuple(t.shape))
+
+    return dist.get_rank(), world, gather
+
+
 def run_sharded(args, model, max_chunk, verbose):
     import torch.distributed as dist
     from libs.amd.pipeline import DeviceSets
@@ -736,7 +785,9 @@ def run_sharded(args, model, max_chunk, verbose):
     sets = DeviceSets(model, args.batch_frames, args.batch_utts, engine.feat_dim, max_chunk, n_sets=3, results="device")
     loader = ScpBatchLoader(entries, threads=_reader_threads(),
                             buffers=[sets.host_buffer(k) for k in range(sets.n_sets)], before_fill=sets.input_consumed)
-    loader.index_all()                                 # all headers in one native call (also what lengths() below reads)
+    # all headers in one native call (also what lengths() below reads) - under several ranks each reads 1 / world of them and one
+    # all-gather completes the table (ASV_AMD_SHARD_INDEX=0: every rank reads all of them)
+    loader.index_all(ranks=index_ranks(dev))
     if args.utt2num_frames:
         table = dict(line.split() for line in open(args.utt2num_frames) if line.strip())
         lengths = np.array([int(table[k]) for k, _ in entries], dtype=np.int64)

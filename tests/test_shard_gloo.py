@@ -329,3 +329,101 @@ def test_a_one_sided_exit_does_not_leave_the_other_rank_in_a_collective(tmp_path
         assert "KeyboardInterrupt" in r1 and "another rank failed" in r0, (r0, r1)
     else:
         assert "rank 1 cannot write" in r1, (r0, r1)
+
+
+def _load_script():
+    import importlib.util
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("extract_embeddings_mod", os.path.join(repo, "asv-subtools_amd", "pytorch", "pipeline", "onestep", "extract_embeddings.py"))
+    ee = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ee)
+    return ee
+
+
+def _write_feature_table(directory, utts, broken_for=None):
+    """feats.ark / feats.scp of `utts` float32 matrices of 1 .. 40 frames x 8; `broken_for`: an entry whose offset points behind the file."""
+    rs = np.random.RandomState(3)
+    ark, scp = os.path.join(directory, "feats.ark"), os.path.join(directory, "feats.scp")
+    lens = []
+    with open(ark, "wb") as f, open(scp, "w") as s:
+        pos = 0
+        for i in range(utts):
+            t = int(rs.randint(1, 41))
+            lens.append(t)
+            key = ("u%05d " % i).encode()
+            f.write(key)
+            pos += len(key)
+            s.write("u%05d %s:%d\n" % (i, ark, pos if i != broken_for else 10 ** 9))
+            blob = b"\0BFM \4" + np.int32(t).tobytes() + b"\4" + np.int32(8).tobytes() + rs.randn(t, 8).astype(np.float32).tobytes()
+            f.write(blob)
+            pos += len(blob)
+    return scp, lens
+
+
+def _worker_index(rank, world, port, scp, out_dir, differ):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ee = _load_script()
+        entries = ee.read_scp("scp:" + scp)
+        if differ and rank == 1:
+            entries = entries[: len(entries) - 1] if isinstance(entries, list) else ee.read_scp("scp:" + scp + ".short")
+        calls = []
+        ranks = ee.index_ranks()
+        assert ranks is not None and ranks[:2] == (rank, world)
+        counted = (ranks[0], ranks[1], lambda a: (calls.append(a.shape), ranks[2](a))[1])
+        shared = ee.ScpBatchLoader(entries, threads=2)
+        ok = shared.index_all(ranks=counted)
+        alone = ee.ScpBatchLoader(entries, threads=2)
+        ok_alone = alone.index_all()
+        same = bool(ok == ok_alone) and (not ok or all(np.array_equal(a, b) for a, b in zip(shared._table[:5], alone._table[:5])))
+        np.save(os.path.join(out_dir, "index%d.npy" % rank), np.array([int(ok), int(ok_alone), int(same), len(calls)] + ([int(calls[-1][0])] if calls else [0])))
+        if ok:
+            np.save(os.path.join(out_dir, "lengths%d.npy" % rank), shared.lengths())
+        shared.close(); alone.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_header_pass_shared_between_the_ranks_equals_the_whole_pass(tmp_path, world):
+    """--sharded with several ranks (round 6): every rank reads the headers of 1 / world of the table and one all-gather completes it - the
+    table (plain flags, file ids, payload offsets, rows, columns) and the lengths are what the whole pass on one rank gives; each rank's
+    second gather carried ceil(n / world) + 1 rows, not n."""
+    import torch.multiprocessing as mp
+    from libs.support import native_io
+    if native_io.lib() is None:
+        pytest.skip("libasv_io.so not built")
+    scp, lens = _write_feature_table(str(tmp_path), 101)
+    mp.spawn(_worker_index, args=(world, _free_port(), scp, str(tmp_path), False), nprocs=world, join=True)
+    for r in range(world):
+        ok, ok_alone, same, n_calls, rows = np.load(tmp_path / ("index%d.npy" % r))
+        assert (ok, ok_alone, same, n_calls) == (1, 1, 1, 2) and rows == -(-101 // world) + 1, (r, ok, ok_alone, same, n_calls, rows)
+        assert np.array_equal(np.load(tmp_path / ("lengths%d.npy" % r)), np.asarray(lens))
+
+
+def test_header_pass_ranks_with_different_tables_or_a_failed_read_agree_on_the_fallback(tmp_path):
+    """Two ranks that do not hold the same table notice it in the first (16-byte) gather and index for themselves - no second collective
+    with mismatched shapes; a header read that fails on one rank sends BOTH to the per-entry path (index_all -> False on both)."""
+    import torch.multiprocessing as mp
+    from libs.support import native_io
+    if native_io.lib() is None:
+        pytest.skip("libasv_io.so not built")
+    d1 = tmp_path / "a"
+    d1.mkdir()
+    scp, lens = _write_feature_table(str(d1), 50)
+    with open(scp) as f, open(scp + ".short", "w") as g:
+        g.writelines(f.readlines()[:-1])
+    mp.spawn(_worker_index, args=(2, _free_port(), scp, str(d1), True), nprocs=2, join=True)
+    for r in range(2):
+        ok, ok_alone, same, n_calls, rows = np.load(d1 / ("index%d.npy" % r))
+        assert (ok, ok_alone, same, n_calls) == (1, 1, 1, 1), (r, ok, ok_alone, same, n_calls)
+    d2 = tmp_path / "b"
+    d2.mkdir()
+    scp2, _ = _write_feature_table(str(d2), 50, broken_for=40)           # the second rank's half holds the entry behind the end of the file
+    mp.spawn(_worker_index, args=(2, _free_port(), scp2, str(d2), False), nprocs=2, join=True)
+    for r in range(2):
+        ok, ok_alone, same, n_calls, rows = np.load(d2 / ("index%d.npy" % r))
+        assert (ok, ok_alone, n_calls) == (0, 0, 2), (r, ok, ok_alone, n_calls)

@@ -4,12 +4,13 @@
 N in {1, 2, 4, 8} concurrent processes - the ranks of `extract_embeddings.py --sharded true` on one node - each run the rank-side host work
 of pipeline/onestep/extract_embeddings.py extract_sharded_scp on ITS share of one feature table read from the page cache:
 
-    read_scp -> ScpBatchLoader.index_all (all headers, one native call) -> lengths -> per segment: shard.balance_by_length over the N ranks,
+    read_scp -> ScpBatchLoader.index_all (the headers: 1 / N of them per rank + one all-gather - a shared-memory gather between the harness'
+    processes stands in for the script's RCCL one; --whole-index: all of them on every rank, the path before round 6's last step) -> lengths -> per segment: shard.balance_by_length over the N ranks,
     shard.plan_batches (row-aware, --batch-frames 65536 / --batch-utts 1024) -> ScpBatchLoader.load_batch of every batch of the rank
     (positioned native reads into three rotating [65536, 80] buffers, as into libs.amd.pipeline.DeviceSets' page-locked ones)
 
 and, on rank 0 only (as in the script: rank 0 writes), the packing of ALL N shards' embeddings into ark bytes (kaldi_io.vec_flt_ark_bytes, 512-dim,
-written to /dev/null).  No device, no collective: the device side and the gather are measured elsewhere (bench.py, tools/bench_pipeline.py) -
+written to /dev/null).  No device, no collective but that one: the device side and the embeddings' gather are measured elsewhere (bench.py, tools/bench_pipeline.py) -
 this is the part that shares ONE host between the ranks.  Reported per (table, N, reader threads per rank): the wall time from the common start
 to the last rank's end, aggregate utterances/s and GB/s, the slowest rank's split, and the reader-thread count that maximises the aggregate.
 
@@ -58,8 +59,28 @@ def write_table(directory, name, utts, lengths=None, frames=200, dim=80):
     return scp, os.path.getsize(ark)
 
 
-def rank_main(rank, world, scp, threads, ready, go, out, batch_frames=65536, batch_utts=1024, segment=4096, embed_dim=512):
+def rank_main(rank, world, scp, threads, ready, go, out, share=None, batch_frames=65536, batch_utts=1024, segment=4096, embed_dim=512):
     ee = load_script()                                   # (imports torch: seconds, outside the measurement)
+    ranks = None
+    if share is not None and world > 1:
+        # The header pass is shared between the ranks (ScpBatchLoader.index_all(ranks=...)): each reads 1 / world of the headers and an all-gather
+        # of 16 bytes per entry completes the table.  The script does it over its RCCL group (~0.1 ms for this size); here a shared-memory
+        # gather between the harness' processes stands in for it (a gloo group over loopback was tried first: seconds per collective on the
+        # GPU hosts' network set-up - it measured gloo, not the loaders: profiles/r6z_loaders_gloo_standin.txt).
+        from multiprocessing import shared_memory
+        shm_name, rows_cap, barrier = share
+        shm = shared_memory.SharedMemory(name=shm_name)
+        board = np.ndarray((world, rows_cap, 16), dtype=np.uint8, buffer=shm.buf)
+
+        def gather(local):
+            k = local.shape[0]
+            board[rank, :k] = local
+            barrier.wait()
+            full = board[:, :k].copy()
+            barrier.wait()
+            return full
+
+        ranks = (rank, world, gather)
     from libs.amd import shard
     from libs.support import kaldi_io, native_io
     native_io.lib()
@@ -72,7 +93,7 @@ def rank_main(rank, world, scp, threads, ready, go, out, batch_frames=65536, bat
     bufs = [np.empty((batch_frames, 80), dtype=np.float32) for _ in range(3)]
     loader = ee.ScpBatchLoader(entries, threads=threads, buffers=bufs)
     t0 = time.perf_counter()
-    loader.index_all()
+    loader.index_all(ranks=ranks)
     lengths = loader.lengths()
     spent["index"] = time.perf_counter() - t0
     n = len(lengths)
@@ -100,15 +121,24 @@ def rank_main(rank, world, scp, threads, ready, go, out, batch_frames=65536, bat
             spent["pack"] += time.perf_counter() - t0
     loader.close()
     total = time.perf_counter() - t_begin
+    if ranks is not None:
+        shm.close()
     out.put({"rank": rank, "utts": mine, "frames": frames, "bytes": nbytes, "seconds": total, "begin": begin, "end": time.time(), **{k: round(v, 4) for k, v in spent.items()}})
 
 
-def run(scp, world, threads, repeats):
+def run(scp, world, threads, repeats, shared_index=True):
     best = None
     for _ in range(repeats):
         ctx = mp.get_context("spawn")
         out, ready, go = ctx.Queue(), ctx.Queue(), ctx.Event()
-        procs = [ctx.Process(target=rank_main, args=(r, world, scp, threads, ready, go, out)) for r in range(world)]
+        share, shm = None, None
+        if shared_index and world > 1:
+            from multiprocessing import shared_memory
+            with open(scp) as f:
+                rows_cap = sum(1 for _ in f) + 2
+            shm = shared_memory.SharedMemory(create=True, size=world * rows_cap * 16)
+            share = (shm.name, rows_cap, ctx.Barrier(world))
+        procs = [ctx.Process(target=rank_main, args=(r, world, scp, threads, ready, go, out, share)) for r in range(world)]
         for p in procs:
             p.start()
         for _ in procs:
@@ -117,6 +147,9 @@ def run(scp, world, threads, repeats):
         recs = [out.get(timeout=600) for _ in procs]
         for p in procs:
             p.join()
+        if shm is not None:
+            shm.close()
+            shm.unlink()
         wall = max(r["end"] for r in recs) - min(r["begin"] for r in recs)
         utts, nbytes = sum(r["utts"] for r in recs), sum(r["bytes"] for r in recs)
         slow = max(recs, key=lambda r: r["seconds"])
@@ -136,6 +169,7 @@ def main():
     ap.add_argument("--threads", default="1,2,4,8")
     ap.add_argument("--dir", default="/tmp/asv_loaders")
     ap.add_argument("--repeats", type=int, default=3)
+    ap.add_argument("--whole-index", action="store_true", help="every rank reads ALL headers (the path before the shared header pass; ASV_AMD_SHARD_INDEX=0 in the script)")
     args = ap.parse_args()
     try:
         cores = len(os.sched_getaffinity(0))
@@ -155,7 +189,7 @@ def main():
                     pass
             rows = []
             for world in (int(v) for v in args.ranks.split(",")):
-                per = [run(scp, world, th, args.repeats) for th in (int(v) for v in args.threads.split(","))]
+                per = [run(scp, world, th, args.repeats, shared_index=not args.whole_index) for th in (int(v) for v in args.threads.split(","))]
                 top = max(per, key=lambda r: r["utts_per_s"])
                 rows.append({"ranks": world, "best_reader_threads": top["reader_threads_per_rank"], "best_utts_per_s": top["utts_per_s"], "best_GB_per_s": top["GB_per_s"],
                              "by_threads": {str(r["reader_threads_per_rank"]): r["utts_per_s"] for r in per}, "slowest_rank_at_best": top["slowest_rank"]})
