@@ -7,7 +7,7 @@
 // NEXT iteration's matrix instructions as operands (so the loads are real dependencies, a step ahead, as in the kernels).  Source:
 //   mode 0  a 64 KiB region per workgroup walked linearly (L1 / L2 hits after the first pass: the latency is short, the path is what is measured)
 //   mode 1  a 48 MiB region shared by all workgroups walked linearly (the weight stream of the chain kernels: L2 hits + misses into the MALL)
-// Output per L (loads per 16 matrix instructions of a wave) and fetch distance D: time per iteration from HIP events, the share of the bf16
+// Output per L (loads per 16 matrix instructions of a wave), spacing S (a load behind every S-th instruction) and fetch distance D: time per iteration from HIP events, the share of the bf16
 // matrix peak the chip reached, the load bandwidth over the chip, and the s_memtime count per iteration (NOT core cycles: a pure matrix
 // loop at 97 % of the 2.5 PF peak counts 24.4 per instruction where the pipe needs 32 core cycles - the counter runs at ~0.76 of the core clock there).
 //
@@ -24,7 +24,8 @@ typedef __bf16 v8b __attribute__((ext_vector_type(8)));
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-template <int L, int D>
+// S = spacing of the loads in matrix-instruction slots (1: behind instructions 0 .. L - 1; 16 / L: spread evenly over the 16)
+template <int L, int D, int S>
 __global__ __launch_bounds__(512, 2) void probe(const unsigned char *src, size_t region, size_t wg_stride, int iters, float *out, unsigned long long *cyc) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned char *base = src + (size_t)blockIdx.x * wg_stride + (size_t)lane * 16;
@@ -49,8 +50,8 @@ __global__ __launch_bounds__(512, 2) void probe(const unsigned char *src, size_t
       uint4 (&nxt)[8] = w[(half + D) % (D + 1)];
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        if (q < L) {
-          nxt[q & 7] = *reinterpret_cast<const uint4 *>(base + off + (size_t)q * 1024);
+        if (q % S == 0 && q / S < L) {
+          nxt[(q / S) & 7] = *reinterpret_cast<const uint4 *>(base + off + (size_t)(q / S) * 1024);
         }
         const v8b a = __builtin_bit_cast(v8b, cur[q & 7]), b = __builtin_bit_cast(v8b, cur[(q + 3) & 7]);
         acc[q & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[q & 7], 0, 0, 0);
@@ -103,14 +104,14 @@ __global__ __launch_bounds__(512, 2) void calib(unsigned long long *res, float *
 }
 
 static int cus_g = 256;
-template <int L, int D = 1>
+template <int L, int D = 1, int S = 1>
 static void run(const unsigned char *src, size_t region, size_t wg_stride, int wgs, int iters, float *out, unsigned long long *cyc, const char *what) {
   CK(hipMemset(cyc, 0, (size_t)wgs * 8 * 8));
-  hipLaunchKernelGGL((probe<L, D>), dim3(wgs), dim3(512), 0, 0, src, region, wg_stride, 66, out, cyc);        // warm
+  hipLaunchKernelGGL((probe<L, D, S>), dim3(wgs), dim3(512), 0, 0, src, region, wg_stride, 66, out, cyc);        // warm
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   CK(hipEventRecord(e0));
-  hipLaunchKernelGGL((probe<L, D>), dim3(wgs), dim3(512), 0, 0, src, region, wg_stride, iters, out, cyc);
+  hipLaunchKernelGGL((probe<L, D, S>), dim3(wgs), dim3(512), 0, 0, src, region, wg_stride, iters, out, cyc);
   CK(hipEventRecord(e1));
   CK(hipDeviceSynchronize());
   float ms = 0;
@@ -122,8 +123,8 @@ static void run(const unsigned char *src, size_t region, size_t wg_stride, int w
   const double per_it = sum / (double)h.size() / iters;
   // per CU and iteration (= one step of both waves of every SIMD): 8 waves x L KiB
   const double ns_it = (double)ms * 1e6 / iters;
-  printf("%-28s L = %d loads per 16 matrix instructions, fetched %d x 16 instructions ahead: %6.1f ns per iteration = %5.1f %% of the bf16 matrix peak (2.5 PF), %5.2f TB/s over the chip; s_memtime %7.1f per iteration\n",
-         what, L, D, ns_it, 100.0 * (double)cus_g * 4 * 32 * 32768.0 / (ns_it * 1e-9) / 2.5e15, (double)cus_g * 8.0 * L * 1024.0 / (ns_it * 1e-9) / 1e12, per_it);
+  printf("%-28s L = %d loads per 16 matrix instructions, one every %d, fetched %d x 16 instructions ahead: %6.1f ns per iteration = %5.1f %% of the bf16 matrix peak (2.5 PF), %5.2f TB/s over the chip; s_memtime %7.1f per iteration\n",
+         what, L, S, D, ns_it, 100.0 * (double)cus_g * 4 * 32 * 32768.0 / (ns_it * 1e-9) / 2.5e15, (double)cus_g * 8.0 * L * 1024.0 / (ns_it * 1e-9) / 1e12, per_it);
 }
 
 int main() {
@@ -171,6 +172,14 @@ int main() {
     run<8, 2>(src, shared_region, 0, cus, iters, out, cyc, "shared 48 MiB stream");
     run<4, 2>(src, priv, priv, cus, iters, out, cyc, "private 64 KiB (cache hits)");
     run<8, 2>(src, priv, priv, cus, iters, out, cyc, "private 64 KiB (cache hits)");
+    run<2, 1, 8>(src, shared_region, 0, cus, iters, out, cyc, "shared 48 MiB stream");
+    run<2, 1, 4>(src, shared_region, 0, cus, iters, out, cyc, "shared 48 MiB stream");
+    run<2, 1, 2>(src, shared_region, 0, cus, iters, out, cyc, "shared 48 MiB stream");
+    run<4, 1, 4>(src, shared_region, 0, cus, iters, out, cyc, "shared 48 MiB stream");
+    run<4, 1, 2>(src, shared_region, 0, cus, iters, out, cyc, "shared 48 MiB stream");
+    run<4, 2, 4>(src, shared_region, 0, cus, iters, out, cyc, "shared 48 MiB stream");
+    run<8, 1, 2>(src, shared_region, 0, cus, iters, out, cyc, "shared 48 MiB stream");
+    run<8, 2, 2>(src, shared_region, 0, cus, iters, out, cyc, "shared 48 MiB stream");
   }
   return 0;
 }
