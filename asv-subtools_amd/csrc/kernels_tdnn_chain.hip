@@ -43,9 +43,11 @@
 // What bounds the K loops (round 6, experiment builds -DCHAIN_EXP below, profiles/r6z_chain_fetch_experiments.txt; csrc/tools/vmem_probe.hip,
 // profiles/r6z_vmem_probe.txt): every layer's loop runs at 79 % (20.6 k ticks per 16 steps against 16.4 k at 32 per matrix instruction).  With
 // one of the two weight-fragment loads per k-group taken away the same loop runs at 16.6 - 16.8 k; with all loads but from one address (L1
-// hits) at 20.1 k.  It is what a 1 KiB vector load costs the SIMD that issues it (~60 matrix-issue clocks, whatever level serves it): a bare
-// probe with this kernel's 4 loads per 16 matrix instructions reaches 61 - 65 % of the datasheet rate, with 1 load 92 %.  The load count is
-// the tile's weight bytes / 1 KiB: more frames per resident tile is the only lever (128 x 512 x 16 bit IS the LDS).
+// hits) at 20.1 k.  It is what the operand fetches cost the SIMD that issues them, whatever level serves them: a bare probe with this
+// kernel's exact mix - per 16 matrix instructions 4 fragment loads of 1 KiB, spread and two chunks ahead, + 16 ds_read_b128 - reaches 71 % of
+// the datasheet rate on trivial operands (the loads alone 87 %, the LDS reads alone 76 %, no fetches 98 %); these loops run at ~67 % in wall-clock
+// terms.  0.75 fetches per matrix instruction is what 128 accumulator registers per wave allow whatever the wave's tile shape; more frames
+// per resident tile would cut the loads (128 x 512 x 16 bit IS the LDS).
 // One workgroup (512 threads, 160 KiB LDS) per CU.
 #include <cstdlib>
 

@@ -25,9 +25,13 @@ typedef __bf16 v8b __attribute__((ext_vector_type(8)));
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 // S = spacing of the loads in matrix-instruction slots (1: behind instructions 0 .. L - 1; 16 / L: spread evenly over the 16)
-template <int L, int D, int S>
+// R = ds_read_b128 per 16 matrix instructions (one behind each of the first R; the chain kernels read their frame operands from LDS: 16 per 16)
+template <int L, int D, int S, int R>
 __global__ __launch_bounds__(512, 2) void probe(const unsigned char *src, size_t region, size_t wg_stride, int iters, float *out, unsigned long long *cyc) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[65536];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (R > 0) { for (int i = threadIdx.x; i < 65536 / 16; i += 512) reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u); __syncthreads(); }
+  uint4 xr[2] = {make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u), make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u)};
   const unsigned char *base = src + (size_t)blockIdx.x * wg_stride + (size_t)lane * 16;
   v16f acc[8];
 #pragma unroll
@@ -53,7 +57,8 @@ __global__ __launch_bounds__(512, 2) void probe(const unsigned char *src, size_t
         if (q % S == 0 && q / S < L) {
           nxt[(q / S) & 7] = *reinterpret_cast<const uint4 *>(base + off + (size_t)(q / S) * 1024);
         }
-        const v8b a = __builtin_bit_cast(v8b, cur[q & 7]), b = __builtin_bit_cast(v8b, cur[(q + 3) & 7]);
+        if (q < R) xr[q & 1] = *reinterpret_cast<const uint4 *>(lds + ((wave * 8192 + q * 1024 + lane * 16 + (int)(off >> 6)) & 65535 & ~15));
+        const v8b a = __builtin_bit_cast(v8b, cur[q & 7]), b = __builtin_bit_cast(v8b, R > 0 ? xr[(q + 1) & 1] : cur[(q + 3) & 7]);
         acc[q & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[q & 7], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -104,14 +109,14 @@ __global__ __launch_bounds__(512, 2) void calib(unsigned long long *res, float *
 }
 
 static int cus_g = 256;
-template <int L, int D = 1, int S = 1>
+template <int L, int D = 1, int S = 1, int R = 0>
 static void run(const unsigned char *src, size_t region, size_t wg_stride, int wgs, int iters, float *out, unsigned long long *cyc, const char *what) {
   CK(hipMemset(cyc, 0, (size_t)wgs * 8 * 8));
-  hipLaunchKernelGGL((probe<L, D, S>), dim3(wgs), dim3(512), 0, 0, src, region, wg_stride, 66, out, cyc);        // warm
+  hipLaunchKernelGGL((probe<L, D, S, R>), dim3(wgs), dim3(512), 0, 0, src, region, wg_stride, 66, out, cyc);        // warm
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   CK(hipEventRecord(e0));
-  hipLaunchKernelGGL((probe<L, D, S>), dim3(wgs), dim3(512), 0, 0, src, region, wg_stride, iters, out, cyc);
+  hipLaunchKernelGGL((probe<L, D, S, R>), dim3(wgs), dim3(512), 0, 0, src, region, wg_stride, iters, out, cyc);
   CK(hipEventRecord(e1));
   CK(hipDeviceSynchronize());
   float ms = 0;
@@ -123,8 +128,8 @@ static void run(const unsigned char *src, size_t region, size_t wg_stride, int w
   const double per_it = sum / (double)h.size() / iters;
   // per CU and iteration (= one step of both waves of every SIMD): 8 waves x L KiB
   const double ns_it = (double)ms * 1e6 / iters;
-  printf("%-28s L = %d loads per 16 matrix instructions, one every %d, fetched %d x 16 instructions ahead: %6.1f ns per iteration = %5.1f %% of the bf16 matrix peak (2.5 PF), %5.2f TB/s over the chip; s_memtime %7.1f per iteration\n",
-         what, L, S, D, ns_it, 100.0 * (double)cus_g * 4 * 32 * 32768.0 / (ns_it * 1e-9) / 2.5e15, (double)cus_g * 8.0 * L * 1024.0 / (ns_it * 1e-9) / 1e12, per_it);
+  printf("%-28s L = %d loads + %d LDS reads per 16 matrix instructions, a load every %d, fetched %d x 16 instructions ahead: %6.1f ns per iteration = %5.1f %% of the bf16 matrix peak (2.5 PF), %5.2f TB/s over the chip; s_memtime %7.1f per iteration\n",
+         what, L, R, S, D, ns_it, 100.0 * (double)cus_g * 4 * 32 * 32768.0 / (ns_it * 1e-9) / 2.5e15, (double)cus_g * 8.0 * L * 1024.0 / (ns_it * 1e-9) / 1e12, per_it);
 }
 
 int main() {
@@ -180,6 +185,12 @@ int main() {
     run<4, 2, 4>(src, shared_region, 0, cus, iters, out, cyc, "shared 48 MiB stream");
     run<8, 1, 2>(src, shared_region, 0, cus, iters, out, cyc, "shared 48 MiB stream");
     run<8, 2, 2>(src, shared_region, 0, cus, iters, out, cyc, "shared 48 MiB stream");
+    run<0, 1, 1, 8>(src, shared_region, 0, cus, iters, out, cyc, "shared 48 MiB stream");
+    run<0, 1, 1, 16>(src, shared_region, 0, cus, iters, out, cyc, "shared 48 MiB stream");
+    run<4, 2, 4, 8>(src, shared_region, 0, cus, iters, out, cyc, "shared 48 MiB stream");
+    run<4, 2, 4, 16>(src, shared_region, 0, cus, iters, out, cyc, "shared 48 MiB stream");
+    run<8, 2, 2, 16>(src, shared_region, 0, cus, iters, out, cyc, "shared 48 MiB stream");
+    run<8, 1, 1, 16>(src, shared_region, 0, cus, iters, out, cyc, "shared 48 MiB stream");
   }
   return 0;
 }
