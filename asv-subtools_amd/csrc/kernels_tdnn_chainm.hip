@@ -37,7 +37,9 @@
 // conversion, the window DMA, the order of the fragment array (a copy in step order changed nothing), the fetch distance of the fragments
 // (350 -> 1250 cycles: nothing), the stream from L2 as such (every step fetching the SAME fragments: -5 %), the LDS reads (0 %).  The
 // cause, by experiment builds (-DCHAINM_EXP, r6x) and tools/vmem_probe.hip (r6z): the NUMBER of fragment loads a CU issues per step - 8 x 1
-// KiB per wave, ~60 matrix-issue clocks each whatever level serves them (a bare probe with 8 loads per 16 matrix instructions: 47 - 59 %); with half of those loads the loop's cycles drop 9 % and the shader clock RISES 8 % (power),
+// KiB per wave, whatever level serves them (a bare probe with this kernel's mix - 8 loads + 16 LDS reads per 16 matrix instructions - runs at
+// 60 - 63 % of the bf16 datasheet rate on trivial operands; spreading the loads over the step, 71 % against 55 % in the probe without the LDS
+// reads, measured SLOWER in the kernel: tools/chainm_spread_loads.patch, profiles/r6z_chainm_spread_loads_ab.txt); with half of those loads the loop's cycles drop 9 % and the shader clock RISES 8 % (power),
 // together -13 % per workgroup.  4 bytes per weight is what this form costs; more frames per fetched byte is the lever and LDS capacity
 // (2 KiB per resident frame) stops it - the 96-frame kernel (x_hi8 made in registers to fit) paid more in conversions than it gained.
 // Alternating the issue priority between the two waves of a SIMD step by step gives 3 % (r6p).
