@@ -888,3 +888,25 @@ def test_loader_over_a_native_table_equals_the_list_path(tmp_path):
     finally:
         a.close()
         b.close()
+
+
+def test_bench_loaders_harness_runs_both_header_passes(tmp_path):
+    """tools/bench_loaders.py (the host side of --sharded under N concurrent ranks, no device): a tiny table through the shared header pass
+    (1 / N of the headers per rank + a shared-memory gather standing in for the all-gather) and through --whole-index - both must account
+    for every utterance exactly once across the ranks."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from libs.support import native_io
+    if native_io.lib() is None:
+        pytest.skip("libasv_io.so not built")
+    for extra in ([], ["--whole-index"]):
+        r = subprocess.run([sys.executable, os.path.join(repo, "tools", "bench_loaders.py"), "--utts", "600", "--ragged-utts", "0", "--ranks", "1,2", "--threads", "2",
+                            "--repeats", "1", "--dir", str(tmp_path / "tables")] + extra, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        rec = json.loads(r.stdout.strip().splitlines()[-1])
+        rows = rec["tables"]["fixed200"]["rows"]
+        assert [row["ranks"] for row in rows] == [1, 2]
+        for row in rows:
+            assert row["best_utts_per_s"] > 0 and set(row["slowest_rank_at_best"]) == {"rank", "seconds", "index", "plan", "read", "pack"}
