@@ -427,7 +427,10 @@ class ScpBatchLoader(object):
             return self._table is not False
         self._table = False
         from libs.support import native_io
+        sharing = ranks is not None and ranks[1] > 1
         if native_io.lib() is None:
+            if sharing:
+                ranks[2](np.zeros((1, 16), dtype=np.uint8))          # take part in the agreement (as "nothing to share"): nobody waits for this rank
             return False
         n = len(self.entries)
         if hasattr(self.entries, "plain_index"):
@@ -461,13 +464,15 @@ class ScpBatchLoader(object):
             fid, off = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int64)
             fid[cand], off[cand] = c_fid, c_off
         if len(cand) == 0 or len(files) > self.max_open:
+            if sharing:
+                ranks[2](np.zeros((1, 16), dtype=np.uint8))          # (as above)
             return False
         cand = np.asarray(cand, dtype=np.int64)
         keep = set(files)
         lut = np.asarray([self._fd(path, keep=keep) for path in files], dtype=np.int32)
         nc = len(cand)
         shared = False
-        if ranks is not None and ranks[1] > 1:
+        if sharing:
             rank, world, gather = ranks
             mine = np.zeros((1, 16), dtype=np.uint8)
             mine.view("<i8")[0, 0], mine.view("<i8")[0, 1] = nc * 1000003 + n, int(np.bitwise_xor.reduce(off[cand] * 31 + fid[cand]))

@@ -369,7 +369,7 @@ def _worker_index(rank, world, port, scp, out_dir, differ):
         ee = _load_script()
         entries = ee.read_scp("scp:" + scp)
         if differ and rank == 1:
-            entries = entries[: len(entries) - 1] if isinstance(entries, list) else ee.read_scp("scp:" + scp + ".short")
+            entries = ee.read_scp("scp:" + scp + (".missing" if differ == "missing" else ".short"))
         calls = []
         ranks = ee.index_ranks()
         assert ranks is not None and ranks[:2] == (rank, world)
@@ -420,6 +420,12 @@ def test_header_pass_ranks_with_different_tables_or_a_failed_read_agree_on_the_f
     for r in range(2):
         ok, ok_alone, same, n_calls, rows = np.load(d1 / ("index%d.npy" % r))
         assert (ok, ok_alone, same, n_calls) == (1, 1, 1, 1), (r, ok, ok_alone, same, n_calls)
+    # a rank that cannot index at all (its table names a file it does not see) still takes part in the agreement: nobody waits for it
+    with open(scp) as f, open(scp + ".missing", "w") as g:
+        g.writelines(line.replace("feats.ark", "not_there.ark") for line in f)
+    mp.spawn(_worker_index, args=(2, _free_port(), scp, str(d1), "missing"), nprocs=2, join=True)
+    got = [tuple(int(v) for v in np.load(d1 / ("index%d.npy" % r))[:4]) for r in range(2)]
+    assert got == [(1, 1, 1, 1), (0, 0, 1, 1)], got
     d2 = tmp_path / "b"
     d2.mkdir()
     scp2, _ = _write_feature_table(str(d2), 50, broken_for=40)           # the second rank's half holds the entry behind the end of the file
