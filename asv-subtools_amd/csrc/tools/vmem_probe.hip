@@ -76,6 +76,72 @@ __global__ __launch_bounds__(512, 2) void probe(const unsigned char *src, size_t
   if (lane == 0) cyc[(size_t)blockIdx.x * 8 + wave] = t1 - t0;
 }
 
+// The same question for ONE wave per SIMD with 256 accumulator registers (a 128 x 128 wave tile: 4 + 4 operand fetches per 16 matrix
+// instructions = 0.5 per instruction instead of 0.75): 4 waves per CU, 32 matrix instructions per wave and iteration on 16 accumulators,
+// L loads (spread, two iterations ahead) and R LDS reads beside them.
+template <int L, int R>
+__global__ __launch_bounds__(256, 1) void probe4(const unsigned char *src, size_t region, int iters, float *out) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[65536];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 65536 / 16; i += 256) reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+  __syncthreads();
+  const unsigned char *base = src + (size_t)lane * 16;
+  v16f acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+  uint4 w[3][8], xr[4];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[d][k] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) xr[k] = w[0][0];
+  size_t off = (size_t)wave * 8 * 1024;
+  constexpr int S = L > 0 ? 32 / L : 32;
+#pragma unroll 1
+  for (int it = 0; it < iters; it += 3) {
+#pragma unroll
+    for (int half = 0; half < 3; ++half) {
+      uint4 (&cur)[8] = w[half];
+      uint4 (&nxt)[8] = w[(half + 2) % 3];
+#pragma unroll
+      for (int q = 0; q < 32; ++q) {
+        if (L > 0 && q % S == 0 && q / S < L) nxt[(q / S) & 7] = *reinterpret_cast<const uint4 *>(base + off + (size_t)(q / S) * 1024);
+        if (R > 0 && q % (32 / (R > 0 ? R : 1)) == 0) xr[(q >> 2) & 3] = *reinterpret_cast<const uint4 *>(lds + ((wave * 16384 + q * 512 + lane * 16 + (int)(off >> 6)) & 65535 & ~15));
+        const v8b a = __builtin_bit_cast(v8b, cur[q & 7]), b = __builtin_bit_cast(v8b, R > 0 ? xr[((q >> 2) + 1) & 3] : cur[(q + 3) & 7]);
+        acc[q & 15] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[q & 15], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      off += 32 * 1024;
+      if (off + 32 * 1024 > region) off = (size_t)wave * 8 * 1024;
+    }
+  }
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[i][r];
+  out[(size_t)blockIdx.x * 512 + threadIdx.x] = s;
+}
+
+template <int L, int R>
+static void run4(const unsigned char *src, size_t region, int wgs, int iters, float *out) {
+  hipLaunchKernelGGL((probe4<L, R>), dim3(wgs), dim3(256), 0, 0, src, region, 66, out);
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  CK(hipEventRecord(e0));
+  hipLaunchKernelGGL((probe4<L, R>), dim3(wgs), dim3(256), 0, 0, src, region, iters, out);
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  const double ns_it = (double)ms * 1e6 / iters;
+  printf("one wave per SIMD, 256 accumulators: %d loads + %d LDS reads per 32 matrix instructions (%.2f fetches per instruction): %6.1f ns per iteration = %5.1f %% of the bf16 matrix peak\n",
+         L, R, (L + R) / 32.0, ns_it, 100.0 * (double)wgs * 4 * 32 * 32768.0 / (ns_it * 1e-9) / 2.5e15);
+}
+
 // Calibration of s_memtime: wave 0 of every workgroup sleeps (s_sleep 16 = 16 x 64 sequencer clocks, 64 times) between two stamps while the
 // other 7 waves either idle (LOAD = 0) or stream matrix instructions (LOAD = 1); s_memrealtime (100 MHz) brackets the same region.
 template <int LOAD>
@@ -160,6 +226,14 @@ int main() {
     printf("calibration, %s: 64 x s_sleep 16 (= 65536 sequencer clocks + loop overhead) = %.0f s_memtime ticks = %.2f us of s_memrealtime -> s_memtime runs at %.0f MHz, the sequencer at >= %.0f MHz\n",
            load ? "7 waves of matrix instructions beside" : "idle CU", t / cus, r / cus / 100.0, 100.0 * t / r, 100.0 * 65536.0 * cus / r);
     CK(hipFree(res));
+  }
+  for (int round = 0; round < 2; ++round) {
+    run4<0, 0>(src, shared_region, cus, 2049, out);
+    run4<8, 0>(src, shared_region, cus, 2049, out);
+    run4<0, 8>(src, shared_region, cus, 2049, out);
+    run4<8, 8>(src, shared_region, cus, 2049, out);
+    run4<4, 16>(src, shared_region, cus, 2049, out);
+    run4<8, 16>(src, shared_region, cus, 2049, out);
   }
   const int iters = 4098;                                // a multiple of 2 and of 3
   for (int round = 0; round < 2; ++round) {
